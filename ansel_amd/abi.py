@@ -1,0 +1,129 @@
+"""ctypes mirror of include/ansel_hip.h (the C-ABI of libansel_hip).
+
+Field order and types follow the header one to one; tests/test_abi.py checks the
+sizes against the compiled library (dt_hip_abi_sizeof)."""
+import ctypes as C
+
+DT_HIP_SUCCESS = 0
+DT_HIP_DEFAULT_ERROR = -999
+DT_HIP_SYSMEM_ALLOCATION = -998
+DT_HIP_INVALID_ARG = -997
+
+DT_HIP_TYPE_FLOAT = 1
+DT_HIP_TYPE_UINT16 = 2
+
+DT_HIP_HIGHLIGHTS_CLIP = 0
+
+DT_HIP_DEMOSAIC_PPG = 0
+DT_HIP_DEMOSAIC_AMAZE = 1
+DT_HIP_DEMOSAIC_RCD = 5
+
+DT_HIP_ADAPTATION_LINEAR_BRADFORD = 0
+DT_HIP_ADAPTATION_CAT16 = 1
+DT_HIP_ADAPTATION_FULL_BRADFORD = 2
+DT_HIP_ADAPTATION_XYZ = 3
+DT_HIP_ADAPTATION_RGB = 4
+
+DT_HIP_LUT_SAMPLES = 0x10000
+
+f4 = C.c_float * 4
+f3 = C.c_float * 3
+f5 = C.c_float * 5
+m34 = (C.c_float * 4) * 3
+m33 = (C.c_float * 3) * 3
+
+
+class Roi(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("scale", C.c_double)]
+
+    @classmethod
+    def make(cls, x, y, w, h, scale=1.0):
+        return cls(int(x), int(y), int(w), int(h), float(scale))
+
+
+class Piece(C.Structure):
+    _fields_ = [("roi_in", Roi), ("roi_out", Roi), ("filters", C.c_uint32), ("channels", C.c_uint32),
+                ("datatype", C.c_uint32), ("_pad", C.c_uint32), ("processed_maximum", f4)]
+
+    @classmethod
+    def make(cls, width, height, filters=0, channels=4, datatype=DT_HIP_TYPE_FLOAT,
+             processed_maximum=(1.0, 1.0, 1.0, 1.0), roi_in=None, roi_out=None):
+        p = cls()
+        p.roi_in = roi_in if roi_in is not None else Roi.make(0, 0, width, height)
+        p.roi_out = roi_out if roi_out is not None else Roi.make(0, 0, width, height)
+        p.filters = filters
+        p.channels = channels
+        p.datatype = datatype
+        p.processed_maximum = f4(*processed_maximum)
+        return p
+
+
+class Tiling(C.Structure):
+    _fields_ = [("factor", C.c_float), ("factor_cl", C.c_float), ("maxbuf", C.c_float),
+                ("maxbuf_cl", C.c_float), ("overhead", C.c_uint), ("overlap", C.c_uint),
+                ("xalign", C.c_uint), ("yalign", C.c_uint)]
+
+
+class RawprepareData(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("sub", f4), ("div", f4)]
+
+
+class TemperatureData(C.Structure):
+    _fields_ = [("coeffs", f4)]
+
+
+class HighlightsData(C.Structure):
+    _fields_ = [("mode", C.c_int), ("clip", C.c_float)]
+
+
+class DemosaicData(C.Structure):
+    _fields_ = [("green_eq", C.c_uint32), ("color_smoothing", C.c_uint32),
+                ("demosaicing_method", C.c_uint32), ("median_thrs", C.c_float)]
+
+
+class ExposureData(C.Structure):
+    _fields_ = [("black", C.c_float), ("scale", C.c_float)]
+
+
+class Conversion(C.Structure):
+    _fields_ = [("matrix", m34), ("clip_matrix", m34), ("has_clipping", C.c_int),
+                ("nonlinear_source", C.c_int), ("nonlinear_target", C.c_int), ("blue_mapping", C.c_int),
+                ("coeffs_source", m33), ("coeffs_target", m33),
+                ("lut_source", C.c_void_p * 3), ("lut_target", C.c_void_p * 3),
+                ("lut_source_first", f3), ("lut_target_first", f3)]
+
+
+class ChannelmixerrgbData(C.Structure):
+    _fields_ = [("XYZ_to_RGB", m34), ("RGB_to_XYZ", m34), ("MIX", m34), ("illuminant", f4),
+                ("saturation", f4), ("lightness", f4), ("grey", f4), ("p", C.c_float),
+                ("gamut", C.c_float), ("clip", C.c_int), ("apply_grey", C.c_int),
+                ("adaptation", C.c_int), ("version", C.c_int)]
+
+
+class FilmicSpline(C.Structure):
+    _fields_ = [("M1", f4), ("M2", f4), ("M3", f4), ("M4", f4), ("M5", f4),
+                ("latitude_min", C.c_float), ("latitude_max", C.c_float), ("y", f5), ("x", f5),
+                ("type", C.c_int * 2)]
+
+
+class FilmicrgbData(C.Structure):
+    _fields_ = [("white_source", C.c_float), ("grey_source", C.c_float), ("black_source", C.c_float),
+                ("dynamic_range", C.c_float), ("saturation", C.c_float), ("output_power", C.c_float),
+                ("agx_beta_hue", C.c_float), ("preserve_color", C.c_int), ("version", C.c_int),
+                ("use_output_profile", C.c_int), ("spline", FilmicSpline),
+                ("work_matrix_in", m34), ("work_matrix_out", m34),
+                ("export_matrix_in", m34), ("export_matrix_out", m34)]
+
+
+def set_m34(dst, rows):
+    """fill a float[3][4] from a 3x3 (or 3x4) nested sequence"""
+    for r in range(3):
+        for c in range(4):
+            dst[r][c] = float(rows[r][c]) if c < len(rows[r]) else 0.0
+
+
+def set_vec(dst, vals):
+    for i, v in enumerate(vals):
+        dst[i] = float(v)

@@ -1,0 +1,284 @@
+/*
+ * ansel_hip.h -- C-ABI of libansel_hip: the MI355X-native peer of Ansel's OpenCL layer
+ * and the device entry points of the hot iop modules of the export pixelpipe.
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes; no torch/HIP types leak
+ * through.  Two groups of symbols:
+ *
+ *   1. dt_hip_*            device runtime.  Stands where the reference has
+ *                          src/common/opencl.{c,h} (dt_opencl_*, opencl.h:333-651);
+ *                          same return conventions (0 = success, negative = error,
+ *                          allocators return NULL, dt_hip_finish TRUE on success).
+ *   2. dt_hip_iop_<op>_*   one process entry per hot module: what that module's
+ *                          process_cl() (src/iop/iop_api.h:277-278) calls instead of
+ *                          dt_opencl_set_kernel_arg()/dt_opencl_enqueue_kernel_2d().
+ *                          Arguments are (devid, piece view, module data, dev_in, dev_out):
+ *                          the same information process_cl() reads from `piece`.
+ *
+ * Device buffers are linear, tightly packed, row-major (pitch = bpp * width), exactly the
+ * host layout of a pixelpipe cacheline (src/develop/pixelpipe_hb.c:985): 1 x u16 or 1 x f32
+ * per photosite before demosaic, float4 RGBA after.
+ *
+ * INTEGRATION.md shows the process_cl() stub a maintainer adds for each entry.
+ */
+#ifndef ANSEL_HIP_H
+#define ANSEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: mirror src/common/opencl.h:61-62 ------------------------------- */
+#define DT_HIP_SUCCESS 0
+#define DT_HIP_DEFAULT_ERROR (-999)
+#define DT_HIP_SYSMEM_ALLOCATION (-998)
+#define DT_HIP_INVALID_ARG (-997)
+#define DT_HIP_MAX_ERRORS 5 /* src/common/opencl.h:50 */
+
+/* opaque device allocation, stands for cl_mem */
+typedef void *dt_hip_mem_t;
+
+/* ---- shared plain views of host structs ----------------------------------------- */
+
+/* == dt_iop_roi_t, src/pixel/format.h:44-48 (same field order and types) */
+typedef struct dt_hip_roi_t
+{
+  int x, y, width, height;
+  double scale;
+} dt_hip_roi_t;
+
+/* The read-only slice of dt_dev_pixelpipe_iop_t (src/develop/pixelpipe_hb.h:101-166) and of
+ * its dt_iop_buffer_dsc_t dsc_in (src/pixel/format.h:82-123) that the hot modules read. */
+typedef struct dt_hip_piece_t
+{
+  dt_hip_roi_t roi_in, roi_out;
+  uint32_t filters;           /* piece->dsc_in.filters: dcraw Bayer word, 0 = not mosaiced */
+  uint32_t channels;          /* piece->dsc_in.channels: 1 or 4 */
+  uint32_t datatype;          /* piece->dsc_in.datatype: DT_HIP_TYPE_* */
+  uint32_t _pad;
+  float processed_maximum[4]; /* piece->dsc_in.processed_maximum */
+} dt_hip_piece_t;
+
+#define DT_HIP_TYPE_FLOAT 1  /* TYPE_FLOAT  (src/pixel/format.h:52) */
+#define DT_HIP_TYPE_UINT16 2 /* TYPE_UINT16 */
+
+/* == dt_develop_tiling_t, src/develop/tiling.h:39-59 */
+typedef struct dt_hip_tiling_t
+{
+  float factor, factor_cl;
+  float maxbuf, maxbuf_cl;
+  unsigned overhead;
+  unsigned overlap;
+  unsigned xalign, yalign;
+} dt_hip_tiling_t;
+
+/* ---- 1. device runtime (peer of src/common/opencl.h) ------------------------------ */
+
+/* lifecycle: dt_opencl_init/cleanup/is_inited (opencl.h:333-336,460) */
+int dt_hip_init(void);
+void dt_hip_cleanup(void);
+int dt_hip_is_inited(void);
+int dt_hip_get_num_devices(void);                            /* opencl.h:364 */
+const char *dt_hip_get_device_name(int devid);
+size_t dt_hip_get_device_available(int devid);               /* free HBM bytes; opencl.h:405 */
+size_t dt_hip_get_device_memalloc(int devid);                /* largest single allocation */
+/* device exclusivity: dt_opencl_lock_device/unlock_device (opencl.c:1642-1755).
+ * lock returns a devid >= 0 or -1; pipetype is ignored (one priority list). */
+int dt_hip_lock_device(int pipetype);
+int dt_hip_lock_device_by_id(int devid);
+void dt_hip_unlock_device(int devid);
+/* dt_opencl_image_fits_device (opencl.h:571): would factor * w*h*bpp + overhead fit? */
+int dt_hip_image_fits_device(int devid, size_t width, size_t height, unsigned bpp, float factor, size_t overhead);
+
+/* stream each device's work is enqueued on.  By default the runtime creates one
+ * non-blocking stream per device; a host that already owns a stream (e.g. the one a
+ * torch allocator orders its frees on) can adopt it.  `stream` is a hipStream_t. */
+void *dt_hip_get_stream(int devid);
+int dt_hip_set_stream(int devid, void *stream);
+
+/* memory: dt_opencl_alloc_device[_buffer], release, get_mem_object_size (opencl.h:508-561) */
+dt_hip_mem_t dt_hip_alloc_device(int devid, int width, int height, int bpp);
+dt_hip_mem_t dt_hip_alloc_device_buffer(int devid, size_t size);
+void dt_hip_release_mem_object(dt_hip_mem_t mem);
+size_t dt_hip_get_mem_object_size(dt_hip_mem_t mem);
+void dt_hip_memory_statistics(int devid, size_t *current, size_t *peak); /* opencl.h:648 */
+
+/* copies: dt_opencl_write_host_to_device / read_host_from_device (+_rowpitch,
+ * _non_blocking) and enqueue_copy_* (opencl.h:473-537).  rowpitch in bytes. */
+int dt_hip_write_host_to_device(int devid, const void *host, dt_hip_mem_t device, int width, int height, int bpp);
+int dt_hip_write_host_to_device_rowpitch(int devid, const void *host, dt_hip_mem_t device, int width, int height, int bpp, size_t rowpitch, int blocking);
+int dt_hip_read_host_from_device(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp);
+int dt_hip_read_host_from_device_rowpitch(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp, size_t rowpitch, int blocking);
+int dt_hip_enqueue_copy_buffer_to_buffer(int devid, dt_hip_mem_t src, dt_hip_mem_t dst, size_t srcoffset, size_t dstoffset, size_t size);
+/* copy a w x h window of `bpp`-byte pixels between two linear images (used by tiling and
+ * by the row-band halo exchange) */
+int dt_hip_enqueue_copy_region(int devid, dt_hip_mem_t src, int src_width, int src_x, int src_y,
+                               dt_hip_mem_t dst, int dst_width, int dst_x, int dst_y, int width, int height, int bpp);
+
+/* sync + profiling: dt_opencl_finish (TRUE on success), events_* (opencl.h:343-346,594-608) */
+int dt_hip_finish(int devid);
+void dt_hip_events_enable(int devid, int enable);
+void dt_hip_events_reset(int devid);
+/* wait for all tagged launches, aggregate per tag; returns number of distinct tags.
+ * Fills up to `max` entries: tags[i] -> static string, ms[i] = summed duration, counts[i]. */
+int dt_hip_events_profiling(int devid, const char **tags, float *ms, int *counts, int max);
+/* last error text of this thread (never NULL) */
+const char *dt_hip_last_error(void);
+
+/* ---- 2. module entry points --------------------------------------------------------- */
+/* All return DT_HIP_SUCCESS or a negative error; a process_cl() stub returns (err == 0).
+ * All enqueue on dt_hip_get_stream(devid) and do not synchronise. */
+
+/* rawprepare: src/iop/rawprepare.c:467-520 (raw mosaic u16 or f32 -> normalised f32) */
+typedef struct dt_hip_rawprepare_data_t
+{
+  int32_t x, y, width, height; /* sensor crop, rawprepare.c:94-98 */
+  float sub[4];
+  float div[4];
+} dt_hip_rawprepare_data_t;
+int dt_hip_iop_rawprepare_process(int devid, const dt_hip_piece_t *piece, const dt_hip_rawprepare_data_t *d,
+                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* temperature (white balance): src/iop/temperature.c:487-600, Bayer and 4-channel paths */
+typedef struct dt_hip_temperature_data_t
+{
+  float coeffs[4];
+} dt_hip_temperature_data_t;
+int dt_hip_iop_temperature_process(int devid, const dt_hip_piece_t *piece, const dt_hip_temperature_data_t *d,
+                                   dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* highlights, clip mode only: src/iop/highlights.c:680-789 + highlights/clip.c:62-84,
+ * including the "fewer than 25 clipped photosites -> copy input" early bypass
+ * (highlights.c:266-300, highlights/common.h:218). */
+typedef struct dt_hip_highlights_data_t
+{
+  int mode;   /* DT_HIP_HIGHLIGHTS_CLIP only; other modes return DT_HIP_INVALID_ARG */
+  float clip;
+} dt_hip_highlights_data_t;
+#define DT_HIP_HIGHLIGHTS_CLIP 0
+int dt_hip_iop_highlights_process(int devid, const dt_hip_piece_t *piece, const dt_hip_highlights_data_t *d,
+                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* demosaic: src/iop/demosaic.c:1041-1253 dispatching to
+ * rcd_demosaic (src/iop/demosaic/rcd.c:274-564) or demosaic_ppg (src/iop/demosaic/ppg.c:20-217).
+ * piece->filters is the UNSHIFTED dsc_in.filters; the roi_in shift
+ * (dt_dev_get_roi_filters, src/develop/imageop.c:139) is applied inside. */
+#define DT_HIP_DEMOSAIC_PPG 0   /* DT_IOP_DEMOSAIC_PPG   (demosaic.c enum) */
+#define DT_HIP_DEMOSAIC_AMAZE 1 /* DT_IOP_DEMOSAIC_AMAZE */
+#define DT_HIP_DEMOSAIC_RCD 5   /* DT_IOP_DEMOSAIC_RCD   */
+typedef struct dt_hip_demosaic_data_t
+{
+  uint32_t green_eq;         /* must be 0 (DT_IOP_GREEN_EQ_NO) */
+  uint32_t color_smoothing;  /* must be 0 */
+  uint32_t demosaicing_method;
+  float median_thrs;         /* must be 0 */
+} dt_hip_demosaic_data_t;
+int dt_hip_iop_demosaic_process(int devid, const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d,
+                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+void dt_hip_iop_demosaic_tiling(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d, dt_hip_tiling_t *tiling);
+
+/* exposure: src/iop/exposure.c:501-545, out = (in - black) * scale */
+typedef struct dt_hip_exposure_data_t
+{
+  float black;
+  float scale;
+} dt_hip_exposure_data_t;
+int dt_hip_iop_exposure_process(int devid, const dt_hip_piece_t *piece, const dt_hip_exposure_data_t *d,
+                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* colorin / colorout matrix path: dt_colorspaces_apply_conversion -> _apply_matrix
+ * (src/colorprofiles/conversion.c:593-682) with its optional source curves, clipping detour
+ * and target curves (_apply_target_curves, conversion.c:546-582).  The fields are the ones
+ * the accessors at conversion.c:756-834 hand to a device kernel.  LUTs are device buffers of
+ * DT_HIP_LUT_SAMPLES floats; NULL or lut[0] < 0 means "channel is linear". */
+#define DT_HIP_LUT_SAMPLES 0x10000
+typedef struct dt_hip_conversion_t
+{
+  float matrix[3][4];       /* rows of conversion->matrix, 4th column ignored */
+  float clip_matrix[3][4];
+  int has_clipping;
+  int nonlinear_source;
+  int nonlinear_target;
+  int blue_mapping;         /* colorin legacy hook, colorin.c:690-709 */
+  float coeffs_source[3][3];
+  float coeffs_target[3][3];
+  dt_hip_mem_t lut_source[3];
+  dt_hip_mem_t lut_target[3];
+  /* lut[c][0] of each curve, copied host side when the curve is uploaded so that the
+   * "linear channel" sentinel needs no device read */
+  float lut_source_first[3];
+  float lut_target_first[3];
+} dt_hip_conversion_t;
+int dt_hip_iop_colorin_process(int devid, const dt_hip_piece_t *piece, const dt_hip_conversion_t *d,
+                               dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+int dt_hip_iop_colorout_process(int devid, const dt_hip_piece_t *piece, const dt_hip_conversion_t *d,
+                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* color calibration: loop_switch, src/iop/channelmixerrgb.c:766-960.  Arguments are
+ * loop_switch()'s own (filled by process() at channelmixerrgb.c:1960-2079). */
+#define DT_HIP_ADAPTATION_LINEAR_BRADFORD 0 /* src/pixel/chromatic_adaptation.h:30-38 */
+#define DT_HIP_ADAPTATION_CAT16 1
+#define DT_HIP_ADAPTATION_FULL_BRADFORD 2
+#define DT_HIP_ADAPTATION_XYZ 3
+#define DT_HIP_ADAPTATION_RGB 4
+typedef struct dt_hip_channelmixerrgb_data_t
+{
+  float XYZ_to_RGB[3][4];
+  float RGB_to_XYZ[3][4];
+  float MIX[3][4];
+  float illuminant[4];
+  float saturation[4];
+  float lightness[4];
+  float grey[4];
+  float p;
+  float gamut;
+  int clip;
+  int apply_grey;
+  int adaptation; /* DT_HIP_ADAPTATION_* */
+  int version;    /* CHANNELMIXERRGB_V_1..3 = 0..2 */
+} dt_hip_channelmixerrgb_data_t;
+int dt_hip_iop_channelmixerrgb_process(int devid, const dt_hip_piece_t *piece,
+                                       const dt_hip_channelmixerrgb_data_t *d, dt_hip_mem_t dev_in,
+                                       dt_hip_mem_t dev_out);
+
+/* filmic RGB tone mapping: filmic_agx / filmic_v5 / filmic_chroma_v4 / filmic_split_v4,
+ * src/iop/filmicrgb.c:2153-2587; highlight reconstruction bypassed (hl_deprecated, :2733).
+ * spline == dt_iop_filmic_rgb_spline_t (:216-223).  work_*, export_* are the 3x3 parts of
+ * the work / export dt_iop_order_iccprofile_info_t matrix_in, matrix_out. */
+typedef struct dt_hip_filmic_spline_t
+{
+  float M1[4], M2[4], M3[4], M4[4], M5[4];
+  float latitude_min, latitude_max;
+  float y[5];
+  float x[5];
+  int type[2];
+} dt_hip_filmic_spline_t;
+typedef struct dt_hip_filmicrgb_data_t
+{
+  float white_source, grey_source, black_source;
+  float dynamic_range;
+  float saturation;
+  float output_power;
+  float agx_beta_hue;
+  int preserve_color; /* dt_iop_filmicrgb_methods_type_t */
+  int version;        /* dt_iop_filmicrgb_colorscience_type_t, 3..9 supported (v6, v7, AgX) */
+  int use_output_profile;
+  dt_hip_filmic_spline_t spline;
+  float work_matrix_in[3][4], work_matrix_out[3][4];
+  float export_matrix_in[3][4], export_matrix_out[3][4];
+} dt_hip_filmicrgb_data_t;
+int dt_hip_iop_filmicrgb_process(int devid, const dt_hip_piece_t *piece, const dt_hip_filmicrgb_data_t *d,
+                                 dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* final float -> integer conversion of the export driver:
+ * src/imageio/imageio_core.c:706-737 (RGBA f32 -> RGBA u16 / u8) */
+int dt_hip_export_convert_u16(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+int dt_hip_export_convert_u8(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANSEL_HIP_H */

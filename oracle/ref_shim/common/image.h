@@ -1,0 +1,2 @@
+/* shim: see ref_host.h */
+#include "ref_host.h"

@@ -1,0 +1,48 @@
+/* oracle/ref_wrap/ref_demosaic.c -- TEST INFRASTRUCTURE ONLY.
+ * Includes the reference's RCD and PPG demosaic translation-unit fragments verbatim
+ * (src/iop/demosaic/rcd.c, src/iop/demosaic/ppg.c are #include'd by src/iop/demosaic.c
+ * in the reference as well, demosaic.c:1013-1022). */
+#include "ref_piece.h"
+#include "gen/imageop_math.inc"
+#include "gen/demosaic.inc" /* intp(), pre_median helpers the fragments use */
+
+#define INLINE inline
+#include "iop/demosaic/rcd.c"
+#include "iop/demosaic/ppg.c"
+
+/* dt_rawspeed_crop_dcraw_filters -> rawspeed ColorFilterArray::shiftDcrawFilter
+ * (src/imageio/imageio_rawspeed.cc:146-151; rawspeed is an un-vendored submodule).
+ * Published algorithm: the dcraw filter word holds 8 rows x 2 columns of 2-bit colours;
+ * shifting the pattern origin by (x, y) rotates rows by y (mod 8) and swaps the two column
+ * entries of every row when x is odd.  tests/test_filters.py pins it against the identity
+ * FC(r + y, c + x, f) == FC(r, c, shifted) the reference's call sites rely on. */
+uint32_t ref_shift_dcraw_filters(uint32_t filters, uint32_t x, uint32_t y)
+{
+  if(!filters || filters == 9u) return filters;
+  uint32_t out = 0;
+  for(int r = 0; r < 8; r++)
+    for(int c = 0; c < 2; c++)
+    {
+      const uint32_t col = FC(r + y, c + x, filters);
+      out |= col << (((r << 1 & 14) + (c & 1)) << 1);
+    }
+  return out;
+}
+
+int ref_demosaic(const dt_hip_piece_t *v, const dt_hip_demosaic_data_t *d, const void *in, void *out)
+{
+  ref_reset_fp_mode();
+  dt_dev_pixelpipe_iop_t piece;
+  ref_fill_piece(&piece, v, NULL);
+  dt_iop_roi_t roi = piece.roi_in;
+  dt_iop_roi_t roo = piece.roi_out;
+  roo.x = roo.y = 0;
+  const uint32_t filters = ref_shift_dcraw_filters(v->filters, piece.roi_in.x, piece.roi_in.y);
+  if(d->demosaicing_method == DT_HIP_DEMOSAIC_RCD)
+    rcd_demosaic(&piece, (float *)out, (const float *)in, &roo, &roi, filters);
+  else if(d->demosaicing_method == DT_HIP_DEMOSAIC_PPG)
+    return demosaic_ppg((float *)out, (const float *)in, &roo, &roi, filters, d->median_thrs);
+  else
+    return 1;
+  return 0;
+}

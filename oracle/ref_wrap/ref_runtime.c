@@ -1,0 +1,61 @@
+/* oracle/ref_wrap/ref_runtime.c -- TEST INFRASTRUCTURE ONLY.
+ * Allocation/threads runtime the reference pixel code links against
+ * (stand-ins for src/caches/pixelpipe_cache.c arena and src/system/mem_alloc.c). */
+#include "ref_host.h"
+
+int dt_get_num_openmp_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+void *dt_alloc_align(size_t size)
+{
+  void *p = NULL;
+  if(posix_memalign(&p, 64, size ? size : 64)) return NULL;
+  return p;
+}
+
+void *dt_pixelpipe_cache_alloc_align_cache_impl(size_t size, int id, const char *name)
+{
+  (void)id; (void)name;
+  return dt_alloc_align(size);
+}
+
+void dt_pixelpipe_cache_free_align_cache(void **mem, const char *message)
+{
+  (void)message;
+  if(mem && *mem) { free(*mem); *mem = NULL; }
+}
+
+void ref_set_num_threads(int n)
+{
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+
+int ref_get_num_threads(void) { return dt_get_num_openmp_threads(); }
+
+/* The reference leaves FTZ/DAZ set in every OpenMP worker after RCD ran
+ * (src/iop/demosaic/rcd.c:300 never restores MXCSR).  To keep each wrapped call's
+ * arithmetic independent of call history we force the default IEEE mode on every
+ * worker at the entry of each wrapper; rcd_demosaic() then sets its own fast mode. */
+void ref_reset_fp_mode(void)
+{
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+#if defined(__x86_64__)
+    unsigned int mxcsr = _mm_getcsr();
+    mxcsr &= ~(_MM_FLUSH_ZERO_ON | 0x0040u /* DAZ */);
+    _mm_setcsr(mxcsr);
+#endif
+  }
+}
