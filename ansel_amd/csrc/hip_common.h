@@ -1,0 +1,65 @@
+// hip_common.h -- internals shared by the translation units of libansel_hip.
+// Not part of the C-ABI (that is include/ansel_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "ansel_hip.h"
+
+namespace ansel
+{
+
+void set_last_error(const char *fmt, ...);
+
+// per-device state owned by runtime.cpp
+hipStream_t stream_of(int devid);
+bool valid_device(int devid);
+
+// Tagged launch bracket: the HIP peer of dt_opencl_events_get_slot() + the event the
+// OpenCL enqueue fills (src/common/opencl.c:3048-3240).  When profiling is enabled for the
+// device, a start/stop hipEvent pair is recorded on the device's stream around the launch;
+// dt_hip_events_profiling() later harvests them per tag.
+struct launch_scope
+{
+  int devid;
+  const char *tag;
+  hipEvent_t start, stop;
+  bool active;
+  launch_scope(int devid, const char *tag);
+  ~launch_scope();
+};
+
+static inline int check_launch(const char *what)
+{
+  const hipError_t e = hipGetLastError();
+  if(e != hipSuccess)
+  {
+    set_last_error("%s: %s", what, hipGetErrorString(e));
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  return DT_HIP_SUCCESS;
+}
+
+#define ANSEL_HIP_CHECK(expr)                                                                   \
+  do                                                                                            \
+  {                                                                                             \
+    const hipError_t _e = (expr);                                                               \
+    if(_e != hipSuccess)                                                                        \
+    {                                                                                           \
+      ansel::set_last_error("%s:%d %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+      return DT_HIP_DEFAULT_ERROR;                                                              \
+    }                                                                                           \
+  } while(0)
+
+// Grid for a grid-stride streaming kernel: enough workgroups to fill 256 CUs x 8 and no more
+// (cdna_hip_programming.md Guideline 11).
+static inline unsigned stream_grid(size_t work_items, unsigned block)
+{
+  size_t g = (work_items + block - 1) / block;
+  if(g > 2048u * 4u) g = 2048u * 4u;
+  if(g < 1) g = 1;
+  return (unsigned)g;
+}
+
+} // namespace ansel

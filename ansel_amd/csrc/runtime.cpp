@@ -1,0 +1,471 @@
+// runtime.cpp -- device runtime of libansel_hip: the HIP peer of the reference's
+// src/common/opencl.c (4.9 k lines of dlopen'd OpenCL: device discovery and priority
+// opencl.c:1512-1640, per-device lock :1642-1755, image/buffer alloc :2593-2704, copies
+// :2311-2455, event-list profiling :3048-3431, memory accounting :2783-2971).
+//
+// MI355X-first differences, on purpose:
+//   * no program cache / kernel table / set_kernel_arg: kernels are compiled into this
+//     library for gfx950 and launched directly by the module entry points;
+//   * "images" are linear, tightly packed device buffers (the host cacheline layout), so a
+//     module output can be handed to the next module, to a peer GPU or to the host without
+//     a layout change;
+//   * one in-order HIP stream per device replaces the OpenCL command queue; freed blocks go
+//     to a size-keyed pool so a steady-state export performs no hipMalloc at all (288 GB of
+//     HBM: we never need to give memory back between frames).
+#include "hip_common.h"
+
+#include <mutex>
+#include <unordered_map>
+#include <map>
+#include <vector>
+#include <string>
+#include <stdarg.h>
+
+namespace
+{
+
+struct event_rec
+{
+  const char *tag;
+  hipEvent_t start, stop;
+};
+
+struct device_t
+{
+  int hip_id = -1;
+  std::string name;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::mutex lock; // device exclusivity, == dt_opencl_lock_device
+  bool events_enabled = false;
+  std::vector<event_rec> events;
+  std::vector<hipEvent_t> event_pool;
+  size_t cur_bytes = 0, peak_bytes = 0;
+  std::multimap<size_t, void *> free_pool;
+};
+
+struct alloc_t
+{
+  size_t size;
+  int devid;
+};
+
+std::mutex g_mutex; // protects g_allocs, pools, counters
+bool g_inited = false;
+std::vector<device_t *> g_devs;
+std::unordered_map<void *, alloc_t> g_allocs;
+thread_local char t_error[512] = "";
+
+} // namespace
+
+namespace ansel
+{
+
+void set_last_error(const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(t_error, sizeof(t_error), fmt, ap);
+  va_end(ap);
+}
+
+bool valid_device(int devid) { return g_inited && devid >= 0 && devid < (int)g_devs.size(); }
+
+hipStream_t stream_of(int devid) { return valid_device(devid) ? g_devs[devid]->stream : nullptr; }
+
+launch_scope::launch_scope(int devid_, const char *tag_) : devid(devid_), tag(tag_), active(false)
+{
+  if(!valid_device(devid)) return;
+  device_t *d = g_devs[devid];
+  if(!d->events_enabled) return;
+  auto get = [&]() {
+    hipEvent_t e;
+    if(!d->event_pool.empty())
+    {
+      e = d->event_pool.back();
+      d->event_pool.pop_back();
+    }
+    else if(hipEventCreate(&e) != hipSuccess)
+      e = nullptr;
+    return e;
+  };
+  start = get();
+  stop = get();
+  if(!start || !stop) return;
+  active = true;
+  (void)hipEventRecord(start, d->stream);
+}
+
+launch_scope::~launch_scope()
+{
+  if(!active) return;
+  device_t *d = g_devs[devid];
+  (void)hipEventRecord(stop, d->stream);
+  d->events.push_back({ tag, start, stop });
+}
+
+} // namespace ansel
+
+using namespace ansel;
+
+extern "C" {
+
+const char *dt_hip_last_error(void) { return t_error; }
+
+int dt_hip_init(void)
+{
+  std::lock_guard<std::mutex> g(g_mutex);
+  if(g_inited) return DT_HIP_SUCCESS;
+  int n = 0;
+  if(hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+  {
+    set_last_error("dt_hip_init: no HIP device visible");
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  for(int i = 0; i < n; i++)
+  {
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
+    device_t *d = new device_t;
+    d->hip_id = i;
+    d->name = prop.name;
+    if(hipSetDevice(i) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+      delete d;
+      continue;
+    }
+    d->own_stream = true;
+    g_devs.push_back(d);
+  }
+  if(g_devs.empty())
+  {
+    set_last_error("dt_hip_init: no usable HIP device");
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  (void)hipSetDevice(g_devs[0]->hip_id);
+  g_inited = true;
+  return DT_HIP_SUCCESS;
+}
+
+void dt_hip_cleanup(void)
+{
+  std::lock_guard<std::mutex> g(g_mutex);
+  if(!g_inited) return;
+  for(device_t *d : g_devs)
+  {
+    (void)hipSetDevice(d->hip_id);
+    (void)hipStreamSynchronize(d->stream);
+    for(auto &kv : d->free_pool) (void)hipFree(kv.second);
+    for(auto &e : d->events)
+    {
+      (void)hipEventDestroy(e.start);
+      (void)hipEventDestroy(e.stop);
+    }
+    for(auto e : d->event_pool) (void)hipEventDestroy(e);
+    if(d->own_stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+  }
+  for(auto &kv : g_allocs) (void)hipFree(kv.first);
+  g_allocs.clear();
+  g_devs.clear();
+  g_inited = false;
+}
+
+int dt_hip_is_inited(void) { return g_inited ? 1 : 0; }
+
+int dt_hip_get_num_devices(void) { return g_inited ? (int)g_devs.size() : 0; }
+
+const char *dt_hip_get_device_name(int devid) { return valid_device(devid) ? g_devs[devid]->name.c_str() : ""; }
+
+size_t dt_hip_get_device_available(int devid)
+{
+  if(!valid_device(devid)) return 0;
+  size_t fr = 0, tot = 0;
+  (void)hipSetDevice(g_devs[devid]->hip_id);
+  if(hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+  // pooled blocks are ours to reuse
+  std::lock_guard<std::mutex> g(g_mutex);
+  for(auto &kv : g_devs[devid]->free_pool) fr += kv.first;
+  return fr;
+}
+
+size_t dt_hip_get_device_memalloc(int devid)
+{
+  // HIP has no separate max-allocation limit below free memory on MI355X
+  return dt_hip_get_device_available(devid);
+}
+
+int dt_hip_lock_device(int pipetype)
+{
+  (void)pipetype;
+  if(!g_inited) return -1;
+  for(size_t i = 0; i < g_devs.size(); i++)
+    if(g_devs[i]->lock.try_lock()) return (int)i;
+  return -1;
+}
+
+int dt_hip_lock_device_by_id(int devid)
+{
+  if(!valid_device(devid)) return -1;
+  g_devs[devid]->lock.lock();
+  return devid;
+}
+
+void dt_hip_unlock_device(int devid)
+{
+  if(valid_device(devid)) g_devs[devid]->lock.unlock();
+}
+
+int dt_hip_image_fits_device(int devid, size_t width, size_t height, unsigned bpp, float factor, size_t overhead)
+{
+  if(!valid_device(devid)) return 0;
+  const double need = (double)width * (double)height * (double)bpp * (double)factor + (double)overhead;
+  return need <= (double)dt_hip_get_device_available(devid) ? 1 : 0;
+}
+
+void *dt_hip_get_stream(int devid) { return (void *)stream_of(devid); }
+
+int dt_hip_set_stream(int devid, void *stream)
+{
+  if(!valid_device(devid)) return DT_HIP_INVALID_ARG;
+  device_t *d = g_devs[devid];
+  if(d->own_stream && d->stream)
+  {
+    (void)hipStreamSynchronize(d->stream);
+    (void)hipStreamDestroy(d->stream);
+  }
+  d->stream = (hipStream_t)stream;
+  d->own_stream = false;
+  return DT_HIP_SUCCESS;
+}
+
+dt_hip_mem_t dt_hip_alloc_device_buffer(int devid, size_t size)
+{
+  if(!valid_device(devid) || size == 0) return nullptr;
+  device_t *d = g_devs[devid];
+  const size_t rounded = (size + 255) & ~(size_t)255;
+  std::lock_guard<std::mutex> g(g_mutex);
+  void *p = nullptr;
+  auto it = d->free_pool.find(rounded);
+  if(it != d->free_pool.end())
+  {
+    p = it->second;
+    d->free_pool.erase(it);
+  }
+  else
+  {
+    (void)hipSetDevice(d->hip_id);
+    hipError_t e = hipMalloc(&p, rounded);
+    if(e != hipSuccess)
+    {
+      // flush the pool and retry once: dt_opencl_alloc_device's "flush cached cl_mem and
+      // retry" (src/common/opencl.c:2604-2616)
+      for(auto &kv : d->free_pool) (void)hipFree(kv.second);
+      d->free_pool.clear();
+      (void)hipGetLastError();
+      e = hipMalloc(&p, rounded);
+    }
+    if(e != hipSuccess)
+    {
+      set_last_error("dt_hip_alloc_device_buffer: %zu bytes: %s", rounded, hipGetErrorString(e));
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
+  g_allocs[p] = { rounded, devid };
+  d->cur_bytes += rounded;
+  if(d->cur_bytes > d->peak_bytes) d->peak_bytes = d->cur_bytes;
+  return p;
+}
+
+dt_hip_mem_t dt_hip_alloc_device(int devid, int width, int height, int bpp)
+{
+  if(width <= 0 || height <= 0 || bpp <= 0) return nullptr;
+  return dt_hip_alloc_device_buffer(devid, (size_t)width * (size_t)height * (size_t)bpp);
+}
+
+void dt_hip_release_mem_object(dt_hip_mem_t mem)
+{
+  if(!mem) return;
+  std::lock_guard<std::mutex> g(g_mutex);
+  auto it = g_allocs.find(mem);
+  if(it == g_allocs.end()) return; // not ours (e.g. a torch tensor): nothing to do
+  const alloc_t a = it->second;
+  g_allocs.erase(it);
+  if(a.devid >= 0 && a.devid < (int)g_devs.size())
+  {
+    device_t *d = g_devs[a.devid];
+    d->cur_bytes -= a.size;
+    // stream-ordered reuse is safe: every consumer of this runtime enqueues on d->stream
+    d->free_pool.insert({ a.size, mem });
+  }
+  else
+    (void)hipFree(mem);
+}
+
+size_t dt_hip_get_mem_object_size(dt_hip_mem_t mem)
+{
+  std::lock_guard<std::mutex> g(g_mutex);
+  auto it = g_allocs.find(mem);
+  return it == g_allocs.end() ? 0 : it->second.size;
+}
+
+void dt_hip_memory_statistics(int devid, size_t *current, size_t *peak)
+{
+  if(current) *current = valid_device(devid) ? g_devs[devid]->cur_bytes : 0;
+  if(peak) *peak = valid_device(devid) ? g_devs[devid]->peak_bytes : 0;
+}
+
+int dt_hip_write_host_to_device_rowpitch(int devid, const void *host, dt_hip_mem_t device, int width, int height,
+                                         int bpp, size_t rowpitch, int blocking)
+{
+  if(!valid_device(devid) || !host || !device) return DT_HIP_INVALID_ARG;
+  hipStream_t s = stream_of(devid);
+  const size_t wbytes = (size_t)width * bpp;
+  launch_scope ls(devid, "[Write Image (from host to device)]");
+  if(rowpitch == wbytes)
+    ANSEL_HIP_CHECK(hipMemcpyAsync(device, host, wbytes * height, hipMemcpyHostToDevice, s));
+  else
+    ANSEL_HIP_CHECK(hipMemcpy2DAsync(device, wbytes, host, rowpitch, wbytes, height, hipMemcpyHostToDevice, s));
+  if(blocking) ANSEL_HIP_CHECK(hipStreamSynchronize(s));
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_write_host_to_device(int devid, const void *host, dt_hip_mem_t device, int width, int height, int bpp)
+{
+  return dt_hip_write_host_to_device_rowpitch(devid, host, device, width, height, bpp, (size_t)width * bpp, 1);
+}
+
+int dt_hip_read_host_from_device_rowpitch(int devid, void *host, dt_hip_mem_t device, int width, int height,
+                                          int bpp, size_t rowpitch, int blocking)
+{
+  if(!valid_device(devid) || !host || !device) return DT_HIP_INVALID_ARG;
+  hipStream_t s = stream_of(devid);
+  const size_t wbytes = (size_t)width * bpp;
+  launch_scope ls(devid, "[Read Image (from device to host)]");
+  if(rowpitch == wbytes)
+    ANSEL_HIP_CHECK(hipMemcpyAsync(host, device, wbytes * height, hipMemcpyDeviceToHost, s));
+  else
+    ANSEL_HIP_CHECK(hipMemcpy2DAsync(host, rowpitch, device, wbytes, wbytes, height, hipMemcpyDeviceToHost, s));
+  if(blocking) ANSEL_HIP_CHECK(hipStreamSynchronize(s));
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_read_host_from_device(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp)
+{
+  return dt_hip_read_host_from_device_rowpitch(devid, host, device, width, height, bpp, (size_t)width * bpp, 1);
+}
+
+int dt_hip_enqueue_copy_buffer_to_buffer(int devid, dt_hip_mem_t src, dt_hip_mem_t dst, size_t srcoffset,
+                                         size_t dstoffset, size_t size)
+{
+  if(!valid_device(devid) || !src || !dst) return DT_HIP_INVALID_ARG;
+  launch_scope ls(devid, "[Copy Buffer to Buffer (on device)]");
+  ANSEL_HIP_CHECK(hipMemcpyAsync((char *)dst + dstoffset, (const char *)src + srcoffset, size,
+                                 hipMemcpyDeviceToDevice, stream_of(devid)));
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_enqueue_copy_region(int devid, dt_hip_mem_t src, int src_width, int src_x, int src_y, dt_hip_mem_t dst,
+                               int dst_width, int dst_x, int dst_y, int width, int height, int bpp)
+{
+  if(!valid_device(devid) || !src || !dst) return DT_HIP_INVALID_ARG;
+  if(width <= 0 || height <= 0) return DT_HIP_SUCCESS;
+  launch_scope ls(devid, "[Copy Image (on device)]");
+  const char *s = (const char *)src + ((size_t)src_y * src_width + src_x) * bpp;
+  char *d = (char *)dst + ((size_t)dst_y * dst_width + dst_x) * bpp;
+  ANSEL_HIP_CHECK(hipMemcpy2DAsync(d, (size_t)dst_width * bpp, s, (size_t)src_width * bpp, (size_t)width * bpp,
+                                   height, hipMemcpyDeviceToDevice, stream_of(devid)));
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_finish(int devid)
+{
+  if(!valid_device(devid)) return 0;
+  const hipError_t e = hipStreamSynchronize(stream_of(devid));
+  if(e != hipSuccess)
+  {
+    set_last_error("dt_hip_finish: %s", hipGetErrorString(e));
+    return 0;
+  }
+  return 1; // TRUE on success, like dt_opencl_finish
+}
+
+void dt_hip_events_enable(int devid, int enable)
+{
+  if(valid_device(devid)) g_devs[devid]->events_enabled = enable != 0;
+}
+
+void dt_hip_events_reset(int devid)
+{
+  if(!valid_device(devid)) return;
+  device_t *d = g_devs[devid];
+  (void)hipStreamSynchronize(d->stream);
+  for(auto &e : d->events)
+  {
+    d->event_pool.push_back(e.start);
+    d->event_pool.push_back(e.stop);
+  }
+  d->events.clear();
+}
+
+int dt_hip_events_profiling(int devid, const char **tags, float *ms, int *counts, int max)
+{
+  if(!valid_device(devid)) return 0;
+  device_t *d = g_devs[devid];
+  (void)hipStreamSynchronize(d->stream);
+  std::vector<const char *> order;
+  std::unordered_map<std::string, int> idx;
+  std::vector<float> tsum;
+  std::vector<int> cnt;
+  for(auto &e : d->events)
+  {
+    float t = 0.f;
+    if(hipEventElapsedTime(&t, e.start, e.stop) != hipSuccess) continue;
+    auto it = idx.find(e.tag);
+    int k;
+    if(it == idx.end())
+    {
+      k = (int)order.size();
+      idx[e.tag] = k;
+      order.push_back(e.tag);
+      tsum.push_back(0.f);
+      cnt.push_back(0);
+    }
+    else
+      k = it->second;
+    tsum[k] += t;
+    cnt[k] += 1;
+  }
+  const int n = (int)order.size();
+  for(int i = 0; i < n && i < max; i++)
+  {
+    if(tags) tags[i] = order[i];
+    if(ms) ms[i] = tsum[i];
+    if(counts) counts[i] = cnt[i];
+  }
+  return n;
+}
+
+// sizes of the C-ABI structs as this library was compiled, for the ctypes mirror's self-check
+size_t dt_hip_abi_sizeof(const char *name)
+{
+#define S(n, t) \
+  if(!strcmp(name, n)) return sizeof(t)
+  S("roi", dt_hip_roi_t);
+  S("piece", dt_hip_piece_t);
+  S("tiling", dt_hip_tiling_t);
+  S("rawprepare", dt_hip_rawprepare_data_t);
+  S("temperature", dt_hip_temperature_data_t);
+  S("highlights", dt_hip_highlights_data_t);
+  S("demosaic", dt_hip_demosaic_data_t);
+  S("exposure", dt_hip_exposure_data_t);
+  S("conversion", dt_hip_conversion_t);
+  S("channelmixerrgb", dt_hip_channelmixerrgb_data_t);
+  S("filmic_spline", dt_hip_filmic_spline_t);
+  S("filmicrgb", dt_hip_filmicrgb_data_t);
+#undef S
+  return 0;
+}
+
+} // extern "C"

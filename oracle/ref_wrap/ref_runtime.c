@@ -16,6 +16,10 @@ void *dt_alloc_align(size_t size)
 {
   void *p = NULL;
   if(posix_memalign(&p, 64, size ? size : 64)) return NULL;
+  /* Scratch starts zeroed: the reference reads a few scratch words it never wrote (see
+   * oracle/src/demosaic_rcd.c), and a recycled heap block would make those reads depend on
+   * what this process computed before. */
+  memset(p, 0, size ? size : 64);
   return p;
 }
 
