@@ -1,0 +1,84 @@
+"""Build libansel_hip.so (the product) for gfx950 with hipcc, in-tree.
+
+    python -m ansel_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Each translation unit becomes an object under
+ansel_amd/csrc/_obj/ (rebuilt only when it or a header is newer), then everything is linked
+into ansel_amd/libansel_hip.so, which is what ansel_amd.lib loads and what travels to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libansel_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# -ffp-contract=off: one IEEE operation per source operation, nothing fused that the reference's
+# strict CPU build does not fuse (explicit fmaf() stays a single v_fma_f32).
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+          "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+# per-file extra flags
+EXTRA = {
+    # rcd_demosaic() runs with FTZ/DAZ set (src/iop/demosaic/rcd.c:300)
+    "demosaic_rcd.hip": ["-fgpu-flush-denormals-to-zero"],
+}
+
+
+def _sources():
+    out = []
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".hip") or f.endswith(".cpp"):
+            out.append(f)
+    return out
+
+
+def _headers_mtime():
+    m = 0.0
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                m = max(m, os.path.getmtime(os.path.join(d, f)))
+    return max(m, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hm = _headers_mtime()
+    objs = []
+    procs = []
+    for f in _sources():
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hm):
+            continue
+        cmd = [HIPCC] + COMMON + EXTRA.get(f, []) + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print("[ansel_amd.build] hipcc", f, flush=True)
+        procs.append((f, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for f, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(out.decode(errors="replace"))
+            sys.stderr.write("[ansel_amd.build] FAILED: %s\n" % f)
+        elif verbose and out.strip():
+            sys.stdout.write(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print("[ansel_amd.build] link", os.path.relpath(LIB, ROOT), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

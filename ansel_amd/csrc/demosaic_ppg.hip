@@ -1,0 +1,41 @@
+// demosaic_ppg.hip -- PPG demosaic of a Bayer mosaic: demosaic_ppg(), src/iop/demosaic/ppg.c:20-217
+// (median pre-filter off).  One launch, one thread per finished float4 pixel: see ppg_device.h.
+// Algorithmic bytes: 4 read + 16 written per pixel.
+#include "hip_common.h"
+#include "ppg_device.h"
+
+using namespace ansel;
+
+namespace
+{
+__global__ __launch_bounds__(256) void ppg_full(float4 *__restrict__ out, const ppg_ctx k)
+{
+  // 64 x 4 pixel patch per workgroup: a wave covers 64 consecutive pixels of one row, the four
+  // waves four consecutive rows, so the 7x7 footprints overlap in L1
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(i >= k.w || j >= k.h) return;
+  out[(size_t)j * k.w + i] = ppg_pixel<false>(k, j, i);
+}
+} // namespace
+
+namespace ansel
+{
+int ppg_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out)
+{
+  ppg_ctx k;
+  k.in = in;
+  k.iw = piece->roi_in.width;
+  k.ih = piece->roi_in.height;
+  k.w = piece->roi_out.width;
+  k.h = piece->roi_out.height;
+  k.ox = 0; // process() zeroes roo.x/y before calling demosaic_ppg (demosaic.c:1050-1052)
+  k.oy = 0;
+  k.filters = filters;
+  if(k.w <= 0 || k.h <= 0) return DT_HIP_SUCCESS;
+  dim3 grid((k.w + 63) / 64, (k.h + 3) / 4);
+  launch_scope ls(devid, "ppg_full");
+  ppg_full<<<grid, 256, 0, stream_of(devid)>>>(out, k);
+  return check_launch("ppg_full");
+}
+} // namespace ansel

@@ -1,0 +1,406 @@
+// demosaic_rcd.hip -- ratio-corrected demosaic (RCD) of a Bayer mosaic on gfx950.
+//
+// Reference: rcd_demosaic(), src/iop/demosaic/rcd.c:274-564 and rcd_ppg_border(), :92-272
+// (CPU path; the reference's OpenCL version, data/kernels/demosaic_rcd.cl, is 13 full-frame
+// launches over 8 full-size float scratch planes and is NOT what this follows).
+//
+// MI355X design.  The CPU code works on 112 x 112 tiles whose inner 94 x 94 are written out,
+// and its results near a tile rim depend on the tile grid (VH_Dir is zero on the 4-px rim), so
+// the grid is part of the algorithm.  Here ONE WORKGROUP OWNS ONE REFERENCE TILE and keeps the
+// whole working set in LDS -- 147 KiB of the CU's 160 KiB:
+//
+//     cfa   112 x 112 f32   normalised, clamped mosaic                        50176 B
+//     vh    112 x 112 f32   VH_Dir (vertical/horizontal discrimination)       50176 B
+//     g     112 x  56 f32   green at red/blue sites                           25088 B
+//     x     112 x  56 f32   low-pass filter -> PQ_Dir -> colour at the        25088 B
+//                           opposite-colour site, reusing one buffer as each dies
+//
+// so HBM sees exactly one read of the mosaic (+19 % halo) and one float4 write per pixel:
+// 4 + 16 = 20 B/px, against ~250 B/px of full-frame scratch traffic in the reference's OpenCL
+// decomposition.  The P/Q colour-difference high-pass planes of the CPU code are not stored:
+// each PQ_Dir needs three samples of each, recomputed from cfa in LDS (17 LDS reads, same count
+// as storing and re-reading them).  Half-resolution planes are indexed (row * 112 + col) / 2,
+// exactly as in the reference (that indexing is visible in its results, see below).
+//
+// Numerics.  Same operation order as the CPU code, one IEEE operation per C operation
+// (-ffp-contract=off).  The reference's gradient sums call fabs() -- double -- so they are
+// accumulated in binary64 and rounded once (rcd.c:414-417, 478-481, 508-527); the kernel does the
+// same in v_add_f64.  rcd_demosaic() runs with FTZ/DAZ (rcd.c:300); this file is compiled with
+// -fgpu-flush-denormals-to-zero.  Scratch words the CPU code reads without having written them in
+// the current tile are 0.0f (see oracle/src/demosaic_rcd.c for the two places this matters).
+#include "hip_common.h"
+#include "ppg_device.h"
+
+using namespace ansel;
+
+namespace
+{
+
+constexpr int TS = 112;        // RCD_TILESIZE
+constexpr int HS = TS / 2;     // row length of a half-resolution plane
+constexpr int RCD_BORDER = 9;
+constexpr int RCD_MARGIN = 6;
+constexpr int TV = TS - 2 * RCD_BORDER;
+constexpr int W1 = TS, W2 = 2 * TS, W3 = 3 * TS, W4 = 4 * TS;
+constexpr int NT = 896;        // 14 waves: 112*112 / 896 = 14 and 112*56 / 896 = 7 exactly
+constexpr int FULL_ITERS = TS * TS / NT;
+constexpr int HALF_ITERS = TS * HS / NT;
+constexpr size_t LDS_BYTES = sizeof(float) * (2 * TS * TS + 2 * TS * HS);
+
+#define EPS 1e-5f
+#define EPSSQ 1e-10f
+
+__device__ __forceinline__ int fc(const int row, const int col, const uint32_t filters)
+{
+  return filters >> ((((row << 1) & 14) + (col & 1)) << 1) & 3;
+}
+__device__ __forceinline__ float sqf(const float v) { return v * v; }
+__device__ __forceinline__ float intp(const float a, const float b, const float c) { return a * (b - c) + c; }
+__device__ __forceinline__ double dabs(const float v) { return fabs((double)v); }
+
+__device__ __forceinline__ float hpf(const float *c, const int i, const int s)
+{
+  return sqf((c[i - 3 * s] - c[i - s] - c[i + s] + c[i + 3 * s]) - 3.0f * (c[i - 2 * s] + c[i + 2 * s]) + 6.0f * c[i]);
+}
+
+// P/Q_CDiff_Hpf word idx2 of the reference (rcd.c:444-451): computed at (row, odd col) with
+// idx2 == (row*TS + col)/2; 0 where step 4.0 of this tile does not write it
+__device__ __forceinline__ float pq_hpf(const float *cfa, const int idx2, const int tileRows, const int tileCols,
+                                        const int s)
+{
+  const int row = idx2 / HS;
+  const int col = 2 * (idx2 - row * HS) + 1;
+  if(row < 3 || row >= tileRows - 3 || col < 3 || col >= tileCols - 3) return 0.0f;
+  return hpf(cfa, row * TS + col, s);
+}
+
+struct rcd_args
+{
+  int width, height;
+  uint32_t filters;
+  float scaler, revscaler;
+  int num_vertical, num_horizontal;
+};
+
+__global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, float4 *__restrict__ out,
+                                                 const rcd_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *const cfa = lds;
+  float *const vh = cfa + TS * TS;
+  float *const g = vh + TS * TS;
+  float *const x = g + TS * HS;
+
+  const int tid = threadIdx.x;
+  const int tile_vertical = blockIdx.x / a.num_horizontal;
+  const int tile_horizontal = blockIdx.x - tile_vertical * a.num_horizontal;
+  const int rowStart = tile_vertical * TV, rowEnd = min(rowStart + TS, a.height);
+  const int colStart = tile_horizontal * TV, colEnd = min(colStart + TS, a.width);
+  const int tileRows = rowEnd - rowStart, tileCols = colEnd - colStart;
+  const uint32_t filters = a.filters;
+  // column parity of the red/blue sites of tile row 0 and 1 (tile origins are even)
+  const int p0 = fc(0, 0, filters) & 1, p1 = fc(1, 0, filters) & 1;
+
+  // ---- step 0 (rcd.c:345-354): cfa = fmaxf(0, in) * revscaler, zero outside a partial tile
+#pragma unroll
+  for(int it = 0; it < FULL_ITERS; it++)
+  {
+    const int idx = tid + it * NT;
+    const int row = idx / TS, col = idx - row * TS;
+    float v = 0.0f;
+    if(row < tileRows && col < tileCols)
+      v = fmaxf(0.0f, in[(size_t)(rowStart + row) * a.width + colStart + col]) * a.revscaler;
+    cfa[idx] = v;
+  }
+  __syncthreads();
+
+  // ---- step 1 (rcd.c:356-390) VH_Dir, 0 on the rim; step 2.1 (rcd.c:394-402) lpf at red/blue
+  //      sites; rgb[1] starts as cfa (rcd.c:352)
+#pragma unroll
+  for(int it = 0; it < FULL_ITERS; it++)
+  {
+    const int idx = tid + it * NT;
+    const int row = idx / TS, col = idx - row * TS;
+    float v = 0.0f;
+    if(row >= 4 && row < tileRows - 4 && col >= 4 && col < tileCols - 4)
+    {
+      const float V_Stat = fmaxf(EPSSQ, hpf(cfa, idx - W1, W1) + hpf(cfa, idx, W1) + hpf(cfa, idx + W1, W1));
+      const float H_Stat = fmaxf(EPSSQ, hpf(cfa, idx - 1, 1) + hpf(cfa, idx, 1) + hpf(cfa, idx + 1, 1));
+      v = V_Stat / (V_Stat + H_Stat);
+    }
+    vh[idx] = v;
+  }
+#pragma unroll
+  for(int it = 0; it < HALF_ITERS; it++)
+  {
+    const int h = tid + it * NT;
+    const int row = h / HS, col = 2 * (h - row * HS) + ((row & 1) ? p1 : p0);
+    const int idx = row * TS + col;
+    float lp = 0.0f;
+    if(row >= 2 && row < tileRows - 2 && col >= 2 && col < tileCols - 2)
+      lp = cfa[idx] + 0.5f * (cfa[idx - W1] + cfa[idx + W1] + cfa[idx - 1] + cfa[idx + 1])
+           + 0.25f * (cfa[idx - W1 - 1] + cfa[idx - W1 + 1] + cfa[idx + W1 - 1] + cfa[idx + W1 + 1]);
+    x[h] = lp;
+    g[h] = cfa[idx];
+  }
+  __syncthreads();
+
+  // ---- step 3.1 (rcd.c:406-440): green at red/blue sites
+#pragma unroll
+  for(int it = 0; it < HALF_ITERS; it++)
+  {
+    const int h = tid + it * NT;
+    const int row = h / HS, col = 2 * (h - row * HS) + ((row & 1) ? p1 : p0);
+    if(row < 4 || row >= tileRows - 4 || col < 4 || col >= tileCols - 4) continue;
+    const int indx = row * TS + col;
+    const float cfai = cfa[indx];
+    const float cN1 = cfa[indx - W1], cS1 = cfa[indx + W1], cW1 = cfa[indx - 1], cE1 = cfa[indx + 1];
+    const float cN2 = cfa[indx - W2], cS2 = cfa[indx + W2], cW2 = cfa[indx - 2], cE2 = cfa[indx + 2];
+    const float N_Grad = (float)((double)EPS + dabs(cN1 - cS1) + dabs(cfai - cN2) + dabs(cN1 - cfa[indx - W3]) + dabs(cN2 - cfa[indx - W4]));
+    const float S_Grad = (float)((double)EPS + dabs(cN1 - cS1) + dabs(cfai - cS2) + dabs(cS1 - cfa[indx + W3]) + dabs(cS2 - cfa[indx + W4]));
+    const float W_Grad = (float)((double)EPS + dabs(cW1 - cE1) + dabs(cfai - cW2) + dabs(cW1 - cfa[indx - 3]) + dabs(cW2 - cfa[indx - 4]));
+    const float E_Grad = (float)((double)EPS + dabs(cW1 - cE1) + dabs(cfai - cE2) + dabs(cE1 - cfa[indx + 3]) + dabs(cE2 - cfa[indx + 4]));
+    const float lpfi = x[h];
+    const float N_Est = cN1 * (lpfi + lpfi) / (EPS + lpfi + x[h - W1]);
+    const float S_Est = cS1 * (lpfi + lpfi) / (EPS + lpfi + x[h + W1]);
+    const float W_Est = cW1 * (lpfi + lpfi) / (EPS + lpfi + x[h - 1]);
+    const float E_Est = cE1 * (lpfi + lpfi) / (EPS + lpfi + x[h + 1]);
+    const float V_Est = (S_Grad * N_Est + N_Grad * S_Est) / (N_Grad + S_Grad);
+    const float H_Est = (W_Grad * E_Est + E_Grad * W_Est) / (E_Grad + W_Grad);
+    const float VH_Central_Value = vh[indx];
+    const float VH_Neighbourhood_Value = 0.25f * (vh[indx - W1 - 1] + vh[indx - W1 + 1] + vh[indx + W1 - 1] + vh[indx + W1 + 1]);
+    const float VH_Disc = (fabsf(0.5f - VH_Central_Value) < fabsf(0.5f - VH_Neighbourhood_Value)) ? VH_Neighbourhood_Value : VH_Central_Value;
+    g[h] = intp(VH_Disc, H_Est, V_Est);
+  }
+  __syncthreads();
+
+  // ---- steps 4.0 + 4.1 (rcd.c:444-463): PQ_Dir over the lpf buffer
+#pragma unroll
+  for(int it = 0; it < HALF_ITERS; it++)
+  {
+    const int h = tid + it * NT;
+    const int row = h / HS, col = 2 * (h - row * HS) + ((row & 1) ? p1 : p0);
+    if(row < 4 || row >= tileRows - 4 || col < 4 || col >= tileCols - 4) continue;
+    const int indx = row * TS + col;
+    const int indx3 = (indx - W1 - 1) / 2, indx4 = (indx + W1 - 1) / 2;
+    const float P_Stat = fmaxf(EPSSQ, pq_hpf(cfa, indx3, tileRows, tileCols, W1 + 1) + pq_hpf(cfa, h, tileRows, tileCols, W1 + 1) + pq_hpf(cfa, indx4 + 1, tileRows, tileCols, W1 + 1));
+    const float Q_Stat = fmaxf(EPSSQ, pq_hpf(cfa, indx3 + 1, tileRows, tileCols, W1 - 1) + pq_hpf(cfa, h, tileRows, tileCols, W1 - 1) + pq_hpf(cfa, indx4, tileRows, tileCols, W1 - 1));
+    x[h] = P_Stat / (P_Stat + Q_Stat);
+  }
+  __syncthreads();
+
+  // ---- step 4.2 (rcd.c:466-496): red at blue sites / blue at red sites, kept in registers
+  //      until every thread has read its PQ_Dir neighbourhood, then stored over PQ_Dir
+  float co[HALF_ITERS];
+#pragma unroll
+  for(int it = 0; it < HALF_ITERS; it++)
+  {
+    const int h = tid + it * NT;
+    const int row = h / HS, col = 2 * (h - row * HS) + ((row & 1) ? p1 : p0);
+    co[it] = 0.0f;
+    if(row < 4 || row >= tileRows - 4 || col < 4 || col >= tileCols - 4) continue;
+    const int indx = row * TS + col;
+    const int pqindx2 = (indx - W1 - 1) / 2, pqindx3 = (indx + W1 - 1) / 2;
+    const float PQ_Central_Value = x[h];
+    const float PQ_Neighbourhood_Value = 0.25f * (x[pqindx2] + x[pqindx2 + 1] + x[pqindx3] + x[pqindx3 + 1]);
+    const float PQ_Disc = (fabsf(0.5f - PQ_Central_Value) < fabsf(0.5f - PQ_Neighbourhood_Value)) ? PQ_Neighbourhood_Value : PQ_Central_Value;
+    const float nw = cfa[indx - W1 - 1], ne = cfa[indx - W1 + 1], sw = cfa[indx + W1 - 1], se = cfa[indx + W1 + 1];
+    const float g0 = g[h];
+    const float NW_Grad = (float)((double)EPS + dabs(nw - se) + dabs(nw - cfa[indx - W3 - 3]) + dabs(g0 - g[(indx - W2 - 2) / 2]));
+    const float NE_Grad = (float)((double)EPS + dabs(ne - sw) + dabs(ne - cfa[indx - W3 + 3]) + dabs(g0 - g[(indx - W2 + 2) / 2]));
+    const float SW_Grad = (float)((double)EPS + dabs(ne - sw) + dabs(sw - cfa[indx + W3 - 3]) + dabs(g0 - g[(indx + W2 - 2) / 2]));
+    const float SE_Grad = (float)((double)EPS + dabs(nw - se) + dabs(se - cfa[indx + W3 + 3]) + dabs(g0 - g[(indx + W2 + 2) / 2]));
+    const float NW_Est = nw - g[(indx - W1 - 1) / 2];
+    const float NE_Est = ne - g[(indx - W1 + 1) / 2];
+    const float SW_Est = sw - g[(indx + W1 - 1) / 2];
+    const float SE_Est = se - g[(indx + W1 + 1) / 2];
+    const float P_Est = (NW_Grad * SE_Est + SE_Grad * NW_Est) / (NW_Grad + SE_Grad);
+    const float Q_Est = (NE_Grad * SW_Est + SW_Grad * NE_Est) / (NE_Grad + SW_Grad);
+    co[it] = g0 + intp(PQ_Disc, Q_Est, P_Est);
+  }
+  __syncthreads();
+#pragma unroll
+  for(int it = 0; it < HALF_ITERS; it++) x[tid + it * NT] = co[it];
+  __syncthreads();
+
+  // ---- output (rcd.c:539-555) with step 4.3 (rcd.c:499-536) evaluated at the green sites that
+  //      are written out
+  const int first_vertical = (tile_vertical == 0) ? RCD_MARGIN : RCD_BORDER;
+  const int last_vertical = tileRows - ((tile_vertical == a.num_vertical - 1) ? RCD_MARGIN : RCD_BORDER);
+  const int first_horizontal = (tile_horizontal == 0) ? RCD_MARGIN : RCD_BORDER;
+  const int last_horizontal = tileCols - ((tile_horizontal == a.num_horizontal - 1) ? RCD_MARGIN : RCD_BORDER);
+  const int orows = last_vertical - first_vertical, ocols = last_horizontal - first_horizontal;
+  if(orows <= 0 || ocols <= 0) return;
+  const int kw = (ocols + 1) >> 1; // sites of one kind per output row, at most
+  const int nsites = orows * kw;
+  const float scaler = a.scaler;
+
+  // red / blue sites
+  for(int s = tid; s < nsites; s += NT)
+  {
+    const int r = s / kw, k = s - r * kw;
+    const int row = first_vertical + r;
+    const int p = (row & 1) ? p1 : p0;
+    const int col = first_horizontal + ((first_horizontal & 1) != p) + 2 * k;
+    if(col >= last_horizontal) continue;
+    const int indx = row * TS + col;
+    const int f = fc(row, col, filters); // 0 or 2
+    const float native = scaler * fmaxf(0.0f, cfa[indx]);
+    const float green = scaler * fmaxf(0.0f, g[indx >> 1]);
+    const float other = scaler * fmaxf(0.0f, x[indx >> 1]);
+    float4 o;
+    o.x = (f == 0) ? native : other;
+    o.y = green;
+    o.z = (f == 0) ? other : native;
+    o.w = 0.0f;
+    out[(size_t)(rowStart + row) * a.width + colStart + col] = o;
+  }
+
+  // green sites
+  for(int s = tid; s < nsites; s += NT)
+  {
+    const int r = s / kw, k = s - r * kw;
+    const int row = first_vertical + r;
+    const int p = 1 - ((row & 1) ? p1 : p0);
+    const int col = first_horizontal + ((first_horizontal & 1) != p) + 2 * k;
+    if(col >= last_horizontal) continue;
+    const int indx = row * TS + col;
+    const float VH_Central_Value = vh[indx];
+    const float VH_Neighbourhood_Value = 0.25f * (vh[indx - W1 - 1] + vh[indx - W1 + 1] + vh[indx + W1 - 1] + vh[indx + W1 + 1]);
+    const float VH_Disc = (fabsf(0.5f - VH_Central_Value) < fabsf(0.5f - VH_Neighbourhood_Value)) ? VH_Neighbourhood_Value : VH_Central_Value;
+    const float rgb1 = cfa[indx];
+    const float N1 = (float)((double)EPS + dabs(rgb1 - cfa[indx - W2]));
+    const float S1 = (float)((double)EPS + dabs(rgb1 - cfa[indx + W2]));
+    const float W1g = (float)((double)EPS + dabs(rgb1 - cfa[indx - 2]));
+    const float E1 = (float)((double)EPS + dabs(rgb1 - cfa[indx + 2]));
+    const float rgb1mw1 = g[(indx - W1) >> 1], rgb1pw1 = g[(indx + W1) >> 1];
+    const float rgb1m1 = g[(indx - 1) >> 1], rgb1p1 = g[(indx + 1) >> 1];
+    // the row neighbours carry colour `ch` natively, the column neighbours the other one; the
+    // non-native samples are step 4.2 results (x)
+    const int ch = fc(row, col + 1, filters);
+    float res[2];
+#pragma unroll
+    for(int ci = 0; ci < 2; ci++)
+    {
+      const int c = 2 * ci;
+      const bool hn = (c == ch);
+      const float cN1 = hn ? x[(indx - W1) >> 1] : cfa[indx - W1];
+      const float cS1 = hn ? x[(indx + W1) >> 1] : cfa[indx + W1];
+      const float cN3 = hn ? x[(indx - W3) >> 1] : cfa[indx - W3];
+      const float cS3 = hn ? x[(indx + W3) >> 1] : cfa[indx + W3];
+      const float cW1 = hn ? cfa[indx - 1] : x[(indx - 1) >> 1];
+      const float cE1 = hn ? cfa[indx + 1] : x[(indx + 1) >> 1];
+      const float cW3 = hn ? cfa[indx - 3] : x[(indx - 3) >> 1];
+      const float cE3 = hn ? cfa[indx + 3] : x[(indx + 3) >> 1];
+      const float SNabs = fabsf(cN1 - cS1);
+      const float EWabs = fabsf(cW1 - cE1);
+      const float N_Grad = (float)((double)(N1 + SNabs) + dabs(cN1 - cN3));
+      const float S_Grad = (float)((double)(S1 + SNabs) + dabs(cS1 - cS3));
+      const float W_Grad = (float)((double)(W1g + EWabs) + dabs(cW1 - cW3));
+      const float E_Grad = (float)((double)(E1 + EWabs) + dabs(cE1 - cE3));
+      const float N_Est = cN1 - rgb1mw1;
+      const float S_Est = cS1 - rgb1pw1;
+      const float W_Est = cW1 - rgb1m1;
+      const float E_Est = cE1 - rgb1p1;
+      const float V_Est = (N_Grad * S_Est + S_Grad * N_Est) / (N_Grad + S_Grad);
+      const float H_Est = (E_Grad * W_Est + W_Grad * E_Est) / (E_Grad + W_Grad);
+      res[ci] = rgb1 + intp(VH_Disc, H_Est, V_Est);
+    }
+    float4 o;
+    o.x = scaler * fmaxf(0.0f, res[0]);
+    o.y = scaler * fmaxf(0.0f, rgb1);
+    o.z = scaler * fmaxf(0.0f, res[1]);
+    o.w = 0.0f;
+    out[(size_t)(rowStart + row) * a.width + colStart + col] = o;
+  }
+}
+
+// ---- border ring: rcd_ppg_border(), rcd.c:92-272, through ppg_device.h (clamped samples) ----
+__global__ __launch_bounds__(256) void rcd_border(const float *__restrict__ in, float4 *__restrict__ out,
+                                                   const int width, const int height, const uint32_t filters)
+{
+  // enumerate the ring of RCD_MARGIN pixels: top rows, bottom rows, then left/right columns
+  const int M = RCD_MARGIN;
+  const long top = (long)M * width, side = (long)(height - 2 * M) * 2 * M;
+  const long total = 2 * top + (side > 0 ? side : 0);
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= total) return;
+  int j, i;
+  if(t < top)
+  {
+    j = (int)(t / width);
+    i = (int)(t - (long)j * width);
+  }
+  else if(t < 2 * top)
+  {
+    const long u = t - top;
+    j = height - M + (int)(u / width);
+    i = (int)(u % width);
+  }
+  else
+  {
+    const long u = t - 2 * top;
+    j = M + (int)(u / (2 * M));
+    const int q = (int)(u % (2 * M));
+    i = q < M ? q : width - 2 * M + q;
+  }
+  if(j < 0 || j >= height || i < 0 || i >= width) return;
+  const ppg_ctx k = { in, width, height, width, height, 0, 0, filters };
+  out[(size_t)j * width + i] = ppg_pixel<true>(k, j, i);
+}
+
+} // namespace
+
+// FC-based shift of the dcraw filter word: dt_rawspeed_crop_dcraw_filters()
+// (src/imageio/imageio_rawspeed.cc:146-151 -> rawspeed ColorFilterArray::shiftDcrawFilter)
+extern "C" uint32_t dt_hip_crop_dcraw_filters(uint32_t filters, uint32_t crop_x, uint32_t crop_y)
+{
+  if(!filters || filters == 9u) return filters;
+  uint32_t out = 0;
+  for(int r = 0; r < 8; r++)
+    for(int c = 0; c < 2; c++)
+    {
+      const int row = r + crop_y, col = c + crop_x;
+      const uint32_t colour = filters >> ((((row << 1) & 14) + (col & 1)) << 1) & 3;
+      out |= colour << ((((r << 1) & 14) + (c & 1)) << 1);
+    }
+  return out;
+}
+
+namespace ansel
+{
+
+int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out)
+{
+  const int width = piece->roi_in.width, height = piece->roi_in.height;
+  if(width < 16 || height < 16) return DT_HIP_SUCCESS; // rcd.c:280-284: "too small area", output untouched
+  // rows alternate R/G and G/B with period 2 for every Bayer filter word rawspeed produces;
+  // the CPU code already relies on it by mixing image-row and tile-row FC() calls
+  hipStream_t s = stream_of(devid);
+  {
+    const long ring = 2L * RCD_MARGIN * width + 2L * RCD_MARGIN * (height > 2 * RCD_MARGIN ? height - 2 * RCD_MARGIN : 0);
+    launch_scope ls(devid, "rcd_border");
+    rcd_border<<<(unsigned)((ring + 255) / 256), 256, 0, s>>>(in, out, width, height, filters);
+  }
+  rcd_args a;
+  a.width = width;
+  a.height = height;
+  a.filters = filters;
+  a.scaler = fmaxf(piece->processed_maximum[0], fmaxf(piece->processed_maximum[1], piece->processed_maximum[2]));
+  a.revscaler = 1.0f / a.scaler;
+  a.num_vertical = 1 + (height - 2 * RCD_BORDER - 1) / TV;
+  a.num_horizontal = 1 + (width - 2 * RCD_BORDER - 1) / TV;
+  static bool attr_set = false;
+  if(!attr_set)
+  {
+    ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)rcd_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    attr_set = true;
+  }
+  {
+    launch_scope ls(devid, "rcd_tiles");
+    rcd_tiles<<<(unsigned)(a.num_vertical * a.num_horizontal), NT, LDS_BYTES, s>>>(in, out, a);
+  }
+  return check_launch("rcd_tiles");
+}
+
+} // namespace ansel

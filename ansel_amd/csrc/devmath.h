@@ -1,0 +1,252 @@
+// devmath.h -- single-precision powf / log2f / exp2f / expf that return, bit for bit, what the
+// glibc 2.35 libm of this image returns on x86-64 -- on the GPU.
+//
+// Why not the ROCm device-libs functions: the reference's CPU path gets its transcendentals from
+// libm (filmic: log2f + powf per channel, src/iop/filmicrgb.c:1047-1051, :2124-2146; colour TRCs:
+// powf above white, src/colorprofiles/iop_profile.h:558-562; color calibration: powf,
+// src/iop/channelmixerrgb.c:665, src/pixel/chromatic_adaptation.h:205), their results feed further
+// arithmetic, and the parity bar is 1 ULP at the END of each module.  OCML's powf/log2f are
+// accurate to 1-2 ULP, glibc's to < 0.52 ULP: differences of that size are amplified by the
+// filmic spline and by the 3x3 matrices that follow.  So this header restates glibc's algorithms
+// (ARM optimized-routines, Szabolcs Nagy: table-driven log2 in double, exp2 in double, one final
+// rounding to float) with the same tables (libm_tables.h) and the same polynomial evaluation
+// order.  MI355X runs v_fma_f64 at half the f32 rate, so a powf costs ~25 double operations.
+//
+// Contraction: on x86-64 with FMA+AVX2 (this image's Xeon, the MI355X hosts' EPYCs) glibc
+// dispatches powf/log2f/exp2f/expf to its *_fma builds, in which gcc contracts every `a * b + c`
+// of the source into one fused operation.  The fma() calls below are exactly those.  (The two
+// variants differ in the last bit of the float result about once in 10^8 calls.)
+//
+// tests/test_devmath.py: host build of this header vs libm on 10^8 arguments (bit-exact), and
+// on the GPU box the device build vs the host's libm on the same arguments.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include "libm_tables.h"
+
+#if defined(__HIPCC__)
+#define ANSEL_HD __host__ __device__ __forceinline__
+#else
+#define ANSEL_HD static inline
+#endif
+
+namespace ansel_math
+{
+
+#if defined(__HIP_DEVICE_COMPILE__)
+ANSEL_LIBM_TABLES(static __device__ const)
+#else
+ANSEL_LIBM_TABLES(static const)
+#endif
+
+ANSEL_HD uint32_t asuint(const float f)
+{
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  return u;
+}
+ANSEL_HD float asfloat(const uint32_t u)
+{
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+ANSEL_HD uint64_t asuint64(const double f)
+{
+  uint64_t u;
+  __builtin_memcpy(&u, &f, 8);
+  return u;
+}
+ANSEL_HD double asdouble(const uint64_t u)
+{
+  double f;
+  __builtin_memcpy(&f, &u, 8);
+  return f;
+}
+
+// ---- log2f: sysdeps/ieee754/flt-32/e_log2f.c ------------------------------------------
+ANSEL_HD float log2f_exact(const float x)
+{
+  uint32_t ix = asuint(x);
+  if(ix == 0x3f800000u) return 0.0f;
+  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u)
+  {
+    if(ix * 2 == 0) return -INFINITY;                              // log2(+-0) = -inf
+    if(ix == 0x7f800000u) return x;                                // log2(inf) = inf
+    if((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return NAN;    // x < 0 or NaN
+    ix = asuint(x * 0x1p23f);                                      // subnormal: normalise
+    ix -= 23u << 23;
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (tmp >> (23 - 4)) % 16;
+  const uint32_t top = tmp & 0xff800000u;
+  const uint32_t iz = ix - top;
+  const int k = (int32_t)tmp >> 23;
+  const double invc = k_log2f_tab[2 * i], logc = k_log2f_tab[2 * i + 1];
+  const double z = (double)asfloat(iz);
+  const double r = fma(z, invc, -1.0);
+  const double y0 = logc + (double)k;
+  const double r2 = r * r;
+  double y = fma(k_log2f_poly[1], r, k_log2f_poly[2]);
+  y = fma(k_log2f_poly[0], r2, y);
+  const double p = fma(k_log2f_poly[3], r, y0);
+  y = fma(y, r2, p);
+  return (float)y;
+}
+
+// ---- exp2 of a double argument, rounded to float: exp2_inline() of e_powf.c -------------
+ANSEL_HD float exp2_from_double(const double xd, const uint32_t sign_bias)
+{
+  double kd = xd + k_exp2f_shift_scaled;
+  const uint64_t ki = asuint64(kd);
+  kd -= k_exp2f_shift_scaled;
+  const double r = xd - kd;
+  uint64_t t = k_exp2f_tab[ki % 32];
+  const uint64_t ski = ki + sign_bias;
+  t += ski << (52 - 5);
+  const double s = asdouble(t);
+  const double z = fma(k_exp2f_poly[0], r, k_exp2f_poly[1]);
+  const double r2 = r * r;
+  double y = fma(k_exp2f_poly[2], r, 1.0);
+  y = fma(z, r2, y);
+  y = y * s;
+  return (float)y;
+}
+
+// checkint() of e_powf.c: 0 = not an integer, 1 = odd integer, 2 = even integer
+ANSEL_HD int powf_checkint(const uint32_t iy)
+{
+  const int e = iy >> 23 & 0xff;
+  if(e < 0x7f) return 0;
+  if(e > 0x7f + 23) return 2;
+  if(iy & ((1u << (0x7f + 23 - e)) - 1)) return 0;
+  if(iy & (1u << (0x7f + 23 - e))) return 1;
+  return 2;
+}
+
+ANSEL_HD bool powf_zeroinfnan(const uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000u - 1; }
+
+// ---- powf: sysdeps/ieee754/flt-32/e_powf.c ------------------------------------------------
+ANSEL_HD float powf_exact(const float x, const float y)
+{
+  uint32_t sign_bias = 0;
+  uint32_t ix = asuint(x);
+  const uint32_t iy = asuint(y);
+  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy))
+  {
+    if(powf_zeroinfnan(iy))
+    {
+      if(2 * iy == 0) return 1.0f;
+      if(ix == 0x3f800000u) return 1.0f;
+      if(2 * ix > 2u * 0x7f800000u || 2 * iy > 2u * 0x7f800000u) return x + y;
+      if(2 * ix == 2 * 0x3f800000u) return 1.0f;
+      if((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;
+      return y * y;
+    }
+    if(powf_zeroinfnan(ix))
+    {
+      float x2 = x * x;
+      if((ix & 0x80000000u) && powf_checkint(iy) == 1)
+      {
+        x2 = -x2;
+        sign_bias = 1;
+      }
+      if(2 * ix == 0 && (iy & 0x80000000u)) return sign_bias ? -INFINITY : INFINITY;
+      return (iy & 0x80000000u) ? 1 / x2 : x2;
+    }
+    if(ix & 0x80000000u)
+    {
+      const int yint = powf_checkint(iy);
+      if(yint == 0) return NAN;
+      if(yint == 1) sign_bias = 1u << (5 + 11);
+      ix &= 0x7fffffffu;
+    }
+    if(ix < 0x00800000u)
+    {
+      ix = asuint(x * 0x1p23f);
+      ix &= 0x7fffffffu;
+      ix -= 23u << 23;
+    }
+  }
+  // log2_inline()
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (tmp >> (23 - 4)) % 16;
+  const uint32_t top = tmp & 0xff800000u;
+  const uint32_t iz = ix - top;
+  const int k = (int32_t)top >> 23;
+  const double invc = k_powf_log2_tab[2 * i], logc = k_powf_log2_tab[2 * i + 1];
+  const double z = (double)asfloat(iz);
+  const double r = fma(z, invc, -1.0);
+  const double y0 = logc + (double)k;
+  const double r2 = r * r;
+  double yy = fma(k_powf_log2_poly[0], r, k_powf_log2_poly[1]);
+  const double p = fma(k_powf_log2_poly[2], r, k_powf_log2_poly[3]);
+  const double r4 = r2 * r2;
+  double q = fma(k_powf_log2_poly[4], r, y0);
+  q = fma(p, r2, q);
+  yy = fma(yy, r4, q);
+  const double ylogx = (double)y * yy;
+  if((asuint64(ylogx) >> 47 & 0xffff) >= asuint64(126.0) >> 47)
+  {
+    if(ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -INFINITY : INFINITY; // overflow
+    if(ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;                      // underflow
+  }
+  return exp2_from_double(ylogx, sign_bias);
+}
+
+// ---- exp2f: sysdeps/ieee754/flt-32/e_exp2f.c ----------------------------------------------
+ANSEL_HD float exp2f_exact(const float x)
+{
+  const double xd = (double)x;
+  const uint32_t abstop = (asuint(x) >> 20) & 0x7ff;
+  if(abstop >= (asuint(128.0f) >> 20))
+  {
+    if(asuint(x) == asuint(-INFINITY)) return 0.0f;
+    if(abstop >= (asuint(INFINITY) >> 20)) return x + x;
+    if(x > 0.0f) return INFINITY;
+    if(x <= -150.0f) return 0.0f;
+  }
+  double kd = xd + k_exp2f_shift_scaled;
+  const uint64_t ki = asuint64(kd);
+  kd -= k_exp2f_shift_scaled;
+  const double r = xd - kd;
+  uint64_t t = k_exp2f_tab[ki % 32];
+  t += ki << (52 - 5);
+  const double s = asdouble(t);
+  const double z = fma(k_exp2f_poly[0], r, k_exp2f_poly[1]);
+  const double r2 = r * r;
+  double y = fma(k_exp2f_poly[2], r, 1.0);
+  y = fma(z, r2, y);
+  y = y * s;
+  return (float)y;
+}
+
+// ---- expf: sysdeps/ieee754/flt-32/e_expf.c --------------------------------------------------
+ANSEL_HD float expf_exact(const float x)
+{
+  const double xd = (double)x;
+  const uint32_t abstop = (asuint(x) >> 20) & 0x7ff;
+  if(abstop >= (asuint(88.0f) >> 20))
+  {
+    if(asuint(x) == asuint(-INFINITY)) return 0.0f;
+    if(abstop >= (asuint(INFINITY) >> 20)) return x + x;
+    if(x > 0x1.62e42ep6f) return INFINITY;
+    if(x < -0x1.9fe368p6f) return 0.0f;
+  }
+  const double z = k_exp2f_invln2_scaled * xd;
+  double kd = z + k_exp2f_shift;
+  const uint64_t ki = asuint64(kd);
+  kd -= k_exp2f_shift;
+  const double r = z - kd;
+  uint64_t t = k_exp2f_tab[ki % 32];
+  t += ki << (52 - 5);
+  const double s = asdouble(t);
+  const double zz = fma(k_exp2f_poly_scaled[0], r, k_exp2f_poly_scaled[1]);
+  const double r2 = r * r;
+  double y = fma(k_exp2f_poly_scaled[2], r, 1.0);
+  y = fma(zz, r2, y);
+  y = y * s;
+  return (float)y;
+}
+
+} // namespace ansel_math

@@ -52,6 +52,16 @@ static inline int check_launch(const char *what)
     }                                                                                           \
   } while(0)
 
+// Streaming (non-temporal) 16-byte store: module outputs are written once and read by the next
+// kernel from HBM/L2, never re-read by the writer -- the device analogue of the reference's
+// dt_store_simd_nontemporal() (src/system/simd.h:160-181).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(float4 *p, const float4 v)
+{
+  const v4f_t t = { v.x, v.y, v.z, v.w };
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p));
+}
+
 // Grid for a grid-stride streaming kernel: enough workgroups to fill 256 CUs x 8 and no more
 // (cdna_hip_programming.md Guideline 11).
 static inline unsigned stream_grid(size_t work_items, unsigned block)

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void rawprepare_1f(const in_t *__restrict__ in
       o.y = (v1 - sub1) * inv1;
       o.z = (v2 - sub0) * inv0;
       o.w = (v3 - sub1) * inv1;
-      __builtin_nontemporal_store(o, reinterpret_cast<float4 *>(out + pout));
+      nt_store(reinterpret_cast<float4 *>(out + pout), o);
     }
     else
     {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void temperature_1f(const float *__restrict__ 
       const float4 r = *reinterpret_cast<const float4 *>(in + p);
       float4 o;
       o.x = r.x * c0; o.y = r.y * c1; o.z = r.z * c0; o.w = r.w * c1;
-      __builtin_nontemporal_store(o, reinterpret_cast<float4 *>(out + p));
+      nt_store(reinterpret_cast<float4 *>(out + p), o);
     }
     else
     {
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void temperature_4f(const float4 *__restrict__
     const float4 r = in[k];
     float4 o;
     o.x = r.x * coeffs.x; o.y = r.y * coeffs.y; o.z = r.z * coeffs.z; o.w = r.w;
-    __builtin_nontemporal_store(o, out + k);
+    nt_store(out + k, o);
   }
 }
 
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void highlights_clip_1f(const float *__restric
       o.y = clip < r.y ? clip : r.y;
       o.z = clip < r.z ? clip : r.z;
       o.w = clip < r.w ? clip : r.w;
-      __builtin_nontemporal_store(o, reinterpret_cast<float4 *>(out) + k);
+      nt_store(reinterpret_cast<float4 *>(out) + k, o);
     }
   }
   // tail (n % 4 elements), handled by the first wave of block 0
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void exposure_f4(const float4 *__restrict__ in
     o.y = (r.y - black) * scale;
     o.z = (r.z - black) * scale;
     o.w = (r.w - black) * scale;
-    __builtin_nontemporal_store(o, out + k);
+    nt_store(out + k, o);
   }
 }
 

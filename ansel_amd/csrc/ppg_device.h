@@ -1,0 +1,147 @@
+// ppg_device.h -- per-pixel PPG interpolation, shared by the RCD border ring and the PPG demosaic.
+//
+// Reference: demosaic_ppg(), src/iop/demosaic/ppg.c:20-217 (raw samples) and rcd_ppg_border(),
+// src/iop/demosaic/rcd.c:92-272 (samples clamped with fmaxf(0, .), outer RCD_MARGIN ring only).
+// Both are three in-place passes on the CPU; pass 3 only reads a neighbour's native sample and
+// its green, which are final after passes 1-2, so every output pixel is a pure function of the
+// mosaic.  That is the form used here: one thread = one finished float4, no inter-pass buffer,
+// no second launch.  The 4..8 neighbour greens a pixel needs are recomputed (13 taps each, all
+// L1/L2 hits) instead of being exchanged through HBM.
+#pragma once
+#include "hip_common.h"
+
+namespace ansel
+{
+
+__device__ __forceinline__ int ppg_fc(const int row, const int col, const uint32_t filters)
+{
+  return filters >> ((((row << 1) & 14) + (col & 1)) << 1) & 3;
+}
+
+struct ppg_ctx
+{
+  const float *in;
+  int iw, ih; // input geometry
+  int w, h;   // output geometry
+  int ox, oy; // output window origin inside the input
+  uint32_t filters;
+};
+
+template <bool CLAMP> __device__ __forceinline__ float bs(const ppg_ctx &k, const int j, const int i)
+{
+  const float v = k.in[(size_t)(j + k.oy) * k.iw + i + k.ox];
+  return CLAMP ? fmaxf(0.0f, v) : v;
+}
+__device__ __forceinline__ bool ring_lt(const ppg_ctx &k, const int j, const int i, const int r)
+{
+  return j < r || i < r || j >= k.h - r || i >= k.w - r;
+}
+
+// pass 1: ppg.c:30-57 / rcd.c:96-127 -- per-colour average of the in-bounds 3x3 neighbours
+template <bool CLAMP> __device__ void ppg_pass1(const ppg_ctx &k, const int j, const int i, float rgb[3])
+{
+  float sum[4] = { 0.f, 0.f, 0.f, 0.f }, cnt[4] = { 0.f, 0.f, 0.f, 0.f };
+  for(int y = j - 1; y != j + 2; y++)
+    for(int x = i - 1; x != i + 2; x++)
+    {
+      const int yy = y + k.oy, xx = x + k.ox;
+      if(yy >= 0 && xx >= 0 && yy < k.ih && xx < k.iw)
+      {
+        const int f = ppg_fc(y, x, k.filters);
+        const float v = bs<CLAMP>(k, y, x);
+#pragma unroll
+        for(int c = 0; c < 4; c++)
+          if(c == f)
+          {
+            sum[c] += v;
+            cnt[c] += 1.0f;
+          }
+      }
+    }
+  const int f = ppg_fc(j, i, k.filters);
+  const float self = bs<CLAMP>(k, j, i);
+#pragma unroll
+  for(int c = 0; c < 3; c++) rgb[c] = (c != f && cnt[c] > 0.0f) ? sum[c] / cnt[c] : self;
+}
+
+// pass 2 green at a red/blue site: ppg.c:83-115 / rcd.c:146-187
+template <bool CLAMP> __device__ float ppg_pass2_green(const ppg_ctx &k, const int j, const int i)
+{
+  const float pc = bs<CLAMP>(k, j, i);
+  const float pym = bs<CLAMP>(k, j - 1, i), pym2 = bs<CLAMP>(k, j - 2, i), pym3 = bs<CLAMP>(k, j - 3, i);
+  const float pyM = bs<CLAMP>(k, j + 1, i), pyM2 = bs<CLAMP>(k, j + 2, i), pyM3 = bs<CLAMP>(k, j + 3, i);
+  const float pxm = bs<CLAMP>(k, j, i - 1), pxm2 = bs<CLAMP>(k, j, i - 2), pxm3 = bs<CLAMP>(k, j, i - 3);
+  const float pxM = bs<CLAMP>(k, j, i + 1), pxM2 = bs<CLAMP>(k, j, i + 2), pxM3 = bs<CLAMP>(k, j, i + 3);
+  const float guessx = (pxm + pc + pxM) * 2.0f - pxM2 - pxm2;
+  const float diffx = (fabsf(pxm2 - pc) + fabsf(pxM2 - pc) + fabsf(pxm - pxM)) * 3.0f
+                      + (fabsf(pxM3 - pxM) + fabsf(pxm3 - pxm)) * 2.0f;
+  const float guessy = (pym + pc + pyM) * 2.0f - pyM2 - pym2;
+  const float diffy = (fabsf(pym2 - pc) + fabsf(pyM2 - pc) + fabsf(pym - pyM)) * 3.0f
+                      + (fabsf(pyM3 - pyM) + fabsf(pym3 - pym)) * 2.0f;
+  if(diffx > diffy) return fmaxf(fminf(guessy * .25f, fmaxf(pym, pyM)), fminf(pym, pyM));
+  return fmaxf(fminf(guessx * .25f, fmaxf(pxm, pxM)), fminf(pxm, pxM));
+}
+
+// channel c (native colour or green) of pixel (j,i) after passes 1-2
+template <bool CLAMP> __device__ float ppg_pre3(const ppg_ctx &k, const int j, const int i, const int c)
+{
+  if(ring_lt(k, j, i, 3))
+  {
+    float rgb[3];
+    ppg_pass1<CLAMP>(k, j, i, rgb);
+    return c == 0 ? rgb[0] : (c == 1 ? rgb[1] : rgb[2]);
+  }
+  const int f = ppg_fc(j, i, k.filters);
+  if(c == 1 && !(f & 1)) return ppg_pass2_green<CLAMP>(k, j, i);
+  return bs<CLAMP>(k, j, i);
+}
+
+// the finished pixel (pass 3: ppg.c:130-205 / rcd.c:191-269)
+template <bool CLAMP> __device__ float4 ppg_pixel(const ppg_ctx &k, const int j, const int i)
+{
+  const int c = ppg_fc(j, i, k.filters);
+  float color[3];
+  if(ring_lt(k, j, i, 3))
+    ppg_pass1<CLAMP>(k, j, i, color);
+  else
+  {
+    color[0] = color[2] = 0.0f;
+    const float self = bs<CLAMP>(k, j, i);
+    if(c == 0) color[0] = self;
+    if(c == 2) color[2] = self;
+    color[1] = ppg_pre3<CLAMP>(k, j, i, 1);
+  }
+  if(!ring_lt(k, j, i, 1))
+  {
+    if(c & 1)
+    {
+      const int hcol = (ppg_fc(j, i + 1, k.filters) == 0) ? 0 : 2;
+      const int vcol = 2 - hcol;
+      const float vv = (ppg_pre3<CLAMP>(k, j - 1, i, vcol) + ppg_pre3<CLAMP>(k, j + 1, i, vcol) + 2.0f * color[1]
+                        - ppg_pre3<CLAMP>(k, j - 1, i, 1) - ppg_pre3<CLAMP>(k, j + 1, i, 1)) * .5f;
+      const float hv = (ppg_pre3<CLAMP>(k, j, i - 1, hcol) + ppg_pre3<CLAMP>(k, j, i + 1, hcol) + 2.0f * color[1]
+                        - ppg_pre3<CLAMP>(k, j, i - 1, 1) - ppg_pre3<CLAMP>(k, j, i + 1, 1)) * .5f;
+      color[0] = (hcol == 0) ? hv : vv;
+      color[2] = (hcol == 0) ? vv : hv;
+    }
+    else
+    {
+      const int o = 2 - c;
+      const float tl = ppg_pre3<CLAMP>(k, j - 1, i - 1, o), br = ppg_pre3<CLAMP>(k, j + 1, i + 1, o);
+      const float tr = ppg_pre3<CLAMP>(k, j - 1, i + 1, o), bl = ppg_pre3<CLAMP>(k, j + 1, i - 1, o);
+      const float tlg = ppg_pre3<CLAMP>(k, j - 1, i - 1, 1), brg = ppg_pre3<CLAMP>(k, j + 1, i + 1, 1);
+      const float trg = ppg_pre3<CLAMP>(k, j - 1, i + 1, 1), blg = ppg_pre3<CLAMP>(k, j + 1, i - 1, 1);
+      const float diff1 = fabsf(tl - br) + fabsf(tlg - color[1]) + fabsf(brg - color[1]);
+      const float guess1 = tl + br + 2.0f * color[1] - tlg - brg;
+      const float diff2 = fabsf(tr - bl) + fabsf(trg - color[1]) + fabsf(blg - color[1]);
+      const float guess2 = tr + bl + 2.0f * color[1] - trg - blg;
+      const float v = (diff1 > diff2) ? guess2 * .5f : ((diff1 < diff2) ? guess1 * .5f : (guess1 + guess2) * .25f);
+      if(o == 0) color[0] = v; else color[2] = v;
+    }
+  }
+  // alpha: the reference writes 0 from ring 3 inwards and leaves the caller's buffer alone on the
+  // outer 3 px; a fresh pixelpipe cacheline is what it finds there, so 0 everywhere
+  return make_float4(color[0], color[1], color[2], 0.0f);
+}
+
+} // namespace ansel

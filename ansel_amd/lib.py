@@ -1,0 +1,145 @@
+"""Loader and thin Python face of libansel_hip.so (the C-ABI of include/ansel_hip.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible, calls raise."""
+import ctypes as C
+import os
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libansel_hip.so")
+
+_lib = None
+
+
+class AnselHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libansel_hip.so and declare prototypes.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AnselHipError(
+            "%s not found: build it with `python -m ansel_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i, u, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
+    P = C.POINTER
+    protos = {
+        "dt_hip_init": (i, []),
+        "dt_hip_cleanup": (None, []),
+        "dt_hip_is_inited": (i, []),
+        "dt_hip_get_num_devices": (i, []),
+        "dt_hip_get_device_name": (C.c_char_p, [i]),
+        "dt_hip_get_device_available": (sz, [i]),
+        "dt_hip_get_device_memalloc": (sz, [i]),
+        "dt_hip_lock_device": (i, [i]),
+        "dt_hip_lock_device_by_id": (i, [i]),
+        "dt_hip_unlock_device": (None, [i]),
+        "dt_hip_image_fits_device": (i, [i, sz, sz, C.c_uint, C.c_float, sz]),
+        "dt_hip_get_stream": (vp, [i]),
+        "dt_hip_set_stream": (i, [i, vp]),
+        "dt_hip_alloc_device": (vp, [i, i, i, i]),
+        "dt_hip_alloc_device_buffer": (vp, [i, sz]),
+        "dt_hip_release_mem_object": (None, [vp]),
+        "dt_hip_get_mem_object_size": (sz, [vp]),
+        "dt_hip_memory_statistics": (None, [i, P(sz), P(sz)]),
+        "dt_hip_write_host_to_device": (i, [i, vp, vp, i, i, i]),
+        "dt_hip_write_host_to_device_rowpitch": (i, [i, vp, vp, i, i, i, sz, i]),
+        "dt_hip_read_host_from_device": (i, [i, vp, vp, i, i, i]),
+        "dt_hip_read_host_from_device_rowpitch": (i, [i, vp, vp, i, i, i, sz, i]),
+        "dt_hip_enqueue_copy_buffer_to_buffer": (i, [i, vp, vp, sz, sz, sz]),
+        "dt_hip_enqueue_copy_region": (i, [i, vp, i, i, i, vp, i, i, i, i, i, i]),
+        "dt_hip_finish": (i, [i]),
+        "dt_hip_events_enable": (None, [i, i]),
+        "dt_hip_events_reset": (None, [i]),
+        "dt_hip_events_profiling": (i, [i, P(C.c_char_p), P(C.c_float), P(i), i]),
+        "dt_hip_last_error": (C.c_char_p, []),
+        "dt_hip_abi_sizeof": (sz, [C.c_char_p]),
+        "dt_hip_crop_dcraw_filters": (u, [u, u, u]),
+        "dt_hip_iop_rawprepare_process": (i, [i, P(abi.Piece), P(abi.RawprepareData), vp, vp]),
+        "dt_hip_iop_temperature_process": (i, [i, P(abi.Piece), P(abi.TemperatureData), vp, vp]),
+        "dt_hip_iop_highlights_process": (i, [i, P(abi.Piece), P(abi.HighlightsData), vp, vp]),
+        "dt_hip_iop_demosaic_process": (i, [i, P(abi.Piece), P(abi.DemosaicData), vp, vp]),
+        "dt_hip_iop_demosaic_tiling": (None, [P(abi.Piece), P(abi.DemosaicData), P(abi.Tiling)]),
+        "dt_hip_iop_exposure_process": (i, [i, P(abi.Piece), P(abi.ExposureData), vp, vp]),
+        "dt_hip_iop_colorin_process": (i, [i, P(abi.Piece), P(abi.Conversion), vp, vp]),
+        "dt_hip_iop_colorout_process": (i, [i, P(abi.Piece), P(abi.Conversion), vp, vp]),
+        "dt_hip_iop_channelmixerrgb_process": (i, [i, P(abi.Piece), P(abi.ChannelmixerrgbData), vp, vp]),
+        "dt_hip_iop_filmicrgb_process": (i, [i, P(abi.Piece), P(abi.FilmicrgbData), vp, vp]),
+        "dt_hip_export_convert_u16": (i, [i, i, i, vp, vp]),
+        "dt_hip_export_convert_u8": (i, [i, i, i, vp, vp]),
+    }
+    missing = []
+    for name, (res, args) in protos.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    lib._ansel_missing = missing
+    lib._ansel_protos = protos
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != abi.DT_HIP_SUCCESS:
+        msg = load().dt_hip_last_error()
+        raise AnselHipError("%s failed with %d: %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def init():
+    """dt_hip_init(): raises when no GPU is visible -- the product path fails loudly."""
+    lib = load()
+    if lib._ansel_missing:
+        raise AnselHipError("libansel_hip.so lacks symbols declared in include/ansel_hip.h: %s"
+                            % ", ".join(lib._ansel_missing))
+    check(lib.dt_hip_init(), "dt_hip_init")
+    return lib
+
+
+class DeviceBuffer:
+    """A dt_hip_alloc_device_buffer() allocation with numpy upload/download helpers."""
+
+    def __init__(self, devid, nbytes):
+        self.lib = load()
+        self.devid = devid
+        self.nbytes = int(nbytes)
+        self.ptr = self.lib.dt_hip_alloc_device_buffer(devid, self.nbytes)
+        if not self.ptr:
+            raise AnselHipError("device allocation of %d bytes failed: %s"
+                                % (self.nbytes, self.lib.dt_hip_last_error().decode()))
+
+    @classmethod
+    def from_numpy(cls, devid, arr):
+        import numpy as np
+        arr = np.ascontiguousarray(arr)
+        b = cls(devid, arr.nbytes)
+        check(b.lib.dt_hip_write_host_to_device(devid, arr.ctypes.data_as(C.c_void_p), b.ptr, arr.nbytes, 1, 1),
+              "write_host_to_device")
+        return b
+
+    def to_numpy(self, shape, dtype):
+        import numpy as np
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.lib.dt_hip_read_host_from_device(self.devid, out.ctypes.data_as(C.c_void_p), self.ptr,
+                                                    out.nbytes, 1, 1), "read_host_from_device")
+        return out
+
+    def release(self):
+        if self.ptr:
+            self.lib.dt_hip_release_mem_object(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

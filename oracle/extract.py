@@ -49,10 +49,15 @@ def _scan_chunks(text):
             i += 1
             continue
         # preprocessor line at top level
-        if c == '#' and depth_brace == 0 and depth_paren == 0 and start is None:
+        if c == '#' and depth_brace == 0 and depth_paren == 0:
             # must be first non-blank on the line
             ls = text.rfind('\n', 0, i) + 1
             if text[ls:i].strip() == '':
+                if start is not None:
+                    # a macro invocation without ';' (DT_MODULE_INTROSPECTION(...)) is pending:
+                    # close it here so the directive is seen on its own
+                    chunks.append((start, ls, 'decl'))
+                    start = None
                 j = i
                 while True:
                     e = text.find('\n', j)
