@@ -1,0 +1,35 @@
+// testhooks.hip -- device-side self-test entry points (not part of include/ansel_hip.h).
+#include "hip_common.h"
+#include "devmath.h"
+
+using namespace ansel;
+
+// ---- test hooks: the device build of devmath.h on plain arrays (tests/test_gpu_devmath.py) ----
+namespace
+{
+template <int FN>
+__global__ void devmath_test(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ o, const size_t n)
+{
+  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+  {
+    float r;
+    if(FN == 0) r = ansel_math::powf_exact(x[k], y[k]);
+    else if(FN == 1) r = ansel_math::log2f_exact(x[k]);
+    else if(FN == 2) r = ansel_math::exp2f_exact(x[k]);
+    else r = ansel_math::expf_exact(x[k]);
+    o[k] = r;
+  }
+}
+template <int FN> int devmath_launch(int devid, const void *x, const void *y, void *o, size_t n)
+{
+  if(!valid_device(devid)) return DT_HIP_INVALID_ARG;
+  devmath_test<FN><<<stream_grid(n, 256), 256, 0, stream_of(devid)>>>((const float *)x, (const float *)y, (float *)o, n);
+  return check_launch("devmath_test");
+}
+} // namespace
+extern "C" {
+int dt_hip_test_powf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<0>(devid, x, y, o, n); }
+int dt_hip_test_log2f(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<1>(devid, x, y, o, n); }
+int dt_hip_test_exp2f(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<2>(devid, x, y, o, n); }
+int dt_hip_test_expf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<3>(devid, x, y, o, n); }
+}

@@ -1,0 +1,71 @@
+"""Host-side mirror of the export pixelpipe for the hot path: an ordered list of nodes, each a
+module with its committed `data` and its piece view, executed on one device through the C-ABI --
+what dt_dev_pixelpipe_process_rec() + pixelpipe_process_on_GPU() do in the reference
+(src/develop/pixelpipe_hb.c:881-1282, src/develop/pixelpipe_gpu.c:191-744), reduced to the
+device-resident chain: every module output stays in HBM and is the next module's input.
+
+Buffers are caller-provided device pointers (torch tensors in bench.py, DeviceBuffer in tests).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, lib, params, synth
+
+# bytes per pixel of each module's input / output (algorithmic traffic)
+MODULE_BPP = {
+    "rawprepare": (2, 4), "temperature": (4, 4), "highlights": (4, 4), "demosaic": (4, 16),
+    "exposure": (16, 16), "colorin": (16, 16), "channelmixerrgb": (16, 16), "filmicrgb": (16, 16),
+    "colorout": (16, 16), "export_u16": (16, 8),
+}
+
+
+class Node:
+    def __init__(self, op, data, piece):
+        self.op = op
+        self.data = data
+        self.piece = piece
+
+
+def light_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, with_filmic=True, filmic=None,
+                     demosaic_method=abi.DT_HIP_DEMOSAIC_RCD):
+    """config 2 of BASELINE.json: rawprepare -> temperature -> highlights(clip) -> demosaic ->
+    exposure -> colorin -> color calibration -> filmic -> colorout -> u16, module defaults."""
+    raw = abi.Piece.make(width, height, filters=synth.FILTERS_RGGB, channels=1, datatype=abi.DT_HIP_TYPE_UINT16)
+    cfa1 = abi.Piece.make(width, height, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=(1, 1, 1, 1))
+    cfa2 = abi.Piece.make(width, height, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS)
+    rgb = abi.Piece.make(width, height, channels=4, processed_maximum=synth.WB_COEFFS)
+    rng = float(synth.WHITE - synth.BLACK)
+    nodes = [
+        Node("rawprepare", abi.RawprepareData(0, 0, 0, 0, abi.f4(*[synth.BLACK] * 4), abi.f4(*[rng] * 4)), raw),
+        Node("temperature", abi.TemperatureData(abi.f4(*synth.WB_COEFFS)), cfa1),
+        Node("highlights", abi.HighlightsData(abi.DT_HIP_HIGHLIGHTS_CLIP, 1.0), cfa2),
+        Node("demosaic", abi.DemosaicData(0, 0, demosaic_method, 0.0), cfa2),
+        # exposure +0.7 EV, black -0.000244 (module defaults for scene-referred workflow)
+        Node("exposure", abi.ExposureData(-0.000244140625, float(np.float32(2.0) ** np.float32(0.7))), rgb),
+        Node("colorin", params.conversion(params.WORK_OUT @ params.CAMERA_TO_XYZ), rgb),
+        Node("channelmixerrgb", params.channelmixerrgb(), rgb),
+    ]
+    if with_filmic:
+        nodes.append(Node("filmicrgb", filmic, rgb))
+    lt = [(lut_target_ptr, lut_first, lut_coeffs)] * 3
+    nodes.append(Node("colorout", params.conversion(params.SRGB_OUT @ params.WORK_IN, lut_target=lt), rgb))
+    nodes.append(Node("export_u16", None, rgb))
+    return nodes
+
+
+def algorithmic_bytes_per_pixel(nodes):
+    return sum(sum(MODULE_BPP[n.op]) for n in nodes)
+
+
+def run_nodes(devid, nodes, buffers):
+    """buffers: list of len(nodes)+1 device pointers; node i reads buffers[i], writes buffers[i+1]"""
+    l = lib.load()
+    for i, n in enumerate(nodes):
+        src, dst = buffers[i], buffers[i + 1]
+        if n.op == "export_u16":
+            rc = l.dt_hip_export_convert_u16(devid, n.piece.roi_out.width, n.piece.roi_out.height, src, dst)
+        else:
+            fn = getattr(l, "dt_hip_iop_%s_process" % n.op)
+            rc = fn(devid, C.byref(n.piece), C.byref(n.data), src, dst)
+        lib.check(rc, n.op)

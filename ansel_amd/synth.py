@@ -106,3 +106,12 @@ def adversarial_rgba(width, height, seed=7):
     if height > 6 * h8 + 2 and width > 4:
         img[6 * h8 + 1, width // 2, :3] = 1000.0
     return img
+
+
+def bayer_mosaic_tiled(width, height, seed=1, tile=2048, iso=400.0):
+    """Large mosaics for the benchmark: one seeded tile x tile mosaic repeated to width x height
+    (tile is even, so the CFA phase is preserved).  Seconds instead of minutes at 100 MP."""
+    t = bayer_mosaic(min(tile, width), min(tile, height), seed=seed, iso=iso)
+    ry = -(-height // t.shape[0])
+    rx = -(-width // t.shape[1])
+    return np.ascontiguousarray(np.tile(t, (ry, rx))[:height, :width])

@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- MPix/s of the full-resolution export pixelpipe on MI355X, with the HBM roofline of
+the dominant kernel and the reference's CPU path timed beside it.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the export pipe over one synthetic raw frame: every module of the pipe,
+input mosaic already resident in HBM, output RGBA u16 left in HBM.  Workload (config.workload):
+BASELINE.json's metric is quoted on a 100 MP raw (11648 x 8736 RGGB); the pipe is config 2's
+module list (rawprepare, white balance, highlight clip, RCD demosaic, exposure, colorin,
+color calibration, filmic RGB, colorout, float->u16), all at module defaults.
+
+N > 1: one process per GPU, one frame per GPU (BASELINE.json config 5: batch export shards
+frames across GPUs, no data-path collective) -> "scaling": "weak"; value = N frames / max time.
+
+PyTorch is used for device memory, the stream and torch.distributed only; all pixel work goes
+through the C-ABI of libansel_hip.so (include/ansel_hip.h).  There is no CPU fallback.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", default="100MP", help="24MP | 45MP | 60MP | 100MP | WxH")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="24MP", help="frame size of the bounded CPU sample")
+    return ap.parse_args()
+
+
+def frame_size(name):
+    from ansel_amd import synth
+    if name in synth.SIZES:
+        return synth.SIZES[name]
+    w, h = name.lower().split("x")
+    return int(w), int(h)
+
+
+def build_pipe(width, height, lut_ptr, lut, with_filmic):
+    from ansel_amd import params, pipe
+    filmic = None
+    if with_filmic:
+        from ansel_amd import filmic as fm
+        filmic = fm.default_data()
+    coeffs = params.unbounded_coeffs(lut)
+    return pipe.light_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, with_filmic=with_filmic,
+                                 filmic=filmic)
+
+
+def have_filmic():
+    try:
+        from ansel_amd import filmic  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+def cpu_baseline(size_name, with_filmic):
+    """The reference's own process() code (oracle/_ref/libansel_ref_fast.so: its sources compiled
+    in place with its release flags, OpenMP on every host core) on a bounded sample of the same
+    workload.  Falls back to the C restatement (kind "port", 1 thread) where _ref is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import checkers as ck
+    from ansel_amd import params, pipe, synth
+    w, h = frame_size(size_name)
+    ref = ck.ref(fast=True)
+    kind = "reference" if ref is not None else "port"
+    l = ref if ref is not None else ck.oracle()
+    if l is None:
+        return None
+    prefix = "ref_" if ref is not None else "oracle_"
+    cores = 1
+    if ref is not None:
+        ref.ref_get_num_threads.restype = C.c_int
+        cores = int(ref.ref_get_num_threads())
+    lut = params.srgb_encode_lut()
+    nodes = build_pipe(w, h, lut.ctypes.data, lut, with_filmic)
+    raw = synth.bayer_mosaic_tiled(w, h, seed=1)
+    cfa = [np.empty((h, w), np.float32) for _ in range(2)]
+    rgb = [np.empty((h, w, 4), np.float32) for _ in range(2)]
+    out16 = np.empty((h, w, 4), np.uint16)
+
+    def one_pass():
+        src = raw
+        ci = ri = 0
+        for n in nodes:
+            if n.op == "export_u16":
+                getattr(l, prefix + "export_convert_u16")(w, h, ck.ptr(src), ck.ptr(out16))
+                continue
+            if n.op in ("rawprepare", "temperature", "highlights"):
+                dst = cfa[ci]
+                ci ^= 1
+            else:
+                dst = rgb[ri]
+                ri ^= 1
+            rc = ck.call(l, prefix + n.op, n.piece, n.data, src, dst)
+            assert rc == 0, n.op
+            src = dst
+
+    one_pass()  # warm-up: page in, spin up the OpenMP team
+    times = []
+    t_end = time.time() + 20.0
+    while len(times) < 3 or (time.time() < t_end and len(times) < 8):
+        t0 = time.perf_counter()
+        one_pass()
+        times.append(time.perf_counter() - t0)
+    best = sorted(times)[len(times) // 2]
+    return {"value": round(w * h / 1e6 / best, 3), "unit": "MPix/s", "cores": cores, "kind": kind,
+            "sample": "%d x %d RGGB frame (%s), same module chain, median of %d passes, %.2f s per pass"
+                      % (w, h, size_name, len(times), best)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ansel_amd import lib, params, pipe, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    l = lib.init()
+    devid = local_rank
+    stream = torch.cuda.current_stream(dev)
+    lib.check(l.dt_hip_set_stream(devid, C.c_void_p(stream.cuda_stream)), "dt_hip_set_stream")
+
+    width, height = frame_size(args.size)
+    npix = width * height
+    with_filmic = have_filmic()
+
+    # ---- inputs resident in HBM before the timed region
+    raw_host = synth.bayer_mosaic_tiled(width, height, seed=1 + rank)
+    raw = torch.from_numpy(raw_host.view(np.int16)).to(dev)
+    lut_host = params.srgb_encode_lut()
+    lut = torch.from_numpy(lut_host).to(dev)
+    nodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic)
+    cfa = [torch.empty((height, width), dtype=torch.float32, device=dev) for _ in range(2)]
+    rgb = [torch.empty((height, width, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    out16 = torch.empty((height, width, 4), dtype=torch.int16, device=dev)
+    bufs = [raw.data_ptr()]
+    ci = ri = 0
+    for n in nodes:
+        if n.op == "export_u16":
+            bufs.append(out16.data_ptr())
+        elif n.op in ("rawprepare", "temperature", "highlights"):
+            bufs.append(cfa[ci].data_ptr())
+            ci ^= 1
+        else:
+            bufs.append(rgb[ri].data_ptr())
+            ri ^= 1
+
+    def step():
+        pipe.run_nodes(devid, nodes, bufs)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    l.dt_hip_events_reset(devid)
+    l.dt_hip_events_enable(devid, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    l.dt_hip_events_enable(devid, 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel HIP-event timings of the timed region (recorded on the launch stream)
+    maxk = 64
+    tags = (C.c_char_p * maxk)()
+    ms = (C.c_float * maxk)()
+    cnt = (C.c_int * maxk)()
+    nk = l.dt_hip_events_profiling(devid, tags, ms, cnt, maxk)
+    kernels = {}
+    for i in range(min(nk, maxk)):
+        kernels[tags[i].decode()] = {"ms_avg": ms[i] / max(cnt[i], 1), "launches": cnt[i]}
+
+    if rank == 0:
+        # algorithmic bytes per pixel of each tagged kernel
+        tag_bpp = {"rawprepare_1f": 6, "temperature_1f": 8, "highlights_clip_1f": 8, "rcd_tiles": 20,
+                   "ppg_full": 20, "exposure": 32, "colorin": 32, "channelmixerrgb": 32, "filmicrgb": 32,
+                   "colorout": 32, "export_u16": 24}
+        dominant = max((k for k in kernels if k in tag_bpp), key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])
+        dom = kernels[dominant]
+        dom_bytes = tag_bpp[dominant] * npix
+        achieved = dom_bytes / (dom["ms_avg"] * 1e-3) / 1e9
+        pipe_bpp = pipe.algorithmic_bytes_per_pixel(nodes)
+        ms_per_step = elapsed / args.steps * 1e3
+        kernel_ms = sum(v["ms_avg"] for k, v in kernels.items())
+        line = {
+            "metric": "MPix/s full export pixelpipe (100 MP raw); % MI355X HBM roofline",
+            "value": round(world * npix / 1e6 / (elapsed / args.steps), 2),
+            "unit": "MPix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d x %d RGGB u16 raw (%s), export pipe: %s; module defaults; one frame per GPU"
+                            % (width, height, args.size, " > ".join(n.op for n in nodes)),
+                "frame_mpix": round(npix / 1e6, 2),
+                "pipe_algorithmic_bytes_per_px": pipe_bpp,
+                "pipe_hbm_frac": round(pipe_bpp * npix / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pipe_kernel_ms": round(kernel_ms, 4),
+                "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(kernels.items())},
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dominant,
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.cpu_sample, with_filmic)
+            if cb is not None:
+                line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""-m gpu: RCD and PPG demosaic on the GPU vs the CPU checkers, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import checkers as ck
+import hipcheck as hc
+from ansel_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _normalised_cfa(w, h, seed=3):
+    cfa = synth.bayer_mosaic(w, h, seed=seed).astype(np.float32)
+    out = (cfa - 512.0) / np.float32(synth.WHITE - 512)
+    # white balance, as temperature does upstream
+    rows = np.arange(h)[:, None]
+    cols = np.arange(w)[None, :]
+    wb = np.asarray(synth.WB_COEFFS, dtype=np.float32)[synth.fc(rows, cols)]
+    return (out * wb).astype(np.float32)
+
+
+def _stale_mask(w, h, filters):
+    m = np.zeros((h, w), np.uint8)
+    ck.oracle().oracle_rcd_stale_mask(ck.ptr(m), w, h, C.c_uint32(filters))
+    return m
+
+
+# single tile, partial tile, multi-tile with even and odd last-tile widths, non-RGGB phases
+RCD_SIZES = [(112, 112), (100, 90), (300, 200), (207, 131), (512, 384), (1502, 1002), (2000, 1300)]
+
+
+@pytest.mark.parametrize("w,h", RCD_SIZES)
+@pytest.mark.parametrize("roi_xy", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_rcd(w, h, roi_xy):
+    if roi_xy != (0, 0) and (w, h) not in [(300, 200), (512, 384)]:
+        pytest.skip("CFA phase variants on two sizes only")
+    img = _normalised_cfa(w, h)
+    pm = synth.WB_COEFFS
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=pm,
+                           roi_in=abi.Roi.make(*roi_xy, w, h), roi_out=abi.Roi.make(*roi_xy, w, h))
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.0)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4))
+    exp = hc.run_cpu("oracle", "demosaic", piece, d, img, (h, w, 4))
+    hc.assert_bit_exact(got, exp, "rcd vs oracle")
+    ref = hc.run_cpu("ref", "demosaic", piece, d, img, (h, w, 4))
+    if ref is not None:
+        # the reference reads stale per-thread scratch on <= 3 columns of a partial last tile
+        # column (oracle/src/demosaic_rcd.c header); everywhere else it must agree exactly
+        filters = hc.hip().dt_hip_crop_dcraw_filters(synth.FILTERS_RGGB, roi_xy[0], roi_xy[1])
+        mask = _stale_mask(w, h, filters)
+        hc.assert_bit_exact(got, ref, "rcd vs reference", mask=mask[..., None])
+
+
+@pytest.mark.parametrize("w,h", [(300, 200), (1502, 1002), (65, 40)])
+def test_ppg(w, h):
+    img = _normalised_cfa(w, h)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS)
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4))
+    for which in hc.checkers_available():
+        hc.assert_bit_exact(got, hc.run_cpu(which, "demosaic", piece, d, img, (h, w, 4)), "ppg vs " + which)
+
+
+def test_rcd_negative_and_clipped_input():
+    w, h = 300, 200
+    img = _normalised_cfa(w, h, seed=8)
+    img[50:60, 50:80] = -0.05
+    img[100:110, :] = 3.0
+    img[150, 10:20] = np.nan
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS)
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.0)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4))
+    hc.assert_bit_exact(got, hc.run_cpu("oracle", "demosaic", piece, d, img, (h, w, 4)), "rcd edge input vs oracle")
+
+
+def test_demosaic_rejects_unsupported():
+    from ansel_amd import lib
+    h_ = hc.hip()
+    piece = abi.Piece.make(64, 64, filters=9, channels=1)
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.0)
+    buf = lib.DeviceBuffer(0, 64 * 64 * 16)
+    assert h_.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
+    d2 = abi.DemosaicData(0, 0, 3, 0.0)
+    piece2 = abi.Piece.make(64, 64, filters=synth.FILTERS_RGGB, channels=1)
+    assert h_.dt_hip_iop_demosaic_process(0, C.byref(piece2), C.byref(d2), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
