@@ -178,6 +178,11 @@ __global__ __launch_bounds__(256) void highlights_clip_1f(const float *__restric
   // whole-wave trip count so that __ballot() sees every lane
   const size_t iters = (nvec + stride - 1) / stride;
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // Once 25 clipped photosites are known the exact count is irrelevant (only `count < 25` is
+  // ever tested), so a wave stops touching the journal for good: on a frame with 1 % blown
+  // highlights every wave would otherwise queue on one L2 atomic (measured 3.2 ms at 100 MP
+  // against 0.16 ms for the copy itself).
+  bool settled = false;
   for(size_t it = 0; it < iters; it++, k += stride)
   {
     const bool live = k < nvec;
@@ -185,10 +190,17 @@ __global__ __launch_bounds__(256) void highlights_clip_1f(const float *__restric
     if(live) r = reinterpret_cast<const float4 *>(in)[k];
     const bool o0 = live && r.x > threshold, o1 = live && r.y > threshold;
     const bool o2 = live && r.z > threshold, o3 = live && r.w > threshold;
-    hl_note(journal, o0, 4 * k + 0, r.x);
-    hl_note(journal, o1, 4 * k + 1, r.y);
-    hl_note(journal, o2, 4 * k + 2, r.z);
-    hl_note(journal, o3, 4 * k + 3, r.w);
+    if(!settled && __ballot(o0 | o1 | o2 | o3) != 0ull)
+    {
+      settled = __hip_atomic_load(&journal->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= HL_MIN_CLIPPED;
+      if(!settled)
+      {
+        hl_note(journal, o0, 4 * k + 0, r.x);
+        hl_note(journal, o1, 4 * k + 1, r.y);
+        hl_note(journal, o2, 4 * k + 2, r.z);
+        hl_note(journal, o3, 4 * k + 3, r.w);
+      }
+    }
     if(live)
     {
       float4 o; // MIN(clip, in) == ((clip) < (in) ? (clip) : (in)), highlights/clip.c:73

@@ -128,7 +128,7 @@ int dt_hip_init(void)
     if(hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
     device_t *d = new device_t;
     d->hip_id = i;
-    d->name = prop.name;
+    d->name = prop.name[0] ? prop.name : prop.gcnArchName;
     if(hipSetDevice(i) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess)
     {
       delete d;

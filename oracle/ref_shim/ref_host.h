@@ -42,6 +42,10 @@ extern "C" {
 #define N_(x) (x)
 #endif
 
+/* module registration macro of src/common/module_api.h: the extractor may carry an invocation
+ * along with the declaration that follows it */
+#define DT_MODULE_INTROSPECTION(version, type)
+
 #define dt_control_log(...) ((void)0)
 #define dt_print(...) ((void)0)
 #define dt_iop_fmt_log(...) ((void)0)

@@ -8,3 +8,17 @@ $X $R/colorprofiles/conversion.c $G/conversion.inc dt_colorspaces_conversion_t _
 $X $R/colorprofiles/iop_profile.h $G/iop_profile.inc extrapolate_lut eval_exp dt_ioppr_eval_trc
 $X $R/iop/colorin.c $G/colorin.inc apply_blue_mapping
 $X $R/iop/channelmixerrgb.c $G/channelmixerrgb.inc INVERSE_SQRT_3 dt_iop_channelmixer_rgb_version_t gamut_mapping luma_chroma loop_switch
+$X $R/colorprofiles/iop_profile.h $G/iop_profile_info.inc dt_iop_order_iccprofile_info_t _apply_trc dt_ioppr_get_rgb_matrix_luminance
+$X $R/iop/filmicrgb.c $G/filmicrgb.inc INVERSE_SQRT_3 SAFETY_MARGIN CIE_Y_1931_to_CIE_Y_2006 ORDER_4 ORDER_3 \
+  dt_iop_filmicrgb_methods_type_t dt_iop_filmicrgb_curve_type_t dt_iop_filmicrgb_colorscience_type_t \
+  dt_iop_filmicrgb_spline_version_type_t dt_iop_filmic_noise_distribution_t _filmic_is_agx \
+  dt_iop_filmic_rgb_spline_t dt_iop_filmicrgb_params_t dt_iop_filmicrgb_data_t \
+  dt_iop_filmicrgb_v3_geometry_t dt_iop_filmicrgb_v3_nodes_t filmic_v3_compute_geometry filmic_v3_compute_nodes_from_legacy \
+  pixel_rgb_norm_power_simd get_pixel_norm_simd log_tonemapping exp_tonemapping_v2 filmic_spline \
+  pipe_RGB_to_Ych_simd Ych_to_pipe_RGB_simd filmic_desaturate_v4 clip_chroma_white_raw clip_chroma_white \
+  clip_chroma_black clip_chroma gamut_check_Yrg_filmic_simd gamut_check_RGB_simd gamut_mapping_simd \
+  filmic_v4_prepare_matrices dt_iop_filmicrgb_simd_matrices_t filmic_prepare_simd_matrices \
+  norm_tone_mapping_v4_simd RGB_tone_mapping_v4_simd filmic_chroma_v4 filmic_split_v4 filmic_v5 \
+  _filmic_agx_xyz_D50_to_Yrg _filmic_agx_Yrg_to_xyz_D50 _mat3_identity _filmic_agx_build_displaced \
+  filmic_agx_prepare_bracket filmic_agx_compress_negatives filmic_agx filmic_sigmoid_scale \
+  dt_iop_filmic_rgb_compute_spline

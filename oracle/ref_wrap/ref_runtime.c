@@ -35,6 +35,12 @@ void dt_pixelpipe_cache_free_align_cache(void **mem, const char *message)
   if(mem && *mem) { free(*mem); *mem = NULL; }
 }
 
+/* glib's allocator pair, so that the few g_malloc/g_free sites of the lifted code
+ * (src/math/gaussian_elimination.h) link without libglib */
+void *g_malloc(gsize n) { return n ? malloc(n) : NULL; }
+void *g_malloc0(gsize n) { return n ? calloc(1, n) : NULL; }
+void g_free(void *p) { free(p); }
+
 void ref_set_num_threads(int n)
 {
 #ifdef _OPENMP

@@ -1,0 +1,61 @@
+"""-m gpu: filmic RGB (AgX v8, v7, v6 split/chroma) on the GPU vs the CPU checkers, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import checkers as ck
+import hipcheck as hc
+from ansel_amd import abi, filmic, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1200, 801
+
+
+def _images():
+    return {"scene": synth.rgba_image(W, H, seed=2, lo=-0.02, hi=6.0), "adversarial": synth.adversarial_rgba(W, H)}
+
+
+def _check(d, img):
+    piece = abi.Piece.make(W, H)
+    got = hc.run_hip("dt_hip_iop_filmicrgb_process", piece, d, img, img.shape)
+    for which in hc.checkers_available():
+        hc.assert_bit_exact(got, hc.run_cpu(which, "filmicrgb", piece, d, img, img.shape), "filmicrgb vs " + which)
+
+
+@pytest.mark.parametrize("imgname", ["scene", "adversarial"])
+@pytest.mark.parametrize("version", [3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("curves", [(3, 3), (0, 1), (1, 0), (2, 2)])
+def test_filmic_versions_and_curves(imgname, version, curves):
+    p = filmic.UserParams.defaults(version=version, shadows=curves[0], highlights=curves[1],
+                                   saturation=10.0 if version < 5 else 25.0)
+    _check(filmic.commit(p), _images()[imgname])
+
+
+@pytest.mark.parametrize("preserve_color", [0, 1, 2, 3, 4, 5])
+def test_filmic_v6_norms(preserve_color):
+    p = filmic.UserParams.defaults(version=filmic.V6_2022, preserve_color=preserve_color, saturation=-15.0)
+    _check(filmic.commit(p), _images()["scene"])
+
+
+@pytest.mark.parametrize("use_output_profile", [True, False])
+def test_filmic_output_profile_switch(use_output_profile):
+    p = filmic.UserParams.defaults()
+    _check(filmic.commit(p, use_output_profile=use_output_profile), _images()["scene"])
+
+
+def test_filmic_nondefault_geometry():
+    p = filmic.UserParams.defaults(contrast=1.5, latitude=25.0, balance=12.0, output_power=3.2,
+                                   white_point_source=5.5, black_point_source=-9.2, saturation=-40.0)
+    _check(filmic.commit(p), _images()["scene"])
+
+
+def test_filmic_rejects_legacy_colour_science():
+    from ansel_amd import lib
+    h = hc.hip()
+    d = filmic.commit(filmic.UserParams.defaults())
+    d.version = 1
+    piece = abi.Piece.make(8, 8)
+    buf = lib.DeviceBuffer(0, 8 * 8 * 16)
+    assert h.dt_hip_iop_filmicrgb_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG

@@ -1,0 +1,145 @@
+"""not gpu: the committed C restatement (oracle/liboracle.so) against the reference's own code
+compiled in place (oracle/_ref/libansel_ref.so) -- the parity pin of the oracle.  Runs where
+/root/reference was available at build time; the GPU box only carries the prebuilt _ref."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import checkers as ck
+from ansel_amd import abi, filmic, params, synth
+
+
+def _pair(name, piece, data, inp, shape, dtype=np.float32):
+    r, o = ck.ref(), ck.oracle()
+    a = np.zeros(shape, dtype)
+    b = np.zeros(shape, dtype)
+    assert ck.call(r, "ref_" + name, piece, data, np.ascontiguousarray(inp), a) == 0
+    assert ck.call(o, "oracle_" + name, piece, data, np.ascontiguousarray(inp), b) == 0
+    return a, b
+
+
+def _exact(a, b, what, mask=None):
+    d = ck.ulp_diff(a, b)
+    if mask is not None:
+        d = d * (mask == 0)
+    assert int((d > 0).sum()) == 0, "%s: %d differ, max %d ulp" % (what, int((d > 0).sum()), int(d.max()))
+
+
+@pytest.fixture(autouse=True)
+def _need_ref(ref_lib, oracle_lib):
+    pass
+
+
+@pytest.mark.parametrize("w,h", [(300, 200), (65, 33)])
+def test_glue_modules(w, h):
+    cfa = synth.bayer_mosaic(w + 8, h + 6, seed=4)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, datatype=abi.DT_HIP_TYPE_UINT16,
+                           roi_in=abi.Roi.make(0, 0, w + 8, h + 6), roi_out=abi.Roi.make(0, 0, w, h))
+    d = abi.RawprepareData(3, 1, 5, 5, abi.f4(512, 510, 514, 512), abi.f4(15871, 15873, 15869, 15871))
+    a, b = _pair("rawprepare", piece, d, cfa, (h, w))
+    _exact(a, b, "rawprepare")
+    p2 = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, roi_in=abi.Roi.make(1, 1, w, h),
+                        roi_out=abi.Roi.make(1, 1, w, h), processed_maximum=synth.WB_COEFFS)
+    t = abi.TemperatureData(abi.f4(*synth.WB_COEFFS))
+    a2, b2 = _pair("temperature", p2, t, a, (h, w))
+    _exact(a2, b2, "temperature")
+    for clip in (1.0, 0.2):
+        hd = abi.HighlightsData(0, clip)
+        a3, b3 = _pair("highlights", p2, hd, a2, (h, w))
+        _exact(a3, b3, "highlights")
+    img = synth.adversarial_rgba(w, h)
+    p4 = abi.Piece.make(w, h)
+    a4, b4 = _pair("exposure", p4, abi.ExposureData(-0.0002, 1.7), img, (h, w, 4))
+    _exact(a4, b4, "exposure")
+
+
+@pytest.mark.parametrize("w,h", [(112, 112), (100, 90), (300, 200), (207, 131), (512, 384)])
+@pytest.mark.parametrize("method", [abi.DT_HIP_DEMOSAIC_RCD, abi.DT_HIP_DEMOSAIC_PPG])
+def test_demosaic(w, h, method):
+    cfa = synth.bayer_mosaic(w, h, seed=3).astype(np.float32)
+    img = ((cfa - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS)
+    d = abi.DemosaicData(0, 0, method, 0.0)
+    a, b = _pair("demosaic", piece, d, img, (h, w, 4))
+    mask = None
+    if method == abi.DT_HIP_DEMOSAIC_RCD:
+        m = np.zeros((h, w), np.uint8)
+        ck.oracle().oracle_rcd_stale_mask(ck.ptr(m), w, h, C.c_uint32(synth.FILTERS_RGGB))
+        # only case (b) of oracle/src/demosaic_rcd.c can differ with zeroed scratch: cols W-9..W-7
+        mask = np.zeros((h, w), np.uint8)
+        mask[:, w - 9:w - 6] = m[:, w - 9:w - 6]
+        mask = mask[..., None]
+    _exact(a, b, "demosaic %d" % method, mask)
+
+
+def test_export_convert():
+    w, h = 257, 65
+    img = synth.adversarial_rgba(w, h)
+    img[0, :4, 0] = [np.nan, np.inf, -np.inf, 0.5 / 65535]
+    for kind, dt in (("u16", np.uint16), ("u8", np.uint8)):
+        a = np.zeros((h, w, 4), dt)
+        b = np.zeros((h, w, 4), dt)
+        getattr(ck.ref(), "ref_export_convert_" + kind)(w, h, ck.ptr(img), ck.ptr(a))
+        getattr(ck.oracle(), "oracle_export_convert_" + kind)(w, h, ck.ptr(img), ck.ptr(b))
+        assert np.array_equal(a, b), kind
+
+
+W, H = 400, 301
+
+
+@pytest.mark.parametrize("imgname", ["scene", "adversarial"])
+def test_colour_modules(imgname):
+    img = synth.rgba_image(W, H, seed=2, lo=-0.05, hi=1.6) if imgname == "scene" else synth.adversarial_rgba(W, H)
+    piece = abi.Piece.make(W, H)
+    enc, dec = params.srgb_encode_lut(), params.srgb_decode_lut()
+    ce, cd = params.unbounded_coeffs(enc), params.unbounded_coeffs(dec)
+    lt = [(enc.ctypes.data, float(enc[0]), ce)] * 3
+    ls = [(dec.ctypes.data, float(dec[0]), cd)] * 3
+    cam = params.WORK_OUT @ params.CAMERA_TO_XYZ
+    out = params.SRGB_OUT @ params.WORK_IN
+    for name, d in (("colorin", params.conversion(cam)), ("colorin", params.conversion(cam, blue_mapping=True)),
+                    ("colorout", params.conversion(out, lut_target=lt)),
+                    ("colorout", params.conversion(out, clip_matrix=np.eye(3), lut_source=ls, lut_target=lt))):
+        a, b = _pair(name, piece, d, img, img.shape)
+        _exact(a, b, name)
+    for ad in range(5):
+        for ver in range(3):
+            d = params.channelmixerrgb(adaptation=ad, version=ver, saturation=(0.1, -0.2, 0.05), lightness=(0.05, 0.0, -0.1))
+            a, b = _pair("channelmixerrgb", piece, d, img, img.shape)
+            _exact(a, b, "channelmixerrgb %d %d" % (ad, ver))
+    d = params.channelmixerrgb(grey=(0.3, 0.5, 0.2), clip=False, gamut=2.0)
+    a, b = _pair("channelmixerrgb", piece, d, img, img.shape)
+    _exact(a, b, "channelmixerrgb grey")
+
+
+@pytest.mark.parametrize("version", [3, 4, 5, 7, 9])
+@pytest.mark.parametrize("curves", [(3, 3), (0, 1), (2, 2)])
+def test_filmic(version, curves):
+    img = synth.rgba_image(W, H, seed=2, lo=-0.02, hi=6.0)
+    piece = abi.Piece.make(W, H)
+    for pc in ((0, 1, 2, 3, 4, 5) if version == 3 else (1,)):
+        p = filmic.UserParams.defaults(version=version, shadows=curves[0], highlights=curves[1], preserve_color=pc,
+                                       saturation=10.0 if version < 5 else 25.0)
+        d = filmic.commit(p)
+        a, b = _pair("filmicrgb", piece, d, img, img.shape)
+        _exact(a, b, "filmic v%d" % version)
+    a, b = _pair("filmicrgb", piece, filmic.commit(filmic.UserParams.defaults(version=version), use_output_profile=False),
+                 synth.adversarial_rgba(W, H), img.shape)
+    _exact(a, b, "filmic adversarial, no export profile")
+
+
+def test_filmic_commit_matches_reference_solver():
+    """ansel_amd.filmic.commit() == commit_params() + dt_iop_filmic_rgb_compute_spline(), byte for byte"""
+    r = ck.ref()
+    for ver in (3, 4, 7):
+        for sh in range(4):
+            for hl in range(4):
+                for extra in ({}, {"contrast": 1.5, "latitude": 25.0, "balance": 12.0, "output_power": 3.2,
+                                   "white_point_source": 5.5, "black_point_source": -9.2},
+                              {"custom_grey": 1, "grey_point_source": 12.0, "grey_point_target": 20.0, "balance": -20.0}):
+                    p = filmic.UserParams.defaults(version=ver, shadows=sh, highlights=hl, saturation=25.0, **extra)
+                    d = abi.FilmicrgbData()
+                    r.ref_filmicrgb_commit(C.byref(p), C.byref(d))
+                    filmic.set_profiles(d)
+                    assert bytes(d) == bytes(filmic.commit(p)), (ver, sh, hl, extra)
