@@ -609,3 +609,24 @@ int oracle_filmicrgb(const dt_hip_piece_t *piece, const dt_hip_filmicrgb_data_t 
   }
   return 0;
 }
+
+/* ---- known-answer hooks: the helpers the reference's only hot-path unit test exercises
+ * (tests/unittests/iop/test_filmicrgb.c:89-320), exported so tests/test_filmic_kat.py can run the
+ * same closed-form expectations against this restatement ---------------------------------------- */
+float oracle_kat_clamp_simd(const float x) { return clamp_simd(x); }
+
+float oracle_kat_pixel_norm(const float px[4], const int variant)
+{
+  prep_t p;
+  memset(&p, 0, sizeof(p));
+  p.luma[0] = 0.2225045f; /* the no-profile fallback of get_pixel_norm_simd(), filmicrgb.c:1033 */
+  p.luma[1] = 0.7168786f;
+  p.luma[2] = 0.0606169f;
+  const v4 v = { { px[0], px[1], px[2], px[3] } };
+  return pixel_norm(v, variant, &p);
+}
+
+float oracle_kat_log_tonemapping(const float x, const float grey, const float black, const float dynamic_range)
+{
+  return log_tonemapping(x, grey, black, dynamic_range);
+}

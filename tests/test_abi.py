@@ -1,0 +1,71 @@
+"""not gpu: the C-ABI library loads, exports every symbol include/ansel_hip.h declares, its struct
+layouts match the ctypes mirror, and the product path fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from ansel_amd import abi, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ansel_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dt_hip_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    l = lib.load()
+    missing = [s for s in _declared_symbols() if not hasattr(l, s)]
+    assert not missing, missing
+    assert not l._ansel_missing, l._ansel_missing
+
+
+def test_ctypes_mirror_covers_the_header():
+    declared = set(_declared_symbols())
+    mirrored = set(lib.load()._ansel_protos)
+    assert declared <= mirrored | {"dt_hip_abi_sizeof"}, sorted(declared - mirrored)
+
+
+@pytest.mark.parametrize("name,ctype", [
+    ("roi", abi.Roi), ("piece", abi.Piece), ("tiling", abi.Tiling), ("rawprepare", abi.RawprepareData),
+    ("temperature", abi.TemperatureData), ("highlights", abi.HighlightsData), ("demosaic", abi.DemosaicData),
+    ("exposure", abi.ExposureData), ("conversion", abi.Conversion), ("channelmixerrgb", abi.ChannelmixerrgbData),
+    ("filmic_spline", abi.FilmicSpline), ("filmicrgb", abi.FilmicrgbData)])
+def test_struct_sizes_match_the_compiled_library(name, ctype):
+    l = lib.load()
+    assert l.dt_hip_abi_sizeof(name.encode()) == C.sizeof(ctype), name
+
+
+def test_no_cpu_fallback():
+    """without a GPU the product refuses to run instead of computing on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(lib.AnselHipError):
+        lib.init()
+    l = lib.load()
+    piece = abi.Piece.make(8, 8)
+    d = abi.ExposureData(0.0, 1.0)
+    buf = (C.c_float * 256)()
+    rc = l.dt_hip_iop_exposure_process(0, C.byref(piece), C.byref(d), C.addressof(buf), C.addressof(buf))
+    assert rc != abi.DT_HIP_SUCCESS
+
+
+def test_product_does_not_touch_the_oracle():
+    """nothing under ansel_amd/ or include/ may import, link or name the oracle"""
+    bad = []
+    for base in ("ansel_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            if "_obj" in dp or "__pycache__" in dp:
+                continue
+            for f in files:
+                if f.endswith((".so", ".o", ".pyc")):
+                    continue
+                text = open(os.path.join(dp, f), errors="replace").read()
+                if re.search(r"liboracle|libansel_ref|import\s+checkers|oracle_\w+\s*\(|ref_\w+process", text):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
