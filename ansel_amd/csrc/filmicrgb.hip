@@ -16,425 +16,19 @@
 //
 // The per-call matrix preparation the reference does at the top of each of these functions runs
 // on the host here (filmic_prepare below), in the same binary32 operation order.
-#include "hip_common.h"
-#include "devmath.h"
-#include <float.h>
+#include "px_filmicrgb.h"
 
 using namespace ansel;
 
 namespace
 {
 
-#define CIE_Y_1931_to_CIE_Y_2006(x) (1.05785528f * (x))
-#define INVERSE_SQRT_3 0.5773502691896258f
-
-struct m3
-{
-  float r[3][3];
-};
-
-struct fargs
-{
-  m3 input, output, export_input, export_output, inset, outset;
-  float luma[3];
-  float norm_min, norm_max;
-  float display_black, display_white;
-  float grey_source, black_source, dynamic_range, output_power, saturation, beta_hue;
-  // spline
-  float M1[3], M2[3], M3[3], M4[3], M5[3];
-  float latitude_min, latitude_max, y0, y4;
-  int type0, type1;
-  int preserve_color;
-};
-
-struct v4
-{
-  float x, y, z, w;
-};
-
-// dt_mat3x4_mul_vec4 (src/system/simd.h:188-197); lane 3 carries 0*x + 0*y + 0*z
-__device__ __forceinline__ v4 mat3(const m3 &m, const v4 v)
-{
-  v4 o;
-  o.x = m.r[0][0] * v.x;
-  o.y = m.r[1][0] * v.x;
-  o.z = m.r[2][0] * v.x;
-  o.w = 0.0f * v.x;
-  o.x = m.r[0][1] * v.y + o.x;
-  o.y = m.r[1][1] * v.y + o.y;
-  o.z = m.r[2][1] * v.y + o.z;
-  o.w = 0.0f * v.y + o.w;
-  o.x = m.r[0][2] * v.z + o.x;
-  o.y = m.r[1][2] * v.z + o.y;
-  o.z = m.r[2][2] * v.z + o.z;
-  o.w = 0.0f * v.z + o.w;
-  return o;
-}
-
-__device__ __forceinline__ float min_(const float a, const float b) { return a < b ? a : b; }         // glib MIN
-__device__ __forceinline__ float max_(const float a, const float b) { return a > b ? a : b; }         // glib MAX
-__device__ __forceinline__ float clamp_glib(const float x, const float lo, const float hi) { return x > hi ? hi : (x < lo ? lo : x); }
-__device__ __forceinline__ float clampf(const float a, const float mn, const float mx) { return a >= mn ? (a <= mx ? a : mx) : mn; }
-__device__ __forceinline__ float clamp_simd(const float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
-
-// ---- Yrg / Ych: src/common/colorspaces_inline_conversions.h:1033-1074 ----------------------
-__device__ __forceinline__ v4 LMS_to_Yrg(const v4 LMS)
-{
-  const float Y = 0.68990272f * LMS.x + 0.34832189f * LMS.y;
-  const float a = LMS.x + LMS.y + LMS.z;
-  const float inv_a = (a == 0.f) ? 0.f : 1.f / a;
-  const float l = LMS.x * inv_a, m = LMS.y * inv_a, s = LMS.z * inv_a;
-  // LMS_to_gradingRGB_simd(): rows of LMS_D65_to_filmlightRGB_D65
-  float r0 = 1.0877193f * l;
-  float r1 = -0.0877193f * l;
-  r0 = -0.66666667f * m + r0;
-  r1 = 1.66666667f * m + r1;
-  r0 = 0.02061856f * s + r0;
-  r1 = -0.05154639f * s + r1;
-  return { Y, r0, r1, 0.f };
-}
-
-__device__ __forceinline__ v4 Yrg_to_LMS(const float Y, const float r, const float g)
-{
-  const float b = 1.f - r - g;
-  // gradingRGB_to_LMS_simd(): rows of filmlightRGB_D65_to_LMS_D65
-  float l0 = 0.95f * r;
-  float l1 = 0.05f * r;
-  float l2 = 0.00f * r;
-  l0 = 0.38f * g + l0;
-  l1 = 0.62f * g + l1;
-  l2 = 0.00f * g + l2;
-  l0 = 0.00f * b + l0;
-  l1 = 0.03f * b + l1;
-  l2 = 0.97f * b + l2;
-  const float denom = 0.68990272f * l0 + 0.34832189f * l1;
-  const float a = (denom == 0.f) ? 0.f : Y / denom;
-  return { l0 * a, l1 * a, l2 * a, 0.f };
-}
-
-__device__ __forceinline__ v4 pipe_RGB_to_Ych(const v4 in, const m3 &M)
-{
-  const v4 Yrg = LMS_to_Yrg(mat3(M, in));
-  const float r = Yrg.y - 0.21902143f;
-  const float g = Yrg.z - 0.54371398f;
-  const float c = sqrtf(g * g + r * r); // dt_fast_hypotf(g, r)
-  const float cos_h = c != 0.f ? r / c : 1.f;
-  const float sin_h = c != 0.f ? g / c : 0.f;
-  return { Yrg.x, c, cos_h, sin_h };
-}
-
-__device__ __forceinline__ v4 Ych_to_pipe_RGB(const v4 in, const m3 &M)
-{
-  return mat3(M, Yrg_to_LMS(in.x, in.y * in.z + 0.21902143f, in.y * in.w + 0.54371398f));
-}
-
-// ---- tone curve ------------------------------------------------------------------------------
-__device__ __forceinline__ float log_tonemapping(const float x, const fargs &a)
-{
-  return clamp_simd((ansel_math::log2f_exact(x / a.grey_source) - a.black_source) / a.dynamic_range);
-}
-
-__device__ __forceinline__ float filmic_spline(const float x, const fargs &a)
-{
-  using ansel_math::powf_exact;
-  float result;
-  if(x < a.latitude_min)
-  {
-    if(a.type0 == 3)
-    {
-      if(a.M5[0] != 0.f)
-        result = a.M3[2] + fmaxf(0.f, a.M3[0] * powf_exact(fmaxf(x, 0.f), a.M4[0]));
-      else
-      {
-        const float ty = a.latitude_min * a.M2[2] + a.M1[2];
-        const float u = a.M2[2] * (x - a.latitude_min) / a.M1[0];
-        result = a.M1[0] * (u / powf_exact(1.f + powf_exact(u, a.M2[0]), 1.f / a.M2[0])) + ty;
-      }
-    }
-    else if(a.type0 == 0)
-      result = a.M1[0] + x * (a.M2[0] + x * (a.M3[0] + x * (a.M4[0] + x * a.M5[0])));
-    else if(a.type0 == 1)
-      result = a.M1[0] + x * (a.M2[0] + x * (a.M3[0] + x * a.M4[0]));
-    else
-    {
-      const float xi = a.latitude_min - x;
-      const float rat = xi * (xi * a.M2[0] + 1.f);
-      result = a.M4[0] - a.M1[0] * rat / (rat + a.M3[0]);
-    }
-  }
-  else if(x > a.latitude_max)
-  {
-    if(a.type1 == 3)
-    {
-      if(a.M5[1] != 0.f)
-        result = a.M4[2] - fmaxf(0.f, a.M3[1] * powf_exact(fmaxf(1.f - x, 0.f), a.M4[1]));
-      else
-      {
-        const float ty = a.latitude_max * a.M2[2] + a.M1[2];
-        const float u = a.M2[2] * (x - a.latitude_max) / a.M1[1];
-        result = a.M1[1] * (u / powf_exact(1.f + powf_exact(u, a.M2[1]), 1.f / a.M2[1])) + ty;
-      }
-    }
-    else if(a.type1 == 0)
-      result = a.M1[1] + x * (a.M2[1] + x * (a.M3[1] + x * (a.M4[1] + x * a.M5[1])));
-    else if(a.type1 == 1)
-      result = a.M1[1] + x * (a.M2[1] + x * (a.M3[1] + x * a.M4[1]));
-    else
-    {
-      const float xi = x - a.latitude_max;
-      const float rat = xi * (xi * a.M2[1] + 1.f);
-      result = a.M4[1] + a.M1[1] * rat / (rat + a.M3[1]);
-    }
-  }
-  else
-    result = a.M1[2] + x * a.M2[2];
-  return result;
-}
-
-__device__ __forceinline__ float tone_channel(const float v, const fargs &a, const float lo)
-{
-  const float mapped = log_tonemapping(v, a);
-  return ansel_math::powf_exact(clampf(filmic_spline(mapped, a), lo, a.y4), a.output_power);
-}
-
-__device__ __forceinline__ v4 RGB_tone_mapping_v4(const v4 p, const fargs &a)
-{
-  return { tone_channel(p.x, a, 0.f), tone_channel(p.y, a, 0.f), tone_channel(p.z, a, 0.f), p.w };
-}
-
-__device__ __forceinline__ float pixel_norm(const v4 p, const int variant, const fargs &a)
-{
-  switch(variant)
-  {
-    case 1: return fmaxf(fmaxf(p.x, p.y), p.z);
-    case 3:
-    {
-      float numerator = 0.0f, denominator = 0.0f;
-      const float c[3] = { p.x, p.y, p.z };
-#pragma unroll
-      for(int k = 0; k < 3; k++)
-      {
-        const float value = fabsf(c[k]);
-        const float sq = value * value;
-        numerator += sq * value;
-        denominator += sq;
-      }
-      return numerator / fmaxf(denominator, 1e-12f);
-    }
-    case 4: return sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
-    case 5: return sqrtf(p.x * p.x + p.y * p.y + p.z * p.z) * INVERSE_SQRT_3;
-    default: return a.luma[0] * p.x + a.luma[1] * p.y + a.luma[2] * p.z;
-  }
-}
-
-__device__ __forceinline__ v4 norm_tone_mapping_v4(const v4 p, const int type, const fargs &a)
-{
-  float norm = clampf(pixel_norm(p, type, a), a.norm_min, a.norm_max);
-  const v4 ratios = { p.x / norm, p.y / norm, p.z / norm, p.w / norm };
-  norm = log_tonemapping(norm, a);
-  norm = ansel_math::powf_exact(clampf(filmic_spline(norm, a), a.y0, a.y4), a.output_power);
-  return { ratios.x * norm, ratios.y * norm, ratios.z * norm, ratios.w * norm };
-}
-
-// ---- gamut mapping ----------------------------------------------------------------------------
-__device__ __forceinline__ v4 filmic_desaturate_v4(const v4 Yo, v4 Yf, const float saturation)
-{
-  const float chroma_original = Yo.y * Yo.x;
-  float chroma_final = Yf.y * Yf.x;
-  const float delta_chroma = saturation * (chroma_original - chroma_final);
-  const bool filmic_brightens = (Yf.x > Yo.x);
-  const bool filmic_resat = (chroma_original < chroma_final);
-  const bool filmic_desat = (chroma_original > chroma_final);
-  const bool user_resat = (saturation > 0.f);
-  const bool user_desat = (saturation < 0.f);
-  chroma_final = (filmic_brightens && filmic_resat) ? (chroma_original + chroma_final) / 2.f
-                 : ((user_resat && filmic_desat) || user_desat) ? chroma_final + delta_chroma
-                                                                : chroma_final;
-  Yf.y = fmaxf(chroma_final / Yf.x, 0.f);
-  return Yf;
-}
-
-__device__ __forceinline__ float clip_chroma_white_raw(const float c[3], const float target_white, const float Y,
-                                                       const float cos_h, const float sin_h)
-{
-  const float denominator_Y_coeff = c[0] * (0.979381443298969f * cos_h + 0.391752577319588f * sin_h)
-                                    + c[1] * (0.0206185567010309f * cos_h + 0.608247422680412f * sin_h)
-                                    - c[2] * (cos_h + sin_h);
-  const float denominator_target_term = target_white * (0.68285981628866f * cos_h + 0.482137060515464f * sin_h);
-  if(denominator_Y_coeff == 0.f) return FLT_MAX;
-  const float Y_asymptote = denominator_target_term / denominator_Y_coeff;
-  if(Y <= Y_asymptote) return FLT_MAX;
-  const float denominator = Y * denominator_Y_coeff - denominator_target_term;
-  const float numerator = -0.427506877216495f
-                          * (Y * (c[0] + 0.856492345150334f * c[1] + 0.554995960637719f * c[2])
-                             - 0.988237752433297f * target_white);
-  return numerator / denominator;
-}
-
-__device__ __forceinline__ float clip_chroma_white(const float c[3], const float target_white, const float Y,
-                                                   const float cos_h, const float sin_h)
-{
-  const float eps = 1e-3f;
-  const float max_Y = CIE_Y_1931_to_CIE_Y_2006(target_white);
-  const float delta_Y = max_(max_Y - Y, 0.f);
-  float max_chroma;
-  if(delta_Y < eps)
-    max_chroma = delta_Y / (eps * max_Y) * clip_chroma_white_raw(c, target_white, (1.f - eps) * max_Y, cos_h, sin_h);
-  else
-    max_chroma = clip_chroma_white_raw(c, target_white, Y, cos_h, sin_h);
-  return max_chroma >= 0.f ? max_chroma : FLT_MAX;
-}
-
-__device__ __forceinline__ float clip_chroma_black(const float c[3], const float cos_h, const float sin_h)
-{
-  const float denominator = c[0] * (0.979381443298969f * cos_h + 0.391752577319588f * sin_h)
-                            + c[1] * (0.0206185567010309f * cos_h + 0.608247422680412f * sin_h)
-                            - c[2] * (cos_h + sin_h);
-  if(denominator == 0.f) return FLT_MAX;
-  const float numerator = -0.427506877216495f * (c[0] + 0.856492345150334f * c[1] + 0.554995960637719f * c[2]);
-  const float max_chroma = numerator / denominator;
-  return max_chroma >= 0.f ? max_chroma : FLT_MAX;
-}
-
-__device__ __forceinline__ float clip_chroma(const m3 &mo, const float target_white, const float Y, const float cos_h,
-                                             const float sin_h, const float chroma)
-{
-  const float wr = clip_chroma_white(mo.r[0], target_white, Y, cos_h, sin_h);
-  const float wg = clip_chroma_white(mo.r[1], target_white, Y, cos_h, sin_h);
-  const float wb = clip_chroma_white(mo.r[2], target_white, Y, cos_h, sin_h);
-  const float max_chroma_white = min_(min_(wr, wg), wb);
-  const float br = clip_chroma_black(mo.r[0], cos_h, sin_h);
-  const float bg = clip_chroma_black(mo.r[1], cos_h, sin_h);
-  const float bb = clip_chroma_black(mo.r[2], cos_h, sin_h);
-  const float max_chroma_black = min_(min_(br, bg), bb);
-  return min_(min_(chroma, max_chroma_black), max_chroma_white);
-}
-
-__device__ __forceinline__ v4 gamut_check_Yrg(const v4 Ych)
-{
-  const float Yrg1 = Ych.y * Ych.z + 0.21902143f;
-  const float Yrg2 = Ych.y * Ych.w + 0.54371398f;
-  float max_c = Ych.y;
-  if(Yrg1 < 0.f) max_c = fminf(-0.21902143f / Ych.z, max_c);
-  if(Yrg2 < 0.f) max_c = fminf(-0.54371398f / Ych.w, max_c);
-  if(Yrg1 + Yrg2 > 1.f) max_c = fminf((1.f - 0.21902143f - 0.54371398f) / (Ych.z + Ych.w), max_c);
-  return { Ych.x, max_c, Ych.z, Ych.w };
-}
-
-__device__ __forceinline__ v4 gamut_check_RGB(const m3 &mi, const m3 &mo, const float display_black,
-                                              const float display_white, const v4 Ych_in)
-{
-  v4 b = Ych_to_pipe_RGB(Ych_in, mo);
-  const float min_pix = min_(min_(b.x, b.y), b.z);
-  const float black_offset = max_(-min_pix, 0.f);
-  b = { b.x + black_offset, b.y + black_offset, b.z + black_offset, b.w + black_offset };
-  const v4 Ych_brightened = pipe_RGB_to_Ych(b, mi);
-  const float Y = clamp_glib((Ych_in.x + Ych_brightened.x) / 2.f, CIE_Y_1931_to_CIE_Y_2006(display_black),
-                             CIE_Y_1931_to_CIE_Y_2006(display_white));
-  const float new_chroma = clip_chroma(mo, display_white, Y, Ych_in.z, Ych_in.w, Ych_in.y);
-  v4 o = Ych_to_pipe_RGB({ Y, new_chroma, Ych_in.z, Ych_in.w }, mo);
-  o.x = clamp_glib(o.x, 0.f, display_white);
-  o.y = clamp_glib(o.y, 0.f, display_white);
-  o.z = clamp_glib(o.z, 0.f, display_white);
-  o.w = clamp_glib(o.w, 0.f, display_white);
-  return o;
-}
-
-template <bool EXPORT>
-__device__ __forceinline__ v4 gamut_mapping(v4 Yf, const v4 Yo, const fargs &a, const float saturation)
-{
-  Yf.z = Yo.z;
-  Yf.w = Yo.w;
-  Yf.x = clamp_glib(Yf.x, CIE_Y_1931_to_CIE_Y_2006(a.display_black), CIE_Y_1931_to_CIE_Y_2006(a.display_white));
-  Yf = filmic_desaturate_v4(Yo, Yf, saturation);
-  Yf = gamut_check_Yrg(Yf);
-  if(!EXPORT) return gamut_check_RGB(a.input, a.output, a.display_black, a.display_white, Yf);
-  const v4 pix_out = gamut_check_RGB(a.export_input, a.export_output, a.display_black, a.display_white, Yf);
-  return mat3(a.output, mat3(a.export_input, pix_out));
-}
-
-__device__ __forceinline__ v4 agx_compress_negatives(const v4 p, const float luma[3])
-{
-  const float input_y = p.x * luma[0] + p.y * luma[1] + p.z * luma[2];
-  const float max_rgb = fmaxf(fmaxf(p.x, p.y), p.z);
-  const float min_rgb = fminf(fminf(p.x, p.y), p.z);
-  const float o0 = max_rgb - p.x, o1 = max_rgb - p.y, o2 = max_rgb - p.z;
-  const float opponent_y = o0 * luma[0] + o1 * luma[1] + o2 * luma[2];
-  const float max_opponent = fmaxf(fmaxf(o0, o1), o2);
-  const float y_compensated = max_opponent - opponent_y + input_y;
-  const float offset = fmaxf(-min_rgb, 0.f);
-  const v4 s = { p.x + offset, p.y + offset, p.z + offset, p.w + offset };
-  const float max_shifted = fmaxf(fmaxf(s.x, s.y), s.z);
-  const float q0 = max_shifted - s.x, q1 = max_shifted - s.y, q2 = max_shifted - s.z;
-  const float max_opponent_shifted = fmaxf(fmaxf(q0, q1), q2);
-  const float y_opponent_shifted = q0 * luma[0] + q1 * luma[1] + q2 * luma[2];
-  float y_new = s.x * luma[0] + s.y * luma[1] + s.z * luma[2];
-  y_new += max_opponent_shifted - y_opponent_shifted;
-  const float ratio = (y_new > y_compensated && y_new > 1e-6f) ? y_compensated / y_new : 1.f;
-  return { s.x * ratio, s.y * ratio, s.z * ratio, s.w * ratio };
-}
-
-enum { MODE_AGX = 0, MODE_V5 = 1, MODE_SPLIT_V4 = 2, MODE_CHROMA_V4 = 3 };
-
 template <int MODE, bool EXPORT>
 __global__ __launch_bounds__(256) void filmic_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                       const size_t npixels, const fargs a)
 {
   for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
-  {
-    const float4 pi = in[k];
-    v4 pix_in = { pi.x, pi.y, pi.z, pi.w };
-    v4 res;
-    if(MODE == MODE_AGX)
-    {
-      pix_in.x = isnan(pix_in.x) ? 0.f : clampf(pix_in.x, -1e6f, 1e6f);
-      pix_in.y = isnan(pix_in.y) ? 0.f : clampf(pix_in.y, -1e6f, 1e6f);
-      pix_in.z = isnan(pix_in.z) ? 0.f : clampf(pix_in.z, -1e6f, 1e6f);
-      const v4 compressed = agx_compress_negatives(pix_in, a.luma);
-      const v4 Yo = pipe_RGB_to_Ych(compressed, a.input);
-      v4 rendering = mat3(a.inset, compressed);
-      rendering = RGB_tone_mapping_v4(rendering, a);
-      const v4 pix_out = mat3(a.outset, rendering);
-      v4 Yf = pipe_RGB_to_Ych(pix_out, a.input);
-      const float chroma_final = fminf(Yo.y, Yf.y);
-      const float r_mix = a.beta_hue * Yo.y * Yo.z + (1.f - a.beta_hue) * chroma_final * Yf.z;
-      const float g_mix = a.beta_hue * Yo.y * Yo.w + (1.f - a.beta_hue) * chroma_final * Yf.w;
-      const float norm_mix = sqrtf(g_mix * g_mix + r_mix * r_mix);
-      v4 Yref = Yo;
-      Yref.z = (norm_mix > 1e-9f) ? r_mix / norm_mix : Yo.z;
-      Yref.w = (norm_mix > 1e-9f) ? g_mix / norm_mix : Yo.w;
-      Yf.y = chroma_final;
-      res = gamut_mapping<EXPORT>(Yf, Yref, a, 0.f);
-    }
-    else if(MODE == MODE_V5)
-    {
-      const v4 naive = RGB_tone_mapping_v4(pix_in, a);
-      const v4 mx = norm_tone_mapping_v4(pix_in, 1, a);
-      const float ws = 0.5f + a.saturation, wn = 0.5f - a.saturation;
-      v4 po = { ws * mx.x, ws * mx.y, ws * mx.z, ws * mx.w };
-      po = { wn * naive.x + po.x, wn * naive.y + po.y, wn * naive.z + po.z, wn * naive.w + po.w };
-      const v4 Yo = pipe_RGB_to_Ych(pix_in, a.input);
-      v4 Yf = pipe_RGB_to_Ych(po, a.input);
-      Yf.y = fminf(Yo.y, Yf.y);
-      res = gamut_mapping<EXPORT>(Yf, Yo, a, 0.f);
-    }
-    else if(MODE == MODE_SPLIT_V4)
-    {
-      const v4 po = RGB_tone_mapping_v4(pix_in, a);
-      const v4 Yo = pipe_RGB_to_Ych(pix_in, a.input);
-      v4 Yf = pipe_RGB_to_Ych(po, a.input);
-      Yf.y = fminf(Yo.y, Yf.y);
-      res = gamut_mapping<EXPORT>(Yf, Yo, a, a.saturation);
-    }
-    else
-    {
-      const v4 po = norm_tone_mapping_v4(pix_in, a.preserve_color, a);
-      const v4 Yo = pipe_RGB_to_Ych(pix_in, a.input);
-      const v4 Yf = pipe_RGB_to_Ych(po, a.input);
-      res = gamut_mapping<EXPORT>(Yf, Yo, a, a.saturation);
-    }
-    nt_store(out + k, make_float4(res.x, res.y, res.z, res.w));
-  }
+    nt_store(out + k, px_filmicrgb<MODE, EXPORT>(in[k], a));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -683,33 +277,49 @@ void launch_m(const bool exp, const unsigned grid, hipStream_t s, const float4 *
 
 } // namespace
 
-extern "C" int dt_hip_iop_filmicrgb_process(int devid, const dt_hip_piece_t *piece, const dt_hip_filmicrgb_data_t *d,
-                                            dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+namespace ansel
 {
-  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
-  if(piece->channels != 4) return DT_HIP_INVALID_ARG;
+int filmicrgb_fill_args(const dt_hip_filmicrgb_data_t *d, fargs &a)
+{
   if(d->version < 3 || d->version > 9)
   {
     set_last_error("filmicrgb: colour science %d (v3/v4/v5, 2019-2021) is not implemented on device", d->version);
     return DT_HIP_INVALID_ARG;
   }
+  filmic_prepare(d, a);
+  a.use_export = d->use_output_profile != 0;
+  if(d->version >= 5)
+    a.mode = MODE_AGX;
+  else if(d->version == 4)
+    a.mode = MODE_V5;
+  else
+    a.mode = d->preserve_color == 0 ? MODE_SPLIT_V4 : MODE_CHROMA_V4;
+  return DT_HIP_SUCCESS;
+}
+} // namespace ansel
+
+extern "C" int dt_hip_iop_filmicrgb_process(int devid, const dt_hip_piece_t *piece, const dt_hip_filmicrgb_data_t *d,
+                                            dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
+  if(piece->channels != 4) return DT_HIP_INVALID_ARG;
+  fargs a;
+  const int err = filmicrgb_fill_args(d, a);
+  if(err != DT_HIP_SUCCESS) return err;
   const size_t np = (size_t)piece->roi_out.width * piece->roi_out.height;
   if(np == 0) return DT_HIP_SUCCESS;
-  fargs a;
-  filmic_prepare(d, a);
   const unsigned grid = stream_grid(np, 256);
   hipStream_t s = stream_of(devid);
   const float4 *in = (const float4 *)dev_in;
   float4 *out = (float4 *)dev_out;
-  const bool exp = d->use_output_profile != 0;
+  const bool exp = a.use_export != 0;
   launch_scope ls(devid, "filmicrgb");
-  if(d->version >= 5)
-    launch_m<MODE_AGX>(exp, grid, s, in, out, np, a);
-  else if(d->version == 4)
-    launch_m<MODE_V5>(exp, grid, s, in, out, np, a);
-  else if(d->preserve_color == 0)
-    launch_m<MODE_SPLIT_V4>(exp, grid, s, in, out, np, a);
-  else
-    launch_m<MODE_CHROMA_V4>(exp, grid, s, in, out, np, a);
+  switch(a.mode)
+  {
+    case MODE_AGX: launch_m<MODE_AGX>(exp, grid, s, in, out, np, a); break;
+    case MODE_V5: launch_m<MODE_V5>(exp, grid, s, in, out, np, a); break;
+    case MODE_SPLIT_V4: launch_m<MODE_SPLIT_V4>(exp, grid, s, in, out, np, a); break;
+    default: launch_m<MODE_CHROMA_V4>(exp, grid, s, in, out, np, a); break;
+  }
   return check_launch("filmicrgb");
 }

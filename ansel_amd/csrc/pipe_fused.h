@@ -1,0 +1,39 @@
+// pipe_fused.h -- launchers of the fused stage groups (pipe_fused.hip), used by the executor (pipe.cpp)
+#pragma once
+#include "hip_common.h"
+
+namespace ansel
+{
+
+// ---- fused CFA group: rawprepare [-> temperature] [-> highlights(clip)] --------------------
+struct raw_group_t
+{
+  dt_hip_piece_t rawprepare_piece;
+  dt_hip_rawprepare_data_t rawprepare;
+  bool has_temperature;
+  dt_hip_piece_t temperature_piece;
+  dt_hip_temperature_data_t temperature;
+  bool has_highlights;
+  dt_hip_piece_t highlights_piece;
+  dt_hip_highlights_data_t highlights;
+};
+int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+bool raw_group_supported(const raw_group_t &g);
+
+// ---- fused RGBA group: any order of exposure, colorin, channelmixerrgb, filmicrgb, colorout,
+//      optionally closed by the float -> u16 conversion ------------------------------------------
+enum rgb_op_t { RGB_OP_EXPOSURE = 0, RGB_OP_COLORIN, RGB_OP_CHANNELMIXER, RGB_OP_FILMIC, RGB_OP_COLOROUT, RGB_OP_END };
+struct rgb_group_t
+{
+  int width, height;
+  int n_ops;
+  int ops[8];
+  dt_hip_exposure_data_t exposure;
+  dt_hip_conversion_t colorin, colorout;
+  dt_hip_channelmixerrgb_data_t channelmixer;
+  dt_hip_filmicrgb_data_t filmic;
+  bool to_u16;
+};
+int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+} // namespace ansel

@@ -1,0 +1,122 @@
+// px_colorspaces.h -- per-pixel body of colorin / colorout (matrix path), shared by the standalone
+// kernels (colorspaces.hip) and the fused pointwise chain (pipe_fused.hip).  See colorspaces.hip for
+// the reference citations.
+#pragma once
+#include "hip_common.h"
+#include "devmath.h"
+
+namespace ansel
+{
+
+struct conv_args
+{
+  float m[3][4];  // rows of the source->target (or source->clip) matrix
+  float cm[3][4]; // rows of the clip->target matrix
+  float cs[3][3]; // source power-law fits {a, b, c} per channel
+  float ct[3][3]; // target
+  const float *ls[3];
+  const float *lt[3];
+  int decode[3], encode[3];
+  int clipping, blue_mapping;
+};
+
+__device__ __forceinline__ float extrapolate_lut(const float *__restrict__ lut, const float v)
+{
+  // iop_profile.h:537-547, lutsize = 0x10000
+  const float a = v * 65535.0f;
+  const float ft = a > 0.0f ? (a < 65535.0f ? a : 65535.0f) : 0.0f; // CLAMPS(v * (lutsize - 1), 0, lutsize - 1)
+  const int t = (int)((ft < 65534.0f) ? ft : 65534.0f);
+  const float f = ft - (float)t;
+  const float l1 = lut[t];
+  const float l2 = lut[t + 1];
+  return l1 * (1.0f - f) + l2 * f;
+}
+
+__device__ __forceinline__ float eval_trc(const float x, const float *__restrict__ lut, const float *coeff)
+{
+  return (x < 1.0f) ? extrapolate_lut(lut, x) : coeff[1] * ansel_math::powf_exact(x * coeff[0], coeff[2]);
+}
+
+// dt_mat3x4_mul_vec4(), src/system/simd.h:188-197, on all four lanes (the 4th matrix column is 0,
+// so lane 3 is 0*x + 0*y + 0*z: a signed zero, or NaN for a non-finite input -- kept as is)
+__device__ __forceinline__ float4 mat3x4(const float x, const float y, const float z, const float m[3][4])
+{
+  float4 o;
+  o.x = m[0][0] * x;
+  o.y = m[1][0] * x;
+  o.z = m[2][0] * x;
+  o.w = 0.0f * x;
+  o.x = m[0][1] * y + o.x;
+  o.y = m[1][1] * y + o.y;
+  o.z = m[2][1] * y + o.z;
+  o.w = 0.0f * y + o.w;
+  o.x = m[0][2] * z + o.x;
+  o.y = m[1][2] * z + o.y;
+  o.z = m[2][2] * z + o.z;
+  o.w = 0.0f * z + o.w;
+  return o;
+}
+
+__device__ __forceinline__ float clamp01(const float v)
+{
+  // CLAMP(v, 0.0f, 1.0f) of glib
+  return v > 1.0f ? 1.0f : (v < 0.0f ? 0.0f : v);
+}
+
+
+// the whole conversion of one pixel; lane 3 of the result is the 0*x + 0*y + 0*z the reference's
+// 4-lane product leaves there
+// (the four switches are compile-time constants at the standalone kernels' call sites and
+// wave-uniform run-time values in the fused chain; forceinline folds the former)
+__device__ __forceinline__ float4 px_conversion(const float4 p, const conv_args &a, const bool DECODE,
+                                                const bool ENCODE, const bool CLIP, const bool HOOK)
+{
+  float s0 = p.x, s1 = p.y, s2 = p.z;
+  if(DECODE)
+  {
+    if(a.decode[0]) s0 = eval_trc(s0, a.ls[0], a.cs[0]);
+    if(a.decode[1]) s1 = eval_trc(s1, a.ls[1], a.cs[1]);
+    if(a.decode[2]) s2 = eval_trc(s2, a.ls[2], a.cs[2]);
+  }
+  if(HOOK)
+  {
+    // apply_blue_mapping(), colorin.c:690-709
+    const float YY = s0 + s1 + s2;
+    if(YY > 0.0f)
+    {
+      const float zz = s2 / YY;
+      const float bound_z = 0.5f, bound_Y = 0.5f, amount = 0.11f;
+      if(zz > bound_z)
+      {
+        // fminf(1.0, YY / bound_Y): double literal, so fminf receives (float)1.0
+        const float t = (zz - bound_z) / (1.0f - bound_z) * fminf(1.0f, YY / bound_Y);
+        s1 += t * amount;
+        s2 -= t * amount;
+      }
+    }
+  }
+  float4 v = mat3x4(s0, s1, s2, a.m);
+  if(CLIP) v = mat3x4(clamp01(v.x), clamp01(v.y), clamp01(v.z), a.cm);
+  if(ENCODE)
+  {
+    if(a.encode[0]) v.x = eval_trc(v.x, a.lt[0], a.ct[0]);
+    if(a.encode[1]) v.y = eval_trc(v.y, a.lt[1], a.ct[1]);
+    if(a.encode[2]) v.z = eval_trc(v.z, a.lt[2], a.ct[2]);
+  }
+  return v;
+}
+
+// run-time dispatch for the fused chain (all flags are wave-uniform)
+__device__ __forceinline__ float4 px_conversion_rt(const float4 p, const conv_args &a)
+{
+  const bool decode = a.decode[0] | a.decode[1] | a.decode[2];
+  const bool encode = a.encode[0] | a.encode[1] | a.encode[2];
+  if(!decode && !a.clipping && !a.blue_mapping)
+    return encode ? px_conversion(p, a, false, true, false, false) : px_conversion(p, a, false, false, false, false);
+  return px_conversion(p, a, decode, encode, a.clipping != 0, a.blue_mapping != 0);
+}
+
+// host: dt_hip_conversion_t -> kernel arguments; returns the template key (decode<<2 | encode<<1 | clip)
+int conversion_fill_args(const dt_hip_conversion_t *d, conv_args &a);
+
+} // namespace ansel

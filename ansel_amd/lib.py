@@ -72,6 +72,12 @@ def load():
         "dt_hip_iop_filmicrgb_process": (i, [i, P(abi.Piece), P(abi.FilmicrgbData), vp, vp]),
         "dt_hip_export_convert_u16": (i, [i, i, i, vp, vp]),
         "dt_hip_export_convert_u8": (i, [i, i, i, vp, vp]),
+        "dt_hip_pipe_new": (vp, [i]),
+        "dt_hip_pipe_free": (None, [vp]),
+        "dt_hip_pipe_add_node": (i, [vp, C.c_char_p, P(abi.Piece), vp, sz]),
+        "dt_hip_pipe_set_fusion": (None, [vp, i]),
+        "dt_hip_pipe_num_groups": (i, [vp]),
+        "dt_hip_pipe_process": (i, [vp, vp, vp]),
     }
     missing = []
     for name, (res, args) in protos.items():

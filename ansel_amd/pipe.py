@@ -58,6 +58,43 @@ def algorithmic_bytes_per_pixel(nodes):
     return sum(sum(MODULE_BPP[n.op]) for n in nodes)
 
 
+class DevicePipe:
+    """dt_hip_pipe_t: the C++ executor of libansel_hip (pipe.cpp) loaded with a node list"""
+
+    def __init__(self, devid, nodes, fusion=True):
+        self.lib = lib.load()
+        self.nodes = nodes  # keeps the ctypes structs alive
+        self.handle = self.lib.dt_hip_pipe_new(devid)
+        if not self.handle:
+            raise lib.AnselHipError("dt_hip_pipe_new failed: %s" % self.lib.dt_hip_last_error().decode())
+        for n in nodes:
+            if n.data is None:
+                rc = self.lib.dt_hip_pipe_add_node(self.handle, n.op.encode(), C.byref(n.piece), None, 0)
+            else:
+                rc = self.lib.dt_hip_pipe_add_node(self.handle, n.op.encode(), C.byref(n.piece),
+                                                   C.cast(C.byref(n.data), C.c_void_p), C.sizeof(n.data))
+            lib.check(rc, "dt_hip_pipe_add_node(%s)" % n.op)
+        self.lib.dt_hip_pipe_set_fusion(self.handle, 1 if fusion else 0)
+
+    @property
+    def num_groups(self):
+        return self.lib.dt_hip_pipe_num_groups(self.handle)
+
+    def process(self, dev_in, dev_out):
+        lib.check(self.lib.dt_hip_pipe_process(self.handle, dev_in, dev_out), "dt_hip_pipe_process")
+
+    def close(self):
+        if self.handle:
+            self.lib.dt_hip_pipe_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def run_nodes(devid, nodes, buffers):
     """buffers: list of len(nodes)+1 device pointers; node i reads buffers[i], writes buffers[i+1]"""
     l = lib.load()

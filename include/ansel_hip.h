@@ -278,6 +278,32 @@ int dt_hip_iop_filmicrgb_process(int devid, const dt_hip_piece_t *piece, const d
 int dt_hip_export_convert_u16(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 int dt_hip_export_convert_u8(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
+/* ---- 3. export-pipe executor ----------------------------------------------------------- */
+/* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)
+ * for an export: an ordered list of module nodes, each with its piece view and committed data,
+ * run on one device from a raw buffer in HBM to the exported buffer in HBM.  Intermediate module
+ * outputs are taken from and returned to the runtime's pool (they are cachelines nobody re-reads
+ * in an export).  With fusion enabled (default) maximal runs of pointwise modules execute as one
+ * kernel each -- rawprepare/temperature/highlights before demosaic; exposure/colorin/
+ * channelmixerrgb/filmicrgb/colorout/export_u16 after -- with results bit-identical to the
+ * module-by-module chain.  `op` is the module's op name ("rawprepare", "temperature",
+ * "highlights", "demosaic", "exposure", "colorin", "channelmixerrgb", "filmicrgb", "colorout") or
+ * "export_u16" (data NULL) for the final float -> u16 of src/imageio/imageio_core.c:729. */
+typedef struct dt_hip_pipe_t dt_hip_pipe_t;
+dt_hip_pipe_t *dt_hip_pipe_new(int devid);
+void dt_hip_pipe_free(dt_hip_pipe_t *pipe);
+int dt_hip_pipe_add_node(dt_hip_pipe_t *pipe, const char *op, const dt_hip_piece_t *piece, const void *data,
+                         size_t data_size);
+void dt_hip_pipe_set_fusion(dt_hip_pipe_t *pipe, int enabled);
+/* number of kernel groups the current node list is executed as (after fusion planning) */
+int dt_hip_pipe_num_groups(dt_hip_pipe_t *pipe);
+int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* layout self-check for language bindings: sizeof() of the struct named `name` as compiled */
+size_t dt_hip_abi_sizeof(const char *name);
+/* dt_rawspeed_crop_dcraw_filters(): shift a dcraw Bayer filter word by a crop origin */
+uint32_t dt_hip_crop_dcraw_filters(uint32_t filters, uint32_t crop_x, uint32_t crop_y);
+
 #ifdef __cplusplus
 }
 #endif

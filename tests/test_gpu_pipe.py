@@ -1,0 +1,125 @@
+"""-m gpu: the export pipe end to end on the GPU -- module-by-module through the per-module C-ABI,
+through the C++ executor (dt_hip_pipe_*) with fusion off and on -- must give the same bytes, and
+those bytes must be what the CPU checkers produce for the same chain."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import checkers as ck
+import hipcheck as hc
+from ansel_amd import abi, filmic, lib, params, pipe, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(w, h, seed=1):
+    hc.hip()
+    raw = synth.bayer_mosaic(w, h, seed=seed)
+    lut = params.srgb_encode_lut()
+    d_lut = lib.DeviceBuffer.from_numpy(0, lut)
+    coeffs = params.unbounded_coeffs(lut)
+    return raw, lut, d_lut, coeffs
+
+
+def _nodes(w, h, lut_ptr, lut, coeffs, **kw):
+    return pipe.light_pipe_nodes(w, h, lut_ptr, float(lut[0]), coeffs, with_filmic=True,
+                                 filmic=filmic.default_data(), **kw)
+
+
+def _run_chain_modulewise(nodes, raw, w, h):
+    sizes = {"rawprepare": 4, "temperature": 4, "highlights": 4, "export_u16": 8}
+    bufs = [lib.DeviceBuffer.from_numpy(0, raw)]
+    for n in nodes:
+        bufs.append(lib.DeviceBuffer(0, w * h * sizes.get(n.op, 16)))
+    pipe.run_nodes(0, nodes, [b.ptr for b in bufs])
+    assert lib.load().dt_hip_finish(0) == 1
+    out = bufs[-1].to_numpy((h, w, 4), np.uint16)
+    for b in bufs:
+        b.release()
+    return out
+
+
+def _run_executor(nodes, raw, w, h, fusion):
+    din = lib.DeviceBuffer.from_numpy(0, raw)
+    dout = lib.DeviceBuffer(0, w * h * 8)
+    p = pipe.DevicePipe(0, nodes, fusion=fusion)
+    groups = p.num_groups
+    p.process(din.ptr, dout.ptr)
+    assert lib.load().dt_hip_finish(0) == 1
+    out = dout.to_numpy((h, w, 4), np.uint16)
+    p.close()
+    din.release()
+    dout.release()
+    return out, groups
+
+
+def _run_cpu(which, nodes, raw, w, h):
+    l = ck.ref() if which == "ref" else ck.oracle()
+    prefix = "ref_" if which == "ref" else "oracle_"
+    src = raw
+    for n in nodes:
+        if n.op == "export_u16":
+            out = np.zeros((h, w, 4), np.uint16)
+            getattr(l, prefix + "export_convert_u16")(w, h, ck.ptr(src), ck.ptr(out))
+            return out
+        dst = np.zeros((h, w) if n.op in ("rawprepare", "temperature", "highlights") else (h, w, 4), np.float32)
+        assert ck.call(l, prefix + n.op, n.piece, n.data, np.ascontiguousarray(src), dst) == 0, n.op
+        src = dst
+
+
+@pytest.mark.parametrize("w,h", [(1504, 1000), (400, 300)])
+def test_fused_pipe_equals_modulewise_and_cpu(w, h):
+    raw, lut, d_lut, coeffs = _setup(w, h)
+    dev_nodes = _nodes(w, h, d_lut.ptr, lut, coeffs)
+    modulewise = _run_chain_modulewise(dev_nodes, raw, w, h)
+    unfused, g0 = _run_executor(dev_nodes, raw, w, h, fusion=False)
+    fused, g1 = _run_executor(dev_nodes, raw, w, h, fusion=True)
+    assert g0 == len(dev_nodes) and g1 == 3, (g0, g1)  # raw chain, demosaic, rgb chain
+    assert np.array_equal(modulewise, unfused)
+    assert np.array_equal(modulewise, fused)
+    host_nodes = _nodes(w, h, lut.ctypes.data, lut, coeffs)
+    mask = np.zeros((h, w), np.uint8)
+    ck.oracle().oracle_rcd_stale_mask(ck.ptr(mask), w, h, C.c_uint32(synth.FILTERS_RGGB))
+    stale = np.zeros((h, w), bool)
+    stale[:, w - 9:w - 6] = mask[:, w - 9:w - 6] != 0
+    for which in hc.checkers_available():
+        cpu = _run_cpu(which, host_nodes, raw, w, h)
+        diff = (cpu != fused).any(axis=-1)
+        if which == "ref":
+            diff &= ~stale  # reference reads stale scratch on <= 3 columns
+        assert not diff.any(), "%s: %d pixels differ" % (which, int(diff.sum()))
+
+
+def test_executor_falls_back_to_single_launches_for_unfusable_geometry():
+    """width not a multiple of 4: the CFA group is not fusable; results must still be exact"""
+    w, h = 402, 301
+    raw, lut, d_lut, coeffs = _setup(w, h, seed=5)
+    nodes = _nodes(w, h, d_lut.ptr, lut, coeffs)
+    modulewise = _run_chain_modulewise(nodes, raw, w, h)
+    fused, groups = _run_executor(nodes, raw, w, h, fusion=True)
+    assert groups == 5  # rawprepare, temperature, highlights, demosaic, rgb chain
+    assert np.array_equal(modulewise, fused)
+
+
+def test_executor_bypass_of_highlight_clipping_in_fused_raw_chain():
+    """fewer than 25 clipped photosites: the fused CFA group must copy them through unclipped"""
+    w, h = 400, 300
+    raw, lut, d_lut, coeffs = _setup(w, h, seed=7)
+    raw = np.minimum(raw, 6000).astype(np.uint16)
+    raw[10, 10] = 16383
+    raw[20, 31] = 16383
+    nodes = _nodes(w, h, d_lut.ptr, lut, coeffs)
+    modulewise = _run_chain_modulewise(nodes, raw, w, h)
+    fused, _ = _run_executor(nodes, raw, w, h, fusion=True)
+    assert np.array_equal(modulewise, fused)
+
+
+def test_executor_rejects_unknown_module():
+    l = hc.hip()
+    p = l.dt_hip_pipe_new(0)
+    piece = abi.Piece.make(8, 8)
+    assert l.dt_hip_pipe_add_node(p, b"lens", C.byref(piece), None, 0) == abi.DT_HIP_INVALID_ARG
+    d = abi.ExposureData(0.0, 1.0)
+    assert l.dt_hip_pipe_add_node(p, b"exposure", C.byref(piece), C.cast(C.byref(d), C.c_void_p), 4) == abi.DT_HIP_INVALID_ARG
+    l.dt_hip_pipe_free(p)
