@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void channelmixerrgb(const float4 *__restrict_
                                                         const size_t npixels, const cm_args a)
 {
   for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
-    nt_store(out + k, px_channelmixerrgb<KIND, CLIP>(in[k], a));
+    nt_store(out + k, px_channelmixerrgb<KIND>(in[k], a, CLIP));
 }
 
 template <int KIND>

@@ -231,87 +231,90 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
   const int last_horizontal = tileCols - ((tile_horizontal == a.num_horizontal - 1) ? RCD_MARGIN : RCD_BORDER);
   const int orows = last_vertical - first_vertical, ocols = last_horizontal - first_horizontal;
   if(orows <= 0 || ocols <= 0) return;
-  const int kw = (ocols + 1) >> 1; // sites of one kind per output row, at most
-  const int nsites = orows * kw;
   const float scaler = a.scaler;
 
-  // red / blue sites
-  for(int s = tid; s < nsites; s += NT)
+  // One lane = one horizontally adjacent {red/blue site, green site} pair starting at an even
+  // column: every lane does the same work (one cheap assembly, one step-4.3 evaluation) and a wave
+  // stores 64 x 32 contiguous bytes -- full lines instead of two half-populated passes (the first
+  // version wrote 1.68x the output bytes to HBM, profiles/r01_a_pmc_*).
+  const int pbase = first_horizontal & ~1;
+  const int npairs = ((last_horizontal - pbase) + 1) >> 1;
+  const int nwork = orows * npairs;
+  for(int s = tid; s < nwork; s += NT)
   {
-    const int r = s / kw, k = s - r * kw;
+    const int r = s / npairs, k = s - r * npairs;
     const int row = first_vertical + r;
-    const int p = (row & 1) ? p1 : p0;
-    const int col = first_horizontal + ((first_horizontal & 1) != p) + 2 * k;
-    if(col >= last_horizontal) continue;
-    const int indx = row * TS + col;
-    const int f = fc(row, col, filters); // 0 or 2
-    const float native = scaler * fmaxf(0.0f, cfa[indx]);
-    const float green = scaler * fmaxf(0.0f, g[indx >> 1]);
-    const float other = scaler * fmaxf(0.0f, x[indx >> 1]);
-    float4 o;
-    o.x = (f == 0) ? native : other;
-    o.y = green;
-    o.z = (f == 0) ? other : native;
-    o.w = 0.0f;
-    out[(size_t)(rowStart + row) * a.width + colStart + col] = o;
-  }
-
-  // green sites
-  for(int s = tid; s < nsites; s += NT)
-  {
-    const int r = s / kw, k = s - r * kw;
-    const int row = first_vertical + r;
-    const int p = 1 - ((row & 1) ? p1 : p0);
-    const int col = first_horizontal + ((first_horizontal & 1) != p) + 2 * k;
-    if(col >= last_horizontal) continue;
-    const int indx = row * TS + col;
-    const float VH_Central_Value = vh[indx];
-    const float VH_Neighbourhood_Value = 0.25f * (vh[indx - W1 - 1] + vh[indx - W1 + 1] + vh[indx + W1 - 1] + vh[indx + W1 + 1]);
-    const float VH_Disc = (fabsf(0.5f - VH_Central_Value) < fabsf(0.5f - VH_Neighbourhood_Value)) ? VH_Neighbourhood_Value : VH_Central_Value;
-    const float rgb1 = cfa[indx];
-    const float N1 = (float)((double)EPS + dabs(rgb1 - cfa[indx - W2]));
-    const float S1 = (float)((double)EPS + dabs(rgb1 - cfa[indx + W2]));
-    const float W1g = (float)((double)EPS + dabs(rgb1 - cfa[indx - 2]));
-    const float E1 = (float)((double)EPS + dabs(rgb1 - cfa[indx + 2]));
-    const float rgb1mw1 = g[(indx - W1) >> 1], rgb1pw1 = g[(indx + W1) >> 1];
-    const float rgb1m1 = g[(indx - 1) >> 1], rgb1p1 = g[(indx + 1) >> 1];
-    // the row neighbours carry colour `ch` natively, the column neighbours the other one; the
-    // non-native samples are step 4.2 results (x)
-    const int ch = fc(row, col + 1, filters);
-    float res[2];
-#pragma unroll
-    for(int ci = 0; ci < 2; ci++)
+    const int p = (row & 1) ? p1 : p0;      // column parity of the red/blue sites of this row
+    const int c0 = pbase + 2 * k;
+    const int col_rb = c0 + p, col_g = c0 + 1 - p;
+    const bool ok_rb = col_rb >= first_horizontal && col_rb < last_horizontal;
+    const bool ok_g = col_g >= first_horizontal && col_g < last_horizontal;
+    float4 o_rb = make_float4(0.f, 0.f, 0.f, 0.f), o_g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if(ok_rb)
     {
-      const int c = 2 * ci;
-      const bool hn = (c == ch);
-      const float cN1 = hn ? x[(indx - W1) >> 1] : cfa[indx - W1];
-      const float cS1 = hn ? x[(indx + W1) >> 1] : cfa[indx + W1];
-      const float cN3 = hn ? x[(indx - W3) >> 1] : cfa[indx - W3];
-      const float cS3 = hn ? x[(indx + W3) >> 1] : cfa[indx + W3];
-      const float cW1 = hn ? cfa[indx - 1] : x[(indx - 1) >> 1];
-      const float cE1 = hn ? cfa[indx + 1] : x[(indx + 1) >> 1];
-      const float cW3 = hn ? cfa[indx - 3] : x[(indx - 3) >> 1];
-      const float cE3 = hn ? cfa[indx + 3] : x[(indx + 3) >> 1];
-      const float SNabs = fabsf(cN1 - cS1);
-      const float EWabs = fabsf(cW1 - cE1);
-      const float N_Grad = (float)((double)(N1 + SNabs) + dabs(cN1 - cN3));
-      const float S_Grad = (float)((double)(S1 + SNabs) + dabs(cS1 - cS3));
-      const float W_Grad = (float)((double)(W1g + EWabs) + dabs(cW1 - cW3));
-      const float E_Grad = (float)((double)(E1 + EWabs) + dabs(cE1 - cE3));
-      const float N_Est = cN1 - rgb1mw1;
-      const float S_Est = cS1 - rgb1pw1;
-      const float W_Est = cW1 - rgb1m1;
-      const float E_Est = cE1 - rgb1p1;
-      const float V_Est = (N_Grad * S_Est + S_Grad * N_Est) / (N_Grad + S_Grad);
-      const float H_Est = (E_Grad * W_Est + W_Grad * E_Est) / (E_Grad + W_Grad);
-      res[ci] = rgb1 + intp(VH_Disc, H_Est, V_Est);
+      const int indx = row * TS + col_rb;
+      const int f = fc(row, col_rb, filters); // 0 or 2
+      const float native = scaler * fmaxf(0.0f, cfa[indx]);
+      const float green = scaler * fmaxf(0.0f, g[indx >> 1]);
+      const float other = scaler * fmaxf(0.0f, x[indx >> 1]);
+      o_rb.x = (f == 0) ? native : other;
+      o_rb.y = green;
+      o_rb.z = (f == 0) ? other : native;
     }
-    float4 o;
-    o.x = scaler * fmaxf(0.0f, res[0]);
-    o.y = scaler * fmaxf(0.0f, rgb1);
-    o.z = scaler * fmaxf(0.0f, res[1]);
-    o.w = 0.0f;
-    out[(size_t)(rowStart + row) * a.width + colStart + col] = o;
+    if(ok_g)
+    {
+      // step 4.3 (rcd.c:499-536) at this green site
+      const int indx = row * TS + col_g;
+      const float VH_Central_Value = vh[indx];
+      const float VH_Neighbourhood_Value = 0.25f * (vh[indx - W1 - 1] + vh[indx - W1 + 1] + vh[indx + W1 - 1] + vh[indx + W1 + 1]);
+      const float VH_Disc = (fabsf(0.5f - VH_Central_Value) < fabsf(0.5f - VH_Neighbourhood_Value)) ? VH_Neighbourhood_Value : VH_Central_Value;
+      const float rgb1 = cfa[indx];
+      const float N1 = (float)((double)EPS + dabs(rgb1 - cfa[indx - W2]));
+      const float S1 = (float)((double)EPS + dabs(rgb1 - cfa[indx + W2]));
+      const float W1g = (float)((double)EPS + dabs(rgb1 - cfa[indx - 2]));
+      const float E1 = (float)((double)EPS + dabs(rgb1 - cfa[indx + 2]));
+      const float rgb1mw1 = g[(indx - W1) >> 1], rgb1pw1 = g[(indx + W1) >> 1];
+      const float rgb1m1 = g[(indx - 1) >> 1], rgb1p1 = g[(indx + 1) >> 1];
+      // the row neighbours carry colour `ch` natively, the column neighbours the other one; the
+      // non-native samples are step 4.2 results (x)
+      const int ch = fc(row, col_g + 1, filters);
+      float res[2];
+#pragma unroll
+      for(int ci = 0; ci < 2; ci++)
+      {
+        const int c = 2 * ci;
+        const bool hn = (c == ch);
+        const float cN1 = hn ? x[(indx - W1) >> 1] : cfa[indx - W1];
+        const float cS1 = hn ? x[(indx + W1) >> 1] : cfa[indx + W1];
+        const float cN3 = hn ? x[(indx - W3) >> 1] : cfa[indx - W3];
+        const float cS3 = hn ? x[(indx + W3) >> 1] : cfa[indx + W3];
+        const float cW1 = hn ? cfa[indx - 1] : x[(indx - 1) >> 1];
+        const float cE1 = hn ? cfa[indx + 1] : x[(indx + 1) >> 1];
+        const float cW3 = hn ? cfa[indx - 3] : x[(indx - 3) >> 1];
+        const float cE3 = hn ? cfa[indx + 3] : x[(indx + 3) >> 1];
+        const float SNabs = fabsf(cN1 - cS1);
+        const float EWabs = fabsf(cW1 - cE1);
+        const float N_Grad = (float)((double)(N1 + SNabs) + dabs(cN1 - cN3));
+        const float S_Grad = (float)((double)(S1 + SNabs) + dabs(cS1 - cS3));
+        const float W_Grad = (float)((double)(W1g + EWabs) + dabs(cW1 - cW3));
+        const float E_Grad = (float)((double)(E1 + EWabs) + dabs(cE1 - cE3));
+        const float N_Est = cN1 - rgb1mw1;
+        const float S_Est = cS1 - rgb1pw1;
+        const float W_Est = cW1 - rgb1m1;
+        const float E_Est = cE1 - rgb1p1;
+        const float V_Est = (N_Grad * S_Est + S_Grad * N_Est) / (N_Grad + S_Grad);
+        const float H_Est = (E_Grad * W_Est + W_Grad * E_Est) / (E_Grad + W_Grad);
+        res[ci] = rgb1 + intp(VH_Disc, H_Est, V_Est);
+      }
+      o_g.x = scaler * fmaxf(0.0f, res[0]);
+      o_g.y = scaler * fmaxf(0.0f, rgb1);
+      o_g.z = scaler * fmaxf(0.0f, res[1]);
+    }
+    float4 *dst = out + (size_t)(rowStart + row) * a.width + colStart + c0;
+    const float4 lo = p ? o_g : o_rb, hi = p ? o_rb : o_g; // column c0, column c0 + 1
+    const bool ok_lo = p ? ok_g : ok_rb, ok_hi = p ? ok_rb : ok_g;
+    if(ok_lo) dst[0] = lo;
+    if(ok_hi) dst[1] = hi;
   }
 }
 

@@ -65,18 +65,9 @@ ANSEL_HD double asdouble(const uint64_t u)
 }
 
 // ---- log2f: sysdeps/ieee754/flt-32/e_log2f.c ------------------------------------------
-ANSEL_HD float log2f_exact(const float x)
+// The table-driven core, valid for a positive normal (or pre-normalised) bit pattern ix.
+ANSEL_HD float log2f_core(const uint32_t ix)
 {
-  uint32_t ix = asuint(x);
-  if(ix == 0x3f800000u) return 0.0f;
-  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u)
-  {
-    if(ix * 2 == 0) return -INFINITY;                              // log2(+-0) = -inf
-    if(ix == 0x7f800000u) return x;                                // log2(inf) = inf
-    if((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return NAN;    // x < 0 or NaN
-    ix = asuint(x * 0x1p23f);                                      // subnormal: normalise
-    ix -= 23u << 23;
-  }
   const uint32_t tmp = ix - 0x3f330000u;
   const int i = (tmp >> (23 - 4)) % 16;
   const uint32_t top = tmp & 0xff800000u;
@@ -92,6 +83,24 @@ ANSEL_HD float log2f_exact(const float x)
   const double p = fma(k_log2f_poly[3], r, y0);
   y = fma(y, r2, p);
   return (float)y;
+}
+
+// glibc's control flow folded for a SIMT machine: one predicate separates the positive normal
+// arguments (straight-line code, the only path a wave of image data ever takes) from everything
+// glibc special-cases (zero, negative, inf, NaN, subnormal), which share one cold block.
+ANSEL_HD float log2f_exact(const float x)
+{
+  uint32_t ix = asuint(x);
+  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u)
+  {
+    if(ix * 2 == 0) return -INFINITY;                              // log2(+-0) = -inf
+    if(ix == 0x7f800000u) return x;                                // log2(inf) = inf
+    if((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return NAN;    // x < 0 or NaN
+    ix = asuint(x * 0x1p23f);                                      // subnormal: normalise
+    ix -= 23u << 23;
+  }
+  const float r = log2f_core(ix);
+  return ix == 0x3f800000u ? 0.0f : r;                             // log2(1) is exactly +0
 }
 
 // ---- exp2 of a double argument, rounded to float: exp2_inline() of e_powf.c -------------
@@ -127,48 +136,10 @@ ANSEL_HD int powf_checkint(const uint32_t iy)
 ANSEL_HD bool powf_zeroinfnan(const uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000u - 1; }
 
 // ---- powf: sysdeps/ieee754/flt-32/e_powf.c ------------------------------------------------
-ANSEL_HD float powf_exact(const float x, const float y)
+// log2_inline() + the range checks + exp2_inline() for |x| given as a positive normal (or
+// pre-normalised) bit pattern ix: straight-line code, overflow / underflow handled by selects.
+ANSEL_HD float powf_core(const uint32_t ix, const float y, const uint32_t sign_bias)
 {
-  uint32_t sign_bias = 0;
-  uint32_t ix = asuint(x);
-  const uint32_t iy = asuint(y);
-  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy))
-  {
-    if(powf_zeroinfnan(iy))
-    {
-      if(2 * iy == 0) return 1.0f;
-      if(ix == 0x3f800000u) return 1.0f;
-      if(2 * ix > 2u * 0x7f800000u || 2 * iy > 2u * 0x7f800000u) return x + y;
-      if(2 * ix == 2 * 0x3f800000u) return 1.0f;
-      if((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;
-      return y * y;
-    }
-    if(powf_zeroinfnan(ix))
-    {
-      float x2 = x * x;
-      if((ix & 0x80000000u) && powf_checkint(iy) == 1)
-      {
-        x2 = -x2;
-        sign_bias = 1;
-      }
-      if(2 * ix == 0 && (iy & 0x80000000u)) return sign_bias ? -INFINITY : INFINITY;
-      return (iy & 0x80000000u) ? 1 / x2 : x2;
-    }
-    if(ix & 0x80000000u)
-    {
-      const int yint = powf_checkint(iy);
-      if(yint == 0) return NAN;
-      if(yint == 1) sign_bias = 1u << (5 + 11);
-      ix &= 0x7fffffffu;
-    }
-    if(ix < 0x00800000u)
-    {
-      ix = asuint(x * 0x1p23f);
-      ix &= 0x7fffffffu;
-      ix -= 23u << 23;
-    }
-  }
-  // log2_inline()
   const uint32_t tmp = ix - 0x3f330000u;
   const int i = (tmp >> (23 - 4)) % 16;
   const uint32_t top = tmp & 0xff800000u;
@@ -186,12 +157,68 @@ ANSEL_HD float powf_exact(const float x, const float y)
   q = fma(p, r2, q);
   yy = fma(yy, r4, q);
   const double ylogx = (double)y * yy;
-  if((asuint64(ylogx) >> 47 & 0xffff) >= asuint64(126.0) >> 47)
+  const float res = exp2_from_double(ylogx, sign_bias);
+  // |y * log2(x)| >= 126: overflow above 0x1.fffffffd1d571p+6, underflow at or below -150
+  const bool big = (asuint64(ylogx) >> 47 & 0xffff) >= asuint64(126.0) >> 47;
+  const bool of = big && ylogx > 0x1.fffffffd1d571p+6;
+  const bool uf = big && ylogx <= -150.0;
+  const float inf_s = sign_bias ? -INFINITY : INFINITY;
+  const float zero_s = sign_bias ? -0.0f : 0.0f;
+  return of ? inf_s : (uf ? zero_s : res);
+}
+
+// everything glibc special-cases: x zero / negative / inf / NaN / subnormal, y zero / inf / NaN
+ANSEL_HD float powf_special(const float x, const float y)
+{
+  uint32_t sign_bias = 0;
+  uint32_t ix = asuint(x);
+  const uint32_t iy = asuint(y);
+  if(powf_zeroinfnan(iy))
   {
-    if(ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -INFINITY : INFINITY; // overflow
-    if(ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;                      // underflow
+    if(2 * iy == 0) return 1.0f;
+    if(ix == 0x3f800000u) return 1.0f;
+    if(2 * ix > 2u * 0x7f800000u || 2 * iy > 2u * 0x7f800000u) return x + y;
+    if(2 * ix == 2 * 0x3f800000u) return 1.0f;
+    if((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;
+    return y * y;
   }
-  return exp2_from_double(ylogx, sign_bias);
+  if(powf_zeroinfnan(ix))
+  {
+    float x2 = x * x;
+    if((ix & 0x80000000u) && powf_checkint(iy) == 1)
+    {
+      x2 = -x2;
+      sign_bias = 1;
+    }
+    if(2 * ix == 0 && (iy & 0x80000000u)) return sign_bias ? -INFINITY : INFINITY;
+    return (iy & 0x80000000u) ? 1 / x2 : x2;
+  }
+  if(ix & 0x80000000u)
+  {
+    const int yint = powf_checkint(iy);
+    if(yint == 0) return NAN;
+    if(yint == 1) sign_bias = 1u << (5 + 11);
+    ix &= 0x7fffffffu;
+  }
+  if(ix < 0x00800000u)
+  {
+    ix = asuint(x * 0x1p23f);
+    ix &= 0x7fffffffu;
+    ix -= 23u << 23;
+  }
+  return powf_core(ix, y, sign_bias);
+}
+
+ANSEL_HD float powf_exact(const float x, const float y)
+{
+  const uint32_t ix = asuint(x);
+  const uint32_t iy = asuint(y);
+  // glibc's powf(x, 1.0f) returns x for every one of the 2^32 bit patterns of x (checked
+  // exhaustively against this image's libm; NaNs stay NaN): a uniform-exponent shortcut for the
+  // modules whose default exponent is 1 (color calibration gamut compression)
+  if(iy == 0x3f800000u && x == x) return x;
+  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) return powf_special(x, y);
+  return powf_core(ix, y, 0);
 }
 
 // ---- exp2f: sysdeps/ieee754/flt-32/e_exp2f.c ----------------------------------------------

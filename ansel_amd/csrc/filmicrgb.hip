@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void filmic_kernel(const float4 *__restrict__ 
                                                       const size_t npixels, const fargs a)
 {
   for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
-    nt_store(out + k, px_filmicrgb<MODE, EXPORT>(in[k], a));
+    nt_store(out + k, px_filmicrgb<MODE>(in[k], a, EXPORT));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -257,6 +257,8 @@ void filmic_prepare(const dt_hip_filmicrgb_data_t *d, fargs &a)
     a.M4[k] = d->spline.M4[k];
     a.M5[k] = d->spline.M5[k];
   }
+  a.inv_M2[0] = 1.f / d->spline.M2[0];
+  a.inv_M2[1] = 1.f / d->spline.M2[1];
   a.latitude_min = d->spline.latitude_min;
   a.latitude_max = d->spline.latitude_max;
   a.y0 = d->spline.y[0];

@@ -155,12 +155,15 @@ struct dt_hip_pipe_t
         memset(&r, 0, sizeof(r));
         r.width = nodes[i].piece.roi_out.width;
         r.height = nodes[i].piece.roi_out.height;
-        bool seen[OP_UNKNOWN] = { false };
+        // the fused kernel applies its stages in the reference's pipe order (exposure < colorin <
+        // channelmixerrgb < filmicrgb < colorout, src/develop/iop_order.c); a run is fusable as long
+        // as it walks that order
+        int last_op = -1;
         int j = i;
         while(j < n && r.n_ops < 8)
         {
           const node_t &nd = nodes[j];
-          if(nd.op < OP_EXPOSURE || nd.op > OP_COLOROUT || seen[nd.op]) break;
+          if(nd.op < OP_EXPOSURE || nd.op > OP_COLOROUT || (int)nd.op <= last_op) break;
           if(nd.piece.roi_out.width != r.width || nd.piece.roi_out.height != r.height || nd.piece.channels != 4) break;
           if(nd.op == OP_FILMICRGB)
           {
@@ -168,7 +171,7 @@ struct dt_hip_pipe_t
             if(v < 3 || v > 9) break;
           }
           if(nd.op == OP_CHANNELMIXERRGB && nd.as<dt_hip_channelmixerrgb_data_t>()->adaptation > DT_HIP_ADAPTATION_RGB) break;
-          seen[nd.op] = true;
+          last_op = (int)nd.op;
           switch(nd.op)
           {
             case OP_EXPOSURE: r.ops[r.n_ops++] = RGB_OP_EXPOSURE; r.exposure = *nd.as<dt_hip_exposure_data_t>(); break;

@@ -12,67 +12,12 @@
 // The reference has no equivalent: its pixelpipe materialises every module output as a cacheline
 // (src/develop/pixelpipe_hb.c:985, :1043-1047) because the GUI re-uses them; an export does not.
 #include "pipe_fused.h"
-#include "px_colorspaces.h"
-#include "px_channelmixerrgb.h"
-#include "px_filmicrgb.h"
+#include "rgb_chain_kernel.h"
 
 using namespace ansel;
 
 namespace
 {
-
-// ---------------------------------------------------------------------------------------------
-// RGBA chain
-// ---------------------------------------------------------------------------------------------
-struct chain_args
-{
-  int n_ops;
-  int ops[8];
-  float exp_black, exp_scale;
-  conv_args colorin, colorout;
-  cm_args cm;
-  fargs filmic;
-};
-
-__device__ __forceinline__ float glib_clamp_(const float x, const float lo, const float hi) { return x > hi ? hi : (x < lo ? lo : x); }
-
-template <bool TO_U16>
-__global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, void *__restrict__ out,
-                                                  const size_t npixels, const chain_args a)
-{
-  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
-  {
-    float4 v = in[k];
-    for(int s = 0; s < a.n_ops; s++)
-    {
-      switch(a.ops[s])
-      {
-        case RGB_OP_EXPOSURE:
-          v.x = (v.x - a.exp_black) * a.exp_scale;
-          v.y = (v.y - a.exp_black) * a.exp_scale;
-          v.z = (v.z - a.exp_black) * a.exp_scale;
-          v.w = (v.w - a.exp_black) * a.exp_scale;
-          break;
-        case RGB_OP_COLORIN: v = px_conversion_rt(v, a.colorin); break;
-        case RGB_OP_CHANNELMIXER: v = px_channelmixerrgb_rt(v, a.cm); break;
-        case RGB_OP_FILMIC: v = px_filmicrgb_rt(v, a.filmic); break;
-        case RGB_OP_COLOROUT: v = px_conversion_rt(v, a.colorout); break;
-        default: break;
-      }
-    }
-    if(TO_U16)
-    {
-      ushort4 o; // _export_final_buffer_to_uint16(), src/imageio/imageio_core.c:729-737
-      o.x = (unsigned short)(int)glib_clamp_(roundf(v.x * 65535.f), 0.f, 65535.f);
-      o.y = (unsigned short)(int)glib_clamp_(roundf(v.y * 65535.f), 0.f, 65535.f);
-      o.z = (unsigned short)(int)glib_clamp_(roundf(v.z * 65535.f), 0.f, 65535.f);
-      o.w = (unsigned short)(int)glib_clamp_(roundf(v.w * 65535.f), 0.f, 65535.f);
-      reinterpret_cast<ushort4 *>(out)[k] = o;
-    }
-    else
-      nt_store(reinterpret_cast<float4 *>(out) + k, v);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // CFA chain: rawprepare [-> temperature] [-> highlights clip]
@@ -299,34 +244,55 @@ int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hi
   if(np == 0) return DT_HIP_SUCCESS;
   chain_args a;
   memset(&a, 0, sizeof(a));
-  a.n_ops = g.n_ops;
+  int cm_kind = CM_NONE, fm = FM_NONE;
   for(int i = 0; i < g.n_ops && i < 8; i++)
   {
-    a.ops[i] = g.ops[i];
     switch(g.ops[i])
     {
       case RGB_OP_EXPOSURE:
+        a.has_exposure = 1;
         a.exp_black = g.exposure.black;
         a.exp_scale = g.exposure.scale;
         break;
-      case RGB_OP_COLORIN: conversion_fill_args(&g.colorin, a.colorin); break;
-      case RGB_OP_COLOROUT: conversion_fill_args(&g.colorout, a.colorout); break;
-      case RGB_OP_CHANNELMIXER: channelmixerrgb_fill_args(&g.channelmixer, a.cm); break;
+      case RGB_OP_COLORIN:
+        a.has_colorin = 1;
+        conversion_fill_args(&g.colorin, a.colorin);
+        break;
+      case RGB_OP_COLOROUT:
+        a.has_colorout = 1;
+        conversion_fill_args(&g.colorout, a.colorout);
+        break;
+      case RGB_OP_CHANNELMIXER:
+        channelmixerrgb_fill_args(&g.channelmixer, a.cm);
+        cm_kind = a.cm.kind;
+        a.cm_clip = a.cm.clip;
+        break;
       case RGB_OP_FILMIC:
       {
         const int err = filmicrgb_fill_args(&g.filmic, a.filmic);
         if(err != DT_HIP_SUCCESS) return err;
+        fm = a.filmic.mode;
+        a.filmic_export = a.filmic.use_export;
         break;
       }
       default: return DT_HIP_INVALID_ARG;
     }
   }
+  a.to_u16 = g.to_u16;
   hipStream_t s = stream_of(devid);
+  const unsigned grid = stream_grid(np, 256);
+  const float4 *in = (const float4 *)dev_in;
   launch_scope ls(devid, g.to_u16 ? "rgb_chain_u16" : "rgb_chain");
-  if(g.to_u16)
-    rgb_chain<true><<<stream_grid(np, 256), 256, 0, s>>>((const float4 *)dev_in, dev_out, np, a);
-  else
-    rgb_chain<false><<<stream_grid(np, 256), 256, 0, s>>>((const float4 *)dev_in, dev_out, np, a);
+  int err;
+  switch(fm)
+  {
+    case FM_NONE: err = rgb_chain_launch_none(cm_kind, grid, s, in, dev_out, np, a); break;
+    case MODE_AGX: err = rgb_chain_launch_agx(cm_kind, grid, s, in, dev_out, np, a); break;
+    case MODE_V5: err = rgb_chain_launch_v5(cm_kind, grid, s, in, dev_out, np, a); break;
+    case MODE_SPLIT_V4: err = rgb_chain_launch_split_v4(cm_kind, grid, s, in, dev_out, np, a); break;
+    default: err = rgb_chain_launch_chroma_v4(cm_kind, grid, s, in, dev_out, np, a); break;
+  }
+  if(err != DT_HIP_SUCCESS) return err;
   return check_launch("rgb_chain");
 }
 

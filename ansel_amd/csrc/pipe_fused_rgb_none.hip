@@ -1,0 +1,10 @@
+// pipe_fused_rgb_none.hip -- instantiations of the fused RGBA chain (rgb_chain_kernel.h) for filmic
+// mode FM_NONE, one per color-calibration adaptation.
+#include "rgb_chain_kernel.h"
+namespace ansel
+{
+int rgb_chain_launch_none(int cm_kind, unsigned grid, hipStream_t s, const float4 *in, void *out, size_t np, const chain_args &a)
+{
+  return rgb_chain_launch_fm<FM_NONE>(cm_kind, grid, s, in, out, np, a);
+}
+} // namespace ansel

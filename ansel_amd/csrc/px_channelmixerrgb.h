@@ -68,7 +68,7 @@ template <int KIND> __device__ __forceinline__ f3 lms_to_xyz(const f3 v)
   return v;
 }
 
-template <bool CLIP> __device__ __forceinline__ f3 gamut_mapping(const f3 input, const float compression)
+__device__ __forceinline__ f3 gamut_mapping(const f3 input, const float compression, const bool CLIP)
 {
   const float sum = input.x + input.y + input.z;
   const float Y = input.y;
@@ -143,7 +143,9 @@ __device__ __forceinline__ f3 luma_chroma(const f3 in, const float sat[3], const
 }
 
 
-template <int KIND, bool CLIP> __device__ __forceinline__ float4 px_channelmixerrgb(const float4 p, const cm_args &a)
+// KIND is a template parameter (it selects matrices and the adaptation formula); CLIP is a
+// compile-time constant at the standalone kernel's call site and wave-uniform in the fused chain
+template <int KIND> __device__ __forceinline__ float4 px_channelmixerrgb(const float4 p, const cm_args &a, const bool CLIP)
 {
   f3 one, two = { p.x, p.y, p.z };
   if(CLIP) two = max_zero(two);
@@ -191,7 +193,7 @@ template <int KIND, bool CLIP> __device__ __forceinline__ float4 px_channelmixer
     one = mat3(a.RGB_to_XYZ, one);
   }
 
-  two = gamut_mapping<CLIP>(one, a.gamut);
+  two = gamut_mapping(one, a.gamut, CLIP);
   one = (KIND == DT_HIP_ADAPTATION_RGB) ? mat3(a.XYZ_to_RGB, two) : xyz_to_lms<KIND>(two);
   if(CLIP) one = max_zero(one);
   two = luma_chroma(one, a.saturation, a.lightness, a.version);
@@ -212,24 +214,6 @@ template <int KIND, bool CLIP> __device__ __forceinline__ float4 px_channelmixer
     o = make_float4(two.x, two.y, two.z, p.w);
   }
   return o;
-}
-
-// run-time dispatch for the fused chain (adaptation kind and clip flag are wave-uniform)
-__device__ __forceinline__ float4 px_channelmixerrgb_rt(const float4 p, const cm_args &a)
-{
-  switch(a.kind * 2 + (a.clip ? 1 : 0))
-  {
-    case 2 * DT_HIP_ADAPTATION_LINEAR_BRADFORD: return px_channelmixerrgb<DT_HIP_ADAPTATION_LINEAR_BRADFORD, false>(p, a);
-    case 2 * DT_HIP_ADAPTATION_LINEAR_BRADFORD + 1: return px_channelmixerrgb<DT_HIP_ADAPTATION_LINEAR_BRADFORD, true>(p, a);
-    case 2 * DT_HIP_ADAPTATION_CAT16: return px_channelmixerrgb<DT_HIP_ADAPTATION_CAT16, false>(p, a);
-    case 2 * DT_HIP_ADAPTATION_CAT16 + 1: return px_channelmixerrgb<DT_HIP_ADAPTATION_CAT16, true>(p, a);
-    case 2 * DT_HIP_ADAPTATION_FULL_BRADFORD: return px_channelmixerrgb<DT_HIP_ADAPTATION_FULL_BRADFORD, false>(p, a);
-    case 2 * DT_HIP_ADAPTATION_FULL_BRADFORD + 1: return px_channelmixerrgb<DT_HIP_ADAPTATION_FULL_BRADFORD, true>(p, a);
-    case 2 * DT_HIP_ADAPTATION_XYZ: return px_channelmixerrgb<DT_HIP_ADAPTATION_XYZ, false>(p, a);
-    case 2 * DT_HIP_ADAPTATION_XYZ + 1: return px_channelmixerrgb<DT_HIP_ADAPTATION_XYZ, true>(p, a);
-    case 2 * DT_HIP_ADAPTATION_RGB: return px_channelmixerrgb<DT_HIP_ADAPTATION_RGB, false>(p, a);
-    default: return px_channelmixerrgb<DT_HIP_ADAPTATION_RGB, true>(p, a);
-  }
 }
 
 // host: dt_hip_channelmixerrgb_data_t -> kernel arguments

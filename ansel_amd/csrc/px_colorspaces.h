@@ -27,9 +27,11 @@ __device__ __forceinline__ float extrapolate_lut(const float *__restrict__ lut, 
   const float ft = a > 0.0f ? (a < 65535.0f ? a : 65535.0f) : 0.0f; // CLAMPS(v * (lutsize - 1), 0, lutsize - 1)
   const int t = (int)((ft < 65534.0f) ? ft : 65534.0f);
   const float f = ft - (float)t;
-  const float l1 = lut[t];
-  const float l2 = lut[t + 1];
-  return l1 * (1.0f - f) + l2 * f;
+  // the two adjacent samples in ONE 8-byte gather (dword-aligned): the tone-curve stage is bound by
+  // the number of L1/L2 requests, one per lane per load instruction
+  typedef float f2u_t __attribute__((ext_vector_type(2), aligned(4)));
+  const f2u_t l = *reinterpret_cast<const f2u_t *>(lut + t);
+  return l.x * (1.0f - f) + l.y * f;
 }
 
 __device__ __forceinline__ float eval_trc(const float x, const float *__restrict__ lut, const float *coeff)

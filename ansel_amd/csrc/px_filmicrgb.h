@@ -25,6 +25,7 @@ struct fargs
   float grey_source, black_source, dynamic_range, output_power, saturation, beta_hue;
   // spline
   float M1[3], M2[3], M3[3], M4[3], M5[3];
+  float inv_M2[2]; // 1.f / M2[side], the sigmoid's outer exponent (uniform, computed once on the host)
   float latitude_min, latitude_max, y0, y4;
   int type0, type1;
   int preserve_color;
@@ -118,24 +119,53 @@ __device__ __forceinline__ float log_tonemapping(const float x, const fargs &a)
   return clamp_simd((ansel_math::log2f_exact(x / a.grey_source) - a.black_source) / a.dynamic_range);
 }
 
+// filmic_spline(), filmicrgb.c:1063-1160.  Same arithmetic per lane as the reference's three-way
+// branch, organised for a 64-wide wave: toe, latitude and shoulder pixels sit side by side in real
+// images, so a branch per zone would run every powf of every zone for the whole wave (2 + 1 per
+// channel with the default "perceptual" curves).  Instead each lane selects the operands of its
+// FIRST power (toe sigmoid: u^p; slope-matched power toe / shoulder: x^q or (1-x)^q) and all lanes
+// that need one run it together; the toe sigmoid's second power runs the same way.  Polynomial and
+// rational curves have no powf and keep their closed forms.
 __device__ __forceinline__ float filmic_spline(const float x, const fargs &a)
 {
   using ansel_math::powf_exact;
-  float result;
-  if(x < a.latitude_min)
+  const bool toe = x < a.latitude_min;
+  const bool shoulder = !toe && x > a.latitude_max;
+  const bool sig0 = a.type0 == 3, sig1 = a.type1 == 3;     // uniform
+  const bool pow0 = a.M5[0] != 0.f, pow1 = a.M5[1] != 0.f; // uniform: slope-matched power curve instead of the sigmoid
+  float result = a.M1[2] + x * a.M2[2]; // latitude
+  if(sig0 | sig1)
   {
-    if(a.type0 == 3)
+    const bool t_sig = toe && sig0, s_sig = shoulder && sig1;
+    // first power.  One division for the sigmoid argument u = slope * (x - x_t) / scale, whichever
+    // side the lane is on
+    const float xt = t_sig ? a.latitude_min : a.latitude_max;
+    const float sc = t_sig ? a.M1[0] : a.M1[1];
+    const bool powcurve = t_sig ? pow0 : pow1;
+    const float u = a.M2[2] * (x - xt) / sc;
+    const float base1 = powcurve ? fmaxf(t_sig ? x : 1.f - x, 0.f) : u;
+    const float e1 = t_sig ? (pow0 ? a.M4[0] : a.M2[0]) : (pow1 ? a.M4[1] : a.M2[1]);
+    float p1 = 0.f;
+    if(t_sig | s_sig) p1 = powf_exact(base1, e1);
+    // second power: the generalized sigmoid u / (1 + u^p)^(1/p)
+    const bool need2 = (t_sig | s_sig) && !powcurve;
+    float p2 = 1.f;
+    if(need2) p2 = powf_exact(1.f + p1, t_sig ? a.inv_M2[0] : a.inv_M2[1]);
+    const float u0 = u, u1 = u;
+    if(t_sig)
     {
-      if(a.M5[0] != 0.f)
-        result = a.M3[2] + fmaxf(0.f, a.M3[0] * powf_exact(fmaxf(x, 0.f), a.M4[0]));
-      else
-      {
-        const float ty = a.latitude_min * a.M2[2] + a.M1[2];
-        const float u = a.M2[2] * (x - a.latitude_min) / a.M1[0];
-        result = a.M1[0] * (u / powf_exact(1.f + powf_exact(u, a.M2[0]), 1.f / a.M2[0])) + ty;
-      }
+      const float ty = a.latitude_min * a.M2[2] + a.M1[2];
+      result = pow0 ? a.M3[2] + fmaxf(0.f, a.M3[0] * p1) : a.M1[0] * (u0 / p2) + ty;
     }
-    else if(a.type0 == 0)
+    if(s_sig)
+    {
+      const float ty = a.latitude_max * a.M2[2] + a.M1[2];
+      result = pow1 ? a.M4[2] - fmaxf(0.f, a.M3[1] * p1) : a.M1[1] * (u1 / p2) + ty;
+    }
+  }
+  if(toe && !sig0)
+  {
+    if(a.type0 == 0)
       result = a.M1[0] + x * (a.M2[0] + x * (a.M3[0] + x * (a.M4[0] + x * a.M5[0])));
     else if(a.type0 == 1)
       result = a.M1[0] + x * (a.M2[0] + x * (a.M3[0] + x * a.M4[0]));
@@ -146,20 +176,9 @@ __device__ __forceinline__ float filmic_spline(const float x, const fargs &a)
       result = a.M4[0] - a.M1[0] * rat / (rat + a.M3[0]);
     }
   }
-  else if(x > a.latitude_max)
+  if(shoulder && !sig1)
   {
-    if(a.type1 == 3)
-    {
-      if(a.M5[1] != 0.f)
-        result = a.M4[2] - fmaxf(0.f, a.M3[1] * powf_exact(fmaxf(1.f - x, 0.f), a.M4[1]));
-      else
-      {
-        const float ty = a.latitude_max * a.M2[2] + a.M1[2];
-        const float u = a.M2[2] * (x - a.latitude_max) / a.M1[1];
-        result = a.M1[1] * (u / powf_exact(1.f + powf_exact(u, a.M2[1]), 1.f / a.M2[1])) + ty;
-      }
-    }
-    else if(a.type1 == 0)
+    if(a.type1 == 0)
       result = a.M1[1] + x * (a.M2[1] + x * (a.M3[1] + x * (a.M4[1] + x * a.M5[1])));
     else if(a.type1 == 1)
       result = a.M1[1] + x * (a.M2[1] + x * (a.M3[1] + x * a.M4[1]));
@@ -170,8 +189,6 @@ __device__ __forceinline__ float filmic_spline(const float x, const fargs &a)
       result = a.M4[1] + a.M1[1] * rat / (rat + a.M3[1]);
     }
   }
-  else
-    result = a.M1[2] + x * a.M2[2];
   return result;
 }
 
@@ -324,8 +341,7 @@ __device__ __forceinline__ v4 gamut_check_RGB(const m3 &mi, const m3 &mo, const 
   return o;
 }
 
-template <bool EXPORT>
-__device__ __forceinline__ v4 gamut_mapping(v4 Yf, const v4 Yo, const fargs &a, const float saturation)
+__device__ __forceinline__ v4 gamut_mapping(v4 Yf, const v4 Yo, const fargs &a, const float saturation, const bool EXPORT)
 {
   Yf.z = Yo.z;
   Yf.w = Yo.w;
@@ -361,7 +377,7 @@ __device__ __forceinline__ v4 agx_compress_negatives(const v4 p, const float lum
 enum { MODE_AGX = 0, MODE_V5 = 1, MODE_SPLIT_V4 = 2, MODE_CHROMA_V4 = 3 };
 
 
-template <int MODE, bool EXPORT> __device__ __forceinline__ float4 px_filmicrgb(const float4 pi, const fargs &a)
+template <int MODE> __device__ __forceinline__ float4 px_filmicrgb(const float4 pi, const fargs &a, const bool EXPORT)
 {
   v4 pix_in = { pi.x, pi.y, pi.z, pi.w };
   v4 res;
@@ -384,7 +400,7 @@ template <int MODE, bool EXPORT> __device__ __forceinline__ float4 px_filmicrgb(
     Yref.z = (norm_mix > 1e-9f) ? r_mix / norm_mix : Yo.z;
     Yref.w = (norm_mix > 1e-9f) ? g_mix / norm_mix : Yo.w;
     Yf.y = chroma_final;
-    res = gamut_mapping<EXPORT>(Yf, Yref, a, 0.f);
+    res = gamut_mapping(Yf, Yref, a, 0.f, EXPORT);
   }
   else if(MODE == MODE_V5)
   {
@@ -396,7 +412,7 @@ template <int MODE, bool EXPORT> __device__ __forceinline__ float4 px_filmicrgb(
     const v4 Yo = pipe_RGB_to_Ych(pix_in, a.input);
     v4 Yf = pipe_RGB_to_Ych(po, a.input);
     Yf.y = fminf(Yo.y, Yf.y);
-    res = gamut_mapping<EXPORT>(Yf, Yo, a, 0.f);
+    res = gamut_mapping(Yf, Yo, a, 0.f, EXPORT);
   }
   else if(MODE == MODE_SPLIT_V4)
   {
@@ -404,32 +420,16 @@ template <int MODE, bool EXPORT> __device__ __forceinline__ float4 px_filmicrgb(
     const v4 Yo = pipe_RGB_to_Ych(pix_in, a.input);
     v4 Yf = pipe_RGB_to_Ych(po, a.input);
     Yf.y = fminf(Yo.y, Yf.y);
-    res = gamut_mapping<EXPORT>(Yf, Yo, a, a.saturation);
+    res = gamut_mapping(Yf, Yo, a, a.saturation, EXPORT);
   }
   else
   {
     const v4 po = norm_tone_mapping_v4(pix_in, a.preserve_color, a);
     const v4 Yo = pipe_RGB_to_Ych(pix_in, a.input);
     const v4 Yf = pipe_RGB_to_Ych(po, a.input);
-    res = gamut_mapping<EXPORT>(Yf, Yo, a, a.saturation);
+    res = gamut_mapping(Yf, Yo, a, a.saturation, EXPORT);
   }
   return make_float4(res.x, res.y, res.z, res.w);
-}
-
-// run-time dispatch for the fused chain (mode and export switch are wave-uniform)
-__device__ __forceinline__ float4 px_filmicrgb_rt(const float4 p, const fargs &a)
-{
-  switch(a.mode * 2 + (a.use_export ? 1 : 0))
-  {
-    case 2 * MODE_AGX: return px_filmicrgb<MODE_AGX, false>(p, a);
-    case 2 * MODE_AGX + 1: return px_filmicrgb<MODE_AGX, true>(p, a);
-    case 2 * MODE_V5: return px_filmicrgb<MODE_V5, false>(p, a);
-    case 2 * MODE_V5 + 1: return px_filmicrgb<MODE_V5, true>(p, a);
-    case 2 * MODE_SPLIT_V4: return px_filmicrgb<MODE_SPLIT_V4, false>(p, a);
-    case 2 * MODE_SPLIT_V4 + 1: return px_filmicrgb<MODE_SPLIT_V4, true>(p, a);
-    case 2 * MODE_CHROMA_V4: return px_filmicrgb<MODE_CHROMA_V4, false>(p, a);
-    default: return px_filmicrgb<MODE_CHROMA_V4, true>(p, a);
-  }
 }
 
 // host: dt_hip_filmicrgb_data_t -> kernel arguments (per-call matrix preparation included);

@@ -1,0 +1,86 @@
+// rgb_chain_kernel.h -- the fused RGBA chain kernel (see pipe_fused.hip), instantiated per
+// {color-calibration adaptation, filmic colour science} in pipe_fused_rgb_*.hip so that the
+// translation units compile in parallel.  Stage order is the reference's pipe order
+// (src/develop/iop_order.c:565-: exposure 25 < colorin 31 < channelmixerrgb 33 < filmicrgb 49 <
+// colorout): exposure -> colorin -> color calibration -> filmic -> colorout -> [float -> u16].
+#pragma once
+#include "px_colorspaces.h"
+#include "px_channelmixerrgb.h"
+#include "px_filmicrgb.h"
+
+namespace ansel
+{
+
+struct chain_args
+{
+  int has_exposure, has_colorin, has_colorout, to_u16;
+  int cm_clip, filmic_export;
+  float exp_black, exp_scale;
+  conv_args colorin, colorout;
+  cm_args cm;
+  fargs filmic;
+};
+
+constexpr int CM_NONE = -1;
+constexpr int FM_NONE = -1;
+
+template <int CM, int FM>
+__global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, void *__restrict__ out,
+                                                  const size_t npixels, const chain_args a)
+{
+  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
+  {
+    float4 v = in[k];
+    if(a.has_exposure)
+    {
+      // exposure.c:521-524 on all four lanes
+      v.x = (v.x - a.exp_black) * a.exp_scale;
+      v.y = (v.y - a.exp_black) * a.exp_scale;
+      v.z = (v.z - a.exp_black) * a.exp_scale;
+      v.w = (v.w - a.exp_black) * a.exp_scale;
+    }
+    if(a.has_colorin) v = px_conversion_rt(v, a.colorin);
+    if(CM != CM_NONE) v = px_channelmixerrgb<(CM == CM_NONE ? 0 : CM)>(v, a.cm, a.cm_clip != 0);
+    if(FM != FM_NONE) v = px_filmicrgb<(FM == FM_NONE ? 0 : FM)>(v, a.filmic, a.filmic_export != 0);
+    if(a.has_colorout) v = px_conversion_rt(v, a.colorout);
+    if(a.to_u16)
+    {
+      // _export_final_buffer_to_uint16(), src/imageio/imageio_core.c:729-737 (glib CLAMP)
+      ushort4 o;
+      const float x = roundf(v.x * 65535.f), y = roundf(v.y * 65535.f), z = roundf(v.z * 65535.f), w = roundf(v.w * 65535.f);
+      o.x = (unsigned short)(int)(x > 65535.f ? 65535.f : (x < 0.f ? 0.f : x));
+      o.y = (unsigned short)(int)(y > 65535.f ? 65535.f : (y < 0.f ? 0.f : y));
+      o.z = (unsigned short)(int)(z > 65535.f ? 65535.f : (z < 0.f ? 0.f : z));
+      o.w = (unsigned short)(int)(w > 65535.f ? 65535.f : (w < 0.f ? 0.f : w));
+      reinterpret_cast<ushort4 *>(out)[k] = o;
+    }
+    else
+      nt_store(reinterpret_cast<float4 *>(out) + k, v);
+  }
+}
+
+template <int FM>
+int rgb_chain_launch_fm(const int cm_kind, const unsigned grid, hipStream_t s, const float4 *in, void *out,
+                        const size_t np, const chain_args &a)
+{
+  switch(cm_kind)
+  {
+    case CM_NONE: rgb_chain<CM_NONE, FM><<<grid, 256, 0, s>>>(in, out, np, a); break;
+    case DT_HIP_ADAPTATION_LINEAR_BRADFORD: rgb_chain<DT_HIP_ADAPTATION_LINEAR_BRADFORD, FM><<<grid, 256, 0, s>>>(in, out, np, a); break;
+    case DT_HIP_ADAPTATION_CAT16: rgb_chain<DT_HIP_ADAPTATION_CAT16, FM><<<grid, 256, 0, s>>>(in, out, np, a); break;
+    case DT_HIP_ADAPTATION_FULL_BRADFORD: rgb_chain<DT_HIP_ADAPTATION_FULL_BRADFORD, FM><<<grid, 256, 0, s>>>(in, out, np, a); break;
+    case DT_HIP_ADAPTATION_XYZ: rgb_chain<DT_HIP_ADAPTATION_XYZ, FM><<<grid, 256, 0, s>>>(in, out, np, a); break;
+    case DT_HIP_ADAPTATION_RGB: rgb_chain<DT_HIP_ADAPTATION_RGB, FM><<<grid, 256, 0, s>>>(in, out, np, a); break;
+    default: return DT_HIP_INVALID_ARG;
+  }
+  return DT_HIP_SUCCESS;
+}
+
+// one per translation unit
+int rgb_chain_launch_none(int cm_kind, unsigned grid, hipStream_t s, const float4 *in, void *out, size_t np, const chain_args &a);
+int rgb_chain_launch_agx(int cm_kind, unsigned grid, hipStream_t s, const float4 *in, void *out, size_t np, const chain_args &a);
+int rgb_chain_launch_v5(int cm_kind, unsigned grid, hipStream_t s, const float4 *in, void *out, size_t np, const chain_args &a);
+int rgb_chain_launch_split_v4(int cm_kind, unsigned grid, hipStream_t s, const float4 *in, void *out, size_t np, const chain_args &a);
+int rgb_chain_launch_chroma_v4(int cm_kind, unsigned grid, hipStream_t s, const float4 *in, void *out, size_t np, const chain_args &a);
+
+} // namespace ansel
