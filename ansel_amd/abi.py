@@ -127,3 +127,18 @@ def set_m34(dst, rows):
 def set_vec(dst, vals):
     for i, v in enumerate(vals):
         dst[i] = float(v)
+
+
+class Band(C.Structure):
+    """dt_hip_band_t: a row band of a frame split over several devices"""
+    _fields_ = [("row0", C.c_int32), ("rows", C.c_int32), ("halo_top", C.c_int32), ("halo_bottom", C.c_int32),
+                ("tile_row0", C.c_int32), ("tile_row1", C.c_int32)]
+
+
+class BandState(C.Structure):
+    """dt_hip_band_state_t"""
+    _fields_ = [("halo_buf", C.c_void_p), ("row_bytes", C.c_size_t), ("clipped_count", C.c_void_p),
+                ("priv", C.c_void_p)]
+
+
+DT_HIP_HIGHLIGHTS_JOURNAL_BYTES = 320

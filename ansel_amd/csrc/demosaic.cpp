@@ -4,17 +4,18 @@
 
 namespace ansel
 {
-int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
+int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out,
+                        const rcd_band_t *band);
 int ppg_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
 }
 extern "C" uint32_t dt_hip_crop_dcraw_filters(uint32_t filters, uint32_t crop_x, uint32_t crop_y);
 
 using namespace ansel;
 
-extern "C" {
-
-int dt_hip_iop_demosaic_process(int devid, const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d,
-                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+namespace ansel
+{
+int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d,
+                                     const rcd_band_t *band, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
   if(!piece->filters || piece->filters == 9u || piece->channels != 1)
@@ -38,13 +39,28 @@ int dt_hip_iop_demosaic_process(int devid, const dt_hip_piece_t *piece, const dt
   switch(d->demosaicing_method)
   {
     case DT_HIP_DEMOSAIC_RCD:
-      return rcd_demosaic_launch(devid, piece, filters, (const float *)dev_in, (float4 *)dev_out);
+      return rcd_demosaic_launch(devid, piece, filters, (const float *)dev_in, (float4 *)dev_out, band);
     case DT_HIP_DEMOSAIC_PPG:
+      if(band)
+      {
+        set_last_error("demosaic: PPG has no row-band mode");
+        return DT_HIP_INVALID_ARG;
+      }
       return ppg_demosaic_launch(devid, piece, filters, (const float *)dev_in, (float4 *)dev_out);
     default:
       set_last_error("demosaic: method %u is not implemented on device", d->demosaicing_method);
       return DT_HIP_INVALID_ARG;
   }
+}
+
+} // namespace ansel
+
+extern "C" {
+
+int dt_hip_iop_demosaic_process(int devid, const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d,
+                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  return dt_hip_iop_demosaic_process_band(devid, piece, d, nullptr, dev_in, dev_out);
 }
 
 // tiling_callback(), src/iop/demosaic.c:1930-1990: RCD overlap 10, PPG/AMaZE 5; 2x2 alignment

@@ -80,6 +80,10 @@ struct rcd_args
   uint32_t filters;
   float scaler, revscaler;
   int num_vertical, num_horizontal;
+  // band mode (multi-GPU row bands): the launch covers tile rows tv0.. of the
+  // frame's own tile grid; `in` row 0 is frame row in_row0, `out` row 0 is frame row out_row0 and
+  // only frame rows [out_row0, out_row1) are written.  Whole frame: 0, 0, 0, height.
+  int tv0, in_row0, out_row0, out_row1;
 };
 
 __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, float4 *__restrict__ out,
@@ -92,8 +96,9 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
   float *const x = g + TS * HS;
 
   const int tid = threadIdx.x;
-  const int tile_vertical = blockIdx.x / a.num_horizontal;
-  const int tile_horizontal = blockIdx.x - tile_vertical * a.num_horizontal;
+  const int tile_vertical_local = blockIdx.x / a.num_horizontal;
+  const int tile_horizontal = blockIdx.x - tile_vertical_local * a.num_horizontal;
+  const int tile_vertical = a.tv0 + tile_vertical_local;
   const int rowStart = tile_vertical * TV, rowEnd = min(rowStart + TS, a.height);
   const int colStart = tile_horizontal * TV, colEnd = min(colStart + TS, a.width);
   const int tileRows = rowEnd - rowStart, tileCols = colEnd - colStart;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
     const int row = idx / TS, col = idx - row * TS;
     float v = 0.0f;
     if(row < tileRows && col < tileCols)
-      v = fmaxf(0.0f, in[(size_t)(rowStart + row) * a.width + colStart + col]) * a.revscaler;
+      v = fmaxf(0.0f, in[(size_t)(rowStart - a.in_row0 + row) * a.width + colStart + col]) * a.revscaler;
     cfa[idx] = v;
   }
   __syncthreads();
@@ -310,9 +315,11 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
       o_g.y = scaler * fmaxf(0.0f, rgb1);
       o_g.z = scaler * fmaxf(0.0f, res[1]);
     }
-    float4 *dst = out + (size_t)(rowStart + row) * a.width + colStart + c0;
+    const int frame_row = rowStart + row;
+    float4 *dst = out + (size_t)(frame_row - a.out_row0) * a.width + colStart + c0;
     const float4 lo = p ? o_g : o_rb, hi = p ? o_rb : o_g; // column c0, column c0 + 1
-    const bool ok_lo = p ? ok_g : ok_rb, ok_hi = p ? ok_rb : ok_g;
+    const bool in_band = frame_row >= a.out_row0 && frame_row < a.out_row1;
+    const bool ok_lo = in_band && (p ? ok_g : ok_rb), ok_hi = in_band && (p ? ok_rb : ok_g);
     if(ok_lo) dst[0] = lo;
     if(ok_hi) dst[1] = hi;
   }
@@ -320,7 +327,9 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
 
 // ---- border ring: rcd_ppg_border(), rcd.c:92-272, through ppg_device.h (clamped samples) ----
 __global__ __launch_bounds__(256) void rcd_border(const float *__restrict__ in, float4 *__restrict__ out,
-                                                   const int width, const int height, const uint32_t filters)
+                                                   const int width, const int height, const uint32_t filters,
+                                                   const int in_row0, const int in_rows, const int out_row0,
+                                                   const int out_row1)
 {
   // enumerate the ring of RCD_MARGIN pixels: top rows, bottom rows, then left/right columns
   const int M = RCD_MARGIN;
@@ -348,8 +357,13 @@ __global__ __launch_bounds__(256) void rcd_border(const float *__restrict__ in, 
     i = q < M ? q : width - 2 * M + q;
   }
   if(j < 0 || j >= height || i < 0 || i >= width) return;
-  const ppg_ctx k = { in, width, height, width, height, 0, 0, filters };
-  out[(size_t)j * width + i] = ppg_pixel<true>(k, j, i);
+  if(j < out_row0 || j >= out_row1) return;
+  // band mode: the ring pixel reads frame rows j-4..j+4, all inside the band's halo (>= 9 rows) or
+  // outside the frame (never dereferenced); address the band buffer as if it were the whole frame
+  const float *frame = in - (ptrdiff_t)in_row0 * width;
+  const ppg_ctx k = { frame, width, height, width, height, 0, 0, filters };
+  (void)in_rows;
+  out[(size_t)(j - out_row0) * width + i] = ppg_pixel<true>(k, j, i);
 }
 
 } // namespace
@@ -373,17 +387,24 @@ extern "C" uint32_t dt_hip_crop_dcraw_filters(uint32_t filters, uint32_t crop_x,
 namespace ansel
 {
 
-int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out)
+// band == nullptr: the whole frame.  Otherwise piece describes the whole frame, `in` holds frame rows
+// [in_row0, in_row0 + in_rows) and `out` frame rows [out_row0, out_row0 + out_rows); the launch runs
+// the frame's tile rows [tv0, tv1) and the part of the border ring inside the output rows.
+int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out,
+                        const rcd_band_t *band)
 {
   const int width = piece->roi_in.width, height = piece->roi_in.height;
   if(width < 16 || height < 16) return DT_HIP_SUCCESS; // rcd.c:280-284: "too small area", output untouched
+  const int in_row0 = band ? band->in_row0 : 0, in_rows = band ? band->in_rows : height;
+  const int out_row0 = band ? band->out_row0 : 0, out_row1 = band ? band->out_row0 + band->out_rows : height;
   // rows alternate R/G and G/B with period 2 for every Bayer filter word rawspeed produces;
   // the CPU code already relies on it by mixing image-row and tile-row FC() calls
   hipStream_t s = stream_of(devid);
   {
     const long ring = 2L * RCD_MARGIN * width + 2L * RCD_MARGIN * (height > 2 * RCD_MARGIN ? height - 2 * RCD_MARGIN : 0);
     launch_scope ls(devid, "rcd_border");
-    rcd_border<<<(unsigned)((ring + 255) / 256), 256, 0, s>>>(in, out, width, height, filters);
+    rcd_border<<<(unsigned)((ring + 255) / 256), 256, 0, s>>>(in, out, width, height, filters, in_row0, in_rows,
+                                                              out_row0, out_row1);
   }
   rcd_args a;
   a.width = width;
@@ -393,6 +414,17 @@ int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters
   a.revscaler = 1.0f / a.scaler;
   a.num_vertical = 1 + (height - 2 * RCD_BORDER - 1) / TV;
   a.num_horizontal = 1 + (width - 2 * RCD_BORDER - 1) / TV;
+  a.tv0 = band ? band->tv0 : 0;
+  a.in_row0 = in_row0;
+  a.out_row0 = out_row0;
+  a.out_row1 = out_row1;
+  const int tile_rows = band ? band->tv1 - band->tv0 : a.num_vertical;
+  if(band && (band->tv0 < 0 || band->tv1 > a.num_vertical || tile_rows <= 0 || band->tv0 * TV < in_row0
+              || min(band->tv0 * TV + (tile_rows - 1) * TV + TS, height) > in_row0 + in_rows))
+  {
+    set_last_error("rcd band: tile rows [%d,%d) need frame rows outside the band buffer", band->tv0, band->tv1);
+    return DT_HIP_INVALID_ARG;
+  }
   static bool attr_set = false;
   if(!attr_set)
   {
@@ -401,7 +433,7 @@ int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters
   }
   {
     launch_scope ls(devid, "rcd_tiles");
-    rcd_tiles<<<(unsigned)(a.num_vertical * a.num_horizontal), NT, LDS_BYTES, s>>>(in, out, a);
+    rcd_tiles<<<(unsigned)(tile_rows * a.num_horizontal), NT, LDS_BYTES, s>>>(in, out, a);
   }
   return check_launch("rcd_tiles");
 }

@@ -62,6 +62,26 @@ __device__ __forceinline__ void nt_store(float4 *p, const float4 v)
   __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p));
 }
 
+// Journal of the highlight-clip pass (pointwise.hip, pipe_fused.hip): number of photosites above the
+// threshold and the first 25 of them {index in the output buffer, unclipped value}.  In band mode
+// the leading count is summed over all bands before highlights_resolve_launch() decides the bypass.
+#define HL_MIN_CLIPPED 25
+struct hl_journal
+{
+  unsigned long long count;
+  unsigned long long index[HL_MIN_CLIPPED];
+  float value[HL_MIN_CLIPPED];
+};
+int highlights_resolve_launch(int devid, float *out, const hl_journal *journal);
+
+// A row band of a frame for the RCD launch (multi-GPU row bands)
+struct rcd_band_t
+{
+  int tv0, tv1;          // tile rows of the frame's own 94-row tile grid
+  int in_row0, in_rows;  // frame rows held by the input buffer
+  int out_row0, out_rows; // frame rows held by the output buffer
+};
+
 // Grid for a grid-stride streaming kernel: enough workgroups to fill 256 CUs x 8 and no more
 // (cdna_hip_programming.md Guideline 11).
 static inline unsigned stream_grid(size_t work_items, unsigned block)

@@ -14,6 +14,12 @@
 
 using namespace ansel;
 
+namespace ansel
+{
+int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d,
+                                     const rcd_band_t *band, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+}
+
 namespace
 {
 
@@ -298,6 +304,301 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
     cur_owned = out_owned;
   }
   return DT_HIP_SUCCESS;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// row bands (include/ansel_hip.h section 3b)
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+const int RCD_TV = 94, RCD_TS = 112, RCD_HALO = 9; // tile pitch, tile size, RCD_BORDER (rcd.c:70-76)
+
+struct band_priv_t
+{
+  dt_hip_mem_t cfa;     // output of the CFA stages (halo layout when a demosaic follows)
+  bool cfa_owned;
+  dt_hip_mem_t journal; // deferred highlights journal or nullptr
+  dt_hip_mem_t hl_out;  // the buffer the journal indexes
+  size_t next_group;
+};
+
+bool is_cfa_op(op_t o) { return o == OP_RAWPREPARE || o == OP_TEMPERATURE || o == OP_HIGHLIGHTS; }
+
+// the band's view of a node: same columns, rows [row0, row0 + rows) of the frame
+void band_piece(dt_hip_piece_t &p, const dt_hip_band_t &b)
+{
+  p.roi_in.y += b.row0;
+  p.roi_in.height = b.rows;
+  p.roi_out.y += b.row0;
+  p.roi_out.height = b.rows;
+}
+void band_rawprepare(dt_hip_piece_t &p, dt_hip_rawprepare_data_t &d, const dt_hip_band_t &b)
+{
+  // the band input starts at input row crop_y + row0: fold the crop into the CFA phase
+  p.roi_out.y += d.y + b.row0;
+  d.y = 0;
+  p.roi_in.height = b.rows;
+  p.roi_out.height = b.rows;
+}
+} // namespace
+
+extern "C" {
+
+int dt_hip_plan_bands(int width, int height, int demosaic_method, int n_bands, dt_hip_band_t *bands)
+{
+  if(width <= 0 || height <= 0 || n_bands <= 0 || !bands) return DT_HIP_INVALID_ARG;
+  memset(bands, 0, sizeof(dt_hip_band_t) * (size_t)n_bands);
+  if(demosaic_method == DT_HIP_DEMOSAIC_RCD)
+  {
+    if(width < 16 || height < 16) return DT_HIP_INVALID_ARG;
+    const int num_vertical = 1 + (height - 2 * RCD_HALO - 1) / RCD_TV; // rcd.c:286
+    if(num_vertical < n_bands)
+    {
+      set_last_error("dt_hip_plan_bands: %d rows give %d RCD tile rows, fewer than %d bands", height, num_vertical, n_bands);
+      return DT_HIP_INVALID_ARG;
+    }
+    for(int k = 0; k < n_bands; k++)
+    {
+      const int tv0 = (int)((long)k * num_vertical / n_bands), tv1 = (int)((long)(k + 1) * num_vertical / n_bands);
+      dt_hip_band_t &b = bands[k];
+      b.tile_row0 = tv0;
+      b.tile_row1 = tv1;
+      b.row0 = tv0 ? tv0 * RCD_TV + RCD_HALO : 0;
+      const int row1 = (tv1 < num_vertical) ? tv1 * RCD_TV + RCD_HALO : height;
+      b.rows = row1 - b.row0;
+      b.halo_top = b.row0 - tv0 * RCD_TV;
+      const int need1 = (tv1 - 1) * RCD_TV + RCD_TS < height ? (tv1 - 1) * RCD_TV + RCD_TS : height;
+      b.halo_bottom = need1 > row1 ? need1 - row1 : 0;
+    }
+    return DT_HIP_SUCCESS;
+  }
+  if(demosaic_method != -1)
+  {
+    set_last_error("dt_hip_plan_bands: demosaic method %d has no band mode", demosaic_method);
+    return DT_HIP_INVALID_ARG;
+  }
+  if(height / 2 < n_bands) return DT_HIP_INVALID_ARG;
+  for(int k = 0; k < n_bands; k++)
+  {
+    const int r0 = (int)((long)k * (height / 2) / n_bands) * 2;
+    const int r1 = (k + 1 == n_bands) ? height : (int)((long)(k + 1) * (height / 2) / n_bands) * 2;
+    bands[k].row0 = r0;
+    bands[k].rows = r1 - r0;
+  }
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_mem_t dev_in_band,
+                           dt_hip_band_state_t *state)
+{
+  if(!pipe || !band || !dev_in_band || !state || band->rows <= 0) return DT_HIP_INVALID_ARG;
+  memset(state, 0, sizeof(*state));
+  if(pipe->nodes.empty()) return DT_HIP_INVALID_ARG;
+  if(!pipe->planned) pipe->plan();
+  const int devid = pipe->devid;
+  const dt_hip_band_t &b = *band;
+  const int W = pipe->nodes[0].piece.roi_out.width, H = pipe->nodes[0].piece.roi_out.height;
+  for(const node_t &n : pipe->nodes)
+    if(n.piece.roi_out.width != W || n.piece.roi_out.height != H)
+    {
+      set_last_error("band mode: every node must produce the same %d x %d geometry", W, H);
+      return DT_HIP_INVALID_ARG;
+    }
+  if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
+  const size_t ng = pipe->groups.size();
+  // the CFA stage ends where the first non-CFA group starts
+  size_t n_cfa = 0;
+  while(n_cfa < ng && is_cfa_op(pipe->nodes[pipe->groups[n_cfa].first].op)) n_cfa++;
+  const bool has_demosaic = n_cfa < ng && pipe->nodes[pipe->groups[n_cfa].first].op == OP_DEMOSAIC;
+  if(!has_demosaic && (b.halo_top || b.halo_bottom)) return DT_HIP_INVALID_ARG;
+  band_priv_t *pv = new band_priv_t;
+  memset(pv, 0, sizeof(*pv));
+  const size_t row_bytes = (size_t)W * 4;
+  const size_t halo_rows = (size_t)b.halo_top + b.rows + b.halo_bottom;
+
+  int err = DT_HIP_SUCCESS;
+  dt_hip_mem_t cur = dev_in_band;
+  bool cur_owned = false;
+  for(size_t gi = 0; gi < n_cfa && err == DT_HIP_SUCCESS; gi++)
+  {
+    const group_t &g = pipe->groups[gi];
+    const bool last_cfa = gi + 1 == n_cfa;
+    dt_hip_mem_t buf = dt_hip_alloc_device_buffer(devid, last_cfa ? halo_rows * row_bytes : (size_t)b.rows * row_bytes);
+    if(!buf)
+    {
+      err = DT_HIP_SYSMEM_ALLOCATION;
+      break;
+    }
+    dt_hip_mem_t out = last_cfa ? (dt_hip_mem_t)((char *)buf + (size_t)b.halo_top * row_bytes) : buf;
+    const node_t &first = pipe->nodes[g.first];
+    if(g.kind == group_t::RAW)
+    {
+      raw_group_t r = g.raw;
+      band_rawprepare(r.rawprepare_piece, r.rawprepare, b);
+      if(r.has_temperature) band_piece(r.temperature_piece, b);
+      if(r.has_highlights)
+      {
+        band_piece(r.highlights_piece, b);
+        pv->journal = dt_hip_alloc_device_buffer(devid, DT_HIP_HIGHLIGHTS_JOURNAL_BYTES);
+        pv->hl_out = out;
+        if(!pv->journal) err = DT_HIP_SYSMEM_ALLOCATION;
+      }
+      if(err == DT_HIP_SUCCESS) err = raw_group_launch(devid, r, cur, out, pv->journal);
+    }
+    else
+    {
+      dt_hip_piece_t p = first.piece;
+      if(first.op == OP_RAWPREPARE)
+      {
+        dt_hip_rawprepare_data_t d = *first.as<dt_hip_rawprepare_data_t>();
+        band_rawprepare(p, d, b);
+        err = dt_hip_iop_rawprepare_process(devid, &p, &d, cur, out);
+      }
+      else if(first.op == OP_TEMPERATURE)
+      {
+        band_piece(p, b);
+        err = dt_hip_iop_temperature_process(devid, &p, first.as<dt_hip_temperature_data_t>(), cur, out);
+      }
+      else
+      {
+        band_piece(p, b);
+        pv->journal = dt_hip_alloc_device_buffer(devid, DT_HIP_HIGHLIGHTS_JOURNAL_BYTES);
+        pv->hl_out = out;
+        if(!pv->journal) err = DT_HIP_SYSMEM_ALLOCATION;
+        else err = dt_hip_iop_highlights_process_deferred(devid, &p, first.as<dt_hip_highlights_data_t>(), cur, out, pv->journal);
+      }
+    }
+    if(cur_owned) dt_hip_release_mem_object(cur);
+    cur = buf;
+    cur_owned = true;
+  }
+  if(err == DT_HIP_SUCCESS && n_cfa == 0 && has_demosaic)
+  {
+    // the pipe starts at demosaic: stage the band's mosaic rows into the halo layout
+    dt_hip_mem_t buf = dt_hip_alloc_device_buffer(devid, halo_rows * row_bytes);
+    if(!buf) err = DT_HIP_SYSMEM_ALLOCATION;
+    else
+    {
+      err = dt_hip_enqueue_copy_buffer_to_buffer(devid, cur, buf, 0, (size_t)b.halo_top * row_bytes, (size_t)b.rows * row_bytes);
+      cur = buf;
+      cur_owned = true;
+    }
+  }
+  if(err != DT_HIP_SUCCESS)
+  {
+    if(cur_owned) dt_hip_release_mem_object(cur);
+    if(pv->journal) dt_hip_release_mem_object(pv->journal);
+    delete pv;
+    return err;
+  }
+  pv->cfa = cur;
+  pv->cfa_owned = cur_owned;
+  pv->next_group = n_cfa;
+  state->halo_buf = (has_demosaic && cur_owned) ? cur : nullptr;
+  state->row_bytes = row_bytes;
+  state->clipped_count = pv->journal;
+  state->priv = pv;
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state)
+{
+  if(!pipe || !band || !state || !state->priv) return DT_HIP_INVALID_ARG;
+  band_priv_t *pv = (band_priv_t *)state->priv;
+  int err = DT_HIP_SUCCESS;
+  if(pv->journal)
+  {
+    // must precede the halo exchange: the neighbours read these rows after the bypass decision
+    err = dt_hip_iop_highlights_resolve(pipe->devid, pv->hl_out, pv->journal);
+    dt_hip_release_mem_object(pv->journal);
+    pv->journal = nullptr;
+    state->clipped_count = nullptr;
+  }
+  return err;
+}
+
+int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state,
+                            dt_hip_mem_t dev_out_band)
+{
+  if(!pipe || !band || !state || !state->priv || !dev_out_band) return DT_HIP_INVALID_ARG;
+  band_priv_t *pv = (band_priv_t *)state->priv;
+  const int devid = pipe->devid;
+  const dt_hip_band_t &b = *band;
+  const size_t ng = pipe->groups.size();
+  int err = DT_HIP_SUCCESS;
+  if(pv->journal) err = dt_hip_pipe_band_resolve(pipe, band, state); // caller skipped the explicit step
+  dt_hip_mem_t cur = pv->cfa;
+  bool cur_owned = pv->cfa_owned;
+  if(pv->next_group >= ng && err == DT_HIP_SUCCESS)
+  {
+    // CFA-only pipe: the result is the band buffer itself
+    const node_t &last = pipe->nodes.back();
+    err = dt_hip_enqueue_copy_buffer_to_buffer(devid, cur, dev_out_band, 0, 0,
+                                               (size_t)b.rows * last.piece.roi_out.width * 4);
+  }
+  for(size_t gi = pv->next_group; gi < ng && err == DT_HIP_SUCCESS; gi++)
+  {
+    const group_t &g = pipe->groups[gi];
+    const node_t &first = pipe->nodes[g.first];
+    const node_t &last = pipe->nodes[g.first + g.count - 1];
+    dt_hip_mem_t out = dev_out_band;
+    bool out_owned = false;
+    if(gi + 1 < ng)
+    {
+      node_t sized = last;
+      sized.piece.roi_out.height = b.rows;
+      out = dt_hip_alloc_device_buffer(devid, out_bytes(sized));
+      if(!out)
+      {
+        err = DT_HIP_SYSMEM_ALLOCATION;
+        break;
+      }
+      out_owned = true;
+    }
+    if(first.op == OP_DEMOSAIC)
+    {
+      const dt_hip_demosaic_data_t *d = first.as<dt_hip_demosaic_data_t>();
+      if(d->demosaicing_method != DT_HIP_DEMOSAIC_RCD)
+      {
+        set_last_error("band mode: only the RCD demosaic runs on row bands");
+        err = DT_HIP_INVALID_ARG;
+      }
+      else
+      {
+        rcd_band_t rb;
+        rb.tv0 = b.tile_row0;
+        rb.tv1 = b.tile_row1;
+        rb.in_row0 = b.row0 - b.halo_top;
+        rb.in_rows = b.halo_top + b.rows + b.halo_bottom;
+        rb.out_row0 = b.row0;
+        rb.out_rows = b.rows;
+        err = dt_hip_iop_demosaic_process_band(devid, &first.piece, d, &rb, cur, out);
+      }
+    }
+    else if(g.kind == group_t::RGB)
+    {
+      rgb_group_t r = g.rgb;
+      r.height = b.rows;
+      err = rgb_group_launch(devid, r, cur, out);
+    }
+    else
+    {
+      node_t n = first;
+      band_piece(n.piece, b);
+      err = run_single(devid, n, cur, out);
+    }
+    if(cur_owned) dt_hip_release_mem_object(cur);
+    cur = out;
+    cur_owned = out_owned;
+  }
+  if(cur_owned && cur != dev_out_band) dt_hip_release_mem_object(cur);
+  delete pv;
+  state->priv = nullptr;
+  state->halo_buf = nullptr;
+  state->clipped_count = nullptr;
+  return err;
 }
 
 } // extern "C"

@@ -17,7 +17,8 @@ struct raw_group_t
   dt_hip_piece_t highlights_piece;
   dt_hip_highlights_data_t highlights;
 };
-int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                     dt_hip_mem_t deferred_journal = nullptr);
 bool raw_group_supported(const raw_group_t &g);
 
 // ---- fused RGBA group: any order of exposure, colorin, channelmixerrgb, filmicrgb, colorout,

@@ -22,14 +22,6 @@ namespace
 // ---------------------------------------------------------------------------------------------
 // CFA chain: rawprepare [-> temperature] [-> highlights clip]
 // ---------------------------------------------------------------------------------------------
-#define HL_MIN_CLIPPED 25
-struct hl_journal
-{
-  unsigned long long count;
-  unsigned long long index[HL_MIN_CLIPPED];
-  float value[HL_MIN_CLIPPED];
-};
-
 struct raw_args
 {
   int width, height, in_width;
@@ -64,7 +56,7 @@ __device__ __forceinline__ void hl_note_(hl_journal *j, const bool over, const s
     const unsigned long long rank = base + __popcll(mask & ((1ull << lane) - 1ull));
     if(rank < HL_MIN_CLIPPED)
     {
-      j->index[rank] = index;
+      j->index[rank] = index + 1; // 0 = empty slot
       j->value[rank] = value;
     }
   }
@@ -142,13 +134,6 @@ __global__ __launch_bounds__(256) void raw_chain(const in_t *__restrict__ in, fl
   }
 }
 
-__global__ void raw_chain_restore(float *__restrict__ out, const hl_journal *journal)
-{
-  const unsigned long long n = journal->count;
-  if(n >= HL_MIN_CLIPPED) return;
-  if(threadIdx.x < n) out[journal->index[threadIdx.x]] = journal->value[threadIdx.x];
-}
-
 } // namespace
 
 namespace ansel
@@ -175,7 +160,9 @@ bool raw_group_supported(const raw_group_t &g)
   return true;
 }
 
-int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+// deferred != nullptr (band mode): the caller's journal is used and the <25 bypass is left to
+// highlights_resolve_launch() once the count has been summed over all bands
+int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out, dt_hip_mem_t deferred)
 {
   if(!valid_device(devid) || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
   if(!raw_group_supported(g)) return DT_HIP_INVALID_ARG;
@@ -213,11 +200,11 @@ int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hi
       pmax[c] = (g.highlights_piece.processed_maximum[c] > 0.f) ? g.highlights_piece.processed_maximum[c] : 1.0f;
     a.clip = g.highlights.clip * fminf(pmax[0], fminf(pmax[1], pmax[2]));
     a.threshold = a.clip;
-    journal = (hl_journal *)dt_hip_alloc_device_buffer(devid, sizeof(hl_journal));
+    journal = deferred ? (hl_journal *)deferred : (hl_journal *)dt_hip_alloc_device_buffer(devid, sizeof(hl_journal));
     if(!journal) return DT_HIP_SYSMEM_ALLOCATION;
     if(hipMemsetAsync(journal, 0, sizeof(hl_journal), s) != hipSuccess)
     {
-      dt_hip_release_mem_object(journal);
+      if(!deferred) dt_hip_release_mem_object(journal);
       return DT_HIP_DEFAULT_ERROR;
     }
   }
@@ -229,9 +216,9 @@ int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hi
     else
       raw_chain<float><<<stream_grid(work, 256), 256, 0, s>>>((const float *)dev_in, (float *)dev_out, a, journal);
   }
-  if(journal)
+  if(journal && !deferred)
   {
-    raw_chain_restore<<<1, 64, 0, s>>>((float *)dev_out, journal);
+    highlights_resolve_launch(devid, (float *)dev_out, journal);
     dt_hip_release_mem_object(journal);
   }
   return check_launch("raw_chain");

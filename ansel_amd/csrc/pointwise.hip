@@ -139,14 +139,6 @@ __global__ __launch_bounds__(256) void temperature_4f(const float4 *__restrict__
 // of an 8 B/px module, so one pass clips, counts, and journals the first 25 clipped
 // photosites {index, original value}; a one-wave epilogue restores them if the bypass
 // condition turns out to hold.  Bit-exact either way.
-#define HL_MIN_CLIPPED 25
-struct hl_journal
-{
-  unsigned long long count;
-  unsigned long long index[HL_MIN_CLIPPED];
-  float value[HL_MIN_CLIPPED];
-};
-
 __device__ __forceinline__ void hl_note(hl_journal *j, const bool over, const size_t index, const float value)
 {
   const unsigned long long mask = __ballot(over);
@@ -162,7 +154,7 @@ __device__ __forceinline__ void hl_note(hl_journal *j, const bool over, const si
     const unsigned long long rank = base + __popcll(mask & ((1ull << lane) - 1ull));
     if(rank < HL_MIN_CLIPPED)
     {
-      j->index[rank] = index;
+      j->index[rank] = index + 1; // 0 = empty slot
       j->value[rank] = value;
     }
   }
@@ -250,9 +242,10 @@ __global__ __launch_bounds__(256) void highlights_clip_4f(const float4 *__restri
 
 __global__ void highlights_restore_1f(float *__restrict__ out, const hl_journal *journal)
 {
-  const unsigned long long n = journal->count;
-  if(n >= HL_MIN_CLIPPED) return;
-  if(threadIdx.x < n) out[journal->index[threadIdx.x]] = journal->value[threadIdx.x];
+  // count may be the sum over several bands: each band restores the slots it journalled itself
+  if(journal->count >= HL_MIN_CLIPPED || threadIdx.x >= HL_MIN_CLIPPED) return;
+  const unsigned long long slot = journal->index[threadIdx.x];
+  if(slot) out[slot - 1] = journal->value[threadIdx.x];
 }
 
 // 4-channel bypass: fewer than 25 pixels over threshold -> output must equal the input.
@@ -342,6 +335,15 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 } // namespace
 
+namespace ansel
+{
+int highlights_resolve_launch(int devid, float *out, const hl_journal *journal)
+{
+  highlights_restore_1f<<<1, 64, 0, stream_of(devid)>>>(out, journal);
+  return check_launch("highlights_restore_1f");
+}
+} // namespace ansel
+
 extern "C" {
 
 int dt_hip_iop_rawprepare_process(int devid, const dt_hip_piece_t *piece, const dt_hip_rawprepare_data_t *d,
@@ -426,8 +428,40 @@ int dt_hip_iop_temperature_process(int devid, const dt_hip_piece_t *piece, const
   return check_launch("temperature_4f");
 }
 
+static int highlights_launch(int devid, const dt_hip_piece_t *piece, const dt_hip_highlights_data_t *d,
+                             dt_hip_mem_t dev_in, dt_hip_mem_t dev_out, dt_hip_mem_t deferred);
+
 int dt_hip_iop_highlights_process(int devid, const dt_hip_piece_t *piece, const dt_hip_highlights_data_t *d,
                                   dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  return highlights_launch(devid, piece, d, dev_in, dev_out, nullptr);
+}
+
+// Band mode (multi-GPU row bands): the bypass of highlights.c:728-733 depends on the number of
+// clipped photosites of the WHOLE frame.  _deferred clips this band and journals into the caller's
+// buffer (DT_HIP_HIGHLIGHTS_JOURNAL_BYTES); the caller sums the leading uint64 over all bands
+// (all-reduce) and calls _resolve, which restores this band's journalled photosites if the sum < 25.
+int dt_hip_iop_highlights_process_deferred(int devid, const dt_hip_piece_t *piece, const dt_hip_highlights_data_t *d,
+                                           dt_hip_mem_t dev_in, dt_hip_mem_t dev_out, dt_hip_mem_t journal)
+{
+  if(!journal || !piece || !piece->filters)
+  {
+    set_last_error("highlights (deferred): needs a journal buffer and a mosaic input");
+    return DT_HIP_INVALID_ARG;
+  }
+  return highlights_launch(devid, piece, d, dev_in, dev_out, journal);
+}
+
+static_assert(sizeof(hl_journal) <= DT_HIP_HIGHLIGHTS_JOURNAL_BYTES, "journal does not fit the ABI constant");
+
+int dt_hip_iop_highlights_resolve(int devid, dt_hip_mem_t dev_out, dt_hip_mem_t journal)
+{
+  if(!valid_device(devid) || !dev_out || !journal) return DT_HIP_INVALID_ARG;
+  return highlights_resolve_launch(devid, (float *)dev_out, (const hl_journal *)journal);
+}
+
+static int highlights_launch(int devid, const dt_hip_piece_t *piece, const dt_hip_highlights_data_t *d,
+                             dt_hip_mem_t dev_in, dt_hip_mem_t dev_out, dt_hip_mem_t deferred)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
   if(d->mode != DT_HIP_HIGHLIGHTS_CLIP)
@@ -444,7 +478,7 @@ int dt_hip_iop_highlights_process(int devid, const dt_hip_piece_t *piece, const 
   // _hl_count_thresholds(): clip mode tests the scalar clip on every channel (highlights.c:232-255)
   const float4 thr = make_float4(clip, clip, clip, clip);
   hipStream_t s = stream_of(devid);
-  hl_journal *journal = (hl_journal *)dt_hip_alloc_device_buffer(devid, sizeof(hl_journal));
+  hl_journal *journal = deferred ? (hl_journal *)deferred : (hl_journal *)dt_hip_alloc_device_buffer(devid, sizeof(hl_journal));
   if(!journal) return DT_HIP_SYSMEM_ALLOCATION;
   int err = DT_HIP_SUCCESS;
   if(hipMemsetAsync(journal, 0, sizeof(hl_journal), s) != hipSuccess) err = DT_HIP_DEFAULT_ERROR;
@@ -460,7 +494,7 @@ int dt_hip_iop_highlights_process(int devid, const dt_hip_piece_t *piece, const 
         highlights_clip_1f<<<stream_grid(np / 4 + 1, 256), 256, 0, s>>>((const float *)dev_in, (float *)dev_out, np,
                                                                           clip, raw_threshold, journal);
       }
-      highlights_restore_1f<<<1, 64, 0, s>>>((float *)dev_out, journal);
+      if(!deferred) highlights_restore_1f<<<1, 64, 0, s>>>((float *)dev_out, journal);
       err = check_launch("highlights_clip_1f");
     }
   }
@@ -479,7 +513,7 @@ int dt_hip_iop_highlights_process(int devid, const dt_hip_piece_t *piece, const 
       err = check_launch("highlights_clip_4f");
     }
   }
-  dt_hip_release_mem_object(journal); // stream-ordered: reused only by later work on this stream
+  if(!deferred) dt_hip_release_mem_object(journal); // stream-ordered: reused only by later work on this stream
   return err;
 }
 

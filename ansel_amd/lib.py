@@ -78,6 +78,12 @@ def load():
         "dt_hip_pipe_set_fusion": (None, [vp, i]),
         "dt_hip_pipe_num_groups": (i, [vp]),
         "dt_hip_pipe_process": (i, [vp, vp, vp]),
+        "dt_hip_plan_bands": (i, [i, i, i, i, P(abi.Band)]),
+        "dt_hip_pipe_band_begin": (i, [vp, P(abi.Band), vp, P(abi.BandState)]),
+        "dt_hip_pipe_band_resolve": (i, [vp, P(abi.Band), P(abi.BandState)]),
+        "dt_hip_pipe_band_finish": (i, [vp, P(abi.Band), P(abi.BandState), vp]),
+        "dt_hip_iop_highlights_process_deferred": (i, [i, P(abi.Piece), P(abi.HighlightsData), vp, vp, vp]),
+        "dt_hip_iop_highlights_resolve": (i, [i, vp, vp]),
     }
     missing = []
     for name, (res, args) in protos.items():

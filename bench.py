@@ -14,6 +14,8 @@ color calibration, filmic RGB, colorout, float->u16), all at module defaults.
 
 N > 1: one process per GPU, one frame per GPU (BASELINE.json config 5: batch export shards
 frames across GPUs, no data-path collective) -> "scaling": "weak"; value = N frames / max time.
+--mode tiled is BASELINE.json config 4 instead: ONE frame cut into N row bands (ansel_amd/tiled.py),
+an 8-byte all-reduce and one 9-row halo send/recv per frame -> "scaling": "strong".
 
 PyTorch is used for device memory, the stream and torch.distributed only; all pixel work goes
 through the C-ABI of libansel_hip.so (include/ansel_hip.h).  There is no CPU fallback.
@@ -40,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per module (A/B against the fused executor)")
     ap.add_argument("--cpu-sample", default="24MP", help="frame size of the bounded CPU sample")
+    ap.add_argument("--mode", default="batch", choices=("batch", "tiled"),
+                    help="N > 1: batch = one frame per GPU (config 5, weak); tiled = ONE frame cut into row bands, "
+                         "one band per GPU, halo rows exchanged over RCCL (config 4, strong)")
     return ap.parse_args()
 
 
@@ -131,7 +136,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ansel_amd import lib, params, pipe, synth
+    from ansel_amd import lib, params, pipe, synth, tiled
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,13 +163,28 @@ def main():
     lut_host = params.srgb_encode_lut()
     lut = torch.from_numpy(lut_host).to(dev)
     nodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic)
-    out16 = torch.empty((height, width, 4), dtype=torch.int16, device=dev)
     # intermediates belong to the executor: it draws them from the runtime's pool
     executor = pipe.DevicePipe(devid, nodes, fusion=not args.no_fusion)
+    my_rows = height
+    if args.mode == "tiled":
+        # every rank synthesises the same frame and keeps only its band resident
+        raw_host = synth.bayer_mosaic_tiled(width, height, seed=1)
+        bands = tiled.plan_bands(width, height, world, tiled.pipe_demosaic_method(nodes))
+        band = bands[rank]
+        my_rows = band.rows
+        raw = torch.from_numpy(np.ascontiguousarray(raw_host[band.row0:band.row0 + band.rows]).view(np.int16)).to(dev)
+        out16 = torch.empty((band.rows, width, 4), dtype=torch.int16, device=dev)
+        engine = tiled.HipBandEngine(executor, dev)
 
-    def step():
-        # the C++ executor (dt_hip_pipe_process): raw u16 in HBM -> exported RGBA u16 in HBM
-        executor.process(raw.data_ptr(), out16.data_ptr())
+        def step():
+            tiled.process_band(engine, bands, rank, raw.data_ptr(), out16.data_ptr(), width,
+                               dist=dist if world > 1 else None)
+    else:
+        out16 = torch.empty((height, width, 4), dtype=torch.int16, device=dev)
+
+        def step():
+            # the C++ executor (dt_hip_pipe_process): raw u16 in HBM -> exported RGBA u16 in HBM
+            executor.process(raw.data_ptr(), out16.data_ptr())
 
     def sync_all():
         if world > 1:
@@ -212,31 +232,33 @@ def main():
                                            if n.op in ("exposure", "colorin", "channelmixerrgb", "filmicrgb", "colorout", "export_u16"))
         dominant = max((k for k in kernels if k in tag_bpp), key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])
         dom = kernels[dominant]
-        dom_bytes = tag_bpp[dominant] * npix
+        dom_bytes = tag_bpp[dominant] * my_rows * width  # rank 0's share of the frame in tiled mode
         achieved = dom_bytes / (dom["ms_avg"] * 1e-3) / 1e9
         pipe_bpp = pipe.algorithmic_bytes_per_pixel(nodes)
         ms_per_step = elapsed / args.steps * 1e3
         kernel_ms = sum(v["ms_avg"] for k, v in kernels.items())
         line = {
             "metric": "MPix/s full export pixelpipe (100 MP raw); % MI355X HBM roofline",
-            "value": round(world * npix / 1e6 / (elapsed / args.steps), 2),
+            "value": round((1 if args.mode == "tiled" else world) * npix / 1e6 / (elapsed / args.steps), 2),
             "unit": "MPix/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.mode == "tiled" else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%d x %d RGGB u16 raw (%s), export pipe: %s; module defaults; one frame per GPU"
-                            % (width, height, args.size, " > ".join(n.op for n in nodes)),
+                "workload": "%d x %d RGGB u16 raw (%s), export pipe: %s; module defaults; %s"
+                            % (width, height, args.size, " > ".join(n.op for n in nodes),
+                               "one frame cut into %d row bands, one per GPU" % world if args.mode == "tiled"
+                               else "one frame per GPU"),
                 "frame_mpix": round(npix / 1e6, 2),
                 "executor": "dt_hip_pipe_process, %d launch groups (fusion %s)" % (executor.num_groups, "off" if args.no_fusion else "on"),
                 "pipe_algorithmic_bytes_per_px": pipe_bpp,
-                "pipe_hbm_frac": round(pipe_bpp * npix / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pipe_hbm_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "pipe_kernel_ms": round(kernel_ms, 4),
                 "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(kernels.items())},
             },

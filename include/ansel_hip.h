@@ -161,6 +161,16 @@ typedef struct dt_hip_highlights_data_t
 #define DT_HIP_HIGHLIGHTS_CLIP 0
 int dt_hip_iop_highlights_process(int devid, const dt_hip_piece_t *piece, const dt_hip_highlights_data_t *d,
                                   dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+/* Row-band form (a frame split over several devices): the bypass above depends on the clipped
+ * count of the WHOLE frame.  _deferred clips this band and journals into `journal` (device memory,
+ * DT_HIP_HIGHLIGHTS_JOURNAL_BYTES, zeroed by the call; its leading uint64 is the band's clipped
+ * count); the caller sums that uint64 over all bands, then _resolve restores the band's journalled
+ * photosites if the sum is below 25.  Mosaic (1-channel) input only. */
+#define DT_HIP_HIGHLIGHTS_JOURNAL_BYTES 320
+int dt_hip_iop_highlights_process_deferred(int devid, const dt_hip_piece_t *piece,
+                                           const dt_hip_highlights_data_t *d, dt_hip_mem_t dev_in,
+                                           dt_hip_mem_t dev_out, dt_hip_mem_t journal);
+int dt_hip_iop_highlights_resolve(int devid, dt_hip_mem_t dev_out, dt_hip_mem_t journal);
 
 /* demosaic: src/iop/demosaic.c:1041-1253 dispatching to
  * rcd_demosaic (src/iop/demosaic/rcd.c:274-564) or demosaic_ppg (src/iop/demosaic/ppg.c:20-217).
@@ -298,6 +308,50 @@ void dt_hip_pipe_set_fusion(dt_hip_pipe_t *pipe, int enabled);
 /* number of kernel groups the current node list is executed as (after fusion planning) */
 int dt_hip_pipe_num_groups(dt_hip_pipe_t *pipe);
 int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* ---- 3b. one frame over several devices: row bands ---------------------------------------- */
+/* Replaces default_process_tiling_cl() / _default_process_tiling_cl_ptp() (src/develop/tiling.c:842,
+ * :1394) for a frame that is split because there are several GPUs, not because it does not fit.
+ * The reference re-runs each module on overlapping tiles and accepts seam differences for modules
+ * whose result depends on the tile origin (RCD); here a band runs the frame's OWN RCD tile rows, so
+ * the assembled bands are bit-identical to the unsplit frame.
+ *
+ * A band owns frame rows [row0, row0 + rows) of every module output (all modules of the export
+ * pipe run at scale 1 with identical geometry; rawprepare's crop is the only offset).  Bands are
+ * cut on RCD tile rows: row0 = 94 * tv0 + 9 (0 for the first band).  The demosaic of a band reads
+ * `halo` = 9 mosaic rows of each neighbour; those rows are exchanged once, after the CFA stages:
+ *
+ *   dt_hip_pipe_band_begin()   CFA stages on the band's own rows, into a buffer laid out as
+ *                              [halo_top rows][rows][halo_bottom rows] of `row_bytes` each
+ *   -- caller: all-reduce `clipped_count` (a device uint64; NULL if the pipe has no highlights) --
+ *   dt_hip_pipe_band_resolve() highlights bypass decision on the summed count (own rows final)
+ *   -- caller: fill the halo rows from the neighbours' last / first own rows (send/recv) --
+ *   dt_hip_pipe_band_finish()  demosaic on the frame's tile rows, RGBA stages on the band's own
+ *                              rows -> dev_out_band (rows x width)
+ *
+ * dev_in_band holds the band's input rows only: input rows [crop_y + row0, crop_y + row0 + rows),
+ * full input width. */
+typedef struct dt_hip_band_t
+{
+  int32_t row0, rows;
+  int32_t halo_top, halo_bottom; /* mosaic rows needed from the bands above / below */
+  int32_t tile_row0, tile_row1;  /* RCD tile rows [tile_row0, tile_row1) of the frame */
+} dt_hip_band_t;
+typedef struct dt_hip_band_state_t
+{
+  dt_hip_mem_t halo_buf; /* NULL when the pipe has no demosaic node */
+  size_t row_bytes;
+  dt_hip_mem_t clipped_count;
+  void *priv;
+} dt_hip_band_state_t;
+/* pure function (no device needed): cut a height-row frame into n_bands bands for the given
+ * demosaic method (DT_HIP_DEMOSAIC_RCD, or -1 for a pipe without demosaic: 2-row aligned cuts) */
+int dt_hip_plan_bands(int width, int height, int demosaic_method, int n_bands, dt_hip_band_t *bands);
+int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_mem_t dev_in_band,
+                           dt_hip_band_state_t *state);
+int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state);
+int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state,
+                            dt_hip_mem_t dev_out_band);
 
 /* layout self-check for language bindings: sizeof() of the struct named `name` as compiled */
 size_t dt_hip_abi_sizeof(const char *name);

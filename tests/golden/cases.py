@@ -26,9 +26,15 @@ def _rgba():
     return np.ascontiguousarray(np.concatenate([a, b], axis=0))
 
 
+_LUTS = []
+
+
 def luts():
-    enc, dec = params.srgb_encode_lut(), params.srgb_decode_lut()
-    return enc, dec, params.unbounded_coeffs(enc), params.unbounded_coeffs(dec)
+    # module-lifetime arrays: the conversion structs carry raw host pointers into them
+    if not _LUTS:
+        enc, dec = params.srgb_encode_lut(), params.srgb_decode_lut()
+        _LUTS.append((enc, dec, params.unbounded_coeffs(enc), params.unbounded_coeffs(dec)))
+    return _LUTS[0]
 
 
 def cases(lut_ptrs=None):

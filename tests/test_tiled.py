@@ -1,0 +1,119 @@
+"""CPU: the multi-GPU row-band path (ansel_amd/tiled.py, include/ansel_hip.h section 3b) without a GPU.
+
+  * dt_hip_plan_bands() is a pure host function of libansel_hip.so: partition + halo properties
+  * world_size 2 over gloo: the real driver (begin -> all-reduce + send/recv -> finish) with the
+    oracle-backed engine of tests/band_engine.py; the gathered bands must equal the unsplit
+    oracle chain bit for bit, including the highlights bypass that depends on the count of the
+    WHOLE frame (20 clipped photosites: 10 per band -> bypass; 40: 20 per band -> clip)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import band_engine as be  # noqa: E402
+import checkers as ck  # noqa: E402
+from ansel_amd import abi, filmic, params, pipe, tiled  # noqa: E402
+
+needs_oracle = pytest.mark.skipif(ck.oracle() is None, reason="oracle/liboracle.so not built")
+
+
+@pytest.mark.parametrize("w,h", [(11648, 8736), (9504, 6336), (640, 480), (400, 300)])
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_rcd_bands_partition_the_frame_on_tile_rows(w, h, n):
+    num_vertical = 1 + (h - 19) // 94
+    if num_vertical < n:
+        with pytest.raises(Exception):
+            tiled.plan_bands(w, h, n)
+        return
+    bands = tiled.plan_bands(w, h, n)
+    assert bands[0].row0 == 0 and bands[-1].row0 + bands[-1].rows == h
+    assert bands[0].tile_row0 == 0 and bands[-1].tile_row1 == num_vertical
+    for k, b in enumerate(bands):
+        if k:
+            assert b.row0 == bands[k - 1].row0 + bands[k - 1].rows
+            assert b.tile_row0 == bands[k - 1].tile_row1
+            assert b.row0 == 94 * b.tile_row0 + 9 and b.halo_top == 9
+        else:
+            assert b.halo_top == 0
+        # the band's buffer holds every input row its tile rows read (rcd.c:296-300)
+        assert b.row0 - b.halo_top == 94 * b.tile_row0
+        assert b.row0 + b.rows + b.halo_bottom == min(94 * (b.tile_row1 - 1) + 112, h)
+        assert b.rows >= 9  # a neighbour's halo never spans more than one band
+
+
+def test_bands_without_demosaic_are_two_row_aligned():
+    bands = tiled.plan_bands(640, 486, 4, demosaic_method=-1)
+    assert sum(b.rows for b in bands) == 486
+    assert all(b.row0 % 2 == 0 and b.halo_top == 0 and b.halo_bottom == 0 for b in bands)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _nodes(w, h, lut):
+    coeffs = params.unbounded_coeffs(lut)
+    return pipe.light_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, with_filmic=True,
+                                 filmic=filmic.default_data())
+
+
+def _rank_main(rank, world, port, w, h, n_top, n_bottom, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lut = params.srgb_encode_lut()
+        nodes = _nodes(w, h, lut)
+        raw = be.test_frame(w, h, n_top, n_bottom)
+        bands = tiled.plan_bands(w, h, world, tiled.pipe_demosaic_method(nodes))
+        b = bands[rank]
+        engine = be.OracleBandEngine(nodes, w, h)
+        out = np.zeros((b.rows, w, 4), np.uint16)
+        tiled.process_band(engine, bands, rank, raw[b.row0:b.row0 + b.rows], out, w, dist=dist)
+        np.save(os.path.join(outdir, "band%d.npy" % rank), out)
+    finally:
+        dist.destroy_process_group()
+
+
+@needs_oracle
+@pytest.mark.parametrize("n_top,n_bottom", [(10, 10), (20, 20)])
+def test_two_ranks_over_gloo_equal_the_unsplit_frame(tmp_path, n_top, n_bottom):
+    import torch.multiprocessing as mp
+    w, h, world = 256, 400, 2
+    port = _free_port()
+    mp.spawn(_rank_main, args=(world, port, w, h, n_top, n_bottom, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("band%d.npy" % r)) for r in range(world)], axis=0)
+    lut = params.srgb_encode_lut()
+    nodes = _nodes(w, h, lut)
+    raw = be.test_frame(w, h, n_top, n_bottom)
+    want = be.whole_frame(nodes, raw, w, h)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    # the two cases really differ in the bypass decision: each band alone sees < 25 clipped photosites
+    clipped_frame = int((raw == 65535).sum())
+    assert (clipped_frame < 25) == (n_top + n_bottom < 25)
+
+
+@needs_oracle
+@pytest.mark.parametrize("n_top,n_bottom", [(4, 30), (12, 8)])
+def test_local_protocol_matches_the_unsplit_frame_for_three_bands(n_top, n_bottom):
+    """same protocol, all bands in one process (the data motion the single-GPU test uses)"""
+    w, h, n = 256, 500, 3
+    lut = params.srgb_encode_lut()
+    nodes = _nodes(w, h, lut)
+    raw = be.test_frame(w, h, n_top, n_bottom)
+    bands = tiled.plan_bands(w, h, n)
+    engine = be.OracleBandEngine(nodes, w, h)
+    outs = [np.zeros((b.rows, w, 4), np.uint16) for b in bands]
+    tiled.process_bands_locally(engine, bands, [raw[b.row0:b.row0 + b.rows] for b in bands], outs, w)
+    assert np.array_equal(np.concatenate(outs, axis=0), be.whole_frame(nodes, raw, w, h))
