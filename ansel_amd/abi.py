@@ -87,6 +87,16 @@ class ExposureData(C.Structure):
     _fields_ = [("black", C.c_float), ("scale", C.c_float)]
 
 
+class DiffuseData(C.Structure):
+    """dt_hip_diffuse_data_t == dt_iop_diffuse_params_t (src/iop/diffuse.c:76-105) + pipe->iscale"""
+    _fields_ = [("iterations", C.c_int), ("sharpness", C.c_float), ("radius", C.c_int),
+                ("regularization", C.c_float), ("variance_threshold", C.c_float),
+                ("anisotropy_first", C.c_float), ("anisotropy_second", C.c_float),
+                ("anisotropy_third", C.c_float), ("anisotropy_fourth", C.c_float), ("threshold", C.c_float),
+                ("first", C.c_float), ("second", C.c_float), ("third", C.c_float), ("fourth", C.c_float),
+                ("radius_center", C.c_int), ("iscale", C.c_float)]
+
+
 class Conversion(C.Structure):
     _fields_ = [("matrix", m34), ("clip_matrix", m34), ("has_clipping", C.c_int),
                 ("nonlinear_source", C.c_int), ("nonlinear_target", C.c_int), ("blue_mapping", C.c_int),

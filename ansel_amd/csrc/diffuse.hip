@@ -1,0 +1,424 @@
+// diffuse.hip -- diffuse or sharpen on gfx950.
+//
+// Reference: process(), src/iop/diffuse.c:1155-1258; wavelets_process() :978-1106;
+// decompose_2D_Bspline(), src/pixel/bspline.h:351-377; heat_PDE_diffusion(), diffuse.c:760-968.
+// (process_cl() :1436-1580 runs the same two steps as OpenCL kernels diffuse_pde / filmic_bspline_*.)
+//
+// Per iteration: `scales` a-trous B-spline analyses (dilation 2^s) that each leave a detail plane
+// HF[s] and a low-pass plane, then `scales` PDE updates from coarse to fine, each a 3x3 stencil at
+// dilation 2^s over HF[s] and the running low-pass.  Everything is a float4 plane resident in HBM;
+// algorithmic traffic is 48 B/px per analysis (in -> LF + HF) and 48 B/px per PDE (HF + LF -> out).
+//
+// Device layout of the analysis: the reference blurs vertically into a row buffer, clips negatives,
+// blurs that row horizontally, clips again.  Here one workgroup owns a piece of one row: the
+// vertically blurred, clipped samples it needs are built in LDS (5 global taps each, L2/MALL hits
+// because workgroups walk the rows in dilation order), the horizontal taps then come from LDS.  At
+// dilation m the horizontal taps of column j are j-2m..j+2m, so a workgroup takes R adjacent
+// columns x T steps of m (R*16 B = one 128-byte line per step) and pays a (T+4)/T halo.  Border
+// taps clamp to column 0 / width-1 whatever the dilation (bspline.h:143-149), so those two columns
+// are blurred by every workgroup as well.
+#include "hip_common.h"
+
+#include <math.h>
+
+using namespace ansel;
+
+namespace
+{
+
+#define DIFFUSE_MAX_SCALES 10             // MAX_NUM_SCALES, diffuse.c:75
+#define BSPLINE_SIGMA 1.0553651328015339f // B_SPLINE_SIGMA, bspline.h:39
+#define PDE_KAPPA 0.25f                   // KAPPA, diffuse.c:625
+
+// the MAX(a, b) macro of the reference: a > b ? a : b (a NaN in b passes through)
+__device__ __forceinline__ float max_first(const float a, const float b) { return a > b ? a : b; }
+// dt_simd_max_zero(), src/system/simd.h:108-114
+__device__ __forceinline__ float max_zero(const float v) { return isfinite(v) ? max_first(v, 0.0f) : 0.0f; }
+__device__ __forceinline__ int clampi(const int v, const int lo, const int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// sparse_scalar_product(), bspline.h:86-118: left-to-right weighted sum, then MAX(0, .)
+__device__ __forceinline__ float tap5(const float a, const float b, const float c, const float d, const float e)
+{
+  const float s = 0.0625f * a + 0.25f * b + 0.375f * c + 0.25f * d + 0.0625f * e;
+  return max_first(0.0f, s);
+}
+__device__ __forceinline__ float4 tap5(const float4 a, const float4 b, const float4 c, const float4 d, const float4 e)
+{
+  return make_float4(tap5(a.x, b.x, c.x, d.x, e.x), tap5(a.y, b.y, c.y, d.y, e.y), tap5(a.z, b.z, c.z, d.z, e.z),
+                     tap5(a.w, b.w, c.w, d.w, e.w));
+}
+
+// row walked by workgroup row `b`: rows of one dilation class back to back (0, m, 2m, ... then
+// 1, m+1, ...), the order dwt_interleave_rows() (src/pixel/dwt.h:93-104) gives the CPU for the
+// same reason -- consecutive workgroups share 4 of their 5 vertical taps.  Returns -1 past the end.
+__device__ __forceinline__ int walk_row(const int b, const int height, const int mult)
+{
+  if(height <= mult) return b < height ? b : -1;
+  const int per_pass = (height + mult - 1) / mult;
+  const int row = (b % per_pass) * mult + b / per_pass;
+  return row < height ? row : -1;
+}
+
+__device__ __forceinline__ float4 vertical5(const float4 *__restrict__ in, const int width, const int height,
+                                            const int row, const int col, const int mult, float4 *centre)
+{
+  const float4 a = in[(size_t)clampi(row - 2 * mult, 0, height - 1) * width + col];
+  const float4 b = in[(size_t)clampi(row - mult, 0, height - 1) * width + col];
+  const float4 c = in[(size_t)row * width + col];
+  const float4 d = in[(size_t)clampi(row + mult, 0, height - 1) * width + col];
+  const float4 e = in[(size_t)clampi(row + 2 * mult, 0, height - 1) * width + col];
+  if(centre) *centre = c;
+  return tap5(a, b, c, d, e);
+}
+
+// R adjacent columns x T steps of the dilation; R * T == 256
+template <int R, int T>
+__global__ __launch_bounds__(256) void bspline_decompose(const float4 *__restrict__ in, float4 *__restrict__ hf,
+                                                         float4 *__restrict__ lf, const int width, const int height,
+                                                         const int mult, const int groups)
+{
+  __shared__ float4 vert[(T + 4) * R + 2];
+  const int row = walk_row(blockIdx.y, height, mult);
+  if(row < 0) return;
+  // blockIdx.x = step tile * groups + residue group
+  const int group = blockIdx.x % groups, tile = blockIdx.x / groups;
+  const int r0 = group * R, k0 = tile * T;
+  const int tid = threadIdx.x;
+  const int r = tid % R, k = tid / R;
+  const int col = r0 + r + (k0 + k) * mult;
+  float4 centre = make_float4(0.f, 0.f, 0.f, 0.f);
+  // own sample -> slot (k + 2) * R + r
+  if(col < width) vert[(k + 2) * R + r] = vertical5(in, width, height, row, col, mult, &centre);
+  // halo: steps k0-2, k0-1, k0+T, k0+T+1
+  if(tid < 4 * R)
+  {
+    const int hr = tid % R, hs = tid / R; // hs 0..3
+    const int hk = hs < 2 ? hs - 2 : T + hs - 2;
+    const int hcol = r0 + hr + (k0 + hk) * mult;
+    if(hcol >= 0 && hcol < width) vert[(hk + 2) * R + hr] = vertical5(in, width, height, row, hcol, mult, nullptr);
+  }
+  else if(tid == 4 * R)
+    vert[(T + 4) * R] = vertical5(in, width, height, row, 0, mult, nullptr);
+  else if(tid == 4 * R + 1)
+    vert[(T + 4) * R + 1] = vertical5(in, width, height, row, width - 1, mult, nullptr);
+  __syncthreads();
+  if(col >= width) return;
+  float4 t[5];
+#pragma unroll
+  for(int s = -2; s <= 2; s++)
+  {
+    const int c = col + s * mult;
+    t[s + 2] = c < 0 ? vert[(T + 4) * R] : (c > width - 1 ? vert[(T + 4) * R + 1] : vert[(k + s + 2) * R + r]);
+  }
+  const float4 low = tap5(t[0], t[1], t[2], t[3], t[4]);
+  const size_t o = (size_t)row * width + col;
+  lf[o] = low;
+  nt_store(hf + o, make_float4(centre.x - low.x, centre.y - low.y, centre.z - low.z, centre.w - low.w));
+}
+
+struct pde_args
+{
+  int width, height, mult;
+  float anisotropy[4];
+  int kind[4]; // 0 isotrope, 1 isophote, 2 gradient (check_isotropy_mode(), diffuse.c:151-161)
+  float variance_threshold, regularization;
+  float abcd[4], strength;
+};
+
+// dt_fast_expf(), src/math/math.h:254-267.  The float -> int conversion of an out-of-range or NaN
+// value is INT_MIN on the reference's target (cvttss2si), which its k0 > 0 test turns into 0.
+__device__ __forceinline__ float fast_expf(const float x)
+{
+  const float t = 1065353216.0f + x * 11401300.0f;
+  int k = (t > -2147483648.0f && t < 2147483648.0f) ? (int)t : 0;
+  k = k > 0 ? k : 0;
+  return __int_as_float(k);
+}
+
+// diffuse.c:851-866: magnitude of a 2-vector and {cos^2, sin^2, cos*sin} of its argument
+__device__ __forceinline__ float direction(float gx, float gy, float &cos2, float &sin2, float &cs)
+{
+  const float mag = sqrtf(gx * gx + gy * gy);
+  const float nonzero = (mag != 0.0f) ? 1.0f : 0.0f;
+  const float inv = 1.0f / (mag + (1.0f - nonzero));
+  gx = gx * inv + (1.0f - nonzero);
+  gy = gy * inv;
+  cos2 = gx * gx;
+  sin2 = gy * gy;
+  cs = gx * gy;
+  return mag;
+}
+
+// compute_kernel(), diffuse.c:725-757, convolved on the spot with the 9 samples p[] (k = 0..8 order
+// of the reference's accumulation loop, :913-919): d = kern[k] * p[k] + d
+__device__ __forceinline__ float convolve(const int kind, const float c2, const float cs, const float cos2,
+                                          const float sin2, const float p[9])
+{
+  float k0, k1, k2, k3, k4;
+  if(kind == 0)
+  {
+    k0 = 0.25f; k1 = 0.5f; k2 = 0.25f; k3 = 0.5f; k4 = -3.0f; // isotrope_laplacian(), :705-723
+  }
+  else
+  {
+    float a00, a11, a01;
+    if(kind == 1)
+    {
+      a00 = cos2 + c2 * sin2; // rotation_matrix_isophote(), :646-659
+      a11 = c2 * cos2 + sin2;
+      a01 = (c2 - 1.0f) * cs;
+    }
+    else
+    {
+      a00 = c2 * cos2 + sin2; // rotation_matrix_gradient(), :661-674
+      a11 = cos2 + c2 * sin2;
+      a01 = (1.0f - c2) * cs;
+    }
+    k0 = a01 * 0.5f; // build_matrix(), :677-703
+    k1 = a11;
+    k2 = -k0;
+    k3 = a00;
+    k4 = -2.0f * (a00 + a11);
+  }
+  float d = 0.0f;
+  d = k0 * p[0] + d;
+  d = k1 * p[1] + d;
+  d = k2 * p[2] + d;
+  d = k3 * p[3] + d;
+  d = k4 * p[4] + d;
+  d = k3 * p[5] + d;
+  d = k2 * p[6] + d;
+  d = k1 * p[7] + d;
+  d = k0 * p[8] + d;
+  return d;
+}
+
+__device__ __forceinline__ float pde_channel(const float H[9], const float L[9], const pde_args &a)
+{
+  // HF/LF energy over the 3x3 support, diffuse.c:823-845
+  float energy = 0.0f;
+#pragma unroll
+  for(int k = 0; k < 9; k++)
+  {
+    const float safe = max_zero(L[k] - 1e-8f) + 1e-8f;
+    const float ratio = H[k] / safe;
+    energy += ratio * ratio;
+  }
+  energy = max_zero(a.variance_threshold + energy * a.regularization - 1e-8f) + 1e-8f;
+  float cos2g, sin2g, csg, cos2l, sin2l, csl;
+  const float mg = direction((L[7] - L[1]) * 0.5f, (L[5] - L[3]) * 0.5f, cos2g, sin2g, csg);
+  const float ml = direction((H[7] - H[1]) * 0.5f, (H[5] - H[3]) * 0.5f, cos2l, sin2l, csl);
+  const float d0 = convolve(a.kind[0], fast_expf(-mg * a.anisotropy[0]), csg, cos2g, sin2g, L);
+  const float d1 = convolve(a.kind[1], fast_expf(-ml * a.anisotropy[1]), csl, cos2l, sin2l, L);
+  const float d2 = convolve(a.kind[2], fast_expf(-mg * a.anisotropy[2]), csg, cos2g, sin2g, H);
+  const float d3 = convolve(a.kind[3], fast_expf(-ml * a.anisotropy[3]), csl, cos2l, sin2l, H);
+  float update = d0 * a.abcd[0];
+  update = d1 * a.abcd[1] + update;
+  update = d2 * a.abcd[2] + update;
+  update = d3 * a.abcd[3] + update;
+  const float acc = H[4] * a.strength + update / energy;
+  return max_zero(acc + L[4]);
+}
+
+__global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf, const float4 *__restrict__ lf,
+                                                   float4 *__restrict__ out, const pde_args a, const int final_pass)
+{
+  const int row = walk_row(blockIdx.y, a.height, a.mult);
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if(row < 0 || col >= a.width) return;
+  const size_t rows[3] = { (size_t)clampi(row - a.mult, 0, a.height - 1) * a.width, (size_t)row * a.width,
+                           (size_t)clampi(row + a.mult, 0, a.height - 1) * a.width };
+  const int cols[3] = { clampi(col - a.mult, 0, a.width - 1), col, clampi(col + a.mult, 0, a.width - 1) };
+  float4 H4[9], L4[9];
+#pragma unroll
+  for(int ii = 0; ii < 3; ii++)
+#pragma unroll
+    for(int jj = 0; jj < 3; jj++)
+    {
+      H4[3 * ii + jj] = hf[rows[ii] + cols[jj]];
+      L4[3 * ii + jj] = lf[rows[ii] + cols[jj]];
+    }
+  float H[9], L[9];
+  float4 o;
+#pragma unroll
+  for(int k = 0; k < 9; k++) { H[k] = H4[k].x; L[k] = L4[k].x; }
+  o.x = pde_channel(H, L, a);
+#pragma unroll
+  for(int k = 0; k < 9; k++) { H[k] = H4[k].y; L[k] = L4[k].y; }
+  o.y = pde_channel(H, L, a);
+#pragma unroll
+  for(int k = 0; k < 9; k++) { H[k] = H4[k].z; L[k] = L4[k].z; }
+  o.z = pde_channel(H, L, a);
+#pragma unroll
+  for(int k = 0; k < 9; k++) { H[k] = H4[k].w; L[k] = L4[k].w; }
+  o.w = pde_channel(H, L, a);
+  const size_t idx = rows[1] + col;
+  if(final_pass) nt_store(out + idx, o);
+  else out[idx] = o;
+}
+
+inline float sqf(const float x) { return x * x; }
+
+// equivalent_sigma_at_step(), bspline.h:55-66
+float sigma_at_step(const float sigma, const unsigned s)
+{
+  float acc = sigma;
+  for(unsigned k = 1; k <= s; k++) acc = sqrtf(sqf(acc) + sqf(exp2f((float)k) * sigma));
+  return acc;
+}
+
+// num_steps_to_reach_equivalent_sigma(), bspline.h:68-80
+unsigned steps_to_sigma(const float sigma_filter, const float sigma_final)
+{
+  unsigned s = 0;
+  float radius = sigma_filter;
+  while(radius < sigma_final)
+  {
+    ++s;
+    radius = sqrtf(sqf(radius) + sqf((float)(1 << s) * sigma_filter));
+  }
+  return s + 1;
+}
+
+int scales_of(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d)
+{
+  const float zoom = (float)(d->iscale / piece->roi_in.scale);
+  const float final_radius = (float)(d->radius + d->radius_center) * 2.0f / zoom;
+  const int s = (int)steps_to_sigma(BSPLINE_SIGMA, final_radius);
+  return s < 1 ? 1 : (s > DIFFUSE_MAX_SCALES ? DIFFUSE_MAX_SCALES : s);
+}
+
+int launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, float4 *lf, int w, int h, int mult)
+{
+  const int steps = (w + mult - 1) / mult; // steps of the dilation across a row
+  const int rows = (h <= mult) ? h : ((h + mult - 1) / mult) * mult;
+  launch_scope ls(devid, "diffuse_decompose");
+  if(mult == 1)
+    bspline_decompose<1, 256><<<dim3((steps + 255) / 256, rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1);
+  else if(mult == 2)
+    bspline_decompose<2, 128><<<dim3((steps + 127) / 128, rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1);
+  else if(mult == 4)
+    bspline_decompose<4, 64><<<dim3((steps + 63) / 64, rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1);
+  else
+  {
+    const int groups = mult / 8;
+    bspline_decompose<8, 32><<<dim3(((steps + 31) / 32) * groups, rows), 256, 0, s>>>(in, hf, lf, w, h, mult, groups);
+  }
+  return check_launch("diffuse_decompose");
+}
+
+} // namespace
+
+extern "C" {
+
+int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d,
+                               dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
+  if(piece->channels != 4)
+  {
+    set_last_error("diffuse: needs a 4-channel float input");
+    return DT_HIP_INVALID_ARG;
+  }
+  if(d->threshold > 0.0f)
+  {
+    set_last_error("diffuse: luminance-masked inpainting (threshold > 0) is not implemented on device");
+    return DT_HIP_INVALID_ARG;
+  }
+  const int w = piece->roi_out.width, h = piece->roi_out.height;
+  if(w <= 0 || h <= 0) return DT_HIP_SUCCESS;
+  if(!(d->iscale > 0.0f) || !(piece->roi_in.scale > 0.0)) return DT_HIP_INVALID_ARG;
+  const size_t plane = (size_t)w * h * sizeof(float4);
+  const float zoom = (float)(d->iscale / piece->roi_in.scale);
+  const int scales = scales_of(piece, d);
+  const int it_req = (int)ceilf((float)d->iterations);
+  const int iterations = it_req > 1 ? it_req : 1;
+
+  // planes: HF[scales], two low-pass ping-pong, two iteration ping-pong (diffuse.c:1167-1195)
+  float4 *hf[DIFFUSE_MAX_SCALES] = { nullptr };
+  float4 *lf[2] = { nullptr, nullptr }, *tmp[2] = { nullptr, nullptr };
+  bool ok = true;
+  for(int s = 0; s < scales; s++) ok &= (hf[s] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
+  for(int k = 0; k < 2; k++) ok &= (lf[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
+  if(iterations > 1)
+    for(int k = 0; k < 2 && k < iterations - 1; k++)
+      ok &= (tmp[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
+  int err = ok ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
+
+  pde_args a;
+  memset(&a, 0, sizeof(a));
+  a.width = w;
+  a.height = h;
+  const float user_aniso[4] = { d->anisotropy_first, d->anisotropy_second, d->anisotropy_third, d->anisotropy_fourth };
+  for(int k = 0; k < 4; k++)
+  {
+    a.anisotropy[k] = sqf(user_aniso[k]); // compute_anisotropy_factor(), diffuse.c:970-976
+    a.kind[k] = user_aniso[k] == 0.0f ? 0 : (user_aniso[k] > 0.0f ? 1 : 2);
+  }
+  const float regularization = powf(10.0f, d->regularization) - 1.0f; // diffuse.c:999-1000
+  a.variance_threshold = powf(10.0f, d->variance_threshold);
+  const float speed[4] = { d->first, d->second, d->third, d->fourth };
+
+  hipStream_t st = stream_of(devid);
+  const float4 *src = (const float4 *)dev_in;
+  for(int it = 0; err == DT_HIP_SUCCESS && it < iterations; it++)
+  {
+    // iteration ping-pong, diffuse.c:1223-1249 (tmp[0] = "temp2", tmp[1] = "temp1")
+    float4 *dst = (it == iterations - 1) ? (float4 *)dev_out : tmp[it % 2];
+    const float4 *level = src;
+    float4 *residual = lf[0];
+    for(int s = 0; s < scales && err == DT_HIP_SUCCESS; s++)
+    {
+      float4 *low = lf[s % 2];
+      err = launch_decompose(devid, st, level, hf[s], low, w, h, 1 << s);
+      level = low;
+      residual = low;
+    }
+    float4 *pp[2] = { residual == lf[1] ? lf[0] : lf[1], residual };
+    const float4 *cur = residual;
+    int count = 0;
+    for(int s = scales - 1; s >= 0 && err == DT_HIP_SUCCESS; s--, count++)
+    {
+      // per-band constants, diffuse.c:1053-1074
+      const float real_radius = sigma_at_step(BSPLINE_SIGMA, (unsigned)s) * zoom;
+      a.regularization = regularization / 9.0f * sqf(real_radius);
+      const float norm = expf(-sqf(real_radius - (float)d->radius_center) / sqf((float)d->radius));
+      for(int k = 0; k < 4; k++) a.abcd[k] = speed[k] * PDE_KAPPA * norm;
+      a.strength = d->sharpness * norm + 1.0f;
+      a.mult = 1 << s;
+      float4 *to = (s == 0) ? dst : pp[count % 2];
+      const int rows = (h <= a.mult) ? h : ((h + a.mult - 1) / a.mult) * a.mult;
+      {
+        launch_scope ls(devid, "diffuse_pde");
+        diffuse_pde<<<dim3((w + 255) / 256, rows), 256, 0, st>>>(hf[s], cur, to, a, s == 0);
+      }
+      err = check_launch("diffuse_pde");
+      cur = to;
+    }
+    src = dst;
+  }
+  for(int s = 0; s < scales; s++)
+    if(hf[s]) dt_hip_release_mem_object(hf[s]);
+  for(int k = 0; k < 2; k++)
+  {
+    if(lf[k]) dt_hip_release_mem_object(lf[k]);
+    if(tmp[k]) dt_hip_release_mem_object(tmp[k]);
+  }
+  return err;
+}
+
+// tiling_callback(), diffuse.c:585-610
+void dt_hip_iop_diffuse_tiling(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, dt_hip_tiling_t *tiling)
+{
+  const int scales = scales_of(piece, d);
+  tiling->factor = 6.0625f + scales;
+  tiling->factor_cl = 6.0625f + scales;
+  tiling->maxbuf = 1.0f;
+  tiling->maxbuf_cl = 1.0f;
+  tiling->overhead = 0;
+  tiling->overlap = 1 << scales;
+  tiling->xalign = 1;
+  tiling->yalign = 1;
+}
+
+} // extern "C"

@@ -139,3 +139,27 @@ def channelmixerrgb(adaptation=abi.DT_HIP_ADAPTATION_CAT16, illuminant_xy=(0.345
     d.p = float(np.power(np.float32(0.818155) / np.float32(d.illuminant[2]), np.float32(0.0834)))
     d.version = version
     return d
+
+
+# ---- diffuse or sharpen (src/iop/diffuse.c) ---------------------------------------------------
+def diffuse(preset="default", iscale=1.0, **over):
+    """dt_hip_diffuse_data_t from the module defaults ($DEFAULT annotations, diffuse.c:79-101) or one
+    of the presets of init_presets() (diffuse.c:298-583)"""
+    base = dict(iterations=1, sharpness=0.0, radius=8, regularization=0.0, variance_threshold=0.0,
+                anisotropy_first=0.0, anisotropy_second=0.0, anisotropy_third=0.0, anisotropy_fourth=0.0,
+                threshold=0.0, first=0.0, second=0.0, third=0.0, fourth=0.0, radius_center=0)
+    presets = {
+        "default": {},
+        # "lens deblur: soft", diffuse.c:304-325
+        "lens_deblur_soft": dict(regularization=1.0, anisotropy_first=2.0, anisotropy_third=2.0, first=-0.25,
+                                 second=0.125, third=-0.125, fourth=0.0625, radius=8, iterations=8),
+        # "fast local contrast", diffuse.c:561-583
+        "fast_local_contrast": dict(radius_center=512, radius=512, anisotropy_third=5.0, third=-0.5, iterations=1),
+    }
+    base.update(presets[preset])
+    base.update(over)
+    d = abi.DiffuseData()
+    for k, v in base.items():
+        setattr(d, k, v)
+    d.iscale = iscale
+    return d

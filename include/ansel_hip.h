@@ -288,6 +288,30 @@ int dt_hip_iop_filmicrgb_process(int devid, const dt_hip_piece_t *piece, const d
 int dt_hip_export_convert_u16(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 int dt_hip_export_convert_u8(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
+/* diffuse or sharpen: process(), src/iop/diffuse.c:1155-1258 -> wavelets_process() (:978-1106),
+ * decompose_2D_Bspline() (src/pixel/bspline.h:351-377), heat_PDE_diffusion() (diffuse.c:760-968).
+ * The struct is dt_iop_diffuse_params_t (diffuse.c:76-105; commit_params memcpy's it, :133-138)
+ * followed by pipe->iscale, which process() reads through dt_dev_get_module_scale()
+ * (src/develop/imageop.c:134-137).  threshold > 0 (luminance-masked inpainting with gaussian
+ * noise, diffuse.c:1109-1152) is not implemented on device: DT_HIP_INVALID_ARG. */
+typedef struct dt_hip_diffuse_data_t
+{
+  int iterations;
+  float sharpness;
+  int radius;
+  float regularization;
+  float variance_threshold;
+  float anisotropy_first, anisotropy_second, anisotropy_third, anisotropy_fourth;
+  float threshold;
+  float first, second, third, fourth;
+  int radius_center;
+  float iscale; /* dt_dev_pixelpipe_t::iscale, 1 for a full-resolution export */
+} dt_hip_diffuse_data_t;
+int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d,
+                               dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+/* tiling_callback(), diffuse.c:585-610 */
+void dt_hip_iop_diffuse_tiling(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, dt_hip_tiling_t *tiling);
+
 /* ---- 3. export-pipe executor ----------------------------------------------------------- */
 /* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)
  * for an export: an ordered list of module nodes, each with its piece view and committed data,

@@ -79,6 +79,7 @@ typedef struct dt_dev_pixelpipe_t
   int type;
   int mask_display;
   dt_develop_t *dev;
+  float iscale;
 } dt_dev_pixelpipe_t;
 
 typedef struct dt_dev_pixelpipe_iop_t
@@ -95,6 +96,9 @@ typedef struct dt_iop_module_t
   dt_develop_t *dev;
   void *global_data;
 } dt_iop_module_t;
+
+/* src/develop/imageop.c:134-137 */
+#define dt_dev_get_module_scale(pipe, roi_in) ((float)((pipe)->iscale / (roi_in)->scale))
 
 /* src/common/imagebuf.h: plain float copy of a w x h x ch buffer */
 static inline void dt_iop_image_copy_by_size(float *const out, const float *const in, const size_t w,

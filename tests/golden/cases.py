@@ -80,4 +80,12 @@ def cases(lut_ptrs=None):
             yield ("filmic_v%d_%d%d" % (ver, curves[0], curves[1]), "filmicrgb", rgb, filmic.commit(p), img, img.shape)
     yield ("filmic_split_v4", "filmicrgb", rgb, filmic.commit(filmic.UserParams.defaults(version=3, preserve_color=0, saturation=-15.0)), img, img.shape)
     yield ("filmic_no_export_profile", "filmicrgb", rgb, filmic.commit(filmic.UserParams.defaults(), use_output_profile=False), img, img.shape)
+    # diffuse or sharpen: module defaults, two presets (several scales and iterations), mixed anisotropies
+    yield ("diffuse_default", "diffuse", rgb, params.diffuse(), img, img.shape)
+    yield ("diffuse_deblur", "diffuse", rgb, params.diffuse("lens_deblur_soft", iterations=3), img, img.shape)
+    yield ("diffuse_contrast", "diffuse", rgb, params.diffuse("fast_local_contrast", radius=24, radius_center=12), img, img.shape)
+    yield ("diffuse_mixed", "diffuse", rgb,
+           params.diffuse("lens_deblur_soft", iterations=2, anisotropy_first=-2.0, anisotropy_second=1.5,
+                          anisotropy_fourth=-3.0, variance_threshold=-0.5, regularization=2.5, sharpness=0.2),
+           img, img.shape)
     del keep

@@ -143,3 +143,33 @@ def test_filmic_commit_matches_reference_solver():
                     r.ref_filmicrgb_commit(C.byref(p), C.byref(d))
                     filmic.set_profiles(d)
                     assert bytes(d) == bytes(filmic.commit(p)), (ver, sh, hl, extra)
+
+
+DIFFUSE_CASES = [
+    ("default", {}),
+    ("default", dict(sharpness=0.3, radius=16)),
+    ("lens_deblur_soft", dict(iterations=3)),
+    ("lens_deblur_soft", dict(iterations=2, anisotropy_first=-2.0, anisotropy_second=1.5, anisotropy_fourth=-3.0,
+                              variance_threshold=-0.5, regularization=2.5)),
+    ("fast_local_contrast", dict(radius=40, radius_center=24)),
+]
+
+
+@pytest.mark.parametrize("preset,over", DIFFUSE_CASES)
+@pytest.mark.parametrize("imgname", ["scene", "adversarial"])
+def test_diffuse(preset, over, imgname):
+    w, h = 150, 97
+    img = synth.rgba_image(w, h, seed=4, lo=-0.02, hi=1.4) if imgname == "scene" else synth.adversarial_rgba(w, h)
+    d = params.diffuse(preset, **over)
+    a, b = _pair("diffuse", abi.Piece.make(w, h), d, img, img.shape)
+    _exact(a, b, "diffuse %s %s" % (preset, imgname))
+    assert np.isfinite(a).all()
+
+
+def test_diffuse_scaled_roi():
+    """zoom = iscale / roi.scale enters the scale count and the per-band radii"""
+    w, h = 120, 80
+    img = synth.rgba_image(w, h, seed=5)
+    piece = abi.Piece.make(w, h, roi_in=abi.Roi.make(0, 0, w, h, 0.5), roi_out=abi.Roi.make(0, 0, w, h, 0.5))
+    a, b = _pair("diffuse", piece, params.diffuse("lens_deblur_soft", iterations=2), img, img.shape)
+    _exact(a, b, "diffuse scale 0.5")

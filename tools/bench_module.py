@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Time one module of libansel_hip.so on a synthetic float4 plane resident in HBM.
+
+    python tools/bench_module.py diffuse --size 60MP --preset lens_deblur_soft --iterations 2
+
+Prints per-kernel HIP-event averages and the module's algorithmic-bytes roofline fraction."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("module")
+    ap.add_argument("--size", default="60MP")
+    ap.add_argument("--preset", default="lens_deblur_soft")
+    ap.add_argument("--iterations", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from ansel_amd import abi, lib, params, synth
+    l = lib.init()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+    lib.check(l.dt_hip_set_stream(0, C.c_void_p(stream.cuda_stream)), "set_stream")
+    w, h = synth.SIZES[args.size] if args.size in synth.SIZES else map(int, args.size.split("x"))
+    tile = synth.rgba_image(1024, 1024, seed=3, lo=0.0, hi=1.3)
+    ty, tx = -(-h // 1024), -(-w // 1024)
+    img = torch.from_numpy(tile).to(dev).repeat(ty, tx, 1)[:h, :w].contiguous()
+    out = torch.empty_like(img)
+    piece = abi.Piece.make(w, h)
+    if args.module == "diffuse":
+        over = {} if args.iterations is None else {"iterations": args.iterations}
+        d = params.diffuse(args.preset, **over)
+        scales = None
+        fn = l.dt_hip_iop_diffuse_process
+    else:
+        raise SystemExit("unknown module")
+
+    def run():
+        lib.check(fn(0, C.byref(piece), C.byref(d), img.data_ptr(), out.data_ptr()), args.module)
+
+    run()
+    torch.cuda.synchronize()
+    l.dt_hip_events_reset(0)
+    l.dt_hip_events_enable(0, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    l.dt_hip_events_enable(0, 0)
+    maxk = 64
+    tags = (C.c_char_p * maxk)()
+    tms = (C.c_float * maxk)()
+    cnt = (C.c_int * maxk)()
+    nk = l.dt_hip_events_profiling(0, tags, tms, cnt, maxk)
+    kernels = {tags[i].decode(): {"ms_total_per_step": tms[i] / args.steps, "launches_per_step": cnt[i] / args.steps,
+                                  "ms_avg": tms[i] / max(cnt[i], 1)} for i in range(min(nk, maxk))}
+    npix = w * h
+    res = {"module": args.module, "size": "%dx%d" % (w, h), "ms_per_call": round(ms, 3), "kernels": kernels}
+    for k, v in kernels.items():
+        v["GBps_at_48B_per_px"] = round(48 * npix / (v["ms_avg"] * 1e-3) / 1e9, 1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
