@@ -97,6 +97,22 @@ class DiffuseData(C.Structure):
                 ("radius_center", C.c_int), ("iscale", C.c_float)]
 
 
+class DenoiseprofileData(C.Structure):
+    """dt_hip_denoiseprofile_data_t: the fields of dt_iop_denoiseprofile_data_t (src/iop/denoiseprofile.c:352-371)
+    the wavelets path reads + the white-balance coefficients of the input buffer descriptor"""
+    _fields_ = [("radius", C.c_float), ("nbhood", C.c_float), ("strength", C.c_float), ("shadows", C.c_float),
+                ("bias", C.c_float), ("scattering", C.c_float), ("central_pixel_weight", C.c_float),
+                ("overshooting", C.c_float), ("a", f3), ("b", f3), ("mode", C.c_int),
+                ("force", (C.c_float * 7) * 6), ("wb_adaptive_anscombe", C.c_int),
+                ("fix_anscombe_and_nlmeans_norm", C.c_int), ("use_new_vst", C.c_int),
+                ("wavelet_color_mode", C.c_int), ("wb_coeffs", f4)]
+
+
+DT_HIP_DENOISEPROFILE_WAVELETS = 1
+DT_HIP_DENOISEPROFILE_RGB = 0
+DT_HIP_DENOISEPROFILE_Y0U0V0 = 1
+
+
 class Conversion(C.Structure):
     _fields_ = [("matrix", m34), ("clip_matrix", m34), ("has_clipping", C.c_int),
                 ("nonlinear_source", C.c_int), ("nonlinear_target", C.c_int), ("blue_mapping", C.c_int),

@@ -1,0 +1,609 @@
+// denoiseprofile.hip -- denoise (profiled), wavelets mode, on gfx950.
+//
+// Reference: process_wavelets(), src/iop/denoiseprofile.c:1289-1447 (process_wavelets_cl() :2150-2480
+// is the same chain as OpenCL kernels): variance-stabilising transform -> max_scale bands of the
+// edge-aware a-trous step eaw_dn_decompose() (src/pixel/eaw.c:242-327) -> BayesShrink threshold from
+// the band's sum of squared details (variance_stabilizing_xform(), :1223-1287) -> soft-threshold
+// accumulate eaw_synthesize() (eaw.c:157-175) -> + residue -> inverse transform.
+//
+// Launches per frame: 1 precondition, per band {decompose, threshold, synthesize}, 1 finish
+// (residue add + inverse transform fused: same arithmetic, one pass less than the reference).
+// Nothing returns to the host between launches: the band threshold is computed on the device from
+// the reduced sums and consumed by the synthesize kernel through a 16-byte buffer.
+//
+// The sum of squared details is an OpenMP float reduction in the reference, so its value depends on
+// the host's thread count.  Here (and in oracle/src/denoiseprofile.c) it is the binary64 sum of the
+// binary32 products det*det in a fixed order:
+//   1. per 256-pixel row segment (= one workgroup): halving reduction inside each wave of 64
+//      (v[m] += v[m + off], off = 32..1), then the four wave sums left to right;
+//   2. segment sums, numbered row-major, dealt round-robin to 1024 accumulators (increasing segment
+//      number), which are then reduced by halving (off = 512..1); rounded once to binary32.
+#include "hip_common.h"
+#include "devmath.h"
+
+#include <math.h>
+
+using namespace ansel;
+
+namespace
+{
+
+#define BANDS DT_HIP_DENOISEPROFILE_BANDS
+#define P_FULCRUM 0.05f // DT_IOP_DENOISE_PROFILE_P_FULCRUM, denoiseprofile.c:118
+
+__host__ __device__ __forceinline__ float max_first(const float a, const float b) { return a > b ? a : b; } // MAX(a, b)
+__host__ __device__ __forceinline__ float min_first(const float a, const float b) { return a < b ? a : b; } // MIN(a, b)
+__device__ __forceinline__ int clampi(const int v, const int lo, const int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct dn_setup
+{
+  int max_scale;
+  int vst; // 0 legacy Anscombe, 1 v2 RGB, 2 v2 Y0U0V0
+  float wb[4], p[4], aa[4], bb[4];
+  float toY[3][4], toRGB[3][4];
+  float a_v2, b_v2, bias;
+};
+
+// per-channel constants of the forward / inverse transform, prepared on the host
+struct vst_args
+{
+  int vst;
+  float k[4];      // legacy: sigma^2 + 3/8 (forward) or + 1/8 (inverse)
+  float aa[4];     // legacy: a
+  float expon[4];  // v2
+  float scale[4];  // v2: "denom" (RGB) or "scale" (Y0U0V0)
+  float wb[4];     // v2 RGB
+  float bias_wb[4];
+  float b, bias, sqrt_3_2;
+  float m[3][4];   // Y0U0V0: toY0U0V0 (forward) / toRGB (inverse)
+};
+
+__device__ __forceinline__ float chan(const float4 &v, const int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// precondition(), precondition_v2(), precondition_Y0U0V0(): denoiseprofile.c:852-870, :916-933, :1021-1051
+__global__ __launch_bounds__(256) void dn_precondition(const float4 *__restrict__ in, float4 *__restrict__ buf,
+                                                       const size_t npix, const vst_args a)
+{
+  for(size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += (size_t)gridDim.x * blockDim.x)
+  {
+    const float4 px = in[j];
+    float o[4];
+    if(a.vst == 0)
+    {
+#pragma unroll
+      for(int c = 0; c < 4; c++)
+      {
+        const float d = fmaxf(0.0f, chan(px, c) / a.aa[c] + a.k[c]);
+        o[c] = 2.0f * sqrtf(d);
+      }
+    }
+    else if(a.vst == 1)
+    {
+#pragma unroll
+      for(int c = 0; c < 4; c++)
+        o[c] = 2.0f * ansel_math::powf_exact(max_first(chan(px, c) / a.wb[c] + a.b, 0.0f), a.expon[c]) / a.scale[c];
+    }
+    else
+    {
+      float t[4];
+#pragma unroll
+      for(int c = 0; c < 4; c++) t[c] = ansel_math::powf_exact(max_first(chan(px, c) + a.b, 0.0f), a.expon[c]) * a.scale[c];
+#pragma unroll
+      for(int c = 0; c < 3; c++)
+      {
+        float sum = 0.0f;
+#pragma unroll
+        for(int k = 0; k < 4; k++) sum += a.m[c][k] * t[k];
+        o[c] = sum;
+      }
+      o[3] = 0.0f;
+    }
+    buf[j] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// out[k] += residue[k] (denoiseprofile.c:1423-1425) followed by backtransform(), backtransform_v2(),
+// backtransform_Y0U0V0(): :872-897, :996-1019, :1053-1090
+__global__ __launch_bounds__(256) void dn_finish(float4 *__restrict__ out, const float4 *__restrict__ residue,
+                                                 const size_t npix, const vst_args a)
+{
+  for(size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += (size_t)gridDim.x * blockDim.x)
+  {
+    const float4 acc = out[j], res = residue[j];
+    const float v[4] = { acc.x + res.x, acc.y + res.y, acc.z + res.z, acc.w + res.w };
+    float o[4];
+    if(a.vst == 0)
+    {
+#pragma unroll
+      for(int c = 0; c < 4; c++)
+      {
+        const float x = v[c], x2 = x * x;
+        o[c] = (x < 0.5f) ? 0.0f
+                          : a.aa[c] * (1.f / 4.f * x2 + 1.f / 4.f * a.sqrt_3_2 / x - 11.f / 8.f / x2
+                                       + 5.f / 8.f * a.sqrt_3_2 / (x * x2) - a.k[c]);
+      }
+    }
+    else if(a.vst == 1)
+    {
+#pragma unroll
+      for(int c = 0; c < 4; c++)
+      {
+        const float x = max_first(v[c], 0.0f);
+        const float delta = x * x + a.bias;
+        const float z1 = (x + sqrtf(max_first(delta, 0.0f))) / a.scale[c];
+        o[c] = a.wb[c] * (ansel_math::powf_exact(z1, a.expon[c]) - a.b);
+      }
+    }
+    else
+    {
+      float rgb[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+      for(int k = 0; k < 3; k++)
+#pragma unroll
+        for(int c = 0; c < 4; c++) rgb[k] += a.m[k][c] * v[c];
+#pragma unroll
+      for(int c = 0; c < 4; c++)
+      {
+        const float x = max_first(rgb[c], 0.0f);
+        const float delta = x * x + a.bias_wb[c];
+        const float z1 = (x + sqrtf(max_first(delta, 0.0f))) * a.scale[c];
+        o[c] = ansel_math::powf_exact(z1, a.expon[c]) - a.b;
+      }
+    }
+    nt_store(out + j, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+// fast_mexp2f(), src/math/math.h:306-317
+__device__ __forceinline__ float mexp2(const float x)
+{
+  const float k0 = 1065353216.0f + x * (1056964608.0f - 1065353216.0f);
+  return __int_as_float(k0 >= 8388608.0f ? (int)k0 : 0);
+}
+
+__device__ __forceinline__ int walk_row(const int b, const int height, const int mult)
+{
+  if(height <= mult) return b < height ? b : -1;
+  const int per_pass = (height + mult - 1) / mult;
+  const int row = (b % per_pass) * mult + b / per_pass;
+  return row < height ? row : -1;
+}
+
+__device__ __forceinline__ double wave_sum_halving(double v)
+{
+#pragma unroll
+  for(int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  return v; // lane 0 holds the halving-tree sum of the wave
+}
+
+// eaw_dn_decompose(), eaw.c:242-327: one workgroup = one 256-pixel segment of one row
+__global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ in, float4 *__restrict__ coarse,
+                                                    float4 *__restrict__ detail, double *__restrict__ partial,
+                                                    const int width, const int height, const int mult,
+                                                    const float inv_sigma2)
+{
+  __shared__ double runs[4][4];
+  const int row = walk_row(blockIdx.y, height, mult);
+  if(row < 0) return;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  double sq[4] = { 0.0, 0.0, 0.0, 0.0 };
+  if(col < width)
+  {
+    const float4 px = in[(size_t)row * width + col];
+    float sum[4] = { 0.f, 0.f, 0.f, 0.f }, wgt = 0.f;
+#pragma unroll
+    for(int jj = 0; jj < 5; jj++)
+    {
+      const size_t y = (size_t)clampi(row + mult * (jj - 2), 0, height - 1) * width;
+      const float fj = jj == 0 || jj == 4 ? 0.0625f : (jj == 2 ? 0.375f : 0.25f);
+#pragma unroll
+      for(int ii = 0; ii < 5; ii++)
+      {
+        const int x = clampi(col + mult * (ii - 2), 0, width - 1);
+        const float fi = ii == 0 || ii == 4 ? 0.0625f : (ii == 2 ? 0.375f : 0.25f);
+        const float4 p2 = in[y + x];
+        // dn_weight(), eaw.c:181-195
+        const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
+        const float dot = (dx * dx + dy * dy + dz * dz) * inv_sigma2;
+        const float arg = dot * 0.02f - 9.0f;
+        const float wp = mexp2(0 > arg ? 0.0f : arg);
+        const float w = (fi * fj) * wp;
+        wgt += w; // the reference keeps one weight sum per channel; they are identical
+        sum[0] += w * p2.x;
+        sum[1] += w * p2.y;
+        sum[2] += w * p2.z;
+        sum[3] += w * p2.w;
+      }
+    }
+    float c4[4], d4[4];
+    const float pin[4] = { px.x, px.y, px.z, px.w };
+#pragma unroll
+    for(int c = 0; c < 4; c++)
+    {
+      c4[c] = sum[c] / wgt;
+      d4[c] = pin[c] - c4[c];
+      sq[c] = (double)(d4[c] * d4[c]);
+    }
+    const size_t o = (size_t)row * width + col;
+    coarse[o] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+    detail[o] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for(int c = 0; c < 4; c++)
+  {
+    const double s = wave_sum_halving(sq[c]);
+    if(lane == 0) runs[wave][c] = s;
+  }
+  __syncthreads();
+  if(threadIdx.x < 4)
+  {
+    const int c = threadIdx.x;
+    const double seg = ((runs[0][c] + runs[1][c]) + runs[2][c]) + runs[3][c];
+    partial[4 * ((size_t)row * gridDim.x + blockIdx.x) + c] = seg;
+  }
+}
+
+struct thr_args
+{
+  size_t n_partial;
+  float n1;        // (float)npixels - 1.0f
+  float sb2;       // sigma_band^2
+  float adjt[4];   // 8 x the band's force factors
+};
+
+// step 2 of the canonical sum + variance_stabilizing_xform(), denoiseprofile.c:1223-1287
+__global__ __launch_bounds__(1024) void dn_band_threshold(const double *__restrict__ partial, const thr_args a,
+                                                          float *__restrict__ thrs)
+{
+  __shared__ double acc[4][1024];
+  const int t = threadIdx.x;
+  double s[4] = { 0.0, 0.0, 0.0, 0.0 };
+  for(size_t k = t; k < a.n_partial; k += 1024)
+  {
+    s[0] += partial[4 * k + 0];
+    s[1] += partial[4 * k + 1];
+    s[2] += partial[4 * k + 2];
+    s[3] += partial[4 * k + 3];
+  }
+#pragma unroll
+  for(int c = 0; c < 4; c++) acc[c][t] = s[c];
+  __syncthreads();
+  for(int off = 512; off >= 1; off >>= 1)
+  {
+    if(t < off)
+    {
+#pragma unroll
+      for(int c = 0; c < 4; c++) acc[c][t] += acc[c][t + off];
+    }
+    __syncthreads();
+  }
+  if(t < 4)
+  {
+    const float sum_y2 = (float)acc[t][0];
+    const float std_x = t < 3 ? sqrtf(max_first(1e-6f, sum_y2 / a.n1 - a.sb2)) : 1.0f;
+    thrs[t] = a.adjt[t] * a.sb2 / std_x;
+  }
+}
+
+// eaw_synthesize() with boost 1, eaw.c:157-175; first band: the accumulator is the zeroed output
+// (denoiseprofile.c:1398), i.e. 0 + amount
+__global__ __launch_bounds__(256) void dn_synthesize(float4 *__restrict__ out, const float4 *__restrict__ detail,
+                                                     const float *__restrict__ thrs, const size_t npix, const int first)
+{
+  const float t0 = thrs[0], t1 = thrs[1], t2 = thrs[2], t3 = thrs[3];
+  for(size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += (size_t)gridDim.x * blockDim.x)
+  {
+    const float4 d = detail[j];
+    float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : out[j];
+    acc.x = acc.x + (1.0f * (max_first(d.x - t0, 0.0f) + min_first(d.x + t0, 0.0f)));
+    acc.y = acc.y + (1.0f * (max_first(d.y - t1, 0.0f) + min_first(d.y + t1, 0.0f)));
+    acc.z = acc.z + (1.0f * (max_first(d.z - t2, 0.0f) + min_first(d.z + t2, 0.0f)));
+    acc.w = acc.w + (1.0f * (max_first(d.w - t3, 0.0f) + min_first(d.w + t3, 0.0f)));
+    out[j] = acc;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+
+// invert_matrix(), denoiseprofile.c:1132-1161
+bool invert3(const float in[3][4], float out[3][4])
+{
+  const float A = in[1][1] * in[2][2] - in[1][2] * in[2][1];
+  const float B = -in[1][0] * in[2][2] + in[1][2] * in[2][0];
+  const float C = in[1][0] * in[2][1] - in[1][1] * in[2][0];
+  const float D = -in[0][1] * in[2][2] + in[0][2] * in[2][1];
+  const float E = in[0][0] * in[2][2] - in[0][2] * in[2][0];
+  const float F = -in[0][0] * in[2][1] + in[0][1] * in[2][0];
+  const float G = in[0][1] * in[1][2] - in[0][2] * in[1][1];
+  const float H = -in[0][0] * in[1][2] + in[0][2] * in[1][0];
+  const float I = in[0][0] * in[1][1] - in[0][1] * in[1][0];
+  const float det = in[0][0] * A + in[0][1] * B + in[0][2] * C;
+  if(det == 0.0f) return false;
+  const float r = 1.0f / det;
+  out[0][0] = r * A; out[0][1] = r * D; out[0][2] = r * G; out[0][3] = 0.0f;
+  out[1][0] = r * B; out[1][1] = r * E; out[1][2] = r * H; out[1][3] = 0.0f;
+  out[2][0] = r * C; out[2][1] = r * F; out[2][2] = r * I; out[2][3] = 0.0f;
+  return true;
+}
+
+void setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, dn_setup &s)
+{
+  memset(&s, 0, sizeof(s));
+  const float in_scale = fminf((float)piece->roi_in.scale, 1.0f);
+  // number of bands, denoiseprofile.c:1301-1317 (piece->buf_in == roi_in for a full-frame export)
+  const float big = (float)(piece->roi_in.height > piece->roi_in.width ? piece->roi_in.height : piece->roi_in.width);
+  const float supp0 = min_first((float)(2 * (2u << (BANDS - 1)) + 1), big * 0.2f);
+  const float i0 = log2f((supp0 - 1.0f) * .5f);
+  int max_scale = 0;
+  for(; max_scale < BANDS; max_scale++)
+  {
+    const float supp = (float)(2 * (2u << max_scale) + 1);
+    const float supp_in = supp * (1.0f / in_scale);
+    const float i_in = log2f((supp_in - 1) * .5f) - 1.0f;
+    const float t = 1.0f - (i_in + .5f) / i0;
+    if(t < 0.0f) break;
+  }
+  s.max_scale = max_scale;
+
+  // compute_wb_factors() with weights {2, 1, 2, 0}, :1097-1128
+  const float weights[4] = { 2.0f, 1.0f, 2.0f, 0.0f };
+  const float wb_mean = (d->wb_coeffs[0] + d->wb_coeffs[1] + d->wb_coeffs[2]) / 3.0f;
+  float *wb = s.wb;
+  wb[0] = wb[1] = wb[2] = wb[3] = wb_mean;
+  if(d->fix_anscombe_and_nlmeans_norm)
+  {
+    if(wb_mean != 0.0f && d->wb_adaptive_anscombe)
+      for(int i = 0; i < 3; i++) wb[i] = d->wb_coeffs[i];
+    else if(wb_mean == 0.0f)
+      for(int i = 0; i < 4; i++) wb[i] = 1.0f;
+  }
+  else
+    for(int i = 0; i < 4; i++) wb[i] = weights[i] * piece->processed_maximum[i];
+
+  // adaptive p, :1339-1343 (a binary64 expression stored to binary32)
+  for(int i = 0; i < 3; i++)
+  {
+    const double v = (double)d->shadows + 0.1 * (double)logf(in_scale / wb[i]);
+    s.p[i] = (float)(v > 0.0 ? v : 0.0);
+  }
+  s.p[3] = 0.0f;
+  const float compensate_p = P_FULCRUM / powf(P_FULCRUM, d->shadows);
+
+  // set_up_conversion_matrices(), :1163-1221
+  float toY[3][4] = { { 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f, 0.0f }, { 0.5f, 0.0f, -0.5f, 0.0f }, { 0.25f, -0.5f, 0.25f, 0.0f } };
+  float toRGB[3][4];
+  memset(toRGB, 0, sizeof(toRGB));
+  float sum_invwb = 1.0f / wb[0] + 1.0f / wb[1] + 1.0f / wb[2];
+  sum_invwb *= sqrtf(3);
+  toY[0][0] = sum_invwb / wb[0];
+  toY[0][1] = sum_invwb / wb[1];
+  toY[0][2] = sum_invwb / wb[2];
+  toY[0][3] = 0.0f;
+  const float sdU = sqrtf(0.5f * 0.5f * wb[0] * wb[0] + 0.5f * 0.5f * wb[2] * wb[2]);
+  const float sdV = sqrtf(0.25f * 0.25f * wb[0] * wb[0] + 0.5f * 0.5f * wb[1] * wb[1] + 0.25f * 0.25f * wb[2] * wb[2]);
+  for(int c = 0; c < 3; c++)
+  {
+    toY[1][c] /= sdU;
+    toY[2][c] /= sdV;
+  }
+  toY[1][3] = toY[2][3] = 0.0f;
+  if(!invert3(toY, toRGB))
+  {
+    const float sdY = sqrtf(1.0f / 9.0f * (wb[0] * wb[0] + wb[1] * wb[1] + wb[2] * wb[2]));
+    toY[0][0] = toY[0][1] = toY[0][2] = 1.0f / (3.0f * sdY);
+    toY[0][3] = 0.0f;
+    invert3(toY, toRGB);
+  }
+  const float compensate_strength = (d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB) ? 1.0f : 2.5f;
+  const float gain = d->strength * compensate_strength * in_scale;
+  for(int k = 0; k < 3; k++)
+    for(int c = 0; c < 4; c++)
+    {
+      toY[k][c] /= gain;
+      toRGB[k][c] *= gain;
+    }
+  for(int i = 0; i < 4; i++) wb[i] *= gain;
+  memcpy(s.toY, toY, sizeof(toY));
+  memcpy(s.toRGB, toRGB, sizeof(toRGB));
+  for(int i = 0; i < 3; i++)
+  {
+    s.aa[i] = d->a[1] * wb[i];
+    s.bb[i] = d->b[1] * wb[i];
+  }
+  s.aa[3] = s.bb[3] = 0.0f;
+  s.a_v2 = d->a[1] * compensate_p;
+  s.b_v2 = d->b[1];
+  s.bias = (float)((double)d->bias - 0.5 * (double)logf(in_scale));
+  s.vst = !d->use_new_vst ? 0 : (d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB ? 1 : 2);
+}
+
+void forward_args(const dn_setup &s, vst_args &a)
+{
+  memset(&a, 0, sizeof(a));
+  a.vst = s.vst;
+  a.b = s.b_v2;
+  const float sa = sqrtf(s.a_v2);
+  for(int c = 0; c < 4; c++)
+  {
+    a.aa[c] = s.aa[c];
+    a.wb[c] = s.wb[c];
+  }
+  if(s.vst == 0)
+  {
+    for(int c = 0; c < 3; c++) a.k[c] = (s.bb[c] / s.aa[c]) * (s.bb[c] / s.aa[c]) + 3.f / 8.f;
+    a.k[3] = 0.0f;
+    return;
+  }
+  for(int c = 0; c < 3; c++) a.expon[c] = -s.p[c] / 2 + 1;
+  a.expon[3] = 1.0f;
+  for(int c = 0; c < 3; c++) a.scale[c] = s.vst == 1 ? (-s.p[c] + 2) * sa : 2.0f / ((-s.p[c] + 2) * sa);
+  a.scale[3] = 1.0f;
+  memcpy(a.m, s.toY, sizeof(a.m));
+}
+
+void inverse_args(const dn_setup &s, vst_args &a)
+{
+  memset(&a, 0, sizeof(a));
+  a.vst = s.vst;
+  a.b = s.b_v2;
+  a.bias = s.bias;
+  a.sqrt_3_2 = sqrtf(3.0f / 2.0f);
+  const float sa = sqrtf(s.a_v2);
+  for(int c = 0; c < 4; c++)
+  {
+    a.aa[c] = s.aa[c];
+    a.wb[c] = s.wb[c];
+  }
+  if(s.vst == 0)
+  {
+    for(int c = 0; c < 3; c++) a.k[c] = (s.bb[c] / s.aa[c]) * (s.bb[c] / s.aa[c]) + 1.f / 8.f;
+    a.k[3] = 0.0f;
+    return;
+  }
+  for(int c = 0; c < 3; c++) a.expon[c] = 1.0f / (1.0f - s.p[c] / 2.0f);
+  a.expon[3] = 1.0f;
+  for(int c = 0; c < 3; c++)
+  {
+    a.scale[c] = s.vst == 1 ? 4.0f / (sa * (2.0f - s.p[c])) : (sa * (2.0f - s.p[c])) / 4.0f;
+    a.bias_wb[c] = s.bias * s.wb[c];
+  }
+  a.scale[3] = 1.0f;
+  a.bias_wb[3] = 0.0f;
+  memcpy(a.m, s.toRGB, sizeof(a.m));
+}
+
+// the host part of variance_stabilizing_xform(): everything that does not depend on the sums
+void threshold_args(const dt_hip_denoiseprofile_data_t *d, const int scale, const int max_scale, const size_t npixels,
+                    thr_args &t)
+{
+  const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
+  const float sigma_band = powf(varf, scale) * 1.0f;
+  t.sb2 = sigma_band * sigma_band;
+  t.n1 = (float)npixels - 1.0f;
+  float adjt[4] = { 8.0f, 8.0f, 8.0f, 0.0f };
+  const int band = BANDS - (scale + (BANDS - max_scale) + 1);
+  if(d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB)
+  {
+    float f = d->force[0][band];
+    f *= f;
+    f *= 4;
+    for(int c = 0; c < 4; c++) adjt[c] *= f;
+    for(int c = 0; c < 3; c++)
+    {
+      f = d->force[1 + c][band];
+      f *= f;
+      f *= 4;
+      adjt[c] *= f;
+    }
+  }
+  else
+  {
+    float f = d->force[4][band];
+    f *= f;
+    f *= 4;
+    adjt[0] *= f;
+    f = d->force[5][band];
+    f *= f;
+    f *= 4;
+    adjt[1] *= f;
+    adjt[2] *= f;
+  }
+  for(int c = 0; c < 4; c++) t.adjt[c] = adjt[c];
+}
+
+} // namespace
+
+extern "C" {
+
+int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
+                                      dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
+  if(d->mode != DT_HIP_DENOISEPROFILE_WAVELETS)
+  {
+    set_last_error("denoiseprofile: only the wavelets mode is implemented on device");
+    return DT_HIP_INVALID_ARG;
+  }
+  if(piece->channels != 4 || !(piece->roi_in.scale > 0.0)) return DT_HIP_INVALID_ARG;
+  const int w = piece->roi_in.width, h = piece->roi_in.height;
+  if(w <= 0 || h <= 0) return DT_HIP_SUCCESS;
+  const size_t npix = (size_t)w * h, plane = npix * sizeof(float4);
+  dn_setup s;
+  setup(piece, d, s);
+  if(s.max_scale < 1)
+  {
+    set_last_error("denoiseprofile: frame too small for a single wavelet band");
+    return DT_HIP_INVALID_ARG;
+  }
+  const int max_mult = 1 << (s.max_scale - 1);
+  hipStream_t st = stream_of(devid);
+  if(w < 2 * max_mult || h < 2 * max_mult) // denoiseprofile.c:1325-1329: too small, copy through
+    return dt_hip_enqueue_copy_buffer_to_buffer(devid, dev_in, dev_out, 0, 0, plane);
+  if(w < 4 * max_mult)
+  {
+    // eaw.c:308-323 reads before the start of the row in this case (undefined in the reference)
+    set_last_error("denoiseprofile: %d columns is less than 4x the coarsest dilation %d", w, max_mult);
+    return DT_HIP_INVALID_ARG;
+  }
+  const int nseg = (w + 255) / 256;
+  const size_t n_partial = (size_t)h * nseg;
+  float4 *precond = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
+  float4 *tmp = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
+  float4 *det = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
+  double *partial = (double *)dt_hip_alloc_device_buffer(devid, n_partial * 4 * sizeof(double));
+  float *thrs = (float *)dt_hip_alloc_device_buffer(devid, 4 * sizeof(float));
+  int err = (precond && tmp && det && partial && thrs) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
+  float4 *out = (float4 *)dev_out;
+  const unsigned sgrid = stream_grid(npix, 256);
+  if(err == DT_HIP_SUCCESS)
+  {
+    vst_args fa;
+    forward_args(s, fa);
+    launch_scope ls(devid, "dn_precondition");
+    dn_precondition<<<sgrid, 256, 0, st>>>((const float4 *)dev_in, precond, npix, fa);
+  }
+  float4 *b1 = precond, *b2 = tmp;
+  for(int scale = 0; scale < s.max_scale && err == DT_HIP_SUCCESS; scale++)
+  {
+    const int mult = 1 << scale;
+    const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
+    const float sigma_band = powf(varf, scale) * 1.0f;
+    const int rows = (h <= mult) ? h : ((h + mult - 1) / mult) * mult;
+    {
+      launch_scope ls(devid, "dn_decompose");
+      dn_decompose<<<dim3(nseg, rows), 256, 0, st>>>(b1, b2, det, partial, w, h, mult, 1.0f / (sigma_band * sigma_band));
+    }
+    thr_args ta;
+    ta.n_partial = n_partial;
+    threshold_args(d, scale, s.max_scale, npix, ta);
+    {
+      launch_scope ls(devid, "dn_band_threshold");
+      dn_band_threshold<<<1, 1024, 0, st>>>(partial, ta, thrs);
+    }
+    {
+      launch_scope ls(devid, "dn_synthesize");
+      dn_synthesize<<<sgrid, 256, 0, st>>>(out, det, thrs, npix, scale == 0);
+    }
+    err = check_launch("denoiseprofile band");
+    float4 *t = b2;
+    b2 = b1;
+    b1 = t;
+  }
+  if(err == DT_HIP_SUCCESS)
+  {
+    vst_args ia;
+    inverse_args(s, ia);
+    launch_scope ls(devid, "dn_finish");
+    dn_finish<<<sgrid, 256, 0, st>>>(out, b1, npix, ia);
+    err = check_launch("dn_finish");
+  }
+  if(precond) dt_hip_release_mem_object(precond);
+  if(tmp) dt_hip_release_mem_object(tmp);
+  if(det) dt_hip_release_mem_object(det);
+  if(partial) dt_hip_release_mem_object(partial);
+  if(thrs) dt_hip_release_mem_object(thrs);
+  return err;
+}
+
+} // extern "C"

@@ -10,7 +10,7 @@ import math
 
 import numpy as np
 
-from . import abi
+from . import abi, synth
 
 # ---- colour science constants -----------------------------------------------------------
 D50_XYZ = np.array([0.9642119944211994, 1.0, 0.8251882845188288])
@@ -162,4 +162,29 @@ def diffuse(preset="default", iscale=1.0, **over):
     for k, v in base.items():
         setattr(d, k, v)
     d.iscale = iscale
+    return d
+
+
+# ---- denoise (profiled), wavelets (src/iop/denoiseprofile.c) ------------------------------------
+def denoiseprofile(color_mode=abi.DT_HIP_DENOISEPROFILE_Y0U0V0, use_new_vst=True, fix=True, wb_adaptive=True,
+                   strength=1.0, shadows=1.0, bias=0.0, a=2.0e-5 * 4, b=-2.0e-7, force=None, wb=None):
+    """module defaults ($DEFAULT annotations, denoiseprofile.c:270-305) with a Sony-like ISO 400 noise
+    profile {a, b} and flat 0.5 force curves"""
+    d = abi.DenoiseprofileData()
+    d.radius, d.nbhood, d.strength, d.shadows, d.bias = 1.0, 7.0, strength, shadows, bias
+    d.scattering, d.central_pixel_weight, d.overshooting = 0.0, 0.1, 1.0
+    for k in range(3):
+        d.a[k] = a
+        d.b[k] = b
+    d.mode = abi.DT_HIP_DENOISEPROFILE_WAVELETS
+    for c in range(6):
+        for band in range(7):
+            d.force[c][band] = 0.5 if force is None else float(force[c][band])
+    d.wb_adaptive_anscombe = 1 if wb_adaptive else 0
+    d.fix_anscombe_and_nlmeans_norm = 1 if fix else 0
+    d.use_new_vst = 1 if use_new_vst else 0
+    d.wavelet_color_mode = color_mode
+    wbc = synth.WB_COEFFS if wb is None else wb
+    for k in range(4):
+        d.wb_coeffs[k] = wbc[k] if k < len(wbc) else 0.0
     return d

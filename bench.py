@@ -96,10 +96,12 @@ def cpu_baseline(size_name, with_filmic):
         cores = int(ref.ref_get_num_threads())
     lut = params.srgb_encode_lut()
     nodes = build_pipe(w, h, lut.ctypes.data, lut, with_filmic)
-    raw = synth.bayer_mosaic_tiled(w, h, seed=1)
-    cfa = [np.empty((h, w), np.float32) for _ in range(2)]
-    rgb = [np.empty((h, w, 4), np.float32) for _ in range(2)]
-    out16 = np.empty((h, w, 4), np.uint16)
+    # 64-byte aligned like the reference's pixelpipe buffers (checkers.call would otherwise copy)
+    raw = ck.aligned_empty((h, w), np.uint16)
+    raw[...] = synth.bayer_mosaic_tiled(w, h, seed=1)
+    cfa = [ck.aligned_empty((h, w), np.float32) for _ in range(2)]
+    rgb = [ck.aligned_empty((h, w, 4), np.float32) for _ in range(2)]
+    out16 = ck.aligned_empty((h, w, 4), np.uint16)
 
     def one_pass():
         src = raw

@@ -312,6 +312,39 @@ int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_
 /* tiling_callback(), diffuse.c:585-610 */
 void dt_hip_iop_diffuse_tiling(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, dt_hip_tiling_t *tiling);
 
+/* denoise (profiled), wavelets mode: process_wavelets(), src/iop/denoiseprofile.c:1289-1447, with
+ * eaw_dn_decompose() / eaw_synthesize() (src/pixel/eaw.c:242-327, :157-175), the variance-stabilising
+ * transforms precondition*() / backtransform*() (denoiseprofile.c:852-1095) and the BayesShrink
+ * threshold variance_stabilizing_xform() (:1223-1287).
+ * Fields are those of dt_iop_denoiseprofile_data_t (denoiseprofile.c:352-371) the path reads;
+ * force[][] is the per-band curve sampling commit_params() leaves there (:3088-3100);
+ * wb_coeffs = piece->dsc_in.temperature.coeffs (read by compute_wb_factors(), :1097-1128).
+ * mode: only DT_HIP_DENOISEPROFILE_WAVELETS is implemented on device.
+ *
+ * The sum of squared detail coefficients per band is an OpenMP reduction in the reference, i.e. its
+ * value depends on the host's thread count; the device (and the oracle) define it as the binary64
+ * sum in the fixed order documented in DESIGN.md, rounded once to binary32. */
+#define DT_HIP_DENOISEPROFILE_BANDS 7
+#define DT_HIP_DENOISEPROFILE_NLMEANS 0
+#define DT_HIP_DENOISEPROFILE_WAVELETS 1
+#define DT_HIP_DENOISEPROFILE_RGB 0
+#define DT_HIP_DENOISEPROFILE_Y0U0V0 1
+typedef struct dt_hip_denoiseprofile_data_t
+{
+  float radius, nbhood, strength, shadows, bias, scattering, central_pixel_weight, overshooting;
+  float a[3], b[3];
+  int mode;
+  float force[6][DT_HIP_DENOISEPROFILE_BANDS]; /* rows: all, R, G, B, Y0, U0V0 */
+  int wb_adaptive_anscombe;
+  int fix_anscombe_and_nlmeans_norm;
+  int use_new_vst;
+  int wavelet_color_mode;
+  float wb_coeffs[4];
+} dt_hip_denoiseprofile_data_t;
+int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece,
+                                      const dt_hip_denoiseprofile_data_t *d, dt_hip_mem_t dev_in,
+                                      dt_hip_mem_t dev_out);
+
 /* ---- 3. export-pipe executor ----------------------------------------------------------- */
 /* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)
  * for an export: an ordered list of module nodes, each with its piece view and committed data,

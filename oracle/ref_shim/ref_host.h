@@ -100,12 +100,15 @@ typedef struct dt_iop_module_t
 /* src/develop/imageop.c:134-137 */
 #define dt_dev_get_module_scale(pipe, roi_in) ((float)((pipe)->iscale / (roi_in)->scale))
 
-/* src/common/imagebuf.h: plain float copy of a w x h x ch buffer */
+/* src/common/imagebuf.h: plain float copy of a w x h x ch buffer (units that compile the real
+ * common/imagebuf.c define REF_REAL_IMAGEBUF and get the reference's own) */
+#ifndef REF_REAL_IMAGEBUF
 static inline void dt_iop_image_copy_by_size(float *const out, const float *const in, const size_t w,
                                              const size_t h, const size_t ch)
 {
   memcpy(out, in, sizeof(float) * w * h * ch);
 }
+#endif
 
 static inline void dt_iop_alpha_copy(const void *i, void *o, int w, int h) { (void)i; (void)o; (void)w; (void)h; }
 

@@ -41,10 +41,29 @@ def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def aligned_empty(shape, dtype, align=64):
+    """numpy only guarantees 16-byte alignment; the reference's loops carry `aligned(...:64)` clauses
+    (pixelpipe buffers are 64-byte aligned there), so unaligned buffers fault in oracle/_ref"""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.empty(n + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
 def call(lib, name, piece, data, inp, out):
     fn = getattr(lib, name)
     fn.restype = C.c_int
-    rc = fn(C.byref(piece), C.byref(data) if data is not None else None, ptr(inp), ptr(out))
+    src = inp
+    if inp.ctypes.data % 64:
+        src = aligned_empty(inp.shape, inp.dtype)
+        src[...] = inp
+    dst = out
+    if out.ctypes.data % 64:
+        dst = aligned_empty(out.shape, out.dtype)
+        dst[...] = out
+    rc = fn(C.byref(piece), C.byref(data) if data is not None else None, ptr(src), ptr(dst))
+    if dst is not out:
+        out[...] = dst
     return rc
 
 

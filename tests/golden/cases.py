@@ -26,6 +26,17 @@ def _rgba():
     return np.ascontiguousarray(np.concatenate([a, b], axis=0))
 
 
+SINGLE_THREAD_OPS = ("denoiseprofile",)
+DNW, DNH = 288, 176    # denoiseprofile: 5 wavelet bands
+
+
+def _noisy_rgba():
+    rng = np.random.default_rng(31)
+    img = synth.rgba_image(DNW, DNH, seed=8, lo=0.0, hi=0.9)
+    img[..., :3] += rng.normal(0.0, 0.01, size=(DNH, DNW, 3)).astype(np.float32) * np.sqrt(np.maximum(img[..., :3], 0.01))
+    return np.ascontiguousarray(img.astype(np.float32))
+
+
 _LUTS = []
 
 
@@ -88,4 +99,12 @@ def cases(lut_ptrs=None):
            params.diffuse("lens_deblur_soft", iterations=2, anisotropy_first=-2.0, anisotropy_second=1.5,
                           anisotropy_fourth=-3.0, variance_threshold=-0.5, regularization=2.5, sharpness=0.2),
            img, img.shape)
+    # denoise (profiled), wavelets: the golden outputs come from the reference run on ONE thread (its
+    # band statistics depend on the thread count, see oracle/src/denoiseprofile.c)
+    dimg = _noisy_rgba()
+    dpiece = abi.Piece.make(DNW, DNH, processed_maximum=synth.WB_COEFFS)
+    yield ("denoiseprofile_y0u0v0", "denoiseprofile", dpiece, params.denoiseprofile(), dimg, dimg.shape)
+    yield ("denoiseprofile_rgb", "denoiseprofile", dpiece,
+           params.denoiseprofile(color_mode=abi.DT_HIP_DENOISEPROFILE_RGB, strength=1.4, shadows=0.7), dimg, dimg.shape)
+    yield ("denoiseprofile_legacy", "denoiseprofile", dpiece, params.denoiseprofile(use_new_vst=False), dimg, dimg.shape)
     del keep

@@ -26,10 +26,14 @@ def main():
     if r is None:
         raise SystemExit("oracle/_ref/libansel_ref.so missing: run `make -C oracle ref` where /root/reference exists")
     out = {}
+    threads = r.ref_get_num_threads()
     for name, op, piece, data, inp, shape in cases.cases():
         res = np.zeros(shape, np.float32)
+        # modules with a thread-count dependent reduction are recorded single-threaded
+        r.ref_set_num_threads(1 if op in cases.SINGLE_THREAD_OPS else threads)
         assert ck.call(r, "ref_" + op, piece, data, np.ascontiguousarray(inp), res) == 0, name
         out[name] = res
+    r.ref_set_num_threads(threads)
     img = [c for c in cases.cases() if c[0] == "exposure"][0][4]
     w, h = img.shape[1], img.shape[0]
     u16 = np.zeros(img.shape, np.uint16)

@@ -173,3 +173,52 @@ def test_diffuse_scaled_roi():
     piece = abi.Piece.make(w, h, roi_in=abi.Roi.make(0, 0, w, h, 0.5), roi_out=abi.Roi.make(0, 0, w, h, 0.5))
     a, b = _pair("diffuse", piece, params.diffuse("lens_deblur_soft", iterations=2), img, img.shape)
     _exact(a, b, "diffuse scale 0.5")
+
+
+DENOISE_CASES = [
+    dict(),                                                         # defaults: Y0U0V0, new VST
+    dict(color_mode=abi.DT_HIP_DENOISEPROFILE_RGB),
+    dict(use_new_vst=False),
+    dict(use_new_vst=False, fix=False),
+    dict(color_mode=abi.DT_HIP_DENOISEPROFILE_RGB, wb_adaptive=False, strength=1.7, shadows=0.6, bias=-3.0),
+    dict(wb=(0.0, 0.0, 0.0, 0.0), strength=0.4),
+]
+
+
+def _noisy(w, h, seed):
+    rng = np.random.default_rng(seed)
+    img = synth.rgba_image(w, h, seed=seed, lo=0.0, hi=0.9)
+    img[..., :3] += rng.normal(0.0, 0.01, size=(h, w, 3)).astype(np.float32) * np.sqrt(np.maximum(img[..., :3], 0.01))
+    return np.ascontiguousarray(img.astype(np.float32))
+
+
+@pytest.mark.parametrize("case", range(len(DENOISE_CASES)))
+def test_denoiseprofile_wavelets(case):
+    """The per-band sum of squared details is an OpenMP float reduction in the reference (its value
+    depends on the thread count); the oracle sums in binary64 in a fixed order.  Everything else is
+    restated operation for operation, so against the reference run on ONE thread at this small size
+    (where the float accumulation is still accurate to ~1e-6) the outputs agree to a few ulp, and
+    most pixels exactly."""
+    w, h = 300, 200
+    img = _noisy(w, h, 11 + case)
+    d = params.denoiseprofile(**DENOISE_CASES[case])
+    piece = abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS)
+    r, o = ck.ref(), ck.oracle()
+    threads = r.ref_get_num_threads()
+    r.ref_set_num_threads(1)
+    try:
+        # (1) with the oracle summing like the single-threaded reference, everything is bit-exact
+        o.oracle_denoiseprofile_sum_order(1)
+        a, b1 = _pair("denoiseprofile", piece, d, img, img.shape)
+        _exact(a, b1, "denoiseprofile, reference summation order")
+        # (2) the canonical order moves the band thresholds by ~1e-7 relative: a few ulp downstream
+        o.oracle_denoiseprofile_sum_order(0)
+        _, b = _pair("denoiseprofile", piece, d, img, img.shape)
+    finally:
+        o.oracle_denoiseprofile_sum_order(0)
+        r.ref_set_num_threads(threads)
+    diff = ck.ulp_diff(a[..., :3], b[..., :3])
+    rel = np.abs(a[..., :3] - b[..., :3]) / np.maximum(np.abs(a[..., :3]), 1e-3)
+    assert float(rel.max()) < 2e-5, float(rel.max())
+    # the filter did something, and the result is sane
+    assert np.isfinite(b[..., :3]).all() and float(np.abs(b[..., :3] - img[..., :3]).max()) > 1e-4

@@ -41,6 +41,10 @@ def main():
         d = params.diffuse(args.preset, **over)
         scales = None
         fn = l.dt_hip_iop_diffuse_process
+    elif args.module == "denoiseprofile":
+        d = params.denoiseprofile()
+        piece = abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS)
+        fn = l.dt_hip_iop_denoiseprofile_process
     else:
         raise SystemExit("unknown module")
 
