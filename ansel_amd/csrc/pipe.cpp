@@ -29,11 +29,13 @@ enum op_t
   OP_TEMPERATURE,
   OP_HIGHLIGHTS,
   OP_DEMOSAIC,
+  OP_DENOISEPROFILE,
   OP_EXPOSURE,
   OP_COLORIN,
   OP_CHANNELMIXERRGB,
   OP_FILMICRGB,
   OP_COLOROUT,
+  OP_DIFFUSE,
   OP_EXPORT_U16,
   OP_UNKNOWN
 };
@@ -50,11 +52,13 @@ const op_info_t k_ops[] = {
   { "temperature", sizeof(dt_hip_temperature_data_t), 0 /* = input */ },
   { "highlights", sizeof(dt_hip_highlights_data_t), 0 },
   { "demosaic", sizeof(dt_hip_demosaic_data_t), 16 },
+  { "denoiseprofile", sizeof(dt_hip_denoiseprofile_data_t), 16 },
   { "exposure", sizeof(dt_hip_exposure_data_t), 0 },
   { "colorin", sizeof(dt_hip_conversion_t), 16 },
   { "channelmixerrgb", sizeof(dt_hip_channelmixerrgb_data_t), 16 },
   { "filmicrgb", sizeof(dt_hip_filmicrgb_data_t), 16 },
   { "colorout", sizeof(dt_hip_conversion_t), 16 },
+  { "diffuse", sizeof(dt_hip_diffuse_data_t), 16 },
   { "export_u16", 0, 8 },
 };
 
@@ -96,6 +100,8 @@ int run_single(int devid, const node_t &n, dt_hip_mem_t in, dt_hip_mem_t out)
     case OP_TEMPERATURE: return dt_hip_iop_temperature_process(devid, &n.piece, n.as<dt_hip_temperature_data_t>(), in, out);
     case OP_HIGHLIGHTS: return dt_hip_iop_highlights_process(devid, &n.piece, n.as<dt_hip_highlights_data_t>(), in, out);
     case OP_DEMOSAIC: return dt_hip_iop_demosaic_process(devid, &n.piece, n.as<dt_hip_demosaic_data_t>(), in, out);
+    case OP_DENOISEPROFILE: return dt_hip_iop_denoiseprofile_process(devid, &n.piece, n.as<dt_hip_denoiseprofile_data_t>(), in, out);
+    case OP_DIFFUSE: return dt_hip_iop_diffuse_process(devid, &n.piece, n.as<dt_hip_diffuse_data_t>(), in, out);
     case OP_EXPOSURE: return dt_hip_iop_exposure_process(devid, &n.piece, n.as<dt_hip_exposure_data_t>(), in, out);
     case OP_COLORIN: return dt_hip_iop_colorin_process(devid, &n.piece, n.as<dt_hip_conversion_t>(), in, out);
     case OP_CHANNELMIXERRGB: return dt_hip_iop_channelmixerrgb_process(devid, &n.piece, n.as<dt_hip_channelmixerrgb_data_t>(), in, out);
@@ -407,6 +413,13 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
       return DT_HIP_INVALID_ARG;
     }
   if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
+  for(const node_t &n : pipe->nodes)
+    if(n.op == OP_DENOISEPROFILE || n.op == OP_DIFFUSE)
+    {
+      // these need a halo of 2^scales rows per band and (denoiseprofile) an all-reduce per wavelet band
+      set_last_error("band mode: '%s' has no row-band implementation yet", k_ops[n.op].name);
+      return DT_HIP_INVALID_ARG;
+    }
   const size_t ng = pipe->groups.size();
   // the CFA stage ends where the first non-CFA group starts
   size_t n_cfa = 0;

@@ -54,8 +54,37 @@ def light_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, with_
     return nodes
 
 
+def denoise_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, filmic=None,
+                       diffuse_preset="lens_deblur_soft", diffuse_iterations=2):
+    """config 3 of BASELINE.json, as far as it runs on device: the light pipe + denoise (profiled)
+    wavelets after demosaic and diffuse-or-sharpen after color calibration, in the reference's module
+    order (src/develop/iop_order.c:196-232)."""
+    nodes = light_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, with_filmic=filmic is not None,
+                             filmic=filmic)
+    rgb = abi.Piece.make(width, height, channels=4, processed_maximum=synth.WB_COEFFS)
+    out = []
+    for n in nodes:
+        out.append(n)
+        if n.op == "demosaic":
+            out.append(Node("denoiseprofile", params.denoiseprofile(), rgb))
+        if n.op == "channelmixerrgb":
+            out.append(Node("diffuse", params.diffuse(diffuse_preset, iterations=diffuse_iterations), rgb))
+    return out
+
+
+def node_bytes_per_px(n):
+    """algorithmic bytes per pixel of one node"""
+    if n.op == "denoiseprofile":
+        from . import modinfo
+        return 112 + 96 * modinfo.denoiseprofile_bands(n.piece)
+    if n.op == "diffuse":
+        from . import modinfo
+        return 96 * max(int(n.data.iterations), 1) * modinfo.diffuse_scales(n.piece, n.data)
+    return sum(MODULE_BPP[n.op])
+
+
 def algorithmic_bytes_per_pixel(nodes):
-    return sum(sum(MODULE_BPP[n.op]) for n in nodes)
+    return sum(node_bytes_per_px(n) for n in nodes)
 
 
 class DevicePipe:

@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per module (A/B against the fused executor)")
     ap.add_argument("--cpu-sample", default="24MP", help="frame size of the bounded CPU sample")
+    ap.add_argument("--pipe", default="light", choices=("light", "denoise"),
+                    help="light = BASELINE.json config 2 (the metric's workload); denoise = config 3 as far as it runs "
+                         "on device (+ denoise (profiled) wavelets + diffuse or sharpen), quoted on 60MP")
     ap.add_argument("--mode", default="batch", choices=("batch", "tiled"),
                     help="N > 1: batch = one frame per GPU (config 5, weak); tiled = ONE frame cut into row bands, "
                          "one band per GPU, halo rows exchanged over RCCL (config 4, strong)")
@@ -56,13 +59,15 @@ def frame_size(name):
     return int(w), int(h)
 
 
-def build_pipe(width, height, lut_ptr, lut, with_filmic):
+def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light"):
     from ansel_amd import params, pipe
     filmic = None
     if with_filmic:
         from ansel_amd import filmic as fm
         filmic = fm.default_data()
     coeffs = params.unbounded_coeffs(lut)
+    if which == "denoise":
+        return pipe.denoise_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, filmic=filmic)
     return pipe.light_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, with_filmic=with_filmic,
                                  filmic=filmic)
 
@@ -75,7 +80,7 @@ def have_filmic():
         return False
 
 
-def cpu_baseline(size_name, with_filmic):
+def cpu_baseline(size_name, with_filmic, which="light"):
     """The reference's own process() code (oracle/_ref/libansel_ref_fast.so: its sources compiled
     in place with its release flags, OpenMP on every host core) on a bounded sample of the same
     workload.  Falls back to the C restatement (kind "port", 1 thread) where _ref is absent."""
@@ -164,7 +169,7 @@ def main():
     raw = torch.from_numpy(raw_host.view(np.int16)).to(dev)
     lut_host = params.srgb_encode_lut()
     lut = torch.from_numpy(lut_host).to(dev)
-    nodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic)
+    nodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic, args.pipe)
     # intermediates belong to the executor: it draws them from the runtime's pool
     executor = pipe.DevicePipe(devid, nodes, fusion=not args.no_fusion)
     my_rows = height
@@ -226,19 +231,24 @@ def main():
         # algorithmic bytes per pixel of each tagged kernel
         tag_bpp = {"rawprepare_1f": 6, "temperature_1f": 8, "highlights_clip_1f": 8, "rcd_tiles": 20,
                    "ppg_full": 20, "exposure": 32, "colorin": 32, "channelmixerrgb": 32, "filmicrgb": 32,
-                   "colorout": 32, "export_u16": 24}
+                   "colorout": 32, "export_u16": 24, "dn_precondition": 32, "dn_decompose": 48, "dn_synthesize": 48,
+                   "dn_finish": 48, "diffuse_decompose": 48, "diffuse_pde": 48}
         if not args.no_fusion:
             # a fused group is credited with the algorithmic bytes of the modules it executes
             tag_bpp["raw_chain"] = sum(sum(pipe.MODULE_BPP[n.op]) for n in nodes if n.op in ("rawprepare", "temperature", "highlights"))
             tag_bpp["rgb_chain_u16"] = sum(sum(pipe.MODULE_BPP[n.op]) for n in nodes
                                            if n.op in ("exposure", "colorin", "channelmixerrgb", "filmicrgb", "colorout", "export_u16"))
+            if args.pipe == "denoise":
+                # two fused RGBA groups: exposure > colorin > calibration | filmic > colorout > u16
+                tag_bpp["rgb_chain"] = 3 * 32
+                tag_bpp["rgb_chain_u16"] = 2 * 32 + 24
         dominant = max((k for k in kernels if k in tag_bpp), key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])
         dom = kernels[dominant]
         dom_bytes = tag_bpp[dominant] * my_rows * width  # rank 0's share of the frame in tiled mode
         achieved = dom_bytes / (dom["ms_avg"] * 1e-3) / 1e9
         pipe_bpp = pipe.algorithmic_bytes_per_pixel(nodes)
         ms_per_step = elapsed / args.steps * 1e3
-        kernel_ms = sum(v["ms_avg"] for k, v in kernels.items())
+        kernel_ms = sum(v["ms_avg"] * v["launches"] for k, v in kernels.items()) / args.steps
         line = {
             "metric": "MPix/s full export pixelpipe (100 MP raw); % MI355X HBM roofline",
             "value": round((1 if args.mode == "tiled" else world) * npix / 1e6 / (elapsed / args.steps), 2),
@@ -263,6 +273,7 @@ def main():
                 "pipe_hbm_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "pipe_kernel_ms": round(kernel_ms, 4),
                 "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(kernels.items())},
+                "kernel_launches_per_step": {k: v["launches"] // args.steps for k, v in sorted(kernels.items())},
             },
             "roofline": {
                 "bound": "hbm",
@@ -275,7 +286,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.cpu_sample, with_filmic)
+            cb = cpu_baseline(args.cpu_sample, with_filmic, args.pipe)
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)

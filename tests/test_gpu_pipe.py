@@ -123,3 +123,18 @@ def test_executor_rejects_unknown_module():
     d = abi.ExposureData(0.0, 1.0)
     assert l.dt_hip_pipe_add_node(p, b"exposure", C.byref(piece), C.cast(C.byref(d), C.c_void_p), 4) == abi.DT_HIP_INVALID_ARG
     l.dt_hip_pipe_free(p)
+
+
+def test_denoise_pipe_executor_equals_modulewise_and_oracle():
+    """config 3 as far as it runs on device: + denoise (profiled) wavelets + diffuse or sharpen.  The
+    stencil modules run as their own launches between the fused pointwise groups."""
+    w, h = 640, 400
+    raw, lut, d_lut, coeffs = _setup(w, h, seed=4)
+    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.ptr, float(lut[0]), coeffs, filmic=filmic.default_data())
+    modulewise = _run_chain_modulewise(nodes, raw, w, h)
+    fused, groups = _run_executor(nodes, raw, w, h, fusion=True)
+    unfused, g0 = _run_executor(nodes, raw, w, h, fusion=False)
+    assert g0 == len(nodes) and groups == 6, (g0, groups)  # raw | rcd | denoise | exp,colorin,calib | diffuse | filmic,colorout,u16
+    assert np.array_equal(modulewise, fused) and np.array_equal(modulewise, unfused)
+    host_nodes = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, filmic=filmic.default_data())
+    assert np.array_equal(fused, _run_cpu("oracle", host_nodes, raw, w, h))
