@@ -113,6 +113,14 @@ DT_HIP_DENOISEPROFILE_RGB = 0
 DT_HIP_DENOISEPROFILE_Y0U0V0 = 1
 
 
+class NlmeansData(C.Structure):
+    """dt_hip_nlmeans_data_t == dt_iop_nlmeans_params_t (src/iop/nlmeans.c:81-88)"""
+    _fields_ = [("radius", C.c_float), ("strength", C.c_float), ("luma", C.c_float), ("chroma", C.c_float)]
+
+
+DT_HIP_DENOISEPROFILE_NLMEANS = 0
+
+
 class Conversion(C.Structure):
     _fields_ = [("matrix", m34), ("clip_matrix", m34), ("has_clipping", C.c_int),
                 ("nonlinear_source", C.c_int), ("nonlinear_target", C.c_int), ("blue_mapping", C.c_int),

@@ -167,16 +167,18 @@ def diffuse(preset="default", iscale=1.0, **over):
 
 # ---- denoise (profiled), wavelets (src/iop/denoiseprofile.c) ------------------------------------
 def denoiseprofile(color_mode=abi.DT_HIP_DENOISEPROFILE_Y0U0V0, use_new_vst=True, fix=True, wb_adaptive=True,
-                   strength=1.0, shadows=1.0, bias=0.0, a=2.0e-5 * 4, b=-2.0e-7, force=None, wb=None):
+                   strength=1.0, shadows=1.0, bias=0.0, a=2.0e-5 * 4, b=-2.0e-7, force=None, wb=None,
+                   mode=abi.DT_HIP_DENOISEPROFILE_WAVELETS, radius=1.0, nbhood=7.0, scattering=0.0,
+                   central_pixel_weight=0.1):
     """module defaults ($DEFAULT annotations, denoiseprofile.c:270-305) with a Sony-like ISO 400 noise
     profile {a, b} and flat 0.5 force curves"""
     d = abi.DenoiseprofileData()
-    d.radius, d.nbhood, d.strength, d.shadows, d.bias = 1.0, 7.0, strength, shadows, bias
-    d.scattering, d.central_pixel_weight, d.overshooting = 0.0, 0.1, 1.0
+    d.radius, d.nbhood, d.strength, d.shadows, d.bias = radius, nbhood, strength, shadows, bias
+    d.scattering, d.central_pixel_weight, d.overshooting = scattering, central_pixel_weight, 1.0
     for k in range(3):
         d.a[k] = a
         d.b[k] = b
-    d.mode = abi.DT_HIP_DENOISEPROFILE_WAVELETS
+    d.mode = mode
     for c in range(6):
         for band in range(7):
             d.force[c][band] = 0.5 if force is None else float(force[c][band])

@@ -319,7 +319,7 @@ void dt_hip_iop_diffuse_tiling(const dt_hip_piece_t *piece, const dt_hip_diffuse
  * Fields are those of dt_iop_denoiseprofile_data_t (denoiseprofile.c:352-371) the path reads;
  * force[][] is the per-band curve sampling commit_params() leaves there (:3088-3100);
  * wb_coeffs = piece->dsc_in.temperature.coeffs (read by compute_wb_factors(), :1097-1128).
- * mode: only DT_HIP_DENOISEPROFILE_WAVELETS is implemented on device.
+ * mode: DT_HIP_DENOISEPROFILE_WAVELETS or DT_HIP_DENOISEPROFILE_NLMEANS.
  *
  * The sum of squared detail coefficients per band is an OpenMP reduction in the reference, i.e. its
  * value depends on the host's thread count; the device (and the oracle) define it as the binary64
@@ -344,6 +344,19 @@ typedef struct dt_hip_denoiseprofile_data_t
 int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece,
                                       const dt_hip_denoiseprofile_data_t *d, dt_hip_mem_t dev_in,
                                       dt_hip_mem_t dev_out);
+
+/* denoise (non-local means): process() -> process_cpu(), src/iop/nlmeans.c:416-465, over
+ * nlmeans_denoise(), src/pixel/nlmeans_core.c:315-532 (Lab input; patch radius P = ceil(radius * scale),
+ * search radius K = ceil(7 * scale), centre weight < 0 branch, luma/chroma blend).
+ * dt_hip_nlmeans_data_t == dt_iop_nlmeans_params_t (nlmeans.c:81-88).
+ * The same core runs denoise (profiled) in DT_HIP_DENOISEPROFILE_NLMEANS mode
+ * (process_nlmeans_cpu(), src/iop/denoiseprofile.c:1599-1648). */
+typedef struct dt_hip_nlmeans_data_t
+{
+  float radius, strength, luma, chroma;
+} dt_hip_nlmeans_data_t;
+int dt_hip_iop_nlmeans_process(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d,
+                               dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
 /* ---- 3. export-pipe executor ----------------------------------------------------------- */
 /* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)

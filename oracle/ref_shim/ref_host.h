@@ -82,8 +82,10 @@ typedef struct dt_dev_pixelpipe_t
   float iscale;
 } dt_dev_pixelpipe_t;
 
+struct dt_iop_module_t;
 typedef struct dt_dev_pixelpipe_iop_t
 {
+  struct dt_iop_module_t *module;
   void *data;
   dt_iop_roi_t roi_in, roi_out;
   dt_iop_roi_t buf_in, buf_out;

@@ -18,7 +18,7 @@ typedef void *GtkWidget;
 int ref_denoiseprofile(const dt_hip_piece_t *v, const dt_hip_denoiseprofile_data_t *h, const void *in, void *out)
 {
   ref_reset_fp_mode();
-  if(h->mode != DT_HIP_DENOISEPROFILE_WAVELETS) return 1;
+  if(h->mode != DT_HIP_DENOISEPROFILE_WAVELETS && h->mode != DT_HIP_DENOISEPROFILE_NLMEANS) return 1;
   dt_iop_denoiseprofile_data_t d;
   memset(&d, 0, sizeof(d));
   d.radius = h->radius;
@@ -34,7 +34,7 @@ int ref_denoiseprofile(const dt_hip_piece_t *v, const dt_hip_denoiseprofile_data
     d.a[k] = h->a[k];
     d.b[k] = h->b[k];
   }
-  d.mode = MODE_WAVELETS;
+  d.mode = h->mode == DT_HIP_DENOISEPROFILE_WAVELETS ? MODE_WAVELETS : MODE_NLMEANS;
   for(int c = 0; c < 6; c++)
     for(int b = 0; b < DT_IOP_DENOISE_PROFILE_BANDS; b++) d.force[c][b] = h->force[c][b];
   d.wb_adaptive_anscombe = h->wb_adaptive_anscombe;
@@ -46,6 +46,9 @@ int ref_denoiseprofile(const dt_hip_piece_t *v, const dt_hip_denoiseprofile_data
   for(int k = 0; k < 4; k++) piece.dsc_in.temperature.coeffs[k] = h->wb_coeffs[k];
   dt_dev_pixelpipe_t pipe;
   memset(&pipe, 0, sizeof(pipe));
+  pipe.type = DT_DEV_PIXELPIPE_EXPORT;
+  if(d.mode == MODE_NLMEANS)
+    return process_nlmeans_cpu(&pipe, &piece, in, out, &piece.roi_in, &piece.roi_out, nlmeans_denoise);
   return process_wavelets(NULL, &pipe, &piece, in, out, &piece.roi_in, &piece.roi_out, eaw_dn_decompose,
                           eaw_synthesize);
 }

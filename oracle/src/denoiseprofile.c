@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
+#include "nlmeans_core.h"
 
 #define BANDS DT_HIP_DENOISEPROFILE_BANDS
 #define P_FULCRUM 0.05f /* denoiseprofile.c:118 */
@@ -74,7 +75,8 @@ static int invert3(const float in[3][4], float out[3][4])
   return 1;
 }
 
-static int dn_setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, dn_setup_t *s)
+/* nlm = 0: process_wavelets() :1331-1378; nlm = 1: nlmeans_precondition() :1510-1546 */
+static int dn_setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, dn_setup_t *s, const int nlm)
 {
   memset(s, 0, sizeof(*s));
   const float in_scale = fminf((float)piece->roi_in.scale, 1.0f);
@@ -94,7 +96,7 @@ static int dn_setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_dat
   s->max_scale = max_scale;
 
   /* compute_wb_factors() with weights {2, 1, 2, 0}, :1097-1128 */
-  const float weights[4] = { 2.0f, 1.0f, 2.0f, 0.0f };
+  const float weights[4] = { nlm ? 1.0f : 2.0f, 1.0f, nlm ? 1.0f : 2.0f, 0.0f };
   const float wb_mean = (d->wb_coeffs[0] + d->wb_coeffs[1] + d->wb_coeffs[2]) / 3.0f;
   float *wb = s->wb;
   wb[0] = wb[1] = wb[2] = wb[3] = wb_mean;
@@ -142,7 +144,7 @@ static int dn_setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_dat
     invert3(toY, toRGB);
   }
   const float compensate_strength = (d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB) ? 1.0f : 2.5f;
-  const float gain = d->strength * compensate_strength * in_scale;
+  const float gain = nlm ? d->strength * in_scale : d->strength * compensate_strength * in_scale;
   for(int k = 0; k < 3; k++)
     for(int c = 0; c < 4; c++)
     {
@@ -157,11 +159,12 @@ static int dn_setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_dat
     s->aa[i] = d->a[1] * wb[i];
     s->bb[i] = d->b[1] * wb[i];
   }
-  s->aa[3] = s->bb[3] = 0.0f;
+  s->aa[3] = nlm ? d->a[1] * wb[3] : 0.0f;
+  s->bb[3] = nlm ? d->b[1] * wb[3] : 0.0f;
   s->a_v2 = d->a[1] * compensate_p;
   s->b_v2 = d->b[1];
   s->bias = (float)((double)d->bias - 0.5 * (double)logf(in_scale));
-  s->vst = !d->use_new_vst ? 0 : (d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB ? 1 : 2);
+  s->vst = !d->use_new_vst ? 0 : ((nlm || d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB) ? 1 : 2);
   return 0;
 }
 
@@ -444,19 +447,60 @@ static void band_threshold(float thrs[4], const int scale, const int max_scale, 
 int oracle_denoiseprofile_bands(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d)
 {
   dn_setup_t s;
-  dn_setup(piece, d, &s);
+  dn_setup(piece, d, &s, 0);
   return s.max_scale;
+}
+
+/* process_nlmeans_cpu(), denoiseprofile.c:1599-1648, with nlmeans_norm() :1457-1472 and
+ * nlmeans_scattering() :1476-1500 (export pipe: no preview output, not a thumbnail) */
+static int denoise_nlmeans(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, const float *in, float *out)
+{
+  const int w = piece->roi_in.width, h = piece->roi_in.height;
+  const size_t npix = (size_t)w * h;
+  const float scale = fminf(fminf((float)piece->roi_in.scale, 2.0f), 1.0f);
+  const int P = (int)ceilf(d->radius * scale);
+  int K = (int)d->nbhood;
+  float scattering = d->scattering;
+  {
+    const int maxk = (int)((K * K * K + 7.0 * K * sqrt(K)) * scattering / 6.0 + K);
+    const float kf = (float)K * scale;
+    const int k4 = K < 4 ? K : 4;
+    K = (int)((float)k4 > kf ? (float)k4 : kf);
+    scattering = (float)((maxk - K) * 6.0 / (K * K * K + 7.0 * K * sqrt(K)));
+  }
+  float norm = .045f / ((2 * P + 1) * (2 * P + 1));
+  if(!d->fix_anscombe_and_nlmeans_norm) norm = .015f / (2 * P + 1);
+  dn_setup_t s;
+  dn_setup(piece, d, &s, 1);
+  float *pre = (float *)malloc(sizeof(float) * 4 * npix);
+  precondition(&s, in, pre, npix);
+  oracle_nlm_params_t p;
+  memset(&p, 0, sizeof(p));
+  p.scattering = scattering;
+  p.scale = scale;
+  p.luma = 1.0f;
+  p.chroma = 1.0f;
+  p.center_weight = d->central_pixel_weight * scale;
+  p.sharpness = norm;
+  p.patch_radius = P;
+  p.search_radius = K;
+  p.norm[0] = p.norm[1] = p.norm[2] = p.norm[3] = 1.0f;
+  oracle_nlmeans_core(pre, out, w, h, &p);
+  free(pre);
+  backtransform(&s, out, npix);
+  return 0;
 }
 
 int oracle_denoiseprofile(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, const void *in_, void *out_)
 {
+  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return denoise_nlmeans(piece, d, (const float *)in_, (float *)out_);
   if(d->mode != DT_HIP_DENOISEPROFILE_WAVELETS) return 1;
   const int w = piece->roi_in.width, h = piece->roi_in.height;
   const size_t npix = (size_t)w * h;
   const float *in = (const float *)in_;
   float *out = (float *)out_;
   dn_setup_t s;
-  dn_setup(piece, d, &s);
+  dn_setup(piece, d, &s, 0);
   const int max_mult = 1 << (s.max_scale - 1);
   if(w < 2 * max_mult || h < 2 * max_mult)
   {

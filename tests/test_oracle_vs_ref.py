@@ -222,3 +222,44 @@ def test_denoiseprofile_wavelets(case):
     assert float(rel.max()) < 2e-5, float(rel.max())
     # the filter did something, and the result is sane
     assert np.isfinite(b[..., :3]).all() and float(np.abs(b[..., :3] - img[..., :3]).max()) > 1e-4
+
+
+def _lab_image(w, h, seed):
+    rng = np.random.default_rng(seed)
+    rgb = synth.rgba_image(w, h, seed=seed, lo=0.0, hi=1.0)
+    lab = np.zeros((h, w, 4), np.float32)
+    lab[..., 0] = 100.0 * rgb[..., 1] + rng.normal(0, 1.5, (h, w))
+    lab[..., 1] = 80.0 * (rgb[..., 0] - rgb[..., 1]) + rng.normal(0, 2.0, (h, w))
+    lab[..., 2] = 80.0 * (rgb[..., 1] - rgb[..., 2]) + rng.normal(0, 2.0, (h, w))
+    return np.ascontiguousarray(lab.astype(np.float32))
+
+
+@pytest.mark.parametrize("w,h", [(150, 131), (73, 61), (300, 64)])
+@pytest.mark.parametrize("radius,strength,luma,chroma", [(2.0, 50.0, 0.5, 1.0), (1.0, 20.0, 1.0, 1.0), (3.0, 200.0, 0.3, 0.8)])
+def test_nlmeans(w, h, radius, strength, luma, chroma):
+    img = _lab_image(w, h, 17)
+    d = abi.NlmeansData(radius, strength, luma, chroma)
+    a, b = _pair("nlmeans", abi.Piece.make(w, h), d, img, img.shape)
+    _exact(a, b, "nlmeans")
+    assert float(np.abs(b[..., :3] - img[..., :3]).max()) > 1e-3
+
+
+def test_nlmeans_scaled():
+    w, h = 120, 90
+    img = _lab_image(w, h, 5)
+    piece = abi.Piece.make(w, h, roi_in=abi.Roi.make(0, 0, w, h, 0.5), roi_out=abi.Roi.make(0, 0, w, h, 0.5))
+    a, b = _pair("nlmeans", piece, abi.NlmeansData(2.0, 50.0, 0.5, 1.0), img, img.shape)
+    _exact(a, b, "nlmeans scale 0.5")
+
+
+@pytest.mark.parametrize("over", [dict(), dict(use_new_vst=False), dict(use_new_vst=False, fix=False),
+                                  dict(radius=2.0, nbhood=5.0, scattering=0.6, central_pixel_weight=0.5, strength=1.3),
+                                  dict(wb_adaptive=False, shadows=0.5, bias=-2.0, nbhood=3.0)])
+def test_denoiseprofile_nlmeans(over):
+    """non-local means mode: no frame-wide reduction, so the match is exact"""
+    w, h = 160, 131
+    img = _noisy(w, h, 23)
+    d = params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS, **over)
+    a, b = _pair("denoiseprofile", abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS), d, img, img.shape)
+    _exact(a, b, "denoiseprofile nlmeans")
+    assert float(np.abs(b[..., :3] - img[..., :3]).max()) > 1e-5
