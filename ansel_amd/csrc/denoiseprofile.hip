@@ -20,6 +20,7 @@
 //      number), which are then reduced by halving (off = 512..1); rounded once to binary32.
 #include "hip_common.h"
 #include "devmath.h"
+#include "nlmeans_core_params.h"
 
 #include <math.h>
 
@@ -109,8 +110,16 @@ __global__ __launch_bounds__(256) void dn_finish(float4 *__restrict__ out, const
 {
   for(size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += (size_t)gridDim.x * blockDim.x)
   {
-    const float4 acc = out[j], res = residue[j];
-    const float v[4] = { acc.x + res.x, acc.y + res.y, acc.z + res.z, acc.w + res.w };
+    const float4 acc = out[j];
+    float v[4] = { acc.x, acc.y, acc.z, acc.w };
+    if(residue)
+    {
+      const float4 res = residue[j];
+      v[0] = acc.x + res.x;
+      v[1] = acc.y + res.y;
+      v[2] = acc.z + res.z;
+      v[3] = acc.w + res.w;
+    }
     float o[4];
     if(a.vst == 0)
     {
@@ -327,7 +336,8 @@ bool invert3(const float in[3][4], float out[3][4])
   return true;
 }
 
-void setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, dn_setup &s)
+// nlm false: process_wavelets() :1331-1378; nlm true: nlmeans_precondition() :1510-1546
+void setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, dn_setup &s, const bool nlm)
 {
   memset(&s, 0, sizeof(s));
   const float in_scale = fminf((float)piece->roi_in.scale, 1.0f);
@@ -347,7 +357,7 @@ void setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, d
   s.max_scale = max_scale;
 
   // compute_wb_factors() with weights {2, 1, 2, 0}, :1097-1128
-  const float weights[4] = { 2.0f, 1.0f, 2.0f, 0.0f };
+  const float weights[4] = { nlm ? 1.0f : 2.0f, 1.0f, nlm ? 1.0f : 2.0f, 0.0f };
   const float wb_mean = (d->wb_coeffs[0] + d->wb_coeffs[1] + d->wb_coeffs[2]) / 3.0f;
   float *wb = s.wb;
   wb[0] = wb[1] = wb[2] = wb[3] = wb_mean;
@@ -396,7 +406,7 @@ void setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, d
     invert3(toY, toRGB);
   }
   const float compensate_strength = (d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB) ? 1.0f : 2.5f;
-  const float gain = d->strength * compensate_strength * in_scale;
+  const float gain = nlm ? d->strength * in_scale : d->strength * compensate_strength * in_scale;
   for(int k = 0; k < 3; k++)
     for(int c = 0; c < 4; c++)
     {
@@ -411,11 +421,12 @@ void setup(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, d
     s.aa[i] = d->a[1] * wb[i];
     s.bb[i] = d->b[1] * wb[i];
   }
-  s.aa[3] = s.bb[3] = 0.0f;
+  s.aa[3] = nlm ? d->a[1] * wb[3] : 0.0f;
+  s.bb[3] = nlm ? d->b[1] * wb[3] : 0.0f;
   s.a_v2 = d->a[1] * compensate_p;
   s.b_v2 = d->b[1];
   s.bias = (float)((double)d->bias - 0.5 * (double)logf(in_scale));
-  s.vst = !d->use_new_vst ? 0 : (d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB ? 1 : 2);
+  s.vst = !d->use_new_vst ? 0 : ((nlm || d->wavelet_color_mode == DT_HIP_DENOISEPROFILE_RGB) ? 1 : 2);
 }
 
 void forward_args(const dn_setup &s, vst_args &a)
@@ -512,6 +523,61 @@ void threshold_args(const dt_hip_denoiseprofile_data_t *d, const int scale, cons
   for(int c = 0; c < 4; c++) t.adjt[c] = adjt[c];
 }
 
+// process_nlmeans_cpu(), denoiseprofile.c:1599-1648, with nlmeans_norm() :1457-1472 and
+// nlmeans_scattering() :1476-1500 for an export pipe (no preview output, not a thumbnail)
+int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, dt_hip_mem_t dev_in,
+                    dt_hip_mem_t dev_out)
+{
+  const int w = piece->roi_in.width, h = piece->roi_in.height;
+  const size_t npix = (size_t)w * h;
+  const float scale = fminf(fminf((float)piece->roi_in.scale, 2.0f), 1.0f);
+  const int P = (int)ceilf(d->radius * scale);
+  int K = (int)d->nbhood;
+  float scattering = d->scattering;
+  {
+    const int maxk = (int)((K * K * K + 7.0 * K * sqrt((double)K)) * scattering / 6.0 + K);
+    const float kf = (float)K * scale;
+    const int k4 = K < 4 ? K : 4;
+    K = (int)((float)k4 > kf ? (float)k4 : kf);
+    scattering = (float)((maxk - K) * 6.0 / (K * K * K + 7.0 * K * sqrt((double)K)));
+  }
+  float norm = .045f / ((2 * P + 1) * (2 * P + 1));
+  if(!d->fix_anscombe_and_nlmeans_norm) norm = .015f / (2 * P + 1);
+  dn_setup s;
+  setup(piece, d, s, true);
+  float4 *pre = (float4 *)dt_hip_alloc_device_buffer(devid, npix * sizeof(float4));
+  if(!pre) return DT_HIP_SYSMEM_ALLOCATION;
+  hipStream_t st = stream_of(devid);
+  const unsigned sgrid = stream_grid(npix, 256);
+  {
+    vst_args fa;
+    forward_args(s, fa);
+    launch_scope ls(devid, "dn_precondition");
+    dn_precondition<<<sgrid, 256, 0, st>>>((const float4 *)dev_in, pre, npix, fa);
+  }
+  nlm_core_params_t p;
+  memset(&p, 0, sizeof(p));
+  p.scattering = scattering;
+  p.scale = scale;
+  p.luma = 1.0f;
+  p.chroma = 1.0f;
+  p.center_weight = d->central_pixel_weight * scale;
+  p.sharpness = norm;
+  p.patch_radius = P;
+  p.search_radius = K;
+  p.norm[0] = p.norm[1] = p.norm[2] = p.norm[3] = 1.0f;
+  int err = nlmeans_core_launch(devid, pre, (float4 *)dev_out, w, h, p);
+  dt_hip_release_mem_object(pre);
+  if(err != DT_HIP_SUCCESS) return err;
+  {
+    vst_args ia;
+    inverse_args(s, ia);
+    launch_scope ls(devid, "dn_finish");
+    dn_finish<<<sgrid, 256, 0, st>>>((float4 *)dev_out, nullptr, npix, ia);
+  }
+  return check_launch("dn_finish");
+}
+
 } // namespace
 
 extern "C" {
@@ -520,17 +586,18 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
                                       dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
-  if(d->mode != DT_HIP_DENOISEPROFILE_WAVELETS)
+  if(d->mode != DT_HIP_DENOISEPROFILE_WAVELETS && d->mode != DT_HIP_DENOISEPROFILE_NLMEANS)
   {
-    set_last_error("denoiseprofile: only the wavelets mode is implemented on device");
+    set_last_error("denoiseprofile: mode %d is not implemented on device (wavelets and non-local means are)", d->mode);
     return DT_HIP_INVALID_ARG;
   }
   if(piece->channels != 4 || !(piece->roi_in.scale > 0.0)) return DT_HIP_INVALID_ARG;
   const int w = piece->roi_in.width, h = piece->roi_in.height;
   if(w <= 0 || h <= 0) return DT_HIP_SUCCESS;
   const size_t npix = (size_t)w * h, plane = npix * sizeof(float4);
+  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return denoise_nlmeans(devid, piece, d, dev_in, dev_out);
   dn_setup s;
-  setup(piece, d, s);
+  setup(piece, d, s, false);
   if(s.max_scale < 1)
   {
     set_last_error("denoiseprofile: frame too small for a single wavelet band");

@@ -1,0 +1,14 @@
+// nlmeans_core_params.h -- dt_nlmeans_param_t (src/pixel/nlmeans_core.h:31-50) as the device core takes it
+#pragma once
+#include "hip_common.h"
+
+namespace ansel
+{
+struct nlm_core_params_t
+{
+  float scattering, scale, luma, chroma, center_weight, sharpness;
+  int patch_radius, search_radius;
+  float norm[4];
+};
+int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int height, const nlm_core_params_t &p);
+} // namespace ansel
