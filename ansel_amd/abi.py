@@ -113,6 +113,17 @@ DT_HIP_DENOISEPROFILE_RGB = 0
 DT_HIP_DENOISEPROFILE_Y0U0V0 = 1
 
 
+class LabData(C.Structure):
+    """dt_hip_lab_data_t: the 3x3 (rows padded to 4) of the RGB <-> Lab glue"""
+    _fields_ = [("matrix", m34)]
+
+    @classmethod
+    def make(cls, m):
+        d = cls()
+        set_m34(d.matrix, m)
+        return d
+
+
 class NlmeansData(C.Structure):
     """dt_hip_nlmeans_data_t == dt_iop_nlmeans_params_t (src/iop/nlmeans.c:81-88)"""
     _fields_ = [("radius", C.c_float), ("strength", C.c_float), ("luma", C.c_float), ("chroma", C.c_float)]

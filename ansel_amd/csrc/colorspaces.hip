@@ -119,3 +119,86 @@ int dt_hip_iop_colorout_process(int devid, const dt_hip_piece_t *piece, const dt
 }
 
 } // extern "C"
+
+namespace
+{
+// lab_f() with cbrt_5f() + cbrta_halleyf(), src/common/colorspaces_inline_conversions.h:50-73
+__device__ __forceinline__ float lab_f(const float x)
+{
+  const float epsilon = 216.0f / 24389.0f, kappa = 24389.0f / 27.0f;
+  if(!(x > epsilon)) return (kappa * x + 16.0f) / 116.0f;
+  const float a = __uint_as_float(__float_as_uint(x) / 3u + 709921077u);
+  const float a3 = a * a * a;
+  return a * (a3 + x + x) / (a3 + a3 + x);
+}
+// lab_f_inv(), :88-94
+__device__ __forceinline__ float lab_f_inv(const float x)
+{
+  const float epsilon = 0.20689655172413796f, kappa = 24389.0f / 27.0f;
+  return (x > epsilon) ? x * x * x : (116.0f * x - 16.0f) / kappa;
+}
+
+struct lab_args
+{
+  float m[3][4];
+};
+
+// _transform_rgb_to_lab_matrix(), src/colorprofiles/iop_profile.c:405-418 + dt_XYZ_to_Lab()
+__global__ __launch_bounds__(256) void rgb_to_lab(const float4 *in, float4 *out, const size_t n,
+                                                  const lab_args a)
+{
+  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+  {
+    const float4 p = in[k];
+    const float4 xyz = mat3x4(p.x, p.y, p.z, a.m);
+    const float f0 = lab_f(xyz.x / 0.9642f), f1 = lab_f(xyz.y / 1.0f), f2 = lab_f(xyz.z / 0.8249f);
+    out[k] = make_float4(116.0f * f1 - 16.0f, 500.0f * (f0 - f1), 200.0f * (f1 - f2), p.w);
+  }
+}
+
+// _transform_lab_to_rgb_matrix(), :423-450 + dt_Lab_to_XYZ()
+__global__ __launch_bounds__(256) void lab_to_rgb(const float4 *in, float4 *out, const size_t n,
+                                                  const lab_args a)
+{
+  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+  {
+    const float4 p = in[k];
+    const float fy = (p.x + 16.0f) / 116.0f;
+    const float fx = p.y / 500.0f + fy;
+    const float fz = fy - p.z / 200.0f;
+    const float4 rgb = mat3x4(0.9642f * lab_f_inv(fx), 1.0f * lab_f_inv(fy), 0.8249f * lab_f_inv(fz), a.m);
+    out[k] = make_float4(rgb.x, rgb.y, rgb.z, p.w);
+  }
+}
+
+int lab_launch(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, dt_hip_mem_t dev_in,
+               dt_hip_mem_t dev_out, const bool to_lab)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || piece->channels != 4) return DT_HIP_INVALID_ARG;
+  const size_t n = (size_t)piece->roi_out.width * piece->roi_out.height;
+  if(n == 0) return DT_HIP_SUCCESS;
+  lab_args a;
+  memcpy(a.m, d->matrix, sizeof(a.m));
+  hipStream_t s = stream_of(devid);
+  launch_scope ls(devid, to_lab ? "rgb_to_lab" : "lab_to_rgb");
+  if(to_lab)
+    rgb_to_lab<<<stream_grid(n, 256), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, n, a);
+  else
+    lab_to_rgb<<<stream_grid(n, 256), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, n, a);
+  return check_launch(to_lab ? "rgb_to_lab" : "lab_to_rgb");
+}
+} // namespace
+
+extern "C" {
+int dt_hip_transform_rgb_to_lab(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, dt_hip_mem_t dev_in,
+                                dt_hip_mem_t dev_out)
+{
+  return lab_launch(devid, piece, d, dev_in, dev_out, true);
+}
+int dt_hip_transform_lab_to_rgb(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, dt_hip_mem_t dev_in,
+                                dt_hip_mem_t dev_out)
+{
+  return lab_launch(devid, piece, d, dev_in, dev_out, false);
+}
+} // extern "C"
+

@@ -467,6 +467,7 @@ size_t dt_hip_abi_sizeof(const char *name)
   S("diffuse", dt_hip_diffuse_data_t);
   S("denoiseprofile", dt_hip_denoiseprofile_data_t);
   S("nlmeans", dt_hip_nlmeans_data_t);
+  S("lab", dt_hip_lab_data_t);
   S("band", dt_hip_band_t);
   S("band_state", dt_hip_band_state_t);
 #undef S

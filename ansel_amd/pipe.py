@@ -16,7 +16,7 @@ from . import abi, lib, params, synth
 MODULE_BPP = {
     "rawprepare": (2, 4), "temperature": (4, 4), "highlights": (4, 4), "demosaic": (4, 16),
     "exposure": (16, 16), "colorin": (16, 16), "channelmixerrgb": (16, 16), "filmicrgb": (16, 16),
-    "colorout": (16, 16), "export_u16": (16, 8),
+    "colorout": (16, 16), "export_u16": (16, 8), "rgb_to_lab": (16, 16), "lab_to_rgb": (16, 16), "nlmeans": (16, 16),
 }
 
 
@@ -55,7 +55,7 @@ def light_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, with_
 
 
 def denoise_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, filmic=None,
-                       diffuse_preset="lens_deblur_soft", diffuse_iterations=2):
+                       diffuse_preset="lens_deblur_soft", diffuse_iterations=2, with_nlmeans=False):
     """config 3 of BASELINE.json, as far as it runs on device: the light pipe + denoise (profiled)
     wavelets after demosaic and diffuse-or-sharpen after color calibration, in the reference's module
     order (src/develop/iop_order.c:196-232)."""
@@ -69,6 +69,11 @@ def denoise_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, fil
             out.append(Node("denoiseprofile", params.denoiseprofile(), rgb))
         if n.op == "channelmixerrgb":
             out.append(Node("diffuse", params.diffuse(diffuse_preset, iterations=diffuse_iterations), rgb))
+            if with_nlmeans:
+                # a Lab module: the pipe converts work RGB -> Lab before and back after it (pixelpipe_cpu.c:59-75)
+                out.append(Node("rgb_to_lab", abi.LabData.make(params.WORK_IN), rgb))
+                out.append(Node("nlmeans", abi.NlmeansData(2.0, 50.0, 0.5, 1.0), rgb))
+                out.append(Node("lab_to_rgb", abi.LabData.make(params.WORK_OUT), rgb))
     return out
 
 
@@ -131,6 +136,8 @@ def run_nodes(devid, nodes, buffers):
         src, dst = buffers[i], buffers[i + 1]
         if n.op == "export_u16":
             rc = l.dt_hip_export_convert_u16(devid, n.piece.roi_out.width, n.piece.roi_out.height, src, dst)
+        elif n.op in ("rgb_to_lab", "lab_to_rgb"):
+            rc = getattr(l, "dt_hip_transform_" + n.op)(devid, C.byref(n.piece), C.byref(n.data), src, dst)
         else:
             fn = getattr(l, "dt_hip_iop_%s_process" % n.op)
             rc = fn(devid, C.byref(n.piece), C.byref(n.data), src, dst)

@@ -358,6 +358,20 @@ typedef struct dt_hip_nlmeans_data_t
 int dt_hip_iop_nlmeans_process(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d,
                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
+/* RGB <-> Lab glue the pixelpipe runs around Lab modules (src/develop/pixelpipe_cpu.c:59-75 ->
+ * dt_ioppr_transform_image_colorspace(), src/colorprofiles/iop_profile.c:540-596) for a linear matrix
+ * work profile: _transform_rgb_to_lab_matrix() / _transform_lab_to_rgb_matrix() (:377-463).
+ * matrix = the profile's RGB -> XYZ(D50) (to Lab) resp. XYZ(D50) -> RGB (from Lab) 3x3, rows padded
+ * to 4.  Alpha is carried over (the pipe converts in place).  dev_in == dev_out is allowed. */
+typedef struct dt_hip_lab_data_t
+{
+  float matrix[3][4];
+} dt_hip_lab_data_t;
+int dt_hip_transform_rgb_to_lab(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d,
+                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+int dt_hip_transform_lab_to_rgb(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d,
+                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
 /* ---- 3. export-pipe executor ----------------------------------------------------------- */
 /* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)
  * for an export: an ordered list of module nodes, each with its piece view and committed data,
@@ -367,7 +381,8 @@ int dt_hip_iop_nlmeans_process(int devid, const dt_hip_piece_t *piece, const dt_
  * kernel each -- rawprepare/temperature/highlights before demosaic; exposure/colorin/
  * channelmixerrgb/filmicrgb/colorout/export_u16 after -- with results bit-identical to the
  * module-by-module chain.  `op` is the module's op name ("rawprepare", "temperature",
- * "highlights", "demosaic", "exposure", "colorin", "channelmixerrgb", "filmicrgb", "colorout") or
+ * "highlights", "demosaic", "denoiseprofile", "exposure", "colorin", "channelmixerrgb", "diffuse",
+ * "nlmeans", "filmicrgb", "colorout"), the colourspace glue "rgb_to_lab" / "lab_to_rgb", or
  * "export_u16" (data NULL) for the final float -> u16 of src/imageio/imageio_core.c:729. */
 typedef struct dt_hip_pipe_t dt_hip_pipe_t;
 dt_hip_pipe_t *dt_hip_pipe_new(int devid);

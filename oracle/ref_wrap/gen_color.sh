@@ -9,6 +9,7 @@ $X $R/colorprofiles/iop_profile.h $G/iop_profile.inc extrapolate_lut eval_exp dt
 $X $R/iop/colorin.c $G/colorin.inc apply_blue_mapping
 $X $R/iop/channelmixerrgb.c $G/channelmixerrgb.inc INVERSE_SQRT_3 dt_iop_channelmixer_rgb_version_t gamut_mapping luma_chroma loop_switch
 $X $R/colorprofiles/iop_profile.h $G/iop_profile_info.inc dt_iop_order_iccprofile_info_t _apply_trc dt_ioppr_get_rgb_matrix_luminance
+$X $R/colorprofiles/iop_profile.c $G/iop_profile_c.inc _apply_tonecurves _transform_rgb_to_lab_matrix _transform_lab_to_rgb_matrix
 $X $R/iop/filmicrgb.c $G/filmicrgb.inc INVERSE_SQRT_3 SAFETY_MARGIN CIE_Y_1931_to_CIE_Y_2006 ORDER_4 ORDER_3 \
   dt_iop_filmicrgb_methods_type_t dt_iop_filmicrgb_curve_type_t dt_iop_filmicrgb_colorscience_type_t \
   dt_iop_filmicrgb_spline_version_type_t dt_iop_filmic_noise_distribution_t _filmic_is_agx \

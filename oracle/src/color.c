@@ -353,3 +353,72 @@ int oracle_channelmixerrgb(const dt_hip_piece_t *piece, const dt_hip_channelmixe
   }
   return 0;
 }
+
+
+/* ---- RGB <-> Lab glue around Lab modules ----------------------------------------------------
+ * dt_ioppr_transform_image_colorspace() for a linear matrix profile:
+ * _transform_rgb_to_lab_matrix() / _transform_lab_to_rgb_matrix(), src/colorprofiles/iop_profile.c:377-463,
+ * with dt_XYZ_to_Lab() / dt_Lab_to_XYZ(), lab_f() / lab_f_inv(), cbrt_5f(), cbrta_halleyf() of
+ * src/common/colorspaces_inline_conversions.h:50-106.  m = RGB -> XYZ(D50) (resp. XYZ -> RGB), rows. */
+static const float LAB_D50[3] = { 0.9642f, 1.0f, 0.8249f };
+
+static inline float lab_f_(const float x)
+{
+  const float epsilon = 216.0f / 24389.0f, kappa = 24389.0f / 27.0f;
+  if(!(x > epsilon)) return (kappa * x + 16.0f) / 116.0f;
+  union { float f; uint32_t u; } b;
+  b.f = x;
+  b.u = b.u / 3 + 709921077u;
+  const float a = b.f, a3 = a * a * a;
+  return a * (a3 + x + x) / (a3 + a3 + x);
+}
+
+static inline float lab_f_inv_(const float x)
+{
+  const float epsilon = 0.20689655172413796f, kappa = 24389.0f / 27.0f;
+  return (x > epsilon) ? x * x * x : (116.0f * x - 16.0f) / kappa;
+}
+
+int oracle_rgb_to_lab(const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, const void *in_, void *out_)
+{
+  const float *in = (const float *)in_;
+  float *out = (float *)out_;
+  const float(*m)[4] = d->matrix;
+  const size_t n = (size_t)piece->roi_out.width * piece->roi_out.height;
+  for(size_t k = 0; k < n; k++)
+  {
+    px_t p;
+    for(int c = 0; c < 4; c++) p.v[c] = in[4 * k + c];
+    const px_t xyz = mat3(m, p);
+    float f[3];
+    for(int i = 0; i < 3; i++) f[i] = lab_f_(xyz.v[i] / LAB_D50[i]);
+    out[4 * k + 0] = 116.0f * f[1] - 16.0f;
+    out[4 * k + 1] = 500.0f * (f[0] - f[1]);
+    out[4 * k + 2] = 200.0f * (f[1] - f[2]);
+    out[4 * k + 3] = in[4 * k + 3]; /* the pipe converts in place: alpha is left as it was */
+  }
+  return 0;
+}
+
+int oracle_lab_to_rgb(const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, const void *in_, void *out_)
+{
+  const float *in = (const float *)in_;
+  float *out = (float *)out_;
+  const float(*m)[4] = d->matrix;
+  const size_t n = (size_t)piece->roi_out.width * piece->roi_out.height;
+  for(size_t k = 0; k < n; k++)
+  {
+    const float fy = (in[4 * k] + 16.0f) / 116.0f;
+    const float fx = in[4 * k + 1] / 500.0f + fy;
+    const float fz = fy - in[4 * k + 2] / 200.0f;
+    px_t xyz;
+    xyz.v[0] = LAB_D50[0] * lab_f_inv_(fx);
+    xyz.v[1] = LAB_D50[1] * lab_f_inv_(fy);
+    xyz.v[2] = LAB_D50[2] * lab_f_inv_(fz);
+    xyz.v[3] = 0.0f;
+    const px_t rgb = mat3(m, xyz);
+    for(int c = 0; c < 3; c++) out[4 * k + c] = rgb.v[c];
+    out[4 * k + 3] = in[4 * k + 3];
+  }
+  return 0;
+}

@@ -37,6 +37,16 @@ def _noisy_rgba():
     return np.ascontiguousarray(img.astype(np.float32))
 
 
+def _lab():
+    rng = np.random.default_rng(77)
+    rgb = synth.rgba_image(W, H, seed=12, lo=0.0, hi=1.0)
+    lab = np.zeros((H, W, 4), np.float32)
+    lab[..., 0] = 100.0 * rgb[..., 1] + rng.normal(0, 1.5, (H, W))
+    lab[..., 1] = 80.0 * (rgb[..., 0] - rgb[..., 1]) + rng.normal(0, 2.0, (H, W))
+    lab[..., 2] = 80.0 * (rgb[..., 1] - rgb[..., 2]) + rng.normal(0, 2.0, (H, W))
+    return np.ascontiguousarray(lab.astype(np.float32))
+
+
 _LUTS = []
 
 
@@ -107,4 +117,11 @@ def cases(lut_ptrs=None):
     yield ("denoiseprofile_rgb", "denoiseprofile", dpiece,
            params.denoiseprofile(color_mode=abi.DT_HIP_DENOISEPROFILE_RGB, strength=1.4, shadows=0.7), dimg, dimg.shape)
     yield ("denoiseprofile_legacy", "denoiseprofile", dpiece, params.denoiseprofile(use_new_vst=False), dimg, dimg.shape)
+    # RGB <-> Lab glue and denoise (non-local means)
+    yield ("rgb_to_lab", "rgb_to_lab", rgb, abi.LabData.make(params.WORK_IN), img, img.shape)
+    lab = _lab()
+    yield ("lab_to_rgb", "lab_to_rgb", rgb, abi.LabData.make(params.WORK_OUT), lab, lab.shape)
+    yield ("nlmeans", "nlmeans", rgb, abi.NlmeansData(2.0, 50.0, 0.5, 1.0), lab, lab.shape)
+    yield ("denoiseprofile_nlmeans", "denoiseprofile", dpiece,
+           params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS), dimg, dimg.shape)
     del keep

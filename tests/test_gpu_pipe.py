@@ -27,6 +27,9 @@ def _nodes(w, h, lut_ptr, lut, coeffs, **kw):
                                  filmic=filmic.default_data(), **kw)
 
 
+_GLUE = {"rgb_to_lab": "dt_hip_transform_rgb_to_lab", "lab_to_rgb": "dt_hip_transform_lab_to_rgb"}
+
+
 def _run_chain_modulewise(nodes, raw, w, h):
     sizes = {"rawprepare": 4, "temperature": 4, "highlights": 4, "export_u16": 8}
     bufs = [lib.DeviceBuffer.from_numpy(0, raw)]
@@ -137,4 +140,17 @@ def test_denoise_pipe_executor_equals_modulewise_and_oracle():
     assert g0 == len(nodes) and groups == 6, (g0, groups)  # raw | rcd | denoise | exp,colorin,calib | diffuse | filmic,colorout,u16
     assert np.array_equal(modulewise, fused) and np.array_equal(modulewise, unfused)
     host_nodes = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, filmic=filmic.default_data())
+    assert np.array_equal(fused, _run_cpu("oracle", host_nodes, raw, w, h))
+
+
+def test_full_config3_pipe_with_nlmeans():
+    """... + RGB -> Lab, denoise (non-local means), Lab -> RGB between diffuse and filmic"""
+    w, h = 300, 220
+    raw, lut, d_lut, coeffs = _setup(w, h, seed=6)
+    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.ptr, float(lut[0]), coeffs, filmic=filmic.default_data(), with_nlmeans=True)
+    fused, groups = _run_executor(nodes, raw, w, h, fusion=True)
+    assert groups == 9, groups
+    assert np.array_equal(fused, _run_chain_modulewise(nodes, raw, w, h))
+    host_nodes = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, filmic=filmic.default_data(),
+                                         with_nlmeans=True)
     assert np.array_equal(fused, _run_cpu("oracle", host_nodes, raw, w, h))

@@ -263,3 +263,21 @@ def test_denoiseprofile_nlmeans(over):
     a, b = _pair("denoiseprofile", abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS), d, img, img.shape)
     _exact(a, b, "denoiseprofile nlmeans")
     assert float(np.abs(b[..., :3] - img[..., :3]).max()) > 1e-5
+
+
+@pytest.mark.parametrize("imgname", ["scene", "adversarial"])
+def test_lab_glue(imgname):
+    """RGB -> Lab and Lab -> RGB with the work profile's matrices, as the pipe runs them around Lab modules"""
+    img = synth.rgba_image(W, H, seed=2, lo=-0.05, hi=1.6) if imgname == "scene" else synth.adversarial_rgba(W, H)
+    img[..., 3] = np.linspace(0, 1, W * H, dtype=np.float32).reshape(H, W)  # alpha must survive
+    piece = abi.Piece.make(W, H)
+    to_lab, to_rgb = abi.LabData.make(params.WORK_IN), abi.LabData.make(params.WORK_OUT)
+    a, b = _pair("rgb_to_lab", piece, to_lab, img, img.shape)
+    _exact(a, b, "rgb_to_lab")
+    assert np.array_equal(b[..., 3], img[..., 3])
+    lab = np.where(np.isfinite(b), b, 0).astype(np.float32)
+    a2, b2 = _pair("lab_to_rgb", piece, to_rgb, lab, lab.shape)
+    _exact(a2, b2, "lab_to_rgb")
+    if imgname == "scene":
+        ok = img[..., :3].min(axis=-1) > 0.01
+        assert float(np.abs(b2[..., :3] - img[..., :3])[ok].max()) < 2e-3  # a round trip, roughly
