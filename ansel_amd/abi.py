@@ -113,6 +113,16 @@ DT_HIP_DENOISEPROFILE_RGB = 0
 DT_HIP_DENOISEPROFILE_Y0U0V0 = 1
 
 
+class BilatData(C.Structure):
+    """dt_hip_bilat_data_t == dt_iop_bilat_params_t (src/iop/bilat.c:78-86) + pipe->iscale"""
+    _fields_ = [("mode", C.c_int), ("sigma_r", C.c_float), ("sigma_s", C.c_float), ("detail", C.c_float),
+                ("midtone", C.c_float), ("iscale", C.c_float)]
+
+    @classmethod
+    def bilateral(cls, sigma_s=50.0, sigma_r=25.0, detail=0.33, iscale=1.0):
+        return cls(0, sigma_r, sigma_s, detail, 0.5, iscale)
+
+
 class LabData(C.Structure):
     """dt_hip_lab_data_t: the 3x3 (rows padded to 4) of the RGB <-> Lab glue"""
     _fields_ = [("matrix", m34)]

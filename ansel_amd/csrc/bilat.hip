@@ -1,0 +1,239 @@
+// bilat.hip -- local contrast, bilateral-grid mode, on gfx950.
+//
+// Reference: process(), src/iop/bilat.c:330-361 -> dt_bilateral_init / _splat / _blur / _slice,
+// src/pixel/bilateral.c:157-393 (OpenCL twin: bilateral_cl.c, whose splat uses float atomics in
+// LDS and is therefore order-free; the pin here is the CPU path).
+//
+// splat   The CPU scatters every pixel into 8 grid cells, per OpenMP slice, and merges the slices;
+//         on one thread that is: every cell accumulates its contributions in pixel row-major order.
+//         The device GATHERS in that order: one thread per grid node (x, y) walks the ~(2 sigma_s)^2
+//         pixels that can reach the node, row by row, and adds into the node's z column kept in LDS.
+//         No atomics, no dependence on launch geometry, bit-identical to the one-thread reference.
+// blur    three in-place line recurrences (x, y: 1-4-6-4-1; z: derivative), one thread per line.
+// slice   trilinear lookup per pixel, L += -detail * sigma_r * 0.04 * grid.
+#include "hip_common.h"
+
+#include <math.h>
+
+using namespace ansel;
+
+namespace
+{
+
+#define MAX_RES_S 3000 // DT_COMMON_BILATERAL_MAX_RES_S, bilateral.c:47
+#define MAX_RES_R 50   // DT_COMMON_BILATERAL_MAX_RES_R
+#define SPLAT_THREADS 64
+
+struct grid_t
+{
+  int size_x, size_y, size_z, width, height;
+  float sigma_s, sigma_r;
+};
+
+__host__ __device__ __forceinline__ float clampf(const float v, const float lo, const float hi)
+{
+  return v > lo ? (v < hi ? v : hi) : lo; // CLAMPS(), src/math/math.h
+}
+inline int clampi_h(const int v, const int lo, const int hi) { return v > lo ? (v < hi ? v : hi) : lo; }
+
+// image_to_grid() / image_to_relgrid(), bilateral.c:127-155: cell index and fraction on one axis
+__device__ __forceinline__ int axis(const float v, const float sigma, const int size, float &frac)
+{
+  const float x = clampf(v / sigma, 0.0f, (float)(size - 1));
+  const int xi = (int)x < size - 2 ? (int)x : size - 2;
+  frac = x - xi;
+  return xi;
+}
+
+// dt_bilateral_splat(), bilateral.c:183-256, gathered per grid node
+__global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat(const float4 *__restrict__ in, float *__restrict__ buf,
+                                                             const grid_t b)
+{
+  extern __shared__ float acc[]; // [size_z][SPLAT_THREADS]
+  const int tid = threadIdx.x;
+  const int node = blockIdx.x * SPLAT_THREADS + tid;
+  const bool live = node < b.size_x * b.size_y;
+  const int Y = live ? node / b.size_x : 0, X = live ? node - Y * b.size_x : 0;
+  for(int z = 0; z < b.size_z; z++) acc[z * SPLAT_THREADS + tid] = 0.0f;
+  if(live)
+  {
+    const float s2 = b.sigma_s * b.sigma_s;
+    const int i0 = max(0, (int)floorf((X - 1) * b.sigma_s) - 2), i1 = min(b.width - 1, (int)ceilf((X + 1) * b.sigma_s) + 2);
+    const int j0 = max(0, (int)floorf((Y - 1) * b.sigma_s) - 2), j1 = min(b.height - 1, (int)ceilf((Y + 1) * b.sigma_s) + 2);
+    for(int j = j0; j <= j1; j++)
+    {
+      float yf;
+      const int yi = axis((float)j, b.sigma_s, b.size_y, yf);
+      if(yi != Y && yi != Y - 1) continue;
+      const float wy = yi == Y ? (1.0f - yf) : yf;
+      for(int i = i0; i <= i1; i++)
+      {
+        float xf, zf;
+        const int xi = axis((float)i, b.sigma_s, b.size_x, xf);
+        if(xi != X && xi != X - 1) continue;
+        const float wx = xi == X ? (1.0f - xf) : xf;
+        const float L = in[(size_t)j * b.width + i].x;
+        const int zi = axis(L, b.sigma_r, b.size_z, zf);
+        const float contrib = wx * wy * 100.0f / s2; // (1-xf)*(1-yf)*100/s2 and its three siblings
+        acc[zi * SPLAT_THREADS + tid] += (contrib * (1.0f - zf));
+        acc[(zi + 1) * SPLAT_THREADS + tid] += (contrib * zf);
+      }
+    }
+    float *const cell = buf + (size_t)(X + Y * b.size_x) * b.size_z;
+    for(int z = 0; z < b.size_z; z++) cell[z] = acc[z * SPLAT_THREADS + tid];
+  }
+}
+
+// blur_line(), bilateral.c:299-338
+__global__ __launch_bounds__(64) void bilat_blur_line(float *__restrict__ buf, const int offset1, const int offset2,
+                                                      const int offset3, const int size1, const int size2, const int size3)
+{
+  const int line = blockIdx.x * blockDim.x + threadIdx.x;
+  if(line >= size1 * size2) return;
+  const int j = line / size1, k = line - j * size1;
+  const float w0 = 6.f / 16.f, w1 = 4.f / 16.f, w2 = 1.f / 16.f;
+  size_t index = (size_t)k * offset1 + (size_t)j * offset2;
+  float tmp1 = buf[index];
+  buf[index] = buf[index] * w0 + w1 * buf[index + offset3] + w2 * buf[index + 2 * offset3];
+  index += offset3;
+  float tmp2 = buf[index];
+  buf[index] = buf[index] * w0 + w1 * (buf[index + offset3] + tmp1) + w2 * buf[index + 2 * offset3];
+  index += offset3;
+  for(int i = 2; i < size3 - 2; i++)
+  {
+    const float tmp3 = buf[index];
+    buf[index] = buf[index] * w0 + w1 * (buf[index + offset3] + tmp2) + w2 * (buf[index + 2 * offset3] + tmp1);
+    index += offset3;
+    tmp1 = tmp2;
+    tmp2 = tmp3;
+  }
+  const float tmp3 = buf[index];
+  buf[index] = buf[index] * w0 + w1 * (buf[index + offset3] + tmp2) + w2 * tmp1;
+  index += offset3;
+  buf[index] = buf[index] * w0 + w1 * tmp3 + w2 * tmp2;
+}
+
+// blur_line_z(), bilateral.c:258-297
+__global__ __launch_bounds__(64) void bilat_blur_line_z(float *__restrict__ buf, const int offset1, const int offset2,
+                                                        const int offset3, const int size1, const int size2,
+                                                        const int size3)
+{
+  const int line = blockIdx.x * blockDim.x + threadIdx.x;
+  if(line >= size1 * size2) return;
+  const int j = line / size1, k = line - j * size1;
+  const float w1 = 4.f / 16.f, w2 = 2.f / 16.f;
+  size_t index = (size_t)k * offset1 + (size_t)j * offset2;
+  float tmp1 = buf[index];
+  buf[index] = w1 * buf[index + offset3] + w2 * buf[index + 2 * offset3];
+  index += offset3;
+  float tmp2 = buf[index];
+  buf[index] = w1 * (buf[index + offset3] - tmp1) + w2 * buf[index + 2 * offset3];
+  index += offset3;
+  for(int i = 2; i < size3 - 2; i++)
+  {
+    const float tmp3 = buf[index];
+    buf[index] = +w1 * (buf[index + offset3] - tmp2) + w2 * (buf[index + 2 * offset3] - tmp1);
+    index += offset3;
+    tmp1 = tmp2;
+    tmp2 = tmp3;
+  }
+  const float tmp3 = buf[index];
+  buf[index] = w1 * (buf[index + offset3] - tmp2) - w2 * tmp1;
+  index += offset3;
+  buf[index] = -w1 * tmp3 - w2 * tmp2;
+}
+
+// dt_bilateral_slice(), bilateral.c:356-393
+__global__ __launch_bounds__(256) void bilat_slice(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                   const float *__restrict__ buf, const grid_t b, const float norm)
+{
+  const int ox = b.size_z, oy = b.size_x * b.size_z, oz = 1;
+  const size_t n = (size_t)b.width * b.height;
+  for(size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x)
+  {
+    const int j = (int)(p / b.width), i = (int)(p - (size_t)j * b.width);
+    const float4 px = in[p];
+    float xf, yf, zf;
+    const float L = px.x;
+    const int xi = axis((float)i, b.sigma_s, b.size_x, xf);
+    const int yi = axis((float)j, b.sigma_s, b.size_y, yf);
+    const int zi = axis(L, b.sigma_r, b.size_z, zf);
+    const size_t gi = ((size_t)xi + (size_t)yi * b.size_x) * b.size_z + zi;
+    const float Lout = fmaxf(0.0f, L
+                       + norm * (buf[gi] * (1.0f - xf) * (1.0f - yf) * (1.0f - zf)
+                                 + buf[gi + ox] * (xf) * (1.0f - yf) * (1.0f - zf)
+                                 + buf[gi + oy] * (1.0f - xf) * (yf) * (1.0f - zf)
+                                 + buf[gi + ox + oy] * (xf) * (yf) * (1.0f - zf)
+                                 + buf[gi + oz] * (1.0f - xf) * (1.0f - yf) * (zf)
+                                 + buf[gi + ox + oz] * (xf) * (1.0f - yf) * (zf)
+                                 + buf[gi + oy + oz] * (1.0f - xf) * (yf) * (zf)
+                                 + buf[gi + ox + oy + oz] * (xf) * (yf) * (zf)));
+    nt_store(out + p, make_float4(Lout, px.y, px.z, px.w));
+  }
+}
+
+// dt_bilateral_grid_size(), bilateral.c:50-74
+void grid_size(grid_t &b, const int width, const int height, const float L_range, float sigma_s, const float sigma_r)
+{
+  if(sigma_s < 0.5) sigma_s = 0.5;
+  const float _x = (float)clampi_h((int)roundf(width / sigma_s), 4, MAX_RES_S);
+  const float _y = (float)clampi_h((int)roundf(height / sigma_s), 4, MAX_RES_S);
+  const float _z = (float)clampi_h((int)roundf(L_range / sigma_r), 4, MAX_RES_R);
+  const float sy = height / _y, sx = width / _x;
+  b.sigma_s = sy > sx ? sy : sx;
+  b.sigma_r = L_range / _z;
+  b.size_x = (int)ceilf(width / b.sigma_s) + 1;
+  b.size_y = (int)ceilf(height / b.sigma_s) + 1;
+  b.size_z = (int)ceilf(L_range / b.sigma_r) + 1;
+  b.width = width;
+  b.height = height;
+}
+
+} // namespace
+
+extern "C" {
+
+int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in,
+                             dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || piece->channels != 4) return DT_HIP_INVALID_ARG;
+  if(d->mode != DT_HIP_BILAT_BILATERAL)
+  {
+    set_last_error("bilat: only the bilateral-grid mode is implemented on device (local laplacian is out of scope)");
+    return DT_HIP_INVALID_ARG;
+  }
+  const int width = piece->roi_in.width, height = piece->roi_in.height;
+  if(width <= 0 || height <= 0) return DT_HIP_SUCCESS;
+  if(!(d->iscale > 0.0f) || !(piece->roi_in.scale > 0.0) || !(d->sigma_r > 0.0f)) return DT_HIP_INVALID_ARG;
+  const float scale = (float)(d->iscale / piece->roi_in.scale); // dt_dev_get_module_scale(), bilat.c:339
+  grid_t b;
+  grid_size(b, width, height, 100.0f, d->sigma_s / scale, d->sigma_r);
+  const size_t cells = (size_t)b.size_x * b.size_y * b.size_z;
+  float *buf = (float *)dt_hip_alloc_device_buffer(devid, cells * sizeof(float));
+  if(!buf) return DT_HIP_SYSMEM_ALLOCATION;
+  hipStream_t s = stream_of(devid);
+  const int ox = b.size_z, oy = b.size_x * b.size_z, oz = 1;
+  {
+    const int nodes = b.size_x * b.size_y;
+    launch_scope ls(devid, "bilat_splat");
+    bilat_splat<<<(nodes + SPLAT_THREADS - 1) / SPLAT_THREADS, SPLAT_THREADS, (size_t)b.size_z * SPLAT_THREADS * sizeof(float),
+                  s>>>((const float4 *)dev_in, buf, b);
+  }
+  {
+    launch_scope ls(devid, "bilat_blur");
+    // dt_bilateral_blur(), bilateral.c:341-352
+    bilat_blur_line<<<(b.size_z * b.size_y + 63) / 64, 64, 0, s>>>(buf, oz, oy, ox, b.size_z, b.size_y, b.size_x);
+    bilat_blur_line<<<(b.size_z * b.size_x + 63) / 64, 64, 0, s>>>(buf, oz, ox, oy, b.size_z, b.size_x, b.size_y);
+    bilat_blur_line_z<<<(b.size_x * b.size_y + 63) / 64, 64, 0, s>>>(buf, ox, oy, oz, b.size_x, b.size_y, b.size_z);
+  }
+  {
+    const float norm = -d->detail * b.sigma_r * 0.04f;
+    launch_scope ls(devid, "bilat_slice");
+    bilat_slice<<<stream_grid((size_t)width * height, 256), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, buf, b,
+                                                                         norm);
+  }
+  dt_hip_release_mem_object(buf);
+  return check_launch("bilat");
+}
+
+} // extern "C"

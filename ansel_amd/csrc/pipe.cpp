@@ -38,6 +38,7 @@ enum op_t
   OP_DIFFUSE,
   OP_RGB_TO_LAB,
   OP_NLMEANS,
+  OP_BILAT,
   OP_LAB_TO_RGB,
   OP_EXPORT_U16,
   OP_UNKNOWN
@@ -64,6 +65,7 @@ const op_info_t k_ops[] = {
   { "diffuse", sizeof(dt_hip_diffuse_data_t), 16 },
   { "rgb_to_lab", sizeof(dt_hip_lab_data_t), 16 },
   { "nlmeans", sizeof(dt_hip_nlmeans_data_t), 16 },
+  { "bilat", sizeof(dt_hip_bilat_data_t), 16 },
   { "lab_to_rgb", sizeof(dt_hip_lab_data_t), 16 },
   { "export_u16", 0, 8 },
 };
@@ -110,6 +112,7 @@ int run_single(int devid, const node_t &n, dt_hip_mem_t in, dt_hip_mem_t out)
     case OP_DIFFUSE: return dt_hip_iop_diffuse_process(devid, &n.piece, n.as<dt_hip_diffuse_data_t>(), in, out);
     case OP_RGB_TO_LAB: return dt_hip_transform_rgb_to_lab(devid, &n.piece, n.as<dt_hip_lab_data_t>(), in, out);
     case OP_NLMEANS: return dt_hip_iop_nlmeans_process(devid, &n.piece, n.as<dt_hip_nlmeans_data_t>(), in, out);
+    case OP_BILAT: return dt_hip_iop_bilat_process(devid, &n.piece, n.as<dt_hip_bilat_data_t>(), in, out);
     case OP_LAB_TO_RGB: return dt_hip_transform_lab_to_rgb(devid, &n.piece, n.as<dt_hip_lab_data_t>(), in, out);
     case OP_EXPOSURE: return dt_hip_iop_exposure_process(devid, &n.piece, n.as<dt_hip_exposure_data_t>(), in, out);
     case OP_COLORIN: return dt_hip_iop_colorin_process(devid, &n.piece, n.as<dt_hip_conversion_t>(), in, out);
@@ -423,7 +426,7 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
     }
   if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
   for(const node_t &n : pipe->nodes)
-    if(n.op == OP_DENOISEPROFILE || n.op == OP_DIFFUSE || n.op == OP_NLMEANS)
+    if(n.op == OP_DENOISEPROFILE || n.op == OP_DIFFUSE || n.op == OP_NLMEANS || n.op == OP_BILAT)
     {
       // these need a halo of 2^scales rows per band and (denoiseprofile) an all-reduce per wavelet band
       set_last_error("band mode: '%s' has no row-band implementation yet", k_ops[n.op].name);

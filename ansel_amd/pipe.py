@@ -17,6 +17,7 @@ MODULE_BPP = {
     "rawprepare": (2, 4), "temperature": (4, 4), "highlights": (4, 4), "demosaic": (4, 16),
     "exposure": (16, 16), "colorin": (16, 16), "channelmixerrgb": (16, 16), "filmicrgb": (16, 16),
     "colorout": (16, 16), "export_u16": (16, 8), "rgb_to_lab": (16, 16), "lab_to_rgb": (16, 16), "nlmeans": (16, 16),
+    "bilat": (16 + 16, 16),  # splat reads L, slice reads + writes the plane (48 B/px)
 }
 
 
@@ -73,6 +74,7 @@ def denoise_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, fil
                 # a Lab module: the pipe converts work RGB -> Lab before and back after it (pixelpipe_cpu.c:59-75)
                 out.append(Node("rgb_to_lab", abi.LabData.make(params.WORK_IN), rgb))
                 out.append(Node("nlmeans", abi.NlmeansData(2.0, 50.0, 0.5, 1.0), rgb))
+                out.append(Node("bilat", abi.BilatData.bilateral(), rgb))
                 out.append(Node("lab_to_rgb", abi.LabData.make(params.WORK_OUT), rgb))
     return out
 

@@ -372,6 +372,25 @@ int dt_hip_transform_rgb_to_lab(int devid, const dt_hip_piece_t *piece, const dt
 int dt_hip_transform_lab_to_rgb(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d,
                                 dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
+/* local contrast, bilateral-grid mode: process(), src/iop/bilat.c:330-361 -> dt_bilateral_init /
+ * _splat / _blur / _slice, src/pixel/bilateral.c:157-393 (Lab input, only L changes).
+ * dt_hip_bilat_data_t == dt_iop_bilat_params_t (bilat.c:78-86) + pipe->iscale.
+ * mode must be DT_HIP_BILAT_BILATERAL; the local-laplacian mode is out of scope.
+ *
+ * dt_bilateral_splat() accumulates the grid in binary32 per OpenMP slice and then merges the
+ * slices, so its rounding depends on the host's thread count; the device accumulates every grid cell
+ * in pixel row-major order, which is exactly what the reference computes on one thread. */
+#define DT_HIP_BILAT_BILATERAL 0
+#define DT_HIP_BILAT_LOCAL_LAPLACIAN 1
+typedef struct dt_hip_bilat_data_t
+{
+  int mode;
+  float sigma_r, sigma_s, detail, midtone;
+  float iscale;
+} dt_hip_bilat_data_t;
+int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d,
+                             dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
 /* ---- 3. export-pipe executor ----------------------------------------------------------- */
 /* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)
  * for an export: an ordered list of module nodes, each with its piece view and committed data,

@@ -7,6 +7,7 @@
 #include "iop/noise_generator.h"
 
 typedef void *GtkWidget;
+#define process ref_diffuse_module_process /* every module calls its entry point process() */
 #include "gen/diffuse.inc"
 
 int ref_diffuse(const dt_hip_piece_t *v, const dt_hip_diffuse_data_t *d, const void *in, void *out)

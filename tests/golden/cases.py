@@ -26,7 +26,7 @@ def _rgba():
     return np.ascontiguousarray(np.concatenate([a, b], axis=0))
 
 
-SINGLE_THREAD_OPS = ("denoiseprofile",)
+SINGLE_THREAD_OPS = ("denoiseprofile", "bilat")
 DNW, DNH = 288, 176    # denoiseprofile: 5 wavelet bands
 
 
@@ -122,6 +122,7 @@ def cases(lut_ptrs=None):
     lab = _lab()
     yield ("lab_to_rgb", "lab_to_rgb", rgb, abi.LabData.make(params.WORK_OUT), lab, lab.shape)
     yield ("nlmeans", "nlmeans", rgb, abi.NlmeansData(2.0, 50.0, 0.5, 1.0), lab, lab.shape)
+    yield ("bilat", "bilat", rgb, abi.BilatData.bilateral(12.0, 10.0, 0.5), lab, lab.shape)
     yield ("denoiseprofile_nlmeans", "denoiseprofile", dpiece,
            params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS), dimg, dimg.shape)
     del keep

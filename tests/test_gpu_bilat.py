@@ -1,0 +1,52 @@
+"""-m gpu: local contrast, bilateral-grid mode, bit for bit against the oracle (= the reference on
+one thread: its splat sums per OpenMP slice, see oracle/src/bilat.c) and within rounding of the
+reference at its default thread count."""
+import numpy as np
+import pytest
+
+import checkers as ck
+import hipcheck as hc
+from ansel_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _lab_image(w, h, seed):
+    rng = np.random.default_rng(seed)
+    rgb = synth.rgba_image(w, h, seed=seed, lo=0.0, hi=1.0)
+    lab = np.zeros((h, w, 4), np.float32)
+    lab[..., 0] = 100.0 * rgb[..., 1] + rng.normal(0, 1.5, (h, w))
+    lab[..., 1] = 80.0 * (rgb[..., 0] - rgb[..., 1]) + rng.normal(0, 2.0, (h, w))
+    lab[..., 2] = 80.0 * (rgb[..., 1] - rgb[..., 2]) + rng.normal(0, 2.0, (h, w))
+    lab[::7, ::5, 0] = -3.0
+    lab[3::11, 2::9, 0] = 140.0
+    lab[..., 3] = 0.25
+    return np.ascontiguousarray(lab.astype(np.float32))
+
+
+@pytest.mark.parametrize("w,h", [(300, 200), (123, 457), (1500, 1000)])
+@pytest.mark.parametrize("ss,sr,detail", [(50.0, 25.0, 0.33), (8.0, 5.0, -0.5), (0.3, 2.0, 1.5), (20.0, 60.0, 4.0)])
+def test_bilat(w, h, ss, sr, detail):
+    if ss < 1.0 and w * h > 500000:
+        pytest.skip("sub-pixel sigma on the large frame: the grid has millions of nodes, covered on the small frames")
+    img = _lab_image(w, h, 29)
+    d = abi.BilatData.bilateral(ss, sr, detail)
+    piece = abi.Piece.make(w, h)
+    got = hc.run_hip("dt_hip_iop_bilat_process", piece, d, img, img.shape)
+    want = np.zeros_like(img)
+    assert ck.call(ck.oracle(), "oracle_bilat", piece, d, img, want) == 0
+    diff = ck.ulp_diff(got, want)
+    assert int((diff > 0).sum()) == 0, "%d values differ, max %d ulp" % (int((diff > 0).sum()), int(diff.max()))
+    assert np.array_equal(got[..., 1:], img[..., 1:])  # a, b, alpha pass through
+    ref = ck.ref()
+    if ref is not None:
+        r = np.zeros_like(img)
+        assert ck.call(ref, "ref_bilat", piece, d, img, r) == 0
+        assert float(np.abs(r[..., 0] - got[..., 0]).max()) < 1e-3
+
+
+def test_bilat_rejects_local_laplacian():
+    img = _lab_image(64, 48, 1)
+    d = abi.BilatData(1, 0.5, 0.5, 0.25, 0.5, 1.0)
+    with pytest.raises(Exception):
+        hc.run_hip("dt_hip_iop_bilat_process", abi.Piece.make(64, 48), d, img, img.shape)

@@ -144,12 +144,13 @@ def test_denoise_pipe_executor_equals_modulewise_and_oracle():
 
 
 def test_full_config3_pipe_with_nlmeans():
-    """... + RGB -> Lab, denoise (non-local means), Lab -> RGB between diffuse and filmic"""
+    """... + RGB -> Lab, denoise (non-local means), local contrast (bilateral grid), Lab -> RGB between
+    diffuse and filmic: every module of BASELINE.json config 3"""
     w, h = 300, 220
     raw, lut, d_lut, coeffs = _setup(w, h, seed=6)
     nodes = pipe.denoise_pipe_nodes(w, h, d_lut.ptr, float(lut[0]), coeffs, filmic=filmic.default_data(), with_nlmeans=True)
     fused, groups = _run_executor(nodes, raw, w, h, fusion=True)
-    assert groups == 9, groups
+    assert groups == 10, groups
     assert np.array_equal(fused, _run_chain_modulewise(nodes, raw, w, h))
     host_nodes = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, filmic=filmic.default_data(),
                                          with_nlmeans=True)

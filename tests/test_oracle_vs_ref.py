@@ -281,3 +281,25 @@ def test_lab_glue(imgname):
     if imgname == "scene":
         ok = img[..., :3].min(axis=-1) > 0.01
         assert float(np.abs(b2[..., :3] - img[..., :3])[ok].max()) < 2e-3  # a round trip, roughly
+
+
+@pytest.mark.parametrize("w,h", [(300, 200), (123, 457)])
+@pytest.mark.parametrize("ss,sr,detail", [(50.0, 25.0, 0.33), (8.0, 5.0, -0.5), (0.3, 2.0, 1.5), (20.0, 60.0, 4.0)])
+def test_bilat_bilateral_grid(w, h, ss, sr, detail):
+    """exact against the reference on ONE thread (its splat sums per OpenMP slice otherwise)"""
+    img = _lab_image(w, h, 29)
+    img[::7, ::5, 0] = -3.0   # L outside [0, 100] exercises the clamps
+    img[3::11, 2::9, 0] = 140.0
+    d = abi.BilatData.bilateral(ss, sr, detail)
+    r = ck.ref()
+    threads = r.ref_get_num_threads()
+    r.ref_set_num_threads(1)
+    try:
+        a, b = _pair("bilat", abi.Piece.make(w, h), d, img, img.shape)
+    finally:
+        r.ref_set_num_threads(threads)
+    _exact(a, b, "bilat")
+    assert float(np.abs(b[..., 0] - np.maximum(img[..., 0], 0)).max()) > 1e-3
+    # and with its default thread count the reference stays within rounding of that
+    a2, _ = _pair("bilat", abi.Piece.make(w, h), d, img, img.shape)
+    assert float(np.abs(a2[..., 0] - b[..., 0]).max()) < 1e-3

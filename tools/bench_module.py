@@ -45,6 +45,9 @@ def main():
         d = params.denoiseprofile()
         piece = abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS)
         fn = l.dt_hip_iop_denoiseprofile_process
+    elif args.module == "bilat":
+        d = abi.BilatData.bilateral()
+        fn = l.dt_hip_iop_bilat_process
     elif args.module == "nlmeans":
         d = abi.NlmeansData(2.0, 50.0, 0.5, 1.0)
         fn = l.dt_hip_iop_nlmeans_process
