@@ -138,6 +138,23 @@ def cpu_baseline(size_name, with_filmic, which="light"):
                       % (w, h, size_name, len(times), best)}
 
 
+def measured_traffic(tag, args):
+    """HBM bytes per launch of `tag` from the committed PMC summary of this exact configuration
+    (tools/profile_round.sh -> tools/pmc_hbm_json.py: separate FETCH_SIZE / WRITE_SIZE passes with the
+    gfx950 corrections of MI355X_MICROARCH.md); None when no summary matches the configuration."""
+    if args.size != "100MP" or args.pipe != "light" or args.no_fusion or args.mode != "batch":
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_bytes_100MP_light_fused.json")
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for key in (tag, tag.replace("_u16", "")):
+        if key in kernels:
+            return kernels[key]["hbm_bytes"]
+    return None
+
+
 def main():
     args = parse()
     import numpy as np
@@ -282,7 +299,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": measured_traffic(dominant, args),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
