@@ -22,7 +22,8 @@ template <int KIND, bool CLIP>
 __global__ __launch_bounds__(256) void channelmixerrgb(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                         const size_t npixels, const cm_args a)
 {
-  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
+  if(k < npixels)
     nt_store(out + k, px_channelmixerrgb<KIND>(in[k], a, CLIP));
 }
 
@@ -75,7 +76,7 @@ extern "C" int dt_hip_iop_channelmixerrgb_process(int devid, const dt_hip_piece_
   if(np == 0) return DT_HIP_SUCCESS;
   cm_args a;
   channelmixerrgb_fill_args(d, a);
-  const unsigned grid = stream_grid(np, 256);
+  const unsigned grid = pixel_grid(np);
   hipStream_t s = stream_of(devid);
   const float4 *in = (const float4 *)dev_in;
   float4 *out = (float4 *)dev_out;

@@ -28,7 +28,8 @@ template <bool DECODE, bool ENCODE, bool CLIP, bool HOOK>
 __global__ __launch_bounds__(256) void apply_matrix(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                      const size_t npixels, const conv_args a)
 {
-  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
+  if(k < npixels)
     nt_store(out + k, px_conversion(in[k], a, DECODE, ENCODE, CLIP, HOOK));
 }
 
@@ -52,7 +53,7 @@ int conversion_process(const int devid, const char *tag, const dt_hip_piece_t *p
   conv_args a;
   const int key = conversion_fill_args(d, a);
   const bool hook = d->blue_mapping != 0;
-  const unsigned grid = stream_grid(np, 256);
+  const unsigned grid = pixel_grid(np);
   hipStream_t s = stream_of(devid);
   const float4 *in = (const float4 *)dev_in;
   float4 *out = (float4 *)dev_out;

@@ -65,7 +65,8 @@ __device__ __forceinline__ float chan(const float4 &v, const int c) { return c =
 __global__ __launch_bounds__(256) void dn_precondition(const float4 *__restrict__ in, float4 *__restrict__ buf,
                                                        const size_t npix, const vst_args a)
 {
-  for(size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += (size_t)gridDim.x * blockDim.x)
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
+  if(j < npix)
   {
     const float4 px = in[j];
     float o[4];
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void dn_precondition(const float4 *__restrict_
 __global__ __launch_bounds__(256) void dn_finish(float4 *__restrict__ out, const float4 *__restrict__ residue,
                                                  const size_t npix, const vst_args a)
 {
-  for(size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += (size_t)gridDim.x * blockDim.x)
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
+  if(j < npix)
   {
     const float4 acc = out[j];
     float v[4] = { acc.x, acc.y, acc.z, acc.w };
@@ -553,7 +555,7 @@ int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoise
     vst_args fa;
     forward_args(s, fa);
     launch_scope ls(devid, "dn_precondition");
-    dn_precondition<<<sgrid, 256, 0, st>>>((const float4 *)dev_in, pre, npix, fa);
+    dn_precondition<<<pixel_grid(npix), 256, 0, st>>>((const float4 *)dev_in, pre, npix, fa);
   }
   nlm_core_params_t p;
   memset(&p, 0, sizeof(p));
@@ -573,7 +575,7 @@ int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoise
     vst_args ia;
     inverse_args(s, ia);
     launch_scope ls(devid, "dn_finish");
-    dn_finish<<<sgrid, 256, 0, st>>>((float4 *)dev_out, nullptr, npix, ia);
+    dn_finish<<<pixel_grid(npix), 256, 0, st>>>((float4 *)dev_out, nullptr, npix, ia);
   }
   return check_launch("dn_finish");
 }
@@ -628,7 +630,7 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
     vst_args fa;
     forward_args(s, fa);
     launch_scope ls(devid, "dn_precondition");
-    dn_precondition<<<sgrid, 256, 0, st>>>((const float4 *)dev_in, precond, npix, fa);
+    dn_precondition<<<pixel_grid(npix), 256, 0, st>>>((const float4 *)dev_in, precond, npix, fa);
   }
   float4 *b1 = precond, *b2 = tmp;
   for(int scale = 0; scale < s.max_scale && err == DT_HIP_SUCCESS; scale++)
@@ -662,7 +664,7 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
     vst_args ia;
     inverse_args(s, ia);
     launch_scope ls(devid, "dn_finish");
-    dn_finish<<<sgrid, 256, 0, st>>>(out, b1, npix, ia);
+    dn_finish<<<pixel_grid(npix), 256, 0, st>>>(out, b1, npix, ia);
     err = check_launch("dn_finish");
   }
   if(precond) dt_hip_release_mem_object(precond);

@@ -27,7 +27,8 @@ template <int MODE, bool EXPORT>
 __global__ __launch_bounds__(256) void filmic_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                       const size_t npixels, const fargs a)
 {
-  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
+  if(k < npixels)
     nt_store(out + k, px_filmicrgb<MODE>(in[k], a, EXPORT));
 }
 
@@ -310,7 +311,7 @@ extern "C" int dt_hip_iop_filmicrgb_process(int devid, const dt_hip_piece_t *pie
   if(err != DT_HIP_SUCCESS) return err;
   const size_t np = (size_t)piece->roi_out.width * piece->roi_out.height;
   if(np == 0) return DT_HIP_SUCCESS;
-  const unsigned grid = stream_grid(np, 256);
+  const unsigned grid = pixel_grid(np);
   hipStream_t s = stream_of(devid);
   const float4 *in = (const float4 *)dev_in;
   float4 *out = (float4 *)dev_out;

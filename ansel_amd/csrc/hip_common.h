@@ -92,4 +92,13 @@ static inline unsigned stream_grid(size_t work_items, unsigned block)
   return (unsigned)g;
 }
 
+// Grid for a one-pixel-per-thread kernel (256-thread workgroups).  Used where a kernel carries a few
+// hundred uniform parameters: inside a grid-stride loop those stay live across iterations and spill
+// out of the 100-odd SGPRs; used once per wave they do not (rgb_chain: 154 -> 32 VGPRs, 6.7 -> 4.9 ms).
+static inline unsigned pixel_grid(size_t pixels)
+{
+  const size_t g = (pixels + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 0x7fffffffu ? 0x7fffffffu : g));
+}
+
 } // namespace ansel

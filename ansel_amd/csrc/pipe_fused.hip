@@ -267,7 +267,7 @@ int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hi
   }
   a.to_u16 = g.to_u16;
   hipStream_t s = stream_of(devid);
-  const unsigned grid = stream_grid(np, 256);
+  const unsigned grid = pixel_grid(np); // one pixel per thread, see rgb_chain_kernel.h
   const float4 *in = (const float4 *)dev_in;
   launch_scope ls(devid, g.to_u16 ? "rgb_chain_u16" : "rgb_chain");
   int err;

@@ -28,7 +28,10 @@ template <int CM, int FM>
 __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, void *__restrict__ out,
                                                   const size_t npixels, const chain_args a)
 {
-  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
+  // one pixel per thread: the ~250 uniform parameters of the five stages are then used once per wave
+  // instead of staying live across a grid-stride loop (which spilled 770 SGPRs to VGPR lanes)
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k < npixels)
   {
     float4 v = in[k];
     if(a.has_exposure)
