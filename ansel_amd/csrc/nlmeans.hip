@@ -11,7 +11,9 @@
 // same recurrences; the parallelism left is across chunks, across the columns of the column-sum
 // recurrence, across the rows of the row-sum recurrence, and across pixels everywhere else.
 //
-// One workgroup (256 threads) = one chunk.  Per patch offset:
+// One workgroup (1024 threads) = one chunk.  The chunk's input window (chunk + patch radius + largest
+// patch shift on every side, RGB planes) is staged in LDS once when it fits next to the two tables
+// (it does for every default: 94 KB at P 2 / K 7), so all four steps below read LDS, not L2.  Per patch offset:
 //   A1  every (row, column) difference term of the column-sum recurrence, all threads, from global
 //   A2  the column-sum recurrence, one thread per column, down the rows of an LDS table
 //   B   the row-sum ("distortion") recurrence, one thread per row, across the columns of that table
@@ -22,6 +24,7 @@
 #include "nlmeans_core_params.h"
 
 #include <math.h>
+#include <algorithm>
 #include <vector>
 
 using namespace ansel;
@@ -31,7 +34,9 @@ namespace
 
 #define SLICE_WIDTH 72  // nlmeans_core.c:55
 #define SLICE_HEIGHT 60 // nlmeans_core.c:56
-#define MAX_PX_PER_THREAD 20 // ceil(72 * 69 / 256)
+#define NLM_THREADS 1024
+#define MAX_PX_PER_THREAD 5 // ceil(72 * 69 / NLM_THREADS)
+#define CS_LANES 128         // table columns are walked 128 lanes at a time (chk_w + 2 * 16 + 1 <= 105)
 
 struct nlm_args
 {
@@ -44,6 +49,8 @@ struct nlm_args
   float norm[3];
   float luma, chroma;
   int skip_blend;
+  int reach;     // patch radius + largest |shift|: rows/columns of input around the chunk a patch can touch
+  int win_pitch; // staged window: (chk_h + 2 reach) rows x win_pitch columns per colour plane
 };
 
 __device__ __forceinline__ int imin(const int a, const int b) { return a < b ? a : b; }
@@ -78,8 +85,26 @@ __device__ __forceinline__ float pixdiff2(const float4 a, const float4 b, const 
   return (ax * ax - cx * cx) * n0 + (ay * ay - cy * cy) * n1 + (az * az - cz * cz) * n2;
 }
 
-__global__ __launch_bounds__(256) void nlm_chunks(const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                  const nlm_args a, const int2 *__restrict__ patches)
+// pixel (r, c) of the frame: from the staged LDS window or from global memory
+template <bool STAGED> struct pixel_source
+{
+  const float4 *in;
+  const float *wr, *wg, *wb; // window planes, indexable by (r - r0) * pitch + (c - c0)
+  int W, r0, c0, pitch;
+  __device__ __forceinline__ float4 operator()(const int r, const int c) const
+  {
+    if(STAGED)
+    {
+      const int i = (r - r0) * pitch + (c - c0);
+      return make_float4(wr[i], wg[i], wb[i], 0.0f);
+    }
+    return in[(long)r * W + c];
+  }
+};
+
+template <bool STAGED>
+__global__ __launch_bounds__(NLM_THREADS) void nlm_chunks(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                          const nlm_args a, const int2 *__restrict__ patches)
 {
   extern __shared__ float lds[];
   const int tid = threadIdx.x;
@@ -91,8 +116,34 @@ __global__ __launch_bounds__(256) void nlm_chunks(const float4 *__restrict__ in,
   const int csw = a.chk_w + 2 * P + 1; // table columns: frame columns left - P - 1 .. left + chk_w + P - 1
   const int cs0 = left - P - 1;
   float *const cs = lds;                         // [chk_h][cs_pitch]
-  float *const dist = lds + a.chk_h * a.cs_pitch; // [chk_h][wt_pitch]
+  float *const dist = lds + (a.chk_h + 16) * a.cs_pitch; // [chk_h][wt_pitch], 16 spare table rows before it
   const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
+
+  pixel_source<STAGED> px;
+  px.in = in;
+  px.W = W;
+  px.r0 = top - a.reach;
+  px.c0 = left - a.reach;
+  px.pitch = a.win_pitch;
+  if(STAGED)
+  {
+    float *const win = dist + a.chk_h * a.wt_pitch;
+    const int wh = a.chk_h + 2 * a.reach, plane = wh * a.win_pitch;
+    px.wr = win;
+    px.wg = win + plane;
+    px.wb = win + 2 * plane;
+    for(int i = tid; i < plane; i += NLM_THREADS)
+    {
+      const int wy = i / a.win_pitch, wx = i - wy * a.win_pitch;
+      const int r = px.r0 + wy, c = px.c0 + wx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if(r >= 0 && r < H && c >= 0 && c < W) v = in[(long)r * W + c];
+      win[i] = v.x;
+      win[i + plane] = v.y;
+      win[i + 2 * plane] = v.z;
+    }
+    __syncthreads();
+  }
 
   // the pixels this thread accumulates for the whole chunk
   float4 acc[MAX_PX_PER_THREAD];
@@ -101,7 +152,7 @@ __global__ __launch_bounds__(256) void nlm_chunks(const float4 *__restrict__ in,
   for(int k = 0; k < MAX_PX_PER_THREAD; k++)
   {
     acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int idx = tid + 256 * k;
+    const int idx = tid + NLM_THREADS * k;
     const int r = idx / cw;
     rc[k] = idx < ch * cw ? ((r << 16) | (idx - r * cw)) : -1;
   }
@@ -118,14 +169,14 @@ __global__ __launch_bounds__(256) void nlm_chunks(const float4 *__restrict__ in,
     const int pc_max = right + imin(P, imin(W - right, W - (right + scol)));
     const int nrows = row_max - row_min;
     const int first_end = imin(row_top, row_bot); // rows below it: "add the new bottom row" branch
-    const long shift = (long)srow * W + scol;
 
     // ---- A1: terms of the column-sum recurrence.  Table row t holds, for t = 0, the from-scratch
     //      sums at row_min (init_column_sums(), :208-262) and, for t >= 1, the update that takes
     //      row_min + t - 1 to row_min + t (:437-488).
-    for(int item = tid; item < nrows * csw; item += 256)
+    const int ci = tid & (CS_LANES - 1);
+    for(int t = tid / CS_LANES; t < nrows; t += NLM_THREADS / CS_LANES)
     {
-      const int t = item / csw, ci = item - t * csw;
+      if(ci >= csw) continue;
       const int c = cs0 + ci;
       float v = 0.0f;
       if(c >= pc_min && c < pc_max)
@@ -135,29 +186,25 @@ __global__ __launch_bounds__(256) void nlm_chunks(const float4 *__restrict__ in,
           const int row = row_min;
           const int rmin = row - imin(P, imin(row, row + srow));
           const int rmax = row + imin(P, imin(H - 1 - row, H - 1 - (row + srow)));
-          for(int r = rmin; r <= rmax; r++)
-          {
-            const long o = (long)r * W + c;
-            v += pixdiff(in[o], in[o + shift], n0, n1, n2);
-          }
+          for(int r = rmin; r <= rmax; r++) v += pixdiff(px(r, c), px(r + srow, c + scol), n0, n1, n2);
         }
         else
         {
           const int row = row_min + t - 1;
           if(row < first_end)
           {
-            const long b = (long)(row + 1 + P) * W + c;
-            v = pixdiff(in[b], in[b + shift], n0, n1, n2);
+            const int b = row + 1 + P;
+            v = pixdiff(px(b, c), px(b + srow, c + scol), n0, n1, n2);
           }
           else if(row < row_bot)
           {
-            const long b = (long)(row + 1 + P) * W + c, tt = (long)(row - P) * W + c;
-            v = pixdiff2(in[b], in[b + shift], in[tt], in[tt + shift], n0, n1, n2);
+            const int b = row + 1 + P, tt = row - P;
+            v = pixdiff2(px(b, c), px(b + srow, c + scol), px(tt, c), px(tt + srow, c + scol), n0, n1, n2);
           }
           else if(row >= row_top)
           {
-            const long tt = (long)(row - P) * W + c;
-            v = pixdiff(in[tt], in[tt + shift], n0, n1, n2); // subtracted in A2
+            const int tt = row - P;
+            v = pixdiff(px(tt, c), px(tt + srow, c + scol), n0, n1, n2); // subtracted in A2
           }
         }
       }
@@ -165,32 +212,59 @@ __global__ __launch_bounds__(256) void nlm_chunks(const float4 *__restrict__ in,
     }
     __syncthreads();
 
-    // ---- A2: the recurrence itself, one thread per table column
+    // ---- A2: the recurrence itself, one thread per table column.  The table is read and written in
+    //      batches of 16 rows with unconditional LDS accesses (the table has 16 spare rows), so the
+    //      round trips overlap instead of serialising the chain; only the adds are sequential.
     if(tid < csw)
     {
       float v = cs[tid];
-      for(int t = 1; t < nrows; t++)
+      for(int t0 = 1; t0 < nrows; t0 += 16)
       {
-        const int row = row_min + t - 1;
-        const float term = cs[t * a.cs_pitch + tid];
-        if(row < row_bot || row < first_end) v = v + term;
-        else if(row >= row_top) v = v - term;
-        cs[t * a.cs_pitch + tid] = v;
+        float term[16];
+        float *const col = cs + t0 * a.cs_pitch + tid;
+#pragma unroll
+        for(int u = 0; u < 16; u++) term[u] = col[u * a.cs_pitch];
+#pragma unroll
+        for(int u = 0; u < 16; u++)
+        {
+          const int row = row_min + t0 + u - 1;
+          const bool live = t0 + u < nrows;
+          const float plus = v + term[u], minus = v - term[u];
+          v = (live && row < row_bot) ? plus : ((live && row >= row_top) ? minus : v);
+          term[u] = v;
+        }
+#pragma unroll
+        for(int u = 0; u < 16; u++) col[u * a.cs_pitch] = term[u];
       }
     }
     __syncthreads();
 
-    // ---- B: sliding row sum, one thread per row (:405-415)
+    // ---- B: sliding row sum, one thread per row (:405-415), batched like A2 (rows of the distortion
+    //      table are padded by 16 columns)
     if(tid < nrows)
     {
       const float *const row_cs = cs + tid * a.cs_pitch - cs0; // indexable by frame column
       float distortion = 0.0f;
       for(int i = col_min - P; i < imin(col_min + P, col_max); i++) distortion += row_cs[i];
       float *const drow = dist + (row_min + tid - top) * a.wt_pitch - left;
-      for(int c = col_min; c < col_max; c++)
+      for(int c0 = col_min; c0 < col_max; c0 += 16)
       {
-        distortion += (row_cs[c + P] - row_cs[c - P - 1]);
-        drow[c] = distortion;
+        float hi[16], lo[16];
+#pragma unroll
+        for(int u = 0; u < 16; u++)
+        {
+          hi[u] = row_cs[c0 + u + P];
+          lo[u] = row_cs[c0 + u - P - 1];
+        }
+#pragma unroll
+        for(int u = 0; u < 16; u++)
+        {
+          const float next = distortion + (hi[u] - lo[u]);
+          distortion = (c0 + u < col_max) ? next : distortion;
+          hi[u] = distortion;
+        }
+#pragma unroll
+        for(int u = 0; u < 16; u++) drow[c0 + u] = hi[u];
       }
     }
     __syncthreads();
@@ -203,14 +277,13 @@ __global__ __launch_bounds__(256) void nlm_chunks(const float4 *__restrict__ in,
       const int row = top + (rc[k] >> 16), col = left + (rc[k] & 0xffff);
       if(row < row_min || row >= row_max || col < col_min || col >= col_max) continue;
       const float distortion = dist[(row - top) * a.wt_pitch + (col - left)];
-      const long o = (long)row * W + col;
-      const float4 q = in[o + shift];
+      const float4 q = px(row + srow, col + scol);
       float w;
       if(a.center_weight < 0)
         w = mexp2(distortion * a.sharpness);
       else
       {
-        const float dis = (distortion + pixdiff(in[o], q, a.cpn, a.cpn, a.cpn)) / (1.0f + a.center_weight);
+        const float dis = (distortion + pixdiff(px(row, col), q, a.cpn, a.cpn, a.cpn)) / (1.0f + a.center_weight);
         w = mexp2(fmaxf(0.0f, dis * a.sharpness - 2.0f));
       }
       acc[k].x += q.x * w;
@@ -308,9 +381,14 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   }
   const int K = p.search_radius;
   std::vector<int2> patches;
+  int max_shift = 0;
   for(int ri = -K; ri <= K; ri++)
     for(int ci = -K; ci <= K; ci++)
-      patches.push_back(make_int2(scatter(p.scale, p.scattering, ri, ci), scatter(p.scale, p.scattering, ci, ri)));
+    {
+      const int r = scatter(p.scale, p.scattering, ri, ci), c = scatter(p.scale, p.scattering, ci, ri);
+      patches.push_back(make_int2(r, c));
+      max_shift = std::max(max_shift, std::max(abs(r), abs(c)));
+    }
   nlm_args a;
   memset(&a, 0, sizeof(a));
   a.W = width;
@@ -322,7 +400,7 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   a.radius = p.patch_radius;
   a.npatch = (int)patches.size();
   a.cs_pitch = (a.chk_w + 2 * a.radius + 1) | 1; // odd pitches: the row-parallel step strides whole rows
-  a.wt_pitch = a.chk_w | 1;
+  a.wt_pitch = (a.chk_w + 16) | 1; // 16 spare columns: the batched row recurrence stores whole batches
   a.sharpness = p.sharpness;
   a.center_weight = p.center_weight;
   a.cpn = p.center_weight * (2 * p.patch_radius + 1) * (2 * p.patch_radius + 1); // compute_center_pixel_norm()
@@ -330,12 +408,20 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   a.luma = p.luma;
   a.chroma = p.chroma;
   a.skip_blend = (p.luma == 1.0 && p.chroma == 1.0);
-  if(a.chk_w * a.chk_h > 256 * MAX_PX_PER_THREAD || a.chk_h > 256)
+  if(a.chk_w * a.chk_h > NLM_THREADS * MAX_PX_PER_THREAD || a.chk_h > NLM_THREADS
+     || a.chk_w + 2 * a.radius + 1 > CS_LANES)
   {
     set_last_error("nlmeans: chunk %d x %d exceeds the kernel's accumulator budget", a.chk_w, a.chk_h);
     return DT_HIP_DEFAULT_ERROR;
   }
-  const size_t lds_bytes = (size_t)a.chk_h * (a.cs_pitch + a.wt_pitch) * sizeof(float);
+  const size_t table_bytes = ((size_t)(a.chk_h + 16) * a.cs_pitch + (size_t)a.chk_h * a.wt_pitch + 64) * sizeof(float);
+  // the window a chunk's patches can touch: init_column_sums() reads radius rows/columns beyond the
+  // chunk, the recurrence one more row below, and everything once more shifted by the patch offset
+  a.reach = a.radius + 1 + max_shift;
+  a.win_pitch = (a.chk_w + 2 * a.reach) | 1;
+  const size_t window_bytes = (size_t)3 * (a.chk_h + 2 * a.reach) * a.win_pitch * sizeof(float);
+  const bool staged = table_bytes + window_bytes <= 160 * 1024;
+  const size_t lds_bytes = table_bytes + (staged ? window_bytes : 0);
   hipStream_t s = stream_of(devid);
   int2 *dev_patches = (int2 *)dt_hip_alloc_device_buffer(devid, patches.size() * sizeof(int2));
   if(!dev_patches) return DT_HIP_SYSMEM_ALLOCATION;
@@ -346,10 +432,14 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     return DT_HIP_DEFAULT_ERROR;
   }
   if(lds_bytes > 64 * 1024)
-    ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)nlm_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    ANSEL_HIP_CHECK(hipFuncSetAttribute(staged ? (const void *)nlm_chunks<true> : (const void *)nlm_chunks<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   {
     launch_scope ls(devid, "nlm_chunks");
-    nlm_chunks<<<(unsigned)(a.nchx * nchy), 256, lds_bytes, s>>>(in, out, a, dev_patches);
+    if(staged)
+      nlm_chunks<true><<<(unsigned)(a.nchx * nchy), NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
+    else
+      nlm_chunks<false><<<(unsigned)(a.nchx * nchy), NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
   }
   dt_hip_release_mem_object(dev_patches);
   return check_launch("nlm_chunks");
