@@ -16,6 +16,9 @@
  * shifting the pattern origin by (x, y) rotates rows by y (mod 8) and swaps the two column
  * entries of every row when x is odd.  tests/test_filters.py pins it against the identity
  * FC(r + y, c + x, f) == FC(r, c, shifted) the reference's call sites rely on. */
+void amaze_demosaic_RT(const dt_dev_pixelpipe_iop_t *piece, const float *const in, float *out,
+                       const dt_iop_roi_t *const roi_in, const dt_iop_roi_t *const roi_out, const int filters);
+
 uint32_t ref_shift_dcraw_filters(uint32_t filters, uint32_t x, uint32_t y)
 {
   if(!filters || filters == 9u) return filters;
@@ -40,6 +43,8 @@ int ref_demosaic(const dt_hip_piece_t *v, const dt_hip_demosaic_data_t *d, const
   const uint32_t filters = ref_shift_dcraw_filters(v->filters, piece.roi_in.x, piece.roi_in.y);
   if(d->demosaicing_method == DT_HIP_DEMOSAIC_RCD)
     rcd_demosaic(&piece, (float *)out, (const float *)in, &roo, &roi, filters);
+  else if(d->demosaicing_method == DT_HIP_DEMOSAIC_AMAZE)
+    amaze_demosaic_RT(&piece, (const float *)in, (float *)out, &roi, &roo, filters);
   else if(d->demosaicing_method == DT_HIP_DEMOSAIC_PPG)
     return demosaic_ppg((float *)out, (const float *)in, &roo, &roi, filters, d->median_thrs);
   else

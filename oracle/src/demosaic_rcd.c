@@ -331,6 +331,8 @@ uint32_t oracle_shift_dcraw_filters(uint32_t filters, uint32_t x, uint32_t y)
 }
 
 int oracle_demosaic_ppg(float *out, const float *in, const dt_hip_roi_t *roi_out, const dt_hip_roi_t *roi_in, uint32_t filters);
+int oracle_demosaic_amaze(float *out, const float *in, const dt_hip_roi_t *roi_out, const dt_hip_roi_t *roi_in,
+                          uint32_t filters, float clip_pt);
 
 /* process(), src/iop/demosaic.c:1041-1253, Bayer branch with green_eq off, no colour smoothing */
 int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d, const void *in, void *out)
@@ -346,6 +348,14 @@ int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d
     dt_hip_roi_t roo = piece->roi_out;
     roo.x = roo.y = 0;
     return oracle_demosaic_ppg((float *)out, (const float *)in, &roo, &piece->roi_in, filters);
+  }
+  if(d->demosaicing_method == DT_HIP_DEMOSAIC_AMAZE)
+  {
+    /* amaze.cc:191-192 */
+    const float clip_pt = fminf(piece->processed_maximum[0], fminf(piece->processed_maximum[1], piece->processed_maximum[2]));
+    dt_hip_roi_t roo = piece->roi_out;
+    roo.x = roo.y = 0;
+    return oracle_demosaic_amaze((float *)out, (const float *)in, &roo, &piece->roi_in, filters, clip_pt);
   }
   return 1;
 }

@@ -303,3 +303,43 @@ def test_bilat_bilateral_grid(w, h, ss, sr, detail):
     # and with its default thread count the reference stays within rounding of that
     a2, _ = _pair("bilat", abi.Piece.make(w, h), d, img, img.shape)
     assert float(np.abs(a2[..., 0] - b[..., 0]).max()) < 1e-3
+
+
+AMAZE_SIZES = [(300, 200), (517, 389), (401, 333), (160, 160), (130, 97), (273, 273), (64, 64), (47, 53)]
+
+
+@pytest.mark.parametrize("w,h", AMAZE_SIZES)
+@pytest.mark.parametrize("filters", [0x94949494, 0x49494949, 0x61616161, 0x16161616])
+def test_demosaic_amaze(w, h, filters):
+    """AMaZE.  The reference keeps its tile buffer from tile to tile (per OpenMP thread) and a few
+    stencils read words the current tile never wrote, so a handful of pixels depend on thread
+    scheduling.  Two pins: (1) with the restatement keeping its buffer the same way and walking the
+    tiles in order, it equals the reference on ONE thread bit for bit, every pixel; (2) in its normal
+    mode (buffer zeroed per tile, what the device implements) it equals the reference at any thread
+    count outside oracle_amaze_stale_mask()."""
+    raw = synth.bayer_mosaic(w, h, seed=w + h).astype(np.float32)
+    cfa = ((raw - 512) / np.float32(synth.WHITE - 512) * np.float32(1.7)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=filters, channels=1, processed_maximum=(1.5, 1.0, 1.2, 1.0))
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_AMAZE, 0.0)
+    r, o = ck.ref(), ck.oracle()
+    threads = r.ref_get_num_threads()
+    pre = np.full((h, w, 4), -7.0, np.float32)
+    try:
+        r.ref_set_num_threads(1)
+        one = pre.copy()
+        assert ck.call(r, "ref_demosaic", piece, d, cfa, one) == 0
+        o.oracle_amaze_persistent(1)
+        pers = pre.copy()
+        assert ck.call(o, "oracle_demosaic", piece, d, cfa, pers) == 0
+    finally:
+        o.oracle_amaze_persistent(0)
+        r.ref_set_num_threads(threads)
+    _exact(one, pers, "amaze, persistent buffer vs one-thread reference")
+    many = pre.copy()
+    assert ck.call(r, "ref_demosaic", piece, d, cfa, many) == 0
+    canon = pre.copy()
+    assert ck.call(o, "oracle_demosaic", piece, d, cfa, canon) == 0
+    mask = np.zeros((h, w), np.uint8)
+    o.oracle_amaze_stale_mask(ck.ptr(mask), w, h)
+    _exact(many, canon, "amaze", mask=mask[..., None] * np.ones(4, np.uint8))
+    assert np.all(canon[..., 3] == -7.0)  # alpha is not written (amaze.cc writes channels 0..2 only)
