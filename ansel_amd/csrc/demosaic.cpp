@@ -7,6 +7,7 @@ namespace ansel
 int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out,
                         const rcd_band_t *band);
 int ppg_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
+int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
 }
 extern "C" uint32_t dt_hip_crop_dcraw_filters(uint32_t filters, uint32_t crop_x, uint32_t crop_y);
 
@@ -47,6 +48,13 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
         return DT_HIP_INVALID_ARG;
       }
       return ppg_demosaic_launch(devid, piece, filters, (const float *)dev_in, (float4 *)dev_out);
+    case DT_HIP_DEMOSAIC_AMAZE:
+      if(band)
+      {
+        set_last_error("demosaic: AMaZE has no row-band mode");
+        return DT_HIP_INVALID_ARG;
+      }
+      return amaze_demosaic_launch(devid, piece, filters, (const float *)dev_in, (float4 *)dev_out);
     default:
       set_last_error("demosaic: method %u is not implemented on device", d->demosaicing_method);
       return DT_HIP_INVALID_ARG;
@@ -74,7 +82,7 @@ void dt_hip_iop_demosaic_tiling(const dt_hip_piece_t *piece, const dt_hip_demosa
   tiling->overhead = 0;
   tiling->xalign = 2;
   tiling->yalign = 2;
-  tiling->overlap = (d->demosaicing_method == DT_HIP_DEMOSAIC_RCD) ? 10 : 5;
+  tiling->overlap = (d->demosaicing_method == DT_HIP_DEMOSAIC_RCD) ? 10 : 5; // PPG and AMaZE: 5
 }
 
 } // extern "C"

@@ -27,6 +27,7 @@ def _rgba():
 
 
 SINGLE_THREAD_OPS = ("denoiseprofile", "bilat")
+SINGLE_THREAD_NAMES = ("demosaic_amaze",)
 DNW, DNH = 288, 176    # denoiseprofile: 5 wavelet bands
 
 
@@ -79,6 +80,8 @@ def cases(lut_ptrs=None):
     dp_ = abi.Piece.make(DW, DH, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS)
     yield ("demosaic_rcd", "demosaic", dp_, abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.0), dcfa, (DH, DW, 4))
     yield ("demosaic_ppg", "demosaic", dp_, abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0), dcfa, (DH, DW, 4))
+    # AMaZE: recorded single-threaded (see SINGLE_THREAD_NAMES); even frame size, so only the tile-row seam is masked
+    yield ("demosaic_amaze", "demosaic", dp_, abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_AMAZE, 0.0), dcfa, (DH, DW, 4))
     img = _rgba()
     rgb = abi.Piece.make(W, H)
     yield ("exposure", "exposure", rgb, abi.ExposureData(-0.000244140625, 1.6245048), img, img.shape)

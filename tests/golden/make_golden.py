@@ -30,7 +30,7 @@ def main():
     for name, op, piece, data, inp, shape in cases.cases():
         res = np.zeros(shape, np.float32)
         # modules with a thread-count dependent reduction are recorded single-threaded
-        r.ref_set_num_threads(1 if op in cases.SINGLE_THREAD_OPS else threads)
+        r.ref_set_num_threads(1 if (op in cases.SINGLE_THREAD_OPS or name in cases.SINGLE_THREAD_NAMES) else threads)
         assert ck.call(r, "ref_" + op, piece, data, np.ascontiguousarray(inp), res) == 0, name
         out[name] = res
     r.ref_set_num_threads(threads)

@@ -45,6 +45,13 @@ def main():
         d = params.denoiseprofile()
         piece = abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS)
         fn = l.dt_hip_iop_denoiseprofile_process
+    elif args.module == "amaze":
+        cfa = torch.from_numpy(((synth.bayer_mosaic_tiled(w, h, seed=1).astype(np.float32) - 512) / (synth.WHITE - 512)).astype(np.float32)).to(dev)
+        img = cfa
+        out = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=(1, 1, 1, 1))
+        d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_AMAZE, 0.0)
+        fn = l.dt_hip_iop_demosaic_process
     elif args.module == "bilat":
         d = abi.BilatData.bilateral()
         fn = l.dt_hip_iop_bilat_process
