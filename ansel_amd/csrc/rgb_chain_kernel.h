@@ -49,13 +49,16 @@ __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, 
     if(a.to_u16)
     {
       // _export_final_buffer_to_uint16(), src/imageio/imageio_core.c:729-737 (glib CLAMP)
-      ushort4 o;
       const float x = roundf(v.x * 65535.f), y = roundf(v.y * 65535.f), z = roundf(v.z * 65535.f), w = roundf(v.w * 65535.f);
-      o.x = (unsigned short)(int)(x > 65535.f ? 65535.f : (x < 0.f ? 0.f : x));
-      o.y = (unsigned short)(int)(y > 65535.f ? 65535.f : (y < 0.f ? 0.f : y));
-      o.z = (unsigned short)(int)(z > 65535.f ? 65535.f : (z < 0.f ? 0.f : z));
-      o.w = (unsigned short)(int)(w > 65535.f ? 65535.f : (w < 0.f ? 0.f : w));
-      reinterpret_cast<ushort4 *>(out)[k] = o;
+      typedef unsigned short v4us_t __attribute__((ext_vector_type(4)));
+      const v4us_t ov = { (unsigned short)(int)(x > 65535.f ? 65535.f : (x < 0.f ? 0.f : x)),
+                          (unsigned short)(int)(y > 65535.f ? 65535.f : (y < 0.f ? 0.f : y)),
+                          (unsigned short)(int)(z > 65535.f ? 65535.f : (z < 0.f ? 0.f : z)),
+                          (unsigned short)(int)(w > 65535.f ? 65535.f : (w < 0.f ? 0.f : w)) };
+      // streaming store: written once, read by nobody on the device (PMC: 1.14 GB of write requests per
+      // 0.81 GB written, against 1.58 GB with a cached store; pairing lanes into 16-byte stores changed
+      // nothing and cost 3 %)
+      __builtin_nontemporal_store(ov, reinterpret_cast<v4us_t *>(out) + k);
     }
     else
       nt_store(reinterpret_cast<float4 *>(out) + k, v);
