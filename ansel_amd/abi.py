@@ -123,6 +123,11 @@ class BilatData(C.Structure):
         return cls(0, sigma_r, sigma_s, detail, 0.5, iscale)
 
 
+class FinalscaleData(C.Structure):
+    """dt_hip_finalscale_data_t: the export interpolator (0 bilinear, 1 bicubic, 2 Mitchell = default)"""
+    _fields_ = [("interpolation", C.c_int)]
+
+
 class LabData(C.Structure):
     """dt_hip_lab_data_t: the 3x3 (rows padded to 4) of the RGB <-> Lab glue"""
     _fields_ = [("matrix", m34)]

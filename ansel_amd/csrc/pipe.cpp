@@ -40,6 +40,7 @@ enum op_t
   OP_NLMEANS,
   OP_BILAT,
   OP_LAB_TO_RGB,
+  OP_FINALSCALE,
   OP_EXPORT_U16,
   OP_UNKNOWN
 };
@@ -67,6 +68,7 @@ const op_info_t k_ops[] = {
   { "nlmeans", sizeof(dt_hip_nlmeans_data_t), 16 },
   { "bilat", sizeof(dt_hip_bilat_data_t), 16 },
   { "lab_to_rgb", sizeof(dt_hip_lab_data_t), 16 },
+  { "finalscale", sizeof(dt_hip_finalscale_data_t), 16 },
   { "export_u16", 0, 8 },
 };
 
@@ -119,6 +121,7 @@ int run_single(int devid, const node_t &n, dt_hip_mem_t in, dt_hip_mem_t out)
     case OP_CHANNELMIXERRGB: return dt_hip_iop_channelmixerrgb_process(devid, &n.piece, n.as<dt_hip_channelmixerrgb_data_t>(), in, out);
     case OP_FILMICRGB: return dt_hip_iop_filmicrgb_process(devid, &n.piece, n.as<dt_hip_filmicrgb_data_t>(), in, out);
     case OP_COLOROUT: return dt_hip_iop_colorout_process(devid, &n.piece, n.as<dt_hip_conversion_t>(), in, out);
+    case OP_FINALSCALE: return dt_hip_iop_finalscale_process(devid, &n.piece, n.as<dt_hip_finalscale_data_t>(), in, out);
     case OP_EXPORT_U16: return dt_hip_export_convert_u16(devid, n.piece.roi_out.width, n.piece.roi_out.height, in, out);
     default: return DT_HIP_INVALID_ARG;
   }
@@ -426,7 +429,7 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
     }
   if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
   for(const node_t &n : pipe->nodes)
-    if(n.op == OP_DENOISEPROFILE || n.op == OP_DIFFUSE || n.op == OP_NLMEANS || n.op == OP_BILAT)
+    if(n.op == OP_DENOISEPROFILE || n.op == OP_DIFFUSE || n.op == OP_NLMEANS || n.op == OP_BILAT || n.op == OP_FINALSCALE)
     {
       // these need a halo of 2^scales rows per band and (denoiseprofile) an all-reduce per wavelet band
       set_last_error("band mode: '%s' has no row-band implementation yet", k_ops[n.op].name);

@@ -391,6 +391,21 @@ typedef struct dt_hip_bilat_data_t
 int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d,
                              dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
+/* finalscale: process(), src/iop/finalscale.c:117-131 -> dt_iop_clip_and_zoom_roi()
+ * (src/develop/imageop_math.c:146-152) -> dt_interpolation_resample_roi(), src/pixel/interpolation.c:898-1062:
+ * separable resampling from roi_in (width, height, scale) to roi_out with the export interpolator
+ * (plans of _prepare_resampling_plan(), :711-895; kernels bilinear / bicubic / Mitchell, :175-296).
+ * roi x/y are ignored like the module does.  scale_out == scale_in copies. */
+#define DT_HIP_INTERPOLATION_BILINEAR 0
+#define DT_HIP_INTERPOLATION_BICUBIC 1
+#define DT_HIP_INTERPOLATION_MITCHELL 2 /* DT_INTERPOLATION_DEFAULT */
+typedef struct dt_hip_finalscale_data_t
+{
+  int interpolation; /* the "plugins/lighttable/export/pixel_interpolator" preference */
+} dt_hip_finalscale_data_t;
+int dt_hip_iop_finalscale_process(int devid, const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d,
+                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
 /* ---- 3. export-pipe executor ----------------------------------------------------------- */
 /* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)
  * for an export: an ordered list of module nodes, each with its piece view and committed data,

@@ -69,3 +69,12 @@ void ref_reset_fp_mode(void)
 #endif
   }
 }
+
+/* the export interpolator preference (see ref_shim/common/conf.h) */
+static const char *ref_interpolator = "mitchell";
+void ref_set_interpolator(const char *name) { ref_interpolator = name; }
+const char *dt_conf_get_string_const(const char *name)
+{
+  (void)name;
+  return ref_interpolator;
+}

@@ -125,6 +125,10 @@ def cases(lut_ptrs=None):
     lab = _lab()
     yield ("lab_to_rgb", "lab_to_rgb", rgb, abi.LabData.make(params.WORK_OUT), lab, lab.shape)
     yield ("nlmeans", "nlmeans", rgb, abi.NlmeansData(2.0, 50.0, 0.5, 1.0), lab, lab.shape)
+    fpiece = abi.Piece.make(60, 40, roi_in=abi.Roi.make(0, 0, W, H, 1.0), roi_out=abi.Roi.make(0, 0, 60, 40, 0.625))
+    yield ("finalscale_down", "finalscale", fpiece, abi.FinalscaleData(2), img, (40, 60, 4))
+    upiece = abi.Piece.make(144, 96, roi_in=abi.Roi.make(0, 0, W, H, 1.0), roi_out=abi.Roi.make(0, 0, 144, 96, 1.5))
+    yield ("finalscale_up", "finalscale", upiece, abi.FinalscaleData(1), img, (96, 144, 4))
     yield ("bilat", "bilat", rgb, abi.BilatData.bilateral(12.0, 10.0, 0.5), lab, lab.shape)
     yield ("denoiseprofile_nlmeans", "denoiseprofile", dpiece,
            params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS), dimg, dimg.shape)

@@ -343,3 +343,16 @@ def test_demosaic_amaze(w, h, filters):
     o.oracle_amaze_stale_mask(ck.ptr(mask), w, h)
     _exact(many, canon, "amaze", mask=mask[..., None] * np.ones(4, np.uint8))
     assert np.all(canon[..., 3] == -7.0)  # alpha is not written (amaze.cc writes channels 0..2 only)
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+@pytest.mark.parametrize("iw,ih,scale", [(300, 200, 0.5), (301, 199, 0.37), (200, 150, 0.91), (160, 120, 1.5),
+                                         (97, 61, 2.75), (400, 300, 0.1), (128, 128, 1.0)])
+def test_finalscale(interp, iw, ih, scale):
+    """the export resampler: down- and up-scaling, all three interpolators"""
+    ow, oh = max(int(round(iw * scale)), 1), max(int(round(ih * scale)), 1)
+    img = synth.rgba_image(iw, ih, seed=31, lo=-0.05, hi=1.3)
+    img[..., 3] = 0.5
+    piece = abi.Piece.make(ow, oh, roi_in=abi.Roi.make(7, 3, iw, ih, 1.0), roi_out=abi.Roi.make(5, 9, ow, oh, scale))
+    a, b = _pair("finalscale", piece, abi.FinalscaleData(interp), img, (oh, ow, 4))
+    _exact(a, b, "finalscale")
