@@ -122,6 +122,12 @@ class BilatData(C.Structure):
     def bilateral(cls, sigma_s=50.0, sigma_r=25.0, detail=0.33, iscale=1.0):
         return cls(0, sigma_r, sigma_s, detail, 0.5, iscale)
 
+    @classmethod
+    def local_laplacian(cls, highlights=0.5, shadows=0.5, detail=0.25, midtone=0.5):
+        """the module's default mode and $DEFAULT values (src/iop/bilat.c:78-86): sigma_r carries the
+        highlights slider, sigma_s the shadows slider"""
+        return cls(1, highlights, shadows, detail, midtone, 1.0)
+
 
 class FinalscaleData(C.Structure):
     """dt_hip_finalscale_data_t: the export interpolator (0 bilinear, 1 bicubic, 2 Mitchell = default)"""

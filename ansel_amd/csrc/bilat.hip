@@ -191,19 +191,28 @@ void grid_size(grid_t &b, const int width, const int height, const float L_range
 
 } // namespace
 
+namespace ansel
+{
+int local_laplacian_launch(int devid, const float4 *in, float4 *out, int wd, int ht, float sigma, float shadows,
+                           float highlights, float clarity);
+}
+
 extern "C" {
 
 int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in,
                              dt_hip_mem_t dev_out)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || piece->channels != 4) return DT_HIP_INVALID_ARG;
-  if(d->mode != DT_HIP_BILAT_BILATERAL)
-  {
-    set_last_error("bilat: only the bilateral-grid mode is implemented on device (local laplacian is out of scope)");
-    return DT_HIP_INVALID_ARG;
-  }
   const int width = piece->roi_in.width, height = piece->roi_in.height;
   if(width <= 0 || height <= 0) return DT_HIP_SUCCESS;
+  if(d->mode == DT_HIP_BILAT_LOCAL_LAPLACIAN) // bilat.c:352-357: (midtone, sigma_s, sigma_r, detail)
+    return local_laplacian_launch(devid, (const float4 *)dev_in, (float4 *)dev_out, width, height, d->midtone, d->sigma_s,
+                                  d->sigma_r, d->detail);
+  if(d->mode != DT_HIP_BILAT_BILATERAL)
+  {
+    set_last_error("bilat: unknown mode %d", d->mode);
+    return DT_HIP_INVALID_ARG;
+  }
   if(!(d->iscale > 0.0f) || !(piece->roi_in.scale > 0.0) || !(d->sigma_r > 0.0f)) return DT_HIP_INVALID_ARG;
   const float scale = (float)(d->iscale / piece->roi_in.scale); // dt_dev_get_module_scale(), bilat.c:339
   grid_t b;

@@ -550,7 +550,6 @@ int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoise
   float4 *pre = (float4 *)dt_hip_alloc_device_buffer(devid, npix * sizeof(float4));
   if(!pre) return DT_HIP_SYSMEM_ALLOCATION;
   hipStream_t st = stream_of(devid);
-  const unsigned sgrid = stream_grid(npix, 256);
   {
     vst_args fa;
     forward_args(s, fa);

@@ -372,10 +372,12 @@ int dt_hip_transform_rgb_to_lab(int devid, const dt_hip_piece_t *piece, const dt
 int dt_hip_transform_lab_to_rgb(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d,
                                 dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
-/* local contrast, bilateral-grid mode: process(), src/iop/bilat.c:330-361 -> dt_bilateral_init /
+/* local contrast, both modes: process(), src/iop/bilat.c:330-361; bilateral grid -> dt_bilateral_init /
  * _splat / _blur / _slice, src/pixel/bilateral.c:157-393 (Lab input, only L changes).
  * dt_hip_bilat_data_t == dt_iop_bilat_params_t (bilat.c:78-86) + pipe->iscale.
- * mode must be DT_HIP_BILAT_BILATERAL; the local-laplacian mode is out of scope.
+ * DT_HIP_BILAT_LOCAL_LAPLACIAN (the module's default mode): local_laplacian_internal(),
+ * src/pixel/locallaplacian.c:354-563, regular mode (an export has no preview boundary);
+ * sigma_r / sigma_s then carry the highlights / shadows sliders, midtone the curve width.
  *
  * dt_bilateral_splat() accumulates the grid in binary32 per OpenMP slice and then merges the
  * slices, so its rounding depends on the host's thread count; the device accumulates every grid cell

@@ -1,22 +1,21 @@
 /* oracle/ref_wrap/ref_bilat.c -- TEST INFRASTRUCTURE ONLY.
- * The reference's local contrast module in bilateral-grid mode: process() of src/iop/bilat.c lifted
- * verbatim at build time, over src/pixel/bilateral.c compiled from where it lies. */
+ * The reference's local contrast module, both modes: process() of src/iop/bilat.c lifted verbatim at
+ * build time, over src/pixel/bilateral.c and src/pixel/locallaplacian.c compiled from where they lie. */
 #include "ref_piece.h"
 #include "pixel/bilateral.h"
 
 typedef void *GtkWidget;
-/* the local-laplacian branch of process() is never taken here */
-#define local_laplacian(i, o, w, h, m, ss, sr, d, x) (1)
+#include "pixel/locallaplacian.h"
 #define process ref_bilat_module_process /* every module calls its entry point process() */
 #include "gen/bilat.inc"
 
 int ref_bilat(const dt_hip_piece_t *v, const dt_hip_bilat_data_t *h, const void *in, void *out)
 {
   ref_reset_fp_mode();
-  if(h->mode != DT_HIP_BILAT_BILATERAL) return 1;
+  if(h->mode != DT_HIP_BILAT_BILATERAL && h->mode != DT_HIP_BILAT_LOCAL_LAPLACIAN) return 1;
   dt_iop_bilat_params_t p;
   memset(&p, 0, sizeof(p));
-  p.mode = s_mode_bilateral;
+  p.mode = h->mode == DT_HIP_BILAT_BILATERAL ? s_mode_bilateral : s_mode_local_laplacian;
   p.sigma_r = h->sigma_r;
   p.sigma_s = h->sigma_s;
   p.detail = h->detail;

@@ -133,8 +133,14 @@ void oracle_bilat_grid(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d
   sigmas[1] = b.sigma_r;
 }
 
+int oracle_local_laplacian(const float *input, float *out, int wd, int ht, float sigma, float shadows, float highlights,
+                           float clarity);
+
 int oracle_bilat(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, const void *in_, void *out_)
 {
+  if(d->mode == DT_HIP_BILAT_LOCAL_LAPLACIAN) /* bilat.c:352-357 */
+    return oracle_local_laplacian((const float *)in_, (float *)out_, piece->roi_in.width, piece->roi_in.height, d->midtone,
+                                  d->sigma_s, d->sigma_r, d->detail);
   if(d->mode != DT_HIP_BILAT_BILATERAL) return 1;
   const float *in = (const float *)in_;
   float *out = (float *)out_;

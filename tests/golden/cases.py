@@ -129,6 +129,7 @@ def cases(lut_ptrs=None):
     yield ("finalscale_down", "finalscale", fpiece, abi.FinalscaleData(2), img, (40, 60, 4))
     upiece = abi.Piece.make(144, 96, roi_in=abi.Roi.make(0, 0, W, H, 1.0), roi_out=abi.Roi.make(0, 0, 144, 96, 1.5))
     yield ("finalscale_up", "finalscale", upiece, abi.FinalscaleData(1), img, (96, 144, 4))
+    yield ("bilat_local_laplacian", "bilat", rgb, abi.BilatData.local_laplacian(0.7, 0.4, 0.8, 0.4), lab, lab.shape)
     yield ("bilat", "bilat", rgb, abi.BilatData.bilateral(12.0, 10.0, 0.5), lab, lab.shape)
     yield ("denoiseprofile_nlmeans", "denoiseprofile", dpiece,
            params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS), dimg, dimg.shape)

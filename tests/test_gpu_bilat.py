@@ -45,8 +45,21 @@ def test_bilat(w, h, ss, sr, detail):
         assert float(np.abs(r[..., 0] - got[..., 0]).max()) < 1e-3
 
 
-def test_bilat_rejects_local_laplacian():
-    img = _lab_image(64, 48, 1)
-    d = abi.BilatData(1, 0.5, 0.5, 0.25, 0.5, 1.0)
-    with pytest.raises(Exception):
-        hc.run_hip("dt_hip_iop_bilat_process", abi.Piece.make(64, 48), d, img, img.shape)
+@pytest.mark.parametrize("w,h", [(300, 200), (123, 457), (64, 64), (257, 130), (1500, 1000)])
+@pytest.mark.parametrize("hl,sh,detail,mid", [(0.5, 0.5, 0.25, 0.5), (1.0, 0.2, 1.5, 0.3), (0.1, 1.3, -0.6, 0.8)])
+def test_local_laplacian(w, h, hl, sh, detail, mid):
+    """the module's default mode"""
+    img = _lab_image(w, h, 33)
+    d = abi.BilatData.local_laplacian(hl, sh, detail, mid)
+    piece = abi.Piece.make(w, h)
+    pre = np.full(img.shape, -5.0, np.float32)
+    got = hc.run_hip("dt_hip_iop_bilat_process", piece, d, img, img.shape, pre_fill=pre)
+    want = pre.copy()
+    assert ck.call(ck.oracle(), "oracle_bilat", piece, d, img, want) == 0
+    diff = ck.ulp_diff(got, want)
+    assert int((diff > 0).sum()) == 0, "%d values differ, max %d ulp" % (int((diff > 0).sum()), int(diff.max()))
+    ref = ck.ref()
+    if ref is not None and w * h < 500000:
+        r = pre.copy()
+        assert ck.call(ref, "ref_bilat", piece, d, img, r) == 0
+        assert int((ck.ulp_diff(got, r) > 0).sum()) == 0

@@ -356,3 +356,18 @@ def test_finalscale(interp, iw, ih, scale):
     piece = abi.Piece.make(ow, oh, roi_in=abi.Roi.make(7, 3, iw, ih, 1.0), roi_out=abi.Roi.make(5, 9, ow, oh, scale))
     a, b = _pair("finalscale", piece, abi.FinalscaleData(interp), img, (oh, ow, 4))
     _exact(a, b, "finalscale")
+
+
+@pytest.mark.parametrize("w,h", [(300, 200), (123, 457), (64, 64), (257, 130)])
+@pytest.mark.parametrize("hl,sh,detail,mid", [(0.5, 0.5, 0.25, 0.5), (1.0, 0.2, 1.5, 0.3), (0.1, 1.3, -0.6, 0.8)])
+def test_bilat_local_laplacian(w, h, hl, sh, detail, mid):
+    """the module's default mode; no reduction, no shared state: exact at any thread count"""
+    img = _lab_image(w, h, 33)
+    d = abi.BilatData.local_laplacian(hl, sh, detail, mid)
+    pre = np.full(img.shape, -5.0, np.float32)
+    r, o = ck.ref(), ck.oracle()
+    a, b = pre.copy(), pre.copy()
+    assert ck.call(r, "ref_bilat", abi.Piece.make(w, h), d, img, a) == 0
+    assert ck.call(o, "oracle_bilat", abi.Piece.make(w, h), d, img, b) == 0
+    _exact(a, b, "local laplacian")
+    assert np.all(b[..., 3] == -5.0) and float(np.abs(b[..., 0] - img[..., 0]).max()) > 1e-3

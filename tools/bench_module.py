@@ -52,6 +52,9 @@ def main():
         piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=(1, 1, 1, 1))
         d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_AMAZE, 0.0)
         fn = l.dt_hip_iop_demosaic_process
+    elif args.module == "locallaplacian":
+        d = abi.BilatData.local_laplacian()
+        fn = l.dt_hip_iop_bilat_process
     elif args.module == "bilat":
         d = abi.BilatData.bilateral()
         fn = l.dt_hip_iop_bilat_process
