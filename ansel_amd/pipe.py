@@ -56,7 +56,7 @@ def light_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, with_
 
 
 def denoise_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, filmic=None,
-                       diffuse_preset="lens_deblur_soft", diffuse_iterations=2, with_nlmeans=False):
+                       diffuse_preset="lens_deblur_soft", diffuse_iterations=2, with_nlmeans=False, with_bilat=None):
     """config 3 of BASELINE.json, as far as it runs on device: the light pipe + denoise (profiled)
     wavelets after demosaic and diffuse-or-sharpen after color calibration, in the reference's module
     order (src/develop/iop_order.c:196-232)."""
@@ -74,7 +74,8 @@ def denoise_pipe_nodes(width, height, lut_target_ptr, lut_first, lut_coeffs, fil
                 # a Lab module: the pipe converts work RGB -> Lab before and back after it (pixelpipe_cpu.c:59-75)
                 out.append(Node("rgb_to_lab", abi.LabData.make(params.WORK_IN), rgb))
                 out.append(Node("nlmeans", abi.NlmeansData(2.0, 50.0, 0.5, 1.0), rgb))
-                out.append(Node("bilat", abi.BilatData.bilateral(), rgb))
+                if with_bilat is None or with_bilat:
+                    out.append(Node("bilat", abi.BilatData.bilateral(), rgb))
                 out.append(Node("lab_to_rgb", abi.LabData.make(params.WORK_OUT), rgb))
     return out
 

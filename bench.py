@@ -43,8 +43,8 @@ def parse():
     ap.add_argument("--no-fusion", action="store_true", help="one launch per module (A/B against the fused executor)")
     ap.add_argument("--cpu-sample", default="24MP", help="frame size of the bounded CPU sample")
     ap.add_argument("--pipe", default="light", choices=("light", "denoise"),
-                    help="light = BASELINE.json config 2 (the metric's workload); denoise = config 3 as far as it runs "
-                         "on device (+ denoise (profiled) wavelets + diffuse or sharpen), quoted on 60MP")
+                    help="light = BASELINE.json config 2 (the metric's workload); denoise = config 3 (+ denoise (profiled) "
+                         "wavelets + non-local means in Lab + diffuse or sharpen), quoted on 60MP")
     ap.add_argument("--mode", default="batch", choices=("batch", "tiled"),
                     help="N > 1: batch = one frame per GPU (config 5, weak); tiled = ONE frame cut into row bands, "
                          "one band per GPU, halo rows exchanged over RCCL (config 4, strong)")
@@ -67,7 +67,9 @@ def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light"):
         filmic = fm.default_data()
     coeffs = params.unbounded_coeffs(lut)
     if which == "denoise":
-        return pipe.denoise_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, filmic=filmic)
+        # BASELINE.json config 3: + denoise (profiled wavelets) + non-local means + diffuse or sharpen
+        return pipe.denoise_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, filmic=filmic, with_nlmeans=True,
+                                       with_bilat=False)
     return pipe.light_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, with_filmic=with_filmic,
                                  filmic=filmic)
 
@@ -114,6 +116,13 @@ def cpu_baseline(size_name, with_filmic, which="light"):
         for n in nodes:
             if n.op == "export_u16":
                 getattr(l, prefix + "export_convert_u16")(w, h, ck.ptr(src), ck.ptr(out16))
+                continue
+            if n.op in ("rgb_to_lab", "lab_to_rgb"):
+                dst = rgb[ri]
+                ri ^= 1
+                rc = ck.call(l, prefix + n.op, n.piece, n.data, src, dst)
+                assert rc == 0, n.op
+                src = dst
                 continue
             if n.op in ("rawprepare", "temperature", "highlights"):
                 dst = cfa[ci]
@@ -249,7 +258,8 @@ def main():
         tag_bpp = {"rawprepare_1f": 6, "temperature_1f": 8, "highlights_clip_1f": 8, "rcd_tiles": 20,
                    "ppg_full": 20, "exposure": 32, "colorin": 32, "channelmixerrgb": 32, "filmicrgb": 32,
                    "colorout": 32, "export_u16": 24, "dn_precondition": 32, "dn_decompose": 48, "dn_synthesize": 48,
-                   "dn_finish": 48, "diffuse_decompose": 48, "diffuse_pde": 48}
+                   "dn_finish": 48, "diffuse_decompose": 48, "diffuse_pde": 48, "nlm_chunks": 32, "rgb_to_lab": 32,
+                   "lab_to_rgb": 32}
         if not args.no_fusion:
             # a fused group is credited with the algorithmic bytes of the modules it executes
             tag_bpp["raw_chain"] = sum(sum(pipe.MODULE_BPP[n.op]) for n in nodes if n.op in ("rawprepare", "temperature", "highlights"))
