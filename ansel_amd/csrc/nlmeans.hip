@@ -317,6 +317,425 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks(const float4 *__restri
   }
 }
 
+// ---- the pipelined kernel ------------------------------------------------------------------------
+// Same four steps, software-pipelined over the patch offsets so that the two recurrences -- which
+// only have one column / one row per lane to offer -- run beside the two fully parallel steps instead
+// of between them.  Waves 0-3 are the "serial" group, waves 4-15 the "parallel" group; two column-sum
+// tables alternate, and one iteration i of the loop is
+//   phase 1   parallel: C(i-1) on table (i-1)&1          serial (waves 0-1): A2(i) on table i&1
+//   phase 2   parallel: A1(i+1) into table (i+1)&1       serial (waves 2-3): B(i) in place on table i&1
+//                                                        serial (waves 0-1): row 0 of A1(i+1)
+// with one workgroup barrier after each phase.  Differences in bookkeeping (never in arithmetic):
+//   * A1 stores SIGNED terms -- a row leaving the patch is stored negated, a row that neither enters
+//     nor leaves as +0 -- so the recurrence A2 is a bare chain of additions (x - y == x + (-y), and a
+//     column sum is never -0, so adding +0 is the identity);
+//   * a term's entering and leaving rows are masked to 0 instead of branching on the row class
+//     ((a - 0) * n == a * n and (0 - c) * n == -(c * n) exactly);
+//   * B writes the row sums in place, distortion of frame column c into the slot of column c - P - 1,
+//     which it has just read for the last time.
+// The staged window uses a compile-time pitch and keeps the three colour planes of a row next to each
+// other, so that the twelve LDS reads of a term are immediate offsets from four addresses.
+#define NLP_SERIAL 256                      // threads of the serial group
+#define NLP_PAR (NLM_THREADS - NLP_SERIAL)  // threads of the parallel group
+#define NLP_PX 7                            // accumulators per parallel thread: ceil(72 * 69 / 768)
+#define NLP_WP 96                           // window pitch (floats); a window row is 3 planes x NLP_WP
+#define NLP_TP 81                           // table pitch (floats), odd: B walks the table one row per lane
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct nlm_geom
+{
+  int srow, scol, row_min, row_max, row_top, row_bot, col_min, col_max, pc_min, pc_max, nrows;
+};
+
+__device__ __forceinline__ nlm_geom geom_of(const int2 sh, const int top, const int bot, const int left, const int right,
+                                            const int P, const int W, const int H)
+{
+  nlm_geom g;
+  g.srow = sh.x;
+  g.scol = sh.y;
+  g.row_min = imax(top, imax(0, -g.srow));
+  g.row_max = imin(bot, H - imax(0, g.srow));
+  g.nrows = g.row_max - g.row_min;
+  g.row_top = imax(g.row_min, imax(P, P - g.srow));
+  g.row_bot = imin(g.row_max, H - 1 - imax(P, P + g.srow));
+  g.col_min = imax(left, -g.scol);
+  g.col_max = imin(right, W - g.scol);
+  g.pc_min = left - imin(P, imin(left, left + g.scol));
+  g.pc_max = right + imin(P, imin(W - right, W - (right + g.scol)));
+  return g;
+}
+
+__global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                                    const nlm_args a, const int2 *__restrict__ patches)
+{
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  const int cy = blockIdx.x / a.nchx, cx = blockIdx.x - cy * a.nchx;
+  const int top = cy * a.chk_h, left = cx * a.chk_w;
+  const int bot = imin(top + a.chk_h, a.H), right = imin(left + a.chk_w, a.W);
+  const int ch = bot - top, cw = right - left;
+  const int P = a.radius, W = a.W, H = a.H;
+  const int csw = a.chk_w + 2 * P + 1; // table columns: frame columns left - P - 1 .. left + chk_w + P - 1
+  const int cs0 = left - P - 1;
+  constexpr int pitch = NLP_TP;
+  const int tabsz = a.chk_h * pitch;
+  float *const win = lds + 2 * tabsz + 16 * pitch + 64; // 16 spare rows: the batched recurrences read whole batches
+  const int r0 = top - a.reach, c0 = left - a.reach;
+  const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
+  const int n = a.npatch;
+
+  {
+    const int wh = a.chk_h + 2 * a.reach;
+    for(int i = tid; i < wh * NLP_WP; i += NLM_THREADS)
+    {
+      const int wy = i / NLP_WP, wx = i - wy * NLP_WP;
+      const int r = r0 + wy, c = c0 + wx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if(r >= 0 && r < H && c >= 0 && c < W) v = in[(long)r * W + c];
+      float *const w = win + wy * 3 * NLP_WP + wx;
+      w[0] = v.x;
+      w[NLP_WP] = v.y;
+      w[2 * NLP_WP] = v.z;
+    }
+  }
+
+  const bool par = tid >= NLP_SERIAL;
+  if(!par) __builtin_amdgcn_s_setprio(3); // the recurrences are latency chains: let them issue ahead of the parallel waves
+  const int u = tid - NLP_SERIAL;
+  // parallel group: the pixels this thread accumulates for the whole chunk (prc = chunk row << 16 | chunk
+  // column, wbase = the pixel's place in the window) ...
+  float4 acc[NLP_PX];
+  int prc[NLP_PX];
+#pragma unroll
+  for(int k = 0; k < NLP_PX; k++)
+  {
+    acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int idx = u + NLP_PAR * k;
+    const int r = idx / cw, c = idx - r * cw;
+    const bool ok = par && idx < ch * cw;
+    prc[k] = ok ? ((r << 16) | c) : -1;
+  }
+  const int wbase0 = ((top - r0) * 3) * NLP_WP + (left - c0); // window offset of the chunk's first pixel
+  // ... and the A1 terms it computes for every patch offset: term j is table row t + 1, table column ci
+  // (columns 1 .. csw-1; column 0, frame column left - P - 1, is outside every patch and stays 0), packed
+  // as window offset of (row t, column ci) | table offset << 16
+  int a1[NLP_PX];
+#pragma unroll
+  for(int k = 0; k < NLP_PX; k++)
+  {
+    const int idx = u + NLP_PAR * k;
+    const int t = idx / (csw - 1), ci = 1 + idx - t * (csw - 1);
+    a1[k] = (t * 3 * NLP_WP + ci) | (((t + 1) * pitch + ci) << 16);
+  }
+  __syncthreads();
+
+  // ---- A1, rows 1.. of the table: signed terms of the column-sum recurrence (:437-488), parallel group
+  auto A1 = [&](const nlm_geom &g, float *const T) {
+    const int dS = g.srow * 3 * NLP_WP + g.scol;
+    const int dT = (2 * P + 1) * 3 * NLP_WP;
+    // window offset of (row_min + 1 + P, table column 0)
+    const float *const wb = win + ((g.row_min + 1 + P - r0) * 3) * NLP_WP + (cs0 - c0);
+    const int tend = g.nrows * pitch; // terms of table rows 1 .. nrows - 1
+    // every row both enters and leaves, every column is inside the patch range: no masks
+    const bool plain = g.row_top <= g.row_min && g.row_bot >= g.row_max - 1 && g.pc_min == left - P
+                       && g.pc_max == left + a.chk_w + P;
+    const f2 n01 = { n0, n1 };
+    if(u < g.nrows - 1) T[(u + 1) * pitch] = 0.0f; // column 0 (B leaves row sums in it)
+    if(plain)
+    {
+#pragma unroll
+      for(int k = 0; k < NLP_PX; k++)
+      {
+        if(k == 4) asm volatile("" ::: "memory"); // keeps the register footprint of the hoisted LDS reads at four terms
+        int pk = a1[k];
+        asm volatile("" : "+v"(pk)); // unpack here, every time: hoisted out of the offset loop the fields cost 14 registers
+        const int ti = (unsigned)pk >> 16;
+        if(ti >= tend) continue;
+        const float *const pb = wb + (pk & 0xffff);
+        const float *const pt = pb - dT;
+        const f2 b = { pb[0], pb[NLP_WP] }, bs = { pb[dS], pb[dS + NLP_WP] };
+        const f2 l = { pt[0], pt[NLP_WP] }, ls = { pt[dS], pt[dS + NLP_WP] };
+        const f2 z = { pb[2 * NLP_WP], pt[2 * NLP_WP] }, zs = { pb[dS + 2 * NLP_WP], pt[dS + 2 * NLP_WP] };
+        f2 e = b - bs, q = l - ls, w = z - zs;
+        e = e * e;
+        q = q * q;
+        w = w * w;
+        const f2 d = (e - q) * n01;
+        T[ti] = d.x + d.y + (w.x - w.y) * n2;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for(int k = 0; k < NLP_PX; k++)
+      {
+        if(k == 4) asm volatile("" ::: "memory");
+        int pk = a1[k];
+        asm volatile("" : "+v"(pk));
+        const int ti = (unsigned)pk >> 16;
+        if(ti >= tend) continue;
+        const int lw = pk & 0xffff;
+        const int t = (int)(((unsigned)lw * 58255u) >> 24); // lw / (3 * NLP_WP), exact below 2^16
+        const int row = g.row_min + t, c = cs0 + (lw - t * 3 * NLP_WP);
+        const float *const pb = wb + lw;
+        const float *const pt = pb - dT;
+        const float ax = pb[0] - pb[dS], ay = pb[NLP_WP] - pb[dS + NLP_WP], az = pb[2 * NLP_WP] - pb[dS + 2 * NLP_WP];
+        const float tx = pt[0] - pt[dS], ty = pt[NLP_WP] - pt[dS + NLP_WP], tz = pt[2 * NLP_WP] - pt[dS + 2 * NLP_WP];
+        const bool colok = c >= g.pc_min && c < g.pc_max;
+        const bool enter = colok && row < g.row_bot, leave = colok && row >= g.row_top;
+        const float ex = enter ? ax * ax : 0.f, ey = enter ? ay * ay : 0.f, ez = enter ? az * az : 0.f;
+        const float lx = leave ? tx * tx : 0.f, ly = leave ? ty * ty : 0.f, lz = leave ? tz * tz : 0.f;
+        T[ti] = (ex - lx) * n0 + (ey - ly) * n1 + (ez - lz) * n2;
+      }
+    }
+  };
+  // ---- row 0 of the table: the from-scratch sums at row_min (init_column_sums(), :208-262), threads 0..csw-1
+  auto A1_first = [&](const nlm_geom &g, float *const T) {
+    const int c = cs0 + tid;
+    float v = 0.0f;
+    if(c >= g.pc_min && c < g.pc_max)
+    {
+      const int row = g.row_min;
+      const int rmin = row - imin(P, imin(row, row + g.srow));
+      const int rmax = row + imin(P, imin(H - 1 - row, H - 1 - (row + g.srow)));
+      const int dS = g.srow * 3 * NLP_WP + g.scol;
+      const float *pr = win + ((rmin - r0) * 3) * NLP_WP + (c - c0);
+      for(int r = rmin; r <= rmax; r++, pr += 3 * NLP_WP)
+      {
+        const float dx = pr[0] - pr[dS], dy = pr[NLP_WP] - pr[dS + NLP_WP], dz = pr[2 * NLP_WP] - pr[dS + 2 * NLP_WP];
+        v += dx * dx * n0 + dy * dy * n1 + dz * dz * n2;
+      }
+    }
+    T[tid] = v;
+  };
+  // ---- A2: the recurrence, one thread per table column, 16 rows of LDS traffic in flight and ONE dependent
+  //      addition per row.  A lone wave issues an instruction every four to five cycles, so the instruction
+  //      count of this loop IS the length of phase 1: read, add, write per row, addresses as immediates
+  auto A2 = [&](const nlm_geom &g, float *const T) {
+    float v = T[tid];
+    int t0 = 1;
+    for(; t0 + 16 <= g.nrows; t0 += 16)
+    {
+      float term[16];
+      float *const col = T + t0 * pitch + tid;
+#pragma unroll
+      for(int k = 0; k < 16; k++) term[k] = col[k * pitch];
+      term[0] = v + term[0];
+#pragma unroll
+      for(int k = 1; k < 16; k++) term[k] = term[k - 1] + term[k];
+      v = term[15];
+#pragma unroll
+      for(int k = 0; k < 16; k++) col[k * pitch] = term[k];
+    }
+    if(t0 < g.nrows)
+    {
+      float term[16];
+      float *const col = T + t0 * pitch + tid;
+      const int live = g.nrows - t0;
+#pragma unroll
+      for(int k = 0; k < 16; k++) term[k] = col[k * pitch];
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+      {
+        const float next = v + term[k];
+        v = k < live ? next : v;
+        term[k] = v;
+      }
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+        if(k < live) col[k * pitch] = term[k];
+    }
+  };
+  // ---- B: sliding row sum (:405-415), one thread per table row, in place; same shape
+  auto B = [&](const nlm_geom &g, float *const T, const int rr) {
+    float *const rowp = T + rr * pitch - cs0; // indexable by frame column
+    float distortion = 0.0f;
+    for(int i = g.col_min - P; i < imin(g.col_min + P, g.col_max); i++) distortion += rowp[i];
+    int cb = g.col_min;
+    for(; cb + 16 <= g.col_max; cb += 16)
+    {
+      float hi[16], lo[16];
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+      {
+        hi[k] = rowp[cb + k + P];
+        lo[k] = rowp[cb + k - P - 1];
+      }
+#pragma unroll
+      for(int k = 0; k < 16; k++) hi[k] = hi[k] - lo[k];
+      hi[0] = distortion + hi[0];
+#pragma unroll
+      for(int k = 1; k < 16; k++) hi[k] = hi[k - 1] + hi[k];
+      distortion = hi[15];
+#pragma unroll
+      for(int k = 0; k < 16; k++) rowp[cb + k - P - 1] = hi[k];
+    }
+    if(cb < g.col_max)
+    {
+      float hi[16], lo[16];
+      const int live = g.col_max - cb;
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+      {
+        hi[k] = rowp[cb + k + P];
+        lo[k] = rowp[cb + k - P - 1];
+      }
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+      {
+        const float next = distortion + (hi[k] - lo[k]);
+        distortion = k < live ? next : distortion;
+        hi[k] = distortion;
+      }
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+        if(k < live) rowp[cb + k - P - 1] = hi[k];
+    }
+  };
+  // ---- C: weights and accumulation (:416-436), parallel group; all LDS reads first, then the arithmetic
+  auto C = [&](const nlm_geom &g, const float *const T) {
+    const int dS = g.srow * 3 * NLP_WP + g.scol;
+    const int trow = (g.row_min - top) * pitch; // table row 0 is chunk row row_min - top
+    const bool whole = g.row_min == top && g.row_max == bot && g.col_min == left && g.col_max == right;
+    float dist[NLP_PX], qx[NLP_PX], qy[NLP_PX], qz[NLP_PX];
+    bool ok[NLP_PX];
+#pragma unroll
+    for(int k = 0; k < NLP_PX; k++)
+    {
+      int pk = prc[k];
+      asm volatile("" : "+v"(pk));
+      const int r = pk >> 16, c = pk & 0xffff;
+      ok[k] = pk >= 0;
+      if(!whole)
+      {
+        const int row = top + r, col = left + c;
+        ok[k] = ok[k] && row >= g.row_min && row < g.row_max && col >= g.col_min && col < g.col_max;
+      }
+      const int ti = ok[k] ? __mul24(r, pitch) + c - trow : 0;
+      dist[k] = T[ti];
+      const float *const pq = win + (wbase0 + dS) + __mul24(r, 3 * NLP_WP) + c;
+      qx[k] = pq[0];
+      qy[k] = pq[NLP_WP];
+      qz[k] = pq[2 * NLP_WP];
+    }
+    if(a.center_weight < 0)
+    {
+#pragma unroll
+      for(int k = 0; k < NLP_PX; k++)
+      {
+        const float w = mexp2(dist[k] * a.sharpness);
+        const float sx = acc[k].x + qx[k] * w, sy = acc[k].y + qy[k] * w, sz = acc[k].z + qz[k] * w, sw = acc[k].w + 1.0f * w;
+        acc[k].x = ok[k] ? sx : acc[k].x;
+        acc[k].y = ok[k] ? sy : acc[k].y;
+        acc[k].z = ok[k] ? sz : acc[k].z;
+        acc[k].w = ok[k] ? sw : acc[k].w;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for(int k = 0; k < NLP_PX; k++)
+      {
+        int pk = prc[k];
+        asm volatile("" : "+v"(pk));
+        const float *const pp = win + wbase0 + __mul24(pk >> 16, 3 * NLP_WP) + (pk & 0xffff);
+        const float dx = pp[0] - qx[k], dy = pp[NLP_WP] - qy[k], dz = pp[2 * NLP_WP] - qz[k];
+        const float dis = (dist[k] + (dx * dx * a.cpn + dy * dy * a.cpn + dz * dz * a.cpn)) / (1.0f + a.center_weight);
+        const float w = mexp2(fmaxf(0.0f, dis * a.sharpness - 2.0f));
+        const float sx = acc[k].x + qx[k] * w, sy = acc[k].y + qy[k] * w, sz = acc[k].z + qz[k] * w, sw = acc[k].w + 1.0f * w;
+        acc[k].x = ok[k] ? sx : acc[k].x;
+        acc[k].y = ok[k] ? sy : acc[k].y;
+        acc[k].z = ok[k] ? sz : acc[k].z;
+        acc[k].w = ok[k] ? sw : acc[k].w;
+      }
+    }
+  };
+
+  // the patch shifts of offsets i - 1, i, i + 1 stay in scalar registers and the one for i + 2 is fetched an
+  // iteration ahead: a scalar load at the top of every phase would sit on every wave's critical path
+  auto geom = [&](const int2 sh) { return geom_of(sh, top, bot, left, right, P, W, H); };
+  int2 sh_prev = make_int2(0, 0), sh_cur = patches[0], sh_next = patches[n > 1 ? 1 : 0];
+  {
+    const nlm_geom g = geom(sh_cur);
+    if(g.nrows > 0)
+    {
+      if(par) A1(g, lds);
+      else if(tid < csw) A1_first(g, lds);
+    }
+  }
+  __syncthreads();
+  for(int i = 0; i <= n; i++)
+  {
+    const int2 sh_next2 = patches[i + 2 < n ? i + 2 : n - 1];
+    float *const Ti = lds + (i & 1) * tabsz;       // offset i, and i + 2
+    float *const To = lds + ((i + 1) & 1) * tabsz; // offsets i - 1 and i + 1
+    // phase 1
+    if(par)
+    {
+      if(i >= 1)
+      {
+        const nlm_geom g = geom(sh_prev);
+        if(g.nrows > 0) C(g, To);
+      }
+    }
+    else if(tid < csw && i < n)
+    {
+      const nlm_geom g = geom(sh_cur);
+      if(g.nrows > 0) A2(g, Ti);
+    }
+    __syncthreads();
+    // phase 2
+    if(par)
+    {
+      if(i + 1 < n)
+      {
+        const nlm_geom g = geom(sh_next);
+        if(g.nrows > 0) A1(g, To);
+      }
+    }
+    else if(tid < 128)
+    {
+      if(tid < csw && i + 1 < n)
+      {
+        const nlm_geom g = geom(sh_next);
+        if(g.nrows > 0) A1_first(g, To);
+      }
+    }
+    else if(i < n)
+    {
+      const nlm_geom g = geom(sh_cur);
+      if(tid - 128 < g.nrows) B(g, Ti, tid - 128);
+    }
+    __syncthreads();
+    sh_prev = sh_cur;
+    sh_cur = sh_next;
+    sh_next = sh_next2;
+  }
+
+  // ---- normalise, blend (:490-521)
+#pragma unroll
+  for(int k = 0; k < NLP_PX; k++)
+  {
+    if(prc[k] < 0) continue;
+    const int row = top + (prc[k] >> 16), col = left + (prc[k] & 0xffff);
+    const long o = (long)row * W + col;
+    const float4 s = acc[k];
+    float4 r;
+    if(a.skip_blend)
+      r = make_float4(s.x / s.w, s.y / s.w, s.z / s.w, s.w / s.w);
+    else
+    {
+      const float4 ip = in[o];
+      r.x = (ip.x * (1.0f - a.luma)) + (s.x / s.w * a.luma);
+      r.y = (ip.y * (1.0f - a.chroma)) + (s.y / s.w * a.chroma);
+      r.z = (ip.z * (1.0f - a.chroma)) + (s.z / s.w * a.chroma);
+      r.w = (ip.w * 0.0f) + (s.w / s.w * 1.0f);
+    }
+    out[o] = r;
+  }
+}
+
 int sgn(const int v) { return (v > 0) - (v < 0); }
 
 // scatter(), nlmeans_core.c:95-105
@@ -414,14 +833,19 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     set_last_error("nlmeans: chunk %d x %d exceeds the kernel's accumulator budget", a.chk_w, a.chk_h);
     return DT_HIP_DEFAULT_ERROR;
   }
-  const size_t table_bytes = ((size_t)(a.chk_h + 16) * a.cs_pitch + (size_t)a.chk_h * a.wt_pitch + 64) * sizeof(float);
   // the window a chunk's patches can touch: init_column_sums() reads radius rows/columns beyond the
   // chunk, the recurrence one more row below, and everything once more shifted by the patch offset
   a.reach = a.radius + 1 + max_shift;
   a.win_pitch = (a.chk_w + 2 * a.reach) | 1;
+  // the pipelined kernel: two tables + the planar window with its fixed pitch
+  const size_t pipe_bytes = ((size_t)2 * a.chk_h * NLP_TP + 16 * NLP_TP + 64
+                             + (size_t)(a.chk_h + 2 * a.reach) * 3 * NLP_WP) * sizeof(float);
+  const bool pipelined = pipe_bytes <= 160 * 1024 && a.chk_w + 2 * a.reach <= NLP_WP && a.chk_h <= NLP_SERIAL / 2
+                         && a.chk_w + 2 * a.radius + 1 <= NLP_TP && a.chk_w * a.chk_h <= NLP_PAR * NLP_PX;
+  const size_t table_bytes = ((size_t)(a.chk_h + 16) * a.cs_pitch + (size_t)a.chk_h * a.wt_pitch + 64) * sizeof(float);
   const size_t window_bytes = (size_t)3 * (a.chk_h + 2 * a.reach) * a.win_pitch * sizeof(float);
   const bool staged = table_bytes + window_bytes <= 160 * 1024;
-  const size_t lds_bytes = table_bytes + (staged ? window_bytes : 0);
+  const size_t lds_bytes = pipelined ? pipe_bytes : table_bytes + (staged ? window_bytes : 0);
   hipStream_t s = stream_of(devid);
   int2 *dev_patches = (int2 *)dt_hip_alloc_device_buffer(devid, patches.size() * sizeof(int2));
   if(!dev_patches) return DT_HIP_SYSMEM_ALLOCATION;
@@ -431,15 +855,19 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     dt_hip_release_mem_object(dev_patches);
     return DT_HIP_DEFAULT_ERROR;
   }
+  const void *const fn = pipelined ? (const void *)nlm_chunks_pipelined
+                                   : (staged ? (const void *)nlm_chunks<true> : (const void *)nlm_chunks<false>);
   if(lds_bytes > 64 * 1024)
-    ANSEL_HIP_CHECK(hipFuncSetAttribute(staged ? (const void *)nlm_chunks<true> : (const void *)nlm_chunks<false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    ANSEL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   {
     launch_scope ls(devid, "nlm_chunks");
-    if(staged)
-      nlm_chunks<true><<<(unsigned)(a.nchx * nchy), NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
+    const unsigned grid = (unsigned)(a.nchx * nchy);
+    if(pipelined)
+      nlm_chunks_pipelined<<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
+    else if(staged)
+      nlm_chunks<true><<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
     else
-      nlm_chunks<false><<<(unsigned)(a.nchx * nchy), NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
+      nlm_chunks<false><<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
   }
   dt_hip_release_mem_object(dev_patches);
   return check_launch("nlm_chunks");
