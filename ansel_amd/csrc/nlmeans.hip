@@ -26,6 +26,7 @@
 #include <math.h>
 #include <algorithm>
 #include <vector>
+#include <type_traits>
 
 using namespace ansel;
 
@@ -430,288 +431,314 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4
   }
   __syncthreads();
 
-  // ---- A1, rows 1.. of the table: signed terms of the column-sum recurrence (:437-488), parallel group
-  auto A1 = [&](const nlm_geom &g, float *const T) {
-    const int dS = g.srow * 3 * NLP_WP + g.scol;
-    const int dT = (2 * P + 1) * 3 * NLP_WP;
-    // window offset of (row_min + 1 + P, table column 0)
-    const float *const wb = win + ((g.row_min + 1 + P - r0) * 3) * NLP_WP + (cs0 - c0);
-    const int tend = g.nrows * pitch; // terms of table rows 1 .. nrows - 1
-    // every row both enters and leaves, every column is inside the patch range: no masks
-    const bool plain = g.row_top <= g.row_min && g.row_bot >= g.row_max - 1 && g.pc_min == left - P
-                       && g.pc_max == left + a.chk_w + P;
-    const f2 n01 = { n0, n1 };
-    if(u < g.nrows - 1) T[(u + 1) * pitch] = 0.0f; // column 0 (B leaves row sums in it)
-    if(plain)
-    {
-#pragma unroll
-      for(int k = 0; k < NLP_PX; k++)
-      {
-        if(k == 4) asm volatile("" ::: "memory"); // keeps the register footprint of the hoisted LDS reads at four terms
-        int pk = a1[k];
-        asm volatile("" : "+v"(pk)); // unpack here, every time: hoisted out of the offset loop the fields cost 14 registers
-        const int ti = (unsigned)pk >> 16;
-        if(ti >= tend) continue;
-        const float *const pb = wb + (pk & 0xffff);
-        const float *const pt = pb - dT;
-        const f2 b = { pb[0], pb[NLP_WP] }, bs = { pb[dS], pb[dS + NLP_WP] };
-        const f2 l = { pt[0], pt[NLP_WP] }, ls = { pt[dS], pt[dS + NLP_WP] };
-        const f2 z = { pb[2 * NLP_WP], pt[2 * NLP_WP] }, zs = { pb[dS + 2 * NLP_WP], pt[dS + 2 * NLP_WP] };
-        f2 e = b - bs, q = l - ls, w = z - zs;
-        e = e * e;
-        q = q * q;
-        w = w * w;
-        const f2 d = (e - q) * n01;
-        T[ti] = d.x + d.y + (w.x - w.y) * n2;
-      }
-    }
-    else
-    {
-#pragma unroll
-      for(int k = 0; k < NLP_PX; k++)
-      {
-        if(k == 4) asm volatile("" ::: "memory");
-        int pk = a1[k];
-        asm volatile("" : "+v"(pk));
-        const int ti = (unsigned)pk >> 16;
-        if(ti >= tend) continue;
-        const int lw = pk & 0xffff;
-        const int t = (int)(((unsigned)lw * 58255u) >> 24); // lw / (3 * NLP_WP), exact below 2^16
-        const int row = g.row_min + t, c = cs0 + (lw - t * 3 * NLP_WP);
-        const float *const pb = wb + lw;
-        const float *const pt = pb - dT;
-        const float ax = pb[0] - pb[dS], ay = pb[NLP_WP] - pb[dS + NLP_WP], az = pb[2 * NLP_WP] - pb[dS + 2 * NLP_WP];
-        const float tx = pt[0] - pt[dS], ty = pt[NLP_WP] - pt[dS + NLP_WP], tz = pt[2 * NLP_WP] - pt[dS + 2 * NLP_WP];
-        const bool colok = c >= g.pc_min && c < g.pc_max;
-        const bool enter = colok && row < g.row_bot, leave = colok && row >= g.row_top;
-        const float ex = enter ? ax * ax : 0.f, ey = enter ? ay * ay : 0.f, ez = enter ? az * az : 0.f;
-        const float lx = leave ? tx * tx : 0.f, ly = leave ? ty * ty : 0.f, lz = leave ? tz * tz : 0.f;
-        T[ti] = (ex - lx) * n0 + (ey - ly) * n1 + (ez - lz) * n2;
-      }
-    }
-  };
-  // ---- row 0 of the table: the from-scratch sums at row_min (init_column_sums(), :208-262), threads 0..csw-1
-  auto A1_first = [&](const nlm_geom &g, float *const T) {
-    const int c = cs0 + tid;
-    float v = 0.0f;
-    if(c >= g.pc_min && c < g.pc_max)
-    {
-      const int row = g.row_min;
-      const int rmin = row - imin(P, imin(row, row + g.srow));
-      const int rmax = row + imin(P, imin(H - 1 - row, H - 1 - (row + g.srow)));
+  // Everything below runs once per patch offset.  For a chunk that no patch can carry over the frame border
+  // (all but the outermost ring of chunks) the geometry of an offset is the chunk itself, so that case is
+  // compiled separately: no per-offset scalar arithmetic, no masks, no range tests.
+  auto run = [&](auto interior_tag) {
+    constexpr bool INTERIOR = decltype(interior_tag)::value;
+    // ---- A1, rows 1.. of the table: signed terms of the column-sum recurrence (:437-488), parallel group
+    auto A1 = [&](const nlm_geom &g, float *const T) {
       const int dS = g.srow * 3 * NLP_WP + g.scol;
-      const float *pr = win + ((rmin - r0) * 3) * NLP_WP + (c - c0);
-      for(int r = rmin; r <= rmax; r++, pr += 3 * NLP_WP)
+      const int dT = (2 * P + 1) * 3 * NLP_WP;
+      // window offset of (row_min + 1 + P, table column 0)
+      const float *const wb = win + ((g.row_min + 1 + P - r0) * 3) * NLP_WP + (cs0 - c0);
+      const int tend = g.nrows * pitch; // terms of table rows 1 .. nrows - 1
+      // every row both enters and leaves, every column is inside the patch range: no masks
+      const bool plain = INTERIOR || (g.row_top <= g.row_min && g.row_bot >= g.row_max - 1 && g.pc_min == left - P
+                         && g.pc_max == left + a.chk_w + P);
+      const f2 n01 = { n0, n1 };
+      if(u < g.nrows - 1) T[(u + 1) * pitch] = 0.0f; // column 0 (B leaves row sums in it)
+      if(plain)
       {
-        const float dx = pr[0] - pr[dS], dy = pr[NLP_WP] - pr[dS + NLP_WP], dz = pr[2 * NLP_WP] - pr[dS + 2 * NLP_WP];
-        v += dx * dx * n0 + dy * dy * n1 + dz * dz * n2;
+  #pragma unroll
+        for(int k = 0; k < NLP_PX; k++)
+        {
+          if(k == 4) asm volatile("" ::: "memory"); // keeps the register footprint of the hoisted LDS reads at four terms
+          int pk = a1[k];
+          asm volatile("" : "+v"(pk)); // unpack here, every time: hoisted out of the offset loop the fields cost 14 registers
+          const int ti = (unsigned)pk >> 16;
+          if(ti >= tend) continue;
+          const float *const pb = wb + (pk & 0xffff);
+          const float *const pt = pb - dT;
+          const f2 b = { pb[0], pb[NLP_WP] }, bs = { pb[dS], pb[dS + NLP_WP] };
+          const f2 l = { pt[0], pt[NLP_WP] }, ls = { pt[dS], pt[dS + NLP_WP] };
+          const f2 z = { pb[2 * NLP_WP], pt[2 * NLP_WP] }, zs = { pb[dS + 2 * NLP_WP], pt[dS + 2 * NLP_WP] };
+          f2 e = b - bs, q = l - ls, w = z - zs;
+          e = e * e;
+          q = q * q;
+          w = w * w;
+          const f2 d = (e - q) * n01;
+          T[ti] = d.x + d.y + (w.x - w.y) * n2;
+        }
       }
-    }
-    T[tid] = v;
-  };
-  // ---- A2: the recurrence, one thread per table column, 16 rows of LDS traffic in flight and ONE dependent
-  //      addition per row.  A lone wave issues an instruction every four to five cycles, so the instruction
-  //      count of this loop IS the length of phase 1: read, add, write per row, addresses as immediates
-  auto A2 = [&](const nlm_geom &g, float *const T) {
-    float v = T[tid];
-    int t0 = 1;
-    for(; t0 + 16 <= g.nrows; t0 += 16)
-    {
-      float term[16];
-      float *const col = T + t0 * pitch + tid;
-#pragma unroll
-      for(int k = 0; k < 16; k++) term[k] = col[k * pitch];
-      term[0] = v + term[0];
-#pragma unroll
-      for(int k = 1; k < 16; k++) term[k] = term[k - 1] + term[k];
-      v = term[15];
-#pragma unroll
-      for(int k = 0; k < 16; k++) col[k * pitch] = term[k];
-    }
-    if(t0 < g.nrows)
-    {
-      float term[16];
-      float *const col = T + t0 * pitch + tid;
-      const int live = g.nrows - t0;
-#pragma unroll
-      for(int k = 0; k < 16; k++) term[k] = col[k * pitch];
-#pragma unroll
-      for(int k = 0; k < 16; k++)
+      else
       {
-        const float next = v + term[k];
-        v = k < live ? next : v;
-        term[k] = v;
+  #pragma unroll
+        for(int k = 0; k < NLP_PX; k++)
+        {
+          if(k == 4) asm volatile("" ::: "memory");
+          int pk = a1[k];
+          asm volatile("" : "+v"(pk));
+          const int ti = (unsigned)pk >> 16;
+          if(ti >= tend) continue;
+          const int lw = pk & 0xffff;
+          const int t = (int)(((unsigned)lw * 58255u) >> 24); // lw / (3 * NLP_WP), exact below 2^16
+          const int row = g.row_min + t, c = cs0 + (lw - t * 3 * NLP_WP);
+          const float *const pb = wb + lw;
+          const float *const pt = pb - dT;
+          const float ax = pb[0] - pb[dS], ay = pb[NLP_WP] - pb[dS + NLP_WP], az = pb[2 * NLP_WP] - pb[dS + 2 * NLP_WP];
+          const float tx = pt[0] - pt[dS], ty = pt[NLP_WP] - pt[dS + NLP_WP], tz = pt[2 * NLP_WP] - pt[dS + 2 * NLP_WP];
+          const bool colok = c >= g.pc_min && c < g.pc_max;
+          const bool enter = colok && row < g.row_bot, leave = colok && row >= g.row_top;
+          const float ex = enter ? ax * ax : 0.f, ey = enter ? ay * ay : 0.f, ez = enter ? az * az : 0.f;
+          const float lx = leave ? tx * tx : 0.f, ly = leave ? ty * ty : 0.f, lz = leave ? tz * tz : 0.f;
+          T[ti] = (ex - lx) * n0 + (ey - ly) * n1 + (ez - lz) * n2;
+        }
       }
-#pragma unroll
-      for(int k = 0; k < 16; k++)
-        if(k < live) col[k * pitch] = term[k];
-    }
-  };
-  // ---- B: sliding row sum (:405-415), one thread per table row, in place; same shape
-  auto B = [&](const nlm_geom &g, float *const T, const int rr) {
-    float *const rowp = T + rr * pitch - cs0; // indexable by frame column
-    float distortion = 0.0f;
-    for(int i = g.col_min - P; i < imin(g.col_min + P, g.col_max); i++) distortion += rowp[i];
-    int cb = g.col_min;
-    for(; cb + 16 <= g.col_max; cb += 16)
-    {
-      float hi[16], lo[16];
-#pragma unroll
-      for(int k = 0; k < 16; k++)
+    };
+    // ---- row 0 of the table: the from-scratch sums at row_min (init_column_sums(), :208-262), threads 0..csw-1
+    auto A1_first = [&](const nlm_geom &g, float *const T) {
+      const int c = cs0 + tid;
+      float v = 0.0f;
+      if(c >= g.pc_min && c < g.pc_max)
       {
-        hi[k] = rowp[cb + k + P];
-        lo[k] = rowp[cb + k - P - 1];
+        const int row = g.row_min;
+        const int rmin = row - imin(P, imin(row, row + g.srow));
+        const int rmax = row + imin(P, imin(H - 1 - row, H - 1 - (row + g.srow)));
+        const int dS = g.srow * 3 * NLP_WP + g.scol;
+        const float *pr = win + ((rmin - r0) * 3) * NLP_WP + (c - c0);
+        for(int r = rmin; r <= rmax; r++, pr += 3 * NLP_WP)
+        {
+          const float dx = pr[0] - pr[dS], dy = pr[NLP_WP] - pr[dS + NLP_WP], dz = pr[2 * NLP_WP] - pr[dS + 2 * NLP_WP];
+          v += dx * dx * n0 + dy * dy * n1 + dz * dz * n2;
+        }
       }
-#pragma unroll
-      for(int k = 0; k < 16; k++) hi[k] = hi[k] - lo[k];
-      hi[0] = distortion + hi[0];
-#pragma unroll
-      for(int k = 1; k < 16; k++) hi[k] = hi[k - 1] + hi[k];
-      distortion = hi[15];
-#pragma unroll
-      for(int k = 0; k < 16; k++) rowp[cb + k - P - 1] = hi[k];
-    }
-    if(cb < g.col_max)
-    {
-      float hi[16], lo[16];
-      const int live = g.col_max - cb;
-#pragma unroll
-      for(int k = 0; k < 16; k++)
+      T[tid] = v;
+    };
+    // ---- A2: the recurrence, one thread per table column, 16 rows of LDS traffic in flight and ONE dependent
+    //      addition per row.  A lone wave issues an instruction every four to five cycles, so the instruction
+    //      count of this loop IS the length of phase 1: read, add, write per row, addresses as immediates
+    auto A2 = [&](const nlm_geom &g, float *const T) {
+      float v = T[tid];
+      int t0 = 1;
+      for(; t0 + 16 <= g.nrows; t0 += 16)
       {
-        hi[k] = rowp[cb + k + P];
-        lo[k] = rowp[cb + k - P - 1];
+        float term[16];
+        float *const col = T + t0 * pitch + tid;
+  #pragma unroll
+        for(int k = 0; k < 16; k++) term[k] = col[k * pitch];
+        term[0] = v + term[0];
+  #pragma unroll
+        for(int k = 1; k < 16; k++) term[k] = term[k - 1] + term[k];
+        v = term[15];
+  #pragma unroll
+        for(int k = 0; k < 16; k++) col[k * pitch] = term[k];
       }
-#pragma unroll
-      for(int k = 0; k < 16; k++)
+      if(t0 < g.nrows)
       {
-        const float next = distortion + (hi[k] - lo[k]);
-        distortion = k < live ? next : distortion;
-        hi[k] = distortion;
+        float term[16];
+        float *const col = T + t0 * pitch + tid;
+        const int live = g.nrows - t0;
+  #pragma unroll
+        for(int k = 0; k < 16; k++) term[k] = col[k * pitch];
+  #pragma unroll
+        for(int k = 0; k < 16; k++)
+        {
+          const float next = v + term[k];
+          v = k < live ? next : v;
+          term[k] = v;
+        }
+  #pragma unroll
+        for(int k = 0; k < 16; k++)
+          if(k < live) col[k * pitch] = term[k];
       }
-#pragma unroll
-      for(int k = 0; k < 16; k++)
-        if(k < live) rowp[cb + k - P - 1] = hi[k];
-    }
-  };
-  // ---- C: weights and accumulation (:416-436), parallel group; all LDS reads first, then the arithmetic
-  auto C = [&](const nlm_geom &g, const float *const T) {
-    const int dS = g.srow * 3 * NLP_WP + g.scol;
-    const int trow = (g.row_min - top) * pitch; // table row 0 is chunk row row_min - top
-    const bool whole = g.row_min == top && g.row_max == bot && g.col_min == left && g.col_max == right;
-    float dist[NLP_PX], qx[NLP_PX], qy[NLP_PX], qz[NLP_PX];
-    bool ok[NLP_PX];
-#pragma unroll
-    for(int k = 0; k < NLP_PX; k++)
-    {
-      int pk = prc[k];
-      asm volatile("" : "+v"(pk));
-      const int r = pk >> 16, c = pk & 0xffff;
-      ok[k] = pk >= 0;
-      if(!whole)
+    };
+    // ---- B: sliding row sum (:405-415), one thread per table row, in place; same shape
+    auto B = [&](const nlm_geom &g, float *const T, const int rr) {
+      float *const rowp = T + rr * pitch - cs0; // indexable by frame column
+      float distortion = 0.0f;
+      for(int i = g.col_min - P; i < imin(g.col_min + P, g.col_max); i++) distortion += rowp[i];
+      int cb = g.col_min;
+      for(; cb + 16 <= g.col_max; cb += 16)
       {
-        const int row = top + r, col = left + c;
-        ok[k] = ok[k] && row >= g.row_min && row < g.row_max && col >= g.col_min && col < g.col_max;
+        float hi[16], lo[16];
+  #pragma unroll
+        for(int k = 0; k < 16; k++)
+        {
+          hi[k] = rowp[cb + k + P];
+          lo[k] = rowp[cb + k - P - 1];
+        }
+  #pragma unroll
+        for(int k = 0; k < 16; k++) hi[k] = hi[k] - lo[k];
+        hi[0] = distortion + hi[0];
+  #pragma unroll
+        for(int k = 1; k < 16; k++) hi[k] = hi[k - 1] + hi[k];
+        distortion = hi[15];
+  #pragma unroll
+        for(int k = 0; k < 16; k++) rowp[cb + k - P - 1] = hi[k];
       }
-      const int ti = ok[k] ? __mul24(r, pitch) + c - trow : 0;
-      dist[k] = T[ti];
-      const float *const pq = win + (wbase0 + dS) + __mul24(r, 3 * NLP_WP) + c;
-      qx[k] = pq[0];
-      qy[k] = pq[NLP_WP];
-      qz[k] = pq[2 * NLP_WP];
-    }
-    if(a.center_weight < 0)
-    {
-#pragma unroll
-      for(int k = 0; k < NLP_PX; k++)
+      if(cb < g.col_max)
       {
-        const float w = mexp2(dist[k] * a.sharpness);
-        const float sx = acc[k].x + qx[k] * w, sy = acc[k].y + qy[k] * w, sz = acc[k].z + qz[k] * w, sw = acc[k].w + 1.0f * w;
-        acc[k].x = ok[k] ? sx : acc[k].x;
-        acc[k].y = ok[k] ? sy : acc[k].y;
-        acc[k].z = ok[k] ? sz : acc[k].z;
-        acc[k].w = ok[k] ? sw : acc[k].w;
+        float hi[16], lo[16];
+        const int live = g.col_max - cb;
+  #pragma unroll
+        for(int k = 0; k < 16; k++)
+        {
+          hi[k] = rowp[cb + k + P];
+          lo[k] = rowp[cb + k - P - 1];
+        }
+  #pragma unroll
+        for(int k = 0; k < 16; k++)
+        {
+          const float next = distortion + (hi[k] - lo[k]);
+          distortion = k < live ? next : distortion;
+          hi[k] = distortion;
+        }
+  #pragma unroll
+        for(int k = 0; k < 16; k++)
+          if(k < live) rowp[cb + k - P - 1] = hi[k];
       }
-    }
-    else
-    {
-#pragma unroll
+    };
+    // ---- C: weights and accumulation (:416-436), parallel group; all LDS reads first, then the arithmetic
+    auto C = [&](const nlm_geom &g, const float *const T) {
+      const int dS = g.srow * 3 * NLP_WP + g.scol;
+      const int trow = (g.row_min - top) * pitch; // table row 0 is chunk row row_min - top
+      const bool whole = INTERIOR || (g.row_min == top && g.row_max == bot && g.col_min == left && g.col_max == right);
+      float dist[NLP_PX], qx[NLP_PX], qy[NLP_PX], qz[NLP_PX];
+      bool ok[NLP_PX];
+  #pragma unroll
       for(int k = 0; k < NLP_PX; k++)
       {
         int pk = prc[k];
         asm volatile("" : "+v"(pk));
-        const float *const pp = win + wbase0 + __mul24(pk >> 16, 3 * NLP_WP) + (pk & 0xffff);
-        const float dx = pp[0] - qx[k], dy = pp[NLP_WP] - qy[k], dz = pp[2 * NLP_WP] - qz[k];
-        const float dis = (dist[k] + (dx * dx * a.cpn + dy * dy * a.cpn + dz * dz * a.cpn)) / (1.0f + a.center_weight);
-        const float w = mexp2(fmaxf(0.0f, dis * a.sharpness - 2.0f));
-        const float sx = acc[k].x + qx[k] * w, sy = acc[k].y + qy[k] * w, sz = acc[k].z + qz[k] * w, sw = acc[k].w + 1.0f * w;
-        acc[k].x = ok[k] ? sx : acc[k].x;
-        acc[k].y = ok[k] ? sy : acc[k].y;
-        acc[k].z = ok[k] ? sz : acc[k].z;
-        acc[k].w = ok[k] ? sw : acc[k].w;
+        const int r = pk >> 16, c = pk & 0xffff;
+        ok[k] = pk >= 0;
+        if(!whole)
+        {
+          const int row = top + r, col = left + c;
+          ok[k] = ok[k] && row >= g.row_min && row < g.row_max && col >= g.col_min && col < g.col_max;
+        }
+        const int ti = ok[k] ? __mul24(r, pitch) + c - trow : 0;
+        dist[k] = T[ti];
+        const float *const pq = win + (wbase0 + dS) + __mul24(r, 3 * NLP_WP) + c;
+        qx[k] = pq[0];
+        qy[k] = pq[NLP_WP];
+        qz[k] = pq[2 * NLP_WP];
       }
-    }
-  };
+      if(a.center_weight < 0)
+      {
+  #pragma unroll
+        for(int k = 0; k < NLP_PX; k++)
+        {
+          const float w = mexp2(dist[k] * a.sharpness);
+          const float sx = acc[k].x + qx[k] * w, sy = acc[k].y + qy[k] * w, sz = acc[k].z + qz[k] * w, sw = acc[k].w + 1.0f * w;
+          acc[k].x = ok[k] ? sx : acc[k].x;
+          acc[k].y = ok[k] ? sy : acc[k].y;
+          acc[k].z = ok[k] ? sz : acc[k].z;
+          acc[k].w = ok[k] ? sw : acc[k].w;
+        }
+      }
+      else
+      {
+  #pragma unroll
+        for(int k = 0; k < NLP_PX; k++)
+        {
+          int pk = prc[k];
+          asm volatile("" : "+v"(pk));
+          const float *const pp = win + wbase0 + __mul24(pk >> 16, 3 * NLP_WP) + (pk & 0xffff);
+          const float dx = pp[0] - qx[k], dy = pp[NLP_WP] - qy[k], dz = pp[2 * NLP_WP] - qz[k];
+          const float dis = (dist[k] + (dx * dx * a.cpn + dy * dy * a.cpn + dz * dz * a.cpn)) / (1.0f + a.center_weight);
+          const float w = mexp2(fmaxf(0.0f, dis * a.sharpness - 2.0f));
+          const float sx = acc[k].x + qx[k] * w, sy = acc[k].y + qy[k] * w, sz = acc[k].z + qz[k] * w, sw = acc[k].w + 1.0f * w;
+          acc[k].x = ok[k] ? sx : acc[k].x;
+          acc[k].y = ok[k] ? sy : acc[k].y;
+          acc[k].z = ok[k] ? sz : acc[k].z;
+          acc[k].w = ok[k] ? sw : acc[k].w;
+        }
+      }
+    };
 
-  // the patch shifts of offsets i - 1, i, i + 1 stay in scalar registers and the one for i + 2 is fetched an
-  // iteration ahead: a scalar load at the top of every phase would sit on every wave's critical path
-  auto geom = [&](const int2 sh) { return geom_of(sh, top, bot, left, right, P, W, H); };
-  int2 sh_prev = make_int2(0, 0), sh_cur = patches[0], sh_next = patches[n > 1 ? 1 : 0];
-  {
-    const nlm_geom g = geom(sh_cur);
-    if(g.nrows > 0)
-    {
-      if(par) A1(g, lds);
-      else if(tid < csw) A1_first(g, lds);
-    }
-  }
-  __syncthreads();
-  for(int i = 0; i <= n; i++)
-  {
-    const int2 sh_next2 = patches[i + 2 < n ? i + 2 : n - 1];
-    float *const Ti = lds + (i & 1) * tabsz;       // offset i, and i + 2
-    float *const To = lds + ((i + 1) & 1) * tabsz; // offsets i - 1 and i + 1
-    // phase 1
-    if(par)
-    {
-      if(i >= 1)
-      {
-        const nlm_geom g = geom(sh_prev);
-        if(g.nrows > 0) C(g, To);
-      }
-    }
-    else if(tid < csw && i < n)
+    // the patch shifts of offsets i - 1, i, i + 1 stay in scalar registers and the one for i + 2 is fetched an
+    // iteration ahead: a scalar load at the top of every phase would sit on every wave's critical path
+    auto geom = [&](const int2 sh) {
+      if(!INTERIOR) return geom_of(sh, top, bot, left, right, P, W, H);
+      nlm_geom g;
+      g.srow = sh.x;
+      g.scol = sh.y;
+      g.row_min = g.row_top = top;
+      g.row_max = g.row_bot = bot;
+      g.nrows = ch;
+      g.col_min = left;
+      g.col_max = right;
+      g.pc_min = left - P;
+      g.pc_max = right + P;
+      return g;
+    };
+    int2 sh_prev = make_int2(0, 0), sh_cur = patches[0], sh_next = patches[n > 1 ? 1 : 0];
     {
       const nlm_geom g = geom(sh_cur);
-      if(g.nrows > 0) A2(g, Ti);
-    }
-    __syncthreads();
-    // phase 2
-    if(par)
-    {
-      if(i + 1 < n)
+      if(g.nrows > 0)
       {
-        const nlm_geom g = geom(sh_next);
-        if(g.nrows > 0) A1(g, To);
+        if(par) A1(g, lds);
+        else if(tid < csw) A1_first(g, lds);
       }
     }
-    else if(tid < 128)
-    {
-      if(tid < csw && i + 1 < n)
-      {
-        const nlm_geom g = geom(sh_next);
-        if(g.nrows > 0) A1_first(g, To);
-      }
-    }
-    else if(i < n)
-    {
-      const nlm_geom g = geom(sh_cur);
-      if(tid - 128 < g.nrows) B(g, Ti, tid - 128);
-    }
     __syncthreads();
-    sh_prev = sh_cur;
-    sh_cur = sh_next;
-    sh_next = sh_next2;
-  }
+    for(int i = 0; i <= n; i++)
+    {
+      const int2 sh_next2 = patches[i + 2 < n ? i + 2 : n - 1];
+      float *const Ti = lds + (i & 1) * tabsz;       // offset i, and i + 2
+      float *const To = lds + ((i + 1) & 1) * tabsz; // offsets i - 1 and i + 1
+      // phase 1
+      if(par)
+      {
+        if(i >= 1)
+        {
+          const nlm_geom g = geom(sh_prev);
+          if(g.nrows > 0) C(g, To);
+        }
+      }
+      else if(tid < csw && i < n)
+      {
+        const nlm_geom g = geom(sh_cur);
+        if(g.nrows > 0) A2(g, Ti);
+      }
+      __syncthreads();
+      // phase 2
+      if(par)
+      {
+        if(i + 1 < n)
+        {
+          const nlm_geom g = geom(sh_next);
+          if(g.nrows > 0) A1(g, To);
+        }
+      }
+      else if(tid < 128)
+      {
+        if(tid < csw && i + 1 < n)
+        {
+          const nlm_geom g = geom(sh_next);
+          if(g.nrows > 0) A1_first(g, To);
+        }
+      }
+      else if(i < n)
+      {
+        const nlm_geom g = geom(sh_cur);
+        if(tid - 128 < g.nrows) B(g, Ti, tid - 128);
+      }
+      __syncthreads();
+      sh_prev = sh_cur;
+      sh_cur = sh_next;
+      sh_next = sh_next2;
+    }
+
+  };
+  const bool interior = top >= a.reach && bot + a.reach <= H && left >= a.reach && right + a.reach <= W && ch == a.chk_h
+                        && cw == a.chk_w;
+  if(interior)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
 
   // ---- normalise, blend (:490-521)
 #pragma unroll
