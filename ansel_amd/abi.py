@@ -208,3 +208,72 @@ class BandState(C.Structure):
 
 
 DT_HIP_HIGHLIGHTS_JOURNAL_BYTES = 320
+
+
+# dt_develop_blend_mode_t (src/develop/blend.h:61-107): the operators of the "RGB (scene)" colourspace
+BLEND_NORMAL = 0x18
+BLEND_MULTIPLY = 0x04
+BLEND_AVERAGE = 0x05
+BLEND_ADD = 0x06
+BLEND_SUBTRACT = 0x07
+BLEND_DIFFERENCE = 0x17
+BLEND_LIGHTNESS = 0x10
+BLEND_CHROMATICITY = 0x11
+BLEND_RGB_R = 0x21
+BLEND_RGB_G = 0x22
+BLEND_RGB_B = 0x23
+BLEND_SUBTRACT_INVERSE = 0x25
+BLEND_DIVIDE = 0x26
+BLEND_DIVIDE_INVERSE = 0x27
+BLEND_GEOMETRIC_MEAN = 0x28
+BLEND_HARMONIC_MEAN = 0x29
+BLEND_REVERSE = 0x80000000
+BLEND_RGB_SCENE_MODES = (BLEND_NORMAL, BLEND_MULTIPLY, BLEND_AVERAGE, BLEND_ADD, BLEND_SUBTRACT, BLEND_DIFFERENCE,
+                         BLEND_LIGHTNESS, BLEND_CHROMATICITY, BLEND_RGB_R, BLEND_RGB_G, BLEND_RGB_B,
+                         BLEND_SUBTRACT_INVERSE, BLEND_DIVIDE, BLEND_DIVIDE_INVERSE, BLEND_GEOMETRIC_MEAN,
+                         BLEND_HARMONIC_MEAN)
+# dt_develop_blendif_channels_t (blend.h:141-197), RGB (scene) names
+BLENDIF_GRAY_in, BLENDIF_RED_in, BLENDIF_GREEN_in, BLENDIF_BLUE_in = 0, 1, 2, 3
+BLENDIF_GRAY_out, BLENDIF_RED_out, BLENDIF_GREEN_out, BLENDIF_BLUE_out = 4, 5, 6, 7
+BLENDIF_Jz_in, BLENDIF_Cz_in, BLENDIF_hz_in = 8, 9, 10
+BLENDIF_Jz_out, BLENDIF_Cz_out, BLENDIF_hz_out = 12, 13, 14
+MASK_ENABLED, MASK_SHAPE, MASK_PARAMETRIC, MASK_RASTER = 1, 2, 4, 8
+COMBINE_INV, COMBINE_INCL = 1, 2
+BLEND_CS_RGB_SCENE = 4
+
+
+class BlendData(C.Structure):
+    """dt_hip_blend_data_t: the fields of dt_develop_blend_params_t (src/develop/blend.h:199-244) the
+    uniform / parametric RGB (scene) blend reads + the work profile's RGB -> XYZ(D50) matrix"""
+    _fields_ = [("mask_mode", C.c_uint32), ("blend_cst", C.c_int32), ("blend_mode", C.c_uint32),
+                ("blend_parameter", C.c_float), ("opacity", C.c_float), ("mask_combine", C.c_uint32),
+                ("blendif", C.c_uint32), ("feathering_radius", C.c_float), ("blur_radius", C.c_float),
+                ("details", C.c_float), ("contrast", C.c_float), ("brightness", C.c_float),
+                ("blendif_parameters", C.c_float * 64), ("blendif_boost_factors", C.c_float * 16), ("matrix_in", m34)]
+
+    @classmethod
+    def uniform(cls, matrix_in, opacity=100.0, blend_mode=BLEND_NORMAL, blend_parameter=0.0):
+        """dt_develop_blend_init_blend_parameters() (blend.c:173-212) with a uniform mask: every channel's
+        trapezoid is the whole range {0, 0, 1, 1}"""
+        d = cls()
+        d.mask_mode = MASK_ENABLED
+        d.blend_cst = BLEND_CS_RGB_SCENE
+        d.blend_mode = blend_mode
+        d.blend_parameter = blend_parameter
+        d.opacity = opacity
+        for ch in range(16):
+            d.blendif_parameters[4 * ch + 2] = 1.0
+            d.blendif_parameters[4 * ch + 3] = 1.0
+        set_m34(d.matrix_in, matrix_in)
+        return d
+
+    def channel(self, ch, lo0, lo1, hi0, hi1, invert=False, boost=0.0):
+        """switch on one parametric channel with its trapezoid (and the parametric mask with it)"""
+        self.mask_mode |= MASK_PARAMETRIC
+        self.blendif |= 1 << ch
+        if invert:
+            self.blendif |= 1 << (16 + ch)
+        for k, v in enumerate((lo0, lo1, hi0, hi1)):
+            self.blendif_parameters[4 * ch + k] = v
+        self.blendif_boost_factors[ch] = boost
+        return self

@@ -1,0 +1,405 @@
+// blend.hip -- the blend stage on gfx950: opacity mask and blend operator in ONE pass.
+//
+// Reference: dt_develop_blend_process(), src/develop/blend.c:657-900, which runs after the process()
+// of every blending-capable module (src/develop/pixelpipe_cpu.c:137-228): fill / build the mask
+// (dt_develop_blendif_rgb_jzczhz_make_mask(), src/develop/blends/blendif_rgb_jzczhz.c:196-324),
+// post-process it (_develop_blend_process_mask_tone_curve(), blend.c:626-655), then blend the
+// module's input into its output (dt_develop_blendif_rgb_jzczhz_blend(), :878-960).  The reference
+// makes one pass over the frame per active mask channel, one for the combination, one for the tone
+// curve, copies the output and makes one more pass for the operator -- a 4-byte mask plane and a
+// 16-byte copy through memory each time.  Without a spatial mask operation (feathering, blur, drawn
+// shapes: refused here) every one of those steps is pointwise, so this kernel does them all on the
+// pixel in registers: 16 B in + 16 B out read, 16 B written, 48 B per pixel.
+//
+// Arithmetic: the parametric channels Jz, Cz, hz go through two powf per LMS channel, one atan2f and
+// one hypotf (src/common/colorspaces_inline_conversions.h:672-781); those are the glibc-exact ones
+// of devmath.h.  The per-channel parameter table, the masking profile and exp2f / expf of the
+// uniform parameters are prepared on the host with the host's libm, as the reference does.
+#include "hip_common.h"
+#include "devmath.h"
+
+#include <math.h>
+
+using namespace ansel;
+
+namespace
+{
+
+#define PARAM_ITEMS 6 // DEVELOP_BLENDIF_PARAMETER_ITEMS
+#define RGB_MASK 0x77FFu
+#define GRAY_OUT 4
+
+enum
+{
+  MODE_MULTIPLY = 0x04,
+  MODE_AVERAGE = 0x05,
+  MODE_ADD = 0x06,
+  MODE_SUBTRACT = 0x07,
+  MODE_DIFFERENCE = 0x08,
+  MODE_LIGHTNESS = 0x10,
+  MODE_CHROMATICITY = 0x11,
+  MODE_DIFFERENCE2 = 0x17,
+  MODE_RGB_R = 0x21,
+  MODE_RGB_G = 0x22,
+  MODE_RGB_B = 0x23,
+  MODE_SUBTRACT_INVERSE = 0x25,
+  MODE_DIVIDE = 0x26,
+  MODE_DIVIDE_INVERSE = 0x27,
+  MODE_GEOMETRIC_MEAN = 0x28,
+  MODE_HARMONIC_MEAN = 0x29,
+};
+
+struct blend_args
+{
+  int owidth, oheight, iwidth, xoffs, yoffs;
+  float constant; // the mask when it does not depend on the pixel
+  float global_opacity, seed;
+  int inclusive, inversed;
+  unsigned blendif; // inclusive-combine inversion applied
+  float parameters[PARAM_ITEMS * DT_HIP_BLENDIF_SIZE];
+  float luma[3];
+  float mT[3][4]; // masking profile: RGB -> XYZ D65, transposed
+  int tone;
+  float e, brightness, opacity;
+  unsigned mode;
+  int reverse;
+  float p;
+};
+
+// _blendif_compute_factor(), blendif_rgb_jzczhz.c:42-73
+__device__ __forceinline__ float compute_factor(const float value, const unsigned invert, const float *p)
+{
+  float factor;
+  if(value <= p[0]) factor = 0.0f;
+  else if(value < p[1]) factor = (value - p[0]) * p[4];
+  else if(value <= p[2]) factor = 1.0f;
+  else if(value < p[3]) factor = 1.0f - (value - p[2]) * p[5];
+  else factor = 0.0f;
+  return invert ? 1.0f - factor : factor;
+}
+
+// dt_ioppr_rgb_matrix_to_xyz() on a linear profile, dt_XYZ_2_JzAzBz(), dt_JzAzBz_2_JzCzhz()
+__device__ __forceinline__ void rgb_to_JzCzhz(const float4 rgb, const float (&mT)[3][4], float (&JzCzhz)[3])
+{
+  const float b = 1.15f, g = 0.66f, c1 = 0.8359375f, c2 = 18.8515625f, c3 = 18.6875f, n = 0.159301758f,
+              p = 134.034375f, d = -0.56f, d0 = 1.6295499532821566e-11f;
+  const float M[3][3] = { { 0.41478972f, 0.579999f, 0.0146480f },
+                          { -0.2015100f, 1.120649f, 0.0531008f },
+                          { -0.0166008f, 0.264800f, 0.6684799f } };
+  const float A_T[3][3] = { { 0.5f, 3.524000f, 0.199076f }, { 0.5f, -4.066708f, 1.096799f }, { 0.0f, 0.542708f, -1.295875f } };
+  float D65[3];
+#pragma unroll
+  for(int c = 0; c < 3; c++)
+  {
+    float o = mT[0][c] * rgb.x;
+    o = mT[1][c] * rgb.y + o;
+    D65[c] = mT[2][c] * rgb.z + o;
+  }
+  float XYZ[3], LMS[3], Jab[3];
+  XYZ[0] = b * D65[0] - (b - 1.0f) * D65[2];
+  XYZ[1] = g * D65[1] - (g - 1.0f) * D65[0];
+  XYZ[2] = D65[2];
+#pragma unroll
+  for(int i = 0; i < 3; i++)
+  {
+    LMS[i] = M[i][0] * XYZ[0] + M[i][1] * XYZ[1] + M[i][2] * XYZ[2];
+    LMS[i] = ansel_math::powf_exact(fmaxf(LMS[i] / 10000.f, 0.0f), n);
+    LMS[i] = ansel_math::powf_exact((c1 + c2 * LMS[i]) / (1.0f + c3 * LMS[i]), p);
+  }
+#pragma unroll
+  for(int c = 0; c < 3; c++) Jab[c] = A_T[0][c] * LMS[0] + A_T[1][c] * LMS[1] + A_T[2][c] * LMS[2];
+  Jab[0] = fmaxf(((1.0f + d) * Jab[0]) / (1.0f + d * Jab[0]) - d0, 0.f);
+  const float var_H = ansel_math::atan2f_exact(Jab[2], Jab[1]) / (2.0f * 3.14159265358979324f);
+  JzCzhz[0] = Jab[0];
+  JzCzhz[1] = ansel_math::hypotf_exact(Jab[1], Jab[2]);
+  JzCzhz[2] = var_H >= 0.0f ? var_H : 1.0f + var_H;
+}
+
+// _blendif_combine_channels(), blendif_rgb_jzczhz.c:151-194; OUT selects the output-side channels
+template <int OUT> __device__ __forceinline__ float combine_channels(const float4 px, float temp, const blend_args &a)
+{
+  const unsigned blendif = OUT ? a.blendif >> GRAY_OUT : a.blendif; // uniform
+  const float *const params = a.parameters + (OUT ? PARAM_ITEMS * GRAY_OUT : 0);
+  if(blendif & 1u)
+  {
+    const float value = a.luma[0] * px.x + a.luma[1] * px.y + a.luma[2] * px.z;
+    temp *= compute_factor(value, (blendif >> 16) & 1u, params);
+  }
+  if(blendif & 2u) temp *= compute_factor(px.x, (blendif >> 16) & 2u, params + PARAM_ITEMS * 1);
+  if(blendif & 4u) temp *= compute_factor(px.y, (blendif >> 16) & 4u, params + PARAM_ITEMS * 2);
+  if(blendif & 8u) temp *= compute_factor(px.z, (blendif >> 16) & 8u, params + PARAM_ITEMS * 3);
+  if(blendif & ((1u << 8) | (1u << 9) | (1u << 10)))
+  {
+    float JzCzhz[3];
+    rgb_to_JzCzhz(px, a.mT, JzCzhz);
+    float factor = 1.0f;
+#pragma unroll
+    for(unsigned i = 0; i < 3; i++)
+      factor *= compute_factor(JzCzhz[i], (blendif >> 16) & (1u << (8 + i)), params + PARAM_ITEMS * (8 + i));
+    temp *= factor;
+  }
+  return temp;
+}
+
+// _develop_blend_process_mask_tone_curve(), blend.c:626-655
+__host__ __device__ __forceinline__ float tone_curve(const float m, const blend_args &a)
+{
+  const float mask_epsilon = 16 * 1.19209290e-7f;
+  float x = m / a.opacity;
+  x = 2.f * x - 1.f;
+  if(1.f - a.brightness <= 0.f) x = m <= mask_epsilon ? -1.f : 1.f;
+  else if(1.f + a.brightness <= 0.f) x = m >= 1.f - mask_epsilon ? 1.f : -1.f;
+  else if(a.brightness > 0.f)
+  {
+    x = (x + a.brightness) / (1.f - a.brightness);
+    x = fminf(x, 1.f);
+  }
+  else
+  {
+    x = (x + a.brightness) / (1.f + a.brightness);
+    x = fmaxf(x, -1.f);
+  }
+  const float r = ((x * a.e / (1.f + (a.e - 1.f) * fabsf(x))) / 2.f + 0.5f) * a.opacity;
+  return r > 1.f ? 1.f : (r < 0.f ? 0.f : r);
+}
+
+// C fmax() on a float promoted to double, converted back (exact): max with NaN returning the other
+__device__ __forceinline__ float fmax_d(const float x, const float y) { return (float)fmax((double)x, (double)y); }
+
+// the _blend_* row functions (blendif_rgb_jzczhz.c:328-585), one pixel: a = bottom, b = top layer
+__device__ __forceinline__ float4 blend_pixel(const unsigned mode, const float4 a4, const float4 b4, const float p, const float lo)
+{
+  const float a[3] = { a4.x, a4.y, a4.z }, b[3] = { b4.x, b4.y, b4.z };
+  float o[3];
+  switch(mode)
+  {
+    case MODE_MULTIPLY:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + (a[k] * b[k] * p) * lo;
+      break;
+    case MODE_AVERAGE:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + (a[k] + b[k]) / 2.0f * lo;
+      break;
+    case MODE_ADD:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + (a[k] + p * b[k]) * lo;
+      break;
+    case MODE_SUBTRACT:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + fmaxf(a[k] - p * b[k], 0.0f) * lo;
+      break;
+    case MODE_SUBTRACT_INVERSE:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + fmaxf(b[k] - p * a[k], 0.0f) * lo;
+      break;
+    case MODE_DIFFERENCE:
+    case MODE_DIFFERENCE2:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + fabsf(a[k] - b[k]) * lo;
+      break;
+    case MODE_DIVIDE:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + a[k] / fmaxf(p * b[k], 1e-6f) * lo;
+      break;
+    case MODE_DIVIDE_INVERSE:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + b[k] / fmaxf(p * a[k], 1e-6f) * lo;
+      break;
+    case MODE_GEOMETRIC_MEAN:
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + sqrtf(fmax_d(a[k] * b[k], 0.0f)) * lo;
+      break;
+    case MODE_HARMONIC_MEAN:
+#pragma unroll
+      for(int k = 0; k < 3; k++)
+        o[k] = a[k] * (1.0f - lo) + 2.0f * a[k] * b[k] / (fmaxf(a[k], 5e-7f) + fmaxf(b[k], 5e-7f)) * lo;
+      break;
+    case MODE_CHROMATICITY:
+    case MODE_LIGHTNESS:
+    {
+      const float norm_a = fmax_d(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-6f);
+      const float norm_b = fmax_d(sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]), 1e-6f);
+      if(mode == MODE_CHROMATICITY)
+      {
+#pragma unroll
+        for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + b[k] * norm_a / norm_b * lo;
+      }
+      else
+      {
+#pragma unroll
+        for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + a[k] * norm_b / norm_a * lo;
+      }
+      break;
+    }
+    case MODE_RGB_R:
+      o[0] = a[0] * (1.0f - lo) + p * b[0] * lo;
+      o[1] = a[1];
+      o[2] = a[2];
+      break;
+    case MODE_RGB_G:
+      o[0] = a[0];
+      o[1] = a[1] * (1.0f - lo) + p * b[1] * lo;
+      o[2] = a[2];
+      break;
+    case MODE_RGB_B:
+      o[0] = a[0];
+      o[1] = a[1];
+      o[2] = a[2] * (1.0f - lo) + p * b[2] * lo;
+      break;
+    default: // normal
+#pragma unroll
+      for(int k = 0; k < 3; k++) o[k] = a[k] * (1.0f - lo) + b[k] * lo;
+      break;
+  }
+  return make_float4(o[0], o[1], o[2], lo);
+}
+
+template <bool PARAMETRIC>
+__global__ __launch_bounds__(256) void blend_rgb_scene(const float4 *__restrict__ in, float4 *__restrict__ out, const blend_args a)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= (size_t)a.owidth * a.oheight) return;
+  const int y = (int)(k / a.owidth), x = (int)(k - (size_t)y * a.owidth);
+  const float4 pa = in[(size_t)(y + a.yoffs) * a.iwidth + a.xoffs + x];
+  const float4 pb = out[k];
+  float m = a.constant;
+  if(PARAMETRIC)
+  {
+    float temp = 1.0f;
+    temp = combine_channels<0>(pa, temp, a);
+    temp = combine_channels<1>(pb, temp, a);
+    if(a.inclusive)
+      m = a.inversed ? a.global_opacity * (1.0f - a.seed) * temp : a.global_opacity * (1.0f - (1.0f - a.seed) * temp);
+    else
+      m = a.inversed ? a.global_opacity * (1.0f - a.seed * temp) : a.global_opacity * a.seed * temp;
+    if(a.tone) m = tone_curve(m, a);
+  }
+  const float4 r = a.reverse ? blend_pixel(a.mode, pb, pa, a.p, m) : blend_pixel(a.mode, pa, pb, a.p, m);
+  nt_store(out + k, r);
+}
+
+} // namespace
+
+extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d,
+                                            dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
+  if(d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE)
+  {
+    set_last_error("blend: colourspace %d is not built (only RGB (scene), %d)", d->blend_cst, DT_HIP_BLEND_CS_RGB_SCENE);
+    return DT_HIP_INVALID_ARG;
+  }
+  if(piece->channels != 4) return DT_HIP_INVALID_ARG;
+  if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->blur_radius != 0.f
+     || d->details != 0.f)
+  {
+    set_last_error("blend: drawn / raster masks, feathering, mask blur and the details threshold are not built");
+    return DT_HIP_INVALID_ARG;
+  }
+  if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return DT_HIP_SUCCESS; // blend.c:673
+  blend_args a;
+  memset(&a, 0, sizeof(a));
+  a.xoffs = piece->roi_out.x - piece->roi_in.x;
+  a.yoffs = piece->roi_out.y - piece->roi_in.y;
+  a.iwidth = piece->roi_in.width;
+  a.owidth = piece->roi_out.width;
+  a.oheight = piece->roi_out.height;
+  if(a.owidth <= 0 || a.oheight <= 0) return DT_HIP_SUCCESS;
+  // "skipped blending: roi's do not match", blend.c:697-702
+  if(piece->roi_out.scale != piece->roi_in.scale || a.xoffs < 0 || a.yoffs < 0
+     || ((a.xoffs > 0 || a.yoffs > 0)
+         && (a.owidth + a.xoffs > a.iwidth || a.oheight + a.yoffs > piece->roi_in.height)))
+    return DT_HIP_SUCCESS;
+
+  const float opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f);
+  // dt_develop_blend_get_mask_usage(), blend.c:262-320: is any parametric channel away from its full range
+  bool parametric = false;
+  if(d->mask_mode & DT_HIP_MASK_PARAMETRIC)
+    for(unsigned ch = 0; ch < DT_HIP_BLENDIF_SIZE; ch++)
+    {
+      const unsigned bit = 1u << ch;
+      if(!(RGB_MASK & bit) || !(d->blendif & bit)) continue;
+      const float *c = &d->blendif_parameters[ch * 4];
+      if(fabsf(c[0]) > 1e-6f || fabsf(c[1]) > 1e-6f || fabsf(c[2] - 1.0f) > 1e-6f || fabsf(c[3] - 1.0f) > 1e-6f)
+        parametric = true;
+    }
+  // make_mask(), blendif_rgb_jzczhz.c:196-324: which of its three cases
+  const unsigned any_channel_active = d->blendif & RGB_MASK;
+  const unsigned mask_inclusive = d->mask_combine & DT_HIP_COMBINE_INCL;
+  const unsigned mask_inversed = d->mask_combine & DT_HIP_COMBINE_INV;
+  const unsigned blendif = d->blendif ^ (mask_inclusive ? RGB_MASK << 16 : 0);
+  const unsigned canceling_channel = (blendif >> 16) & ~blendif & RGB_MASK;
+  const float global_opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f); // clamp_simd()
+  const float seed = mask_inclusive ? 0.0f : 1.0f; // the form mask of a parametric-only blend, blend.c:749-757
+  bool per_pixel = false;
+  a.constant = opacity;
+  if(parametric)
+  {
+    if(!canceling_channel && !any_channel_active)
+      a.constant = mask_inversed ? global_opacity * (1.0f - seed) : seed * global_opacity;
+    else if(canceling_channel || !any_channel_active)
+      a.constant = ((mask_inversed == 0) ^ (mask_inclusive == 0)) ? global_opacity : 0.0f;
+    else
+      per_pixel = true;
+  }
+  a.global_opacity = global_opacity;
+  a.seed = seed;
+  a.inclusive = mask_inclusive != 0;
+  a.inversed = mask_inversed != 0;
+  a.blendif = blendif;
+  a.opacity = opacity;
+  a.brightness = d->brightness;
+  a.e = expf(3.f * d->contrast);
+  a.tone = parametric && (fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f;
+  a.mode = d->blend_mode & 0xFFu;
+  a.reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
+  a.p = exp2f(d->blend_parameter);
+  if(per_pixel)
+  {
+    // dt_develop_blendif_process_parameters(), blend.c:214-260
+    for(size_t i = 0, j = 0; i < DT_HIP_BLENDIF_SIZE; i++, j += PARAM_ITEMS)
+    {
+      float *p = a.parameters + j;
+      if(d->blendif & (1u << i))
+      {
+        const float *bp = d->blendif_parameters + i * 4;
+        const float boost = exp2f(d->blendif_boost_factors[i]);
+        for(int k = 0; k < 4; k++) p[k] = (bp[k] - 0.0f) * boost;
+        p[4] = 1.0f / fmaxf(0.001f, p[1] - p[0]);
+        p[5] = 1.0f / fmaxf(0.001f, p[3] - p[2]);
+        if(bp[0] <= 0.0f && bp[1] <= 0.0f) p[0] = p[1] = -INFINITY;
+        if(bp[2] >= 1.0f && bp[3] >= 1.0f) p[2] = p[3] = INFINITY;
+      }
+      else
+      {
+        p[0] = p[1] = -INFINITY;
+        p[2] = p[3] = INFINITY;
+        p[4] = p[5] = 0.0f;
+      }
+    }
+    // dt_develop_blendif_init_masking_profile(), blend.c:322-353: Bradford D50 -> D65 times RGB -> XYZ
+    static const float Mb[3][3] = { { 0.9555766f, -0.0230393f, 0.0631636f },
+                                    { -0.0282895f, 1.0099416f, 0.0210077f },
+                                    { 0.0122982f, -0.0204830f, 1.3299098f } };
+    for(int y = 0; y < 3; y++)
+      for(int c = 0; c < 3; c++)
+      {
+        float sum = 0.0f;
+        for(int i = 0; i < 3; i++) sum += Mb[y][i] * d->matrix_in[i][c];
+        a.mT[c][y] = sum;
+      }
+    for(int c = 0; c < 3; c++) a.luma[c] = d->matrix_in[1][c];
+  }
+  if(!per_pixel && a.tone) a.constant = tone_curve(a.constant, a); // the same value for every pixel
+  const size_t np = (size_t)a.owidth * a.oheight;
+  hipStream_t s = stream_of(devid);
+  {
+    launch_scope ls(devid, "blend_rgb_scene");
+    if(per_pixel)
+      blend_rgb_scene<true><<<pixel_grid(np), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, a);
+    else
+      blend_rgb_scene<false><<<pixel_grid(np), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, a);
+  }
+  return check_launch("blend_rgb_scene");
+}

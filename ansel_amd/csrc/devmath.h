@@ -276,4 +276,138 @@ ANSEL_HD float expf_exact(const float x)
   return (float)y;
 }
 
+// ---- atanf / atan2f / hypotf ----------------------------------------------------------------
+// glibc 2.35 has no multiarch build of these three on x86-64: atanf and atan2f are the fdlibm
+// single-precision routines (sysdeps/ieee754/flt-32/s_atanf.c, e_atan2f.c) compiled without
+// contraction, hypotf is one double-precision square root (sysdeps/ieee754/flt-32/e_hypotf.c).
+// Callers: the JzCzhz / LCh hue and chroma of the parametric blend masks
+// (src/common/colorspaces_inline_conversions.h:775-781, src/develop/blends/*.c).
+ANSEL_HD float atanf_exact(float x)
+{
+  const float atanhi[4] = { 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f };
+  const float atanlo[4] = { 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f };
+  const float aT[11] = { 3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f,
+                         9.0908870101e-02f, -7.6918758452e-02f, 6.6610731184e-02f, -5.8335702866e-02f,
+                         4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f };
+  const int32_t hx = (int32_t)asuint(x);
+  const int32_t ix = hx & 0x7fffffff;
+  int id;
+  if(ix >= 0x4c000000) // |x| >= 2^25
+  {
+    if(ix > 0x7f800000) return x + x; // NaN
+    return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+  }
+  if(ix < 0x3ee00000) // |x| < 0.4375
+  {
+    if(ix < 0x31000000) return x; // |x| < 2^-29
+    id = -1;
+  }
+  else
+  {
+    x = fabsf(x);
+    if(ix < 0x3f980000) // |x| < 1.1875
+    {
+      if(ix < 0x3f300000) // 7/16 <= |x| < 11/16
+      {
+        id = 0;
+        x = (2.0f * x - 1.0f) / (2.0f + x);
+      }
+      else // 11/16 <= |x| < 19/16
+      {
+        id = 1;
+        x = (x - 1.0f) / (x + 1.0f);
+      }
+    }
+    else
+    {
+      if(ix < 0x401c0000) // |x| < 2.4375
+      {
+        id = 2;
+        x = (x - 1.5f) / (1.0f + 1.5f * x);
+      }
+      else // 2.4375 <= |x| < 2^25
+      {
+        id = 3;
+        x = -1.0f / x;
+      }
+    }
+  }
+  const float z = x * x;
+  const float w = z * z;
+  const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+  const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+  if(id < 0) return x - x * (s1 + s2);
+  const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+  return hx < 0 ? -r : r;
+}
+
+ANSEL_HD float atan2f_exact(const float y, const float x)
+{
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
+              pi_lo = -8.7422776573e-08f;
+  const int32_t hx = (int32_t)asuint(x), hy = (int32_t)asuint(y);
+  const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  if(ix > 0x7f800000 || iy > 0x7f800000) return x + y; // NaN
+  if(hx == 0x3f800000) return atanf_exact(y);           // x = 1
+  const int32_t m = ((hy >> 31) & 1) | ((hx >> 30) & 2); // 2 * sign(x) + sign(y)
+  if(iy == 0)
+  {
+    switch(m)
+    {
+      case 0:
+      case 1: return y;
+      case 2: return pi + tiny;
+      default: return -pi - tiny;
+    }
+  }
+  if(ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if(ix == 0x7f800000)
+  {
+    if(iy == 0x7f800000)
+    {
+      switch(m)
+      {
+        case 0: return pi_o_4 + tiny;
+        case 1: return -pi_o_4 - tiny;
+        case 2: return 3.0f * pi_o_4 + tiny;
+        default: return -3.0f * pi_o_4 - tiny;
+      }
+    }
+    switch(m)
+    {
+      case 0: return 0.0f;
+      case 1: return -0.0f;
+      case 2: return pi + tiny;
+      default: return -pi - tiny;
+    }
+  }
+  if(iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  const int32_t k = (iy - ix) >> 23;
+  float z;
+  if(k > 60) z = pi_o_2 + 0.5f * pi_lo;     // |y / x| > 2^60
+  else if(hx < 0 && k < -60) z = 0.0f;      // |y| / x < -2^60
+  else z = atanf_exact(fabsf(y / x));
+  switch(m)
+  {
+    case 0: return z;
+    case 1: return asfloat(asuint(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+  }
+}
+
+ANSEL_HD float hypotf_exact(const float x, const float y)
+{
+  const uint32_t ax = asuint(x) & 0x7fffffffu, ay = asuint(y) & 0x7fffffffu;
+  if(ax >= 0x7f800000u || ay >= 0x7f800000u)
+  {
+    // an infinity wins over a quiet NaN, a signalling NaN over everything
+    const bool sx = ax > 0x7f800000u && ax < 0x7fc00000u, sy = ay > 0x7f800000u && ay < 0x7fc00000u;
+    if((ax == 0x7f800000u || ay == 0x7f800000u) && !sx && !sy) return INFINITY;
+    return x + y;
+  }
+  const double dx = (double)x, dy = (double)y;
+  return (float)sqrt(dx * dx + dy * dy);
+}
+
 } // namespace ansel_math

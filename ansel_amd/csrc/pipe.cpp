@@ -42,6 +42,7 @@ enum op_t
   OP_LAB_TO_RGB,
   OP_FINALSCALE,
   OP_EXPORT_U16,
+  OP_BLEND,
   OP_UNKNOWN
 };
 
@@ -70,6 +71,7 @@ const op_info_t k_ops[] = {
   { "lab_to_rgb", sizeof(dt_hip_lab_data_t), 16 },
   { "finalscale", sizeof(dt_hip_finalscale_data_t), 16 },
   { "export_u16", 0, 8 },
+  { "blend", sizeof(dt_hip_blend_data_t), 0 },
 };
 
 struct node_t
@@ -141,6 +143,8 @@ struct dt_hip_pipe_t
   {
     groups.clear();
     const int n = (int)nodes.size();
+    // a module followed by a "blend" node keeps both its input and its output as buffers: it is never fused
+    auto blended = [&](const int k) { return k + 1 < n && nodes[k + 1].op == OP_BLEND; };
     int i = 0;
     while(i < n)
     {
@@ -148,7 +152,7 @@ struct dt_hip_pipe_t
       g.kind = group_t::SINGLE;
       g.first = i;
       g.count = 1;
-      if(fusion && nodes[i].op == OP_RAWPREPARE)
+      if(fusion && nodes[i].op == OP_RAWPREPARE && !blended(i) && !blended(i + 1) && !blended(i + 2))
       {
         raw_group_t r;
         memset(&r, 0, sizeof(r));
@@ -176,7 +180,7 @@ struct dt_hip_pipe_t
           g.raw = r;
         }
       }
-      else if(fusion && nodes[i].op >= OP_EXPOSURE && nodes[i].op <= OP_COLOROUT && nodes[i].piece.channels == 4)
+      else if(fusion && nodes[i].op >= OP_EXPOSURE && nodes[i].op <= OP_COLOROUT && nodes[i].piece.channels == 4 && !blended(i))
       {
         rgb_group_t r;
         memset(&r, 0, sizeof(r));
@@ -190,7 +194,7 @@ struct dt_hip_pipe_t
         while(j < n && r.n_ops < 8)
         {
           const node_t &nd = nodes[j];
-          if(nd.op < OP_EXPOSURE || nd.op > OP_COLOROUT || (int)nd.op <= last_op) break;
+          if(nd.op < OP_EXPOSURE || nd.op > OP_COLOROUT || (int)nd.op <= last_op || blended(j)) break;
           if(nd.piece.roi_out.width != r.width || nd.piece.roi_out.height != r.height || nd.piece.channels != 4) break;
           if(nd.op == OP_FILMICRGB)
           {
@@ -291,14 +295,33 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
   const int devid = pipe->devid;
   dt_hip_mem_t cur = dev_in;
   bool cur_owned = false;
+  dt_hip_mem_t held = NULL; // the input of a module whose output is about to be blended
+  bool held_owned = false;
   const size_t ng = pipe->groups.size();
+  auto is_blend = [&](const size_t k) { return k < ng && pipe->nodes[pipe->groups[k].first].op == OP_BLEND; };
   for(size_t gi = 0; gi < ng; gi++)
   {
     const group_t &g = pipe->groups[gi];
     const node_t &last = pipe->nodes[g.first + g.count - 1];
+    if(last.op == OP_BLEND)
+    {
+      // dt_develop_blend_process() after the module's process(), pixelpipe_cpu.c:137-228: in place in the output
+      int err = DT_HIP_INVALID_ARG;
+      if(held) err = dt_hip_develop_blend_process(devid, &last.piece, last.as<dt_hip_blend_data_t>(), held, cur);
+      else set_last_error("pipe: a blend node needs the module it blends in front of it");
+      if(held_owned) dt_hip_release_mem_object(held);
+      held = NULL;
+      if(err != DT_HIP_SUCCESS)
+      {
+        if(cur_owned) dt_hip_release_mem_object(cur);
+        return err;
+      }
+      continue;
+    }
     dt_hip_mem_t out = dev_out;
     bool out_owned = false;
-    if(gi + 1 < ng)
+    const bool final_out = gi + 1 == ng || (is_blend(gi + 1) && gi + 2 == ng);
+    if(!final_out)
     {
       out = dt_hip_alloc_device_buffer(devid, out_bytes(last));
       if(!out)
@@ -315,7 +338,13 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
       err = rgb_group_launch(devid, g.rgb, cur, out);
     else
       err = run_single(devid, pipe->nodes[g.first], cur, out);
-    if(cur_owned) dt_hip_release_mem_object(cur); // stream-ordered: re-used only by later launches
+    if(err == DT_HIP_SUCCESS && is_blend(gi + 1))
+    {
+      held = cur;
+      held_owned = cur_owned;
+    }
+    else if(cur_owned)
+      dt_hip_release_mem_object(cur); // stream-ordered: re-used only by later launches
     if(err != DT_HIP_SUCCESS)
     {
       if(out_owned) dt_hip_release_mem_object(out);
@@ -429,7 +458,8 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
     }
   if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
   for(const node_t &n : pipe->nodes)
-    if(n.op == OP_DENOISEPROFILE || n.op == OP_DIFFUSE || n.op == OP_NLMEANS || n.op == OP_BILAT || n.op == OP_FINALSCALE)
+    if(n.op == OP_DENOISEPROFILE || n.op == OP_DIFFUSE || n.op == OP_NLMEANS || n.op == OP_BILAT || n.op == OP_FINALSCALE
+       || n.op == OP_BLEND)
     {
       // these need a halo of 2^scales rows per band and (denoiseprofile) an all-reduce per wavelet band
       set_last_error("band mode: '%s' has no row-band implementation yet", k_ops[n.op].name);

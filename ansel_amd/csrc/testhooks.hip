@@ -16,7 +16,9 @@ __global__ void devmath_test(const float *__restrict__ x, const float *__restric
     if(FN == 0) r = ansel_math::powf_exact(x[k], y[k]);
     else if(FN == 1) r = ansel_math::log2f_exact(x[k]);
     else if(FN == 2) r = ansel_math::exp2f_exact(x[k]);
-    else r = ansel_math::expf_exact(x[k]);
+    else if(FN == 3) r = ansel_math::expf_exact(x[k]);
+    else if(FN == 4) r = ansel_math::atan2f_exact(x[k], y[k]);
+    else r = ansel_math::hypotf_exact(x[k], y[k]);
     o[k] = r;
   }
 }
@@ -32,4 +34,6 @@ int dt_hip_test_powf(int devid, const void *x, const void *y, void *o, size_t n)
 int dt_hip_test_log2f(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<1>(devid, x, y, o, n); }
 int dt_hip_test_exp2f(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<2>(devid, x, y, o, n); }
 int dt_hip_test_expf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<3>(devid, x, y, o, n); }
+int dt_hip_test_atan2f(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<4>(devid, x, y, o, n); }
+int dt_hip_test_hypotf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<5>(devid, x, y, o, n); }
 }

@@ -408,6 +408,52 @@ typedef struct dt_hip_finalscale_data_t
 int dt_hip_iop_finalscale_process(int devid, const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d,
                                   dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
+/* ---- 2b. the blend stage ---------------------------------------------------------------- */
+/* dt_develop_blend_process(), src/develop/blend.c:657-965: what the pixelpipe runs after the
+ * process() of every blending-capable module (src/develop/pixelpipe_cpu.c:137-228) -- build the
+ * opacity mask, then blend the module's input into its output, IN PLACE in the output buffer,
+ * leaving the per-pixel opacity in the alpha channel.  The struct carries the fields of
+ * dt_develop_blend_params_t (src/develop/blend.h:199-244) the supported paths read, under the
+ * reference's names, plus the work profile's RGB -> XYZ(D50) matrix that
+ * dt_develop_blendif_init_masking_profile() (blend.c:322-353) turns into the masking profile.
+ * Built this round: blend colourspace "RGB (scene)" (src/develop/blends/blendif_rgb_jzczhz.c) with
+ * a LINEAR work profile (nonlinearlut == 0, every scene-referred module's case), mask modes
+ * uniform and parametric (gray, R, G, B, Jz, Cz, hz on input and output, all combine / invert
+ * variants), the mask tone curve (contrast / brightness, blend.c:626-655), the sixteen blend
+ * operators of blendif_rgb_jzczhz.c:328-650 and the reverse flag.  Refused with
+ * DT_HIP_INVALID_ARG (never approximated): drawn and raster masks, feathering, mask blur, the
+ * details threshold, the other blend colourspaces, GUI mask display. */
+#define DT_HIP_BLEND_CS_RAW 1 /* dt_develop_blend_colorspace_t, blend.h:51-58 */
+#define DT_HIP_BLEND_CS_LAB 2
+#define DT_HIP_BLEND_CS_RGB_DISPLAY 3
+#define DT_HIP_BLEND_CS_RGB_SCENE 4
+#define DT_HIP_MASK_ENABLED 1u /* dt_develop_mask_mode_t, blend.h:110-118 */
+#define DT_HIP_MASK_SHAPE 2u
+#define DT_HIP_MASK_PARAMETRIC 4u
+#define DT_HIP_MASK_RASTER 8u
+#define DT_HIP_COMBINE_INV 1u /* dt_develop_mask_combine_mode_t, blend.h:120-131 */
+#define DT_HIP_COMBINE_INCL 2u
+#define DT_HIP_BLEND_REVERSE 0x80000000u /* dt_develop_blend_mode_t flag, blend.h:106 */
+#define DT_HIP_BLENDIF_SIZE 16
+typedef struct dt_hip_blend_data_t
+{
+  uint32_t mask_mode;     /* DT_HIP_MASK_* bits */
+  int32_t blend_cst;      /* DT_HIP_BLEND_CS_* */
+  uint32_t blend_mode;    /* DEVELOP_BLEND_* value (blend.h:61-107), DT_HIP_BLEND_REVERSE or-ed in */
+  float blend_parameter;  /* exposure fulcrum of the scene-referred operators, EV */
+  float opacity;          /* 0 .. 100 */
+  uint32_t mask_combine;  /* DT_HIP_COMBINE_* bits */
+  uint32_t blendif;       /* bit i: channel i active; bit 16 + i: channel i inverted (blend.h:141-197) */
+  float feathering_radius, blur_radius, details; /* must be 0 (refused otherwise) */
+  float contrast, brightness;                    /* mask tone curve */
+  float blendif_parameters[4 * DT_HIP_BLENDIF_SIZE];
+  float blendif_boost_factors[DT_HIP_BLENDIF_SIZE];
+  float matrix_in[3][4]; /* dt_iop_order_iccprofile_info_t.matrix_in of the work profile */
+} dt_hip_blend_data_t;
+/* dev_in: the module's input, roi_in; dev_out: the module's output, roi_out, blended in place */
+int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d,
+                                 dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
 /* ---- 3. export-pipe executor ----------------------------------------------------------- */
 /* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)
  * for an export: an ordered list of module nodes, each with its piece view and committed data,

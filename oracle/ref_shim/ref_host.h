@@ -91,6 +91,7 @@ typedef struct dt_dev_pixelpipe_iop_t
   dt_iop_roi_t buf_in, buf_out;
   dt_iop_buffer_dsc_t dsc_in, dsc_out;
   int process_cl_ready, process_tiling_ready;
+  void *blendop_data;
 } dt_dev_pixelpipe_iop_t;
 
 typedef struct dt_iop_module_t

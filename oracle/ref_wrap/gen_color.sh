@@ -23,3 +23,15 @@ $X $R/iop/filmicrgb.c $G/filmicrgb.inc INVERSE_SQRT_3 SAFETY_MARGIN CIE_Y_1931_t
   _filmic_agx_xyz_D50_to_Yrg _filmic_agx_Yrg_to_xyz_D50 _mat3_identity _filmic_agx_build_displaced \
   filmic_agx_prepare_bracket filmic_agx_compress_negatives filmic_agx filmic_sigmoid_scale \
   dt_iop_filmic_rgb_compute_spline
+$X $R/colorprofiles/iop_profile.h $G/iop_profile_xyz.inc dt_ioppr_rgb_matrix_to_xyz
+$X $R/develop/blend.h $G/blend_h.inc dt_develop_blend_colorspace_t dt_develop_blend_mode_t dt_develop_mask_mode_t \
+  dt_develop_mask_combine_mode_t dt_develop_mask_feathering_guide_t dt_develop_blendif_channels_t dt_develop_blend_params_t \
+  DEVELOP_BLENDIF_PARAMETER_ITEMS
+$X $R/develop/blend.c $G/blend_c.inc dt_develop_blendif_process_parameters dt_develop_blendif_init_masking_profile \
+  _develop_blend_process_mask_tone_curve
+$X $R/develop/blends/blendif_rgb_jzczhz.c $G/blendif_rgb_jzczhz.inc DT_BLENDIF_RGB_CH DT_BLENDIF_RGB_BCH \
+  _blendif_compute_factor _blendif_gray _blendif_rgb_red _blendif_rgb_green _blendif_rgb_blue _blendif_jzczhz \
+  _blendif_combine_channels dt_develop_blendif_rgb_jzczhz_make_mask _blend_normal _blend_multiply _blend_add _blend_subtract \
+  _blend_subtract_inverse _blend_difference _blend_divide _blend_divide_inverse _blend_average _blend_geometric_mean \
+  _blend_harmonic_mean _blend_chromaticity _blend_luminance _blend_RGB_R _blend_RGB_G _blend_RGB_B _choose_blend_func _copy_mask \
+  dt_develop_blendif_rgb_jzczhz_blend

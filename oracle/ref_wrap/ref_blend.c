@@ -1,0 +1,137 @@
+/* oracle/ref_wrap/ref_blend.c -- TEST INFRASTRUCTURE ONLY.
+ * The blend stage for the "RGB (scene)" blend colourspace.  Lifted verbatim at build time:
+ *   src/develop/blends/blendif_rgb_jzczhz.c   the parametric mask (make_mask and its channel functions)
+ *                                             and the blend operators (blend and its row functions)
+ *   src/develop/blend.c                       dt_develop_blendif_process_parameters(),
+ *                                             dt_develop_blendif_init_masking_profile(),
+ *                                             _develop_blend_process_mask_tone_curve()
+ *   src/develop/blend.h                       the parameter struct and its enums
+ * The driver below follows dt_develop_blend_process() (blend.c:657-900) for the mask sources this
+ * build supports (uniform, parametric); it contains no pixel arithmetic of its own. */
+#define REF_REAL_IMAGEBUF 1
+#include "ref_piece.h"
+#include "common/imagebuf.h"
+#include "common/colorspaces_inline_conversions.h"
+#include "math/openmp_maths.h"
+
+typedef int dt_colorspaces_color_profile_type_t;
+typedef int dt_colorspaces_color_mode_t;
+typedef enum dt_iop_color_intent_t { DT_INTENT_PERCEPTUAL = 0 } dt_iop_color_intent_t;
+#define DT_IOP_COLOR_ICC_LEN 512
+#include "gen/iop_profile.inc"
+#include "gen/iop_profile_info.inc"
+#include "gen/iop_profile_xyz.inc"
+
+typedef char dt_dev_operation_t[20];
+typedef int dt_dev_pixelpipe_display_mask_t;
+#define DT_DEV_PIXELPIPE_DISPLAY_NONE 0
+#define DT_DEV_PIXELPIPE_DISPLAY_ANY 0x3fc /* never requested here */
+typedef struct dt_iop_module_so_t dt_iop_module_so_t;
+#include "gen/blend_h.inc"
+
+/* the profile dt_develop_blendif_init_masking_profile() copies: the work profile of the pipe */
+static __thread const dt_iop_order_iccprofile_info_t *ref_blend_work_profile;
+#define dt_ioppr_get_pipe_current_profile_info(module, pipe) (ref_blend_work_profile)
+#define dt_ioppr_get_iop_work_profile_info(module, iop) (ref_blend_work_profile)
+#include "gen/blend_c.inc"
+
+/* GUI channel display is never requested on an export */
+static void _display_channel(const float *a, float *b, const float *mask, size_t stride, int channel,
+                             const float *boost, const dt_iop_order_iccprofile_info_t *profile)
+{
+  (void)a; (void)b; (void)mask; (void)stride; (void)channel; (void)boost; (void)profile;
+}
+/* the row-function type of blendif_rgb_jzczhz.c:37-38 (a function typedef, which extract.py does not lift) */
+typedef void(_blend_row_func)(const float *const restrict a, const float *const restrict b, const float p,
+                              float *const restrict out, const float *const restrict mask, const size_t stride);
+#include "gen/blendif_rgb_jzczhz.inc"
+
+/* dt_develop_blend_get_mask_usage(), blend.c:262-320: the parametric part */
+static int parametric_used(const dt_develop_blend_params_t *params)
+{
+  if(!(params->mask_mode & DEVELOP_MASK_PARAMETRIC)) return 0;
+  const float threshold_epsilon = 1e-6f;
+  const uint32_t channel_mask = params->blend_cst == DEVELOP_BLEND_CS_LAB ? DEVELOP_BLENDIF_Lab_MASK : DEVELOP_BLENDIF_RGB_MASK;
+  uint32_t active_channels = 0;
+  for(uint32_t ch = 0; ch < DEVELOP_BLENDIF_SIZE; ch++)
+  {
+    const uint32_t bit = 1u << ch;
+    if(!(channel_mask & bit) || !(params->blendif & bit)) continue;
+    const float *channel = &params->blendif_parameters[ch * 4];
+    if(fabsf(channel[0]) > threshold_epsilon || fabsf(channel[1]) > threshold_epsilon
+       || fabsf(channel[2] - 1.0f) > threshold_epsilon || fabsf(channel[3] - 1.0f) > threshold_epsilon)
+      active_channels |= bit;
+  }
+  return active_channels != 0;
+}
+
+/* `in` = the module's input (roi_in), `out` = the module's output (roi_out), blended in place */
+int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, const void *in, void *out)
+{
+  ref_reset_fp_mode();
+  if(h->blend_cst != DEVELOP_BLEND_CS_RGB_SCENE || (h->mask_mode & (DEVELOP_MASK_SHAPE | DEVELOP_MASK_RASTER))
+     || h->feathering_radius != 0.f || h->blur_radius != 0.f || h->details != 0.f)
+    return -1;
+  dt_develop_blend_params_t d;
+  memset(&d, 0, sizeof(d));
+  d.mask_mode = h->mask_mode;
+  d.blend_cst = h->blend_cst;
+  d.blend_mode = h->blend_mode;
+  d.blend_parameter = h->blend_parameter;
+  d.opacity = h->opacity;
+  d.mask_combine = h->mask_combine;
+  d.blendif = h->blendif;
+  d.contrast = h->contrast;
+  d.brightness = h->brightness;
+  memcpy(d.blendif_parameters, h->blendif_parameters, sizeof(d.blendif_parameters));
+  memcpy(d.blendif_boost_factors, h->blendif_boost_factors, sizeof(d.blendif_boost_factors));
+
+  dt_iop_order_iccprofile_info_t work;
+  static float linear[4] = { -1.0f, 0.f, 0.f, 0.f };
+  memset(&work, 0, sizeof(work));
+  work.nonlinearlut = 0;
+  work.lutsize = 0x10000;
+  for(int k = 0; k < 3; k++)
+  {
+    work.lut_in[k] = linear;
+    work.lut_out[k] = linear;
+    for(int c = 0; c < 3; c++)
+    {
+      work.matrix_in[k][c] = h->matrix_in[k][c];
+      work.matrix_in_transposed[c][k] = h->matrix_in[k][c];
+    }
+  }
+  ref_blend_work_profile = &work;
+
+  dt_iop_module_t module;
+  memset(&module, 0, sizeof(module));
+  dt_dev_pixelpipe_iop_t piece;
+  ref_fill_piece(&piece, v, NULL);
+  piece.module = &module;
+  piece.blendop_data = &d;
+  dt_dev_pixelpipe_t pipe;
+  memset(&pipe, 0, sizeof(pipe));
+  pipe.type = DT_DEV_PIXELPIPE_EXPORT;
+
+  if(!(d.mask_mode & DEVELOP_MASK_ENABLED)) return 0;
+  const int owidth = piece.roi_out.width, oheight = piece.roi_out.height;
+  const size_t buffsize = (size_t)owidth * oheight;
+  const float opacity = fminf(fmaxf(d.opacity / 100.0f, 0.0f), 1.0f);
+  float *mask = dt_pixelpipe_cache_alloc_align_float(buffsize, &pipe);
+  if(!mask) return 1;
+  if(!parametric_used(&d))
+    dt_iop_image_fill(mask, opacity, owidth, oheight, 1);
+  else
+  {
+    const float fill = (d.mask_combine & DEVELOP_COMBINE_INCL) ? 0.0f : 1.0f;
+    dt_iop_image_fill(mask, fill, owidth, oheight, 1);
+    dt_develop_blendif_rgb_jzczhz_make_mask(&pipe, &piece, (const float *)in, (const float *)out, mask);
+    /* _develop_mask_get_post_operations(), blend.c:427-469, with feathering and blur absent */
+    const int mask_tone_curve = fabsf(d.contrast) >= 0.01f || fabsf(d.brightness) >= 0.01f;
+    if(mask_tone_curve && opacity > 1e-4f)
+      _develop_blend_process_mask_tone_curve(mask, buffsize, d.contrast, d.brightness, opacity);
+  }
+  dt_develop_blendif_rgb_jzczhz_blend(&pipe, &piece, (const float *)in, (float *)out, mask, DT_DEV_PIXELPIPE_DISPLAY_NONE);
+  dt_pixelpipe_cache_free_align(mask);
+  return 0;
+}

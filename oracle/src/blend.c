@@ -1,0 +1,340 @@
+/* oracle/src/blend.c -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+ *
+ * CPU restatement of the blend stage, blend colourspace "RGB (scene)", for the mask sources the
+ * device path supports (uniform opacity, parametric mask, mask tone curve).  It follows
+ *   dt_develop_blend_process()                  src/develop/blend.c:657-900 (driver)
+ *   dt_develop_blend_get_mask_usage()           src/develop/blend.c:262-320 (is the parametric mask in use)
+ *   dt_develop_blendif_process_parameters()     src/develop/blend.c:214-260
+ *   dt_develop_blendif_init_masking_profile()   src/develop/blend.c:322-353
+ *   _develop_blend_process_mask_tone_curve()    src/develop/blend.c:626-655
+ *   dt_develop_blendif_rgb_jzczhz_make_mask()   src/develop/blends/blendif_rgb_jzczhz.c:196-324
+ *   _blendif_* channel functions                src/develop/blends/blendif_rgb_jzczhz.c:42-194
+ *   _blend_* operators, _choose_blend_func()    src/develop/blends/blendif_rgb_jzczhz.c:328-650
+ *   dt_develop_blendif_rgb_jzczhz_blend()       src/develop/blends/blendif_rgb_jzczhz.c:878-960
+ *   dt_XYZ_2_JzAzBz(), dt_JzAzBz_2_JzCzhz()     src/common/colorspaces_inline_conversions.h:672-781
+ * One pass per pixel instead of the reference's one pass per mask channel: every step is pointwise,
+ * so the order of the passes does not enter the arithmetic.
+ * Pinned by tests/test_oracle_vs_ref.py against oracle/_ref (the reference's own functions). */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PARAM_ITEMS 6 /* DEVELOP_BLENDIF_PARAMETER_ITEMS */
+#define RGB_MASK 0x77FFu
+#define LAB_MASK 0x3377u
+#define GRAY_OUT 4
+
+enum
+{
+  MODE_MULTIPLY = 0x04,
+  MODE_AVERAGE = 0x05,
+  MODE_ADD = 0x06,
+  MODE_SUBTRACT = 0x07,
+  MODE_DIFFERENCE = 0x08,
+  MODE_LIGHTNESS = 0x10,
+  MODE_CHROMATICITY = 0x11,
+  MODE_DIFFERENCE2 = 0x17,
+  MODE_RGB_R = 0x21,
+  MODE_RGB_G = 0x22,
+  MODE_RGB_B = 0x23,
+  MODE_SUBTRACT_INVERSE = 0x25,
+  MODE_DIVIDE = 0x26,
+  MODE_DIVIDE_INVERSE = 0x27,
+  MODE_GEOMETRIC_MEAN = 0x28,
+  MODE_HARMONIC_MEAN = 0x29,
+};
+
+typedef struct blend_ctx_t
+{
+  float parameters[PARAM_ITEMS * DT_HIP_BLENDIF_SIZE];
+  float luma[3];           /* matrix_in row 1 */
+  float xyz_d65_T[3][4];   /* masking profile matrix_out_transposed: RGB -> XYZ D65 */
+  unsigned blendif;        /* with the inclusive-combine inversion applied */
+} blend_ctx_t;
+
+/* _blendif_compute_factor() */
+static float compute_factor(const float value, const unsigned invert, const float *p)
+{
+  float factor;
+  if(value <= p[0]) factor = 0.0f;
+  else if(value < p[1]) factor = (value - p[0]) * p[4];
+  else if(value <= p[2]) factor = 1.0f;
+  else if(value < p[3]) factor = 1.0f - (value - p[2]) * p[5];
+  else factor = 0.0f;
+  return invert ? 1.0f - factor : factor;
+}
+
+/* dt_ioppr_rgb_matrix_to_xyz() on a linear profile + dt_XYZ_2_JzAzBz() + dt_JzAzBz_2_JzCzhz() */
+static void rgb_to_JzCzhz(const float *rgb, const float mT[3][4], float JzCzhz[3])
+{
+  const float b = 1.15f, g = 0.66f, c1 = 0.8359375f, c2 = 18.8515625f, c3 = 18.6875f, n = 0.159301758f,
+              p = 134.034375f, d = -0.56f, d0 = 1.6295499532821566e-11f;
+  static const float M[3][3] = { { 0.41478972f, 0.579999f, 0.0146480f },
+                                 { -0.2015100f, 1.120649f, 0.0531008f },
+                                 { -0.0166008f, 0.264800f, 0.6684799f } };
+  static const float A_T[3][3] = { { 0.5f, 3.524000f, 0.199076f }, { 0.5f, -4.066708f, 1.096799f }, { 0.0f, 0.542708f, -1.295875f } };
+  float D65[3];
+  for(int c = 0; c < 3; c++)
+  {
+    float o = mT[0][c] * rgb[0];
+    o = mT[1][c] * rgb[1] + o;
+    D65[c] = mT[2][c] * rgb[2] + o;
+  }
+  float XYZ[3], LMS[3], Jab[3];
+  XYZ[0] = b * D65[0] - (b - 1.0f) * D65[2];
+  XYZ[1] = g * D65[1] - (g - 1.0f) * D65[0];
+  XYZ[2] = D65[2];
+  for(int i = 0; i < 3; i++)
+  {
+    LMS[i] = M[i][0] * XYZ[0] + M[i][1] * XYZ[1] + M[i][2] * XYZ[2];
+    LMS[i] = powf(fmaxf(LMS[i] / 10000.f, 0.0f), n);
+    LMS[i] = powf((c1 + c2 * LMS[i]) / (1.0f + c3 * LMS[i]), p);
+  }
+  for(int c = 0; c < 3; c++) Jab[c] = A_T[0][c] * LMS[0] + A_T[1][c] * LMS[1] + A_T[2][c] * LMS[2];
+  Jab[0] = fmaxf(((1.0f + d) * Jab[0]) / (1.0f + d * Jab[0]) - d0, 0.f);
+  const float var_H = atan2f(Jab[2], Jab[1]) / (2.0f * 3.14159265358979324f);
+  JzCzhz[0] = Jab[0];
+  JzCzhz[1] = hypotf(Jab[1], Jab[2]);
+  JzCzhz[2] = var_H >= 0.0f ? var_H : 1.0f + var_H;
+}
+
+/* _blendif_combine_channels(): `blendif` and `params` already shifted for the output side */
+static float combine_channels(const float *px, float temp, const unsigned blendif, const float *params, const blend_ctx_t *x)
+{
+  if(blendif & 1u)
+  {
+    const float value = x->luma[0] * px[0] + x->luma[1] * px[1] + x->luma[2] * px[2];
+    temp *= compute_factor(value, (blendif >> 16) & 1u, params);
+  }
+  for(unsigned c = 1; c <= 3; c++)
+    if(blendif & (1u << c)) temp *= compute_factor(px[c - 1], (blendif >> 16) & (1u << c), params + PARAM_ITEMS * c);
+  if(blendif & ((1u << 8) | (1u << 9) | (1u << 10)))
+  {
+    float JzCzhz[3];
+    rgb_to_JzCzhz(px, x->xyz_d65_T, JzCzhz);
+    float factor = 1.0f;
+    for(unsigned i = 0; i < 3; i++)
+      factor *= compute_factor(JzCzhz[i], (blendif >> 16) & (1u << (8 + i)), params + PARAM_ITEMS * (8 + i));
+    temp *= factor;
+  }
+  return temp;
+}
+
+/* _develop_blend_process_mask_tone_curve(), one value */
+static float tone_curve(const float m, const float e, const float brightness, const float opacity)
+{
+  const float mask_epsilon = 16 * 1.19209290e-7f;
+  float x = m / opacity;
+  x = 2.f * x - 1.f;
+  if(1.f - brightness <= 0.f) x = m <= mask_epsilon ? -1.f : 1.f;
+  else if(1.f + brightness <= 0.f) x = m >= 1.f - mask_epsilon ? 1.f : -1.f;
+  else if(brightness > 0.f)
+  {
+    x = (x + brightness) / (1.f - brightness);
+    x = fminf(x, 1.f);
+  }
+  else
+  {
+    x = (x + brightness) / (1.f + brightness);
+    x = fmaxf(x, -1.f);
+  }
+  const float r = ((x * e / (1.f + (e - 1.f) * fabsf(x))) / 2.f + 0.5f) * opacity;
+  return r > 1.f ? 1.f : (r < 0.f ? 0.f : r);
+}
+
+/* the _blend_* row functions, one pixel: a = bottom layer, b = top layer, lo = local opacity */
+static void blend_pixel(const unsigned mode, const float *a, const float *b, const float p, const float lo, float *out)
+{
+  switch(mode)
+  {
+    case MODE_MULTIPLY:
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + (a[k] * b[k] * p) * lo;
+      break;
+    case MODE_AVERAGE:
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + (a[k] + b[k]) / 2.0f * lo;
+      break;
+    case MODE_ADD:
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + (a[k] + p * b[k]) * lo;
+      break;
+    case MODE_SUBTRACT:
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + fmaxf(a[k] - p * b[k], 0.0f) * lo;
+      break;
+    case MODE_SUBTRACT_INVERSE:
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + fmaxf(b[k] - p * a[k], 0.0f) * lo;
+      break;
+    case MODE_DIFFERENCE:
+    case MODE_DIFFERENCE2:
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + fabsf(a[k] - b[k]) * lo;
+      break;
+    case MODE_DIVIDE:
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + a[k] / fmaxf(p * b[k], 1e-6f) * lo;
+      break;
+    case MODE_DIVIDE_INVERSE:
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + b[k] / fmaxf(p * a[k], 1e-6f) * lo;
+      break;
+    case MODE_GEOMETRIC_MEAN:
+      /* fmax(), the double one, on a float product: the conversion back is exact */
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + sqrtf((float)fmax(a[k] * b[k], 0.0f)) * lo;
+      break;
+    case MODE_HARMONIC_MEAN:
+      for(int k = 0; k < 3; k++)
+        out[k] = a[k] * (1.0f - lo) + 2.0f * a[k] * b[k] / (fmaxf(a[k], 5e-7f) + fmaxf(b[k], 5e-7f)) * lo;
+      break;
+    case MODE_CHROMATICITY:
+    case MODE_LIGHTNESS:
+    {
+      const float norm_a = (float)fmax(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-6f);
+      const float norm_b = (float)fmax(sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]), 1e-6f);
+      if(mode == MODE_CHROMATICITY)
+        for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + b[k] * norm_a / norm_b * lo;
+      else
+        for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + a[k] * norm_b / norm_a * lo;
+      break;
+    }
+    case MODE_RGB_R:
+      out[0] = a[0] * (1.0f - lo) + p * b[0] * lo;
+      out[1] = a[1];
+      out[2] = a[2];
+      break;
+    case MODE_RGB_G:
+      out[0] = a[0];
+      out[1] = a[1] * (1.0f - lo) + p * b[1] * lo;
+      out[2] = a[2];
+      break;
+    case MODE_RGB_B:
+      out[0] = a[0];
+      out[1] = a[1];
+      out[2] = a[2] * (1.0f - lo) + p * b[2] * lo;
+      break;
+    default: /* normal */
+      for(int k = 0; k < 3; k++) out[k] = a[k] * (1.0f - lo) + b[k] * lo;
+      break;
+  }
+  out[3] = lo;
+}
+
+int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d, const void *in_, void *out_)
+{
+  if(!piece || !d || !in_ || !out_) return 1;
+  if(d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE || (d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER))
+     || d->feathering_radius != 0.f || d->blur_radius != 0.f || d->details != 0.f || piece->channels != 4)
+    return 1;
+  if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return 0;
+  const float *in = (const float *)in_;
+  float *out = (float *)out_;
+  const int xoffs = piece->roi_out.x - piece->roi_in.x, yoffs = piece->roi_out.y - piece->roi_in.y;
+  const int iwidth = piece->roi_in.width, iheight = piece->roi_in.height;
+  const int owidth = piece->roi_out.width, oheight = piece->roi_out.height;
+  if(piece->roi_out.scale != piece->roi_in.scale || xoffs < 0 || yoffs < 0
+     || ((xoffs > 0 || yoffs > 0) && (owidth + xoffs > iwidth || oheight + yoffs > iheight)))
+    return 0; /* "skipped blending: roi's do not match", blend.c:697-702 */
+
+  const float opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f);
+
+  /* dt_develop_blend_get_mask_usage(): parametric part */
+  int parametric = 0;
+  if(d->mask_mode & DT_HIP_MASK_PARAMETRIC)
+    for(unsigned ch = 0; ch < DT_HIP_BLENDIF_SIZE; ch++)
+    {
+      const unsigned bit = 1u << ch;
+      if(!(RGB_MASK & bit) || !(d->blendif & bit)) continue;
+      const float *c = &d->blendif_parameters[ch * 4];
+      if(fabsf(c[0]) > 1e-6f || fabsf(c[1]) > 1e-6f || fabsf(c[2] - 1.0f) > 1e-6f || fabsf(c[3] - 1.0f) > 1e-6f) parametric = 1;
+    }
+
+  /* make_mask(): which of its three cases */
+  const unsigned any_channel_active = d->blendif & RGB_MASK;
+  const unsigned mask_inclusive = d->mask_combine & DT_HIP_COMBINE_INCL;
+  const unsigned mask_inversed = d->mask_combine & DT_HIP_COMBINE_INV;
+  const unsigned blendif = d->blendif ^ (mask_inclusive ? RGB_MASK << 16 : 0);
+  const unsigned canceling_channel = (blendif >> 16) & ~blendif & RGB_MASK;
+  const float global_opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f);
+  const float seed = mask_inclusive ? 0.0f : 1.0f; /* the form mask of a parametric-only blend, blend.c:749-757 */
+  int kind; /* 0 uniform, 1 constant after make_mask, 2 per pixel */
+  float constant = opacity;
+  if(!parametric) kind = 0;
+  else if(!canceling_channel && !any_channel_active)
+  {
+    kind = 1;
+    constant = mask_inversed ? global_opacity * (1.0f - seed) : seed * global_opacity;
+  }
+  else if(canceling_channel || !any_channel_active)
+  {
+    kind = 1;
+    constant = ((mask_inversed == 0) ^ (mask_inclusive == 0)) ? global_opacity : 0.0f;
+  }
+  else kind = 2;
+
+  blend_ctx_t x;
+  memset(&x, 0, sizeof(x));
+  x.blendif = blendif;
+  if(kind == 2)
+  {
+    /* dt_develop_blendif_process_parameters() */
+    for(size_t i = 0, j = 0; i < DT_HIP_BLENDIF_SIZE; i++, j += PARAM_ITEMS)
+    {
+      float *p = x.parameters + j;
+      if(d->blendif & (1u << i))
+      {
+        const float *bp = d->blendif_parameters + i * 4;
+        const float boost = exp2f(d->blendif_boost_factors[i]);
+        const float offset = 0.0f; /* 0.5 for the a/b channels of the Lab colourspace only */
+        for(int k = 0; k < 4; k++) p[k] = (bp[k] - offset) * boost;
+        p[4] = 1.0f / fmaxf(0.001f, p[1] - p[0]);
+        p[5] = 1.0f / fmaxf(0.001f, p[3] - p[2]);
+        if(bp[0] <= 0.0f && bp[1] <= 0.0f) p[0] = p[1] = -INFINITY;
+        if(bp[2] >= 1.0f && bp[3] >= 1.0f) p[2] = p[3] = INFINITY;
+      }
+      else
+      {
+        p[0] = p[1] = -INFINITY;
+        p[2] = p[3] = INFINITY;
+        p[4] = p[5] = 0.0f;
+      }
+    }
+    /* dt_develop_blendif_init_masking_profile(): Bradford D50 -> D65 times the profile's RGB -> XYZ */
+    static const float Mb[3][3] = { { 0.9555766f, -0.0230393f, 0.0631636f },
+                                    { -0.0282895f, 1.0099416f, 0.0210077f },
+                                    { 0.0122982f, -0.0204830f, 1.3299098f } };
+    for(int y = 0; y < 3; y++)
+      for(int c = 0; c < 3; c++)
+      {
+        float sum = 0.0f;
+        for(int i = 0; i < 3; i++) sum += Mb[y][i] * d->matrix_in[i][c];
+        x.xyz_d65_T[c][y] = sum;
+      }
+    for(int c = 0; c < 3; c++) x.luma[c] = d->matrix_in[1][c];
+  }
+
+  const int tone = parametric && (fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f;
+  const float e = expf(3.f * d->contrast);
+  const float p = exp2f(d->blend_parameter);
+  const unsigned mode = d->blend_mode & 0xFFu;
+  const int reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
+
+#pragma omp parallel for schedule(static)
+  for(int y = 0; y < oheight; y++)
+    for(int xx = 0; xx < owidth; xx++)
+    {
+      const float *a = in + ((size_t)(y + yoffs) * iwidth + xoffs + xx) * 4;
+      float *bo = out + ((size_t)y * owidth + xx) * 4;
+      const float b[4] = { bo[0], bo[1], bo[2], bo[3] };
+      float m = constant;
+      if(kind == 2)
+      {
+        float temp = 1.0f;
+        temp = combine_channels(a, temp, x.blendif, x.parameters, &x);
+        temp = combine_channels(b, temp, x.blendif >> GRAY_OUT, x.parameters + PARAM_ITEMS * GRAY_OUT, &x);
+        if(mask_inclusive)
+          m = mask_inversed ? global_opacity * (1.0f - seed) * temp : global_opacity * (1.0f - (1.0f - seed) * temp);
+        else
+          m = mask_inversed ? global_opacity * (1.0f - seed * temp) : global_opacity * seed * temp;
+      }
+      if(tone) m = tone_curve(m, e, d->brightness, opacity);
+      if(reverse) blend_pixel(mode, b, a, p, m, bo);
+      else blend_pixel(mode, a, b, p, m, bo);
+    }
+  return 0;
+}

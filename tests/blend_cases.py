@@ -1,0 +1,72 @@
+"""Parameter sets for the blend-stage tests (CPU: oracle vs oracle/_ref; GPU: HIP vs oracle)."""
+import numpy as np
+
+from ansel_amd import abi, params, synth
+
+M = params.WORK_IN  # work profile RGB -> XYZ(D50)
+
+
+def images(w, h, seed, iw=None, ih=None):
+    """(module input, module output): two related scene-referred frames with negatives, values above 1,
+    exact zeros and a few non-finite pixels"""
+    iw, ih = iw or w, ih or h
+    a = synth.rgba_image(iw, ih, seed=seed, lo=-0.02, hi=2.5)
+    rng = np.random.default_rng(seed + 100)
+    b = synth.rgba_image(w, h, seed=seed + 1, lo=-0.02, hi=2.5)
+    b[..., :3] = 0.6 * b[..., :3] + 0.4 * a[:h, :w, :3] * rng.uniform(0.5, 1.8, size=(h, w, 1)).astype(np.float32)
+    a[3, 5, :3] = 0.0
+    b[4, 6, :3] = 0.0
+    b[7, 2, 1] = 0.0
+    a[9, 9, 0] = np.inf
+    b[11, 3, 2] = np.nan
+    a[..., 3] = 0.25
+    b[..., 3] = 0.75
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def cases():
+    out = []
+    for mode in abi.BLEND_RGB_SCENE_MODES:
+        out.append(("uniform-%02x" % mode, abi.BlendData.uniform(M, opacity=63.0, blend_mode=mode, blend_parameter=0.7)))
+    out.append(("uniform-reverse-multiply", abi.BlendData.uniform(M, 40.0, abi.BLEND_MULTIPLY | abi.BLEND_REVERSE, -1.3)))
+    out.append(("uniform-reverse-normal", abi.BlendData.uniform(M, 100.0, abi.BLEND_NORMAL | abi.BLEND_REVERSE)))
+    out.append(("uniform-full", abi.BlendData.uniform(M, 100.0)))
+    out.append(("uniform-zero", abi.BlendData.uniform(M, 0.0)))
+    out.append(("uniform-over", abi.BlendData.uniform(M, 130.0, abi.BLEND_ADD, 1.0)))
+    # parametric: one channel at a time, input and output side
+    for ch, tr in ((abi.BLENDIF_GRAY_in, (0.05, 0.2, 0.6, 0.9)), (abi.BLENDIF_RED_in, (0.0, 0.0, 0.5, 0.8)),
+                   (abi.BLENDIF_GREEN_in, (0.1, 0.3, 1.0, 1.0)), (abi.BLENDIF_BLUE_in, (0.2, 0.2001, 0.7, 0.7002)),
+                   (abi.BLENDIF_GRAY_out, (0.1, 0.4, 0.8, 1.0)), (abi.BLENDIF_RED_out, (0.3, 0.5, 1.0, 1.0)),
+                   (abi.BLENDIF_GREEN_out, (0.0, 0.0, 0.4, 0.6)), (abi.BLENDIF_BLUE_out, (0.05, 0.1, 0.9, 0.95)),
+                   (abi.BLENDIF_Jz_in, (0.1, 0.3, 0.7, 0.9)), (abi.BLENDIF_Cz_in, (0.0, 0.0, 0.3, 0.6)),
+                   (abi.BLENDIF_hz_in, (0.2, 0.35, 0.6, 0.8)), (abi.BLENDIF_Jz_out, (0.2, 0.4, 1.0, 1.0)),
+                   (abi.BLENDIF_Cz_out, (0.1, 0.2, 0.5, 0.7)), (abi.BLENDIF_hz_out, (0.0, 0.0, 0.5, 0.55))):
+        boost = {abi.BLENDIF_GRAY_in: 1.0, abi.BLENDIF_Jz_in: -5.0, abi.BLENDIF_Cz_in: -6.5, abi.BLENDIF_Jz_out: -5.0,
+                 abi.BLENDIF_Cz_out: -6.5}.get(ch, 0.0)
+        out.append(("param-ch%d" % ch, abi.BlendData.uniform(M, 85.0).channel(ch, *tr, boost=boost)))
+        out.append(("param-ch%d-inv" % ch, abi.BlendData.uniform(M, 85.0, abi.BLEND_AVERAGE).channel(ch, *tr, invert=True, boost=boost)))
+    # several channels, every combine mode, with and without the tone curve
+    for combine in (0, abi.COMBINE_INV, abi.COMBINE_INCL, abi.COMBINE_INV | abi.COMBINE_INCL):
+        for contrast, brightness in ((0.0, 0.0), (0.4, -0.3), (-0.5, 0.6), (0.2, 1.0), (0.0, -1.0)):
+            d = abi.BlendData.uniform(M, 72.0, abi.BLEND_NORMAL)
+            d.channel(abi.BLENDIF_GRAY_in, 0.05, 0.25, 0.7, 1.0, boost=1.5)
+            d.channel(abi.BLENDIF_BLUE_out, 0.0, 0.0, 0.6, 0.9, invert=True)
+            d.channel(abi.BLENDIF_Jz_in, 0.05, 0.2, 1.0, 1.0, boost=-4.0)
+            d.channel(abi.BLENDIF_hz_out, 0.1, 0.3, 0.8, 0.95)
+            d.mask_combine = combine
+            d.contrast = contrast
+            d.brightness = brightness
+            out.append(("multi-c%d-%g-%g" % (combine, contrast, brightness), d))
+    # a channel that is switched on with the full range and inverted cancels the mask (make_mask's second case)
+    d = abi.BlendData.uniform(M, 55.0).channel(abi.BLENDIF_GRAY_in, 0.1, 0.2, 0.8, 0.9)
+    d.blendif |= 1 << (16 + abi.BLENDIF_RED_in)
+    out.append(("canceling", d))
+    d = abi.BlendData.uniform(M, 55.0).channel(abi.BLENDIF_GRAY_in, 0.1, 0.2, 0.8, 0.9)
+    d.blendif |= 1 << (16 + abi.BLENDIF_RED_in)
+    d.mask_combine = abi.COMBINE_INCL
+    out.append(("canceling-incl", d))
+    # the mask is disabled: nothing happens
+    d = abi.BlendData.uniform(M, 50.0)
+    d.mask_mode = 0
+    out.append(("disabled", d))
+    return out

@@ -29,6 +29,10 @@ void devmath_powf(const float *x, const float *y, float *o, size_t n) { for(size
 void devmath_log2f(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::log2f_exact(x[i]); }
 void devmath_exp2f(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::exp2f_exact(x[i]); }
 void devmath_expf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::expf_exact(x[i]); }
+void devmath_atan2f(const float *y, const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::atan2f_exact(y[i], x[i]); }
+void devmath_hypotf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::hypotf_exact(x[i], y[i]); }
+void libm_atan2f(const float *y, const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = atan2f(y[i], x[i]); }
+void libm_hypotf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = hypotf(x[i], y[i]); }
 void libm_powf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = powf(x[i], y[i]); }
 void libm_log2f(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = log2f(x[i]); }
 void libm_exp2f(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = exp2f(x[i]); }
@@ -61,6 +65,16 @@ int main(int argc, char **argv)
       else if(mode == 2) { a = rnd_range(0.f, 1.f); b = rnd_range(-3.f, 3.f); }
       else { a = fabsf(rnd_bits()); b = rnd_range(-8.f, 8.f); }
       r0 = powf(a, b); r1 = ansel_math::powf_exact(a, b);
+    }
+    else if(!strcmp(fn, "atan2f") || !strcmp(fn, "hypotf"))
+    {
+      // mode 0: arbitrary bit patterns; 1: chroma-like small components; 2: one operand dominating; 3: around the axes
+      if(mode == 0) { a = rnd_bits(); b = rnd_bits(); }
+      else if(mode == 1) { a = rnd_range(-0.5f, 0.5f); b = rnd_range(-0.5f, 0.5f); }
+      else if(mode == 2) { a = rnd_range(-1e-3f, 1e-3f); b = rnd_range(-200.f, 200.f); if(i & 4) { const float t = a; a = b; b = t; } }
+      else { a = rnd_range(-2.f, 2.f); b = (i & 4) ? 1.0f : ((i & 8) ? 0.0f : -0.0f); if(i & 16) { const float t = a; a = b; b = t; } }
+      if(!strcmp(fn, "atan2f")) { r0 = atan2f(a, b); r1 = ansel_math::atan2f_exact(a, b); }
+      else { r0 = hypotf(a, b); r1 = ansel_math::hypotf_exact(a, b); }
     }
     else if(!strcmp(fn, "log2f"))
     {

@@ -1,4 +1,4 @@
-"""not gpu: the host build of ansel_amd/csrc/devmath.h (the restated glibc powf/log2f/exp2f/expf)
+"""not gpu: the host build of ansel_amd/csrc/devmath.h (the restated glibc powf/log2f/exp2f/expf/atan2f/hypotf)
 returns the bits of this machine's libm on every argument tried, including arbitrary bit patterns."""
 import os
 import subprocess
@@ -17,7 +17,7 @@ def harness(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("fn", ["powf", "log2f", "exp2f", "expf"])
+@pytest.mark.parametrize("fn", ["powf", "log2f", "exp2f", "expf", "atan2f", "hypotf"])
 def test_restated_libm_is_bit_exact(harness, fn):
     out = subprocess.run([harness, fn, "6000000", "7"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr

@@ -1,0 +1,72 @@
+"""-m gpu: the blend stage (RGB (scene): uniform / parametric mask, tone curve, sixteen operators) through the
+C-ABI, bit for bit against the oracle and the reference's own functions."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import blend_cases
+import checkers as ck
+import hipcheck as hc
+from ansel_amd import abi, lib
+
+pytestmark = pytest.mark.gpu
+CASES = blend_cases.cases()
+
+
+def _check(piece, d, a, b, what):
+    got = hc.run_hip("dt_hip_develop_blend_process", piece, d, a, b.shape, pre_fill=b)
+    want = b.copy()
+    assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, want) == 0
+    diff = ck.ulp_diff(got, want)
+    assert int((diff > 0).sum()) == 0, "%s: %d values differ, max %d ulp" % (what, int((diff > 0).sum()), int(diff.max()))
+    ref = ck.ref()
+    if ref is not None:
+        r = b.copy()
+        assert ck.call(ref, "ref_develop_blend", piece, d, a, r) == 0
+        assert int((ck.ulp_diff(got, r) > 0).sum()) == 0, what + " (vs reference)"
+    return got
+
+
+@pytest.mark.parametrize("name,d", CASES, ids=[c[0] for c in CASES])
+def test_blend(name, d):
+    w, h = 131, 67
+    a, b = blend_cases.images(w, h, 41)
+    got = _check(abi.Piece.make(w, h), d, a, b, name)
+    if name.startswith("param") or name == "multi-c0-0-0":
+        # the parametric masks of the test set are real ones: some pixels in, some out, some in between
+        m = got[..., 3][np.isfinite(got[..., 3])]
+        assert m.min() < m.max(), name
+
+
+def test_blend_roi_offset():
+    w, h, iw, ih = 90, 50, 120, 70
+    a, b = blend_cases.images(w, h, 43, iw, ih)
+    piece = abi.Piece.make(w, h, roi_in=abi.Roi.make(10, 20, iw, ih, 1.0), roi_out=abi.Roi.make(25, 31, w, h, 1.0))
+    d = abi.BlendData.uniform(blend_cases.M, 70.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.3, 0.8, 1.0)
+    _check(piece, d, a, b, "roi offset")
+
+
+def test_blend_full_frame():
+    """24 MP, every kind of channel active"""
+    w, h = 6000, 4000
+    a, b = blend_cases.images(w, h, 47)
+    d = dict(CASES)["multi-c0-0.4--0.3"]
+    _check(abi.Piece.make(w, h), d, a, b, "24 MP")
+
+
+@pytest.mark.parametrize("field,value", [("blend_cst", 2), ("feathering_radius", 5.0), ("blur_radius", 3.0), ("details", 0.5),
+                                         ("mask_mode", abi.MASK_ENABLED | abi.MASK_SHAPE),
+                                         ("mask_mode", abi.MASK_ENABLED | abi.MASK_RASTER)])
+def test_blend_refuses_what_is_not_built(field, value):
+    """never an approximation: unsupported mask sources and colourspaces are an error"""
+    w, h = 32, 16
+    a, b = blend_cases.images(w, h, 3)
+    d = abi.BlendData.uniform(blend_cases.M, 50.0)
+    setattr(d, field, value)
+    h_ = hc.hip()
+    da, db = lib.DeviceBuffer.from_numpy(0, a), lib.DeviceBuffer.from_numpy(0, b)
+    rc = h_.dt_hip_develop_blend_process(0, C.byref(abi.Piece.make(w, h)), C.byref(d), da.ptr, db.ptr)
+    assert rc == -997  # DT_HIP_INVALID_ARG
+    assert h_.dt_hip_finish(0) == 1
+    assert np.array_equal(db.to_numpy(b.shape, np.float32).view(np.uint32), b.view(np.uint32))

@@ -28,12 +28,16 @@ def _args(n, seed):
     return np.ascontiguousarray(x), np.ascontiguousarray(y)
 
 
-@pytest.mark.parametrize("fn", ["powf", "log2f", "exp2f", "expf"])
+@pytest.mark.parametrize("fn", ["powf", "log2f", "exp2f", "expf", "atan2f", "hypotf"])
 def test_device_libm_matches_host_libm(fn):
     n = 2_000_000
     x, y = _args(n, 17)
     if fn == "exp2f":
         x = np.concatenate([x[:n], np.random.default_rng(3).random(2 * n, dtype=np.float32) * 300.0 - 160.0])
+    if fn in ("atan2f", "hypotf"):
+        rng = np.random.default_rng(5)
+        x = np.concatenate([x[:n], (rng.random(n, dtype=np.float32) - 0.5).astype(np.float32), (rng.random(n, dtype=np.float32) * 2e-3 - 1e-3).astype(np.float32)])
+        y = np.concatenate([y[:n], (rng.random(n, dtype=np.float32) - 0.5).astype(np.float32), (rng.random(n, dtype=np.float32) * 400.0 - 200.0).astype(np.float32)])
     if fn == "expf":
         x = np.concatenate([x[:n], np.random.default_rng(4).random(2 * n, dtype=np.float32) * 205.0 - 110.0])
     h = hc.hip()
@@ -47,7 +51,10 @@ def test_device_libm_matches_host_libm(fn):
     got = do.to_numpy(x.shape, np.float32)
     exp = np.empty_like(x)
     hl = _hostlib()
-    if fn == "powf":
+    if fn in ("atan2f", "hypotf"):
+        # first operand of the hook is y for atan2f(y, x)
+        getattr(hl, "libm_" + fn)(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+    elif fn == "powf":
         hl.libm_powf(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
     else:
         getattr(hl, "libm_" + fn)(x.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))

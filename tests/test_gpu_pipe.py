@@ -155,3 +155,85 @@ def test_full_config3_pipe_with_nlmeans():
     host_nodes = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, filmic=filmic.default_data(),
                                          with_nlmeans=True)
     assert np.array_equal(fused, _run_cpu("oracle", host_nodes, raw, w, h))
+
+
+def _blended_nodes(w, h, lut_ptr, lut, coeffs):
+    """the light pipe with a uniform 60 % multiply blend on exposure and a parametric mask (grey + Jz in, hue
+    out, tone curve) on color calibration"""
+    nodes = _nodes(w, h, lut_ptr, lut, coeffs)
+    rgb = abi.Piece.make(w, h, channels=4, processed_maximum=synth.WB_COEFFS)
+    out = []
+    for n in nodes:
+        out.append(n)
+        if n.op == "exposure":
+            out.append(pipe.Node("blend", abi.BlendData.uniform(params.WORK_IN, 60.0, abi.BLEND_MULTIPLY, 0.5), rgb))
+        if n.op == "channelmixerrgb":
+            d = abi.BlendData.uniform(params.WORK_IN, 80.0)
+            d.channel(abi.BLENDIF_GRAY_in, 0.02, 0.15, 0.6, 0.9, boost=1.0)
+            d.channel(abi.BLENDIF_Jz_in, 0.05, 0.2, 1.0, 1.0, boost=-4.0)
+            d.channel(abi.BLENDIF_hz_out, 0.1, 0.3, 0.8, 0.95)
+            d.contrast, d.brightness = 0.3, -0.2
+            out.append(pipe.Node("blend", d, rgb))
+    return out
+
+
+def _run_cpu_blended(nodes, raw, w, h):
+    """the oracle chain with the blend stage: blend(input of the module, output of the module) in place"""
+    o = ck.oracle()
+    src, prev = raw, None
+    for n in nodes:
+        if n.op == "export_u16":
+            out = np.zeros((h, w, 4), np.uint16)
+            o.oracle_export_convert_u16(w, h, ck.ptr(src), ck.ptr(out))
+            return out
+        if n.op == "blend":
+            assert ck.call(o, "oracle_develop_blend", n.piece, n.data, np.ascontiguousarray(prev), src) == 0
+            continue
+        dst = np.zeros((h, w) if n.op in ("rawprepare", "temperature", "highlights") else (h, w, 4), np.float32)
+        assert ck.call(o, "oracle_" + n.op, n.piece, n.data, np.ascontiguousarray(src), dst) == 0, n.op
+        prev, src = src, dst
+
+
+def test_executor_runs_the_blend_stage():
+    """a blended module is not fused with its neighbours (its input and output both exist as buffers), the
+    blend runs in place in its output, and the result is the oracle's"""
+    w, h = 640, 400
+    raw, lut, d_lut, coeffs = _setup(w, h, seed=9)
+    nodes = _blended_nodes(w, h, d_lut.ptr, lut, coeffs)
+    fused, g1 = _run_executor(nodes, raw, w, h, fusion=True)
+    unfused, g0 = _run_executor(nodes, raw, w, h, fusion=False)
+    # raw chain | rcd | exposure | blend | colorin | calibration | blend | filmic, colorout, u16
+    assert g0 == len(nodes) and g1 == 8, (g0, g1)
+    assert np.array_equal(fused, unfused)
+    host_nodes = _blended_nodes(w, h, lut.ctypes.data, lut, coeffs)
+    cpu = _run_cpu_blended(host_nodes, raw, w, h)
+    diff = (cpu != fused).any(axis=-1)
+    assert not diff.any(), "%d pixels differ" % int(diff.sum())
+    plain, _ = _run_executor(_nodes(w, h, d_lut.ptr, lut, coeffs), raw, w, h, fusion=True)
+    assert not np.array_equal(plain, fused)
+
+
+def test_executor_blend_as_last_node_and_misplaced():
+    w, h = 64, 48
+    hc.hip()
+    img = synth.rgba_image(w, h, seed=2, lo=0.0, hi=1.5)
+    rgb = abi.Piece.make(w, h, channels=4)
+    nodes = [pipe.Node("exposure", abi.ExposureData(0.01, 1.7), rgb),
+             pipe.Node("blend", abi.BlendData.uniform(params.WORK_IN, 35.0, abi.BLEND_AVERAGE), rgb)]
+    din = lib.DeviceBuffer.from_numpy(0, img)
+    dout = lib.DeviceBuffer(0, w * h * 16)
+    p = pipe.DevicePipe(0, nodes, fusion=True)
+    p.process(din.ptr, dout.ptr)
+    assert lib.load().dt_hip_finish(0) == 1
+    got = dout.to_numpy((h, w, 4), np.float32)
+    p.close()
+    o = ck.oracle()
+    mid = np.zeros_like(img)
+    assert ck.call(o, "oracle_exposure", rgb, nodes[0].data, img, mid) == 0
+    assert ck.call(o, "oracle_develop_blend", rgb, nodes[1].data, img, mid) == 0
+    assert int((ck.ulp_diff(got, mid) > 0).sum()) == 0
+    # a blend node with no module in front of it is an error, not a no-op
+    p = pipe.DevicePipe(0, nodes[1:], fusion=True)
+    with pytest.raises(lib.AnselHipError):
+        p.process(din.ptr, dout.ptr)
+    p.close()

@@ -371,3 +371,36 @@ def test_bilat_local_laplacian(w, h, hl, sh, detail, mid):
     assert ck.call(o, "oracle_bilat", abi.Piece.make(w, h), d, img, b) == 0
     _exact(a, b, "local laplacian")
     assert np.all(b[..., 3] == -5.0) and float(np.abs(b[..., 0] - img[..., 0]).max()) > 1e-3
+
+
+import blend_cases
+
+
+@pytest.mark.parametrize("name,d", blend_cases.cases(), ids=[c[0] for c in blend_cases.cases()])
+def test_develop_blend(name, d):
+    """the blend stage, RGB (scene): uniform and parametric masks, tone curve, every operator"""
+    w, h = 131, 67
+    a, b = blend_cases.images(w, h, 41)
+    piece = abi.Piece.make(w, h)
+    r, o = ck.ref(), ck.oracle()
+    x, y = b.copy(), b.copy()
+    assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
+    assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
+    _exact(x, y, "blend " + name)
+    if name == "disabled":
+        assert np.array_equal(x.view(np.uint32), b.view(np.uint32))
+    elif name != "uniform-zero":
+        assert not np.array_equal(x.view(np.uint32), b.view(np.uint32))
+
+
+def test_develop_blend_roi_offset():
+    """module input larger than its output (roi_in contains roi_out at an offset), blend.c:683-702"""
+    w, h, iw, ih = 90, 50, 120, 70
+    a, b = blend_cases.images(w, h, 43, iw, ih)
+    piece = abi.Piece.make(w, h, roi_in=abi.Roi.make(10, 20, iw, ih, 1.0), roi_out=abi.Roi.make(25, 31, w, h, 1.0))
+    d = abi.BlendData.uniform(blend_cases.M, 70.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.3, 0.8, 1.0)
+    r, o = ck.ref(), ck.oracle()
+    x, y = b.copy(), b.copy()
+    assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
+    assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
+    _exact(x, y, "blend roi offset")
