@@ -133,4 +133,11 @@ def cases(lut_ptrs=None):
     yield ("bilat", "bilat", rgb, abi.BilatData.bilateral(12.0, 10.0, 0.5), lab, lab.shape)
     yield ("denoiseprofile_nlmeans", "denoiseprofile", dpiece,
            params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS), dimg, dimg.shape)
+    # the blend stage: `inp` carries (module input, module output); the output is blended in place
+    import blend_cases
+    ba, bb = blend_cases.images(W, H, 41)
+    pair = np.ascontiguousarray(np.stack([ba, bb]))
+    bc = dict(blend_cases.cases())
+    for nm in ("uniform-18", "uniform-reverse-multiply", "param-ch0", "param-ch10-inv", "multi-c1-0.4--0.3", "multi-c2--0.5-0.6"):
+        yield ("blend_" + nm, "develop_blend", rgb, bc[nm], pair, (H, W, 4))
     del keep

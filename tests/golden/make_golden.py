@@ -31,6 +31,9 @@ def main():
         res = np.zeros(shape, np.float32)
         # modules with a thread-count dependent reduction are recorded single-threaded
         r.ref_set_num_threads(1 if (op in cases.SINGLE_THREAD_OPS or name in cases.SINGLE_THREAD_NAMES) else threads)
+        if op == "develop_blend":  # in place: (module input, module output)
+            res[...] = inp[1]
+            inp = inp[0]
         assert ck.call(r, "ref_" + op, piece, data, np.ascontiguousarray(inp), res) == 0, name
         out[name] = res
     r.ref_set_num_threads(threads)
