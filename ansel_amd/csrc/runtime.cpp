@@ -14,6 +14,7 @@
 //     HBM: we never need to give memory back between frames).
 #include "hip_common.h"
 
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 #include <map>
@@ -354,6 +355,27 @@ int dt_hip_read_host_from_device_rowpitch(int devid, void *host, dt_hip_mem_t de
 int dt_hip_read_host_from_device(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp)
 {
   return dt_hip_read_host_from_device_rowpitch(devid, host, device, width, height, bpp, (size_t)width * bpp, 1);
+}
+
+// process() of iop/basebuffer.c:118-160: crop-copy of the sensor buffer into the first cacheline
+int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iwidth, int iheight, int bpp,
+                                  const void *host_full, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !piece || !host_full || !dev_out || iwidth <= 0 || iheight <= 0 || bpp <= 0)
+    return DT_HIP_INVALID_ARG;
+  const size_t x = piece->roi_out.x > 0 ? (size_t)piece->roi_out.x : 0, y = piece->roi_out.y > 0 ? (size_t)piece->roi_out.y : 0;
+  if(piece->roi_out.width <= 0 || piece->roi_out.height <= 0 || x >= (size_t)iwidth || y >= (size_t)iheight)
+    return DT_HIP_SUCCESS;
+  const size_t in_width = std::min((size_t)piece->roi_out.width, (size_t)iwidth - x);
+  const size_t in_height = std::min((size_t)piece->roi_out.height, (size_t)iheight - y);
+  const size_t in_stride = (size_t)iwidth * bpp, out_stride = (size_t)piece->roi_out.width * bpp;
+  const size_t row_bytes = std::min(in_width * bpp, out_stride);
+  const char *src = (const char *)host_full + y * in_stride + x * bpp;
+  hipStream_t s = stream_of(devid);
+  launch_scope ls(devid, "[Write Image (from host to device)]");
+  ANSEL_HIP_CHECK(hipMemcpy2DAsync(dev_out, out_stride, src, in_stride, row_bytes, in_height, hipMemcpyHostToDevice, s));
+  ANSEL_HIP_CHECK(hipStreamSynchronize(s)); // the source is the caller's memory
+  return DT_HIP_SUCCESS;
 }
 
 int dt_hip_enqueue_copy_buffer_to_buffer(int devid, dt_hip_mem_t src, dt_hip_mem_t dst, size_t srcoffset,

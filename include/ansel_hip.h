@@ -408,6 +408,14 @@ typedef struct dt_hip_finalscale_data_t
 int dt_hip_iop_finalscale_process(int devid, const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d,
                                   dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
+/* basebuffer: process(), src/iop/basebuffer.c:118-160 -- the first node of every pipe copies the region
+ * roi_out of the full sensor buffer (host memory of the mipmap cache, iwidth x iheight pixels of bpp bytes,
+ * unpadded rows) into the pipe's first cacheline.  On the device that is the frame's upload: one 2-D
+ * host-to-device copy on the device's stream (PCIe; excluded from every HBM roofline figure).  Rows and
+ * columns of roi_out beyond the sensor are left untouched, as the reference leaves them. */
+int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iwidth, int iheight, int bpp,
+                                  const void *host_full, dt_hip_mem_t dev_out);
+
 /* ---- 2b. the blend stage ---------------------------------------------------------------- */
 /* dt_develop_blend_process(), src/develop/blend.c:657-965: what the pixelpipe runs after the
  * process() of every blending-capable module (src/develop/pixelpipe_cpu.c:137-228) -- build the
