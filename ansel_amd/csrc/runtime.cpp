@@ -357,6 +357,33 @@ int dt_hip_read_host_from_device(int devid, void *host, dt_hip_mem_t device, int
   return dt_hip_read_host_from_device_rowpitch(devid, host, device, width, height, bpp, (size_t)width * bpp, 1);
 }
 
+void *dt_hip_alloc_host_pinned(size_t size)
+{
+  void *p = NULL;
+  if(size == 0 || hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return NULL;
+  }
+  return p;
+}
+
+void dt_hip_free_host_pinned(void *host)
+{
+  if(host) (void)hipHostFree(host);
+}
+
+int dt_hip_is_pinned_memory(const void *host)
+{
+  hipPointerAttribute_t attr;
+  if(!host || hipPointerGetAttributes(&attr, host) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
 // process() of iop/basebuffer.c:118-160: crop-copy of the sensor buffer into the first cacheline
 int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iwidth, int iheight, int bpp,
                                   const void *host_full, dt_hip_mem_t dev_out)

@@ -79,6 +79,9 @@ def load():
         "dt_hip_iop_finalscale_process": (i, [i, P(abi.Piece), P(abi.FinalscaleData), vp, vp]),
         "dt_hip_develop_blend_process": (i, [i, P(abi.Piece), P(abi.BlendData), vp, vp]),
         "dt_hip_iop_basebuffer_process": (i, [i, P(abi.Piece), i, i, i, vp, vp]),
+        "dt_hip_alloc_host_pinned": (vp, [sz]),
+        "dt_hip_free_host_pinned": (None, [vp]),
+        "dt_hip_is_pinned_memory": (i, [vp]),
         "dt_hip_iop_diffuse_tiling": (None, [P(abi.Piece), P(abi.DiffuseData), P(abi.Tiling)]),
         "dt_hip_export_convert_u16": (i, [i, i, i, vp, vp]),
         "dt_hip_export_convert_u8": (i, [i, i, i, vp, vp]),

@@ -169,7 +169,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ansel_amd import lib, params, pipe, synth, tiled
+    from ansel_amd import abi, lib, params, pipe, synth, tiled
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -253,6 +253,27 @@ def main():
     for i in range(min(nk, maxk)):
         kernels[tags[i].decode()] = {"ms_avg": ms[i] / max(cnt[i], 1), "launches": cnt[i]}
 
+    # ---- the same step with the boundary's two PCIe legs (never `value`): sensor buffer in pinned host memory ->
+    #      basebuffer upload -> pipe -> exported frame back into pinned host memory
+    host_ms = None
+    if rank == 0 and world == 1 and args.mode == "batch":
+        nb_in, nb_out = raw_host.nbytes, npix * 8
+        pin_in, pin_out = l.dt_hip_alloc_host_pinned(nb_in), l.dt_hip_alloc_host_pinned(nb_out)
+        if pin_in and pin_out:
+            C.memmove(pin_in, raw_host.ctypes.data, nb_in)
+            full = abi.Piece.make(width, height, channels=1, datatype=abi.DT_HIP_TYPE_UINT16)
+            times = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                lib.check(l.dt_hip_iop_basebuffer_process(devid, C.byref(full), width, height, 2, pin_in, raw.data_ptr()), "basebuffer")
+                executor.process(raw.data_ptr(), out16.data_ptr())
+                lib.check(l.dt_hip_read_host_from_device(devid, pin_out, out16.data_ptr(), width, height, 8), "read")
+                times.append(time.perf_counter() - t1)
+            host_ms = min(times) * 1e3
+        l.dt_hip_free_host_pinned(pin_in)
+        l.dt_hip_free_host_pinned(pin_out)
+
     if rank == 0:
         # algorithmic bytes per pixel of each tagged kernel
         tag_bpp = {"rawprepare_1f": 6, "temperature_1f": 8, "highlights_clip_1f": 8, "rcd_tiles": 20,
@@ -301,6 +322,8 @@ def main():
                 "pipe_kernel_ms": round(kernel_ms, 4),
                 "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(kernels.items())},
                 "kernel_launches_per_step": {k: v["launches"] // args.steps for k, v in sorted(kernels.items())},
+                # not `value`: one frame from pinned host memory to pinned host memory over PCIe, no overlap
+                "host_to_host_ms": None if host_ms is None else round(host_ms, 3),
             },
             "roofline": {
                 "bound": "hbm",

@@ -105,6 +105,13 @@ dt_hip_mem_t dt_hip_alloc_device_buffer(int devid, size_t size);
 void dt_hip_release_mem_object(dt_hip_mem_t mem);
 size_t dt_hip_get_mem_object_size(dt_hip_mem_t mem);
 void dt_hip_memory_statistics(int devid, size_t *current, size_t *peak); /* opencl.h:648 */
+/* page-locked host memory for the two ends of an export (the sensor buffer going up, the exported frame
+ * coming down): the peer of the reference's pinned transfer buffers (dt_opencl_use_pinned_memory(),
+ * CL_MEM_ALLOC_HOST_PTR in dt_opencl_alloc_device_use_host_pointer(), opencl.h:541-561, 650-651).
+ * Copies from / to such memory run at PCIe rate and can be non-blocking. */
+void *dt_hip_alloc_host_pinned(size_t size);
+void dt_hip_free_host_pinned(void *host);
+int dt_hip_is_pinned_memory(const void *host);
 
 /* copies: dt_opencl_write_host_to_device / read_host_from_device (+_rowpitch,
  * _non_blocking) and enqueue_copy_* (opencl.h:473-537).  rowpitch in bytes. */
