@@ -21,13 +21,22 @@ struct chain_args
   fargs filmic;
 };
 
+// offset of the by-value chain_args in the kernarg segment of rgb_chain(): after two pointers and a size_t
+constexpr int CHAIN_ARGS_KERNARG_OFFSET = 24;
 constexpr int CM_NONE = -1;
 constexpr int FM_NONE = -1;
 
 template <int CM, int FM>
 __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, void *__restrict__ out,
-                                                  const size_t npixels, const chain_args a)
+                                                  const size_t npixels, const chain_args a_by_value)
 {
+  // The ~340 dwords of parameters are read where they are used, straight from the kernarg segment: as a
+  // by-value argument they are all loaded in the entry block, 3x more than there are scalar registers, and
+  // come back one v_readlane at a time (162 SGPRs spilled, ~500 lane moves in the instruction stream).
+  typedef const chain_args __attribute__((address_space(4))) *kernarg_t;
+  const chain_args &a = *(const chain_args *)(kernarg_t)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr()
+                                                         + CHAIN_ARGS_KERNARG_OFFSET);
+  (void)a_by_value;
   // one pixel per thread: the ~250 uniform parameters of the five stages are then used once per wave
   // instead of staying live across a grid-stride loop (which spilled 770 SGPRs to VGPR lanes)
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
