@@ -256,8 +256,10 @@ __device__ __forceinline__ float4 blend_pixel(const unsigned mode, const float4 
 }
 
 template <bool PARAMETRIC>
-__global__ __launch_bounds__(256) void blend_rgb_scene(const float4 *__restrict__ in, float4 *__restrict__ out, const blend_args a)
+__global__ __launch_bounds__(256) void blend_rgb_scene(const float4 *__restrict__ in, float4 *__restrict__ out, const blend_args a_by_value)
 {
+  const blend_args &a = kernarg_at<blend_args>(16); // after the two pointers
+  (void)a_by_value;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= (size_t)a.owidth * a.oheight) return;
   const int y = (int)(k / a.owidth), x = (int)(k - (size_t)y * a.owidth);

@@ -25,8 +25,10 @@ namespace
 
 template <int MODE, bool EXPORT>
 __global__ __launch_bounds__(256) void filmic_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                      const size_t npixels, const fargs a)
+                                                      const size_t npixels, const fargs a_by_value)
 {
+  const fargs &a = kernarg_at<fargs>(24); // after two pointers and a size_t (hip_common.h)
+  (void)a_by_value;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
   if(k < npixels)
     nt_store(out + k, px_filmicrgb<MODE>(in[k], a, EXPORT));

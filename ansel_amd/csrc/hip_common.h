@@ -62,6 +62,17 @@ __device__ __forceinline__ void nt_store(float4 *p, const float4 v)
   __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p));
 }
 
+// A large by-value kernel argument, read in place from the kernarg segment at its byte offset.  As a
+// by-value argument every field is loaded in the kernel's entry block; a struct of a few hundred dwords then
+// exceeds the ~100 scalar registers and comes back one v_readlane at a time (rgb_chain: 162 SGPRs spilled,
+// 4.95 -> 4.35 ms once the fields are loaded where they are used).  The argument stays in the signature so
+// that the host marshals it; the kernel must not name it.
+template <typename T> __device__ __forceinline__ const T &kernarg_at(const int offset)
+{
+  typedef const T __attribute__((address_space(4))) *p4;
+  return *(const T *)(p4)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+
 // Journal of the highlight-clip pass (pointwise.hip, pipe_fused.hip): number of photosites above the
 // threshold and the first 25 of them {index in the output buffer, unclipped value}.  In band mode
 // the leading count is summed over all bands before highlights_resolve_launch() decides the bypass.

@@ -30,12 +30,8 @@ template <int CM, int FM>
 __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, void *__restrict__ out,
                                                   const size_t npixels, const chain_args a_by_value)
 {
-  // The ~340 dwords of parameters are read where they are used, straight from the kernarg segment: as a
-  // by-value argument they are all loaded in the entry block, 3x more than there are scalar registers, and
-  // come back one v_readlane at a time (162 SGPRs spilled, ~500 lane moves in the instruction stream).
-  typedef const chain_args __attribute__((address_space(4))) *kernarg_t;
-  const chain_args &a = *(const chain_args *)(kernarg_t)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr()
-                                                         + CHAIN_ARGS_KERNARG_OFFSET);
+  // the ~340 dwords of parameters are read where they are used (hip_common.h kernarg_at())
+  const chain_args &a = kernarg_at<chain_args>(CHAIN_ARGS_KERNARG_OFFSET);
   (void)a_by_value;
   // one pixel per thread: the ~250 uniform parameters of the five stages are then used once per wave
   // instead of staying live across a grid-stride loop (which spilled 770 SGPRs to VGPR lanes)
