@@ -240,6 +240,15 @@ BLENDIF_Jz_out, BLENDIF_Cz_out, BLENDIF_hz_out = 12, 13, 14
 MASK_ENABLED, MASK_SHAPE, MASK_PARAMETRIC, MASK_RASTER = 1, 2, 4, 8
 COMBINE_INV, COMBINE_INCL = 1, 2
 BLEND_CS_RGB_SCENE = 4
+BLEND_CS_LAB = 2
+# the operators of the "Lab" colourspace (src/develop/blends/blendif_lab.c:1070-1160) built on the device;
+# chroma 0x11, hue 0x12, color 0x13 and coloradjust 0x16 go through LCh and are refused
+BLEND_LAB_MODES = (0x18, 0x19, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x17, 0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x0E, 0x0F,
+                   0x10, 0x1A, 0x1B, 0x1E, 0x1F, 0x20)
+BLEND_LAB_REFUSED = (0x11, 0x12, 0x13, 0x16)
+# dt_develop_blendif_channels_t, Lab names
+BLENDIF_L_in, BLENDIF_A_in, BLENDIF_B_in, BLENDIF_C_in, BLENDIF_h_in = 0, 1, 2, 8, 9
+BLENDIF_L_out, BLENDIF_A_out, BLENDIF_B_out, BLENDIF_C_out, BLENDIF_h_out = 4, 5, 6, 12, 13
 
 
 class BlendData(C.Structure):
@@ -252,12 +261,12 @@ class BlendData(C.Structure):
                 ("blendif_parameters", C.c_float * 64), ("blendif_boost_factors", C.c_float * 16), ("matrix_in", m34)]
 
     @classmethod
-    def uniform(cls, matrix_in, opacity=100.0, blend_mode=BLEND_NORMAL, blend_parameter=0.0):
+    def uniform(cls, matrix_in, opacity=100.0, blend_mode=BLEND_NORMAL, blend_parameter=0.0, blend_cst=BLEND_CS_RGB_SCENE):
         """dt_develop_blend_init_blend_parameters() (blend.c:173-212) with a uniform mask: every channel's
         trapezoid is the whole range {0, 0, 1, 1}"""
         d = cls()
         d.mask_mode = MASK_ENABLED
-        d.blend_cst = BLEND_CS_RGB_SCENE
+        d.blend_cst = blend_cst
         d.blend_mode = blend_mode
         d.blend_parameter = blend_parameter
         d.opacity = opacity

@@ -1,4 +1,5 @@
-// blend.hip -- the blend stage on gfx950: opacity mask and blend operator in ONE pass.
+// blend.hip -- the blend stage on gfx950 (blend colourspaces "RGB (scene)" and "Lab"): opacity mask and
+// blend operator in ONE pass.
 //
 // Reference: dt_develop_blend_process(), src/develop/blend.c:657-900, which runs after the process()
 // of every blending-capable module (src/develop/pixelpipe_cpu.c:137-228): fill / build the mask
@@ -27,6 +28,7 @@ namespace
 
 #define PARAM_ITEMS 6 // DEVELOP_BLENDIF_PARAMETER_ITEMS
 #define RGB_MASK 0x77FFu
+#define LAB_MASK 0x3377u
 #define GRAY_OUT 4
 
 enum
@@ -255,8 +257,199 @@ __device__ __forceinline__ float4 blend_pixel(const unsigned mode, const float4 
   return make_float4(o[0], o[1], o[2], lo);
 }
 
-template <bool PARAMETRIC>
-__global__ __launch_bounds__(256) void blend_rgb_scene(const float4 *__restrict__ in, float4 *__restrict__ out, const blend_args a_by_value)
+
+// ---- Lab (src/develop/blends/blendif_lab.c) -----------------------------------------------------
+enum
+{
+  LAB_LIGHTEN = 0x02, LAB_DARKEN = 0x03, LAB_MULTIPLY = 0x04, LAB_AVERAGE = 0x05, LAB_ADD = 0x06, LAB_SUBTRACT = 0x07,
+  LAB_DIFFERENCE = 0x08, LAB_SCREEN = 0x09, LAB_OVERLAY = 0x0A, LAB_SOFTLIGHT = 0x0B, LAB_HARDLIGHT = 0x0C,
+  LAB_VIVIDLIGHT = 0x0D, LAB_LINEARLIGHT = 0x0E, LAB_PINLIGHT = 0x0F, LAB_LIGHTNESS = 0x10, LAB_CHROMATICITY = 0x11,
+  LAB_HUE = 0x12, LAB_COLOR = 0x13, LAB_COLORADJUST = 0x16, LAB_DIFFERENCE2 = 0x17, LAB_BOUNDED = 0x19,
+  LAB_LAB_LIGHTNESS = 0x1A, LAB_LAB_COLOR = 0x1B, LAB_LAB_L = 0x1E, LAB_LAB_A = 0x1F, LAB_LAB_B = 0x20,
+};
+
+// _blendif_combine_channels() of blendif_lab.c:139-173: L / 100, a / 256, b / 256, and C, h of dt_Lab_2_LCH()
+// (src/common/colorspaces_inline_conversions.h:594-606)
+template <int OUT> __device__ __forceinline__ float combine_channels_lab(const float4 px, float temp, const blend_args &a)
+{
+  const unsigned blendif = OUT ? a.blendif >> GRAY_OUT : a.blendif; // uniform
+  const float *const params = a.parameters + (OUT ? PARAM_ITEMS * GRAY_OUT : 0);
+  if(blendif & 1u) temp *= compute_factor(px.x / 100.0f, (blendif >> 16) & 1u, params);
+  if(blendif & 2u) temp *= compute_factor(px.y / 256.0f, (blendif >> 16) & 2u, params + PARAM_ITEMS * 1);
+  if(blendif & 4u) temp *= compute_factor(px.z / 256.0f, (blendif >> 16) & 4u, params + PARAM_ITEMS * 2);
+  if(blendif & ((1u << 8) | (1u << 9)))
+  {
+    const float c_scale = 1.0f / (128.0f * 1.41421354f); // 1.0f / (128.0f * sqrtf(2.0f))
+    float var_H = ansel_math::atan2f_exact(px.z, px.y);
+    if(var_H > 0.0f) var_H = var_H / (2.0f * 3.14159265358979324f);
+    else var_H = 1.0f - fabsf(var_H) / (2.0f * 3.14159265358979324f);
+    const float C = ansel_math::hypotf_exact(px.y, px.z);
+    float factor = 1.0f;
+    factor *= compute_factor(C * c_scale, (blendif >> 16) & (1u << 8), params + PARAM_ITEMS * 8);
+    factor *= compute_factor(var_H, (blendif >> 16) & (1u << 9), params + PARAM_ITEMS * 9);
+    temp *= factor;
+  }
+  return temp;
+}
+
+__device__ __forceinline__ float CL(const float x, const float lo, const float hi) { return fminf(fmaxf(x, lo), hi); } // _CLAMP()
+
+// the _blend_* row functions of blendif_lab.c:320-1068, one pixel: a = bottom, b = top layer
+__device__ __forceinline__ float4 blend_pixel_lab(const unsigned mode, const float4 a4, const float4 b4, const float lo)
+{
+  const float min[3] = { 0.0f, -1.0f, -1.0f }, max[3] = { 1.0f, 1.0f, 1.0f };
+  const float scale[3] = { 1 / 100.0f, 1 / 128.0f, 1 / 128.0f }, rescale[3] = { 100.0f, 128.0f, 128.0f };
+  const float a[3] = { a4.x, a4.y, a4.z }, b[3] = { b4.x, b4.y, b4.z };
+  float ta[3], tb[3];
+#pragma unroll
+  for(int c = 0; c < 3; c++)
+  {
+    ta[c] = a[c] * scale[c];
+    tb[c] = b[c] * scale[c];
+  }
+  const float lo2 = lo * lo;
+  // the lightness-based operators work on L shifted into [0, lmax]
+  const float lmin = 0.0f, lmax = max[0] + fabsf(min[0]);
+  const float la = CL(ta[0] + fabsf(min[0]), lmin, lmax), lb = CL(tb[0] + fabsf(min[0]), lmin, lmax);
+  const float halfmax = lmax / 2.0f, doublemax = lmax * 2.0f;
+  const float f = fmaxf(ta[0], 0.01f);
+  bool chroma_follows = false; // a, b scaled by the lightness ratio with opacity lo2 (overlay .. linearlight)
+  switch(mode)
+  {
+    case LAB_BOUNDED:
+#pragma unroll
+      for(int x = 0; x < 3; x++) tb[x] = CL(ta[x] * (1.0f - lo) + tb[x] * lo, min[x], max[x]);
+      break;
+    case LAB_LIGHTEN:
+    case LAB_DARKEN:
+    {
+      const float pick = mode == LAB_LIGHTEN ? (ta[0] > tb[0] ? ta[0] : tb[0]) : (ta[0] < tb[0] ? ta[0] : tb[0]);
+      tb[0] = CL(ta[0] * (1.0f - lo) + pick * lo, min[0], max[0]);
+      tb[1] = CL(ta[1] * (1.0f - fabsf(tb[0] - ta[0])) + 0.5f * (ta[1] + tb[1]) * fabsf(tb[0] - ta[0]), min[1], max[1]);
+      tb[2] = CL(ta[2] * (1.0f - fabsf(tb[0] - ta[0])) + 0.5f * (ta[2] + tb[2]) * fabsf(tb[0] - ta[0]), min[2], max[2]);
+      break;
+    }
+    case LAB_MULTIPLY:
+      tb[0] = CL(ta[0] * (1.0f - lo) + (ta[0] * tb[0]) * lo, min[0], max[0]);
+      tb[1] = CL(ta[1] * (1.0f - lo) + (ta[1] + tb[1]) * tb[0] / f * lo, min[1], max[1]);
+      tb[2] = CL(ta[2] * (1.0f - lo) + (ta[2] + tb[2]) * tb[0] / f * lo, min[2], max[2]);
+      break;
+    case LAB_AVERAGE:
+#pragma unroll
+      for(int x = 0; x < 3; x++) tb[x] = CL(ta[x] * (1.0f - lo) + (ta[x] + tb[x]) / 2.0f * lo, min[x], max[x]);
+      break;
+    case LAB_ADD:
+#pragma unroll
+      for(int x = 0; x < 3; x++) tb[x] = CL(ta[x] * (1.0f - lo) + (ta[x] + tb[x]) * lo, min[x], max[x]);
+      break;
+    case LAB_SUBTRACT:
+#pragma unroll
+      for(int x = 0; x < 3; x++)
+        tb[x] = CL(ta[x] * (1.0f - lo) + ((tb[x] + ta[x]) - (fabsf(min[x] + max[x]))) * lo, min[x], max[x]);
+      break;
+    case LAB_DIFFERENCE:
+#pragma unroll
+      for(int x = 0; x < 3; x++)
+      {
+        const float xmax = max[x] + fabsf(min[x]);
+        const float xa = CL(ta[x] + fabsf(min[x]), lmin, xmax), xb = CL(tb[x] + fabsf(min[x]), lmin, xmax);
+        tb[x] = CL(xa * (1.0f - lo) + fabsf(xa - xb) * lo, lmin, xmax) - fabsf(min[x]);
+      }
+      break;
+    case LAB_DIFFERENCE2:
+#pragma unroll
+      for(int x = 0; x < 3; x++) tb[x] = fabsf(ta[x] - tb[x]) / fabsf(max[x] - min[x]);
+      tb[0] = fmaxf(tb[0], fmaxf(tb[1], tb[2]));
+      tb[0] = CL(ta[0] * (1.0f - lo) + tb[0] * lo, min[0], max[0]);
+      tb[1] = 0.0f;
+      tb[2] = 0.0f;
+      break;
+    case LAB_SCREEN:
+      tb[0] = CL(la * (1.0f - lo) + ((lmax - (lmax - la) * (lmax - lb))) * lo, lmin, lmax) - fabsf(min[0]);
+      tb[1] = CL(ta[1] * (1.0f - lo) + 0.5f * (ta[1] + tb[1]) * tb[0] / f * lo, min[1], max[1]);
+      tb[2] = CL(ta[2] * (1.0f - lo) + 0.5f * (ta[2] + tb[2]) * tb[0] / f * lo, min[2], max[2]);
+      break;
+    case LAB_OVERLAY:
+      tb[0] = CL(la * (1.0f - lo2)
+                     + (la > halfmax ? lmax - (lmax - doublemax * (la - halfmax)) * (lmax - lb) : (doublemax * la) * lb) * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      chroma_follows = true;
+      break;
+    case LAB_SOFTLIGHT:
+      tb[0] = CL(la * (1.0f - lo2) + (lb > halfmax ? lmax - (lmax - la) * (lmax - (lb - halfmax)) : la * (lb + halfmax)) * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      chroma_follows = true;
+      break;
+    case LAB_HARDLIGHT:
+      tb[0] = CL(la * (1.0f - lo2)
+                     + (lb > halfmax ? lmax - (lmax - doublemax * (la - halfmax)) * (lmax - lb) : doublemax * la * lb) * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      chroma_follows = true;
+      break;
+    case LAB_VIVIDLIGHT:
+      tb[0] = CL(la * (1.0f - lo2)
+                     + (lb > halfmax ? (lb >= lmax ? lmax : la / (doublemax * (lmax - lb)))
+                                     : (lb <= lmin ? lmin : lmax - (lmax - la) / (doublemax * lb)))
+                           * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      chroma_follows = true;
+      break;
+    case LAB_LINEARLIGHT:
+      tb[0] = CL(la * (1.0f - lo2) + (la + doublemax * lb - lmax) * lo2, lmin, lmax) - fabsf(min[0]);
+      chroma_follows = true;
+      break;
+    case LAB_PINLIGHT:
+      tb[0] = CL(la * (1.0f - lo2) + (lb > halfmax ? fmaxf(la, doublemax * (lb - halfmax)) : fminf(la, doublemax * lb)) * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      tb[1] = CL(ta[1], min[1], max[1]);
+      tb[2] = CL(ta[2], min[2], max[2]);
+      break;
+    case LAB_LIGHTNESS:
+      tb[0] = CL(ta[0] * (1.0f - lo) + tb[0] * lo, min[0], max[0]);
+      tb[1] = CL(ta[1], min[1], max[1]);
+      tb[2] = CL(ta[2], min[2], max[2]);
+      break;
+    case LAB_LAB_LIGHTNESS:
+    case LAB_LAB_L:
+      tb[0] = ta[0] * (1.0f - lo) + tb[0] * lo;
+      tb[1] = ta[1];
+      tb[2] = ta[2];
+      break;
+    case LAB_LAB_A:
+      tb[0] = ta[0];
+      tb[1] = ta[1] * (1.0f - lo) + tb[1] * lo;
+      tb[2] = ta[2];
+      break;
+    case LAB_LAB_B:
+      tb[0] = ta[0];
+      tb[1] = ta[1];
+      tb[2] = ta[2] * (1.0f - lo) + tb[2] * lo;
+      break;
+    case LAB_LAB_COLOR:
+      tb[0] = ta[0];
+      tb[1] = ta[1] * (1.0f - lo) + tb[1] * lo;
+      tb[2] = ta[2] * (1.0f - lo) + tb[2] * lo;
+      break;
+    default: // normal, unbounded
+#pragma unroll
+      for(int x = 0; x < 3; x++) tb[x] = ta[x] * (1.0f - lo) + tb[x] * lo;
+      break;
+  }
+  if(chroma_follows)
+  {
+    tb[1] = CL(ta[1] * (1.0f - lo2) + (ta[1] + tb[1]) * tb[0] / f * lo2, min[1], max[1]);
+    tb[2] = CL(ta[2] * (1.0f - lo2) + (ta[2] + tb[2]) * tb[0] / f * lo2, min[2], max[2]);
+  }
+  return make_float4(tb[0] * rescale[0], tb[1] * rescale[1], tb[2] * rescale[2], lo);
+}
+
+template <bool LAB, bool PARAMETRIC>
+__global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, const blend_args a_by_value)
 {
   const blend_args &a = kernarg_at<blend_args>(16); // after the two pointers
   (void)a_by_value;
@@ -269,15 +462,25 @@ __global__ __launch_bounds__(256) void blend_rgb_scene(const float4 *__restrict_
   if(PARAMETRIC)
   {
     float temp = 1.0f;
-    temp = combine_channels<0>(pa, temp, a);
-    temp = combine_channels<1>(pb, temp, a);
+    if(LAB)
+    {
+      temp = combine_channels_lab<0>(pa, temp, a);
+      temp = combine_channels_lab<1>(pb, temp, a);
+    }
+    else
+    {
+      temp = combine_channels<0>(pa, temp, a);
+      temp = combine_channels<1>(pb, temp, a);
+    }
     if(a.inclusive)
       m = a.inversed ? a.global_opacity * (1.0f - a.seed) * temp : a.global_opacity * (1.0f - (1.0f - a.seed) * temp);
     else
       m = a.inversed ? a.global_opacity * (1.0f - a.seed * temp) : a.global_opacity * a.seed * temp;
     if(a.tone) m = tone_curve(m, a);
   }
-  const float4 r = a.reverse ? blend_pixel(a.mode, pb, pa, a.p, m) : blend_pixel(a.mode, pa, pb, a.p, m);
+  float4 r;
+  if(LAB) r = a.reverse ? blend_pixel_lab(a.mode, pb, pa, m) : blend_pixel_lab(a.mode, pa, pb, m);
+  else r = a.reverse ? blend_pixel(a.mode, pb, pa, a.p, m) : blend_pixel(a.mode, pa, pb, a.p, m);
   nt_store(out + k, r);
 }
 
@@ -287,11 +490,22 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
                                             dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
-  if(d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE)
+  const bool lab = d->blend_cst == DT_HIP_BLEND_CS_LAB;
+  if(d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab)
   {
-    set_last_error("blend: colourspace %d is not built (only RGB (scene), %d)", d->blend_cst, DT_HIP_BLEND_CS_RGB_SCENE);
+    set_last_error("blend: colourspace %d is not built (RGB (scene) %d and Lab %d are)", d->blend_cst,
+                   DT_HIP_BLEND_CS_RGB_SCENE, DT_HIP_BLEND_CS_LAB);
     return DT_HIP_INVALID_ARG;
   }
+  {
+    const unsigned m = d->blend_mode & 0xFFu;
+    if(lab && (m == LAB_CHROMATICITY || m == LAB_HUE || m == LAB_COLOR || m == LAB_COLORADJUST))
+    {
+      set_last_error("blend: the Lab operators through LCh (chroma, hue, color, coloradjust) are not built");
+      return DT_HIP_INVALID_ARG;
+    }
+  }
+  const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
   if(piece->channels != 4) return DT_HIP_INVALID_ARG;
   if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->blur_radius != 0.f
      || d->details != 0.f)
@@ -321,17 +535,17 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     for(unsigned ch = 0; ch < DT_HIP_BLENDIF_SIZE; ch++)
     {
       const unsigned bit = 1u << ch;
-      if(!(RGB_MASK & bit) || !(d->blendif & bit)) continue;
+      if(!(CH_MASK & bit) || !(d->blendif & bit)) continue;
       const float *c = &d->blendif_parameters[ch * 4];
       if(fabsf(c[0]) > 1e-6f || fabsf(c[1]) > 1e-6f || fabsf(c[2] - 1.0f) > 1e-6f || fabsf(c[3] - 1.0f) > 1e-6f)
         parametric = true;
     }
   // make_mask(), blendif_rgb_jzczhz.c:196-324: which of its three cases
-  const unsigned any_channel_active = d->blendif & RGB_MASK;
+  const unsigned any_channel_active = d->blendif & CH_MASK;
   const unsigned mask_inclusive = d->mask_combine & DT_HIP_COMBINE_INCL;
   const unsigned mask_inversed = d->mask_combine & DT_HIP_COMBINE_INV;
-  const unsigned blendif = d->blendif ^ (mask_inclusive ? RGB_MASK << 16 : 0);
-  const unsigned canceling_channel = (blendif >> 16) & ~blendif & RGB_MASK;
+  const unsigned blendif = d->blendif ^ (mask_inclusive ? CH_MASK << 16 : 0);
+  const unsigned canceling_channel = (blendif >> 16) & ~blendif & CH_MASK;
   const float global_opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f); // clamp_simd()
   const float seed = mask_inclusive ? 0.0f : 1.0f; // the form mask of a parametric-only blend, blend.c:749-757
   bool per_pixel = false;
@@ -367,7 +581,8 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
       {
         const float *bp = d->blendif_parameters + i * 4;
         const float boost = exp2f(d->blendif_boost_factors[i]);
-        for(int k = 0; k < 4; k++) p[k] = (bp[k] - 0.0f) * boost;
+        const float offset = (lab && (i == 1 || i == 2 || i == 5 || i == 6)) ? 0.5f : 0.0f; // Lab a, b in / out
+        for(int k = 0; k < 4; k++) p[k] = (bp[k] - offset) * boost;
         p[4] = 1.0f / fmaxf(0.001f, p[1] - p[0]);
         p[5] = 1.0f / fmaxf(0.001f, p[3] - p[2]);
         if(bp[0] <= 0.0f && bp[1] <= 0.0f) p[0] = p[1] = -INFINITY;
@@ -397,11 +612,13 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   const size_t np = (size_t)a.owidth * a.oheight;
   hipStream_t s = stream_of(devid);
   {
-    launch_scope ls(devid, "blend_rgb_scene");
-    if(per_pixel)
-      blend_rgb_scene<true><<<pixel_grid(np), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, a);
-    else
-      blend_rgb_scene<false><<<pixel_grid(np), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, a);
+    launch_scope ls(devid, "blend_kernel");
+    const float4 *const in = (const float4 *)dev_in;
+    float4 *const out = (float4 *)dev_out;
+    if(lab && per_pixel) blend_kernel<true, true><<<pixel_grid(np), 256, 0, s>>>(in, out, a);
+    else if(lab) blend_kernel<true, false><<<pixel_grid(np), 256, 0, s>>>(in, out, a);
+    else if(per_pixel) blend_kernel<false, true><<<pixel_grid(np), 256, 0, s>>>(in, out, a);
+    else blend_kernel<false, false><<<pixel_grid(np), 256, 0, s>>>(in, out, a);
   }
-  return check_launch("blend_rgb_scene");
+  return check_launch("blend_kernel");
 }

@@ -35,3 +35,12 @@ $X $R/develop/blends/blendif_rgb_jzczhz.c $G/blendif_rgb_jzczhz.inc DT_BLENDIF_R
   _blend_subtract_inverse _blend_difference _blend_divide _blend_divide_inverse _blend_average _blend_geometric_mean \
   _blend_harmonic_mean _blend_chromaticity _blend_luminance _blend_RGB_R _blend_RGB_G _blend_RGB_B _choose_blend_func _copy_mask \
   dt_develop_blendif_rgb_jzczhz_blend
+$X $R/colorprofiles/iop_profile.h $G/iop_profile_lab.inc dt_ioppr_rgb_matrix_to_lab
+$X $R/develop/blends/blendif_lab.c $G/blendif_lab.inc DT_BLENDIF_LAB_CH DT_BLENDIF_LAB_BCH _CLAMP _CLAMP_XYZ \
+  _blendif_compute_factor _blendif_lab_l _blendif_lab_a _blendif_lab_b _blendif_lch _blendif_combine_channels \
+  dt_develop_blendif_lab_make_mask _blend_Lab_scale _blend_Lab_rescale _blend_normal_bounded _blend_normal_unbounded \
+  _blend_lighten _blend_darken _blend_multiply _blend_average _blend_add _blend_subtract _blend_difference \
+  _blend_difference2 _blend_screen _blend_overlay _blend_softlight _blend_hardlight _blend_vividlight \
+  _blend_linearlight _blend_pinlight _blend_lightness _blend_chromaticity _blend_hue _blend_color _blend_coloradjust \
+  _blend_Lab_lightness _blend_Lab_a _blend_Lab_b _blend_Lab_color _choose_blend_func _copy_mask \
+  dt_develop_blendif_lab_blend

@@ -1,7 +1,7 @@
 /* oracle/src/blend.c -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
  *
- * CPU restatement of the blend stage, blend colourspace "RGB (scene)", for the mask sources the
- * device path supports (uniform opacity, parametric mask, mask tone curve).  It follows
+ * CPU restatement of the blend stage, blend colourspaces "RGB (scene)" and "Lab", for the mask sources
+ * the device path supports (uniform opacity, parametric mask, mask tone curve).  It follows
  *   dt_develop_blend_process()                  src/develop/blend.c:657-900 (driver)
  *   dt_develop_blend_get_mask_usage()           src/develop/blend.c:262-320 (is the parametric mask in use)
  *   dt_develop_blendif_process_parameters()     src/develop/blend.c:214-260
@@ -12,6 +12,10 @@
  *   _blend_* operators, _choose_blend_func()    src/develop/blends/blendif_rgb_jzczhz.c:328-650
  *   dt_develop_blendif_rgb_jzczhz_blend()       src/develop/blends/blendif_rgb_jzczhz.c:878-960
  *   dt_XYZ_2_JzAzBz(), dt_JzAzBz_2_JzCzhz()     src/common/colorspaces_inline_conversions.h:672-781
+ *   Lab: make_mask, channel functions, operators, blend   src/develop/blends/blendif_lab.c:56-300, :302-1068, :1302-1420
+ *   dt_Lab_2_LCH()                              src/common/colorspaces_inline_conversions.h:594-606
+ * (the four Lab operators that go through LCh -- chroma, hue, color, coloradjust -- are not restated: the
+ * device path refuses them)
  * One pass per pixel instead of the reference's one pass per mask channel: every step is pointwise,
  * so the order of the passes does not enter the arithmetic.
  * Pinned by tests/test_oracle_vs_ref.py against oracle/_ref (the reference's own functions). */
@@ -215,12 +219,200 @@ static void blend_pixel(const unsigned mode, const float *a, const float *b, con
   out[3] = lo;
 }
 
+/* ---- Lab ---------------------------------------------------------------------------------------- */
+enum
+{
+  LAB_LIGHTEN = 0x02, LAB_DARKEN = 0x03, LAB_MULTIPLY = 0x04, LAB_AVERAGE = 0x05, LAB_ADD = 0x06, LAB_SUBTRACT = 0x07,
+  LAB_DIFFERENCE = 0x08, LAB_SCREEN = 0x09, LAB_OVERLAY = 0x0A, LAB_SOFTLIGHT = 0x0B, LAB_HARDLIGHT = 0x0C,
+  LAB_VIVIDLIGHT = 0x0D, LAB_LINEARLIGHT = 0x0E, LAB_PINLIGHT = 0x0F, LAB_LIGHTNESS = 0x10, LAB_CHROMATICITY = 0x11,
+  LAB_HUE = 0x12, LAB_COLOR = 0x13, LAB_COLORADJUST = 0x16, LAB_DIFFERENCE2 = 0x17, LAB_BOUNDED = 0x19,
+  LAB_LAB_LIGHTNESS = 0x1A, LAB_LAB_COLOR = 0x1B, LAB_LAB_L = 0x1E, LAB_LAB_A = 0x1F, LAB_LAB_B = 0x20,
+};
+
+static int lab_mode_supported(const unsigned mode)
+{
+  return mode != LAB_CHROMATICITY && mode != LAB_HUE && mode != LAB_COLOR && mode != LAB_COLORADJUST;
+}
+
+/* _blendif_combine_channels() of blendif_lab.c:139-173 */
+static float combine_channels_lab(const float *px, float temp, const unsigned blendif, const float *params)
+{
+  if(blendif & 1u) temp *= compute_factor(px[0] / 100.0f, (blendif >> 16) & 1u, params);
+  if(blendif & 2u) temp *= compute_factor(px[1] / 256.0f, (blendif >> 16) & 2u, params + PARAM_ITEMS * 1);
+  if(blendif & 4u) temp *= compute_factor(px[2] / 256.0f, (blendif >> 16) & 4u, params + PARAM_ITEMS * 2);
+  if(blendif & ((1u << 8) | (1u << 9)))
+  {
+    const float c_scale = 1.0f / (128.0f * sqrtf(2.0f));
+    /* dt_Lab_2_LCH() */
+    float var_H = atan2f(px[2], px[1]);
+    if(var_H > 0.0f) var_H = var_H / (2.0f * 3.14159265358979324f);
+    else var_H = 1.0f - fabsf(var_H) / (2.0f * 3.14159265358979324f);
+    const float C = hypotf(px[1], px[2]);
+    float factor = 1.0f;
+    factor *= compute_factor(C * c_scale, (blendif >> 16) & (1u << 8), params + PARAM_ITEMS * 8);
+    factor *= compute_factor(var_H, (blendif >> 16) & (1u << 9), params + PARAM_ITEMS * 9);
+    temp *= factor;
+  }
+  return temp;
+}
+
+static float CL(const float x, const float lo, const float hi) { return fminf(fmaxf(x, lo), hi); } /* _CLAMP() */
+
+/* the _blend_* row functions of blendif_lab.c:320-1068, one pixel: a = bottom layer, b = top layer */
+static void blend_pixel_lab(const unsigned mode, const float *a, const float *b, const float lo, float *out)
+{
+  static const float min[4] = { 0.0f, -1.0f, -1.0f, 0.0f }, max[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+  static const float scale[3] = { 1 / 100.0f, 1 / 128.0f, 1 / 128.0f }, rescale[3] = { 100.0f, 128.0f, 128.0f };
+  float ta[3], tb[3];
+  for(int c = 0; c < 3; c++)
+  {
+    ta[c] = a[c] * scale[c];
+    tb[c] = b[c] * scale[c];
+  }
+  const float lo2 = lo * lo;
+  /* the lightness-based operators work on L shifted into [0, lmax] */
+  const float lmin = 0.0f, lmax = max[0] + fabsf(min[0]);
+  const float la = CL(ta[0] + fabsf(min[0]), lmin, lmax), lb = CL(tb[0] + fabsf(min[0]), lmin, lmax);
+  const float halfmax = lmax / 2.0f, doublemax = lmax * 2.0f;
+  const float f = fmaxf(ta[0], 0.01f);
+  int chroma_follows = 0; /* a, b scaled by the lightness ratio with opacity lo2 (overlay .. linearlight) */
+  switch(mode)
+  {
+    case LAB_BOUNDED:
+      for(int x = 0; x < 3; x++) tb[x] = CL(ta[x] * (1.0f - lo) + tb[x] * lo, min[x], max[x]);
+      break;
+    case LAB_LIGHTEN:
+    case LAB_DARKEN:
+    {
+      const float pick = mode == LAB_LIGHTEN ? (ta[0] > tb[0] ? ta[0] : tb[0]) : (ta[0] < tb[0] ? ta[0] : tb[0]);
+      tb[0] = CL(ta[0] * (1.0f - lo) + pick * lo, min[0], max[0]);
+      tb[1] = CL(ta[1] * (1.0f - fabsf(tb[0] - ta[0])) + 0.5f * (ta[1] + tb[1]) * fabsf(tb[0] - ta[0]), min[1], max[1]);
+      tb[2] = CL(ta[2] * (1.0f - fabsf(tb[0] - ta[0])) + 0.5f * (ta[2] + tb[2]) * fabsf(tb[0] - ta[0]), min[2], max[2]);
+      break;
+    }
+    case LAB_MULTIPLY:
+      tb[0] = CL(ta[0] * (1.0f - lo) + (ta[0] * tb[0]) * lo, min[0], max[0]);
+      tb[1] = CL(ta[1] * (1.0f - lo) + (ta[1] + tb[1]) * tb[0] / f * lo, min[1], max[1]);
+      tb[2] = CL(ta[2] * (1.0f - lo) + (ta[2] + tb[2]) * tb[0] / f * lo, min[2], max[2]);
+      break;
+    case LAB_AVERAGE:
+      for(int x = 0; x < 3; x++) tb[x] = CL(ta[x] * (1.0f - lo) + (ta[x] + tb[x]) / 2.0f * lo, min[x], max[x]);
+      break;
+    case LAB_ADD:
+      for(int x = 0; x < 3; x++) tb[x] = CL(ta[x] * (1.0f - lo) + (ta[x] + tb[x]) * lo, min[x], max[x]);
+      break;
+    case LAB_SUBTRACT:
+      for(int x = 0; x < 3; x++)
+        tb[x] = CL(ta[x] * (1.0f - lo) + ((tb[x] + ta[x]) - (fabsf(min[x] + max[x]))) * lo, min[x], max[x]);
+      break;
+    case LAB_DIFFERENCE:
+      for(int x = 0; x < 3; x++)
+      {
+        const float xmax = max[x] + fabsf(min[x]);
+        const float xa = CL(ta[x] + fabsf(min[x]), lmin, xmax), xb = CL(tb[x] + fabsf(min[x]), lmin, xmax);
+        tb[x] = CL(xa * (1.0f - lo) + fabsf(xa - xb) * lo, lmin, xmax) - fabsf(min[x]);
+      }
+      break;
+    case LAB_DIFFERENCE2:
+      for(int x = 0; x < 3; x++) tb[x] = fabsf(ta[x] - tb[x]) / fabsf(max[x] - min[x]);
+      tb[0] = fmaxf(tb[0], fmaxf(tb[1], tb[2]));
+      tb[0] = CL(ta[0] * (1.0f - lo) + tb[0] * lo, min[0], max[0]);
+      tb[1] = 0.0f;
+      tb[2] = 0.0f;
+      break;
+    case LAB_SCREEN:
+      tb[0] = CL(la * (1.0f - lo) + ((lmax - (lmax - la) * (lmax - lb))) * lo, lmin, lmax) - fabsf(min[0]);
+      tb[1] = CL(ta[1] * (1.0f - lo) + 0.5f * (ta[1] + tb[1]) * tb[0] / f * lo, min[1], max[1]);
+      tb[2] = CL(ta[2] * (1.0f - lo) + 0.5f * (ta[2] + tb[2]) * tb[0] / f * lo, min[2], max[2]);
+      break;
+    case LAB_OVERLAY:
+      tb[0] = CL(la * (1.0f - lo2)
+                     + (la > halfmax ? lmax - (lmax - doublemax * (la - halfmax)) * (lmax - lb) : (doublemax * la) * lb) * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      chroma_follows = 1;
+      break;
+    case LAB_SOFTLIGHT:
+      tb[0] = CL(la * (1.0f - lo2) + (lb > halfmax ? lmax - (lmax - la) * (lmax - (lb - halfmax)) : la * (lb + halfmax)) * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      chroma_follows = 1;
+      break;
+    case LAB_HARDLIGHT:
+      tb[0] = CL(la * (1.0f - lo2)
+                     + (lb > halfmax ? lmax - (lmax - doublemax * (la - halfmax)) * (lmax - lb) : doublemax * la * lb) * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      chroma_follows = 1;
+      break;
+    case LAB_VIVIDLIGHT:
+      tb[0] = CL(la * (1.0f - lo2)
+                     + (lb > halfmax ? (lb >= lmax ? lmax : la / (doublemax * (lmax - lb)))
+                                     : (lb <= lmin ? lmin : lmax - (lmax - la) / (doublemax * lb)))
+                           * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      chroma_follows = 1;
+      break;
+    case LAB_LINEARLIGHT:
+      tb[0] = CL(la * (1.0f - lo2) + (la + doublemax * lb - lmax) * lo2, lmin, lmax) - fabsf(min[0]);
+      chroma_follows = 1;
+      break;
+    case LAB_PINLIGHT:
+      tb[0] = CL(la * (1.0f - lo2) + (lb > halfmax ? fmaxf(la, doublemax * (lb - halfmax)) : fminf(la, doublemax * lb)) * lo2,
+                 lmin, lmax)
+              - fabsf(min[0]);
+      tb[1] = CL(ta[1], min[1], max[1]);
+      tb[2] = CL(ta[2], min[2], max[2]);
+      break;
+    case LAB_LIGHTNESS:
+      tb[0] = CL(ta[0] * (1.0f - lo) + tb[0] * lo, min[0], max[0]);
+      tb[1] = CL(ta[1], min[1], max[1]);
+      tb[2] = CL(ta[2], min[2], max[2]);
+      break;
+    case LAB_LAB_LIGHTNESS:
+    case LAB_LAB_L:
+      tb[0] = ta[0] * (1.0f - lo) + tb[0] * lo;
+      tb[1] = ta[1];
+      tb[2] = ta[2];
+      break;
+    case LAB_LAB_A:
+      tb[0] = ta[0];
+      tb[1] = ta[1] * (1.0f - lo) + tb[1] * lo;
+      tb[2] = ta[2];
+      break;
+    case LAB_LAB_B:
+      tb[0] = ta[0];
+      tb[1] = ta[1];
+      tb[2] = ta[2] * (1.0f - lo) + tb[2] * lo;
+      break;
+    case LAB_LAB_COLOR:
+      tb[0] = ta[0];
+      tb[1] = ta[1] * (1.0f - lo) + tb[1] * lo;
+      tb[2] = ta[2] * (1.0f - lo) + tb[2] * lo;
+      break;
+    default: /* normal, unbounded */
+      for(int x = 0; x < 3; x++) tb[x] = ta[x] * (1.0f - lo) + tb[x] * lo;
+      break;
+  }
+  if(chroma_follows)
+  {
+    tb[1] = CL(ta[1] * (1.0f - lo2) + (ta[1] + tb[1]) * tb[0] / f * lo2, min[1], max[1]);
+    tb[2] = CL(ta[2] * (1.0f - lo2) + (ta[2] + tb[2]) * tb[0] / f * lo2, min[2], max[2]);
+  }
+  for(int c = 0; c < 3; c++) out[c] = tb[c] * rescale[c];
+  out[3] = lo;
+}
+
 int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d, const void *in_, void *out_)
 {
   if(!piece || !d || !in_ || !out_) return 1;
-  if(d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE || (d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER))
+  const int lab = d->blend_cst == DT_HIP_BLEND_CS_LAB;
+  if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab) || (d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER))
      || d->feathering_radius != 0.f || d->blur_radius != 0.f || d->details != 0.f || piece->channels != 4)
     return 1;
+  if(lab && !lab_mode_supported(d->blend_mode & 0xFFu)) return 1;
+  const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
   if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return 0;
   const float *in = (const float *)in_;
   float *out = (float *)out_;
@@ -239,17 +431,17 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
     for(unsigned ch = 0; ch < DT_HIP_BLENDIF_SIZE; ch++)
     {
       const unsigned bit = 1u << ch;
-      if(!(RGB_MASK & bit) || !(d->blendif & bit)) continue;
+      if(!(CH_MASK & bit) || !(d->blendif & bit)) continue;
       const float *c = &d->blendif_parameters[ch * 4];
       if(fabsf(c[0]) > 1e-6f || fabsf(c[1]) > 1e-6f || fabsf(c[2] - 1.0f) > 1e-6f || fabsf(c[3] - 1.0f) > 1e-6f) parametric = 1;
     }
 
   /* make_mask(): which of its three cases */
-  const unsigned any_channel_active = d->blendif & RGB_MASK;
+  const unsigned any_channel_active = d->blendif & CH_MASK;
   const unsigned mask_inclusive = d->mask_combine & DT_HIP_COMBINE_INCL;
   const unsigned mask_inversed = d->mask_combine & DT_HIP_COMBINE_INV;
-  const unsigned blendif = d->blendif ^ (mask_inclusive ? RGB_MASK << 16 : 0);
-  const unsigned canceling_channel = (blendif >> 16) & ~blendif & RGB_MASK;
+  const unsigned blendif = d->blendif ^ (mask_inclusive ? CH_MASK << 16 : 0);
+  const unsigned canceling_channel = (blendif >> 16) & ~blendif & CH_MASK;
   const float global_opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f);
   const float seed = mask_inclusive ? 0.0f : 1.0f; /* the form mask of a parametric-only blend, blend.c:749-757 */
   int kind; /* 0 uniform, 1 constant after make_mask, 2 per pixel */
@@ -280,7 +472,7 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
       {
         const float *bp = d->blendif_parameters + i * 4;
         const float boost = exp2f(d->blendif_boost_factors[i]);
-        const float offset = 0.0f; /* 0.5 for the a/b channels of the Lab colourspace only */
+        const float offset = (lab && (i == 1 || i == 2 || i == 5 || i == 6)) ? 0.5f : 0.0f; /* a, b in / out */
         for(int k = 0; k < 4; k++) p[k] = (bp[k] - offset) * boost;
         p[4] = 1.0f / fmaxf(0.001f, p[1] - p[0]);
         p[5] = 1.0f / fmaxf(0.001f, p[3] - p[2]);
@@ -325,15 +517,28 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
       if(kind == 2)
       {
         float temp = 1.0f;
-        temp = combine_channels(a, temp, x.blendif, x.parameters, &x);
-        temp = combine_channels(b, temp, x.blendif >> GRAY_OUT, x.parameters + PARAM_ITEMS * GRAY_OUT, &x);
+        if(lab)
+        {
+          temp = combine_channels_lab(a, temp, x.blendif, x.parameters);
+          temp = combine_channels_lab(b, temp, x.blendif >> GRAY_OUT, x.parameters + PARAM_ITEMS * GRAY_OUT);
+        }
+        else
+        {
+          temp = combine_channels(a, temp, x.blendif, x.parameters, &x);
+          temp = combine_channels(b, temp, x.blendif >> GRAY_OUT, x.parameters + PARAM_ITEMS * GRAY_OUT, &x);
+        }
         if(mask_inclusive)
           m = mask_inversed ? global_opacity * (1.0f - seed) * temp : global_opacity * (1.0f - (1.0f - seed) * temp);
         else
           m = mask_inversed ? global_opacity * (1.0f - seed * temp) : global_opacity * seed * temp;
       }
       if(tone) m = tone_curve(m, e, d->brightness, opacity);
-      if(reverse) blend_pixel(mode, b, a, p, m, bo);
+      if(lab)
+      {
+        if(reverse) blend_pixel_lab(mode, b, a, m, bo);
+        else blend_pixel_lab(mode, a, b, m, bo);
+      }
+      else if(reverse) blend_pixel(mode, b, a, p, m, bo);
       else blend_pixel(mode, a, b, p, m, bo);
     }
   return 0;

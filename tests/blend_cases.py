@@ -70,3 +70,57 @@ def cases():
     d.mask_mode = 0
     out.append(("disabled", d))
     return out
+
+
+def lab_images(w, h, seed):
+    """(module input, module output) in Lab: L 0..100 (a little outside), a/b +-90, exact zeros, greys, non-finite"""
+    rng = np.random.default_rng(seed)
+
+    def one(sd):
+        rgb = synth.rgba_image(w, h, seed=sd, lo=0.0, hi=1.0)
+        lab = np.zeros((h, w, 4), np.float32)
+        lab[..., 0] = 104.0 * rgb[..., 1] - 2.0
+        lab[..., 1] = 110.0 * (rgb[..., 0] - rgb[..., 1]) + rng.normal(0, 3.0, (h, w))
+        lab[..., 2] = 110.0 * (rgb[..., 1] - rgb[..., 2]) + rng.normal(0, 3.0, (h, w))
+        return lab.astype(np.float32)
+
+    a, b = one(seed), one(seed + 1)
+    b[..., :3] = 0.5 * b[..., :3] + 0.5 * a[..., :3] * rng.uniform(0.6, 1.4, size=(h, w, 1)).astype(np.float32)
+    a[2, 3, 1:3] = 0.0
+    b[4, 5, 1:3] = 0.0
+    a[6, 7, :3] = 0.0
+    b[8, 9, 0] = 0.0
+    a[10, 11, 1] = np.inf
+    b[12, 13, 2] = np.nan
+    a[..., 3] = 0.25
+    b[..., 3] = 0.75
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def lab_cases():
+    out = []
+    L = abi.BLEND_CS_LAB
+    for mode in abi.BLEND_LAB_MODES:
+        out.append(("lab-uniform-%02x" % mode, abi.BlendData.uniform(M, 57.0, mode, blend_cst=L)))
+    out.append(("lab-uniform-reverse-overlay", abi.BlendData.uniform(M, 80.0, 0x0A | abi.BLEND_REVERSE, blend_cst=L)))
+    out.append(("lab-uniform-full-vivid", abi.BlendData.uniform(M, 100.0, 0x0D, blend_cst=L)))
+    for ch, tr in ((abi.BLENDIF_L_in, (0.1, 0.3, 0.7, 0.9)), (abi.BLENDIF_A_in, (0.4, 0.45, 0.55, 0.7)),
+                   (abi.BLENDIF_B_in, (0.0, 0.0, 0.5, 0.6)), (abi.BLENDIF_C_in, (0.05, 0.15, 1.0, 1.0)),
+                   (abi.BLENDIF_h_in, (0.1, 0.3, 0.6, 0.8)), (abi.BLENDIF_L_out, (0.2, 0.4, 1.0, 1.0)),
+                   (abi.BLENDIF_A_out, (0.3, 0.5, 0.6, 0.8)), (abi.BLENDIF_B_out, (0.45, 0.5, 1.0, 1.0)),
+                   (abi.BLENDIF_C_out, (0.0, 0.0, 0.3, 0.5)), (abi.BLENDIF_h_out, (0.5, 0.6, 0.9, 0.95))):
+        boost = {abi.BLENDIF_A_in: 1.0, abi.BLENDIF_C_out: 0.5}.get(ch, 0.0)
+        out.append(("lab-param-ch%d" % ch, abi.BlendData.uniform(M, 85.0, blend_cst=L).channel(ch, *tr, boost=boost)))
+        out.append(("lab-param-ch%d-inv" % ch, abi.BlendData.uniform(M, 85.0, 0x05, blend_cst=L).channel(ch, *tr, invert=True, boost=boost)))
+    for combine in (0, abi.COMBINE_INV, abi.COMBINE_INCL, abi.COMBINE_INV | abi.COMBINE_INCL):
+        for contrast, brightness in ((0.0, 0.0), (0.4, -0.3)):
+            d = abi.BlendData.uniform(M, 72.0, 0x0B, blend_cst=L)
+            d.channel(abi.BLENDIF_L_in, 0.05, 0.25, 0.7, 1.0)
+            d.channel(abi.BLENDIF_B_out, 0.3, 0.45, 0.6, 0.9, invert=True)
+            d.channel(abi.BLENDIF_C_in, 0.02, 0.1, 1.0, 1.0)
+            d.channel(abi.BLENDIF_h_out, 0.1, 0.3, 0.8, 0.95)
+            d.mask_combine = combine
+            d.contrast = contrast
+            d.brightness = brightness
+            out.append(("lab-multi-c%d-%g-%g" % (combine, contrast, brightness), d))
+    return out

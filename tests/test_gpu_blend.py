@@ -1,4 +1,4 @@
-"""-m gpu: the blend stage (RGB (scene): uniform / parametric mask, tone curve, sixteen operators) through the
+"""-m gpu: the blend stage (RGB (scene) and Lab: uniform / parametric mask, tone curve, 16 + 23 operators) through the
 C-ABI, bit for bit against the oracle and the reference's own functions."""
 import ctypes as C
 
@@ -39,6 +39,30 @@ def test_blend(name, d):
         assert m.min() < m.max(), name
 
 
+LAB_CASES = blend_cases.lab_cases()
+
+
+@pytest.mark.parametrize("name,d", LAB_CASES, ids=[c[0] for c in LAB_CASES])
+def test_blend_lab(name, d):
+    w, h = 131, 67
+    a, b = blend_cases.lab_images(w, h, 51)
+    got = _check(abi.Piece.make(w, h), d, a, b, name)
+    if name.startswith("lab-param") and not name.endswith("-inv"):
+        m = got[..., 3][np.isfinite(got[..., 3])]
+        assert m.min() < m.max(), name
+
+
+@pytest.mark.parametrize("mode", abi.BLEND_LAB_REFUSED)
+def test_blend_lab_refuses_the_lch_operators(mode):
+    w, h = 32, 16
+    a, b = blend_cases.lab_images(w, h, 3)
+    d = abi.BlendData.uniform(blend_cases.M, 50.0, mode, blend_cst=abi.BLEND_CS_LAB)
+    h_ = hc.hip()
+    da, db = lib.DeviceBuffer.from_numpy(0, a), lib.DeviceBuffer.from_numpy(0, b)
+    assert h_.dt_hip_develop_blend_process(0, C.byref(abi.Piece.make(w, h)), C.byref(d), da.ptr, db.ptr) == -997
+    assert h_.dt_hip_finish(0) == 1
+
+
 def test_blend_roi_offset():
     w, h, iw, ih = 90, 50, 120, 70
     a, b = blend_cases.images(w, h, 43, iw, ih)
@@ -55,7 +79,7 @@ def test_blend_full_frame():
     _check(abi.Piece.make(w, h), d, a, b, "24 MP")
 
 
-@pytest.mark.parametrize("field,value", [("blend_cst", 2), ("feathering_radius", 5.0), ("blur_radius", 3.0), ("details", 0.5),
+@pytest.mark.parametrize("field,value", [("blend_cst", 3), ("blend_cst", 1), ("feathering_radius", 5.0), ("blur_radius", 3.0), ("details", 0.5),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_SHAPE),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_RASTER)])
 def test_blend_refuses_what_is_not_built(field, value):

@@ -404,3 +404,17 @@ def test_develop_blend_roi_offset():
     assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
     assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
     _exact(x, y, "blend roi offset")
+
+
+@pytest.mark.parametrize("name,d", blend_cases.lab_cases(), ids=[c[0] for c in blend_cases.lab_cases()])
+def test_develop_blend_lab(name, d):
+    """the blend stage, Lab: uniform and parametric masks (L, a, b, C, h), 23 operators"""
+    w, h = 131, 67
+    a, b = blend_cases.lab_images(w, h, 51)
+    piece = abi.Piece.make(w, h)
+    r, o = ck.ref(), ck.oracle()
+    x, y = b.copy(), b.copy()
+    assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
+    assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
+    _exact(x, y, "blend " + name)
+    assert not np.array_equal(x.view(np.uint32), b.view(np.uint32))
