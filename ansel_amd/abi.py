@@ -241,6 +241,9 @@ MASK_ENABLED, MASK_SHAPE, MASK_PARAMETRIC, MASK_RASTER = 1, 2, 4, 8
 COMBINE_INV, COMBINE_INCL = 1, 2
 BLEND_CS_RGB_SCENE = 4
 BLEND_CS_LAB = 2
+BLEND_CS_RAW = 1
+# the operators of the "raw" colourspace (src/develop/blends/blendif_raw.c:290-353)
+BLEND_RAW_MODES = (0x18, 0x19, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x17, 0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x0E, 0x0F)
 # the operators of the "Lab" colourspace (src/develop/blends/blendif_lab.c:1070-1160) built on the device;
 # chroma 0x11, hue 0x12, color 0x13 and coloradjust 0x16 go through LCh and are refused
 BLEND_LAB_MODES = (0x18, 0x19, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x17, 0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x0E, 0x0F,

@@ -448,6 +448,57 @@ __device__ __forceinline__ float4 blend_pixel_lab(const unsigned mode, const flo
   return make_float4(tb[0] * rescale[0], tb[1] * rescale[1], tb[2] * rescale[2], lo);
 }
 
+
+// ---- raw, one channel (src/develop/blends/blendif_raw.c:66-288) -----------------------------------------
+__device__ __forceinline__ float clamp01(const float x) { return fminf(fmaxf(x, 0.0f), 1.0f); } // clamp_simd()
+
+__device__ __forceinline__ float blend_value_raw(const unsigned mode, const float a, const float b, const float lo)
+{
+  const float lo2 = lo * lo;
+  const float la = clamp01(a), lb = clamp01(b);
+  switch(mode)
+  {
+    case LAB_BOUNDED: return clamp01(a * (1.0f - lo) + b * lo);
+    case LAB_LIGHTEN: return clamp01(a * (1.0f - lo) + fmaxf(a, b) * lo);
+    case LAB_DARKEN: return clamp01(a * (1.0f - lo) + fminf(a, b) * lo);
+    case LAB_MULTIPLY: return clamp01(a * (1.0f - lo) + (a * b) * lo);
+    case LAB_AVERAGE: return clamp01(a * (1.0f - lo) + (a + b) / 2.0f * lo);
+    case LAB_ADD: return clamp01(a * (1.0f - lo) + (a + b) * lo);
+    case LAB_SUBTRACT: return clamp01(a * (1.0f - lo) + ((b + a) - 1.0f) * lo);
+    case LAB_DIFFERENCE:
+    case LAB_DIFFERENCE2: return clamp01(a * (1.0f - lo) + fabsf(a - b) * lo);
+    case LAB_SCREEN: return clamp01(la * (1.0f - lo) + (1.0f - (1.0f - la) * (1.0f - lb)) * lo);
+    case LAB_OVERLAY:
+      return clamp01(la * (1.0f - lo2) + (la > 0.5f ? 1.0f - (1.0f - 2.0f * (la - 0.5f)) * (1.0f - lb) : 2.0f * la * lb) * lo2);
+    case LAB_SOFTLIGHT:
+      return clamp01(la * (1.0f - lo2) + (lb > 0.5f ? 1.0f - (1.0f - la) * (1.0f - (lb - 0.5f)) : la * (lb + 0.5f)) * lo2);
+    case LAB_HARDLIGHT:
+      return clamp01(la * (1.0f - lo2) + (lb > 0.5f ? 1.0f - (1.0f - 2.0f * (la - 0.5f)) * (1.0f - lb) : 2.0f * la * lb) * lo2);
+    case LAB_VIVIDLIGHT:
+      return clamp01(la * (1.0f - lo2)
+                     + (lb > 0.5f ? (lb >= 1.0f ? 1.0f : la / (2.0f * (1.0f - lb)))
+                                  : (lb <= 0.0f ? 0.0f : 1.0f - (1.0f - la) / (2.0f * lb)))
+                           * lo2);
+    case LAB_LINEARLIGHT: return clamp01(la * (1.0f - lo2) + (la + 2.0f * lb - 1.0f) * lo2);
+    case LAB_PINLIGHT:
+      return clamp01(la * (1.0f - lo2) + (lb > 0.5f ? fmaxf(la, 2.0f * (lb - 0.5f)) : fminf(la, 2.0f * lb)) * lo2);
+    default: return a * (1.0f - lo) + b * lo; // normal, unbounded
+  }
+}
+
+// the mask of the raw colourspace never depends on the photosite (blendif_raw.c:36-62)
+__global__ __launch_bounds__(256) void blend_raw_kernel(const float *__restrict__ in, float *__restrict__ out, const int owidth,
+                                                        const int oheight, const int iwidth, const int xoffs, const int yoffs,
+                                                        const float m, const unsigned mode, const int reverse)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= (size_t)owidth * oheight) return;
+  const int y = (int)(k / owidth), x = (int)(k - (size_t)y * owidth);
+  const float a = in[(size_t)(y + yoffs) * iwidth + xoffs + x];
+  const float b = out[k];
+  out[k] = reverse ? blend_value_raw(mode, b, a, m) : blend_value_raw(mode, a, b, m);
+}
+
 template <bool LAB, bool PARAMETRIC>
 __global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, const blend_args a_by_value)
 {
@@ -490,11 +541,11 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
                                             dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
-  const bool lab = d->blend_cst == DT_HIP_BLEND_CS_LAB;
-  if(d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab)
+  const bool lab = d->blend_cst == DT_HIP_BLEND_CS_LAB, raw = d->blend_cst == DT_HIP_BLEND_CS_RAW;
+  if(d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !raw)
   {
-    set_last_error("blend: colourspace %d is not built (RGB (scene) %d and Lab %d are)", d->blend_cst,
-                   DT_HIP_BLEND_CS_RGB_SCENE, DT_HIP_BLEND_CS_LAB);
+    set_last_error("blend: colourspace %d is not built (RGB (scene) %d, Lab %d and raw %d are)", d->blend_cst,
+                   DT_HIP_BLEND_CS_RGB_SCENE, DT_HIP_BLEND_CS_LAB, DT_HIP_BLEND_CS_RAW);
     return DT_HIP_INVALID_ARG;
   }
   {
@@ -506,7 +557,7 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     }
   }
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
-  if(piece->channels != 4) return DT_HIP_INVALID_ARG;
+  if(piece->channels != (raw ? 1 : 4)) return DT_HIP_INVALID_ARG;
   if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->blur_radius != 0.f
      || d->details != 0.f)
   {
@@ -571,6 +622,20 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   a.mode = d->blend_mode & 0xFFu;
   a.reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
   a.p = exp2f(d->blend_parameter);
+  if(raw)
+  {
+    // dt_develop_blendif_raw_make_mask(), blendif_raw.c:36-62: global opacity, optionally inverted -- the
+    // conditions of a parametric mask have no channels to look at
+    if(parametric) a.constant = mask_inversed ? global_opacity * (1.0f - seed) : seed * global_opacity;
+    if(a.tone) a.constant = tone_curve(a.constant, a);
+    const size_t np = (size_t)a.owidth * a.oheight;
+    {
+      launch_scope ls(devid, "blend_raw");
+      blend_raw_kernel<<<pixel_grid(np), 256, 0, stream_of(devid)>>>((const float *)dev_in, (float *)dev_out, a.owidth, a.oheight,
+                                                                      a.iwidth, a.xoffs, a.yoffs, a.constant, a.mode, a.reverse);
+    }
+    return check_launch("blend_raw");
+  }
   if(per_pixel)
   {
     // dt_develop_blendif_process_parameters(), blend.c:214-260

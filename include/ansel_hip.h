@@ -432,13 +432,14 @@ int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iw
  * reference's names, plus the work profile's RGB -> XYZ(D50) matrix that
  * dt_develop_blendif_init_masking_profile() (blend.c:322-353) turns into the masking profile.
  * Built: the blend colourspaces "RGB (scene)" (src/develop/blends/blendif_rgb_jzczhz.c; LINEAR work profile,
- * nonlinearlut == 0, every scene-referred module's case) and "Lab" (src/develop/blends/blendif_lab.c, the
- * default of the Lab modules); mask modes uniform and parametric -- gray, R, G, B, Jz, Cz, hz resp. L, a, b,
+ * nonlinearlut == 0, every scene-referred module's case), "Lab" (src/develop/blends/blendif_lab.c, the
+ * default of the Lab modules) and "raw" (src/develop/blends/blendif_raw.c: one-channel buffers before
+ * demosaic, seventeen operators, opacity-only mask); mask modes uniform and parametric -- gray, R, G, B, Jz, Cz, hz resp. L, a, b,
  * C, h on input and output, all combine / invert variants --, the mask tone curve (contrast / brightness,
  * blend.c:626-655), the sixteen operators of blendif_rgb_jzczhz.c:328-650 resp. twenty-three of the
  * twenty-seven of blendif_lab.c:320-1068, and the reverse flag.  Refused with DT_HIP_INVALID_ARG (never
  * approximated): drawn and raster masks, feathering, mask blur, the details threshold, the Lab operators that
- * go through LCh (chroma, hue, color, coloradjust), the display-RGB and raw colourspaces, GUI mask display. */
+ * go through LCh (chroma, hue, color, coloradjust), the display-RGB colourspace, GUI mask display. */
 #define DT_HIP_BLEND_CS_RAW 1 /* dt_develop_blend_colorspace_t, blend.h:51-58 */
 #define DT_HIP_BLEND_CS_LAB 2
 #define DT_HIP_BLEND_CS_RGB_DISPLAY 3

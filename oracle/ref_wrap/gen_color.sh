@@ -44,3 +44,7 @@ $X $R/develop/blends/blendif_lab.c $G/blendif_lab.inc DT_BLENDIF_LAB_CH DT_BLEND
   _blend_linearlight _blend_pinlight _blend_lightness _blend_chromaticity _blend_hue _blend_color _blend_coloradjust \
   _blend_Lab_lightness _blend_Lab_a _blend_Lab_b _blend_Lab_color _choose_blend_func _copy_mask \
   dt_develop_blendif_lab_blend
+$X $R/develop/blends/blendif_raw.c $G/blendif_raw.inc dt_develop_blendif_raw_make_mask _blend_normal_bounded \
+  _blend_normal_unbounded _blend_lighten _blend_darken _blend_multiply _blend_average _blend_add _blend_subtract \
+  _blend_difference _blend_screen _blend_overlay _blend_softlight _blend_hardlight _blend_vividlight _blend_linearlight \
+  _blend_pinlight _choose_blend_func dt_develop_blendif_raw_blend

@@ -1,6 +1,6 @@
 /* oracle/src/blend.c -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
  *
- * CPU restatement of the blend stage, blend colourspaces "RGB (scene)" and "Lab", for the mask sources
+ * CPU restatement of the blend stage, blend colourspaces "RGB (scene)", "Lab" and "raw", for the mask sources
  * the device path supports (uniform opacity, parametric mask, mask tone curve).  It follows
  *   dt_develop_blend_process()                  src/develop/blend.c:657-900 (driver)
  *   dt_develop_blend_get_mask_usage()           src/develop/blend.c:262-320 (is the parametric mask in use)
@@ -14,6 +14,7 @@
  *   dt_XYZ_2_JzAzBz(), dt_JzAzBz_2_JzCzhz()     src/common/colorspaces_inline_conversions.h:672-781
  *   Lab: make_mask, channel functions, operators, blend   src/develop/blends/blendif_lab.c:56-300, :302-1068, :1302-1420
  *   dt_Lab_2_LCH()                              src/common/colorspaces_inline_conversions.h:594-606
+ *   raw: make_mask, operators, blend            src/develop/blends/blendif_raw.c:36-62, :66-353, :355-412
  * (the four Lab operators that go through LCh -- chroma, hue, color, coloradjust -- are not restated: the
  * device path refuses them)
  * One pass per pixel instead of the reference's one pass per mask channel: every step is pointwise,
@@ -404,9 +405,98 @@ static void blend_pixel_lab(const unsigned mode, const float *a, const float *b,
   out[3] = lo;
 }
 
+/* ---- raw (one channel) ----------------------------------------------------------------------------
+ * the _blend_* row functions of src/develop/blends/blendif_raw.c:66-288, one photosite */
+static float clamp01(const float x) { return fminf(fmaxf(x, 0.0f), 1.0f); } /* clamp_simd() */
+
+static float blend_value_raw(const unsigned mode, const float a, const float b, const float lo)
+{
+  const float lo2 = lo * lo;
+  const float la = clamp01(a), lb = clamp01(b);
+  switch(mode)
+  {
+    case LAB_BOUNDED: return clamp01(a * (1.0f - lo) + b * lo);
+    case LAB_LIGHTEN: return clamp01(a * (1.0f - lo) + fmaxf(a, b) * lo);
+    case LAB_DARKEN: return clamp01(a * (1.0f - lo) + fminf(a, b) * lo);
+    case LAB_MULTIPLY: return clamp01(a * (1.0f - lo) + (a * b) * lo);
+    case LAB_AVERAGE: return clamp01(a * (1.0f - lo) + (a + b) / 2.0f * lo);
+    case LAB_ADD: return clamp01(a * (1.0f - lo) + (a + b) * lo);
+    case LAB_SUBTRACT: return clamp01(a * (1.0f - lo) + ((b + a) - 1.0f) * lo);
+    case LAB_DIFFERENCE:
+    case LAB_DIFFERENCE2: return clamp01(a * (1.0f - lo) + fabsf(a - b) * lo);
+    case LAB_SCREEN: return clamp01(la * (1.0f - lo) + (1.0f - (1.0f - la) * (1.0f - lb)) * lo);
+    case LAB_OVERLAY:
+      return clamp01(la * (1.0f - lo2) + (la > 0.5f ? 1.0f - (1.0f - 2.0f * (la - 0.5f)) * (1.0f - lb) : 2.0f * la * lb) * lo2);
+    case LAB_SOFTLIGHT:
+      return clamp01(la * (1.0f - lo2) + (lb > 0.5f ? 1.0f - (1.0f - la) * (1.0f - (lb - 0.5f)) : la * (lb + 0.5f)) * lo2);
+    case LAB_HARDLIGHT:
+      return clamp01(la * (1.0f - lo2) + (lb > 0.5f ? 1.0f - (1.0f - 2.0f * (la - 0.5f)) * (1.0f - lb) : 2.0f * la * lb) * lo2);
+    case LAB_VIVIDLIGHT:
+      return clamp01(la * (1.0f - lo2)
+                     + (lb > 0.5f ? (lb >= 1.0f ? 1.0f : la / (2.0f * (1.0f - lb)))
+                                  : (lb <= 0.0f ? 0.0f : 1.0f - (1.0f - la) / (2.0f * lb)))
+                           * lo2);
+    case LAB_LINEARLIGHT: return clamp01(la * (1.0f - lo2) + (la + 2.0f * lb - 1.0f) * lo2);
+    case LAB_PINLIGHT:
+      return clamp01(la * (1.0f - lo2) + (lb > 0.5f ? fmaxf(la, 2.0f * (lb - 0.5f)) : fminf(la, 2.0f * lb)) * lo2);
+    default: return a * (1.0f - lo) + b * lo; /* normal, unbounded */
+  }
+}
+
+/* dt_develop_blend_process() for a one-channel buffer: the mask never depends on the photosite
+ * (dt_develop_blendif_raw_make_mask(), blendif_raw.c:36-62: global opacity, optionally inverted) */
+static int blend_raw(const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d, const float *in, float *out)
+{
+  const int xoffs = piece->roi_out.x - piece->roi_in.x, yoffs = piece->roi_out.y - piece->roi_in.y;
+  const int iwidth = piece->roi_in.width, iheight = piece->roi_in.height;
+  const int owidth = piece->roi_out.width, oheight = piece->roi_out.height;
+  if(piece->roi_out.scale != piece->roi_in.scale || xoffs < 0 || yoffs < 0
+     || ((xoffs > 0 || yoffs > 0) && (owidth + xoffs > iwidth || oheight + yoffs > iheight)))
+    return 0;
+  const float opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f);
+  int parametric = 0;
+  if(d->mask_mode & DT_HIP_MASK_PARAMETRIC)
+    for(unsigned ch = 0; ch < DT_HIP_BLENDIF_SIZE; ch++)
+    {
+      const unsigned bit = 1u << ch;
+      if(!(RGB_MASK & bit) || !(d->blendif & bit)) continue;
+      const float *c = &d->blendif_parameters[ch * 4];
+      if(fabsf(c[0]) > 1e-6f || fabsf(c[1]) > 1e-6f || fabsf(c[2] - 1.0f) > 1e-6f || fabsf(c[3] - 1.0f) > 1e-6f) parametric = 1;
+    }
+  float m = opacity;
+  if(parametric)
+  {
+    const float seed = (d->mask_combine & DT_HIP_COMBINE_INCL) ? 0.0f : 1.0f;
+    const float global_opacity = fminf(fmaxf(0.0f, (d->opacity / 100.0f)), 1.0f);
+    m = (d->mask_combine & DT_HIP_COMBINE_INV) ? global_opacity * (1.0f - seed) : seed * global_opacity;
+    if((fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f)
+      m = tone_curve(m, expf(3.f * d->contrast), d->brightness, opacity);
+  }
+  const unsigned mode = d->blend_mode & 0xFFu;
+  const int reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
+#pragma omp parallel for schedule(static)
+  for(int y = 0; y < oheight; y++)
+    for(int x = 0; x < owidth; x++)
+    {
+      const float a = in[(size_t)(y + yoffs) * iwidth + xoffs + x];
+      float *bo = out + (size_t)y * owidth + x;
+      const float b = *bo;
+      *bo = reverse ? blend_value_raw(mode, b, a, m) : blend_value_raw(mode, a, b, m);
+    }
+  return 0;
+}
+
 int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d, const void *in_, void *out_)
 {
   if(!piece || !d || !in_ || !out_) return 1;
+  if(d->blend_cst == DT_HIP_BLEND_CS_RAW)
+  {
+    if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->blur_radius != 0.f
+       || d->details != 0.f || piece->channels != 1)
+      return 1;
+    if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return 0;
+    return blend_raw(piece, d, (const float *)in_, (float *)out_);
+  }
   const int lab = d->blend_cst == DT_HIP_BLEND_CS_LAB;
   if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab) || (d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER))
      || d->feathering_radius != 0.f || d->blur_radius != 0.f || d->details != 0.f || piece->channels != 4)

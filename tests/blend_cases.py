@@ -124,3 +124,31 @@ def lab_cases():
             d.brightness = brightness
             out.append(("lab-multi-c%d-%g-%g" % (combine, contrast, brightness), d))
     return out
+
+
+def raw_images(w, h, seed):
+    """(module input, module output): one-channel mosaics around [0, 1] with excursions, zeros, non-finite"""
+    rng = np.random.default_rng(seed)
+    a = (rng.random((h, w), dtype=np.float32) * 1.3 - 0.1).astype(np.float32)
+    b = (0.6 * a + 0.4 * rng.random((h, w), dtype=np.float32) * 1.2).astype(np.float32)
+    a[1, 2] = 0.0
+    b[3, 4] = 0.0
+    b[5, 6] = 1.0
+    a[7, 8] = np.inf
+    b[9, 10] = np.nan
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def raw_cases():
+    out = []
+    R = abi.BLEND_CS_RAW
+    for mode in abi.BLEND_RAW_MODES:
+        out.append(("raw-uniform-%02x" % mode, abi.BlendData.uniform(M, 61.0, mode, blend_cst=R)))
+    out.append(("raw-reverse-softlight", abi.BlendData.uniform(M, 90.0, 0x0B | abi.BLEND_REVERSE, blend_cst=R)))
+    # a "parametric" raw mask has no channel to test: the opacity, optionally inverted, through the tone curve
+    for combine in (0, abi.COMBINE_INV, abi.COMBINE_INCL, abi.COMBINE_INV | abi.COMBINE_INCL):
+        d = abi.BlendData.uniform(M, 70.0, 0x18, blend_cst=R).channel(abi.BLENDIF_GRAY_in, 0.1, 0.2, 0.8, 0.9)
+        d.mask_combine = combine
+        d.contrast, d.brightness = 0.3, 0.2
+        out.append(("raw-parametric-c%d" % combine, d))
+    return out

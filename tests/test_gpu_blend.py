@@ -63,6 +63,16 @@ def test_blend_lab_refuses_the_lch_operators(mode):
     assert h_.dt_hip_finish(0) == 1
 
 
+RAW_CASES = blend_cases.raw_cases()
+
+
+@pytest.mark.parametrize("name,d", RAW_CASES, ids=[c[0] for c in RAW_CASES])
+def test_blend_raw(name, d):
+    w, h = 133, 65
+    a, b = blend_cases.raw_images(w, h, 61)
+    _check(abi.Piece.make(w, h, channels=1), d, a, b, name)
+
+
 def test_blend_roi_offset():
     w, h, iw, ih = 90, 50, 120, 70
     a, b = blend_cases.images(w, h, 43, iw, ih)
@@ -79,7 +89,7 @@ def test_blend_full_frame():
     _check(abi.Piece.make(w, h), d, a, b, "24 MP")
 
 
-@pytest.mark.parametrize("field,value", [("blend_cst", 3), ("blend_cst", 1), ("feathering_radius", 5.0), ("blur_radius", 3.0), ("details", 0.5),
+@pytest.mark.parametrize("field,value", [("blend_cst", 3), ("feathering_radius", 5.0), ("blur_radius", 3.0), ("details", 0.5),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_SHAPE),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_RASTER)])
 def test_blend_refuses_what_is_not_built(field, value):

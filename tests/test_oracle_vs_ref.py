@@ -418,3 +418,16 @@ def test_develop_blend_lab(name, d):
     assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
     _exact(x, y, "blend " + name)
     assert not np.array_equal(x.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,d", blend_cases.raw_cases(), ids=[c[0] for c in blend_cases.raw_cases()])
+def test_develop_blend_raw(name, d):
+    """the blend stage before demosaic: one channel, 17 operators, opacity-only mask"""
+    w, h = 133, 65
+    a, b = blend_cases.raw_images(w, h, 61)
+    piece = abi.Piece.make(w, h, channels=1)
+    r, o = ck.ref(), ck.oracle()
+    x, y = b.copy(), b.copy()
+    assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
+    assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
+    _exact(x, y, "blend " + name)
