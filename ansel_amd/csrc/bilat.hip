@@ -206,8 +206,17 @@ int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hi
   const int width = piece->roi_in.width, height = piece->roi_in.height;
   if(width <= 0 || height <= 0) return DT_HIP_SUCCESS;
   if(d->mode == DT_HIP_BILAT_LOCAL_LAPLACIAN) // bilat.c:352-357: (midtone, sigma_s, sigma_r, detail)
+  {
+    if((width < height ? width : height) == 2 || (width < height ? width : height) == 3)
+    {
+      // one pyramid level: the reference indexes its level array at -1 (locallaplacian.c:405) and, for a side of
+      // 3, pads for two levels -- it reads outside its buffers (and crashes): nothing to be identical to
+      set_last_error("bilat: local laplacian is undefined in the reference for a 2- or 3-pixel side (%d x %d)", width, height);
+      return DT_HIP_INVALID_ARG;
+    }
     return local_laplacian_launch(devid, (const float4 *)dev_in, (float4 *)dev_out, width, height, d->midtone, d->sigma_s,
                                   d->sigma_r, d->detail);
+  }
   if(d->mode != DT_HIP_BILAT_BILATERAL)
   {
     set_last_error("bilat: unknown mode %d", d->mode);
@@ -217,6 +226,14 @@ int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hi
   const float scale = (float)(d->iscale / piece->roi_in.scale); // dt_dev_get_module_scale(), bilat.c:339
   grid_t b;
   grid_size(b, width, height, 100.0f, d->sigma_s / scale, d->sigma_r);
+  if(b.size_x < 4 || b.size_y < 4 || b.size_z < 4)
+  {
+    // blur_line() / blur_line_z() (src/pixel/bilateral.c:266-340) touch four entries of every grid line
+    // unconditionally: on a shorter line the reference writes past it (heap corruption on the CPU)
+    set_last_error("bilat: a %d x %d x %d grid is below the 4 entries per line the reference's blur assumes", b.size_x,
+                   b.size_y, b.size_z);
+    return DT_HIP_INVALID_ARG;
+  }
   const size_t cells = (size_t)b.size_x * b.size_y * b.size_z;
   float *buf = (float *)dt_hip_alloc_device_buffer(devid, cells * sizeof(float));
   if(!buf) return DT_HIP_SYSMEM_ALLOCATION;

@@ -15,7 +15,18 @@ __global__ __launch_bounds__(256) void ppg_full(float4 *__restrict__ out, const 
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
   if(i >= k.w || j >= k.h) return;
-  out[(size_t)j * k.w + i] = ppg_pixel<false>(k, j, i);
+  const float4 v = ppg_pixel<false>(k, j, i);
+  float4 *const o = out + (size_t)j * k.w + i;
+  if(ring_lt(k, j, i, 3))
+  {
+    // the outer 3 px come from the first pass (ppg.c:30-57), which stores three channels: whatever the
+    // caller's buffer holds in the fourth stays there
+    o->x = v.x;
+    o->y = v.y;
+    o->z = v.z;
+  }
+  else
+    *o = v;
 }
 } // namespace
 

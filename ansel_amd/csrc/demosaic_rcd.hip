@@ -363,7 +363,17 @@ __global__ __launch_bounds__(256) void rcd_border(const float *__restrict__ in, 
   const float *frame = in - (ptrdiff_t)in_row0 * width;
   const ppg_ctx k = { frame, width, height, width, height, 0, 0, filters };
   (void)in_rows;
-  out[(size_t)(j - out_row0) * width + i] = ppg_pixel<true>(k, j, i);
+  const float4 v = ppg_pixel<true>(k, j, i);
+  float4 *const o = out + (size_t)(j - out_row0) * width + i;
+  if(ring_lt(k, j, i, 3))
+  {
+    // first pass of rcd_ppg_border() (rcd.c:96-127): three channels stored, the fourth is the caller's
+    o->x = v.x;
+    o->y = v.y;
+    o->z = v.z;
+  }
+  else
+    *o = v;
 }
 
 } // namespace

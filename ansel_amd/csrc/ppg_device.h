@@ -140,7 +140,7 @@ template <bool CLAMP> __device__ float4 ppg_pixel(const ppg_ctx &k, const int j,
     }
   }
   // alpha: the reference writes 0 from ring 3 inwards and leaves the caller's buffer alone on the
-  // outer 3 px; a fresh pixelpipe cacheline is what it finds there, so 0 everywhere
+  // outer 3 px (the callers store three channels there)
   return make_float4(color[0], color[1], color[2], 0.0f);
 }
 

@@ -139,8 +139,15 @@ int oracle_local_laplacian(const float *input, float *out, int wd, int ht, float
 int oracle_bilat(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, const void *in_, void *out_)
 {
   if(d->mode == DT_HIP_BILAT_LOCAL_LAPLACIAN) /* bilat.c:352-357 */
+  {
+    /* a 2- or 3-pixel side makes the reference read outside its buffers: undefined, refused (as the device does) */
+    {
+      const int m = piece->roi_in.width < piece->roi_in.height ? piece->roi_in.width : piece->roi_in.height;
+      if(m == 2 || m == 3) return 1;
+    }
     return oracle_local_laplacian((const float *)in_, (float *)out_, piece->roi_in.width, piece->roi_in.height, d->midtone,
                                   d->sigma_s, d->sigma_r, d->detail);
+  }
   if(d->mode != DT_HIP_BILAT_BILATERAL) return 1;
   const float *in = (const float *)in_;
   float *out = (float *)out_;
@@ -148,6 +155,9 @@ int oracle_bilat(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, cons
   const float scale = (float)(d->iscale / piece->roi_in.scale);
   grid_t b;
   grid_size(&b, width, height, 100.0f, d->sigma_s / scale, d->sigma_r);
+  /* the reference's blur touches four entries of every grid line unconditionally (bilateral.c:266-340): shorter
+   * lines are written past their end there -- undefined, refused (as the device does) */
+  if(b.size_x < 4 || b.size_y < 4 || b.size_z < 4) return 1;
   const int ox = b.size_z, oy = b.size_x * b.size_z, oz = 1;
   /* two spare grid rows like the reference's slice buffer (slicerows = size_y + 2 on one thread) */
   float *buf = (float *)calloc((size_t)oy * (b.size_y + 2), sizeof(float));

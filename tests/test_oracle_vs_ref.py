@@ -431,3 +431,37 @@ def test_develop_blend_raw(name, d):
     assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
     assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
     _exact(x, y, "blend " + name)
+
+
+import edge_cases
+
+
+@pytest.mark.parametrize("size", edge_cases.SIZES, ids=["%dx%d" % s for s in edge_cases.SIZES])
+@pytest.mark.parametrize("module", edge_cases.MODULES)
+def test_tiny_frames(module, size):
+    """one pixel, one row, one column, smaller than any tile / chunk / pyramid level / grid cell: the restatement
+    follows the reference wherever the reference is defined, and refuses where it is not"""
+    w, h = size
+    op, piece, data, inp, shape, pre = edge_cases.case(module, w, h)
+    o, r = ck.oracle(), ck.ref()
+    b = np.zeros(shape, np.float32) if pre is None else pre.copy()
+    if edge_cases.undefined_in_reference(module, w, h):
+        if module in ("bilat", "bilat_ll"):
+            assert ck.call(o, "oracle_" + op, piece, data, np.ascontiguousarray(inp), b) != 0
+        return  # the reference reads or writes outside its buffers here (it may crash): never called
+    a = b.copy()
+    threads = r.ref_get_num_threads()
+    r.ref_set_num_threads(1)  # the bilateral splat and the AMaZE tile buffer depend on the thread count
+    try:
+        assert ck.call(r, "ref_" + op, piece, data, np.ascontiguousarray(inp), a) == 0
+    finally:
+        r.ref_set_num_threads(threads)
+    assert ck.call(o, "oracle_" + op, piece, data, np.ascontiguousarray(inp), b) == 0
+    if module == "denoiseprofile":
+        o.oracle_denoiseprofile_sum_order(1)  # the one-thread reference's summation order
+        try:
+            b = np.zeros(shape, np.float32)
+            assert ck.call(o, "oracle_" + op, piece, data, np.ascontiguousarray(inp), b) == 0
+        finally:
+            o.oracle_denoiseprofile_sum_order(0)
+    _exact(a, b, "%s %dx%d" % (module, w, h))
