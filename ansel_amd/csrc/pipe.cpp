@@ -396,6 +396,117 @@ void band_rawprepare(dt_hip_piece_t &p, dt_hip_rawprepare_data_t &d, const dt_hi
 
 extern "C" {
 
+// ---- a stream of frames through one pipe: upload / kernels / download of consecutive frames overlap ----
+struct batch_slot_t
+{
+  dt_hip_mem_t d_in, d_out;
+  hipEvent_t up, done, down;
+  bool in_flight;
+};
+
+struct dt_hip_batch_t
+{
+  dt_hip_pipe_t *pipe;
+  size_t in_bytes, out_bytes;
+  hipStream_t s_up, s_down;
+  std::vector<batch_slot_t> slots;
+  int next;
+};
+
+dt_hip_batch_t *dt_hip_batch_new(dt_hip_pipe_t *pipe, int depth, size_t in_bytes, size_t out_bytes)
+{
+  if(!pipe || depth < 1 || depth > 8 || !in_bytes || !out_bytes) return nullptr;
+  dt_hip_batch_t *b = new dt_hip_batch_t;
+  b->pipe = pipe;
+  b->in_bytes = in_bytes;
+  b->out_bytes = out_bytes;
+  b->next = 0;
+  b->s_up = b->s_down = nullptr;
+  bool ok = hipStreamCreateWithFlags(&b->s_up, hipStreamNonBlocking) == hipSuccess
+            && hipStreamCreateWithFlags(&b->s_down, hipStreamNonBlocking) == hipSuccess;
+  for(int k = 0; k < depth && ok; k++)
+  {
+    batch_slot_t sl;
+    memset(&sl, 0, sizeof(sl));
+    sl.d_in = dt_hip_alloc_device_buffer(pipe->devid, in_bytes);
+    sl.d_out = dt_hip_alloc_device_buffer(pipe->devid, out_bytes);
+    ok = sl.d_in && sl.d_out && hipEventCreateWithFlags(&sl.up, hipEventDisableTiming) == hipSuccess
+         && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess
+         && hipEventCreateWithFlags(&sl.down, hipEventDisableTiming) == hipSuccess;
+    b->slots.push_back(sl);
+  }
+  if(!ok)
+  {
+    set_last_error("dt_hip_batch_new: could not create %d slots of %zu + %zu bytes", depth, in_bytes, out_bytes);
+    dt_hip_batch_free(b);
+    return nullptr;
+  }
+  return b;
+}
+
+void dt_hip_batch_free(dt_hip_batch_t *b)
+{
+  if(!b) return;
+  dt_hip_batch_drain(b);
+  for(batch_slot_t &sl : b->slots)
+  {
+    if(sl.d_in) dt_hip_release_mem_object(sl.d_in);
+    if(sl.d_out) dt_hip_release_mem_object(sl.d_out);
+    if(sl.up) (void)hipEventDestroy(sl.up);
+    if(sl.done) (void)hipEventDestroy(sl.done);
+    if(sl.down) (void)hipEventDestroy(sl.down);
+  }
+  if(b->s_up) (void)hipStreamDestroy(b->s_up);
+  if(b->s_down) (void)hipStreamDestroy(b->s_down);
+  delete b;
+}
+
+int dt_hip_batch_wait(dt_hip_batch_t *b, int slot)
+{
+  if(!b || slot < 0 || slot >= (int)b->slots.size()) return DT_HIP_INVALID_ARG;
+  batch_slot_t &sl = b->slots[slot];
+  if(!sl.in_flight) return DT_HIP_SUCCESS;
+  ANSEL_HIP_CHECK(hipEventSynchronize(sl.down));
+  sl.in_flight = false;
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_batch_drain(dt_hip_batch_t *b)
+{
+  if(!b) return DT_HIP_INVALID_ARG;
+  int err = DT_HIP_SUCCESS;
+  for(int k = 0; k < (int)b->slots.size(); k++)
+  {
+    const int e = dt_hip_batch_wait(b, k);
+    if(e != DT_HIP_SUCCESS) err = e;
+  }
+  return err;
+}
+
+int dt_hip_batch_submit(dt_hip_batch_t *b, const void *host_in, void *host_out)
+{
+  if(!b || !host_in || !host_out) return DT_HIP_INVALID_ARG;
+  const int k = b->next;
+  batch_slot_t &sl = b->slots[k];
+  // the slot's previous frame must have left the device before its buffers are reused
+  const int w = dt_hip_batch_wait(b, k);
+  if(w != DT_HIP_SUCCESS) return w;
+  hipStream_t compute = stream_of(b->pipe->devid);
+  ANSEL_HIP_CHECK(hipMemcpyAsync(sl.d_in, host_in, b->in_bytes, hipMemcpyHostToDevice, b->s_up));
+  ANSEL_HIP_CHECK(hipEventRecord(sl.up, b->s_up));
+  ANSEL_HIP_CHECK(hipStreamWaitEvent(compute, sl.up, 0));
+  const int err = dt_hip_pipe_process(b->pipe, sl.d_in, sl.d_out);
+  if(err != DT_HIP_SUCCESS) return err;
+  ANSEL_HIP_CHECK(hipEventRecord(sl.done, compute));
+  ANSEL_HIP_CHECK(hipStreamWaitEvent(b->s_down, sl.done, 0));
+  ANSEL_HIP_CHECK(hipMemcpyAsync(host_out, sl.d_out, b->out_bytes, hipMemcpyDeviceToHost, b->s_down));
+  ANSEL_HIP_CHECK(hipEventRecord(sl.down, b->s_down));
+  sl.in_flight = true;
+  b->next = (k + 1) % (int)b->slots.size();
+  return k;
+}
+
+
 int dt_hip_plan_bands(int width, int height, int demosaic_method, int n_bands, dt_hip_band_t *bands)
 {
   if(width <= 0 || height <= 0 || n_bands <= 0 || !bands) return DT_HIP_INVALID_ARG;

@@ -91,6 +91,11 @@ def load():
         "dt_hip_pipe_set_fusion": (None, [vp, i]),
         "dt_hip_pipe_num_groups": (i, [vp]),
         "dt_hip_pipe_process": (i, [vp, vp, vp]),
+        "dt_hip_batch_new": (vp, [vp, i, sz, sz]),
+        "dt_hip_batch_free": (None, [vp]),
+        "dt_hip_batch_submit": (i, [vp, vp, vp]),
+        "dt_hip_batch_wait": (i, [vp, i]),
+        "dt_hip_batch_drain": (i, [vp]),
         "dt_hip_plan_bands": (i, [i, i, i, i, P(abi.Band)]),
         "dt_hip_pipe_band_begin": (i, [vp, P(abi.Band), vp, P(abi.BandState)]),
         "dt_hip_pipe_band_resolve": (i, [vp, P(abi.Band), P(abi.BandState)]),
@@ -149,6 +154,13 @@ class DeviceBuffer:
         check(b.lib.dt_hip_write_host_to_device(devid, arr.ctypes.data_as(C.c_void_p), b.ptr, arr.nbytes, 1, 1),
               "write_host_to_device")
         return b
+
+    def upload(self, arr):
+        import numpy as np
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(self.lib.dt_hip_write_host_to_device(self.devid, arr.ctypes.data_as(C.c_void_p), self.ptr, arr.nbytes, 1, 1),
+              "write_host_to_device")
 
     def to_numpy(self, shape, dtype):
         import numpy as np

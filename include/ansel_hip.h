@@ -493,6 +493,22 @@ void dt_hip_pipe_set_fusion(dt_hip_pipe_t *pipe, int enabled);
 int dt_hip_pipe_num_groups(dt_hip_pipe_t *pipe);
 int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
+/* ---- 3a. a stream of frames through one pipe (batch export) ---------------------------------- */
+/* The export loop of a batch (src/cli + dt_imageio_export_with_flags(), src/imageio/imageio_core.c) pushes one
+ * frame after the other through the same pipe.  Serially a frame costs upload + kernels + download; here the three
+ * legs of consecutive frames overlap: `depth` slots, each with its own device input and output buffer, the upload
+ * on one copy stream, the kernels on the device's compute stream, the download on a second copy stream, ordered by
+ * events.  Host buffers must be pinned (dt_hip_alloc_host_pinned) and stay untouched until the slot is waited for.
+ *   slot = dt_hip_batch_submit(b, host_in, host_out)   enqueue a frame; blocks only when every slot is in flight
+ *   dt_hip_batch_wait(b, slot)                          the frame submitted into `slot` is in host_out
+ *   dt_hip_batch_drain(b)                               all of them are */
+typedef struct dt_hip_batch_t dt_hip_batch_t;
+dt_hip_batch_t *dt_hip_batch_new(dt_hip_pipe_t *pipe, int depth, size_t in_bytes, size_t out_bytes);
+void dt_hip_batch_free(dt_hip_batch_t *batch);
+int dt_hip_batch_submit(dt_hip_batch_t *batch, const void *host_in, void *host_out);
+int dt_hip_batch_wait(dt_hip_batch_t *batch, int slot);
+int dt_hip_batch_drain(dt_hip_batch_t *batch);
+
 /* ---- 3b. one frame over several devices: row bands ---------------------------------------- */
 /* Replaces default_process_tiling_cl() / _default_process_tiling_cl_ptp() (src/develop/tiling.c:842,
  * :1394) for a frame that is split because there are several GPUs, not because it does not fit.
