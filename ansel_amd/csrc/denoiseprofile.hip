@@ -191,12 +191,14 @@ __device__ __forceinline__ double wave_sum_halving(double v)
 __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                     float4 *__restrict__ detail, double *__restrict__ partial,
                                                     const int width, const int height, const int mult,
-                                                    const float inv_sigma2)
+                                                    const float inv_sigma2, const int nseg)
 {
   __shared__ double runs[4][4];
+  const int bx = xcd_col(); // hip_common.h: the column block, pinned to an XCD for 64 rows of the walk
+  if(bx >= nseg) return;
   const int row = walk_row(blockIdx.y, height, mult);
   if(row < 0) return;
-  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int col = bx * 256 + threadIdx.x;
   double sq[4] = { 0.0, 0.0, 0.0, 0.0 };
   if(col < width)
   {
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
   {
     const int c = threadIdx.x;
     const double seg = ((runs[0][c] + runs[1][c]) + runs[2][c]) + runs[3][c];
-    partial[4 * ((size_t)row * gridDim.x + blockIdx.x) + c] = seg;
+    partial[4 * ((size_t)row * nseg + bx) + c] = seg;
   }
 }
 
@@ -640,7 +642,8 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
     const int rows = (h <= mult) ? h : ((h + mult - 1) / mult) * mult;
     {
       launch_scope ls(devid, "dn_decompose");
-      dn_decompose<<<dim3(nseg, rows), 256, 0, st>>>(b1, b2, det, partial, w, h, mult, 1.0f / (sigma_band * sigma_band));
+      dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(b1, b2, det, partial, w, h, mult,
+                                                               1.0f / (sigma_band * sigma_band), nseg);
     }
     thr_args ta;
     ta.n_partial = n_partial;

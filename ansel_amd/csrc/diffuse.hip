@@ -75,13 +75,15 @@ __device__ __forceinline__ float4 vertical5(const float4 *__restrict__ in, const
 template <int R, int T>
 __global__ __launch_bounds__(256) void bspline_decompose(const float4 *__restrict__ in, float4 *__restrict__ hf,
                                                          float4 *__restrict__ lf, const int width, const int height,
-                                                         const int mult, const int groups)
+                                                         const int mult, const int groups, const int gx)
 {
   __shared__ float4 vert[(T + 4) * R + 2];
+  const int bx = xcd_col(); // hip_common.h: the column block, pinned to an XCD for 64 rows of the walk
+  if(bx >= gx) return;
   const int row = walk_row(blockIdx.y, height, mult);
   if(row < 0) return;
-  // blockIdx.x = step tile * groups + residue group
-  const int group = blockIdx.x % groups, tile = blockIdx.x / groups;
+  // bx = step tile * groups + residue group
+  const int group = bx % groups, tile = bx / groups;
   const int r0 = group * R, k0 = tile * T;
   const int tid = threadIdx.x;
   const int r = tid % R, k = tid / R;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf
                                                    float4 *__restrict__ out, const pde_args a, const int final_pass)
 {
   const int row = walk_row(blockIdx.y, a.height, a.mult);
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int col = xcd_col() * blockDim.x + threadIdx.x; // hip_common.h: column block pinned to an XCD for 64 rows
   if(row < 0 || col >= a.width) return;
   const size_t rows[3] = { (size_t)clampi(row - a.mult, 0, a.height - 1) * a.width, (size_t)row * a.width,
                            (size_t)clampi(row + a.mult, 0, a.height - 1) * a.width };
@@ -294,15 +296,16 @@ int launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, flo
   const int rows = (h <= mult) ? h : ((h + mult - 1) / mult) * mult;
   launch_scope ls(devid, "diffuse_decompose");
   if(mult == 1)
-    bspline_decompose<1, 256><<<dim3((steps + 255) / 256, rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1);
+    bspline_decompose<1, 256><<<dim3(xcd_pad((steps + 255) / 256), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 255) / 256);
   else if(mult == 2)
-    bspline_decompose<2, 128><<<dim3((steps + 127) / 128, rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1);
+    bspline_decompose<2, 128><<<dim3(xcd_pad((steps + 127) / 128), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 127) / 128);
   else if(mult == 4)
-    bspline_decompose<4, 64><<<dim3((steps + 63) / 64, rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1);
+    bspline_decompose<4, 64><<<dim3(xcd_pad((steps + 63) / 64), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 63) / 64);
   else
   {
     const int groups = mult / 8;
-    bspline_decompose<8, 32><<<dim3(((steps + 31) / 32) * groups, rows), 256, 0, s>>>(in, hf, lf, w, h, mult, groups);
+    bspline_decompose<8, 32><<<dim3(xcd_pad(((steps + 31) / 32) * groups), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, groups,
+                                                                                          ((steps + 31) / 32) * groups);
   }
   return check_launch("diffuse_decompose");
 }
@@ -390,7 +393,8 @@ int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_
       const int rows = (h <= a.mult) ? h : ((h + a.mult - 1) / a.mult) * a.mult;
       {
         launch_scope ls(devid, "diffuse_pde");
-        diffuse_pde<<<dim3((w + 255) / 256, rows), 256, 0, st>>>(hf[s], cur, to, a, s == 0);
+        // gridDim.x padded to a multiple of 8: a column block stays on one XCD, the rows above and below hit its L2
+        diffuse_pde<<<dim3(xcd_pad((w + 255) / 256), rows), 256, 0, st>>>(hf[s], cur, to, a, s == 0);
       }
       err = check_launch("diffuse_pde");
       cur = to;

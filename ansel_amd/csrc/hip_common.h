@@ -73,6 +73,18 @@ template <typename T> __device__ __forceinline__ const T &kernarg_at(const int o
   return *(const T *)(p4)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offset);
 }
 
+// XCD-aware 2-D launch for stencil kernels that walk the frame row by row.  The eight XCDs of an MI355X have
+// private L2s and workgroups are handed to them round-robin by linear workgroup id (x fastest); with gridDim.x not
+// a multiple of 8 the workgroups of a column block land on a different XCD row after row, and the rows a stencil
+// re-reads come from HBM / the Infinity Cache every time (dn_decompose: 5.2 planes fetched per plane of input).
+// With gridDim.x padded to a multiple of 8, column block bx always runs on XCD bx % 8 and that XCD sweeps the rows
+// in order: vertical taps hit its L2.  The padding workgroups (blockIdx.x >= the real count) must exit at once.
+// The padding would leave the XCDs that only get padding columns idle (38 column blocks: six XCDs sweep five, two
+// sweep four), so the assignment rotates by one XCD every 64 rows of the walk: xcd_col() is the logical column
+// block of this workgroup, >= gx for padding.
+static inline unsigned xcd_pad(const int gx) { return (unsigned)((gx + 7) / 8) * 8; }
+__device__ __forceinline__ int xcd_col() { return (int)((blockIdx.x + blockIdx.y / 64) % gridDim.x); }
+
 // Journal of the highlight-clip pass (pointwise.hip, pipe_fused.hip): number of photosites above the
 // threshold and the first 25 of them {index in the output buffer, unclipped value}.  In band mode
 // the leading count is summed over all bands before highlights_resolve_launch() decides the bypass.
