@@ -100,3 +100,25 @@ def undefined_in_reference(module, w, h):
         s = max(w / _x, h / _y)
         return int(np.ceil(w / s)) + 1 < 4 or int(np.ceil(h / s)) + 1 < 4
     return False
+
+
+STENCIL_MODULES = ["demosaic_rcd", "demosaic_ppg", "demosaic_amaze", "denoiseprofile", "denoiseprofile_nlm", "nlmeans", "bilat",
+                   "bilat_ll", "diffuse", "finalscale"]
+
+
+def adversarial(module, w=200, h=150):
+    """a stencil module's case with non-finite, denormal, huge and negative samples sprinkled over the input: what a
+    neighbourhood does with them (spreads a NaN, clamps it, divides by it) must be the reference's doing"""
+    op, piece, data, inp, shape, pre = case(module, w, h)
+    inp = np.array(inp, copy=True)
+    rng = np.random.default_rng(3)
+    specials = [np.nan, np.inf, -np.inf, 1e-41, -1e-41, 1e30, -1e30, -0.0, -5.0]
+    if module == "demosaic_amaze":
+        # finite samples only: a NaN born inside AMaZE is 0xFFC00000 on x86 and 0x7FC00000 on the GPU, and the
+        # reference reads those bytes back as Nyquist flags through its aliased planes (amaze.cc:300-327, :830) --
+        # a mosaic is finite by construction (u16 -> rawprepare), so that path has no input that reaches it
+        specials = specials[3:]
+    flat = inp.reshape(-1)
+    for k, i in enumerate(rng.choice(flat.size, size=60, replace=False)):
+        flat[i] = specials[k % len(specials)]
+    return op, piece, data, inp, shape, pre

@@ -62,3 +62,20 @@ def test_tiny_frames(module, size):
         ck.oracle().oracle_amaze_stale_mask(ck.ptr(m), w, h)  # rows / columns whose reference value is not a function of the input
         d = d * (m[..., None] == 0)
     assert int((d > 0).sum()) == 0, "%s %dx%d: %d differ, max %d ulp" % (module, w, h, int((d > 0).sum()), int(d.max()))
+
+
+@pytest.mark.parametrize("module", ec.STENCIL_MODULES)
+def test_stencils_on_adversarial_input(module):
+    """NaN, +-Inf, denormals, +-1e30, -0, negatives inside the neighbourhoods of the stencil modules: bit for bit what
+    the oracle (and through it the reference) makes of them"""
+    op, piece, data, inp, shape, pre = ec.adversarial(module)
+    want = np.zeros(shape, np.float32) if pre is None else pre.copy()
+    assert ck.call(ck.oracle(), "oracle_" + op, piece, data, np.ascontiguousarray(inp), want) == 0
+    got = hc.run_hip(_FN.get(op, "dt_hip_iop_%s_process" % op), piece, data, inp, shape, pre_fill=pre)
+    d = ck.ulp_diff(got, want)
+    if module == "demosaic_amaze":
+        h, w = shape[:2]
+        m = np.zeros((h, w), np.uint8)
+        ck.oracle().oracle_amaze_stale_mask(ck.ptr(m), w, h)
+        d = d * (m[..., None] == 0)
+    assert int((d > 0).sum()) == 0, "%s: %d differ, max %d ulp" % (module, int((d > 0).sum()), int(d.max()))

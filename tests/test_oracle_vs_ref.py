@@ -465,3 +465,31 @@ def test_tiny_frames(module, size):
         finally:
             o.oracle_denoiseprofile_sum_order(0)
     _exact(a, b, "%s %dx%d" % (module, w, h))
+
+
+@pytest.mark.parametrize("module", edge_cases.STENCIL_MODULES)
+def test_stencils_on_adversarial_input(module):
+    """NaN, +-Inf, denormals, +-1e30, -0, negatives inside the neighbourhoods of the stencil modules"""
+    op, piece, data, inp, shape, pre = edge_cases.adversarial(module)
+    o, r = ck.oracle(), ck.ref()
+    a = np.zeros(shape, np.float32) if pre is None else pre.copy()
+    b = a.copy()
+    threads = r.ref_get_num_threads()
+    r.ref_set_num_threads(1)
+    if module == "denoiseprofile":
+        o.oracle_denoiseprofile_sum_order(1)
+    try:
+        assert ck.call(r, "ref_" + op, piece, data, np.ascontiguousarray(inp), a) == 0
+        assert ck.call(o, "oracle_" + op, piece, data, np.ascontiguousarray(inp), b) == 0
+    finally:
+        r.ref_set_num_threads(threads)
+        o.oracle_denoiseprofile_sum_order(0)
+    mask = None
+    if module == "demosaic_rcd":
+        h, w = shape[:2]
+        m = np.zeros((h, w), np.uint8)
+        o.oracle_rcd_stale_mask(ck.ptr(m), w, h, C.c_uint32(synth.FILTERS_RGGB))
+        mask = np.zeros((h, w), np.uint8)
+        mask[:, w - 9:w - 6] = m[:, w - 9:w - 6]
+        mask = mask[..., None]
+    _exact(a, b, module + " adversarial", mask)
