@@ -237,3 +237,24 @@ def test_executor_blend_as_last_node_and_misplaced():
     with pytest.raises(lib.AnselHipError):
         p.process(din.ptr, dout.ptr)
     p.close()
+
+
+def test_very_large_frame_fused_equals_modulewise():
+    """201 MP (16384 x 12288): 3.2 GB per float4 plane, byte offsets beyond 2^31 in every RGBA kernel; the fused
+    executor, the unfused executor and the per-module entry points must export the same bytes"""
+    w, h = 16384, 12288
+    hc.hip()
+    raw = synth.bayer_mosaic_tiled(w, h, seed=3)
+    lut = params.srgb_encode_lut()
+    d_lut = lib.DeviceBuffer.from_numpy(0, lut)
+    coeffs = params.unbounded_coeffs(lut)
+    nodes = _nodes(w, h, d_lut.ptr, lut, coeffs)
+    fused, g1 = _run_executor(nodes, raw, w, h, fusion=True)
+    assert g1 == 3
+    # the last rows are where a 32-bit offset would have wrapped
+    assert fused[-64:].any() and fused[:64].any()
+    unfused, _ = _run_executor(nodes, raw, w, h, fusion=False)
+    assert np.array_equal(fused, unfused)
+    del unfused
+    modulewise = _run_chain_modulewise(nodes, raw, w, h)
+    assert np.array_equal(fused, modulewise)
