@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", default="100MP", help="24MP | 45MP | 60MP | 100MP | WxH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-legs", action="store_true",
+                    help="skip the PCIe-inclusive host-to-host measurements (profiling runs: only the timed region's kernels)")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per module (A/B against the fused executor)")
     ap.add_argument("--cpu-sample", default="24MP", help="frame size of the bounded CPU sample")
     ap.add_argument("--pipe", default="light", choices=("light", "denoise"),
@@ -153,7 +155,7 @@ def measured_traffic(tag, args):
     gfx950 corrections of MI355X_MICROARCH.md); None when no summary matches the configuration."""
     if args.size != "100MP" or args.pipe != "light" or args.no_fusion or args.mode != "batch":
         return None
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_bytes_100MP_light_fused.json")
+    path = os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_bytes_100MP_light_fused.json")
     try:
         kernels = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):
@@ -257,7 +259,7 @@ def main():
     #      basebuffer upload -> pipe -> exported frame back into pinned host memory
     host_ms = None
     host_overlap_ms = None
-    if rank == 0 and world == 1 and args.mode == "batch":
+    if rank == 0 and world == 1 and args.mode == "batch" and not args.no_host_legs:
         nb_in, nb_out = raw_host.nbytes, npix * 8
         pin_in, pin_out = l.dt_hip_alloc_host_pinned(nb_in), l.dt_hip_alloc_host_pinned(nb_out)
         if pin_in and pin_out:

@@ -9,9 +9,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python bench.py "$@" > "$OUT/bench.log" 2>&1
 tail -1 "$OUT/bench.log"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py "$@" --no-cpu-baseline > "$OUT/stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python bench.py "$@" --no-cpu-baseline > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python bench.py "$@" --no-cpu-baseline > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py "$@" --no-cpu-baseline --no-host-legs > "$OUT/stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python bench.py "$@" --no-cpu-baseline --no-host-legs > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python bench.py "$@" --no-cpu-baseline --no-host-legs > "$OUT/write.log" 2>&1
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/write" -name '*counter_collection.csv' | head -1)
 S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
