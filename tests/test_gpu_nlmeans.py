@@ -50,6 +50,15 @@ def test_nlmeans(w, h, radius, strength, luma, chroma):
     assert float(np.abs(got[..., :3] - img[..., :3]).max()) > 1e-3
 
 
+@pytest.mark.parametrize("radius", [5.0, 9.0])
+def test_nlmeans_large_patch_radius_takes_the_fallback_kernels(radius):
+    """patch radii whose column-sum table is wider than the pipelined kernel's fixed pitch (P >= 5) run the
+    barrier-per-step kernel, with the window staged in LDS while it fits and read from global beyond"""
+    w, h = 230, 150
+    img = _lab_image(w, h, 29)
+    _check("nlmeans", abi.Piece.make(w, h), abi.NlmeansData(radius, 80.0, 0.7, 0.9), img)
+
+
 def test_nlmeans_scaled_roi():
     w, h = 240, 170
     img = _lab_image(w, h, 5)
