@@ -244,11 +244,10 @@ BLEND_CS_LAB = 2
 BLEND_CS_RAW = 1
 # the operators of the "raw" colourspace (src/develop/blends/blendif_raw.c:290-353)
 BLEND_RAW_MODES = (0x18, 0x19, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x17, 0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x0E, 0x0F)
-# the operators of the "Lab" colourspace (src/develop/blends/blendif_lab.c:1070-1160) built on the device;
-# chroma 0x11, hue 0x12, color 0x13 and coloradjust 0x16 go through LCh and are refused
+# the operators of the "Lab" colourspace (src/develop/blends/blendif_lab.c:1070-1160), all twenty-seven
 BLEND_LAB_MODES = (0x18, 0x19, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x17, 0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x0E, 0x0F,
-                   0x10, 0x1A, 0x1B, 0x1E, 0x1F, 0x20)
-BLEND_LAB_REFUSED = (0x11, 0x12, 0x13, 0x16)
+                   0x10, 0x11, 0x12, 0x13, 0x16, 0x1A, 0x1B, 0x1E, 0x1F, 0x20)
+BLEND_LAB_REFUSED = ()
 # dt_develop_blendif_channels_t, Lab names
 BLENDIF_L_in, BLENDIF_A_in, BLENDIF_B_in, BLENDIF_C_in, BLENDIF_h_in = 0, 1, 2, 8, 9
 BLENDIF_L_out, BLENDIF_A_out, BLENDIF_B_out, BLENDIF_C_out, BLENDIF_h_out = 4, 5, 6, 12, 13

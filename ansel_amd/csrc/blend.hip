@@ -294,6 +294,24 @@ template <int OUT> __device__ __forceinline__ float combine_channels_lab(const f
 
 __device__ __forceinline__ float CL(const float x, const float lo, const float hi) { return fminf(fmaxf(x, lo), hi); } // _CLAMP()
 
+// dt_Lab_2_LCH() / dt_LCH_2_Lab(), src/common/colorspaces_inline_conversions.h:594-620
+__device__ __forceinline__ void lab_to_lch(const float (&Lab)[3], float (&LCH)[3])
+{
+  float var_H = ansel_math::atan2f_exact(Lab[2], Lab[1]);
+  if(var_H > 0.0f) var_H = var_H / (2.0f * 3.14159265358979324f);
+  else var_H = 1.0f - fabsf(var_H) / (2.0f * 3.14159265358979324f);
+  LCH[0] = Lab[0];
+  LCH[1] = ansel_math::hypotf_exact(Lab[1], Lab[2]);
+  LCH[2] = var_H;
+}
+
+__device__ __forceinline__ void lch_to_lab(const float (&LCH)[3], float (&Lab)[3])
+{
+  Lab[0] = LCH[0];
+  Lab[1] = ansel_math::cosf_exact(2.0f * 3.14159265358979324f * LCH[2]) * LCH[1];
+  Lab[2] = ansel_math::sinf_exact(2.0f * 3.14159265358979324f * LCH[2]) * LCH[1];
+}
+
 // the _blend_* row functions of blendif_lab.c:320-1068, one pixel: a = bottom, b = top layer
 __device__ __forceinline__ float4 blend_pixel_lab(const unsigned mode, const float4 a4, const float4 b4, const float lo)
 {
@@ -414,6 +432,34 @@ __device__ __forceinline__ float4 blend_pixel_lab(const unsigned mode, const flo
       tb[1] = CL(ta[1], min[1], max[1]);
       tb[2] = CL(ta[2], min[2], max[2]);
       break;
+    case LAB_CHROMATICITY:
+    case LAB_HUE:
+    case LAB_COLOR:
+    case LAB_COLORADJUST:
+    {
+      // blendif_lab.c:843-975: through LCh, hue blended along the shortest way round the colour circle; fmodf is
+      // exact in any correct implementation
+      float tta[3], ttb[3];
+#pragma unroll
+      for(int x = 0; x < 3; x++)
+      {
+        ta[x] = CL(ta[x], min[x], max[x]);
+        tb[x] = CL(tb[x], min[x], max[x]);
+      }
+      lab_to_lch(ta, tta);
+      lab_to_lch(tb, ttb);
+      if(mode != LAB_COLORADJUST) ttb[0] = tta[0];
+      const float chroma = (tta[1] * (1.0f - lo)) + ttb[1] * lo;
+      const float d = fabsf(tta[2] - ttb[2]);
+      const float sh = d > 0.5f ? -lo * (1.0f - d) / d : lo;
+      const float hue = fmodf((tta[2] * (1.0f - sh)) + ttb[2] * sh + 1.0f, 1.0f);
+      ttb[1] = mode == LAB_HUE ? tta[1] : chroma;
+      ttb[2] = mode == LAB_CHROMATICITY ? tta[2] : hue;
+      lch_to_lab(ttb, tb);
+#pragma unroll
+      for(int x = 0; x < 3; x++) tb[x] = CL(tb[x], min[x], max[x]);
+      break;
+    }
     case LAB_LAB_LIGHTNESS:
     case LAB_LAB_L:
       tb[0] = ta[0] * (1.0f - lo) + tb[0] * lo;
@@ -547,14 +593,6 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     set_last_error("blend: colourspace %d is not built (RGB (scene) %d, Lab %d and raw %d are)", d->blend_cst,
                    DT_HIP_BLEND_CS_RGB_SCENE, DT_HIP_BLEND_CS_LAB, DT_HIP_BLEND_CS_RAW);
     return DT_HIP_INVALID_ARG;
-  }
-  {
-    const unsigned m = d->blend_mode & 0xFFu;
-    if(lab && (m == LAB_CHROMATICITY || m == LAB_HUE || m == LAB_COLOR || m == LAB_COLORADJUST))
-    {
-      set_last_error("blend: the Lab operators through LCh (chroma, hue, color, coloradjust) are not built");
-      return DT_HIP_INVALID_ARG;
-    }
   }
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
   if(piece->channels != (raw ? 1 : 4)) return DT_HIP_INVALID_ARG;

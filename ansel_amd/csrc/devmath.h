@@ -410,4 +410,94 @@ ANSEL_HD float hypotf_exact(const float x, const float y)
   return (float)sqrt(dx * dx + dy * dy);
 }
 
+// ---- sinf / cosf: sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h --------------------------
+// (ARM optimized-routines: binary64 polynomials after a reduction by pi/2).  On x86-64 both are ifuncs and an
+// FMA-capable CPU runs the *_fma build, in which gcc contracts every a + b * c of the source: the fma() calls
+// below.  Callers: dt_LCH_2_Lab() of the Lab blend operators hue / color / chroma / coloradjust
+// (src/common/colorspaces_inline_conversions.h:608-620, src/develop/blends/blendif_lab.c:843-975).
+ANSEL_HD uint32_t sincosf_abstop12(const float x) { return (asuint(x) >> 20) & 0x7ff; }
+
+// sinf_poly(): n even -> sine polynomial, odd -> cosine; `alt` selects __sincosf_table[1] (cosine negated)
+ANSEL_HD float sincosf_poly(const double x, const double x2, const bool alt, const int n)
+{
+  const double sg = alt ? -1.0 : 1.0;
+  const double c0 = sg * 0x1p0, c1 = sg * -0x1.ffffffd0c621cp-2, c2 = sg * 0x1.55553e1068f19p-5,
+               c3 = sg * -0x1.6c087e89a359dp-10, c4 = sg * 0x1.99343027bf8c3p-16;
+  const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+  if((n & 1) == 0)
+  {
+    const double x3 = x * x2;
+    const double t1 = fma(x2, s3, s2);
+    const double x7 = x3 * x2;
+    const double t = fma(x3, s1, x);
+    return (float)fma(x7, t1, t);
+  }
+  const double x4 = x2 * x2;
+  const double u2 = fma(x2, c4, c3);
+  const double u1 = fma(x2, c1, c0);
+  const double x6 = x4 * x2;
+  const double u = fma(x4, c2, u1);
+  return (float)fma(x6, u2, u);
+}
+
+// reduce_fast(): |x| < 120
+ANSEL_HD double sincosf_reduce_fast(const double x, int *np)
+{
+  const double r = x * 0x1.45f306dc9c883p+23; // 2/pi * 2^24
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  *np = n;
+  return fma(-(double)n, 0x1.921fb54442d18p+0, x);
+}
+
+// reduce_large(): 120 <= |x| < inf, 192 bits of 4/pi
+ANSEL_HD double sincosf_reduce_large(uint32_t xi, int *np)
+{
+  const uint32_t inv_pio4[24] = { 0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+                                  0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+                                  0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041 };
+  const int idx = (xi >> 26) & 15;
+  const int shift = (xi >> 23) & 7;
+  xi = (xi & 0xffffff) | 0x800000;
+  xi <<= shift;
+  uint64_t res0 = (uint32_t)(xi * inv_pio4[idx]);
+  const uint64_t res1 = (uint64_t)xi * inv_pio4[idx + 4];
+  const uint64_t res2 = (uint64_t)xi * inv_pio4[idx + 8];
+  res0 = (res2 >> 32) | (res0 << 32);
+  res0 += res1;
+  const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+  res0 -= n << 62;
+  *np = (int)n;
+  return (double)(int64_t)res0 * 0x1.921fb54442d18p-62;
+}
+
+template <int COS> ANSEL_HD float sincosf_exact(const float y)
+{
+  const double sign[4] = { 1.0, -1.0, -1.0, 1.0 };
+  double x = (double)y;
+  int n;
+  if(sincosf_abstop12(y) < sincosf_abstop12(0x1.921fb6p-1f))
+  {
+    if(sincosf_abstop12(y) < sincosf_abstop12(0x1p-12f)) return COS ? 1.0f : y;
+    return sincosf_poly(x, x * x, false, COS);
+  }
+  if(sincosf_abstop12(y) < sincosf_abstop12(120.0f))
+  {
+    x = sincosf_reduce_fast(x, &n);
+    const double sg = sign[n & 3];
+    return sincosf_poly(x * sg, x * x, (n & 2) != 0, n ^ COS);
+  }
+  if(sincosf_abstop12(y) < sincosf_abstop12(INFINITY))
+  {
+    const uint32_t xi = asuint(y);
+    const int sgn = (int)(xi >> 31);
+    x = sincosf_reduce_large(xi, &n);
+    const double sg = sign[(n + sgn) & 3];
+    return sincosf_poly(x * sg, x * x, ((n + sgn) & 2) != 0, n ^ COS);
+  }
+  return (y - y) / (y - y); // __math_invalidf(): NaN
+}
+
+ANSEL_HD float sinf_exact(const float x) { return sincosf_exact<0>(x); }
+ANSEL_HD float cosf_exact(const float x) { return sincosf_exact<1>(x); }
+
 } // namespace ansel_math

@@ -436,10 +436,9 @@ int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iw
  * default of the Lab modules) and "raw" (src/develop/blends/blendif_raw.c: one-channel buffers before
  * demosaic, seventeen operators, opacity-only mask); mask modes uniform and parametric -- gray, R, G, B, Jz, Cz, hz resp. L, a, b,
  * C, h on input and output, all combine / invert variants --, the mask tone curve (contrast / brightness,
- * blend.c:626-655), the sixteen operators of blendif_rgb_jzczhz.c:328-650 resp. twenty-three of the
- * twenty-seven of blendif_lab.c:320-1068, and the reverse flag.  Refused with DT_HIP_INVALID_ARG (never
- * approximated): drawn and raster masks, feathering, mask blur, the details threshold, the Lab operators that
- * go through LCh (chroma, hue, color, coloradjust), the display-RGB colourspace, GUI mask display. */
+ * blend.c:626-655), the sixteen operators of blendif_rgb_jzczhz.c:328-650 resp. all twenty-seven of
+ * blendif_lab.c:320-1068, and the reverse flag.  Refused with DT_HIP_INVALID_ARG (never approximated): drawn and
+ * raster masks, feathering, mask blur, the details threshold, the display-RGB colourspace, GUI mask display. */
 #define DT_HIP_BLEND_CS_RAW 1 /* dt_develop_blend_colorspace_t, blend.h:51-58 */
 #define DT_HIP_BLEND_CS_LAB 2
 #define DT_HIP_BLEND_CS_RGB_DISPLAY 3

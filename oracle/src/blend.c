@@ -15,8 +15,6 @@
  *   Lab: make_mask, channel functions, operators, blend   src/develop/blends/blendif_lab.c:56-300, :302-1068, :1302-1420
  *   dt_Lab_2_LCH()                              src/common/colorspaces_inline_conversions.h:594-606
  *   raw: make_mask, operators, blend            src/develop/blends/blendif_raw.c:36-62, :66-353, :355-412
- * (the four Lab operators that go through LCh -- chroma, hue, color, coloradjust -- are not restated: the
- * device path refuses them)
  * One pass per pixel instead of the reference's one pass per mask channel: every step is pointwise,
  * so the order of the passes does not enter the arithmetic.
  * Pinned by tests/test_oracle_vs_ref.py against oracle/_ref (the reference's own functions). */
@@ -232,7 +230,26 @@ enum
 
 static int lab_mode_supported(const unsigned mode)
 {
-  return mode != LAB_CHROMATICITY && mode != LAB_HUE && mode != LAB_COLOR && mode != LAB_COLORADJUST;
+  (void)mode;
+  return 1;
+}
+
+/* dt_Lab_2_LCH() / dt_LCH_2_Lab(), src/common/colorspaces_inline_conversions.h:594-620 */
+static void lab_to_lch(const float *Lab, float *LCH)
+{
+  float var_H = atan2f(Lab[2], Lab[1]);
+  if(var_H > 0.0f) var_H = var_H / (2.0f * 3.14159265358979324f);
+  else var_H = 1.0f - fabsf(var_H) / (2.0f * 3.14159265358979324f);
+  LCH[0] = Lab[0];
+  LCH[1] = hypotf(Lab[1], Lab[2]);
+  LCH[2] = var_H;
+}
+
+static void lch_to_lab(const float *LCH, float *Lab)
+{
+  Lab[0] = LCH[0];
+  Lab[1] = cosf(2.0f * 3.14159265358979324f * LCH[2]) * LCH[1];
+  Lab[2] = sinf(2.0f * 3.14159265358979324f * LCH[2]) * LCH[1];
 }
 
 /* _blendif_combine_channels() of blendif_lab.c:139-173 */
@@ -371,6 +388,31 @@ static void blend_pixel_lab(const unsigned mode, const float *a, const float *b,
       tb[1] = CL(ta[1], min[1], max[1]);
       tb[2] = CL(ta[2], min[2], max[2]);
       break;
+    case LAB_CHROMATICITY:
+    case LAB_HUE:
+    case LAB_COLOR:
+    case LAB_COLORADJUST:
+    {
+      /* blendif_lab.c:843-975: through LCh, hue blended along the shortest way round the colour circle */
+      float tta[3], ttb[3];
+      for(int x = 0; x < 3; x++)
+      {
+        ta[x] = CL(ta[x], min[x], max[x]);
+        tb[x] = CL(tb[x], min[x], max[x]);
+      }
+      lab_to_lch(ta, tta);
+      lab_to_lch(tb, ttb);
+      if(mode != LAB_COLORADJUST) ttb[0] = tta[0];
+      const float chroma = (tta[1] * (1.0f - lo)) + ttb[1] * lo;
+      const float d = fabsf(tta[2] - ttb[2]);
+      const float sh = d > 0.5f ? -lo * (1.0f - d) / d : lo;
+      const float hue = fmodf((tta[2] * (1.0f - sh)) + ttb[2] * sh + 1.0f, 1.0f);
+      ttb[1] = mode == LAB_HUE ? tta[1] : chroma;
+      ttb[2] = mode == LAB_CHROMATICITY ? tta[2] : hue;
+      lch_to_lab(ttb, tb);
+      for(int x = 0; x < 3; x++) tb[x] = CL(tb[x], min[x], max[x]);
+      break;
+    }
     case LAB_LAB_LIGHTNESS:
     case LAB_LAB_L:
       tb[0] = ta[0] * (1.0f - lo) + tb[0] * lo;

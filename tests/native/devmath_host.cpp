@@ -31,6 +31,11 @@ void devmath_exp2f(const float *x, float *o, size_t n) { for(size_t i = 0; i < n
 void devmath_expf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::expf_exact(x[i]); }
 void devmath_atan2f(const float *y, const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::atan2f_exact(y[i], x[i]); }
 void devmath_hypotf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::hypotf_exact(x[i], y[i]); }
+void devmath_sinf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::sinf_exact(x[i]); }
+void devmath_cosf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::cosf_exact(x[i]); }
+void libm_sinf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = sinf(x[i]); }
+void libm_cosf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = cosf(x[i]); }
+void libm_fmodf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = fmodf(x[i], y[i]); }
 void libm_atan2f(const float *y, const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = atan2f(y[i], x[i]); }
 void libm_hypotf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = hypotf(x[i], y[i]); }
 void libm_powf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = powf(x[i], y[i]); }
@@ -75,6 +80,17 @@ int main(int argc, char **argv)
       else { a = rnd_range(-2.f, 2.f); b = (i & 4) ? 1.0f : ((i & 8) ? 0.0f : -0.0f); if(i & 16) { const float t = a; a = b; b = t; } }
       if(!strcmp(fn, "atan2f")) { r0 = atan2f(a, b); r1 = ansel_math::atan2f_exact(a, b); }
       else { r0 = hypotf(a, b); r1 = ansel_math::hypotf_exact(a, b); }
+    }
+    else if(!strcmp(fn, "sinf") || !strcmp(fn, "cosf"))
+    {
+      // mode 0: arbitrary bit patterns; 1: one turn (the hue angles of the callers); 2: the fast-reduction range; 3: beyond it
+      if(mode == 0) a = rnd_bits();
+      else if(mode == 1) a = rnd_range(-6.5f, 6.5f);
+      else if(mode == 2) a = rnd_range(-120.f, 120.f);
+      else a = rnd_range(-1e7f, 1e7f);
+      b = 0;
+      if(!strcmp(fn, "sinf")) { r0 = sinf(a); r1 = ansel_math::sinf_exact(a); }
+      else { r0 = cosf(a); r1 = ansel_math::cosf_exact(a); }
     }
     else if(!strcmp(fn, "log2f"))
     {

@@ -28,7 +28,7 @@ def _args(n, seed):
     return np.ascontiguousarray(x), np.ascontiguousarray(y)
 
 
-@pytest.mark.parametrize("fn", ["powf", "log2f", "exp2f", "expf", "atan2f", "hypotf"])
+@pytest.mark.parametrize("fn", ["powf", "log2f", "exp2f", "expf", "atan2f", "hypotf", "sinf", "cosf", "fmodf"])
 def test_device_libm_matches_host_libm(fn):
     n = 2_000_000
     x, y = _args(n, 17)
@@ -38,6 +38,14 @@ def test_device_libm_matches_host_libm(fn):
         rng = np.random.default_rng(5)
         x = np.concatenate([x[:n], (rng.random(n, dtype=np.float32) - 0.5).astype(np.float32), (rng.random(n, dtype=np.float32) * 2e-3 - 1e-3).astype(np.float32)])
         y = np.concatenate([y[:n], (rng.random(n, dtype=np.float32) - 0.5).astype(np.float32), (rng.random(n, dtype=np.float32) * 400.0 - 200.0).astype(np.float32)])
+    if fn in ("sinf", "cosf"):
+        rng = np.random.default_rng(6)
+        x = np.concatenate([x[:n], (rng.random(n, dtype=np.float32) * 13.0 - 6.5).astype(np.float32),
+                            (rng.random(n, dtype=np.float32) * 2e7 - 1e7).astype(np.float32)])
+    if fn == "fmodf":
+        rng = np.random.default_rng(7)
+        x = np.concatenate([x[:n], (rng.random(n, dtype=np.float32) * 4.0 - 1.0).astype(np.float32), (rng.random(n, dtype=np.float32) * 2000.0 - 1000.0).astype(np.float32)])
+        y = np.concatenate([y[:n], np.ones(n, np.float32), (rng.random(n, dtype=np.float32) * 7.0 + 0.01).astype(np.float32)])
     if fn == "expf":
         x = np.concatenate([x[:n], np.random.default_rng(4).random(2 * n, dtype=np.float32) * 205.0 - 110.0])
     h = hc.hip()
@@ -51,7 +59,9 @@ def test_device_libm_matches_host_libm(fn):
     got = do.to_numpy(x.shape, np.float32)
     exp = np.empty_like(x)
     hl = _hostlib()
-    if fn in ("atan2f", "hypotf"):
+    if fn == "fmodf":
+        hl.libm_fmodf(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+    elif fn in ("atan2f", "hypotf"):
         # first operand of the hook is y for atan2f(y, x)
         getattr(hl, "libm_" + fn)(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
     elif fn == "powf":
