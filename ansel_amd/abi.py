@@ -242,6 +242,11 @@ COMBINE_INV, COMBINE_INCL = 1, 2
 BLEND_CS_RGB_SCENE = 4
 BLEND_CS_LAB = 2
 BLEND_CS_RAW = 1
+BLEND_CS_RGB_DISPLAY = 3
+# the operators of the "RGB (display)" colourspace (src/develop/blends/blendif_rgb_hsl.c:915-1008), all thirty
+BLEND_DISPLAY_MODES = (0x18, 0x19, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x17, 0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x0E, 0x0F,
+                       0x10, 0x11, 0x12, 0x13, 0x16, 0x1C, 0x1D, 0x21, 0x22, 0x23)
+BLENDIF_H_in, BLENDIF_S_in, BLENDIF_l_in, BLENDIF_H_out, BLENDIF_S_out, BLENDIF_l_out = 8, 9, 10, 12, 13, 14
 # the operators of the "raw" colourspace (src/develop/blends/blendif_raw.c:290-353)
 BLEND_RAW_MODES = (0x18, 0x19, 0x02, 0x03, 0x04, 0x05, 0x06, 0x07, 0x08, 0x17, 0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x0E, 0x0F)
 # the operators of the "Lab" colourspace (src/develop/blends/blendif_lab.c:1070-1160), all twenty-seven

@@ -1,4 +1,4 @@
-// blend.hip -- the blend stage on gfx950 (blend colourspaces "RGB (scene)" and "Lab"): opacity mask and
+// blend.hip -- the blend stage on gfx950 (all four blend colourspaces: RGB scene, RGB display, Lab, raw): opacity mask and
 // blend operator in ONE pass.
 //
 // Reference: dt_develop_blend_process(), src/develop/blend.c:657-900, which runs after the process()
@@ -118,7 +118,10 @@ __device__ __forceinline__ void rgb_to_JzCzhz(const float4 rgb, const float (&mT
 }
 
 // _blendif_combine_channels(), blendif_rgb_jzczhz.c:151-194; OUT selects the output-side channels
-template <int OUT> __device__ __forceinline__ float combine_channels(const float4 px, float temp, const blend_args &a)
+__device__ __forceinline__ void rgb_to_hsl(const float (&RGB)[3], float (&HSL)[3]);
+
+// HSL: the RGB (display) colourspace, whose channels 8..10 are H, S, L instead of Jz, Cz, hz
+template <int OUT, bool HSL> __device__ __forceinline__ float combine_channels(const float4 px, float temp, const blend_args &a)
 {
   const unsigned blendif = OUT ? a.blendif >> GRAY_OUT : a.blendif; // uniform
   const float *const params = a.parameters + (OUT ? PARAM_ITEMS * GRAY_OUT : 0);
@@ -133,7 +136,13 @@ template <int OUT> __device__ __forceinline__ float combine_channels(const float
   if(blendif & ((1u << 8) | (1u << 9) | (1u << 10)))
   {
     float JzCzhz[3];
-    rgb_to_JzCzhz(px, a.mT, JzCzhz);
+    if(HSL)
+    {
+      const float rgb[3] = { px.x, px.y, px.z };
+      rgb_to_hsl(rgb, JzCzhz);
+    }
+    else
+      rgb_to_JzCzhz(px, a.mT, JzCzhz);
     float factor = 1.0f;
 #pragma unroll
     for(unsigned i = 0; i < 3; i++)
@@ -545,7 +554,182 @@ __global__ __launch_bounds__(256) void blend_raw_kernel(const float *__restrict_
   out[k] = reverse ? blend_value_raw(mode, b, a, m) : blend_value_raw(mode, a, b, m);
 }
 
-template <bool LAB, bool PARAMETRIC>
+
+// ---- RGB (display): src/develop/blends/blendif_rgb_hsl.c; HSL / HSV conversions of
+//      src/common/colorspaces_inline_conversions.h:421-565 -----------------------------------------------
+__device__ __forceinline__ float rgb_hue(const float (&RGB)[3], const float max, const float delta) // _dt_RGB_2_Hue()
+{
+  float hue;
+  if(RGB[0] == max) hue = (RGB[1] - RGB[2]) / delta;
+  else if(RGB[1] == max) hue = 2.0f + (RGB[2] - RGB[0]) / delta;
+  else hue = 4.0f + (RGB[0] - RGB[1]) / delta;
+  hue /= 6.0f;
+  if(hue < 0.0f) hue += 1.0f;
+  if(hue > 1.0f) hue -= 1.0f;
+  return hue;
+}
+
+__device__ __forceinline__ void hue_to_rgb(float (&RGB)[3], const float H, const float C, const float min) // _dt_Hue_2_RGB()
+{
+  const float h = H * 6.0f;
+  const float i = floorf(h);
+  const float f = h - i;
+  const float fc = f * C;
+  const float top = C + min;
+  const float inc = fc + min;
+  const float dec = top - fc;
+  // (size_t)i of the reference on x86: anything but 0 .. 4 (negative, >= 5, NaN) takes the last branch
+  const int sector = (i >= 0.0f && i < 5.0f) ? (int)i : 5;
+  RGB[0] = sector == 0 || sector == 5 ? top : (sector == 1 ? dec : (sector == 4 ? inc : min));
+  RGB[1] = sector == 1 || sector == 2 ? top : (sector == 0 ? inc : (sector == 3 ? dec : min));
+  RGB[2] = sector == 3 || sector == 4 ? top : (sector == 2 ? inc : (sector == 5 ? dec : min));
+}
+
+__device__ __forceinline__ void rgb_to_hsl(const float (&RGB)[3], float (&HSL)[3]) // dt_RGB_2_HSL()
+{
+  const float min = fminf(RGB[0], fminf(RGB[1], RGB[2]));
+  const float max = fmaxf(RGB[0], fmaxf(RGB[1], RGB[2]));
+  const float delta = max - min;
+  const float L = (max + min) / 2.0f;
+  float H = 0.0f, S = 0.0f;
+  if(fabsf(max) > 1e-6f && fabsf(delta) > 1e-6f)
+  {
+    if(L < 0.5f) S = delta / (max + min);
+    else S = delta / (2.0f - max - min);
+    H = rgb_hue(RGB, max, delta);
+  }
+  HSL[0] = H;
+  HSL[1] = S;
+  HSL[2] = L;
+}
+
+__device__ __forceinline__ void hsl_to_rgb(const float (&HSL)[3], float (&RGB)[3]) // dt_HSL_2_RGB()
+{
+  const float L = HSL[2];
+  float C;
+  if(L < 0.5f) C = L * HSL[1];
+  else C = (1.0f - L) * HSL[1];
+  const float m = L - C;
+  hue_to_rgb(RGB, HSL[0], 2.0f * C, m);
+}
+
+__device__ __forceinline__ void rgb_to_hsv(const float (&RGB)[3], float (&HSV)[3]) // dt_RGB_2_HSV()
+{
+  const float min = fminf(RGB[0], fminf(RGB[1], RGB[2]));
+  const float max = fmaxf(RGB[0], fmaxf(RGB[1], RGB[2]));
+  const float delta = max - min;
+  float S = 0.0f, H = 0.0f;
+  if(fabsf(max) > 1e-6f && fabsf(delta) > 1e-6f)
+  {
+    S = delta / max;
+    H = rgb_hue(RGB, max, delta);
+  }
+  HSV[0] = H;
+  HSV[1] = S;
+  HSV[2] = max;
+}
+
+__device__ __forceinline__ void hsv_to_rgb(const float (&HSV)[3], float (&RGB)[3]) // dt_HSV_2_RGB()
+{
+  const float C = HSV[1] * HSV[2];
+  const float m = HSV[2] - C;
+  hue_to_rgb(RGB, HSV[0], C, m);
+}
+
+enum { DSP_HSV_VALUE = 0x1C, DSP_HSV_COLOR = 0x1D };
+
+__device__ __forceinline__ float blend_value_raw(const unsigned mode, const float a, const float b, const float lo);
+
+// the _blend_* row functions of blendif_rgb_hsl.c:348-913, one pixel
+__device__ __forceinline__ float4 blend_pixel_display(const unsigned mode, const float4 a4, const float4 b4, const float lo)
+{
+  const float a[3] = { a4.x, a4.y, a4.z }, b[3] = { b4.x, b4.y, b4.z };
+  float out[3];
+  switch(mode)
+  {
+    case LAB_LIGHTNESS:
+    case LAB_CHROMATICITY:
+    case LAB_HUE:
+    case LAB_COLOR:
+    case LAB_COLORADJUST:
+    {
+      float ta[3], tb[3], tta[3], ttb[3];
+#pragma unroll
+      for(int k = 0; k < 3; k++)
+      {
+        ta[k] = fminf(fmaxf(a[k], 0.0f), 1.0f);
+        tb[k] = fminf(fmaxf(b[k], 0.0f), 1.0f);
+      }
+      rgb_to_hsl(ta, tta);
+      rgb_to_hsl(tb, ttb);
+      const float d = fabsf(tta[0] - ttb[0]);
+      const float sh = d > 0.5f ? -lo * (1.0f - d) / d : lo;
+      const float hue = fmodf((tta[0] * (1.0f - sh)) + ttb[0] * sh + 1.0f, 1.0f);
+      const float sat = (tta[1] * (1.0f - lo)) + ttb[1] * lo;
+      const float lig = (tta[2] * (1.0f - lo)) + ttb[2] * lo;
+      if(mode == LAB_LIGHTNESS) { ttb[0] = tta[0]; ttb[1] = tta[1]; ttb[2] = lig; }
+      else if(mode == LAB_CHROMATICITY) { ttb[0] = tta[0]; ttb[1] = sat; ttb[2] = tta[2]; }
+      else if(mode == LAB_HUE) { ttb[0] = hue; ttb[1] = tta[1]; ttb[2] = tta[2]; }
+      else if(mode == LAB_COLOR) { ttb[0] = hue; ttb[1] = sat; ttb[2] = tta[2]; }
+      else { ttb[0] = hue; ttb[1] = sat; } // coloradjust: lightness of the module output
+      hsl_to_rgb(ttb, out);
+#pragma unroll
+      for(int k = 0; k < 3; k++) out[k] = fminf(fmaxf(out[k], 0.0f), 1.0f);
+      break;
+    }
+    case DSP_HSV_VALUE:
+    {
+      float ta[3], tb[3];
+      rgb_to_hsv(a, ta);
+      rgb_to_hsv(b, tb);
+      tb[0] = ta[0];
+      tb[1] = ta[1];
+      tb[2] = ta[2] * (1.0f - lo) + tb[2] * lo;
+      hsv_to_rgb(tb, out);
+      break;
+    }
+    case DSP_HSV_COLOR:
+    {
+      float ta[3], tb[3];
+      rgb_to_hsv(a, ta);
+      rgb_to_hsv(b, tb);
+      const float xa = ta[1] * ansel_math::cosf_exact(2.0f * 3.14159265358979324f * ta[0]);
+      const float ya = ta[1] * ansel_math::sinf_exact(2.0f * 3.14159265358979324f * ta[0]);
+      const float xb = tb[1] * ansel_math::cosf_exact(2.0f * 3.14159265358979324f * tb[0]);
+      const float yb = tb[1] * ansel_math::sinf_exact(2.0f * 3.14159265358979324f * tb[0]);
+      const float xc = xa * (1.0f - lo) + xb * lo;
+      const float yc = ya * (1.0f - lo) + yb * lo;
+      tb[0] = ansel_math::atan2f_exact(yc, xc) / (2.0f * 3.14159265358979324f);
+      if(tb[0] < 0.0f) tb[0] += 1.0f;
+      tb[1] = sqrtf(xc * xc + yc * yc);
+      tb[2] = ta[2];
+      hsv_to_rgb(tb, out);
+      break;
+    }
+    case MODE_RGB_R:
+      out[0] = a[0] * (1.0f - lo) + b[0] * lo;
+      out[1] = a[1];
+      out[2] = a[2];
+      break;
+    case MODE_RGB_G:
+      out[0] = a[0];
+      out[1] = a[1] * (1.0f - lo) + b[1] * lo;
+      out[2] = a[2];
+      break;
+    case MODE_RGB_B:
+      out[0] = a[0];
+      out[1] = a[1];
+      out[2] = a[2] * (1.0f - lo) + b[2] * lo;
+      break;
+    default: // the per-channel operators: the formulas of the one-channel colourspace on each of R, G, B
+#pragma unroll
+      for(int k = 0; k < 3; k++) out[k] = blend_value_raw(mode, a[k], b[k], lo);
+      break;
+  }
+  return make_float4(out[0], out[1], out[2], lo);
+}
+
+template <int CS, bool PARAMETRIC>
 __global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, const blend_args a_by_value)
 {
   const blend_args &a = kernarg_at<blend_args>(16); // after the two pointers
@@ -559,15 +743,15 @@ __global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ i
   if(PARAMETRIC)
   {
     float temp = 1.0f;
-    if(LAB)
+    if(CS == DT_HIP_BLEND_CS_LAB)
     {
       temp = combine_channels_lab<0>(pa, temp, a);
       temp = combine_channels_lab<1>(pb, temp, a);
     }
     else
     {
-      temp = combine_channels<0>(pa, temp, a);
-      temp = combine_channels<1>(pb, temp, a);
+      temp = combine_channels<0, CS == DT_HIP_BLEND_CS_RGB_DISPLAY>(pa, temp, a);
+      temp = combine_channels<1, CS == DT_HIP_BLEND_CS_RGB_DISPLAY>(pb, temp, a);
     }
     if(a.inclusive)
       m = a.inversed ? a.global_opacity * (1.0f - a.seed) * temp : a.global_opacity * (1.0f - (1.0f - a.seed) * temp);
@@ -576,7 +760,8 @@ __global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ i
     if(a.tone) m = tone_curve(m, a);
   }
   float4 r;
-  if(LAB) r = a.reverse ? blend_pixel_lab(a.mode, pb, pa, m) : blend_pixel_lab(a.mode, pa, pb, m);
+  if(CS == DT_HIP_BLEND_CS_LAB) r = a.reverse ? blend_pixel_lab(a.mode, pb, pa, m) : blend_pixel_lab(a.mode, pa, pb, m);
+  else if(CS == DT_HIP_BLEND_CS_RGB_DISPLAY) r = a.reverse ? blend_pixel_display(a.mode, pb, pa, m) : blend_pixel_display(a.mode, pa, pb, m);
   else r = a.reverse ? blend_pixel(a.mode, pb, pa, a.p, m) : blend_pixel(a.mode, pa, pb, a.p, m);
   nt_store(out + k, r);
 }
@@ -588,10 +773,10 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
   const bool lab = d->blend_cst == DT_HIP_BLEND_CS_LAB, raw = d->blend_cst == DT_HIP_BLEND_CS_RAW;
-  if(d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !raw)
+  const bool display = d->blend_cst == DT_HIP_BLEND_CS_RGB_DISPLAY;
+  if(d->blend_cst < DT_HIP_BLEND_CS_RAW || d->blend_cst > DT_HIP_BLEND_CS_RGB_SCENE)
   {
-    set_last_error("blend: colourspace %d is not built (RGB (scene) %d, Lab %d and raw %d are)", d->blend_cst,
-                   DT_HIP_BLEND_CS_RGB_SCENE, DT_HIP_BLEND_CS_LAB, DT_HIP_BLEND_CS_RAW);
+    set_last_error("blend: unknown colourspace %d", d->blend_cst);
     return DT_HIP_INVALID_ARG;
   }
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
@@ -718,10 +903,13 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     launch_scope ls(devid, "blend_kernel");
     const float4 *const in = (const float4 *)dev_in;
     float4 *const out = (float4 *)dev_out;
-    if(lab && per_pixel) blend_kernel<true, true><<<pixel_grid(np), 256, 0, s>>>(in, out, a);
-    else if(lab) blend_kernel<true, false><<<pixel_grid(np), 256, 0, s>>>(in, out, a);
-    else if(per_pixel) blend_kernel<false, true><<<pixel_grid(np), 256, 0, s>>>(in, out, a);
-    else blend_kernel<false, false><<<pixel_grid(np), 256, 0, s>>>(in, out, a);
+    const unsigned grid = pixel_grid(np);
+    if(lab && per_pixel) blend_kernel<DT_HIP_BLEND_CS_LAB, true><<<grid, 256, 0, s>>>(in, out, a);
+    else if(lab) blend_kernel<DT_HIP_BLEND_CS_LAB, false><<<grid, 256, 0, s>>>(in, out, a);
+    else if(display && per_pixel) blend_kernel<DT_HIP_BLEND_CS_RGB_DISPLAY, true><<<grid, 256, 0, s>>>(in, out, a);
+    else if(display) blend_kernel<DT_HIP_BLEND_CS_RGB_DISPLAY, false><<<grid, 256, 0, s>>>(in, out, a);
+    else if(per_pixel) blend_kernel<DT_HIP_BLEND_CS_RGB_SCENE, true><<<grid, 256, 0, s>>>(in, out, a);
+    else blend_kernel<DT_HIP_BLEND_CS_RGB_SCENE, false><<<grid, 256, 0, s>>>(in, out, a);
   }
   return check_launch("blend_kernel");
 }

@@ -48,3 +48,10 @@ $X $R/develop/blends/blendif_raw.c $G/blendif_raw.inc dt_develop_blendif_raw_mak
   _blend_normal_unbounded _blend_lighten _blend_darken _blend_multiply _blend_average _blend_add _blend_subtract \
   _blend_difference _blend_screen _blend_overlay _blend_softlight _blend_hardlight _blend_vividlight _blend_linearlight \
   _blend_pinlight _choose_blend_func dt_develop_blendif_raw_blend
+$X $R/develop/blends/blendif_rgb_hsl.c $G/blendif_rgb_hsl.inc DT_BLENDIF_RGB_CH DT_BLENDIF_RGB_BCH _CLAMP_XYZ _PX_COPY \
+  _blendif_compute_factor _blendif_gray _blendif_gray_fb _blendif_rgb_red _blendif_rgb_green _blendif_rgb_blue _blendif_hsl \
+  _blendif_combine_channels dt_develop_blendif_rgb_hsl_make_mask _blend_normal_bounded _blend_normal_unbounded \
+  _blend_lighten _blend_darken _blend_multiply _blend_average _blend_add _blend_subtract _blend_difference _blend_screen \
+  _blend_overlay _blend_softlight _blend_hardlight _blend_vividlight _blend_linearlight _blend_pinlight _blend_lightness \
+  _blend_chromaticity _blend_hue _blend_color _blend_coloradjust _blend_HSV_value _blend_HSV_color _blend_RGB_R \
+  _blend_RGB_G _blend_RGB_B _choose_blend_func _copy_mask dt_develop_blendif_rgb_hsl_blend

@@ -53,6 +53,13 @@ void dt_develop_blendif_lab_blend(const struct dt_dev_pixelpipe_t *pipe, const s
                                   const float *const a, float *const b, const float *const restrict mask,
                                   const dt_dev_pixelpipe_display_mask_t request_mask_display);
 
+/* src/develop/blends/blendif_rgb_hsl.c, compiled in ref_blend_hsl.c */
+void dt_develop_blendif_rgb_hsl_make_mask(const struct dt_dev_pixelpipe_t *pipe, const struct dt_dev_pixelpipe_iop_t *piece,
+                                          const float *const restrict a, const float *const restrict b, float *const restrict mask);
+void dt_develop_blendif_rgb_hsl_blend(const struct dt_dev_pixelpipe_t *pipe, const struct dt_dev_pixelpipe_iop_t *piece,
+                                      const float *const restrict a, float *const restrict b, const float *const restrict mask,
+                                      const dt_dev_pixelpipe_display_mask_t request_mask_display);
+
 /* src/develop/blends/blendif_raw.c, compiled in ref_blend_raw.c */
 void dt_develop_blendif_raw_make_mask(const struct dt_dev_pixelpipe_iop_t *piece, const float *const restrict a,
                                       const float *const restrict b, float *const restrict mask);
@@ -83,7 +90,7 @@ static int parametric_used(const dt_develop_blend_params_t *params)
 int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, const void *in, void *out)
 {
   ref_reset_fp_mode();
-  if((h->blend_cst != DEVELOP_BLEND_CS_RGB_SCENE && h->blend_cst != DEVELOP_BLEND_CS_LAB && h->blend_cst != DEVELOP_BLEND_CS_RAW)
+  if(h->blend_cst < DEVELOP_BLEND_CS_RAW || h->blend_cst > DEVELOP_BLEND_CS_RGB_SCENE
      || (h->mask_mode & (DEVELOP_MASK_SHAPE | DEVELOP_MASK_RASTER))
      || h->feathering_radius != 0.f || h->blur_radius != 0.f || h->details != 0.f)
     return -1;
@@ -144,6 +151,8 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
       dt_develop_blendif_lab_make_mask(&piece, (const float *)in, (const float *)out, mask);
     else if(d.blend_cst == DEVELOP_BLEND_CS_RAW)
       dt_develop_blendif_raw_make_mask(&piece, (const float *)in, (const float *)out, mask);
+    else if(d.blend_cst == DEVELOP_BLEND_CS_RGB_DISPLAY)
+      dt_develop_blendif_rgb_hsl_make_mask(&pipe, &piece, (const float *)in, (const float *)out, mask);
     else
       dt_develop_blendif_rgb_jzczhz_make_mask(&pipe, &piece, (const float *)in, (const float *)out, mask);
     /* _develop_mask_get_post_operations(), blend.c:427-469, with feathering and blur absent */
@@ -155,6 +164,8 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
     dt_develop_blendif_lab_blend(&pipe, &piece, (const float *)in, (float *)out, mask, DT_DEV_PIXELPIPE_DISPLAY_NONE);
   else if(d.blend_cst == DEVELOP_BLEND_CS_RAW)
     dt_develop_blendif_raw_blend(&pipe, &piece, (const float *)in, (float *)out, mask, DT_DEV_PIXELPIPE_DISPLAY_NONE);
+  else if(d.blend_cst == DEVELOP_BLEND_CS_RGB_DISPLAY)
+    dt_develop_blendif_rgb_hsl_blend(&pipe, &piece, (const float *)in, (float *)out, mask, DT_DEV_PIXELPIPE_DISPLAY_NONE);
   else
     dt_develop_blendif_rgb_jzczhz_blend(&pipe, &piece, (const float *)in, (float *)out, mask, DT_DEV_PIXELPIPE_DISPLAY_NONE);
   dt_pixelpipe_cache_free_align(mask);

@@ -1,6 +1,6 @@
 /* oracle/src/blend.c -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
  *
- * CPU restatement of the blend stage, blend colourspaces "RGB (scene)", "Lab" and "raw", for the mask sources
+ * CPU restatement of the blend stage, all four blend colourspaces (RGB scene, RGB display, Lab, raw), for the mask sources
  * the device path supports (uniform opacity, parametric mask, mask tone curve).  It follows
  *   dt_develop_blend_process()                  src/develop/blend.c:657-900 (driver)
  *   dt_develop_blend_get_mask_usage()           src/develop/blend.c:262-320 (is the parametric mask in use)
@@ -15,6 +15,8 @@
  *   Lab: make_mask, channel functions, operators, blend   src/develop/blends/blendif_lab.c:56-300, :302-1068, :1302-1420
  *   dt_Lab_2_LCH()                              src/common/colorspaces_inline_conversions.h:594-606
  *   raw: make_mask, operators, blend            src/develop/blends/blendif_raw.c:36-62, :66-353, :355-412
+ *   RGB (display): mask channels, operators     src/develop/blends/blendif_rgb_hsl.c:56-216, :348-1008
+ *   dt_RGB_2_HSL() ... dt_HSV_2_RGB()           src/common/colorspaces_inline_conversions.h:421-565
  * One pass per pixel instead of the reference's one pass per mask channel: every step is pointwise,
  * so the order of the passes does not enter the arithmetic.
  * Pinned by tests/test_oracle_vs_ref.py against oracle/_ref (the reference's own functions). */
@@ -104,7 +106,11 @@ static void rgb_to_JzCzhz(const float *rgb, const float mT[3][4], float JzCzhz[3
 }
 
 /* _blendif_combine_channels(): `blendif` and `params` already shifted for the output side */
-static float combine_channels(const float *px, float temp, const unsigned blendif, const float *params, const blend_ctx_t *x)
+static void rgb_to_hsl(const float *RGB, float *HSL);
+
+/* `hsl`: the RGB (display) colourspace, whose channels 8..10 are H, S, L instead of Jz, Cz, hz */
+static float combine_channels(const float *px, float temp, const unsigned blendif, const float *params, const blend_ctx_t *x,
+                              const int hsl)
 {
   if(blendif & 1u)
   {
@@ -116,7 +122,8 @@ static float combine_channels(const float *px, float temp, const unsigned blendi
   if(blendif & ((1u << 8) | (1u << 9) | (1u << 10)))
   {
     float JzCzhz[3];
-    rgb_to_JzCzhz(px, x->xyz_d65_T, JzCzhz);
+    if(hsl) rgb_to_hsl(px, JzCzhz);
+    else rgb_to_JzCzhz(px, x->xyz_d65_T, JzCzhz);
     float factor = 1.0f;
     for(unsigned i = 0; i < 3; i++)
       factor *= compute_factor(JzCzhz[i], (blendif >> 16) & (1u << (8 + i)), params + PARAM_ITEMS * (8 + i));
@@ -528,6 +535,186 @@ static int blend_raw(const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d, 
   return 0;
 }
 
+/* ---- RGB (display) --------------------------------------------------------------------------------
+ * src/develop/blends/blendif_rgb_hsl.c; HSL / HSV conversions of src/common/colorspaces_inline_conversions.h:421-565 */
+static float rgb_hue(const float *RGB, const float max, const float delta) /* _dt_RGB_2_Hue() */
+{
+  float hue;
+  if(RGB[0] == max) hue = (RGB[1] - RGB[2]) / delta;
+  else if(RGB[1] == max) hue = 2.0f + (RGB[2] - RGB[0]) / delta;
+  else hue = 4.0f + (RGB[0] - RGB[1]) / delta;
+  hue /= 6.0f;
+  if(hue < 0.0f) hue += 1.0f;
+  if(hue > 1.0f) hue -= 1.0f;
+  return hue;
+}
+
+static void hue_to_rgb(float *RGB, const float H, const float C, const float min) /* _dt_Hue_2_RGB() */
+{
+  const float h = H * 6.0f;
+  const float i = floorf(h);
+  const float f = h - i;
+  const float fc = f * C;
+  const float top = C + min;
+  const float inc = fc + min;
+  const float dec = top - fc;
+  /* (size_t)i of the reference: anything but 0 .. 4 (negative, >= 5, NaN) takes the last branch */
+  const int sector = (i >= 0.0f && i < 5.0f) ? (int)i : 5;
+  if(sector == 0) { RGB[0] = top; RGB[1] = inc; RGB[2] = min; }
+  else if(sector == 1) { RGB[0] = dec; RGB[1] = top; RGB[2] = min; }
+  else if(sector == 2) { RGB[0] = min; RGB[1] = top; RGB[2] = inc; }
+  else if(sector == 3) { RGB[0] = min; RGB[1] = dec; RGB[2] = top; }
+  else if(sector == 4) { RGB[0] = inc; RGB[1] = min; RGB[2] = top; }
+  else { RGB[0] = top; RGB[1] = min; RGB[2] = dec; }
+}
+
+static void rgb_to_hsl(const float *RGB, float *HSL) /* dt_RGB_2_HSL() */
+{
+  const float min = fminf(RGB[0], fminf(RGB[1], RGB[2]));
+  const float max = fmaxf(RGB[0], fmaxf(RGB[1], RGB[2]));
+  const float delta = max - min;
+  const float L = (max + min) / 2.0f;
+  float H, S;
+  if(fabsf(max) > 1e-6f && fabsf(delta) > 1e-6f)
+  {
+    if(L < 0.5f) S = delta / (max + min);
+    else S = delta / (2.0f - max - min);
+    H = rgb_hue(RGB, max, delta);
+  }
+  else
+  {
+    H = 0.0f;
+    S = 0.0f;
+  }
+  HSL[0] = H;
+  HSL[1] = S;
+  HSL[2] = L;
+}
+
+static void hsl_to_rgb(const float *HSL, float *RGB) /* dt_HSL_2_RGB() */
+{
+  const float L = HSL[2];
+  float C;
+  if(L < 0.5f) C = L * HSL[1];
+  else C = (1.0f - L) * HSL[1];
+  const float m = L - C;
+  hue_to_rgb(RGB, HSL[0], 2.0f * C, m);
+}
+
+static void rgb_to_hsv(const float *RGB, float *HSV) /* dt_RGB_2_HSV() */
+{
+  const float min = fminf(RGB[0], fminf(RGB[1], RGB[2]));
+  const float max = fmaxf(RGB[0], fmaxf(RGB[1], RGB[2]));
+  const float delta = max - min;
+  float S, H;
+  if(fabsf(max) > 1e-6f && fabsf(delta) > 1e-6f)
+  {
+    S = delta / max;
+    H = rgb_hue(RGB, max, delta);
+  }
+  else
+  {
+    S = 0.0f;
+    H = 0.0f;
+  }
+  HSV[0] = H;
+  HSV[1] = S;
+  HSV[2] = max;
+}
+
+static void hsv_to_rgb(const float *HSV, float *RGB) /* dt_HSV_2_RGB() */
+{
+  const float C = HSV[1] * HSV[2];
+  const float m = HSV[2] - C;
+  hue_to_rgb(RGB, HSV[0], C, m);
+}
+
+enum { DSP_HSV_VALUE = 0x1C, DSP_HSV_COLOR = 0x1D };
+
+/* the _blend_* row functions of blendif_rgb_hsl.c:348-913, one pixel */
+static void blend_pixel_display(const unsigned mode, const float *a, const float *b, const float lo, float *out)
+{
+  switch(mode)
+  {
+    case LAB_LIGHTNESS:
+    case LAB_CHROMATICITY:
+    case LAB_HUE:
+    case LAB_COLOR:
+    case LAB_COLORADJUST:
+    {
+      float ta[3], tb[3], tta[3], ttb[3];
+      for(int k = 0; k < 3; k++)
+      {
+        ta[k] = clamp01(a[k]);
+        tb[k] = clamp01(b[k]);
+      }
+      rgb_to_hsl(ta, tta);
+      rgb_to_hsl(tb, ttb);
+      const float d = fabsf(tta[0] - ttb[0]);
+      const float sh = d > 0.5f ? -lo * (1.0f - d) / d : lo;
+      const float hue = fmodf((tta[0] * (1.0f - sh)) + ttb[0] * sh + 1.0f, 1.0f);
+      const float sat = (tta[1] * (1.0f - lo)) + ttb[1] * lo;
+      const float lig = (tta[2] * (1.0f - lo)) + ttb[2] * lo;
+      if(mode == LAB_LIGHTNESS) { ttb[0] = tta[0]; ttb[1] = tta[1]; ttb[2] = lig; }
+      else if(mode == LAB_CHROMATICITY) { ttb[0] = tta[0]; ttb[1] = sat; ttb[2] = tta[2]; }
+      else if(mode == LAB_HUE) { ttb[0] = hue; ttb[1] = tta[1]; ttb[2] = tta[2]; }
+      else if(mode == LAB_COLOR) { ttb[0] = hue; ttb[1] = sat; ttb[2] = tta[2]; }
+      else { ttb[0] = hue; ttb[1] = sat; } /* coloradjust: lightness of the module output */
+      hsl_to_rgb(ttb, out);
+      for(int k = 0; k < 3; k++) out[k] = clamp01(out[k]);
+      break;
+    }
+    case DSP_HSV_VALUE:
+    {
+      float ta[3], tb[3];
+      rgb_to_hsv(a, ta);
+      rgb_to_hsv(b, tb);
+      tb[0] = ta[0];
+      tb[1] = ta[1];
+      tb[2] = ta[2] * (1.0f - lo) + tb[2] * lo;
+      hsv_to_rgb(tb, out);
+      break;
+    }
+    case DSP_HSV_COLOR:
+    {
+      float ta[3], tb[3];
+      rgb_to_hsv(a, ta);
+      rgb_to_hsv(b, tb);
+      const float xa = ta[1] * cosf(2.0f * 3.14159265358979324f * ta[0]);
+      const float ya = ta[1] * sinf(2.0f * 3.14159265358979324f * ta[0]);
+      const float xb = tb[1] * cosf(2.0f * 3.14159265358979324f * tb[0]);
+      const float yb = tb[1] * sinf(2.0f * 3.14159265358979324f * tb[0]);
+      const float xc = xa * (1.0f - lo) + xb * lo;
+      const float yc = ya * (1.0f - lo) + yb * lo;
+      tb[0] = atan2f(yc, xc) / (2.0f * 3.14159265358979324f);
+      if(tb[0] < 0.0f) tb[0] += 1.0f;
+      tb[1] = sqrtf(xc * xc + yc * yc);
+      tb[2] = ta[2];
+      hsv_to_rgb(tb, out);
+      break;
+    }
+    case MODE_RGB_R:
+      out[0] = a[0] * (1.0f - lo) + b[0] * lo;
+      out[1] = a[1];
+      out[2] = a[2];
+      break;
+    case MODE_RGB_G:
+      out[0] = a[0];
+      out[1] = a[1] * (1.0f - lo) + b[1] * lo;
+      out[2] = a[2];
+      break;
+    case MODE_RGB_B:
+      out[0] = a[0];
+      out[1] = a[1];
+      out[2] = a[2] * (1.0f - lo) + b[2] * lo;
+      break;
+    default: /* the per-channel operators: the formulas of the one-channel colourspace on each of R, G, B */
+      for(int k = 0; k < 3; k++) out[k] = blend_value_raw(mode, a[k], b[k], lo);
+      break;
+  }
+  out[3] = lo;
+}
+
 int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d, const void *in_, void *out_)
 {
   if(!piece || !d || !in_ || !out_) return 1;
@@ -539,8 +726,8 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
     if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return 0;
     return blend_raw(piece, d, (const float *)in_, (float *)out_);
   }
-  const int lab = d->blend_cst == DT_HIP_BLEND_CS_LAB;
-  if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab) || (d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER))
+  const int lab = d->blend_cst == DT_HIP_BLEND_CS_LAB, display = d->blend_cst == DT_HIP_BLEND_CS_RGB_DISPLAY;
+  if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !display) || (d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER))
      || d->feathering_radius != 0.f || d->blur_radius != 0.f || d->details != 0.f || piece->channels != 4)
     return 1;
   if(lab && !lab_mode_supported(d->blend_mode & 0xFFu)) return 1;
@@ -656,8 +843,8 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
         }
         else
         {
-          temp = combine_channels(a, temp, x.blendif, x.parameters, &x);
-          temp = combine_channels(b, temp, x.blendif >> GRAY_OUT, x.parameters + PARAM_ITEMS * GRAY_OUT, &x);
+          temp = combine_channels(a, temp, x.blendif, x.parameters, &x, display);
+          temp = combine_channels(b, temp, x.blendif >> GRAY_OUT, x.parameters + PARAM_ITEMS * GRAY_OUT, &x, display);
         }
         if(mask_inclusive)
           m = mask_inversed ? global_opacity * (1.0f - seed) * temp : global_opacity * (1.0f - (1.0f - seed) * temp);
@@ -669,6 +856,11 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
       {
         if(reverse) blend_pixel_lab(mode, b, a, m, bo);
         else blend_pixel_lab(mode, a, b, m, bo);
+      }
+      else if(display)
+      {
+        if(reverse) blend_pixel_display(mode, b, a, m, bo);
+        else blend_pixel_display(mode, a, b, m, bo);
       }
       else if(reverse) blend_pixel(mode, b, a, p, m, bo);
       else blend_pixel(mode, a, b, p, m, bo);

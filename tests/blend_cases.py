@@ -152,3 +152,44 @@ def raw_cases():
         d.contrast, d.brightness = 0.3, 0.2
         out.append(("raw-parametric-c%d" % combine, d))
     return out
+
+
+def display_images(w, h, seed):
+    """(module input, module output), display-referred: mostly inside [0, 1], some outside, greys, zeros, non-finite"""
+    a = synth.rgba_image(w, h, seed=seed, lo=-0.05, hi=1.15)
+    rng = np.random.default_rng(seed + 200)
+    b = synth.rgba_image(w, h, seed=seed + 1, lo=-0.05, hi=1.15)
+    b[..., :3] = 0.5 * b[..., :3] + 0.5 * a[..., :3] * rng.uniform(0.6, 1.5, size=(h, w, 1)).astype(np.float32)
+    a[2, 3, :3] = 0.4          # grey: delta 0
+    b[4, 5, :3] = 0.0
+    a[6, 7, :3] = (1.0, 1.0, 0.2)
+    b[8, 9, :3] = (0.3, 0.9, 0.9)
+    a[10, 11, 0] = np.inf
+    b[12, 13, 2] = np.nan
+    a[..., 3] = 0.25
+    b[..., 3] = 0.75
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def display_cases():
+    out = []
+    D = abi.BLEND_CS_RGB_DISPLAY
+    for mode in abi.BLEND_DISPLAY_MODES:
+        out.append(("dsp-uniform-%02x" % mode, abi.BlendData.uniform(M, 64.0, mode, blend_cst=D)))
+    out.append(("dsp-reverse-color", abi.BlendData.uniform(M, 75.0, 0x13 | abi.BLEND_REVERSE, blend_cst=D)))
+    for ch, tr in ((abi.BLENDIF_GRAY_in, (0.05, 0.2, 0.6, 0.9)), (abi.BLENDIF_RED_out, (0.3, 0.5, 1.0, 1.0)),
+                   (abi.BLENDIF_H_in, (0.1, 0.3, 0.6, 0.8)), (abi.BLENDIF_S_in, (0.0, 0.0, 0.4, 0.7)),
+                   (abi.BLENDIF_l_in, (0.2, 0.4, 1.0, 1.0)), (abi.BLENDIF_H_out, (0.5, 0.6, 0.9, 0.95)),
+                   (abi.BLENDIF_S_out, (0.1, 0.3, 1.0, 1.0)), (abi.BLENDIF_l_out, (0.0, 0.0, 0.5, 0.8))):
+        out.append(("dsp-param-ch%d" % ch, abi.BlendData.uniform(M, 85.0, blend_cst=D).channel(ch, *tr)))
+        out.append(("dsp-param-ch%d-inv" % ch, abi.BlendData.uniform(M, 85.0, 0x0A, blend_cst=D).channel(ch, *tr, invert=True)))
+    for combine in (0, abi.COMBINE_INV, abi.COMBINE_INCL, abi.COMBINE_INV | abi.COMBINE_INCL):
+        d = abi.BlendData.uniform(M, 72.0, 0x12, blend_cst=D)
+        d.channel(abi.BLENDIF_GRAY_in, 0.05, 0.25, 0.7, 1.0)
+        d.channel(abi.BLENDIF_H_in, 0.1, 0.3, 0.8, 0.95)
+        d.channel(abi.BLENDIF_S_out, 0.05, 0.2, 1.0, 1.0)
+        d.channel(abi.BLENDIF_l_out, 0.0, 0.0, 0.6, 0.9, invert=True)
+        d.mask_combine = combine
+        d.contrast, d.brightness = 0.3, -0.2
+        out.append(("dsp-multi-c%d" % combine, d))
+    return out

@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_checker_threads():
+    """The CPU checkers (oracle, oracle/_ref) are OpenMP code; on a 256-thread host their loops over the small
+    frames of these tests spend seconds per call forking and joining.  32 threads keep the full-frame checks fast
+    and the small ones cheap.  (bench.py's cpu_baseline is a separate process and uses every core.)"""
+    import ctypes
+    if (os.cpu_count() or 1) > 32 and "OMP_NUM_THREADS" not in os.environ:
+        try:
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(32)
+        except OSError:
+            pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def ref_lib():
     import checkers

@@ -1,4 +1,4 @@
-"""-m gpu: the blend stage (RGB (scene) and Lab: uniform / parametric mask, tone curve, 16 + 23 operators) through the
+"""-m gpu: the blend stage (all four blend colourspaces: uniform / parametric mask, tone curve, 16 + 30 + 27 + 17 operators) through the
 C-ABI, bit for bit against the oracle and the reference's own functions."""
 import ctypes as C
 
@@ -63,6 +63,16 @@ def test_blend_lab_refuses_the_lch_operators(mode):
     assert h_.dt_hip_finish(0) == 1
 
 
+DSP_CASES = blend_cases.display_cases()
+
+
+@pytest.mark.parametrize("name,d", DSP_CASES, ids=[c[0] for c in DSP_CASES])
+def test_blend_display(name, d):
+    w, h = 131, 67
+    a, b = blend_cases.display_images(w, h, 71)
+    _check(abi.Piece.make(w, h), d, a, b, name)
+
+
 RAW_CASES = blend_cases.raw_cases()
 
 
@@ -89,7 +99,7 @@ def test_blend_full_frame():
     _check(abi.Piece.make(w, h), d, a, b, "24 MP")
 
 
-@pytest.mark.parametrize("field,value", [("blend_cst", 3), ("feathering_radius", 5.0), ("blur_radius", 3.0), ("details", 0.5),
+@pytest.mark.parametrize("field,value", [("blend_cst", 5), ("blend_cst", 0), ("feathering_radius", 5.0), ("blur_radius", 3.0), ("details", 0.5),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_SHAPE),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_RASTER)])
 def test_blend_refuses_what_is_not_built(field, value):

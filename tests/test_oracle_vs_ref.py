@@ -493,3 +493,16 @@ def test_stencils_on_adversarial_input(module):
         mask[:, w - 9:w - 6] = m[:, w - 9:w - 6]
         mask = mask[..., None]
     _exact(a, b, module + " adversarial", mask)
+
+
+@pytest.mark.parametrize("name,d", blend_cases.display_cases(), ids=[c[0] for c in blend_cases.display_cases()])
+def test_develop_blend_display(name, d):
+    """the blend stage, RGB (display): gray / R / G / B / H / S / L masks, all 30 operators (HSL, HSV, per channel)"""
+    w, h = 131, 67
+    a, b = blend_cases.display_images(w, h, 71)
+    piece = abi.Piece.make(w, h)
+    r, o = ck.ref(), ck.oracle()
+    x, y = b.copy(), b.copy()
+    assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
+    assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
+    _exact(x, y, "blend " + name)
