@@ -431,14 +431,13 @@ int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iw
  * dt_develop_blend_params_t (src/develop/blend.h:199-244) the supported paths read, under the
  * reference's names, plus the work profile's RGB -> XYZ(D50) matrix that
  * dt_develop_blendif_init_masking_profile() (blend.c:322-353) turns into the masking profile.
- * Built: the blend colourspaces "RGB (scene)" (src/develop/blends/blendif_rgb_jzczhz.c; LINEAR work profile,
- * nonlinearlut == 0, every scene-referred module's case), "Lab" (src/develop/blends/blendif_lab.c, the
- * default of the Lab modules) and "raw" (src/develop/blends/blendif_raw.c: one-channel buffers before
- * demosaic, seventeen operators, opacity-only mask); mask modes uniform and parametric -- gray, R, G, B, Jz, Cz, hz resp. L, a, b,
- * C, h on input and output, all combine / invert variants --, the mask tone curve (contrast / brightness,
- * blend.c:626-655), the sixteen operators of blendif_rgb_jzczhz.c:328-650 resp. all twenty-seven of
- * blendif_lab.c:320-1068, and the reverse flag.  Refused with DT_HIP_INVALID_ARG (never approximated): drawn and
- * raster masks, feathering, mask blur, the details threshold, the display-RGB colourspace, GUI mask display. */
+ * Built: all four blend colourspaces -- "RGB (scene)" (src/develop/blends/blendif_rgb_jzczhz.c), "RGB (display)"
+ * (blendif_rgb_hsl.c), "Lab" (blendif_lab.c), "raw" (blendif_raw.c: one-channel buffers before demosaic); the RGB
+ * ones with a LINEAR work profile (nonlinearlut == 0) for the gray channel of the mask.  Mask modes uniform and
+ * parametric -- gray, R, G, B and Jz, Cz, hz resp. H, S, L; L, a, b, C, h -- on input and output, all combine / invert
+ * variants; the mask tone curve (contrast / brightness, blend.c:626-655); every operator of the four files (16, 30,
+ * 27, 17) and the reverse flag.  Refused with DT_HIP_INVALID_ARG (never approximated): drawn and raster masks,
+ * feathering, mask blur, the details threshold, GUI mask display. */
 #define DT_HIP_BLEND_CS_RAW 1 /* dt_develop_blend_colorspace_t, blend.h:51-58 */
 #define DT_HIP_BLEND_CS_LAB 2
 #define DT_HIP_BLEND_CS_RGB_DISPLAY 3

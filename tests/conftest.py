@@ -21,9 +21,13 @@ def _bounded_checker_threads():
     import ctypes
     if (os.cpu_count() or 1) > 32 and "OMP_NUM_THREADS" not in os.environ:
         try:
-            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(32)
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(32)  # the oracle (gcc)
         except OSError:
             pass
+        import checkers
+        r = checkers.ref()  # the reference's own code (clang, libomp)
+        if r is not None:
+            r.ref_set_num_threads(32)
     yield
 
 
