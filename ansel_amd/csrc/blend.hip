@@ -542,16 +542,17 @@ __device__ __forceinline__ float blend_value_raw(const unsigned mode, const floa
 }
 
 // the mask of the raw colourspace never depends on the photosite (blendif_raw.c:36-62)
-__global__ __launch_bounds__(256) void blend_raw_kernel(const float *__restrict__ in, float *__restrict__ out, const int owidth,
-                                                        const int oheight, const int iwidth, const int xoffs, const int yoffs,
-                                                        const float m, const unsigned mode, const int reverse)
+__global__ __launch_bounds__(256) void blend_raw_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                        const float *__restrict__ plane, const blend_args q)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if(k >= (size_t)owidth * oheight) return;
-  const int y = (int)(k / owidth), x = (int)(k - (size_t)y * owidth);
-  const float a = in[(size_t)(y + yoffs) * iwidth + xoffs + x];
+  if(k >= (size_t)q.owidth * q.oheight) return;
+  const int y = (int)(k / q.owidth), x = (int)(k - (size_t)y * q.owidth);
+  const float a = in[(size_t)(y + q.yoffs) * q.iwidth + q.xoffs + x];
   const float b = out[k];
-  out[k] = reverse ? blend_value_raw(mode, b, a, m) : blend_value_raw(mode, a, b, m);
+  float m = plane ? plane[k] : q.constant; // the blurred mask plane, or the same value everywhere
+  if(plane && q.tone) m = tone_curve(m, q);
+  out[k] = q.reverse ? blend_value_raw(q.mode, b, a, m) : blend_value_raw(q.mode, a, b, m);
 }
 
 
@@ -729,10 +730,99 @@ __device__ __forceinline__ float4 blend_pixel_display(const unsigned mode, const
   return make_float4(out[0], out[1], out[2], lo);
 }
 
-template <int CS, bool PARAMETRIC>
-__global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, const blend_args a_by_value)
+// ---- mask blur: dt_gaussian_blur(), src/pixel/gaussian.c:176-326, one channel, order 0, clamped to [0, 1] on the way
+//      in (CLAMPF, src/math/math.h:91).  Two recursive passes, each a forward and a backward second-order recurrence:
+//      sequential along the pass direction, one lane per column (vertical) or per row (horizontal).
+struct gauss_args
 {
-  const blend_args &a = kernarg_at<blend_args>(16); // after the two pointers
+  int width, height;
+  float a0, a1, a2, a3, b1, b2, coefp, coefn;
+};
+
+__device__ __forceinline__ float clampf01(const float a) { return a >= 0.0f ? (a <= 1.0f ? a : 1.0f) : 0.0f; }
+
+// one lane walks `n` samples `stride` apart: forward filter into dst, backward filter added to it
+__device__ __forceinline__ void gauss_line(const float *__restrict__ src, float *__restrict__ dst, const int n, const size_t stride,
+                                           const gauss_args &g)
+{
+  float xp = clampf01(src[0]), yb = xp * g.coefp, yp = yb;
+  for(int j = 0; j < n; j++)
+  {
+    const float xc = clampf01(src[j * stride]);
+    const float yc = (g.a0 * xc) + (g.a1 * xp) - (g.b1 * yp) - (g.b2 * yb);
+    dst[j * stride] = yc;
+    xp = xc;
+    yb = yp;
+    yp = yc;
+  }
+  float xn = clampf01(src[(size_t)(n - 1) * stride]), xa = xn, yn = xn * g.coefn, ya = yn;
+  for(int j = n - 1; j > -1; j--)
+  {
+    const float xc = clampf01(src[j * stride]);
+    const float yc = (g.a2 * xn) + (g.a3 * xa) - (g.b1 * yn) - (g.b2 * ya);
+    xa = xn;
+    xn = xc;
+    ya = yn;
+    yn = yc;
+    dst[j * stride] += yc;
+  }
+}
+
+__global__ __launch_bounds__(64) void gauss_vertical(const float *__restrict__ src, float *__restrict__ dst, const gauss_args g)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x; // consecutive lanes = consecutive columns: coalesced at every step
+  if(i < g.width) gauss_line(src + i, dst + i, g.height, (size_t)g.width, g);
+}
+
+__global__ __launch_bounds__(64) void gauss_horizontal(const float *__restrict__ src, float *__restrict__ dst, const gauss_args g)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x; // one row per lane; a lane re-uses its 64-byte line for 16 steps out of L1
+  if(j < g.height) gauss_line(src + (size_t)j * g.width, dst + (size_t)j * g.width, g.width, 1, g);
+}
+
+__global__ __launch_bounds__(256) void fill_plane(float *__restrict__ p, const size_t n, const float v)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k < n) p[k] = v;
+}
+
+// the parametric mask of a pixel, before the post operations (make_mask(), blendif_*.c)
+template <int CS> __device__ __forceinline__ float parametric_mask(const float4 pa, const float4 pb, const blend_args &a)
+{
+  float temp = 1.0f;
+  if(CS == DT_HIP_BLEND_CS_LAB)
+  {
+    temp = combine_channels_lab<0>(pa, temp, a);
+    temp = combine_channels_lab<1>(pb, temp, a);
+  }
+  else
+  {
+    temp = combine_channels<0, CS == DT_HIP_BLEND_CS_RGB_DISPLAY>(pa, temp, a);
+    temp = combine_channels<1, CS == DT_HIP_BLEND_CS_RGB_DISPLAY>(pb, temp, a);
+  }
+  if(a.inclusive) return a.inversed ? a.global_opacity * (1.0f - a.seed) * temp : a.global_opacity * (1.0f - (1.0f - a.seed) * temp);
+  return a.inversed ? a.global_opacity * (1.0f - a.seed * temp) : a.global_opacity * a.seed * temp;
+}
+
+// the mask plane of a frame, for the post operations that are not pointwise (blur)
+template <int CS>
+__global__ __launch_bounds__(256) void blend_mask_kernel(const float4 *__restrict__ in, const float4 *__restrict__ out,
+                                                         float *__restrict__ plane, const blend_args a_by_value)
+{
+  const blend_args &a = kernarg_at<blend_args>(24); // after the three pointers
+  (void)a_by_value;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= (size_t)a.owidth * a.oheight) return;
+  const int y = (int)(k / a.owidth), x = (int)(k - (size_t)y * a.owidth);
+  plane[k] = parametric_mask<CS>(in[(size_t)(y + a.yoffs) * a.iwidth + a.xoffs + x], out[k], a);
+}
+
+// MASK: 0 = the same value everywhere, 1 = parametric, computed here, 2 = read from the (blurred) mask plane
+template <int CS, int MASK>
+__global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                    const float *__restrict__ plane, const blend_args a_by_value)
+{
+  const blend_args &a = kernarg_at<blend_args>(24); // after the three pointers
   (void)a_by_value;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= (size_t)a.owidth * a.oheight) return;
@@ -740,23 +830,14 @@ __global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ i
   const float4 pa = in[(size_t)(y + a.yoffs) * a.iwidth + a.xoffs + x];
   const float4 pb = out[k];
   float m = a.constant;
-  if(PARAMETRIC)
+  if(MASK == 2)
   {
-    float temp = 1.0f;
-    if(CS == DT_HIP_BLEND_CS_LAB)
-    {
-      temp = combine_channels_lab<0>(pa, temp, a);
-      temp = combine_channels_lab<1>(pb, temp, a);
-    }
-    else
-    {
-      temp = combine_channels<0, CS == DT_HIP_BLEND_CS_RGB_DISPLAY>(pa, temp, a);
-      temp = combine_channels<1, CS == DT_HIP_BLEND_CS_RGB_DISPLAY>(pb, temp, a);
-    }
-    if(a.inclusive)
-      m = a.inversed ? a.global_opacity * (1.0f - a.seed) * temp : a.global_opacity * (1.0f - (1.0f - a.seed) * temp);
-    else
-      m = a.inversed ? a.global_opacity * (1.0f - a.seed * temp) : a.global_opacity * a.seed * temp;
+    m = plane[k];
+    if(a.tone) m = tone_curve(m, a);
+  }
+  if(MASK == 1)
+  {
+    m = parametric_mask<CS>(pa, pb, a);
     if(a.tone) m = tone_curve(m, a);
   }
   float4 r;
@@ -781,10 +862,9 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   }
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
   if(piece->channels != (raw ? 1 : 4)) return DT_HIP_INVALID_ARG;
-  if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->blur_radius != 0.f
-     || d->details != 0.f)
+  if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->details != 0.f)
   {
-    set_last_error("blend: drawn / raster masks, feathering, mask blur and the details threshold are not built");
+    set_last_error("blend: drawn / raster masks, feathering and the details threshold are not built");
     return DT_HIP_INVALID_ARG;
   }
   if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return DT_HIP_SUCCESS; // blend.c:673
@@ -845,18 +925,66 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   a.mode = d->blend_mode & 0xFFu;
   a.reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
   a.p = exp2f(d->blend_parameter);
+  // post operations run on parametric masks only (blend.c:759-900): blur, then the tone curve
+  const bool blur = parametric && d->blur_radius > 0.1f;
+  const size_t np = (size_t)a.owidth * a.oheight;
+  hipStream_t s = stream_of(devid);
+  // the blurred mask plane: `plane` holds the mask, `scratch` the vertically blurred one
+  float *plane = nullptr, *scratch = nullptr;
+  if(blur)
+  {
+    plane = (float *)dt_hip_alloc_device_buffer(devid, np * sizeof(float));
+    scratch = (float *)dt_hip_alloc_device_buffer(devid, np * sizeof(float));
+    if(!plane || !scratch)
+    {
+      if(plane) dt_hip_release_mem_object(plane);
+      if(scratch) dt_hip_release_mem_object(scratch);
+      return DT_HIP_SYSMEM_ALLOCATION;
+    }
+  }
+  auto blur_plane = [&]() {
+    // compute_gauss_params(), gaussian.c:44-95, order 0; sigma = blur_radius * roi_out->scale (blend.c:871)
+    gauss_args g;
+    g.width = a.owidth;
+    g.height = a.oheight;
+    const float sigma = d->blur_radius * (float)piece->roi_out.scale;
+    const float alpha = 1.695f / sigma;
+    const float ema = expf(-alpha);
+    const float ema2 = expf(-2.0f * alpha);
+    g.b1 = -2.0f * ema;
+    g.b2 = ema2;
+    const float k = (1.0f - ema) * (1.0f - ema) / (1.0f + (2.0f * alpha * ema) - ema2);
+    g.a0 = k;
+    g.a1 = k * (alpha - 1.0f) * ema;
+    g.a2 = k * (alpha + 1.0f) * ema;
+    g.a3 = -k * ema2;
+    g.coefp = (g.a0 + g.a1) / (1.0f + g.b1 + g.b2);
+    g.coefn = (g.a2 + g.a3) / (1.0f + g.b1 + g.b2);
+    launch_scope ls(devid, "blend_mask_blur");
+    gauss_vertical<<<(a.owidth + 63) / 64, 64, 0, s>>>(plane, scratch, g);
+    gauss_horizontal<<<(a.oheight + 63) / 64, 64, 0, s>>>(scratch, plane, g);
+  };
+  auto release_planes = [&]() {
+    if(plane) dt_hip_release_mem_object(plane);   // stream-ordered: re-used only by later launches
+    if(scratch) dt_hip_release_mem_object(scratch);
+  };
   if(raw)
   {
     // dt_develop_blendif_raw_make_mask(), blendif_raw.c:36-62: global opacity, optionally inverted -- the
     // conditions of a parametric mask have no channels to look at
     if(parametric) a.constant = mask_inversed ? global_opacity * (1.0f - seed) : seed * global_opacity;
-    if(a.tone) a.constant = tone_curve(a.constant, a);
-    const size_t np = (size_t)a.owidth * a.oheight;
+    if(blur)
+    {
+      fill_plane<<<pixel_grid(np), 256, 0, s>>>(plane, np, a.constant);
+      blur_plane();
+    }
+    else if(a.tone)
+      a.constant = tone_curve(a.constant, a);
     {
       launch_scope ls(devid, "blend_raw");
-      blend_raw_kernel<<<pixel_grid(np), 256, 0, stream_of(devid)>>>((const float *)dev_in, (float *)dev_out, a.owidth, a.oheight,
-                                                                      a.iwidth, a.xoffs, a.yoffs, a.constant, a.mode, a.reverse);
+      blend_raw_kernel<<<pixel_grid(np), 256, 0, s>>>((const float *)dev_in, (float *)dev_out, plane, a);
     }
+    release_planes();
     return check_launch("blend_raw");
   }
   if(per_pixel)
@@ -896,20 +1024,38 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
       }
     for(int c = 0; c < 3; c++) a.luma[c] = d->matrix_in[1][c];
   }
-  if(!per_pixel && a.tone) a.constant = tone_curve(a.constant, a); // the same value for every pixel
-  const size_t np = (size_t)a.owidth * a.oheight;
-  hipStream_t s = stream_of(devid);
+  const float4 *const in = (const float4 *)dev_in;
+  float4 *const out = (float4 *)dev_out;
+  const unsigned grid = pixel_grid(np);
+  const int cs = lab ? DT_HIP_BLEND_CS_LAB : (display ? DT_HIP_BLEND_CS_RGB_DISPLAY : DT_HIP_BLEND_CS_RGB_SCENE);
+  int mask = per_pixel ? 1 : 0;
+  if(blur)
+  {
+    // the mask as a plane (before the post operations), blurred in place
+    launch_scope ls(devid, "blend_mask");
+    if(!per_pixel) fill_plane<<<grid, 256, 0, s>>>(plane, np, a.constant);
+    else if(cs == DT_HIP_BLEND_CS_LAB) blend_mask_kernel<DT_HIP_BLEND_CS_LAB><<<grid, 256, 0, s>>>(in, out, plane, a);
+    else if(cs == DT_HIP_BLEND_CS_RGB_DISPLAY) blend_mask_kernel<DT_HIP_BLEND_CS_RGB_DISPLAY><<<grid, 256, 0, s>>>(in, out, plane, a);
+    else blend_mask_kernel<DT_HIP_BLEND_CS_RGB_SCENE><<<grid, 256, 0, s>>>(in, out, plane, a);
+    mask = 2;
+  }
+  else if(!per_pixel && a.tone)
+    a.constant = tone_curve(a.constant, a); // the same value for every pixel
+  if(blur) blur_plane();
   {
     launch_scope ls(devid, "blend_kernel");
-    const float4 *const in = (const float4 *)dev_in;
-    float4 *const out = (float4 *)dev_out;
-    const unsigned grid = pixel_grid(np);
-    if(lab && per_pixel) blend_kernel<DT_HIP_BLEND_CS_LAB, true><<<grid, 256, 0, s>>>(in, out, a);
-    else if(lab) blend_kernel<DT_HIP_BLEND_CS_LAB, false><<<grid, 256, 0, s>>>(in, out, a);
-    else if(display && per_pixel) blend_kernel<DT_HIP_BLEND_CS_RGB_DISPLAY, true><<<grid, 256, 0, s>>>(in, out, a);
-    else if(display) blend_kernel<DT_HIP_BLEND_CS_RGB_DISPLAY, false><<<grid, 256, 0, s>>>(in, out, a);
-    else if(per_pixel) blend_kernel<DT_HIP_BLEND_CS_RGB_SCENE, true><<<grid, 256, 0, s>>>(in, out, a);
-    else blend_kernel<DT_HIP_BLEND_CS_RGB_SCENE, false><<<grid, 256, 0, s>>>(in, out, a);
+#define BLEND_LAUNCH(CS_)                                                                   \
+  do                                                                                        \
+  {                                                                                         \
+    if(mask == 2) blend_kernel<CS_, 2><<<grid, 256, 0, s>>>(in, out, plane, a);             \
+    else if(mask == 1) blend_kernel<CS_, 1><<<grid, 256, 0, s>>>(in, out, plane, a);        \
+    else blend_kernel<CS_, 0><<<grid, 256, 0, s>>>(in, out, plane, a);                      \
+  } while(0)
+    if(cs == DT_HIP_BLEND_CS_LAB) BLEND_LAUNCH(DT_HIP_BLEND_CS_LAB);
+    else if(cs == DT_HIP_BLEND_CS_RGB_DISPLAY) BLEND_LAUNCH(DT_HIP_BLEND_CS_RGB_DISPLAY);
+    else BLEND_LAUNCH(DT_HIP_BLEND_CS_RGB_SCENE);
+#undef BLEND_LAUNCH
   }
+  release_planes();
   return check_launch("blend_kernel");
 }

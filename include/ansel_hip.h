@@ -435,9 +435,10 @@ int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iw
  * (blendif_rgb_hsl.c), "Lab" (blendif_lab.c), "raw" (blendif_raw.c: one-channel buffers before demosaic); the RGB
  * ones with a LINEAR work profile (nonlinearlut == 0) for the gray channel of the mask.  Mask modes uniform and
  * parametric -- gray, R, G, B and Jz, Cz, hz resp. H, S, L; L, a, b, C, h -- on input and output, all combine / invert
- * variants; the mask tone curve (contrast / brightness, blend.c:626-655); every operator of the four files (16, 30,
- * 27, 17) and the reverse flag.  Refused with DT_HIP_INVALID_ARG (never approximated): drawn and raster masks,
- * feathering, mask blur, the details threshold, GUI mask display. */
+ * variants; the post operations mask blur (the recursive gaussian of src/pixel/gaussian.c, blend.c:869-881) and mask
+ * tone curve (contrast / brightness, blend.c:626-655); every operator of the four files (16, 30, 27, 17) and the
+ * reverse flag.  Refused with DT_HIP_INVALID_ARG (never approximated): drawn and raster masks, feathering (guided
+ * filter), the details threshold, GUI mask display. */
 #define DT_HIP_BLEND_CS_RAW 1 /* dt_develop_blend_colorspace_t, blend.h:51-58 */
 #define DT_HIP_BLEND_CS_LAB 2
 #define DT_HIP_BLEND_CS_RGB_DISPLAY 3
@@ -459,7 +460,7 @@ typedef struct dt_hip_blend_data_t
   float opacity;          /* 0 .. 100 */
   uint32_t mask_combine;  /* DT_HIP_COMBINE_* bits */
   uint32_t blendif;       /* bit i: channel i active; bit 16 + i: channel i inverted (blend.h:141-197) */
-  float feathering_radius, blur_radius, details; /* must be 0 (refused otherwise) */
+  float feathering_radius, blur_radius, details; /* feathering_radius and details must be 0 (refused otherwise) */
   float contrast, brightness;                    /* mask tone curve */
   float blendif_parameters[4 * DT_HIP_BLENDIF_SIZE];
   float blendif_boost_factors[DT_HIP_BLENDIF_SIZE];

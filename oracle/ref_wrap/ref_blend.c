@@ -13,6 +13,7 @@
 #include "common/imagebuf.h"
 #include "common/colorspaces_inline_conversions.h"
 #include "math/openmp_maths.h"
+#include "pixel/gaussian.h"
 
 typedef int dt_colorspaces_color_profile_type_t;
 typedef int dt_colorspaces_color_mode_t;
@@ -92,7 +93,7 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
   ref_reset_fp_mode();
   if(h->blend_cst < DEVELOP_BLEND_CS_RAW || h->blend_cst > DEVELOP_BLEND_CS_RGB_SCENE
      || (h->mask_mode & (DEVELOP_MASK_SHAPE | DEVELOP_MASK_RASTER))
-     || h->feathering_radius != 0.f || h->blur_radius != 0.f || h->details != 0.f)
+     || h->feathering_radius != 0.f || h->details != 0.f)
     return -1;
   dt_develop_blend_params_t d;
   memset(&d, 0, sizeof(d));
@@ -104,6 +105,7 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
   d.mask_combine = h->mask_combine;
   d.blendif = h->blendif;
   d.contrast = h->contrast;
+  d.blur_radius = h->blur_radius;
   d.brightness = h->brightness;
   memcpy(d.blendif_parameters, h->blendif_parameters, sizeof(d.blendif_parameters));
   memcpy(d.blendif_boost_factors, h->blendif_boost_factors, sizeof(d.blendif_boost_factors));
@@ -155,7 +157,20 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
       dt_develop_blendif_rgb_hsl_make_mask(&pipe, &piece, (const float *)in, (const float *)out, mask);
     else
       dt_develop_blendif_rgb_jzczhz_make_mask(&pipe, &piece, (const float *)in, (const float *)out, mask);
-    /* _develop_mask_get_post_operations(), blend.c:427-469, with feathering and blur absent */
+    /* _develop_mask_get_post_operations(), blend.c:427-469, with feathering absent: blur, then the tone curve */
+    if(d.blur_radius > 0.1f)
+    {
+      /* DEVELOP_MASK_POST_BLUR, blend.c:869-881 */
+      const float sigma = d.blur_radius * piece.roi_out.scale;
+      const float mmax[] = { 1.0f };
+      const float mmin[] = { 0.0f };
+      dt_gaussian_t *g = dt_gaussian_init(owidth, oheight, 1, mmax, mmin, sigma, 0);
+      if(g)
+      {
+        dt_gaussian_blur(g, mask, mask);
+        dt_gaussian_free(g);
+      }
+    }
     const int mask_tone_curve = fabsf(d.contrast) >= 0.01f || fabsf(d.brightness) >= 0.01f;
     if(mask_tone_curve && opacity > 1e-4f)
       _develop_blend_process_mask_tone_curve(mask, buffsize, d.contrast, d.brightness, opacity);

@@ -454,6 +454,80 @@ static void blend_pixel_lab(const unsigned mode, const float *a, const float *b,
   out[3] = lo;
 }
 
+/* ---- mask blur: dt_gaussian_blur(), src/pixel/gaussian.c:44-95 (parameters), :176-326 (the two recursive
+ * passes), one channel, order 0, values clamped to [0, 1] on the way in (CLAMPF, src/math/math.h:91) ---------- */
+static float clampf01(const float a) { return a >= 0.0f ? (a <= 1.0f ? a : 1.0f) : 0.0f; }
+
+static void gaussian_blur_mask(float *buf, const int width, const int height, const float sigma)
+{
+  const float alpha = 1.695f / sigma;
+  const float ema = expf(-alpha);
+  const float ema2 = expf(-2.0f * alpha);
+  const float b1 = -2.0f * ema, b2 = ema2;
+  const float k = (1.0f - ema) * (1.0f - ema) / (1.0f + (2.0f * alpha * ema) - ema2);
+  const float a0 = k, a1 = k * (alpha - 1.0f) * ema, a2 = k * (alpha + 1.0f) * ema, a3 = -k * ema2;
+  const float coefp = (a0 + a1) / (1.0f + b1 + b2), coefn = (a2 + a3) / (1.0f + b1 + b2);
+  float *temp = (float *)malloc(sizeof(float) * (size_t)width * height);
+  if(!temp) return;
+  /* vertical, column by column: forward then backward, both from the unblurred input */
+#pragma omp parallel for schedule(static)
+  for(int i = 0; i < width; i++)
+  {
+    float xp = clampf01(buf[i]), yb = xp * coefp, yp = yb;
+    for(int j = 0; j < height; j++)
+    {
+      const size_t o = (size_t)j * width + i;
+      const float xc = clampf01(buf[o]);
+      const float yc = (a0 * xc) + (a1 * xp) - (b1 * yp) - (b2 * yb);
+      temp[o] = yc;
+      xp = xc;
+      yb = yp;
+      yp = yc;
+    }
+    float xn = clampf01(buf[(size_t)(height - 1) * width + i]), xa = xn, yn = xn * coefn, ya = yn;
+    for(int j = height - 1; j > -1; j--)
+    {
+      const size_t o = (size_t)j * width + i;
+      const float xc = clampf01(buf[o]);
+      const float yc = (a2 * xn) + (a3 * xa) - (b1 * yn) - (b2 * ya);
+      xa = xn;
+      xn = xc;
+      ya = yn;
+      yn = yc;
+      temp[o] += yc;
+    }
+  }
+  /* horizontal, line by line, from the vertically blurred plane */
+#pragma omp parallel for schedule(static)
+  for(int j = 0; j < height; j++)
+  {
+    const float *t = temp + (size_t)j * width;
+    float *out = buf + (size_t)j * width;
+    float xp = clampf01(t[0]), yb = xp * coefp, yp = yb;
+    for(int i = 0; i < width; i++)
+    {
+      const float xc = clampf01(t[i]);
+      const float yc = (a0 * xc) + (a1 * xp) - (b1 * yp) - (b2 * yb);
+      out[i] = yc;
+      xp = xc;
+      yb = yp;
+      yp = yc;
+    }
+    float xn = clampf01(t[width - 1]), xa = xn, yn = xn * coefn, ya = yn;
+    for(int i = width - 1; i > -1; i--)
+    {
+      const float xc = clampf01(t[i]);
+      const float yc = (a2 * xn) + (a3 * xa) - (b1 * yn) - (b2 * ya);
+      xa = xn;
+      xn = xc;
+      ya = yn;
+      yn = yc;
+      out[i] += yc;
+    }
+  }
+  free(temp);
+}
+
 /* ---- raw (one channel) ----------------------------------------------------------------------------
  * the _blend_* row functions of src/develop/blends/blendif_raw.c:66-288, one photosite */
 static float clamp01(const float x) { return fminf(fmaxf(x, 0.0f), 1.0f); } /* clamp_simd() */
@@ -518,9 +592,18 @@ static int blend_raw(const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d, 
     const float seed = (d->mask_combine & DT_HIP_COMBINE_INCL) ? 0.0f : 1.0f;
     const float global_opacity = fminf(fmaxf(0.0f, (d->opacity / 100.0f)), 1.0f);
     m = (d->mask_combine & DT_HIP_COMBINE_INV) ? global_opacity * (1.0f - seed) : seed * global_opacity;
-    if((fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f)
-      m = tone_curve(m, expf(3.f * d->contrast), d->brightness, opacity);
   }
+  /* post operations (blur, then the tone curve), only on a parametric mask: blend.c:759-900 */
+  float *plane = NULL;
+  if(parametric && d->blur_radius > 0.1f)
+  {
+    plane = (float *)malloc(sizeof(float) * (size_t)owidth * oheight);
+    if(!plane) return 1;
+    for(size_t k = 0; k < (size_t)owidth * oheight; k++) plane[k] = m;
+    gaussian_blur_mask(plane, owidth, oheight, d->blur_radius * (float)piece->roi_out.scale);
+  }
+  const int tone = parametric && (fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f;
+  const float e = expf(3.f * d->contrast);
   const unsigned mode = d->blend_mode & 0xFFu;
   const int reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
 #pragma omp parallel for schedule(static)
@@ -530,8 +613,11 @@ static int blend_raw(const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d, 
       const float a = in[(size_t)(y + yoffs) * iwidth + xoffs + x];
       float *bo = out + (size_t)y * owidth + x;
       const float b = *bo;
-      *bo = reverse ? blend_value_raw(mode, b, a, m) : blend_value_raw(mode, a, b, m);
+      float mm = plane ? plane[(size_t)y * owidth + x] : m;
+      if(tone) mm = tone_curve(mm, e, d->brightness, opacity);
+      *bo = reverse ? blend_value_raw(mode, b, a, mm) : blend_value_raw(mode, a, b, mm);
     }
+  free(plane);
   return 0;
 }
 
@@ -720,15 +806,15 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   if(!piece || !d || !in_ || !out_) return 1;
   if(d->blend_cst == DT_HIP_BLEND_CS_RAW)
   {
-    if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->blur_radius != 0.f
-       || d->details != 0.f || piece->channels != 1)
+    if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->details != 0.f
+       || piece->channels != 1)
       return 1;
     if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return 0;
     return blend_raw(piece, d, (const float *)in_, (float *)out_);
   }
   const int lab = d->blend_cst == DT_HIP_BLEND_CS_LAB, display = d->blend_cst == DT_HIP_BLEND_CS_RGB_DISPLAY;
   if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !display) || (d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER))
-     || d->feathering_radius != 0.f || d->blur_radius != 0.f || d->details != 0.f || piece->channels != 4)
+     || d->feathering_radius != 0.f || d->details != 0.f || piece->channels != 4)
     return 1;
   if(lab && !lab_mode_supported(d->blend_mode & 0xFFu)) return 1;
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
@@ -825,6 +911,17 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   const unsigned mode = d->blend_mode & 0xFFu;
   const int reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
 
+  /* with a mask blur the mask becomes a plane: build it, blur it, then tone curve + operator per pixel */
+  float *plane = NULL;
+  const int blur = parametric && d->blur_radius > 0.1f;
+  if(blur)
+  {
+    plane = (float *)malloc(sizeof(float) * (size_t)owidth * oheight);
+    if(!plane) return 1;
+  }
+  for(int pass = blur ? 0 : 1; pass < 2; pass++)
+  {
+  if(pass == 1 && blur) gaussian_blur_mask(plane, owidth, oheight, d->blur_radius * (float)piece->roi_out.scale);
 #pragma omp parallel for schedule(static)
   for(int y = 0; y < oheight; y++)
     for(int xx = 0; xx < owidth; xx++)
@@ -833,7 +930,8 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
       float *bo = out + ((size_t)y * owidth + xx) * 4;
       const float b[4] = { bo[0], bo[1], bo[2], bo[3] };
       float m = constant;
-      if(kind == 2)
+      if(pass == 1 && blur) m = plane[(size_t)y * owidth + xx];
+      else if(kind == 2)
       {
         float temp = 1.0f;
         if(lab)
@@ -851,6 +949,11 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
         else
           m = mask_inversed ? global_opacity * (1.0f - seed * temp) : global_opacity * seed * temp;
       }
+      if(pass == 0)
+      {
+        plane[(size_t)y * owidth + xx] = m;
+        continue;
+      }
       if(tone) m = tone_curve(m, e, d->brightness, opacity);
       if(lab)
       {
@@ -865,5 +968,7 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
       else if(reverse) blend_pixel(mode, b, a, p, m, bo);
       else blend_pixel(mode, a, b, p, m, bo);
     }
+  }
+  free(plane);
   return 0;
 }

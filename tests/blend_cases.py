@@ -193,3 +193,34 @@ def display_cases():
         d.contrast, d.brightness = 0.3, -0.2
         out.append(("dsp-multi-c%d" % combine, d))
     return out
+
+
+def blur_cases():
+    """(name, data, which images): a parametric mask through the recursive gaussian (blend.c:869-881) and the tone curve"""
+    out = []
+    for radius in (0.5, 3.0, 25.0):
+        d = abi.BlendData.uniform(M, 80.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.2, 0.6, 0.9, boost=1.0)
+        d.blur_radius = radius
+        out.append(("blur-scene-%g" % radius, d, "scene"))
+    d = abi.BlendData.uniform(M, 70.0, abi.BLEND_MULTIPLY, 0.5).channel(abi.BLENDIF_Jz_in, 0.05, 0.2, 1.0, 1.0, boost=-4.0)
+    d.blur_radius, d.contrast, d.brightness = 6.0, 0.4, -0.2
+    d.mask_combine = abi.COMBINE_INV
+    out.append(("blur-scene-tone-inv", d, "scene"))
+    d = abi.BlendData.uniform(M, 90.0, 0x0B, blend_cst=abi.BLEND_CS_LAB).channel(abi.BLENDIF_L_in, 0.2, 0.4, 0.7, 0.9)
+    d.blur_radius = 4.0
+    out.append(("blur-lab", d, "lab"))
+    d = abi.BlendData.uniform(M, 60.0, 0x12, blend_cst=abi.BLEND_CS_RGB_DISPLAY).channel(abi.BLENDIF_S_in, 0.1, 0.3, 1.0, 1.0)
+    d.blur_radius, d.contrast = 2.0, -0.3
+    out.append(("blur-display", d, "display"))
+    d = abi.BlendData.uniform(M, 70.0, 0x18, blend_cst=abi.BLEND_CS_RAW).channel(abi.BLENDIF_GRAY_in, 0.1, 0.2, 0.8, 0.9)
+    d.blur_radius = 5.0
+    out.append(("blur-raw", d, "raw"))
+    # a blur radius on a uniform mask does nothing (post operations run on parametric masks only)
+    d = abi.BlendData.uniform(M, 45.0)
+    d.blur_radius = 9.0
+    out.append(("blur-uniform-ignored", d, "scene"))
+    return out
+
+
+def images_for(kind, w, h, seed):
+    return {"scene": images, "lab": lab_images, "display": display_images, "raw": raw_images}[kind](w, h, seed)

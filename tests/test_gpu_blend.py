@@ -73,6 +73,20 @@ def test_blend_display(name, d):
     _check(abi.Piece.make(w, h), d, a, b, name)
 
 
+BLUR_CASES = blend_cases.blur_cases()
+
+
+@pytest.mark.parametrize("name,d,kind", BLUR_CASES, ids=[c[0] for c in BLUR_CASES])
+@pytest.mark.parametrize("w,h", [(131, 67), (40, 3), (1, 50), (700, 500)])
+def test_blend_mask_blur(name, d, kind, w, h):
+    """the mask through the recursive gaussian (src/pixel/gaussian.c) between make_mask and the tone curve"""
+    if w > 20 and h > 20:
+        a, b = blend_cases.images_for(kind, w, h, 81)
+    else:
+        a, b = [np.ascontiguousarray(z[:h, :w]) for z in blend_cases.images_for(kind, 64, 64, 81)]
+    _check(abi.Piece.make(w, h, channels=1 if kind == "raw" else 4), d, a, b, name)
+
+
 RAW_CASES = blend_cases.raw_cases()
 
 
@@ -99,7 +113,7 @@ def test_blend_full_frame():
     _check(abi.Piece.make(w, h), d, a, b, "24 MP")
 
 
-@pytest.mark.parametrize("field,value", [("blend_cst", 5), ("blend_cst", 0), ("feathering_radius", 5.0), ("blur_radius", 3.0), ("details", 0.5),
+@pytest.mark.parametrize("field,value", [("blend_cst", 5), ("blend_cst", 0), ("feathering_radius", 5.0), ("details", 0.5),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_SHAPE),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_RASTER)])
 def test_blend_refuses_what_is_not_built(field, value):

@@ -506,3 +506,16 @@ def test_develop_blend_display(name, d):
     assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
     assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
     _exact(x, y, "blend " + name)
+
+
+@pytest.mark.parametrize("name,d,kind", blend_cases.blur_cases(), ids=[c[0] for c in blend_cases.blur_cases()])
+@pytest.mark.parametrize("w,h", [(131, 67), (40, 3), (1, 50)])
+def test_develop_blend_mask_blur(name, d, kind, w, h):
+    """mask blur: the recursive gaussian of src/pixel/gaussian.c on the mask plane, between make_mask and the tone curve"""
+    a, b = blend_cases.images_for(kind, w, h, 81) if w > 20 and h > 20 else [z[:h, :w].copy() for z in blend_cases.images_for(kind, 64, 64, 81)]
+    piece = abi.Piece.make(w, h, channels=1 if kind == "raw" else 4)
+    r, o = ck.ref(), ck.oracle()
+    x, y = b.copy(), b.copy()
+    assert ck.call(r, "ref_develop_blend", piece, d, np.ascontiguousarray(a), x) == 0
+    assert ck.call(o, "oracle_develop_blend", piece, d, np.ascontiguousarray(a), y) == 0
+    _exact(x, y, "blend " + name)
