@@ -527,13 +527,10 @@ void threshold_args(const dt_hip_denoiseprofile_data_t *d, const int scale, cons
   for(int c = 0; c < 4; c++) t.adjt[c] = adjt[c];
 }
 
-// process_nlmeans_cpu(), denoiseprofile.c:1599-1648, with nlmeans_norm() :1457-1472 and
-// nlmeans_scattering() :1476-1500 for an export pipe (no preview output, not a thumbnail)
-int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, dt_hip_mem_t dev_in,
-                    dt_hip_mem_t dev_out)
+// nlmeans_norm() :1457-1472 and nlmeans_scattering() :1476-1500 for an export pipe (no preview output, not a
+// thumbnail): the dt_nlmeans_param_t of process_nlmeans_cpu(), denoiseprofile.c:1599-1648
+nlm_core_params_t nlm_params_of(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d)
 {
-  const int w = piece->roi_in.width, h = piece->roi_in.height;
-  const size_t npix = (size_t)w * h;
   const float scale = fminf(fminf((float)piece->roi_in.scale, 2.0f), 1.0f);
   const int P = (int)ceilf(d->radius * scale);
   int K = (int)d->nbhood;
@@ -547,17 +544,6 @@ int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoise
   }
   float norm = .045f / ((2 * P + 1) * (2 * P + 1));
   if(!d->fix_anscombe_and_nlmeans_norm) norm = .015f / (2 * P + 1);
-  dn_setup s;
-  setup(piece, d, s, true);
-  float4 *pre = (float4 *)dt_hip_alloc_device_buffer(devid, npix * sizeof(float4));
-  if(!pre) return DT_HIP_SYSMEM_ALLOCATION;
-  hipStream_t st = stream_of(devid);
-  {
-    vst_args fa;
-    forward_args(s, fa);
-    launch_scope ls(devid, "dn_precondition");
-    dn_precondition<<<pixel_grid(npix), 256, 0, st>>>((const float4 *)dev_in, pre, npix, fa);
-  }
   nlm_core_params_t p;
   memset(&p, 0, sizeof(p));
   p.scattering = scattering;
@@ -569,6 +555,30 @@ int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoise
   p.patch_radius = P;
   p.search_radius = K;
   p.norm[0] = p.norm[1] = p.norm[2] = p.norm[3] = 1.0f;
+  return p;
+}
+
+// process_nlmeans_cpu(), denoiseprofile.c:1599-1648.  On a row band (hip_common.h band_view_t) dev_in holds
+// buf_rows rows from frame row band->buf_row0 on and dev_out the band's own rows.
+int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, const band_view_t *band,
+                    const int buf_rows, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  const int w = piece->roi_in.width, h = piece->roi_in.height;
+  const size_t npix_in = (size_t)w * (band ? buf_rows : h);
+  const size_t npix_out = (size_t)w * (band ? band->row1 - band->row0 : h);
+  dn_setup s;
+  setup(piece, d, s, true);
+  float4 *pre = (float4 *)dt_hip_alloc_device_buffer(devid, npix_in * sizeof(float4));
+  if(!pre) return DT_HIP_SYSMEM_ALLOCATION;
+  hipStream_t st = stream_of(devid);
+  {
+    vst_args fa;
+    forward_args(s, fa);
+    launch_scope ls(devid, "dn_precondition");
+    dn_precondition<<<pixel_grid(npix_in), 256, 0, st>>>((const float4 *)dev_in, pre, npix_in, fa);
+  }
+  nlm_core_params_t p = nlm_params_of(piece, d);
+  p.band = band;
   int err = nlmeans_core_launch(devid, pre, (float4 *)dev_out, w, h, p);
   dt_hip_release_mem_object(pre);
   if(err != DT_HIP_SUCCESS) return err;
@@ -576,12 +586,192 @@ int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoise
     vst_args ia;
     inverse_args(s, ia);
     launch_scope ls(devid, "dn_finish");
-    dn_finish<<<pixel_grid(npix), 256, 0, st>>>((float4 *)dev_out, nullptr, npix, ia);
+    dn_finish<<<pixel_grid(npix_out), 256, 0, st>>>((float4 *)dev_out, nullptr, npix_out, ia);
   }
   return check_launch("dn_finish");
 }
 
+// what process_wavelets() refuses or copies through, on the FRAME's geometry: 1 = run, 0 = copy, < 0 error
+int wavelets_runnable(const dt_hip_piece_t *piece, const dn_setup &s)
+{
+  const int w = piece->roi_in.width, h = piece->roi_in.height;
+  if(s.max_scale < 1)
+  {
+    set_last_error("denoiseprofile: frame too small for a single wavelet band");
+    return -1;
+  }
+  const int max_mult = 1 << (s.max_scale - 1);
+  if(w < 2 * max_mult || h < 2 * max_mult) return 0; // denoiseprofile.c:1325-1329: too small, copy through
+  if(w < 4 * max_mult)
+  {
+    // eaw.c:308-323 reads before the start of the row in this case (undefined in the reference)
+    set_last_error("denoiseprofile: %d columns is less than 4x the coarsest dilation %d", w, max_mult);
+    return -1;
+  }
+  return 1;
+}
+
 } // namespace
+
+namespace ansel
+{
+
+// ---- row bands (pipe.cpp) --------------------------------------------------------------
+struct dn_band_job_t
+{
+  int devid, w, buf_rows, frame_h, max_scale;
+  dt_hip_denoiseprofile_data_t d;
+  dn_setup s;
+  float4 *b[2];
+  float4 *det[BANDS];
+  float4 *residual;
+  double *sums; // [max_scale][frame_h * nseg][4]
+  float *thrs;
+};
+
+void denoiseprofile_band_abort(dn_band_job_t *j)
+{
+  if(!j) return;
+  for(int k = 0; k < 2; k++)
+    if(j->b[k]) dt_hip_release_mem_object(j->b[k]);
+  for(int k = 0; k < BANDS; k++)
+    if(j->det[k]) dt_hip_release_mem_object(j->det[k]);
+  if(j->sums) dt_hip_release_mem_object(j->sums);
+  if(j->thrs) dt_hip_release_mem_object(j->thrs);
+  delete j;
+}
+
+int denoiseprofile_halo_rows(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d)
+{
+  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return nlmeans_core_halo_rows(piece->roi_in.height, nlm_params_of(piece, d));
+  dn_setup s;
+  setup(piece, d, s, false);
+  if(wavelets_runnable(piece, s) != 1) return -1;
+  return 2 * ((1 << s.max_scale) - 1); // scale k reads 2 * 2^k rows of scale k - 1 on either side
+}
+
+int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
+                              const band_view_t *band, const int buf_rows, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                              dn_band_job_t **job, double **sums, size_t *sum_count)
+{
+  *job = nullptr;
+  *sums = nullptr;
+  *sum_count = 0;
+  if(!valid_device(devid) || !piece || !d || !band || !dev_in || buf_rows <= 0) return DT_HIP_INVALID_ARG;
+  if(piece->channels != 4 || !(piece->roi_in.scale > 0.0)) return DT_HIP_INVALID_ARG;
+  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return denoise_nlmeans(devid, piece, d, band, buf_rows, dev_in, dev_out);
+  if(d->mode != DT_HIP_DENOISEPROFILE_WAVELETS) return DT_HIP_INVALID_ARG;
+  dn_band_job_t *j = new dn_band_job_t;
+  memset(j, 0, sizeof(*j));
+  j->devid = devid;
+  j->w = piece->roi_in.width;
+  j->buf_rows = buf_rows;
+  j->frame_h = band->frame_h;
+  j->d = *d;
+  setup(piece, d, j->s, false);
+  if(wavelets_runnable(piece, j->s) != 1)
+  {
+    delete j;
+    return DT_HIP_INVALID_ARG; // the planner (denoiseprofile_halo_rows) does not send such a frame here
+  }
+  j->max_scale = j->s.max_scale;
+  const int w = j->w, nseg = (w + 255) / 256;
+  const size_t npix = (size_t)w * buf_rows, plane = npix * sizeof(float4);
+  const size_t n_frame = (size_t)band->frame_h * nseg; // partial sums of one wavelet band of the frame
+  const size_t sums_bytes = (size_t)j->max_scale * n_frame * 4 * sizeof(double);
+  bool ok = true;
+  for(int k = 0; k < 2; k++) ok &= (j->b[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
+  for(int k = 0; k < j->max_scale; k++) ok &= (j->det[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
+  ok &= (j->sums = (double *)dt_hip_alloc_device_buffer(devid, sums_bytes)) != nullptr;
+  ok &= (j->thrs = (float *)dt_hip_alloc_device_buffer(devid, 4 * sizeof(float))) != nullptr;
+  double *local = ok ? (double *)dt_hip_alloc_device_buffer(devid, (size_t)buf_rows * nseg * 4 * sizeof(double)) : nullptr;
+  if(!ok || !local)
+  {
+    if(local) dt_hip_release_mem_object(local);
+    denoiseprofile_band_abort(j);
+    return DT_HIP_SYSMEM_ALLOCATION;
+  }
+  hipStream_t st = stream_of(devid);
+  int err = hipMemsetAsync(j->sums, 0, sums_bytes, st) == hipSuccess ? DT_HIP_SUCCESS : DT_HIP_DEFAULT_ERROR;
+  if(err == DT_HIP_SUCCESS)
+  {
+    vst_args fa;
+    forward_args(j->s, fa);
+    launch_scope ls(devid, "dn_precondition");
+    dn_precondition<<<pixel_grid(npix), 256, 0, st>>>((const float4 *)dev_in, j->b[0], npix, fa);
+  }
+  float4 *b1 = j->b[0], *b2 = j->b[1];
+  const int own0 = band->row0 - band->buf_row0, own_rows = band->row1 - band->row0;
+  for(int scale = 0; scale < j->max_scale && err == DT_HIP_SUCCESS; scale++)
+  {
+    const int mult = 1 << scale;
+    const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
+    const float sigma_band = powf(varf, scale) * 1.0f;
+    const int rows = (buf_rows <= mult) ? buf_rows : ((buf_rows + mult - 1) / mult) * mult;
+    {
+      launch_scope ls(devid, "dn_decompose");
+      dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(b1, b2, j->det[scale], local, w, buf_rows, mult,
+                                                               1.0f / (sigma_band * sigma_band), nseg);
+    }
+    err = check_launch("denoiseprofile band decompose");
+    // the own rows' partial sums at their place in the frame's table
+    if(err == DT_HIP_SUCCESS
+       && hipMemcpyAsync(j->sums + ((size_t)scale * n_frame + (size_t)band->row0 * nseg) * 4, local + (size_t)own0 * nseg * 4,
+                         (size_t)own_rows * nseg * 4 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      err = DT_HIP_DEFAULT_ERROR;
+    float4 *t = b2;
+    b2 = b1;
+    b1 = t;
+  }
+  dt_hip_release_mem_object(local); // stream-ordered
+  j->residual = b1;
+  if(err != DT_HIP_SUCCESS)
+  {
+    denoiseprofile_band_abort(j);
+    return err;
+  }
+  *job = j;
+  *sums = j->sums;
+  *sum_count = (size_t)j->max_scale * n_frame * 4;
+  return DT_HIP_SUCCESS;
+}
+
+int denoiseprofile_band_finish(dn_band_job_t *j, dt_hip_mem_t dev_out)
+{
+  if(!j || !dev_out) return DT_HIP_INVALID_ARG;
+  const int devid = j->devid, nseg = (j->w + 255) / 256;
+  const size_t npix = (size_t)j->w * j->buf_rows, n_frame = (size_t)j->frame_h * nseg;
+  hipStream_t st = stream_of(devid);
+  float4 *out = (float4 *)dev_out;
+  int err = DT_HIP_SUCCESS;
+  for(int scale = 0; scale < j->max_scale && err == DT_HIP_SUCCESS; scale++)
+  {
+    thr_args ta;
+    ta.n_partial = n_frame;
+    threshold_args(&j->d, scale, j->max_scale, (size_t)j->w * j->frame_h, ta);
+    {
+      launch_scope ls(devid, "dn_band_threshold");
+      dn_band_threshold<<<1, 1024, 0, st>>>(j->sums + (size_t)scale * n_frame * 4, ta, j->thrs);
+    }
+    {
+      launch_scope ls(devid, "dn_synthesize");
+      dn_synthesize<<<stream_grid(npix, 256), 256, 0, st>>>(out, j->det[scale], j->thrs, npix, scale == 0);
+    }
+    err = check_launch("denoiseprofile band synthesis");
+  }
+  if(err == DT_HIP_SUCCESS)
+  {
+    vst_args ia;
+    inverse_args(j->s, ia);
+    launch_scope ls(devid, "dn_finish");
+    dn_finish<<<pixel_grid(npix), 256, 0, st>>>(out, j->residual, npix, ia);
+    err = check_launch("dn_finish");
+  }
+  denoiseprofile_band_abort(j);
+  return err;
+}
+
+} // namespace ansel
 
 extern "C" {
 
@@ -598,24 +788,13 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
   const int w = piece->roi_in.width, h = piece->roi_in.height;
   if(w <= 0 || h <= 0) return DT_HIP_SUCCESS;
   const size_t npix = (size_t)w * h, plane = npix * sizeof(float4);
-  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return denoise_nlmeans(devid, piece, d, dev_in, dev_out);
+  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return denoise_nlmeans(devid, piece, d, nullptr, h, dev_in, dev_out);
   dn_setup s;
   setup(piece, d, s, false);
-  if(s.max_scale < 1)
-  {
-    set_last_error("denoiseprofile: frame too small for a single wavelet band");
-    return DT_HIP_INVALID_ARG;
-  }
-  const int max_mult = 1 << (s.max_scale - 1);
+  const int runnable = wavelets_runnable(piece, s);
+  if(runnable < 0) return DT_HIP_INVALID_ARG;
   hipStream_t st = stream_of(devid);
-  if(w < 2 * max_mult || h < 2 * max_mult) // denoiseprofile.c:1325-1329: too small, copy through
-    return dt_hip_enqueue_copy_buffer_to_buffer(devid, dev_in, dev_out, 0, 0, plane);
-  if(w < 4 * max_mult)
-  {
-    // eaw.c:308-323 reads before the start of the row in this case (undefined in the reference)
-    set_last_error("denoiseprofile: %d columns is less than 4x the coarsest dilation %d", w, max_mult);
-    return DT_HIP_INVALID_ARG;
-  }
+  if(!runnable) return dt_hip_enqueue_copy_buffer_to_buffer(devid, dev_in, dev_out, 0, 0, plane);
   const int nseg = (w + 255) / 256;
   const size_t n_partial = (size_t)h * nseg;
   float4 *precond = (float4 *)dt_hip_alloc_device_buffer(devid, plane);

@@ -312,6 +312,20 @@ int launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, flo
 
 } // namespace
 
+namespace ansel
+{
+// Rows of input the own rows of a band depend on: per iteration the decompositions reach 2 * (1 + 2 + ... +
+// 2^(scales-1)) rows and the PDE passes, coarse to fine, one dilation each
+int diffuse_halo_rows(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d)
+{
+  if(!(d->iscale > 0.0f) || !(piece->roi_in.scale > 0.0)) return -1;
+  const int scales = scales_of(piece, d);
+  const int it_req = (int)ceilf((float)d->iterations);
+  const int iterations = it_req > 1 ? it_req : 1;
+  return iterations * 3 * ((1 << scales) - 1);
+}
+} // namespace ansel
+
 extern "C" {
 
 int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d,

@@ -105,6 +105,33 @@ struct rcd_band_t
   int out_row0, out_rows; // frame rows held by the output buffer
 };
 
+// A row band in front of a stencil module (pipe.cpp): the input buffer holds frame rows
+// from buf_row0 on (own rows + the halo fetched from the neighbours), the band owns frame rows [row0, row1)
+struct band_view_t
+{
+  int frame_h;
+  int buf_row0;
+  int row0, row1;
+};
+// stencil modules on a row band
+int nlmeans_halo_rows(const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d);
+int nlmeans_process_band(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d, const band_view_t *band,
+                         dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+int diffuse_halo_rows(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d);
+// denoiseprofile: -1 when the frame is too small for the module to do anything but copy
+int denoiseprofile_halo_rows(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d);
+struct dn_band_job_t;
+// non-local means mode: one call (job == nullptr on return).  Wavelets mode: decomposes every band of the
+// buffer (buf_rows rows, as a frame of its own), leaves the frame-wide table of partial sums of detail^2
+// in *sums (own rows filled, the rest zero: an all-reduce SUM over the bands is exact in any order) and
+// returns a job for denoiseprofile_band_finish()
+int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
+                              const band_view_t *band, int buf_rows, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                              dn_band_job_t **job, double **sums, size_t *sum_count);
+// thresholds from the reduced sums, synthesis, inverse transform; dev_out holds buf_rows rows.  Frees the job
+int denoiseprofile_band_finish(dn_band_job_t *job, dt_hip_mem_t dev_out);
+void denoiseprofile_band_abort(dn_band_job_t *job);
+
 // Grid for a grid-stride streaming kernel: enough workgroups to fill 256 CUs x 8 and no more
 // (cdna_hip_programming.md Guideline 11).
 static inline unsigned stream_grid(size_t work_items, unsigned block)

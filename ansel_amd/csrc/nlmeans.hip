@@ -52,6 +52,9 @@ struct nlm_args
   int skip_blend;
   int reach;     // patch radius + largest |shift|: rows/columns of input around the chunk a patch can touch
   int win_pitch; // staged window: (chk_h + 2 reach) rows x win_pitch columns per colour plane
+  // row bands (hip_common.h band_view_t): the launch covers chunk rows cy0.. of the FRAME's grid and
+  // stores frame rows [out_row0, out_row1) only; `in` / `out` are addressed with frame row indices
+  int cy0, out_row0, out_row1;
 };
 
 __device__ __forceinline__ int imin(const int a, const int b) { return a < b ? a : b; }
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks(const float4 *__restri
 {
   extern __shared__ float lds[];
   const int tid = threadIdx.x;
-  const int cy = blockIdx.x / a.nchx, cx = blockIdx.x - cy * a.nchx;
+  const int cy_launch = blockIdx.x / a.nchx, cx = blockIdx.x - cy_launch * a.nchx;
+  const int cy = cy_launch + a.cy0;
   const int top = cy * a.chk_h, left = cx * a.chk_w;
   const int bot = imin(top + a.chk_h, a.H), right = imin(left + a.chk_w, a.W);
   const int ch = bot - top, cw = right - left;
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks(const float4 *__restri
   {
     if(rc[k] < 0) continue;
     const int row = top + (rc[k] >> 16), col = left + (rc[k] & 0xffff);
+    if(row < a.out_row0 || row >= a.out_row1) continue;
     const long o = (long)row * W + col;
     const float4 s = acc[k];
     float4 r;
@@ -372,7 +377,8 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4
 {
   extern __shared__ float lds[];
   const int tid = threadIdx.x;
-  const int cy = blockIdx.x / a.nchx, cx = blockIdx.x - cy * a.nchx;
+  const int cy_launch = blockIdx.x / a.nchx, cx = blockIdx.x - cy_launch * a.nchx;
+  const int cy = cy_launch + a.cy0;
   const int top = cy * a.chk_h, left = cx * a.chk_w;
   const int bot = imin(top + a.chk_h, a.H), right = imin(left + a.chk_w, a.W);
   const int ch = bot - top, cw = right - left;
@@ -746,6 +752,7 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4
   {
     if(prc[k] < 0) continue;
     const int row = top + (prc[k] >> 16), col = left + (prc[k] & 0xffff);
+    if(row < a.out_row0 || row >= a.out_row1) continue;
     const long o = (long)row * W + col;
     const float4 s = acc[k];
     float4 r;
@@ -818,6 +825,8 @@ namespace ansel
 
 int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int height, const nlm_core_params_t &p)
 {
+  if(p.band && (p.band->frame_h <= 0 || p.band->row0 < 0 || p.band->row1 > p.band->frame_h || p.band->row0 >= p.band->row1))
+    return DT_HIP_INVALID_ARG;
   if(width <= 0 || height <= 0) return DT_HIP_SUCCESS;
   if(p.patch_radius < 0 || p.patch_radius > 16 || p.search_radius < 0 || p.search_radius > 32)
   {
@@ -837,12 +846,25 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     }
   nlm_args a;
   memset(&a, 0, sizeof(a));
+  // a row band (p.band != nullptr): `in` holds frame rows from band->buf_row0 on, `out` the band's own rows
+  // [row0, row1); the chunk grid, the validity tests and every index are the FRAME's, the launch covers
+  // the chunk rows that intersect the own rows
+  const band_view_t *const bv = p.band;
+  if(bv) height = bv->frame_h;
   a.W = width;
   a.H = height;
   a.chk_h = slice_height(height);
   a.chk_w = slice_width(width);
   a.nchx = (width + a.chk_w - 1) / a.chk_w;
-  const int nchy = (height + a.chk_h - 1) / a.chk_h;
+  a.cy0 = bv ? bv->row0 / a.chk_h : 0;
+  a.out_row0 = bv ? bv->row0 : 0;
+  a.out_row1 = bv ? bv->row1 : height;
+  const int nchy = bv ? (bv->row1 + a.chk_h - 1) / a.chk_h - a.cy0 : (height + a.chk_h - 1) / a.chk_h;
+  if(bv)
+  {
+    in -= (size_t)bv->buf_row0 * width;
+    out -= (size_t)bv->row0 * width;
+  }
   a.radius = p.patch_radius;
   a.npatch = (int)patches.size();
   a.cs_pitch = (a.chk_w + 2 * a.radius + 1) | 1; // odd pitches: the row-parallel step strides whole rows
@@ -904,12 +926,50 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
 
 extern "C" {
 
-// process_cpu(), src/iop/nlmeans.c:416-457
 int dt_hip_iop_nlmeans_process(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d,
                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
 {
+  return nlmeans_process_band(devid, piece, d, nullptr, dev_in, dev_out);
+}
+
+} // extern "C"
+
+namespace ansel
+{
+
+static nlm_core_params_t nlmeans_params(const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d);
+
+// rows/columns of input a chunk's patches touch beyond the chunk (a.reach of the launch) + the chunk height:
+// what a row band needs from its neighbours (pipe.cpp)
+int nlmeans_core_halo_rows(const int frame_h, const nlm_core_params_t &p)
+{
+  const int K = p.search_radius;
+  int max_shift = 0;
+  for(int ri = -K; ri <= K; ri++)
+    for(int ci = -K; ci <= K; ci++)
+      max_shift = std::max(max_shift, std::max(abs(scatter(p.scale, p.scattering, ri, ci)), abs(scatter(p.scale, p.scattering, ci, ri))));
+  return p.patch_radius + 1 + max_shift + slice_height(frame_h) - 1;
+}
+
+int nlmeans_halo_rows(const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d)
+{
+  return nlmeans_core_halo_rows(piece->roi_out.height, nlmeans_params(piece, d));
+}
+
+int nlmeans_process_band(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d, const band_view_t *band,
+                         dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
   if(piece->channels != 4) return DT_HIP_INVALID_ARG;
+  nlm_core_params_t p = nlmeans_params(piece, d);
+  p.band = band;
+  return nlmeans_core_launch(devid, (const float4 *)dev_in, (float4 *)dev_out, piece->roi_out.width,
+                             piece->roi_out.height, p);
+}
+
+// process_cpu(), src/iop/nlmeans.c:416-457
+static nlm_core_params_t nlmeans_params(const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d)
+{
   const float scale = (float)fmin(piece->roi_in.scale, 2.0f);
   const float max_L = 120.0f, max_C = 512.0f;
   const float nL = 1.0f / max_L, nC = 1.0f / max_C;
@@ -927,8 +987,7 @@ int dt_hip_iop_nlmeans_process(int devid, const dt_hip_piece_t *piece, const dt_
   p.norm[1] = nC * nC;
   p.norm[2] = nC * nC;
   p.norm[3] = 1.0f;
-  return nlmeans_core_launch(devid, (const float4 *)dev_in, (float4 *)dev_out, piece->roi_out.width,
-                             piece->roi_out.height, p);
+  return p;
 }
 
-} // extern "C"
+} // namespace ansel

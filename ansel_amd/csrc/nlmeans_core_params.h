@@ -9,6 +9,8 @@ struct nlm_core_params_t
   float scattering, scale, luma, chroma, center_weight, sharpness;
   int patch_radius, search_radius;
   float norm[4];
+  const band_view_t *band; // nullptr: the buffers are the frame
 };
 int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int height, const nlm_core_params_t &p);
+int nlmeans_core_halo_rows(int frame_h, const nlm_core_params_t &p);
 } // namespace ansel

@@ -372,7 +372,29 @@ struct band_priv_t
   dt_hip_mem_t journal; // deferred highlights journal or nullptr
   dt_hip_mem_t hl_out;  // the buffer the journal indexes
   size_t next_group;
+  // dt_hip_pipe_band_finish() is resumable: where the walk stands
+  bool walking;
+  dt_hip_mem_t cur, cur_base; // the band's own rows of the current module input / the allocation they live in
+  bool cur_owned, cur_is_halo_layout;
+  int stage;                  // inside a stencil group: 0 before the halo exchange, 1 after it, 2 after the sums, 3 done
+  dt_hip_mem_t out;
+  bool out_own_rows;
+  dn_band_job_t *dn_job;
 };
+
+bool is_stencil_op(op_t o) { return o == OP_DENOISEPROFILE || o == OP_DIFFUSE || o == OP_NLMEANS; }
+
+// rows of its input a stencil module's own rows depend on beyond the band (-1: the module passes this frame through)
+int band_halo_rows(const node_t &n)
+{
+  switch(n.op)
+  {
+    case OP_DENOISEPROFILE: return denoiseprofile_halo_rows(&n.piece, n.as<dt_hip_denoiseprofile_data_t>());
+    case OP_DIFFUSE: return diffuse_halo_rows(&n.piece, n.as<dt_hip_diffuse_data_t>());
+    case OP_NLMEANS: return nlmeans_halo_rows(&n.piece, n.as<dt_hip_nlmeans_data_t>());
+    default: return 0;
+  }
+}
 
 bool is_cfa_op(op_t o) { return o == OP_RAWPREPARE || o == OP_TEMPERATURE || o == OP_HIGHLIGHTS; }
 
@@ -569,11 +591,11 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
     }
   if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
   for(const node_t &n : pipe->nodes)
-    if(n.op == OP_DENOISEPROFILE || n.op == OP_DIFFUSE || n.op == OP_NLMEANS || n.op == OP_BILAT || n.op == OP_FINALSCALE
-       || n.op == OP_BLEND)
+    if(n.op == OP_BILAT || n.op == OP_FINALSCALE || n.op == OP_BLEND)
     {
-      // these need a halo of 2^scales rows per band and (denoiseprofile) an all-reduce per wavelet band
-      set_last_error("band mode: '%s' has no row-band implementation yet", k_ops[n.op].name);
+      // the bilateral grid is one accumulation over the whole frame in pixel order; finalscale
+      // changes the geometry; a blend needs the module input kept
+      set_last_error("band mode: '%s' has no row-band implementation", k_ops[n.op].name);
       return DT_HIP_INVALID_ARG;
     }
   const size_t ng = pipe->groups.size();
@@ -688,6 +710,22 @@ int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_
   return err;
 }
 
+int dt_hip_band_halo_rows(const char *op, const dt_hip_piece_t *piece, const void *data, size_t data_size)
+{
+  if(!op || !piece) return -1;
+  node_t n;
+  n.op = OP_UNKNOWN;
+  for(int k = 0; k < (int)OP_UNKNOWN; k++)
+    if(!strcmp(op, k_ops[k].name)) n.op = (op_t)k;
+  if(n.op == OP_UNKNOWN || data_size != k_ops[n.op].data_size || (data_size && !data)) return -1;
+  n.piece = *piece;
+  if(data_size) n.data.assign((const unsigned char *)data, (const unsigned char *)data + data_size);
+  return band_halo_rows(n);
+}
+
+// Resumable: returns DT_HIP_BAND_EXCHANGE in front of a stencil module (fill the halo rows of state->halo_buf)
+// and in the middle of the profiled wavelets (all-reduce state->sum_buf); the caller does what the state
+// asks for and calls again with the same arguments.
 int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state,
                             dt_hip_mem_t dev_out_band)
 {
@@ -696,34 +734,198 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
   const int devid = pipe->devid;
   const dt_hip_band_t &b = *band;
   const size_t ng = pipe->groups.size();
+  const int W = pipe->nodes[0].piece.roi_out.width, H = pipe->nodes[0].piece.roi_out.height;
+  const size_t rgba_row = (size_t)W * 16;
   int err = DT_HIP_SUCCESS;
-  if(pv->journal) err = dt_hip_pipe_band_resolve(pipe, band, state); // caller skipped the explicit step
-  dt_hip_mem_t cur = pv->cfa;
-  bool cur_owned = pv->cfa_owned;
-  if(pv->next_group >= ng && err == DT_HIP_SUCCESS)
+  state->halo_rows = 0;
+  state->sum_buf = nullptr;
+  state->sum_count = 0;
+  if(!pv->walking)
   {
-    // CFA-only pipe: the result is the band buffer itself
-    const node_t &last = pipe->nodes.back();
-    err = dt_hip_enqueue_copy_buffer_to_buffer(devid, cur, dev_out_band, 0, 0,
-                                               (size_t)b.rows * last.piece.roi_out.width * 4);
+    if(pv->journal) err = dt_hip_pipe_band_resolve(pipe, band, state); // caller skipped the explicit step
+    pv->cur = pv->cur_base = pv->cfa;
+    pv->cur_owned = pv->cfa_owned;
+    pv->walking = true;
+    if(pv->next_group >= ng && err == DT_HIP_SUCCESS)
+    {
+      // CFA-only pipe: the result is the band buffer itself
+      const node_t &last = pipe->nodes.back();
+      err = dt_hip_enqueue_copy_buffer_to_buffer(devid, pv->cur, dev_out_band, 0, 0,
+                                                 (size_t)b.rows * last.piece.roi_out.width * 4);
+    }
   }
-  for(size_t gi = pv->next_group; gi < ng && err == DT_HIP_SUCCESS; gi++)
+  auto drop_cur = [&]() {
+    if(pv->cur_owned && pv->cur_base && pv->cur_base != dev_out_band) dt_hip_release_mem_object(pv->cur_base);
+    pv->cur = pv->cur_base = nullptr;
+    pv->cur_owned = false;
+  };
+  // rows a stencil group takes from the neighbours, clipped at the frame
+  auto halo_of = [&](const size_t gi, int &top, int &bottom) {
+    const int h = band_halo_rows(pipe->nodes[pipe->groups[gi].first]);
+    top = h < b.row0 ? h : b.row0;
+    bottom = h < H - (b.row0 + b.rows) ? h : H - (b.row0 + b.rows);
+    return h;
+  };
+  while(pv->next_group < ng && err == DT_HIP_SUCCESS)
   {
+    const size_t gi = pv->next_group;
     const group_t &g = pipe->groups[gi];
     const node_t &first = pipe->nodes[g.first];
     const node_t &last = pipe->nodes[g.first + g.count - 1];
-    dt_hip_mem_t out = dev_out_band;
-    bool out_owned = false;
-    if(gi + 1 < ng)
+    const bool final_group = gi + 1 == ng;
+    if(g.kind == group_t::SINGLE && is_stencil_op(first.op))
+    {
+      int top, bottom;
+      const int h = halo_of(gi, top, bottom);
+      const int buf_rows = top + b.rows + bottom;
+      if(pv->stage == 0)
+      {
+        if(h < 0)
+        {
+          // the module does nothing on a frame this small (denoiseprofile.c:1325-1329): pass the rows through
+          pv->stage = 3;
+          continue;
+        }
+        if(!pv->cur_is_halo_layout)
+        {
+          // own rows into the middle of a [top][rows][bottom] buffer
+          dt_hip_mem_t hb = dt_hip_alloc_device_buffer(devid, (size_t)buf_rows * rgba_row);
+          if(!hb)
+          {
+            err = DT_HIP_SYSMEM_ALLOCATION;
+            break;
+          }
+          err = dt_hip_enqueue_copy_buffer_to_buffer(devid, pv->cur, hb, 0, (size_t)top * rgba_row, (size_t)b.rows * rgba_row);
+          drop_cur();
+          pv->cur_base = hb;
+          pv->cur = (char *)hb + (size_t)top * rgba_row;
+          pv->cur_owned = true;
+          if(err != DT_HIP_SUCCESS) break;
+        }
+        pv->cur_is_halo_layout = false;
+        pv->stage = 1;
+        if(top || bottom)
+        {
+          state->halo_buf = pv->cur_base;
+          state->row_bytes = rgba_row;
+          state->halo_rows = h;
+          return DT_HIP_BAND_EXCHANGE;
+        }
+      }
+      if(pv->stage == 1)
+      {
+        // the module on the buffer.  diffuse and the wavelets run on it as on a frame of its own: every row whose
+        // stencils stay inside the buffer or hit a real frame border is exact, and the halo covers the rest.
+        // non-local means keeps the frame's chunk grid and stores own rows only.
+        state->halo_buf = nullptr;
+        band_view_t v;
+        v.frame_h = H;
+        v.buf_row0 = b.row0 - top;
+        v.row0 = b.row0;
+        v.row1 = b.row0 + b.rows;
+        const bool own_rows_out = first.op == OP_NLMEANS
+                                  || (first.op == OP_DENOISEPROFILE
+                                      && first.as<dt_hip_denoiseprofile_data_t>()->mode == DT_HIP_DENOISEPROFILE_NLMEANS);
+        dt_hip_mem_t out = dev_out_band;
+        if(!(own_rows_out && final_group))
+        {
+          out = dt_hip_alloc_device_buffer(devid, (size_t)(own_rows_out ? b.rows : buf_rows) * rgba_row);
+          if(!out)
+          {
+            err = DT_HIP_SYSMEM_ALLOCATION;
+            break;
+          }
+        }
+        pv->out = out;
+        pv->out_own_rows = own_rows_out;
+        if(first.op == OP_NLMEANS)
+          err = nlmeans_process_band(devid, &first.piece, first.as<dt_hip_nlmeans_data_t>(), &v, pv->cur_base, out);
+        else if(first.op == OP_DIFFUSE)
+        {
+          dt_hip_piece_t p = first.piece;
+          p.roi_in.height = p.roi_out.height = buf_rows;
+          err = dt_hip_iop_diffuse_process(devid, &p, first.as<dt_hip_diffuse_data_t>(), pv->cur_base, out);
+        }
+        else
+        {
+          double *sums = nullptr;
+          size_t count = 0;
+          err = denoiseprofile_band_begin(devid, &first.piece, first.as<dt_hip_denoiseprofile_data_t>(), &v, buf_rows,
+                                          pv->cur_base, out, &pv->dn_job, &sums, &count);
+          if(err == DT_HIP_SUCCESS && pv->dn_job)
+          {
+            pv->stage = 2;
+            if(b.rows < H)
+            {
+              state->sum_buf = sums;
+              state->sum_count = count;
+              return DT_HIP_BAND_EXCHANGE;
+            }
+          }
+        }
+        if(err != DT_HIP_SUCCESS)
+        {
+          if(out != dev_out_band) dt_hip_release_mem_object(out);
+          pv->out = nullptr;
+          break;
+        }
+        if(pv->stage != 2) pv->stage = 3;
+      }
+      if(pv->stage == 2)
+      {
+        err = denoiseprofile_band_finish(pv->dn_job, pv->out);
+        pv->dn_job = nullptr;
+        if(err != DT_HIP_SUCCESS)
+        {
+          if(pv->out != dev_out_band) dt_hip_release_mem_object(pv->out);
+          pv->out = nullptr;
+          break;
+        }
+        pv->stage = 3;
+      }
+      // stage 3: the module's output becomes the current buffer
+      if(pv->out)
+      {
+        drop_cur();
+        pv->cur_base = pv->out;
+        pv->cur = pv->out_own_rows ? pv->out : (dt_hip_mem_t)((char *)pv->out + (size_t)top * rgba_row);
+        pv->cur_owned = pv->out != dev_out_band;
+        pv->out = nullptr;
+      }
+      if(final_group && pv->cur != dev_out_band)
+        err = dt_hip_enqueue_copy_buffer_to_buffer(devid, pv->cur_base, dev_out_band, (size_t)((char *)pv->cur - (char *)pv->cur_base),
+                                                   0, (size_t)b.rows * rgba_row);
+      pv->stage = 0;
+      pv->next_group++;
+      continue;
+    }
+    // demosaic and pointwise groups
+    dt_hip_mem_t out = dev_out_band, out_base = dev_out_band;
+    bool out_owned = false, out_halo_layout = false;
+    if(!final_group)
     {
       node_t sized = last;
       sized.piece.roi_out.height = b.rows;
-      out = dt_hip_alloc_device_buffer(devid, out_bytes(sized));
-      if(!out)
+      size_t bytes = out_bytes(sized), lead = 0;
+      const group_t &nx = pipe->groups[gi + 1];
+      if(nx.kind == group_t::SINGLE && is_stencil_op(pipe->nodes[nx.first].op) && bytes == (size_t)b.rows * rgba_row)
+      {
+        // the next group is a stencil: write the own rows where its halo layout wants them
+        int top, bottom;
+        if(halo_of(gi + 1, top, bottom) >= 0)
+        {
+          bytes = (size_t)(top + b.rows + bottom) * rgba_row;
+          lead = (size_t)top * rgba_row;
+          out_halo_layout = true;
+        }
+      }
+      out_base = dt_hip_alloc_device_buffer(devid, bytes);
+      if(!out_base)
       {
         err = DT_HIP_SYSMEM_ALLOCATION;
         break;
       }
+      out = (char *)out_base + lead;
       out_owned = true;
     }
     if(first.op == OP_DEMOSAIC)
@@ -743,26 +945,31 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
         rb.in_rows = b.halo_top + b.rows + b.halo_bottom;
         rb.out_row0 = b.row0;
         rb.out_rows = b.rows;
-        err = dt_hip_iop_demosaic_process_band(devid, &first.piece, d, &rb, cur, out);
+        err = dt_hip_iop_demosaic_process_band(devid, &first.piece, d, &rb, pv->cur, out);
       }
     }
     else if(g.kind == group_t::RGB)
     {
       rgb_group_t r = g.rgb;
       r.height = b.rows;
-      err = rgb_group_launch(devid, r, cur, out);
+      err = rgb_group_launch(devid, r, pv->cur, out);
     }
     else
     {
       node_t n = first;
       band_piece(n.piece, b);
-      err = run_single(devid, n, cur, out);
+      err = run_single(devid, n, pv->cur, out);
     }
-    if(cur_owned) dt_hip_release_mem_object(cur);
-    cur = out;
-    cur_owned = out_owned;
+    drop_cur();
+    pv->cur = out;
+    pv->cur_base = out_base;
+    pv->cur_owned = out_owned;
+    pv->cur_is_halo_layout = out_halo_layout;
+    pv->next_group++;
   }
-  if(cur_owned && cur != dev_out_band) dt_hip_release_mem_object(cur);
+  drop_cur();
+  if(pv->out && pv->out != dev_out_band) dt_hip_release_mem_object(pv->out);
+  if(pv->dn_job) denoiseprofile_band_abort(pv->dn_job);
   delete pv;
   state->priv = nullptr;
   state->halo_buf = nullptr;

@@ -10,7 +10,15 @@ the assembled result is bit-identical to the unsplit frame.  Per frame and rank:
     send/recv       `halo` = 9 mosaic rows with the band above and below   (RCCL over xGMI)
     engine.finish   demosaic on the frame's tile rows + RGBA stages        (device)
 
-There is no other data-path communication: every module after demosaic on this path is pointwise.
+On the light pipe there is no other data-path communication: every module after the demosaic is pointwise.
+The stencil modules of the full pipe (denoiseprofile, diffuse, nlmeans) make engine.finish() resumable: it
+stops in front of such a module and hands back a BandRequest --
+
+    request.halo    RGBA rows [min(h, row0)][rows][min(h, H - row1)]: send/recv of h rows with each neighbour
+    request.sums    the frame-wide table of the profiled wavelets' partial sums, own entries filled, the rest
+                    zero: all-reduce(SUM), exact in any order
+
+-- the driver serves it and calls finish() again (serve_request / process_band below).
 The communication layer is torch.distributed ("nccl" is RCCL on ROCm; "gloo" in the CPU tests);
 the compute engine is the C++ executor of libansel_hip.so -- HipBandEngine below.  tests/ plug an
 oracle-backed engine into the same driver to cover the N > 1 logic without a GPU.
@@ -46,6 +54,17 @@ class BandWork:
         self.token = token
 
 
+class BandRequest:
+    """what a resumable engine.finish() asks of the other bands: `halo` = the [top][rows][bottom] rows of the
+    module input whose first / last part the neighbours fill (`h` rows each, clipped at the frame), `sums` =
+    a float64 vector to all-reduce; either may be None"""
+
+    def __init__(self, halo, h, sums):
+        self.halo = halo
+        self.h = h
+        self.sums = sums
+
+
 class _DevicePtr:
     """__cuda_array_interface__ carrier so torch can view memory owned by the dt_hip runtime"""
 
@@ -72,6 +91,7 @@ class HipBandEngine:
         stream = torch.cuda.current_stream(self.device)
         lib.check(self.lib.dt_hip_set_stream(self.device.index or 0, C.c_void_p(stream.cuda_stream)),
                   "dt_hip_set_stream")
+        self.frame_height = int(device_pipe.nodes[0].piece.roi_out.height)
 
     def begin(self, band, dev_in_band, width):
         st = abi.BandState()
@@ -90,8 +110,20 @@ class HipBandEngine:
                   "dt_hip_pipe_band_resolve")
 
     def finish(self, band, work, dev_out_band):
-        lib.check(self.lib.dt_hip_pipe_band_finish(self.pipe.handle, C.byref(band), C.byref(work.token), dev_out_band),
-                  "dt_hip_pipe_band_finish")
+        """None when the band is done, else the BandRequest to serve before calling again"""
+        st = work.token
+        rc = self.lib.dt_hip_pipe_band_finish(self.pipe.handle, C.byref(band), C.byref(st), dev_out_band)
+        if rc != abi.DT_HIP_BAND_EXCHANGE:
+            lib.check(rc, "dt_hip_pipe_band_finish")
+            return None
+        halo = sums = None
+        if st.halo_rows > 0:
+            top = min(st.halo_rows, band.row0)
+            bottom = min(st.halo_rows, self.frame_height - band.row0 - band.rows)
+            halo = device_view(st.halo_buf, (top + band.rows + bottom, st.row_bytes // 4), "<f4", self.device)
+        if st.sum_buf:
+            sums = device_view(st.sum_buf, (st.sum_count,), "<f8", self.device)
+        return BandRequest(halo, st.halo_rows, sums)
 
 
 def sum_clipped(work, bands, dist=None, group=None):
@@ -126,6 +158,40 @@ def exchange_halo(work, bands, rank, dist=None, group=None):
             req.wait()
 
 
+def _halo_parts(bands, k, h, height):
+    b = bands[k]
+    return min(h, b.row0), min(h, height - b.row0 - b.rows)
+
+
+def serve_request(req, bands, rank, dist=None, group=None):
+    """the collectives of one BandRequest (no-ops for one band)"""
+    n = len(bands)
+    if n == 1 or dist is None:
+        return
+    if req.sums is not None:
+        dist.all_reduce(req.sums, op=dist.ReduceOp.SUM, group=group)
+    if req.halo is None:
+        return
+    height = bands[-1].row0 + bands[-1].rows
+    b, h = bands[rank], req.h
+    top, bottom = _halo_parts(bands, rank, h, height)
+    for k in (rank - 1, rank + 1):
+        if 0 <= k < n and bands[k].rows < h:
+            raise lib.AnselHipError("band %d owns %d rows, fewer than the %d halo rows its neighbour needs: "
+                                    "use fewer bands" % (k, bands[k].rows, h))
+    ops = []
+    if rank > 0:
+        need = _halo_parts(bands, rank - 1, h, height)[1]  # rows the band above reads from me
+        ops.append(dist.P2POp(dist.isend, req.halo[top:top + need], rank - 1, group=group))
+        ops.append(dist.P2POp(dist.irecv, req.halo[0:top], rank - 1, group=group))
+    if rank + 1 < n:
+        need = _halo_parts(bands, rank + 1, h, height)[0]
+        ops.append(dist.P2POp(dist.isend, req.halo[top + b.rows - need:top + b.rows], rank + 1, group=group))
+        ops.append(dist.P2POp(dist.irecv, req.halo[top + b.rows:top + b.rows + bottom], rank + 1, group=group))
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+
+
 def process_band(engine, bands, rank, dev_in_band, dev_out_band, width, dist=None, group=None):
     """one frame, this rank's band"""
     band = bands[rank]
@@ -133,12 +199,16 @@ def process_band(engine, bands, rank, dev_in_band, dev_out_band, width, dist=Non
     sum_clipped(work, bands, dist, group)
     engine.resolve(band, work)
     exchange_halo(work, bands, rank, dist, group)
-    engine.finish(band, work, dev_out_band)
+    while True:
+        req = engine.finish(band, work, dev_out_band)
+        if req is None:
+            break
+        serve_request(req, bands, rank, dist, group)
 
 
 def process_bands_locally(engine, bands, ins, outs, width):
-    """all bands of a frame in one process, one after the other (single-GPU test of the band path):
-    the same protocol with the two collectives done as tensor copies"""
+    """all bands of a frame in one process, in lockstep (single-GPU test of the band path):
+    the same protocol with the collectives done as tensor copies"""
     works = [engine.begin(b, i, width) for b, i in zip(bands, ins)]
     counts = [w.count for w in works if w.count is not None]
     if counts:
@@ -148,8 +218,32 @@ def process_bands_locally(engine, bands, ins, outs, width):
     for b, w in zip(bands, works):
         engine.resolve(b, w)
     local_halo(works, bands)
-    for b, w, o in zip(bands, works, outs):
-        engine.finish(b, w, o)
+    height = bands[-1].row0 + bands[-1].rows
+    while True:
+        reqs = [engine.finish(b, w, o) for b, w, o in zip(bands, works, outs)]
+        if all(r is None for r in reqs):
+            return
+        assert all(r is not None for r in reqs), "the bands of a frame stop at the same modules"
+        if reqs[0].sums is not None:
+            total = reqs[0].sums.clone()
+            for r in reqs[1:]:
+                total += r.sums
+            for r in reqs:
+                r.sums.copy_(total)
+        if reqs[0].halo is not None:
+            h = reqs[0].h
+            for k, (r, b) in enumerate(zip(reqs, bands)):
+                top, bottom = _halo_parts(bands, k, h, height)
+                if top:
+                    up, ub = reqs[k - 1], bands[k - 1]
+                    assert ub.rows >= top
+                    utop = _halo_parts(bands, k - 1, h, height)[0]
+                    r.halo[0:top].copy_(up.halo[utop + ub.rows - top:utop + ub.rows])
+                if bottom:
+                    dn = reqs[k + 1]
+                    assert bands[k + 1].rows >= bottom
+                    dtop = _halo_parts(bands, k + 1, h, height)[0]
+                    r.halo[top + b.rows:top + b.rows + bottom].copy_(dn.halo[dtop:dtop + bottom])
 
 
 def local_halo(works, bands):

@@ -529,7 +529,30 @@ int dt_hip_batch_drain(dt_hip_batch_t *batch);
  *                              rows -> dev_out_band (rows x width)
  *
  * dev_in_band holds the band's input rows only: input rows [crop_y + row0, crop_y + row0 + rows),
- * full input width. */
+ * full input width.
+ *
+ * Stencil modules after the demosaic (denoiseprofile, diffuse, nlmeans): dt_hip_pipe_band_finish() is
+ * resumable.  It returns DT_HIP_BAND_EXCHANGE (> 0) when the band needs something from the others, with the
+ * request in `state`; the caller serves it and calls again with the same arguments, until DT_HIP_SUCCESS
+ * (or an error, which ends the walk and frees the state):
+ *
+ *   state->halo_rows = h > 0   halo_buf holds RGBA rows [min(h, row0)][rows][min(h, H - row0 - rows)] of
+ *                              `row_bytes`; fill the first and last part with the neighbours' last / first
+ *                              own rows of the same buffer.  h is the same on every band (it is a
+ *                              function of the module: dt_hip_band_halo_rows()); a neighbour must own at
+ *                              least h rows.
+ *   state->sum_buf != NULL     sum_count doubles to all-reduce (SUM) over the bands: the frame-wide table of
+ *                              partial sums of the profiled wavelets (eaw.c:253-255), each band having filled
+ *                              the entries of its own rows and zeroed the rest, so the reduced table -- and
+ *                              the thresholds taken from it in a fixed order -- do not depend on how the
+ *                              collective associates.
+ *
+ * What a band computes is bit-identical to the rows of the unsplit frame: diffuse and the wavelets run on
+ * [halo][rows][halo] as on a frame of its own (h covers every stencil of every iteration / scale, so only halo
+ * rows see the artificial border); non-local means runs the chunk rows of the FRAME's grid that intersect the
+ * band (nlmeans_core.c:264-313: the grid is a function of the frame size).  bilat (one grid accumulated over
+ * the frame in pixel order), finalscale and blend nodes are refused in band mode. */
+#define DT_HIP_BAND_EXCHANGE 1
 typedef struct dt_hip_band_t
 {
   int32_t row0, rows;
@@ -542,10 +565,18 @@ typedef struct dt_hip_band_state_t
   size_t row_bytes;
   dt_hip_mem_t clipped_count;
   void *priv;
+  /* requests of a dt_hip_pipe_band_finish() that returned DT_HIP_BAND_EXCHANGE */
+  int32_t halo_rows;
+  int32_t reserved;
+  double *sum_buf;
+  size_t sum_count;
 } dt_hip_band_state_t;
 /* pure function (no device needed): cut a height-row frame into n_bands bands for the given
  * demosaic method (DT_HIP_DEMOSAIC_RCD, or -1 for a pipe without demosaic: 2-row aligned cuts) */
 int dt_hip_plan_bands(int width, int height, int demosaic_method, int n_bands, dt_hip_band_t *bands);
+/* pure function: rows of a neighbour a band needs in front of module `op` (0 for a pointwise module, -1 when
+ * the module has no band mode or passes a frame of this size through).  piece = the module's FRAME geometry */
+int dt_hip_band_halo_rows(const char *op, const dt_hip_piece_t *piece, const void *data, size_t data_size);
 int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_mem_t dev_in_band,
                            dt_hip_band_state_t *state);
 int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state);

@@ -13,9 +13,18 @@ import torch
 
 import checkers as ck
 from ansel_amd import abi
-from ansel_amd.tiled import BandWork
+from ansel_amd import lib as hiplib
+from ansel_amd.tiled import BandRequest, BandWork
 
 CFA_OPS = ("rawprepare", "temperature", "highlights")
+STENCIL_OPS = ("denoiseprofile", "diffuse", "nlmeans")
+
+
+def halo_rows(node):
+    """dt_hip_band_halo_rows(): a pure host function of libansel_hip.so"""
+    l = hiplib.load()
+    return l.dt_hip_band_halo_rows(node.op.encode(), C.byref(node.piece), C.cast(C.byref(node.data), C.c_void_p),
+                                   C.sizeof(node.data))
 
 
 def _band_piece(piece, band):
@@ -70,6 +79,43 @@ class OracleBandEngine:
             work.halo.numpy()[band.halo_top:band.halo_top + band.rows] = work.token
 
     def finish(self, band, work, out_band):
+        """resumable like dt_hip_pipe_band_finish(): a BandRequest to serve, or None when the band is done"""
+        if getattr(work, "walk", None) is None:
+            work.walk = self._walk(band, work, out_band)
+        try:
+            return next(work.walk)
+        except StopIteration:
+            return None
+
+    def _stencil(self, n, band, src):
+        """a stencil module on a band.  The module input of the band + the halo rows the driver fetched go into
+        a frame that is zero elsewhere, the oracle runs on that frame and the band's rows are cut out: they only
+        depend on rows within the halo, so they are the rows of the real whole-frame result -- if and only if the
+        halo dt_hip_band_halo_rows() asks for is large enough, which is what this checks on CPU.  The profiled
+        wavelets also need frame-wide sums; this stand-in gets them the blunt way, by all-reducing the module
+        input itself (own rows filled, zero elsewhere: the sum is the frame, exactly)."""
+        rows, w, h = band.rows, self.w, self.h
+        hr = halo_rows(n)
+        if hr < 0:
+            return src
+        top, bottom = min(hr, band.row0), min(hr, h - band.row0 - rows)
+        hb = torch.zeros((top + rows + bottom, w * 4), dtype=torch.float32)
+        hb[top:top + rows] = torch.from_numpy(src.reshape(rows, w * 4))
+        if top or bottom:
+            yield BandRequest(hb, hr, None)
+        frame = np.zeros((h, w, 4), np.float32)
+        frame[band.row0 - top:band.row0 + rows + bottom] = hb.numpy().reshape(-1, w, 4)
+        if n.op == "denoiseprofile" and n.data.mode == abi.DT_HIP_DENOISEPROFILE_WAVELETS and rows < h:
+            f64 = torch.zeros((h, w, 4), dtype=torch.float64)
+            f64[band.row0:band.row0 + rows] = torch.from_numpy(src.astype(np.float64))
+            f64 = f64.reshape(-1)
+            yield BandRequest(None, 0, f64)
+            frame = f64.numpy().reshape(h, w, 4).astype(np.float32)
+        full = np.zeros((h, w, 4), np.float32)
+        assert ck.call(self.l, "oracle_" + n.op, n.piece, n.data, frame, full) == 0, n.op
+        return np.ascontiguousarray(full[band.row0:band.row0 + rows])
+
+    def _walk(self, band, work, out_band):
         rows, w, h = band.rows, self.w, self.h
         cfa = work.halo.numpy()
         frame = np.zeros((h, w), np.float32)
@@ -86,6 +132,8 @@ class OracleBandEngine:
             elif n.op == "export_u16":
                 self.l.oracle_export_convert_u16(w, rows, ck.ptr(src), ck.ptr(out_band))
                 return
+            elif n.op in STENCIL_OPS:
+                src = yield from self._stencil(n, band, src)
             else:
                 dst = np.zeros((rows, w, 4), np.float32)
                 assert ck.call(self.l, "oracle_" + n.op, _band_piece(n.piece, band), n.data, src, dst) == 0, n.op

@@ -111,3 +111,59 @@ def test_rccl_accepts_runtime_owned_buffers():
         assert np.array_equal(d_out.cpu().numpy().view(np.uint16), _whole(torch, nodes, raw, w, h, True))
     finally:
         dist.destroy_process_group()
+
+
+# ---- the stencil modules of the full pipe on row bands (config 4 of BASELINE.json) ----------------------------
+def _full_nodes(w, h, d_lut, lut, which):
+    from ansel_amd import abi
+    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
+                                    filmic=filmic.default_data(), diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
+    drop = {"wavelets": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
+            "diffuse": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
+            "nlmeans": ("denoiseprofile", "diffuse"),
+            "dn_nlmeans": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
+            "all": ()}[which]
+    nodes = [n for n in nodes if n.op not in drop]
+    if which == "dn_nlmeans":
+        for n in nodes:
+            if n.op == "denoiseprofile":
+                n.data = params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS)
+    return nodes
+
+
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "nlmeans", "dn_nlmeans", "all"])
+@pytest.mark.parametrize("w,h,n", [(752, 2000, 2), (752, 2000, 5), (400, 640, 2), (400, 640, 1)])
+def test_full_pipe_bands_equal_the_unsplit_frame(w, h, n, which):
+    """denoise (profiled) wavelets / non-local means, diffuse-or-sharpen and nlmeans on row bands: halo rows
+    from the neighbours, the wavelets' thresholds from the frame-wide sums -- bit-identical to the unsplit run"""
+    torch, lut, d_lut = _setup()
+    nodes = _full_nodes(w, h, d_lut, lut, which)
+    raw = synth.bayer_mosaic(w, h, seed=7)
+    whole = _whole(torch, nodes, raw, w, h, True)
+    banded = _banded(torch, nodes, raw, w, h, n, True)
+    assert np.array_equal(banded, whole)
+    assert whole.std() > 100  # a real picture came out
+
+
+def test_full_pipe_bands_equal_the_oracle():
+    torch, lut, d_lut = _setup()
+    w, h = 256, 480
+    raw = be.test_frame(w, h, 9, 9)
+    dev = _banded(torch, _full_nodes(w, h, d_lut, lut, "all"), raw, w, h, 3, True)
+    host = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), params.unbounded_coeffs(lut),
+                                   filmic=filmic.default_data(), diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
+    assert np.array_equal(dev, be.whole_frame(host, raw, w, h))
+
+
+def test_modules_without_a_band_mode_are_refused():
+    torch, lut, d_lut = _setup()
+    w, h = 400, 640
+    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
+                                    filmic=filmic.default_data(), with_nlmeans=True, with_bilat=True)
+    p = pipe.DevicePipe(0, nodes)
+    engine = tiled.HipBandEngine(p, "cuda:0")
+    bands = tiled.plan_bands(w, h, 2)
+    d_in = torch.zeros((bands[0].rows, w), dtype=torch.int16, device="cuda:0")
+    with pytest.raises(lib.AnselHipError, match="bilat"):
+        engine.begin(bands[0], d_in.data_ptr(), w)
+    p.close()

@@ -117,3 +117,105 @@ def test_local_protocol_matches_the_unsplit_frame_for_three_bands(n_top, n_botto
     outs = [np.zeros((b.rows, w, 4), np.uint16) for b in bands]
     tiled.process_bands_locally(engine, bands, [raw[b.row0:b.row0 + b.rows] for b in bands], outs, w)
     assert np.array_equal(np.concatenate(outs, axis=0), be.whole_frame(nodes, raw, w, h))
+
+
+# ---- the stencil modules of the full pipe on row bands (config 4 of BASELINE.json) ----------------------------
+def _full_nodes(w, h, lut, which):
+    coeffs = params.unbounded_coeffs(lut)
+    nodes = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, filmic=filmic.default_data(),
+                                    diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
+    drop = {"wavelets": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
+            "diffuse": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
+            "nlmeans": ("denoiseprofile", "diffuse"),
+            "dn_nlmeans": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
+            "all": ()}[which]
+    nodes = [n for n in nodes if n.op not in drop]
+    if which == "dn_nlmeans":
+        for n in nodes:
+            if n.op == "denoiseprofile":
+                n.data = params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS)
+    return nodes
+
+
+def test_halo_rows_of_the_stencil_modules():
+    """dt_hip_band_halo_rows(): pure host function"""
+    lut = params.srgb_encode_lut()
+    by_op = {n.op: n for n in _full_nodes(752, 2000, lut, "all")}
+    # 7 wavelet bands at this size (denoiseprofile.c:1301-1317): 2 * (1 + 2 + ... + 64) rows
+    assert be.halo_rows(by_op["denoiseprofile"]) == 254
+    # patch radius 2 + 1 + search radius 7, + the 60-row-ish chunk the band boundary may cut (nlmeans_core.c:264-295)
+    assert 10 + 50 <= be.halo_rows(by_op["nlmeans"]) <= 10 + 70
+    it, scales = 2, oracle_scales(by_op["diffuse"])
+    assert be.halo_rows(by_op["diffuse"]) == it * 3 * ((1 << scales) - 1)
+    assert be.halo_rows(by_op["colorin"]) == 0
+    # a frame the wavelets pass through untouched (denoiseprofile.c:1325-1329)
+    small = {n.op: n for n in _full_nodes(100, 2000, lut, "all")}  # 100 columns < 2 x the coarsest dilation 64
+    assert be.halo_rows(small["denoiseprofile"]) == -1
+
+
+def oracle_scales(node):
+    import ctypes as C
+    l = ck.oracle()
+    if l is None:
+        pytest.skip("oracle/liboracle.so not built")
+    l.oracle_diffuse_scales.restype = C.c_int
+    return l.oracle_diffuse_scales(C.byref(node.piece), C.byref(node.data))
+
+
+def _full_rank_main(rank, world, port, w, h, which, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "8"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lut = params.srgb_encode_lut()
+        nodes = _full_nodes(w, h, lut, which)
+        raw = be.test_frame(w, h, 10, 10)
+        bands = tiled.plan_bands(w, h, world, tiled.pipe_demosaic_method(nodes))
+        b = bands[rank]
+        engine = be.OracleBandEngine(nodes, w, h)
+        out = np.zeros((b.rows, w, 4), np.uint16)
+        tiled.process_band(engine, bands, rank, raw[b.row0:b.row0 + b.rows], out, w, dist=dist)
+        np.save(os.path.join(outdir, "band%d.npy" % rank), out)
+    finally:
+        dist.destroy_process_group()
+
+
+@needs_oracle
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "nlmeans", "dn_nlmeans", "all"])
+def test_two_ranks_full_pipe_over_gloo_equal_the_unsplit_frame(tmp_path, which):
+    """halo send/recv of float4 rows + the all-reduce of the wavelets, and the halo sizes themselves: a band cut
+    from a frame that is zero beyond the halo equals the rows of the real frame only if the halo is enough"""
+    import torch.multiprocessing as mp
+    w, h, world = 128, 400, 2
+    port = _free_port()
+    mp.spawn(_full_rank_main, args=(world, port, w, h, which, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("band%d.npy" % r)) for r in range(world)], axis=0)
+    lut = params.srgb_encode_lut()
+    want = be.whole_frame(_full_nodes(w, h, lut, which), be.test_frame(w, h, 10, 10), w, h)
+    assert np.array_equal(got, want)
+
+
+@needs_oracle
+def test_local_protocol_full_pipe_three_bands():
+    w, h, n = 128, 480, 3
+    lut = params.srgb_encode_lut()
+    nodes = _full_nodes(w, h, lut, "all")
+    raw = be.test_frame(w, h, 4, 30)
+    bands = tiled.plan_bands(w, h, n)
+    engine = be.OracleBandEngine(nodes, w, h)
+    outs = [np.zeros((b.rows, w, 4), np.uint16) for b in bands]
+    tiled.process_bands_locally(engine, bands, [raw[b.row0:b.row0 + b.rows] for b in bands], outs, w)
+    assert np.array_equal(np.concatenate(outs, axis=0), be.whole_frame(nodes, raw, w, h))
+
+
+def test_a_neighbour_thinner_than_the_halo_is_refused():
+    class _Dist:
+        pass
+    bands = tiled.plan_bands(128, 400, 4)
+    req = tiled.BandRequest(halo=object(), h=200, sums=None)
+    with pytest.raises(Exception, match="fewer than"):
+        tiled.serve_request(req, bands, 1, dist=_Dist())
