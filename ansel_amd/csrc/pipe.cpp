@@ -378,7 +378,7 @@ struct band_priv_t
   bool cur_owned, cur_is_halo_layout;
   int stage;                  // inside a stencil group: 0 before the halo exchange, 1 after it, 2 after the sums, 3 done
   dt_hip_mem_t out;
-  bool out_own_rows;
+  bool out_own_rows, out_owned;
   dn_band_job_t *dn_job;
 };
 
@@ -710,6 +710,24 @@ int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_
   return err;
 }
 
+// Give up a band between dt_hip_pipe_band_begin() and the last dt_hip_pipe_band_finish(): frees what the state holds
+void dt_hip_pipe_band_abort(dt_hip_pipe_t *pipe, dt_hip_band_state_t *state)
+{
+  if(!pipe || !state || !state->priv) return;
+  band_priv_t *pv = (band_priv_t *)state->priv;
+  if(pv->walking)
+  {
+    if(pv->cur_owned && pv->cur_base) dt_hip_release_mem_object(pv->cur_base);
+  }
+  else if(pv->cfa_owned && pv->cfa)
+    dt_hip_release_mem_object(pv->cfa);
+  if(pv->out && pv->out_owned) dt_hip_release_mem_object(pv->out);
+  if(pv->journal) dt_hip_release_mem_object(pv->journal);
+  if(pv->dn_job) denoiseprofile_band_abort(pv->dn_job);
+  delete pv;
+  memset(state, 0, sizeof(*state));
+}
+
 int dt_hip_band_halo_rows(const char *op, const dt_hip_piece_t *piece, const void *data, size_t data_size)
 {
   if(!op || !piece) return -1;
@@ -838,6 +856,7 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
         }
         pv->out = out;
         pv->out_own_rows = own_rows_out;
+        pv->out_owned = out != dev_out_band;
         if(first.op == OP_NLMEANS)
           err = nlmeans_process_band(devid, &first.piece, first.as<dt_hip_nlmeans_data_t>(), &v, pv->cur_base, out);
         else if(first.op == OP_DIFFUSE)

@@ -125,6 +125,10 @@ class HipBandEngine:
             sums = device_view(st.sum_buf, (st.sum_count,), "<f8", self.device)
         return BandRequest(halo, st.halo_rows, sums)
 
+    def abort(self, work):
+        """free a band whose walk will not be finished"""
+        self.lib.dt_hip_pipe_band_abort(self.pipe.handle, C.byref(work.token))
+
 
 def sum_clipped(work, bands, dist=None, group=None):
     """collective 1: the frame-wide clipped count (no-op for one band)"""
@@ -196,14 +200,19 @@ def process_band(engine, bands, rank, dev_in_band, dev_out_band, width, dist=Non
     """one frame, this rank's band"""
     band = bands[rank]
     work = engine.begin(band, dev_in_band, width)
-    sum_clipped(work, bands, dist, group)
-    engine.resolve(band, work)
-    exchange_halo(work, bands, rank, dist, group)
-    while True:
-        req = engine.finish(band, work, dev_out_band)
-        if req is None:
-            break
-        serve_request(req, bands, rank, dist, group)
+    try:
+        sum_clipped(work, bands, dist, group)
+        engine.resolve(band, work)
+        exchange_halo(work, bands, rank, dist, group)
+        while True:
+            req = engine.finish(band, work, dev_out_band)
+            if req is None:
+                break
+            serve_request(req, bands, rank, dist, group)
+    except Exception:
+        if hasattr(engine, "abort"):
+            engine.abort(work)  # a finish() that failed has freed the state already: abort is then a no-op
+        raise
 
 
 def process_bands_locally(engine, bands, ins, outs, width):

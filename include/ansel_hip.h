@@ -582,6 +582,8 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
 int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state);
 int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state,
                             dt_hip_mem_t dev_out_band);
+/* give up a band whose walk has not ended (an error on another rank, a cancelled export): frees the state */
+void dt_hip_pipe_band_abort(dt_hip_pipe_t *pipe, dt_hip_band_state_t *state);
 
 /* layout self-check for language bindings: sizeof() of the struct named `name` as compiled */
 size_t dt_hip_abi_sizeof(const char *name);
