@@ -262,4 +262,48 @@ int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hi
   return check_launch("bilat");
 }
 
+
+// tiling_callback(), src/iop/bilat.c:252-297.  factor / maxbuf / overlap are the reference's, for the host's own
+// tiling; factor_cl / maxbuf_cl are what THIS implementation holds on the device: in + out + one grid (the blur is
+// in place), or in + out + the (2 + 6)-plane padded pyramid of local_laplacian_memory_use(), locallaplacian.c:566-591
+void dt_hip_iop_bilat_tiling(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_tiling_t *tiling)
+{
+  const int width = piece->roi_in.width, height = piece->roi_in.height;
+  const float basebuffer = (float)sizeof(float) * piece->channels * width * height;
+  const float scale = (float)(d->iscale / piece->roi_in.scale);
+  memset(tiling, 0, sizeof(*tiling));
+  tiling->xalign = tiling->yalign = 1;
+  if(d->mode == DT_HIP_BILAT_BILATERAL)
+  {
+    grid_t b;
+    const float sigma_s = d->sigma_s / scale;
+    grid_size(b, width, height, 100.0f, sigma_s, d->sigma_r);
+    const float grid = (float)((size_t)b.size_x * b.size_y * b.size_z * sizeof(float));
+    tiling->factor = 2.0f + 2.0f * grid / basebuffer; // dt_bilateral_memory_use(), bilateral.c:80-94 (OpenCL build)
+    tiling->maxbuf = fmaxf(1.0f, grid / basebuffer);
+    tiling->factor_cl = 2.0f + grid / basebuffer;
+    tiling->maxbuf_cl = tiling->maxbuf;
+    tiling->overlap = (unsigned)ceilf(4 * sigma_s);
+  }
+  else
+  {
+    const int m = width < height ? width : height;
+    const int nl = m > 0 ? 31 - __builtin_clz((unsigned)m) : 0;
+    const int num_levels = nl < 30 ? nl : 30;
+    const int max_supp = num_levels > 0 ? 1 << (num_levels - 1) : 1;
+    auto dl = [](int size, const int level) {
+      for(int l = 0; l < level; l++) size = (size - 1) / 2 + 1;
+      return size;
+    };
+    float mem = 0.0f;
+    for(int l = 0; l < num_levels; l++)
+      mem += (float)sizeof(float) * (2 + 6) * dl(width + 2 * max_supp, l) * dl(height + 2 * max_supp, l);
+    const float single = (float)sizeof(float) * (width + 2 * max_supp) * (height + 2 * max_supp);
+    tiling->factor = tiling->factor_cl = 2.0f + mem / basebuffer;
+    tiling->maxbuf = tiling->maxbuf_cl = fmaxf(1.0f, single / basebuffer);
+    const float rad = ceilf(256.0f / scale);
+    tiling->overlap = (unsigned)((float)width < rad ? (float)width : rad);
+  }
+}
+
 } // extern "C"

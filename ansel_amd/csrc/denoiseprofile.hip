@@ -856,4 +856,33 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
   return err;
 }
 
+
+// tiling_callback(), src/iop/denoiseprofile.c:796-848.  factor / overlap as the reference states them for the host;
+// factor_cl = the planes this implementation holds on the device: wavelets in + out + precond + tmp + detail (the
+// partial sums are W / 64 of a plane), non-local means in + out + the preconditioned copy (the tables live in LDS)
+void dt_hip_iop_denoiseprofile_tiling(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
+                                      dt_hip_tiling_t *tiling)
+{
+  memset(tiling, 0, sizeof(*tiling));
+  tiling->maxbuf = tiling->maxbuf_cl = 1.0f;
+  tiling->xalign = tiling->yalign = 1;
+  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS)
+  {
+    const float scale = fminf(fminf((float)piece->roi_in.scale, 2.0f), 1.0f);
+    const int P = (int)ceilf(d->radius * scale), K = (int)ceilf(d->nbhood * scale);
+    const int K_scattered = (int)ceilf(d->scattering * (K * K * K + 7.0 * K * sqrt((double)K)) / 6.0) + K;
+    tiling->factor = 2.0f + 0.25f;
+    tiling->factor_cl = 3.0f;
+    tiling->overlap = (unsigned)(P + K_scattered);
+  }
+  else
+  {
+    dn_setup s;
+    setup(piece, d, s, false);
+    tiling->factor = 5.0f;
+    tiling->factor_cl = 5.0f + 1.0f / 64.0f;
+    tiling->overlap = 1u << s.max_scale;
+  }
+}
+
 } // extern "C"

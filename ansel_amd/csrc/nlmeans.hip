@@ -932,6 +932,19 @@ int dt_hip_iop_nlmeans_process(int devid, const dt_hip_piece_t *piece, const dt_
   return nlmeans_process_band(devid, piece, d, nullptr, dev_in, dev_out);
 }
 
+// tiling_callback(), src/iop/nlmeans.c:400-414 (factor: in + out + tmp + the per-thread column sums, NUM_BUCKETS 4);
+// on the device the sums live in LDS: in + out
+void dt_hip_iop_nlmeans_tiling(const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d, dt_hip_tiling_t *tiling)
+{
+  const float scale = (float)fmin(piece->roi_in.scale, 2.0f);
+  memset(tiling, 0, sizeof(*tiling));
+  tiling->factor = 2.0f + 1.0f + 0.25f * 4;
+  tiling->factor_cl = 2.0f;
+  tiling->maxbuf = tiling->maxbuf_cl = 1.0f;
+  tiling->overlap = (unsigned)((int)ceilf(d->radius * scale) + (int)ceilf(7 * scale));
+  tiling->xalign = tiling->yalign = 1;
+}
+
 } // extern "C"
 
 namespace ansel

@@ -710,6 +710,20 @@ int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_
   return err;
 }
 
+// default_tiling_callback(), src/develop/tiling.c:1423-1463, for the modules without a callback of their own
+// (rawprepare, temperature, highlights, exposure, colorin, channelmixerrgb, filmicrgb, colorout, finalscale)
+void dt_hip_default_tiling(const dt_hip_piece_t *piece, int before_demosaic, dt_hip_tiling_t *tiling)
+{
+  const float ioratio = ((float)piece->roi_out.width * (float)piece->roi_out.height)
+                        / ((float)piece->roi_in.width * (float)piece->roi_in.height);
+  tiling->factor = tiling->factor_cl = 1.0f + ioratio;
+  tiling->maxbuf = tiling->maxbuf_cl = 1.0f;
+  tiling->overhead = 0;
+  tiling->overlap = 0;
+  tiling->xalign = tiling->yalign = 1;
+  if(before_demosaic && piece->filters) tiling->xalign = tiling->yalign = piece->filters == 9u ? 3 : 2;
+}
+
 // Give up a band between dt_hip_pipe_band_begin() and the last dt_hip_pipe_band_finish(): frees what the state holds
 void dt_hip_pipe_band_abort(dt_hip_pipe_t *pipe, dt_hip_band_state_t *state)
 {

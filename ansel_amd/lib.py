@@ -82,6 +82,10 @@ def load():
         "dt_hip_alloc_host_pinned": (vp, [sz]),
         "dt_hip_free_host_pinned": (None, [vp]),
         "dt_hip_is_pinned_memory": (i, [vp]),
+        "dt_hip_default_tiling": (None, [P(abi.Piece), i, P(abi.Tiling)]),
+        "dt_hip_iop_denoiseprofile_tiling": (None, [P(abi.Piece), P(abi.DenoiseprofileData), P(abi.Tiling)]),
+        "dt_hip_iop_nlmeans_tiling": (None, [P(abi.Piece), P(abi.NlmeansData), P(abi.Tiling)]),
+        "dt_hip_iop_bilat_tiling": (None, [P(abi.Piece), P(abi.BilatData), P(abi.Tiling)]),
         "dt_hip_iop_diffuse_tiling": (None, [P(abi.Piece), P(abi.DiffuseData), P(abi.Tiling)]),
         "dt_hip_export_convert_u16": (i, [i, i, i, vp, vp]),
         "dt_hip_export_convert_u8": (i, [i, i, i, vp, vp]),

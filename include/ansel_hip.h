@@ -74,6 +74,12 @@ typedef struct dt_hip_tiling_t
   unsigned overlap;
   unsigned xalign, yalign;
 } dt_hip_tiling_t;
+/* The tiling callbacks below (dt_hip_iop_<op>_tiling) fill the struct like the module's tiling_callback()
+ * (iop_api.h:119-120): factor / maxbuf / overlap / alignment as the reference states them -- the host's own
+ * tiling and ROI planning keep working -- and factor_cl / maxbuf_cl with what THIS implementation holds on the
+ * device, which is what dt_hip_image_fits_device() is asked about.  Modules without a callback of their own take
+ * default_tiling_callback(), src/develop/tiling.c:1423-1463: */
+void dt_hip_default_tiling(const dt_hip_piece_t *piece, int before_demosaic, dt_hip_tiling_t *tiling);
 
 /* ---- 1. device runtime (peer of src/common/opencl.h) ------------------------------ */
 
@@ -351,6 +357,9 @@ typedef struct dt_hip_denoiseprofile_data_t
 int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece,
                                       const dt_hip_denoiseprofile_data_t *d, dt_hip_mem_t dev_in,
                                       dt_hip_mem_t dev_out);
+/* tiling_callback(), denoiseprofile.c:796-848 */
+void dt_hip_iop_denoiseprofile_tiling(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
+                                      dt_hip_tiling_t *tiling);
 
 /* denoise (non-local means): process() -> process_cpu(), src/iop/nlmeans.c:416-465, over
  * nlmeans_denoise(), src/pixel/nlmeans_core.c:315-532 (Lab input; patch radius P = ceil(radius * scale),
@@ -364,6 +373,8 @@ typedef struct dt_hip_nlmeans_data_t
 } dt_hip_nlmeans_data_t;
 int dt_hip_iop_nlmeans_process(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d,
                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+/* tiling_callback(), nlmeans.c:400-414 */
+void dt_hip_iop_nlmeans_tiling(const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d, dt_hip_tiling_t *tiling);
 
 /* RGB <-> Lab glue the pixelpipe runs around Lab modules (src/develop/pixelpipe_cpu.c:59-75 ->
  * dt_ioppr_transform_image_colorspace(), src/colorprofiles/iop_profile.c:540-596) for a linear matrix
@@ -399,6 +410,8 @@ typedef struct dt_hip_bilat_data_t
 } dt_hip_bilat_data_t;
 int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d,
                              dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+/* tiling_callback(), bilat.c:252-297 */
+void dt_hip_iop_bilat_tiling(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_tiling_t *tiling);
 
 /* finalscale: process(), src/iop/finalscale.c:117-131 -> dt_iop_clip_and_zoom_roi()
  * (src/develop/imageop_math.c:146-152) -> dt_interpolation_resample_roi(), src/pixel/interpolation.c:898-1062:
