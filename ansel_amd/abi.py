@@ -195,6 +195,11 @@ def set_vec(dst, vals):
         dst[i] = float(v)
 
 
+class ExportRowsData(C.Structure):
+    """dt_hip_export_rows_t: the scanline packing of the format writers (tiff.c:293-360)"""
+    _fields_ = [("bpp", C.c_int32), ("layers", C.c_int32)]
+
+
 class Band(C.Structure):
     """dt_hip_band_t: a row band of a frame split over several devices"""
     _fields_ = [("row0", C.c_int32), ("rows", C.c_int32), ("halo_top", C.c_int32), ("halo_bottom", C.c_int32),

@@ -43,6 +43,7 @@ enum op_t
   OP_FINALSCALE,
   OP_EXPORT_U16,
   OP_BLEND,
+  OP_EXPORT_ROWS,
   OP_UNKNOWN
 };
 
@@ -72,6 +73,7 @@ const op_info_t k_ops[] = {
   { "finalscale", sizeof(dt_hip_finalscale_data_t), 16 },
   { "export_u16", 0, 8 },
   { "blend", sizeof(dt_hip_blend_data_t), 0 },
+  { "export_rows", sizeof(dt_hip_export_rows_t), 0 },
 };
 
 struct node_t
@@ -100,6 +102,8 @@ size_t out_bytes(const node_t &n)
     case OP_HIGHLIGHTS:
     case OP_EXPOSURE: return px * 4 * n.piece.channels;
     case OP_EXPORT_U16: return px * 8;
+    case OP_EXPORT_ROWS:
+      return px * (size_t)n.as<dt_hip_export_rows_t>()->layers * (size_t)(n.as<dt_hip_export_rows_t>()->bpp / 8);
     default: return px * 16;
   }
 }
@@ -125,6 +129,9 @@ int run_single(int devid, const node_t &n, dt_hip_mem_t in, dt_hip_mem_t out)
     case OP_COLOROUT: return dt_hip_iop_colorout_process(devid, &n.piece, n.as<dt_hip_conversion_t>(), in, out);
     case OP_FINALSCALE: return dt_hip_iop_finalscale_process(devid, &n.piece, n.as<dt_hip_finalscale_data_t>(), in, out);
     case OP_EXPORT_U16: return dt_hip_export_convert_u16(devid, n.piece.roi_out.width, n.piece.roi_out.height, in, out);
+    case OP_EXPORT_ROWS:
+      return dt_hip_export_pack_rows(devid, n.piece.roi_out.width, n.piece.roi_out.height, n.as<dt_hip_export_rows_t>()->bpp,
+                                     n.as<dt_hip_export_rows_t>()->layers, in, out);
     default: return DT_HIP_INVALID_ARG;
   }
 }
@@ -216,8 +223,16 @@ struct dt_hip_pipe_t
         if(j < n && nodes[j].op == OP_EXPORT_U16 && nodes[j].piece.roi_out.width == r.width
            && nodes[j].piece.roi_out.height == r.height)
         {
-          r.to_u16 = true;
+          r.to_u16 = 1;
           j++;
+          // ... and straight into the scanlines of the format writer
+          if(j < n && nodes[j].op == OP_EXPORT_ROWS && nodes[j].as<dt_hip_export_rows_t>()->bpp == 16
+             && nodes[j].as<dt_hip_export_rows_t>()->layers == 3 && nodes[j].piece.roi_out.width == r.width
+             && nodes[j].piece.roi_out.height == r.height)
+          {
+            r.to_u16 = 2;
+            j++;
+          }
         }
         if(j - i > 1)
         {

@@ -33,7 +33,7 @@ struct rgb_group_t
   dt_hip_conversion_t colorin, colorout;
   dt_hip_channelmixerrgb_data_t channelmixer;
   dt_hip_filmicrgb_data_t filmic;
-  bool to_u16;
+  int to_u16; // 0: float4 out, 1: RGBA u16, 2: RGB u16 rows (export_u16 + export_rows)
 };
 int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 

@@ -269,7 +269,7 @@ int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hi
   hipStream_t s = stream_of(devid);
   const unsigned grid = pixel_grid(np); // one pixel per thread, see rgb_chain_kernel.h
   const float4 *in = (const float4 *)dev_in;
-  launch_scope ls(devid, g.to_u16 ? "rgb_chain_u16" : "rgb_chain");
+  launch_scope ls(devid, g.to_u16 == 2 ? "rgb_chain_rows16" : (g.to_u16 ? "rgb_chain_u16" : "rgb_chain"));
   int err;
   switch(fm)
   {

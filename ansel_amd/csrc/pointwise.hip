@@ -299,6 +299,25 @@ __device__ __forceinline__ float clampf(const float a, const float mn, const flo
   return a >= mn ? (a <= mx ? a : mx) : mn;
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void pack_rows(const T *__restrict__ in, T *__restrict__ out, const size_t npixels,
+                                                 const int layers)
+{
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < npixels; k += (size_t)gridDim.x * blockDim.x)
+  {
+    const t4 v = reinterpret_cast<const t4 *>(in)[k];
+    if(layers == 3)
+    {
+      out[3 * k] = v.x;
+      out[3 * k + 1] = v.y;
+      out[3 * k + 2] = v.z;
+    }
+    else
+      out[k] = v.x;
+  }
+}
+
 __global__ __launch_bounds__(256) void export_u16(const float4 *__restrict__ in, ushort4 *__restrict__ out,
                                                    const size_t npixels)
 {
@@ -532,6 +551,28 @@ int dt_hip_iop_exposure_process(int devid, const dt_hip_piece_t *piece, const dt
                                                          d->scale);
   if(n % 4) exposure_tail<<<1, 64, 0, s>>>((const float *)dev_in, (float *)dev_out, nvec * 4, n, d->black, d->scale);
   return check_launch("exposure");
+}
+
+// the row loop of the format writers: `layers` of the 4 samples of every pixel, packed
+// (src/imageio/format/tiff.c:293-360 for 32 / 16 / 8 bits per sample; png.c and jpeg.c hand RGB rows to their
+// libraries the same way)
+int dt_hip_export_pack_rows(int devid, int width, int height, int bpp, int layers, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !dev_in || !dev_out || (layers != 3 && layers != 1)) return DT_HIP_INVALID_ARG;
+  const size_t np = (size_t)width * height;
+  if(width <= 0 || height <= 0) return DT_HIP_SUCCESS;
+  launch_scope ls(devid, "export_rows");
+  hipStream_t s = stream_of(devid);
+  const unsigned grid = stream_grid(np, 256);
+  if(bpp == 32)
+    pack_rows<float><<<grid, 256, 0, s>>>((const float *)dev_in, (float *)dev_out, np, layers);
+  else if(bpp == 16)
+    pack_rows<unsigned short><<<grid, 256, 0, s>>>((const unsigned short *)dev_in, (unsigned short *)dev_out, np, layers);
+  else if(bpp == 8)
+    pack_rows<unsigned char><<<grid, 256, 0, s>>>((const unsigned char *)dev_in, (unsigned char *)dev_out, np, layers);
+  else
+    return DT_HIP_INVALID_ARG;
+  return check_launch("export_rows");
 }
 
 int dt_hip_export_convert_u16(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)

@@ -60,10 +60,19 @@ __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, 
                           (unsigned short)(int)(y > 65535.f ? 65535.f : (y < 0.f ? 0.f : y)),
                           (unsigned short)(int)(z > 65535.f ? 65535.f : (z < 0.f ? 0.f : z)),
                           (unsigned short)(int)(w > 65535.f ? 65535.f : (w < 0.f ? 0.f : w)) };
-      // streaming store: written once, read by nobody on the device (PMC: 1.14 GB of write requests per
-      // 0.81 GB written, against 1.58 GB with a cached store; pairing lanes into 16-byte stores changed
-      // nothing and cost 3 %)
-      __builtin_nontemporal_store(ov, reinterpret_cast<v4us_t *>(out) + k);
+      if(a.to_u16 == 2)
+      {
+        // the scanline a format writer hands to its library: 3 samples per pixel (tiff.c:322-339)
+        unsigned short *const o = reinterpret_cast<unsigned short *>(out) + 3 * k;
+        __builtin_nontemporal_store(ov.x, o);
+        __builtin_nontemporal_store(ov.y, o + 1);
+        __builtin_nontemporal_store(ov.z, o + 2);
+      }
+      else
+        // streaming store: written once, read by nobody on the device (PMC: 1.14 GB of write requests per
+        // 0.81 GB written, against 1.58 GB with a cached store; pairing lanes into 16-byte stores changed
+        // nothing and cost 3 %)
+        __builtin_nontemporal_store(ov, reinterpret_cast<v4us_t *>(out) + k);
     }
     else
       nt_store(reinterpret_cast<float4 *>(out) + k, v);

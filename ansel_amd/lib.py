@@ -25,6 +25,13 @@ def load():
         raise AnselHipError(
             "%s not found: build it with `python -m ansel_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own HIP runtime; a process that uses both (bench.py, the row-band driver) must have
+    # torch's loaded first, or torch.cuda finds no device afterwards.  C callers never get here.
+    if os.environ.get("ANSEL_HIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     vp, i, u, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
     P = C.POINTER
@@ -89,6 +96,7 @@ def load():
         "dt_hip_iop_diffuse_tiling": (None, [P(abi.Piece), P(abi.DiffuseData), P(abi.Tiling)]),
         "dt_hip_export_convert_u16": (i, [i, i, i, vp, vp]),
         "dt_hip_export_convert_u8": (i, [i, i, i, vp, vp]),
+        "dt_hip_export_pack_rows": (i, [i, i, i, i, i, vp, vp]),
         "dt_hip_pipe_new": (vp, [i]),
         "dt_hip_pipe_free": (None, [vp]),
         "dt_hip_pipe_add_node": (i, [vp, C.c_char_p, P(abi.Piece), vp, sz]),

@@ -300,6 +300,16 @@ int dt_hip_iop_filmicrgb_process(int devid, const dt_hip_piece_t *piece, const d
  * src/imageio/imageio_core.c:706-737 (RGBA f32 -> RGBA u16 / u8) */
 int dt_hip_export_convert_u16(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 int dt_hip_export_convert_u8(int devid, int width, int height, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+/* The row loop of the format writers (src/imageio/format/tiff.c:293-360; png.c / jpeg.c likewise): `layers`
+ * (3, or 1 for tiff's grayscale "shortfile" mode) of the 4 samples of every pixel, packed -- the bytes of the
+ * scanlines, so the download carries 3/4 of the frame.  bpp = bits per sample of dev_in: 32, 16 or 8.
+ * In a pipe: node "export_rows" (data dt_hip_export_rows_t) after "export_u16"; fused into the RGBA chain. */
+typedef struct dt_hip_export_rows_t
+{
+  int32_t bpp, layers;
+} dt_hip_export_rows_t;
+int dt_hip_export_pack_rows(int devid, int width, int height, int bpp, int layers, dt_hip_mem_t dev_in,
+                            dt_hip_mem_t dev_out);
 
 /* diffuse or sharpen: process(), src/iop/diffuse.c:1155-1258 -> wavelets_process() (:978-1106),
  * decompose_2D_Bspline() (src/pixel/bspline.h:351-377), heat_PDE_diffusion() (diffuse.c:760-968).
