@@ -37,7 +37,7 @@ struct device_t
   std::string name;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  std::mutex lock; // device exclusivity, == dt_opencl_lock_device
+  std::mutex lock; // device exclusivity: dt_opencl_reserve_device_for_pipe() / _release_device()
   bool events_enabled = false;
   std::vector<event_rec> events;
   std::vector<hipEvent_t> event_pool;
@@ -49,6 +49,8 @@ struct alloc_t
 {
   size_t size;
   int devid;
+  int width, height, bpp; // dt_hip_alloc_device() geometry (0 for plain buffers)
+  void *host;             // dt_hip_alloc_device_use_host_pointer(): the pinned host memory this aliases, not pooled
 };
 
 std::mutex g_mutex; // protects g_allocs, pools, counters
@@ -196,7 +198,9 @@ size_t dt_hip_get_device_memalloc(int devid)
   return dt_hip_get_device_available(devid);
 }
 
-int dt_hip_lock_device(int pipetype)
+// dt_opencl_reserve_device_for_pipe(), opencl.c:1642-1725: the first free device (one priority list: every device is
+// an MI355X), -1 when all are busy.  Reserving a device and locking it are the same act.
+int dt_hip_reserve_device_for_pipe(int pipetype)
 {
   (void)pipetype;
   if(!g_inited) return -1;
@@ -205,23 +209,98 @@ int dt_hip_lock_device(int pipetype)
   return -1;
 }
 
-int dt_hip_lock_device_by_id(int devid)
+// dt_opencl_reserve_device_by_id(), opencl.c:1737-1747: blocks until the device is free; out-of-range ids are ignored
+void dt_hip_reserve_device_by_id(int devid)
 {
-  if(!valid_device(devid)) return -1;
-  g_devs[devid]->lock.lock();
-  return devid;
+  if(valid_device(devid)) g_devs[devid]->lock.lock();
 }
 
-void dt_hip_unlock_device(int devid)
+// dt_opencl_try_reserve_device_by_id(), opencl.c:1749-1755: 0 when reserved (pthread convention), never waits
+int dt_hip_try_reserve_device_by_id(int devid)
+{
+  if(!valid_device(devid)) return 1;
+  return g_devs[devid]->lock.try_lock() ? 0 : 1;
+}
+
+// dt_opencl_release_device(), opencl.c:1727-1735
+void dt_hip_release_device(int devid)
 {
   if(valid_device(devid)) g_devs[devid]->lock.unlock();
 }
+
+// dt_opencl_get_device_max_image_size(), opencl.c:1772-1780.  Images are linear allocations here: what bounds a
+// side is the 32-bit pixel coordinates of the kernels, not a texture unit
+int dt_hip_get_device_max_image_size(int devid, int *width, int *height)
+{
+  if(!valid_device(devid)) return 0;
+  if(width) *width = 1 << 20;
+  if(height) *height = 1 << 20;
+  return 1;
+}
+
+size_t dt_hip_get_device_max_global_mem(int devid)
+{
+  if(!valid_device(devid)) return 0;
+  size_t free_b = 0, total_b = 0;
+  (void)hipSetDevice(g_devs[devid]->hip_id);
+  if(hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  return total_b;
+}
+
+// dt_opencl_report_pipe_error(), opencl.c:1790-1802: 1 = this run failed, retry elsewhere; 2 = too many failures
+// (DT_OPENCL_MAX_ERRORS 5, opencl.h:50), the device path is off for the session (dt_hip_is_enabled() -> 0)
+static int g_error_count = 0;
+static bool g_stopped = false;
+int dt_hip_report_pipe_error(void)
+{
+  if(!g_inited) return 2;
+  std::lock_guard<std::mutex> g(g_mutex);
+  g_error_count++;
+  if(g_error_count < 5) return 1;
+  g_stopped = true;
+  return 2;
+}
+
+// dt_opencl_is_enabled() / update_settings(), opencl.h:464-470
+int dt_hip_is_enabled(void) { return (g_inited && !g_stopped) ? 1 : 0; }
+int dt_hip_update_settings(void) { return dt_hip_is_enabled(); }
+
+// per-device tuning knobs the host asks about (opencl.h:584-591, 648-651): nothing to tune on this part --
+// no atomics workaround, no nap between launches, pinned transfers always
+void dt_hip_check_tuning(int devid) { (void)devid; }
+int dt_hip_avoid_atomics(int devid) { (void)devid; return 0; }
+int dt_hip_micro_nap(int devid) { (void)devid; return 0; }
+int dt_hip_use_pinned_memory(int devid) { return valid_device(devid) ? 1 : 0; }
+// dt_opencl_dev_roundup_width / _height, opencl.c:2973-2982: launch sizes are the library's own business, so the
+// granularity a host would round to is one wavefront
+int dt_hip_dev_roundup_width(int size, int devid) { (void)devid; return size % 64 == 0 ? size : (size / 64 + 1) * 64; }
+int dt_hip_dev_roundup_height(int size, int devid) { (void)devid; return size; }
 
 int dt_hip_image_fits_device(int devid, size_t width, size_t height, unsigned bpp, float factor, size_t overhead)
 {
   if(!valid_device(devid)) return 0;
   const double need = (double)width * (double)height * (double)bpp * (double)factor + (double)overhead;
   return need <= (double)dt_hip_get_device_available(devid) ? 1 : 0;
+}
+
+// dt_opencl_image_fits_device_reason(), opencl.h:577: 0 = fits, 1 = one buffer exceeds the largest allocation,
+// 2 = the total exceeds the free memory; *needed / *limit report the pair that decided
+int dt_hip_image_fits_device_reason(int devid, size_t width, size_t height, unsigned bpp, float factor, size_t overhead,
+                                    size_t *needed, size_t *limit)
+{
+  if(!valid_device(devid)) return 2;
+  const double single = (double)width * (double)height * (double)bpp;
+  const double total = single * (double)factor + (double)overhead;
+  const size_t avail = dt_hip_get_device_available(devid), memalloc = dt_hip_get_device_memalloc(devid);
+  if(single > (double)memalloc)
+  {
+    if(needed) *needed = (size_t)single;
+    if(limit) *limit = memalloc;
+    return 1;
+  }
+  if(needed) *needed = (size_t)total;
+  if(limit) *limit = avail;
+  return total <= (double)avail ? 0 : 2;
 }
 
 void *dt_hip_get_stream(int devid) { return (void *)stream_of(devid); }
@@ -273,7 +352,7 @@ dt_hip_mem_t dt_hip_alloc_device_buffer(int devid, size_t size)
       return nullptr;
     }
   }
-  g_allocs[p] = { rounded, devid };
+  g_allocs[p] = { rounded, devid, 0, 0, 0, nullptr };
   d->cur_bytes += rounded;
   if(d->cur_bytes > d->peak_bytes) d->peak_bytes = d->cur_bytes;
   return p;
@@ -282,7 +361,16 @@ dt_hip_mem_t dt_hip_alloc_device_buffer(int devid, size_t size)
 dt_hip_mem_t dt_hip_alloc_device(int devid, int width, int height, int bpp)
 {
   if(width <= 0 || height <= 0 || bpp <= 0) return nullptr;
-  return dt_hip_alloc_device_buffer(devid, (size_t)width * (size_t)height * (size_t)bpp);
+  dt_hip_mem_t p = dt_hip_alloc_device_buffer(devid, (size_t)width * (size_t)height * (size_t)bpp);
+  if(p)
+  {
+    std::lock_guard<std::mutex> g(g_mutex);
+    alloc_t &a = g_allocs[p];
+    a.width = width;
+    a.height = height;
+    a.bpp = bpp;
+  }
+  return p;
 }
 
 void dt_hip_release_mem_object(dt_hip_mem_t mem)
@@ -293,6 +381,7 @@ void dt_hip_release_mem_object(dt_hip_mem_t mem)
   if(it == g_allocs.end()) return; // not ours (e.g. a torch tensor): nothing to do
   const alloc_t a = it->second;
   g_allocs.erase(it);
+  if(a.host) return; // an alias of pinned host memory: the host buffer stays with its owner
   if(a.devid >= 0 && a.devid < (int)g_devs.size())
   {
     device_t *d = g_devs[a.devid];
@@ -311,6 +400,117 @@ size_t dt_hip_get_mem_object_size(dt_hip_mem_t mem)
   return it == g_allocs.end() ? 0 : it->second.size;
 }
 
+// dt_opencl_get_image_width / _height / _element_size, opencl.h:554-558
+static alloc_t alloc_of(dt_hip_mem_t mem)
+{
+  std::lock_guard<std::mutex> g(g_mutex);
+  auto it = g_allocs.find(mem);
+  return it == g_allocs.end() ? alloc_t{ 0, -1, 0, 0, 0, nullptr } : it->second;
+}
+int dt_hip_get_image_width(dt_hip_mem_t mem) { return alloc_of(mem).width; }
+int dt_hip_get_image_height(dt_hip_mem_t mem) { return alloc_of(mem).height; }
+int dt_hip_get_image_element_size(dt_hip_mem_t mem) { return alloc_of(mem).bpp; }
+int dt_hip_get_mem_context_id(dt_hip_mem_t mem) { return alloc_of(mem).devid; }
+
+// dt_opencl_alloc_device_use_host_pointer(), opencl.h:521: a device view of page-locked host memory (zero copy);
+// NULL unless `host` is pinned (dt_hip_alloc_host_pinned), in which case the caller takes the copying path
+dt_hip_mem_t dt_hip_alloc_device_use_host_pointer(int devid, int width, int height, int bpp, void *host, int flags)
+{
+  (void)flags;
+  if(!valid_device(devid) || !host || width <= 0 || height <= 0 || bpp <= 0 || !dt_hip_is_pinned_memory(host)) return nullptr;
+  void *dev = nullptr;
+  (void)hipSetDevice(g_devs[devid]->hip_id);
+  if(hipHostGetDevicePointer(&dev, host, 0) != hipSuccess || !dev)
+  {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> g(g_mutex);
+  g_allocs[dev] = { (size_t)width * height * bpp, devid, width, height, bpp, host };
+  return dev;
+}
+
+// dt_opencl_map_image / map_buffer / unmap_mem_object, opencl.h:545-550 (pixelpipe_cache.c maps pinned cache lines):
+// an object made by dt_hip_alloc_device_use_host_pointer() maps to its host memory once the stream has drained;
+// device-only memory has no host mapping (NULL: the caller copies)
+void *dt_hip_map_buffer(int devid, dt_hip_mem_t buffer, int blocking, int flags, size_t offset, size_t size)
+{
+  (void)flags;
+  (void)size;
+  const alloc_t a = alloc_of(buffer);
+  if(!a.host || !valid_device(devid)) return nullptr;
+  if(blocking && hipStreamSynchronize(stream_of(devid)) != hipSuccess) return nullptr;
+  return (char *)a.host + offset;
+}
+void *dt_hip_map_image(int devid, dt_hip_mem_t buffer, int blocking, int flags, size_t width, size_t height, int bpp)
+{
+  (void)width;
+  (void)height;
+  (void)bpp;
+  return dt_hip_map_buffer(devid, buffer, blocking, flags, 0, 0);
+}
+int dt_hip_unmap_mem_object(int devid, dt_hip_mem_t mem, void *mapped_ptr)
+{
+  (void)mapped_ptr;
+  return (valid_device(devid) && alloc_of(mem).host) ? DT_HIP_SUCCESS : DT_HIP_INVALID_ARG;
+}
+
+// dt_opencl_copy_host_to_device[_rowpitch|_constant], opencl.h:508-514: allocate + upload, NULL on failure
+dt_hip_mem_t dt_hip_copy_host_to_device_rowpitch(int devid, void *host, int width, int height, int bpp, int rowpitch)
+{
+  dt_hip_mem_t d = dt_hip_alloc_device(devid, width, height, bpp);
+  if(!d) return nullptr;
+  if(dt_hip_write_host_to_device_rowpitch(devid, host, d, width, height, bpp, (size_t)rowpitch, 1) != DT_HIP_SUCCESS)
+  {
+    dt_hip_release_mem_object(d);
+    return nullptr;
+  }
+  return d;
+}
+dt_hip_mem_t dt_hip_copy_host_to_device(int devid, void *host, int width, int height, int bpp)
+{
+  return dt_hip_copy_host_to_device_rowpitch(devid, host, width, height, bpp, 0);
+}
+dt_hip_mem_t dt_hip_copy_host_to_device_constant(int devid, size_t size, void *host)
+{
+  dt_hip_mem_t d = dt_hip_alloc_device_buffer(devid, size);
+  if(!d) return nullptr;
+  if(dt_hip_write_buffer_to_device(devid, host, d, 0, size, 1) != DT_HIP_SUCCESS)
+  {
+    dt_hip_release_mem_object(d);
+    return nullptr;
+  }
+  return d;
+}
+int dt_hip_copy_device_to_host(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp)
+{
+  return dt_hip_read_host_from_device(devid, host, device, width, height, bpp);
+}
+
+// dt_opencl_read_buffer_from_device / write_buffer_to_device, opencl.h:533-537
+int dt_hip_read_buffer_from_device(int devid, void *host, dt_hip_mem_t device, size_t offset, size_t size, int blocking)
+{
+  if(!valid_device(devid) || !host || !device) return DT_HIP_INVALID_ARG;
+  if(!size) return DT_HIP_SUCCESS;
+  hipStream_t s = stream_of(devid);
+  ANSEL_HIP_CHECK(hipMemcpyAsync(host, (const char *)device + offset, size, hipMemcpyDeviceToHost, s));
+  if(blocking) ANSEL_HIP_CHECK(hipStreamSynchronize(s));
+  return DT_HIP_SUCCESS;
+}
+int dt_hip_write_buffer_to_device(int devid, const void *host, dt_hip_mem_t device, size_t offset, size_t size, int blocking)
+{
+  if(!valid_device(devid) || !host || !device) return DT_HIP_INVALID_ARG;
+  if(!size) return DT_HIP_SUCCESS;
+  hipStream_t s = stream_of(devid);
+  ANSEL_HIP_CHECK(hipMemcpyAsync((char *)device + offset, host, size, hipMemcpyHostToDevice, s));
+  // a pageable source is staged before hipMemcpyAsync returns, a pinned one is read when the copy runs
+  if(blocking || dt_hip_is_pinned_memory(host)) ANSEL_HIP_CHECK(hipStreamSynchronize(s));
+  return DT_HIP_SUCCESS;
+}
+
+// dt_opencl_enqueue_barrier(), opencl.h:346: the device's stream is in order, every launch is already a barrier
+int dt_hip_enqueue_barrier(int devid) { return valid_device(devid) ? DT_HIP_SUCCESS : DT_HIP_INVALID_ARG; }
+
 void dt_hip_memory_statistics(int devid, size_t *current, size_t *peak)
 {
   if(current) *current = valid_device(devid) ? g_devs[devid]->cur_bytes : 0;
@@ -324,7 +524,7 @@ int dt_hip_write_host_to_device_rowpitch(int devid, const void *host, dt_hip_mem
   hipStream_t s = stream_of(devid);
   const size_t wbytes = (size_t)width * bpp;
   launch_scope ls(devid, "[Write Image (from host to device)]");
-  if(rowpitch == wbytes)
+  if(rowpitch == wbytes || rowpitch == 0) // 0 = tightly packed, the OpenCL convention
     ANSEL_HIP_CHECK(hipMemcpyAsync(device, host, wbytes * height, hipMemcpyHostToDevice, s));
   else
     ANSEL_HIP_CHECK(hipMemcpy2DAsync(device, wbytes, host, rowpitch, wbytes, height, hipMemcpyHostToDevice, s));
@@ -344,7 +544,7 @@ int dt_hip_read_host_from_device_rowpitch(int devid, void *host, dt_hip_mem_t de
   hipStream_t s = stream_of(devid);
   const size_t wbytes = (size_t)width * bpp;
   launch_scope ls(devid, "[Read Image (from device to host)]");
-  if(rowpitch == wbytes)
+  if(rowpitch == wbytes || rowpitch == 0) // 0 = tightly packed, the OpenCL convention
     ANSEL_HIP_CHECK(hipMemcpyAsync(host, device, wbytes * height, hipMemcpyDeviceToHost, s));
   else
     ANSEL_HIP_CHECK(hipMemcpy2DAsync(host, rowpitch, device, wbytes, wbytes, height, hipMemcpyDeviceToHost, s));
@@ -456,6 +656,26 @@ void dt_hip_events_reset(int devid)
     d->event_pool.push_back(e.stop);
   }
   d->events.clear();
+}
+
+// dt_opencl_events_wait_for() / events_flush(), opencl.h:601-605: the tagged launches live on one in-order stream,
+// so waiting for them is draining it; flush reports the stream's status and optionally drops the records
+void dt_hip_events_wait_for(int devid)
+{
+  if(valid_device(devid)) (void)hipStreamSynchronize(g_devs[devid]->stream);
+}
+
+int dt_hip_events_flush(int devid, int reset)
+{
+  if(!valid_device(devid)) return DT_HIP_INVALID_ARG;
+  const hipError_t e = hipStreamSynchronize(g_devs[devid]->stream);
+  if(reset) dt_hip_events_reset(devid);
+  if(e != hipSuccess)
+  {
+    set_last_error("dt_hip_events_flush: %s", hipGetErrorString(e));
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  return DT_HIP_SUCCESS;
 }
 
 int dt_hip_events_profiling(int devid, const char **tags, float *ms, int *counts, int max)

@@ -43,9 +43,39 @@ def load():
         "dt_hip_get_device_name": (C.c_char_p, [i]),
         "dt_hip_get_device_available": (sz, [i]),
         "dt_hip_get_device_memalloc": (sz, [i]),
-        "dt_hip_lock_device": (i, [i]),
-        "dt_hip_lock_device_by_id": (i, [i]),
-        "dt_hip_unlock_device": (None, [i]),
+        "dt_hip_reserve_device_for_pipe": (i, [i]),
+        "dt_hip_reserve_device_by_id": (None, [i]),
+        "dt_hip_try_reserve_device_by_id": (i, [i]),
+        "dt_hip_release_device": (None, [i]),
+        "dt_hip_get_device_max_image_size": (i, [i, P(i), P(i)]),
+        "dt_hip_get_device_max_global_mem": (sz, [i]),
+        "dt_hip_report_pipe_error": (i, []),
+        "dt_hip_is_enabled": (i, []),
+        "dt_hip_update_settings": (i, []),
+        "dt_hip_check_tuning": (None, [i]),
+        "dt_hip_avoid_atomics": (i, [i]),
+        "dt_hip_micro_nap": (i, [i]),
+        "dt_hip_use_pinned_memory": (i, [i]),
+        "dt_hip_dev_roundup_width": (i, [i, i]),
+        "dt_hip_dev_roundup_height": (i, [i, i]),
+        "dt_hip_image_fits_device_reason": (i, [i, sz, sz, C.c_uint, C.c_float, sz, P(sz), P(sz)]),
+        "dt_hip_get_image_width": (i, [vp]),
+        "dt_hip_get_image_height": (i, [vp]),
+        "dt_hip_get_image_element_size": (i, [vp]),
+        "dt_hip_get_mem_context_id": (i, [vp]),
+        "dt_hip_alloc_device_use_host_pointer": (vp, [i, i, i, i, vp, i]),
+        "dt_hip_map_buffer": (vp, [i, vp, i, i, sz, sz]),
+        "dt_hip_map_image": (vp, [i, vp, i, i, sz, sz, i]),
+        "dt_hip_unmap_mem_object": (i, [i, vp, vp]),
+        "dt_hip_copy_host_to_device": (vp, [i, vp, i, i, i]),
+        "dt_hip_copy_host_to_device_rowpitch": (vp, [i, vp, i, i, i, i]),
+        "dt_hip_copy_host_to_device_constant": (vp, [i, sz, vp]),
+        "dt_hip_copy_device_to_host": (i, [i, vp, vp, i, i, i]),
+        "dt_hip_read_buffer_from_device": (i, [i, vp, vp, sz, sz, i]),
+        "dt_hip_write_buffer_to_device": (i, [i, vp, vp, sz, sz, i]),
+        "dt_hip_enqueue_barrier": (i, [i]),
+        "dt_hip_events_wait_for": (None, [i]),
+        "dt_hip_events_flush": (i, [i, i]),
         "dt_hip_image_fits_device": (i, [i, sz, sz, C.c_uint, C.c_float, sz]),
         "dt_hip_get_stream": (vp, [i]),
         "dt_hip_set_stream": (i, [i, vp]),

@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     fprintf(stderr, "dt_hip_init: %s\n", dt_hip_last_error());
     return 2; /* no GPU: there is no CPU fallback */
   }
-  const int dev = dt_hip_lock_device(0);
+  const int dev = dt_hip_reserve_device_for_pipe(0);
   if(dev < 0) return 2;
 
   /* the "sensor buffer": 14-bit values from a 64-bit LCG, in pinned host memory */
@@ -114,7 +114,7 @@ int main(int argc, char **argv)
   dt_hip_release_mem_object(dev_out);
   dt_hip_free_host_pinned(raw);
   dt_hip_free_host_pinned(out);
-  dt_hip_unlock_device(dev);
+  dt_hip_release_device(dev);
   dt_hip_cleanup();
   return 0;
 }

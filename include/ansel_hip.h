@@ -91,13 +91,35 @@ int dt_hip_get_num_devices(void);                            /* opencl.h:364 */
 const char *dt_hip_get_device_name(int devid);
 size_t dt_hip_get_device_available(int devid);               /* free HBM bytes; opencl.h:405 */
 size_t dt_hip_get_device_memalloc(int devid);                /* largest single allocation */
-/* device exclusivity: dt_opencl_lock_device/unlock_device (opencl.c:1642-1755).
- * lock returns a devid >= 0 or -1; pipetype is ignored (one priority list). */
-int dt_hip_lock_device(int pipetype);
-int dt_hip_lock_device_by_id(int devid);
-void dt_hip_unlock_device(int devid);
+/* device exclusivity: dt_opencl_reserve_device_for_pipe / reserve_device_by_id / try_reserve_device_by_id /
+ * release_device (opencl.h:351-419, opencl.c:1642-1755).  There is one lock per device; reserving a device and
+ * locking it are the same act.  _for_pipe returns the device id or -1 when every device is busy; _by_id blocks;
+ * try_ returns 0 when the device was reserved (pthread convention) and never waits. */
+int dt_hip_reserve_device_for_pipe(int pipetype);
+void dt_hip_reserve_device_by_id(int devid);
+int dt_hip_try_reserve_device_by_id(int devid);
+void dt_hip_release_device(int devid);
+/* dt_opencl_get_device_max_image_size / _max_global_mem (opencl.h:399-402): TRUE when written */
+int dt_hip_get_device_max_image_size(int devid, int *width, int *height);
+size_t dt_hip_get_device_max_global_mem(int devid);
+/* dt_opencl_report_pipe_error (opencl.h:415): 1 = this run failed, retry; 2 = fifth failure, the device path is
+ * off for the session and dt_hip_is_enabled() turns 0.  dt_opencl_is_enabled / update_settings (:464-470) */
+int dt_hip_report_pipe_error(void);
+int dt_hip_is_enabled(void);
+int dt_hip_update_settings(void);
+/* per-device knobs the host queries (opencl.h:584-591, 648-650); constants on this part */
+void dt_hip_check_tuning(int devid);
+int dt_hip_avoid_atomics(int devid);
+int dt_hip_micro_nap(int devid);
+int dt_hip_use_pinned_memory(int devid);
+int dt_hip_dev_roundup_width(int size, int devid);
+int dt_hip_dev_roundup_height(int size, int devid);
 /* dt_opencl_image_fits_device (opencl.h:571): would factor * w*h*bpp + overhead fit? */
 int dt_hip_image_fits_device(int devid, size_t width, size_t height, unsigned bpp, float factor, size_t overhead);
+/* dt_opencl_image_fits_device_reason (opencl.h:577): 0 fits, 1 one buffer exceeds the largest allocation, 2 the
+ * total exceeds free memory; *needed / *limit (may be NULL) report the pair that decided */
+int dt_hip_image_fits_device_reason(int devid, size_t width, size_t height, unsigned bpp, float factor, size_t overhead,
+                                    size_t *needed, size_t *limit);
 
 /* stream each device's work is enqueued on.  By default the runtime creates one
  * non-blocking stream per device; a host that already owns a stream (e.g. the one a
@@ -111,6 +133,20 @@ dt_hip_mem_t dt_hip_alloc_device_buffer(int devid, size_t size);
 void dt_hip_release_mem_object(dt_hip_mem_t mem);
 size_t dt_hip_get_mem_object_size(dt_hip_mem_t mem);
 void dt_hip_memory_statistics(int devid, size_t *current, size_t *peak); /* opencl.h:648 */
+/* dt_opencl_get_image_width / _height / _element_size / get_mem_context_id (opencl.h:554-560): the geometry
+ * dt_hip_alloc_device() was called with (0 for plain buffers); the device an object lives on (-1: not ours) */
+int dt_hip_get_image_width(dt_hip_mem_t mem);
+int dt_hip_get_image_height(dt_hip_mem_t mem);
+int dt_hip_get_image_element_size(dt_hip_mem_t mem);
+int dt_hip_get_mem_context_id(dt_hip_mem_t mem);
+/* dt_opencl_alloc_device_use_host_pointer (opencl.h:521): a device view of page-locked host memory (zero copy);
+ * NULL unless `host` came from dt_hip_alloc_host_pinned().  dt_opencl_map_buffer / map_image / unmap_mem_object
+ * (:545-550, used by pixelpipe_cache.c for pinned cache lines): such an object maps to its host memory (after
+ * draining the stream when `blocking`); device-only memory has no host mapping and returns NULL. */
+dt_hip_mem_t dt_hip_alloc_device_use_host_pointer(int devid, int width, int height, int bpp, void *host, int flags);
+void *dt_hip_map_buffer(int devid, dt_hip_mem_t buffer, int blocking, int flags, size_t offset, size_t size);
+void *dt_hip_map_image(int devid, dt_hip_mem_t buffer, int blocking, int flags, size_t width, size_t height, int bpp);
+int dt_hip_unmap_mem_object(int devid, dt_hip_mem_t mem, void *mapped_ptr);
 /* page-locked host memory for the two ends of an export (the sensor buffer going up, the exported frame
  * coming down): the peer of the reference's pinned transfer buffers (dt_opencl_use_pinned_memory(),
  * CL_MEM_ALLOC_HOST_PTR in dt_opencl_alloc_device_use_host_pointer(), opencl.h:541-561, 650-651).
@@ -125,6 +161,14 @@ int dt_hip_write_host_to_device(int devid, const void *host, dt_hip_mem_t device
 int dt_hip_write_host_to_device_rowpitch(int devid, const void *host, dt_hip_mem_t device, int width, int height, int bpp, size_t rowpitch, int blocking);
 int dt_hip_read_host_from_device(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp);
 int dt_hip_read_host_from_device_rowpitch(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp, size_t rowpitch, int blocking);
+/* dt_opencl_copy_host_to_device[_rowpitch|_constant] (opencl.h:508-514): allocate + upload, NULL on failure;
+ * dt_opencl_copy_device_to_host (:473); dt_opencl_read_buffer_from_device / write_buffer_to_device (:533-537) */
+dt_hip_mem_t dt_hip_copy_host_to_device(int devid, void *host, int width, int height, int bpp);
+dt_hip_mem_t dt_hip_copy_host_to_device_rowpitch(int devid, void *host, int width, int height, int bpp, int rowpitch);
+dt_hip_mem_t dt_hip_copy_host_to_device_constant(int devid, size_t size, void *host);
+int dt_hip_copy_device_to_host(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp);
+int dt_hip_read_buffer_from_device(int devid, void *host, dt_hip_mem_t device, size_t offset, size_t size, int blocking);
+int dt_hip_write_buffer_to_device(int devid, const void *host, dt_hip_mem_t device, size_t offset, size_t size, int blocking);
 int dt_hip_enqueue_copy_buffer_to_buffer(int devid, dt_hip_mem_t src, dt_hip_mem_t dst, size_t srcoffset, size_t dstoffset, size_t size);
 /* copy a w x h window of `bpp`-byte pixels between two linear images (used by tiling and
  * by the row-band halo exchange) */
@@ -133,6 +177,11 @@ int dt_hip_enqueue_copy_region(int devid, dt_hip_mem_t src, int src_width, int s
 
 /* sync + profiling: dt_opencl_finish (TRUE on success), events_* (opencl.h:343-346,594-608) */
 int dt_hip_finish(int devid);
+/* dt_opencl_enqueue_barrier (opencl.h:346): the stream is in order, so this only validates devid */
+int dt_hip_enqueue_barrier(int devid);
+/* dt_opencl_events_wait_for / events_flush (opencl.h:601-605) */
+void dt_hip_events_wait_for(int devid);
+int dt_hip_events_flush(int devid, int reset);
 void dt_hip_events_enable(int devid, int enable);
 void dt_hip_events_reset(int devid);
 /* wait for all tagged launches, aggregate per tag; returns number of distinct tags.
