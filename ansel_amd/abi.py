@@ -195,6 +195,12 @@ def set_vec(dst, vals):
         dst[i] = float(v)
 
 
+class TilePlan(C.Structure):
+    """dt_hip_tile_plan_t: the tile plan of _default_process_tiling_cl_ptp() (src/develop/tiling.c:868-979)"""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("tile_wd", C.c_int32), ("tile_ht", C.c_int32),
+                ("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("overlap", C.c_int32)]
+
+
 class ExportRowsData(C.Structure):
     """dt_hip_export_rows_t: the scanline packing of the format writers (tiff.c:293-360)"""
     _fields_ = [("bpp", C.c_int32), ("layers", C.c_int32)]

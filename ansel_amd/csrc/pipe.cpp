@@ -9,6 +9,7 @@
 #include "hip_common.h"
 #include "pipe_fused.h"
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -723,6 +724,174 @@ int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_
     state->clipped_count = nullptr;
   }
   return err;
+}
+
+// ---- default_process_tiling_cl() for roi_in == roi_out, src/develop/tiling.c:842-1067 ----------------------------
+// the tile plan of _default_process_tiling_cl_ptp(), :868-979, as a pure function of the frame, the module's
+// requirements and the device's limits
+int dt_hip_plan_tiles_ptp(int roi_width, int roi_height, int in_bpp, int out_bpp, const dt_hip_tiling_t *tiling,
+                          unsigned filters, size_t available_bytes, size_t memalloc_bytes, int max_width, int max_height,
+                          dt_hip_tile_plan_t *plan)
+{
+  if(!tiling || !plan || roi_width <= 0 || roi_height <= 0 || in_bpp <= 0 || out_bpp <= 0) return DT_HIP_INVALID_ARG;
+  auto gcd = [](unsigned a, unsigned b) {
+    while(b)
+    {
+      const unsigned t = b;
+      b = a % b;
+      a = t;
+    }
+    return a;
+  };
+  auto lcm = [&](unsigned a, unsigned b) { return (a && b) ? a / gcd(a, b) * b : 0u; };
+  const int max_bpp = in_bpp > out_bpp ? in_bpp : out_bpp;
+  const float available = (float)available_bytes;
+  const float factor = fmaxf(tiling->factor_cl, 1.0f);
+  const float singlebuffer = fminf(fmaxf((available - tiling->overhead) / factor, 0.0f), (float)memalloc_bytes);
+  const float maxbuf = fmaxf(tiling->maxbuf_cl, 1.0f);
+  int width = roi_width < max_width ? roi_width : max_width;
+  int height = roi_height < max_height ? roi_height : max_height;
+  // shrink the tile when it exceeds the per-buffer budget, :879-899
+  if((float)width * height * max_bpp * maxbuf > singlebuffer)
+  {
+    const float scale = singlebuffer / ((float)width * height * max_bpp * maxbuf);
+    if(width < height && scale >= 0.333f)
+      height = (int)floorf(height * scale);
+    else if(height <= width && scale >= 0.333f)
+      width = (int)floorf(width * scale);
+    else
+    {
+      width = (int)floorf(width * sqrtf(scale));
+      height = (int)floorf(height * sqrtf(scale));
+    }
+  }
+  // squares when the overlap would eat the tile, :901-907
+  if(3 * tiling->overlap > (unsigned)width || 3 * tiling->overlap > (unsigned)height)
+    width = height = (int)floorf(sqrtf((float)width * height));
+  // alignment, :917-933 (CL_ALIGNMENT, :54: 4 unless X-Trans)
+  const unsigned xyalign = lcm(tiling->xalign, tiling->yalign);
+  const unsigned walign = lcm(xyalign, filters != 9u ? 4u : 1u);
+  const unsigned halign = xyalign;
+  if(!xyalign || !walign) return DT_HIP_INVALID_ARG;
+  if(width < roi_width) width = (width / walign) * walign;
+  if(height < roi_height) height = (height / halign) * halign;
+  // the rounded-footprint loop, :941-950 (linear allocations are not rounded: dt_hip_dev_roundup_* are identities)
+  while((float)width * height * max_bpp * maxbuf > singlebuffer)
+  {
+    if(width <= (int)walign && height <= (int)halign) break;
+    if(width < height && height > (int)halign)
+      height -= halign;
+    else if(width > (int)walign)
+      width -= walign;
+    else
+      height -= halign;
+  }
+  // :961-962
+  auto align_down = [](int n, int a) { return n - n % a; };
+  if(width < roi_width) width = std::max((int)walign, align_down(width, (int)walign));
+  if(height < roi_height) height = std::max((int)halign, align_down(height, (int)halign));
+  const int overlap = tiling->overlap % xyalign != 0 ? (tiling->overlap / xyalign + 1) * xyalign : tiling->overlap;
+  plan->width = width;
+  plan->height = height;
+  plan->overlap = overlap;
+  plan->tile_wd = width - 2 * overlap > 0 ? width - 2 * overlap : 1;
+  plan->tile_ht = height - 2 * overlap > 0 ? height - 2 * overlap : 1;
+  plan->tiles_x = width < roi_width ? (int)ceilf(roi_width / (float)plan->tile_wd) : 1;
+  plan->tiles_y = height < roi_height ? (int)ceilf(roi_height / (float)plan->tile_ht) : 1;
+  if((long)plan->tiles_x * plan->tiles_y > 10000) // _maximum_number_tiles(), :110-113
+  {
+    set_last_error("tiling: %d x %d tiles is too many", plan->tiles_x, plan->tiles_y);
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  return DT_HIP_SUCCESS;
+}
+
+// the tile loop, :981-1054: upload a tile of the host input, run the module on it with the tile's ROIs, download the
+// part of its output that is not overlap.  available_bytes = 0 asks the device.
+int dt_hip_default_process_tiling_ptp(int devid, const char *op, const dt_hip_piece_t *piece, const void *data,
+                                      size_t data_size, const dt_hip_tiling_t *tiling, const void *host_in, void *host_out,
+                                      int in_bpp, int out_bpp, size_t available_bytes)
+{
+  if(!valid_device(devid) || !op || !piece || !tiling || !host_in || !host_out) return DT_HIP_INVALID_ARG;
+  node_t n;
+  n.op = OP_UNKNOWN;
+  for(int k = 0; k < (int)OP_UNKNOWN; k++)
+    if(!strcmp(op, k_ops[k].name)) n.op = (op_t)k;
+  if(n.op == OP_UNKNOWN || n.op == OP_BLEND || data_size != k_ops[n.op].data_size || (data_size && !data))
+  {
+    set_last_error("tiling: module '%s' cannot be tiled here", op);
+    return DT_HIP_INVALID_ARG;
+  }
+  if(data_size) n.data.assign((const unsigned char *)data, (const unsigned char *)data + data_size);
+  const dt_hip_roi_t &ri = piece->roi_in, &ro = piece->roi_out;
+  if(ri.x != ro.x || ri.y != ro.y || ri.width != ro.width || ri.height != ro.height || ri.scale != ro.scale)
+  {
+    set_last_error("tiling: '%s' changes the geometry (roi_in != roi_out): only the point-to-point plan is implemented", op);
+    return DT_HIP_INVALID_ARG;
+  }
+  int max_w = 0, max_h = 0;
+  dt_hip_get_device_max_image_size(devid, &max_w, &max_h);
+  dt_hip_tile_plan_t pl;
+  int err = dt_hip_plan_tiles_ptp(ri.width, ri.height, in_bpp, out_bpp, tiling, piece->filters,
+                                  available_bytes ? available_bytes : dt_hip_get_device_available(devid),
+                                  dt_hip_get_device_memalloc(devid), max_w, max_h, &pl);
+  if(err != DT_HIP_SUCCESS) return err;
+  const size_t ipitch = (size_t)ri.width * in_bpp, opitch = (size_t)ro.width * out_bpp;
+  hipStream_t st = stream_of(devid);
+  for(int tx = 0; tx < pl.tiles_x; tx++)
+    for(int ty = 0; ty < pl.tiles_y; ty++)
+    {
+      const int wd = tx * pl.tile_wd + pl.width > ri.width ? ri.width - tx * pl.tile_wd : pl.width;
+      const int ht = ty * pl.tile_ht + pl.height > ri.height ? ri.height - ty * pl.tile_ht : pl.height;
+      // end tiles that are all overlap carry nothing new, :990-991
+      if((wd <= 2 * pl.overlap && tx > 0) || (ht <= 2 * pl.overlap && ty > 0)) continue;
+      n.piece = *piece;
+      n.piece.roi_in.x = ri.x + tx * pl.tile_wd;
+      n.piece.roi_in.y = ri.y + ty * pl.tile_ht;
+      n.piece.roi_in.width = n.piece.roi_out.width = wd;
+      n.piece.roi_in.height = n.piece.roi_out.height = ht;
+      n.piece.roi_out.x = ro.x + tx * pl.tile_wd;
+      n.piece.roi_out.y = ro.y + ty * pl.tile_ht;
+      const size_t ioffs = (size_t)ty * pl.tile_ht * ipitch + (size_t)tx * pl.tile_wd * in_bpp;
+      size_t ooffs = (size_t)ty * pl.tile_ht * opitch + (size_t)tx * pl.tile_wd * out_bpp;
+      dt_hip_mem_t input = dt_hip_alloc_device(devid, wd, ht, in_bpp), output = dt_hip_alloc_device(devid, wd, ht, out_bpp);
+      err = (input && output) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
+      if(err == DT_HIP_SUCCESS)
+        err = dt_hip_write_host_to_device_rowpitch(devid, (const char *)host_in + ioffs, input, wd, ht, in_bpp, ipitch, 1);
+      // a module may leave part of its output to the caller (the alpha of the demosaic border ring): the tile buffer
+      // comes from the pool, so give those bytes a value
+      if(err == DT_HIP_SUCCESS && hipMemsetAsync(output, 0, (size_t)wd * ht * out_bpp, st) != hipSuccess) err = DT_HIP_DEFAULT_ERROR;
+      if(err == DT_HIP_SUCCESS) err = run_single(devid, n, input, output);
+      if(err == DT_HIP_SUCCESS)
+      {
+        // only the good part goes back, :1023-1040
+        int ox = 0, oy = 0, rw = wd, rh = ht;
+        if(tx > 0)
+        {
+          ox = pl.overlap;
+          rw -= pl.overlap;
+          ooffs += (size_t)pl.overlap * out_bpp;
+        }
+        if(ty > 0)
+        {
+          oy = pl.overlap;
+          rh -= pl.overlap;
+          ooffs += (size_t)pl.overlap * opitch;
+        }
+        const char *src = (const char *)output + ((size_t)oy * wd + ox) * out_bpp;
+        if(hipMemcpy2DAsync((char *)host_out + ooffs, opitch, src, (size_t)wd * out_bpp, (size_t)rw * out_bpp, rh,
+                            hipMemcpyDeviceToHost, st) != hipSuccess
+           || hipStreamSynchronize(st) != hipSuccess)
+        {
+          set_last_error("tiling: download of tile (%d, %d) failed: %s", tx, ty, hipGetErrorString(hipGetLastError()));
+          err = DT_HIP_DEFAULT_ERROR;
+        }
+      }
+      if(input) dt_hip_release_mem_object(input);
+      if(output) dt_hip_release_mem_object(output);
+      if(err != DT_HIP_SUCCESS) return err;
+    }
+  return DT_HIP_SUCCESS;
 }
 
 // default_tiling_callback(), src/develop/tiling.c:1423-1463, for the modules without a callback of their own

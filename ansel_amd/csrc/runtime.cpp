@@ -271,9 +271,8 @@ void dt_hip_check_tuning(int devid) { (void)devid; }
 int dt_hip_avoid_atomics(int devid) { (void)devid; return 0; }
 int dt_hip_micro_nap(int devid) { (void)devid; return 0; }
 int dt_hip_use_pinned_memory(int devid) { return valid_device(devid) ? 1 : 0; }
-// dt_opencl_dev_roundup_width / _height, opencl.c:2973-2982: launch sizes are the library's own business, so the
-// granularity a host would round to is one wavefront
-int dt_hip_dev_roundup_width(int size, int devid) { (void)devid; return size % 64 == 0 ? size : (size / 64 + 1) * 64; }
+// dt_opencl_dev_roundup_width / _height, opencl.c:2973-2982: images are linear allocations, nothing is rounded
+int dt_hip_dev_roundup_width(int size, int devid) { (void)devid; return size; }
 int dt_hip_dev_roundup_height(int size, int devid) { (void)devid; return size; }
 
 int dt_hip_image_fits_device(int devid, size_t width, size_t height, unsigned bpp, float factor, size_t overhead)
@@ -741,6 +740,7 @@ size_t dt_hip_abi_sizeof(const char *name)
   S("finalscale", dt_hip_finalscale_data_t);
   S("blend", dt_hip_blend_data_t);
   S("export_rows", dt_hip_export_rows_t);
+  S("tile_plan", dt_hip_tile_plan_t);
   S("band", dt_hip_band_t);
   S("band_state", dt_hip_band_state_t);
 #undef S

@@ -119,6 +119,8 @@ def load():
         "dt_hip_alloc_host_pinned": (vp, [sz]),
         "dt_hip_free_host_pinned": (None, [vp]),
         "dt_hip_is_pinned_memory": (i, [vp]),
+        "dt_hip_plan_tiles_ptp": (i, [i, i, i, i, P(abi.Tiling), C.c_uint, sz, sz, i, i, P(abi.TilePlan)]),
+        "dt_hip_default_process_tiling_ptp": (i, [i, C.c_char_p, P(abi.Piece), vp, sz, P(abi.Tiling), vp, vp, i, i, sz]),
         "dt_hip_default_tiling": (None, [P(abi.Piece), i, P(abi.Tiling)]),
         "dt_hip_iop_denoiseprofile_tiling": (None, [P(abi.Piece), P(abi.DenoiseprofileData), P(abi.Tiling)]),
         "dt_hip_iop_nlmeans_tiling": (None, [P(abi.Piece), P(abi.NlmeansData), P(abi.Tiling)]),

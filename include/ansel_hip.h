@@ -80,6 +80,29 @@ typedef struct dt_hip_tiling_t
  * device, which is what dt_hip_image_fits_device() is asked about.  Modules without a callback of their own take
  * default_tiling_callback(), src/develop/tiling.c:1423-1463: */
 void dt_hip_default_tiling(const dt_hip_piece_t *piece, int before_demosaic, dt_hip_tiling_t *tiling);
+/* default_process_tiling_cl() for a module that does not move pixels (roi_in == roi_out),
+ * _default_process_tiling_cl_ptp(), src/develop/tiling.c:842-1067 -- what the host falls back to when
+ * dt_hip_image_fits_device() says no (pixelpipe_gpu.c:514): the frame stays in HOST memory, tiles of it go through
+ * the device with `overlap` pixels of context on every side and only their interior comes back.
+ * dt_hip_plan_tiles_ptp() is the tile plan of :868-979 as a pure function (no device needed);
+ * dt_hip_default_process_tiling_ptp() runs module `op` (the names of dt_hip_pipe_add_node) over it:
+ * host_in / host_out are full frames of in_bpp / out_bpp bytes per pixel, `tiling` is the module's callback
+ * result, available_bytes = 0 asks the device (a smaller value forces tiling).  As in the reference, a tile is an
+ * ordinary module run on a cropped frame: results equal the untiled run for every pixel whose dependencies stay
+ * within `overlap` -- all of them for pointwise modules. */
+typedef struct dt_hip_tile_plan_t
+{
+  int32_t width, height;     /* largest tile, overlap included */
+  int32_t tile_wd, tile_ht;  /* step between tile origins = the part of a tile that is kept */
+  int32_t tiles_x, tiles_y;
+  int32_t overlap;           /* the module's overlap rounded up to its alignment */
+} dt_hip_tile_plan_t;
+int dt_hip_plan_tiles_ptp(int roi_width, int roi_height, int in_bpp, int out_bpp, const dt_hip_tiling_t *tiling,
+                          unsigned filters, size_t available_bytes, size_t memalloc_bytes, int max_width, int max_height,
+                          dt_hip_tile_plan_t *plan);
+int dt_hip_default_process_tiling_ptp(int devid, const char *op, const dt_hip_piece_t *piece, const void *data,
+                                      size_t data_size, const dt_hip_tiling_t *tiling, const void *host_in, void *host_out,
+                                      int in_bpp, int out_bpp, size_t available_bytes);
 
 /* ---- 1. device runtime (peer of src/common/opencl.h) ------------------------------ */
 

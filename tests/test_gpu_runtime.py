@@ -57,8 +57,7 @@ def test_device_queries():
     assert l.dt_hip_get_device_max_global_mem(9) == 0
     assert l.dt_hip_use_pinned_memory(0) == 1 and l.dt_hip_avoid_atomics(0) == 0 and l.dt_hip_micro_nap(0) == 0
     l.dt_hip_check_tuning(0)
-    assert l.dt_hip_dev_roundup_width(1, 0) == 64 and l.dt_hip_dev_roundup_width(128, 0) == 128
-    assert l.dt_hip_dev_roundup_height(77, 0) == 77
+    assert l.dt_hip_dev_roundup_width(131, 0) == 131 and l.dt_hip_dev_roundup_height(77, 0) == 77  # linear: nothing rounded
     assert l.dt_hip_is_enabled() == 1 and l.dt_hip_update_settings() == 1
     assert l.dt_hip_enqueue_barrier(0) == abi.DT_HIP_SUCCESS and l.dt_hip_enqueue_barrier(5) != abi.DT_HIP_SUCCESS
 
