@@ -151,6 +151,8 @@ class NlmeansData(C.Structure):
 
 
 DT_HIP_DENOISEPROFILE_NLMEANS = 0
+DT_HIP_DENOISEPROFILE_NLMEANS_AUTO = 3
+DT_HIP_DENOISEPROFILE_WAVELETS_AUTO = 4
 
 
 class Conversion(C.Structure):

@@ -643,7 +643,7 @@ void denoiseprofile_band_abort(dn_band_job_t *j)
 
 int denoiseprofile_halo_rows(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d)
 {
-  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return nlmeans_core_halo_rows(piece->roi_in.height, nlm_params_of(piece, d));
+  if(DT_HIP_DENOISEPROFILE_IS_NLMEANS(d->mode)) return nlmeans_core_halo_rows(piece->roi_in.height, nlm_params_of(piece, d));
   dn_setup s;
   setup(piece, d, s, false);
   if(wavelets_runnable(piece, s) != 1) return -1;
@@ -659,8 +659,8 @@ int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_h
   *sum_count = 0;
   if(!valid_device(devid) || !piece || !d || !band || !dev_in || buf_rows <= 0) return DT_HIP_INVALID_ARG;
   if(piece->channels != 4 || !(piece->roi_in.scale > 0.0)) return DT_HIP_INVALID_ARG;
-  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return denoise_nlmeans(devid, piece, d, band, buf_rows, dev_in, dev_out);
-  if(d->mode != DT_HIP_DENOISEPROFILE_WAVELETS) return DT_HIP_INVALID_ARG;
+  if(DT_HIP_DENOISEPROFILE_IS_NLMEANS(d->mode)) return denoise_nlmeans(devid, piece, d, band, buf_rows, dev_in, dev_out);
+  if(!DT_HIP_DENOISEPROFILE_IS_WAVELETS(d->mode)) return DT_HIP_INVALID_ARG;
   dn_band_job_t *j = new dn_band_job_t;
   memset(j, 0, sizeof(*j));
   j->devid = devid;
@@ -779,7 +779,7 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
                                       dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
-  if(d->mode != DT_HIP_DENOISEPROFILE_WAVELETS && d->mode != DT_HIP_DENOISEPROFILE_NLMEANS)
+  if(!DT_HIP_DENOISEPROFILE_IS_WAVELETS(d->mode) && !DT_HIP_DENOISEPROFILE_IS_NLMEANS(d->mode))
   {
     set_last_error("denoiseprofile: mode %d is not implemented on device (wavelets and non-local means are)", d->mode);
     return DT_HIP_INVALID_ARG;
@@ -788,7 +788,7 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
   const int w = piece->roi_in.width, h = piece->roi_in.height;
   if(w <= 0 || h <= 0) return DT_HIP_SUCCESS;
   const size_t npix = (size_t)w * h, plane = npix * sizeof(float4);
-  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return denoise_nlmeans(devid, piece, d, nullptr, h, dev_in, dev_out);
+  if(DT_HIP_DENOISEPROFILE_IS_NLMEANS(d->mode)) return denoise_nlmeans(devid, piece, d, nullptr, h, dev_in, dev_out);
   dn_setup s;
   setup(piece, d, s, false);
   const int runnable = wavelets_runnable(piece, s);
@@ -866,7 +866,7 @@ void dt_hip_iop_denoiseprofile_tiling(const dt_hip_piece_t *piece, const dt_hip_
   memset(tiling, 0, sizeof(*tiling));
   tiling->maxbuf = tiling->maxbuf_cl = 1.0f;
   tiling->xalign = tiling->yalign = 1;
-  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS)
+  if(DT_HIP_DENOISEPROFILE_IS_NLMEANS(d->mode))
   {
     const float scale = fminf(fminf((float)piece->roi_in.scale, 2.0f), 1.0f);
     const int P = (int)ceilf(d->radius * scale), K = (int)ceilf(d->nbhood * scale);

@@ -1041,7 +1041,7 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
         v.row1 = b.row0 + b.rows;
         const bool own_rows_out = first.op == OP_NLMEANS
                                   || (first.op == OP_DENOISEPROFILE
-                                      && first.as<dt_hip_denoiseprofile_data_t>()->mode == DT_HIP_DENOISEPROFILE_NLMEANS);
+                                      && DT_HIP_DENOISEPROFILE_IS_NLMEANS(first.as<dt_hip_denoiseprofile_data_t>()->mode));
         dt_hip_mem_t out = dev_out_band;
         if(!(own_rows_out && final_group))
         {

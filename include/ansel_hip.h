@@ -422,6 +422,13 @@ void dt_hip_iop_diffuse_tiling(const dt_hip_piece_t *piece, const dt_hip_diffuse
 #define DT_HIP_DENOISEPROFILE_BANDS 7
 #define DT_HIP_DENOISEPROFILE_NLMEANS 0
 #define DT_HIP_DENOISEPROFILE_WAVELETS 1
+/* MODE_NLMEANS_AUTO / MODE_WAVELETS_AUTO (denoiseprofile.c:124-125): the "auto" sliders are resolved into the same
+ * fields at commit time, process() dispatches them like the manual modes (:2617-2621).  MODE_VARIANCE (2, a
+ * noise-profiling aid) is refused. */
+#define DT_HIP_DENOISEPROFILE_NLMEANS_AUTO 3
+#define DT_HIP_DENOISEPROFILE_WAVELETS_AUTO 4
+#define DT_HIP_DENOISEPROFILE_IS_NLMEANS(mode) ((mode) == DT_HIP_DENOISEPROFILE_NLMEANS || (mode) == DT_HIP_DENOISEPROFILE_NLMEANS_AUTO)
+#define DT_HIP_DENOISEPROFILE_IS_WAVELETS(mode) ((mode) == DT_HIP_DENOISEPROFILE_WAVELETS || (mode) == DT_HIP_DENOISEPROFILE_WAVELETS_AUTO)
 #define DT_HIP_DENOISEPROFILE_RGB 0
 #define DT_HIP_DENOISEPROFILE_Y0U0V0 1
 typedef struct dt_hip_denoiseprofile_data_t

@@ -493,8 +493,8 @@ static int denoise_nlmeans(const dt_hip_piece_t *piece, const dt_hip_denoiseprof
 
 int oracle_denoiseprofile(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d, const void *in_, void *out_)
 {
-  if(d->mode == DT_HIP_DENOISEPROFILE_NLMEANS) return denoise_nlmeans(piece, d, (const float *)in_, (float *)out_);
-  if(d->mode != DT_HIP_DENOISEPROFILE_WAVELETS) return 1;
+  if(DT_HIP_DENOISEPROFILE_IS_NLMEANS(d->mode)) return denoise_nlmeans(piece, d, (const float *)in_, (float *)out_);
+  if(!DT_HIP_DENOISEPROFILE_IS_WAVELETS(d->mode)) return 1;
   const int w = piece->roi_in.width, h = piece->roi_in.height;
   const size_t npix = (size_t)w * h;
   const float *in = (const float *)in_;

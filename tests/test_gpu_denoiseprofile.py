@@ -59,3 +59,29 @@ def test_denoiseprofile_small_frames():
     want = np.zeros_like(img)
     assert ck.call(ck.oracle(), "oracle_denoiseprofile", piece, d, img, want) == 0
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("auto,manual", [(abi.DT_HIP_DENOISEPROFILE_WAVELETS_AUTO, abi.DT_HIP_DENOISEPROFILE_WAVELETS),
+                                         (abi.DT_HIP_DENOISEPROFILE_NLMEANS_AUTO, abi.DT_HIP_DENOISEPROFILE_NLMEANS)])
+def test_auto_modes_run_like_their_manual_mode(auto, manual):
+    """MODE_*_AUTO: the auto sliders are resolved into the same fields at commit time and process() dispatches
+    them like the manual modes (denoiseprofile.c:2617-2621)"""
+    w, h = 300, 200
+    img = _noisy(w, h, 9)
+    piece = abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS)
+    got = hc.run_hip("dt_hip_iop_denoiseprofile_process", piece, params.denoiseprofile(mode=auto), img, img.shape)
+    same = hc.run_hip("dt_hip_iop_denoiseprofile_process", piece, params.denoiseprofile(mode=manual), img, img.shape)
+    assert got.tobytes() == same.tobytes()
+    want = np.zeros_like(img)
+    assert ck.call(ck.oracle(), "oracle_denoiseprofile", piece, params.denoiseprofile(mode=auto), img, want) == 0
+    assert got.tobytes() == want.tobytes()
+
+
+def test_variance_mode_is_refused():
+    import ctypes as C
+    from ansel_amd import lib
+    l = hc.hip()
+    buf = lib.DeviceBuffer(0, 64 * 64 * 16)
+    piece = abi.Piece.make(64, 64)
+    d = params.denoiseprofile(mode=2)
+    assert l.dt_hip_iop_denoiseprofile_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
