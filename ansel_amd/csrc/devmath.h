@@ -103,6 +103,35 @@ ANSEL_HD float log2f_exact(const float x)
   return ix == 0x3f800000u ? 0.0f : r;                             // log2(1) is exactly +0
 }
 
+// ---- logf: sysdeps/ieee754/flt-32/e_logf.c (the FMA build the x86-64 ifunc selects) ----------------------
+// Caller: the Box-Muller noise that seeds diffuse-or-sharpen's inpainting (src/iop/noise_generator.h:81-93).
+ANSEL_HD float logf_exact(const float x)
+{
+  uint32_t ix = asuint(x);
+  if(ix == 0x3f800000u) return 0.0f;
+  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u)
+  {
+    if(ix * 2 == 0) return -INFINITY;
+    if(ix == 0x7f800000u) return x;
+    if((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return NAN;
+    ix = asuint(x * 0x1p23f);
+    ix -= 23u << 23;
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (tmp >> (23 - 4)) % 16;
+  const int k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & 0xff800000u);
+  const double invc = k_logf_tab[2 * i], logc = k_logf_tab[2 * i + 1];
+  const double z = (double)asfloat(iz);
+  const double r = fma(z, invc, -1.0);
+  const double y0 = fma((double)k, k_logf_ln2, logc);
+  const double r2 = r * r;
+  double y = fma(k_logf_poly[1], r, k_logf_poly[2]);
+  y = fma(k_logf_poly[0], r2, y);
+  y = fma(y, r2, y0 + r);
+  return (float)y;
+}
+
 // ---- exp2 of a double argument, rounded to float: exp2_inline() of e_powf.c -------------
 ANSEL_HD float exp2_from_double(const double xd, const uint32_t sign_bias)
 {

@@ -18,6 +18,7 @@
 // taps clamp to column 0 / width-1 whatever the dilation (bspline.h:143-149), so those two columns
 // are blurred by every workgroup as well.
 #include "hip_common.h"
+#include "devmath.h"
 
 #include <math.h>
 
@@ -223,11 +224,22 @@ __device__ __forceinline__ float pde_channel(const float H[9], const float L[9],
 }
 
 __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf, const float4 *__restrict__ lf,
-                                                   float4 *__restrict__ out, const pde_args a, const int final_pass)
+                                                   float4 *__restrict__ out, const pde_args a, const int final_pass,
+                                                   const unsigned char *__restrict__ mask)
 {
   const int row = walk_row(blockIdx.y, a.height, a.mult);
   const int col = xcd_col() * blockDim.x + threadIdx.x; // hip_common.h: column block pinned to an XCD for 64 rows
   if(row < 0 || col >= a.width) return;
+  if(mask && !mask[(size_t)row * a.width + col])
+  {
+    // outside the luminance mask: "only copy input to output", diffuse.c:927-937
+    const size_t c = (size_t)row * a.width + col;
+    const float4 h = hf[c], l = lf[c];
+    const float4 o = make_float4(max_zero(h.x + l.x), max_zero(h.y + l.y), max_zero(h.z + l.z), max_zero(h.w + l.w));
+    if(final_pass) nt_store(out + c, o);
+    else out[c] = o;
+    return;
+  }
   const size_t rows[3] = { (size_t)clampi(row - a.mult, 0, a.height - 1) * a.width, (size_t)row * a.width,
                            (size_t)clampi(row + a.mult, 0, a.height - 1) * a.width };
   const int cols[3] = { clampi(col - a.mult, 0, a.width - 1), col, clampi(col + a.mult, 0, a.width - 1) };
@@ -257,6 +269,72 @@ __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf
   const size_t idx = rows[1] + col;
   if(final_pass) nt_store(out + idx, o);
   else out[idx] = o;
+}
+
+// ---- build_mask() + inpaint_mask(), diffuse.c:1106-1152, with the generators of src/iop/noise_generator.h:36-93 ----
+__device__ __forceinline__ uint32_t splitmix32(const uint64_t seed)
+{
+  uint64_t result = (seed ^ (seed >> 33)) * 0x62a9d9ed799705f5ull;
+  result = (result ^ (result >> 28)) * 0xcb24d0a5c88c35b3ull;
+  return (uint32_t)(result >> 32);
+}
+
+__device__ __forceinline__ float xoshiro128plus(uint32_t state[4])
+{
+  const uint32_t result = state[0] + state[3];
+  const uint32_t t = state[1] << 9;
+  state[2] ^= state[0];
+  state[3] ^= state[1];
+  state[1] ^= state[2];
+  state[0] ^= state[3];
+  state[2] ^= t;
+  state[3] = (state[3] << 11) | (state[3] >> 21);
+  return (float)(result >> 8) * 0x1.0p-24f;
+}
+
+// gaussian_noise(), noise_generator.h:81-93: Box-Muller with the C library's logf / cosf / sinf (devmath.h restates
+// them) and the angle formed in binary64 (2.f * M_PI * u2) before it is narrowed for the call
+__device__ __forceinline__ float gaussian_noise(const float mu, const float sigma, const bool flip, uint32_t state[4])
+{
+  const float x1 = xoshiro128plus(state);
+  const float u1 = x1 > 1.17549435e-38f ? x1 : 1.17549435e-38f; // fmaxf(x, FLT_MIN); x is never NaN
+  const float u2 = xoshiro128plus(state);
+  const float angle = (float)(6.283185307179586 * (double)u2);
+  const float radius = sqrtf(-2.0f * ansel_math::logf_exact(u1));
+  const float noise = flip ? radius * ansel_math::cosf_exact(angle) : radius * ansel_math::sinf_exact(angle);
+  return noise * sigma + mu;
+}
+
+// k = the FLOAT index of the pixel in the frame; the reference takes k / width for its "row" and k - row for its
+// "column" (sic) and seeds the generator with them.  first_pixel: the frame index of in[0] (a row band of a frame)
+__global__ __launch_bounds__(256) void diffuse_inpaint(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                       unsigned char *__restrict__ mask, const float threshold,
+                                                       const size_t npixels, const size_t width, const size_t first_pixel)
+{
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(p >= npixels) return;
+  const float4 v = in[p];
+  const bool m = v.x > threshold || v.y > threshold || v.z > threshold;
+  mask[p] = m ? 1 : 0;
+  float4 o = v;
+  if(m)
+  {
+    const size_t k = 4 * (p + first_pixel);
+    const uint32_t i = (uint32_t)(k / width);
+    const uint32_t j = (uint32_t)(k - i);
+    uint32_t state[4] = { splitmix32((uint32_t)(j + 1)), splitmix32((uint64_t)(uint32_t)(j + 1) * (uint32_t)(i + 3)),
+                          splitmix32(1337), splitmix32(666) };
+    xoshiro128plus(state);
+    xoshiro128plus(state);
+    xoshiro128plus(state);
+    xoshiro128plus(state);
+    const bool flip = (i % 2) || (j % 2);
+    o.x = fabsf(gaussian_noise(v.x, v.x, flip, state));
+    o.y = fabsf(gaussian_noise(v.y, v.y, flip, state));
+    o.z = fabsf(gaussian_noise(v.z, v.z, flip, state));
+    o.w = fabsf(gaussian_noise(v.w, v.w, flip, state));
+  }
+  out[p] = o;
 }
 
 inline float sqf(const float x) { return x * x; }
@@ -331,15 +409,23 @@ extern "C" {
 int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d,
                                dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
 {
+  return diffuse_process_rows(devid, piece, d, 0, dev_in, dev_out);
+}
+
+} // extern "C"
+
+namespace ansel
+{
+
+// first_row: the frame row of the buffer's first row (a row band, pipe.cpp) -- it only enters the seeds of the
+// inpainting noise, which the reference derives from the pixel's index in the frame
+int diffuse_process_rows(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, int first_row,
+                         dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
   if(piece->channels != 4)
   {
     set_last_error("diffuse: needs a 4-channel float input");
-    return DT_HIP_INVALID_ARG;
-  }
-  if(d->threshold > 0.0f)
-  {
-    set_last_error("diffuse: luminance-masked inpainting (threshold > 0) is not implemented on device");
     return DT_HIP_INVALID_ARG;
   }
   const int w = piece->roi_out.width, h = piece->roi_out.height;
@@ -378,6 +464,24 @@ int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_
 
   hipStream_t st = stream_of(devid);
   const float4 *src = (const float4 *)dev_in;
+  unsigned char *mask = nullptr;
+  float4 *inpainted = nullptr;
+  if(err == DT_HIP_SUCCESS && d->threshold > 0.0f)
+  {
+    // diffuse.c:1207-1219: mask of the pixels above the threshold, noise-seeded copy as the first iteration's input
+    // (the reference reuses "temp1" for it; the second iteration's output may overwrite it, so may ours)
+    const size_t np = (size_t)w * h;
+    mask = (unsigned char *)dt_hip_alloc_device_buffer(devid, np);
+    inpainted = tmp[1] ? tmp[1] : (tmp[1] = (float4 *)dt_hip_alloc_device_buffer(devid, plane));
+    if(!mask || !inpainted) err = DT_HIP_SYSMEM_ALLOCATION;
+    else
+    {
+      launch_scope ls(devid, "diffuse_inpaint");
+      diffuse_inpaint<<<pixel_grid(np), 256, 0, st>>>(src, inpainted, mask, d->threshold, np, (size_t)w, (size_t)first_row * w);
+      err = check_launch("diffuse_inpaint");
+      src = inpainted;
+    }
+  }
   for(int it = 0; err == DT_HIP_SUCCESS && it < iterations; it++)
   {
     // iteration ping-pong, diffuse.c:1223-1249 (tmp[0] = "temp2", tmp[1] = "temp1")
@@ -408,7 +512,7 @@ int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_
       {
         launch_scope ls(devid, "diffuse_pde");
         // gridDim.x padded to a multiple of 8: a column block stays on one XCD, the rows above and below hit its L2
-        diffuse_pde<<<dim3(xcd_pad((w + 255) / 256), rows), 256, 0, st>>>(hf[s], cur, to, a, s == 0);
+        diffuse_pde<<<dim3(xcd_pad((w + 255) / 256), rows), 256, 0, st>>>(hf[s], cur, to, a, s == 0, mask);
       }
       err = check_launch("diffuse_pde");
       cur = to;
@@ -422,8 +526,13 @@ int dt_hip_iop_diffuse_process(int devid, const dt_hip_piece_t *piece, const dt_
     if(lf[k]) dt_hip_release_mem_object(lf[k]);
     if(tmp[k]) dt_hip_release_mem_object(tmp[k]);
   }
+  if(mask) dt_hip_release_mem_object(mask);
   return err;
 }
+
+} // namespace ansel
+
+extern "C" {
 
 // tiling_callback(), diffuse.c:585-610
 void dt_hip_iop_diffuse_tiling(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, dt_hip_tiling_t *tiling)

@@ -118,6 +118,8 @@ int nlmeans_halo_rows(const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *
 int nlmeans_process_band(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d, const band_view_t *band,
                          dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 int diffuse_halo_rows(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d);
+int diffuse_process_rows(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, int first_row,
+                         dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 // denoiseprofile: -1 when the frame is too small for the module to do anything but copy
 int denoiseprofile_halo_rows(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d);
 struct dn_band_job_t;

@@ -1061,7 +1061,7 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
         {
           dt_hip_piece_t p = first.piece;
           p.roi_in.height = p.roi_out.height = buf_rows;
-          err = dt_hip_iop_diffuse_process(devid, &p, first.as<dt_hip_diffuse_data_t>(), pv->cur_base, out);
+          err = diffuse_process_rows(devid, &p, first.as<dt_hip_diffuse_data_t>(), v.buf_row0, pv->cur_base, out);
         }
         else
         {

@@ -21,6 +21,7 @@ __global__ void devmath_test(const float *__restrict__ x, const float *__restric
     else if(FN == 5) r = ansel_math::hypotf_exact(x[k], y[k]);
     else if(FN == 6) r = ansel_math::sinf_exact(x[k]);
     else if(FN == 7) r = ansel_math::cosf_exact(x[k]);
+    else if(FN == 9) r = ansel_math::logf_exact(x[k]);
     else r = fmodf(x[k], y[k]); // the device library's: fmod is exact, any correct implementation agrees
     o[k] = r;
   }
@@ -42,4 +43,5 @@ int dt_hip_test_hypotf(int devid, const void *x, const void *y, void *o, size_t 
 int dt_hip_test_sinf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<6>(devid, x, y, o, n); }
 int dt_hip_test_cosf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<7>(devid, x, y, o, n); }
 int dt_hip_test_fmodf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<8>(devid, x, y, o, n); }
+int dt_hip_test_logf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<9>(devid, x, y, o, n); }
 }

@@ -153,6 +153,8 @@ def diffuse(preset="default", iscale=1.0, **over):
         # "lens deblur: soft", diffuse.c:304-325
         "lens_deblur_soft": dict(regularization=1.0, anisotropy_first=2.0, anisotropy_third=2.0, first=-0.25,
                                  second=0.125, third=-0.125, fourth=0.0625, radius=8, iterations=8),
+        # "inpaint highlights", diffuse.c:520-538: everything above the threshold is seeded with noise and diffused
+        "inpaint_highlights": dict(iterations=32, radius=4, threshold=1.41, anisotropy_fourth=2.0, fourth=0.5),
         # "fast local contrast", diffuse.c:561-583
         "fast_local_contrast": dict(radius_center=512, radius=512, anisotropy_third=5.0, third=-0.5, iterations=1),
     }

@@ -387,8 +387,9 @@ int dt_hip_export_pack_rows(int devid, int width, int height, int bpp, int layer
  * decompose_2D_Bspline() (src/pixel/bspline.h:351-377), heat_PDE_diffusion() (diffuse.c:760-968).
  * The struct is dt_iop_diffuse_params_t (diffuse.c:76-105; commit_params memcpy's it, :133-138)
  * followed by pipe->iscale, which process() reads through dt_dev_get_module_scale()
- * (src/develop/imageop.c:134-137).  threshold > 0 (luminance-masked inpainting with gaussian
- * noise, diffuse.c:1109-1152) is not implemented on device: DT_HIP_INVALID_ARG. */
+ * (src/develop/imageop.c:134-137).  threshold > 0: build_mask() / inpaint_mask() (diffuse.c:1106-1152) -- pixels
+ * above the threshold are re-seeded with Box-Muller noise from a generator keyed on the pixel's position
+ * (src/iop/noise_generator.h:36-93: splitmix32, xoshiro128+, logf / cosf / sinf) and only they are diffused. */
 typedef struct dt_hip_diffuse_data_t
 {
   int iterations;

@@ -11,12 +11,15 @@
  *   dt_fast_expf()           src/math/math.h:254-267       integer-trick exp
  *   dt_simd_max_zero()       src/system/simd.h:108-114     non-finite -> 0, else MAX(v, 0)
  *
- * The luminance-masked branch (threshold > 0: build_mask/inpaint_mask, diffuse.c:1109-1152) seeds the
- * masked area with Box-Muller noise; it is not restated (the device rejects it), oracle returns 1.
+ * The luminance-masked branch (threshold > 0: build_mask / inpaint_mask, diffuse.c:1106-1152) seeds the
+ * masked area with Box-Muller noise from src/iop/noise_generator.h:36-93 (splitmix32 seeds from the pixel's
+ * position in the buffer, xoshiro128+); pixels outside the mask pass through every PDE step as HF + LF
+ * (diffuse.c:802, 927-937).
  *
  * Arithmetic: binary32, one rounding per operation, in the reference's order: the vector code there
  * is GCC vector-extension arithmetic, lane-wise identical to the scalar form below.
  */
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -158,7 +161,62 @@ static inline float direction(float gx, float gy, float *cos2, float *sin2, floa
   return mag;
 }
 
-static void pde(const float *hf, const float *lf, float *out, const int w, const int h, const int mult, const pde_t *p)
+/* ---- noise_generator.h:36-93 ---- */
+static uint32_t splitmix32(const uint64_t seed)
+{
+  uint64_t result = (seed ^ (seed >> 33)) * 0x62a9d9ed799705f5ul;
+  result = (result ^ (result >> 28)) * 0xcb24d0a5c88c35b3ul;
+  return (uint32_t)(result >> 32);
+}
+
+static float xoshiro128plus(uint32_t state[4])
+{
+  const unsigned int result = state[0] + state[3];
+  const unsigned int t = state[1] << 9;
+  state[2] ^= state[0];
+  state[3] ^= state[1];
+  state[1] ^= state[2];
+  state[0] ^= state[3];
+  state[2] ^= t;
+  state[3] = (state[3] << 11) | (state[3] >> (32 - 11));
+  return (float)(result >> 8) * 0x1.0p-24f;
+}
+
+static float gaussian_noise(const float mu, const float sigma, const int flip, uint32_t state[4])
+{
+  const float u1 = fmaxf(xoshiro128plus(state), FLT_MIN);
+  const float u2 = xoshiro128plus(state);
+  const float noise = (flip) ? sqrtf(-2.0f * logf(u1)) * cosf(2.f * M_PI * u2) : sqrtf(-2.0f * logf(u1)) * sinf(2.f * M_PI * u2);
+  return noise * sigma + mu;
+}
+
+/* build_mask() + inpaint_mask(), diffuse.c:1106-1152.  k is the FLOAT index of the pixel; the reference derives its
+ * "row" as k / width and its "column" as k - row (sic), which is what seeds the generator */
+static void build_and_inpaint(const float *in, float *inpainted, uint8_t *mask, const float threshold, const size_t width,
+                              const size_t height)
+{
+#pragma omp parallel for
+  for(size_t k = 0; k < height * width * 4; k += 4)
+  {
+    mask[k / 4] = (in[k] > threshold || in[k + 1] > threshold || in[k + 2] > threshold);
+    if(mask[k / 4])
+    {
+      const uint32_t i = k / width;
+      const uint32_t j = k - i;
+      uint32_t state[4] = { splitmix32(j + 1), splitmix32((uint64_t)(j + 1) * (i + 3)), splitmix32(1337), splitmix32(666) };
+      xoshiro128plus(state);
+      xoshiro128plus(state);
+      xoshiro128plus(state);
+      xoshiro128plus(state);
+      for(int c = 0; c < 4; c++) inpainted[k + c] = fabsf(gaussian_noise(in[k + c], in[k + c], i % 2 || j % 2, state));
+    }
+    else
+      for(int c = 0; c < 4; c++) inpainted[k + c] = in[k + c];
+  }
+}
+
+static void pde(const float *hf, const float *lf, const uint8_t *mask, float *out, const int w, const int h, const int mult,
+                const pde_t *p)
 {
 #pragma omp parallel for
   for(int i = 0; i < h; i++)
@@ -179,6 +237,12 @@ static void pde(const float *hf, const float *lf, float *out, const int w, const
           }
         }
       float *o = out + 4 * ((size_t)i * w + j);
+      if(mask && !mask[(size_t)i * w + j])
+      {
+        /* outside the mask: only copy input to output, diffuse.c:927-937 */
+        for(int c = 0; c < 4; c++) o[c] = max_zero(H[4][c] + L[4][c]);
+        continue;
+      }
       for(int c = 0; c < 4; c++)
       {
         /* HF/LF energy over the 3x3 support, diffuse.c:823-840 */
@@ -233,7 +297,6 @@ int oracle_diffuse_scales(const dt_hip_piece_t *piece, const dt_hip_diffuse_data
 int oracle_diffuse(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, const void *in_, void *out_)
 {
   const int w = piece->roi_out.width, h = piece->roi_out.height;
-  if(d->threshold > 0.0f) return 1;
   const size_t plane = sizeof(float) * 4 * (size_t)w * h;
   const float zoom = (float)(d->iscale / piece->roi_in.scale);
   const int scales = oracle_diffuse_scales(piece, d);
@@ -257,6 +320,15 @@ int oracle_diffuse(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, 
   const float speed[4] = { d->first, d->second, d->third, d->fourth };
 
   const float *src = (const float *)in_;
+  uint8_t *mask = NULL;
+  if(ok && d->threshold > 0.0f)
+  {
+    /* diffuse.c:1207-1219: the iterations start from the inpainted copy in "temp1" */
+    mask = (uint8_t *)malloc((size_t)w * h);
+    ok = mask != NULL;
+    if(ok) build_and_inpaint(src, t1, mask, d->threshold, (size_t)w, (size_t)h);
+    src = t1;
+  }
   for(int it = 0; ok && it < iterations; it++)
   {
     /* iteration ping-pong, diffuse.c:1223-1249 */
@@ -284,12 +356,12 @@ int oracle_diffuse(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, 
       for(int k = 0; k < 4; k++) p.abcd[k] = speed[k] * PDE_KAPPA * norm;
       p.strength = d->sharpness * norm + 1.0f;
       float *to = (s == 0) ? dst : pp[count % 2];
-      pde(hf[s], cur, to, w, h, 1 << s, &p);
+      pde(hf[s], cur, mask, to, w, h, 1 << s, &p);
       cur = to;
     }
     src = dst;
   }
-  free(lf_a); free(lf_b); free(t1); free(t2);
+  free(lf_a); free(lf_b); free(t1); free(t2); free(mask);
   for(int s = 0; s < scales; s++) free(hf[s]);
   return ok ? 0 : 1;
 }

@@ -33,6 +33,8 @@ void devmath_atan2f(const float *y, const float *x, float *o, size_t n) { for(si
 void devmath_hypotf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::hypotf_exact(x[i], y[i]); }
 void devmath_sinf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::sinf_exact(x[i]); }
 void devmath_cosf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::cosf_exact(x[i]); }
+void devmath_logf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = ansel_math::logf_exact(x[i]); }
+void libm_logf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = logf(x[i]); }
 void libm_sinf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = sinf(x[i]); }
 void libm_cosf(const float *x, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = cosf(x[i]); }
 void libm_fmodf(const float *x, const float *y, float *o, size_t n) { for(size_t i = 0; i < n; i++) o[i] = fmodf(x[i], y[i]); }
@@ -96,6 +98,12 @@ int main(int argc, char **argv)
     {
       a = (mode == 0) ? rnd_bits() : ((mode == 1) ? rnd_range(0.f, 2.f) : fabsf(rnd_bits()));
       b = 0; r0 = log2f(a); r1 = ansel_math::log2f_exact(a);
+    }
+    else if(!strcmp(fn, "logf"))
+    {
+      // mode 0: arbitrary bit patterns; 1: the uniform deviates of the Box-Muller caller; 2: positive patterns; 3: around 1
+      a = (mode == 0) ? rnd_bits() : ((mode == 1) ? rnd_range(0.f, 1.f) : ((mode == 2) ? fabsf(rnd_bits()) : rnd_range(0.9f, 1.1f)));
+      b = 0; r0 = logf(a); r1 = ansel_math::logf_exact(a);
     }
     else if(!strcmp(fn, "exp2f"))
     {

@@ -28,7 +28,7 @@ def _args(n, seed):
     return np.ascontiguousarray(x), np.ascontiguousarray(y)
 
 
-@pytest.mark.parametrize("fn", ["powf", "log2f", "exp2f", "expf", "atan2f", "hypotf", "sinf", "cosf", "fmodf"])
+@pytest.mark.parametrize("fn", ["powf", "log2f", "logf", "exp2f", "expf", "atan2f", "hypotf", "sinf", "cosf", "fmodf"])
 def test_device_libm_matches_host_libm(fn):
     n = 2_000_000
     x, y = _args(n, 17)
@@ -46,6 +46,8 @@ def test_device_libm_matches_host_libm(fn):
         rng = np.random.default_rng(7)
         x = np.concatenate([x[:n], (rng.random(n, dtype=np.float32) * 4.0 - 1.0).astype(np.float32), (rng.random(n, dtype=np.float32) * 2000.0 - 1000.0).astype(np.float32)])
         y = np.concatenate([y[:n], np.ones(n, np.float32), (rng.random(n, dtype=np.float32) * 7.0 + 0.01).astype(np.float32)])
+    if fn == "logf":
+        x = np.concatenate([x[:n], np.random.default_rng(8).random(2 * n, dtype=np.float32)])  # the Box-Muller deviates
     if fn == "expf":
         x = np.concatenate([x[:n], np.random.default_rng(4).random(2 * n, dtype=np.float32) * 205.0 - 110.0])
     h = hc.hip()

@@ -49,11 +49,36 @@ def test_diffuse_matches_cpu(preset, over, size, imgname):
         assert int((ck.ulp_diff(got, ref) > 0).sum()) == 0
 
 
-def test_diffuse_rejects_masked_inpainting():
-    w, h = 64, 48
-    img = synth.rgba_image(w, h, seed=1)
-    with pytest.raises(Exception):
-        hc.run_hip("dt_hip_iop_diffuse_process", abi.Piece.make(w, h), params.diffuse(threshold=1.0), img, img.shape)
+INPAINT_CASES = [
+    ("inpaint_highlights", dict(iterations=4, threshold=1.0), (333, 217)),
+    ("inpaint_highlights", dict(iterations=1, threshold=0.25, radius=8, sharpness=0.2), (640, 401)),
+    ("inpaint_highlights", dict(iterations=2, threshold=1.41), (417, 283)),          # the preset's threshold
+    ("lens_deblur_soft", dict(iterations=3, threshold=0.6), (500, 300)),
+    ("default", dict(threshold=1e-3), (97, 150)),                                      # nearly every pixel masked
+]
+
+
+@pytest.mark.parametrize("preset,over,size", INPAINT_CASES)
+@pytest.mark.parametrize("imgname", ["scene", "adversarial"])
+def test_diffuse_luminance_masked_inpainting(preset, over, size, imgname):
+    """threshold > 0 (build_mask / inpaint_mask, diffuse.c:1106-1152): pixels above the threshold are seeded with
+    Box-Muller noise drawn from a generator keyed on the pixel's position -- splitmix32, xoshiro128+, and the C
+    library's logf / cosf / sinf, all restated on the device -- and only they are diffused"""
+    w, h = size
+    img = synth.rgba_image(w, h, seed=8, lo=-0.02, hi=1.8) if imgname == "scene" else synth.adversarial_rgba(w, h)
+    piece = abi.Piece.make(w, h)
+    d = params.diffuse(preset, **over)
+    got = hc.run_hip("dt_hip_iop_diffuse_process", piece, d, img, img.shape)
+    want = _cpu("oracle", piece, d, img)
+    diff = ck.ulp_diff(got, want)
+    assert int((diff > 0).sum()) == 0, "%d values differ, max %d ulp" % (int((diff > 0).sum()), int(diff.max()))
+    ref = _cpu("ref", piece, d, img)
+    if ref is not None:
+        assert int((ck.ulp_diff(got, ref) > 0).sum()) == 0
+    if imgname == "scene":
+        masked = (img[..., :3] > d.threshold).any(axis=2)
+        assert 0 < masked.sum()
+        assert not np.array_equal(got[masked], img[masked])
 
 
 def test_diffuse_tiling_follows_the_reference():

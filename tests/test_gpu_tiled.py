@@ -120,10 +120,16 @@ def _full_nodes(w, h, d_lut, lut, which):
                                     filmic=filmic.default_data(), diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
     drop = {"wavelets": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "diffuse": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
+            "diffuse_inpaint": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "nlmeans": ("denoiseprofile", "diffuse"),
             "dn_nlmeans": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "all": ()}[which]
     nodes = [n for n in nodes if n.op not in drop]
+    if which == "diffuse_inpaint":
+        # threshold > 0: the inpainting noise is keyed on the pixel's position in the FRAME
+        for n in nodes:
+            if n.op == "diffuse":
+                n.data = params.diffuse("inpaint_highlights", iterations=2, threshold=0.05)
     if which == "dn_nlmeans":
         for n in nodes:
             if n.op == "denoiseprofile":
@@ -131,7 +137,7 @@ def _full_nodes(w, h, d_lut, lut, which):
     return nodes
 
 
-@pytest.mark.parametrize("which", ["wavelets", "diffuse", "nlmeans", "dn_nlmeans", "all"])
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "all"])
 @pytest.mark.parametrize("w,h,n", [(752, 2000, 2), (752, 2000, 5), (400, 640, 2), (400, 640, 1)])
 def test_full_pipe_bands_equal_the_unsplit_frame(w, h, n, which):
     """denoise (profiled) wavelets / non-local means, diffuse-or-sharpen and nlmeans on row bands: halo rows

@@ -152,6 +152,10 @@ DIFFUSE_CASES = [
     ("lens_deblur_soft", dict(iterations=2, anisotropy_first=-2.0, anisotropy_second=1.5, anisotropy_fourth=-3.0,
                               variance_threshold=-0.5, regularization=2.5)),
     ("fast_local_contrast", dict(radius=40, radius_center=24)),
+    # luminance-masked inpainting: build_mask / inpaint_mask with the position-seeded Box-Muller noise (diffuse.c:1106-1152)
+    ("inpaint_highlights", dict(iterations=3, threshold=1.0)),
+    ("inpaint_highlights", dict(iterations=2, threshold=0.25, radius=8, sharpness=0.2)),
+    ("lens_deblur_soft", dict(iterations=2, threshold=0.6)),
 ]
 
 

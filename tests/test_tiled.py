@@ -126,10 +126,16 @@ def _full_nodes(w, h, lut, which):
                                     diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
     drop = {"wavelets": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "diffuse": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
+            "diffuse_inpaint": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "nlmeans": ("denoiseprofile", "diffuse"),
             "dn_nlmeans": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "all": ()}[which]
     nodes = [n for n in nodes if n.op not in drop]
+    if which == "diffuse_inpaint":
+        # threshold > 0: the inpainting noise is keyed on the pixel's position in the FRAME
+        for n in nodes:
+            if n.op == "diffuse":
+                n.data = params.diffuse("inpaint_highlights", iterations=2, threshold=0.05)
     if which == "dn_nlmeans":
         for n in nodes:
             if n.op == "denoiseprofile":
@@ -185,7 +191,7 @@ def _full_rank_main(rank, world, port, w, h, which, outdir):
 
 
 @needs_oracle
-@pytest.mark.parametrize("which", ["wavelets", "diffuse", "nlmeans", "dn_nlmeans", "all"])
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "all"])
 def test_two_ranks_full_pipe_over_gloo_equal_the_unsplit_frame(tmp_path, which):
     """halo send/recv of float4 rows + the all-reduce of the wavelets, and the halo sizes themselves: a band cut
     from a frame that is zero beyond the halo equals the rows of the real frame only if the halo is enough"""
