@@ -80,7 +80,7 @@ class HighlightsData(C.Structure):
 
 class DemosaicData(C.Structure):
     _fields_ = [("green_eq", C.c_uint32), ("color_smoothing", C.c_uint32),
-                ("demosaicing_method", C.c_uint32), ("median_thrs", C.c_float)]
+                ("demosaicing_method", C.c_uint32), ("median_thrs", C.c_float), ("green_eq_threshold", C.c_float)]
 
 
 class ExposureData(C.Structure):

@@ -1,12 +1,17 @@
 // demosaic.cpp -- device entry of the demosaic module: the part of process()/process_cl()
 // (src/iop/demosaic.c:1041-1253, :1443-1530) that picks the interpolation for a Bayer mosaic.
 #include "hip_common.h"
+#include <math.h>
 
 namespace ansel
 {
 int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out,
                         const rcd_band_t *band);
-int ppg_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
+int ppg_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, const float *in_pass1,
+                        float4 *out);
+int green_eq_lavg_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, int x, int y, float thr);
+int pre_median_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, float threshold);
+int color_smoothing_launch(int devid, float4 *img, int width, int height, int passes);
 int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
 }
 extern "C" uint32_t dt_hip_crop_dcraw_filters(uint32_t filters, uint32_t crop_x, uint32_t crop_y);
@@ -24,9 +29,16 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
     set_last_error("demosaic: only Bayer mosaics are implemented on device");
     return DT_HIP_INVALID_ARG;
   }
-  if(d->green_eq || d->color_smoothing || d->median_thrs != 0.0f)
+  if(d->green_eq > 1)
   {
-    set_last_error("demosaic: green equilibration / colour smoothing / median are not implemented on device");
+    // green_equilibration_favg(), basic.c:296-329: the ratio of two binary64 OpenMP sums over the frame
+    set_last_error("demosaic: the full-average green equilibration depends on the host's thread count: not reproduced");
+    return DT_HIP_INVALID_ARG;
+  }
+  if(d->color_smoothing > 5 || (d->median_thrs != 0.0f && d->demosaicing_method != DT_HIP_DEMOSAIC_PPG))
+  {
+    set_last_error("demosaic: %u smoothing passes / a median threshold with method %u are not states of the module",
+                   d->color_smoothing, d->demosaicing_method);
     return DT_HIP_INVALID_ARG;
   }
   if(piece->roi_out.width != piece->roi_in.width || piece->roi_out.height != piece->roi_in.height)
@@ -35,30 +47,63 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
     set_last_error("demosaic: roi_in and roi_out differ");
     return DT_HIP_INVALID_ARG;
   }
+  if(band && (d->green_eq || d->color_smoothing))
+  {
+    set_last_error("demosaic: green equilibration / colour smoothing have no row-band mode");
+    return DT_HIP_INVALID_ARG;
+  }
+  const int w = piece->roi_in.width, h = piece->roi_in.height;
+  if(w <= 0 || h <= 0) return DT_HIP_SUCCESS;
   // dt_dev_get_roi_filters(), src/develop/imageop.c:139-142
   const uint32_t filters = dt_hip_crop_dcraw_filters(piece->filters, piece->roi_in.x, piece->roi_in.y);
-  switch(d->demosaicing_method)
+  const float *in = (const float *)dev_in;
+  float *geq = nullptr, *med = nullptr;
+  int err = DT_HIP_SUCCESS;
+  if(d->green_eq == 1)
   {
-    case DT_HIP_DEMOSAIC_RCD:
-      return rcd_demosaic_launch(devid, piece, filters, (const float *)dev_in, (float4 *)dev_out, band);
-    case DT_HIP_DEMOSAIC_PPG:
-      if(band)
-      {
-        set_last_error("demosaic: PPG has no row-band mode");
-        return DT_HIP_INVALID_ARG;
-      }
-      return ppg_demosaic_launch(devid, piece, filters, (const float *)dev_in, (float4 *)dev_out);
-    case DT_HIP_DEMOSAIC_AMAZE:
-      if(band)
-      {
-        set_last_error("demosaic: AMaZE has no row-band mode");
-        return DT_HIP_INVALID_ARG;
-      }
-      return amaze_demosaic_launch(devid, piece, filters, (const float *)dev_in, (float4 *)dev_out);
-    default:
-      set_last_error("demosaic: method %u is not implemented on device", d->demosaicing_method);
-      return DT_HIP_INVALID_ARG;
+    geq = (float *)dt_hip_alloc_device_buffer(devid, (size_t)w * h * sizeof(float));
+    err = geq ? green_eq_lavg_launch(devid, in, geq, w, h, piece->filters, piece->roi_in.x, piece->roi_in.y, d->green_eq_threshold)
+              : DT_HIP_SYSMEM_ALLOCATION;
+    in = geq;
   }
+  if(err == DT_HIP_SUCCESS)
+    switch(d->demosaicing_method)
+    {
+      case DT_HIP_DEMOSAIC_RCD:
+        err = rcd_demosaic_launch(devid, piece, filters, in, (float4 *)dev_out, band);
+        break;
+      case DT_HIP_DEMOSAIC_PPG:
+        if(band)
+        {
+          set_last_error("demosaic: PPG has no row-band mode");
+          err = DT_HIP_INVALID_ARG;
+          break;
+        }
+        if(d->median_thrs > 0.0f)
+        {
+          med = (float *)dt_hip_alloc_device_buffer(devid, (size_t)w * h * sizeof(float));
+          err = med ? pre_median_launch(devid, in, med, w, h, filters, d->median_thrs) : DT_HIP_SYSMEM_ALLOCATION;
+        }
+        if(err == DT_HIP_SUCCESS) err = ppg_demosaic_launch(devid, piece, filters, med ? med : in, in, (float4 *)dev_out);
+        break;
+      case DT_HIP_DEMOSAIC_AMAZE:
+        if(band)
+        {
+          set_last_error("demosaic: AMaZE has no row-band mode");
+          err = DT_HIP_INVALID_ARG;
+          break;
+        }
+        err = amaze_demosaic_launch(devid, piece, filters, in, (float4 *)dev_out);
+        break;
+      default:
+        set_last_error("demosaic: method %u is not implemented on device", d->demosaicing_method);
+        err = DT_HIP_INVALID_ARG;
+    }
+  if(err == DT_HIP_SUCCESS && d->color_smoothing)
+    err = color_smoothing_launch(devid, (float4 *)dev_out, piece->roi_out.width, piece->roi_out.height, (int)d->color_smoothing);
+  if(geq) dt_hip_release_mem_object(geq);
+  if(med) dt_hip_release_mem_object(med);
+  return err;
 }
 
 } // namespace ansel
@@ -71,12 +116,17 @@ int dt_hip_iop_demosaic_process(int devid, const dt_hip_piece_t *piece, const dt
   return dt_hip_iop_demosaic_process_band(devid, piece, d, nullptr, dev_in, dev_out);
 }
 
-// tiling_callback(), src/iop/demosaic.c:1930-1990: RCD overlap 10, PPG/AMaZE 5; 2x2 alignment
+// tiling_callback(), src/iop/demosaic.c:1916-1990, Bayer methods: factor in units of the larger (output) buffer as the
+// reference counts them -- in + out + max(tmp + green-eq copy, smoothing copy); RCD overlap 10, PPG / AMaZE 5; 2x2
+// alignment.  factor_cl: what this implementation holds -- the mosaic and its green-equalised / median-filtered
+// copies are a quarter of an output buffer each, colour smoothing runs in place
 void dt_hip_iop_demosaic_tiling(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d, dt_hip_tiling_t *tiling)
 {
-  (void)piece;
-  tiling->factor = 1.0f + 4.0f; // in (1 ch) + out (4 ch), in units of the input buffer
-  tiling->factor_cl = tiling->factor;
+  const float ioratio = (float)piece->roi_out.width * piece->roi_out.height / ((float)piece->roi_in.width * piece->roi_in.height);
+  const float smooth = d->color_smoothing ? ioratio : 0.0f;
+  const float greeneq = (piece->filters != 9u && d->green_eq) ? 0.25f : 0.0f;
+  tiling->factor = 1.0f + ioratio + fmaxf(1.0f + greeneq, smooth);
+  tiling->factor_cl = ioratio + 0.25f + greeneq + (d->median_thrs > 0.0f ? 0.25f : 0.0f);
   tiling->maxbuf = 1.0f;
   tiling->maxbuf_cl = 1.0f;
   tiling->overhead = 0;

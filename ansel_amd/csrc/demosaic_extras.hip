@@ -1,0 +1,166 @@
+// demosaic_extras.hip -- the optional steps process() runs around the interpolation (src/iop/demosaic.c:1137-1250):
+//   green_equilibration_lavg()  src/iop/demosaic/basic.c:248-293   on the mosaic, before
+//   pre_median()                src/iop/demosaic/basic.c:136-186   on the green sites, inside demosaic_ppg() (ppg.c:58-67)
+//   color_smoothing()           src/iop/demosaic/basic.c:191-243   on the output, after
+// All three are local: one thread per pixel, reads through L1/L2.  Algorithmic bytes: 8 / 8 / 2 x (16 + 16 + 16) per pass.
+#include "hip_common.h"
+
+using namespace ansel;
+
+namespace
+{
+
+__device__ __forceinline__ int fc(const int row, const int col, const uint32_t filters)
+{
+  return filters >> (((row << 1 & 14) + (col & 1)) << 1) & 3; // FC(), src/develop/imageop_math.h:190
+}
+
+__global__ __launch_bounds__(256) void green_eq_lavg(const float *__restrict__ in, float *__restrict__ out, const int width,
+                                                     const int height, const int oj, const int oi, const float thr)
+{
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(i >= width || j >= height) return;
+  const size_t w = (size_t)width, p = (size_t)j * w + i;
+  float v = in[p];
+  if(j >= oj && j < height - 2 && ((j - oj) & 1) == 0 && i >= oi && i < width - 2 && ((i - oi) & 1) == 0)
+  {
+    const float maximum = 1.0f;
+    const float o1_1 = in[p - w - 1], o1_2 = in[p - w + 1], o1_3 = in[p + w - 1], o1_4 = in[p + w + 1];
+    const float o2_1 = in[p - 2 * w], o2_2 = in[p + 2 * w], o2_3 = in[p - 2], o2_4 = in[p + 2];
+    const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
+    const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
+    if((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f))
+    {
+      const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4)
+                        + fabsf(o1_2 - o1_4)) / 6.0f;
+      const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4)
+                        + fabsf(o2_2 - o2_4)) / 6.0f;
+      if((v < maximum * 0.95f) && (c1 < maximum * thr) && (c2 < maximum * thr)) v = v * m1 / m2;
+    }
+  }
+  out[p] = v;
+}
+
+// pre_median_b(), one pass: the exchange order of the reference's sort is kept (it decides where a NaN ends up)
+__global__ __launch_bounds__(256) void pre_median(const float *__restrict__ in, float *__restrict__ out, const int width,
+                                                  const int height, const uint32_t filters, const float threshold)
+{
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), row = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(col >= width || row >= height) return;
+  const size_t p = (size_t)row * width + col;
+  float v = in[p];
+  const int f3 = fc(row, 3, filters);
+  const int col0 = (f3 != 1 && f3 != 3) ? 4 : 3;
+  if(row >= 3 && row < height - 3 && col >= col0 && col < width - 3 && ((col - col0) & 1) == 0)
+  {
+    float med[9];
+    int cnt = 0;
+    // the diamond of same-colour neighbours, rows -2..2 with column offsets {0}, {-1, 1}, {-2, 0, 2}, {-1, 1}, {0} (:142-168)
+    const int dy[9] = { -2, -1, -1, 0, 0, 0, 1, 1, 2 }, dx[9] = { 0, -1, 1, -2, 0, 2, -1, 1, 0 };
+#pragma unroll
+    for(int k = 0; k < 9; k++)
+    {
+      const float s = in[p + (ptrdiff_t)width * dy[k] + dx[k]];
+      if(fabsf(s - v) < threshold)
+      {
+        med[k] = s;
+        cnt++;
+      }
+      else
+        med[k] = 64.0f + s;
+    }
+#pragma unroll
+    for(int i = 0; i < 8; i++)
+#pragma unroll
+      for(int ii = i + 1; ii < 9; ii++)
+        if(med[i] > med[ii])
+        {
+          const float t = med[i];
+          med[i] = med[ii];
+          med[ii] = t;
+        }
+    // med[(cnt - 1) / 2] with cnt = 1..9 (the centre always counts unless it is NaN: cnt 0 -> med[0], C truncation)
+    const int idx = (cnt - 1) / 2;
+    float pick = med[0];
+#pragma unroll
+    for(int q = 1; q < 5; q++) pick = idx == q ? med[q] : pick;
+    v = (cnt == 1) ? med[4] - 64.0f : pick;
+  }
+  out[p] = v;
+}
+
+// color_smoothing(): first the channel goes to alpha over the whole frame, then the 3x3 median of (alpha - green)
+__global__ __launch_bounds__(256) void smooth_stash(float4 *__restrict__ img, const size_t npixels, const int c)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= npixels) return;
+  float4 v = img[k];
+  v.w = c == 0 ? v.x : v.z;
+  img[k] = v;
+}
+
+__global__ __launch_bounds__(256) void smooth_median(float4 *__restrict__ img, const int width, const int height, const int c)
+{
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(i < 1 || j < 1 || i >= width - 1 || j >= height - 1) return;
+  const size_t p = (size_t)j * width + i;
+  float med[9];
+#pragma unroll
+  for(int dj = -1; dj <= 1; dj++)
+#pragma unroll
+    for(int di = -1; di <= 1; di++)
+    {
+      // alpha and green of the neighbours: neither is written by this launch (it stores red or blue only)
+      const float *const n = reinterpret_cast<const float *>(img + (p + (ptrdiff_t)dj * width + di));
+      med[3 * (dj + 1) + (di + 1)] = n[3] - n[1];
+    }
+#define SWAPmed(I, J) if(med[I] > med[J]) { const float t_ = med[I]; med[I] = med[J]; med[J] = t_; }
+  SWAPmed(1, 2) SWAPmed(4, 5) SWAPmed(7, 8) SWAPmed(0, 1) SWAPmed(3, 4) SWAPmed(6, 7) SWAPmed(1, 2) SWAPmed(4, 5)
+  SWAPmed(7, 8) SWAPmed(0, 3) SWAPmed(5, 8) SWAPmed(4, 7) SWAPmed(3, 6) SWAPmed(1, 4) SWAPmed(2, 5) SWAPmed(4, 7)
+  SWAPmed(4, 2) SWAPmed(6, 4) SWAPmed(4, 2)
+#undef SWAPmed
+  const float own_green = reinterpret_cast<const float *>(img + p)[1];
+  const float r = fmaxf(med[4] + own_green, 0.0f);
+  float *const o = reinterpret_cast<float *>(img + p);
+  o[c] = r;
+}
+
+} // namespace
+
+namespace ansel
+{
+
+int green_eq_lavg_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, int x, int y, float thr)
+{
+  auto FCh = [&](int row, int col) { return (int)(filters >> (((row << 1 & 14) + (col & 1)) << 1) & 3); };
+  int oj = 2, oi = 2;
+  if(FCh(oj + y, oi + x) != 1) oj++;
+  if(FCh(oj + y, oi + x) != 1) oi++;
+  if(FCh(oj + y, oi + x) != 1) oj--;
+  launch_scope ls(devid, "green_eq_lavg");
+  green_eq_lavg<<<dim3((width + 63) / 64, (height + 3) / 4), 256, 0, stream_of(devid)>>>(in, out, width, height, oj, oi, thr);
+  return check_launch("green_eq_lavg");
+}
+
+int pre_median_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, float threshold)
+{
+  launch_scope ls(devid, "pre_median");
+  pre_median<<<dim3((width + 63) / 64, (height + 3) / 4), 256, 0, stream_of(devid)>>>(in, out, width, height, filters, threshold);
+  return check_launch("pre_median");
+}
+
+int color_smoothing_launch(int devid, float4 *img, int width, int height, int passes)
+{
+  hipStream_t s = stream_of(devid);
+  const size_t np = (size_t)width * height;
+  launch_scope ls(devid, "color_smoothing");
+  for(int pass = 0; pass < passes; pass++)
+    for(int c = 0; c < 3; c += 2)
+    {
+      smooth_stash<<<pixel_grid(np), 256, 0, s>>>(img, np, c);
+      smooth_median<<<dim3((width + 63) / 64, (height + 3) / 4), 256, 0, s>>>(img, width, height, c);
+    }
+  return check_launch("color_smoothing");
+}
+
+} // namespace ansel

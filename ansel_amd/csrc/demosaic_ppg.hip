@@ -1,5 +1,5 @@
 // demosaic_ppg.hip -- PPG demosaic of a Bayer mosaic: demosaic_ppg(), src/iop/demosaic/ppg.c:20-217
-// (median pre-filter off).  One launch, one thread per finished float4 pixel: see ppg_device.h.
+// (the median pre-filter is demosaic_extras.hip's pre_median; pass 1 then reads the unfiltered mosaic).  One launch, one thread per finished float4 pixel: see ppg_device.h.
 // Algorithmic bytes: 4 read + 16 written per pixel.
 #include "hip_common.h"
 #include "ppg_device.h"
@@ -32,10 +32,12 @@ __global__ __launch_bounds__(256) void ppg_full(float4 *__restrict__ out, const 
 
 namespace ansel
 {
-int ppg_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out)
+int ppg_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, const float *in_pass1,
+                        float4 *out)
 {
   ppg_ctx k;
   k.in = in;
+  k.in1 = in_pass1;
   k.iw = piece->roi_in.width;
   k.ih = piece->roi_in.height;
   k.w = piece->roi_out.width;

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void rcd_border(const float *__restrict__ in, 
   // band mode: the ring pixel reads frame rows j-4..j+4, all inside the band's halo (>= 9 rows) or
   // outside the frame (never dereferenced); address the band buffer as if it were the whole frame
   const float *frame = in - (ptrdiff_t)in_row0 * width;
-  const ppg_ctx k = { frame, width, height, width, height, 0, 0, filters };
+  const ppg_ctx k = { frame, width, height, width, height, 0, 0, filters, nullptr };
   (void)in_rows;
   const float4 v = ppg_pixel<true>(k, j, i);
   float4 *const o = out + (size_t)(j - out_row0) * width + i;

@@ -25,7 +25,14 @@ struct ppg_ctx
   int w, h;   // output geometry
   int ox, oy; // output window origin inside the input
   uint32_t filters;
+  const float *in1; // what pass 1 reads: the mosaic before PPG's median pre-filter (ppg.c:30-57 vs :60-67); nullptr = in
 };
+
+template <bool CLAMP> __device__ __forceinline__ float bs1(const ppg_ctx &k, const int j, const int i)
+{
+  const float v = (k.in1 ? k.in1 : k.in)[(size_t)(j + k.oy) * k.iw + i + k.ox];
+  return CLAMP ? fmaxf(0.0f, v) : v;
+}
 
 template <bool CLAMP> __device__ __forceinline__ float bs(const ppg_ctx &k, const int j, const int i)
 {
@@ -48,7 +55,7 @@ template <bool CLAMP> __device__ void ppg_pass1(const ppg_ctx &k, const int j, c
       if(yy >= 0 && xx >= 0 && yy < k.ih && xx < k.iw)
       {
         const int f = ppg_fc(y, x, k.filters);
-        const float v = bs<CLAMP>(k, y, x);
+        const float v = bs1<CLAMP>(k, y, x);
 #pragma unroll
         for(int c = 0; c < 4; c++)
           if(c == f)
@@ -59,7 +66,7 @@ template <bool CLAMP> __device__ void ppg_pass1(const ppg_ctx &k, const int j, c
       }
     }
   const int f = ppg_fc(j, i, k.filters);
-  const float self = bs<CLAMP>(k, j, i);
+  const float self = bs1<CLAMP>(k, j, i);
 #pragma unroll
   for(int c = 0; c < 3; c++) rgb[c] = (c != f && cnt[c] > 0.0f) ? sum[c] / cnt[c] : self;
 }

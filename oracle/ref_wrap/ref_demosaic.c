@@ -41,13 +41,27 @@ int ref_demosaic(const dt_hip_piece_t *v, const dt_hip_demosaic_data_t *d, const
   dt_iop_roi_t roo = piece.roi_out;
   roo.x = roo.y = 0;
   const uint32_t filters = ref_shift_dcraw_filters(v->filters, piece.roi_in.x, piece.roi_in.y);
+  /* the optional steps of process(), demosaic.c:1137-1250, in its order */
+  float *geq = NULL;
+  if(d->green_eq == 1)
+  {
+    geq = (float *)malloc(sizeof(float) * (size_t)roi.width * roi.height);
+    if(!geq) return 1;
+    green_equilibration_lavg(geq, (const float *)in, roi.width, roi.height, v->filters, roi.x, roi.y, d->green_eq_threshold);
+    in = geq;
+  }
+  else if(d->green_eq)
+    return 1;
+  int rc = 0;
   if(d->demosaicing_method == DT_HIP_DEMOSAIC_RCD)
     rcd_demosaic(&piece, (float *)out, (const float *)in, &roo, &roi, filters);
   else if(d->demosaicing_method == DT_HIP_DEMOSAIC_AMAZE)
     amaze_demosaic_RT(&piece, (const float *)in, (float *)out, &roi, &roo, filters);
   else if(d->demosaicing_method == DT_HIP_DEMOSAIC_PPG)
-    return demosaic_ppg((float *)out, (const float *)in, &roo, &roi, filters, d->median_thrs);
+    rc = demosaic_ppg((float *)out, (const float *)in, &roo, &roi, filters, d->median_thrs);
   else
-    return 1;
-  return 0;
+    rc = 1;
+  free(geq);
+  if(rc == 0 && d->color_smoothing) color_smoothing((float *)out, &roo, (int)d->color_smoothing);
+  return rc;
 }

@@ -269,7 +269,7 @@ static int rcd_run(float *out, const float *in, const int width, const int heigh
 {
   if(width < 16 || height < 16) return 0; /* rcd.c:280-284: logs and leaves the output untouched */
   /* border first (rcd.c:286), then the tiles overwrite everything from row/col RCD_MARGIN on */
-  const ppg_ctx_t k = { in, width, height, width, height, 0, 0, filters, 1 };
+  const ppg_ctx_t k = { in, width, height, width, height, 0, 0, filters, 1, NULL };
   for(int j = 0; j < height; j++)
     for(int i = 0; i < width; i++)
     {
@@ -330,15 +330,13 @@ uint32_t oracle_shift_dcraw_filters(uint32_t filters, uint32_t x, uint32_t y)
   return out;
 }
 
-int oracle_demosaic_ppg(float *out, const float *in, const dt_hip_roi_t *roi_out, const dt_hip_roi_t *roi_in, uint32_t filters);
+int oracle_demosaic_ppg(float *out, const float *in, const dt_hip_roi_t *roi_out, const dt_hip_roi_t *roi_in, uint32_t filters,
+                        float median_thrs);
 int oracle_demosaic_amaze(float *out, const float *in, const dt_hip_roi_t *roi_out, const dt_hip_roi_t *roi_in,
                           uint32_t filters, float clip_pt);
 
-/* process(), src/iop/demosaic.c:1041-1253, Bayer branch with green_eq off, no colour smoothing */
-int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d, const void *in, void *out)
+static int demosaic_methods(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d, const float *in, void *out)
 {
-  if(d->green_eq || d->color_smoothing || d->median_thrs != 0.0f) return 1;
-  if(!piece->filters || piece->filters == 9u) return 1;
   const uint32_t filters = oracle_shift_dcraw_filters(piece->filters, piece->roi_in.x, piece->roi_in.y);
   if(d->demosaicing_method == DT_HIP_DEMOSAIC_RCD)
     return rcd_run((float *)out, (const float *)in, piece->roi_in.width, piece->roi_in.height, filters,
@@ -347,7 +345,7 @@ int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d
   {
     dt_hip_roi_t roo = piece->roi_out;
     roo.x = roo.y = 0;
-    return oracle_demosaic_ppg((float *)out, (const float *)in, &roo, &piece->roi_in, filters);
+    return oracle_demosaic_ppg((float *)out, (const float *)in, &roo, &piece->roi_in, filters, d->median_thrs);
   }
   if(d->demosaicing_method == DT_HIP_DEMOSAIC_AMAZE)
   {
@@ -358,4 +356,92 @@ int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d
     return oracle_demosaic_amaze((float *)out, (const float *)in, &roo, &piece->roi_in, filters, clip_pt);
   }
   return 1;
+}
+
+/* green_equilibration_lavg(), src/iop/demosaic/basic.c:248-293 */
+static void green_eq_lavg(float *out, const float *in, const int width, const int height, const uint32_t filters, const int x,
+                          const int y, const float thr)
+{
+  const float maximum = 1.0f;
+  int oj = 2, oi = 2;
+  if(oracle_fc(oj + y, oi + x, filters) != 1) oj++;
+  if(oracle_fc(oj + y, oi + x, filters) != 1) oi++;
+  if(oracle_fc(oj + y, oi + x, filters) != 1) oj--;
+  memcpy(out, in, sizeof(float) * (size_t)width * height);
+  for(size_t j = oj; j + 2 < (size_t)height; j += 2)
+    for(size_t i = oi; i + 2 < (size_t)width; i += 2)
+    {
+      const float o1_1 = in[(j - 1) * width + i - 1], o1_2 = in[(j - 1) * width + i + 1];
+      const float o1_3 = in[(j + 1) * width + i - 1], o1_4 = in[(j + 1) * width + i + 1];
+      const float o2_1 = in[(j - 2) * width + i], o2_2 = in[(j + 2) * width + i];
+      const float o2_3 = in[j * width + i - 2], o2_4 = in[j * width + i + 2];
+      const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
+      const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
+      if((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f))
+      {
+        const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4)
+                          + fabsf(o1_2 - o1_4)) / 6.0f;
+        const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4)
+                          + fabsf(o2_2 - o2_4)) / 6.0f;
+        if((in[j * width + i] < maximum * 0.95f) && (c1 < maximum * thr) && (c2 < maximum * thr))
+          out[j * width + i] = in[j * width + i] * m1 / m2;
+      }
+    }
+}
+
+/* color_smoothing(), src/iop/demosaic/basic.c:191-243: `passes` x (red, blue): the channel minus green goes through a
+ * 3x3 median (the reference's 19-exchange network, whose result for NaN operands depends on the exchange order) */
+static void color_smoothing(float *out, const int width, const int height, const int passes)
+{
+  const int width4 = 4 * width;
+#define SWAPmed(I, J) if(med[I] > med[J]) { const float t_ = med[I]; med[I] = med[J]; med[J] = t_; }
+  for(int pass = 0; pass < passes; pass++)
+    for(int c = 0; c < 3; c += 2)
+    {
+      for(size_t k = 0; k < (size_t)width * height; k++) out[4 * k + 3] = out[4 * k + c];
+#pragma omp parallel for
+      for(int j = 1; j < height - 1; j++)
+      {
+        float *outp = out + (size_t)4 * j * width + 4;
+        for(int i = 1; i < width - 1; i++, outp += 4)
+        {
+          float med[9] = {
+            outp[-width4 - 4 + 3] - outp[-width4 - 4 + 1], outp[-width4 + 0 + 3] - outp[-width4 + 0 + 1],
+            outp[-width4 + 4 + 3] - outp[-width4 + 4 + 1], outp[-4 + 3] - outp[-4 + 1],
+            outp[+0 + 3] - outp[+0 + 1], outp[+4 + 3] - outp[+4 + 1],
+            outp[+width4 - 4 + 3] - outp[+width4 - 4 + 1], outp[+width4 + 0 + 3] - outp[+width4 + 0 + 1],
+            outp[+width4 + 4 + 3] - outp[+width4 + 4 + 1],
+          };
+          SWAPmed(1, 2) SWAPmed(4, 5) SWAPmed(7, 8) SWAPmed(0, 1) SWAPmed(3, 4) SWAPmed(6, 7) SWAPmed(1, 2) SWAPmed(4, 5)
+          SWAPmed(7, 8) SWAPmed(0, 3) SWAPmed(5, 8) SWAPmed(4, 7) SWAPmed(3, 6) SWAPmed(1, 4) SWAPmed(2, 5) SWAPmed(4, 7)
+          SWAPmed(4, 2) SWAPmed(6, 4) SWAPmed(4, 2)
+          outp[c] = fmaxf(med[4] + outp[1], 0.0f);
+        }
+      }
+    }
+#undef SWAPmed
+}
+
+/* process(), src/iop/demosaic.c:1041-1253, Bayer branch: [green equilibration, local average] -> demosaic ->
+ * [colour smoothing].  The "full average" equilibration (basic.c:296-329) scales one green by the ratio of two
+ * binary64 OpenMP sums over the frame -- not a function of the input alone; neither this nor the device runs it. */
+int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d, const void *in_, void *out)
+{
+  if(d->green_eq > 1 || d->color_smoothing > 5) return 1;
+  if(d->median_thrs != 0.0f && d->demosaicing_method != DT_HIP_DEMOSAIC_PPG) return 1;
+  if(!piece->filters || piece->filters == 9u) return 1;
+  const float *in = (const float *)in_;
+  float *geq = NULL;
+  if(d->green_eq == 1)
+  {
+    geq = (float *)malloc(sizeof(float) * (size_t)piece->roi_in.width * piece->roi_in.height);
+    if(!geq) return 1;
+    green_eq_lavg(geq, in, piece->roi_in.width, piece->roi_in.height, piece->filters, piece->roi_in.x, piece->roi_in.y,
+                  d->green_eq_threshold);
+    in = geq;
+  }
+  const int rc = demosaic_methods(piece, d, in, out);
+  free(geq);
+  if(rc == 0 && d->color_smoothing) color_smoothing((float *)out, piece->roi_out.width, piece->roi_out.height, (int)d->color_smoothing);
+  return rc;
 }

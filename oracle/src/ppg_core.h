@@ -26,6 +26,8 @@ typedef struct
   int ox, oy; /* position of the output window inside the input */
   uint32_t filters;
   int clamp;  /* 1: samples go through fmaxf(0, .)  (rcd_ppg_border) */
+  const float *in1; /* what pass 1 reads: the mosaic BEFORE the median pre-filter (ppg.c:30-57 run on `in`, the later
+                       passes on `input`, :60-67); NULL = in */
 } ppg_ctx_t;
 
 static inline float ppg_s(const ppg_ctx_t *k, const int j, const int i)
@@ -50,12 +52,17 @@ static inline void ppg_pass1(const ppg_ctx_t *k, const int j, const int i, float
       if(yy >= 0 && xx >= 0 && yy < k->ih && xx < k->iw)
       {
         const int f = oracle_fc(y, x, k->filters);
-        sum[f] += ppg_s(k, y, x);
+        {
+          const float v1 = (k->in1 ? k->in1 : k->in)[(size_t)(y + k->oy) * k->iw + x + k->ox];
+          sum[f] += k->clamp ? fmaxf(0.0f, v1) : v1;
+        }
         sum[f + 4]++;
       }
     }
   const int f = oracle_fc(j, i, k->filters);
-  for(int c = 0; c < 3; c++) rgb[c] = (c != f && sum[c + 4] > 0.0f) ? sum[c] / sum[c + 4] : ppg_s(k, j, i);
+  const float own1 = (k->in1 ? k->in1 : k->in)[(size_t)(j + k->oy) * k->iw + i + k->ox];
+  const float own = k->clamp ? fmaxf(0.0f, own1) : own1;
+  for(int c = 0; c < 3; c++) rgb[c] = (c != f && sum[c + 4] > 0.0f) ? sum[c] / sum[c + 4] : own;
 }
 
 /* pass 2 green at a red/blue site: ppg.c:83-115 / rcd.c:146-187 */

@@ -85,3 +85,56 @@ def test_demosaic_rejects_unsupported():
     d2 = abi.DemosaicData(0, 0, 3, 0.0)
     piece2 = abi.Piece.make(64, 64, filters=synth.FILTERS_RGGB, channels=1)
     assert h_.dt_hip_iop_demosaic_process(0, C.byref(piece2), C.byref(d2), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
+
+
+EXTRAS = [
+    # (method, green_eq, colour smoothing passes, PPG median threshold, green_eq threshold)
+    (abi.DT_HIP_DEMOSAIC_PPG, 0, 0, 0.05, 0.0),
+    (abi.DT_HIP_DEMOSAIC_PPG, 0, 0, 1.0, 0.0),
+    (abi.DT_HIP_DEMOSAIC_PPG, 1, 2, 0.02, 0.08),
+    (abi.DT_HIP_DEMOSAIC_PPG, 0, 5, 0.0, 0.0),
+    (abi.DT_HIP_DEMOSAIC_RCD, 1, 0, 0.0, 0.64),
+    (abi.DT_HIP_DEMOSAIC_RCD, 1, 3, 0.0, 0.01),
+    (abi.DT_HIP_DEMOSAIC_AMAZE, 1, 1, 0.0, 0.32),
+]
+
+
+@pytest.mark.parametrize("w,h,xy", [(640, 400, (0, 0)), (207, 131, (1, 1)), (1504, 1000, (1, 0)), (120, 96, (0, 1))])
+@pytest.mark.parametrize("method,geq,smooth,median,geq_thr", EXTRAS)
+def test_demosaic_optional_steps(w, h, xy, method, geq, smooth, median, geq_thr):
+    """green equilibration (local average), PPG's median pre-filter, colour smoothing (demosaic.c:1137-1250,
+    demosaic/basic.c:136-293) around each interpolation, for every CFA phase of the roi origin: HIP == oracle"""
+    import ctypes as C
+    import numpy as np
+    import checkers as ck
+    import hipcheck as hc
+    from ansel_amd import synth
+    rng = np.random.default_rng(w + 3 * h + 7 * method)
+    cfa = synth.bayer_mosaic(w, h, seed=5).astype(np.float32)
+    img = ((cfa - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    if method != abi.DT_HIP_DEMOSAIC_AMAZE:  # AMaZE with non-finite samples is not reproduced (DESIGN.md section 3)
+        img[rng.integers(4, h - 4, 6), rng.integers(4, w - 4, 6)] = [0.0, -0.01, 2.0, np.nan, np.inf, 1e-30]
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(xy[0], xy[1], w, h), roi_out=abi.Roi.make(xy[0], xy[1], w, h))
+    d = abi.DemosaicData(geq, smooth, method, median, geq_thr)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4), pre_fill=np.zeros((h, w, 4), np.float32))
+    want = np.zeros((h, w, 4), np.float32)
+    assert ck.call(ck.oracle(), "oracle_demosaic", piece, d, img, want) == 0
+    hc.assert_bit_exact(got, want, "demosaic method %d geq %d smooth %d median %g" % (method, geq, smooth, median))
+    plain = hc.run_hip("dt_hip_iop_demosaic_process", piece, abi.DemosaicData(0, 0, method, 0.0, 0.0), img, (h, w, 4),
+                       pre_fill=np.zeros((h, w, 4), np.float32))
+    assert not np.array_equal(np.nan_to_num(got), np.nan_to_num(plain))  # the steps did something
+
+
+def test_full_average_green_equilibration_is_refused():
+    import ctypes as C
+    import hipcheck as hc
+    from ansel_amd import lib, synth
+    l = hc.hip()
+    buf = lib.DeviceBuffer(0, 64 * 48 * 16)
+    piece = abi.Piece.make(64, 48, filters=synth.FILTERS_RGGB, channels=1)
+    for geq in (2, 3):
+        d = abi.DemosaicData(geq, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.1)
+        assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.3, 0.0)   # a median threshold only exists for PPG
+    assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG

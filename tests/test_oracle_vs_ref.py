@@ -523,3 +523,58 @@ def test_develop_blend_mask_blur(name, d, kind, w, h):
     assert ck.call(r, "ref_develop_blend", piece, d, np.ascontiguousarray(a), x) == 0
     assert ck.call(o, "oracle_develop_blend", piece, d, np.ascontiguousarray(a), y) == 0
     _exact(x, y, "blend " + name)
+
+
+DEMOSAIC_EXTRAS = [
+    # (method, green_eq, colour smoothing passes, PPG median threshold, green_eq threshold = 1e-4 * ISO)
+    (abi.DT_HIP_DEMOSAIC_PPG, 0, 0, 0.05, 0.0),
+    (abi.DT_HIP_DEMOSAIC_PPG, 0, 0, 1.0, 0.0),
+    (abi.DT_HIP_DEMOSAIC_PPG, 1, 2, 0.02, 0.08),
+    (abi.DT_HIP_DEMOSAIC_PPG, 0, 5, 0.0, 0.0),
+    (abi.DT_HIP_DEMOSAIC_RCD, 1, 0, 0.0, 0.64),
+    (abi.DT_HIP_DEMOSAIC_RCD, 1, 3, 0.0, 0.01),
+    (abi.DT_HIP_DEMOSAIC_AMAZE, 1, 1, 0.0, 0.32),
+]
+
+
+@pytest.mark.parametrize("w,h,xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (120, 96, (1, 0)), (64, 40, (0, 1))])
+@pytest.mark.parametrize("method,geq,smooth,median,geq_thr", DEMOSAIC_EXTRAS)
+def test_demosaic_optional_steps(w, h, xy, method, geq, smooth, median, geq_thr):
+    """green equilibration (local average) before, PPG's median pre-filter inside, colour smoothing after the
+    interpolation (demosaic.c:1137-1250; demosaic/basic.c:136-293): oracle == the reference's code, bit for bit,
+    for every CFA phase of the roi origin"""
+    if method == abi.DT_HIP_DEMOSAIC_AMAZE and (w < 100 or h < 100):
+        pytest.skip("AMaZE tile size")
+    rng = np.random.default_rng(w + 3 * h + 7 * method)
+    cfa = synth.bayer_mosaic(w, h, seed=5).astype(np.float32)
+    img = ((cfa - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    img[rng.integers(4, h - 4, 6), rng.integers(4, w - 4, 6)] = [0.0, -0.01, 2.0, np.nan, np.inf, 1e-30]
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(xy[0], xy[1], w, h), roi_out=abi.Roi.make(xy[0], xy[1], w, h))
+    d = abi.DemosaicData(geq, smooth, method, median, geq_thr)
+    a, b = _pair("demosaic", piece, d, img, (h, w, 4))
+    mask = None
+    if method == abi.DT_HIP_DEMOSAIC_RCD:
+        m = np.zeros((h, w), np.uint8)
+        filters = ck.oracle().oracle_shift_dcraw_filters(C.c_uint32(synth.FILTERS_RGGB), xy[0], xy[1])
+        ck.oracle().oracle_rcd_stale_mask(ck.ptr(m), w, h, C.c_uint32(filters))
+        mask = np.zeros((h, w), np.uint8)
+        mask[:, w - 9:w - 6] = m[:, w - 9:w - 6]
+        if smooth:  # the 3x3 medians spread a stale value by one pixel per pass
+            from scipy.ndimage import binary_dilation
+            mask = binary_dilation(mask, iterations=smooth, structure=np.ones((3, 3))).astype(np.uint8)
+        mask = mask[..., None]
+    if method == abi.DT_HIP_DEMOSAIC_AMAZE:
+        fin = np.isfinite(img)
+        if not fin.all():
+            pytest.skip("AMaZE with non-finite samples is not reproduced (DESIGN.md section 3)")
+    _exact(a, b, "demosaic extras", mask)
+
+
+def test_full_average_green_equilibration_is_refused():
+    w, h = 64, 48
+    img = np.random.default_rng(0).random((h, w)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1)
+    out = np.zeros((h, w, 4), np.float32)
+    for geq in (2, 3):
+        assert ck.call(ck.oracle(), "oracle_demosaic", piece, abi.DemosaicData(geq, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.1), img, out) != 0

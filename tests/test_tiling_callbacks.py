@@ -116,3 +116,15 @@ def test_default_tiling():
     fs.roi_out.width, fs.roi_out.height = 320, 240
     l.dt_hip_default_tiling(C.byref(fs), 0, C.byref(t))
     assert t.factor == 1.25
+
+
+@pytest.mark.parametrize("method,overlap", [(abi.DT_HIP_DEMOSAIC_PPG, 5), (abi.DT_HIP_DEMOSAIC_AMAZE, 5), (abi.DT_HIP_DEMOSAIC_RCD, 10)])
+@pytest.mark.parametrize("geq,smooth", [(0, 0), (1, 0), (0, 3), (1, 2)])
+def test_demosaic_tiling(method, overlap, geq, smooth):
+    # demosaic.c:1916-1990: in + out + max(tmp + green-eq copy, smoothing copy)
+    from ansel_amd import synth
+    piece = abi.Piece.make(640, 480, filters=synth.FILTERS_RGGB, channels=1)
+    t = _t("dt_hip_iop_demosaic_tiling", piece, abi.DemosaicData(geq, smooth, method, 0.0, 0.0))
+    assert t.factor == pytest.approx(2.0 + max(1.0 + (0.25 if geq else 0.0), 1.0 if smooth else 0.0))
+    assert (t.overlap, t.xalign, t.yalign, t.maxbuf) == (overlap, 2, 2, 1.0)
+    assert t.factor_cl == pytest.approx(1.25 + (0.25 if geq else 0.0)) and t.factor_cl < t.factor
