@@ -155,7 +155,7 @@ def measured_traffic(tag, args):
     gfx950 corrections of MI355X_MICROARCH.md); None when no summary matches the configuration."""
     if args.size != "100MP" or args.pipe != "light" or args.no_fusion or args.mode != "batch":
         return None
-    path = os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_bytes_100MP_light_fused.json")
+    path = os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_bytes_100MP_light_fused.json")
     try:
         kernels = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):
