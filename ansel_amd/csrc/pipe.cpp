@@ -45,6 +45,7 @@ enum op_t
   OP_EXPORT_U16,
   OP_BLEND,
   OP_EXPORT_ROWS,
+  OP_EXPORT_U8,
   OP_UNKNOWN
 };
 
@@ -75,6 +76,7 @@ const op_info_t k_ops[] = {
   { "export_u16", 0, 8 },
   { "blend", sizeof(dt_hip_blend_data_t), 0 },
   { "export_rows", sizeof(dt_hip_export_rows_t), 0 },
+  { "export_u8", 0, 4 },
 };
 
 struct node_t
@@ -103,6 +105,7 @@ size_t out_bytes(const node_t &n)
     case OP_HIGHLIGHTS:
     case OP_EXPOSURE: return px * 4 * n.piece.channels;
     case OP_EXPORT_U16: return px * 8;
+    case OP_EXPORT_U8: return px * 4;
     case OP_EXPORT_ROWS:
       return px * (size_t)n.as<dt_hip_export_rows_t>()->layers * (size_t)(n.as<dt_hip_export_rows_t>()->bpp / 8);
     default: return px * 16;
@@ -130,6 +133,7 @@ int run_single(int devid, const node_t &n, dt_hip_mem_t in, dt_hip_mem_t out)
     case OP_COLOROUT: return dt_hip_iop_colorout_process(devid, &n.piece, n.as<dt_hip_conversion_t>(), in, out);
     case OP_FINALSCALE: return dt_hip_iop_finalscale_process(devid, &n.piece, n.as<dt_hip_finalscale_data_t>(), in, out);
     case OP_EXPORT_U16: return dt_hip_export_convert_u16(devid, n.piece.roi_out.width, n.piece.roi_out.height, in, out);
+    case OP_EXPORT_U8: return dt_hip_export_convert_u8(devid, n.piece.roi_out.width, n.piece.roi_out.height, in, out);
     case OP_EXPORT_ROWS:
       return dt_hip_export_pack_rows(devid, n.piece.roi_out.width, n.piece.roi_out.height, n.as<dt_hip_export_rows_t>()->bpp,
                                      n.as<dt_hip_export_rows_t>()->layers, in, out);

@@ -383,7 +383,8 @@ int dt_hip_export_convert_u8(int devid, int width, int height, dt_hip_mem_t dev_
 /* The row loop of the format writers (src/imageio/format/tiff.c:293-360; png.c / jpeg.c likewise): `layers`
  * (3, or 1 for tiff's grayscale "shortfile" mode) of the 4 samples of every pixel, packed -- the bytes of the
  * scanlines, so the download carries 3/4 of the frame.  bpp = bits per sample of dev_in: 32, 16 or 8.
- * In a pipe: node "export_rows" (data dt_hip_export_rows_t) after "export_u16"; fused into the RGBA chain. */
+ * In a pipe: node "export_rows" (data dt_hip_export_rows_t) after "export_u16" (fused into the RGBA chain) or after
+ * "export_u8" (the 8-bit writers: jpeg.c, png.c at 8 bits). */
 typedef struct dt_hip_export_rows_t
 {
   int32_t bpp, layers;

@@ -64,3 +64,33 @@ def test_pipe_exports_scanlines(w, h, fusion):
     p.close()
     assert torch.equal(rows, rgba[..., :3])
     assert rows.cpu().numpy().view(np.uint16).std() > 100
+
+
+def test_pipe_exports_8_bit_scanlines():
+    """the 8-bit writers (jpeg, png8): ... -> colorout -> export_u8 -> export_rows{8, 3} == the u8 conversion of the
+    float pipe output (imageio_core.c:706-727), alpha dropped"""
+    hc.hip()
+    import torch
+    w, h = 400, 300
+    lut = params.srgb_encode_lut()
+    d_lut = torch.from_numpy(lut).to("cuda:0")
+    nodes = pipe.light_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
+                                  with_filmic=True, filmic=filmic.default_data())
+    float_nodes = nodes[:-1]                                       # without export_u16: float4 out
+    raw = synth.bayer_mosaic(w, h, seed=12)
+    d_in = torch.from_numpy(raw.view(np.int16)).to("cuda:0")
+    p = pipe.DevicePipe(0, float_nodes)
+    f = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    p.process(d_in.data_ptr(), f.data_ptr())
+    p.close()
+    l = lib.load()
+    u8 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
+    lib.check(l.dt_hip_export_convert_u8(0, w, h, f.data_ptr(), u8.data_ptr()), "u8")
+    rows_nodes = float_nodes + [pipe.Node("export_u8", None, nodes[-1].piece),
+                                pipe.Node("export_rows", abi.ExportRowsData(8, 3), nodes[-1].piece)]
+    p = pipe.DevicePipe(0, rows_nodes)
+    rows = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    p.process(d_in.data_ptr(), rows.data_ptr())
+    torch.cuda.synchronize()
+    p.close()
+    assert torch.equal(rows, u8[..., :3]) and rows.float().std() > 10
