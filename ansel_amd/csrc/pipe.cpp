@@ -399,6 +399,8 @@ struct band_priv_t
   int stage;                  // inside a stencil group: 0 before the halo exchange, 1 after it, 2 after the sums, 3 done
   dt_hip_mem_t out;
   bool out_own_rows, out_owned;
+  dt_hip_mem_t held, held_base; // own rows of the input of a module whose output is about to be blended
+  bool held_owned;
   dn_band_job_t *dn_job;
 };
 
@@ -611,13 +613,21 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
     }
   if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
   for(const node_t &n : pipe->nodes)
-    if(n.op == OP_BILAT || n.op == OP_FINALSCALE || n.op == OP_BLEND)
+  {
+    if(n.op == OP_BILAT || n.op == OP_FINALSCALE)
     {
       // the bilateral grid is one accumulation over the whole frame in pixel order; finalscale
-      // changes the geometry; a blend needs the module input kept
+      // changes the geometry
       set_last_error("band mode: '%s' has no row-band implementation", k_ops[n.op].name);
       return DT_HIP_INVALID_ARG;
     }
+    if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->blur_radius > 0.0f)
+    {
+      // uniform and parametric masks are pointwise; the mask blur is a recursive filter down whole columns
+      set_last_error("band mode: a blend with a mask blur has no row-band implementation");
+      return DT_HIP_INVALID_ARG;
+    }
+  }
   const size_t ng = pipe->groups.size();
   // the CFA stage ends where the first non-CFA group starts
   size_t n_cfa = 0;
@@ -924,6 +934,7 @@ void dt_hip_pipe_band_abort(dt_hip_pipe_t *pipe, dt_hip_band_state_t *state)
   else if(pv->cfa_owned && pv->cfa)
     dt_hip_release_mem_object(pv->cfa);
   if(pv->out && pv->out_owned) dt_hip_release_mem_object(pv->out);
+  if(pv->held_owned && pv->held_base) dt_hip_release_mem_object(pv->held_base);
   if(pv->journal) dt_hip_release_mem_object(pv->journal);
   if(pv->dn_job) denoiseprofile_band_abort(pv->dn_job);
   delete pv;
@@ -979,6 +990,20 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
     pv->cur = pv->cur_base = nullptr;
     pv->cur_owned = false;
   };
+  auto next_is_blend = [&](const size_t gi) { return gi + 1 < ng && pipe->nodes[pipe->groups[gi + 1].first].op == OP_BLEND; };
+  // the current buffer stops being the module input: free it, or keep it for the blend that follows the module
+  auto retire_cur = [&](const size_t gi) {
+    if(next_is_blend(gi))
+    {
+      pv->held = pv->cur;
+      pv->held_base = pv->cur_base;
+      pv->held_owned = pv->cur_owned;
+      pv->cur = pv->cur_base = nullptr;
+      pv->cur_owned = false;
+    }
+    else
+      drop_cur();
+  };
   // rows a stencil group takes from the neighbours, clipped at the frame
   auto halo_of = [&](const size_t gi, int &top, int &bottom) {
     const int h = band_halo_rows(pipe->nodes[pipe->groups[gi].first]);
@@ -992,7 +1017,25 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
     const group_t &g = pipe->groups[gi];
     const node_t &first = pipe->nodes[g.first];
     const node_t &last = pipe->nodes[g.first + g.count - 1];
-    const bool final_group = gi + 1 == ng;
+    const bool final_group = gi + 1 == ng || (next_is_blend(gi) && gi + 2 == ng);
+    if(first.op == OP_BLEND)
+    {
+      // dt_develop_blend_process() after the module's process(), pixelpipe_cpu.c:137-228: in place in the output
+      if(!pv->held)
+      {
+        set_last_error("pipe: a blend node needs the module it blends in front of it");
+        err = DT_HIP_INVALID_ARG;
+        break;
+      }
+      node_t n = first;
+      band_piece(n.piece, b);
+      err = dt_hip_develop_blend_process(devid, &n.piece, n.as<dt_hip_blend_data_t>(), pv->held, pv->cur);
+      if(pv->held_owned && pv->held_base) dt_hip_release_mem_object(pv->held_base);
+      pv->held = pv->held_base = nullptr;
+      pv->held_owned = false;
+      pv->next_group++;
+      continue;
+    }
     if(g.kind == group_t::SINGLE && is_stencil_op(first.op))
     {
       int top, bottom;
@@ -1107,15 +1150,19 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
       // stage 3: the module's output becomes the current buffer
       if(pv->out)
       {
-        drop_cur();
+        retire_cur(gi);
         pv->cur_base = pv->out;
         pv->cur = pv->out_own_rows ? pv->out : (dt_hip_mem_t)((char *)pv->out + (size_t)top * rgba_row);
         pv->cur_owned = pv->out != dev_out_band;
         pv->out = nullptr;
       }
       if(final_group && pv->cur != dev_out_band)
+      {
         err = dt_hip_enqueue_copy_buffer_to_buffer(devid, pv->cur_base, dev_out_band, (size_t)((char *)pv->cur - (char *)pv->cur_base),
                                                    0, (size_t)b.rows * rgba_row);
+        drop_cur(); // stream-ordered; a blend that closes the pipe then works in dev_out_band
+        pv->cur = pv->cur_base = dev_out_band;
+      }
       pv->stage = 0;
       pv->next_group++;
       continue;
@@ -1181,7 +1228,7 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
       band_piece(n.piece, b);
       err = run_single(devid, n, pv->cur, out);
     }
-    drop_cur();
+    retire_cur(gi);
     pv->cur = out;
     pv->cur_base = out_base;
     pv->cur_owned = out_owned;
@@ -1189,6 +1236,7 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
     pv->next_group++;
   }
   drop_cur();
+  if(pv->held_owned && pv->held_base) dt_hip_release_mem_object(pv->held_base);
   if(pv->out && pv->out != dev_out_band) dt_hip_release_mem_object(pv->out);
   if(pv->dn_job) denoiseprofile_band_abort(pv->dn_job);
   delete pv;

@@ -662,8 +662,9 @@ int dt_hip_batch_drain(dt_hip_batch_t *batch);
  * What a band computes is bit-identical to the rows of the unsplit frame: diffuse and the wavelets run on
  * [halo][rows][halo] as on a frame of its own (h covers every stencil of every iteration / scale, so only halo
  * rows see the artificial border); non-local means runs the chunk rows of the FRAME's grid that intersect the
- * band (nlmeans_core.c:264-313: the grid is a function of the frame size).  bilat (one grid accumulated over
- * the frame in pixel order), finalscale and blend nodes are refused in band mode. */
+ * band (nlmeans_core.c:264-313: the grid is a function of the frame size).  Blend nodes with uniform or parametric
+ * masks are pointwise and run on the band; bilat (one grid accumulated over the frame in pixel order), finalscale and
+ * blends with a mask blur are refused in band mode. */
 #define DT_HIP_BAND_EXCHANGE 1
 typedef struct dt_hip_band_t
 {

@@ -121,7 +121,7 @@ class OracleBandEngine:
         frame = np.zeros((h, w), np.float32)
         r0 = band.row0 - band.halo_top
         frame[r0:r0 + cfa.shape[0]] = cfa
-        src = None
+        src = held = None
         for n in self.nodes:
             if n.op in CFA_OPS:
                 continue
@@ -132,11 +132,17 @@ class OracleBandEngine:
             elif n.op == "export_u16":
                 self.l.oracle_export_convert_u16(w, rows, ck.ptr(src), ck.ptr(out_band))
                 return
+            elif n.op == "blend":
+                # dt_develop_blend_process(): blend(input of the module, output of the module) in place
+                assert ck.call(self.l, "oracle_develop_blend", _band_piece(n.piece, band), n.data,
+                               np.ascontiguousarray(held), src) == 0
             elif n.op in STENCIL_OPS:
+                held = src
                 src = yield from self._stencil(n, band, src)
             else:
                 dst = np.zeros((rows, w, 4), np.float32)
                 assert ck.call(self.l, "oracle_" + n.op, _band_piece(n.piece, band), n.data, src, dst) == 0, n.op
+                held = src
                 src = dst
         out_band[...] = src
 
@@ -145,13 +151,18 @@ def whole_frame(nodes, raw, w, h):
     """the unsplit oracle chain"""
     l = ck.oracle()
     src = raw
+    prev = None
     for n in nodes:
+        if n.op == "blend":
+            assert ck.call(l, "oracle_develop_blend", n.piece, n.data, np.ascontiguousarray(prev), src) == 0
+            continue
         if n.op == "export_u16":
             out = np.zeros((h, w, 4), np.uint16)
             l.oracle_export_convert_u16(w, h, ck.ptr(src), ck.ptr(out))
             return out
         dst = np.zeros((h, w) if n.op in CFA_OPS else (h, w, 4), np.float32)
         assert ck.call(l, "oracle_" + n.op, n.piece, n.data, np.ascontiguousarray(src), dst) == 0, n.op
+        prev = src
         src = dst
     return src
 

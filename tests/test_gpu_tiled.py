@@ -123,8 +123,25 @@ def _full_nodes(w, h, d_lut, lut, which):
             "diffuse_inpaint": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "nlmeans": ("denoiseprofile", "diffuse"),
             "dn_nlmeans": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
-            "all": ()}[which]
+            "blended": (), "all": ()}[which]
     nodes = [n for n in nodes if n.op not in drop]
+    if which == "blended":
+        # blends on a pointwise module (uniform) and on two stencil modules (parametric masks, tone curve); the last
+        # node of the RGBA part is itself blended
+        nodes = [n for n in nodes if n.op not in ("nlmeans", "rgb_to_lab", "lab_to_rgb")]
+        out = []
+        for n in nodes:
+            out.append(n)
+            if n.op == "exposure":
+                out.append(pipe.Node("blend", abi.BlendData.uniform(params.WORK_IN, 60.0, abi.BLEND_MULTIPLY, 0.5), n.piece))
+            if n.op in ("denoiseprofile", "diffuse"):
+                d = abi.BlendData.uniform(params.WORK_IN, 80.0)
+                d.channel(abi.BLENDIF_GRAY_in, 0.02, 0.15, 0.6, 0.9, boost=1.0)
+                d.channel(abi.BLENDIF_Jz_in, 0.05, 0.2, 1.0, 1.0, boost=-4.0)
+                d.channel(abi.BLENDIF_hz_out, 0.1, 0.3, 0.8, 0.95)
+                d.contrast, d.brightness = 0.3, -0.2
+                out.append(pipe.Node("blend", d, n.piece))
+        return out
     if which == "diffuse_inpaint":
         # threshold > 0: the inpainting noise is keyed on the pixel's position in the FRAME
         for n in nodes:
@@ -137,7 +154,7 @@ def _full_nodes(w, h, d_lut, lut, which):
     return nodes
 
 
-@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "all"])
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "blended", "all"])
 @pytest.mark.parametrize("w,h,n", [(752, 2000, 2), (752, 2000, 5), (400, 640, 2), (400, 640, 1)])
 def test_full_pipe_bands_equal_the_unsplit_frame(w, h, n, which):
     """denoise (profiled) wavelets / non-local means, diffuse-or-sharpen and nlmeans on row bands: halo rows
@@ -159,6 +176,38 @@ def test_full_pipe_bands_equal_the_oracle():
     host = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), params.unbounded_coeffs(lut),
                                    filmic=filmic.default_data(), diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
     assert np.array_equal(dev, be.whole_frame(host, raw, w, h))
+
+
+def test_blended_pipe_closed_by_a_blend_on_bands():
+    """a pipe whose LAST node is a blend: the module in front of it writes the band's output buffer, the blend works
+    in place there"""
+    from ansel_amd import abi
+    torch, lut, d_lut = _setup()
+    w, h = 400, 640
+    rgb = abi.Piece.make(w, h, channels=4)
+    nodes = [pipe.Node("diffuse", params.diffuse("lens_deblur_soft", iterations=2), rgb),
+             pipe.Node("blend", abi.BlendData.uniform(params.WORK_IN, 35.0, abi.BLEND_AVERAGE), rgb)]
+    img = synth.rgba_image(w, h, seed=3)
+    d_in = torch.from_numpy(img).to("cuda:0")
+    p = pipe.DevicePipe(0, nodes)
+    whole = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    p.process(d_in.data_ptr(), whole.data_ptr())
+    engine = tiled.HipBandEngine(p, "cuda:0")
+    bands = tiled.plan_bands(w, h, 3, -1)
+    outs = [torch.zeros((b.rows, w, 4), dtype=torch.float32, device="cuda:0") for b in bands]
+    tiled.process_bands_locally(engine, bands, [d_in[b.row0:b.row0 + b.rows].data_ptr() for b in bands],
+                                [t.data_ptr() for t in outs], w)
+    torch.cuda.synchronize()
+    p.close()
+    assert torch.equal(torch.cat(outs, dim=0), whole)
+    # and a mask blur is refused on bands
+    d = abi.BlendData.uniform(params.WORK_IN, 50.0)
+    d.blur_radius = 3.0
+    p = pipe.DevicePipe(0, [nodes[0], pipe.Node("blend", d, rgb)])
+    engine = tiled.HipBandEngine(p, "cuda:0")
+    with pytest.raises(lib.AnselHipError, match="mask blur"):
+        engine.begin(bands[0], d_in.data_ptr(), w)
+    p.close()
 
 
 def test_modules_without_a_band_mode_are_refused():

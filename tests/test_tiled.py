@@ -129,8 +129,25 @@ def _full_nodes(w, h, lut, which):
             "diffuse_inpaint": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "nlmeans": ("denoiseprofile", "diffuse"),
             "dn_nlmeans": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
-            "all": ()}[which]
+            "blended": (), "all": ()}[which]
     nodes = [n for n in nodes if n.op not in drop]
+    if which == "blended":
+        # blends on a pointwise module (uniform) and on two stencil modules (parametric masks, tone curve); the last
+        # node of the RGBA part is itself blended
+        nodes = [n for n in nodes if n.op not in ("nlmeans", "rgb_to_lab", "lab_to_rgb")]
+        out = []
+        for n in nodes:
+            out.append(n)
+            if n.op == "exposure":
+                out.append(pipe.Node("blend", abi.BlendData.uniform(params.WORK_IN, 60.0, abi.BLEND_MULTIPLY, 0.5), n.piece))
+            if n.op in ("denoiseprofile", "diffuse"):
+                d = abi.BlendData.uniform(params.WORK_IN, 80.0)
+                d.channel(abi.BLENDIF_GRAY_in, 0.02, 0.15, 0.6, 0.9, boost=1.0)
+                d.channel(abi.BLENDIF_Jz_in, 0.05, 0.2, 1.0, 1.0, boost=-4.0)
+                d.channel(abi.BLENDIF_hz_out, 0.1, 0.3, 0.8, 0.95)
+                d.contrast, d.brightness = 0.3, -0.2
+                out.append(pipe.Node("blend", d, n.piece))
+        return out
     if which == "diffuse_inpaint":
         # threshold > 0: the inpainting noise is keyed on the pixel's position in the FRAME
         for n in nodes:
@@ -191,7 +208,7 @@ def _full_rank_main(rank, world, port, w, h, which, outdir):
 
 
 @needs_oracle
-@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "all"])
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "blended", "all"])
 def test_two_ranks_full_pipe_over_gloo_equal_the_unsplit_frame(tmp_path, which):
     """halo send/recv of float4 rows + the all-reduce of the wavelets, and the halo sizes themselves: a band cut
     from a frame that is zero beyond the halo equals the rows of the real frame only if the halo is enough"""
