@@ -191,8 +191,11 @@ __device__ __forceinline__ double wave_sum_halving(double v)
 __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                     float4 *__restrict__ detail, double *__restrict__ partial,
                                                     const int width, const int height, const int mult,
-                                                    const float inv_sigma2, const int nseg)
+                                                    const float inv_sigma2, const int nseg, const int in_row0,
+                                                    const int in_rows)
 {
+  // `height` rows are computed.  Normally they are the whole input (in_row0 = 0, in_rows = height); on a row band
+  // (pipe.cpp) the input additionally holds in_row0 halo rows above and in_rows - in_row0 - height below them
   __shared__ double runs[4][4];
   const int bx = xcd_col(); // hip_common.h: the column block, pinned to an XCD for 64 rows of the walk
   if(bx >= nseg) return;
@@ -202,12 +205,12 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
   double sq[4] = { 0.0, 0.0, 0.0, 0.0 };
   if(col < width)
   {
-    const float4 px = in[(size_t)row * width + col];
+    const float4 px = in[(size_t)(row + in_row0) * width + col];
     float sum[4] = { 0.f, 0.f, 0.f, 0.f }, wgt = 0.f;
 #pragma unroll
     for(int jj = 0; jj < 5; jj++)
     {
-      const size_t y = (size_t)clampi(row + mult * (jj - 2), 0, height - 1) * width;
+      const size_t y = (size_t)clampi(row + in_row0 + mult * (jj - 2), 0, in_rows - 1) * width;
       const float fj = jj == 0 || jj == 4 ? 0.0625f : (jj == 2 ? 0.375f : 0.25f);
 #pragma unroll
       for(int ii = 0; ii < 5; ii++)
@@ -617,46 +620,55 @@ namespace ansel
 {
 
 // ---- row bands (pipe.cpp) --------------------------------------------------------------
+// The band computes its OWN rows of every wavelet scale.  Scale k reads 2 * 2^k rows of scale k - 1 on either side, so
+// before each decomposition the neighbours' rows of the current coarse plane are fetched: the module input comes in
+// with 2 halo rows, and every decomposition writes its coarse plane into the middle of a buffer laid out for the next,
+// twice as large, exchange.  No row is computed twice.
 struct dn_band_job_t
 {
-  int devid, w, buf_rows, frame_h, max_scale;
+  int devid, w, frame_h, max_scale, row0, rows;
   dt_hip_denoiseprofile_data_t d;
   dn_setup s;
-  float4 *b[2];
-  float4 *det[BANDS];
-  float4 *residual;
-  double *sums; // [max_scale][frame_h * nseg][4]
+  float4 *cur;          // coarse plane of scale next_scale - 1: [cur_top][rows][cur_bottom] rows
+  int cur_top, cur_bottom;
+  float4 *det[BANDS];   // own rows
+  double *sums;         // [max_scale][frame_h * nseg][4]
+  double *local;        // own rows' partial sums of one scale
   float *thrs;
+  int next_scale;
+  bool sums_requested;
 };
 
 void denoiseprofile_band_abort(dn_band_job_t *j)
 {
   if(!j) return;
-  for(int k = 0; k < 2; k++)
-    if(j->b[k]) dt_hip_release_mem_object(j->b[k]);
+  if(j->cur) dt_hip_release_mem_object(j->cur);
   for(int k = 0; k < BANDS; k++)
     if(j->det[k]) dt_hip_release_mem_object(j->det[k]);
   if(j->sums) dt_hip_release_mem_object(j->sums);
+  if(j->local) dt_hip_release_mem_object(j->local);
   if(j->thrs) dt_hip_release_mem_object(j->thrs);
   delete j;
 }
 
+// rows of the module INPUT a band needs from each neighbour; the wavelets then ask for 2 * 2^k rows of their own
+// coarse planes before every later scale (denoiseprofile_band_step)
 int denoiseprofile_halo_rows(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d)
 {
   if(DT_HIP_DENOISEPROFILE_IS_NLMEANS(d->mode)) return nlmeans_core_halo_rows(piece->roi_in.height, nlm_params_of(piece, d));
   dn_setup s;
   setup(piece, d, s, false);
   if(wavelets_runnable(piece, s) != 1) return -1;
-  return 2 * ((1 << s.max_scale) - 1); // scale k reads 2 * 2^k rows of scale k - 1 on either side
+  return 2;
 }
+
+static int clip_halo(const int h, const int avail) { return h < avail ? h : avail; }
 
 int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
                               const band_view_t *band, const int buf_rows, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
-                              dn_band_job_t **job, double **sums, size_t *sum_count)
+                              dn_band_job_t **job)
 {
   *job = nullptr;
-  *sums = nullptr;
-  *sum_count = 0;
   if(!valid_device(devid) || !piece || !d || !band || !dev_in || buf_rows <= 0) return DT_HIP_INVALID_ARG;
   if(piece->channels != 4 || !(piece->roi_in.scale > 0.0)) return DT_HIP_INVALID_ARG;
   if(DT_HIP_DENOISEPROFILE_IS_NLMEANS(d->mode)) return denoise_nlmeans(devid, piece, d, band, buf_rows, dev_in, dev_out);
@@ -665,8 +677,9 @@ int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_h
   memset(j, 0, sizeof(*j));
   j->devid = devid;
   j->w = piece->roi_in.width;
-  j->buf_rows = buf_rows;
   j->frame_h = band->frame_h;
+  j->row0 = band->row0;
+  j->rows = band->row1 - band->row0;
   j->d = *d;
   setup(piece, d, j->s, false);
   if(wavelets_runnable(piece, j->s) != 1)
@@ -676,71 +689,116 @@ int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_h
   }
   j->max_scale = j->s.max_scale;
   const int w = j->w, nseg = (w + 255) / 256;
-  const size_t npix = (size_t)w * buf_rows, plane = npix * sizeof(float4);
+  const size_t npix = (size_t)w * buf_rows;
   const size_t n_frame = (size_t)band->frame_h * nseg; // partial sums of one wavelet band of the frame
   const size_t sums_bytes = (size_t)j->max_scale * n_frame * 4 * sizeof(double);
-  bool ok = true;
-  for(int k = 0; k < 2; k++) ok &= (j->b[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
-  for(int k = 0; k < j->max_scale; k++) ok &= (j->det[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
+  j->cur_top = band->row0 - band->buf_row0;
+  j->cur_bottom = buf_rows - j->cur_top - j->rows;
+  bool ok = (j->cur = (float4 *)dt_hip_alloc_device_buffer(devid, npix * sizeof(float4))) != nullptr;
   ok &= (j->sums = (double *)dt_hip_alloc_device_buffer(devid, sums_bytes)) != nullptr;
+  ok &= (j->local = (double *)dt_hip_alloc_device_buffer(devid, (size_t)j->rows * nseg * 4 * sizeof(double))) != nullptr;
   ok &= (j->thrs = (float *)dt_hip_alloc_device_buffer(devid, 4 * sizeof(float))) != nullptr;
-  double *local = ok ? (double *)dt_hip_alloc_device_buffer(devid, (size_t)buf_rows * nseg * 4 * sizeof(double)) : nullptr;
-  if(!ok || !local)
+  if(!ok || j->cur_bottom < 0)
   {
-    if(local) dt_hip_release_mem_object(local);
     denoiseprofile_band_abort(j);
     return DT_HIP_SYSMEM_ALLOCATION;
   }
   hipStream_t st = stream_of(devid);
-  int err = hipMemsetAsync(j->sums, 0, sums_bytes, st) == hipSuccess ? DT_HIP_SUCCESS : DT_HIP_DEFAULT_ERROR;
-  if(err == DT_HIP_SUCCESS)
+  if(hipMemsetAsync(j->sums, 0, sums_bytes, st) != hipSuccess)
   {
+    denoiseprofile_band_abort(j);
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  {
+    // pointwise, so the halo rows of the input become halo rows of the preconditioned plane
     vst_args fa;
     forward_args(j->s, fa);
     launch_scope ls(devid, "dn_precondition");
-    dn_precondition<<<pixel_grid(npix), 256, 0, st>>>((const float4 *)dev_in, j->b[0], npix, fa);
+    dn_precondition<<<pixel_grid(npix), 256, 0, st>>>((const float4 *)dev_in, j->cur, npix, fa);
   }
-  float4 *b1 = j->b[0], *b2 = j->b[1];
-  const int own0 = band->row0 - band->buf_row0, own_rows = band->row1 - band->row0;
-  for(int scale = 0; scale < j->max_scale && err == DT_HIP_SUCCESS; scale++)
-  {
-    const int mult = 1 << scale;
-    const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
-    const float sigma_band = powf(varf, scale) * 1.0f;
-    const int rows = (buf_rows <= mult) ? buf_rows : ((buf_rows + mult - 1) / mult) * mult;
-    {
-      launch_scope ls(devid, "dn_decompose");
-      dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(b1, b2, j->det[scale], local, w, buf_rows, mult,
-                                                               1.0f / (sigma_band * sigma_band), nseg);
-    }
-    err = check_launch("denoiseprofile band decompose");
-    // the own rows' partial sums at their place in the frame's table
-    if(err == DT_HIP_SUCCESS
-       && hipMemcpyAsync(j->sums + ((size_t)scale * n_frame + (size_t)band->row0 * nseg) * 4, local + (size_t)own0 * nseg * 4,
-                         (size_t)own_rows * nseg * 4 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
-      err = DT_HIP_DEFAULT_ERROR;
-    float4 *t = b2;
-    b2 = b1;
-    b1 = t;
-  }
-  dt_hip_release_mem_object(local); // stream-ordered
-  j->residual = b1;
+  const int err = check_launch("dn_precondition");
   if(err != DT_HIP_SUCCESS)
   {
     denoiseprofile_band_abort(j);
     return err;
   }
   *job = j;
-  *sums = j->sums;
-  *sum_count = (size_t)j->max_scale * n_frame * 4;
   return DT_HIP_SUCCESS;
 }
 
+// One decomposition per call.  Returns 1 with *halo_buf / *halo_rows set when the coarse plane just written needs the
+// neighbours' rows before the next call, 2 with *sums / *sum_count set once every scale is done (the frame-wide table of
+// partial sums to all-reduce), 0 when there is nothing left but denoiseprofile_band_finish(); < 0 on error (job freed).
+int denoiseprofile_band_step(dn_band_job_t *j, dt_hip_mem_t *halo_buf, int *halo_rows, double **sums, size_t *sum_count)
+{
+  *halo_buf = nullptr;
+  *halo_rows = 0;
+  *sums = nullptr;
+  *sum_count = 0;
+  const int devid = j->devid, w = j->w, nseg = (w + 255) / 256;
+  const size_t n_frame = (size_t)j->frame_h * nseg;
+  if(j->next_scale >= j->max_scale)
+  {
+    if(j->sums_requested) return 0;
+    j->sums_requested = true;
+    *sums = j->sums;
+    *sum_count = (size_t)j->max_scale * n_frame * 4;
+    return 2;
+  }
+  hipStream_t st = stream_of(devid);
+  const int scale = j->next_scale, mult = 1 << scale;
+  const bool last = scale + 1 == j->max_scale;
+  // the coarse plane of this scale, with room for the rows the next scale reads beyond the band
+  const int h_next = last ? 0 : 2 * (2 << scale);
+  const int top = clip_halo(h_next, j->row0), bottom = clip_halo(h_next, j->frame_h - j->row0 - j->rows);
+  float4 *coarse = (float4 *)dt_hip_alloc_device_buffer(devid, (size_t)(top + j->rows + bottom) * w * sizeof(float4));
+  j->det[scale] = (float4 *)dt_hip_alloc_device_buffer(devid, (size_t)j->rows * w * sizeof(float4));
+  if(!coarse || !j->det[scale])
+  {
+    if(coarse) dt_hip_release_mem_object(coarse);
+    denoiseprofile_band_abort(j);
+    return DT_HIP_SYSMEM_ALLOCATION;
+  }
+  const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
+  const float sigma_band = powf(varf, scale) * 1.0f;
+  const int rows = (j->rows <= mult) ? j->rows : ((j->rows + mult - 1) / mult) * mult;
+  {
+    launch_scope ls(devid, "dn_decompose");
+    dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(j->cur, coarse + (size_t)top * w, j->det[scale], j->local, w, j->rows,
+                                                             mult, 1.0f / (sigma_band * sigma_band), nseg, j->cur_top,
+                                                             j->cur_top + j->rows + j->cur_bottom);
+  }
+  int err = check_launch("denoiseprofile band decompose");
+  // the own rows' partial sums at their place in the frame's table
+  if(err == DT_HIP_SUCCESS
+     && hipMemcpyAsync(j->sums + ((size_t)scale * n_frame + (size_t)j->row0 * nseg) * 4, j->local,
+                       (size_t)j->rows * nseg * 4 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    err = DT_HIP_DEFAULT_ERROR;
+  dt_hip_release_mem_object(j->cur); // stream-ordered
+  j->cur = coarse;
+  j->cur_top = top;
+  j->cur_bottom = bottom;
+  j->next_scale++;
+  if(err != DT_HIP_SUCCESS)
+  {
+    denoiseprofile_band_abort(j);
+    return err;
+  }
+  if(!last && (top || bottom))
+  {
+    *halo_buf = coarse;
+    *halo_rows = h_next;
+    return 1;
+  }
+  return denoiseprofile_band_step(j, halo_buf, halo_rows, sums, sum_count);
+}
+
+// thresholds from the reduced sums, synthesis, inverse transform on the band's own rows.  Frees the job
 int denoiseprofile_band_finish(dn_band_job_t *j, dt_hip_mem_t dev_out)
 {
   if(!j || !dev_out) return DT_HIP_INVALID_ARG;
   const int devid = j->devid, nseg = (j->w + 255) / 256;
-  const size_t npix = (size_t)j->w * j->buf_rows, n_frame = (size_t)j->frame_h * nseg;
+  const size_t npix = (size_t)j->w * j->rows, n_frame = (size_t)j->frame_h * nseg;
   hipStream_t st = stream_of(devid);
   float4 *out = (float4 *)dev_out;
   int err = DT_HIP_SUCCESS;
@@ -761,10 +819,11 @@ int denoiseprofile_band_finish(dn_band_job_t *j, dt_hip_mem_t dev_out)
   }
   if(err == DT_HIP_SUCCESS)
   {
+    // the last coarse plane has no halo: j->cur holds the band's own rows of the residual
     vst_args ia;
     inverse_args(j->s, ia);
     launch_scope ls(devid, "dn_finish");
-    dn_finish<<<pixel_grid(npix), 256, 0, st>>>(out, j->residual, npix, ia);
+    dn_finish<<<pixel_grid(npix), 256, 0, st>>>(out, j->cur + (size_t)j->cur_top * j->w, npix, ia);
     err = check_launch("dn_finish");
   }
   denoiseprofile_band_abort(j);
@@ -822,7 +881,7 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
     {
       launch_scope ls(devid, "dn_decompose");
       dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(b1, b2, det, partial, w, h, mult,
-                                                               1.0f / (sigma_band * sigma_band), nseg);
+                                                               1.0f / (sigma_band * sigma_band), nseg, 0, h);
     }
     thr_args ta;
     ta.n_partial = n_partial;

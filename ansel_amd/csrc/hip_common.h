@@ -123,14 +123,16 @@ int diffuse_process_rows(int devid, const dt_hip_piece_t *piece, const dt_hip_di
 // denoiseprofile: -1 when the frame is too small for the module to do anything but copy
 int denoiseprofile_halo_rows(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d);
 struct dn_band_job_t;
-// non-local means mode: one call (job == nullptr on return).  Wavelets mode: decomposes every band of the
-// buffer (buf_rows rows, as a frame of its own), leaves the frame-wide table of partial sums of detail^2
-// in *sums (own rows filled, the rest zero: an all-reduce SUM over the bands is exact in any order) and
-// returns a job for denoiseprofile_band_finish()
+// non-local means mode: one call (job == nullptr on return, dev_out = the band's own rows).  Wavelets mode:
+// preconditions the buffer (buf_rows rows: own rows + 2 halo rows) and returns a job; denoiseprofile_band_step() then
+// runs one decomposition per call and says what the band needs next -- 1: the neighbours' *halo_rows rows of
+// *halo_buf ([min(h, row0)][rows][min(h, H - row1)], RGBA float), 2: an all-reduce (SUM) of *sums (the frame-wide table
+// of partial sums of detail^2: own rows filled, the rest zero, so the sum is exact in any order), 0: nothing, call
+// denoiseprofile_band_finish() (thresholds, synthesis, inverse transform into dev_out = own rows; frees the job)
 int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
                               const band_view_t *band, int buf_rows, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
-                              dn_band_job_t **job, double **sums, size_t *sum_count);
-// thresholds from the reduced sums, synthesis, inverse transform; dev_out holds buf_rows rows.  Frees the job
+                              dn_band_job_t **job);
+int denoiseprofile_band_step(dn_band_job_t *job, dt_hip_mem_t *halo_buf, int *halo_rows, double **sums, size_t *sum_count);
 int denoiseprofile_band_finish(dn_band_job_t *job, dt_hip_mem_t dev_out);
 void denoiseprofile_band_abort(dn_band_job_t *job);
 

@@ -1086,9 +1086,8 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
         v.buf_row0 = b.row0 - top;
         v.row0 = b.row0;
         v.row1 = b.row0 + b.rows;
-        const bool own_rows_out = first.op == OP_NLMEANS
-                                  || (first.op == OP_DENOISEPROFILE
-                                      && DT_HIP_DENOISEPROFILE_IS_NLMEANS(first.as<dt_hip_denoiseprofile_data_t>()->mode));
+        // only diffuse runs on the whole buffer and leaves its halo rows in the output
+        const bool own_rows_out = first.op != OP_DIFFUSE;
         dt_hip_mem_t out = dev_out_band;
         if(!(own_rows_out && final_group))
         {
@@ -1112,20 +1111,9 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
         }
         else
         {
-          double *sums = nullptr;
-          size_t count = 0;
           err = denoiseprofile_band_begin(devid, &first.piece, first.as<dt_hip_denoiseprofile_data_t>(), &v, buf_rows,
-                                          pv->cur_base, out, &pv->dn_job, &sums, &count);
-          if(err == DT_HIP_SUCCESS && pv->dn_job)
-          {
-            pv->stage = 2;
-            if(b.rows < H)
-            {
-              state->sum_buf = sums;
-              state->sum_count = count;
-              return DT_HIP_BAND_EXCHANGE;
-            }
-          }
+                                          pv->cur_base, out, &pv->dn_job);
+          if(err == DT_HIP_SUCCESS && pv->dn_job) pv->stage = 2; // wavelets: one decomposition per step below
         }
         if(err != DT_HIP_SUCCESS)
         {
@@ -1137,6 +1125,39 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
       }
       if(pv->stage == 2)
       {
+        // the profiled wavelets: a decomposition, then the neighbours' rows of its coarse plane for the next one; after
+        // the last, the frame-wide sums; then thresholds and synthesis
+        int rc;
+        do
+        {
+          dt_hip_mem_t hbuf = nullptr;
+          int hrows = 0;
+          double *sums = nullptr;
+          size_t count = 0;
+          rc = denoiseprofile_band_step(pv->dn_job, &hbuf, &hrows, &sums, &count);
+          if(rc < 0)
+          {
+            pv->dn_job = nullptr; // freed by the failing step
+            err = rc;
+            break;
+          }
+          if(rc > 0 && b.rows < H)
+          {
+            state->halo_buf = hbuf;
+            state->halo_rows = hrows;
+            state->row_bytes = rgba_row;
+            state->sum_buf = sums;
+            state->sum_count = count;
+            return DT_HIP_BAND_EXCHANGE;
+          }
+        } while(rc > 0);
+        if(err != DT_HIP_SUCCESS)
+        {
+          if(pv->out != dev_out_band) dt_hip_release_mem_object(pv->out);
+          pv->out = nullptr;
+          break;
+        }
+        state->halo_buf = nullptr;
         err = denoiseprofile_band_finish(pv->dn_job, pv->out);
         pv->dn_job = nullptr;
         if(err != DT_HIP_SUCCESS)

@@ -164,8 +164,9 @@ def test_halo_rows_of_the_stencil_modules():
     """dt_hip_band_halo_rows(): pure host function"""
     lut = params.srgb_encode_lut()
     by_op = {n.op: n for n in _full_nodes(752, 2000, lut, "all")}
-    # 7 wavelet bands at this size (denoiseprofile.c:1301-1317): 2 * (1 + 2 + ... + 64) rows
-    assert be.halo_rows(by_op["denoiseprofile"]) == 254
+    # the profiled wavelets take 2 rows of their input (scale 0 reads +-2) and then 2 * 2^k rows of their own coarse
+    # plane before scale k: no row is computed twice
+    assert be.halo_rows(by_op["denoiseprofile"]) == 2
     # patch radius 2 + 1 + search radius 7, + the 60-row-ish chunk the band boundary may cut (nlmeans_core.c:264-295)
     assert 10 + 50 <= be.halo_rows(by_op["nlmeans"]) <= 10 + 70
     it, scales = 2, oracle_scales(by_op["diffuse"])
