@@ -650,16 +650,18 @@ int dt_hip_batch_drain(dt_hip_batch_t *batch);
  *
  *   state->halo_rows = h > 0   halo_buf holds RGBA rows [min(h, row0)][rows][min(h, H - row0 - rows)] of
  *                              `row_bytes`; fill the first and last part with the neighbours' last / first
- *                              own rows of the same buffer.  h is the same on every band (it is a
- *                              function of the module: dt_hip_band_halo_rows()); a neighbour must own at
- *                              least h rows.
+ *                              own rows of the same buffer.  h is the same on every band: in front of a
+ *                              module it is dt_hip_band_halo_rows(); the profiled wavelets then stop once
+ *                              more before each later scale k with h = 2 * 2^k rows of their own coarse
+ *                              plane.  A neighbour must own at least h rows.
  *   state->sum_buf != NULL     sum_count doubles to all-reduce (SUM) over the bands: the frame-wide table of
  *                              partial sums of the profiled wavelets (eaw.c:253-255), each band having filled
  *                              the entries of its own rows and zeroed the rest, so the reduced table -- and
  *                              the thresholds taken from it in a fixed order -- do not depend on how the
  *                              collective associates.
  *
- * What a band computes is bit-identical to the rows of the unsplit frame: diffuse and the wavelets run on
+ * What a band computes is bit-identical to the rows of the unsplit frame: the wavelets compute their own rows
+ * of every scale from own + fetched rows of the scale before; diffuse runs on
  * [halo][rows][halo] as on a frame of its own (h covers every stencil of every iteration / scale, so only halo
  * rows see the artificial border); non-local means runs the chunk rows of the FRAME's grid that intersect the
  * band (nlmeans_core.c:264-313: the grid is a function of the frame size).  Blend nodes with uniform or parametric
