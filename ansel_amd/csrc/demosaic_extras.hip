@@ -15,6 +15,18 @@ __device__ __forceinline__ int fc(const int row, const int col, const uint32_t f
   return filters >> (((row << 1 & 14) + (col & 1)) << 1) & 3; // FC(), src/develop/imageop_math.h:190
 }
 
+// mean absolute difference of the six pairs of four greens: (0,1) (0,2) (0,3) (1,2) (2,3) (1,3), left to right
+__device__ __forceinline__ float mean_abs_pairs(const float g[4])
+{
+  float acc = fabsf(g[0] - g[1]);
+  acc = acc + fabsf(g[0] - g[2]);
+  acc = acc + fabsf(g[0] - g[3]);
+  acc = acc + fabsf(g[1] - g[2]);
+  acc = acc + fabsf(g[2] - g[3]);
+  acc = acc + fabsf(g[1] - g[3]);
+  return acc / 6.0f;
+}
+
 __global__ __launch_bounds__(256) void green_eq_lavg(const float *__restrict__ in, float *__restrict__ out, const int width,
                                                      const int height, const int oj, const int oi, const float thr)
 {
@@ -24,18 +36,15 @@ __global__ __launch_bounds__(256) void green_eq_lavg(const float *__restrict__ i
   float v = in[p];
   if(j >= oj && j < height - 2 && ((j - oj) & 1) == 0 && i >= oi && i < width - 2 && ((i - oi) & 1) == 0)
   {
-    const float maximum = 1.0f;
-    const float o1_1 = in[p - w - 1], o1_2 = in[p - w + 1], o1_3 = in[p + w - 1], o1_4 = in[p + w + 1];
-    const float o2_1 = in[p - 2 * w], o2_2 = in[p + 2 * w], o2_3 = in[p - 2], o2_4 = in[p + 2];
-    const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
-    const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
-    if((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f))
+    // the four diagonal greens and the four axial greens at distance 2; sums in the reference's operand order
+    const float diag[4] = { in[p - w - 1], in[p - w + 1], in[p + w - 1], in[p + w + 1] };
+    const float axial[4] = { in[p - 2 * w], in[p + 2 * w], in[p - 2], in[p + 2] };
+    const float m_diag = (((diag[0] + diag[1]) + diag[2]) + diag[3]) / 4.0f;
+    const float m_axial = (((axial[0] + axial[1]) + axial[2]) + axial[3]) / 4.0f;
+    if((m_axial > 0.0f) && (m_diag > 0.0f) && (m_diag / m_axial < 2.0f))
     {
-      const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4)
-                        + fabsf(o1_2 - o1_4)) / 6.0f;
-      const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4)
-                        + fabsf(o2_2 - o2_4)) / 6.0f;
-      if((v < maximum * 0.95f) && (c1 < maximum * thr) && (c2 < maximum * thr)) v = v * m1 / m2;
+      const float flat_d = mean_abs_pairs(diag), flat_a = mean_abs_pairs(axial);
+      if((v < 0.95f) && (flat_d < thr) && (flat_a < thr)) v = v * m_diag / m_axial;
     }
   }
   out[p] = v;

@@ -7,41 +7,38 @@
 #include "ppg_core.h"
 
 /* pre_median_b(), basic.c:136-180, one pass: every green site at least 3 px from the border becomes the median of
- * the 9 greens of its diamond that lie within `threshold` of it (the others are pushed out of the way by + 64) */
+ * the 9 greens of its diamond (rows -2..2 with column offsets {0}, {-1, 1}, {-2, 0, 2}, {-1, 1}, {0}) that lie within
+ * `threshold` of it; the others are pushed out of the way by + 64.  The sort is the reference's exchange sort. */
 static void pre_median(float *out, const float *in, const int width, const int height, const uint32_t filters,
                        const float threshold)
 {
+  static const int dy[9] = { -2, -1, -1, 0, 0, 0, 1, 1, 2 }, dx[9] = { 0, -1, 1, -2, 0, 2, -1, 1, 0 };
   memcpy(out, in, sizeof(float) * (size_t)width * height);
-  const int lim[5] = { 0, 1, 2, 1, 0 };
+#pragma omp parallel for
   for(int row = 3; row < height - 3; row++)
   {
-    float med[9];
-    int col = 3;
-    if(oracle_fc(row, col, filters) != 1 && oracle_fc(row, col, filters) != 3) col++;
-    for(; col < width - 3; col += 2)
+    const int f3 = oracle_fc(row, 3, filters);
+    for(int col = (f3 != 1 && f3 != 3) ? 4 : 3; col < width - 3; col += 2)
     {
-      const float *pixi = in + (size_t)width * row + col;
-      int cnt = 0;
-      for(int k = 0, i = 0; i < 5; i++)
-        for(int j = -lim[i]; j <= lim[i]; j += 2)
-        {
-          if(fabsf(pixi[width * (i - 2) + j] - pixi[0]) < threshold)
+      const float *c = in + (size_t)width * row + col;
+      float v[9];
+      int close = 0;
+      for(int k = 0; k < 9; k++)
+      {
+        const float s = c[width * dy[k] + dx[k]];
+        const int near_ = fabsf(s - c[0]) < threshold;
+        v[k] = near_ ? s : 64.0f + s;
+        close += near_;
+      }
+      for(int a = 0; a < 8; a++)
+        for(int b = a + 1; b < 9; b++)
+          if(v[a] > v[b])
           {
-            med[k++] = pixi[width * (i - 2) + j];
-            cnt++;
+            const float t = v[a];
+            v[a] = v[b];
+            v[b] = t;
           }
-          else
-            med[k++] = 64.0f + pixi[width * (i - 2) + j];
-        }
-      for(int i = 0; i < 8; i++)
-        for(int ii = i + 1; ii < 9; ii++)
-          if(med[i] > med[ii])
-          {
-            const float t = med[i];
-            med[i] = med[ii];
-            med[ii] = t;
-          }
-      out[(size_t)width * row + col] = (cnt == 1 ? med[4] - 64.0f : med[(cnt - 1) / 2]);
+      out[(size_t)width * row + col] = (close == 1) ? v[4] - 64.0f : v[(close - 1) / 2];
     }
   }
 }

@@ -38,6 +38,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
 #include "oracle.h"
 #include "ppg_core.h"
 
@@ -358,68 +359,81 @@ static int demosaic_methods(const dt_hip_piece_t *piece, const dt_hip_demosaic_d
   return 1;
 }
 
-/* green_equilibration_lavg(), src/iop/demosaic/basic.c:248-293 */
+/* green_equilibration_lavg(), src/iop/demosaic/basic.c:248-293: a green site on the lattice anchored at (oj, oi) is
+ * scaled by mean(diagonal greens) / mean(axial greens at distance 2) where both neighbourhoods are flat (mean absolute
+ * difference of the six pairs below thr) and the site is below 0.95.  Sums run in the reference's operand order. */
+static float mean_abs_pairs(const float g[4])
+{
+  /* pairs (0,1) (0,2) (0,3) (1,2) (2,3) (1,3), accumulated left to right */
+  static const int pa[6] = { 0, 0, 0, 1, 2, 1 }, pb[6] = { 1, 2, 3, 2, 3, 3 };
+  float acc = fabsf(g[pa[0]] - g[pb[0]]);
+  for(int k = 1; k < 6; k++) acc = acc + fabsf(g[pa[k]] - g[pb[k]]);
+  return acc / 6.0f;
+}
+
 static void green_eq_lavg(float *out, const float *in, const int width, const int height, const uint32_t filters, const int x,
                           const int y, const float thr)
 {
-  const float maximum = 1.0f;
+  /* the lattice origin: the first green of the second kind at or after (2, 2), basic.c:253-256 */
   int oj = 2, oi = 2;
   if(oracle_fc(oj + y, oi + x, filters) != 1) oj++;
   if(oracle_fc(oj + y, oi + x, filters) != 1) oi++;
   if(oracle_fc(oj + y, oi + x, filters) != 1) oj--;
   memcpy(out, in, sizeof(float) * (size_t)width * height);
-  for(size_t j = oj; j + 2 < (size_t)height; j += 2)
-    for(size_t i = oi; i + 2 < (size_t)width; i += 2)
+#pragma omp parallel for
+  for(int j = oj; j < height - 2; j += 2)
+    for(int i = oi; i < width - 2; i += 2)
     {
-      const float o1_1 = in[(j - 1) * width + i - 1], o1_2 = in[(j - 1) * width + i + 1];
-      const float o1_3 = in[(j + 1) * width + i - 1], o1_4 = in[(j + 1) * width + i + 1];
-      const float o2_1 = in[(j - 2) * width + i], o2_2 = in[(j + 2) * width + i];
-      const float o2_3 = in[j * width + i - 2], o2_4 = in[j * width + i + 2];
-      const float m1 = (o1_1 + o1_2 + o1_3 + o1_4) / 4.0f;
-      const float m2 = (o2_1 + o2_2 + o2_3 + o2_4) / 4.0f;
-      if((m2 > 0.0f) && (m1 > 0.0f) && (m1 / m2 < maximum * 2.0f))
-      {
-        const float c1 = (fabsf(o1_1 - o1_2) + fabsf(o1_1 - o1_3) + fabsf(o1_1 - o1_4) + fabsf(o1_2 - o1_3) + fabsf(o1_3 - o1_4)
-                          + fabsf(o1_2 - o1_4)) / 6.0f;
-        const float c2 = (fabsf(o2_1 - o2_2) + fabsf(o2_1 - o2_3) + fabsf(o2_1 - o2_4) + fabsf(o2_2 - o2_3) + fabsf(o2_3 - o2_4)
-                          + fabsf(o2_2 - o2_4)) / 6.0f;
-        if((in[j * width + i] < maximum * 0.95f) && (c1 < maximum * thr) && (c2 < maximum * thr))
-          out[j * width + i] = in[j * width + i] * m1 / m2;
-      }
+      const float *c = in + (size_t)j * width + i;
+      const float diag[4] = { c[-width - 1], c[-width + 1], c[width - 1], c[width + 1] };
+      const float axial[4] = { c[-2 * width], c[2 * width], c[-2], c[2] };
+      const float m_diag = (((diag[0] + diag[1]) + diag[2]) + diag[3]) / 4.0f;
+      const float m_axial = (((axial[0] + axial[1]) + axial[2]) + axial[3]) / 4.0f;
+      if(!(m_axial > 0.0f) || !(m_diag > 0.0f) || !(m_diag / m_axial < 2.0f)) continue;
+      if((c[0] < 0.95f) && (mean_abs_pairs(diag) < thr) && (mean_abs_pairs(axial) < thr))
+        out[(size_t)j * width + i] = c[0] * m_diag / m_axial;
     }
 }
 
 /* color_smoothing(), src/iop/demosaic/basic.c:191-243: `passes` x (red, blue): the channel minus green goes through a
- * 3x3 median (the reference's 19-exchange network, whose result for NaN operands depends on the exchange order) */
+ * 3x3 median, found with the reference's 19 compare-exchanges in its order (which decides where a NaN ends up) */
+static const unsigned char k_median9[19][2] = { { 1, 2 }, { 4, 5 }, { 7, 8 }, { 0, 1 }, { 3, 4 }, { 6, 7 }, { 1, 2 },
+                                                { 4, 5 }, { 7, 8 }, { 0, 3 }, { 5, 8 }, { 4, 7 }, { 3, 6 }, { 1, 4 },
+                                                { 2, 5 }, { 4, 7 }, { 4, 2 }, { 6, 4 }, { 4, 2 } };
+
 static void color_smoothing(float *out, const int width, const int height, const int passes)
 {
-  const int width4 = 4 * width;
-#define SWAPmed(I, J) if(med[I] > med[J]) { const float t_ = med[I]; med[I] = med[J]; med[J] = t_; }
+  const size_t npix = (size_t)width * height;
   for(int pass = 0; pass < passes; pass++)
-    for(int c = 0; c < 3; c += 2)
+    for(int ch = 0; ch < 3; ch += 2)
     {
-      for(size_t k = 0; k < (size_t)width * height; k++) out[4 * k + 3] = out[4 * k + c];
+      /* the channel is parked in alpha for the whole frame first, :198-204 */
+      for(size_t k = 0; k < npix; k++) out[4 * k + 3] = out[4 * k + ch];
 #pragma omp parallel for
       for(int j = 1; j < height - 1; j++)
-      {
-        float *outp = out + (size_t)4 * j * width + 4;
-        for(int i = 1; i < width - 1; i++, outp += 4)
+        for(int i = 1; i < width - 1; i++)
         {
-          float med[9] = {
-            outp[-width4 - 4 + 3] - outp[-width4 - 4 + 1], outp[-width4 + 0 + 3] - outp[-width4 + 0 + 1],
-            outp[-width4 + 4 + 3] - outp[-width4 + 4 + 1], outp[-4 + 3] - outp[-4 + 1],
-            outp[+0 + 3] - outp[+0 + 1], outp[+4 + 3] - outp[+4 + 1],
-            outp[+width4 - 4 + 3] - outp[+width4 - 4 + 1], outp[+width4 + 0 + 3] - outp[+width4 + 0 + 1],
-            outp[+width4 + 4 + 3] - outp[+width4 + 4 + 1],
-          };
-          SWAPmed(1, 2) SWAPmed(4, 5) SWAPmed(7, 8) SWAPmed(0, 1) SWAPmed(3, 4) SWAPmed(6, 7) SWAPmed(1, 2) SWAPmed(4, 5)
-          SWAPmed(7, 8) SWAPmed(0, 3) SWAPmed(5, 8) SWAPmed(4, 7) SWAPmed(3, 6) SWAPmed(1, 4) SWAPmed(2, 5) SWAPmed(4, 7)
-          SWAPmed(4, 2) SWAPmed(6, 4) SWAPmed(4, 2)
-          outp[c] = fmaxf(med[4] + outp[1], 0.0f);
+          float *px = out + 4 * ((size_t)j * width + i);
+          float v[9];
+          for(int dj = -1, n = 0; dj <= 1; dj++)
+            for(int di = -1; di <= 1; di++, n++)
+            {
+              const float *q = px + 4 * ((ptrdiff_t)dj * width + di);
+              v[n] = q[3] - q[1];
+            }
+          for(int e = 0; e < 19; e++)
+          {
+            const int lo = k_median9[e][0], hi = k_median9[e][1];
+            if(v[lo] > v[hi])
+            {
+              const float t = v[lo];
+              v[lo] = v[hi];
+              v[hi] = t;
+            }
+          }
+          px[ch] = fmaxf(v[4] + px[1], 0.0f);
         }
-      }
     }
-#undef SWAPmed
 }
 
 /* process(), src/iop/demosaic.c:1041-1253, Bayer branch: [green equilibration, local average] -> demosaic ->
