@@ -109,6 +109,14 @@ def test_rccl_accepts_runtime_owned_buffers():
         torch.cuda.synchronize()
         p.close()
         assert np.array_equal(d_out.cpu().numpy().view(np.uint16), _whole(torch, nodes, raw, w, h, True))
+        # the wavelets' table of partial sums is binary64 in runtime-owned memory: what serve_request() all-reduces
+        vals = np.random.default_rng(1).random(4096)
+        buf = lib.DeviceBuffer.from_numpy(0, vals)
+        view = tiled.device_view(buf.ptr, (4096,), "<f8", torch.device("cuda:0"))
+        dist.all_reduce(view, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.to_numpy((4096,), np.float64), vals)
+        buf.release()
     finally:
         dist.destroy_process_group()
 
