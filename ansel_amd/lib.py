@@ -30,7 +30,7 @@ def load():
     if os.environ.get("ANSEL_HIP_NO_TORCH") != "1":
         try:
             import torch  # noqa: F401
-        except ImportError:
+        except Exception:  # no torch (a plain ctypes user), or one that does not load: the library does not need it
             pass
     lib = C.CDLL(LIB_PATH)
     vp, i, u, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t

@@ -218,6 +218,45 @@ def test_blended_pipe_closed_by_a_blend_on_bands():
     p.close()
 
 
+def test_band_abort_frees_what_a_stopped_walk_holds():
+    """dt_hip_pipe_band_abort(): a band given up at any stop of the walk (an error on another rank, a cancelled export)
+    returns every buffer it holds to the pool"""
+    import ctypes as C
+    torch, lut, d_lut = _setup()
+    l = lib.load()
+    w, h = 400, 640
+    nodes = _full_nodes(w, h, d_lut, lut, "all")
+    raw = synth.bayer_mosaic(w, h, seed=7)
+    p = pipe.DevicePipe(0, nodes)
+    engine = tiled.HipBandEngine(p, "cuda:0")
+    bands = tiled.plan_bands(w, h, 2, tiled.pipe_demosaic_method(nodes))
+    d_in = torch.from_numpy(np.ascontiguousarray(raw[:bands[0].rows]).view(np.int16)).to("cuda:0")
+    d_out = torch.zeros((bands[0].rows, w, 4), dtype=torch.int16, device="cuda:0")
+    cur, peak = C.c_size_t(0), C.c_size_t(0)
+    torch.cuda.synchronize()
+    l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
+    base = cur.value
+    for stops in range(0, 12):
+        work = engine.begin(bands[0], d_in.data_ptr(), w)
+        engine.resolve(bands[0], work)
+        done = False
+        for _ in range(stops):
+            if engine.finish(bands[0], work, d_out.data_ptr()) is None:
+                done = True
+                break
+        if not done:
+            l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
+            assert cur.value > base                      # the stopped walk holds buffers
+            engine.abort(work)
+        l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
+        assert cur.value == base, (stops, cur.value - base)
+        engine.abort(work)                               # a second abort (or one after the walk ended) is a no-op
+        if done:
+            break
+    assert done and stops >= 8                           # mosaic halo aside: wavelets 2 + 6 scales + sums, diffuse, nlmeans
+    p.close()
+
+
 def test_modules_without_a_band_mode_are_refused():
     torch, lut, d_lut = _setup()
     w, h = 400, 640
