@@ -258,3 +258,50 @@ def test_very_large_frame_fused_equals_modulewise():
     del unfused
     modulewise = _run_chain_modulewise(nodes, raw, w, h)
     assert np.array_equal(fused, modulewise)
+
+
+def test_executor_returns_every_intermediate_to_the_pool():
+    """dt_hip_pipe_process() on the full pipe (stencil modules, Lab glue, two blends) and on a pipe that fails in the
+    middle: the runtime's allocation counter is back at its baseline afterwards"""
+    import ctypes as C
+    import torch
+    from ansel_amd import filmic
+    l = hc.hip()
+    w, h = 400, 300
+    lut = params.srgb_encode_lut()
+    d_lut = torch.from_numpy(lut).to("cuda:0")
+    coeffs = params.unbounded_coeffs(lut)
+    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), coeffs, filmic=filmic.default_data(),
+                                    diffuse_iterations=2, with_nlmeans=True, with_bilat=True)
+    out = []
+    for n in nodes:
+        out.append(n)
+        if n.op in ("exposure", "diffuse"):
+            out.append(pipe.Node("blend", abi.BlendData.uniform(params.WORK_IN, 60.0, abi.BLEND_MULTIPLY, 0.5), n.piece))
+    raw = torch.from_numpy(synth.bayer_mosaic(w, h, seed=2).view(np.int16)).to("cuda:0")
+    res = torch.zeros((h, w, 4), dtype=torch.int16, device="cuda:0")
+    cur, peak = C.c_size_t(0), C.c_size_t(0)
+    torch.cuda.synchronize()
+    l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
+    base = cur.value
+    p = pipe.DevicePipe(0, out)
+    for _ in range(2):
+        p.process(raw.data_ptr(), res.data_ptr())
+    torch.cuda.synchronize()
+    l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
+    assert cur.value == base and peak.value > base
+    p.close()
+    # a module that refuses its parameters half way down the pipe (diffuse with iscale 0)
+    bad = [n for n in nodes]
+    for k, n in enumerate(bad):
+        if n.op == "diffuse":
+            d = params.diffuse("lens_deblur_soft", iterations=1)
+            d.iscale = 0.0
+            bad[k] = pipe.Node("diffuse", d, n.piece)
+    p = pipe.DevicePipe(0, bad)
+    with pytest.raises(lib.AnselHipError):
+        p.process(raw.data_ptr(), res.data_ptr())
+    torch.cuda.synchronize()
+    l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
+    assert cur.value == base
+    p.close()
