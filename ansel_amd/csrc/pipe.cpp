@@ -466,7 +466,9 @@ dt_hip_batch_t *dt_hip_batch_new(dt_hip_pipe_t *pipe, int depth, size_t in_bytes
   b->out_bytes = out_bytes;
   b->next = 0;
   b->s_up = b->s_down = nullptr;
-  bool ok = hipStreamCreateWithFlags(&b->s_up, hipStreamNonBlocking) == hipSuccess
+  // streams and events belong to the device that is current when they are made: the pipe's, not whatever the
+  // calling thread used last (hipEventRecord rejects an event of another device than its stream's)
+  bool ok = make_current(pipe->devid) && hipStreamCreateWithFlags(&b->s_up, hipStreamNonBlocking) == hipSuccess
             && hipStreamCreateWithFlags(&b->s_down, hipStreamNonBlocking) == hipSuccess;
   for(int k = 0; k < depth && ok; k++)
   {
@@ -491,7 +493,12 @@ dt_hip_batch_t *dt_hip_batch_new(dt_hip_pipe_t *pipe, int depth, size_t in_bytes
 void dt_hip_batch_free(dt_hip_batch_t *b)
 {
   if(!b) return;
+  make_current(b->pipe->devid);
   dt_hip_batch_drain(b);
+  // a submit that failed half way leaves its upload (or download) enqueued without marking the slot in flight:
+  // the copy streams must be idle before the slot buffers go back to the pool
+  if(b->s_up) (void)hipStreamSynchronize(b->s_up);
+  if(b->s_down) (void)hipStreamSynchronize(b->s_down);
   for(batch_slot_t &sl : b->slots)
   {
     if(sl.d_in) dt_hip_release_mem_object(sl.d_in);

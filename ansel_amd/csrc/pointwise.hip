@@ -214,6 +214,30 @@ __global__ __launch_bounds__(256) void highlights_clip_1f(const float *__restric
   }
 }
 
+// the same for buffers whose base is not 16-byte aligned (a row band of a frame whose width is not a multiple
+// of 4 starts its own rows behind 9 halo rows): one photosite per lane
+__global__ __launch_bounds__(256) void highlights_clip_1f_scalar(const float *__restrict__ in, float *__restrict__ out,
+                                                                  const size_t n, const float clip, const float threshold,
+                                                                  hl_journal *journal)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t iters = (n + stride - 1) / stride; // whole-wave trip count so that __ballot() sees every lane
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool settled = false;
+  for(size_t it = 0; it < iters; it++, k += stride)
+  {
+    const bool live = k < n;
+    const float v = live ? in[k] : 0.f;
+    const bool over = live && v > threshold;
+    if(!settled && __ballot(over) != 0ull)
+    {
+      settled = __hip_atomic_load(&journal->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= HL_MIN_CLIPPED;
+      if(!settled) hl_note(journal, over, k, v);
+    }
+    if(live) out[k] = clip < v ? clip : v;
+  }
+}
+
 // elements: RGBA pixels (ch = 4) -- a pixel counts once if any of R,G,B is over its threshold;
 // process_clip clamps all 4 channels (highlights/clip.c:78-83)
 __global__ __launch_bounds__(256) void highlights_clip_4f(const float4 *__restrict__ in, float4 *__restrict__ out,
@@ -504,18 +528,18 @@ static int highlights_launch(int devid, const dt_hip_piece_t *piece, const dt_hi
   const size_t np = (size_t)width * height;
   if(err == DT_HIP_SUCCESS && piece->filters)
   {
-    if(!aligned16(dev_in) || !aligned16(dev_out)) err = DT_HIP_INVALID_ARG;
-    else
+    const float raw_threshold = fminf(fminf(thr.x, thr.y), thr.z);
     {
-      const float raw_threshold = fminf(fminf(thr.x, thr.y), thr.z);
-      {
-        launch_scope ls(devid, "highlights_clip_1f");
+      launch_scope ls(devid, "highlights_clip_1f");
+      if(aligned16(dev_in) && aligned16(dev_out))
         highlights_clip_1f<<<stream_grid(np / 4 + 1, 256), 256, 0, s>>>((const float *)dev_in, (float *)dev_out, np,
                                                                           clip, raw_threshold, journal);
-      }
-      if(!deferred) highlights_restore_1f<<<1, 64, 0, s>>>((float *)dev_out, journal);
-      err = check_launch("highlights_clip_1f");
+      else
+        highlights_clip_1f_scalar<<<stream_grid(np, 256), 256, 0, s>>>((const float *)dev_in, (float *)dev_out, np,
+                                                                         clip, raw_threshold, journal);
     }
+    if(!deferred) highlights_restore_1f<<<1, 64, 0, s>>>((float *)dev_out, journal);
+    err = check_launch("highlights_clip_1f");
   }
   else if(err == DT_HIP_SUCCESS)
   {

@@ -74,13 +74,32 @@ void set_last_error(const char *fmt, ...)
 
 bool valid_device(int devid) { return g_inited && devid >= 0 && devid < (int)g_devs.size(); }
 
-hipStream_t stream_of(int devid) { return valid_device(devid) ? g_devs[devid]->stream : nullptr; }
+// Streams, events and allocations belong to the device that is current when they are made, and HIP rejects an
+// event recorded on a stream of another device.  The thread's current device is therefore made `devid`'s wherever
+// work for `devid` starts: every module entry point fetches its stream through stream_of(), every allocation,
+// event and stream creation goes through make_current().  A caller that drives several devices from one thread
+// gets the right device per call; a thread per device (dt_hip_pipe_process_bands) pays one hipGetDevice() per call.
+bool make_current(int devid)
+{
+  if(!valid_device(devid)) return false;
+  const int want = g_devs[devid]->hip_id;
+  int cur = -1;
+  if(hipGetDevice(&cur) == hipSuccess && cur == want) return true;
+  return hipSetDevice(want) == hipSuccess;
+}
+
+hipStream_t stream_of(int devid)
+{
+  if(!make_current(devid)) return nullptr;
+  return g_devs[devid]->stream;
+}
 
 launch_scope::launch_scope(int devid_, const char *tag_) : devid(devid_), tag(tag_), active(false)
 {
   if(!valid_device(devid)) return;
   device_t *d = g_devs[devid];
   if(!d->events_enabled) return;
+  make_current(devid); // an event belongs to the device that is current when it is created
   auto get = [&]() {
     hipEvent_t e;
     if(!d->event_pool.empty())
@@ -94,16 +113,28 @@ launch_scope::launch_scope(int devid_, const char *tag_) : devid(devid_), tag(ta
   };
   start = get();
   stop = get();
-  if(!start || !stop) return;
+  if(!start || !stop || hipEventRecord(start, d->stream) != hipSuccess)
+  {
+    // no timing for this launch; what was acquired goes back to the pool
+    (void)hipGetLastError();
+    if(start) d->event_pool.push_back(start);
+    if(stop) d->event_pool.push_back(stop);
+    return;
+  }
   active = true;
-  (void)hipEventRecord(start, d->stream);
 }
 
 launch_scope::~launch_scope()
 {
   if(!active) return;
   device_t *d = g_devs[devid];
-  (void)hipEventRecord(stop, d->stream);
+  if(hipEventRecord(stop, d->stream) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    d->event_pool.push_back(start);
+    d->event_pool.push_back(stop);
+    return;
+  }
   d->events.push_back({ tag, start, stop });
 }
 
@@ -168,7 +199,10 @@ void dt_hip_cleanup(void)
     if(d->own_stream) (void)hipStreamDestroy(d->stream);
     delete d;
   }
-  for(auto &kv : g_allocs) (void)hipFree(kv.first);
+  // live allocations the caller never released; a device ALIAS of pinned host memory
+  // (dt_hip_alloc_device_use_host_pointer) is not ours to free -- the host buffer stays with its owner
+  for(auto &kv : g_allocs)
+    if(!kv.second.host) (void)hipFree(kv.first);
   g_allocs.clear();
   g_devs.clear();
   g_inited = false;
@@ -184,7 +218,7 @@ size_t dt_hip_get_device_available(int devid)
 {
   if(!valid_device(devid)) return 0;
   size_t fr = 0, tot = 0;
-  (void)hipSetDevice(g_devs[devid]->hip_id);
+  make_current(devid);
   if(hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
   // pooled blocks are ours to reuse
   std::lock_guard<std::mutex> g(g_mutex);
@@ -242,7 +276,7 @@ size_t dt_hip_get_device_max_global_mem(int devid)
 {
   if(!valid_device(devid)) return 0;
   size_t free_b = 0, total_b = 0;
-  (void)hipSetDevice(g_devs[devid]->hip_id);
+  make_current(devid);
   if(hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
   return total_b;
 }
@@ -308,11 +342,12 @@ int dt_hip_set_stream(int devid, void *stream)
 {
   if(!valid_device(devid)) return DT_HIP_INVALID_ARG;
   device_t *d = g_devs[devid];
-  if(d->own_stream && d->stream)
-  {
-    (void)hipStreamSynchronize(d->stream);
-    (void)hipStreamDestroy(d->stream);
-  }
+  make_current(devid);
+  if((hipStream_t)stream == d->stream) return DT_HIP_SUCCESS;
+  // blocks released under the outgoing stream are handed out again under the new one: the pool's reuse is only
+  // stream-ordered within ONE stream, so the outgoing stream is drained, owned or not
+  if(d->stream || d->own_stream) (void)hipStreamSynchronize(d->stream);
+  if(d->own_stream && d->stream) (void)hipStreamDestroy(d->stream);
   d->stream = (hipStream_t)stream;
   d->own_stream = false;
   return DT_HIP_SUCCESS;
@@ -333,7 +368,7 @@ dt_hip_mem_t dt_hip_alloc_device_buffer(int devid, size_t size)
   }
   else
   {
-    (void)hipSetDevice(d->hip_id);
+    make_current(devid);
     hipError_t e = hipMalloc(&p, rounded);
     if(e != hipSuccess)
     {
@@ -418,7 +453,7 @@ dt_hip_mem_t dt_hip_alloc_device_use_host_pointer(int devid, int width, int heig
   (void)flags;
   if(!valid_device(devid) || !host || width <= 0 || height <= 0 || bpp <= 0 || !dt_hip_is_pinned_memory(host)) return nullptr;
   void *dev = nullptr;
-  (void)hipSetDevice(g_devs[devid]->hip_id);
+  make_current(devid);
   if(hipHostGetDevicePointer(&dev, host, 0) != hipSuccess || !dev)
   {
     (void)hipGetLastError();

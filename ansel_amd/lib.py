@@ -197,23 +197,24 @@ class DeviceBuffer:
         import numpy as np
         arr = np.ascontiguousarray(arr)
         b = cls(devid, arr.nbytes)
-        check(b.lib.dt_hip_write_host_to_device(devid, arr.ctypes.data_as(C.c_void_p), b.ptr, arr.nbytes, 1, 1),
-              "write_host_to_device")
+        # the size_t entry point: a 201 MP float4 plane is 3.2 GB, more than the int width of the image calls holds
+        check(b.lib.dt_hip_write_buffer_to_device(devid, arr.ctypes.data_as(C.c_void_p), b.ptr, 0, arr.nbytes, 1),
+              "write_buffer_to_device")
         return b
 
     def upload(self, arr):
         import numpy as np
         arr = np.ascontiguousarray(arr)
         assert arr.nbytes <= self.nbytes
-        check(self.lib.dt_hip_write_host_to_device(self.devid, arr.ctypes.data_as(C.c_void_p), self.ptr, arr.nbytes, 1, 1),
-              "write_host_to_device")
+        check(self.lib.dt_hip_write_buffer_to_device(self.devid, arr.ctypes.data_as(C.c_void_p), self.ptr, 0, arr.nbytes, 1),
+              "write_buffer_to_device")
 
     def to_numpy(self, shape, dtype):
         import numpy as np
         out = np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes
-        check(self.lib.dt_hip_read_host_from_device(self.devid, out.ctypes.data_as(C.c_void_p), self.ptr,
-                                                    out.nbytes, 1, 1), "read_host_from_device")
+        check(self.lib.dt_hip_read_buffer_from_device(self.devid, out.ctypes.data_as(C.c_void_p), self.ptr, 0,
+                                                      out.nbytes, 1), "read_buffer_from_device")
         return out
 
     def release(self):

@@ -16,6 +16,14 @@ N > 1: one process per GPU, one frame per GPU (BASELINE.json config 5: batch exp
 frames across GPUs, no data-path collective) -> "scaling": "weak"; value = N frames / max time.
 --mode tiled is BASELINE.json config 4 instead: ONE frame cut into N row bands (ansel_amd/tiled.py),
 an 8-byte all-reduce and one 9-row halo send/recv per frame -> "scaling": "strong".
+Started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) it spawns its own N ranks under
+torch.distributed.run on 127.0.0.1; a launcher whose WORLD_SIZE disagrees with --gpus is an error.
+
+Besides `value` (the light pipe on the 100 MP frame, the workload the metric is quoted on) the line carries,
+at N = 1: `config.full_pipe` -- config 3's module list (+ profiled-wavelet denoise, diffuse or sharpen,
+non-local means in Lab) on the SAME 100 MP frame, timed in the same run; `verified` -- the output buffer the
+timed steps wrote, compared word for word with the oracle's chain after the timed region (the oracle is the
+checker here, never the thing measured); `cpu_baseline` -- the reference's own code on the host cores.
 
 PyTorch is used for device memory, the stream and torch.distributed only; all pixel work goes
 through the C-ABI of libansel_hip.so (include/ansel_hip.h).  There is no CPU fallback.
@@ -40,6 +48,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", default="100MP", help="24MP | 45MP | 60MP | 100MP | WxH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the post-timing comparison of the timed output buffer with the oracle chain")
+    ap.add_argument("--no-full-pipe", action="store_true",
+                    help="skip the config.full_pipe leg (config 3's modules on the same frame)")
+    ap.add_argument("--full-steps", type=int, default=3, help="timed steps of the config.full_pipe leg")
     ap.add_argument("--no-host-legs", action="store_true",
                     help="skip the PCIe-inclusive host-to-host measurements (profiling runs: only the timed region's kernels)")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per module (A/B against the fused executor)")
@@ -84,103 +97,236 @@ def have_filmic():
         return False
 
 
-def cpu_baseline(size_name, with_filmic, which="light"):
-    """The reference's own process() code (oracle/_ref/libansel_ref_fast.so: its sources compiled
-    in place with its release flags, OpenMP on every host core) on a bounded sample of the same
-    workload.  Falls back to the C restatement (kind "port", 1 thread) where _ref is absent."""
+def _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16):
+    """one pass of the module chain on host buffers, ping-ponging between two CFA and two RGBA planes"""
+    import checkers as ck
+    src = raw
+    ci = ri = 0
+    for n in nodes:
+        if n.op == "export_u16":
+            getattr(l, prefix + "export_convert_u16")(w, h, ck.ptr(src), ck.ptr(out16))
+            continue
+        if n.op in ("rawprepare", "temperature", "highlights"):
+            dst = cfa[ci]
+            ci ^= 1
+        else:
+            dst = rgb[ri]
+            ri ^= 1
+        rc = ck.call(l, prefix + n.op, n.piece, n.data, src, dst)
+        assert rc == 0, n.op
+        src = dst
+
+
+def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
+    """The reference's own process() code (oracle/_ref/libansel_ref_fast.so: its sources compiled in place with
+    its release flags, OpenMP) on a bounded sample of the same workload: threads bound to cores
+    (OMP_PROC_BIND=spread, OMP_PLACES=cores -- set in main() before the OpenMP runtime starts), the thread count
+    swept over {32, 64, 128, all} on the sample frame and the best kept; when a pass at that count is short enough,
+    one more pass on the DEVICE's frame size replaces the sample.  Buffers are first touched by the OpenMP team
+    (the warm-up pass), so pages land on the NUMA node of the thread that streams them.  Falls back to the C
+    restatement (kind "port") where _ref is absent."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import checkers as ck
-    from ansel_amd import params, pipe, synth
-    w, h = frame_size(size_name)
+    from ansel_amd import params, synth
     ref = ck.ref(fast=True)
     kind = "reference" if ref is not None else "port"
     l = ref if ref is not None else ck.oracle()
     if l is None:
         return None
     prefix = "ref_" if ref is not None else "oracle_"
-    cores = 1
+    ncpu = os.cpu_count() or 1
     if ref is not None:
         ref.ref_get_num_threads.restype = C.c_int
-        cores = int(ref.ref_get_num_threads())
+        set_threads = ref.ref_set_num_threads
+    else:
+        set_threads = C.CDLL("libgomp.so.1").omp_set_num_threads
     lut = params.srgb_encode_lut()
-    nodes = build_pipe(w, h, lut.ctypes.data, lut, with_filmic)
-    # 64-byte aligned like the reference's pixelpipe buffers (checkers.call would otherwise copy)
-    raw = ck.aligned_empty((h, w), np.uint16)
-    raw[...] = synth.bayer_mosaic_tiled(w, h, seed=1)
-    cfa = [ck.aligned_empty((h, w), np.float32) for _ in range(2)]
-    rgb = [ck.aligned_empty((h, w, 4), np.float32) for _ in range(2)]
-    out16 = ck.aligned_empty((h, w, 4), np.uint16)
 
-    def one_pass():
-        src = raw
-        ci = ri = 0
-        for n in nodes:
-            if n.op == "export_u16":
-                getattr(l, prefix + "export_convert_u16")(w, h, ck.ptr(src), ck.ptr(out16))
-                continue
-            if n.op in ("rgb_to_lab", "lab_to_rgb"):
-                dst = rgb[ri]
-                ri ^= 1
-                rc = ck.call(l, prefix + n.op, n.piece, n.data, src, dst)
-                assert rc == 0, n.op
-                src = dst
-                continue
-            if n.op in ("rawprepare", "temperature", "highlights"):
-                dst = cfa[ci]
-                ci ^= 1
-            else:
-                dst = rgb[ri]
-                ri ^= 1
-            rc = ck.call(l, prefix + n.op, n.piece, n.data, src, dst)
-            assert rc == 0, n.op
-            src = dst
+    def buffers(w, h):
+        raw = ck.aligned_empty((h, w), np.uint16)
+        raw[...] = synth.bayer_mosaic_tiled(w, h, seed=1)
+        return (raw, [ck.aligned_empty((h, w), np.float32) for _ in range(2)],
+                [ck.aligned_empty((h, w, 4), np.float32) for _ in range(2)], ck.aligned_empty((h, w, 4), np.uint16))
 
-    one_pass()  # warm-up: page in, spin up the OpenMP team
-    times = []
-    t_end = time.time() + 20.0
-    while len(times) < 3 or (time.time() < t_end and len(times) < 8):
-        t0 = time.perf_counter()
-        one_pass()
-        times.append(time.perf_counter() - t0)
-    best = sorted(times)[len(times) // 2]
-    return {"value": round(w * h / 1e6 / best, 3), "unit": "MPix/s", "cores": cores, "kind": kind,
-            "sample": "%d x %d RGGB frame (%s), same module chain, median of %d passes, %.2f s per pass"
-                      % (w, h, size_name, len(times), best)}
+    w, h = frame_size(size_name)
+    nodes = build_pipe(w, h, lut.ctypes.data, lut, with_filmic, which)
+    raw, cfa, rgb, out16 = buffers(w, h)
+    counts = sorted({c for c in (32, 64, 128, ncpu) if c <= ncpu} | {ncpu})
+    sweep = {}
+    t_budget = time.time() + 25.0
+    for c in reversed(counts):  # all cores first: its warm-up is the parallel first touch
+        set_threads(c)
+        _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16)  # warm-up: page in, spin up the team
+        times = []
+        while len(times) < 2 or (len(times) < 3 and time.time() < t_budget):
+            t0 = time.perf_counter()
+            _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16)
+            times.append(time.perf_counter() - t0)
+        sweep[c] = min(times)
+        if time.time() > t_budget and len(sweep) >= 2:
+            break
+    best_c = min(sweep, key=sweep.get)
+    best = sweep[best_c]
+    sample = "%d x %d RGGB frame (%s), same module chain, best of %d passes, %.2f s per pass" % (w, h, size_name, 3, best)
+    value = w * h / 1e6 / best
+    # the device's own frame size, when one pass of it is affordable (<= ~8 s predicted)
+    if device_size is not None and device_size != (w, h):
+        dw, dh = device_size
+        predicted = best * (dw * dh) / float(w * h)
+        if predicted <= 8.0:
+            del raw, cfa, rgb, out16
+            set_threads(best_c)
+            dn = build_pipe(dw, dh, lut.ctypes.data, lut, with_filmic, which)
+            raw, cfa, rgb, out16 = buffers(dw, dh)
+            _chain_pass(l, prefix, dn, dw, dh, raw, cfa, rgb, out16)
+            t0 = time.perf_counter()
+            _chain_pass(l, prefix, dn, dw, dh, raw, cfa, rgb, out16)
+            t = time.perf_counter() - t0
+            value = dw * dh / 1e6 / t
+            sample = ("%d x %d RGGB frame (the device's), same module chain, one pass after a warm-up, %.2f s; thread "
+                      "count chosen on a %d x %d sample" % (dw, dh, t, w, h))
+    return {"value": round(value, 3), "unit": "MPix/s", "cores": best_c, "kind": kind, "sample": sample,
+            "host_threads": ncpu,
+            "binding": "OMP_PROC_BIND=%s OMP_PLACES=%s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
+            "thread_sweep_mpix_s": {str(c): round(w * h / 1e6 / t, 3) for c, t in sorted(sweep.items())}}
+
+
+def verify_output(out16, raw_host, width, height, with_filmic, which):
+    """AFTER the timed region: the buffer the timed steps wrote against the oracle's module-by-module chain on the
+    same mosaic (oracle/liboracle.so, the checker; every host core).  Returns the `verify` object of the line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import checkers as ck
+    from ansel_amd import params
+    l = ck.oracle()
+    if l is None:
+        return {"verified": None, "why": "oracle/liboracle.so missing"}
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(os.cpu_count() or 1)
+    except OSError:
+        pass
+    lut = params.srgb_encode_lut()
+    nodes = build_pipe(width, height, lut.ctypes.data, lut, with_filmic, which)
+    t0 = time.perf_counter()
+    src = raw_host
+    for n in nodes:
+        if n.op == "export_u16":
+            exp = ck.aligned_empty((height, width, 4), np.uint16)
+            l.oracle_export_convert_u16(width, height, ck.ptr(src), ck.ptr(exp))
+            break
+        dst = ck.aligned_empty((height, width) if n.op in ("rawprepare", "temperature", "highlights") else (height, width, 4),
+                               np.float32)
+        fn = getattr(l, "oracle_" + n.op)
+        fn.restype = C.c_int
+        rc = fn(C.byref(n.piece), C.byref(n.data) if n.data is not None else None, ck.ptr(src), ck.ptr(dst))
+        assert rc == 0, n.op
+        src = dst
+    t_oracle = time.perf_counter() - t0
+    got = out16.cpu().numpy().view(np.uint16)
+    bad = 0
+    for r0 in range(0, height, 512):
+        bad += int((got[r0:r0 + 512] != exp[r0:r0 + 512]).sum())
+    return {"verified": bad == 0, "words": int(got.size), "mismatches": bad,
+            "against": "oracle/liboracle.so chain on the same mosaic, %.1f s on %d host threads" % (t_oracle, os.cpu_count() or 1)}
 
 
 def measured_traffic(tag, args):
-    """HBM bytes per launch of `tag` from the committed PMC summary of this exact configuration
-    (tools/profile_round.sh -> tools/pmc_hbm_json.py: separate FETCH_SIZE / WRITE_SIZE passes with the
-    gfx950 corrections of MI355X_MICROARCH.md); None when no summary matches the configuration."""
+    """HBM bytes per launch of `tag` from the COMMITTED PMC summary of this exact configuration (not collected in
+    this run: counters need rocprofv3 around the process -- tools/profile_round.sh -> tools/pmc_hbm_json.py:
+    separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of MI355X_MICROARCH.md); None when no
+    summary matches the configuration."""
     if args.size != "100MP" or args.pipe != "light" or args.no_fusion or args.mode != "batch":
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_bytes_100MP_light_fused.json")
+        return None, None
+    for name in ("r02_pmc_hbm_bytes_100MP_light_fused.json", "r01_h_pmc_hbm_bytes_100MP_light_fused.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            kernels = json.load(open(path))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for key in (tag, tag.replace("_u16", "")):
+            if key in kernels:
+                return kernels[key]["hbm_bytes"], "committed PMC summary profiles/" + name
+    return None, None
+
+
+# What binds each kernel, and the peak it is priced against.  HBM: 8 TB/s.  VALU: one wave64 instruction per
+# SIMD every 2 cycles for full-rate binary32, 4 for binary64 and packed, 8 for the quarter-rate transcendental
+# unit (profiles/r02_valu_issue_cycles.json, measured by tools/valu_microbench; MI355X_MICROARCH.md "Per-instruction
+# cycle constants") -> the kernel's issue-cycle total from its instruction mix (profiles/r02_isa_mix.json,
+# tools/isa_mix.py) over 1024 SIMDs at 2.4 GHz is its floor.
+KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu", "rcd_tiles": "valu+lds",
+                "nlm_chunks": "valu+lds", "diffuse_pde": "valu", "dn_decompose": "l2", "diffuse_decompose": "hbm",
+                "dn_synthesize": "hbm", "dn_precondition": "hbm", "dn_finish": "hbm", "rgb_to_lab": "hbm", "lab_to_rgb": "hbm"}
+
+
+def valu_floor_ms(tag, n_waves):
+    """issue-cycle floor of `tag` from the committed instruction-mix table; None when the table lacks it"""
     try:
-        kernels = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r02_isa_mix.json")))
+    except (OSError, ValueError):
         return None
-    for key in (tag, tag.replace("_u16", "")):
-        if key in kernels:
-            return kernels[key]["hbm_bytes"]
-    return None
+    k = mix.get("kernels", {}).get(tag)
+    if not k or "issue_cycles_per_wave" not in k:
+        return None
+    return k["issue_cycles_per_wave"] * n_waves / (1024 * 2.4e9) * 1e3
+
+
+def read_kernel_events(l, devid):
+    maxk = 96
+    tags = (C.c_char_p * maxk)()
+    ms = (C.c_float * maxk)()
+    cnt = (C.c_int * maxk)()
+    nk = l.dt_hip_events_profiling(devid, tags, ms, cnt, maxk)
+    kernels = {}
+    for i in range(min(nk, maxk)):
+        kernels[tags[i].decode()] = {"ms_avg": ms[i] / max(cnt[i], 1), "launches": cnt[i]}
+    return kernels
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: run the N ranks ourselves, one process per GPU, on 127.0.0.1"""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; there is no CPU fallback and no oversubscription"
+                         % (args.gpus, have))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_spawn(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, env_world))
+    # the CPU baseline's OpenMP runtime reads these when it starts (first call into oracle/_ref)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import numpy as np
     import torch
     import torch.distributed as dist
     from ansel_amd import abi, lib, params, pipe, synth, tiled
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     l = lib.init()
@@ -246,14 +392,44 @@ def main():
         elapsed = float(t.item())
 
     # ---- per-kernel HIP-event timings of the timed region (recorded on the launch stream)
-    maxk = 64
-    tags = (C.c_char_p * maxk)()
-    ms = (C.c_float * maxk)()
-    cnt = (C.c_int * maxk)()
-    nk = l.dt_hip_events_profiling(devid, tags, ms, cnt, maxk)
-    kernels = {}
-    for i in range(min(nk, maxk)):
-        kernels[tags[i].decode()] = {"ms_avg": ms[i] / max(cnt[i], 1), "launches": cnt[i]}
+    kernels = read_kernel_events(l, devid)
+
+    # ---- after the timed region: the buffer those steps wrote, against the oracle
+    verify = None
+    if rank == 0 and world == 1 and args.mode == "batch" and not args.no_verify:
+        verify = verify_output(out16, raw_host, width, height, with_filmic, args.pipe)
+
+    # ---- config 3's module list on the SAME frame, same run (config.full_pipe)
+    full = None
+    if rank == 0 and world == 1 and args.mode == "batch" and args.pipe == "light" and not args.no_full_pipe:
+        fnodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic, "denoise")
+        fexec = pipe.DevicePipe(devid, fnodes, fusion=not args.no_fusion)
+        fexec.process(raw.data_ptr(), out16.data_ptr())
+        torch.cuda.synchronize(dev)
+        l.dt_hip_events_reset(devid)
+        l.dt_hip_events_enable(devid, 1)
+        t1 = time.perf_counter()
+        for _ in range(args.full_steps):
+            fexec.process(raw.data_ptr(), out16.data_ptr())
+        torch.cuda.synchronize(dev)
+        f_ms = (time.perf_counter() - t1) / args.full_steps * 1e3
+        l.dt_hip_events_enable(devid, 0)
+        fk = read_kernel_events(l, devid)
+        f_bpp = pipe.algorithmic_bytes_per_pixel(fnodes)
+        full = {
+            "workload": "%d x %d RGGB u16 raw, export pipe: %s; module defaults" % (width, height, " > ".join(n.op for n in fnodes)),
+            "steps": args.full_steps,
+            "ms_per_step": round(f_ms, 3),
+            "mpix_s": round(npix / 1e6 / (f_ms * 1e-3), 2),
+            "algorithmic_bytes_per_px": f_bpp,
+            "hbm_frac": round(f_bpp * npix / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "launch_groups": fexec.num_groups,
+            "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / args.full_steps, 3) for k, v in sorted(fk.items())},
+            "kernel_launches_per_step": {k: v["launches"] // args.full_steps for k, v in sorted(fk.items())},
+        }
+        if not args.no_verify and os.environ.get("ANSEL_BENCH_VERIFY_FULL") == "1":
+            full["verify"] = verify_output(out16, raw_host, width, height, with_filmic, "denoise")
+        fexec.close()
 
     # ---- the same step with the boundary's two PCIe legs (never `value`): sensor buffer in pinned host memory ->
     #      basebuffer upload -> pipe -> exported frame back into pinned host memory
@@ -265,12 +441,12 @@ def main():
         pin_in, pin_out = l.dt_hip_alloc_host_pinned(nb_in), l.dt_hip_alloc_host_pinned(nb_out)
         if pin_in and pin_out:
             C.memmove(pin_in, raw_host.ctypes.data, nb_in)
-            full = abi.Piece.make(width, height, channels=1, datatype=abi.DT_HIP_TYPE_UINT16)
+            fullp = abi.Piece.make(width, height, channels=1, datatype=abi.DT_HIP_TYPE_UINT16)
             times = []
             for _ in range(3):
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
-                lib.check(l.dt_hip_iop_basebuffer_process(devid, C.byref(full), width, height, 2, pin_in, raw.data_ptr()), "basebuffer")
+                lib.check(l.dt_hip_iop_basebuffer_process(devid, C.byref(fullp), width, height, 2, pin_in, raw.data_ptr()), "basebuffer")
                 executor.process(raw.data_ptr(), out16.data_ptr())
                 lib.check(l.dt_hip_read_host_from_device(devid, pin_out, out16.data_ptr(), width, height, 8), "read")
                 times.append(time.perf_counter() - t1)
@@ -333,6 +509,20 @@ def main():
         pipe_bpp = pipe.algorithmic_bytes_per_pixel(nodes)
         ms_per_step = elapsed / args.steps * 1e3
         kernel_ms = sum(v["ms_avg"] * v["launches"] for k, v in kernels.items()) / args.steps
+        traffic, traffic_src = measured_traffic(dominant, args)
+        # what binds each kernel of the step: its algorithmic-byte HBM fraction and, where a committed instruction
+        # mix exists, its VALU issue floor (a kernel running at its floor cannot get faster without fewer instructions)
+        per_kernel = {}
+        for k, v in sorted(kernels.items()):
+            if k not in tag_bpp:
+                continue
+            e = {"ms": round(v["ms_avg"], 4), "bound": KERNEL_BOUND.get(k, "hbm"),
+                 "hbm_frac": round(tag_bpp[k] * my_rows * width / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            floor = valu_floor_ms(k, my_rows * width / 64.0)
+            if floor is not None:
+                e["valu_issue_floor_ms"] = round(floor, 4)
+                e["valu_frac"] = round(floor / v["ms_avg"], 4)
+            per_kernel[k] = e
         line = {
             "metric": "MPix/s full export pixelpipe (100 MP raw); % MI355X HBM roofline",
             "value": round((1 if args.mode == "tiled" else world) * npix / 1e6 / (elapsed / args.steps), 2),
@@ -358,23 +548,33 @@ def main():
                 "pipe_kernel_ms": round(kernel_ms, 4),
                 "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(kernels.items())},
                 "kernel_launches_per_step": {k: v["launches"] // args.steps for k, v in sorted(kernels.items())},
+                "kernel_bounds": per_kernel,
+                "full_pipe": full,
                 # not `value`: one frame from pinned host memory to pinned host memory over PCIe, no overlap
                 "host_to_host_ms": None if host_ms is None else round(host_ms, 3),
                 "host_to_host_overlapped_ms": None if host_overlap_ms is None else round(host_overlap_ms, 3),
                 "host_to_host_overlapped_rgb_rows_ms": None if host_rows_ms is None else round(host_rows_ms, 3),
             },
             "roofline": {
+                # the contract's figure: algorithmic bytes of the modules this launch executes / its duration / HBM peak
                 "bound": "hbm",
                 "kernel": dominant,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(dominant, args),
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                # ... and what actually binds this launch (config.kernel_bounds has every kernel of the step)
+                "binds": per_kernel.get(dominant, {}).get("bound"),
+                "valu_frac": per_kernel.get(dominant, {}).get("valu_frac"),
             },
         }
+        if verify is not None:
+            line["verified"] = verify["verified"]
+            line["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.cpu_sample, with_filmic, args.pipe)
+            cb = cpu_baseline(args.cpu_sample, with_filmic, args.pipe, device_size=(width, height))
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)

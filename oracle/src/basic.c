@@ -17,6 +17,7 @@ int oracle_rawprepare(const dt_hip_piece_t *piece, const dt_hip_rawprepare_data_
   float inv_div[4];
   for(int k = 0; k < 4; k++) inv_div[k] = 1.0f / d->div[k];
   float *const out = (float *)ovoid;
+  #pragma omp parallel for schedule(static)
   for(int j = 0; j < height; j++)
   {
     const size_t pin = (size_t)input_width * (j + csy) + csx;
@@ -42,6 +43,7 @@ int oracle_temperature(const dt_hip_piece_t *piece, const dt_hip_temperature_dat
   if(piece->filters == 9u) return 1;
   if(piece->filters)
   {
+    #pragma omp parallel for schedule(static)
     for(int j = 0; j < height; j++)
       for(int i = 0; i < width; i++)
       {
@@ -52,6 +54,7 @@ int oracle_temperature(const dt_hip_piece_t *piece, const dt_hip_temperature_dat
   }
   if(piece->channels != 4) return 1;
   const size_t npixels = (size_t)width * height;
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < npixels; k++)
   {
     out[4 * k + 0] = in[4 * k + 0] * d->coeffs[0];
@@ -80,6 +83,7 @@ int oracle_highlights(const dt_hip_piece_t *piece, const dt_hip_highlights_data_
   if(piece->filters)
   {
     const float raw_threshold = fminf(fminf(thr[0], thr[1]), thr[2]);
+#pragma omp parallel for schedule(static) reduction(+ : clipped)
     for(size_t k = 0; k < npixels; k++) clipped += (in[k] > raw_threshold);
   }
   else
@@ -97,6 +101,7 @@ int oracle_highlights(const dt_hip_piece_t *piece, const dt_hip_highlights_data_
     memcpy(out, in, sizeof(float) * npixels * ch);
     return 0;
   }
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < npixels * ch; k++) out[k] = (clip < in[k]) ? clip : in[k]; /* MIN(clip, in[k]) */
   return 0;
 }
@@ -107,6 +112,7 @@ int oracle_exposure(const dt_hip_piece_t *piece, const dt_hip_exposure_data_t *d
   const float *const in = (const float *)ivoid;
   float *const out = (float *)ovoid;
   const size_t n = (size_t)piece->roi_out.width * piece->roi_out.height * piece->channels;
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < n; k++) out[k] = (in[k] - d->black) * d->scale;
   return 0;
 }
@@ -116,6 +122,7 @@ int oracle_exposure(const dt_hip_piece_t *piece, const dt_hip_exposure_data_t *d
 int oracle_export_convert_u16(int width, int height, const float *in, uint16_t *out)
 {
   const size_t n = (size_t)width * height * 4;
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < n; k++)
   {
     const float x = roundf(in[k] * 65535.f);
@@ -130,6 +137,7 @@ int oracle_export_convert_u16(int width, int height, const float *in, uint16_t *
 int oracle_export_convert_u8(int width, int height, const float *in, uint8_t *out)
 {
   const size_t n = (size_t)width * height * 4;
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < n; k++)
   {
     const float x = roundf(in[k] * 255.f);

@@ -68,6 +68,7 @@ static int conversion(const dt_hip_piece_t *piece, const dt_hip_conversion_t *d,
     ls[c] = (const float *)d->lut_source[c];
     lt[c] = (const float *)d->lut_target[c];
   }
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < npixels; k++)
   {
     px_t s;
@@ -269,6 +270,7 @@ int oracle_channelmixerrgb(const dt_hip_piece_t *piece, const dt_hip_channelmixe
   static const float bradford_D50[4] = { 0.996078f, 1.020646f, 0.818155f, 0.f };
   static const float cat16_D50[4] = { 0.994535f, 1.000997f, 0.833036f, 0.f };
   static const float xyz_D50[4] = { 0.9642119944211994f, 1.0f, 0.8251882845188288f, 0.f };
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < npixels; k++)
   {
     px_t in_v, one, two;
@@ -385,6 +387,7 @@ int oracle_rgb_to_lab(const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, c
   float *out = (float *)out_;
   const float(*m)[4] = d->matrix;
   const size_t n = (size_t)piece->roi_out.width * piece->roi_out.height;
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < n; k++)
   {
     px_t p;
@@ -406,6 +409,7 @@ int oracle_lab_to_rgb(const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, c
   float *out = (float *)out_;
   const float(*m)[4] = d->matrix;
   const size_t n = (size_t)piece->roi_out.width * piece->roi_out.height;
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < n; k++)
   {
     const float fy = (in[4 * k] + 16.0f) / 116.0f;

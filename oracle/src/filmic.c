@@ -550,6 +550,7 @@ int oracle_filmicrgb(const dt_hip_piece_t *piece, const dt_hip_filmicrgb_data_t 
   const size_t npixels = (size_t)piece->roi_out.width * piece->roi_out.height;
   prep_t p;
   prepare(d, &p);
+  #pragma omp parallel for schedule(static)
   for(size_t k = 0; k < npixels; k++)
   {
     v4 pix_in, res;

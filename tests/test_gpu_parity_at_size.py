@@ -1,0 +1,164 @@
+"""-m gpu: HIP against the oracle AT THE FRAME SIZES BASELINE.json NAMES -- the configurations bench.py times.
+
+Every other parity test in this directory runs frames of at most a few megapixels so that the whole suite
+stays fast; those cannot see what only a full frame exercises: 64-bit offsets (a 100 MP float4 plane is
+1.63 GB), more than 1024 segments per row-sum table of the profiled wavelets, the 23 k-chunk grid of the
+non-local means, XCD-rotated launches at real widths, tile grids with thousands of workgroups.  Here:
+
+  config 2   6000 x 4000   light pipe (rawprepare ... RCD ... filmic ... u16)
+  config 3   9504 x 6336   + denoise (profiled) wavelets + diffuse or sharpen + non-local means in Lab
+  metric    11648 x 8736   light pipe                            (what bench.py's `value` is quoted on)
+  config 4  11648 x 8736   config 3's modules, the frame cut into 8 row bands run in lockstep
+
+each compared word for word (RGBA u16, the exported buffer) with the oracle's module-by-module chain on the
+same synthetic mosaic.  The oracle (oracle/liboracle.so) is OpenMP code whose results do not depend on the
+thread count (tests/test_oracle_vs_ref.py pins it against the reference's own sources); it is given every
+host core here.  Frames whose oracle chain does not fit the host's memory are skipped with the reason."""
+import ctypes
+import os
+import time
+
+import numpy as np
+import pytest
+
+import checkers as ck
+import hipcheck as hc
+from ansel_amd import filmic, params, pipe, synth, tiled
+
+pytestmark = pytest.mark.gpu
+
+CFA_OPS = ("rawprepare", "temperature", "highlights")
+
+
+def _all_cores():
+    """the session fixture caps the checkers at 32 threads (small frames); these frames want every core"""
+    n = os.cpu_count() or 1
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(n)
+    except OSError:
+        pass
+    return n
+
+
+def _restore_cores():
+    if (os.cpu_count() or 1) > 32 and "OMP_NUM_THREADS" not in os.environ:
+        try:
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(32)
+        except OSError:
+            pass
+
+
+def _need_host_memory(gib):
+    import psutil
+    have = psutil.virtual_memory().available / 2.0 ** 30
+    if have < gib:
+        pytest.skip("the oracle chain of this frame needs ~%d GiB of host memory, %.0f GiB available" % (gib, have))
+
+
+def _nodes(which, w, h, lut_ptr, lut):
+    coeffs = params.unbounded_coeffs(lut)
+    if which == "light":
+        return pipe.light_pipe_nodes(w, h, lut_ptr, float(lut[0]), coeffs, with_filmic=True, filmic=filmic.default_data())
+    return pipe.denoise_pipe_nodes(w, h, lut_ptr, float(lut[0]), coeffs, filmic=filmic.default_data(),
+                                   diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
+
+
+def oracle_chain(nodes, raw, w, h):
+    """module by module on the host, each intermediate freed as soon as the next exists"""
+    l = ck.oracle()
+    assert l is not None, "oracle/liboracle.so missing: run build()"
+    src = raw
+    for n in nodes:
+        if n.op == "export_u16":
+            out = ck.aligned_empty((h, w, 4), np.uint16)
+            l.oracle_export_convert_u16(w, h, ck.ptr(src), ck.ptr(out))
+            return out
+        dst = ck.aligned_empty((h, w) if n.op in CFA_OPS else (h, w, 4), np.float32)
+        fn = getattr(l, "oracle_" + n.op)
+        fn.restype = ctypes.c_int
+        rc = fn(ctypes.byref(n.piece), ctypes.byref(n.data) if n.data is not None else None, ck.ptr(src), ck.ptr(dst))
+        assert rc == 0, n.op
+        src = dst
+    raise AssertionError("the pipe does not end in export_u16")
+
+
+def _device_whole(torch, nodes, raw, w, h):
+    p = pipe.DevicePipe(0, nodes, fusion=True)
+    d_in = torch.from_numpy(raw.view(np.int16)).to("cuda:0")
+    d_out = torch.zeros((h, w, 4), dtype=torch.int16, device="cuda:0")
+    p.process(d_in.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize()
+    p.close()
+    out = d_out.cpu().numpy().view(np.uint16)
+    del d_in, d_out
+    return out
+
+
+def _device_banded(torch, nodes, raw, w, h, n):
+    p = pipe.DevicePipe(0, nodes, fusion=True)
+    engine = tiled.HipBandEngine(p, "cuda:0")
+    bands = tiled.plan_bands(w, h, n, tiled.pipe_demosaic_method(nodes))
+    ins = [torch.from_numpy(np.ascontiguousarray(raw[b.row0:b.row0 + b.rows]).view(np.int16)).to("cuda:0") for b in bands]
+    outs = [torch.zeros((b.rows, w, 4), dtype=torch.int16, device="cuda:0") for b in bands]
+    tiled.process_bands_locally(engine, bands, [t.data_ptr() for t in ins], [t.data_ptr() for t in outs], w)
+    torch.cuda.synchronize()
+    p.close()
+    return np.concatenate([t.cpu().numpy().view(np.uint16) for t in outs], axis=0)
+
+
+def _compare(dev, exp, what):
+    assert dev.shape == exp.shape
+    # row blocks keep the temporaries of a 100 MP comparison small
+    bad = 0
+    first = None
+    for r0 in range(0, dev.shape[0], 512):
+        d = dev[r0:r0 + 512] != exp[r0:r0 + 512]
+        nb = int(d.sum())
+        if nb and first is None:
+            y, x, c = [int(v[0]) for v in np.nonzero(d)]
+            first = (r0 + y, x, c, int(dev[r0 + y, x, c]), int(exp[r0 + y, x, c]))
+        bad += nb
+    assert bad == 0, "%s: %d of %d exported words differ from the oracle; first at (row %d, col %d, ch %d): device %d, oracle %d" \
+        % ((what, bad, dev.size) + first)
+
+
+def _case(which, size, bands=0, host_gib=8):
+    import torch
+    hc.hip()
+    _need_host_memory(host_gib)
+    w, h = synth.SIZES[size]
+    lut = params.srgb_encode_lut()
+    d_lut = torch.from_numpy(lut).to("cuda:0")
+    raw = synth.bayer_mosaic_tiled(w, h, seed=2)
+    dev_nodes = _nodes(which, w, h, d_lut.data_ptr(), lut)
+    dev = _device_whole(torch, dev_nodes, raw, w, h)
+    assert dev.std() > 100  # a picture came out
+    banded = _device_banded(torch, dev_nodes, raw, w, h, bands) if bands else None
+    torch.cuda.empty_cache()
+    _all_cores()
+    try:
+        t0 = time.time()
+        exp = oracle_chain(_nodes(which, w, h, lut.ctypes.data, lut), raw, w, h)
+        print("oracle chain %s %s: %.1f s on %d host threads" % (which, size, time.time() - t0, os.cpu_count() or 1))
+    finally:
+        _restore_cores()
+    _compare(dev, exp, "%s pipe, %d x %d" % (which, w, h))
+    if banded is not None:
+        _compare(banded, exp, "%s pipe, %d x %d in %d row bands" % (which, w, h, bands))
+
+
+def test_config2_light_pipe_24MP_equals_the_oracle():
+    _case("light", "24MP", host_gib=6)
+
+
+def test_config3_full_pipe_60MP_equals_the_oracle():
+    _case("denoise", "60MP", host_gib=48)
+
+
+def test_metric_light_pipe_100MP_equals_the_oracle():
+    _case("light", "100MP", host_gib=16)
+
+
+def test_config4_full_pipe_100MP_in_8_row_bands_equals_the_oracle():
+    """the unsplit device run, the 8-band lockstep run and the oracle: three times the same 814 MB"""
+    _case("denoise", "100MP", bands=8, host_gib=80)
