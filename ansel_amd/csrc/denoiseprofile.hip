@@ -6,10 +6,13 @@
 // the band's sum of squared details (variance_stabilizing_xform(), :1223-1287) -> soft-threshold
 // accumulate eaw_synthesize() (eaw.c:157-175) -> + residue -> inverse transform.
 //
-// Launches per frame: 1 precondition, per band {decompose, threshold, synthesize}, 1 finish
-// (residue add + inverse transform fused: same arithmetic, one pass less than the reference).
-// Nothing returns to the host between launches: the band threshold is computed on the device from
-// the reduced sums and consumed by the synthesize kernel through a 16-byte buffer.
+// Launches per frame: 1 precondition, per band {decompose, threshold}, 1 finish.  Every band keeps its
+// detail plane (7 x 1.6 GB at 100 MP, of 288 GB), so the soft-threshold accumulation of ALL bands
+// (eaw_synthesize(), in band order, from a zero accumulator: the same additions in the same order), the
+// residue add and the inverse transform are one pass over the frame -- 144 B/px instead of the 384 B/px
+// of one read-modify-write pass per band.  Nothing returns to the host between launches: the band
+// thresholds are computed on the device from the reduced sums and consumed through a 112-byte buffer.
+// The round-robin accumulation of the segment sums runs on 16 workgroups (one CU reads 12.8 MB at ~55 GB/s).
 //
 // The sum of squared details is an OpenMP float reduction in the reference, so its value depends on
 // the host's thread count.  Here (and in oracle/src/denoiseprofile.c) it is the binary64 sum of the
@@ -106,13 +109,39 @@ __global__ __launch_bounds__(256) void dn_precondition(const float4 *__restrict_
 
 // out[k] += residue[k] (denoiseprofile.c:1423-1425) followed by backtransform(), backtransform_v2(),
 // backtransform_Y0U0V0(): :872-897, :996-1019, :1053-1090
+struct synth_args
+{
+  int nbands;                 // 0: `out` already holds the accumulator (the non-local-means path)
+  const float4 *detail[BANDS]; // the bands' detail planes, finest first
+  const float *thrs;          // [nbands][4]
+};
+
+// eaw_synthesize() with boost 1, eaw.c:157-175, for one band on the accumulator in registers
+__device__ __forceinline__ void synthesize_band(float4 &acc, const float4 d, const float *__restrict__ t)
+{
+  acc.x = acc.x + (1.0f * (max_first(d.x - t[0], 0.0f) + min_first(d.x + t[0], 0.0f)));
+  acc.y = acc.y + (1.0f * (max_first(d.y - t[1], 0.0f) + min_first(d.y + t[1], 0.0f)));
+  acc.z = acc.z + (1.0f * (max_first(d.z - t[2], 0.0f) + min_first(d.z + t[2], 0.0f)));
+  acc.w = acc.w + (1.0f * (max_first(d.w - t[3], 0.0f) + min_first(d.w + t[3], 0.0f)));
+}
+
 __global__ __launch_bounds__(256) void dn_finish(float4 *__restrict__ out, const float4 *__restrict__ residue,
-                                                 const size_t npix, const vst_args a)
+                                                 const size_t npix, const vst_args a, const synth_args sy)
 {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
   if(j < npix)
   {
-    const float4 acc = out[j];
+    float4 acc;
+    if(sy.nbands > 0)
+    {
+      // the accumulator of denoiseprofile.c:1398 starts zeroed; bands are added finest first (:1400-1421)
+      acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for(int b = 0; b < BANDS; b++)
+        if(b < sy.nbands) synthesize_band(acc, sy.detail[b][j], sy.thrs + 4 * b);
+    }
+    else
+      acc = out[j];
     float v[4] = { acc.x, acc.y, acc.z, acc.w };
     if(residue)
     {
@@ -217,6 +246,8 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
       {
         const int x = clampi(col + mult * (ii - 2), 0, width - 1);
         const float fi = ii == 0 || ii == 4 ? 0.0625f : (ii == 2 ? 0.375f : 0.25f);
+        // straight from L1 / L2: staging the five tap rows in LDS was measured (2.96 ms against 2.85 ms at 100 MP) --
+        // the kernel is bound by the ~28 VALU instructions of each tap, not by its fetch
         const float4 p2 = in[y + x];
         // dn_weight(), eaw.c:181-195
         const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
@@ -268,22 +299,53 @@ struct thr_args
   float adjt[4];   // 8 x the band's force factors
 };
 
-// step 2 of the canonical sum + variance_stabilizing_xform(), denoiseprofile.c:1223-1287
-__global__ __launch_bounds__(1024) void dn_band_threshold(const double *__restrict__ partial, const thr_args a,
+// step 2 of the canonical sum.  Segment sums, numbered row-major, go round-robin to 1024 accumulators, each adding
+// its segments in increasing order; accumulator t is thread t % 64 of workgroup t / 64 (the order of the additions
+// does not depend on which workgroup holds an accumulator; sixteen CUs read the table sixteen times faster than one)
+#define THR_GROUPS 16
+__global__ __launch_bounds__(64) void dn_band_sums(const double *__restrict__ partial, const size_t n_partial,
+                                                  double *__restrict__ acc /* [4][1024] */)
+{
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  double s[4] = { 0.0, 0.0, 0.0, 0.0 };
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const d4 *const p4 = (const d4 *)partial;
+  size_t k = t;
+  for(; k + 7 * 1024 < n_partial; k += 8 * 1024)
+  {
+    d4 v[8];
+#pragma unroll
+    for(int u = 0; u < 8; u++) v[u] = p4[k + (size_t)u * 1024];
+#pragma unroll
+    for(int u = 0; u < 8; u++)
+    {
+      s[0] += v[u].x;
+      s[1] += v[u].y;
+      s[2] += v[u].z;
+      s[3] += v[u].w;
+    }
+  }
+  for(; k < n_partial; k += 1024)
+  {
+    const d4 v = p4[k];
+    s[0] += v.x;
+    s[1] += v.y;
+    s[2] += v.z;
+    s[3] += v.w;
+  }
+#pragma unroll
+  for(int c = 0; c < 4; c++) acc[c * 1024 + t] = s[c];
+}
+
+// the 1024 accumulators reduced by halving (off = 512..1), rounded once to binary32, then
+// variance_stabilizing_xform(), denoiseprofile.c:1223-1287
+__global__ __launch_bounds__(1024) void dn_band_threshold(const double *__restrict__ sums /* [4][1024] */, const thr_args a,
                                                           float *__restrict__ thrs)
 {
   __shared__ double acc[4][1024];
   const int t = threadIdx.x;
-  double s[4] = { 0.0, 0.0, 0.0, 0.0 };
-  for(size_t k = t; k < a.n_partial; k += 1024)
-  {
-    s[0] += partial[4 * k + 0];
-    s[1] += partial[4 * k + 1];
-    s[2] += partial[4 * k + 2];
-    s[3] += partial[4 * k + 3];
-  }
 #pragma unroll
-  for(int c = 0; c < 4; c++) acc[c][t] = s[c];
+  for(int c = 0; c < 4; c++) acc[c][t] = sums[c * 1024 + t];
   __syncthreads();
   for(int off = 512; off >= 1; off >>= 1)
   {
@@ -299,24 +361,6 @@ __global__ __launch_bounds__(1024) void dn_band_threshold(const double *__restri
     const float sum_y2 = (float)acc[t][0];
     const float std_x = t < 3 ? sqrtf(max_first(1e-6f, sum_y2 / a.n1 - a.sb2)) : 1.0f;
     thrs[t] = a.adjt[t] * a.sb2 / std_x;
-  }
-}
-
-// eaw_synthesize() with boost 1, eaw.c:157-175; first band: the accumulator is the zeroed output
-// (denoiseprofile.c:1398), i.e. 0 + amount
-__global__ __launch_bounds__(256) void dn_synthesize(float4 *__restrict__ out, const float4 *__restrict__ detail,
-                                                     const float *__restrict__ thrs, const size_t npix, const int first)
-{
-  const float t0 = thrs[0], t1 = thrs[1], t2 = thrs[2], t3 = thrs[3];
-  for(size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < npix; j += (size_t)gridDim.x * blockDim.x)
-  {
-    const float4 d = detail[j];
-    float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : out[j];
-    acc.x = acc.x + (1.0f * (max_first(d.x - t0, 0.0f) + min_first(d.x + t0, 0.0f)));
-    acc.y = acc.y + (1.0f * (max_first(d.y - t1, 0.0f) + min_first(d.y + t1, 0.0f)));
-    acc.z = acc.z + (1.0f * (max_first(d.z - t2, 0.0f) + min_first(d.z + t2, 0.0f)));
-    acc.w = acc.w + (1.0f * (max_first(d.w - t3, 0.0f) + min_first(d.w + t3, 0.0f)));
-    out[j] = acc;
   }
 }
 
@@ -589,7 +633,9 @@ int denoise_nlmeans(int devid, const dt_hip_piece_t *piece, const dt_hip_denoise
     vst_args ia;
     inverse_args(s, ia);
     launch_scope ls(devid, "dn_finish");
-    dn_finish<<<pixel_grid(npix_out), 256, 0, st>>>((float4 *)dev_out, nullptr, npix_out, ia);
+    synth_args none;
+    memset(&none, 0, sizeof(none));
+    dn_finish<<<pixel_grid(npix_out), 256, 0, st>>>((float4 *)dev_out, nullptr, npix_out, ia, none);
   }
   return check_launch("dn_finish");
 }
@@ -697,7 +743,7 @@ int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_h
   bool ok = (j->cur = (float4 *)dt_hip_alloc_device_buffer(devid, npix * sizeof(float4))) != nullptr;
   ok &= (j->sums = (double *)dt_hip_alloc_device_buffer(devid, sums_bytes)) != nullptr;
   ok &= (j->local = (double *)dt_hip_alloc_device_buffer(devid, (size_t)j->rows * nseg * 4 * sizeof(double))) != nullptr;
-  ok &= (j->thrs = (float *)dt_hip_alloc_device_buffer(devid, 4 * sizeof(float))) != nullptr;
+  ok &= (j->thrs = (float *)dt_hip_alloc_device_buffer(devid, BANDS * 4 * sizeof(float))) != nullptr;
   if(!ok || j->cur_bottom < 0)
   {
     denoiseprofile_band_abort(j);
@@ -764,9 +810,10 @@ int denoiseprofile_band_step(dn_band_job_t *j, dt_hip_mem_t *halo_buf, int *halo
   const int rows = (j->rows <= mult) ? j->rows : ((j->rows + mult - 1) / mult) * mult;
   {
     launch_scope ls(devid, "dn_decompose");
-    dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(j->cur, coarse + (size_t)top * w, j->det[scale], j->local, w, j->rows,
-                                                             mult, 1.0f / (sigma_band * sigma_band), nseg, j->cur_top,
-                                                             j->cur_top + j->rows + j->cur_bottom);
+    dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(j->cur, coarse + (size_t)top * w, j->det[scale],
+                                                                               j->local, w, j->rows, mult,
+                                                                               1.0f / (sigma_band * sigma_band), nseg, j->cur_top,
+                                                                               j->cur_top + j->rows + j->cur_bottom);
   }
   int err = check_launch("denoiseprofile band decompose");
   // the own rows' partial sums at their place in the frame's table
@@ -802,30 +849,34 @@ int denoiseprofile_band_finish(dn_band_job_t *j, dt_hip_mem_t dev_out)
   hipStream_t st = stream_of(devid);
   float4 *out = (float4 *)dev_out;
   int err = DT_HIP_SUCCESS;
+  synth_args sy;
+  memset(&sy, 0, sizeof(sy));
+  sy.nbands = j->max_scale;
+  sy.thrs = j->thrs;
+  double *accs = (double *)dt_hip_alloc_device_buffer(devid, 4 * 1024 * sizeof(double));
+  if(!accs) err = DT_HIP_SYSMEM_ALLOCATION;
   for(int scale = 0; scale < j->max_scale && err == DT_HIP_SUCCESS; scale++)
   {
     thr_args ta;
     ta.n_partial = n_frame;
     threshold_args(&j->d, scale, j->max_scale, (size_t)j->w * j->frame_h, ta);
-    {
-      launch_scope ls(devid, "dn_band_threshold");
-      dn_band_threshold<<<1, 1024, 0, st>>>(j->sums + (size_t)scale * n_frame * 4, ta, j->thrs);
-    }
-    {
-      launch_scope ls(devid, "dn_synthesize");
-      dn_synthesize<<<stream_grid(npix, 256), 256, 0, st>>>(out, j->det[scale], j->thrs, npix, scale == 0);
-    }
-    err = check_launch("denoiseprofile band synthesis");
+    sy.detail[scale] = j->det[scale];
+    launch_scope ls(devid, "dn_band_threshold");
+    dn_band_sums<<<THR_GROUPS, 64, 0, st>>>(j->sums + (size_t)scale * n_frame * 4, n_frame, accs);
+    dn_band_threshold<<<1, 1024, 0, st>>>(accs, ta, j->thrs + 4 * scale);
+    err = check_launch("denoiseprofile band threshold");
   }
   if(err == DT_HIP_SUCCESS)
   {
-    // the last coarse plane has no halo: j->cur holds the band's own rows of the residual
+    // every band's soft threshold, the residue (the last coarse plane has no halo: j->cur holds the band's own rows)
+    // and the inverse transform in one pass
     vst_args ia;
     inverse_args(j->s, ia);
     launch_scope ls(devid, "dn_finish");
-    dn_finish<<<pixel_grid(npix), 256, 0, st>>>(out, j->cur + (size_t)j->cur_top * j->w, npix, ia);
+    dn_finish<<<pixel_grid(npix), 256, 0, st>>>(out, j->cur + (size_t)j->cur_top * j->w, npix, ia, sy);
     err = check_launch("dn_finish");
   }
+  if(accs) dt_hip_release_mem_object(accs);
   denoiseprofile_band_abort(j);
   return err;
 }
@@ -858,12 +909,23 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
   const size_t n_partial = (size_t)h * nseg;
   float4 *precond = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
   float4 *tmp = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
-  float4 *det = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
   double *partial = (double *)dt_hip_alloc_device_buffer(devid, n_partial * 4 * sizeof(double));
-  float *thrs = (float *)dt_hip_alloc_device_buffer(devid, 4 * sizeof(float));
-  int err = (precond && tmp && det && partial && thrs) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
+  float *thrs = (float *)dt_hip_alloc_device_buffer(devid, BANDS * 4 * sizeof(float));
+  double *accs = (double *)dt_hip_alloc_device_buffer(devid, 4 * 1024 * sizeof(double));
+  int err = (precond && tmp && partial && thrs && accs) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
+  // one detail plane per band, all alive until the single synthesis pass at the end
+  synth_args sy;
+  memset(&sy, 0, sizeof(sy));
+  sy.nbands = s.max_scale;
+  sy.thrs = thrs;
+  float4 *det[BANDS] = { nullptr };
+  for(int k = 0; k < s.max_scale && err == DT_HIP_SUCCESS; k++)
+  {
+    det[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
+    sy.detail[k] = det[k];
+    if(!det[k]) err = DT_HIP_SYSMEM_ALLOCATION;
+  }
   float4 *out = (float4 *)dev_out;
-  const unsigned sgrid = stream_grid(npix, 256);
   if(err == DT_HIP_SUCCESS)
   {
     vst_args fa;
@@ -880,19 +942,16 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
     const int rows = (h <= mult) ? h : ((h + mult - 1) / mult) * mult;
     {
       launch_scope ls(devid, "dn_decompose");
-      dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(b1, b2, det, partial, w, h, mult,
-                                                               1.0f / (sigma_band * sigma_band), nseg, 0, h);
+      dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(b1, b2, det[scale], partial, w, h, mult,
+                                                                                 1.0f / (sigma_band * sigma_band), nseg, 0, h);
     }
     thr_args ta;
     ta.n_partial = n_partial;
     threshold_args(d, scale, s.max_scale, npix, ta);
     {
       launch_scope ls(devid, "dn_band_threshold");
-      dn_band_threshold<<<1, 1024, 0, st>>>(partial, ta, thrs);
-    }
-    {
-      launch_scope ls(devid, "dn_synthesize");
-      dn_synthesize<<<sgrid, 256, 0, st>>>(out, det, thrs, npix, scale == 0);
+      dn_band_sums<<<THR_GROUPS, 64, 0, st>>>(partial, n_partial, accs);
+      dn_band_threshold<<<1, 1024, 0, st>>>(accs, ta, thrs + 4 * scale);
     }
     err = check_launch("denoiseprofile band");
     float4 *t = b2;
@@ -904,21 +963,23 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
     vst_args ia;
     inverse_args(s, ia);
     launch_scope ls(devid, "dn_finish");
-    dn_finish<<<pixel_grid(npix), 256, 0, st>>>(out, b1, npix, ia);
+    dn_finish<<<pixel_grid(npix), 256, 0, st>>>(out, b1, npix, ia, sy);
     err = check_launch("dn_finish");
   }
   if(precond) dt_hip_release_mem_object(precond);
   if(tmp) dt_hip_release_mem_object(tmp);
-  if(det) dt_hip_release_mem_object(det);
+  for(int k = 0; k < BANDS; k++)
+    if(det[k]) dt_hip_release_mem_object(det[k]);
   if(partial) dt_hip_release_mem_object(partial);
   if(thrs) dt_hip_release_mem_object(thrs);
+  if(accs) dt_hip_release_mem_object(accs);
   return err;
 }
 
 
 // tiling_callback(), src/iop/denoiseprofile.c:796-848.  factor / overlap as the reference states them for the host;
-// factor_cl = the planes this implementation holds on the device: wavelets in + out + precond + tmp + detail (the
-// partial sums are W / 64 of a plane), non-local means in + out + the preconditioned copy (the tables live in LDS)
+// factor_cl = the planes this implementation holds on the device: wavelets in + out + precond + tmp + one detail
+// plane per band (the partial sums are W / 64 of a plane), non-local means in + out + the preconditioned copy (the tables live in LDS)
 void dt_hip_iop_denoiseprofile_tiling(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
                                       dt_hip_tiling_t *tiling)
 {
@@ -939,7 +1000,7 @@ void dt_hip_iop_denoiseprofile_tiling(const dt_hip_piece_t *piece, const dt_hip_
     dn_setup s;
     setup(piece, d, s, false);
     tiling->factor = 5.0f;
-    tiling->factor_cl = 5.0f + 1.0f / 64.0f;
+    tiling->factor_cl = 4.0f + (float)s.max_scale + 1.0f / 64.0f; // in, out, precond, tmp, one detail plane per band
     tiling->overlap = 1u << s.max_scale;
   }
 }
