@@ -1,0 +1,367 @@
+// nlm2_body.h -- the non-local-means chunk kernel for INTERIOR chunks (no patch leaves the frame), written once and
+// compiled twice: as the body of nlm_chunks_v2<P> (nlmeans.hip, gfx950) and, with a host environment whose
+// workgroup is 1024 OS threads on a std::barrier, by tests/native/nlm2_host.cpp -- so that every index of the
+// schedule below is checked against the oracle on a CPU before the kernel ever meets a GPU.
+//
+// Same arithmetic as nlm_chunks_pipelined (nlmeans.hip; reference src/pixel/nlmeans_core.c:315-532): per chunk and
+// patch offset the column-sum recurrence down the rows (A2), the row-sum recurrence across the columns (B), the
+// weight 2^-x and the accumulation (C), software-pipelined over the offsets with two tables.  What differs is how
+// much LDS traffic and arithmetic the two fully parallel steps cost:
+//
+//   * the window keeps (x, y) of a pixel as one 8-byte word and z in a plane of its own: a pixel is two LDS reads
+//     (ds_read_b64 + ds_read_b32: 4.4 cycles of the LDS pipe) instead of three ds_read_b32 (6.6);
+//   * A1, the terms of the column recurrence: the term of table row t is D(b) - D(b - S) with b = the row entering
+//     the patch, S = 2 P + 1 and D(r) the squared differences of row r -- so the terms t, t + S, t + 2 S, ... of one
+//     column form a chain in which every D is an "entering" row once and a "leaving" row once.  A work item is such
+//     a chain (<= 10 terms): it squares each row ONCE and keeps it in registers for its second use.  Per term 4.7 LDS
+//     reads and 15 VALU instructions instead of 12 and ~21.  (a - b)^2 is computed by the same two operations on
+//     the same operands as in the reference's diff_of_pixels_diff(), so the term is the same binary32 value;
+//   * B reads every table entry once: the value that leaves the sliding window is the one that entered it S steps
+//     earlier and is still in a register;
+//   * C reads 3 words per pixel and offset instead of 4;
+//   * no per-offset geometry at all: an interior chunk's row / column ranges are the chunk itself.
+#pragma once
+
+#ifdef __HIPCC__
+#define NLM2_FN __device__ __forceinline__
+#else
+#define NLM2_FN inline
+#endif
+
+#define NL2_THREADS 1024
+#define NL2_SERIAL 256                     // threads of the serial group (the two recurrences)
+#define NL2_PAR (NL2_THREADS - NL2_SERIAL) // threads of the parallel group (terms, weights)
+#define NL2_PX 7                           // accumulators per parallel thread: ceil(72 * 69 / 768)
+#define NL2_WP 96                          // window pitch (pixels)
+#define NL2_TP 81                          // table pitch (floats), odd: B walks the table one row per lane
+#define NL2_MSEG 10                        // most terms of one A1 work item (patch radius 3, 69 rows: one chain of 10)
+
+namespace nlm2
+{
+
+struct alignas(8) f2 // one 8-byte LDS word (ds_read_b64); without the alignment the compiler reads it as two dwords
+{
+  float x, y;
+};
+
+NLM2_FN int imin(const int a, const int b) { return a < b ? a : b; }
+
+// dt_fast_mexp2f(), src/math/math.h:290-301; the float -> int conversion as the reference's target does it
+// (cvttss2si: out of range and NaN -> INT_MIN)
+template <class Env> NLM2_FN float mexp2(const float x)
+{
+  const float v = x * -8388608.0f;
+  const int cv = (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+  const int k0 = (int)(0x3f800000u + (unsigned)cv);
+  return Env::int_as_float(k0 >= 0x800000 ? k0 : 0);
+}
+
+// Args: nlm_args of nlmeans.hip (W, H, chk_w, chk_h, nchx, npatch, sharpness, norm[3], luma, chroma, skip_blend,
+// reach, cy0, out_row0, out_row1).  F4 / I2: float4 / int2.
+template <int P, class Env, class Args, class F4, class I2>
+NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches)
+{
+  constexpr int S = 2 * P + 1;
+  constexpr int pitch = NL2_TP;
+  const int tid = env.tid();
+  const int W = a.W, H = a.H;
+  const int cy_launch = env.bid() / a.nchx, cx = env.bid() - cy_launch * a.nchx;
+  const int cy = cy_launch + a.cy0;
+  const int top = cy * a.chk_h, left = cx * a.chk_w;
+  const int bot = imin(top + a.chk_h, H), right = imin(left + a.chk_w, W);
+  const int ch = bot - top, cw = right - left;
+  const int reach = a.reach;
+  // interior: the chunk is whole and no patch of any offset reaches past the frame -- everything else is
+  // nlm_chunks_pipelined's (uniform over the workgroup, before any barrier)
+  if(!(top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w)) return;
+
+  float *const lds = env.lds();
+  const int csw = cw + 2 * P + 1; // table columns: frame columns left - P - 1 .. right + P - 1
+  const int tabsz = ch * pitch;
+  const int wh = ch + 2 * reach;
+  float *const winf = lds + 2 * tabsz + 16 * pitch + 64; // 16 spare table rows: the recurrences read whole batches
+  f2 *const XY = (f2 *)winf;                             // [wh][NL2_WP]
+  float *const Z = winf + 2 * wh * NL2_WP;               // [wh][NL2_WP]
+  const int r0 = top - reach, c0 = left - reach;
+  const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
+  const int n = a.npatch;
+
+  for(int i = tid; i < wh * NL2_WP; i += NL2_THREADS)
+  {
+    const int wy = i / NL2_WP, wx = i - wy * NL2_WP;
+    const int r = r0 + wy, c = c0 + wx; // r is inside the frame for an interior chunk; the pitch may run past its right edge
+    F4 v;
+    v.x = v.y = v.z = v.w = 0.0f;
+    if(c < W) v = in[(long)r * W + c];
+    f2 xy;
+    xy.x = v.x;
+    xy.y = v.y;
+    XY[i] = xy;
+    Z[i] = v.z;
+  }
+
+  const bool par = tid >= NL2_SERIAL;
+  if(!par) env.prio_high(); // the recurrences are latency chains: let them issue ahead of the parallel waves
+  const int u = tid - NL2_SERIAL;
+
+  // ---- parallel group: the pixels a thread accumulates for the whole chunk: window offset | table offset << 16
+  float accx[NL2_PX], accy[NL2_PX], accz[NL2_PX], accw[NL2_PX];
+  int pix[NL2_PX];
+#pragma unroll
+  for(int k = 0; k < NL2_PX; k++)
+  {
+    accx[k] = accy[k] = accz[k] = accw[k] = 0.0f;
+    const int idx = u + NL2_PAR * k;
+    const int r = idx / cw, c = idx - r * cw;
+    pix[k] = (par && idx < ch * cw) ? (((reach + r) * NL2_WP + (reach + c)) | ((r * pitch + c) << 16)) : -1;
+  }
+  // ---- ... and its A1 work item: column ci (1 .. csw-1; column 0 is outside every patch and stays 0), class k of
+  //      the table rows modulo S, segment seg of that class's chain: terms t = 1 + k + (j0 + jj) S, jj < jn
+  int a1w = 0, a1t = 0, jn = 0;
+  {
+    const int ncol = csw - 1;
+    const int nseg = NL2_PAR / (ncol * S);
+    const int m0 = (ch - 2) / S + 1;
+    const int mseg = (m0 + nseg - 1) / nseg;
+    if(par && u < ncol * S * nseg)
+    {
+      const int ci = 1 + u % ncol, q = u / ncol;
+      const int k = q % S, seg = q / S;
+      const int mk = (ch - 2 - k >= 0) ? (ch - 2 - k) / S + 1 : 0;
+      const int j0 = seg * mseg;
+      const int left_over = mk - j0;
+      jn = left_over < 0 ? 0 : (left_over > mseg ? mseg : left_over);
+      a1w = (reach + k + j0 * S - P) * NL2_WP + (reach - P - 1 + ci); // the first row of the chain: the one leaving at t
+      a1t = (1 + k + j0 * S) * pitch + ci;
+    }
+  }
+  env.sync();
+
+  // ---- A1, rows 1.. of the table: the terms of the column recurrence (nlmeans_core.c:437-488), parallel group
+  auto A1 = [&](float *const T, const int dS) {
+    if(u < ch - 1) T[(u + 1) * pitch] = 0.0f; // column 0 (B leaves row sums in it)
+    if(jn > 0)
+    {
+      const f2 *const pxy = XY + a1w;
+      const float *const pz = Z + a1w;
+      f2 o = pxy[0], s = pxy[dS];
+      float oz = pz[0], sz = pz[dS];
+      float dx = o.x - s.x, dy = o.y - s.y, dz = oz - sz;
+      float px2 = dx * dx, py2 = dy * dy, pz2 = dz * dz;
+#pragma unroll
+      for(int jj = 0; jj < NL2_MSEG; jj++)
+      {
+        if(jj < jn)
+        {
+          const int d = (jj + 1) * S * NL2_WP;
+          o = pxy[d];
+          s = pxy[d + dS];
+          oz = pz[d];
+          sz = pz[d + dS];
+          dx = o.x - s.x;
+          dy = o.y - s.y;
+          dz = oz - sz;
+          const float nx2 = dx * dx, ny2 = dy * dy, nz2 = dz * dz;
+          T[a1t + jj * S * pitch] = ((nx2 - px2) * n0 + (ny2 - py2) * n1) + (nz2 - pz2) * n2;
+          px2 = nx2;
+          py2 = ny2;
+          pz2 = nz2;
+        }
+      }
+    }
+  };
+  // ---- row 0 of the table: the from-scratch sums at the chunk's first row (init_column_sums(), :208-262)
+  auto A1_first = [&](float *const T, const int dS) {
+    float v = 0.0f;
+    if(tid >= 1)
+    {
+      const int w0 = (reach - P) * NL2_WP + (reach - P - 1 + tid);
+#pragma unroll
+      for(int r = 0; r < S; r++)
+      {
+        const f2 o = XY[w0 + r * NL2_WP], s = XY[w0 + r * NL2_WP + dS];
+        const float oz = Z[w0 + r * NL2_WP], sz = Z[w0 + r * NL2_WP + dS];
+        const float dx = o.x - s.x, dy = o.y - s.y, dz = oz - sz;
+        v += dx * dx * n0 + dy * dy * n1 + dz * dz * n2;
+      }
+    }
+    T[tid] = v;
+  };
+  // ---- A2: the column recurrence, one thread per table column, 16 rows of LDS traffic in flight, one dependent
+  //      addition per row
+  auto A2 = [&](float *const T) {
+    float v = T[tid];
+    int t0 = 1;
+    for(; t0 + 16 <= ch; t0 += 16)
+    {
+      float term[16];
+      float *const col = T + t0 * pitch + tid;
+#pragma unroll
+      for(int k = 0; k < 16; k++) term[k] = col[k * pitch];
+      term[0] = v + term[0];
+#pragma unroll
+      for(int k = 1; k < 16; k++) term[k] = term[k - 1] + term[k];
+      v = term[15];
+#pragma unroll
+      for(int k = 0; k < 16; k++) col[k * pitch] = term[k];
+    }
+    if(t0 < ch)
+    {
+      float term[16];
+      float *const col = T + t0 * pitch + tid;
+      const int live = ch - t0;
+#pragma unroll
+      for(int k = 0; k < 16; k++) term[k] = col[k * pitch];
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+      {
+        const float next = v + term[k];
+        v = k < live ? next : v;
+        term[k] = v;
+      }
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+        if(k < live) col[k * pitch] = term[k];
+    }
+  };
+  // ---- B: the sliding row sum (:405-415), one thread per table row, in place: the distortion of chunk column j goes
+  //      into slot j, whose own value (the one leaving the window at j) was read S steps earlier and is in `carry`
+  auto B = [&](float *const T, const int rr) {
+    float *const rowp = T + rr * pitch; // slot x = frame column left - P - 1 + x
+    float carry[S];
+#pragma unroll
+    for(int k = 0; k < S; k++) carry[k] = rowp[k];
+    float distortion = 0.0f;
+#pragma unroll
+    for(int k = 1; k < S; k++) distortion += carry[k]; // columns left - P .. left + P - 1
+    int jb = 0;
+    for(; jb + 16 <= cw; jb += 16)
+    {
+      float hi[16], d[16];
+#pragma unroll
+      for(int k = 0; k < 16; k++) hi[k] = rowp[jb + k + S];
+#pragma unroll
+      for(int k = 0; k < 16; k++) d[k] = hi[k] - (k < S ? carry[k < S ? k : 0] : hi[k >= S ? k - S : 0]);
+#pragma unroll
+      for(int k = 0; k < S; k++) carry[k] = hi[16 - S + k];
+      d[0] = distortion + d[0];
+#pragma unroll
+      for(int k = 1; k < 16; k++) d[k] = d[k - 1] + d[k];
+      distortion = d[15];
+#pragma unroll
+      for(int k = 0; k < 16; k++) rowp[jb + k] = d[k];
+    }
+    if(jb < cw)
+    {
+      float hi[16], d[16];
+      const int live = cw - jb;
+#pragma unroll
+      for(int k = 0; k < 16; k++) hi[k] = rowp[jb + k + S];
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+      {
+        const float next = distortion + (hi[k] - (k < S ? carry[k < S ? k : 0] : hi[k >= S ? k - S : 0]));
+        distortion = k < live ? next : distortion;
+        d[k] = distortion;
+      }
+#pragma unroll
+      for(int k = 0; k < 16; k++)
+        if(k < live) rowp[jb + k] = d[k];
+    }
+  };
+  // ---- C: weights and accumulation (:416-436), parallel group; center_weight < 0: w = 2^-(distortion * sharpness)
+  auto C = [&](const float *const T, const int dS) {
+    float dist[NL2_PX], qx[NL2_PX], qy[NL2_PX], qz[NL2_PX];
+#pragma unroll
+    for(int k = 0; k < NL2_PX; k++)
+    {
+      const int pk = pix[k] < 0 ? 0 : pix[k];
+      const int wo = (pk & 0xffff) + dS;
+      dist[k] = T[pk >> 16];
+      const f2 q = XY[wo];
+      qx[k] = q.x;
+      qy[k] = q.y;
+      qz[k] = Z[wo];
+    }
+#pragma unroll
+    for(int k = 0; k < NL2_PX; k++)
+    {
+      const float w = mexp2<Env>(dist[k] * a.sharpness);
+      const float sx = accx[k] + qx[k] * w, sy = accy[k] + qy[k] * w, sz = accz[k] + qz[k] * w, sw = accw[k] + 1.0f * w;
+      const bool ok = pix[k] >= 0;
+      accx[k] = ok ? sx : accx[k];
+      accy[k] = ok ? sy : accy[k];
+      accz[k] = ok ? sz : accz[k];
+      accw[k] = ok ? sw : accw[k];
+    }
+  };
+
+  auto shift_of = [&](const I2 sh) { return sh.x * NL2_WP + sh.y; };
+  I2 sh_cur = patches[0], sh_next = patches[n > 1 ? 1 : 0];
+  int ds_prev = 0, ds_cur = shift_of(sh_cur), ds_next = shift_of(sh_next);
+  if(par) A1(lds, ds_cur);
+  else if(tid < csw) A1_first(lds, ds_cur);
+  env.sync();
+  for(int i = 0; i <= n; i++)
+  {
+    const I2 sh_next2 = patches[i + 2 < n ? i + 2 : n - 1];
+    float *const Ti = lds + (i & 1) * tabsz;       // offset i, and i + 2
+    float *const To = lds + ((i + 1) & 1) * tabsz; // offsets i - 1 and i + 1
+    // phase 1: C(i - 1) beside A2(i)
+    if(par)
+    {
+      if(i >= 1) C(To, ds_prev);
+    }
+    else if(tid < csw && i < n)
+      A2(Ti);
+    env.sync();
+    // phase 2: A1(i + 1) beside B(i) and the first row of A1(i + 1)
+    if(par)
+    {
+      if(i + 1 < n) A1(To, ds_next);
+    }
+    else if(tid < 128)
+    {
+      if(tid < csw && i + 1 < n) A1_first(To, ds_next);
+    }
+    else if(i < n)
+    {
+      if(tid - 128 < ch) B(Ti, tid - 128);
+    }
+    env.sync();
+    ds_prev = ds_cur;
+    ds_cur = ds_next;
+    ds_next = shift_of(sh_next2);
+  }
+
+  // ---- normalise, blend (:490-521)
+#pragma unroll
+  for(int k = 0; k < NL2_PX; k++)
+  {
+    if(pix[k] < 0) continue;
+    const int idx = u + NL2_PAR * k;
+    const int rr = idx / cw;
+    const int row = top + rr, col = left + (idx - rr * cw);
+    if(row < a.out_row0 || row >= a.out_row1) continue;
+    const long o = (long)row * W + col;
+    F4 r;
+    if(a.skip_blend)
+    {
+      r.x = accx[k] / accw[k];
+      r.y = accy[k] / accw[k];
+      r.z = accz[k] / accw[k];
+      r.w = accw[k] / accw[k];
+    }
+    else
+    {
+      const F4 ip = in[o];
+      r.x = (ip.x * (1.0f - a.luma)) + (accx[k] / accw[k] * a.luma);
+      r.y = (ip.y * (1.0f - a.chroma)) + (accy[k] / accw[k] * a.chroma);
+      r.z = (ip.z * (1.0f - a.chroma)) + (accz[k] / accw[k] * a.chroma);
+      r.w = (ip.w * 0.0f) + (accw[k] / accw[k] * 1.0f);
+    }
+    out[o] = r;
+  }
+}
+
+} // namespace nlm2

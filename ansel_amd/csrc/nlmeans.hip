@@ -22,6 +22,7 @@
 // and at the end the normalisation / luma-chroma blend of nlmeans_core.c:490-521.
 #include "hip_common.h"
 #include "nlmeans_core_params.h"
+#include "nlm2_body.h"
 
 #include <math.h>
 #include <algorithm>
@@ -55,6 +56,7 @@ struct nlm_args
   // row bands (hip_common.h band_view_t): the launch covers chunk rows cy0.. of the FRAME's grid and
   // stores frame rows [out_row0, out_row1) only; `in` / `out` are addressed with frame row indices
   int cy0, out_row0, out_row1;
+  int skip_interior; // nlm_chunks_pipelined: leave the interior chunks to nlm_chunks_v2
 };
 
 __device__ __forceinline__ int imin(const int a, const int b) { return a < b ? a : b; }
@@ -383,6 +385,9 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4
   const int bot = imin(top + a.chk_h, a.H), right = imin(left + a.chk_w, a.W);
   const int ch = bot - top, cw = right - left;
   const int P = a.radius, W = a.W, H = a.H;
+  if(a.skip_interior && top >= a.reach && bot + a.reach <= H && left >= a.reach && right + a.reach <= W && ch == a.chk_h
+     && cw == a.chk_w)
+    return; // nlm_chunks_v2's (uniform over the workgroup)
   const int csw = a.chk_w + 2 * P + 1; // table columns: frame columns left - P - 1 .. left + chk_w + P - 1
   const int cs0 = left - P - 1;
   constexpr int pitch = NLP_TP;
@@ -770,6 +775,28 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4
   }
 }
 
+// ---- the interior-chunk kernel: nlm2_body.h (also compiled for the host: tests/native/nlm2_host.cpp) -------------
+struct nlm2_device_env
+{
+  float *lds_;
+  __device__ __forceinline__ int tid() const { return threadIdx.x; }
+  __device__ __forceinline__ int bid() const { return blockIdx.x; }
+  __device__ __forceinline__ float *lds() const { return lds_; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ void prio_high() const { __builtin_amdgcn_s_setprio(3); }
+  static __device__ __forceinline__ float int_as_float(const int v) { return __int_as_float(v); }
+};
+
+template <int P>
+__global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                             const nlm_args a, const int2 *__restrict__ patches)
+{
+  extern __shared__ float lds[];
+  nlm2_device_env env;
+  env.lds_ = lds;
+  nlm2::body<P>(env, in, out, a, patches);
+}
+
 int sgn(const int v) { return (v > 0) - (v < 0); }
 
 // scatter(), nlmeans_core.c:95-105
@@ -908,9 +935,37 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
                                    : (staged ? (const void *)nlm_chunks<true> : (const void *)nlm_chunks<false>);
   if(lds_bytes > 64 * 1024)
     ANSEL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // interior chunks (all but the outermost ring: 97.5 % of a 100 MP frame) go to nlm_chunks_v2 when the
+  // configuration is one it is built for: the weight without the centre-pixel term (denoise (non-local means)),
+  // patch radius 1..3, and the same LDS budget as the pipelined kernel
+  const int S2 = 2 * a.radius + 1, ncol2 = a.chk_w + 2 * a.radius;
+  bool v2 = pipelined && p.center_weight < 0 && a.radius >= 1 && a.radius <= 3 && ncol2 * S2 <= NL2_PAR
+            && a.chk_w * a.chk_h <= NL2_PAR * NL2_PX && getenv("ANSEL_HIP_NLM_V1") == nullptr;
+  if(v2)
+  {
+    const int nseg = NL2_PAR / (ncol2 * S2), m0 = (a.chk_h - 2) / S2 + 1;
+    v2 = (m0 + nseg - 1) / nseg <= NL2_MSEG;
+  }
+  static_assert(NL2_WP == NLP_WP && NL2_TP == NLP_TP && NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS,
+                "nlm_chunks_v2 shares the LDS budget and the launch shape of nlm_chunks_pipelined");
+  if(v2)
+  {
+    const void *const fn2 = a.radius == 1 ? (const void *)nlm_chunks_v2<1>
+                                          : (a.radius == 2 ? (const void *)nlm_chunks_v2<2> : (const void *)nlm_chunks_v2<3>);
+    if(lds_bytes > 64 * 1024)
+      ANSEL_HIP_CHECK(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    a.skip_interior = 1;
+  }
   {
     launch_scope ls(devid, "nlm_chunks");
     const unsigned grid = (unsigned)(a.nchx * nchy);
+    if(v2)
+    {
+      // both launches walk the whole chunk grid; a workgroup whose chunk belongs to the other kernel exits at once
+      if(a.radius == 1) nlm_chunks_v2<1><<<grid, NL2_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
+      else if(a.radius == 2) nlm_chunks_v2<2><<<grid, NL2_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
+      else nlm_chunks_v2<3><<<grid, NL2_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
+    }
     if(pipelined)
       nlm_chunks_pipelined<<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
     else if(staged)

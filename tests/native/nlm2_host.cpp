@@ -1,0 +1,146 @@
+// tests/native/nlm2_host.cpp -- TEST INFRASTRUCTURE: the body of the gfx950 kernel nlm_chunks_v2
+// (ansel_amd/csrc/nlm2_body.h) compiled for the host.  A workgroup is 1024 OS threads meeting at a std::barrier
+// where the kernel has __syncthreads(), its LDS a heap block: every index, every hand-off between the pipelined
+// phases, every table slot of the schedule runs exactly as on the device (minus the timing), so the CPU suite can
+// compare the kernel with the oracle bit for bit before a GPU is involved.  -ffp-contract=off like the device build.
+//
+//   g++ -O2 -std=c++20 -ffp-contract=off -fPIC -shared -pthread -I ansel_amd/csrc tests/native/nlm2_host.cpp -o tests/native/libnlm2_host.so
+#include <barrier>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "nlm2_body.h"
+
+namespace
+{
+
+struct F4
+{
+  float x, y, z, w;
+};
+struct I2
+{
+  int x, y;
+};
+
+// the fields of nlm_args (nlmeans.hip) the body reads
+struct Args
+{
+  int W, H;
+  int chk_w, chk_h, nchx;
+  int radius, npatch;
+  float sharpness;
+  float norm[3];
+  float luma, chroma;
+  int skip_blend;
+  int reach;
+  int cy0, out_row0, out_row1;
+};
+
+struct HostEnv
+{
+  int tid_, bid_;
+  float *lds_;
+  std::barrier<> *bar_;
+  int tid() const { return tid_; }
+  int bid() const { return bid_; }
+  float *lds() const { return lds_; }
+  void sync() const { bar_->arrive_and_wait(); }
+  void prio_high() const {}
+  static float int_as_float(const int v)
+  {
+    float f;
+    memcpy(&f, &v, sizeof(f));
+    return f;
+  }
+};
+
+int sgn(const int v) { return (v > 0) - (v < 0); }
+int scatter(const float scale, const float scattering, const int i1, const int i2)
+{
+  const int a1 = abs(i1), a2 = abs(i2);
+  return (int)(scale * ((a1 * a1 * a1 + 7.0 * a1 * sqrt((double)a2)) * sgn(i1) * scattering / 6.0 + i1));
+}
+
+template <int P> void run(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats)
+{
+  std::vector<float> lds(lds_floats + 4096, 0.0f);
+  std::barrier<> bar(NL2_THREADS);
+  std::vector<std::thread> pool;
+  pool.reserve(NL2_THREADS);
+  for(int t = 0; t < NL2_THREADS; t++)
+    pool.emplace_back([&, t]() {
+      for(int b = 0; b < nchunks; b++)
+      {
+        HostEnv env{ t, b, lds.data(), &bar };
+        nlm2::body<P>(env, in, out, a, patches);
+        bar.arrive_and_wait(); // the next chunk reuses the LDS block
+      }
+    });
+  for(auto &th : pool) th.join();
+}
+
+} // namespace
+
+// Runs the kernel body over every chunk of the frame (only interior chunks write; the rest of `out` is left as it
+// is).  Returns 0, or a negative number when the configuration is outside what nlm_chunks_v2 takes (the same tests as
+// nlmeans_core_launch()).  chk_w / chk_h: the frame's chunk grid (oracle_nlmeans_slice_width / _height).
+extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                             int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                             float luma, float chroma, int *interior_chunks)
+{
+  std::vector<I2> patches;
+  int max_shift = 0;
+  for(int ri = -search_radius; ri <= search_radius; ri++)
+    for(int ci = -search_radius; ci <= search_radius; ci++)
+    {
+      const int r = scatter(scale, scattering, ri, ci), c = scatter(scale, scattering, ci, ri);
+      patches.push_back(I2{ r, c });
+      max_shift = std::max(max_shift, std::max(abs(r), abs(c)));
+    }
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.W = W;
+  a.H = H;
+  a.chk_w = chk_w;
+  a.chk_h = chk_h;
+  a.nchx = (W + chk_w - 1) / chk_w;
+  const int nchy = (H + chk_h - 1) / chk_h;
+  a.radius = patch_radius;
+  a.npatch = (int)patches.size();
+  a.sharpness = sharpness;
+  for(int k = 0; k < 3; k++) a.norm[k] = norm[k];
+  a.luma = luma;
+  a.chroma = chroma;
+  a.skip_blend = (luma == 1.0 && chroma == 1.0);
+  a.reach = patch_radius + 1 + max_shift;
+  a.cy0 = 0;
+  a.out_row0 = 0;
+  a.out_row1 = H;
+  const int S = 2 * patch_radius + 1, ncol = chk_w + 2 * patch_radius;
+  if(patch_radius < 1 || patch_radius > 3) return -1;
+  if(chk_w + 2 * a.reach > NL2_WP || chk_h > NL2_SERIAL / 2 || chk_w + S > NL2_TP || chk_w * chk_h > NL2_PAR * NL2_PX) return -2;
+  if(ncol * S > NL2_PAR) return -3;
+  const int nseg = NL2_PAR / (ncol * S), m0 = (chk_h - 2) / S + 1;
+  if((m0 + nseg - 1) / nseg > NL2_MSEG) return -4;
+  const size_t lds_floats = (size_t)2 * chk_h * NL2_TP + 16 * NL2_TP + 64 + (size_t)(chk_h + 2 * a.reach) * 3 * NL2_WP;
+  if(lds_floats * sizeof(float) > 160 * 1024) return -5;
+  int interior = 0;
+  for(int cy = 0; cy < nchy; cy++)
+    for(int cx = 0; cx < a.nchx; cx++)
+    {
+      const int top = cy * chk_h, left = cx * chk_w;
+      const int bot = std::min(top + chk_h, H), right = std::min(left + chk_w, W);
+      if(top >= a.reach && bot + a.reach <= H && left >= a.reach && right + a.reach <= W && bot - top == chk_h && right - left == chk_w)
+        interior++;
+    }
+  if(interior_chunks) *interior_chunks = interior;
+  const int nchunks = a.nchx * nchy;
+  if(patch_radius == 1) run<1>((const F4 *)in, (F4 *)out, a, patches.data(), nchunks, lds_floats);
+  else if(patch_radius == 2) run<2>((const F4 *)in, (F4 *)out, a, patches.data(), nchunks, lds_floats);
+  else run<3>((const F4 *)in, (F4 *)out, a, patches.data(), nchunks, lds_floats);
+  return 0;
+}

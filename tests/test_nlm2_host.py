@@ -1,0 +1,85 @@
+"""The gfx950 kernel for interior non-local-means chunks (ansel_amd/csrc/nlm2_body.h, launched as nlm_chunks_v2)
+compiled for the HOST -- a workgroup is 1024 OS threads meeting at a barrier where the kernel has __syncthreads()
+(tests/native/nlm2_host.cpp) -- against the oracle, bit for bit.  The same source runs on the device; this pins its
+schedule (the work items of the term chains, the ring of the row recurrence, every table and window index, the
+two-table pipeline) without a GPU.  The -m gpu tests then only have to show that the device executes it the same."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import checkers as ck
+from ansel_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "native", "libnlm2_host.so")
+SRC = os.path.join(ROOT, "tests", "native", "nlm2_host.cpp")
+HDR = os.path.join(ROOT, "ansel_amd", "csrc", "nlm2_body.h")
+
+
+class NlmParams(C.Structure):  # oracle_nlm_params_t, oracle/src/nlmeans_core.h
+    _fields_ = [("scattering", C.c_float), ("scale", C.c_float), ("luma", C.c_float), ("chroma", C.c_float),
+                ("center_weight", C.c_float), ("sharpness", C.c_float), ("patch_radius", C.c_int),
+                ("search_radius", C.c_int), ("norm", C.c_float * 4)]
+
+
+@pytest.fixture(scope="module")
+def host_kernel():
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+                               "-I" + os.path.join(ROOT, "ansel_amd", "csrc"), SRC, "-o", SO])
+    return C.CDLL(SO)
+
+
+def _lab(w, h, seed):
+    rng = np.random.default_rng(seed)
+    rgb = synth.rgba_image(w, h, seed=seed, lo=0.0, hi=1.0)
+    lab = np.zeros((h, w, 4), np.float32)
+    lab[..., 0] = 100.0 * rgb[..., 1] + rng.normal(0, 1.5, (h, w))
+    lab[..., 1] = 80.0 * (rgb[..., 0] - rgb[..., 1]) + rng.normal(0, 2.0, (h, w))
+    lab[..., 2] = 80.0 * (rgb[..., 1] - rgb[..., 2]) + rng.normal(0, 2.0, (h, w))
+    lab[..., 3] = rng.random((h, w))
+    return np.ascontiguousarray(lab.astype(np.float32))
+
+
+# (width, height, patch radius, search radius, scattering, luma, chroma, expected chunk, expected interior chunks)
+CASES = [
+    (170, 150, 2, 7, 0.0, 0.5, 1.0, (64, 51), 1),    # the module's defaults: 225 offsets
+    (256, 207, 2, 2, 0.0, 0.5, 1.0, (72, 69), 2),    # the largest chunk: every accumulator slot of a thread in use
+    (300, 250, 1, 3, 0.0, 1.0, 1.0, (64, 63), 6),    # patch radius 1 (3 chains per column, 3 segments), no blend
+    (300, 250, 3, 2, 0.0, 0.3, 0.8, (64, 63), 6),    # patch radius 3 (7 chains, one segment)
+    (300, 250, 2, 2, 0.9, 0.5, 1.0, (64, 63), 6),    # scattered offsets: shifts beyond the search radius
+]
+
+
+@pytest.mark.parametrize("w,h,P,K,scat,luma,chroma,chunk,n_interior", CASES)
+def test_interior_chunk_kernel_on_the_host_equals_the_oracle(host_kernel, oracle_lib, w, h, P, K, scat, luma, chroma, chunk,
+                                                             n_interior):
+    o = oracle_lib
+    img = _lab(w, h, 11 + P + K)
+    p = NlmParams(scat, 1.0, luma, chroma, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    assert (cw, ch) == chunk
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm2_host_run(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(scat),
+                                   C.c_float(p.sharpness), p.norm, C.c_float(luma), C.c_float(chroma), C.byref(seen))
+    assert rc == 0 and seen.value == n_interior
+    written = ~np.isnan(got[..., 0])
+    assert int(written.sum()) == n_interior * cw * ch  # interior chunks only, each pixel of them
+    assert np.array_equal(got[written].view(np.uint32), want[written].view(np.uint32))
+
+
+def test_configurations_outside_the_kernel_are_refused(host_kernel):
+    img = np.zeros((100, 100, 4), np.float32)
+    norm = (C.c_float * 4)(1, 1, 1, 1)
+    args = (ck.ptr(img), ck.ptr(img), 100, 100, 64, 50)
+    tail = (C.c_float(1.0), C.c_float(0.0), C.c_float(10.0), norm, C.c_float(1.0), C.c_float(1.0), None)
+    assert host_kernel.nlm2_host_run(*args, 4, 2, *tail) == -1   # patch radius 4: the pipelined kernel's
+    assert host_kernel.nlm2_host_run(*args, 2, 20, *tail) == -2  # 20 px of shift: the window does not fit the pitch
