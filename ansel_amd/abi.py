@@ -203,6 +203,16 @@ class TilePlan(C.Structure):
                 ("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("overlap", C.c_int32)]
 
 
+class TilePlanRoi(C.Structure):
+    """dt_hip_tile_plan_roi_t: the tile grid of _default_process_tiling_cl_roi() (src/develop/tiling.c:1100-1220)"""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("tile_wd", C.c_int32), ("tile_ht", C.c_int32),
+                ("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("overlap_in", C.c_int32), ("overlap_out", C.c_int32),
+                ("delta", C.c_int32), ("xyalign", C.c_int32)]
+
+
+DT_HIP_TILE_EMPTY = 2
+
+
 class ExportRowsData(C.Structure):
     """dt_hip_export_rows_t: the scanline packing of the format writers (tiff.c:293-360)"""
     _fields_ = [("bpp", C.c_int32), ("layers", C.c_int32)]
@@ -217,7 +227,7 @@ class Band(C.Structure):
 class BandState(C.Structure):
     """dt_hip_band_state_t"""
     _fields_ = [("halo_buf", C.c_void_p), ("row_bytes", C.c_size_t), ("clipped_count", C.c_void_p),
-                ("priv", C.c_void_p), ("halo_rows", C.c_int32), ("reserved", C.c_int32), ("sum_buf", C.c_void_p),
+                ("priv", C.c_void_p), ("halo_rows", C.c_int32), ("sum_planes", C.c_int32), ("sum_buf", C.c_void_p),
                 ("sum_count", C.c_size_t)]
 
 

@@ -15,6 +15,7 @@ void set_last_error(const char *fmt, ...);
 // per-device state owned by runtime.cpp
 hipStream_t stream_of(int devid); // also makes the device current for the calling thread
 bool make_current(int devid);
+int hip_device_of(int devid); // the HIP ordinal behind a runtime device id (-1: no such device)
 bool valid_device(int devid);
 
 // Tagged launch bracket: the HIP peer of dt_opencl_events_get_slot() + the event the

@@ -1,25 +1,33 @@
 // nlm2_body.h -- the non-local-means chunk kernel for INTERIOR chunks (no patch leaves the frame), written once and
-// compiled twice: as the body of nlm_chunks_v2<P> (nlmeans.hip, gfx950) and, with a host environment whose
-// workgroup is 1024 OS threads on a std::barrier, by tests/native/nlm2_host.cpp -- so that every index of the
-// schedule below is checked against the oracle on a CPU before the kernel ever meets a GPU.
+// compiled twice: as the body of nlm_chunks_v2<...> (nlmeans.hip, gfx950) and, with a host environment whose
+// workgroup is 1024 OS threads on a barrier, by tests/native/nlm2_host.cpp -- so that every index of the schedule
+// below is checked against the oracle on a CPU before the kernel ever meets a GPU.
 //
 // Same arithmetic as nlm_chunks_pipelined (nlmeans.hip; reference src/pixel/nlmeans_core.c:315-532): per chunk and
-// patch offset the column-sum recurrence down the rows (A2), the row-sum recurrence across the columns (B), the
-// weight 2^-x and the accumulation (C), software-pipelined over the offsets with two tables.  What differs is how
-// much LDS traffic and arithmetic the two fully parallel steps cost:
+// patch offset the terms of the column-sum recurrence (A1), the recurrence down the rows (A2), the row-sum recurrence
+// across the columns (B), the weight 2^-x and the accumulation (C).  What differs:
 //
 //   * the window keeps (x, y) of a pixel as one 8-byte word and z in a plane of its own: a pixel is two LDS reads
-//     (ds_read_b64 + ds_read_b32: 4.4 cycles of the LDS pipe) instead of three ds_read_b32 (6.6);
-//   * A1, the terms of the column recurrence: the term of table row t is D(b) - D(b - S) with b = the row entering
-//     the patch, S = 2 P + 1 and D(r) the squared differences of row r -- so the terms t, t + S, t + 2 S, ... of one
-//     column form a chain in which every D is an "entering" row once and a "leaving" row once.  A work item is such
-//     a chain (<= 10 terms): it squares each row ONCE and keeps it in registers for its second use.  Per term 4.7 LDS
-//     reads and 15 VALU instructions instead of 12 and ~21.  (a - b)^2 is computed by the same two operations on
-//     the same operands as in the reference's diff_of_pixels_diff(), so the term is the same binary32 value;
+//     (ds_read_b64 + ds_read_b32) instead of three;
+//   * A1: the term of table row t is D(b) - D(b - S) with b = the row entering the patch, S = 2 P + 1 and D(r) the
+//     squared differences of row r -- so the terms t, t + S, t + 2 S, ... of one column form a chain in which every D
+//     is an "entering" row once and a "leaving" row once.  A work item is such a chain (<= 10 terms): it squares each
+//     row ONCE and keeps it in registers for its second use.  Per term 4.7 LDS reads and 15 VALU instructions instead
+//     of 12 and ~21.  (a - b)^2 is computed by the same two operations on the same operands as in the reference's
+//     diff_of_pixels_diff(), so the term is the same binary32 value;
 //   * B reads every table entry once: the value that leaves the sliding window is the one that entered it S steps
 //     earlier and is still in a register;
-//   * C reads 3 words per pixel and offset instead of 4;
-//   * no per-offset geometry at all: an interior chunk's row / column ranges are the chunk itself.
+//   * C reads 3 words per pixel and offset instead of 4; the offsets' window shifts come from an LDS table, not from a
+//     scalar load at the top of every iteration (whose latency every wave's first LDS wait would pay);
+//   * no per-offset geometry: an interior chunk's row / column ranges are the chunk itself;
+//   * DEEP (when four tables fit LDS beside the window -- chunks up to 58 rows, e.g. the 100 MP frame's 72 x 56): the
+//     four steps run on four DIFFERENT offsets at once, one barrier per offset: A1(i+3) and C(i) on the twelve
+//     parallel waves, A2(i+2) and B(i+1) -- the two latency chains, measured at 60 % of a two-table iteration -- on
+//     serial waves beside them instead of in front of them.  Otherwise two tables, two barriers per offset
+//     (C(i-1) || A2(i), then A1(i+1) || B(i)).
+//   Measured on a 24 MP frame (profiles/r02_nlm_variants.json): steps switched off one at a time put A2 + B at 11.4 ms
+//   of a 16.1 ms two-table run and A1 + C at 7.3 ms; 16-byte / 8-byte table accesses for the recurrences (which need a
+//   16-byte aligned, even pitch) were slower than 4-byte ones on an odd pitch and are not used.
 #pragma once
 
 #ifdef __HIPCC__
@@ -29,12 +37,16 @@
 #endif
 
 #define NL2_THREADS 1024
-#define NL2_SERIAL 256                     // threads of the serial group (the two recurrences)
+#define NL2_SERIAL 256                     // threads of the serial group (the two recurrences, the first table row)
 #define NL2_PAR (NL2_THREADS - NL2_SERIAL) // threads of the parallel group (terms, weights)
 #define NL2_PX 7                           // accumulators per parallel thread: ceil(72 * 69 / 768)
-#define NL2_WP 96                          // window pitch (pixels)
-#define NL2_TP 81                          // table pitch (floats), odd: B walks the table one row per lane
 #define NL2_MSEG 10                        // most terms of one A1 work item (patch radius 3, 69 rows: one chain of 10)
+// two layouts: window pitch (pixels) / table pitch (floats, odd: B walks the table one row per lane).  The tight one
+// is exactly what a 72-column chunk with patch radius 2 and shifts up to 7 needs, and lets four tables fit
+#define NL2_WP_TIGHT 92
+#define NL2_TP_TIGHT 77
+#define NL2_WP_LOOSE 96
+#define NL2_TP_LOOSE 81
 
 namespace nlm2
 {
@@ -45,6 +57,13 @@ struct alignas(8) f2 // one 8-byte LDS word (ds_read_b64); without the alignment
 };
 
 NLM2_FN int imin(const int a, const int b) { return a < b ? a : b; }
+
+// LDS floats of one workgroup: `ntab` tables, 16 spare table rows (the recurrences read whole batches), the offsets'
+// window shifts, the window
+inline size_t lds_floats(const int ntab, const int chk_h, const int reach, const int npatch, const int WP, const int TP)
+{
+  return (size_t)ntab * chk_h * TP + 16 * TP + ((npatch + 3) & ~3) + (size_t)(chk_h + 2 * reach) * 3 * WP;
+}
 
 // dt_fast_mexp2f(), src/math/math.h:290-301; the float -> int conversion as the reference's target does it
 // (cvttss2si: out of range and NaN -> INT_MIN)
@@ -57,12 +76,13 @@ template <class Env> NLM2_FN float mexp2(const float x)
 }
 
 // Args: nlm_args of nlmeans.hip (W, H, chk_w, chk_h, nchx, npatch, sharpness, norm[3], luma, chroma, skip_blend,
-// reach, cy0, out_row0, out_row1).  F4 / I2: float4 / int2.
-template <int P, class Env, class Args, class F4, class I2>
+// reach, cy0, out_row0, out_row1, variant).  F4 / I2: float4 / int2.
+template <int P, int WP, int TP, bool DEEP, class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches)
 {
   constexpr int S = 2 * P + 1;
-  constexpr int pitch = NL2_TP;
+  constexpr int pitch = TP;
+  constexpr int NTAB = DEEP ? 4 : 2;
   const int tid = env.tid();
   const int W = a.W, H = a.H;
   const int cy_launch = env.bid() / a.nchx, cx = env.bid() - cy_launch * a.nchx;
@@ -79,16 +99,17 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int csw = cw + 2 * P + 1; // table columns: frame columns left - P - 1 .. right + P - 1
   const int tabsz = ch * pitch;
   const int wh = ch + 2 * reach;
-  float *const winf = lds + 2 * tabsz + 16 * pitch + 64; // 16 spare table rows: the recurrences read whole batches
-  f2 *const XY = (f2 *)winf;                             // [wh][NL2_WP]
-  float *const Z = winf + 2 * wh * NL2_WP;               // [wh][NL2_WP]
+  const int n = a.npatch;
+  int *const dsv = (int *)(lds + NTAB * tabsz + 16 * pitch); // window shift of every offset
+  float *const winf = lds + NTAB * tabsz + 16 * pitch + ((n + 3) & ~3);
+  f2 *const XY = (f2 *)winf;                  // [wh][WP]
+  float *const Z = winf + 2 * wh * WP;        // [wh][WP]
   const int r0 = top - reach, c0 = left - reach;
   const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
-  const int n = a.npatch;
 
-  for(int i = tid; i < wh * NL2_WP; i += NL2_THREADS)
+  for(int i = tid; i < wh * WP; i += NL2_THREADS)
   {
-    const int wy = i / NL2_WP, wx = i - wy * NL2_WP;
+    const int wy = i / WP, wx = i - wy * WP;
     const int r = r0 + wy, c = c0 + wx; // r is inside the frame for an interior chunk; the pitch may run past its right edge
     F4 v;
     v.x = v.y = v.z = v.w = 0.0f;
@@ -99,6 +120,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     XY[i] = xy;
     Z[i] = v.z;
   }
+  for(int i = tid; i < n; i += NL2_THREADS) dsv[i] = patches[i].x * WP + patches[i].y;
 
   const bool par = tid >= NL2_SERIAL;
   if(!par) env.prio_high(); // the recurrences are latency chains: let them issue ahead of the parallel waves
@@ -113,7 +135,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     accx[k] = accy[k] = accz[k] = accw[k] = 0.0f;
     const int idx = u + NL2_PAR * k;
     const int r = idx / cw, c = idx - r * cw;
-    pix[k] = (par && idx < ch * cw) ? (((reach + r) * NL2_WP + (reach + c)) | ((r * pitch + c) << 16)) : -1;
+    pix[k] = (par && idx < ch * cw) ? (((reach + r) * WP + (reach + c)) | ((r * pitch + c) << 16)) : -1;
   }
   // ---- ... and its A1 work item: column ci (1 .. csw-1; column 0 is outside every patch and stays 0), class k of
   //      the table rows modulo S, segment seg of that class's chain: terms t = 1 + k + (j0 + jj) S, jj < jn
@@ -131,7 +153,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       const int j0 = seg * mseg;
       const int left_over = mk - j0;
       jn = left_over < 0 ? 0 : (left_over > mseg ? mseg : left_over);
-      a1w = (reach + k + j0 * S - P) * NL2_WP + (reach - P - 1 + ci); // the first row of the chain: the one leaving at t
+      a1w = (reach + k + j0 * S - P) * WP + (reach - P - 1 + ci); // the first row of the chain: the one leaving at t
       a1t = (1 + k + j0 * S) * pitch + ci;
     }
   }
@@ -153,7 +175,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       {
         if(jj < jn)
         {
-          const int d = (jj + 1) * S * NL2_WP;
+          const int d = (jj + 1) * S * WP;
           o = pxy[d];
           s = pxy[d + dS];
           oz = pz[d];
@@ -175,12 +197,12 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     float v = 0.0f;
     if(tid >= 1)
     {
-      const int w0 = (reach - P) * NL2_WP + (reach - P - 1 + tid);
+      const int w0 = (reach - P) * WP + (reach - P - 1 + tid);
 #pragma unroll
       for(int r = 0; r < S; r++)
       {
-        const f2 o = XY[w0 + r * NL2_WP], s = XY[w0 + r * NL2_WP + dS];
-        const float oz = Z[w0 + r * NL2_WP], sz = Z[w0 + r * NL2_WP + dS];
+        const f2 o = XY[w0 + r * WP], s = XY[w0 + r * WP + dS];
+        const float oz = Z[w0 + r * WP], sz = Z[w0 + r * WP + dS];
         const float dx = o.x - s.x, dy = o.y - s.y, dz = oz - sz;
         v += dx * dx * n0 + dy * dy * n1 + dz * dz * n2;
       }
@@ -296,42 +318,70 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     }
   };
 
-  auto shift_of = [&](const I2 sh) { return sh.x * NL2_WP + sh.y; };
-  I2 sh_cur = patches[0], sh_next = patches[n > 1 ? 1 : 0];
-  int ds_prev = 0, ds_cur = shift_of(sh_cur), ds_next = shift_of(sh_next);
-  if(par) A1(lds, ds_cur);
-  else if(tid < csw) A1_first(lds, ds_cur);
-  env.sync();
-  for(int i = 0; i <= n; i++)
+
+  // a.variant: 0 = the shipped schedule; bits 4..8 switch a step off (timing experiments only: the result is then
+  // wrong) -- A1, A2, B, C, first row
+  const int var = a.variant;
+  const bool do_a1 = !(var & 16), do_a2 = !(var & 32), do_b = !(var & 64), do_c = !(var & 128), do_first = !(var & 256);
+  if(DEEP)
   {
-    const I2 sh_next2 = patches[i + 2 < n ? i + 2 : n - 1];
-    float *const Ti = lds + (i & 1) * tabsz;       // offset i, and i + 2
-    float *const To = lds + ((i + 1) & 1) * tabsz; // offsets i - 1 and i + 1
-    // phase 1: C(i - 1) beside A2(i)
-    if(par)
+    // stage s: A1(s) and C(s - 3) on the parallel waves; A2(s - 1), then the first table row of offset s, on waves
+    // 0-1; B(s - 2) on wave 2.  Offset p lives in table p & 3 from its A1 (stage p) to its C (stage p + 3); the table
+    // is written again in stage p + 4.
+    for(int s = 0; s < n + 3; s++)
     {
-      if(i >= 1) C(To, ds_prev);
+      if(par)
+      {
+        if(s < n && do_a1) A1(lds + (s & 3) * tabsz, dsv[s]);
+        if(s >= 3 && do_c) C(lds + ((s - 3) & 3) * tabsz, dsv[s - 3]);
+      }
+      else if(tid < 128)
+      {
+        if(tid < csw)
+        {
+          if(s >= 1 && s <= n && do_a2) A2(lds + ((s - 1) & 3) * tabsz);
+          if(s < n && do_first) A1_first(lds + (s & 3) * tabsz, dsv[s]);
+        }
+      }
+      else if(s >= 2 && s <= n + 1 && do_b)
+      {
+        if(tid - 128 < ch) B(lds + ((s - 2) & 3) * tabsz, tid - 128);
+      }
+      env.sync();
     }
-    else if(tid < csw && i < n)
-      A2(Ti);
+  }
+  else
+  {
+    if(par) A1(lds, dsv[0]);
+    else if(tid < csw) A1_first(lds, dsv[0]);
     env.sync();
-    // phase 2: A1(i + 1) beside B(i) and the first row of A1(i + 1)
-    if(par)
+    for(int i = 0; i <= n; i++)
     {
-      if(i + 1 < n) A1(To, ds_next);
+      float *const Ti = lds + (i & 1) * tabsz;       // offset i, and i + 2
+      float *const To = lds + ((i + 1) & 1) * tabsz; // offsets i - 1 and i + 1
+      // phase 1: C(i - 1) beside A2(i)
+      if(par)
+      {
+        if(i >= 1 && do_c) C(To, dsv[i - 1]);
+      }
+      else if(tid < csw && i < n && do_a2)
+        A2(Ti);
+      env.sync();
+      // phase 2: A1(i + 1) beside B(i) and the first row of A1(i + 1)
+      if(par)
+      {
+        if(i + 1 < n && do_a1) A1(To, dsv[i + 1]);
+      }
+      else if(tid < 128)
+      {
+        if(tid < csw && i + 1 < n && do_first) A1_first(To, dsv[i + 1]);
+      }
+      else if(i < n && do_b)
+      {
+        if(tid - 128 < ch) B(Ti, tid - 128);
+      }
+      env.sync();
     }
-    else if(tid < 128)
-    {
-      if(tid < csw && i + 1 < n) A1_first(To, ds_next);
-    }
-    else if(i < n)
-    {
-      if(tid - 128 < ch) B(Ti, tid - 128);
-    }
-    env.sync();
-    ds_prev = ds_cur;
-    ds_cur = ds_next;
-    ds_next = shift_of(sh_next2);
   }
 
   // ---- normalise, blend (:490-521)

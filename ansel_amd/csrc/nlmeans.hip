@@ -57,6 +57,7 @@ struct nlm_args
   // stores frame rows [out_row0, out_row1) only; `in` / `out` are addressed with frame row indices
   int cy0, out_row0, out_row1;
   int skip_interior; // nlm_chunks_pipelined: leave the interior chunks to nlm_chunks_v2
+  int variant;       // nlm_chunks_v2: 0, or the A/B switches of nlm2_body.h (ANSEL_NLM2_VARIANT; timing experiments)
 };
 
 __device__ __forceinline__ int imin(const int a, const int b) { return a < b ? a : b; }
@@ -787,14 +788,21 @@ struct nlm2_device_env
   static __device__ __forceinline__ float int_as_float(const int v) { return __int_as_float(v); }
 };
 
-template <int P>
+template <int P, int WP, int TP, bool DEEP>
 __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                              const nlm_args a, const int2 *__restrict__ patches)
 {
   extern __shared__ float lds[];
   nlm2_device_env env;
   env.lds_ = lds;
-  nlm2::body<P>(env, in, out, a, patches);
+  nlm2::body<P, WP, TP, DEEP>(env, in, out, a, patches);
+}
+
+typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *);
+template <int P> nlm2_kernel_t nlm2_kernel_of(const bool tight, const bool deep)
+{
+  if(tight) return deep ? nlm_chunks_v2<P, NL2_WP_TIGHT, NL2_TP_TIGHT, true> : nlm_chunks_v2<P, NL2_WP_TIGHT, NL2_TP_TIGHT, false>;
+  return deep ? nlm_chunks_v2<P, NL2_WP_LOOSE, NL2_TP_LOOSE, true> : nlm_chunks_v2<P, NL2_WP_LOOSE, NL2_TP_LOOSE, false>;
 }
 
 int sgn(const int v) { return (v > 0) - (v < 0); }
@@ -939,22 +947,31 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   // configuration is one it is built for: the weight without the centre-pixel term (denoise (non-local means)),
   // patch radius 1..3, and the same LDS budget as the pipelined kernel
   const int S2 = 2 * a.radius + 1, ncol2 = a.chk_w + 2 * a.radius;
+  // layout: the tight pitches when the chunk fits them; schedule: four tables (one barrier per offset) when they fit
+  // LDS beside the window, else two (nlm2_body.h)
+  const bool tight = a.chk_w + 2 * a.reach <= NL2_WP_TIGHT && ncol2 + 1 <= NL2_TP_TIGHT && getenv("ANSEL_NLM2_LAYOUT") == nullptr;
+  const int WP2 = tight ? NL2_WP_TIGHT : NL2_WP_LOOSE, TP2 = tight ? NL2_TP_TIGHT : NL2_TP_LOOSE;
+  const bool deep = nlm2::lds_floats(4, a.chk_h, a.reach, a.npatch, WP2, TP2) * sizeof(float) <= 160 * 1024 && a.chk_h <= 64
+                    && getenv("ANSEL_NLM2_DEEP") == nullptr;
+  const size_t v2_bytes = nlm2::lds_floats(deep ? 4 : 2, a.chk_h, a.reach, a.npatch, WP2, TP2) * sizeof(float);
   bool v2 = pipelined && p.center_weight < 0 && a.radius >= 1 && a.radius <= 3 && ncol2 * S2 <= NL2_PAR
-            && a.chk_w * a.chk_h <= NL2_PAR * NL2_PX && getenv("ANSEL_HIP_NLM_V1") == nullptr;
+            && a.chk_w * a.chk_h <= NL2_PAR * NL2_PX && a.chk_w + 2 * a.reach <= WP2 && ncol2 + 1 <= TP2 && a.npatch <= 4096
+            && a.chk_h <= NL2_SERIAL / 2 && v2_bytes <= 160 * 1024 && getenv("ANSEL_HIP_NLM_V1") == nullptr;
   if(v2)
   {
     const int nseg = NL2_PAR / (ncol2 * S2), m0 = (a.chk_h - 2) / S2 + 1;
     v2 = (m0 + nseg - 1) / nseg <= NL2_MSEG;
   }
-  static_assert(NL2_WP == NLP_WP && NL2_TP == NLP_TP && NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS,
-                "nlm_chunks_v2 shares the LDS budget and the launch shape of nlm_chunks_pipelined");
+  static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS, "nlm_chunks_v2 shares the launch shape of nlm_chunks_pipelined");
+  nlm2_kernel_t k2 = nullptr;
   if(v2)
   {
-    const void *const fn2 = a.radius == 1 ? (const void *)nlm_chunks_v2<1>
-                                          : (a.radius == 2 ? (const void *)nlm_chunks_v2<2> : (const void *)nlm_chunks_v2<3>);
-    if(lds_bytes > 64 * 1024)
-      ANSEL_HIP_CHECK(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    k2 = a.radius == 1 ? nlm2_kernel_of<1>(tight, deep) : (a.radius == 2 ? nlm2_kernel_of<2>(tight, deep) : nlm2_kernel_of<3>(tight, deep));
+    if(v2_bytes > 64 * 1024)
+      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_bytes));
     a.skip_interior = 1;
+    const char *const var_env = getenv("ANSEL_NLM2_VARIANT");
+    a.variant = var_env ? atoi(var_env) : 0;
   }
   {
     launch_scope ls(devid, "nlm_chunks");
@@ -962,9 +979,7 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     if(v2)
     {
       // both launches walk the whole chunk grid; a workgroup whose chunk belongs to the other kernel exits at once
-      if(a.radius == 1) nlm_chunks_v2<1><<<grid, NL2_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
-      else if(a.radius == 2) nlm_chunks_v2<2><<<grid, NL2_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
-      else nlm_chunks_v2<3><<<grid, NL2_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
+      k2<<<grid, NL2_THREADS, v2_bytes, s>>>(in, out, a, dev_patches);
     }
     if(pipelined)
       nlm_chunks_pipelined<<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);

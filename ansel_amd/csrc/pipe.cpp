@@ -10,7 +10,10 @@
 #include "pipe_fused.h"
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace ansel;
@@ -747,6 +750,247 @@ int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_
   return err;
 }
 
+// ---- one frame over the devices of ONE process (BASELINE.json config 4 from C) ----------------------------------
+// The reference is a single C process (src/develop/pixelpipe_hb.c:1470): it cannot run one rank per GPU under a
+// launcher, so the band walk of section 3b is also driven from inside the library -- one host thread per band (a
+// module's launch code may block on ITS device, e.g. the patch table upload of the non-local means; with a thread
+// per device the others keep enqueueing), the bands in lockstep at the exchange points, the collectives as peer
+// copies over xGMI:
+//   * the clipped count of the highlights bypass: 8 bytes per band through the host, summed in band order (integers);
+//   * halo rows: each band PULLS the rows it needs from its neighbours' buffers (hipMemcpyPeerAsync on its own
+//     stream), after every band has finished the step that produces them and before any band goes on;
+//   * the profiled wavelets' table of partial sums: every entry is non-zero in exactly one band's table (the band
+//     that owns the row), so the all-reduce is an all-gather of row segments -- one strided peer copy per
+//     neighbour and band, exact by construction (x + 0 + ... + 0), no arithmetic at all.
+// Bands may share a device (the single-GPU test of this path): a peer copy is then a device copy.
+namespace
+{
+struct band_gang_t
+{
+  int n;
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0;
+  unsigned long generation = 0;
+  // all bands meet here; returns the worst (most negative; else largest) code any of them brought
+  std::vector<int> rc;
+  void wait()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    const unsigned long g = generation;
+    if(++waiting == n)
+    {
+      waiting = 0;
+      generation++;
+      cv.notify_all();
+    }
+    else
+      cv.wait(lk, [&] { return generation != g; });
+  }
+};
+
+int copy_between(const int dst_devid, void *dst, const int src_devid, const void *src, const size_t bytes, hipStream_t s)
+{
+  if(!bytes) return DT_HIP_SUCCESS;
+  const int dd = hip_device_of(dst_devid), sd = hip_device_of(src_devid);
+  if(dd == sd) ANSEL_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  else ANSEL_HIP_CHECK(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, s));
+  return DT_HIP_SUCCESS;
+}
+} // namespace
+
+int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_band_t *bands, const dt_hip_mem_t *dev_in,
+                              const dt_hip_mem_t *dev_out)
+{
+  if(!pipes || n < 1 || n > 64 || !bands || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
+  for(int k = 0; k < n; k++)
+    if(!pipes[k] || !dev_in[k] || !dev_out[k] || pipes[k]->nodes.empty() || !valid_device(pipes[k]->devid)) return DT_HIP_INVALID_ARG;
+  const int W = pipes[0]->nodes[0].piece.roi_out.width, H = pipes[0]->nodes[0].piece.roi_out.height;
+  for(int k = 0; k < n; k++)
+  {
+    if(pipes[k]->nodes.size() != pipes[0]->nodes.size() || pipes[k]->nodes[0].piece.roi_out.width != W
+       || pipes[k]->nodes[0].piece.roi_out.height != H)
+    {
+      set_last_error("dt_hip_pipe_process_bands: pipe %d does not hold the node list of pipe 0", k);
+      return DT_HIP_INVALID_ARG;
+    }
+    if(bands[k].row0 != (k ? bands[k - 1].row0 + bands[k - 1].rows : 0) || (k + 1 == n && bands[k].row0 + bands[k].rows != H))
+    {
+      set_last_error("dt_hip_pipe_process_bands: the bands do not tile the %d rows of the frame", H);
+      return DT_HIP_INVALID_ARG;
+    }
+  }
+  band_gang_t gang;
+  gang.n = n;
+  gang.rc.assign(n, DT_HIP_SUCCESS);
+  std::vector<dt_hip_band_state_t> st(n);
+  std::vector<unsigned long long> counts(n, 0ull);
+  std::vector<std::string> errors(n);
+  for(auto &x : st) memset(&x, 0, sizeof(x));
+
+  auto worker = [&](const int k) {
+    dt_hip_pipe_t *const pipe = pipes[k];
+    const int devid = pipe->devid;
+    const dt_hip_band_t &b = bands[k];
+    hipStream_t s = stream_of(devid); // also makes the device current for this thread
+    // direct loads / stores between the devices of the gang (an error only means "already enabled" or "same device")
+    for(int j = 0; j < n; j++)
+      if(hip_device_of(pipes[j]->devid) != hip_device_of(devid))
+      {
+        (void)hipDeviceEnablePeerAccess(hip_device_of(pipes[j]->devid), 0);
+        (void)hipGetLastError();
+      }
+    auto fail = [&](const int code) {
+      gang.rc[k] = code;
+      errors[k] = dt_hip_last_error();
+    };
+    // every band arrives with its stream drained; all leave with the same verdict
+    bool any_stop = false, all_stop = false; // of the last meet(): bands that stopped for an exchange
+    auto meet = [&]() -> bool {
+      if(gang.rc[k] >= 0 && hipStreamSynchronize(s) != hipSuccess) fail(DT_HIP_DEFAULT_ERROR);
+      gang.wait();
+      bool ok = true;
+      any_stop = false;
+      all_stop = true;
+      for(int j = 0; j < n; j++)
+      {
+        ok &= gang.rc[j] >= 0;
+        any_stop |= gang.rc[j] == DT_HIP_BAND_EXCHANGE;
+        all_stop &= gang.rc[j] == DT_HIP_BAND_EXCHANGE;
+      }
+      gang.wait(); // nobody overwrites its code before everybody has read them
+      return ok;
+    };
+    auto give_up = [&]() { dt_hip_pipe_band_abort(pipe, &st[k]); };
+
+    // 1. the CFA stages on the own rows
+    int rc = dt_hip_pipe_band_begin(pipe, &b, dev_in[k], &st[k]);
+    if(rc != DT_HIP_SUCCESS) fail(rc);
+    if(gang.rc[k] >= 0 && st[k].clipped_count
+       && hipMemcpyAsync(&counts[k], st[k].clipped_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess)
+      fail(DT_HIP_DEFAULT_ERROR);
+    if(!meet()) return give_up();
+    // 2. the bypass of the highlight clipping is decided on the frame's count
+    if(st[k].clipped_count)
+    {
+      unsigned long long total = 0;
+      for(int j = 0; j < n; j++) total += counts[j];
+      if(hipMemcpyAsync(st[k].clipped_count, &total, sizeof(total), hipMemcpyHostToDevice, s) != hipSuccess
+         || hipStreamSynchronize(s) != hipSuccess) // `total` is a stack variable
+        fail(DT_HIP_DEFAULT_ERROR);
+    }
+    if(gang.rc[k] >= 0 && (rc = dt_hip_pipe_band_resolve(pipe, &b, &st[k])) != DT_HIP_SUCCESS) fail(rc);
+    if(!meet()) return give_up();
+    // 3. mosaic rows the demosaic reads beyond the band
+    if(st[k].halo_buf)
+    {
+      char *const mine = (char *)st[k].halo_buf;
+      const size_t rb = st[k].row_bytes;
+      if(k > 0 && b.halo_top && st[k - 1].halo_buf)
+      {
+        const dt_hip_band_t &ub = bands[k - 1];
+        rc = copy_between(devid, mine, pipes[k - 1]->devid,
+                          (const char *)st[k - 1].halo_buf + (size_t)(ub.halo_top + ub.rows - b.halo_top) * rb,
+                          (size_t)b.halo_top * rb, s);
+        if(rc != DT_HIP_SUCCESS) fail(rc);
+      }
+      if(k + 1 < n && b.halo_bottom && st[k + 1].halo_buf)
+      {
+        const dt_hip_band_t &db = bands[k + 1];
+        rc = copy_between(devid, mine + (size_t)(b.halo_top + b.rows) * rb, pipes[k + 1]->devid,
+                          (const char *)st[k + 1].halo_buf + (size_t)db.halo_top * rb, (size_t)b.halo_bottom * rb, s);
+        if(rc != DT_HIP_SUCCESS) fail(rc);
+      }
+    }
+    if(!meet()) return give_up();
+    // 4. the walk, stopping where a stencil module needs its neighbours
+    for(;;)
+    {
+      rc = dt_hip_pipe_band_finish(pipe, &b, &st[k], dev_out[k]);
+      if(rc < 0) fail(rc);
+      else gang.rc[k] = rc; // DT_HIP_SUCCESS or DT_HIP_BAND_EXCHANGE
+      const bool ok = meet();
+      if(!ok)
+      {
+        if(gang.rc[k] >= 0 && rc == DT_HIP_BAND_EXCHANGE) give_up(); // a finish() that failed has freed its state itself
+        return;
+      }
+      if(!any_stop) return; // every band has written its rows
+      gang.rc[k] = DT_HIP_SUCCESS;
+      if(!all_stop)
+      {
+        // cannot happen for bands of one node list: they stop in front of the same modules
+        if(rc == DT_HIP_BAND_EXCHANGE) give_up();
+        fail(DT_HIP_DEFAULT_ERROR);
+        errors[k] = "dt_hip_pipe_process_bands: the bands did not stop at the same module";
+        return;
+      }
+      if(st[k].sum_buf && st[k].sum_planes > 0)
+      {
+        const size_t plane = st[k].sum_count / (size_t)st[k].sum_planes, per_row = plane / (size_t)H;
+        for(int j = 0; j < n && gang.rc[k] >= 0; j++)
+        {
+          if(j == k) continue;
+          const size_t off = (size_t)bands[j].row0 * per_row, len = (size_t)bands[j].rows * per_row;
+          // kind Default: the runtime routes the strided copy between the two devices' memories (unified addressing)
+          if(hipMemcpy2DAsync(st[k].sum_buf + off, plane * sizeof(double), st[j].sum_buf + off, plane * sizeof(double),
+                              len * sizeof(double), (size_t)st[k].sum_planes, hipMemcpyDefault, s) != hipSuccess)
+            fail(DT_HIP_DEFAULT_ERROR);
+        }
+      }
+      if(st[k].halo_rows > 0 && st[k].halo_buf)
+      {
+        const int h = st[k].halo_rows;
+        auto parts = [&](const int j, int &top, int &bottom) {
+          top = std::min(h, bands[j].row0);
+          bottom = std::min(h, H - bands[j].row0 - bands[j].rows);
+        };
+        int top, bottom;
+        parts(k, top, bottom);
+        char *const mine = (char *)st[k].halo_buf;
+        const size_t rb = st[k].row_bytes;
+        if((k > 0 && bands[k - 1].rows < top) || (k + 1 < n && bands[k + 1].rows < bottom))
+        {
+          fail(DT_HIP_INVALID_ARG);
+          errors[k] = "dt_hip_pipe_process_bands: a band owns fewer rows than the halo its neighbour needs: use fewer bands";
+        }
+        else
+        {
+          if(k > 0 && top)
+          {
+            int utop, ubot;
+            parts(k - 1, utop, ubot);
+            rc = copy_between(devid, mine, pipes[k - 1]->devid,
+                              (const char *)st[k - 1].halo_buf + (size_t)(utop + bands[k - 1].rows - top) * rb, (size_t)top * rb, s);
+            if(rc != DT_HIP_SUCCESS) fail(rc);
+          }
+          if(k + 1 < n && bottom)
+          {
+            int dtop, dbot;
+            parts(k + 1, dtop, dbot);
+            rc = copy_between(devid, mine + (size_t)(top + b.rows) * rb, pipes[k + 1]->devid,
+                              (const char *)st[k + 1].halo_buf + (size_t)dtop * rb, (size_t)bottom * rb, s);
+            if(rc != DT_HIP_SUCCESS) fail(rc);
+          }
+        }
+      }
+      if(!meet()) return give_up();
+    }
+  };
+
+  std::vector<std::thread> gangsters;
+  gangsters.reserve(n);
+  for(int k = 0; k < n; k++) gangsters.emplace_back(worker, k);
+  for(auto &t : gangsters) t.join();
+  for(int k = 0; k < n; k++)
+    if(gang.rc[k] < 0)
+    {
+      set_last_error("band %d of %d: %s", k, n, errors[k].c_str());
+      return gang.rc[k];
+    }
+  return DT_HIP_SUCCESS;
+}
+
 // ---- default_process_tiling_cl() for roi_in == roi_out, src/develop/tiling.c:842-1067 ----------------------------
 // the tile plan of _default_process_tiling_cl_ptp(), :868-979, as a pure function of the frame, the module's
 // requirements and the device's limits
@@ -915,6 +1159,269 @@ int dt_hip_default_process_tiling_ptp(int devid, const char *op, const dt_hip_pi
   return DT_HIP_SUCCESS;
 }
 
+// ---- default_process_tiling_cl() for roi_in != roi_out, src/develop/tiling.c:1076-1390 (_default_process_tiling_cl_roi)
+// The only module of the export path whose output geometry differs from its input is finalscale, so its
+// modify_roi_in() (src/iop/finalscale.c:76-107, the full-resolution pipeline of an export) is the one restated here.
+namespace
+{
+int ra_align_up(const int n, const int a) { return n + a - (n % a); } // tiling.c:92-95: one more step even when aligned
+int ra_align_down(const int n, const int a) { return n - (n % a); }
+int ra_align_close(const int n, const int a)
+{
+  const int off = n % a;
+  const int shift = (off > a / 2) ? a - off : -off;
+  return n + shift;
+}
+
+// finalscale modify_roi_in(), finalscale.c:76-107
+void finalscale_modify_roi_in(const dt_hip_roi_t *roi_out, dt_hip_roi_t *roi_in)
+{
+  *roi_in = *roi_out;
+  if(roi_in->scale > 1.f)
+  {
+    roi_in->x = (int)roundf((float)roi_in->x / roi_out->scale);
+    roi_in->y = (int)roundf((float)roi_in->y / roi_out->scale);
+    roi_in->width = (int)roundf(roi_out->width / roi_out->scale);
+    roi_in->height = (int)roundf(roi_out->height / roi_out->scale);
+    roi_in->scale = 1.0f;
+  }
+  else
+  {
+    roi_in->width = (int)roundf(roi_out->width / roi_out->scale);
+    roi_in->height = (int)roundf(roi_out->height / roi_out->scale);
+    roi_in->scale = 1.0f;
+    const float resample_scale = roi_out->scale / roi_in->scale;
+    roi_in->x = (int)roundf(roi_in->x / resample_scale);
+    roi_in->y = (int)roundf(roi_in->y / resample_scale);
+  }
+}
+
+// _fit_output_to_input_roi(), tiling.c:197-237, its iterative search.  The Nelder-Mead fallback (:170-190) is for
+// modules that distort; finalscale's search converges in one or two steps, so its failure is reported, not papered over
+bool fit_output_to_input_roi(const dt_hip_roi_t *iroi, dt_hip_roi_t *oroi, const int delta, int iter)
+{
+  dt_hip_roi_t probe = *iroi;
+  finalscale_modify_roi_in(oroi, &probe);
+  while((abs(probe.x - iroi->x) > delta || abs(probe.y - iroi->y) > delta || abs(probe.width - iroi->width) > delta
+         || abs(probe.height - iroi->height) > delta)
+        && iter > 0)
+  {
+    oroi->x += (iroi->x - probe.x) * oroi->scale / iroi->scale;
+    oroi->y += (iroi->y - probe.y) * oroi->scale / iroi->scale;
+    oroi->width += (iroi->width - probe.width) * oroi->scale / iroi->scale;
+    oroi->height += (iroi->height - probe.height) * oroi->scale / iroi->scale;
+    finalscale_modify_roi_in(oroi, &probe);
+    iter--;
+  }
+  return iter > 0;
+}
+} // namespace
+
+// the tile grid of :1100-1220 as a pure function of the two regions, the module's requirements and the device's limits
+int dt_hip_plan_tiles_roi(const dt_hip_roi_t *roi_in, const dt_hip_roi_t *roi_out, int in_bpp, int out_bpp,
+                          const dt_hip_tiling_t *tiling, unsigned filters, size_t available_bytes, size_t memalloc_bytes,
+                          int max_width, int max_height, dt_hip_tile_plan_roi_t *plan)
+{
+  if(!roi_in || !roi_out || !tiling || !plan || roi_in->width <= 0 || roi_in->height <= 0 || roi_out->width <= 0
+     || roi_out->height <= 0 || in_bpp <= 0 || out_bpp <= 0)
+    return DT_HIP_INVALID_ARG;
+  auto gcd = [](unsigned a, unsigned b) {
+    while(b)
+    {
+      const unsigned t = b;
+      b = a % b;
+      a = t;
+    }
+    return a;
+  };
+  auto lcm = [&](unsigned a, unsigned b) { return (a && b) ? a / gcd(a, b) * b : 0u; };
+  const int max_bpp = std::max(in_bpp, out_bpp);
+  const float fullscale = fmaxf((float)(roi_in->scale / roi_out->scale),
+                                sqrtf(((float)roi_in->width * roi_in->height) / ((float)roi_out->width * roi_out->height)));
+  const int delta = (int)ceilf(fullscale);
+  const int inacc = 5 * delta; // RESERVE, :59
+  const float available = (float)available_bytes;
+  const float factor = fmaxf(tiling->factor_cl, 1.0f);
+  const float singlebuffer = fminf(fmaxf((available - tiling->overhead) / factor, 0.0f), (float)memalloc_bytes);
+  const float maxbuf = fmaxf(tiling->maxbuf_cl, 1.0f);
+  int width = std::min(std::max(roi_in->width, roi_out->width), max_width);
+  int height = std::min(std::max(roi_in->height, roi_out->height), max_height);
+  unsigned xyalign = lcm(tiling->xalign, tiling->yalign);
+  xyalign = lcm(xyalign, filters != 9u ? 4u : 1u); // CL_ALIGNMENT, :54
+  if(!xyalign) return DT_HIP_INVALID_ARG;
+  const int al = (int)xyalign;
+  if((float)width * height * max_bpp * maxbuf > singlebuffer)
+  {
+    const float scale = singlebuffer / ((float)width * height * max_bpp * maxbuf);
+    if(width < height && scale >= 0.333f)
+      height = ra_align_down((int)floorf(height * scale), al);
+    else if(height <= width && scale >= 0.333f)
+      width = ra_align_down((int)floorf(width * scale), al);
+    else
+    {
+      width = ra_align_down((int)floorf(width * sqrtf(scale)), al);
+      height = ra_align_down((int)floorf(height * sqrtf(scale)), al);
+    }
+  }
+  if(3 * tiling->overlap > (unsigned)width || 3 * tiling->overlap > (unsigned)height)
+    width = height = ra_align_down((int)floorf(sqrtf((float)width * height)), al);
+  const int overlap_in = ra_align_up((int)tiling->overlap, al);
+  const int overlap_out = (int)ceilf((float)overlap_in / fullscale);
+  // the rounded-footprint loop, :1170-1179 (linear allocations are not rounded: dt_hip_dev_roundup_* are identities)
+  while((float)width * height * max_bpp * maxbuf > singlebuffer)
+  {
+    if(width <= al && height <= al) break;
+    if(width < height && height > al)
+      height -= al;
+    else if(width > al)
+      width -= al;
+    else
+      height -= al;
+  }
+  if(width < std::max(roi_in->width, roi_out->width)) width = std::max(al, ra_align_down(width, al));
+  if(height < std::max(roi_in->height, roi_out->height)) height = std::max(al, ra_align_down(height, al));
+  int tiles_x = 1, tiles_y = 1;
+  if(roi_in->width > roi_out->width)
+    tiles_x = width < roi_in->width ? (int)ceilf((float)roi_in->width / (float)std::max(width - 2 * overlap_in - inacc, 1)) : 1;
+  else
+    tiles_x = width < roi_out->width ? (int)ceilf((float)roi_out->width / (float)std::max(width - 2 * overlap_out, 1)) : 1;
+  if(roi_in->height > roi_out->height)
+    tiles_y = height < roi_in->height ? (int)ceilf((float)roi_in->height / (float)std::max(height - 2 * overlap_in - inacc, 1)) : 1;
+  else
+    tiles_y = height < roi_out->height ? (int)ceilf((float)roi_out->height / (float)std::max(height - 2 * overlap_out, 1)) : 1;
+  if((long)tiles_x * tiles_y > 10000)
+  {
+    set_last_error("tiling: %d x %d tiles is too many", tiles_x, tiles_y);
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  plan->width = width;
+  plan->height = height;
+  plan->tiles_x = tiles_x;
+  plan->tiles_y = tiles_y;
+  plan->tile_wd = ra_align_up(roi_out->width % tiles_x == 0 ? roi_out->width / tiles_x : roi_out->width / tiles_x + 1, al);
+  plan->tile_ht = ra_align_up(roi_out->height % tiles_y == 0 ? roi_out->height / tiles_y : roi_out->height / tiles_y + 1, al);
+  plan->overlap_in = overlap_in;
+  plan->overlap_out = overlap_out;
+  plan->delta = delta;
+  plan->xyalign = al;
+  return DT_HIP_SUCCESS;
+}
+
+// the three regions of tile (tx, ty), :1228-1300: the good part of the output, the input it is computed from (with
+// overlap, alignment and `delta` of slack) and the output region that input produces
+int dt_hip_tile_rois_finalscale(const dt_hip_tile_plan_roi_t *pl, const dt_hip_roi_t *roi_in, const dt_hip_roi_t *roi_out, int tx,
+                                int ty, dt_hip_roi_t *iroi_full_out, dt_hip_roi_t *oroi_full_out, dt_hip_roi_t *oroi_good_out)
+{
+  if(!pl || !roi_in || !roi_out || tx < 0 || ty < 0 || tx >= pl->tiles_x || ty >= pl->tiles_y) return DT_HIP_INVALID_ARG;
+  const int tile_wd = pl->tile_wd, tile_ht = pl->tile_ht, al = pl->xyalign, delta = pl->delta, overlap_in = pl->overlap_in;
+  const int wd = (tx + 1) * tile_wd > roi_out->width ? roi_out->width - tx * tile_wd : tile_wd;
+  const int ht = (ty + 1) * tile_ht > roi_out->height ? roi_out->height - ty * tile_ht : tile_ht;
+  if(wd <= 0 || ht <= 0) return DT_HIP_TILE_EMPTY; // align_up() of the tile step can leave nothing for the last tile
+  dt_hip_roi_t iroi_good = { roi_in->x + tx * tile_wd, roi_in->y + ty * tile_ht, wd, ht, roi_in->scale };
+  dt_hip_roi_t oroi_good = { roi_out->x + tx * tile_wd, roi_out->y + ty * tile_ht, wd, ht, roi_out->scale };
+  finalscale_modify_roi_in(&oroi_good, &iroi_good);
+  iroi_good.x = std::max(iroi_good.x, roi_in->x);
+  iroi_good.y = std::max(iroi_good.y, roi_in->y);
+  iroi_good.width = std::min(iroi_good.width, roi_in->width + roi_in->x - iroi_good.x);
+  iroi_good.height = std::min(iroi_good.height, roi_in->height + roi_in->y - iroi_good.y);
+  const int x_in = iroi_good.x, y_in = iroi_good.y, width_in = iroi_good.width, height_in = iroi_good.height;
+  const int new_x_in = std::max(ra_align_close(x_in - overlap_in - delta, al), roi_in->x);
+  const int new_y_in = std::max(ra_align_close(y_in - overlap_in - delta, al), roi_in->y);
+  const int new_width_in = std::min(ra_align_up(width_in + overlap_in + delta + (x_in - new_x_in), al), roi_in->width + roi_in->x - new_x_in);
+  const int new_height_in = std::min(ra_align_up(height_in + overlap_in + delta + (y_in - new_y_in), al), roi_in->height + roi_in->y - new_y_in);
+  dt_hip_roi_t iroi_full = { new_x_in, new_y_in, new_width_in, new_height_in, iroi_good.scale };
+  dt_hip_roi_t oroi_full = oroi_good;
+  if(!fit_output_to_input_roi(&iroi_full, &oroi_full, delta, 10))
+  {
+    set_last_error("tiling: no output region matches the input of tile (%d, %d)", tx, ty);
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  oroi_full.x = std::min(oroi_full.x, oroi_good.x);
+  oroi_full.y = std::min(oroi_full.y, oroi_good.y);
+  oroi_full.width = std::max(oroi_full.width, oroi_good.x + oroi_good.width - oroi_full.x);
+  oroi_full.height = std::max(oroi_full.height, oroi_good.y + oroi_good.height - oroi_full.y);
+  oroi_full.x = std::max(oroi_full.x, roi_out->x);
+  oroi_full.y = std::max(oroi_full.y, roi_out->y);
+  oroi_full.width = std::min(oroi_full.width, roi_out->width + roi_out->x - oroi_full.x);
+  oroi_full.height = std::min(oroi_full.height, roi_out->height + roi_out->y - oroi_full.y);
+  finalscale_modify_roi_in(&oroi_full, &iroi_full);
+  iroi_full.x = std::max(iroi_full.x, roi_in->x);
+  iroi_full.y = std::max(iroi_full.y, roi_in->y);
+  iroi_full.width = std::min(iroi_full.width, roi_in->width + roi_in->x - iroi_full.x);
+  iroi_full.height = std::min(iroi_full.height, roi_in->height + roi_in->y - iroi_full.y);
+  if(iroi_full_out) *iroi_full_out = iroi_full;
+  if(oroi_full_out) *oroi_full_out = oroi_full;
+  if(oroi_good_out) *oroi_good_out = oroi_good;
+  return DT_HIP_SUCCESS;
+}
+
+// the loop of :1222-1370: host frame -> every tile's full input region through the device -> the good part of its
+// output back into the host frame.  `op` must be "finalscale" (the module whose modify_roi_in() is restated above)
+int dt_hip_default_process_tiling_roi(int devid, const char *op, const dt_hip_piece_t *piece, const void *data, size_t data_size,
+                                      const dt_hip_tiling_t *tiling, const void *host_in, void *host_out, int in_bpp,
+                                      int out_bpp, size_t available_bytes)
+{
+  if(!valid_device(devid) || !op || !piece || !tiling || !host_in || !host_out) return DT_HIP_INVALID_ARG;
+  if(strcmp(op, "finalscale") != 0)
+  {
+    set_last_error("tiling (roi_in != roi_out): '%s' has no modify_roi_in() here; finalscale is the one module of the path that "
+                   "changes the geometry", op);
+    return DT_HIP_INVALID_ARG;
+  }
+  node_t n;
+  n.op = OP_FINALSCALE;
+  if(data_size != k_ops[n.op].data_size || (data_size && !data)) return DT_HIP_INVALID_ARG;
+  if(data_size) n.data.assign((const unsigned char *)data, (const unsigned char *)data + data_size);
+  const dt_hip_roi_t &ri = piece->roi_in, &ro = piece->roi_out;
+  int max_w = 0, max_h = 0;
+  dt_hip_get_device_max_image_size(devid, &max_w, &max_h);
+  dt_hip_tile_plan_roi_t pl;
+  int err = dt_hip_plan_tiles_roi(&ri, &ro, in_bpp, out_bpp, tiling, piece->filters,
+                                  available_bytes ? available_bytes : dt_hip_get_device_available(devid),
+                                  dt_hip_get_device_memalloc(devid), max_w, max_h, &pl);
+  if(err != DT_HIP_SUCCESS) return err;
+  const size_t ipitch = (size_t)ri.width * in_bpp, opitch = (size_t)ro.width * out_bpp;
+  hipStream_t st = stream_of(devid);
+  for(int tx = 0; tx < pl.tiles_x; tx++)
+    for(int ty = 0; ty < pl.tiles_y; ty++)
+    {
+      dt_hip_roi_t iroi_full, oroi_full, oroi_good;
+      err = dt_hip_tile_rois_finalscale(&pl, &ri, &ro, tx, ty, &iroi_full, &oroi_full, &oroi_good);
+      if(err == DT_HIP_TILE_EMPTY) continue;
+      if(err != DT_HIP_SUCCESS) return err;
+      const size_t ioffs = (size_t)(iroi_full.y - ri.y) * ipitch + (size_t)(iroi_full.x - ri.x) * in_bpp;
+      const size_t ooffs = (size_t)(oroi_good.y - ro.y) * opitch + (size_t)(oroi_good.x - ro.x) * out_bpp;
+      dt_hip_mem_t input = dt_hip_alloc_device(devid, iroi_full.width, iroi_full.height, in_bpp);
+      dt_hip_mem_t output = dt_hip_alloc_device(devid, oroi_full.width, oroi_full.height, out_bpp);
+      err = (input && output) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
+      if(err == DT_HIP_SUCCESS)
+        err = dt_hip_write_host_to_device_rowpitch(devid, (const char *)host_in + ioffs, input, iroi_full.width, iroi_full.height,
+                                                   in_bpp, ipitch, 1);
+      if(err == DT_HIP_SUCCESS)
+      {
+        n.piece = *piece;
+        n.piece.roi_in = iroi_full;
+        n.piece.roi_out = oroi_full;
+        err = run_single(devid, n, input, output);
+      }
+      if(err == DT_HIP_SUCCESS)
+      {
+        const char *src = (const char *)output + ((size_t)(oroi_good.y - oroi_full.y) * oroi_full.width + (oroi_good.x - oroi_full.x)) * out_bpp;
+        if(hipMemcpy2DAsync((char *)host_out + ooffs, opitch, src, (size_t)oroi_full.width * out_bpp, (size_t)oroi_good.width * out_bpp,
+                            oroi_good.height, hipMemcpyDeviceToHost, st) != hipSuccess
+           || hipStreamSynchronize(st) != hipSuccess)
+        {
+          set_last_error("tiling: download of tile (%d, %d) failed: %s", tx, ty, hipGetErrorString(hipGetLastError()));
+          err = DT_HIP_DEFAULT_ERROR;
+        }
+      }
+      if(input) dt_hip_release_mem_object(input);
+      if(output) dt_hip_release_mem_object(output);
+      if(err != DT_HIP_SUCCESS) return err;
+    }
+  return DT_HIP_SUCCESS;
+}
+
 // default_tiling_callback(), src/develop/tiling.c:1423-1463, for the modules without a callback of their own
 // (rawprepare, temperature, highlights, exposure, colorin, channelmixerrgb, filmicrgb, colorout, finalscale)
 void dt_hip_default_tiling(const dt_hip_piece_t *piece, int before_demosaic, dt_hip_tiling_t *tiling)
@@ -978,6 +1485,7 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
   state->halo_rows = 0;
   state->sum_buf = nullptr;
   state->sum_count = 0;
+  state->sum_planes = 0;
   if(!pv->walking)
   {
     if(pv->journal) err = dt_hip_pipe_band_resolve(pipe, band, state); // caller skipped the explicit step
@@ -1155,6 +1663,8 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
             state->row_bytes = rgba_row;
             state->sum_buf = sums;
             state->sum_count = count;
+            // planes of [frame rows][segments][4]: each band's own rows are the only non-zero entries of its table
+            state->sum_planes = count ? (int32_t)(count / ((size_t)H * ((W + 255) / 256) * 4)) : 0;
             return DT_HIP_BAND_EXCHANGE;
           }
         } while(rc > 0);

@@ -39,6 +39,7 @@ struct device_t
   bool own_stream = false;
   std::mutex lock; // device exclusivity: dt_opencl_reserve_device_for_pipe() / _release_device()
   bool events_enabled = false;
+  std::mutex ev_lock; // events / event_pool: several host threads may launch on one device (dt_hip_pipe_process_bands)
   std::vector<event_rec> events;
   std::vector<hipEvent_t> event_pool;
   size_t cur_bytes = 0, peak_bytes = 0;
@@ -88,6 +89,8 @@ bool make_current(int devid)
   return hipSetDevice(want) == hipSuccess;
 }
 
+int hip_device_of(int devid) { return valid_device(devid) ? g_devs[devid]->hip_id : -1; }
+
 hipStream_t stream_of(int devid)
 {
   if(!make_current(devid)) return nullptr;
@@ -100,6 +103,7 @@ launch_scope::launch_scope(int devid_, const char *tag_) : devid(devid_), tag(ta
   device_t *d = g_devs[devid];
   if(!d->events_enabled) return;
   make_current(devid); // an event belongs to the device that is current when it is created
+  std::lock_guard<std::mutex> g(d->ev_lock);
   auto get = [&]() {
     hipEvent_t e;
     if(!d->event_pool.empty())
@@ -128,6 +132,7 @@ launch_scope::~launch_scope()
 {
   if(!active) return;
   device_t *d = g_devs[devid];
+  std::lock_guard<std::mutex> g(d->ev_lock);
   if(hipEventRecord(stop, d->stream) != hipSuccess)
   {
     (void)hipGetLastError();

@@ -122,6 +122,9 @@ def load():
         "dt_hip_plan_tiles_ptp": (i, [i, i, i, i, P(abi.Tiling), C.c_uint, sz, sz, i, i, P(abi.TilePlan)]),
         "dt_hip_default_process_tiling_ptp": (i, [i, C.c_char_p, P(abi.Piece), vp, sz, P(abi.Tiling), vp, vp, i, i, sz]),
         "dt_hip_default_tiling": (None, [P(abi.Piece), i, P(abi.Tiling)]),
+        "dt_hip_plan_tiles_roi": (i, [P(abi.Roi), P(abi.Roi), i, i, P(abi.Tiling), C.c_uint, sz, sz, i, i, P(abi.TilePlanRoi)]),
+        "dt_hip_tile_rois_finalscale": (i, [P(abi.TilePlanRoi), P(abi.Roi), P(abi.Roi), i, i, P(abi.Roi), P(abi.Roi), P(abi.Roi)]),
+        "dt_hip_default_process_tiling_roi": (i, [i, C.c_char_p, P(abi.Piece), vp, sz, P(abi.Tiling), vp, vp, i, i, sz]),
         "dt_hip_iop_denoiseprofile_tiling": (None, [P(abi.Piece), P(abi.DenoiseprofileData), P(abi.Tiling)]),
         "dt_hip_iop_nlmeans_tiling": (None, [P(abi.Piece), P(abi.NlmeansData), P(abi.Tiling)]),
         "dt_hip_iop_bilat_tiling": (None, [P(abi.Piece), P(abi.BilatData), P(abi.Tiling)]),
@@ -146,6 +149,7 @@ def load():
         "dt_hip_pipe_band_resolve": (i, [vp, P(abi.Band), P(abi.BandState)]),
         "dt_hip_pipe_band_finish": (i, [vp, P(abi.Band), P(abi.BandState), vp]),
         "dt_hip_pipe_band_abort": (None, [vp, P(abi.BandState)]),
+        "dt_hip_pipe_process_bands": (i, [P(vp), i, P(abi.Band), P(vp), P(vp)]),
         "dt_hip_iop_highlights_process_deferred": (i, [i, P(abi.Piece), P(abi.HighlightsData), vp, vp, vp]),
         "dt_hip_iop_highlights_resolve": (i, [i, vp, vp]),
     }

@@ -103,6 +103,27 @@ int dt_hip_plan_tiles_ptp(int roi_width, int roi_height, int in_bpp, int out_bpp
 int dt_hip_default_process_tiling_ptp(int devid, const char *op, const dt_hip_piece_t *piece, const void *data,
                                       size_t data_size, const dt_hip_tiling_t *tiling, const void *host_in, void *host_out,
                                       int in_bpp, int out_bpp, size_t available_bytes);
+/* ... and for roi_in != roi_out (_default_process_tiling_cl_roi(), src/develop/tiling.c:1076-1390): on the export path
+ * that is finalscale, whose modify_roi_in() (src/iop/finalscale.c:76-107) relates the regions.  dt_hip_plan_tiles_roi()
+ * is the tile grid of :1100-1220, dt_hip_tile_rois_finalscale() the three regions of one tile (:1228-1300) -- both pure
+ * functions -- and dt_hip_default_process_tiling_roi() the loop of :1222-1370.  Like the reference, every tile is
+ * resampled as an image of its own (finalscale ignores the region origins, finalscale.c:124-129). */
+typedef struct dt_hip_tile_plan_roi_t
+{
+  int32_t width, height;     /* largest buffer of a tile (input or output) */
+  int32_t tile_wd, tile_ht;  /* the good part of a tile, in output pixels */
+  int32_t tiles_x, tiles_y;
+  int32_t overlap_in, overlap_out, delta, xyalign;
+} dt_hip_tile_plan_roi_t;
+#define DT_HIP_TILE_EMPTY 2 /* dt_hip_tile_rois_finalscale(): the tile has no output pixels (the grid step is rounded up) */
+int dt_hip_plan_tiles_roi(const dt_hip_roi_t *roi_in, const dt_hip_roi_t *roi_out, int in_bpp, int out_bpp,
+                          const dt_hip_tiling_t *tiling, unsigned filters, size_t available_bytes, size_t memalloc_bytes,
+                          int max_width, int max_height, dt_hip_tile_plan_roi_t *plan);
+int dt_hip_tile_rois_finalscale(const dt_hip_tile_plan_roi_t *plan, const dt_hip_roi_t *roi_in, const dt_hip_roi_t *roi_out,
+                                int tx, int ty, dt_hip_roi_t *iroi_full, dt_hip_roi_t *oroi_full, dt_hip_roi_t *oroi_good);
+int dt_hip_default_process_tiling_roi(int devid, const char *op, const dt_hip_piece_t *piece, const void *data, size_t data_size,
+                                      const dt_hip_tiling_t *tiling, const void *host_in, void *host_out, int in_bpp,
+                                      int out_bpp, size_t available_bytes);
 
 /* ---- 1. device runtime (peer of src/common/opencl.h) ------------------------------ */
 
@@ -682,7 +703,8 @@ typedef struct dt_hip_band_state_t
   void *priv;
   /* requests of a dt_hip_pipe_band_finish() that returned DT_HIP_BAND_EXCHANGE */
   int32_t halo_rows;
-  int32_t reserved;
+  int32_t sum_planes; /* sum_buf = sum_planes tables of [frame rows][segments][4] doubles; a band's own rows are the
+                         only non-zero entries of its table, so SUM over the bands is an all-gather of row segments */
   double *sum_buf;
   size_t sum_count;
 } dt_hip_band_state_t;
@@ -699,6 +721,15 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
                             dt_hip_mem_t dev_out_band);
 /* give up a band whose walk has not ended (an error on another rank, a cancelled export): frees the state */
 void dt_hip_pipe_band_abort(dt_hip_pipe_t *pipe, dt_hip_band_state_t *state);
+/* The whole walk from ONE process, for a host that is one C process like the reference (src/develop/pixelpipe_hb.c:1470
+ * runs every pipe of the application; default_process_tiling_cl(), tiling.c:1394, is its only way to split a frame):
+ * band k of the frame runs on pipes[k] -- n pipes loaded with the same node list, each on its own device (or all on
+ * one: the single-GPU test) -- from dev_in[k] (the band's rows of the input, resident on that device) into
+ * dev_out[k].  One host thread per band inside the call; halo rows and the wavelets' partial sums travel as peer
+ * copies between the devices (xGMI), the 8-byte clipped count through the host.  Returns when every band's rows are
+ * written (streams drained).  The assembled rows are bit-identical to dt_hip_pipe_process() on the whole frame. */
+int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n_bands, const dt_hip_band_t *bands,
+                              const dt_hip_mem_t *dev_in, const dt_hip_mem_t *dev_out);
 
 /* layout self-check for language bindings: sizeof() of the struct named `name` as compiled */
 size_t dt_hip_abi_sizeof(const char *name);

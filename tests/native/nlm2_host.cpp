@@ -38,6 +38,7 @@ struct Args
   int skip_blend;
   int reach;
   int cy0, out_row0, out_row1;
+  int variant;
 };
 
 struct HostEnv
@@ -65,7 +66,8 @@ int scatter(const float scale, const float scattering, const int i1, const int i
   return (int)(scale * ((a1 * a1 * a1 + 7.0 * a1 * sqrt((double)a2)) * sgn(i1) * scattering / 6.0 + i1));
 }
 
-template <int P> void run(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats)
+template <int P, int WP, int TP, bool DEEP>
+void run(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats)
 {
   std::vector<float> lds(lds_floats + 4096, 0.0f);
   std::barrier<> bar(NL2_THREADS);
@@ -76,7 +78,7 @@ template <int P> void run(const F4 *in, F4 *out, const Args &a, const I2 *patche
       for(int b = 0; b < nchunks; b++)
       {
         HostEnv env{ t, b, lds.data(), &bar };
-        nlm2::body<P>(env, in, out, a, patches);
+        nlm2::body<P, WP, TP, DEEP>(env, in, out, a, patches);
         bar.arrive_and_wait(); // the next chunk reuses the LDS block
       }
     });
@@ -92,6 +94,7 @@ extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_
                              int search_radius, float scale, float scattering, float sharpness, const float *norm,
                              float luma, float chroma, int *interior_chunks)
 {
+  const char *const var_env = getenv("ANSEL_NLM2_VARIANT");
   std::vector<I2> patches;
   int max_shift = 0;
   for(int ri = -search_radius; ri <= search_radius; ri++)
@@ -120,13 +123,21 @@ extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_
   a.cy0 = 0;
   a.out_row0 = 0;
   a.out_row1 = H;
+  a.variant = var_env ? atoi(var_env) : 0;
   const int S = 2 * patch_radius + 1, ncol = chk_w + 2 * patch_radius;
   if(patch_radius < 1 || patch_radius > 3) return -1;
-  if(chk_w + 2 * a.reach > NL2_WP || chk_h > NL2_SERIAL / 2 || chk_w + S > NL2_TP || chk_w * chk_h > NL2_PAR * NL2_PX) return -2;
+  // the same choices as nlmeans_core_launch(): the tight layout when the chunk fits it, four tables when they fit LDS
+  // (ANSEL_NLM2_LAYOUT = loose / ANSEL_NLM2_DEEP = 0 force the other paths for the tests)
+  const char *const force_layout = getenv("ANSEL_NLM2_LAYOUT"), *const force_deep = getenv("ANSEL_NLM2_DEEP");
+  const bool tight = chk_w + 2 * a.reach <= NL2_WP_TIGHT && ncol + 1 <= NL2_TP_TIGHT && !(force_layout && !strcmp(force_layout, "loose"));
+  const int WP = tight ? NL2_WP_TIGHT : NL2_WP_LOOSE, TP = tight ? NL2_TP_TIGHT : NL2_TP_LOOSE;
+  if(chk_w + 2 * a.reach > WP || chk_h > NL2_SERIAL / 2 || ncol + 1 > TP || chk_w * chk_h > NL2_PAR * NL2_PX || a.npatch > 4096) return -2;
   if(ncol * S > NL2_PAR) return -3;
   const int nseg = NL2_PAR / (ncol * S), m0 = (chk_h - 2) / S + 1;
   if((m0 + nseg - 1) / nseg > NL2_MSEG) return -4;
-  const size_t lds_floats = (size_t)2 * chk_h * NL2_TP + 16 * NL2_TP + 64 + (size_t)(chk_h + 2 * a.reach) * 3 * NL2_WP;
+  const bool deep = nlm2::lds_floats(4, chk_h, a.reach, a.npatch, WP, TP) * sizeof(float) <= 160 * 1024 && chk_h <= 64
+                    && !(force_deep && !strcmp(force_deep, "0"));
+  const size_t lds_floats = nlm2::lds_floats(deep ? 4 : 2, chk_h, a.reach, a.npatch, WP, TP);
   if(lds_floats * sizeof(float) > 160 * 1024) return -5;
   int interior = 0;
   for(int cy = 0; cy < nchy; cy++)
@@ -139,8 +150,19 @@ extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_
     }
   if(interior_chunks) *interior_chunks = interior;
   const int nchunks = a.nchx * nchy;
-  if(patch_radius == 1) run<1>((const F4 *)in, (F4 *)out, a, patches.data(), nchunks, lds_floats);
-  else if(patch_radius == 2) run<2>((const F4 *)in, (F4 *)out, a, patches.data(), nchunks, lds_floats);
-  else run<3>((const F4 *)in, (F4 *)out, a, patches.data(), nchunks, lds_floats);
-  return 0;
+  const F4 *const fin = (const F4 *)in;
+  F4 *const fout = (F4 *)out;
+#define RUN(P_)                                                                                                      \
+  do                                                                                                                 \
+  {                                                                                                                  \
+    if(tight && deep) run<P_, NL2_WP_TIGHT, NL2_TP_TIGHT, true>(fin, fout, a, patches.data(), nchunks, lds_floats);   \
+    else if(tight) run<P_, NL2_WP_TIGHT, NL2_TP_TIGHT, false>(fin, fout, a, patches.data(), nchunks, lds_floats);     \
+    else if(deep) run<P_, NL2_WP_LOOSE, NL2_TP_LOOSE, true>(fin, fout, a, patches.data(), nchunks, lds_floats);       \
+    else run<P_, NL2_WP_LOOSE, NL2_TP_LOOSE, false>(fin, fout, a, patches.data(), nchunks, lds_floats);               \
+  } while(0)
+  if(patch_radius == 1) RUN(1);
+  else if(patch_radius == 2) RUN(2);
+  else RUN(3);
+#undef RUN
+  return (tight ? 1 : 0) | (deep ? 2 : 0); /* which path ran */
 }

@@ -58,3 +58,16 @@ def test_c_example_exports_the_same_bytes():
     got = dout.to_numpy((h, w, 4), np.uint16)
     p.close()
     assert "%016x" % _fnv1a(got) == fields["fnv1a"]
+
+
+@pytest.mark.parametrize("bands", [2, 5])
+def test_c_example_in_row_bands_exports_the_same_bytes(bands):
+    """examples/export_pipe W H N: the frame cut into N row bands walked by dt_hip_pipe_process_bands() from plain C"""
+    exe = os.path.join(ROOT, "examples", "export_pipe")
+    w, h = 400, 900
+    whole = subprocess.run([exe, str(w), str(h)], capture_output=True, text=True, timeout=120)
+    split = subprocess.run([exe, str(w), str(h), str(bands)], capture_output=True, text=True, timeout=120)
+    assert whole.returncode == 0 and split.returncode == 0, whole.stderr + split.stderr
+    f0 = dict(f.split("=") for f in whole.stdout.split() if "=" in f)
+    f1 = dict(f.split("=") for f in split.stdout.split() if "=" in f)
+    assert f1["bands"] == str(bands) and f0["fnv1a"] == f1["fnv1a"]

@@ -85,3 +85,65 @@ def test_modules_that_move_pixels_are_refused():
     rc = l.dt_hip_default_process_tiling_ptp(0, b"exposure", C.byref(piece), C.cast(C.byref(d), C.c_void_p), C.sizeof(d), C.byref(t),
                                              buf.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), 16, 16, 0)
     assert rc == abi.DT_HIP_INVALID_ARG and b"roi_in != roi_out" in l.dt_hip_last_error()
+
+
+# ---- roi_in != roi_out: _default_process_tiling_cl_roi() (src/develop/tiling.c:1076-1390), finalscale ----------------
+@pytest.mark.parametrize("interp", [0, 2])
+@pytest.mark.parametrize("iw,ih,scale,frac", [(1500, 1000, 0.5, 0.3), (1201, 803, 0.37, 0.15), (900, 1300, 0.25, 0.2),
+                                              (800, 600, 0.61, 4.0)])
+def test_roi_host_tiling_of_finalscale_equals_the_oracle_over_the_same_tiles(iw, ih, scale, frac, interp):
+    """every tile is resampled as an image of its own, like the reference's tiles (finalscale ignores the region
+    origins): the checker is the oracle run on each tile's input region, its good part pasted into the frame"""
+    import tile_plan_roi as tr
+    l = hc.hip()
+    o = ck.oracle()
+    roi_out = tr.R(0, 0, int(iw * scale + 0.5), int(ih * scale + 0.5), scale)
+    roi_in = tr.modify_roi_in(roi_out)
+    roi_in.width, roi_in.height = min(roi_in.width, iw), min(roi_in.height, ih)
+    iw, ih = roi_in.width, roi_in.height
+    ow, oh = roi_out.width, roi_out.height
+    img = synth.rgba_image(iw, ih, seed=33, lo=-0.05, hi=1.3)
+    img[..., 3] = 0.25
+    piece = abi.Piece.make(ow, oh, roi_in=abi.Roi.make(0, 0, iw, ih, 1.0), roi_out=abi.Roi.make(0, 0, ow, oh, scale))
+    d = abi.FinalscaleData(interp)
+    t = abi.Tiling()
+    l.dt_hip_default_tiling(C.byref(piece), 0, C.byref(t))
+    t.overlap = 4
+    avail = int(iw * ih * 16 * max(t.factor_cl, 1.0) * frac)
+    out = np.zeros((oh, ow, 4), np.float32)
+    rc = l.dt_hip_default_process_tiling_roi(0, b"finalscale", C.byref(piece), C.cast(C.byref(d), C.c_void_p), C.sizeof(d),
+                                             C.byref(t), img.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 16, 16, avail)
+    lib.check(rc, "dt_hip_default_process_tiling_roi")
+    p = tr.plan(roi_in, roi_out, 16, 16, t, 0, avail, l.dt_hip_get_device_memalloc(0), 1 << 30, 1 << 30)
+    if frac < 1.0:
+        assert p["tiles_x"] * p["tiles_y"] > 1
+    want = np.zeros_like(out)
+    for tx in range(p["tiles_x"]):
+        for ty in range(p["tiles_y"]):
+            rois = tr.tile_rois(p, roi_in, roi_out, tx, ty)
+            if rois is None:
+                continue
+            a, b, g = rois
+            tp_ = abi.Piece.make(b.width, b.height, roi_in=abi.Roi.make(*a.tup()), roi_out=abi.Roi.make(*b.tup()))
+            tile_in = np.ascontiguousarray(img[a.y:a.y + a.height, a.x:a.x + a.width])
+            tile_out = np.zeros((b.height, b.width, 4), np.float32)
+            assert ck.call(o, "oracle_finalscale", tp_, d, tile_in, tile_out) == 0
+            want[g.y:g.y + g.height, g.x:g.x + g.width] = tile_out[g.y - b.y:g.y - b.y + g.height, g.x - b.x:g.x - b.x + g.width]
+    assert int((ck.ulp_diff(out, want) > 0).sum()) == 0
+    # one tile = the untiled module
+    if p["tiles_x"] * p["tiles_y"] == 1:
+        whole = np.zeros_like(out)
+        assert ck.call(o, "oracle_finalscale", piece, d, img, whole) == 0
+        assert np.array_equal(out, whole)
+
+
+def test_roi_host_tiling_refuses_other_modules():
+    l = hc.hip()
+    piece = abi.Piece.make(64, 64)
+    d = abi.ExposureData(0.0, 1.0)
+    t = abi.Tiling()
+    l.dt_hip_default_tiling(C.byref(piece), 0, C.byref(t))
+    buf = np.zeros((64, 64, 4), np.float32)
+    rc = l.dt_hip_default_process_tiling_roi(0, b"exposure", C.byref(piece), C.cast(C.byref(d), C.c_void_p), C.sizeof(d), C.byref(t),
+                                             buf.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), 16, 16, 0)
+    assert rc == abi.DT_HIP_INVALID_ARG and b"modify_roi_in" in l.dt_hip_last_error()

@@ -270,3 +270,69 @@ def test_modules_without_a_band_mode_are_refused():
     with pytest.raises(lib.AnselHipError, match="bilat"):
         engine.begin(bands[0], d_in.data_ptr(), w)
     p.close()
+
+
+# ---- the walk driven from inside the library: dt_hip_pipe_process_bands() (one C process, a host thread per band) ----
+def _c_driver(torch, nodes, raw, w, h, n):
+    import ctypes as C
+    from ansel_amd import abi
+    l = lib.load()
+    pipes = [pipe.DevicePipe(0, nodes, fusion=True) for _ in range(n)]  # every band on the one device of the test box
+    bands = tiled.plan_bands(w, h, n, tiled.pipe_demosaic_method(nodes))
+    ins = [torch.from_numpy(np.ascontiguousarray(raw[b.row0:b.row0 + b.rows]).view(np.int16)).to("cuda:0") for b in bands]
+    outs = [torch.zeros((b.rows, w, 4), dtype=torch.int16, device="cuda:0") for b in bands]
+    torch.cuda.synchronize()
+    rc = l.dt_hip_pipe_process_bands((C.c_void_p * n)(*[p.handle for p in pipes]), n, (abi.Band * n)(*bands),
+                                     (C.c_void_p * n)(*[t.data_ptr() for t in ins]),
+                                     (C.c_void_p * n)(*[t.data_ptr() for t in outs]))
+    lib.check(rc, "dt_hip_pipe_process_bands")
+    for p in pipes:
+        p.close()
+    return np.concatenate([t.cpu().numpy().view(np.uint16) for t in outs], axis=0)
+
+
+@pytest.mark.parametrize("w,h,n", [(1504, 1000, 2), (1504, 1000, 5), (402, 640, 3), (752, 2000, 8)])
+def test_c_driver_light_pipe_equals_the_unsplit_frame(w, h, n):
+    torch, lut, d_lut = _setup()
+    nodes = _nodes(w, h, d_lut, lut)
+    raw = synth.bayer_mosaic(w, h, seed=5)
+    assert np.array_equal(_c_driver(torch, nodes, raw, w, h, n), _whole(torch, nodes, raw, w, h, True))
+
+
+@pytest.mark.parametrize("n_top,n_bottom", [(10, 10), (0, 3), (13, 12)])
+def test_c_driver_decides_the_highlights_bypass_on_the_whole_frame(n_top, n_bottom):
+    torch, lut, d_lut = _setup()
+    w, h = 512, 600
+    nodes = _nodes(w, h, d_lut, lut)
+    raw = be.test_frame(w, h, n_top, n_bottom)
+    assert np.array_equal(_c_driver(torch, nodes, raw, w, h, 3), _whole(torch, nodes, raw, w, h, True))
+
+
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "nlmeans", "blended", "all"])
+@pytest.mark.parametrize("w,h,n", [(752, 2000, 5), (400, 640, 2)])
+def test_c_driver_full_pipe_equals_the_unsplit_frame(w, h, n, which):
+    """halo pulls between the bands' buffers and the all-gather of the wavelets' partial sums, done by the library"""
+    torch, lut, d_lut = _setup()
+    nodes = _full_nodes(w, h, d_lut, lut, which)
+    raw = synth.bayer_mosaic(w, h, seed=7)
+    assert np.array_equal(_c_driver(torch, nodes, raw, w, h, n), _whole(torch, nodes, raw, w, h, True))
+
+
+def test_c_driver_reports_the_band_that_failed():
+    torch, lut, d_lut = _setup()
+    w, h = 400, 640
+    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
+                                    filmic=filmic.default_data(), with_nlmeans=True, with_bilat=True)  # bilat: no band mode
+    raw = synth.bayer_mosaic(w, h, seed=7)
+    with pytest.raises(lib.AnselHipError, match="bilat"):
+        _c_driver(torch, nodes, raw, w, h, 2)
+    # and the pool is back where it was
+    import ctypes as C
+    cur, peak = C.c_size_t(0), C.c_size_t(0)
+    l = lib.load()
+    l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
+    before = cur.value
+    with pytest.raises(lib.AnselHipError):
+        _c_driver(torch, nodes, raw, w, h, 2)
+    l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
+    assert cur.value == before

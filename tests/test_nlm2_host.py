@@ -70,7 +70,7 @@ def test_interior_chunk_kernel_on_the_host_equals_the_oracle(host_kernel, oracle
     seen = C.c_int(0)
     rc = host_kernel.nlm2_host_run(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(scat),
                                    C.c_float(p.sharpness), p.norm, C.c_float(luma), C.c_float(chroma), C.byref(seen))
-    assert rc == 0 and seen.value == n_interior
+    assert rc >= 0 and seen.value == n_interior  # rc: bit 0 = the tight layout ran, bit 1 = the four-table schedule
     written = ~np.isnan(got[..., 0])
     assert int(written.sum()) == n_interior * cw * ch  # interior chunks only, each pixel of them
     assert np.array_equal(got[written].view(np.uint32), want[written].view(np.uint32))

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Timing experiment for nlm_chunks_v2 (run on the GPU box): denoise (non-local means) on one Lab frame under each
+A/B switch of ansel_amd/csrc/nlm2_body.h (ANSEL_NLM2_VARIANT: 4-byte forms of the recurrences, steps switched off).
+Variants with a step switched off compute garbage: this only measures where the time goes.
+
+    python tools/nlm_variants.py [WxH] > gpurun_out/nlm_variants.json
+
+Default frame 11648 x 2184: the 100 MP frame's width and chunk grid (72 x 56 chunks, which fit the four-table schedule)
+at a quarter of its height."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from ansel_amd import abi, lib  # noqa: E402
+
+
+def main():
+    w, h = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "11648x2184").split("x"))
+    l = lib.init()
+    rng = np.random.default_rng(1)
+    img = rng.random((h, w, 4), dtype=np.float32) * np.float32(100.0)
+    din = lib.DeviceBuffer.from_numpy(0, img)
+    dout = lib.DeviceBuffer(0, img.nbytes)
+    piece = abi.Piece.make(w, h)
+    d = abi.NlmeansData(2.0, 50.0, 0.5, 1.0)
+    # (label, environment) -- ANSEL_NLM2_VARIANT bits: 16 no A1, 32 no A2, 64 no B, 128 no C, 256 no first row
+    names = {"v1 (nlm_chunks_pipelined)": {"ANSEL_HIP_NLM_V1": "1"},
+             "v2 shipped": {},
+             "v2 two tables": {"ANSEL_NLM2_DEEP": "0"},
+             "v2 loose layout": {"ANSEL_NLM2_LAYOUT": "loose"},
+             "no A1": {"ANSEL_NLM2_VARIANT": "16"}, "no A2": {"ANSEL_NLM2_VARIANT": "32"},
+             "no B": {"ANSEL_NLM2_VARIANT": "64"}, "no C": {"ANSEL_NLM2_VARIANT": "128"},
+             "no A2, no B": {"ANSEL_NLM2_VARIANT": "96"}, "no A1, no C": {"ANSEL_NLM2_VARIANT": "144"},
+             "only barriers": {"ANSEL_NLM2_VARIANT": str(16 + 32 + 64 + 128 + 256)},
+             "two tables, no A2, no B": {"ANSEL_NLM2_DEEP": "0", "ANSEL_NLM2_VARIANT": "96"},
+             "two tables, no A1, no C": {"ANSEL_NLM2_DEEP": "0", "ANSEL_NLM2_VARIANT": "144"}}
+    out = {"frame": [w, h], "variants": {}}
+    for name, env in names.items():
+        for k in ("ANSEL_HIP_NLM_V1", "ANSEL_NLM2_VARIANT", "ANSEL_NLM2_DEEP", "ANSEL_NLM2_LAYOUT"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        times = []
+        for rep in range(4):
+            l.dt_hip_finish(0)
+            t0 = time.perf_counter()
+            lib.check(l.dt_hip_iop_nlmeans_process(0, C.byref(piece), C.byref(d), din.ptr, dout.ptr), "nlmeans")
+            l.dt_hip_finish(0)
+            times.append((time.perf_counter() - t0) * 1e3)
+        out["variants"][name] = {"env": env, "ms": round(min(times[1:]), 3)}
+        print("%-28s %8.3f ms" % (name, min(times[1:])), file=sys.stderr, flush=True)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
