@@ -65,12 +65,15 @@ inline size_t lds_floats(const int ntab, const int chk_h, const int reach, const
   return (size_t)ntab * chk_h * TP + 16 * TP + ((npatch + 3) & ~3) + (size_t)(chk_h + 2 * reach) * 3 * WP;
 }
 
-// dt_fast_mexp2f(), src/math/math.h:290-301; the float -> int conversion as the reference's target does it
-// (cvttss2si: out of range and NaN -> INT_MIN)
+// dt_fast_mexp2f(), src/math/math.h:290-301.  The reference's target converts float -> int with cvttss2si: out of
+// range and NaN give INT_MIN.  Env::cvt_i32_sat() is the device's v_cvt_i32_f32 (saturating, NaN -> 0).  Saturation
+// and cvttss2si only differ above 2^31 (INT_MAX against INT_MIN), where both sums 0x3f800000 + cv wrap to a negative
+// k0 and the result is 0 either way; so only NaN needs a correction -- one compare instead of two and an AND.
 template <class Env> NLM2_FN float mexp2(const float x)
 {
   const float v = x * -8388608.0f;
-  const int cv = (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+  const int cs = Env::cvt_i32_sat(v);
+  const int cv = (v != v) ? (int)0x80000000 : cs;
   const int k0 = (int)(0x3f800000u + (unsigned)cv);
   return Env::int_as_float(k0 >= 0x800000 ? k0 : 0);
 }

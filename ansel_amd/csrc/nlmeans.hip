@@ -56,7 +56,6 @@ struct nlm_args
   // row bands (hip_common.h band_view_t): the launch covers chunk rows cy0.. of the FRAME's grid and
   // stores frame rows [out_row0, out_row1) only; `in` / `out` are addressed with frame row indices
   int cy0, out_row0, out_row1;
-  int skip_interior; // nlm_chunks_pipelined: leave the interior chunks to nlm_chunks_v2
   int variant;       // nlm_chunks_v2: 0, or the A/B switches of nlm2_body.h (ANSEL_NLM2_VARIANT; timing experiments)
 };
 
@@ -375,20 +374,18 @@ __device__ __forceinline__ nlm_geom geom_of(const int2 sh, const int top, const 
   return g;
 }
 
-__global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                                    const nlm_args a, const int2 *__restrict__ patches)
+// `chunk`: the workgroup's chunk in the launch's grid, `lds` its dynamic LDS (the body is shared by nlm_chunks_pipelined
+// and by the border workgroups of nlm_chunks_v2)
+__device__ __forceinline__ void pipelined_body(const int chunk, float *const lds, const float4 *__restrict__ in,
+                                               float4 *__restrict__ out, const nlm_args &a, const int2 *__restrict__ patches)
 {
-  extern __shared__ float lds[];
   const int tid = threadIdx.x;
-  const int cy_launch = blockIdx.x / a.nchx, cx = blockIdx.x - cy_launch * a.nchx;
+  const int cy_launch = chunk / a.nchx, cx = chunk - cy_launch * a.nchx;
   const int cy = cy_launch + a.cy0;
   const int top = cy * a.chk_h, left = cx * a.chk_w;
   const int bot = imin(top + a.chk_h, a.H), right = imin(left + a.chk_w, a.W);
   const int ch = bot - top, cw = right - left;
   const int P = a.radius, W = a.W, H = a.H;
-  if(a.skip_interior && top >= a.reach && bot + a.reach <= H && left >= a.reach && right + a.reach <= W && ch == a.chk_h
-     && cw == a.chk_w)
-    return; // nlm_chunks_v2's (uniform over the workgroup)
   const int csw = a.chk_w + 2 * P + 1; // table columns: frame columns left - P - 1 .. left + chk_w + P - 1
   const int cs0 = left - P - 1;
   constexpr int pitch = NLP_TP;
@@ -776,29 +773,55 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4
   }
 }
 
+__global__ __launch_bounds__(NLM_THREADS) void nlm_chunks_pipelined(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                                    const nlm_args a, const int2 *__restrict__ patches)
+{
+  extern __shared__ float lds[];
+  pipelined_body(blockIdx.x, lds, in, out, a, patches);
+}
+
 // ---- the interior-chunk kernel: nlm2_body.h (also compiled for the host: tests/native/nlm2_host.cpp) -------------
 struct nlm2_device_env
 {
   float *lds_;
+  int chunk_;
   __device__ __forceinline__ int tid() const { return threadIdx.x; }
-  __device__ __forceinline__ int bid() const { return blockIdx.x; }
+  __device__ __forceinline__ int bid() const { return chunk_; }
   __device__ __forceinline__ float *lds() const { return lds_; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ void prio_high() const { __builtin_amdgcn_s_setprio(3); }
   static __device__ __forceinline__ float int_as_float(const int v) { return __int_as_float(v); }
+  static __device__ __forceinline__ int cvt_i32_sat(const float v)
+  {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v)); // the instruction's own semantics, not C's (undefined out of range)
+    return r;
+  }
 };
 
 template <int P, int WP, int TP, bool DEEP>
 __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2(const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                             const nlm_args a, const int2 *__restrict__ patches)
+                                                             const nlm_args a, const int2 *__restrict__ patches,
+                                                             const int *__restrict__ order, const int n_border)
 {
+  // ONE launch for the whole grid: `order` lists the chunks whose patches can leave the frame first -- they take the
+  // pipelined kernel's body with all its per-offset geometry and are the slower ones, so they start first and the
+  // interior chunks fill the machine behind them (as a launch of their own the ~2.5 % border chunks of a 100 MP frame
+  // cost three rounds of 256 CUs at the end: 2.6 of 46.6 ms)
   extern __shared__ float lds[];
+  const int chunk = order[blockIdx.x];
+  if(blockIdx.x < n_border)
+  {
+    pipelined_body(chunk, lds, in, out, a, patches);
+    return;
+  }
   nlm2_device_env env;
   env.lds_ = lds;
+  env.chunk_ = chunk;
   nlm2::body<P, WP, TP, DEEP>(env, in, out, a, patches);
 }
 
-typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *);
+typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
 template <int P> nlm2_kernel_t nlm2_kernel_of(const bool tight, const bool deep)
 {
   if(tight) return deep ? nlm_chunks_v2<P, NL2_WP_TIGHT, NL2_TP_TIGHT, true> : nlm_chunks_v2<P, NL2_WP_TIGHT, NL2_TP_TIGHT, false>;
@@ -931,21 +954,13 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   const bool staged = table_bytes + window_bytes <= 160 * 1024;
   const size_t lds_bytes = pipelined ? pipe_bytes : table_bytes + (staged ? window_bytes : 0);
   hipStream_t s = stream_of(devid);
-  int2 *dev_patches = (int2 *)dt_hip_alloc_device_buffer(devid, patches.size() * sizeof(int2));
-  if(!dev_patches) return DT_HIP_SYSMEM_ALLOCATION;
-  if(hipMemcpyAsync(dev_patches, patches.data(), patches.size() * sizeof(int2), hipMemcpyHostToDevice, s) != hipSuccess
-     || hipStreamSynchronize(s) != hipSuccess) // `patches` is a stack-lifetime host buffer
-  {
-    dt_hip_release_mem_object(dev_patches);
-    return DT_HIP_DEFAULT_ERROR;
-  }
   const void *const fn = pipelined ? (const void *)nlm_chunks_pipelined
                                    : (staged ? (const void *)nlm_chunks<true> : (const void *)nlm_chunks<false>);
   if(lds_bytes > 64 * 1024)
     ANSEL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  // interior chunks (all but the outermost ring: 97.5 % of a 100 MP frame) go to nlm_chunks_v2 when the
+  // interior chunks (all but the outermost ring: 97.5 % of a 100 MP frame) take nlm_chunks_v2's body when the
   // configuration is one it is built for: the weight without the centre-pixel term (denoise (non-local means)),
-  // patch radius 1..3, and the same LDS budget as the pipelined kernel
+  // patch radius 1..3
   const int S2 = 2 * a.radius + 1, ncol2 = a.chk_w + 2 * a.radius;
   // layout: the tight pitches when the chunk fits them; schedule: four tables (one barrier per offset) when they fit
   // LDS beside the window, else two (nlm2_body.h)
@@ -953,7 +968,8 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   const int WP2 = tight ? NL2_WP_TIGHT : NL2_WP_LOOSE, TP2 = tight ? NL2_TP_TIGHT : NL2_TP_LOOSE;
   const bool deep = nlm2::lds_floats(4, a.chk_h, a.reach, a.npatch, WP2, TP2) * sizeof(float) <= 160 * 1024 && a.chk_h <= 64
                     && getenv("ANSEL_NLM2_DEEP") == nullptr;
-  const size_t v2_bytes = nlm2::lds_floats(deep ? 4 : 2, a.chk_h, a.reach, a.npatch, WP2, TP2) * sizeof(float);
+  // the border workgroups of the same launch run the pipelined body: the launch's LDS is the larger of the two
+  const size_t v2_bytes = std::max(nlm2::lds_floats(deep ? 4 : 2, a.chk_h, a.reach, a.npatch, WP2, TP2) * sizeof(float), pipe_bytes);
   bool v2 = pipelined && p.center_weight < 0 && a.radius >= 1 && a.radius <= 3 && ncol2 * S2 <= NL2_PAR
             && a.chk_w * a.chk_h <= NL2_PAR * NL2_PX && a.chk_w + 2 * a.reach <= WP2 && ncol2 + 1 <= TP2 && a.npatch <= 4096
             && a.chk_h <= NL2_SERIAL / 2 && v2_bytes <= 160 * 1024 && getenv("ANSEL_HIP_NLM_V1") == nullptr;
@@ -964,24 +980,52 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   }
   static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS, "nlm_chunks_v2 shares the launch shape of nlm_chunks_pipelined");
   nlm2_kernel_t k2 = nullptr;
+  const int nchunks = a.nchx * nchy;
+  // the launch order of the chunks: those a patch can leave the frame from (the pipelined body) first
+  std::vector<int> order;
+  int n_border = 0;
   if(v2)
   {
     k2 = a.radius == 1 ? nlm2_kernel_of<1>(tight, deep) : (a.radius == 2 ? nlm2_kernel_of<2>(tight, deep) : nlm2_kernel_of<3>(tight, deep));
     if(v2_bytes > 64 * 1024)
       ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_bytes));
-    a.skip_interior = 1;
     const char *const var_env = getenv("ANSEL_NLM2_VARIANT");
     a.variant = var_env ? atoi(var_env) : 0;
+    order.resize(nchunks);
+    std::vector<int> inner;
+    inner.reserve(nchunks);
+    for(int c = 0; c < nchunks; c++)
+    {
+      const int cyl = c / a.nchx, cx = c - cyl * a.nchx, cy = cyl + a.cy0;
+      const int top = cy * a.chk_h, left = cx * a.chk_w;
+      const int bot = std::min(top + a.chk_h, a.H), right = std::min(left + a.chk_w, a.W);
+      const bool interior = top >= a.reach && bot + a.reach <= a.H && left >= a.reach && right + a.reach <= a.W
+                            && bot - top == a.chk_h && right - left == a.chk_w; // the test of nlm2::body()
+      if(interior) inner.push_back(c);
+      else order[n_border++] = c;
+    }
+    std::copy(inner.begin(), inner.end(), order.begin() + n_border);
   }
+  // one upload: the patch shifts, then the chunk order
+  const size_t patch_bytes = patches.size() * sizeof(int2), order_bytes = order.size() * sizeof(int);
+  std::vector<unsigned char> host_blob(patch_bytes + order_bytes);
+  memcpy(host_blob.data(), patches.data(), patch_bytes);
+  if(order_bytes) memcpy(host_blob.data() + patch_bytes, order.data(), order_bytes);
+  int2 *dev_patches = (int2 *)dt_hip_alloc_device_buffer(devid, host_blob.size());
+  if(!dev_patches) return DT_HIP_SYSMEM_ALLOCATION;
+  if(hipMemcpyAsync(dev_patches, host_blob.data(), host_blob.size(), hipMemcpyHostToDevice, s) != hipSuccess
+     || hipStreamSynchronize(s) != hipSuccess) // `host_blob` is a stack-lifetime host buffer
+  {
+    dt_hip_release_mem_object(dev_patches);
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  const int *const dev_order = (const int *)((const unsigned char *)dev_patches + patch_bytes);
   {
     launch_scope ls(devid, "nlm_chunks");
-    const unsigned grid = (unsigned)(a.nchx * nchy);
+    const unsigned grid = (unsigned)nchunks;
     if(v2)
-    {
-      // both launches walk the whole chunk grid; a workgroup whose chunk belongs to the other kernel exits at once
-      k2<<<grid, NL2_THREADS, v2_bytes, s>>>(in, out, a, dev_patches);
-    }
-    if(pipelined)
+      k2<<<grid, NL2_THREADS, v2_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border);
+    else if(pipelined)
       nlm_chunks_pipelined<<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
     else if(staged)
       nlm_chunks<true><<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);

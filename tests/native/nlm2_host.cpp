@@ -51,6 +51,14 @@ struct HostEnv
   float *lds() const { return lds_; }
   void sync() const { bar_->arrive_and_wait(); }
   void prio_high() const {}
+  // v_cvt_i32_f32: truncation, saturating, NaN -> 0
+  static int cvt_i32_sat(const float v)
+  {
+    if(v != v) return 0;
+    if(v >= 2147483648.0f) return 0x7fffffff;
+    if(v <= -2147483648.0f) return (int)0x80000000;
+    return (int)v;
+  }
   static float int_as_float(const int v)
   {
     float f;
