@@ -596,6 +596,68 @@ int dt_hip_read_host_from_device(int devid, void *host, dt_hip_mem_t device, int
   return dt_hip_read_host_from_device_rowpitch(devid, host, device, width, height, bpp, (size_t)width * bpp, 1);
 }
 
+// dt_opencl_read_host_from_device_raw / write_host_to_device_raw (opencl.h:489-506): a window {origin, region} of a
+// 2-D device image against host memory with its own row pitch -- what the host tilers move per tile (tiling.c:1018,
+// 1345).  The image's width and pixel size are the ones dt_hip_alloc_device() recorded.
+static int raw_window(int devid, dt_hip_mem_t device, const size_t *origin, const size_t *region, size_t &wbytes, size_t &dpitch,
+                      size_t &doffs)
+{
+  if(!valid_device(devid) || !device || !origin || !region) return DT_HIP_INVALID_ARG;
+  const alloc_t a = alloc_of(device);
+  if(a.width <= 0 || a.bpp <= 0)
+  {
+    set_last_error("window copy: the device object is not a 2-D image of this runtime (dt_hip_alloc_device)");
+    return DT_HIP_INVALID_ARG;
+  }
+  if(origin[0] + region[0] > (size_t)a.width || origin[1] + region[1] > (size_t)a.height) return DT_HIP_INVALID_ARG;
+  wbytes = region[0] * a.bpp;
+  dpitch = (size_t)a.width * a.bpp;
+  doffs = origin[1] * dpitch + origin[0] * a.bpp;
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_read_host_from_device_raw(int devid, void *host, dt_hip_mem_t device, const size_t *origin, const size_t *region,
+                                     int rowpitch, int blocking)
+{
+  size_t wbytes, dpitch, doffs;
+  const int rc = raw_window(devid, device, origin, region, wbytes, dpitch, doffs);
+  if(rc != DT_HIP_SUCCESS || !host) return rc != DT_HIP_SUCCESS ? rc : DT_HIP_INVALID_ARG;
+  if(!wbytes || !region[1]) return DT_HIP_SUCCESS;
+  hipStream_t s = stream_of(devid);
+  launch_scope ls(devid, "[Read Image (from device to host)]");
+  ANSEL_HIP_CHECK(hipMemcpy2DAsync(host, rowpitch ? (size_t)rowpitch : wbytes, (const char *)device + doffs, dpitch, wbytes,
+                                   region[1], hipMemcpyDeviceToHost, s));
+  if(blocking) ANSEL_HIP_CHECK(hipStreamSynchronize(s));
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_write_host_to_device_raw(int devid, const void *host, dt_hip_mem_t device, const size_t *origin, const size_t *region,
+                                    int rowpitch, int blocking)
+{
+  size_t wbytes, dpitch, doffs;
+  const int rc = raw_window(devid, device, origin, region, wbytes, dpitch, doffs);
+  if(rc != DT_HIP_SUCCESS || !host) return rc != DT_HIP_SUCCESS ? rc : DT_HIP_INVALID_ARG;
+  if(!wbytes || !region[1]) return DT_HIP_SUCCESS;
+  hipStream_t s = stream_of(devid);
+  launch_scope ls(devid, "[Write Image (from host to device)]");
+  ANSEL_HIP_CHECK(hipMemcpy2DAsync((char *)device + doffs, dpitch, host, rowpitch ? (size_t)rowpitch : wbytes, wbytes, region[1],
+                                   hipMemcpyHostToDevice, s));
+  // a pageable source is staged before the call returns, a pinned one is read when the copy runs
+  if(blocking || dt_hip_is_pinned_memory(host)) ANSEL_HIP_CHECK(hipStreamSynchronize(s));
+  return DT_HIP_SUCCESS;
+}
+
+// dt_opencl_enqueue_copy_image (opencl.h:516): a window between two 2-D images of equal pixel size
+int dt_hip_enqueue_copy_image(int devid, dt_hip_mem_t src, dt_hip_mem_t dst, const size_t *orig_src, const size_t *orig_dst,
+                              const size_t *region)
+{
+  if(!valid_device(devid) || !src || !dst || !orig_src || !orig_dst || !region) return DT_HIP_INVALID_ARG;
+  const alloc_t a = alloc_of(src), b = alloc_of(dst);
+  if(a.width <= 0 || b.width <= 0 || a.bpp != b.bpp) return DT_HIP_INVALID_ARG;
+  return dt_hip_enqueue_copy_region(devid, src, a.width, (int)orig_src[0], (int)orig_src[1], dst, b.width, (int)orig_dst[0],
+                                    (int)orig_dst[1], (int)region[0], (int)region[1], a.bpp);
+}
+
 void *dt_hip_alloc_host_pinned(size_t size)
 {
   void *p = NULL;

@@ -89,6 +89,9 @@ def load():
         "dt_hip_read_host_from_device": (i, [i, vp, vp, i, i, i]),
         "dt_hip_read_host_from_device_rowpitch": (i, [i, vp, vp, i, i, i, sz, i]),
         "dt_hip_enqueue_copy_buffer_to_buffer": (i, [i, vp, vp, sz, sz, sz]),
+        "dt_hip_read_host_from_device_raw": (i, [i, vp, vp, P(sz), P(sz), i, i]),
+        "dt_hip_write_host_to_device_raw": (i, [i, vp, vp, P(sz), P(sz), i, i]),
+        "dt_hip_enqueue_copy_image": (i, [i, vp, vp, P(sz), P(sz), P(sz)]),
         "dt_hip_enqueue_copy_region": (i, [i, vp, i, i, i, vp, i, i, i, i, i, i]),
         "dt_hip_finish": (i, [i]),
         "dt_hip_events_enable": (None, [i, i]),

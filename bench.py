@@ -254,22 +254,24 @@ def measured_traffic(tag, args):
 # SIMD every 2 cycles for full-rate binary32, 4 for binary64 and packed, 8 for the quarter-rate transcendental
 # unit (profiles/r02_valu_issue_cycles.json, measured by tools/valu_microbench; MI355X_MICROARCH.md "Per-instruction
 # cycle constants") -> the kernel's issue-cycle total from its instruction mix (profiles/r02_isa_mix.json,
-# tools/isa_mix.py) over 1024 SIMDs at 2.4 GHz is its floor.
+# tools/valu_model.py) over 1024 SIMDs at 2.4 GHz is its floor.
 KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu", "rcd_tiles": "valu+lds",
-                "nlm_chunks": "valu+lds", "diffuse_pde": "valu", "dn_decompose": "l2", "diffuse_decompose": "hbm",
+                "nlm_chunks": "valu+lds", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
                 "dn_synthesize": "hbm", "dn_precondition": "hbm", "dn_finish": "hbm", "rgb_to_lab": "hbm", "lab_to_rgb": "hbm"}
 
 
-def valu_floor_ms(tag, n_waves):
-    """issue-cycle floor of `tag` from the committed instruction-mix table; None when the table lacks it"""
+def valu_floor_ms(tag, mpix):
+    """VALU issue floor of `tag` on a frame of `mpix` megapixels from the COMMITTED instruction-mix table
+    (profiles/r02_isa_mix.json: rocprofv3 SQ counters of this bench priced with tools/valu_microbench's cycles per
+    instruction class, tools/valu_model.py); None when the table lacks the kernel"""
     try:
         mix = json.load(open(os.path.join(ROOT, "profiles", "r02_isa_mix.json")))
     except (OSError, ValueError):
         return None
-    k = mix.get("kernels", {}).get(tag)
-    if not k or "issue_cycles_per_wave" not in k:
+    k = mix.get("kernels", {}).get(tag) or mix.get("kernels", {}).get(tag.replace("_u16", ""))
+    if not k or "issue_floor_ms_per_mpix" not in k:
         return None
-    return k["issue_cycles_per_wave"] * n_waves / (1024 * 2.4e9) * 1e3
+    return k["issue_floor_ms_per_mpix"] * mpix
 
 
 def read_kernel_events(l, devid):
@@ -518,7 +520,7 @@ def main():
                 continue
             e = {"ms": round(v["ms_avg"], 4), "bound": KERNEL_BOUND.get(k, "hbm"),
                  "hbm_frac": round(tag_bpp[k] * my_rows * width / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            floor = valu_floor_ms(k, my_rows * width / 64.0)
+            floor = valu_floor_ms(k, my_rows * width / 1e6)
             if floor is not None:
                 e["valu_issue_floor_ms"] = round(floor, 4)
                 e["valu_frac"] = round(floor / v["ms_avg"], 4)

@@ -205,6 +205,15 @@ int dt_hip_write_host_to_device(int devid, const void *host, dt_hip_mem_t device
 int dt_hip_write_host_to_device_rowpitch(int devid, const void *host, dt_hip_mem_t device, int width, int height, int bpp, size_t rowpitch, int blocking);
 int dt_hip_read_host_from_device(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp);
 int dt_hip_read_host_from_device_rowpitch(int devid, void *host, dt_hip_mem_t device, int width, int height, int bpp, size_t rowpitch, int blocking);
+/* dt_opencl_read_host_from_device_raw / write_host_to_device_raw (opencl.h:489-506): the window {origin[2],
+ * region[2]} (pixels) of a 2-D image made by dt_hip_alloc_device() against host memory of `rowpitch` bytes per row
+ * (0: packed); dt_opencl_enqueue_copy_image (:516): a window between two such images.  What the host tilers move. */
+int dt_hip_read_host_from_device_raw(int devid, void *host, dt_hip_mem_t device, const size_t *origin, const size_t *region,
+                                     int rowpitch, int blocking);
+int dt_hip_write_host_to_device_raw(int devid, const void *host, dt_hip_mem_t device, const size_t *origin, const size_t *region,
+                                    int rowpitch, int blocking);
+int dt_hip_enqueue_copy_image(int devid, dt_hip_mem_t src, dt_hip_mem_t dst, const size_t *orig_src, const size_t *orig_dst,
+                              const size_t *region);
 /* dt_opencl_copy_host_to_device[_rowpitch|_constant] (opencl.h:508-514): allocate + upload, NULL on failure;
  * dt_opencl_copy_device_to_host (:473); dt_opencl_read_buffer_from_device / write_buffer_to_device (:533-537) */
 dt_hip_mem_t dt_hip_copy_host_to_device(int devid, void *host, int width, int height, int bpp);

@@ -1,0 +1,395 @@
+/* boundary_stubs.c -- TEST INFRASTRUCTURE (tests/test_boundary_compile.py).
+ *
+ * Linked with the reference's OWN src/develop/pixelpipe_gpu.c and src/develop/tiling.c (compiled from where they lie,
+ * unmodified, against include/ansel_opencl_peer.h) and with libansel_hip.so:
+ *   * the host-side services those two files call -- cache lines, logging, the CPU fallback's entry -- in the simplest
+ *     form that works for one module run (a cache line is a host buffer with at most one device payload);
+ *   * one module written the way INTEGRATION.md section 2 tells a maintainer to write it: `exposure`, whose process_cl()
+ *     is the four-line stub over dt_hip_iop_exposure_process(), with the module's own tiling_callback();
+ *   * two drivers the test calls: the reference's pixelpipe_process_on_GPU() on that module (device path, output synced
+ *     to the host cache line) and the reference's default_process_tiling_cl() on it (host-tiled path, the budget
+ *     squeezed so that the frame takes many tiles).
+ */
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common/opencl.h" /* = include/ansel_opencl_peer.h + boundary_host.h */
+#include "develop/pixelpipe_process.h"
+#include "develop/pixelpipe_cpu.h"
+#include "develop/pixelpipe_gpu.h"
+#include "develop/tiling.h"
+
+/* ---- logging ------------------------------------------------------------------------------------------------------ */
+static unsigned int g_debug = 0;
+static char g_last_message[512];
+void dt_print(dt_debug_thread_t thread, const char *msg, ...)
+{
+  if(!(g_debug & thread)) return;
+  va_list ap;
+  va_start(ap, msg);
+  vfprintf(stderr, msg, ap);
+  va_end(ap);
+}
+void dt_vprint(dt_debug_thread_t thread, const char *msg, ...)
+{
+  (void)thread;
+  (void)msg;
+}
+unsigned int dt_get_debug_flags(void) { return g_debug; }
+void dt_pipeline_message(const char *format, ...)
+{
+  va_list ap;
+  va_start(ap, format);
+  vsnprintf(g_last_message, sizeof(g_last_message), format, ap);
+  va_end(ap);
+}
+const char *boundary_last_message(void) { return g_last_message; }
+
+/* ---- host memory (src/caches/pixelpipe_cache_alloc.h, src/system/sys_resources.h) ---------------------------------- */
+void *dt_pixelpipe_cache_alloc_align_cache_impl(size_t size, int id, const char *name)
+{
+  (void)id;
+  (void)name;
+  return aligned_alloc(64, (size + 63) & ~(size_t)63);
+}
+void dt_pixelpipe_cache_free_align_cache(void **mem, const char *message)
+{
+  (void)message;
+  if(mem && *mem)
+  {
+    free(*mem);
+    *mem = NULL;
+  }
+}
+size_t dt_pixelpipe_cache_get_largest_free_run(void) { return (size_t)8 << 30; }
+size_t dt_get_available_mem() { return (size_t)8 << 30; }
+void dt_dev_pixelpipe_cache_get_usage(size_t *current, size_t *max)
+{
+  if(current) *current = 0;
+  if(max) *max = (size_t)8 << 30;
+}
+int dt_dev_pixel_pipe_cache_remove_lru(void) { return 1; }
+
+/* ---- cache lines (src/caches/pixelpipe_cache.h) ---------------------------------------------------------------------- */
+void *dt_pixel_cache_entry_get_data(struct dt_pixel_cache_entry_t *entry) { return entry ? entry->data : NULL; }
+void *dt_pixel_cache_alloc(struct dt_pixel_cache_entry_t *entry)
+{
+  if(entry && !entry->data) entry->data = aligned_alloc(64, (entry->size + 63) & ~(size_t)63);
+  return entry ? entry->data : NULL;
+}
+void dt_dev_pixelpipe_cache_wrlock_entry(gboolean lock, struct dt_pixel_cache_entry_t *entry)
+{
+  (void)lock;
+  (void)entry;
+}
+void dt_dev_pixelpipe_cache_rdlock_entry(gboolean lock, struct dt_pixel_cache_entry_t *entry)
+{
+  (void)lock;
+  (void)entry;
+}
+gboolean dt_dev_pixelpipe_cache_gpu_device_buffer(const dt_dev_pixelpipe_t *pipe, const dt_pixel_cache_entry_t *cache_entry)
+{
+  (void)cache_entry;
+  return pipe && pipe->devid >= 0;
+}
+int dt_dev_pixelpipe_cache_sync_cl_buffer(int devid, void *host_ptr, void *cl_mem_buffer, const dt_iop_roi_t *roi, int cl_mode,
+                                          size_t bpp, struct dt_iop_module_t *module, const char *message)
+{
+  (void)module;
+  (void)message;
+  if(!host_ptr || !cl_mem_buffer) return 1;
+  const int err = (cl_mode & CL_MAP_WRITE)
+                      ? dt_opencl_write_host_to_device(devid, host_ptr, cl_mem_buffer, roi->width, roi->height, (int)bpp)
+                      : dt_opencl_read_host_from_device(devid, host_ptr, cl_mem_buffer, roi->width, roi->height, (int)bpp);
+  return err != CL_SUCCESS;
+}
+float *dt_dev_pixelpipe_cache_restore_cl_buffer(struct dt_dev_pixelpipe_t *pipe, float *input, void *cl_mem_input,
+                                                const dt_iop_roi_t *roi_in, struct dt_iop_module_t *module, size_t in_bpp,
+                                                struct dt_pixel_cache_entry_t *input_entry, const char *message)
+{
+  if(!input) input = dt_pixel_cache_alloc(input_entry);
+  if(input && cl_mem_input
+     && dt_dev_pixelpipe_cache_sync_cl_buffer(pipe->devid, input, cl_mem_input, roi_in, CL_MAP_READ, in_bpp, module, message))
+    return NULL;
+  return input;
+}
+void dt_dev_pixelpipe_cache_release_cl_buffer(void **cl_mem_buffer, struct dt_pixel_cache_entry_t *entry, void *host_ptr,
+                                              gboolean cache_device)
+{
+  (void)host_ptr;
+  if(!cl_mem_buffer || !*cl_mem_buffer) return;
+  if(cache_device && entry && !entry->cl_mem)
+  {
+    entry->cl_mem = *cl_mem_buffer; /* the line keeps its device payload for the next module */
+    entry->cl_width = dt_opencl_get_image_width(*cl_mem_buffer);
+    entry->cl_height = dt_opencl_get_image_height(*cl_mem_buffer);
+    entry->cl_bpp = dt_opencl_get_image_element_size(*cl_mem_buffer);
+  }
+  else if(!entry || entry->cl_mem != *cl_mem_buffer)
+    dt_opencl_release_mem_object(*cl_mem_buffer);
+  *cl_mem_buffer = NULL;
+}
+void *dt_dev_pixelpipe_cache_borrow_cl_payload(struct dt_pixel_cache_entry_t *entry, int devid, int width, int height, int bpp)
+{
+  (void)devid;
+  if(entry && entry->cl_mem && entry->cl_width == width && entry->cl_height == height && entry->cl_bpp == bpp) return entry->cl_mem;
+  return NULL;
+}
+void dt_dev_pixelpipe_cache_return_cl_payload(struct dt_pixel_cache_entry_t *entry, void *mem)
+{
+  (void)entry;
+  (void)mem;
+}
+void *dt_dev_pixelpipe_cache_alloc_cl_device_buffer(int devid, const dt_iop_roi_t *roi, size_t bpp,
+                                                    const struct dt_iop_module_t *module, const char *message, void *keep)
+{
+  (void)module;
+  (void)message;
+  (void)keep;
+  return dt_opencl_alloc_device(devid, roi->width, roi->height, (int)bpp);
+}
+void *dt_dev_pixelpipe_cache_get_cl_buffer(int devid, void *host_ptr, const dt_iop_roi_t *roi, size_t bpp,
+                                           struct dt_iop_module_t *module, const char *message,
+                                           struct dt_pixel_cache_entry_t *entry, gboolean *out_reused, void *keep)
+{
+  (void)host_ptr;
+  (void)entry;
+  if(out_reused) *out_reused = FALSE;
+  return dt_dev_pixelpipe_cache_alloc_cl_device_buffer(devid, roi, bpp, module, message, keep);
+}
+int dt_dev_pixelpipe_cache_prepare_cl_input(struct dt_dev_pixelpipe_t *pipe, struct dt_iop_module_t *module, float *input,
+                                            void **cl_mem_input, const dt_iop_roi_t *roi_in, size_t in_bpp,
+                                            struct dt_pixel_cache_entry_t *input_entry,
+                                            struct dt_pixel_cache_entry_t **locked_input_entry, void *keep)
+{
+  (void)input_entry;
+  if(locked_input_entry) *locked_input_entry = NULL;
+  if(*cl_mem_input) return 0; /* borrowed from the line */
+  if(!input) return 1;
+  *cl_mem_input = dt_dev_pixelpipe_cache_alloc_cl_device_buffer(pipe->devid, roi_in, in_bpp, module, "input", keep);
+  if(!*cl_mem_input) return 1;
+  return dt_dev_pixelpipe_cache_sync_cl_buffer(pipe->devid, input, *cl_mem_input, roi_in, CL_MAP_WRITE, in_bpp, module, "input");
+}
+gboolean dt_dev_pixelpipe_cache_flush_host_pinned_image(void *host_ptr, struct dt_pixel_cache_entry_t *entry_hint, int devid)
+{
+  (void)host_ptr;
+  (void)entry_hint;
+  (void)devid;
+  return FALSE;
+}
+void dt_dev_pixelpipe_cache_flush_clmem(const int devid) { (void)devid; }
+
+/* ---- what the harness' module never reaches: blending, colourspace conversion, the CPU fallback ------------------------ */
+static int g_unexpected = 0;
+int boundary_unexpected_calls(void) { return g_unexpected; }
+void dt_dev_pixelpipe_debug_dump_module_io(dt_dev_pixelpipe_t *pipe, dt_iop_module_t *module, const char *stage, gboolean is_cl,
+                                           const dt_iop_buffer_dsc_t *in_dsc, const dt_iop_buffer_dsc_t *out_dsc,
+                                           const dt_iop_roi_t *roi_in, const dt_iop_roi_t *roi_out, size_t in_bpp, size_t out_bpp,
+                                           int cst_before, int cst_after)
+{
+  (void)pipe; (void)module; (void)stage; (void)is_cl; (void)in_dsc; (void)out_dsc; (void)roi_in; (void)roi_out; (void)in_bpp;
+  (void)out_bpp; (void)cst_before; (void)cst_after;
+}
+dt_pixelpipe_blend_transform_t dt_dev_pixelpipe_transform_for_blend(const dt_iop_module_t *self, const dt_dev_pixelpipe_iop_t *piece,
+                                                                    const dt_iop_buffer_dsc_t *output_dsc)
+{
+  (void)self; (void)piece; (void)output_dsc;
+  return DT_DEV_PIXELPIPE_BLEND_TRANSFORM_NONE;
+}
+int dt_develop_blend_process(struct dt_iop_module_t *self, struct dt_dev_pixelpipe_t *pipe,
+                             const struct dt_dev_pixelpipe_iop_t *piece, const void *const i, void *const o)
+{
+  (void)self; (void)pipe; (void)piece; (void)i; (void)o;
+  g_unexpected++;
+  return 1;
+}
+int dt_develop_blend_process_cl(struct dt_iop_module_t *self, struct dt_dev_pixelpipe_t *pipe,
+                                const struct dt_dev_pixelpipe_iop_t *piece, void *dev_in, void *dev_out)
+{
+  (void)self; (void)pipe; (void)piece; (void)dev_in; (void)dev_out;
+  g_unexpected++;
+  return 1;
+}
+dt_iop_colorspace_type_t dt_develop_blend_colorspace(const struct dt_dev_pixelpipe_iop_t *const piece, dt_iop_colorspace_type_t cst)
+{
+  (void)piece;
+  return cst;
+}
+dt_iop_order_iccprofile_info_t *dt_ioppr_get_pipe_work_profile_info(const struct dt_dev_pixelpipe_t *pipe)
+{
+  (void)pipe;
+  return NULL;
+}
+int dt_ioppr_get_iop_order(GList *iop_order_list, const char *op_name, const int multi_priority)
+{
+  (void)iop_order_list; (void)op_name; (void)multi_priority;
+  return 0;
+}
+void dt_colorspaces_apply_profile(const char *const op_name, const char *const instance_name, const float *const image_in,
+                                  float *const image_out, const int width, const int height, const int cst_from,
+                                  const int cst_to, int *converted_cst, const dt_iop_order_iccprofile_info_t *const profile_info)
+{
+  (void)op_name; (void)instance_name; (void)image_in; (void)image_out; (void)width; (void)height; (void)cst_from; (void)cst_to;
+  (void)converted_cst; (void)profile_info;
+  g_unexpected++;
+}
+int dt_colorspaces_apply_profile_cl(const char *const op_name, const char *const instance_name, const int devid, void *dev_img_in,
+                                    void *dev_img_out, const int width, const int height, const int cst_from, const int cst_to,
+                                    int *converted_cst, const dt_iop_order_iccprofile_info_t *const profile_info)
+{
+  (void)op_name; (void)instance_name; (void)devid; (void)dev_img_in; (void)dev_img_out; (void)width; (void)height; (void)cst_from;
+  (void)cst_to; (void)converted_cst; (void)profile_info;
+  g_unexpected++;
+  return 0;
+}
+/* src/develop/pixelpipe_cpu.c: there is no CPU fallback behind this library */
+static int g_cpu_fallbacks = 0;
+int boundary_cpu_fallbacks(void) { return g_cpu_fallbacks; }
+int pixelpipe_process_on_CPU(dt_dev_pixelpipe_t *pipe, const dt_dev_pixelpipe_iop_t *piece, const dt_dev_pixelpipe_iop_t *previous_piece,
+                             dt_develop_tiling_t *tiling, dt_pixelpipe_flow_t *pixelpipe_flow, gboolean *const cache_output,
+                             dt_pixel_cache_entry_t *input_entry, dt_pixel_cache_entry_t *output_entry)
+{
+  (void)pipe; (void)piece; (void)previous_piece; (void)tiling; (void)pixelpipe_flow; (void)cache_output; (void)input_entry;
+  (void)output_entry;
+  g_cpu_fallbacks++;
+  return 1;
+}
+
+/* ---- the module: exposure, written as INTEGRATION.md section 2 prescribes ------------------------------------------------ */
+static int g_process_cl_calls = 0;
+static size_t g_tile_budget = 0; /* bytes one buffer of a tile may take (0: the device's real budget) */
+
+static dt_hip_piece_t piece_view(const dt_dev_pixelpipe_iop_t *piece)
+{
+  dt_hip_piece_t v;
+  memset(&v, 0, sizeof(v));
+  v.roi_in.x = piece->roi_in.x; v.roi_in.y = piece->roi_in.y; v.roi_in.width = piece->roi_in.width;
+  v.roi_in.height = piece->roi_in.height; v.roi_in.scale = piece->roi_in.scale;
+  v.roi_out.x = piece->roi_out.x; v.roi_out.y = piece->roi_out.y; v.roi_out.width = piece->roi_out.width;
+  v.roi_out.height = piece->roi_out.height; v.roi_out.scale = piece->roi_out.scale;
+  v.filters = piece->dsc_in.filters;
+  v.channels = piece->dsc_in.channels;
+  v.datatype = DT_HIP_TYPE_FLOAT;
+  for(int c = 0; c < 4; c++) v.processed_maximum[c] = piece->dsc_in.processed_maximum[c];
+  return v;
+}
+static const char *exposure_name(void) { return "exposure"; }
+static int exposure_flags(void) { return IOP_FLAGS_ALLOW_TILING; }
+static int exposure_process_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                               const struct dt_dev_pixelpipe_iop_t *piece, void *dev_in, void *dev_out)
+{
+  (void)self;
+  g_process_cl_calls++;
+  const dt_hip_piece_t v = piece_view(piece);
+  return dt_hip_iop_exposure_process(pipe->devid, &v, (const dt_hip_exposure_data_t *)piece->data, dev_in, dev_out) == DT_HIP_SUCCESS;
+}
+static void exposure_tiling_callback(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                                     const struct dt_dev_pixelpipe_iop_t *piece, struct dt_develop_tiling_t *tiling)
+{
+  default_tiling_callback(self, pipe, piece, tiling); /* the reference's own default, tiling.c:1423-1463 */
+  if(g_tile_budget) /* the test squeezes the per-buffer budget: factor_cl = free memory / budget */
+    tiling->factor_cl = (float)dt_opencl_get_device_available(pipe->devid) / (float)g_tile_budget;
+}
+static int exposure_process_tiling_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                                      const struct dt_dev_pixelpipe_iop_t *piece, const void *const i, void *const o, const int bpp)
+{
+  return default_process_tiling_cl(self, pipe, piece, i, o, bpp);
+}
+
+static void make_module(dt_iop_module_t *m, dt_develop_t *dev)
+{
+  memset(m, 0, sizeof(*m));
+  memset(dev, 0, sizeof(*dev));
+  strcpy(m->op, "exposure");
+  m->dev = dev;
+  m->name = exposure_name;
+  m->flags = exposure_flags;
+  m->tiling_callback = exposure_tiling_callback;
+  m->process_cl = exposure_process_cl;
+  m->process_tiling_cl = exposure_process_tiling_cl;
+}
+static void make_piece(dt_dev_pixelpipe_iop_t *piece, dt_iop_module_t *m, dt_hip_exposure_data_t *d, int w, int h)
+{
+  memset(piece, 0, sizeof(*piece));
+  piece->module = m;
+  piece->data = d;
+  piece->enabled = TRUE;
+  piece->iwidth = w;
+  piece->iheight = h;
+  const dt_iop_roi_t roi = { 0, 0, w, h, 1.0 };
+  piece->buf_in = piece->buf_out = piece->roi_in = piece->roi_out = roi;
+  piece->process_cl_ready = 1;
+  piece->process_tiling_ready = 1;
+  piece->dsc_in.channels = piece->dsc_out.channels = 4;
+  piece->dsc_in.datatype = piece->dsc_out.datatype = TYPE_FLOAT;
+  piece->dsc_in.bpp = piece->dsc_out.bpp = 16;
+  piece->dsc_in.cst = piece->dsc_out.cst = IOP_CS_RGB;
+  for(int c = 0; c < 4; c++) piece->dsc_in.processed_maximum[c] = piece->dsc_out.processed_maximum[c] = 1.0f;
+}
+
+/* the reference's pixelpipe_process_on_GPU() on the module: device path, output synced back into the host line.
+ * Returns its return value; *flow = the dt_pixelpipe_flow_t bits it set, *calls = process_cl() invocations */
+int boundary_run_exposure_gpu(const float *in, float *out, int w, int h, float black, float scale, int *flow, int *calls)
+{
+  if(dt_hip_init() != DT_HIP_SUCCESS) return -1;
+  dt_iop_module_t m;
+  dt_develop_t dev;
+  dt_dev_pixelpipe_iop_t piece;
+  dt_hip_exposure_data_t d = { black, scale };
+  make_module(&m, &dev);
+  make_piece(&piece, &m, &d, w, h);
+  dev.image_storage.dsc = piece.dsc_in;
+  dt_dev_pixelpipe_t pipe;
+  memset(&pipe, 0, sizeof(pipe));
+  pipe.dev = &dev;
+  pipe.type = DT_DEV_PIXELPIPE_EXPORT;
+  pipe.devid = dt_opencl_reserve_device_for_pipe(pipe.type);
+  pipe.opencl_enabled = TRUE;
+  if(pipe.devid < 0) return -2;
+  const size_t bytes = (size_t)w * h * 16;
+  dt_pixel_cache_entry_t ein = { 1, (void *)in, bytes, NULL, 0, 0, 0 }, eout = { 2, out, bytes, NULL, 0, 0, 0 };
+  dt_develop_tiling_t tiling;
+  memset(&tiling, 0, sizeof(tiling));
+  m.tiling_callback(&m, &pipe, &piece, &tiling);
+  dt_pixelpipe_flow_t fl = PIXELPIPE_FLOW_NONE;
+  gboolean cache_output = TRUE; /* the test reads the result from the host line */
+  g_process_cl_calls = 0;
+  g_tile_budget = 0;
+  const int rc = pixelpipe_process_on_GPU(&pipe, &piece, NULL, &tiling, &fl, &cache_output, &ein, &eout);
+  dt_opencl_finish(pipe.devid);
+  if(eout.cl_mem) dt_opencl_release_mem_object(eout.cl_mem); /* the payload the line kept */
+  if(ein.cl_mem) dt_opencl_release_mem_object(ein.cl_mem);
+  dt_opencl_release_device(pipe.devid);
+  if(flow) *flow = (int)fl;
+  if(calls) *calls = g_process_cl_calls;
+  return rc;
+}
+
+/* the reference's default_process_tiling_cl() on the module with `budget` bytes per tile buffer: TRUE on success */
+int boundary_run_exposure_tiled(const float *in, float *out, int w, int h, float black, float scale, size_t budget, int *calls)
+{
+  if(dt_hip_init() != DT_HIP_SUCCESS) return -1;
+  dt_iop_module_t m;
+  dt_develop_t dev;
+  dt_dev_pixelpipe_iop_t piece;
+  dt_hip_exposure_data_t d = { black, scale };
+  make_module(&m, &dev);
+  make_piece(&piece, &m, &d, w, h);
+  dt_dev_pixelpipe_t pipe;
+  memset(&pipe, 0, sizeof(pipe));
+  pipe.dev = &dev;
+  pipe.type = DT_DEV_PIXELPIPE_EXPORT;
+  pipe.devid = dt_opencl_reserve_device_for_pipe(pipe.type);
+  pipe.opencl_enabled = TRUE;
+  if(pipe.devid < 0) return -2;
+  g_process_cl_calls = 0;
+  g_tile_budget = budget;
+  const int ok = m.process_tiling_cl(&m, &pipe, &piece, in, out, 16);
+  dt_opencl_finish(pipe.devid);
+  g_tile_budget = 0;
+  dt_opencl_release_device(pipe.devid);
+  if(calls) *calls = g_process_cl_calls;
+  return ok;
+}

@@ -1,0 +1,2 @@
+/* TEST INFRASTRUCTURE: stands in for src/common/logging.h of the reference when its host files are compiled against libansel_hip */
+#include "boundary_host.h"
