@@ -290,7 +290,8 @@ class BlendData(C.Structure):
                 ("blend_parameter", C.c_float), ("opacity", C.c_float), ("mask_combine", C.c_uint32),
                 ("blendif", C.c_uint32), ("feathering_radius", C.c_float), ("blur_radius", C.c_float),
                 ("details", C.c_float), ("contrast", C.c_float), ("brightness", C.c_float),
-                ("blendif_parameters", C.c_float * 64), ("blendif_boost_factors", C.c_float * 16), ("matrix_in", m34)]
+                ("blendif_parameters", C.c_float * 64), ("blendif_boost_factors", C.c_float * 16), ("matrix_in", m34),
+                ("form_mask", C.c_void_p)]
 
     @classmethod
     def uniform(cls, matrix_in, opacity=100.0, blend_mode=BLEND_NORMAL, blend_parameter=0.0, blend_cst=BLEND_CS_RGB_SCENE):

@@ -787,7 +787,8 @@ __global__ __launch_bounds__(256) void fill_plane(float *__restrict__ p, const s
 }
 
 // the parametric mask of a pixel, before the post operations (make_mask(), blendif_*.c)
-template <int CS> __device__ __forceinline__ float parametric_mask(const float4 pa, const float4 pb, const blend_args &a)
+template <int CS>
+__device__ __forceinline__ float parametric_mask(const float4 pa, const float4 pb, const blend_args &a, const float seed)
 {
   float temp = 1.0f;
   if(CS == DT_HIP_BLEND_CS_LAB)
@@ -800,8 +801,31 @@ template <int CS> __device__ __forceinline__ float parametric_mask(const float4 
     temp = combine_channels<0, CS == DT_HIP_BLEND_CS_RGB_DISPLAY>(pa, temp, a);
     temp = combine_channels<1, CS == DT_HIP_BLEND_CS_RGB_DISPLAY>(pb, temp, a);
   }
-  if(a.inclusive) return a.inversed ? a.global_opacity * (1.0f - a.seed) * temp : a.global_opacity * (1.0f - (1.0f - a.seed) * temp);
-  return a.inversed ? a.global_opacity * (1.0f - a.seed * temp) : a.global_opacity * a.seed * temp;
+  if(a.inclusive) return a.inversed ? a.global_opacity * (1.0f - seed) * temp : a.global_opacity * (1.0f - (1.0f - seed) * temp);
+  return a.inversed ? a.global_opacity * (1.0f - seed * temp) : a.global_opacity * seed * temp;
+}
+
+// The mask of a blend with a host-rendered form mask (drawn forms, a raster mask, the details refinement: blend.c:740-790,
+// uploaded as one plane as in blend.c:1278-1325), before the post operations.  kind 4: a raster mask alone, form * opacity
+// (blend.c:740-745); 3: make_mask() not conditional (blendif_rgb_jzczhz.c:228-240); 2: every conditional channel, the form
+// mask in the place of the constant one
+template <int CS>
+__global__ __launch_bounds__(256) void form_mask_kernel(const float4 *__restrict__ in, const float4 *__restrict__ out,
+                                                        const float *__restrict__ form, float *__restrict__ plane,
+                                                        const blend_args a, const int kind)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= (size_t)a.owidth * a.oheight) return;
+  const float f = form[k];
+  float m;
+  if(kind == 4) m = f * a.opacity;
+  else if(kind == 3) m = a.inversed ? a.global_opacity * (1.0f - f) : f * a.global_opacity;
+  else
+  {
+    const int y = (int)(k / a.owidth), x = (int)(k - (size_t)y * a.owidth);
+    m = parametric_mask<CS>(in[(size_t)(y + a.yoffs) * a.iwidth + a.xoffs + x], out[k], a, f);
+  }
+  plane[k] = m;
 }
 
 // the mask plane of a frame, for the post operations that are not pointwise (blur)
@@ -814,7 +838,7 @@ __global__ __launch_bounds__(256) void blend_mask_kernel(const float4 *__restric
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= (size_t)a.owidth * a.oheight) return;
   const int y = (int)(k / a.owidth), x = (int)(k - (size_t)y * a.owidth);
-  plane[k] = parametric_mask<CS>(in[(size_t)(y + a.yoffs) * a.iwidth + a.xoffs + x], out[k], a);
+  plane[k] = parametric_mask<CS>(in[(size_t)(y + a.yoffs) * a.iwidth + a.xoffs + x], out[k], a, a.seed);
 }
 
 // MASK: 0 = the same value everywhere, 1 = parametric, computed here, 2 = read from the (blurred) mask plane
@@ -837,7 +861,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ i
   }
   if(MASK == 1)
   {
-    m = parametric_mask<CS>(pa, pb, a);
+    m = parametric_mask<CS>(pa, pb, a, a.seed);
     if(a.tone) m = tone_curve(m, a);
   }
   float4 r;
@@ -862,9 +886,22 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   }
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
   if(piece->channels != (raw ? 1 : 4)) return DT_HIP_INVALID_ARG;
-  if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->details != 0.f)
+  if(d->feathering_radius != 0.f)
   {
-    set_last_error("blend: drawn / raster masks, feathering and the details threshold are not built");
+    set_last_error("blend: mask feathering (the guided filter) is not built");
+    return DT_HIP_INVALID_ARG;
+  }
+  // drawn / raster masks and the details threshold: rendered and refined by the host into ONE plane, as the reference's
+  // device blend receives them (blend.c:1278-1325)
+  const float *const form = (const float *)d->form_mask;
+  if(((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->details != 0.f) && !form)
+  {
+    set_last_error("blend: a drawn / raster mask or a details threshold needs the host-rendered form mask (form_mask)");
+    return DT_HIP_INVALID_ARG;
+  }
+  if(form && raw)
+  {
+    set_last_error("blend: form masks in the raw colourspace are not built");
     return DT_HIP_INVALID_ARG;
   }
   if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return DT_HIP_SUCCESS; // blend.c:673
@@ -904,14 +941,28 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   const float seed = mask_inclusive ? 0.0f : 1.0f; // the form mask of a parametric-only blend, blend.c:749-757
   bool per_pixel = false;
   a.constant = opacity;
-  if(parametric)
+  // blend.c:732-760: which mask sources there are; a raster mask alone is form * opacity, without make_mask() and
+  // without post operations
+  const bool use_masks = form || parametric;
+  const bool raster_only = form && (d->mask_mode & DT_HIP_MASK_RASTER) && !(d->mask_mode & DT_HIP_MASK_SHAPE) && !parametric;
+  const bool post = use_masks && !raster_only;
+  int form_kind = 0; // form_mask_kernel: 0 = no form plane involved
+  if(raster_only)
+    form_kind = 4;
+  else if(use_masks)
   {
-    if(!canceling_channel && !any_channel_active)
-      a.constant = mask_inversed ? global_opacity * (1.0f - seed) : seed * global_opacity;
+    if(!(d->mask_mode & DT_HIP_MASK_PARAMETRIC) || (!canceling_channel && !any_channel_active))
+    {
+      if(form) form_kind = 3;
+      else a.constant = mask_inversed ? global_opacity * (1.0f - seed) : seed * global_opacity;
+    }
     else if(canceling_channel || !any_channel_active)
       a.constant = ((mask_inversed == 0) ^ (mask_inclusive == 0)) ? global_opacity : 0.0f;
     else
+    {
       per_pixel = true;
+      if(form) form_kind = 2;
+    }
   }
   a.global_opacity = global_opacity;
   a.seed = seed;
@@ -921,21 +972,21 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   a.opacity = opacity;
   a.brightness = d->brightness;
   a.e = expf(3.f * d->contrast);
-  a.tone = parametric && (fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f;
+  a.tone = post && (fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f;
   a.mode = d->blend_mode & 0xFFu;
   a.reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
   a.p = exp2f(d->blend_parameter);
   // post operations run on parametric masks only (blend.c:759-900): blur, then the tone curve
-  const bool blur = parametric && d->blur_radius > 0.1f;
+  const bool blur = post && d->blur_radius > 0.1f;
   const size_t np = (size_t)a.owidth * a.oheight;
   hipStream_t s = stream_of(devid);
   // the blurred mask plane: `plane` holds the mask, `scratch` the vertically blurred one
   float *plane = nullptr, *scratch = nullptr;
-  if(blur)
+  if(blur || form_kind)
   {
     plane = (float *)dt_hip_alloc_device_buffer(devid, np * sizeof(float));
-    scratch = (float *)dt_hip_alloc_device_buffer(devid, np * sizeof(float));
-    if(!plane || !scratch)
+    if(blur) scratch = (float *)dt_hip_alloc_device_buffer(devid, np * sizeof(float));
+    if(!plane || (blur && !scratch))
     {
       if(plane) dt_hip_release_mem_object(plane);
       if(scratch) dt_hip_release_mem_object(scratch);
@@ -1029,7 +1080,17 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   const unsigned grid = pixel_grid(np);
   const int cs = lab ? DT_HIP_BLEND_CS_LAB : (display ? DT_HIP_BLEND_CS_RGB_DISPLAY : DT_HIP_BLEND_CS_RGB_SCENE);
   int mask = per_pixel ? 1 : 0;
-  if(blur)
+  if(form_kind)
+  {
+    // the mask from the host-rendered form plane, as a plane (the post operations follow below)
+    launch_scope ls(devid, "blend_mask");
+    if(cs == DT_HIP_BLEND_CS_LAB) form_mask_kernel<DT_HIP_BLEND_CS_LAB><<<grid, 256, 0, s>>>(in, out, form, plane, a, form_kind);
+    else if(cs == DT_HIP_BLEND_CS_RGB_DISPLAY)
+      form_mask_kernel<DT_HIP_BLEND_CS_RGB_DISPLAY><<<grid, 256, 0, s>>>(in, out, form, plane, a, form_kind);
+    else form_mask_kernel<DT_HIP_BLEND_CS_RGB_SCENE><<<grid, 256, 0, s>>>(in, out, form, plane, a, form_kind);
+    mask = 2;
+  }
+  else if(blur)
   {
     // the mask as a plane (before the post operations), blurred in place
     launch_scope ls(devid, "blend_mask");

@@ -631,6 +631,12 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
       set_last_error("band mode: '%s' has no row-band implementation", k_ops[n.op].name);
       return DT_HIP_INVALID_ARG;
     }
+    if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->form_mask)
+    {
+      // the plane is the frame's: a band would need its own rows of it
+      set_last_error("band mode: a blend with a host-rendered form mask has no row-band implementation");
+      return DT_HIP_INVALID_ARG;
+    }
     if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->blur_radius > 0.0f)
     {
       // uniform and parametric masks are pointwise; the mask blur is a recursive filter down whole columns

@@ -579,8 +579,13 @@ int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iw
  * parametric -- gray, R, G, B and Jz, Cz, hz resp. H, S, L; L, a, b, C, h -- on input and output, all combine / invert
  * variants; the post operations mask blur (the recursive gaussian of src/pixel/gaussian.c, blend.c:869-881) and mask
  * tone curve (contrast / brightness, blend.c:626-655); every operator of the four files (16, 30, 27, 17) and the
- * reverse flag.  Refused with DT_HIP_INVALID_ARG (never approximated): drawn and raster masks, feathering (guided
- * filter), the details threshold, GUI mask display. */
+ * reverse flag.  Drawn and raster masks -- and the details threshold that refines them -- arrive the way the reference's
+ * own device blend takes them (blend.c:1278-1325: the host rasterises the forms, combines them with the raster mask,
+ * refines with the detail mask, and uploads ONE float plane): `form_mask`, a plane of roi_out's size.  It replaces the
+ * constant form mask of a parametric-only blend in make_mask() (blendif_*.c) and is followed by the same post operations;
+ * a raster mask alone (no drawn form, no active parametric channel) is form * opacity (blend.c:740-745).
+ * Refused with DT_HIP_INVALID_ARG (never approximated): feathering (guided filter), GUI mask display, and a drawn /
+ * raster mask mode or a details threshold WITHOUT the plane. */
 #define DT_HIP_BLEND_CS_RAW 1 /* dt_develop_blend_colorspace_t, blend.h:51-58 */
 #define DT_HIP_BLEND_CS_LAB 2
 #define DT_HIP_BLEND_CS_RGB_DISPLAY 3
@@ -602,11 +607,15 @@ typedef struct dt_hip_blend_data_t
   float opacity;          /* 0 .. 100 */
   uint32_t mask_combine;  /* DT_HIP_COMBINE_* bits */
   uint32_t blendif;       /* bit i: channel i active; bit 16 + i: channel i inverted (blend.h:141-197) */
-  float feathering_radius, blur_radius, details; /* feathering_radius and details must be 0 (refused otherwise) */
+  float feathering_radius, blur_radius, details; /* feathering_radius must be 0 (refused otherwise); details is applied by the
+                                                    host to form_mask before the upload, as in the reference */
   float contrast, brightness;                    /* mask tone curve */
   float blendif_parameters[4 * DT_HIP_BLENDIF_SIZE];
   float blendif_boost_factors[DT_HIP_BLENDIF_SIZE];
   float matrix_in[3][4]; /* dt_iop_order_iccprofile_info_t.matrix_in of the work profile */
+  dt_hip_mem_t form_mask; /* NULL, or the host-rendered form mask: roi_out.width x roi_out.height floats on the device
+                             (dt_hip_copy_host_to_device(devid, mask, width, height, 4)); required when mask_mode has
+                             DT_HIP_MASK_SHAPE / _RASTER or details != 0 */
 } dt_hip_blend_data_t;
 /* dev_in: the module's input, roi_in; dev_out: the module's output, roi_out, blended in place */
 int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d,

@@ -91,10 +91,12 @@ static int parametric_used(const dt_develop_blend_params_t *params)
 int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, const void *in, void *out)
 {
   ref_reset_fp_mode();
-  if(h->blend_cst < DEVELOP_BLEND_CS_RAW || h->blend_cst > DEVELOP_BLEND_CS_RGB_SCENE
-     || (h->mask_mode & (DEVELOP_MASK_SHAPE | DEVELOP_MASK_RASTER))
-     || h->feathering_radius != 0.f || h->details != 0.f)
-    return -1;
+  if(h->blend_cst < DEVELOP_BLEND_CS_RAW || h->blend_cst > DEVELOP_BLEND_CS_RGB_SCENE || h->feathering_radius != 0.f) return -1;
+  /* drawn / raster masks (and the details refinement of them) come rendered, as one plane: what
+   * _develop_blend_init_raster_mask() / _init_drawn_mask() / _refine_with_detail_mask() leave in `mask` (blend.c:740-790) */
+  const float *const form = (const float *)h->form_mask;
+  if(((h->mask_mode & (DEVELOP_MASK_SHAPE | DEVELOP_MASK_RASTER)) || h->details != 0.f) && !form) return -1;
+  if(form && h->blend_cst == DEVELOP_BLEND_CS_RAW) return -1;
   dt_develop_blend_params_t d;
   memset(&d, 0, sizeof(d));
   d.mask_mode = h->mask_mode;
@@ -143,12 +145,26 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
   const float opacity = fminf(fmaxf(d.opacity / 100.0f, 0.0f), 1.0f);
   float *mask = dt_pixelpipe_cache_alloc_align_float(buffsize, &pipe);
   if(!mask) return 1;
-  if(!parametric_used(&d))
+  /* blend.c:732-760 */
+  const int raster_used = form && (d.mask_mode & DEVELOP_MASK_RASTER), drawn_used = form && (d.mask_mode & DEVELOP_MASK_SHAPE);
+  const int use_masks = form || parametric_used(&d);
+  const int raster_only = raster_used && !drawn_used && !parametric_used(&d);
+  if(!use_masks)
     dt_iop_image_fill(mask, opacity, owidth, oheight, 1);
+  else if(raster_only)
+  {
+    memcpy(mask, form, sizeof(float) * buffsize);
+    dt_iop_image_mul_const(mask, opacity, owidth, oheight, 1);
+  }
   else
   {
-    const float fill = (d.mask_combine & DEVELOP_COMBINE_INCL) ? 0.0f : 1.0f;
-    dt_iop_image_fill(mask, fill, owidth, oheight, 1);
+    if(form)
+      memcpy(mask, form, sizeof(float) * buffsize);
+    else
+    {
+      const float fill = (d.mask_combine & DEVELOP_COMBINE_INCL) ? 0.0f : 1.0f;
+      dt_iop_image_fill(mask, fill, owidth, oheight, 1);
+    }
     if(d.blend_cst == DEVELOP_BLEND_CS_LAB)
       dt_develop_blendif_lab_make_mask(&piece, (const float *)in, (const float *)out, mask);
     else if(d.blend_cst == DEVELOP_BLEND_CS_RAW)

@@ -813,9 +813,12 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
     return blend_raw(piece, d, (const float *)in_, (float *)out_);
   }
   const int lab = d->blend_cst == DT_HIP_BLEND_CS_LAB, display = d->blend_cst == DT_HIP_BLEND_CS_RGB_DISPLAY;
-  if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !display) || (d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER))
-     || d->feathering_radius != 0.f || d->details != 0.f || piece->channels != 4)
+  if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !display) || d->feathering_radius != 0.f || piece->channels != 4)
     return 1;
+  /* drawn / raster masks and the details threshold: rendered and refined by the host into ONE plane, as the reference's
+   * device blend receives them (blend.c:1278-1325) */
+  if(((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->details != 0.f) && !d->form_mask) return 1;
+  const float *const form = (const float *)d->form_mask;
   if(lab && !lab_mode_supported(d->blend_mode & 0xFFu)) return 1;
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
   if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return 0;
@@ -849,12 +852,17 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   const unsigned canceling_channel = (blendif >> 16) & ~blendif & CH_MASK;
   const float global_opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f);
   const float seed = mask_inclusive ? 0.0f : 1.0f; /* the form mask of a parametric-only blend, blend.c:749-757 */
-  int kind; /* 0 uniform, 1 constant after make_mask, 2 per pixel */
+  /* blend.c:732-745: a raster mask alone is form * opacity, no make_mask(), no post operations */
+  const int raster_only = form && (d->mask_mode & DT_HIP_MASK_RASTER) && !(d->mask_mode & DT_HIP_MASK_SHAPE) && !parametric;
+  const int use_masks = form || parametric;
+  int kind; /* 0 uniform, 1 constant after make_mask, 2 per pixel, 3 unconditional on a form plane, 4 raster only */
   float constant = opacity;
-  if(!parametric) kind = 0;
-  else if(!canceling_channel && !any_channel_active)
+  if(!use_masks) kind = 0;
+  else if(raster_only) kind = 4;
+  else if(!(d->mask_mode & DT_HIP_MASK_PARAMETRIC) || (!canceling_channel && !any_channel_active))
   {
-    kind = 1;
+    /* make_mask(), blendif_rgb_jzczhz.c:228-240: not conditional */
+    kind = form ? 3 : 1;
     constant = mask_inversed ? global_opacity * (1.0f - seed) : seed * global_opacity;
   }
   else if(canceling_channel || !any_channel_active)
@@ -905,7 +913,8 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
     for(int c = 0; c < 3; c++) x.luma[c] = d->matrix_in[1][c];
   }
 
-  const int tone = parametric && (fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f;
+  const int post = use_masks && !raster_only; /* the post operations follow make_mask() only, blend.c:746-900 */
+  const int tone = post && (fabsf(d->contrast) >= 0.01f || fabsf(d->brightness) >= 0.01f) && opacity > 1e-4f;
   const float e = expf(3.f * d->contrast);
   const float p = exp2f(d->blend_parameter);
   const unsigned mode = d->blend_mode & 0xFFu;
@@ -913,7 +922,7 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
 
   /* with a mask blur the mask becomes a plane: build it, blur it, then tone curve + operator per pixel */
   float *plane = NULL;
-  const int blur = parametric && d->blur_radius > 0.1f;
+  const int blur = post && d->blur_radius > 0.1f;
   if(blur)
   {
     plane = (float *)malloc(sizeof(float) * (size_t)owidth * oheight);
@@ -930,7 +939,10 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
       float *bo = out + ((size_t)y * owidth + xx) * 4;
       const float b[4] = { bo[0], bo[1], bo[2], bo[3] };
       float m = constant;
+      const float sd = form ? form[(size_t)y * owidth + xx] : seed; /* the form mask at this pixel */
       if(pass == 1 && blur) m = plane[(size_t)y * owidth + xx];
+      else if(kind == 4) m = sd * opacity;
+      else if(kind == 3) m = mask_inversed ? global_opacity * (1.0f - sd) : sd * global_opacity;
       else if(kind == 2)
       {
         float temp = 1.0f;
@@ -945,9 +957,9 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
           temp = combine_channels(b, temp, x.blendif >> GRAY_OUT, x.parameters + PARAM_ITEMS * GRAY_OUT, &x, display);
         }
         if(mask_inclusive)
-          m = mask_inversed ? global_opacity * (1.0f - seed) * temp : global_opacity * (1.0f - (1.0f - seed) * temp);
+          m = mask_inversed ? global_opacity * (1.0f - sd) * temp : global_opacity * (1.0f - (1.0f - sd) * temp);
         else
-          m = mask_inversed ? global_opacity * (1.0f - seed * temp) : global_opacity * seed * temp;
+          m = mask_inversed ? global_opacity * (1.0f - sd * temp) : global_opacity * sd * temp;
       }
       if(pass == 0)
       {

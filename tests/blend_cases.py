@@ -224,3 +224,65 @@ def blur_cases():
 
 def images_for(kind, w, h, seed):
     return {"scene": images, "lab": lab_images, "display": display_images, "raw": raw_images}[kind](w, h, seed)
+
+
+def form_plane(w, h, seed=5):
+    """a host-rendered form mask as the reference's blend receives it (blend.c:740-790): a feathered ellipse (a drawn
+    form), times a smooth raster mask, with exact 0 and 1 regions, values slightly outside [0, 1] (the detail refinement
+    can leave those) and one NaN"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    r = np.sqrt(((xx - 0.45 * w) / (0.35 * w)) ** 2 + ((yy - 0.55 * h) / (0.3 * h)) ** 2)
+    m = np.clip((1.2 - r) / 0.4, 0.0, 1.0).astype(np.float32)
+    m *= (0.6 + 0.4 * np.sin(xx / 17.0) * np.cos(yy / 23.0)).astype(np.float32)
+    m[: h // 10] = 0.0
+    m[-h // 12:, : w // 3] = 1.0
+    m[h // 2, w // 2] = 1.02
+    m[h // 2 + 1, w // 2] = -0.01
+    m[5, 7] = np.nan
+    m += (rng.random((h, w), dtype=np.float32) - 0.5) * np.float32(1e-3) * (m > 0) * (m < 1)
+    return np.ascontiguousarray(m.astype(np.float32))
+
+
+def form_cases(blend_cst=abi.BLEND_CS_RGB_SCENE):
+    """(name, BlendData without the plane): drawn / raster masks alone, with parametric channels, every combine mode,
+    with the post operations"""
+    lab = blend_cst == abi.BLEND_CS_LAB
+    m_in = M
+    ch_in, ch_out = (abi.BLENDIF_L_in, abi.BLENDIF_C_out) if lab else (abi.BLENDIF_GRAY_in, abi.BLENDIF_Jz_out)
+    tr_in = (0.05, 0.3, 0.7, 0.95)
+    out = []
+
+    def base(opacity=80.0, mode=abi.BLEND_NORMAL):
+        return abi.BlendData.uniform(m_in, opacity, mode, blend_cst=blend_cst)
+
+    for combine in (0, abi.COMBINE_INV, abi.COMBINE_INCL, abi.COMBINE_INV | abi.COMBINE_INCL):
+        d = base()
+        d.mask_mode |= abi.MASK_SHAPE
+        d.mask_combine = combine
+        out.append(("drawn-c%d" % combine, d))
+        d = base(65.0)
+        d.mask_mode |= abi.MASK_SHAPE | abi.MASK_RASTER
+        d.channel(ch_in, *tr_in, boost=0.0 if lab else 1.0)
+        d.channel(ch_out, 0.0, 0.0, 0.6, 0.9, invert=True, boost=0.0 if lab else -5.0)
+        d.mask_combine = combine
+        d.contrast, d.brightness = 0.3, -0.2
+        out.append(("drawn+raster+parametric-c%d" % combine, d))
+    d = base(55.0)
+    d.mask_mode |= abi.MASK_RASTER
+    d.contrast = 0.5  # a raster mask alone gets no post operation
+    out.append(("raster-only", d))
+    d = base(90.0)
+    d.mask_mode |= abi.MASK_SHAPE
+    d.blur_radius = 4.0
+    d.brightness = 0.25
+    out.append(("drawn-blurred-toned", d))
+    d = base(70.0)
+    d.mask_mode |= abi.MASK_SHAPE | abi.MASK_PARAMETRIC  # the conditional mode switched on, no channel away from its range
+    d.details = 0.4  # applied by the host to the plane
+    out.append(("drawn-details-conditional-idle", d))
+    d = base(70.0)
+    d.channel(ch_in, *tr_in)
+    d.details = -0.3  # a parametric-only mask refined by the detail mask: the host supplies the refined fill
+    out.append(("parametric-details", d))
+    return out

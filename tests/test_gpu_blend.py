@@ -128,3 +128,53 @@ def test_blend_refuses_what_is_not_built(field, value):
     assert rc == -997  # DT_HIP_INVALID_ARG
     assert h_.dt_hip_finish(0) == 1
     assert np.array_equal(db.to_numpy(b.shape, np.float32).view(np.uint32), b.view(np.uint32))
+
+
+# ---- drawn / raster masks and the details threshold: the host-rendered form mask (blend.c:740-790, :1278-1325) -------
+FORM_CASES = [(cs, n, d) for cs in (abi.BLEND_CS_RGB_SCENE, abi.BLEND_CS_RGB_DISPLAY, abi.BLEND_CS_LAB)
+              for n, d in blend_cases.form_cases(cs)]
+
+
+@pytest.mark.parametrize("cs,name,d", FORM_CASES, ids=["cs%d-%s" % (c[0], c[1]) for c in FORM_CASES])
+def test_blend_with_a_host_rendered_form_mask(cs, name, d):
+    """the plane is uploaded once (what blend.c:1285 does with dt_opencl_write_host_to_device) and takes the place of
+    the constant form mask; device == oracle == reference"""
+    l = hc.hip()
+    w, h = 131, 67
+    a, b = blend_cases.lab_images(w, h, 53) if cs == abi.BLEND_CS_LAB else blend_cases.images(w, h, 44)
+    form = blend_cases.form_plane(w, h)
+    dform = lib.DeviceBuffer.from_numpy(0, form)
+    piece = abi.Piece.make(w, h)
+    d.form_mask = dform.ptr
+    got = hc.run_hip("dt_hip_develop_blend_process", piece, d, a, b.shape, pre_fill=b)
+    host_form = ck.aligned_empty(form.shape, np.float32)
+    host_form[...] = form
+    d.form_mask = host_form.ctypes.data
+    want = b.copy()
+    assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, want) == 0
+    assert int((ck.ulp_diff(got, want) > 0).sum()) == 0, name
+    ref = ck.ref()
+    if ref is not None:
+        r = b.copy()
+        assert ck.call(ref, "ref_develop_blend", piece, d, a, r) == 0
+        assert int((ck.ulp_diff(got, r) > 0).sum()) == 0, name + " (vs reference)"
+    # without the plane: refused, with the reason
+    d.form_mask = None
+    buf = lib.DeviceBuffer.from_numpy(0, b)
+    din = lib.DeviceBuffer.from_numpy(0, a)
+    assert l.dt_hip_develop_blend_process(0, C.byref(piece), C.byref(d), din.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
+    assert b"form_mask" in l.dt_hip_last_error()
+    for x in (dform, buf, din):
+        x.release()
+
+
+def test_feathering_is_still_refused():
+    l = hc.hip()
+    w, h = 32, 16
+    a, b = blend_cases.images(w, h, 3)
+    d = abi.BlendData.uniform(blend_cases.M, 50.0)
+    d.feathering_radius = 3.0
+    buf, din = lib.DeviceBuffer.from_numpy(0, b), lib.DeviceBuffer.from_numpy(0, a)
+    piece = abi.Piece.make(w, h)
+    assert l.dt_hip_develop_blend_process(0, C.byref(piece), C.byref(d), din.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
+    assert b"feathering" in l.dt_hip_last_error()

@@ -397,6 +397,33 @@ def test_develop_blend(name, d):
         assert not np.array_equal(x.view(np.uint32), b.view(np.uint32))
 
 
+FORM_CASES = [(cs, n, d) for cs in (abi.BLEND_CS_RGB_SCENE, abi.BLEND_CS_RGB_DISPLAY, abi.BLEND_CS_LAB)
+              for n, d in blend_cases.form_cases(cs)]
+
+
+@pytest.mark.parametrize("cs,name,d", FORM_CASES, ids=["cs%d-%s" % (c[0], c[1]) for c in FORM_CASES])
+def test_develop_blend_with_a_host_rendered_form_mask(cs, name, d):
+    """drawn / raster masks and the details refinement arrive as one plane (blend.c:740-790, :1278-1325): it replaces
+    the constant form mask in make_mask() and takes the same post operations; a raster mask alone is form * opacity"""
+    w, h = 131, 67
+    a, b = blend_cases.lab_images(w, h, 53) if cs == abi.BLEND_CS_LAB else blend_cases.images(w, h, 44)
+    form = blend_cases.form_plane(w, h)
+    aligned = ck.aligned_empty(form.shape, np.float32)
+    aligned[...] = form
+    d.form_mask = aligned.ctypes.data
+    piece = abi.Piece.make(w, h)
+    r, o = ck.ref(), ck.oracle()
+    x, y = b.copy(), b.copy()
+    assert ck.call(r, "ref_develop_blend", piece, d, a, x) == 0
+    assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
+    _exact(x, y, "blend with a form mask, " + name)
+    assert not np.array_equal(x.view(np.uint32), b.view(np.uint32))
+    # and without the plane the same parameters are refused, never approximated
+    d.form_mask = None
+    assert ck.call(o, "oracle_develop_blend", piece, d, a, y) != 0
+    assert ck.call(r, "ref_develop_blend", piece, d, a, x) != 0
+
+
 def test_develop_blend_roi_offset():
     """module input larger than its output (roi_in contains roi_out at an offset), blend.c:683-702"""
     w, h, iw, ih = 90, 50, 120, 70
