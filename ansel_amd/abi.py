@@ -228,7 +228,7 @@ class BandState(C.Structure):
     """dt_hip_band_state_t"""
     _fields_ = [("halo_buf", C.c_void_p), ("row_bytes", C.c_size_t), ("clipped_count", C.c_void_p),
                 ("priv", C.c_void_p), ("halo_rows", C.c_int32), ("sum_planes", C.c_int32), ("sum_buf", C.c_void_p),
-                ("sum_count", C.c_size_t)]
+                ("sum_count", C.c_size_t), ("relay_buf", C.c_void_p), ("relay_bytes", C.c_size_t)]
 
 
 DT_HIP_BAND_EXCHANGE = 1

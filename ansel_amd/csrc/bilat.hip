@@ -46,20 +46,26 @@ __device__ __forceinline__ int axis(const float v, const float sigma, const int 
 }
 
 // dt_bilateral_splat(), bilateral.c:183-256, gathered per grid node
+// Row bands (a frame over several GPUs, pipe.cpp): a band splats its OWN rows [row_lo, row_hi) of the frame on top of
+// what the bands above it have accumulated (`accumulate`: the node's z column starts from `buf` instead of zero) --
+// rows ascend from band to band, so every cell still adds its contributions in pixel row-major order, the binary32
+// partial sums travelling through `buf` unchanged.  `in` is the band's first row.  Whole frame: 0, height, 0.
 __global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat(const float4 *__restrict__ in, float *__restrict__ buf,
-                                                             const grid_t b)
+                                                             const grid_t b, const int row_lo, const int row_hi,
+                                                             const int accumulate)
 {
   extern __shared__ float acc[]; // [size_z][SPLAT_THREADS]
   const int tid = threadIdx.x;
   const int node = blockIdx.x * SPLAT_THREADS + tid;
   const bool live = node < b.size_x * b.size_y;
   const int Y = live ? node / b.size_x : 0, X = live ? node - Y * b.size_x : 0;
-  for(int z = 0; z < b.size_z; z++) acc[z * SPLAT_THREADS + tid] = 0.0f;
+  for(int z = 0; z < b.size_z; z++)
+    acc[z * SPLAT_THREADS + tid] = (accumulate && live) ? buf[(size_t)(X + Y * b.size_x) * b.size_z + z] : 0.0f;
   if(live)
   {
     const float s2 = b.sigma_s * b.sigma_s;
     const int i0 = max(0, (int)floorf((X - 1) * b.sigma_s) - 2), i1 = min(b.width - 1, (int)ceilf((X + 1) * b.sigma_s) + 2);
-    const int j0 = max(0, (int)floorf((Y - 1) * b.sigma_s) - 2), j1 = min(b.height - 1, (int)ceilf((Y + 1) * b.sigma_s) + 2);
+    const int j0 = max(row_lo, (int)floorf((Y - 1) * b.sigma_s) - 2), j1 = min(row_hi - 1, (int)ceilf((Y + 1) * b.sigma_s) + 2);
     for(int j = j0; j <= j1; j++)
     {
       float yf;
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat(const float4 *__res
         const int xi = axis((float)i, b.sigma_s, b.size_x, xf);
         if(xi != X && xi != X - 1) continue;
         const float wx = xi == X ? (1.0f - xf) : xf;
-        const float L = in[(size_t)j * b.width + i].x;
+        const float L = in[(size_t)(j - row_lo) * b.width + i].x;
         const int zi = axis(L, b.sigma_r, b.size_z, zf);
         const float contrib = wx * wy * 100.0f / s2; // (1-xf)*(1-yf)*100/s2 and its three siblings
         acc[zi * SPLAT_THREADS + tid] += (contrib * (1.0f - zf));
@@ -144,14 +150,17 @@ __global__ __launch_bounds__(64) void bilat_blur_line_z(float *__restrict__ buf,
 }
 
 // dt_bilateral_slice(), bilateral.c:356-393
+// `rows` rows from frame row `row0` on (a row band; the whole frame: 0, height); in / out hold those rows
 __global__ __launch_bounds__(256) void bilat_slice(const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                   const float *__restrict__ buf, const grid_t b, const float norm)
+                                                   const float *__restrict__ buf, const grid_t b, const float norm,
+                                                   const int row0, const int rows)
 {
   const int ox = b.size_z, oy = b.size_x * b.size_z, oz = 1;
-  const size_t n = (size_t)b.width * b.height;
+  const size_t n = (size_t)b.width * rows;
   for(size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x)
   {
-    const int j = (int)(p / b.width), i = (int)(p - (size_t)j * b.width);
+    const int jl = (int)(p / b.width), i = (int)(p - (size_t)jl * b.width);
+    const int j = row0 + jl;
     const float4 px = in[p];
     float xf, yf, zf;
     const float L = px.x;
@@ -197,6 +206,101 @@ int local_laplacian_launch(int devid, const float4 *in, float4 *out, int wd, int
                            float highlights, float clarity);
 }
 
+namespace
+{
+// the grid of the FRAME `piece` describes (bilat.c:339-346)
+int bilat_grid_of(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, grid_t &b)
+{
+  const int width = piece->roi_in.width, height = piece->roi_in.height;
+  if(!(d->iscale > 0.0f) || !(piece->roi_in.scale > 0.0) || !(d->sigma_r > 0.0f)) return DT_HIP_INVALID_ARG;
+  const float scale = (float)(d->iscale / piece->roi_in.scale); // dt_dev_get_module_scale(), bilat.c:339
+  grid_size(b, width, height, 100.0f, d->sigma_s / scale, d->sigma_r);
+  if(b.size_x < 4 || b.size_y < 4 || b.size_z < 4)
+  {
+    // blur_line() / blur_line_z() (src/pixel/bilateral.c:266-340) touch four entries of every grid line
+    // unconditionally: on a shorter line the reference writes past it (heap corruption on the CPU)
+    set_last_error("bilat: a %d x %d x %d grid is below the 4 entries per line the reference's blur assumes", b.size_x,
+                   b.size_y, b.size_z);
+    return DT_HIP_INVALID_ARG;
+  }
+  return DT_HIP_SUCCESS;
+}
+
+void bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_rows, int row_lo, int row_hi, int accumulate)
+{
+  hipStream_t s = stream_of(devid);
+  const int nodes = b.size_x * b.size_y;
+  launch_scope ls(devid, "bilat_splat");
+  bilat_splat<<<(nodes + SPLAT_THREADS - 1) / SPLAT_THREADS, SPLAT_THREADS, (size_t)b.size_z * SPLAT_THREADS * sizeof(float), s>>>(
+      in_rows, buf, b, row_lo, row_hi, accumulate);
+}
+
+// dt_bilateral_blur() in place on the complete grid, then the slice of `rows` rows from frame row `row0`
+int bilat_blur_and_slice(int devid, const grid_t &b, float *buf, const dt_hip_bilat_data_t *d, const float4 *in_rows,
+                         float4 *out_rows, int row0, int rows)
+{
+  hipStream_t s = stream_of(devid);
+  const int ox = b.size_z, oy = b.size_x * b.size_z, oz = 1;
+  {
+    launch_scope ls(devid, "bilat_blur");
+    // dt_bilateral_blur(), bilateral.c:341-352
+    bilat_blur_line<<<(b.size_z * b.size_y + 63) / 64, 64, 0, s>>>(buf, oz, oy, ox, b.size_z, b.size_y, b.size_x);
+    bilat_blur_line<<<(b.size_z * b.size_x + 63) / 64, 64, 0, s>>>(buf, oz, ox, oy, b.size_z, b.size_x, b.size_y);
+    bilat_blur_line_z<<<(b.size_x * b.size_y + 63) / 64, 64, 0, s>>>(buf, ox, oy, oz, b.size_x, b.size_y, b.size_z);
+  }
+  {
+    const float norm = -d->detail * b.sigma_r * 0.04f;
+    launch_scope ls(devid, "bilat_slice");
+    bilat_slice<<<stream_grid((size_t)b.width * rows, 256), 256, 0, s>>>(in_rows, out_rows, buf, b, norm, row0, rows);
+  }
+  return check_launch("bilat");
+}
+} // namespace
+
+namespace ansel
+{
+// ---- row bands (pipe.cpp): the grid is ONE accumulation over the frame in pixel order, so the
+// bands splat one after the other into the same grid (a relay: band k starts from what bands 0..k-1 left, a few
+// hundred KB travelling from GPU to GPU), the last band's grid is broadcast, and every band blurs its copy and slices
+// its own rows.  Bit-identical to the unsplit module.
+int bilat_band_supported(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d)
+{
+  grid_t b;
+  return d->mode == DT_HIP_BILAT_BILATERAL && piece->channels == 4 && bilat_grid_of(piece, d, b) == DT_HIP_SUCCESS;
+}
+// allocates the zeroed grid of the frame; *bytes = its size
+int bilat_band_begin(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t *grid, size_t *bytes)
+{
+  grid_t b;
+  const int gerr = bilat_grid_of(piece, d, b);
+  if(gerr != DT_HIP_SUCCESS) return gerr;
+  *bytes = (size_t)b.size_x * b.size_y * b.size_z * sizeof(float);
+  *grid = dt_hip_alloc_device_buffer(devid, *bytes);
+  if(!*grid) return DT_HIP_SYSMEM_ALLOCATION;
+  if(hipMemsetAsync(*grid, 0, *bytes, stream_of(devid)) != hipSuccess) return DT_HIP_DEFAULT_ERROR;
+  return DT_HIP_SUCCESS;
+}
+// the band's rows [row0, row0 + rows) on top of what `grid` holds
+int bilat_band_splat(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t grid,
+                     dt_hip_mem_t in_rows, int row0, int rows)
+{
+  grid_t b;
+  const int gerr = bilat_grid_of(piece, d, b);
+  if(gerr != DT_HIP_SUCCESS) return gerr;
+  bilat_splat_rows(devid, b, (float *)grid, (const float4 *)in_rows, row0, row0 + rows, 1);
+  return check_launch("bilat_splat");
+}
+// `grid` = the complete splat of the frame: blur it (in place, this band's copy) and slice the band's rows
+int bilat_band_finish(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t grid,
+                      dt_hip_mem_t in_rows, dt_hip_mem_t out_rows, int row0, int rows)
+{
+  grid_t b;
+  const int gerr = bilat_grid_of(piece, d, b);
+  if(gerr != DT_HIP_SUCCESS) return gerr;
+  return bilat_blur_and_slice(devid, b, (float *)grid, d, (const float4 *)in_rows, (float4 *)out_rows, row0, rows);
+}
+} // namespace ansel
+
 extern "C" {
 
 int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in,
@@ -222,46 +326,17 @@ int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hi
     set_last_error("bilat: unknown mode %d", d->mode);
     return DT_HIP_INVALID_ARG;
   }
-  if(!(d->iscale > 0.0f) || !(piece->roi_in.scale > 0.0) || !(d->sigma_r > 0.0f)) return DT_HIP_INVALID_ARG;
-  const float scale = (float)(d->iscale / piece->roi_in.scale); // dt_dev_get_module_scale(), bilat.c:339
   grid_t b;
-  grid_size(b, width, height, 100.0f, d->sigma_s / scale, d->sigma_r);
-  if(b.size_x < 4 || b.size_y < 4 || b.size_z < 4)
-  {
-    // blur_line() / blur_line_z() (src/pixel/bilateral.c:266-340) touch four entries of every grid line
-    // unconditionally: on a shorter line the reference writes past it (heap corruption on the CPU)
-    set_last_error("bilat: a %d x %d x %d grid is below the 4 entries per line the reference's blur assumes", b.size_x,
-                   b.size_y, b.size_z);
-    return DT_HIP_INVALID_ARG;
-  }
+  const int gerr = bilat_grid_of(piece, d, b);
+  if(gerr != DT_HIP_SUCCESS) return gerr;
   const size_t cells = (size_t)b.size_x * b.size_y * b.size_z;
   float *buf = (float *)dt_hip_alloc_device_buffer(devid, cells * sizeof(float));
   if(!buf) return DT_HIP_SYSMEM_ALLOCATION;
-  hipStream_t s = stream_of(devid);
-  const int ox = b.size_z, oy = b.size_x * b.size_z, oz = 1;
-  {
-    const int nodes = b.size_x * b.size_y;
-    launch_scope ls(devid, "bilat_splat");
-    bilat_splat<<<(nodes + SPLAT_THREADS - 1) / SPLAT_THREADS, SPLAT_THREADS, (size_t)b.size_z * SPLAT_THREADS * sizeof(float),
-                  s>>>((const float4 *)dev_in, buf, b);
-  }
-  {
-    launch_scope ls(devid, "bilat_blur");
-    // dt_bilateral_blur(), bilateral.c:341-352
-    bilat_blur_line<<<(b.size_z * b.size_y + 63) / 64, 64, 0, s>>>(buf, oz, oy, ox, b.size_z, b.size_y, b.size_x);
-    bilat_blur_line<<<(b.size_z * b.size_x + 63) / 64, 64, 0, s>>>(buf, oz, ox, oy, b.size_z, b.size_x, b.size_y);
-    bilat_blur_line_z<<<(b.size_x * b.size_y + 63) / 64, 64, 0, s>>>(buf, ox, oy, oz, b.size_x, b.size_y, b.size_z);
-  }
-  {
-    const float norm = -d->detail * b.sigma_r * 0.04f;
-    launch_scope ls(devid, "bilat_slice");
-    bilat_slice<<<stream_grid((size_t)width * height, 256), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, buf, b,
-                                                                         norm);
-  }
+  bilat_splat_rows(devid, b, buf, (const float4 *)dev_in, 0, height, 0);
+  const int err = bilat_blur_and_slice(devid, b, buf, d, (const float4 *)dev_in, (float4 *)dev_out, 0, height);
   dt_hip_release_mem_object(buf);
-  return check_launch("bilat");
+  return err;
 }
-
 
 // tiling_callback(), src/iop/bilat.c:252-297.  factor / maxbuf / overlap are the reference's, for the host's own
 // tiling; factor_cl / maxbuf_cl are what THIS implementation holds on the device: in + out + one grid (the blur is

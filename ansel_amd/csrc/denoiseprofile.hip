@@ -291,6 +291,159 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
   }
 }
 
+// The same step on STRIPS: one workgroup = one 256-pixel segment x up to `strip` rows of one dilation class (rows c,
+// c + mult, c + 2 mult, ...: consecutive rows of the class share four of their five tap rows).  The tap rows live in a
+// ring of six LDS rows of 256 + 4 mult pixels (the segment and the 2 mult columns either side, clamped like the
+// reference's indices): per output row ONE new row is fetched -- while the previous output row is computed -- and the 25
+// taps are LDS reads, against 25 fetches per pixel through the vector L1 (64 B/clk per CU: ~400 cycles of the ~1 080 a
+// wave of the per-row kernel took).  Same taps in the same order, so the same binary32 values; the partial sums of
+// detail^2 leave in the same per-(row, segment) slots.
+#define DN_RING 6
+__global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
+                                                          float4 *__restrict__ detail, double *__restrict__ partial,
+                                                          const int width, const int height, const int mult,
+                                                          const float inv_sigma2, const int nseg, const int in_row0,
+                                                          const int in_rows, const int strip, const int strips_per_class)
+{
+  extern __shared__ float4 ring[]; // [DN_RING][256 + 4 * mult]
+  __shared__ double runs[2][4][4];
+  const int bx = blockIdx.x;
+  const int cls = blockIdx.y / strips_per_class, k0 = (blockIdx.y - cls * strips_per_class) * strip;
+  const int n_cls = (height - cls + mult - 1) / mult; // rows of this class
+  if(k0 >= n_cls) return;
+  const int nrows = min(strip, n_cls - k0);
+  const int r_first = cls + k0 * mult;
+  const int tw = 256 + 4 * mult;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = bx * 256 + tid;
+  // the one or two ring entries this thread fetches per row
+  const int ecol0 = clampi(bx * 256 - 2 * mult + tid, 0, width - 1), ecol1 = clampi(bx * 256 - 2 * mult + tid + 256, 0, width - 1);
+  const bool second = tid + 256 < tw;
+  // ring row q of the strip = frame row r_first + (q - 2) mult, clamped into the input buffer like the reference's taps
+#define DN_IN_ROW(q) ((size_t)clampi(r_first + ((q) - 2) * mult + in_row0, 0, in_rows - 1) * width)
+#pragma unroll
+  for(int q = 0; q < 4; q++)
+  {
+    const size_t y = DN_IN_ROW(q);
+    ring[q * tw + tid] = in[y + ecol0];
+    if(second) ring[q * tw + tid + 256] = in[y + ecol1];
+  }
+  float4 n0, n1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const size_t y = DN_IN_ROW(4);
+    n0 = in[y + ecol0];
+    if(second) n1 = in[y + ecol1];
+  }
+  int s0 = 0; // ring slot of row k
+  for(int k = 0; k < nrows; k++)
+  {
+    {
+      const int sl = s0 + 4 >= DN_RING ? s0 + 4 - DN_RING : s0 + 4;
+      ring[sl * tw + tid] = n0;
+      if(second) ring[sl * tw + tid + 256] = n1;
+    }
+    __syncthreads();
+    if(k > 0 && tid < 4)
+    {
+      // the previous row's segment sum (its four run sums were complete at the barrier)
+      const int c = tid, pr = (k - 1) & 1;
+      const double seg = ((runs[pr][0][c] + runs[pr][1][c]) + runs[pr][2][c]) + runs[pr][3][c];
+      partial[4 * ((size_t)(r_first + (k - 1) * mult) * nseg + bx) + c] = seg;
+    }
+    if(k + 1 < nrows)
+    {
+      const size_t y = DN_IN_ROW(k + 5);
+      n0 = in[y + ecol0];
+      if(second) n1 = in[y + ecol1];
+    }
+    const int row = r_first + k * mult;
+    double sq[4] = { 0.0, 0.0, 0.0, 0.0 };
+    if(col < width)
+    {
+      const int sc = s0 + 2 >= DN_RING ? s0 + 2 - DN_RING : s0 + 2;
+      const float4 px = ring[sc * tw + tid + 2 * mult];
+      float sum[4] = { 0.f, 0.f, 0.f, 0.f }, wgt = 0.f;
+#pragma unroll
+      for(int jj = 0; jj < 5; jj++)
+      {
+        const int sl = s0 + jj >= DN_RING ? s0 + jj - DN_RING : s0 + jj;
+        const float4 *const line = ring + sl * tw + tid;
+        const float fj = jj == 0 || jj == 4 ? 0.0625f : (jj == 2 ? 0.375f : 0.25f);
+        float4 tap[5];
+#pragma unroll
+        for(int ii = 0; ii < 5; ii++) tap[ii] = line[ii * mult];
+#pragma unroll
+        for(int ii = 0; ii < 5; ii++)
+        {
+          const float fi = ii == 0 || ii == 4 ? 0.0625f : (ii == 2 ? 0.375f : 0.25f);
+          const float4 p2 = tap[ii];
+          // dn_weight(), eaw.c:181-195
+          const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
+          const float dot = (dx * dx + dy * dy + dz * dz) * inv_sigma2;
+          const float arg = dot * 0.02f - 9.0f;
+          const float wp = mexp2(0 > arg ? 0.0f : arg);
+          const float w = (fi * fj) * wp;
+          wgt += w;
+          sum[0] += w * p2.x;
+          sum[1] += w * p2.y;
+          sum[2] += w * p2.z;
+          sum[3] += w * p2.w;
+        }
+        // five reads in flight, not twenty-five: the next row's reads stay behind the sums of this one
+        asm volatile("" : "+v"(wgt), "+v"(sum[0]), "+v"(sum[1]), "+v"(sum[2]), "+v"(sum[3]) : : "memory");
+      }
+      float c4[4], d4[4];
+      const float pin[4] = { px.x, px.y, px.z, px.w };
+#pragma unroll
+      for(int c = 0; c < 4; c++)
+      {
+        c4[c] = sum[c] / wgt;
+        d4[c] = pin[c] - c4[c];
+        sq[c] = (double)(d4[c] * d4[c]);
+      }
+      const size_t o = (size_t)row * width + col;
+      coarse[o] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+      detail[o] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+    }
+#pragma unroll
+    for(int c = 0; c < 4; c++)
+    {
+      const double s = wave_sum_halving(sq[c]);
+      if(lane == 0) runs[k & 1][wave][c] = s;
+    }
+    s0 = s0 + 1 == DN_RING ? 0 : s0 + 1;
+  }
+#undef DN_IN_ROW
+  __syncthreads();
+  if(tid < 4)
+  {
+    const int c = tid, pr = (nrows - 1) & 1;
+    const double seg = ((runs[pr][0][c] + runs[pr][1][c]) + runs[pr][2][c]) + runs[pr][3][c];
+    partial[4 * ((size_t)(r_first + (nrows - 1) * mult) * nseg + bx) + c] = seg;
+  }
+}
+
+// one a-trous step of `height` rows (see dn_decompose for in_row0 / in_rows)
+static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, float4 *detail, double *partial, const int width,
+                             const int height, const int mult, const float inv_sigma2, const int nseg, const int in_row0,
+                             const int in_rows)
+{
+  static const bool per_row = getenv("ANSEL_HIP_DN_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
+  if(per_row)
+  {
+    const int rows = (height <= mult) ? height : ((height + mult - 1) / mult) * mult;
+    dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg,
+                                                            in_row0, in_rows);
+    return;
+  }
+  const int classes = height < mult ? height : mult, per_class = (height + mult - 1) / mult;
+  int strip = 32;
+  while(strip > 4 && (size_t)nseg * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
+  const int strips_per_class = (per_class + strip - 1) / strip;
+  dn_decompose_strip<<<dim3(nseg, classes * strips_per_class), 256, (size_t)DN_RING * (256 + 4 * mult) * sizeof(float4), st>>>(
+      in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0, in_rows, strip, strips_per_class);
+}
+
 struct thr_args
 {
   size_t n_partial;
@@ -807,13 +960,10 @@ int denoiseprofile_band_step(dn_band_job_t *j, dt_hip_mem_t *halo_buf, int *halo
   }
   const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
   const float sigma_band = powf(varf, scale) * 1.0f;
-  const int rows = (j->rows <= mult) ? j->rows : ((j->rows + mult - 1) / mult) * mult;
   {
     launch_scope ls(devid, "dn_decompose");
-    dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(j->cur, coarse + (size_t)top * w, j->det[scale],
-                                                                               j->local, w, j->rows, mult,
-                                                                               1.0f / (sigma_band * sigma_band), nseg, j->cur_top,
-                                                                               j->cur_top + j->rows + j->cur_bottom);
+    launch_decompose(st, j->cur, coarse + (size_t)top * w, j->det[scale], j->local, w, j->rows, mult,
+                     1.0f / (sigma_band * sigma_band), nseg, j->cur_top, j->cur_top + j->rows + j->cur_bottom);
   }
   int err = check_launch("denoiseprofile band decompose");
   // the own rows' partial sums at their place in the frame's table
@@ -939,11 +1089,9 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
     const int mult = 1 << scale;
     const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
     const float sigma_band = powf(varf, scale) * 1.0f;
-    const int rows = (h <= mult) ? h : ((h + mult - 1) / mult) * mult;
     {
       launch_scope ls(devid, "dn_decompose");
-      dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(b1, b2, det[scale], partial, w, h, mult,
-                                                                                 1.0f / (sigma_band * sigma_band), nseg, 0, h);
+      launch_decompose(st, b1, b2, det[scale], partial, w, h, mult, 1.0f / (sigma_band * sigma_band), nseg, 0, h);
     }
     thr_args ta;
     ta.n_partial = n_partial;

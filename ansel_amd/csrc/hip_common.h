@@ -137,6 +137,15 @@ int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_h
 int denoiseprofile_band_step(dn_band_job_t *job, dt_hip_mem_t *halo_buf, int *halo_rows, double **sums, size_t *sum_count);
 int denoiseprofile_band_finish(dn_band_job_t *job, dt_hip_mem_t dev_out);
 void denoiseprofile_band_abort(dn_band_job_t *job);
+// local contrast (bilateral grid) on row bands: the grid is one accumulation over the frame in pixel order, so the bands
+// take turns (bilat.hip).  begin: the zeroed grid of the frame; splat: the band's rows on top of what the grid holds;
+// finish: blur of the complete grid (this band's copy) and the slice of the band's rows
+int bilat_band_supported(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d);
+int bilat_band_begin(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t *grid, size_t *bytes);
+int bilat_band_splat(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t grid,
+                     dt_hip_mem_t in_rows, int row0, int rows);
+int bilat_band_finish(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t grid,
+                      dt_hip_mem_t in_rows, dt_hip_mem_t out_rows, int row0, int rows);
 
 // Grid for a grid-stride streaming kernel: enough workgroups to fill 256 CUs x 8 and no more
 // (cdna_hip_programming.md Guideline 11).

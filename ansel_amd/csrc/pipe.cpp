@@ -405,6 +405,8 @@ struct band_priv_t
   dt_hip_mem_t held, held_base; // own rows of the input of a module whose output is about to be blended
   bool held_owned;
   dn_band_job_t *dn_job;
+  dt_hip_mem_t relay;  // local contrast: this band's copy of the frame's bilateral grid
+  size_t relay_bytes;
 };
 
 bool is_stencil_op(op_t o) { return o == OP_DENOISEPROFILE || o == OP_DIFFUSE || o == OP_NLMEANS; }
@@ -624,11 +626,16 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
   if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
   for(const node_t &n : pipe->nodes)
   {
-    if(n.op == OP_BILAT || n.op == OP_FINALSCALE)
+    if(n.op == OP_FINALSCALE)
     {
-      // the bilateral grid is one accumulation over the whole frame in pixel order; finalscale
-      // changes the geometry
+      // finalscale changes the geometry
       set_last_error("band mode: '%s' has no row-band implementation", k_ops[n.op].name);
+      return DT_HIP_INVALID_ARG;
+    }
+    if(n.op == OP_BILAT && !bilat_band_supported(&n.piece, n.as<dt_hip_bilat_data_t>()))
+    {
+      // the bilateral grid is relayed from band to band; the local laplacian's pyramid is not
+      set_last_error("band mode: local contrast runs on row bands in its bilateral-grid mode only");
       return DT_HIP_INVALID_ARG;
     }
     if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->form_mask)
@@ -930,6 +937,26 @@ int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_b
         fail(DT_HIP_DEFAULT_ERROR);
         errors[k] = "dt_hip_pipe_process_bands: the bands did not stop at the same module";
         return;
+      }
+      if(st[k].relay_buf)
+      {
+        // local contrast: the bands splat their rows into the grid one after the other (the frame's pixel order), each
+        // starting from the grid its predecessor left; the last band's grid is the frame's and goes to everybody
+        bool relay_ok = true;
+        for(int turn = 0; turn < n && relay_ok; turn++)
+        {
+          if(turn == k)
+          {
+            if(k > 0 && (rc = copy_between(devid, st[k].relay_buf, pipes[k - 1]->devid, st[k - 1].relay_buf, st[k].relay_bytes, s)) != DT_HIP_SUCCESS)
+              fail(rc);
+            else if((rc = dt_hip_pipe_band_relay(pipe, &b, &st[k])) != DT_HIP_SUCCESS)
+              fail(rc);
+          }
+          relay_ok = meet();
+        }
+        if(!relay_ok) return give_up();
+        if(k + 1 < n && (rc = copy_between(devid, st[k].relay_buf, pipes[n - 1]->devid, st[n - 1].relay_buf, st[k].relay_bytes, s)) != DT_HIP_SUCCESS)
+          fail(rc);
       }
       if(st[k].sum_buf && st[k].sum_planes > 0)
       {
@@ -1457,6 +1484,7 @@ void dt_hip_pipe_band_abort(dt_hip_pipe_t *pipe, dt_hip_band_state_t *state)
   if(pv->held_owned && pv->held_base) dt_hip_release_mem_object(pv->held_base);
   if(pv->journal) dt_hip_release_mem_object(pv->journal);
   if(pv->dn_job) denoiseprofile_band_abort(pv->dn_job);
+  if(pv->relay) dt_hip_release_mem_object(pv->relay);
   delete pv;
   memset(state, 0, sizeof(*state));
 }
@@ -1477,6 +1505,22 @@ int dt_hip_band_halo_rows(const char *op, const dt_hip_piece_t *piece, const voi
 // Resumable: returns DT_HIP_BAND_EXCHANGE in front of a stencil module (fill the halo rows of state->halo_buf)
 // and in the middle of the profiled wavelets (all-reduce state->sum_buf); the caller does what the state
 // asks for and calls again with the same arguments.
+// The band's turn in a relay stop: its rows of the module input are accumulated on top of what relay_buf holds (the
+// grid bands 0 .. k-1 left, copied in by the driver).
+int dt_hip_pipe_band_relay(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state)
+{
+  if(!pipe || !band || !state || !state->priv) return DT_HIP_INVALID_ARG;
+  band_priv_t *pv = (band_priv_t *)state->priv;
+  if(!pv->walking || !pv->relay || pv->next_group >= pipe->groups.size())
+  {
+    set_last_error("dt_hip_pipe_band_relay: the band is not at a relay stop");
+    return DT_HIP_INVALID_ARG;
+  }
+  const node_t &n = pipe->nodes[pipe->groups[pv->next_group].first];
+  if(n.op != OP_BILAT || pv->stage != 1) return DT_HIP_INVALID_ARG;
+  return bilat_band_splat(pipe->devid, &n.piece, n.as<dt_hip_bilat_data_t>(), pv->relay, pv->cur, band->row0, band->rows);
+}
+
 int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state,
                             dt_hip_mem_t dev_out_band)
 {
@@ -1492,6 +1536,8 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
   state->sum_buf = nullptr;
   state->sum_count = 0;
   state->sum_planes = 0;
+  state->relay_buf = nullptr;
+  state->relay_bytes = 0;
   if(!pv->walking)
   {
     if(pv->journal) err = dt_hip_pipe_band_resolve(pipe, band, state); // caller skipped the explicit step
@@ -1554,6 +1600,44 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
       if(pv->held_owned && pv->held_base) dt_hip_release_mem_object(pv->held_base);
       pv->held = pv->held_base = nullptr;
       pv->held_owned = false;
+      pv->next_group++;
+      continue;
+    }
+    if(g.kind == group_t::SINGLE && first.op == OP_BILAT)
+    {
+      // the bilateral grid: a relay stop (every band splats its rows in turn), then blur + slice of the own rows
+      const dt_hip_bilat_data_t *d = first.as<dt_hip_bilat_data_t>();
+      if(pv->stage == 0)
+      {
+        err = bilat_band_begin(devid, &first.piece, d, &pv->relay, &pv->relay_bytes);
+        if(err != DT_HIP_SUCCESS) break;
+        pv->stage = 1;
+        state->relay_buf = pv->relay;
+        state->relay_bytes = pv->relay_bytes;
+        return DT_HIP_BAND_EXCHANGE;
+      }
+      dt_hip_mem_t out = dev_out_band;
+      if(!final_group)
+      {
+        out = dt_hip_alloc_device_buffer(devid, (size_t)b.rows * rgba_row);
+        if(!out)
+        {
+          err = DT_HIP_SYSMEM_ALLOCATION;
+          break;
+        }
+      }
+      err = bilat_band_finish(devid, &first.piece, d, pv->relay, pv->cur, out, b.row0, b.rows);
+      dt_hip_release_mem_object(pv->relay); // stream-ordered
+      pv->relay = nullptr;
+      if(err != DT_HIP_SUCCESS)
+      {
+        if(out != dev_out_band) dt_hip_release_mem_object(out);
+        break;
+      }
+      retire_cur(gi);
+      pv->cur = pv->cur_base = out;
+      pv->cur_owned = out != dev_out_band;
+      pv->stage = 0;
       pv->next_group++;
       continue;
     }

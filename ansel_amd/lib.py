@@ -151,6 +151,7 @@ def load():
         "dt_hip_pipe_band_begin": (i, [vp, P(abi.Band), vp, P(abi.BandState)]),
         "dt_hip_pipe_band_resolve": (i, [vp, P(abi.Band), P(abi.BandState)]),
         "dt_hip_pipe_band_finish": (i, [vp, P(abi.Band), P(abi.BandState), vp]),
+        "dt_hip_pipe_band_relay": (i, [vp, P(abi.Band), P(abi.BandState)]),
         "dt_hip_pipe_band_abort": (None, [vp, P(abi.BandState)]),
         "dt_hip_pipe_process_bands": (i, [P(vp), i, P(abi.Band), P(vp), P(vp)]),
         "dt_hip_iop_highlights_process_deferred": (i, [i, P(abi.Piece), P(abi.HighlightsData), vp, vp, vp]),

@@ -17,6 +17,9 @@ stops in front of such a module and hands back a BandRequest --
     request.halo    RGBA rows [min(h, row0)][rows][min(h, H - row1)]: send/recv of h rows with each neighbour
     request.sums    the frame-wide table of the profiled wavelets' partial sums, own entries filled, the rest
                     zero: all-reduce(SUM), exact in any order
+    request.relay   local contrast's bilateral grid (one accumulation over the frame in pixel order): the bands take
+                    turns -- recv from the band above, engine.relay() adds the own rows, send to the band below --
+                    and the last band broadcasts the complete grid (a few hundred KB per hop)
 
 -- the driver serves it and calls finish() again (serve_request / process_band below).
 The communication layer is torch.distributed ("nccl" is RCCL on ROCm; "gloo" in the CPU tests);
@@ -57,12 +60,13 @@ class BandWork:
 class BandRequest:
     """what a resumable engine.finish() asks of the other bands: `halo` = the [top][rows][bottom] rows of the
     module input whose first / last part the neighbours fill (`h` rows each, clipped at the frame), `sums` =
-    a float64 vector to all-reduce; either may be None"""
+    a float64 vector to all-reduce, `relay` = a buffer the bands fill in turn (engine.relay()); each may be None"""
 
-    def __init__(self, halo, h, sums):
+    def __init__(self, halo, h, sums, relay=None):
         self.halo = halo
         self.h = h
         self.sums = sums
+        self.relay = relay
 
 
 class _DevicePtr:
@@ -116,14 +120,21 @@ class HipBandEngine:
         if rc != abi.DT_HIP_BAND_EXCHANGE:
             lib.check(rc, "dt_hip_pipe_band_finish")
             return None
-        halo = sums = None
+        halo = sums = relay = None
+        if st.relay_buf:
+            relay = device_view(st.relay_buf, (st.relay_bytes // 4,), "<f4", self.device)
         if st.halo_rows > 0:
             top = min(st.halo_rows, band.row0)
             bottom = min(st.halo_rows, self.frame_height - band.row0 - band.rows)
             halo = device_view(st.halo_buf, (top + band.rows + bottom, st.row_bytes // 4), "<f4", self.device)
         if st.sum_buf:
             sums = device_view(st.sum_buf, (st.sum_count,), "<f8", self.device)
-        return BandRequest(halo, st.halo_rows, sums)
+        return BandRequest(halo, st.halo_rows, sums, relay)
+
+    def relay(self, band, work):
+        """this band's turn in a relay stop: its rows on top of what the relay buffer holds"""
+        lib.check(self.lib.dt_hip_pipe_band_relay(self.pipe.handle, C.byref(band), C.byref(work.token)),
+                  "dt_hip_pipe_band_relay")
 
     def abort(self, work):
         """free a band whose walk will not be finished"""
@@ -167,9 +178,18 @@ def _halo_parts(bands, k, h, height):
     return min(h, b.row0), min(h, height - b.row0 - b.rows)
 
 
-def serve_request(req, bands, rank, dist=None, group=None):
-    """the collectives of one BandRequest (no-ops for one band)"""
+def serve_request(req, bands, rank, dist=None, group=None, engine=None, work=None):
+    """the collectives of one BandRequest (no-ops for one band, except the band's own turn of a relay)"""
     n = len(bands)
+    if req.relay is not None:
+        many = n > 1 and dist is not None
+        if many and rank > 0:
+            dist.recv(req.relay, src=rank - 1, group=group)
+        engine.relay(bands[rank], work)
+        if many and rank + 1 < n:
+            dist.send(req.relay, dst=rank + 1, group=group)
+        if many:
+            dist.broadcast(req.relay, src=n - 1, group=group)
     if n == 1 or dist is None:
         return
     if req.sums is not None:
@@ -208,7 +228,7 @@ def process_band(engine, bands, rank, dev_in_band, dev_out_band, width, dist=Non
             req = engine.finish(band, work, dev_out_band)
             if req is None:
                 break
-            serve_request(req, bands, rank, dist, group)
+            serve_request(req, bands, rank, dist, group, engine, work)
     except Exception:
         if hasattr(engine, "abort"):
             engine.abort(work)  # a finish() that failed has freed the state already: abort is then a no-op
@@ -233,6 +253,13 @@ def process_bands_locally(engine, bands, ins, outs, width):
         if all(r is None for r in reqs):
             return
         assert all(r is not None for r in reqs), "the bands of a frame stop at the same modules"
+        if reqs[0].relay is not None:
+            for k, (r, b, w) in enumerate(zip(reqs, bands, works)):
+                if k:
+                    r.relay.copy_(reqs[k - 1].relay)
+                engine.relay(b, w)
+            for r in reqs[:-1]:
+                r.relay.copy_(reqs[-1].relay)
         if reqs[0].sums is not None:
             total = reqs[0].sums.clone()
             for r in reqs[1:]:

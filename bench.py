@@ -121,7 +121,7 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
     """The reference's own process() code (oracle/_ref/libansel_ref_fast.so: its sources compiled in place with
     its release flags, OpenMP) on a bounded sample of the same workload: threads bound to cores
     (OMP_PROC_BIND=spread, OMP_PLACES=cores -- set in main() before the OpenMP runtime starts), the thread count
-    swept over {32, 64, 128, all} on the sample frame and the best kept; when a pass at that count is short enough,
+    swept over {16, 32, 64, 128, all} on the sample frame and the best kept; when a pass at that count is short enough,
     one more pass on the DEVICE's frame size replaces the sample.  Buffers are first touched by the OpenMP team
     (the warm-up pass), so pages land on the NUMA node of the thread that streams them.  Falls back to the C
     restatement (kind "port") where _ref is absent."""
@@ -152,7 +152,7 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
     w, h = frame_size(size_name)
     nodes = build_pipe(w, h, lut.ctypes.data, lut, with_filmic, which)
     raw, cfa, rgb, out16 = buffers(w, h)
-    counts = sorted({c for c in (32, 64, 128, ncpu) if c <= ncpu} | {ncpu})
+    counts = sorted({c for c in (16, 32, 64, 128, ncpu) if c <= ncpu} | {ncpu})
     sweep = {}
     t_budget = time.time() + 25.0
     for c in reversed(counts):  # all cores first: its warm-up is the parallel first touch

@@ -725,6 +725,12 @@ typedef struct dt_hip_band_state_t
                          only non-zero entries of its table, so SUM over the bands is an all-gather of row segments */
   double *sum_buf;
   size_t sum_count;
+  /* a RELAY stop (local contrast, bilateral grid: one accumulation over the frame in pixel order): relay_buf is this
+   * band's copy of the frame's grid (relay_bytes).  The driver, for the bands in order 0 .. n-1: copies band k-1's
+   * relay_buf into band k's (k > 0), calls dt_hip_pipe_band_relay() for band k (its rows are accumulated on top);
+   * then copies band n-1's relay_buf -- the complete grid -- into every other band's, and resumes the walk. */
+  dt_hip_mem_t relay_buf;
+  size_t relay_bytes;
 } dt_hip_band_state_t;
 /* pure function (no device needed): cut a height-row frame into n_bands bands for the given
  * demosaic method (DT_HIP_DEMOSAIC_RCD, or -1 for a pipe without demosaic: 2-row aligned cuts) */
@@ -737,6 +743,8 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
 int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state);
 int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state,
                             dt_hip_mem_t dev_out_band);
+/* the band's turn in a relay stop (see dt_hip_band_state_t.relay_buf) */
+int dt_hip_pipe_band_relay(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hip_band_state_t *state);
 /* give up a band whose walk has not ended (an error on another rank, a cancelled export): frees the state */
 void dt_hip_pipe_band_abort(dt_hip_pipe_t *pipe, dt_hip_band_state_t *state);
 /* The whole walk from ONE process, for a host that is one C process like the reference (src/develop/pixelpipe_hb.c:1470

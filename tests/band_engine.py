@@ -83,9 +83,14 @@ class OracleBandEngine:
         if getattr(work, "walk", None) is None:
             work.walk = self._walk(band, work, out_band)
         try:
-            return next(work.walk)
+            work.req = next(work.walk)
+            return work.req
         except StopIteration:
             return None
+
+    def relay(self, band, work):
+        work.relay_frame = work.req.relay
+        work.relay_frame.numpy().reshape(self.h, self.w, 4)[band.row0:band.row0 + band.rows] = work.relay_rows
 
     def _stencil(self, n, band, src):
         """a stencil module on a band.  The module input of the band + the halo rows the driver fetched go into
@@ -136,6 +141,16 @@ class OracleBandEngine:
                 # dt_develop_blend_process(): blend(input of the module, output of the module) in place
                 assert ck.call(self.l, "oracle_develop_blend", _band_piece(n.piece, band), n.data,
                                np.ascontiguousarray(held), src) == 0
+            elif n.op == "bilat":
+                # the relay stop, the blunt way: the frame of module inputs is what travels from band to band (each
+                # adds its rows), the oracle runs on the frame the last band broadcasts
+                work.relay_rows = src
+                yield BandRequest(None, 0, None, torch.zeros((h * w * 4,), dtype=torch.float32))
+                frame_in = work.relay_frame.numpy().reshape(h, w, 4)
+                full = np.zeros((h, w, 4), np.float32)
+                assert ck.call(self.l, "oracle_bilat", n.piece, n.data, np.ascontiguousarray(frame_in), full) == 0
+                held = src
+                src = np.ascontiguousarray(full[band.row0:band.row0 + rows])
             elif n.op in STENCIL_OPS:
                 held = src
                 src = yield from self._stencil(n, band, src)

@@ -126,13 +126,15 @@ def test_rccl_accepts_runtime_owned_buffers():
 def _full_nodes(w, h, d_lut, lut, which):
     from ansel_amd import abi
     nodes = pipe.denoise_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
-                                    filmic=filmic.default_data(), diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
+                                    filmic=filmic.default_data(), diffuse_iterations=2, with_nlmeans=True,
+                                    with_bilat=which in ("bilat", "bilat_fine", "everything"))
     drop = {"wavelets": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "diffuse": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "diffuse_inpaint": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "nlmeans": ("denoiseprofile", "diffuse"),
             "dn_nlmeans": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
-            "blended": (), "all": ()}[which]
+            "bilat": ("denoiseprofile", "diffuse", "nlmeans"), "bilat_fine": ("denoiseprofile", "diffuse", "nlmeans"),
+            "blended": (), "all": (), "everything": ()}[which]
     nodes = [n for n in nodes if n.op not in drop]
     if which == "blended":
         # blends on a pointwise module (uniform) and on two stencil modules (parametric masks, tone curve); the last
@@ -156,6 +158,11 @@ def _full_nodes(w, h, d_lut, lut, which):
         for n in nodes:
             if n.op == "diffuse":
                 n.data = params.diffuse("inpaint_highlights", iterations=2, threshold=0.05)
+    if which == "bilat_fine":
+        # a fine grid: many grid rows per band, band borders inside grid cells
+        for n in nodes:
+            if n.op == "bilat":
+                n.data = abi.BilatData.bilateral(sigma_s=7.0, sigma_r=9.0, detail=-0.6)
     if which == "dn_nlmeans":
         for n in nodes:
             if n.op == "denoiseprofile":
@@ -163,11 +170,13 @@ def _full_nodes(w, h, d_lut, lut, which):
     return nodes
 
 
-@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "blended", "all"])
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "blended", "all", "bilat",
+                                   "bilat_fine", "everything"])
 @pytest.mark.parametrize("w,h,n", [(752, 2000, 2), (752, 2000, 5), (400, 640, 2), (400, 640, 1)])
 def test_full_pipe_bands_equal_the_unsplit_frame(w, h, n, which):
     """denoise (profiled) wavelets / non-local means, diffuse-or-sharpen and nlmeans on row bands: halo rows
-    from the neighbours, the wavelets' thresholds from the frame-wide sums -- bit-identical to the unsplit run"""
+    from the neighbours, the wavelets' thresholds from the frame-wide sums, local contrast's bilateral grid relayed
+    from band to band -- bit-identical to the unsplit run"""
     torch, lut, d_lut = _setup()
     nodes = _full_nodes(w, h, d_lut, lut, which)
     raw = synth.bayer_mosaic(w, h, seed=7)
@@ -219,14 +228,15 @@ def test_blended_pipe_closed_by_a_blend_on_bands():
     p.close()
 
 
-def test_band_abort_frees_what_a_stopped_walk_holds():
+@pytest.mark.parametrize("which", ["all", "everything"])
+def test_band_abort_frees_what_a_stopped_walk_holds(which):
     """dt_hip_pipe_band_abort(): a band given up at any stop of the walk (an error on another rank, a cancelled export)
     returns every buffer it holds to the pool"""
     import ctypes as C
     torch, lut, d_lut = _setup()
     l = lib.load()
     w, h = 400, 640
-    nodes = _full_nodes(w, h, d_lut, lut, "all")
+    nodes = _full_nodes(w, h, d_lut, lut, which)
     raw = synth.bayer_mosaic(w, h, seed=7)
     p = pipe.DevicePipe(0, nodes)
     engine = tiled.HipBandEngine(p, "cuda:0")
@@ -237,7 +247,7 @@ def test_band_abort_frees_what_a_stopped_walk_holds():
     torch.cuda.synchronize()
     l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
     base = cur.value
-    for stops in range(0, 12):
+    for stops in range(0, 14):
         work = engine.begin(bands[0], d_in.data_ptr(), w)
         engine.resolve(bands[0], work)
         done = False
@@ -258,16 +268,26 @@ def test_band_abort_frees_what_a_stopped_walk_holds():
     p.close()
 
 
+def _laplacian_nodes(w, h, d_lut, lut):
+    """local contrast in its local-laplacian mode: a pyramid over the frame, no row-band implementation"""
+    from ansel_amd import abi
+    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
+                                    filmic=filmic.default_data(), with_nlmeans=True, with_bilat=True)
+    for n in nodes:
+        if n.op == "bilat":
+            n.data = abi.BilatData.local_laplacian()
+    return nodes
+
+
 def test_modules_without_a_band_mode_are_refused():
     torch, lut, d_lut = _setup()
     w, h = 400, 640
-    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
-                                    filmic=filmic.default_data(), with_nlmeans=True, with_bilat=True)
+    nodes = _laplacian_nodes(w, h, d_lut, lut)
     p = pipe.DevicePipe(0, nodes)
     engine = tiled.HipBandEngine(p, "cuda:0")
     bands = tiled.plan_bands(w, h, 2)
     d_in = torch.zeros((bands[0].rows, w), dtype=torch.int16, device="cuda:0")
-    with pytest.raises(lib.AnselHipError, match="bilat"):
+    with pytest.raises(lib.AnselHipError, match="bilateral-grid mode only"):
         engine.begin(bands[0], d_in.data_ptr(), w)
     p.close()
 
@@ -308,7 +328,7 @@ def test_c_driver_decides_the_highlights_bypass_on_the_whole_frame(n_top, n_bott
     assert np.array_equal(_c_driver(torch, nodes, raw, w, h, 3), _whole(torch, nodes, raw, w, h, True))
 
 
-@pytest.mark.parametrize("which", ["wavelets", "diffuse", "nlmeans", "blended", "all"])
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "nlmeans", "blended", "all", "bilat", "bilat_fine", "everything"])
 @pytest.mark.parametrize("w,h,n", [(752, 2000, 5), (400, 640, 2)])
 def test_c_driver_full_pipe_equals_the_unsplit_frame(w, h, n, which):
     """halo pulls between the bands' buffers and the all-gather of the wavelets' partial sums, done by the library"""
@@ -321,10 +341,9 @@ def test_c_driver_full_pipe_equals_the_unsplit_frame(w, h, n, which):
 def test_c_driver_reports_the_band_that_failed():
     torch, lut, d_lut = _setup()
     w, h = 400, 640
-    nodes = pipe.denoise_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
-                                    filmic=filmic.default_data(), with_nlmeans=True, with_bilat=True)  # bilat: no band mode
+    nodes = _laplacian_nodes(w, h, d_lut, lut)
     raw = synth.bayer_mosaic(w, h, seed=7)
-    with pytest.raises(lib.AnselHipError, match="bilat"):
+    with pytest.raises(lib.AnselHipError, match="bilateral-grid mode only"):
         _c_driver(torch, nodes, raw, w, h, 2)
     # and the pool is back where it was
     import ctypes as C

@@ -123,13 +123,13 @@ def test_local_protocol_matches_the_unsplit_frame_for_three_bands(n_top, n_botto
 def _full_nodes(w, h, lut, which):
     coeffs = params.unbounded_coeffs(lut)
     nodes = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, filmic=filmic.default_data(),
-                                    diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
+                                    diffuse_iterations=2, with_nlmeans=True, with_bilat=which in ("bilat", "everything"))
     drop = {"wavelets": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "diffuse": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "diffuse_inpaint": ("denoiseprofile", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
             "nlmeans": ("denoiseprofile", "diffuse"),
             "dn_nlmeans": ("diffuse", "nlmeans", "rgb_to_lab", "lab_to_rgb"),
-            "blended": (), "all": ()}[which]
+            "bilat": ("denoiseprofile", "diffuse", "nlmeans"), "blended": (), "all": (), "everything": ()}[which]
     nodes = [n for n in nodes if n.op not in drop]
     if which == "blended":
         # blends on a pointwise module (uniform) and on two stencil modules (parametric masks, tone curve); the last
@@ -209,7 +209,8 @@ def _full_rank_main(rank, world, port, w, h, which, outdir):
 
 
 @needs_oracle
-@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "blended", "all"])
+@pytest.mark.parametrize("which", ["wavelets", "diffuse", "diffuse_inpaint", "nlmeans", "dn_nlmeans", "blended", "all", "bilat",
+                                   "everything"])
 def test_two_ranks_full_pipe_over_gloo_equal_the_unsplit_frame(tmp_path, which):
     """halo send/recv of float4 rows + the all-reduce of the wavelets, and the halo sizes themselves: a band cut
     from a frame that is zero beyond the halo equals the rows of the real frame only if the halo is enough"""
@@ -224,10 +225,11 @@ def test_two_ranks_full_pipe_over_gloo_equal_the_unsplit_frame(tmp_path, which):
 
 
 @needs_oracle
-def test_local_protocol_full_pipe_three_bands():
+@pytest.mark.parametrize("which", ["all", "everything"])
+def test_local_protocol_full_pipe_three_bands(which):
     w, h, n = 128, 480, 3
     lut = params.srgb_encode_lut()
-    nodes = _full_nodes(w, h, lut, "all")
+    nodes = _full_nodes(w, h, lut, which)
     raw = be.test_frame(w, h, 4, 30)
     bands = tiled.plan_bands(w, h, n)
     engine = be.OracleBandEngine(nodes, w, h)
