@@ -24,6 +24,8 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 
 # per-file extra flags
 EXTRA = {
+    # memory-bound float4 taps: the one kernel that gains from the SLP vectoriser
+    "diffuse_bspline.hip": ["-fslp-vectorize"],
     # rcd_demosaic() runs with FTZ/DAZ set (src/iop/demosaic/rcd.c:300)
     # -fno-slp-vectorize: the SLP vectoriser pairs binary32 operations into v_pk_*_f32, which issue at half rate on
     # gfx950 (no gain over two scalar operations) and need their operands in adjacent registers (560 v_mov in this
