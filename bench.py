@@ -32,6 +32,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -120,7 +121,7 @@ def _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16):
 def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
     """The reference's own process() code (oracle/_ref/libansel_ref_fast.so: its sources compiled in place with
     its release flags, OpenMP) on a bounded sample of the same workload: threads bound to cores
-    (OMP_PROC_BIND=spread, OMP_PLACES=cores -- set in main() before the OpenMP runtime starts), the thread count
+    (OMP_PROC_BIND=spread, OMP_PLACES=cores -- set by cpu_baseline_in_child() for a fresh process), the thread count
     swept over {16, 32, 64, 128, all} on the sample frame and the best kept; when a pass at that count is short enough,
     one more pass on the DEVICE's frame size replaces the sample.  Buffers are first touched by the OpenMP team
     (the warm-up pass), so pages land on the NUMA node of the thread that streams them.  Falls back to the C
@@ -155,7 +156,9 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
     counts = sorted({c for c in (16, 32, 64, 128, ncpu) if c <= ncpu} | {ncpu})
     sweep = {}
     t_budget = time.time() + 25.0
-    for c in reversed(counts):  # all cores first: its warm-up is the parallel first touch
+    # 32 first (the count that has won every sweep on the 256-thread hosts), then outwards: the slow all-threads pass
+    # comes last and is skipped when the budget is spent
+    for c in sorted(counts, key=lambda c: (abs(c - 32), c)):
         set_threads(c)
         _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16)  # warm-up: page in, spin up the team
         times = []
@@ -190,6 +193,27 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
             "host_threads": ncpu,
             "binding": "OMP_PROC_BIND=%s OMP_PLACES=%s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
             "thread_sweep_mpix_s": {str(c): round(w * h / 1e6 / t, 3) for c, t in sorted(sweep.items())}}
+
+
+def cpu_baseline_in_child(size_name, with_filmic, which, device_size):
+    """cpu_baseline() in a process of its own: the OpenMP runtime reads its binding once, when it starts, and this
+    process has started it long ago (torch, the oracle's verify pass) -- with threads bound here the same 24 MP chain
+    ran at 5.8 MPix/s against 57 MPix/s in a fresh process (profiles/r02_cpu_baseline_binding_sweep.txt)"""
+    env = dict(os.environ)
+    env.setdefault("OMP_PROC_BIND", "spread")
+    env.setdefault("OMP_PLACES", "cores")
+    code = ("import sys, json; sys.path.insert(0, %r); import bench; "
+            "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline(%r, %r, %r, device_size=%r)))"
+            % (ROOT, size_name, bool(with_filmic), which, tuple(device_size)))
+    try:
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return None
+    for ln in out.stdout.splitlines():
+        if ln.startswith("CPU_BASELINE "):
+            return json.loads(ln[len("CPU_BASELINE "):])
+    sys.stderr.write("bench.py: the CPU baseline child failed:\n" + out.stderr[-600:] + "\n")
+    return None
 
 
 def verify_output(out16, raw_host, width, height, with_filmic, which):
@@ -268,7 +292,9 @@ def valu_floor_ms(tag, mpix):
         mix = json.load(open(os.path.join(ROOT, "profiles", "r02_isa_mix.json")))
     except (OSError, ValueError):
         return None
-    k = mix.get("kernels", {}).get(tag) or mix.get("kernels", {}).get(tag.replace("_u16", ""))
+    alias = {"dn_decompose": "dn_decompose_strip", "nlm_chunks": "nlm_chunks_v2", "diffuse_decompose": "bspline_decompose"}
+    kernels = mix.get("kernels", {})
+    k = kernels.get(tag) or kernels.get(tag.replace("_u16", "")) or kernels.get(alias.get(tag, ""))
     if not k or "issue_floor_ms_per_mpix" not in k:
         return None
     return k["issue_floor_ms_per_mpix"] * mpix
@@ -313,9 +339,6 @@ def main():
         sys.exit(self_spawn(args))
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, env_world))
-    # the CPU baseline's OpenMP runtime reads these when it starts (first call into oracle/_ref)
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
-    os.environ.setdefault("OMP_PLACES", "cores")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -576,7 +599,7 @@ def main():
             line["verified"] = verify["verified"]
             line["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.cpu_sample, with_filmic, args.pipe, device_size=(width, height))
+            cb = cpu_baseline_in_child(args.cpu_sample, with_filmic, args.pipe, (width, height))
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
