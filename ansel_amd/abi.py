@@ -283,6 +283,9 @@ BLENDIF_L_in, BLENDIF_A_in, BLENDIF_B_in, BLENDIF_C_in, BLENDIF_h_in = 0, 1, 2, 
 BLENDIF_L_out, BLENDIF_A_out, BLENDIF_B_out, BLENDIF_C_out, BLENDIF_h_out = 4, 5, 6, 12, 13
 
 
+MASK_GUIDE_IN_BEFORE_BLUR, MASK_GUIDE_OUT_BEFORE_BLUR, MASK_GUIDE_IN_AFTER_BLUR, MASK_GUIDE_OUT_AFTER_BLUR = 1, 2, 5, 6
+
+
 class BlendData(C.Structure):
     """dt_hip_blend_data_t: the fields of dt_develop_blend_params_t (src/develop/blend.h:199-244) the
     uniform / parametric RGB (scene) blend reads + the work profile's RGB -> XYZ(D50) matrix"""
@@ -291,7 +294,7 @@ class BlendData(C.Structure):
                 ("blendif", C.c_uint32), ("feathering_radius", C.c_float), ("blur_radius", C.c_float),
                 ("details", C.c_float), ("contrast", C.c_float), ("brightness", C.c_float),
                 ("blendif_parameters", C.c_float * 64), ("blendif_boost_factors", C.c_float * 16), ("matrix_in", m34),
-                ("form_mask", C.c_void_p)]
+                ("form_mask", C.c_void_p), ("feathering_guide", C.c_uint32)]
 
     @classmethod
     def uniform(cls, matrix_in, opacity=100.0, blend_mode=BLEND_NORMAL, blend_parameter=0.0, blend_cst=BLEND_CS_RGB_SCENE):

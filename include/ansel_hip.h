@@ -584,8 +584,11 @@ int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iw
  * refines with the detail mask, and uploads ONE float plane): `form_mask`, a plane of roi_out's size.  It replaces the
  * constant form mask of a parametric-only blend in make_mask() (blendif_*.c) and is followed by the same post operations;
  * a raster mask alone (no drawn form, no active parametric channel) is form * opacity (blend.c:740-745).
- * Refused with DT_HIP_INVALID_ARG (never approximated): feathering (guided filter), GUI mask display, and a drawn /
- * raster mask mode or a details threshold WITHOUT the plane. */
+ * Feathering (blend.c:603-623, :825-852): the guided filter of src/pixel/guided_filter.c over the mask, guided by the
+ * module's input or output (feathering_guide), before or after the blur as _develop_mask_get_post_operations() orders
+ * them (blend.c:427-469) -- its 512-pixel tile grid and Kahan box means reproduced, bit-identical to the CPU path.
+ * Refused with DT_HIP_INVALID_ARG (never approximated): GUI mask display, and a drawn / raster mask mode or a details
+ * threshold WITHOUT the plane. */
 #define DT_HIP_BLEND_CS_RAW 1 /* dt_develop_blend_colorspace_t, blend.h:51-58 */
 #define DT_HIP_BLEND_CS_LAB 2
 #define DT_HIP_BLEND_CS_RGB_DISPLAY 3
@@ -596,6 +599,10 @@ int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iw
 #define DT_HIP_MASK_RASTER 8u
 #define DT_HIP_COMBINE_INV 1u /* dt_develop_mask_combine_mode_t, blend.h:120-131 */
 #define DT_HIP_COMBINE_INCL 2u
+#define DT_HIP_MASK_GUIDE_IN_BEFORE_BLUR 0x01u /* dt_develop_mask_feathering_guide_t, blend.h:133-139 */
+#define DT_HIP_MASK_GUIDE_OUT_BEFORE_BLUR 0x02u
+#define DT_HIP_MASK_GUIDE_IN_AFTER_BLUR 0x05u
+#define DT_HIP_MASK_GUIDE_OUT_AFTER_BLUR 0x06u
 #define DT_HIP_BLEND_REVERSE 0x80000000u /* dt_develop_blend_mode_t flag, blend.h:106 */
 #define DT_HIP_BLENDIF_SIZE 16
 typedef struct dt_hip_blend_data_t
@@ -607,8 +614,8 @@ typedef struct dt_hip_blend_data_t
   float opacity;          /* 0 .. 100 */
   uint32_t mask_combine;  /* DT_HIP_COMBINE_* bits */
   uint32_t blendif;       /* bit i: channel i active; bit 16 + i: channel i inverted (blend.h:141-197) */
-  float feathering_radius, blur_radius, details; /* feathering_radius must be 0 (refused otherwise); details is applied by the
-                                                    host to form_mask before the upload, as in the reference */
+  float feathering_radius, blur_radius, details; /* details is applied by the host to form_mask before the upload, as in
+                                                    the reference */
   float contrast, brightness;                    /* mask tone curve */
   float blendif_parameters[4 * DT_HIP_BLENDIF_SIZE];
   float blendif_boost_factors[DT_HIP_BLENDIF_SIZE];
@@ -616,6 +623,7 @@ typedef struct dt_hip_blend_data_t
   dt_hip_mem_t form_mask; /* NULL, or the host-rendered form mask: roi_out.width x roi_out.height floats on the device
                              (dt_hip_copy_host_to_device(devid, mask, width, height, 4)); required when mask_mode has
                              DT_HIP_MASK_SHAPE / _RASTER or details != 0 */
+  uint32_t feathering_guide; /* DT_HIP_MASK_GUIDE_*; read when feathering_radius > 0.1 */
 } dt_hip_blend_data_t;
 /* dev_in: the module's input, roi_in; dev_out: the module's output, roi_out, blended in place */
 int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d,

@@ -28,7 +28,8 @@ $X $R/develop/blend.h $G/blend_h.inc dt_develop_blend_colorspace_t dt_develop_bl
   dt_develop_mask_combine_mode_t dt_develop_mask_feathering_guide_t dt_develop_blendif_channels_t dt_develop_blend_params_t \
   DEVELOP_BLENDIF_PARAMETER_ITEMS
 $X $R/develop/blend.c $G/blend_c.inc dt_develop_blendif_process_parameters dt_develop_blendif_init_masking_profile \
-  _develop_blend_process_mask_tone_curve
+  _develop_blend_process_mask_tone_curve _develop_mask_post_processing _develop_mask_get_post_operations \
+  _develop_blend_process_feather
 $X $R/develop/blends/blendif_rgb_jzczhz.c $G/blendif_rgb_jzczhz.inc DT_BLENDIF_RGB_CH DT_BLENDIF_RGB_BCH \
   _blendif_compute_factor _blendif_gray _blendif_rgb_red _blendif_rgb_green _blendif_rgb_blue _blendif_jzczhz \
   _blendif_combine_channels dt_develop_blendif_rgb_jzczhz_make_mask _blend_normal _blend_multiply _blend_add _blend_subtract \

@@ -14,6 +14,7 @@
 #include "common/colorspaces_inline_conversions.h"
 #include "math/openmp_maths.h"
 #include "pixel/gaussian.h"
+#include "pixel/guided_filter.h"
 
 typedef int dt_colorspaces_color_profile_type_t;
 typedef int dt_colorspaces_color_mode_t;
@@ -91,7 +92,7 @@ static int parametric_used(const dt_develop_blend_params_t *params)
 int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, const void *in, void *out)
 {
   ref_reset_fp_mode();
-  if(h->blend_cst < DEVELOP_BLEND_CS_RAW || h->blend_cst > DEVELOP_BLEND_CS_RGB_SCENE || h->feathering_radius != 0.f) return -1;
+  if(h->blend_cst < DEVELOP_BLEND_CS_RAW || h->blend_cst > DEVELOP_BLEND_CS_RGB_SCENE) return -1;
   /* drawn / raster masks (and the details refinement of them) come rendered, as one plane: what
    * _develop_blend_init_raster_mask() / _init_drawn_mask() / _refine_with_detail_mask() leave in `mask` (blend.c:740-790) */
   const float *const form = (const float *)h->form_mask;
@@ -108,6 +109,8 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
   d.blendif = h->blendif;
   d.contrast = h->contrast;
   d.blur_radius = h->blur_radius;
+  d.feathering_radius = h->feathering_radius;
+  d.feathering_guide = h->feathering_guide;
   d.brightness = h->brightness;
   memcpy(d.blendif_parameters, h->blendif_parameters, sizeof(d.blendif_parameters));
   memcpy(d.blendif_boost_factors, h->blendif_boost_factors, sizeof(d.blendif_boost_factors));
@@ -173,23 +176,45 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
       dt_develop_blendif_rgb_hsl_make_mask(&pipe, &piece, (const float *)in, (const float *)out, mask);
     else
       dt_develop_blendif_rgb_jzczhz_make_mask(&pipe, &piece, (const float *)in, (const float *)out, mask);
-    /* _develop_mask_get_post_operations(), blend.c:427-469, with feathering absent: blur, then the tone curve */
-    if(d.blur_radius > 0.1f)
+    /* the post operations, blend.c:815-885, in the order the reference's own _develop_mask_get_post_operations() gives */
+    _develop_mask_post_processing ops[3];
+    const size_t nops = _develop_mask_get_post_operations(&d, &piece, ops);
+    const int rois_equal = piece.roi_in.width == owidth && piece.roi_in.height == oheight
+                           && piece.roi_in.x == piece.roi_out.x && piece.roi_in.y == piece.roi_out.y;
+    for(size_t k = 0; k < nops; k++)
     {
-      /* DEVELOP_MASK_POST_BLUR, blend.c:869-881 */
-      const float sigma = d.blur_radius * piece.roi_out.scale;
-      const float mmax[] = { 1.0f };
-      const float mmin[] = { 0.0f };
-      dt_gaussian_t *g = dt_gaussian_init(owidth, oheight, 1, mmax, mmin, sigma, 0);
-      if(g)
+      if(ops[k] == DEVELOP_MASK_POST_FEATHER_IN || ops[k] == DEVELOP_MASK_POST_FEATHER_OUT)
       {
-        dt_gaussian_blur(g, mask, mask);
-        dt_gaussian_free(g);
+        const float guide_weight = (d.blend_cst == DEVELOP_BLEND_CS_LAB) ? 1.0f : 100.0f; /* dt_iop_colorspace_is_rgb() */
+        /* FEATHER_IN with roi_in != roi_out: the reference's region copy reads past its input (blend.c:823): not run */
+        if(ops[k] == DEVELOP_MASK_POST_FEATHER_IN && !rois_equal)
+        {
+          dt_pixelpipe_cache_free_align(mask);
+          return -1;
+        }
+        const float *guide = ops[k] == DEVELOP_MASK_POST_FEATHER_IN ? (const float *)in : (const float *)out;
+        if(_develop_blend_process_feather(guide, mask, owidth, oheight, 4, guide_weight, d.feathering_radius, piece.roi_out.scale))
+        {
+          dt_pixelpipe_cache_free_align(mask);
+          return 1;
+        }
       }
+      else if(ops[k] == DEVELOP_MASK_POST_BLUR)
+      {
+        /* blend.c:869-881 */
+        const float sigma = d.blur_radius * piece.roi_out.scale;
+        const float mmax[] = { 1.0f };
+        const float mmin[] = { 0.0f };
+        dt_gaussian_t *g = dt_gaussian_init(owidth, oheight, 1, mmax, mmin, sigma, 0);
+        if(g)
+        {
+          dt_gaussian_blur(g, mask, mask);
+          dt_gaussian_free(g);
+        }
+      }
+      else if(ops[k] == DEVELOP_MASK_POST_TONE_CURVE)
+        _develop_blend_process_mask_tone_curve(mask, buffsize, d.contrast, d.brightness, opacity);
     }
-    const int mask_tone_curve = fabsf(d.contrast) >= 0.01f || fabsf(d.brightness) >= 0.01f;
-    if(mask_tone_curve && opacity > 1e-4f)
-      _develop_blend_process_mask_tone_curve(mask, buffsize, d.contrast, d.brightness, opacity);
   }
   if(d.blend_cst == DEVELOP_BLEND_CS_LAB)
     dt_develop_blendif_lab_blend(&pipe, &piece, (const float *)in, (float *)out, mask, DT_DEV_PIXELPIPE_DISPLAY_NONE);

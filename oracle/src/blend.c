@@ -806,15 +806,13 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   if(!piece || !d || !in_ || !out_) return 1;
   if(d->blend_cst == DT_HIP_BLEND_CS_RAW)
   {
-    if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->feathering_radius != 0.f || d->details != 0.f
-       || piece->channels != 1)
-      return 1;
+    /* one channel: no feathering whatever the radius (mask_feather needs >= 3 channels, blend.c:431) */
+    if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->details != 0.f || piece->channels != 1) return 1;
     if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return 0;
     return blend_raw(piece, d, (const float *)in_, (float *)out_);
   }
   const int lab = d->blend_cst == DT_HIP_BLEND_CS_LAB, display = d->blend_cst == DT_HIP_BLEND_CS_RGB_DISPLAY;
-  if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !display) || d->feathering_radius != 0.f || piece->channels != 4)
-    return 1;
+  if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !display) || piece->channels != 4) return 1;
   /* drawn / raster masks and the details threshold: rendered and refined by the host into ONE plane, as the reference's
    * device blend receives them (blend.c:1278-1325) */
   if(((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->details != 0.f) && !d->form_mask) return 1;
@@ -920,17 +918,62 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   const unsigned mode = d->blend_mode & 0xFFu;
   const int reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
 
-  /* with a mask blur the mask becomes a plane: build it, blur it, then tone curve + operator per pixel */
+  /* with a spatial post operation the mask becomes a plane: build it, feather / blur it in the order of
+   * _develop_mask_get_post_operations() (blend.c:427-469), then tone curve + operator per pixel */
   float *plane = NULL;
   const int blur = post && d->blur_radius > 0.1f;
-  if(blur)
+  const int feather = post && d->feathering_radius > 0.1f; /* piece->channels == 4 here */
+  const int feather_before = d->feathering_guide == DT_HIP_MASK_GUIDE_IN_BEFORE_BLUR
+                             || d->feathering_guide == DT_HIP_MASK_GUIDE_OUT_BEFORE_BLUR;
+  const int feather_out = d->feathering_guide == DT_HIP_MASK_GUIDE_OUT_BEFORE_BLUR
+                          || d->feathering_guide == DT_HIP_MASK_GUIDE_OUT_AFTER_BLUR;
+  const int spatial = blur || feather;
+  if(spatial)
   {
     plane = (float *)malloc(sizeof(float) * (size_t)owidth * oheight);
     if(!plane) return 1;
   }
-  for(int pass = blur ? 0 : 1; pass < 2; pass++)
+  for(int pass = spatial ? 0 : 1; pass < 2; pass++)
   {
-  if(pass == 1 && blur) gaussian_blur_mask(plane, owidth, oheight, d->blur_radius * (float)piece->roi_out.scale);
+  if(pass == 1 && spatial)
+  {
+    const int feather_first = feather && blur && feather_before;
+    for(int step = 0; step < 2; step++)
+    {
+      const int do_feather = feather && (feather_first ? step == 0 : step == 1);
+      const int do_blur = blur && (feather_first ? step == 1 : step == 0);
+      if(do_blur) gaussian_blur_mask(plane, owidth, oheight, d->blur_radius * (float)piece->roi_out.scale);
+      if(do_feather)
+      {
+        /* _develop_blend_process_feather(), blend.c:603-623 */
+        int w = (int)(2 * d->feathering_radius * (float)piece->roi_out.scale + 0.5f);
+        if(w < 1) w = 1;
+        const float guide_weight = lab ? 1.0f : 100.0f;
+        float *bak = (float *)malloc(sizeof(float) * (size_t)owidth * oheight);
+        const float *guide = out; /* FEATHER_OUT: the module's output, not yet blended */
+        int err = !bak;
+        if(!err && !feather_out)
+        {
+          /* FEATHER_IN: the module's input.  When roi_in != roi_out the reference copies the region with the row
+           * offset AND the row count multiplied by the channel count (blend.c:823-824 passes ch * yoffs, ch * oheight
+           * to a helper that takes rows): it reads past its input.  Not reproduced: refused. */
+          if(xoffs || yoffs || iwidth != owidth || iheight != oheight) err = 1;
+          guide = in;
+        }
+        if(!err)
+        {
+          memcpy(bak, plane, sizeof(float) * (size_t)owidth * oheight);
+          err = oracle_guided_filter(guide, bak, plane, owidth, oheight, 4, w, 1.f, guide_weight, 0.f, 1.f);
+        }
+        free(bak);
+        if(err)
+        {
+          free(plane);
+          return 1;
+        }
+      }
+    }
+  }
 #pragma omp parallel for schedule(static)
   for(int y = 0; y < oheight; y++)
     for(int xx = 0; xx < owidth; xx++)
@@ -940,7 +983,7 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
       const float b[4] = { bo[0], bo[1], bo[2], bo[3] };
       float m = constant;
       const float sd = form ? form[(size_t)y * owidth + xx] : seed; /* the form mask at this pixel */
-      if(pass == 1 && blur) m = plane[(size_t)y * owidth + xx];
+      if(pass == 1 && spatial) m = plane[(size_t)y * owidth + xx];
       else if(kind == 4) m = sd * opacity;
       else if(kind == 3) m = mask_inversed ? global_opacity * (1.0f - sd) : sd * global_opacity;
       else if(kind == 2)

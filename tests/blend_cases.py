@@ -222,6 +222,39 @@ def blur_cases():
     return out
 
 
+def feather_cases():
+    """(name, data, which images): the guided filter over the mask (blend.c:603-623, :815-852), guided by the module's input
+    or output, before or after the blur, alone or with the tone curve"""
+    out = []
+    for guide in (abi.MASK_GUIDE_IN_BEFORE_BLUR, abi.MASK_GUIDE_OUT_BEFORE_BLUR, abi.MASK_GUIDE_IN_AFTER_BLUR,
+                  abi.MASK_GUIDE_OUT_AFTER_BLUR):
+        d = abi.BlendData.uniform(M, 80.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.2, 0.6, 0.9, boost=1.0)
+        d.feathering_radius, d.feathering_guide = 3.0, guide
+        out.append(("feather-scene-g%d" % guide, d, "scene"))
+        d = abi.BlendData.uniform(M, 65.0, abi.BLEND_MULTIPLY, 0.5).channel(abi.BLENDIF_Jz_in, 0.05, 0.2, 1.0, 1.0, boost=-4.0)
+        d.feathering_radius, d.feathering_guide, d.blur_radius = 1.5, guide, 2.5
+        d.contrast, d.brightness = 0.3, 0.1
+        out.append(("feather-blur-tone-scene-g%d" % guide, d, "scene"))
+    d = abi.BlendData.uniform(M, 90.0, 0x0B, blend_cst=abi.BLEND_CS_LAB).channel(abi.BLENDIF_L_in, 0.2, 0.4, 0.7, 0.9)
+    d.feathering_radius, d.feathering_guide = 4.0, abi.MASK_GUIDE_IN_AFTER_BLUR
+    out.append(("feather-lab", d, "lab"))  # guide weight 1 instead of 100
+    d = abi.BlendData.uniform(M, 60.0, 0x12, blend_cst=abi.BLEND_CS_RGB_DISPLAY).channel(abi.BLENDIF_S_in, 0.1, 0.3, 1.0, 1.0)
+    d.feathering_radius, d.feathering_guide, d.blur_radius = 0.3, abi.MASK_GUIDE_OUT_BEFORE_BLUR, 1.0
+    out.append(("feather-display-w1", d, "display"))  # window 1
+    d = abi.BlendData.uniform(M, 75.0).channel(abi.BLENDIF_GRAY_out, 0.1, 0.3, 0.7, 0.8)
+    d.feathering_radius, d.feathering_guide = 40.0, abi.MASK_GUIDE_OUT_AFTER_BLUR
+    out.append(("feather-scene-wide", d, "scene"))  # window 80: wider than the small frames
+    # a feathering radius on a uniform mask does nothing (post operations run behind make_mask() only)
+    d = abi.BlendData.uniform(M, 45.0)
+    d.feathering_radius, d.feathering_guide = 9.0, abi.MASK_GUIDE_IN_BEFORE_BLUR
+    out.append(("feather-uniform-ignored", d, "scene"))
+    # one-channel buffers are never feathered (blend.c:431)
+    d = abi.BlendData.uniform(M, 70.0, 0x18, blend_cst=abi.BLEND_CS_RAW).channel(abi.BLENDIF_GRAY_in, 0.1, 0.2, 0.8, 0.9)
+    d.feathering_radius, d.feathering_guide = 5.0, abi.MASK_GUIDE_IN_BEFORE_BLUR
+    out.append(("feather-raw-ignored", d, "raw"))
+    return out
+
+
 def images_for(kind, w, h, seed):
     return {"scene": images, "lab": lab_images, "display": display_images, "raw": raw_images}[kind](w, h, seed)
 

@@ -552,6 +552,76 @@ def test_develop_blend_mask_blur(name, d, kind, w, h):
     _exact(x, y, "blend " + name)
 
 
+GF_SIG = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float] * 4
+
+
+@pytest.mark.parametrize("w,h,win,weight", [(131, 67, 3, 100.0), (600, 530, 5, 100.0), (1100, 700, 20, 100.0), (700, 1300, 200, 100.0),
+                                            (50, 40, 30, 100.0), (517, 513, 1, 100.0), (1030, 520, 9, 100.0), (33, 1, 2, 100.0),
+                                            (1, 33, 2, 100.0), (1027, 515, 7, 1.0)])
+def test_guided_filter(w, h, win, weight):
+    """guided_filter(), src/pixel/guided_filter.c:369: its 512-pixel tile grid (sources grown by 2 w, clipped), the Kahan box
+    means of src/pixel/box_filters.c, and the 1-wide column variant's tail that ADDS the sample it should remove
+    (box_filters.c:630-640; on the last (9 * source width) % 4 scalar columns of the variance image: 131, 517, 1027, ... wide
+    sources).  oracle == the reference's own two files, bit for bit"""
+    r, o = ck.ref(), ck.oracle()
+    for l, n in ((o, "oracle_guided_filter"), (r, "ref_guided_filter")):
+        getattr(l, n).argtypes = GF_SIG
+        getattr(l, n).restype = C.c_int
+    rng = np.random.default_rng(w * 7 + h + win)
+    guide = ck.aligned_empty((h, w, 4), np.float32)
+    guide[...] = rng.random((h, w, 4), dtype=np.float32) * 1.2
+    m = ck.aligned_empty((h, w), np.float32)
+    m[...] = (rng.random((h, w)) > 0.5) * rng.random((h, w))
+    x, y = ck.aligned_empty((h, w), np.float32), ck.aligned_empty((h, w), np.float32)
+    x[...], y[...] = 7.0, 9.0
+    assert r.ref_guided_filter(guide.ctypes.data, m.ctypes.data, x.ctypes.data, w, h, 4, win, 1.0, weight, 0.0, 1.0) == 0
+    assert o.oracle_guided_filter(guide.ctypes.data, m.ctypes.data, y.ctypes.data, w, h, 4, win, 1.0, weight, 0.0, 1.0) == 0
+    _exact(x, y, "guided filter")
+    assert 0.0 <= float(x.min()) and float(x.max()) <= 1.0
+
+
+FEATHER_CASES = blend_cases.feather_cases()
+
+
+@pytest.mark.parametrize("name,d,kind", FEATHER_CASES, ids=[c[0] for c in FEATHER_CASES])
+@pytest.mark.parametrize("w,h", [(131, 67), (640, 530), (40, 3)])
+def test_develop_blend_feathering(name, d, kind, w, h):
+    """mask feathering: the guided filter between make_mask() and the blend operator, in the order
+    _develop_mask_get_post_operations() (blend.c:427-469) puts it relative to the blur and the tone curve; the reference
+    side runs its own _develop_mask_get_post_operations() and _develop_blend_process_feather()"""
+    a, b = blend_cases.images_for(kind, w, h, 83) if w > 20 and h > 20 else [z[:h, :w].copy() for z in blend_cases.images_for(kind, 64, 64, 83)]
+    piece = abi.Piece.make(w, h, channels=1 if kind == "raw" else 4)
+    r, o = ck.ref(), ck.oracle()
+    x, y = b.copy(), b.copy()
+    assert ck.call(r, "ref_develop_blend", piece, d, np.ascontiguousarray(a), x) == 0
+    assert ck.call(o, "oracle_develop_blend", piece, d, np.ascontiguousarray(a), y) == 0
+    _exact(x, y, "blend " + name)
+    if "ignored" in name:
+        d2 = abi.BlendData.from_buffer_copy(d)
+        d2.feathering_radius = 0.0
+        z = b.copy()
+        assert ck.call(o, "oracle_develop_blend", piece, d2, np.ascontiguousarray(a), z) == 0
+        _exact(y, z, name)
+
+
+def test_develop_blend_feathering_guided_by_a_larger_input_is_refused():
+    """FEATHER_IN with roi_in != roi_out: the reference copies the region with the row offset and the row count multiplied
+    by the channel count (blend.c:823-824) and reads past its input; nobody reproduces that"""
+    w, h, iw, ih = 90, 50, 120, 70
+    a, b = blend_cases.images(w, h, 43, iw, ih)
+    piece = abi.Piece.make(w, h, roi_in=abi.Roi.make(10, 20, iw, ih, 1.0), roi_out=abi.Roi.make(25, 31, w, h, 1.0))
+    d = abi.BlendData.uniform(blend_cases.M, 70.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.3, 0.8, 1.0)
+    d.feathering_radius, d.feathering_guide = 3.0, abi.MASK_GUIDE_IN_BEFORE_BLUR
+    x = b.copy()
+    assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, x) != 0
+    assert ck.call(ck.ref(), "ref_develop_blend", piece, d, a, b.copy()) != 0
+    d.feathering_guide = abi.MASK_GUIDE_OUT_AFTER_BLUR  # guided by the output: fine
+    y = b.copy()
+    assert ck.call(ck.ref(), "ref_develop_blend", piece, d, a, x) == 0
+    assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, y) == 0
+    _exact(x, y, "feathering guided by the output under a roi offset")
+
+
 DEMOSAIC_EXTRAS = [
     # (method, green_eq, colour smoothing passes, PPG median threshold, green_eq threshold = 1e-4 * ISO)
     (abi.DT_HIP_DEMOSAIC_PPG, 0, 0, 0.05, 0.0),
