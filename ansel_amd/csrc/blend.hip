@@ -886,11 +886,6 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   }
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
   if(piece->channels != (raw ? 1 : 4)) return DT_HIP_INVALID_ARG;
-  if(d->feathering_radius != 0.f)
-  {
-    set_last_error("blend: mask feathering (the guided filter) is not built");
-    return DT_HIP_INVALID_ARG;
-  }
   // drawn / raster masks and the details threshold: rendered and refined by the host into ONE plane, as the reference's
   // device blend receives them (blend.c:1278-1325)
   const float *const form = (const float *)d->form_mask;
@@ -976,13 +971,28 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   a.mode = d->blend_mode & 0xFFu;
   a.reverse = (d->blend_mode & DT_HIP_BLEND_REVERSE) == DT_HIP_BLEND_REVERSE;
   a.p = exp2f(d->blend_parameter);
-  // post operations run on parametric masks only (blend.c:759-900): blur, then the tone curve
+  // post operations follow make_mask() only (blend.c:759-900): feathering and blur in the order of
+  // _develop_mask_get_post_operations() (blend.c:427-469), then the tone curve
   const bool blur = post && d->blur_radius > 0.1f;
+  const bool feather = post && !raw && d->feathering_radius > 0.1f; // one-channel buffers are never feathered, blend.c:431
+  const bool feather_before = d->feathering_guide == DT_HIP_MASK_GUIDE_IN_BEFORE_BLUR
+                              || d->feathering_guide == DT_HIP_MASK_GUIDE_OUT_BEFORE_BLUR;
+  const bool feather_out = d->feathering_guide == DT_HIP_MASK_GUIDE_OUT_BEFORE_BLUR
+                           || d->feathering_guide == DT_HIP_MASK_GUIDE_OUT_AFTER_BLUR;
+  if(feather && !feather_out && (a.xoffs || a.yoffs || a.iwidth != a.owidth || piece->roi_in.height != a.oheight))
+  {
+    // blend.c:823-824 hands the region copy ch * yoffs and ch * oheight where it takes rows: the reference reads past
+    // its input there
+    set_last_error("blend: feathering guided by the module's input needs roi_in == roi_out (the reference reads outside "
+                   "its input otherwise)");
+    return DT_HIP_INVALID_ARG;
+  }
+  const bool spatial = blur || feather;
   const size_t np = (size_t)a.owidth * a.oheight;
   hipStream_t s = stream_of(devid);
   // the blurred mask plane: `plane` holds the mask, `scratch` the vertically blurred one
   float *plane = nullptr, *scratch = nullptr;
-  if(blur || form_kind)
+  if(spatial || form_kind)
   {
     plane = (float *)dt_hip_alloc_device_buffer(devid, np * sizeof(float));
     if(blur) scratch = (float *)dt_hip_alloc_device_buffer(devid, np * sizeof(float));
@@ -1014,6 +1024,23 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     launch_scope ls(devid, "blend_mask_blur");
     gauss_vertical<<<(a.owidth + 63) / 64, 64, 0, s>>>(plane, scratch, g);
     gauss_horizontal<<<(a.oheight + 63) / 64, 64, 0, s>>>(scratch, plane, g);
+  };
+  // the spatial post operations on the plane; false after a failure (error code in `post_err`)
+  int post_err = DT_HIP_SUCCESS;
+  auto spatial_ops = [&]() {
+    const bool feather_first = feather && blur && feather_before;
+    for(int step = 0; step < 2 && post_err == DT_HIP_SUCCESS; step++)
+    {
+      if(blur && (feather_first ? step == 1 : step == 0)) blur_plane();
+      if(feather && (feather_first ? step == 0 : step == 1))
+      {
+        // _develop_blend_process_feather(), blend.c:603-623
+        int w = (int)(2 * d->feathering_radius * (float)piece->roi_out.scale + 0.5f);
+        if(w < 1) w = 1;
+        post_err = guided_filter_launch(devid, feather_out ? (const float4 *)dev_out : (const float4 *)dev_in, plane, a.owidth,
+                                        a.oheight, w, 1.0f, lab ? 1.0f : 100.0f, 0.0f, 1.0f);
+      }
+    }
   };
   auto release_planes = [&]() {
     if(plane) dt_hip_release_mem_object(plane);   // stream-ordered: re-used only by later launches
@@ -1090,9 +1117,9 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     else form_mask_kernel<DT_HIP_BLEND_CS_RGB_SCENE><<<grid, 256, 0, s>>>(in, out, form, plane, a, form_kind);
     mask = 2;
   }
-  else if(blur)
+  else if(spatial)
   {
-    // the mask as a plane (before the post operations), blurred in place
+    // the mask as a plane (before the post operations), feathered / blurred in place
     launch_scope ls(devid, "blend_mask");
     if(!per_pixel) fill_plane<<<grid, 256, 0, s>>>(plane, np, a.constant);
     else if(cs == DT_HIP_BLEND_CS_LAB) blend_mask_kernel<DT_HIP_BLEND_CS_LAB><<<grid, 256, 0, s>>>(in, out, plane, a);
@@ -1102,7 +1129,12 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   }
   else if(!per_pixel && a.tone)
     a.constant = tone_curve(a.constant, a); // the same value for every pixel
-  if(blur) blur_plane();
+  if(spatial) spatial_ops();
+  if(post_err != DT_HIP_SUCCESS)
+  {
+    release_planes();
+    return post_err;
+  }
   {
     launch_scope ls(devid, "blend_kernel");
 #define BLEND_LAUNCH(CS_)                                                                   \

@@ -137,6 +137,10 @@ int denoiseprofile_band_begin(int devid, const dt_hip_piece_t *piece, const dt_h
 int denoiseprofile_band_step(dn_band_job_t *job, dt_hip_mem_t *halo_buf, int *halo_rows, double **sums, size_t *sum_count);
 int denoiseprofile_band_finish(dn_band_job_t *job, dt_hip_mem_t dev_out);
 void denoiseprofile_band_abort(dn_band_job_t *job);
+// guided_filter.hip: guided_filter() of src/pixel/guided_filter.c:369 -- `mask` (width x height floats) filtered in place,
+// guided by width x height float4 pixels
+int guided_filter_launch(int devid, const float4 *guide, float *mask, int width, int height, int w, float sqrt_eps,
+                         float guide_weight, float minv, float maxv);
 // local contrast (bilateral grid) on row bands: the grid is one accumulation over the frame in pixel order, so the bands
 // take turns (bilat.hip).  begin: the zeroed grid of the frame; splat: the band's rows on top of what the grid holds;
 // finish: blur of the complete grid (this band's copy) and the slice of the band's rows

@@ -644,6 +644,12 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
       set_last_error("band mode: a blend with a host-rendered form mask has no row-band implementation");
       return DT_HIP_INVALID_ARG;
     }
+    if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->feathering_radius > 0.1f)
+    {
+      // the guided filter works on its own 512-pixel tile grid over the whole frame
+      set_last_error("band mode: a blend with mask feathering has no row-band implementation");
+      return DT_HIP_INVALID_ARG;
+    }
     if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->blur_radius > 0.0f)
     {
       // uniform and parametric masks are pointwise; the mask blur is a recursive filter down whole columns

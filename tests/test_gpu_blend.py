@@ -113,7 +113,7 @@ def test_blend_full_frame():
     _check(abi.Piece.make(w, h), d, a, b, "24 MP")
 
 
-@pytest.mark.parametrize("field,value", [("blend_cst", 5), ("blend_cst", 0), ("feathering_radius", 5.0), ("details", 0.5),
+@pytest.mark.parametrize("field,value", [("blend_cst", 5), ("blend_cst", 0), ("details", 0.5),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_SHAPE),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_RASTER)])
 def test_blend_refuses_what_is_not_built(field, value):
@@ -168,13 +168,54 @@ def test_blend_with_a_host_rendered_form_mask(cs, name, d):
         x.release()
 
 
-def test_feathering_is_still_refused():
+FEATHER_CASES = blend_cases.feather_cases()
+
+
+@pytest.mark.parametrize("name,d,kind", FEATHER_CASES, ids=[c[0] for c in FEATHER_CASES])
+@pytest.mark.parametrize("w,h", [(131, 67), (640, 530), (40, 3), (1, 50), (1300, 1100)])
+def test_blend_mask_feathering(name, d, kind, w, h):
+    """the guided filter over the mask (src/pixel/guided_filter.c: its 512-pixel tile grid, the Kahan box means of
+    box_filters.c and their 1-wide tail), guided by the module's input or output, before / after the blur: device ==
+    oracle == the reference's own code"""
+    if w > 20 and h > 20:
+        a, b = blend_cases.images_for(kind, w, h, 83)
+    else:
+        a, b = [np.ascontiguousarray(z[:h, :w]) for z in blend_cases.images_for(kind, 64, 64, 83)]
+    _check(abi.Piece.make(w, h, channels=1 if kind == "raw" else 4), d, a, b, name)
+
+
+def test_blend_feathering_with_a_form_mask():
+    """a drawn mask, a parametric condition on top, feathered along the edges of the module's output"""
     l = hc.hip()
-    w, h = 32, 16
-    a, b = blend_cases.images(w, h, 3)
-    d = abi.BlendData.uniform(blend_cases.M, 50.0)
-    d.feathering_radius = 3.0
-    buf, din = lib.DeviceBuffer.from_numpy(0, b), lib.DeviceBuffer.from_numpy(0, a)
+    w, h = 700, 560
+    a, b = blend_cases.images(w, h, 44)
+    form = blend_cases.form_plane(w, h)
+    dform = lib.DeviceBuffer.from_numpy(0, form)
+    d = dict(blend_cases.form_cases(abi.BLEND_CS_RGB_SCENE))["drawn+raster+parametric-c0"]
+    d.feathering_radius, d.feathering_guide = 6.0, abi.MASK_GUIDE_OUT_AFTER_BLUR
     piece = abi.Piece.make(w, h)
+    d.form_mask = dform.ptr
+    got = hc.run_hip("dt_hip_develop_blend_process", piece, d, a, b.shape, pre_fill=b)
+    host_form = ck.aligned_empty(form.shape, np.float32)
+    host_form[...] = form
+    d.form_mask = host_form.ctypes.data
+    want = b.copy()
+    assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, want) == 0
+    assert int((ck.ulp_diff(got, want) > 0).sum()) == 0
+    dform.release()
+    assert l.dt_hip_finish(0) == 1
+
+
+def test_feathering_guided_by_a_larger_input_is_refused():
+    """FEATHER_IN with roi_in != roi_out: the reference reads past its input (blend.c:823-824); refused with the reason"""
+    l = hc.hip()
+    w, h, iw, ih = 90, 50, 120, 70
+    a, b = blend_cases.images(w, h, 43, iw, ih)
+    piece = abi.Piece.make(w, h, roi_in=abi.Roi.make(10, 20, iw, ih, 1.0), roi_out=abi.Roi.make(25, 31, w, h, 1.0))
+    d = abi.BlendData.uniform(blend_cases.M, 70.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.3, 0.8, 1.0)
+    d.feathering_radius, d.feathering_guide = 3.0, abi.MASK_GUIDE_IN_BEFORE_BLUR
+    buf, din = lib.DeviceBuffer.from_numpy(0, b), lib.DeviceBuffer.from_numpy(0, a)
     assert l.dt_hip_develop_blend_process(0, C.byref(piece), C.byref(d), din.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
-    assert b"feathering" in l.dt_hip_last_error()
+    assert b"roi_in == roi_out" in l.dt_hip_last_error()
+    d.feathering_guide = abi.MASK_GUIDE_OUT_AFTER_BLUR  # guided by the output: any roi
+    _check(piece, d, a, b, "feathering guided by the output under a roi offset")

@@ -226,6 +226,14 @@ def test_blended_pipe_closed_by_a_blend_on_bands():
     with pytest.raises(lib.AnselHipError, match="mask blur"):
         engine.begin(bands[0], d_in.data_ptr(), w)
     p.close()
+    # and so is mask feathering (the guided filter's tile grid is the frame's)
+    d = abi.BlendData.uniform(params.WORK_IN, 50.0)
+    d.feathering_radius, d.feathering_guide = 3.0, abi.MASK_GUIDE_OUT_AFTER_BLUR
+    p = pipe.DevicePipe(0, [nodes[0], pipe.Node("blend", d, rgb)])
+    engine = tiled.HipBandEngine(p, "cuda:0")
+    with pytest.raises(lib.AnselHipError, match="feathering"):
+        engine.begin(bands[0], d_in.data_ptr(), w)
+    p.close()
 
 
 @pytest.mark.parametrize("which", ["all", "everything"])
