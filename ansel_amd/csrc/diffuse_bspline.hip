@@ -4,6 +4,8 @@
 // 1.19 ms per plane at 100 MP), while every arithmetic-bound kernel loses to v_pk_*_f32 (ansel_amd/build.py).
 #include "hip_common.h"
 
+#include <cstdlib>
+
 using namespace ansel;
 
 namespace
@@ -95,6 +97,113 @@ __global__ __launch_bounds__(256) void bspline_decompose(const float4 *__restric
   nt_store(hf + o, make_float4(centre.x - low.x, centre.y - low.y, centre.z - low.z, centre.w - low.w));
 }
 
+// The same analysis on STRIPS: a workgroup keeps its R x T columns for up to `strip` rows of one dilation class (rows c,
+// c + m, c + 2 m, ...), whose five vertical taps overlap in four rows: every lane rolls the five samples of its column
+// (and of the halo / border column it also serves) through registers and fetches ONE new row per output row -- issued
+// before the current row is filtered -- instead of five through L2.  The vertically blurred row lives in two LDS
+// buffers used alternately, one barrier per row.  Same taps, same order, same binary32 values.
+template <int R, int T>
+__global__ __launch_bounds__(256) void bspline_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ hf,
+                                                               float4 *__restrict__ lf, const int width, const int height,
+                                                               const int mult, const int groups, const int strip,
+                                                               const int strips_per_class)
+{
+  __shared__ float4 vert[2][(T + 4) * R + 2];
+  const int bx = blockIdx.x;
+  const int cls = blockIdx.y / strips_per_class, k0s = (blockIdx.y - cls * strips_per_class) * strip;
+  const int n_cls = (height - cls + mult - 1) / mult; // rows of this class
+  if(k0s >= n_cls) return;
+  const int nrows = (strip < n_cls - k0s) ? strip : n_cls - k0s;
+  const int r_first = cls + k0s * mult;
+  const int group = bx % groups, tile = bx / groups;
+  const int r0 = group * R, k0 = tile * T;
+  const int tid = threadIdx.x;
+  const int r = tid % R, k = tid / R;
+  const int col = r0 + r + (k0 + k) * mult;
+  const bool own = col < width;
+  // the second column this lane blurs vertically: a halo step (k0-2, k0-1, k0+T, k0+T+1) or a border column
+  int col2 = -1, slot2 = 0;
+  if(tid < 4 * R)
+  {
+    const int hr = tid % R, hs = tid / R;
+    const int hk = hs < 2 ? hs - 2 : T + hs - 2;
+    const int hcol = r0 + hr + (k0 + hk) * mult;
+    if(hcol >= 0 && hcol < width)
+    {
+      col2 = hcol;
+      slot2 = (hk + 2) * R + hr;
+    }
+  }
+  else if(tid == 4 * R)
+  {
+    col2 = 0;
+    slot2 = (T + 4) * R;
+  }
+  else if(tid == 4 * R + 1)
+  {
+    col2 = width - 1;
+    slot2 = (T + 4) * R + 1;
+  }
+  const bool second = col2 >= 0;
+  // tap q of the strip = frame row r_first + q mult, clamped (bspline.h:143-149)
+#define BS_ROW(q) ((size_t)clampi(r_first + (q) * mult, 0, height - 1) * width)
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 a = z, b = z, c = z, d = z, e = z, a2 = z, b2 = z, c2 = z, d2 = z, e2 = z;
+  if(own)
+  {
+    a = in[BS_ROW(-2) + col];
+    b = in[BS_ROW(-1) + col];
+    c = in[BS_ROW(0) + col];
+    d = in[BS_ROW(1) + col];
+    e = in[BS_ROW(2) + col];
+  }
+  if(second)
+  {
+    a2 = in[BS_ROW(-2) + col2];
+    b2 = in[BS_ROW(-1) + col2];
+    c2 = in[BS_ROW(0) + col2];
+    d2 = in[BS_ROW(1) + col2];
+    e2 = in[BS_ROW(2) + col2];
+  }
+  for(int kk = 0; kk < nrows; kk++)
+  {
+    const int row = r_first + kk * mult;
+    const bool more = kk + 1 < nrows;
+    float4 n1 = z, n2 = z;
+    if(more && own) n1 = in[BS_ROW(kk + 3) + col];
+    if(more && second) n2 = in[BS_ROW(kk + 3) + col2];
+    float4 *const V = vert[kk & 1];
+    if(own) V[(k + 2) * R + r] = tap5(a, b, c, d, e);
+    if(second) V[slot2] = tap5(a2, b2, c2, d2, e2);
+    __syncthreads();
+    if(own)
+    {
+      float4 t[5];
+#pragma unroll
+      for(int s = -2; s <= 2; s++)
+      {
+        const int cc = col + s * mult;
+        t[s + 2] = cc < 0 ? V[(T + 4) * R] : (cc > width - 1 ? V[(T + 4) * R + 1] : V[(k + s + 2) * R + r]);
+      }
+      const float4 low = tap5(t[0], t[1], t[2], t[3], t[4]);
+      const size_t o = (size_t)row * width + col;
+      lf[o] = low;
+      nt_store(hf + o, make_float4(c.x - low.x, c.y - low.y, c.z - low.z, c.w - low.w));
+    }
+    a = b;
+    b = c;
+    c = d;
+    d = e;
+    e = n1;
+    a2 = b2;
+    b2 = c2;
+    c2 = d2;
+    d2 = e2;
+    e2 = n2;
+  }
+#undef BS_ROW
+}
+
 } // namespace
 
 namespace ansel
@@ -102,21 +211,35 @@ namespace ansel
 int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, float4 *lf, int w, int h, int mult)
 {
   const int steps = (w + mult - 1) / mult; // steps of the dilation across a row
-  const int rows = (h <= mult) ? h : ((h + mult - 1) / mult) * mult;
   launch_scope ls(devid, "diffuse_decompose");
-  if(mult == 1)
-    bspline_decompose<1, 256><<<dim3(xcd_pad((steps + 255) / 256), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 255) / 256);
-  else if(mult == 2)
-    bspline_decompose<2, 128><<<dim3(xcd_pad((steps + 127) / 128), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 127) / 128);
-  else if(mult == 4)
-    bspline_decompose<4, 64><<<dim3(xcd_pad((steps + 63) / 64), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 63) / 64);
-  else
+  static const bool per_row = getenv("ANSEL_HIP_BSPLINE_PER_ROW") != nullptr; // the per-row kernels, for A/B timing
+  if(per_row)
   {
-    const int groups = mult / 8;
-    bspline_decompose<8, 32><<<dim3(xcd_pad(((steps + 31) / 32) * groups), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, groups,
-                                                                                          ((steps + 31) / 32) * groups);
+    const int rows = (h <= mult) ? h : ((h + mult - 1) / mult) * mult;
+    if(mult == 1)
+      bspline_decompose<1, 256><<<dim3(xcd_pad((steps + 255) / 256), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 255) / 256);
+    else if(mult == 2)
+      bspline_decompose<2, 128><<<dim3(xcd_pad((steps + 127) / 128), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 127) / 128);
+    else if(mult == 4)
+      bspline_decompose<4, 64><<<dim3(xcd_pad((steps + 63) / 64), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, 1, (steps + 63) / 64);
+    else
+    {
+      const int groups = mult / 8;
+      bspline_decompose<8, 32><<<dim3(xcd_pad(((steps + 31) / 32) * groups), rows), 256, 0, s>>>(in, hf, lf, w, h, mult, groups,
+                                                                                            ((steps + 31) / 32) * groups);
+    }
+    return check_launch("diffuse_decompose");
   }
+  const int classes = h < mult ? h : mult, per_class = (h + mult - 1) / mult;
+  const int gx = mult == 1 ? (steps + 255) / 256 : (mult == 2 ? (steps + 127) / 128 : (mult == 4 ? (steps + 63) / 64 : ((steps + 31) / 32) * (mult / 8)));
+  int strip = 32;
+  while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
+  const int spc = (per_class + strip - 1) / strip;
+  const dim3 grid(gx, classes * spc);
+  if(mult == 1) bspline_decompose_strip<1, 256><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc);
+  else if(mult == 2) bspline_decompose_strip<2, 128><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc);
+  else if(mult == 4) bspline_decompose_strip<4, 64><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc);
+  else bspline_decompose_strip<8, 32><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, mult / 8, strip, spc);
   return check_launch("diffuse_decompose");
 }
-
 } // namespace ansel
