@@ -21,6 +21,7 @@
 #include "devmath.h"
 
 #include <math.h>
+#include <cstdlib>
 
 namespace ansel
 {
@@ -277,6 +278,126 @@ __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf
   else out[idx] = o;
 }
 
+// The same update on STRIPS: a workgroup keeps its 256 columns for up to `strip` rows of one dilation class (rows c,
+// c + m, c + 2 m, ...).  The 3 x 3 supports of consecutive rows of a class share two of their three rows, so a lane
+// rolls the three rows of its three columns through registers and fetches ONE new row (6 float4) per output row
+// instead of three (18), and the squared ratios go into a ring of four LDS rows, one NEW row per output row: 4 - 8
+// divisions per pixel where the per-row kernel has 12 - 24.  Same operands, same operations, same order.
+#define PDE_RING 4
+__global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__restrict__ hf, const float4 *__restrict__ lf,
+                                                         float4 *__restrict__ out, const pde_args a, const int final_pass,
+                                                         const unsigned char *__restrict__ mask, const int strip,
+                                                         const int strips_per_class)
+{
+  extern __shared__ float4 r2s[]; // [PDE_RING][256 + 2 * mult]; slot x of a row = column clamp(seg - mult + x)
+  const int mult = a.mult;
+  const int cls = blockIdx.y / strips_per_class, k0s = (blockIdx.y - cls * strips_per_class) * strip;
+  const int n_cls = (a.height - cls + mult - 1) / mult; // rows of this class
+  if(k0s >= n_cls) return;
+  const int nrows = (strip < n_cls - k0s) ? strip : n_cls - k0s;
+  const int r_first = cls + k0s * mult;
+  const int tx = threadIdx.x, tw = 256 + 2 * mult;
+  const int col = (int)blockIdx.x * 256 + tx;
+  const bool live = col < a.width;
+  // lanes past the end of the row keep fetching (clamped): their samples are the clamped columns of their neighbours
+  const int cols[3] = { clampi(col - mult, 0, a.width - 1), clampi(col, 0, a.width - 1), clampi(col + mult, 0, a.width - 1) };
+  // support row v of the strip (output row kk reads v = kk, kk + 1, kk + 2) = frame row r_first + (v - 1) mult, clamped
+#define PDE_ROW(v) ((size_t)clampi(r_first + ((v) - 1) * mult, 0, a.height - 1) * a.width)
+  float4 H4[9], L4[9];
+  // fetch support row v into slot `ii` of the window and leave its squared ratios in ring row v % PDE_RING
+  auto fetch_row = [&](const int v, const int ii) {
+    const size_t y = PDE_ROW(v);
+#pragma unroll
+    for(int jj = 0; jj < 3; jj++)
+    {
+      H4[3 * ii + jj] = hf[y + cols[jj]];
+      L4[3 * ii + jj] = lf[y + cols[jj]];
+    }
+  };
+  auto ratios_of = [&](const int v, const int ii) {
+    float4 *const ring = r2s + (v % PDE_RING) * tw;
+    {
+      const float4 h = H4[3 * ii + 1], l = L4[3 * ii + 1];
+      ring[tx + mult] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
+    }
+    if(tx < mult)
+    {
+      const float4 h = H4[3 * ii], l = L4[3 * ii];
+      ring[tx] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
+    }
+    if(tx >= 256 - mult)
+    {
+      const float4 h = H4[3 * ii + 2], l = L4[3 * ii + 2];
+      ring[tx + 2 * mult] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
+    }
+  };
+  fetch_row(0, 1);
+  fetch_row(1, 2);
+  ratios_of(0, 1);
+  ratios_of(1, 2);
+  for(int kk = 0; kk < nrows; kk++)
+  {
+    // the window moves down one row of the class; the new bottom row
+#pragma unroll
+    for(int jj = 0; jj < 3; jj++)
+    {
+      H4[jj] = H4[3 + jj];
+      L4[jj] = L4[3 + jj];
+      H4[3 + jj] = H4[6 + jj];
+      L4[3 + jj] = L4[6 + jj];
+    }
+    fetch_row(kk + 2, 2);
+    ratios_of(kk + 2, 2);
+    __syncthreads();
+    if(!live) continue;
+    const int row = r_first + kk * mult;
+    float4 energy = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for(int ii = 0; ii < 3; ii++)
+    {
+      const float4 *const ring = r2s + ((kk + ii) % PDE_RING) * tw + tx;
+#pragma unroll
+      for(int jj = 0; jj < 3; jj++)
+      {
+        const float4 r = ring[jj * mult];
+        energy.x += r.x;
+        energy.y += r.y;
+        energy.z += r.z;
+        energy.w += r.w;
+      }
+      // three reads in flight, not nine (they sit on top of the 72 registers of the support)
+      asm volatile("" : "+v"(energy.x), "+v"(energy.y), "+v"(energy.z), "+v"(energy.w) : : "memory");
+    }
+    const size_t idx = (size_t)row * a.width + col;
+    float4 o;
+    if(mask && !mask[idx])
+    {
+      // outside the luminance mask: "only copy input to output", diffuse.c:927-937
+      const float4 h = H4[4], l = L4[4];
+      o = make_float4(max_zero(h.x + l.x), max_zero(h.y + l.y), max_zero(h.z + l.z), max_zero(h.w + l.w));
+    }
+    else
+    {
+      float H[9], L[9];
+#pragma unroll
+      for(int k = 0; k < 9; k++) { H[k] = H4[k].x; L[k] = L4[k].x; }
+      o.x = pde_channel(H, L, energy.x, a);
+#pragma unroll
+      for(int k = 0; k < 9; k++) { H[k] = H4[k].y; L[k] = L4[k].y; }
+      o.y = pde_channel(H, L, energy.y, a);
+#pragma unroll
+      for(int k = 0; k < 9; k++) { H[k] = H4[k].z; L[k] = L4[k].z; }
+      o.z = pde_channel(H, L, energy.z, a);
+#pragma unroll
+      for(int k = 0; k < 9; k++) { H[k] = H4[k].w; L[k] = L4[k].w; }
+      o.w = pde_channel(H, L, energy.w, a);
+    }
+    if(final_pass) nt_store(out + idx, o);
+    else out[idx] = o;
+  }
+#undef PDE_ROW
+}
+
 // ---- build_mask() + inpaint_mask(), diffuse.c:1106-1152, with the generators of src/iop/noise_generator.h:36-93 ----
 __device__ __forceinline__ uint32_t splitmix32(const uint64_t seed)
 {
@@ -499,7 +620,18 @@ int diffuse_process_rows(int devid, const dt_hip_piece_t *piece, const dt_hip_di
         launch_scope ls(devid, "diffuse_pde");
         // gridDim.x padded to a multiple of 8: a column block stays on one XCD, the rows above and below hit its L2
         const dim3 grid(xcd_pad((w + 255) / 256), rows);
-        if(a.mult <= PDE_SHARED_MULT)
+        static const bool per_row = getenv("ANSEL_HIP_PDE_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
+        if(a.mult <= PDE_SHARED_MULT && !per_row)
+        {
+          const int classes = h < a.mult ? h : a.mult, per_class = (h + a.mult - 1) / a.mult;
+          const int gx = (w + 255) / 256;
+          int strip = 32;
+          while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
+          const int spc = (per_class + strip - 1) / strip;
+          diffuse_pde_strip<<<dim3(gx, classes * spc), 256, (size_t)PDE_RING * (256 + 2 * a.mult) * sizeof(float4), st>>>(
+              hf[s], cur, to, a, s == 0, mask, strip, spc);
+        }
+        else if(a.mult <= PDE_SHARED_MULT)
           diffuse_pde<true><<<grid, 256, (size_t)3 * (256 + 2 * a.mult) * sizeof(float4), st>>>(hf[s], cur, to, a, s == 0, mask);
         else
           diffuse_pde<false><<<grid, 256, 0, st>>>(hf[s], cur, to, a, s == 0, mask);
