@@ -78,6 +78,7 @@ template <class Env> NLM2_FN float mexp2(const float x)
   return Env::int_as_float(k0 >= 0x800000 ? k0 : 0);
 }
 
+// Env: tid(), bid(), lds(), sync(), prio_high(), cvt_i32_sat(), int_as_float(); TIMED + clock() for the measuring build.
 // Args: nlm_args of nlmeans.hip (W, H, chk_w, chk_h, nchx, npatch, sharpness, norm[3], luma, chroma, skip_blend,
 // reach, cy0, out_row0, out_row1, variant).  F4 / I2: float4 / int2.
 template <int P, int WP, int TP, bool DEEP, class Env, class Args, class F4, class I2>
@@ -125,9 +126,15 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   }
   for(int i = tid; i < n; i += NL2_THREADS) dsv[i] = patches[i].x * WP + patches[i].y;
 
-  const bool par = tid >= NL2_SERIAL;
+  // DEEP: waves 0-1 run A2 and the first table row, wave 2 runs B, waves 3-15 are the parallel group -- THIRTEEN waves:
+  // a workgroup's waves go to the four SIMDs round-robin, so the SIMD of waves 3, 7, 11, 15 hosts no serial wave, and
+  // with wave 3 idle (as it was) its three parallel waves finished a stage in 2 850 cycles while those that share a
+  // SIMD with a recurrence needed 4 370 (tools/nlm_phase_clocks.py, profiles/r02_nlm_phase_clocks_*.json)
+  constexpr int SER = DEEP ? 192 : NL2_SERIAL;
+  constexpr int PAR = NL2_THREADS - SER;
+  const bool par = tid >= SER;
   if(!par) env.prio_high(); // the recurrences are latency chains: let them issue ahead of the parallel waves
-  const int u = tid - NL2_SERIAL;
+  const int u = tid - SER;
 
   // ---- parallel group: the pixels a thread accumulates for the whole chunk: window offset | table offset << 16
   float accx[NL2_PX], accy[NL2_PX], accz[NL2_PX], accw[NL2_PX];
@@ -136,7 +143,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   for(int k = 0; k < NL2_PX; k++)
   {
     accx[k] = accy[k] = accz[k] = accw[k] = 0.0f;
-    const int idx = u + NL2_PAR * k;
+    const int idx = u + PAR * k;
     const int r = idx / cw, c = idx - r * cw;
     pix[k] = (par && idx < ch * cw) ? (((reach + r) * WP + (reach + c)) | ((r * pitch + c) << 16)) : -1;
   }
@@ -145,7 +152,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   int a1w = 0, a1t = 0, jn = 0;
   {
     const int ncol = csw - 1;
-    const int nseg = NL2_PAR / (ncol * S);
+    const int nseg = PAR / (ncol * S);
     const int m0 = (ch - 2) / S + 1;
     const int mseg = (m0 + nseg - 1) / nseg;
     if(par && u < ncol * S * nseg)
@@ -295,14 +302,19 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     }
   };
   // ---- C: weights and accumulation (:416-436), parallel group; center_weight < 0: w = 2^-(distortion * sharpness)
+  // A lane without a pixel in a slot accumulates harmless garbage from window / table offset 0 -- its accumulators are
+  // never stored -- which saves four selects per pixel and offset.  (Skipping a slot that is empty in every lane of a
+  // wave with a uniform branch was measured: the branches split the LDS reads of the slots into blocks that wait one
+  // after the other, 12.3 against 11.7 ms on 24 MP.)
+#pragma unroll
+  for(int k = 0; k < NL2_PX; k++) pix[k] = pix[k] < 0 ? 0 : pix[k];
   auto C = [&](const float *const T, const int dS) {
     float dist[NL2_PX], qx[NL2_PX], qy[NL2_PX], qz[NL2_PX];
 #pragma unroll
     for(int k = 0; k < NL2_PX; k++)
     {
-      const int pk = pix[k] < 0 ? 0 : pix[k];
-      const int wo = (pk & 0xffff) + dS;
-      dist[k] = T[pk >> 16];
+      const int wo = (pix[k] & 0xffff) + dS;
+      dist[k] = T[pix[k] >> 16];
       const f2 q = XY[wo];
       qx[k] = q.x;
       qy[k] = q.y;
@@ -312,18 +324,17 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     for(int k = 0; k < NL2_PX; k++)
     {
       const float w = mexp2<Env>(dist[k] * a.sharpness);
-      const float sx = accx[k] + qx[k] * w, sy = accy[k] + qy[k] * w, sz = accz[k] + qz[k] * w, sw = accw[k] + 1.0f * w;
-      const bool ok = pix[k] >= 0;
-      accx[k] = ok ? sx : accx[k];
-      accy[k] = ok ? sy : accy[k];
-      accz[k] = ok ? sz : accz[k];
-      accw[k] = ok ? sw : accw[k];
+      accx[k] = accx[k] + qx[k] * w;
+      accy[k] = accy[k] + qy[k] * w;
+      accz[k] = accz[k] + qz[k] * w;
+      accw[k] = accw[k] + 1.0f * w;
     }
   };
 
 
   // a.variant: 0 = the shipped schedule; bits 4..8 switch a step off (timing experiments only: the result is then
   // wrong) -- A1, A2, B, C, first row
+  long long tm_out[6] = { 0, 0, 0, 0, 0, 0 };
   const int var = a.variant;
   const bool do_a1 = !(var & 16), do_a2 = !(var & 32), do_b = !(var & 64), do_c = !(var & 128), do_first = !(var & 256);
   if(DEEP)
@@ -331,26 +342,59 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // stage s: A1(s) and C(s - 3) on the parallel waves; A2(s - 1), then the first table row of offset s, on waves
     // 0-1; B(s - 2) on wave 2.  Offset p lives in table p & 3 from its A1 (stage p) to its C (stage p + 3); the table
     // is written again in stage p + 4.
+    // Env::TIMED (a measuring build, never the product's): cycles of each step of this wave, summed over the offsets;
+    // reading the clock also drains the wave's LDS queue at every step boundary, so the sum is an upper bound
+    long long tm[6] = { 0, 0, 0, 0, 0, 0 }; // A1, C, A2, first row, B, barrier wait
     for(int s = 0; s < n + 3; s++)
     {
+      long long t0 = 0, t1 = 0, t2 = 0;
+      if constexpr(Env::TIMED) t0 = env.clock();
       if(par)
       {
         if(s < n && do_a1) A1(lds + (s & 3) * tabsz, dsv[s]);
+        if constexpr(Env::TIMED) t1 = env.clock();
         if(s >= 3 && do_c) C(lds + ((s - 3) & 3) * tabsz, dsv[s - 3]);
+        if constexpr(Env::TIMED)
+        {
+          t2 = env.clock();
+          tm[0] += t1 - t0;
+          tm[1] += t2 - t1;
+        }
       }
       else if(tid < 128)
       {
         if(tid < csw)
         {
           if(s >= 1 && s <= n && do_a2) A2(lds + ((s - 1) & 3) * tabsz);
+          if constexpr(Env::TIMED) t1 = env.clock();
           if(s < n && do_first) A1_first(lds + (s & 3) * tabsz, dsv[s]);
+          if constexpr(Env::TIMED)
+          {
+            t2 = env.clock();
+            tm[2] += t1 - t0;
+            tm[3] += t2 - t1;
+          }
+        }
+        else if constexpr(Env::TIMED) t2 = t0;
+      }
+      else
+      {
+        if(s >= 2 && s <= n + 1 && do_b)
+        {
+          if(tid - 128 < ch) B(lds + ((s - 2) & 3) * tabsz, tid - 128);
+        }
+        if constexpr(Env::TIMED)
+        {
+          t2 = env.clock();
+          tm[4] += t2 - t0;
         }
       }
-      else if(s >= 2 && s <= n + 1 && do_b)
-      {
-        if(tid - 128 < ch) B(lds + ((s - 2) & 3) * tabsz, tid - 128);
-      }
       env.sync();
+      if constexpr(Env::TIMED) tm[5] += env.clock() - t2;
+    }
+    if constexpr(Env::TIMED)
+    {
+      for(int k = 0; k < 6; k++) tm_out[k] = tm[k];
     }
   }
   else
@@ -391,8 +435,8 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
 #pragma unroll
   for(int k = 0; k < NL2_PX; k++)
   {
-    if(pix[k] < 0) continue;
-    const int idx = u + NL2_PAR * k;
+    const int idx = u + PAR * k;
+    if(!par || idx >= ch * cw) continue;
     const int rr = idx / cw;
     const int row = top + rr, col = left + (idx - rr * cw);
     if(row < a.out_row0 || row >= a.out_row1) continue;
@@ -414,6 +458,26 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       r.w = (ip.w * 0.0f) + (accw[k] / accw[k] * 1.0f);
     }
     out[o] = r;
+  }
+  if constexpr(Env::TIMED)
+  {
+    // over the chunk's first row (the pixels above stay alive for the compiler, the measurement replaces them): pixel
+    // 2 w holds {A1, C, A2, first}, pixel 2 w + 1 {B, barrier wait, 0, 0} of wave w
+    env.sync();
+    if((tid & 63) == 0)
+    {
+      const int wv = tid >> 6;
+      F4 r0_, r1_;
+      r0_.x = (float)tm_out[0];
+      r0_.y = (float)tm_out[1];
+      r0_.z = (float)tm_out[2];
+      r0_.w = (float)tm_out[3];
+      r1_.x = (float)tm_out[4];
+      r1_.y = (float)tm_out[5];
+      r1_.z = r1_.w = 0.0f;
+      out[(long)top * W + left + 2 * wv] = r0_;
+      out[(long)top * W + left + 2 * wv + 1] = r1_;
+    }
   }
 }
 

@@ -790,6 +790,9 @@ struct nlm2_device_env
   __device__ __forceinline__ float *lds() const { return lds_; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ void prio_high() const { __builtin_amdgcn_s_setprio(3); }
+  __device__ __forceinline__ bool any(const bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0; }
+  static constexpr bool TIMED = false;
+  __device__ __forceinline__ long long clock() const { return 0; }
   static __device__ __forceinline__ float int_as_float(const int v) { return __int_as_float(v); }
   static __device__ __forceinline__ int cvt_i32_sat(const float v)
   {
@@ -819,6 +822,24 @@ __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2(const float4 *__res
   env.lds_ = lds;
   env.chunk_ = chunk;
   nlm2::body<P, WP, TP, DEEP>(env, in, out, a, patches);
+}
+
+// the measuring build (ANSEL_NLM2_TIMED, tools/nlm_phase_clocks.py): the same body with a clock read around every step
+struct nlm2_timed_env : nlm2_device_env
+{
+  static constexpr bool TIMED = true;
+  __device__ __forceinline__ long long clock() const { return (long long)__builtin_readcyclecounter(); }
+};
+__global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2_timed(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                                   const nlm_args a, const int2 *__restrict__ patches,
+                                                                   const int *__restrict__ order, const int n_border)
+{
+  extern __shared__ float lds[];
+  if(blockIdx.x < n_border) return;
+  nlm2_timed_env env;
+  env.lds_ = lds;
+  env.chunk_ = order[blockIdx.x];
+  nlm2::body<2, NL2_WP_TIGHT, NL2_TP_TIGHT, true>(env, in, out, a, patches);
 }
 
 typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
@@ -987,6 +1008,7 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   if(v2)
   {
     k2 = a.radius == 1 ? nlm2_kernel_of<1>(tight, deep) : (a.radius == 2 ? nlm2_kernel_of<2>(tight, deep) : nlm2_kernel_of<3>(tight, deep));
+    if(a.radius == 2 && tight && deep && getenv("ANSEL_NLM2_TIMED")) k2 = nlm_chunks_v2_timed;
     if(v2_bytes > 64 * 1024)
       ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_bytes));
     const char *const var_env = getenv("ANSEL_NLM2_VARIANT");

@@ -51,6 +51,9 @@ struct HostEnv
   float *lds() const { return lds_; }
   void sync() const { bar_->arrive_and_wait(); }
   void prio_high() const {}
+  bool any(const bool) const { return true; } // a wave-level vote on the device; every slot stays live here
+  static constexpr bool TIMED = false;
+  long long clock() const { return 0; }
   // v_cvt_i32_f32: truncation, saturating, NaN -> 0
   static int cvt_i32_sat(const float v)
   {
