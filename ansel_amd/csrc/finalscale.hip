@@ -99,8 +99,8 @@ struct plan_host
   std::vector<float> kernel;
 };
 
-// _prepare_resampling_plan(), interpolation.c:711-895, with x0 = 0 on both sides (finalscale.c:123-127)
-void plan_build(plan_host &p, const int kind, const int in, const int out, const float scale)
+// _prepare_resampling_plan(), interpolation.c:711-895 (finalscale: x0 = 0 on both sides, finalscale.c:123-127)
+void plan_build(plan_host &p, const int kind, const int in, const int in_x0, const int out, const int out_x0, const float scale)
 {
   const int w = k_half_width[kind];
   const int maxtaps = scale > 1.f ? 2 * w : (int)ceil_fast((float)2 * (float)w / scale);
@@ -112,16 +112,19 @@ void plan_build(plan_host &p, const int kind, const int in, const int out, const
     int first, taps;
     if(scale > 1.f)
     {
-      const float fx = (float)x / scale - 0; // _compute_upsampling_kernel(), :320-344
+      const float fx = (float)(out_x0 + x) / scale - in_x0; // _compute_upsampling_kernel(), :320-344
       first = (int)floorf(fx) - w + 1;
       taps = 2 * w;
       make_taps(kind, scratch.data(), taps, fx - (float)first, -1.0f);
     }
     else
     {
-      const float xin = ceil_fast(((float)x - (float)w) / scale); // _compute_downsampling_kernel(), :354-392
+      // _compute_downsampling_kernel(.., out_x0 + x), :354-392: the first tap is an absolute input index (in_x0 is not
+      // subtracted, :853)
+      const int xo = out_x0 + x;
+      const float xin = ceil_fast(((float)xo - (float)w) / scale);
       first = (int)xin;
-      const float t = xin * scale - (float)x;
+      const float t = xin * scale - (float)xo;
       taps = (int)(((float)w - t) / scale);
       if(taps > maxtaps + 4) taps = maxtaps + 4;
       make_taps(kind, scratch.data(), taps, t, scale);
@@ -140,32 +143,30 @@ void plan_build(plan_host &p, const int kind, const int in, const int out, const
   }
 }
 
-} // namespace
-
-extern "C" {
-
-int dt_hip_iop_finalscale_process(int devid, const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d,
-                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+// dt_interpolation_resample(), interpolation.c:897-1044, on RGBA pixels; origins: the regions' x / y count (initialscale)
+int resample_launch(int devid, const dt_hip_piece_t *piece, const int kind, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                    const bool origins, const char *tag)
 {
-  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || piece->channels != 4) return DT_HIP_INVALID_ARG;
-  if(d->interpolation < 0 || d->interpolation > 2)
-  {
-    set_last_error("finalscale: unknown interpolator %d", d->interpolation);
-    return DT_HIP_INVALID_ARG;
-  }
   const int iw = piece->roi_in.width, ih = piece->roi_in.height, ow = piece->roi_out.width, oh = piece->roi_out.height;
   if(iw <= 0 || ih <= 0 || ow <= 0 || oh <= 0) return DT_HIP_SUCCESS;
+  const int ix0 = origins ? piece->roi_in.x : 0, iy0 = origins ? piece->roi_in.y : 0;
+  const int ox0 = origins ? piece->roi_out.x : 0, oy0 = origins ? piece->roi_out.y : 0;
   const float so = (float)piece->roi_out.scale, si = (float)piece->roi_in.scale;
   if(!(so > 0.f) || !(si > 0.f)) return DT_HIP_INVALID_ARG;
-  if(so == 1.f || so == si) // interpolation.c:915-931: plain copy of the top-left window
+  if(so == 1.f || so == si) // interpolation.c:915-931: a crop
   {
-    if(ow > iw || oh > ih) return DT_HIP_INVALID_ARG;
-    return dt_hip_enqueue_copy_region(devid, dev_in, iw, 0, 0, dev_out, ow, 0, 0, ow, oh, 16);
+    const int x0 = ox0 - ix0, y0 = oy0 - iy0;
+    if(x0 < 0 || y0 < 0 || x0 + ow > iw || y0 + oh > ih)
+    {
+      set_last_error("%s: the 1:1 region [%d, %d) x [%d, %d) lies outside the %d x %d input", tag, x0, x0 + ow, y0, y0 + oh, iw, ih);
+      return DT_HIP_INVALID_ARG;
+    }
+    return dt_hip_enqueue_copy_region(devid, dev_in, iw, x0, y0, dev_out, ow, 0, 0, ow, oh, 16);
   }
   const float scale = so / si;
   plan_host h, v;
-  plan_build(h, d->interpolation, iw, ow, scale);
-  plan_build(v, d->interpolation, ih, oh, scale);
+  plan_build(h, kind, iw, ix0, ow, ox0, scale);
+  plan_build(v, kind, ih, iy0, oh, oy0, scale);
   // one upload: [h.length h.start h.index v.length v.start v.index | h.kernel v.kernel]
   const size_t n_int = h.length.size() + h.start.size() + h.index.size() + v.length.size() + v.start.size() + v.index.size();
   const size_t n_flt = h.kernel.size() + v.kernel.size();
@@ -191,11 +192,42 @@ int dt_hip_iop_finalscale_process(int devid, const dt_hip_piece_t *piece, const 
   plan_dev ph = { dev + o_hl, dev + o_hs, dev + o_hi, (const float *)(dev + o_hk) };
   plan_dev pv = { dev + o_vl, dev + o_vs, dev + o_vi, (const float *)(dev + o_vk) };
   {
-    launch_scope ls(devid, "finalscale_resample");
+    launch_scope ls(devid, tag);
     resample<<<pixel_grid((size_t)ow * oh), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, iw, ow, oh, ph, pv);
   }
   dt_hip_release_mem_object(dev);
-  return check_launch("finalscale_resample");
+  return check_launch(tag);
+}
+
+
+} // namespace
+
+extern "C" {
+
+int dt_hip_iop_finalscale_process(int devid, const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d,
+                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || piece->channels != 4) return DT_HIP_INVALID_ARG;
+  if(d->interpolation < 0 || d->interpolation > 2)
+  {
+    set_last_error("finalscale: unknown interpolator %d", d->interpolation);
+    return DT_HIP_INVALID_ARG;
+  }
+  return resample_launch(devid, piece, d->interpolation, dev_in, dev_out, false, "finalscale_resample");
+}
+
+// initialscale: process(), src/iop/initialscale.c:120-127 -- the same resampler with the regions as they are (roi_in:
+// the whole input buffer at scale 1, modify_roi_in() :72-83; roi_out: a region of the scaled image)
+int dt_hip_iop_initialscale_process(int devid, const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d,
+                                    dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || piece->channels != 4) return DT_HIP_INVALID_ARG;
+  if(d->interpolation < 0 || d->interpolation > 2)
+  {
+    set_last_error("initialscale: unknown interpolator %d", d->interpolation);
+    return DT_HIP_INVALID_ARG;
+  }
+  return resample_launch(devid, piece, d->interpolation, dev_in, dev_out, true, "initialscale_resample");
 }
 
 } // extern "C"

@@ -45,6 +45,7 @@ enum op_t
   OP_BILAT,
   OP_LAB_TO_RGB,
   OP_FINALSCALE,
+  OP_INITIALSCALE,
   OP_EXPORT_U16,
   OP_BLEND,
   OP_EXPORT_ROWS,
@@ -76,6 +77,7 @@ const op_info_t k_ops[] = {
   { "bilat", sizeof(dt_hip_bilat_data_t), 16 },
   { "lab_to_rgb", sizeof(dt_hip_lab_data_t), 16 },
   { "finalscale", sizeof(dt_hip_finalscale_data_t), 16 },
+  { "initialscale", sizeof(dt_hip_finalscale_data_t), 16 },
   { "export_u16", 0, 8 },
   { "blend", sizeof(dt_hip_blend_data_t), 0 },
   { "export_rows", sizeof(dt_hip_export_rows_t), 0 },
@@ -135,6 +137,7 @@ int run_single(int devid, const node_t &n, dt_hip_mem_t in, dt_hip_mem_t out)
     case OP_FILMICRGB: return dt_hip_iop_filmicrgb_process(devid, &n.piece, n.as<dt_hip_filmicrgb_data_t>(), in, out);
     case OP_COLOROUT: return dt_hip_iop_colorout_process(devid, &n.piece, n.as<dt_hip_conversion_t>(), in, out);
     case OP_FINALSCALE: return dt_hip_iop_finalscale_process(devid, &n.piece, n.as<dt_hip_finalscale_data_t>(), in, out);
+    case OP_INITIALSCALE: return dt_hip_iop_initialscale_process(devid, &n.piece, n.as<dt_hip_finalscale_data_t>(), in, out);
     case OP_EXPORT_U16: return dt_hip_export_convert_u16(devid, n.piece.roi_out.width, n.piece.roi_out.height, in, out);
     case OP_EXPORT_U8: return dt_hip_export_convert_u8(devid, n.piece.roi_out.width, n.piece.roi_out.height, in, out);
     case OP_EXPORT_ROWS:
@@ -626,9 +629,9 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
   if(b.row0 < 0 || b.row0 + b.rows > H) return DT_HIP_INVALID_ARG;
   for(const node_t &n : pipe->nodes)
   {
-    if(n.op == OP_FINALSCALE)
+    if(n.op == OP_FINALSCALE || n.op == OP_INITIALSCALE)
     {
-      // finalscale changes the geometry
+      // finalscale / initialscale change the geometry
       set_last_error("band mode: '%s' has no row-band implementation", k_ops[n.op].name);
       return DT_HIP_INVALID_ARG;
     }

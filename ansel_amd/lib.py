@@ -117,6 +117,7 @@ def load():
         "dt_hip_transform_lab_to_rgb": (i, [i, P(abi.Piece), P(abi.LabData), vp, vp]),
         "dt_hip_iop_bilat_process": (i, [i, P(abi.Piece), P(abi.BilatData), vp, vp]),
         "dt_hip_iop_finalscale_process": (i, [i, P(abi.Piece), P(abi.FinalscaleData), vp, vp]),
+        "dt_hip_iop_initialscale_process": (i, [i, P(abi.Piece), P(abi.FinalscaleData), vp, vp]),
         "dt_hip_develop_blend_process": (i, [i, P(abi.Piece), P(abi.BlendData), vp, vp]),
         "dt_hip_iop_basebuffer_process": (i, [i, P(abi.Piece), i, i, i, vp, vp]),
         "dt_hip_alloc_host_pinned": (vp, [sz]),

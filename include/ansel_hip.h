@@ -556,6 +556,11 @@ typedef struct dt_hip_finalscale_data_t
 } dt_hip_finalscale_data_t;
 int dt_hip_iop_finalscale_process(int devid, const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d,
                                   dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+/* initialscale: process(), src/iop/initialscale.c:120-127 -- dt_iop_clip_and_zoom_roi() with the regions as they are:
+ * roi_in the whole input buffer at scale 1 (modify_roi_in(), :72-83), roi_out a region of the scaled image at its offset;
+ * at scale 1 a crop.  Same data (the interpolator) as finalscale. */
+int dt_hip_iop_initialscale_process(int devid, const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d,
+                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
 /* basebuffer: process(), src/iop/basebuffer.c:118-160 -- the first node of every pipe copies the region
  * roi_out of the full sensor buffer (host memory of the mipmap cache, iwidth x iheight pixels of bpp bytes,

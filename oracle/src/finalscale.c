@@ -66,7 +66,7 @@ static void plan_free(plan_t *p)
   free(p->kernel);
 }
 
-static void plan_build(plan_t *p, const int kind, const int in, const int out, const float scale)
+static void plan_build(plan_t *p, const int kind, const int in, const int in_x0, const int out, const int out_x0, const float scale)
 {
   const int w = half_width[kind];
   const int maxtaps = scale > 1.f ? 2 * w : (int)ceil_fast((float)2 * (float)w / scale);
@@ -81,16 +81,19 @@ static void plan_build(plan_t *p, const int kind, const int in, const int out, c
     int first, taps;
     if(scale > 1.f)
     {
-      const float fx = (float)(0 + x) / scale - 0;
+      const float fx = (float)(out_x0 + x) / scale - in_x0;
       first = (int)floorf(fx) - w + 1;
       taps = 2 * w;
       make_taps(kind, scratch, taps, fx - (float)first, -1.0f);
     }
     else
     {
-      const float xin = ceil_fast(((float)x - (float)w) / scale);
+      /* _compute_downsampling_kernel(.., out_x0 + x): the first tap is an ABSOLUTE input index, in_x0 is not subtracted
+       * (interpolation.c:853) */
+      const int xo = out_x0 + x;
+      const float xin = ceil_fast(((float)xo - (float)w) / scale);
       first = (int)xin;
-      const float t = xin * scale - (float)x;
+      const float t = xin * scale - (float)xo;
       taps = (int)(((float)w - t) / scale);
       make_taps(kind, scratch, taps, t, scale);
     }
@@ -110,22 +113,26 @@ static void plan_build(plan_t *p, const int kind, const int in, const int out, c
   free(scratch);
 }
 
-int oracle_finalscale(const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d, const void *in_, void *out_)
+/* dt_interpolation_resample(), interpolation.c:897-1044, on 4-channel pixels; origins: use the regions' x / y */
+static int resample(const dt_hip_piece_t *piece, const int kind, const float *in, float *out, const int origins)
 {
-  if(d->interpolation < 0 || d->interpolation > 2) return 1;
-  const float *in = (const float *)in_;
-  float *out = (float *)out_;
+  if(kind < 0 || kind > 2) return 1;
   const int iw = piece->roi_in.width, ih = piece->roi_in.height, ow = piece->roi_out.width, oh = piece->roi_out.height;
+  const int ix0 = origins ? piece->roi_in.x : 0, iy0 = origins ? piece->roi_in.y : 0;
+  const int ox0 = origins ? piece->roi_out.x : 0, oy0 = origins ? piece->roi_out.y : 0;
   const float so = (float)piece->roi_out.scale, si = (float)piece->roi_in.scale;
   if(so == 1.f || so == si)
   {
-    for(int y = 0; y < oh; y++) memcpy(out + 4 * (size_t)ow * y, in + 4 * (size_t)iw * y, sizeof(float) * 4 * ow);
+    /* :915-931: a crop */
+    const int x0 = ox0 - ix0, y0 = oy0 - iy0;
+    if(x0 < 0 || y0 < 0 || x0 + ow > iw || y0 + oh > ih) return 1; /* the reference would read outside its input */
+    for(int y = 0; y < oh; y++) memcpy(out + 4 * (size_t)ow * y, in + 4 * ((size_t)iw * (y + y0) + x0), sizeof(float) * 4 * ow);
     return 0;
   }
   const float scale = so / si;
   plan_t h, v;
-  plan_build(&h, d->interpolation, iw, ow, scale);
-  plan_build(&v, d->interpolation, ih, oh, scale);
+  plan_build(&h, kind, iw, ix0, ow, ox0, scale);
+  plan_build(&v, kind, ih, iy0, oh, oy0, scale);
 #pragma omp parallel for
   for(int oy = 0; oy < oh; oy++)
     for(int ox = 0; ox < ow; ox++)
@@ -149,4 +156,17 @@ int oracle_finalscale(const dt_hip_piece_t *piece, const dt_hip_finalscale_data_
   plan_free(&h);
   plan_free(&v);
   return 0;
+}
+
+/* finalscale: process(), src/iop/finalscale.c:117-131 -- the regions' origins are zeroed, only the sizes and scales count */
+int oracle_finalscale(const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d, const void *in_, void *out_)
+{
+  return resample(piece, d->interpolation, (const float *)in_, (float *)out_, 0);
+}
+
+/* initialscale: process(), src/iop/initialscale.c:120-127 -- dt_iop_clip_and_zoom_roi() with the regions as they are:
+ * roi_in is the whole input buffer at scale 1 (modify_roi_in(), :72-83), roi_out a region of the scaled image */
+int oracle_initialscale(const dt_hip_piece_t *piece, const dt_hip_finalscale_data_t *d, const void *in_, void *out_)
+{
+  return resample(piece, d->interpolation, (const float *)in_, (float *)out_, 1);
 }

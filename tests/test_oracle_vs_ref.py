@@ -362,6 +362,26 @@ def test_finalscale(interp, iw, ih, scale):
     _exact(a, b, "finalscale")
 
 
+@pytest.mark.parametrize("interp", [0, 1, 2])
+@pytest.mark.parametrize("iw,ih,scale,ox,oy,ow,oh", [(300, 200, 0.5, 0, 0, 150, 100), (300, 200, 0.37, 11, 7, 90, 60),
+                                                   (257, 131, 0.81, 40, 3, 160, 100), (64, 48, 1.7, 9, 5, 90, 70),
+                                                   (120, 90, 1.0, 17, 23, 80, 50), (33, 29, 0.2, 1, 2, 5, 3)])
+def test_initialscale(interp, iw, ih, scale, ox, oy, ow, oh):
+    """initialscale (src/iop/initialscale.c:120-127): the resampler with the regions as they are -- roi_in the whole
+    buffer at scale 1, roi_out a region of the scaled image at an offset (a crop when the scale is 1)"""
+    img = synth.rgba_image(iw, ih, seed=37, lo=-0.05, hi=1.3)
+    img[..., 3] = 0.25
+    piece = abi.Piece.make(ow, oh, roi_in=abi.Roi.make(0, 0, iw, ih, 1.0), roi_out=abi.Roi.make(ox, oy, ow, oh, scale))
+    a, b = _pair("initialscale", piece, abi.FinalscaleData(interp), img, (oh, ow, 4))
+    _exact(a, b, "initialscale")
+    if scale != 1.0 and (ox or oy):
+        # the origin matters: the same region at the origin is another picture
+        p0 = abi.Piece.make(ow, oh, roi_in=abi.Roi.make(0, 0, iw, ih, 1.0), roi_out=abi.Roi.make(0, 0, ow, oh, scale))
+        c = np.zeros((oh, ow, 4), np.float32)
+        assert ck.call(ck.oracle(), "oracle_initialscale", p0, abi.FinalscaleData(interp), img, c) == 0
+        assert not np.array_equal(b, c)
+
+
 @pytest.mark.parametrize("w,h", [(300, 200), (123, 457), (64, 64), (257, 130)])
 @pytest.mark.parametrize("hl,sh,detail,mid", [(0.5, 0.5, 0.25, 0.5), (1.0, 0.2, 1.5, 0.3), (0.1, 1.3, -0.6, 0.8)])
 def test_bilat_local_laplacian(w, h, hl, sh, detail, mid):
