@@ -292,7 +292,8 @@ def valu_floor_ms(tag, mpix):
         mix = json.load(open(os.path.join(ROOT, "profiles", "r02_isa_mix.json")))
     except (OSError, ValueError):
         return None
-    alias = {"dn_decompose": "dn_decompose_strip", "nlm_chunks": "nlm_chunks_v2", "diffuse_decompose": "bspline_decompose"}
+    alias = {"dn_decompose": "dn_decompose_strip", "nlm_chunks": "nlm_chunks_v2", "diffuse_decompose": "bspline_decompose_strip",
+             "diffuse_pde": "diffuse_pde_strip"}
     kernels = mix.get("kernels", {})
     k = kernels.get(tag) or kernels.get(tag.replace("_u16", "")) or kernels.get(alias.get(tag, ""))
     if not k or "issue_floor_ms_per_mpix" not in k:
