@@ -641,12 +641,6 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
       set_last_error("band mode: local contrast runs on row bands in its bilateral-grid mode only");
       return DT_HIP_INVALID_ARG;
     }
-    if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->form_mask)
-    {
-      // the plane is the frame's: a band would need its own rows of it
-      set_last_error("band mode: a blend with a host-rendered form mask has no row-band implementation");
-      return DT_HIP_INVALID_ARG;
-    }
     if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->feathering_radius > 0.1f)
     {
       // the guided filter works on its own 512-pixel tile grid over the whole frame
@@ -1605,7 +1599,10 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
       }
       node_t n = first;
       band_piece(n.piece, b);
-      err = dt_hip_develop_blend_process(devid, &n.piece, n.as<dt_hip_blend_data_t>(), pv->held, pv->cur);
+      dt_hip_blend_data_t bd = *n.as<dt_hip_blend_data_t>();
+      // the host-rendered form mask is the FRAME's plane (every band's device holds it whole): the band reads its rows
+      if(bd.form_mask) bd.form_mask = (dt_hip_mem_t)((float *)bd.form_mask + (size_t)b.row0 * first.piece.roi_out.width);
+      err = dt_hip_develop_blend_process(devid, &n.piece, &bd, pv->held, pv->cur);
       if(pv->held_owned && pv->held_base) dt_hip_release_mem_object(pv->held_base);
       pv->held = pv->held_base = nullptr;
       pv->held_owned = false;

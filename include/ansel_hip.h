@@ -716,9 +716,10 @@ int dt_hip_batch_drain(dt_hip_batch_t *batch);
  * of every scale from own + fetched rows of the scale before; diffuse runs on
  * [halo][rows][halo] as on a frame of its own (h covers every stencil of every iteration / scale, so only halo
  * rows see the artificial border); non-local means runs the chunk rows of the FRAME's grid that intersect the
- * band (nlmeans_core.c:264-313: the grid is a function of the frame size).  Blend nodes with uniform or parametric
- * masks are pointwise and run on the band; bilat (one grid accumulated over the frame in pixel order), finalscale and
- * blends with a mask blur are refused in band mode. */
+ * band (nlmeans_core.c:264-313: the grid is a function of the frame size).  Blend nodes with uniform, parametric or
+ * host-rendered form masks (form_mask = the FRAME's plane, whole on every band's device) are pointwise and run on the
+ * band; local contrast's bilateral grid is relayed from band to band (relay_buf below).  Refused in band mode: the local
+ * laplacian, finalscale / initialscale, blends with a mask blur or mask feathering. */
 #define DT_HIP_BAND_EXCHANGE 1
 typedef struct dt_hip_band_t
 {

@@ -236,6 +236,35 @@ def test_blended_pipe_closed_by_a_blend_on_bands():
     p.close()
 
 
+def test_blend_with_a_form_mask_on_bands():
+    """a host-rendered form mask (drawn shapes + a parametric condition) in band mode: the plane is the frame's, every
+    band reads its rows"""
+    import blend_cases
+    from ansel_amd import abi
+    torch, lut, d_lut = _setup()
+    w, h = 400, 640
+    rgb = abi.Piece.make(w, h, channels=4)
+    form = torch.from_numpy(blend_cases.form_plane(w, h)).to("cuda:0")
+    d = dict(blend_cases.form_cases(abi.BLEND_CS_RGB_SCENE))["drawn-c0"]
+    d.form_mask = form.data_ptr()
+    nodes = [pipe.Node("diffuse", params.diffuse("lens_deblur_soft", iterations=1), rgb), pipe.Node("blend", d, rgb)]
+    img = synth.rgba_image(w, h, seed=3)
+    d_in = torch.from_numpy(img).to("cuda:0")
+    p = pipe.DevicePipe(0, nodes)
+    whole = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    p.process(d_in.data_ptr(), whole.data_ptr())
+    engine = tiled.HipBandEngine(p, "cuda:0")
+    bands = tiled.plan_bands(w, h, 3, -1)
+    outs = [torch.zeros((b.rows, w, 4), dtype=torch.float32, device="cuda:0") for b in bands]
+    tiled.process_bands_locally(engine, bands, [d_in[b.row0:b.row0 + b.rows].data_ptr() for b in bands],
+                                [t.data_ptr() for t in outs], w)
+    torch.cuda.synchronize()
+    p.close()
+    # bit patterns: the test plane carries a NaN, which the blend hands through
+    assert torch.equal(torch.cat(outs, dim=0).view(torch.int32), whole.view(torch.int32))
+    assert not torch.equal(whole.view(torch.int32), d_in.view(torch.int32))
+
+
 @pytest.mark.parametrize("which", ["all", "everything"])
 def test_band_abort_frees_what_a_stopped_walk_holds(which):
     """dt_hip_pipe_band_abort(): a band given up at any stop of the walk (an error on another rank, a cancelled export)
