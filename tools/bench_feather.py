@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the blend stage with mask feathering (the guided filter) on a 24 MP frame (run on the GPU box).
+"""Time the blend stage with mask feathering (the guided filter) and with a mask blur on a 24 MP frame (run on the GPU box).
 
     python tools/bench_feather.py [radius]"""
 import ctypes as C
@@ -24,8 +24,9 @@ def main():
     da, db = lib.DeviceBuffer.from_numpy(0, a), lib.DeviceBuffer.from_numpy(0, b)
     piece = abi.Piece.make(w, h)
     d = abi.BlendData.uniform(params.WORK_IN, 80.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.2, 0.6, 0.9, boost=1.0)
-    for label, r in (("parametric mask only", 0.0), ("+ feathering radius %g" % radius, radius)):
-        d.feathering_radius, d.feathering_guide = r, abi.MASK_GUIDE_OUT_AFTER_BLUR
+    for label, r, blur in (("parametric mask only", 0.0, 0.0), ("+ feathering radius %g" % radius, radius, 0.0),
+                           ("+ mask blur radius %g" % radius, 0.0, radius)):
+        d.feathering_radius, d.feathering_guide, d.blur_radius = r, abi.MASK_GUIDE_OUT_AFTER_BLUR, blur
         l.dt_hip_events_reset(0)
         l.dt_hip_events_enable(0, 1)
         ts = []
