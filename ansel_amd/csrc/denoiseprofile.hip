@@ -456,9 +456,12 @@ struct thr_args
 // its segments in increasing order; accumulator t is thread t % 64 of workgroup t / 64 (the order of the additions
 // does not depend on which workgroup holds an accumulator; sixteen CUs read the table sixteen times faster than one)
 #define THR_GROUPS 16
-__global__ __launch_bounds__(64) void dn_band_sums(const double *__restrict__ partial, const size_t n_partial,
-                                                  double *__restrict__ acc /* [4][1024] */)
+// (blockIdx.y = the band: the tables and accumulators of all bands of a frame in one launch)
+__global__ __launch_bounds__(64) void dn_band_sums(const double *__restrict__ partial_all, const size_t n_partial,
+                                                  double *__restrict__ acc_all /* [bands][4][1024] */)
 {
+  const double *const partial = partial_all + (size_t)blockIdx.y * n_partial * 4;
+  double *const acc = acc_all + (size_t)blockIdx.y * 4 * 1024;
   const int t = blockIdx.x * 64 + threadIdx.x;
   double s[4] = { 0.0, 0.0, 0.0, 0.0 };
   typedef double d4 __attribute__((ext_vector_type(4)));
@@ -492,10 +495,17 @@ __global__ __launch_bounds__(64) void dn_band_sums(const double *__restrict__ pa
 
 // the 1024 accumulators reduced by halving (off = 512..1), rounded once to binary32, then
 // variance_stabilizing_xform(), denoiseprofile.c:1223-1287
-__global__ __launch_bounds__(1024) void dn_band_threshold(const double *__restrict__ sums /* [4][1024] */, const thr_args a,
-                                                          float *__restrict__ thrs)
+struct thr_args_all
+{
+  thr_args band[BANDS];
+};
+__global__ __launch_bounds__(1024) void dn_band_threshold(const double *__restrict__ sums_all /* [bands][4][1024] */,
+                                                          const thr_args_all all, float *__restrict__ thrs_all)
 {
   __shared__ double acc[4][1024];
+  const double *const sums = sums_all + (size_t)blockIdx.x * 4 * 1024;
+  const thr_args &a = all.band[blockIdx.x];
+  float *const thrs = thrs_all + 4 * blockIdx.x;
   const int t = threadIdx.x;
 #pragma unroll
   for(int c = 0; c < 4; c++) acc[c][t] = sums[c * 1024 + t];
@@ -1003,17 +1013,21 @@ int denoiseprofile_band_finish(dn_band_job_t *j, dt_hip_mem_t dev_out)
   memset(&sy, 0, sizeof(sy));
   sy.nbands = j->max_scale;
   sy.thrs = j->thrs;
-  double *accs = (double *)dt_hip_alloc_device_buffer(devid, 4 * 1024 * sizeof(double));
+  double *accs = (double *)dt_hip_alloc_device_buffer(devid, (size_t)BANDS * 4 * 1024 * sizeof(double));
   if(!accs) err = DT_HIP_SYSMEM_ALLOCATION;
-  for(int scale = 0; scale < j->max_scale && err == DT_HIP_SUCCESS; scale++)
+  thr_args_all all;
+  memset(&all, 0, sizeof(all));
+  for(int scale = 0; scale < j->max_scale; scale++)
   {
-    thr_args ta;
-    ta.n_partial = n_frame;
-    threshold_args(&j->d, scale, j->max_scale, (size_t)j->w * j->frame_h, ta);
+    all.band[scale].n_partial = n_frame;
+    threshold_args(&j->d, scale, j->max_scale, (size_t)j->w * j->frame_h, all.band[scale]);
     sy.detail[scale] = j->det[scale];
+  }
+  if(err == DT_HIP_SUCCESS)
+  {
     launch_scope ls(devid, "dn_band_threshold");
-    dn_band_sums<<<THR_GROUPS, 64, 0, st>>>(j->sums + (size_t)scale * n_frame * 4, n_frame, accs);
-    dn_band_threshold<<<1, 1024, 0, st>>>(accs, ta, j->thrs + 4 * scale);
+    dn_band_sums<<<dim3(THR_GROUPS, j->max_scale), 64, 0, st>>>(j->sums, n_frame, accs);
+    dn_band_threshold<<<j->max_scale, 1024, 0, st>>>(accs, all, j->thrs);
     err = check_launch("denoiseprofile band threshold");
   }
   if(err == DT_HIP_SUCCESS)
@@ -1059,9 +1073,11 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
   const size_t n_partial = (size_t)h * nseg;
   float4 *precond = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
   float4 *tmp = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
-  double *partial = (double *)dt_hip_alloc_device_buffer(devid, n_partial * 4 * sizeof(double));
+  // the tables of partial sums of ALL bands: the thresholds are needed by dn_finish only, so they are reduced together
+  // behind the last decomposition (seven pairs of latency-bound launches in a row cost 0.39 ms per frame)
+  double *partial = (double *)dt_hip_alloc_device_buffer(devid, (size_t)BANDS * n_partial * 4 * sizeof(double));
   float *thrs = (float *)dt_hip_alloc_device_buffer(devid, BANDS * 4 * sizeof(float));
-  double *accs = (double *)dt_hip_alloc_device_buffer(devid, 4 * 1024 * sizeof(double));
+  double *accs = (double *)dt_hip_alloc_device_buffer(devid, (size_t)BANDS * 4 * 1024 * sizeof(double));
   int err = (precond && tmp && partial && thrs && accs) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
   // one detail plane per band, all alive until the single synthesis pass at the end
   synth_args sy;
@@ -1091,20 +1107,27 @@ int dt_hip_iop_denoiseprofile_process(int devid, const dt_hip_piece_t *piece, co
     const float sigma_band = powf(varf, scale) * 1.0f;
     {
       launch_scope ls(devid, "dn_decompose");
-      launch_decompose(st, b1, b2, det[scale], partial, w, h, mult, 1.0f / (sigma_band * sigma_band), nseg, 0, h);
-    }
-    thr_args ta;
-    ta.n_partial = n_partial;
-    threshold_args(d, scale, s.max_scale, npix, ta);
-    {
-      launch_scope ls(devid, "dn_band_threshold");
-      dn_band_sums<<<THR_GROUPS, 64, 0, st>>>(partial, n_partial, accs);
-      dn_band_threshold<<<1, 1024, 0, st>>>(accs, ta, thrs + 4 * scale);
+      launch_decompose(st, b1, b2, det[scale], partial + (size_t)scale * n_partial * 4, w, h, mult,
+                       1.0f / (sigma_band * sigma_band), nseg, 0, h);
     }
     err = check_launch("denoiseprofile band");
     float4 *t = b2;
     b2 = b1;
     b1 = t;
+  }
+  if(err == DT_HIP_SUCCESS)
+  {
+    thr_args_all all;
+    memset(&all, 0, sizeof(all));
+    for(int scale = 0; scale < s.max_scale; scale++)
+    {
+      all.band[scale].n_partial = n_partial;
+      threshold_args(d, scale, s.max_scale, npix, all.band[scale]);
+    }
+    launch_scope ls(devid, "dn_band_threshold");
+    dn_band_sums<<<dim3(THR_GROUPS, s.max_scale), 64, 0, st>>>(partial, n_partial, accs);
+    dn_band_threshold<<<s.max_scale, 1024, 0, st>>>(accs, all, thrs);
+    err = check_launch("denoiseprofile thresholds");
   }
   if(err == DT_HIP_SUCCESS)
   {
