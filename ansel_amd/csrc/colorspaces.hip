@@ -123,22 +123,6 @@ int dt_hip_iop_colorout_process(int devid, const dt_hip_piece_t *piece, const dt
 
 namespace
 {
-// lab_f() with cbrt_5f() + cbrta_halleyf(), src/common/colorspaces_inline_conversions.h:50-73
-__device__ __forceinline__ float lab_f(const float x)
-{
-  const float epsilon = 216.0f / 24389.0f, kappa = 24389.0f / 27.0f;
-  if(!(x > epsilon)) return (kappa * x + 16.0f) / 116.0f;
-  const float a = __uint_as_float(__float_as_uint(x) / 3u + 709921077u);
-  const float a3 = a * a * a;
-  return a * (a3 + x + x) / (a3 + a3 + x);
-}
-// lab_f_inv(), :88-94
-__device__ __forceinline__ float lab_f_inv(const float x)
-{
-  const float epsilon = 0.20689655172413796f, kappa = 24389.0f / 27.0f;
-  return (x > epsilon) ? x * x * x : (116.0f * x - 16.0f) / kappa;
-}
-
 struct lab_args
 {
   float m[3][4];
@@ -149,12 +133,7 @@ __global__ __launch_bounds__(256) void rgb_to_lab(const float4 *in, float4 *out,
                                                   const lab_args a)
 {
   for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
-  {
-    const float4 p = in[k];
-    const float4 xyz = mat3x4(p.x, p.y, p.z, a.m);
-    const float f0 = lab_f(xyz.x / 0.9642f), f1 = lab_f(xyz.y / 1.0f), f2 = lab_f(xyz.z / 0.8249f);
-    out[k] = make_float4(116.0f * f1 - 16.0f, 500.0f * (f0 - f1), 200.0f * (f1 - f2), p.w);
-  }
+    out[k] = px_rgb_to_lab(in[k], a.m);
 }
 
 // _transform_lab_to_rgb_matrix(), :423-450 + dt_Lab_to_XYZ()
@@ -162,14 +141,7 @@ __global__ __launch_bounds__(256) void lab_to_rgb(const float4 *in, float4 *out,
                                                   const lab_args a)
 {
   for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
-  {
-    const float4 p = in[k];
-    const float fy = (p.x + 16.0f) / 116.0f;
-    const float fx = p.y / 500.0f + fy;
-    const float fz = fy - p.z / 200.0f;
-    const float4 rgb = mat3x4(0.9642f * lab_f_inv(fx), 1.0f * lab_f_inv(fy), 0.8249f * lab_f_inv(fz), a.m);
-    out[k] = make_float4(rgb.x, rgb.y, rgb.z, p.w);
-  }
+    out[k] = px_lab_to_rgb(in[k], a.m);
 }
 
 int lab_launch(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, dt_hip_mem_t dev_in,

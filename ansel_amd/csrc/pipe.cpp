@@ -198,7 +198,9 @@ struct dt_hip_pipe_t
           g.raw = r;
         }
       }
-      else if(fusion && nodes[i].op >= OP_EXPOSURE && nodes[i].op <= OP_COLOROUT && nodes[i].piece.channels == 4 && !blended(i))
+      else if(fusion && nodes[i].piece.channels == 4 && !blended(i)
+              && ((nodes[i].op >= OP_EXPOSURE && nodes[i].op <= OP_COLOROUT)
+                  || (nodes[i].op == OP_LAB_TO_RGB && i + 1 < n && nodes[i + 1].op >= OP_EXPOSURE && nodes[i + 1].op <= OP_COLOROUT)))
       {
         rgb_group_t r;
         memset(&r, 0, sizeof(r));
@@ -209,6 +211,13 @@ struct dt_hip_pipe_t
         // as it walks that order
         int last_op = -1;
         int j = i;
+        if(nodes[i].op == OP_LAB_TO_RGB)
+        {
+          // the Lab -> RGB glue behind a Lab module is the first stage of the run that follows it
+          r.pre_lab = 1;
+          r.lab_pre = *nodes[i].as<dt_hip_lab_data_t>();
+          j++;
+        }
         while(j < n && r.n_ops < 8)
         {
           const node_t &nd = nodes[j];
@@ -245,7 +254,15 @@ struct dt_hip_pipe_t
             j++;
           }
         }
-        if(j - i > 1)
+        else if(r.n_ops > 0 && j < n && nodes[j].op == OP_RGB_TO_LAB && !blended(j) && nodes[j].piece.channels == 4
+                && nodes[j].piece.roi_out.width == r.width && nodes[j].piece.roi_out.height == r.height)
+        {
+          // ... and the RGB -> Lab glue in front of a Lab module its last one
+          r.post_lab = 1;
+          r.lab_post = *nodes[j].as<dt_hip_lab_data_t>();
+          j++;
+        }
+        if(j - i > 1 && r.n_ops > 0)
         {
           g.kind = group_t::RGB;
           g.count = j - i;

@@ -22,7 +22,7 @@ int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hi
 bool raw_group_supported(const raw_group_t &g);
 
 // ---- fused RGBA group: any order of exposure, colorin, channelmixerrgb, filmicrgb, colorout,
-//      optionally closed by the float -> u16 conversion ------------------------------------------
+//      optionally opened / closed by the Lab glue of the pipe and closed by the float -> u16 conversion ------------------------------------------
 enum rgb_op_t { RGB_OP_EXPOSURE = 0, RGB_OP_COLORIN, RGB_OP_CHANNELMIXER, RGB_OP_FILMIC, RGB_OP_COLOROUT, RGB_OP_END };
 struct rgb_group_t
 {
@@ -34,6 +34,9 @@ struct rgb_group_t
   dt_hip_channelmixerrgb_data_t channelmixer;
   dt_hip_filmicrgb_data_t filmic;
   int to_u16; // 0: float4 out, 1: RGBA u16, 2: RGB u16 rows (export_u16 + export_rows)
+  // the pipe's colourspace glue next to the run: "lab_to_rgb" in front of it, "rgb_to_lab" behind it (never with to_u16)
+  int pre_lab, post_lab;
+  dt_hip_lab_data_t lab_pre, lab_post;
 };
 int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 

@@ -266,6 +266,10 @@ int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hi
     }
   }
   a.to_u16 = g.to_u16;
+  a.pre_lab = g.pre_lab;
+  a.post_lab = g.post_lab;
+  memcpy(a.lab_pre, g.lab_pre.matrix, sizeof(a.lab_pre));
+  memcpy(a.lab_post, g.lab_post.matrix, sizeof(a.lab_post));
   hipStream_t s = stream_of(devid);
   const unsigned grid = pixel_grid(np); // one pixel per thread, see rgb_chain_kernel.h
   const float4 *in = (const float4 *)dev_in;

@@ -59,6 +59,39 @@ __device__ __forceinline__ float4 mat3x4(const float x, const float y, const flo
   return o;
 }
 
+// ---- the RGB <-> Lab glue of the pipe (pixelpipe_cpu.c:59-75), per pixel: colorspaces.hip and the fused chain ----
+// lab_f() with cbrt_5f() + cbrta_halleyf(), src/common/colorspaces_inline_conversions.h:50-73
+__device__ __forceinline__ float lab_f(const float x)
+{
+  const float epsilon = 216.0f / 24389.0f, kappa = 24389.0f / 27.0f;
+  if(!(x > epsilon)) return (kappa * x + 16.0f) / 116.0f;
+  const float a = __uint_as_float(__float_as_uint(x) / 3u + 709921077u);
+  const float a3 = a * a * a;
+  return a * (a3 + x + x) / (a3 + a3 + x);
+}
+// lab_f_inv(), :88-94
+__device__ __forceinline__ float lab_f_inv(const float x)
+{
+  const float epsilon = 0.20689655172413796f, kappa = 24389.0f / 27.0f;
+  return (x > epsilon) ? x * x * x : (116.0f * x - 16.0f) / kappa;
+}
+// _transform_rgb_to_lab_matrix(), src/colorprofiles/iop_profile.c:405-418 + dt_XYZ_to_Lab()
+__device__ __forceinline__ float4 px_rgb_to_lab(const float4 p, const float m[3][4])
+{
+  const float4 xyz = mat3x4(p.x, p.y, p.z, m);
+  const float f0 = lab_f(xyz.x / 0.9642f), f1 = lab_f(xyz.y / 1.0f), f2 = lab_f(xyz.z / 0.8249f);
+  return make_float4(116.0f * f1 - 16.0f, 500.0f * (f0 - f1), 200.0f * (f1 - f2), p.w);
+}
+// _transform_lab_to_rgb_matrix(), :423-450 + dt_Lab_to_XYZ()
+__device__ __forceinline__ float4 px_lab_to_rgb(const float4 p, const float m[3][4])
+{
+  const float fy = (p.x + 16.0f) / 116.0f;
+  const float fx = p.y / 500.0f + fy;
+  const float fz = fy - p.z / 200.0f;
+  const float4 rgb = mat3x4(0.9642f * lab_f_inv(fx), 1.0f * lab_f_inv(fy), 0.8249f * lab_f_inv(fz), m);
+  return make_float4(rgb.x, rgb.y, rgb.z, p.w);
+}
+
 __device__ __forceinline__ float clamp01(const float v)
 {
   // CLAMP(v, 0.0f, 1.0f) of glib

@@ -15,6 +15,8 @@ struct chain_args
 {
   int has_exposure, has_colorin, has_colorout, to_u16;
   int cm_clip, filmic_export;
+  int pre_lab, post_lab; // the pipe's Lab -> RGB glue in front of the chain / RGB -> Lab behind it
+  float lab_pre[3][4], lab_post[3][4];
   float exp_black, exp_scale;
   conv_args colorin, colorout;
   cm_args cm;
@@ -39,6 +41,7 @@ __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, 
   if(k < npixels)
   {
     float4 v = in[k];
+    if(a.pre_lab) v = px_lab_to_rgb(v, a.lab_pre);
     if(a.has_exposure)
     {
       // exposure.c:521-524 on all four lanes
@@ -51,6 +54,7 @@ __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, 
     if(CM != CM_NONE) v = px_channelmixerrgb<(CM == CM_NONE ? 0 : CM)>(v, a.cm, a.cm_clip != 0);
     if(FM != FM_NONE) v = px_filmicrgb<(FM == FM_NONE ? 0 : FM)>(v, a.filmic, a.filmic_export != 0);
     if(a.has_colorout) v = px_conversion_rt(v, a.colorout);
+    if(a.post_lab) v = px_rgb_to_lab(v, a.lab_post);
     if(a.to_u16)
     {
       // _export_final_buffer_to_uint16(), src/imageio/imageio_core.c:729-737 (glib CLAMP)

@@ -150,7 +150,7 @@ def test_full_config3_pipe_with_nlmeans():
     raw, lut, d_lut, coeffs = _setup(w, h, seed=6)
     nodes = pipe.denoise_pipe_nodes(w, h, d_lut.ptr, float(lut[0]), coeffs, filmic=filmic.default_data(), with_nlmeans=True)
     fused, groups = _run_executor(nodes, raw, w, h, fusion=True)
-    assert groups == 10, groups
+    assert groups == 9, groups  # "lab_to_rgb" is the first stage of the fused run that follows it
     assert np.array_equal(fused, _run_chain_modulewise(nodes, raw, w, h))
     host_nodes = pipe.denoise_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, filmic=filmic.default_data(),
                                          with_nlmeans=True)
@@ -305,3 +305,34 @@ def test_executor_returns_every_intermediate_to_the_pool():
     l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
     assert cur.value == base
     p.close()
+
+
+def test_lab_glue_is_fused_into_the_pointwise_runs():
+    """"lab_to_rgb" in front of a fusable run and "rgb_to_lab" behind one are stages of that run's kernel: one launch, the
+    same bits as the module-by-module chain"""
+    w, h = 320, 200
+    lut = params.srgb_encode_lut()
+    rgb = abi.Piece.make(w, h, channels=4, processed_maximum=synth.WB_COEFFS)
+    img = synth.rgba_image(w, h, seed=9, lo=0.0, hi=1.0)
+    lab_in = np.zeros_like(img)
+    assert ck.call(ck.oracle(), "oracle_rgb_to_lab", rgb, abi.LabData.make(params.WORK_IN), img, lab_in) == 0
+    nodes = [pipe.Node("lab_to_rgb", abi.LabData.make(params.WORK_OUT), rgb),
+             pipe.Node("exposure", abi.ExposureData(-0.000244140625, 1.6245047), rgb),
+             pipe.Node("rgb_to_lab", abi.LabData.make(params.WORK_IN), rgb)]
+    outs = {}
+    for fusion in (True, False):
+        din = lib.DeviceBuffer.from_numpy(0, lab_in)
+        dout = lib.DeviceBuffer(0, w * h * 16)
+        p = pipe.DevicePipe(0, nodes, fusion=fusion)
+        assert p.num_groups == (1 if fusion else 3)
+        p.process(din.ptr, dout.ptr)
+        assert lib.load().dt_hip_finish(0) == 1
+        outs[fusion] = dout.to_numpy((h, w, 4), np.float32)
+        p.close()
+    assert np.array_equal(outs[True].view(np.uint32), outs[False].view(np.uint32))
+    o = ck.oracle()
+    a, b, c = np.zeros_like(img), np.zeros_like(img), np.zeros_like(img)
+    assert ck.call(o, "oracle_lab_to_rgb", rgb, nodes[0].data, lab_in, a) == 0
+    assert ck.call(o, "oracle_exposure", rgb, nodes[1].data, a, b) == 0
+    assert ck.call(o, "oracle_rgb_to_lab", rgb, nodes[2].data, b, c) == 0
+    assert np.array_equal(outs[True].view(np.uint32), c.view(np.uint32))
