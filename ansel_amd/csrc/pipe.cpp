@@ -361,6 +361,37 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
       }
       continue;
     }
+    // denoise (profiled) followed by a pointwise run: the run becomes the tail of the module's last kernel
+    // (denoiseprofile.hip dn_finish_chain) when there is such a kernel for the combination
+    if(pipe->fusion && g.kind == group_t::SINGLE && pipe->nodes[g.first].op == OP_DENOISEPROFILE && gi + 1 < ng
+       && pipe->groups[gi + 1].kind == group_t::RGB && !is_blend(gi + 1))
+    {
+      const group_t &gn = pipe->groups[gi + 1];
+      const node_t &tail = pipe->nodes[gn.first + gn.count - 1];
+      const bool final_pair = gi + 2 == ng || (is_blend(gi + 2) && gi + 3 == ng);
+      dt_hip_mem_t fout = final_pair ? dev_out : dt_hip_alloc_device_buffer(devid, out_bytes(tail));
+      if(fout)
+      {
+        const node_t &dn = pipe->nodes[g.first];
+        const int ferr = denoiseprofile_process_chain(devid, &dn.piece, dn.as<dt_hip_denoiseprofile_data_t>(), cur, fout, &gn.rgb);
+        if(ferr == DT_HIP_SUCCESS)
+        {
+          // a blend behind the run wants the run's input, which no longer exists as a buffer: such runs are not
+          // fused (is_blend(gi + 2) with a non-final pair is excluded below)
+          if(cur_owned) dt_hip_release_mem_object(cur);
+          cur = fout;
+          cur_owned = !final_pair;
+          gi++;
+          continue;
+        }
+        if(!final_pair) dt_hip_release_mem_object(fout);
+        if(ferr != DT_HIP_INVALID_ARG)
+        {
+          if(cur_owned) dt_hip_release_mem_object(cur);
+          return ferr;
+        }
+      }
+    }
     dt_hip_mem_t out = dev_out;
     bool out_owned = false;
     const bool final_out = gi + 1 == ng || (is_blend(gi + 1) && gi + 2 == ng);

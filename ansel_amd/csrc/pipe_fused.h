@@ -39,5 +39,13 @@ struct rgb_group_t
   dt_hip_lab_data_t lab_pre, lab_post;
 };
 int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+// the kernel arguments of a run (rgb_chain_kernel.h): cm_kind = the chromatic adaptation its kernel is instantiated for
+// (CM_NONE without color calibration), fm = the filmic mode (FM_NONE without filmic)
+struct chain_args;
+int rgb_group_fill_args(const rgb_group_t &g, chain_args &a, int &cm_kind, int &fm);
+// denoiseprofile.hip: denoise (profiled), wavelets, with the run `chain` (no filmic, float output) applied in its last
+// kernel; DT_HIP_INVALID_ARG when the combination has no fused kernel (the caller then runs the two one after the other)
+int denoiseprofile_process_chain(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
+                                 dt_hip_mem_t dev_in, dt_hip_mem_t dev_out, const rgb_group_t *chain);
 
 } // namespace ansel

@@ -224,14 +224,11 @@ int raw_group_launch(int devid, const raw_group_t &g, dt_hip_mem_t dev_in, dt_hi
   return check_launch("raw_chain");
 }
 
-int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+int rgb_group_fill_args(const rgb_group_t &g, chain_args &a, int &cm_kind, int &fm)
 {
-  if(!valid_device(devid) || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
-  const size_t np = (size_t)g.width * g.height;
-  if(np == 0) return DT_HIP_SUCCESS;
-  chain_args a;
   memset(&a, 0, sizeof(a));
-  int cm_kind = CM_NONE, fm = FM_NONE;
+  cm_kind = CM_NONE;
+  fm = FM_NONE;
   for(int i = 0; i < g.n_ops && i < 8; i++)
   {
     switch(g.ops[i])
@@ -270,6 +267,18 @@ int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hi
   a.post_lab = g.post_lab;
   memcpy(a.lab_pre, g.lab_pre.matrix, sizeof(a.lab_pre));
   memcpy(a.lab_post, g.lab_post.matrix, sizeof(a.lab_post));
+  return DT_HIP_SUCCESS;
+}
+
+int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  if(!valid_device(devid) || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
+  const size_t np = (size_t)g.width * g.height;
+  if(np == 0) return DT_HIP_SUCCESS;
+  chain_args a;
+  int cm_kind, fm;
+  const int ferr = rgb_group_fill_args(g, a, cm_kind, fm);
+  if(ferr != DT_HIP_SUCCESS) return ferr;
   hipStream_t s = stream_of(devid);
   const unsigned grid = pixel_grid(np); // one pixel per thread, see rgb_chain_kernel.h
   const float4 *in = (const float4 *)dev_in;
