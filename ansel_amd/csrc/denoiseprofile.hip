@@ -67,46 +67,47 @@ struct vst_args
 __device__ __forceinline__ float chan(const float4 &v, const int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 // precondition(), precondition_v2(), precondition_Y0U0V0(): denoiseprofile.c:852-870, :916-933, :1021-1051
+__device__ __forceinline__ float4 dn_precondition_pixel(const float4 px, const vst_args &a)
+{
+  float o[4];
+  if(a.vst == 0)
+  {
+#pragma unroll
+    for(int c = 0; c < 4; c++)
+    {
+      const float d = fmaxf(0.0f, chan(px, c) / a.aa[c] + a.k[c]);
+      o[c] = 2.0f * sqrtf(d);
+    }
+  }
+  else if(a.vst == 1)
+  {
+#pragma unroll
+    for(int c = 0; c < 4; c++)
+      o[c] = 2.0f * ansel_math::powf_exact(max_first(chan(px, c) / a.wb[c] + a.b, 0.0f), a.expon[c]) / a.scale[c];
+  }
+  else
+  {
+    float t[4];
+#pragma unroll
+    for(int c = 0; c < 4; c++) t[c] = ansel_math::powf_exact(max_first(chan(px, c) + a.b, 0.0f), a.expon[c]) * a.scale[c];
+#pragma unroll
+    for(int c = 0; c < 3; c++)
+    {
+      float sum = 0.0f;
+#pragma unroll
+      for(int k = 0; k < 4; k++) sum += a.m[c][k] * t[k];
+      o[c] = sum;
+    }
+    o[3] = 0.0f;
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
 __global__ __launch_bounds__(256) void dn_precondition(const float4 *__restrict__ in, float4 *__restrict__ buf,
                                                        const size_t npix, const vst_args a)
 {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
-  if(j < npix)
-  {
-    const float4 px = in[j];
-    float o[4];
-    if(a.vst == 0)
-    {
-#pragma unroll
-      for(int c = 0; c < 4; c++)
-      {
-        const float d = fmaxf(0.0f, chan(px, c) / a.aa[c] + a.k[c]);
-        o[c] = 2.0f * sqrtf(d);
-      }
-    }
-    else if(a.vst == 1)
-    {
-#pragma unroll
-      for(int c = 0; c < 4; c++)
-        o[c] = 2.0f * ansel_math::powf_exact(max_first(chan(px, c) / a.wb[c] + a.b, 0.0f), a.expon[c]) / a.scale[c];
-    }
-    else
-    {
-      float t[4];
-#pragma unroll
-      for(int c = 0; c < 4; c++) t[c] = ansel_math::powf_exact(max_first(chan(px, c) + a.b, 0.0f), a.expon[c]) * a.scale[c];
-#pragma unroll
-      for(int c = 0; c < 3; c++)
-      {
-        float sum = 0.0f;
-#pragma unroll
-        for(int k = 0; k < 4; k++) sum += a.m[c][k] * t[k];
-        o[c] = sum;
-      }
-      o[3] = 0.0f;
-    }
-    buf[j] = make_float4(o[0], o[1], o[2], o[3]);
-  }
+  if(j < npix) buf[j] = dn_precondition_pixel(in[j], a);
 }
 
 // out[k] += residue[k] (denoiseprofile.c:1423-1425) followed by backtransform(), backtransform_v2(),
@@ -345,13 +346,19 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
 // taps are LDS reads, against 25 fetches per pixel through the vector L1 (64 B/clk per CU: ~400 cycles of the ~1 080 a
 // wave of the per-row kernel took).  Same taps in the same order, so the same binary32 values; the partial sums of
 // detail^2 leave in the same per-(row, segment) slots.
+// PRE: `in` is the module's input and the variance-stabilising transform is applied to every sample as it enters the
+// ring (the finest scale of a whole frame: a row is fetched 1.14 times per strip, which costs less than the pass that
+// wrote and re-read the transformed plane: 0.89 + 1.9 -> 2.4 ms at 100 MP)
 #define DN_RING 6
+template <bool PRE>
 __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                           float4 *__restrict__ detail, double *__restrict__ partial,
                                                           const int width, const int height, const int mult,
                                                           const float inv_sigma2, const int nseg, const int in_row0,
-                                                          const int in_rows, const int strip, const int strips_per_class)
+                                                          const int in_rows, const int strip, const int strips_per_class,
+                                                          const vst_args fa)
 {
+#define DN_FETCH(p) (PRE ? dn_precondition_pixel((p), fa) : (p))
   extern __shared__ float4 ring[]; // [DN_RING][256 + 4 * mult]
   __shared__ double runs[2][4][4];
   const int bx = blockIdx.x;
@@ -372,8 +379,8 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
   for(int q = 0; q < 4; q++)
   {
     const size_t y = DN_IN_ROW(q);
-    ring[q * tw + tid] = in[y + ecol0];
-    if(second) ring[q * tw + tid + 256] = in[y + ecol1];
+    ring[q * tw + tid] = DN_FETCH(in[y + ecol0]);
+    if(second) ring[q * tw + tid + 256] = DN_FETCH(in[y + ecol1]);
   }
   float4 n0, n1 = make_float4(0.f, 0.f, 0.f, 0.f);
   {
@@ -386,8 +393,8 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
   {
     {
       const int sl = s0 + 4 >= DN_RING ? s0 + 4 - DN_RING : s0 + 4;
-      ring[sl * tw + tid] = n0;
-      if(second) ring[sl * tw + tid + 256] = n1;
+      ring[sl * tw + tid] = DN_FETCH(n0);
+      if(second) ring[sl * tw + tid + 256] = DN_FETCH(n1);
     }
     __syncthreads();
     if(k > 0 && tid < 4)
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
     s0 = s0 + 1 == DN_RING ? 0 : s0 + 1;
   }
 #undef DN_IN_ROW
+#undef DN_FETCH
   __syncthreads();
   if(tid < 4)
   {
@@ -473,10 +481,10 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
 // one a-trous step of `height` rows (see dn_decompose for in_row0 / in_rows)
 static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, float4 *detail, double *partial, const int width,
                              const int height, const int mult, const float inv_sigma2, const int nseg, const int in_row0,
-                             const int in_rows)
+                             const int in_rows, const vst_args *pre = nullptr)
 {
   static const bool per_row = getenv("ANSEL_HIP_DN_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
-  if(per_row)
+  if(per_row && !pre)
   {
     const int rows = (height <= mult) ? height : ((height + mult - 1) / mult) * mult;
     dn_decompose<<<dim3(xcd_pad(nseg), rows), 256, 0, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg,
@@ -487,8 +495,16 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
   int strip = 32;
   while(strip > 4 && (size_t)nseg * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
   const int strips_per_class = (per_class + strip - 1) / strip;
-  dn_decompose_strip<<<dim3(nseg, classes * strips_per_class), 256, (size_t)DN_RING * (256 + 4 * mult) * sizeof(float4), st>>>(
-      in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0, in_rows, strip, strips_per_class);
+  const dim3 grid(nseg, classes * strips_per_class);
+  const size_t lds = (size_t)DN_RING * (256 + 4 * mult) * sizeof(float4);
+  vst_args none;
+  memset(&none, 0, sizeof(none));
+  if(pre)
+    dn_decompose_strip<true><<<grid, 256, lds, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0,
+                                                     in_rows, strip, strips_per_class, *pre);
+  else
+    dn_decompose_strip<false><<<grid, 256, lds, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0,
+                                                      in_rows, strip, strips_per_class, none);
 }
 
 struct thr_args
@@ -1149,14 +1165,12 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
     if(!det[k]) err = DT_HIP_SYSMEM_ALLOCATION;
   }
   float4 *out = (float4 *)dev_out;
-  if(err == DT_HIP_SUCCESS)
-  {
-    vst_args fa;
-    forward_args(s, fa);
-    launch_scope ls(devid, "dn_precondition");
-    dn_precondition<<<pixel_grid(npix), 256, 0, st>>>((const float4 *)dev_in, precond, npix, fa);
-  }
-  float4 *b1 = precond, *b2 = tmp;
+  // the variance-stabilising transform is applied by the first decomposition as it fetches the module's input
+  // (dn_decompose_strip<true>): `precond` is only the second of the two coarse planes the scales alternate between
+  vst_args fa;
+  forward_args(s, fa);
+  const float4 *b1 = (const float4 *)dev_in;
+  float4 *b2 = tmp, *b3 = precond;
   for(int scale = 0; scale < s.max_scale && err == DT_HIP_SUCCESS; scale++)
   {
     const int mult = 1 << scale;
@@ -1165,12 +1179,12 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
     {
       launch_scope ls(devid, "dn_decompose");
       launch_decompose(st, b1, b2, det[scale], partial + (size_t)scale * n_partial * 4, w, h, mult,
-                       1.0f / (sigma_band * sigma_band), nseg, 0, h);
+                       1.0f / (sigma_band * sigma_band), nseg, 0, h, scale == 0 ? &fa : nullptr);
     }
     err = check_launch("denoiseprofile band");
-    float4 *t = b2;
-    b2 = b1;
-    b1 = t;
+    b1 = b2; // the coarse plane just written is the next scale's input; the other plane takes the next coarse
+    b2 = b3;
+    b3 = (float4 *)b1;
   }
   if(err == DT_HIP_SUCCESS)
   {
