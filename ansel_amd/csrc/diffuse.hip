@@ -19,6 +19,7 @@
 // are blurred by every workgroup as well.
 #include "hip_common.h"
 #include "devmath.h"
+#include "px_colorspaces.h"
 
 #include <math.h>
 #include <cstdlib>
@@ -61,6 +62,8 @@ struct pde_args
   int kind[4]; // 0 isotrope, 1 isophote, 2 gradient (check_isotropy_mode(), diffuse.c:151-161)
   float variance_threshold, regularization;
   float abcd[4], strength;
+  int post_lab;        // the pipe's RGB -> Lab glue behind the module, applied where the last pass stores (strip kernel)
+  float post_m[3][4];
 };
 
 // dt_fast_expf(), src/math/math.h:254-267.  The float -> int conversion of an out-of-range or NaN
@@ -392,6 +395,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       for(int k = 0; k < 9; k++) { H[k] = H4[k].w; L[k] = L4[k].w; }
       o.w = pde_channel(H, L, energy.w, a);
     }
+    if(a.post_lab) o = px_rgb_to_lab(o, a.post_m);
     if(final_pass) nt_store(out + idx, o);
     else out[idx] = o;
   }
@@ -526,8 +530,22 @@ namespace ansel
 
 // first_row: the frame row of the buffer's first row (a row band, pipe.cpp) -- it only enters the seeds of the
 // inpainting noise, which the reference derives from the pixel's index in the frame
+static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, int first_row, dt_hip_mem_t dev_in,
+                       dt_hip_mem_t dev_out, const dt_hip_lab_data_t *post_lab);
 int diffuse_process_rows(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, int first_row,
                          dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+{
+  return diffuse_run(devid, piece, d, first_row, dev_in, dev_out, nullptr);
+}
+// the module followed by the pipe's RGB -> Lab glue: the conversion is the tail of the module's last kernel
+int diffuse_process_post_lab(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, dt_hip_mem_t dev_in,
+                             dt_hip_mem_t dev_out, const dt_hip_lab_data_t *lab)
+{
+  if(!lab || getenv("ANSEL_HIP_PDE_PER_ROW")) return DT_HIP_INVALID_ARG; // only the strip kernel has the tail
+  return diffuse_run(devid, piece, d, 0, dev_in, dev_out, lab);
+}
+static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, int first_row, dt_hip_mem_t dev_in,
+                       dt_hip_mem_t dev_out, const dt_hip_lab_data_t *post_lab)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
   if(piece->channels != 4)
@@ -614,6 +632,12 @@ int diffuse_process_rows(int devid, const dt_hip_piece_t *piece, const dt_hip_di
       for(int k = 0; k < 4; k++) a.abcd[k] = speed[k] * PDE_KAPPA * norm;
       a.strength = d->sharpness * norm + 1.0f;
       a.mult = 1 << s;
+      a.post_lab = 0;
+      if(post_lab && s == 0 && it == iterations - 1)
+      {
+        a.post_lab = 1;
+        memcpy(a.post_m, post_lab->matrix, sizeof(a.post_m));
+      }
       float4 *to = (s == 0) ? dst : pp[count % 2];
       const int rows = (h <= a.mult) ? h : ((h + a.mult - 1) / a.mult) * a.mult;
       {

@@ -122,6 +122,9 @@ int nlmeans_process_band(int devid, const dt_hip_piece_t *piece, const dt_hip_nl
 int diffuse_halo_rows(const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d);
 int diffuse_process_rows(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, int first_row,
                          dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+// ... followed by "rgb_to_lab" as the tail of its last kernel; DT_HIP_INVALID_ARG when that kernel has no tail
+int diffuse_process_post_lab(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, dt_hip_mem_t dev_in,
+                             dt_hip_mem_t dev_out, const dt_hip_lab_data_t *lab);
 // denoiseprofile: -1 when the frame is too small for the module to do anything but copy
 int denoiseprofile_halo_rows(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d);
 struct dn_band_job_t;

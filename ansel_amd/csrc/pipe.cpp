@@ -392,6 +392,33 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
         }
       }
     }
+    // diffuse or sharpen followed by the RGB -> Lab glue: the conversion is the tail of the module's last kernel
+    if(pipe->fusion && g.kind == group_t::SINGLE && pipe->nodes[g.first].op == OP_DIFFUSE && gi + 1 < ng
+       && pipe->groups[gi + 1].kind == group_t::SINGLE && pipe->nodes[pipe->groups[gi + 1].first].op == OP_RGB_TO_LAB
+       && !is_blend(gi + 2))
+    {
+      const node_t &df = pipe->nodes[g.first], &lab = pipe->nodes[pipe->groups[gi + 1].first];
+      const bool final_pair = gi + 2 == ng;
+      dt_hip_mem_t fout = final_pair ? dev_out : dt_hip_alloc_device_buffer(devid, out_bytes(lab));
+      if(fout)
+      {
+        const int ferr = diffuse_process_post_lab(devid, &df.piece, df.as<dt_hip_diffuse_data_t>(), cur, fout, lab.as<dt_hip_lab_data_t>());
+        if(ferr == DT_HIP_SUCCESS)
+        {
+          if(cur_owned) dt_hip_release_mem_object(cur);
+          cur = fout;
+          cur_owned = !final_pair;
+          gi++;
+          continue;
+        }
+        if(!final_pair) dt_hip_release_mem_object(fout);
+        if(ferr != DT_HIP_INVALID_ARG)
+        {
+          if(cur_owned) dt_hip_release_mem_object(cur);
+          return ferr;
+        }
+      }
+    }
     dt_hip_mem_t out = dev_out;
     bool out_owned = false;
     const bool final_out = gi + 1 == ng || (is_blend(gi + 1) && gi + 2 == ng);
