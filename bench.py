@@ -281,7 +281,8 @@ def measured_traffic(tag, args):
 # tools/valu_model.py) over 1024 SIMDs at 2.4 GHz is its floor.
 KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu", "rcd_tiles": "valu+lds",
                 "nlm_chunks": "valu+lds", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
-                "dn_synthesize": "hbm", "dn_precondition": "hbm", "dn_finish": "hbm", "rgb_to_lab": "hbm", "lab_to_rgb": "hbm"}
+                "dn_synthesize": "hbm", "dn_precondition": "hbm", "dn_finish": "hbm", "dn_finish_chain": "hbm", "rgb_to_lab": "hbm",
+                "lab_to_rgb": "hbm"}
 
 
 def valu_floor_ms(tag, mpix):
@@ -293,7 +294,7 @@ def valu_floor_ms(tag, mpix):
     except (OSError, ValueError):
         return None
     alias = {"dn_decompose": "dn_decompose_strip", "nlm_chunks": "nlm_chunks_v2", "diffuse_decompose": "bspline_decompose_strip",
-             "diffuse_pde": "diffuse_pde_strip"}
+             "diffuse_pde": "diffuse_pde_strip", "dn_finish_chain": "dn_finish_chain"}
     kernels = mix.get("kernels", {})
     k = kernels.get(tag) or kernels.get(tag.replace("_u16", "")) or kernels.get(alias.get(tag, ""))
     if not k or "issue_floor_ms_per_mpix" not in k:
