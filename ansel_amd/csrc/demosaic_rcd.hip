@@ -504,15 +504,20 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
   }
   __syncthreads();
 
-  // ---- step 4.2 (rcd.c:466-496): red at blue sites / blue at red sites, kept in registers until every thread has read
-  //      its PQ_Dir neighbourhood, then stored over PQ_Dir
-  float co[HALF_ITERS];
+  // ---- step 4.2 (rcd.c:466-496): red at blue sites / blue at red sites.  The result goes into the site's own word of
+  //      VH_Dir: steps 3.1 (behind two barriers) was the last to read VH_Dir at red/blue sites -- the output stage reads
+  //      it at green sites and their diagonals, green too -- so nobody waits before storing (the first version kept the
+  //      results in registers behind one more barrier and stored them over PQ_Dir)
+  float *const codst = vh + p * PL + hsite;
 #pragma unroll
   for(int it = 0; it < HALF_ITERS; it++)
   {
     const int row = hrow0 + 16 * it;
-    co[it] = 0.0f;
-    if(!hcol4 || row < 4 || row >= tileRows - 4) continue;
+    if(!hcol4 || row < 4 || row >= tileRows - 4)
+    {
+      codst[it * 16 * HS] = 0.0f;
+      continue;
+    }
     const float *const S = sS + it * 16 * HS, *const O = sO + it * 16 * HS;
     const float *const xq = x + hsite - q + it * 16 * HS, *const gq = g + hsite - q + it * 16 * HS;
     const float *const gh = g + hsite + it * 16 * HS;
@@ -531,11 +536,8 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
     const float SE_Est = se - gq[HS + 1];
     const float P_Est = (NW_Grad * SE_Est + SE_Grad * NW_Est) / (NW_Grad + SE_Grad);
     const float Q_Est = (NE_Grad * SW_Est + SW_Grad * NE_Est) / (NE_Grad + SW_Grad);
-    co[it] = g0 + intp(PQ_Disc, Q_Est, P_Est);
+    codst[it * 16 * HS] = g0 + intp(PQ_Disc, Q_Est, P_Est);
   }
-  __syncthreads();
-#pragma unroll
-  for(int it = 0; it < HALF_ITERS; it++) x[tid + it * NT] = co[it];
   __syncthreads();
 
   // ---- output (rcd.c:539-555) with step 4.3 (rcd.c:499-536) evaluated at the green sites that are written out
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
       const int f = fc(row, col_rb, filters); // 0 or 2
       const float native = scaler * fmaxf(0.0f, cfa[pr * PL + hh]);
       const float green = scaler * fmaxf(0.0f, g[hh]);
-      const float other = scaler * fmaxf(0.0f, x[hh]);
+      const float other = scaler * fmaxf(0.0f, vh[pr * PL + hh]);
       o_rb.x = (f == 0) ? native : other;
       o_rb.y = green;
       o_rb.z = (f == 0) ? other : native;
@@ -580,8 +582,10 @@ __global__ __launch_bounds__(NT) void rcd_tiles(const float *__restrict__ in, fl
       const int e = 1 - pr;
       const float *const S = cfa + e * PL + hh - BIAS, *const O = cfa + pr * PL + hh + e - BIAS;
       const float *const VS = vh + e * PL + hh - BIAS, *const VO = vh + pr * PL + hh + e - BIAS;
-      const float *const ge = g + hh + e, *const xe = x + hh + e; // the red/blue sites left and right: [-1], [0]; +-3: [-2], [1]
-      const float *const gv = g + hh, *const xv = x + hh;         // the red/blue sites above and below: [-+ HS], [-+ 3 HS]
+      // the red/blue sites left and right: [-1], [0]; +-3: [-2], [1]; above and below: [-+ HS], [-+ 3 HS].  Their step-4.2
+      // colour sits in VH_Dir's words of those sites: plane pr in this row, plane e in the rows above and below
+      const float *const ge = g + hh + e, *const xe = vh + pr * PL + hh + e;
+      const float *const gv = g + hh, *const xv = vh + e * PL + hh;
       const float VH_Central_Value = AT(VS, VO, 0, 0);
       const float VH_Neighbourhood_Value = 0.25f * (AT(VS, VO, -1, -1) + AT(VS, VO, -1, 1) + AT(VS, VO, 1, -1) + AT(VS, VO, 1, 1));
       const float VH_Disc = (fabsf(0.5f - VH_Central_Value) < fabsf(0.5f - VH_Neighbourhood_Value)) ? VH_Neighbourhood_Value : VH_Central_Value;
