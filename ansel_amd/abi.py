@@ -211,6 +211,7 @@ class TilePlanRoi(C.Structure):
 
 
 DT_HIP_TILE_EMPTY = 2
+RAW_PACK_MSB, RAW_PACK_LSB = 0, 1  # dt_hip_raw_unpack(): bit order of the packed stream
 
 
 class ExportRowsData(C.Structure):

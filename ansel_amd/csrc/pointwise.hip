@@ -620,3 +620,57 @@ int dt_hip_export_convert_u8(int devid, int width, int height, dt_hip_mem_t dev_
 }
 
 } // extern "C"
+
+// ---- raw unpack: the wire end in front of rawprepare (include/ansel_hip.h) --------------------------------------
+namespace
+{
+template <int ORDER>
+__global__ __launch_bounds__(256) void raw_unpack(const unsigned char *__restrict__ packed, unsigned short *__restrict__ out,
+                                                  const int width, const int height, const size_t row_bytes, const int bits)
+{
+  const size_t n = (size_t)width * height;
+  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+  {
+    const int y = (int)(k / width), x = (int)(k - (size_t)y * width);
+    const unsigned char *const row = packed + (size_t)y * row_bytes;
+    const unsigned bit0 = (unsigned)x * (unsigned)bits;
+    const unsigned byte0 = bit0 >> 3, sh = bit0 & 7u;
+    // the photosite lies in at most three bytes (16 bits at a shift of up to 7); bytes past the row's last are not read
+    const unsigned last = (unsigned)((size_t)width * bits + 7) / 8 - 1;
+    const unsigned b0 = row[byte0], b1 = byte0 + 1 <= last ? row[byte0 + 1] : 0u, b2 = byte0 + 2 <= last ? row[byte0 + 2] : 0u;
+    unsigned v;
+    if(ORDER == DT_HIP_RAW_PACK_MSB)
+      v = ((b0 << 16 | b1 << 8 | b2) >> (24 - sh - bits)) & ((1u << bits) - 1u);
+    else
+      v = ((b0 | b1 << 8 | b2 << 16) >> sh) & ((1u << bits) - 1u);
+    out[k] = (unsigned short)v;
+  }
+}
+} // namespace
+
+extern "C" int dt_hip_raw_unpack(int devid, dt_hip_mem_t dev_packed, int width, int height, size_t row_bytes, int bits, int order,
+                                 dt_hip_mem_t dev_out_u16)
+{
+  if(!valid_device(devid) || !dev_packed || !dev_out_u16 || width < 0 || height < 0) return DT_HIP_INVALID_ARG;
+  if((bits != 8 && bits != 10 && bits != 12 && bits != 14 && bits != 16) || (order != DT_HIP_RAW_PACK_MSB && order != DT_HIP_RAW_PACK_LSB))
+  {
+    set_last_error("raw_unpack: %d bits in order %d is not a layout this unpacks (8, 10, 12, 14, 16 bits; MSB or LSB first)", bits, order);
+    return DT_HIP_INVALID_ARG;
+  }
+  if(row_bytes < ((size_t)width * bits + 7) / 8)
+  {
+    set_last_error("raw_unpack: rows of %zu bytes cannot hold %d photosites of %d bits", row_bytes, width, bits);
+    return DT_HIP_INVALID_ARG;
+  }
+  const size_t n = (size_t)width * height;
+  if(n == 0) return DT_HIP_SUCCESS;
+  hipStream_t s = stream_of(devid);
+  launch_scope ls(devid, "raw_unpack");
+  if(order == DT_HIP_RAW_PACK_MSB)
+    raw_unpack<DT_HIP_RAW_PACK_MSB><<<stream_grid(n, 256), 256, 0, s>>>((const unsigned char *)dev_packed, (unsigned short *)dev_out_u16, width,
+                                                                         height, row_bytes, bits);
+  else
+    raw_unpack<DT_HIP_RAW_PACK_LSB><<<stream_grid(n, 256), 256, 0, s>>>((const unsigned char *)dev_packed, (unsigned short *)dev_out_u16, width,
+                                                                         height, row_bytes, bits);
+  return check_launch("raw_unpack");
+}

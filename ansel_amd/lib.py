@@ -118,6 +118,7 @@ def load():
         "dt_hip_iop_bilat_process": (i, [i, P(abi.Piece), P(abi.BilatData), vp, vp]),
         "dt_hip_iop_finalscale_process": (i, [i, P(abi.Piece), P(abi.FinalscaleData), vp, vp]),
         "dt_hip_iop_initialscale_process": (i, [i, P(abi.Piece), P(abi.FinalscaleData), vp, vp]),
+        "dt_hip_raw_unpack": (i, [i, vp, i, i, C.c_size_t, i, i, vp]),
         "dt_hip_develop_blend_process": (i, [i, P(abi.Piece), P(abi.BlendData), vp, vp]),
         "dt_hip_iop_basebuffer_process": (i, [i, P(abi.Piece), i, i, i, vp, vp]),
         "dt_hip_alloc_host_pinned": (vp, [sz]),

@@ -570,6 +570,23 @@ int dt_hip_iop_initialscale_process(int devid, const dt_hip_piece_t *piece, cons
 int dt_hip_iop_basebuffer_process(int devid, const dt_hip_piece_t *piece, int iwidth, int iheight, int bpp,
                                   const void *host_full, dt_hip_mem_t dev_out);
 
+/* The wire end in front of the pipe: sensor data as the file holds it -- a bit stream of `bits`-bit
+ * photosites, every row starting on a byte -- unpacked into the u16 mosaic rawprepare takes, so that a batch export
+ * uploads 1.25 / 1.5 / 1.75 bytes per photosite instead of 2.  In Ansel this is rawspeed's job (its decompressors for
+ * uncompressed packed data; the submodule src/external/rawspeed is not part of the reference tree, so PARITY IS UNPINNED
+ * by the reference: the two layouts below are restated from the formats themselves -- TIFF / DNG BitsPerSample < 16 with
+ * FillOrder 1, and the little-endian packing of the 10 / 12 / 14-bit vendor containers -- and pinned against numpy's
+ * unpackbits in tests/test_raw_unpack.py).
+ *   DT_HIP_RAW_PACK_MSB: photosite x of a row occupies bits [x * bits, (x + 1) * bits) of the row's bytes read most
+ *                        significant bit first (12 bits: b0 = p0[11:4], b1 = p0[3:0] p1[11:8], b2 = p1[7:0])
+ *   DT_HIP_RAW_PACK_LSB: the row's bytes form a little-endian integer, photosite x its bits [x * bits, (x + 1) * bits)
+ *                        (12 bits: p0 = b0 | (b1 & 15) << 8, p1 = b1 >> 4 | b2 << 4)
+ * bits: 8, 10, 12, 14 or 16 (16: MSB = big-endian words, LSB = a copy).  row_bytes >= ceil(width * bits / 8). */
+#define DT_HIP_RAW_PACK_MSB 0
+#define DT_HIP_RAW_PACK_LSB 1
+int dt_hip_raw_unpack(int devid, dt_hip_mem_t dev_packed, int width, int height, size_t row_bytes, int bits, int order,
+                      dt_hip_mem_t dev_out_u16);
+
 /* ---- 2b. the blend stage ---------------------------------------------------------------- */
 /* dt_develop_blend_process(), src/develop/blend.c:657-965: what the pixelpipe runs after the
  * process() of every blending-capable module (src/develop/pixelpipe_cpu.c:137-228) -- build the

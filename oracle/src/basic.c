@@ -146,3 +146,26 @@ int oracle_export_convert_u8(int width, int height, const float *in, uint8_t *ou
   }
   return 0;
 }
+
+/* dt_hip_raw_unpack() (include/ansel_hip.h): a packed bit stream of photosites -> u16.  NOT a restatement of reference
+ * code -- the unpacking is rawspeed's, which is not part of the reference tree: PARITY UNPINNED by the reference.  Written
+ * here in the plainest form (one bit at a time) as the checker of the device kernel; tests/test_raw_unpack.py pins it
+ * against numpy's unpackbits. */
+int oracle_raw_unpack(const uint8_t *packed, int width, int height, size_t row_bytes, int bits, int order, uint16_t *out)
+{
+  if(bits < 1 || bits > 16 || (order != 0 && order != 1) || row_bytes < ((size_t)width * bits + 7) / 8) return 1;
+  for(int y = 0; y < height; y++)
+    for(int x = 0; x < width; x++)
+    {
+      unsigned v = 0;
+      for(int b = 0; b < bits; b++)
+      {
+        const size_t bit = (size_t)x * bits + b; /* b-th bit of the photosite in stream order */
+        const unsigned byte = packed[(size_t)y * row_bytes + bit / 8];
+        if(order == 0) v = v << 1 | ((byte >> (7 - bit % 8)) & 1u);     /* most significant bit first */
+        else v |= ((byte >> (bit % 8)) & 1u) << b;                       /* least significant bit first */
+      }
+      out[(size_t)y * width + x] = (uint16_t)v;
+    }
+  return 0;
+}
