@@ -269,6 +269,9 @@ void filmic_prepare(const dt_hip_filmicrgb_data_t *d, fargs &a)
   a.type0 = d->spline.type[0];
   a.type1 = d->spline.type[1];
   a.preserve_color = d->preserve_color;
+  a.sigma_toe = powf(d->spline.latitude_min / 3.0f, 2.0f);
+  a.sigma_shoulder = powf((1.0f - d->spline.latitude_max) / 3.0f, 2.0f);
+  a.legacy_version = d->version;
 }
 
 template <int MODE>
@@ -286,9 +289,9 @@ namespace ansel
 {
 int filmicrgb_fill_args(const dt_hip_filmicrgb_data_t *d, fargs &a)
 {
-  if(d->version < 3 || d->version > 9)
+  if(d->version < 0 || d->version > 9)
   {
-    set_last_error("filmicrgb: colour science %d (v3/v4/v5, 2019-2021) is not implemented on device", d->version);
+    set_last_error("filmicrgb: no colour science %d (dt_iop_filmicrgb_colorscience_type_t is 0..9)", d->version);
     return DT_HIP_INVALID_ARG;
   }
   filmic_prepare(d, a);
@@ -297,6 +300,8 @@ int filmicrgb_fill_args(const dt_hip_filmicrgb_data_t *d, fargs &a)
     a.mode = MODE_AGX;
   else if(d->version == 4)
     a.mode = MODE_V5;
+  else if(d->version < 3) // process(), filmicrgb.c:2862-2887
+    a.mode = d->preserve_color == 0 ? MODE_SPLIT_LEGACY : (d->version == 0 ? MODE_CHROMA_V1 : MODE_CHROMA_V2_V3);
   else
     a.mode = d->preserve_color == 0 ? MODE_SPLIT_V4 : MODE_CHROMA_V4;
   return DT_HIP_SUCCESS;
@@ -324,6 +329,9 @@ extern "C" int dt_hip_iop_filmicrgb_process(int devid, const dt_hip_piece_t *pie
     case MODE_AGX: launch_m<MODE_AGX>(exp, grid, s, in, out, np, a); break;
     case MODE_V5: launch_m<MODE_V5>(exp, grid, s, in, out, np, a); break;
     case MODE_SPLIT_V4: launch_m<MODE_SPLIT_V4>(exp, grid, s, in, out, np, a); break;
+    case MODE_SPLIT_LEGACY: launch_m<MODE_SPLIT_LEGACY>(false, grid, s, in, out, np, a); break;
+    case MODE_CHROMA_V1: launch_m<MODE_CHROMA_V1>(false, grid, s, in, out, np, a); break;
+    case MODE_CHROMA_V2_V3: launch_m<MODE_CHROMA_V2_V3>(false, grid, s, in, out, np, a); break;
     default: launch_m<MODE_CHROMA_V4>(exp, grid, s, in, out, np, a); break;
   }
   return check_launch("filmicrgb");

@@ -290,7 +290,10 @@ int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hi
     case MODE_AGX: err = rgb_chain_launch_agx(cm_kind, grid, s, in, dev_out, np, a); break;
     case MODE_V5: err = rgb_chain_launch_v5(cm_kind, grid, s, in, dev_out, np, a); break;
     case MODE_SPLIT_V4: err = rgb_chain_launch_split_v4(cm_kind, grid, s, in, dev_out, np, a); break;
-    default: err = rgb_chain_launch_chroma_v4(cm_kind, grid, s, in, dev_out, np, a); break;
+    case MODE_CHROMA_V4: err = rgb_chain_launch_chroma_v4(cm_kind, grid, s, in, dev_out, np, a); break;
+    default: // the 2019-2020 colour sciences run in their own launch (the planner keeps them out of a run)
+      set_last_error("rgb_chain: filmic mode %d has no fused kernel", fm);
+      return DT_HIP_INVALID_ARG;
   }
   if(err != DT_HIP_SUCCESS) return err;
   return check_launch("rgb_chain");

@@ -30,6 +30,9 @@ struct fargs
   int type0, type1;
   int preserve_color;
   int mode, use_export; // MODE_* of the colour science, export-profile gamut mapping
+  // colour sciences v1..v3: commit_params(), filmicrgb.c:4101-4102, and the version (0..2)
+  float sigma_toe, sigma_shoulder;
+  int legacy_version;
 };
 
 struct v4
@@ -374,7 +377,98 @@ __device__ __forceinline__ v4 agx_compress_negatives(const v4 p, const float lum
   return { s.x * ratio, s.y * ratio, s.z * ratio, s.w * ratio };
 }
 
-enum { MODE_AGX = 0, MODE_V5 = 1, MODE_SPLIT_V4 = 2, MODE_CHROMA_V4 = 3 };
+enum { MODE_AGX = 0, MODE_V5 = 1, MODE_SPLIT_V4 = 2, MODE_CHROMA_V4 = 3, MODE_SPLIT_LEGACY = 4, MODE_CHROMA_V1 = 5, MODE_CHROMA_V2_V3 = 6 };
+
+// ---- colour sciences v1..v3 (2019-2020), kept for old edits ------------------------------------
+#define FILMIC_NORM_MIN 1.52587890625e-05f // src/math/math.h:37
+
+// filmic_desaturate_v1(), filmicrgb.c:1163-1174
+__device__ __forceinline__ float filmic_desaturate_v1(const float x, const fargs &a)
+{
+  const float radius_toe = x;
+  const float radius_shoulder = 1.0f - x;
+  const float key_toe = ansel_math::expf_exact(-0.5f * radius_toe * radius_toe / a.sigma_toe);
+  const float key_shoulder = ansel_math::expf_exact(-0.5f * radius_shoulder * radius_shoulder / a.sigma_shoulder);
+  return 1.0f - clamp_simd((key_toe + key_shoulder) / a.saturation);
+}
+
+// filmic_desaturate_v2(), filmicrgb.c:1178-1189
+__device__ __forceinline__ float filmic_desaturate_v2(const float x, const fargs &a)
+{
+  const float radius_toe = x;
+  const float radius_shoulder = 1.0f - x;
+  const float sat2 = 0.5f / sqrtf(a.saturation);
+  const float key_toe = ansel_math::expf_exact(-radius_toe * radius_toe / a.sigma_toe * sat2);
+  const float key_shoulder = ansel_math::expf_exact(-radius_shoulder * radius_shoulder / a.sigma_shoulder * sat2);
+  return (a.saturation - (key_toe + key_shoulder) * (a.saturation));
+}
+
+// linear_saturation(), filmicrgb.c:1193-1196
+__device__ __forceinline__ float linear_saturation(const float x, const float luminance, const float saturation)
+{
+  return luminance + saturation * (x - luminance);
+}
+
+__device__ __forceinline__ float curve_to_display(const float x, const fargs &a)
+{
+  return ansel_math::powf_exact(clampf(filmic_spline(x, a), a.y0, a.y4), a.output_power);
+}
+
+// filmic_split_v1() :1534-1571 and filmic_split_v2_v3() :1574-1611 (they differ by the desaturation); the reference
+// leaves the output's alpha unwritten, the input's is passed through
+__device__ __forceinline__ v4 filmic_split_legacy(const v4 p, const fargs &a)
+{
+  const float tx = log_tonemapping(fmaxf(p.x, FILMIC_NORM_MIN), a);
+  const float ty = log_tonemapping(fmaxf(p.y, FILMIC_NORM_MIN), a);
+  const float tz = log_tonemapping(fmaxf(p.z, FILMIC_NORM_MIN), a);
+  const float lum = a.luma[0] * tx + a.luma[1] * ty + a.luma[2] * tz;
+  const float desaturation = a.legacy_version ? filmic_desaturate_v2(lum, a) : filmic_desaturate_v1(lum, a);
+  return { curve_to_display(linear_saturation(tx, lum, desaturation), a), curve_to_display(linear_saturation(ty, lum, desaturation), a),
+           curve_to_display(linear_saturation(tz, lum, desaturation), a), p.w };
+}
+
+// filmic_chroma_v1(), filmicrgb.c:1614-1667
+__device__ __forceinline__ v4 filmic_chroma_v1(const v4 p, const fargs &a)
+{
+  float norm = fmaxf(pixel_norm(p, a.preserve_color, a), FILMIC_NORM_MIN);
+  v4 ratios = { p.x / norm, p.y / norm, p.z / norm, p.w / norm };
+  const float min_ratios = fminf(fminf(ratios.x, ratios.y), ratios.z);
+  if(min_ratios < 0.0f) ratios = { ratios.x - min_ratios, ratios.y - min_ratios, ratios.z - min_ratios, ratios.w - min_ratios };
+  norm = log_tonemapping(norm, a);
+  const float desaturation = filmic_desaturate_v1(norm, a);
+  ratios = { ratios.x * norm, ratios.y * norm, ratios.z * norm, ratios.w * norm };
+  const float lum = a.luma[0] * ratios.x + a.luma[1] * ratios.y + a.luma[2] * ratios.z;
+  ratios.x = linear_saturation(ratios.x, lum, desaturation) / norm;
+  ratios.y = linear_saturation(ratios.y, lum, desaturation) / norm;
+  ratios.z = linear_saturation(ratios.z, lum, desaturation) / norm;
+  norm = curve_to_display(norm, a);
+  return { ratios.x * norm, ratios.y * norm, ratios.z * norm, ratios.w * norm };
+}
+
+// filmic_chroma_v2_v3(), filmicrgb.c:1670-1737
+__device__ __forceinline__ v4 filmic_chroma_v2_v3(const v4 p, const fargs &a)
+{
+  float norm = fmaxf(pixel_norm(p, a.preserve_color, a), FILMIC_NORM_MIN);
+  v4 ratios = { p.x / norm, p.y / norm, p.z / norm, p.w / norm };
+  const float min_ratios = fminf(fminf(ratios.x, ratios.y), ratios.z);
+  if(min_ratios < 0.0f) ratios = { ratios.x - min_ratios, ratios.y - min_ratios, ratios.z - min_ratios, ratios.w - min_ratios };
+  norm = log_tonemapping(norm, a);
+  const float desaturation = filmic_desaturate_v2(norm, a);
+  norm = curve_to_display(norm, a);
+  ratios.x = fmaxf(ratios.x + (1.0f - ratios.x) * (1.0f - desaturation), 0.0f);
+  ratios.y = fmaxf(ratios.y + (1.0f - ratios.y) * (1.0f - desaturation), 0.0f);
+  ratios.z = fmaxf(ratios.z + (1.0f - ratios.z) * (1.0f - desaturation), 0.0f);
+  if(a.legacy_version == 2) norm /= fmaxf(pixel_norm(ratios, a.preserve_color, a), FILMIC_NORM_MIN);
+  v4 o = { ratios.x * norm, ratios.y * norm, ratios.z * norm, ratios.w * norm };
+  const float max_pix = fmaxf(fmaxf(o.x, o.y), o.z);
+  if(max_pix > 1.0f)
+  {
+    ratios = { fmaxf(ratios.x + (1.0f - max_pix), 0.0f), fmaxf(ratios.y + (1.0f - max_pix), 0.0f),
+               fmaxf(ratios.z + (1.0f - max_pix), 0.0f), fmaxf(ratios.w + (1.0f - max_pix), 0.0f) };
+    o = { ratios.x * norm, ratios.y * norm, ratios.z * norm, ratios.w * norm };
+  }
+  return o;
+}
 
 
 template <int MODE> __device__ __forceinline__ float4 px_filmicrgb(const float4 pi, const fargs &a, const bool EXPORT)
@@ -422,6 +516,12 @@ template <int MODE> __device__ __forceinline__ float4 px_filmicrgb(const float4 
     Yf.y = fminf(Yo.y, Yf.y);
     res = gamut_mapping(Yf, Yo, a, a.saturation, EXPORT);
   }
+  else if(MODE == MODE_SPLIT_LEGACY)
+    res = filmic_split_legacy(pix_in, a);
+  else if(MODE == MODE_CHROMA_V1)
+    res = filmic_chroma_v1(pix_in, a);
+  else if(MODE == MODE_CHROMA_V2_V3)
+    res = filmic_chroma_v2_v3(pix_in, a);
   else
   {
     const v4 po = norm_tone_mapping_v4(pix_in, a.preserve_color, a);
@@ -433,7 +533,7 @@ template <int MODE> __device__ __forceinline__ float4 px_filmicrgb(const float4 
 }
 
 // host: dt_hip_filmicrgb_data_t -> kernel arguments (per-call matrix preparation included);
-// returns DT_HIP_INVALID_ARG for the legacy colour sciences
+// returns DT_HIP_INVALID_ARG for a colour science outside 0..9
 int filmicrgb_fill_args(const dt_hip_filmicrgb_data_t *d, fargs &a);
 
 } // namespace ansel

@@ -378,7 +378,10 @@ int dt_hip_iop_channelmixerrgb_process(int devid, const dt_hip_piece_t *piece,
                                        dt_hip_mem_t dev_out);
 
 /* filmic RGB tone mapping: filmic_agx / filmic_v5 / filmic_chroma_v4 / filmic_split_v4,
- * src/iop/filmicrgb.c:2153-2587; highlight reconstruction bypassed (hl_deprecated, :2733).
+ * src/iop/filmicrgb.c:2153-2587, and the 2019-2020 colour sciences filmic_split_v1 / _v2_v3, filmic_chroma_v1 /
+ * _v2_v3 (:1534-1737; sigma_toe / sigma_shoulder of commit_params :4101 are derived from the spline's latitude; the
+ * per-channel variants pass the input's alpha through where the reference leaves it unwritten); highlight
+ * reconstruction bypassed (hl_deprecated, :2733).
  * spline == dt_iop_filmic_rgb_spline_t (:216-223).  work_*, export_* are the 3x3 parts of
  * the work / export dt_iop_order_iccprofile_info_t matrix_in, matrix_out. */
 typedef struct dt_hip_filmic_spline_t
@@ -397,7 +400,7 @@ typedef struct dt_hip_filmicrgb_data_t
   float output_power;
   float agx_beta_hue;
   int preserve_color; /* dt_iop_filmicrgb_methods_type_t */
-  int version;        /* dt_iop_filmicrgb_colorscience_type_t, 3..9 supported (v6, v7, AgX) */
+  int version;        /* dt_iop_filmicrgb_colorscience_type_t, 0..9 */
   int use_output_profile;
   dt_hip_filmic_spline_t spline;
   float work_matrix_in[3][4], work_matrix_out[3][4];

@@ -15,7 +15,8 @@ $X $R/iop/filmicrgb.c $G/filmicrgb.inc INVERSE_SQRT_3 SAFETY_MARGIN CIE_Y_1931_t
   dt_iop_filmicrgb_spline_version_type_t dt_iop_filmic_noise_distribution_t _filmic_is_agx \
   dt_iop_filmic_rgb_spline_t dt_iop_filmicrgb_params_t dt_iop_filmicrgb_data_t \
   dt_iop_filmicrgb_v3_geometry_t dt_iop_filmicrgb_v3_nodes_t filmic_v3_compute_geometry filmic_v3_compute_nodes_from_legacy \
-  pixel_rgb_norm_power_simd get_pixel_norm_simd log_tonemapping exp_tonemapping_v2 filmic_spline \
+  pixel_rgb_norm_power_simd get_pixel_norm_simd get_pixel_norm filmic_desaturate_v1 filmic_desaturate_v2 linear_saturation \
+  filmic_split_v1 filmic_split_v2_v3 filmic_chroma_v1 filmic_chroma_v2_v3 log_tonemapping exp_tonemapping_v2 filmic_spline \
   pipe_RGB_to_Ych_simd Ych_to_pipe_RGB_simd filmic_desaturate_v4 clip_chroma_white_raw clip_chroma_white \
   clip_chroma_black clip_chroma gamut_check_Yrg_filmic_simd gamut_check_RGB_simd gamut_mapping_simd \
   filmic_v4_prepare_matrices dt_iop_filmicrgb_simd_matrices_t filmic_prepare_simd_matrices \

@@ -1,6 +1,7 @@
 /* oracle/ref_wrap/ref_filmic.c -- TEST INFRASTRUCTURE ONLY.
  * The reference's filmic RGB tone mapping (src/iop/filmicrgb.c: filmic_agx, filmic_v5,
- * filmic_chroma_v4, filmic_split_v4 and everything they call, plus the spline solver
+ * filmic_chroma_v4, filmic_split_v4, the 2019-2020 variants filmic_split_v1 / _v2_v3 and filmic_chroma_v1 / _v2_v3,
+ * and everything they call, plus the spline solver
  * dt_iop_filmic_rgb_compute_spline), lifted verbatim at build time, behind C entry points that
  * take the C-ABI structs of include/ansel_hip.h. */
 #include "ref_piece.h"
@@ -133,6 +134,9 @@ int ref_filmicrgb(const dt_hip_piece_t *v, const dt_hip_filmicrgb_data_t *d, con
   data.preserve_color = d->preserve_color;
   data.version = d->version;
   data.hl_deprecated = TRUE;
+  /* commit_params(), filmicrgb.c:4101-4102 */
+  data.sigma_toe = powf(d->spline.latitude_min / 3.0f, 2.0f);
+  data.sigma_shoulder = powf((1.0f - d->spline.latitude_max) / 3.0f, 2.0f);
   for(int k = 0; k < 4; k++)
   {
     data.spline.M1[k] = d->spline.M1[k];
@@ -176,6 +180,20 @@ int ref_filmicrgb(const dt_hip_piece_t *v, const dt_hip_filmicrgb_data_t *d, con
                        data.version, black_display, white_display);
   }
   else
-    return 1;
+  {
+    /* the per-channel variants leave the output's alpha unwritten (the pipeline ignores it): the input's here */
+    memcpy(fout, fin, sizeof(float) * 4 * width * height);
+    if(data.preserve_color == DT_FILMIC_METHOD_NONE)
+    {
+      if(data.version == DT_FILMIC_COLORSCIENCE_V1)
+        filmic_split_v1(fin, fout, &work, &data, data.spline, width, height);
+      else
+        filmic_split_v2_v3(fin, fout, &work, &data, data.spline, width, height);
+    }
+    else if(data.version == DT_FILMIC_COLORSCIENCE_V1)
+      filmic_chroma_v1(fin, fout, &work, &data, data.spline, data.preserve_color, width, height);
+    else
+      filmic_chroma_v2_v3(fin, fout, &work, &data, data.spline, data.preserve_color, width, height, 4, data.version);
+  }
   return 0;
 }

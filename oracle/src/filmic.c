@@ -6,6 +6,8 @@
  *   filmic_v5()         filmicrgb.c:2247-2300   colour science v7
  *   filmic_chroma_v4()  filmicrgb.c:2153-2198   colour science v6, chroma preservation on
  *   filmic_split_v4()   filmicrgb.c:2201-2244   colour science v6, per-channel
+ *   filmic_split_v1() :1534, filmic_split_v2_v3() :1574, filmic_chroma_v1() :1614, filmic_chroma_v2_v3() :1670
+ *                       the colour sciences of 2019-2020 (versions 0..2), still run for old edits
  * and what they call: log_tonemapping :1047, filmic_spline :1063-1160, get_pixel_norm_simd
  * :976-1035, pipe_RGB_to_Ych_simd :1740, Ych_to_pipe_RGB_simd :1765, filmic_desaturate_v4 :1781,
  * clip_chroma* :1826-1925, gamut_check_* :1928-1984, gamut_mapping_simd :1986-2030,
@@ -223,6 +225,7 @@ typedef struct
   float norm_min, norm_max;
   float display_black, display_white;
   int use_output_profile;
+  float sigma_toe, sigma_shoulder; /* commit_params(), filmicrgb.c:4101-4102 */
 } prep_t;
 
 static void to_mat(mat_t m, const float a[3][4])
@@ -357,6 +360,8 @@ static void prepare(const dt_hip_filmicrgb_data_t *d, prep_t *p)
   p->norm_max = d->grey_source * exp2f(d->dynamic_range * 1.f + d->black_source);
   p->display_white = powf(d->spline.y[4], d->output_power);
   p->display_black = powf(d->spline.y[0], d->output_power);
+  p->sigma_toe = powf(d->spline.latitude_min / 3.0f, 2.0f);
+  p->sigma_shoulder = powf((1.0f - d->spline.latitude_max) / 3.0f, 2.0f);
 }
 
 /* ---- gamut mapping -------------------------------------------------------------------- */
@@ -517,6 +522,99 @@ static inline v4 RGB_tone_mapping_v4(const v4 pix_in, const dt_hip_filmicrgb_dat
   return o;
 }
 
+/* ---- colour sciences v1..v3 (2019-2020) -------------------------------------------------- */
+#define NORM_MIN_ 1.52587890625e-05f /* src/math/math.h:37 */
+
+/* filmic_desaturate_v1(), filmicrgb.c:1163-1174 */
+static inline float desaturate_v1(const float x, const prep_t *p, const float saturation)
+{
+  const float radius_toe = x;
+  const float radius_shoulder = 1.0f - x;
+  const float key_toe = expf(-0.5f * radius_toe * radius_toe / p->sigma_toe);
+  const float key_shoulder = expf(-0.5f * radius_shoulder * radius_shoulder / p->sigma_shoulder);
+  return 1.0f - clamp_simd((key_toe + key_shoulder) / saturation);
+}
+
+/* filmic_desaturate_v2(), filmicrgb.c:1178-1189 */
+static inline float desaturate_v2(const float x, const prep_t *p, const float saturation)
+{
+  const float radius_toe = x;
+  const float radius_shoulder = 1.0f - x;
+  const float sat2 = 0.5f / sqrtf(saturation);
+  const float key_toe = expf(-radius_toe * radius_toe / p->sigma_toe * sat2);
+  const float key_shoulder = expf(-radius_shoulder * radius_shoulder / p->sigma_shoulder * sat2);
+  return (saturation - (key_toe + key_shoulder) * (saturation));
+}
+
+/* linear_saturation(), filmicrgb.c:1193-1196 */
+static inline float linear_saturation(const float x, const float luminance, const float saturation)
+{
+  return luminance + saturation * (x - luminance);
+}
+
+static inline float curve_to_display(const float x, const dt_hip_filmicrgb_data_t *d)
+{
+  const float sp = filmic_spline(x, &d->spline);
+  return powf(CLAMPF_(sp, d->spline.y[0], d->spline.y[4]), d->output_power);
+}
+
+/* filmic_split_v1() :1534-1571 (v23 == 0) and filmic_split_v2_v3() :1574-1611: the alpha of the output is not
+ * written by the reference; it is passed through here */
+static inline v4 legacy_split(const v4 pix_in, const int v23, const dt_hip_filmicrgb_data_t *d, const prep_t *p)
+{
+  v4 temp = pix_in, o = pix_in;
+  for(int c = 0; c < 3; c++)
+    temp.v[c] = log_tonemapping(fmaxf(pix_in.v[c], NORM_MIN_), d->grey_source, d->black_source, d->dynamic_range);
+  const float lum = p->luma[0] * temp.v[0] + p->luma[1] * temp.v[1] + p->luma[2] * temp.v[2];
+  const float desaturation = v23 ? desaturate_v2(lum, p, d->saturation) : desaturate_v1(lum, p, d->saturation);
+  for(int c = 0; c < 3; c++) o.v[c] = curve_to_display(linear_saturation(temp.v[c], lum, desaturation), d);
+  return o;
+}
+
+/* filmic_chroma_v1(), filmicrgb.c:1614-1667 */
+static inline v4 legacy_chroma_v1(const v4 pix_in, const dt_hip_filmicrgb_data_t *d, const prep_t *p)
+{
+  v4 ratios, o;
+  float norm = fmaxf(pixel_norm(pix_in, d->preserve_color, p), NORM_MIN_);
+  for(int c = 0; c < 4; c++) ratios.v[c] = pix_in.v[c] / norm;
+  const float min_ratios = fminf(fminf(ratios.v[0], ratios.v[1]), ratios.v[2]);
+  if(min_ratios < 0.0f)
+    for(int c = 0; c < 4; c++) ratios.v[c] -= min_ratios;
+  norm = log_tonemapping(norm, d->grey_source, d->black_source, d->dynamic_range);
+  const float desaturation = desaturate_v1(norm, p, d->saturation);
+  for(int c = 0; c < 4; c++) ratios.v[c] *= norm;
+  const float lum = p->luma[0] * ratios.v[0] + p->luma[1] * ratios.v[1] + p->luma[2] * ratios.v[2];
+  for(int c = 0; c < 3; c++) ratios.v[c] = linear_saturation(ratios.v[c], lum, desaturation) / norm;
+  norm = curve_to_display(norm, d);
+  for(int c = 0; c < 4; c++) o.v[c] = ratios.v[c] * norm;
+  return o;
+}
+
+/* filmic_chroma_v2_v3(), filmicrgb.c:1670-1737 (v3: d->version == 2) */
+static inline v4 legacy_chroma_v2_v3(const v4 pix_in, const dt_hip_filmicrgb_data_t *d, const prep_t *p)
+{
+  v4 ratios, o;
+  float norm = fmaxf(pixel_norm(pix_in, d->preserve_color, p), NORM_MIN_);
+  for(int c = 0; c < 4; c++) ratios.v[c] = pix_in.v[c] / norm;
+  const float min_ratios = fminf(fminf(ratios.v[0], ratios.v[1]), ratios.v[2]);
+  if(min_ratios < 0.0f)
+    for(int c = 0; c < 4; c++) ratios.v[c] -= min_ratios;
+  norm = log_tonemapping(norm, d->grey_source, d->black_source, d->dynamic_range);
+  const float desaturation = desaturate_v2(norm, p, d->saturation);
+  norm = curve_to_display(norm, d);
+  for(int c = 0; c < 3; c++) ratios.v[c] = fmaxf(ratios.v[c] + (1.0f - ratios.v[c]) * (1.0f - desaturation), 0.0f);
+  if(d->version == 2) norm /= fmaxf(pixel_norm(ratios, d->preserve_color, p), NORM_MIN_);
+  for(int c = 0; c < 4; c++) o.v[c] = ratios.v[c] * norm;
+  const float max_pix = fmaxf(fmaxf(o.v[0], o.v[1]), o.v[2]);
+  if(max_pix > 1.0f)
+    for(int c = 0; c < 4; c++)
+    {
+      ratios.v[c] = fmaxf(ratios.v[c] + (1.0f - max_pix), 0.0f);
+      o.v[c] = ratios.v[c] * norm;
+    }
+  return o;
+}
+
 static inline v4 agx_compress_negatives(const v4 pix, const float luma[3])
 {
   const float input_y = pix.v[0] * luma[0] + pix.v[1] * luma[1] + pix.v[2] * luma[2];
@@ -544,7 +642,7 @@ static inline v4 agx_compress_negatives(const v4 pix, const float luma[3])
 
 int oracle_filmicrgb(const dt_hip_piece_t *piece, const dt_hip_filmicrgb_data_t *d, const void *ivoid, void *ovoid)
 {
-  if(d->version < 3 || d->version > 9) return 1;
+  if(d->version < 0 || d->version > 9) return 1;
   const float *const in = (const float *)ivoid;
   float *const out = (float *)ovoid;
   const size_t npixels = (size_t)piece->roi_out.width * piece->roi_out.height;
@@ -589,6 +687,14 @@ int oracle_filmicrgb(const dt_hip_piece_t *piece, const dt_hip_filmicrgb_data_t 
       Ych_final.v[1] = fminf(Ych_original.v[1], Ych_final.v[1]);
       res = gamut_mapping(Ych_final, Ych_original, &p, 0.f);
     }
+    else if(d->version < 3)
+    {
+      /* process(), filmicrgb.c:2862-2887 */
+      if(d->preserve_color == 0)
+        res = legacy_split(pix_in, d->version != 0, d, &p);
+      else
+        res = d->version == 0 ? legacy_chroma_v1(pix_in, d, &p) : legacy_chroma_v2_v3(pix_in, d, &p);
+    }
     else if(d->preserve_color == 0)
     {
       /* filmic_split_v4(), filmicrgb.c:2222-2242 */
@@ -630,4 +736,19 @@ float oracle_kat_pixel_norm(const float px[4], const int variant)
 float oracle_kat_log_tonemapping(const float x, const float grey, const float black, const float dynamic_range)
 {
   return log_tonemapping(x, grey, black, dynamic_range);
+}
+
+/* test_filmicrgb.c:350-455 and :459-520 */
+float oracle_kat_desaturate_v1(const float x, const float sigma_toe, const float sigma_shoulder, const float saturation)
+{
+  prep_t p;
+  memset(&p, 0, sizeof(p));
+  p.sigma_toe = sigma_toe;
+  p.sigma_shoulder = sigma_shoulder;
+  return desaturate_v1(x, &p, saturation);
+}
+
+float oracle_kat_linear_saturation(const float x, const float luminance, const float saturation)
+{
+  return linear_saturation(x, luminance, saturation);
 }

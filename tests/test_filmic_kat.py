@@ -2,8 +2,8 @@
 tests/unittests/iop/test_filmicrgb.c (clamp_simd :89-106, pixel_rgb_norm_power :108-178,
 get_pixel_norm :180-250, log_tonemapping :252-320), run against the oracle restatement with the
 reference's own synthetic generators (tests/unittests/util/testimg.c:109-268) and its tolerance
-E = 1e-6 (test_filmicrgb.c:59).  The helpers the test covers that only the legacy colour sciences
-use (filmic_desaturate_v1, linear_saturation) are outside this path."""
+E = 1e-6 (test_filmicrgb.c:59); filmic_desaturate_v1 :350-455 and linear_saturation :459-520 of the 2019-2020
+colour sciences included."""
 import ctypes as C
 
 import numpy as np
@@ -51,6 +51,10 @@ def o(oracle_lib):
     oracle_lib.oracle_kat_pixel_norm.argtypes = [C.POINTER(C.c_float), C.c_int]
     oracle_lib.oracle_kat_log_tonemapping.restype = C.c_float
     oracle_lib.oracle_kat_log_tonemapping.argtypes = [C.c_float] * 4
+    oracle_lib.oracle_kat_desaturate_v1.restype = C.c_float
+    oracle_lib.oracle_kat_desaturate_v1.argtypes = [C.c_float] * 4
+    oracle_lib.oracle_kat_linear_saturation.restype = C.c_float
+    oracle_lib.oracle_kat_linear_saturation.argtypes = [C.c_float] * 3
     return oracle_lib
 
 
@@ -116,3 +120,40 @@ def test_log_tonemapping(o):
     for v in grey_max_dr() + grey_max_dr_neg():
         ret = o.oracle_kat_log_tonemapping(float(v), float(grey), float(black), float(dyn))
         assert 0.0 <= ret <= 1.0
+
+
+def _saturation_gui_to_internal(percent):  # test_filmicrgb.c:337-347, "copied from filmicrgb.c"
+    return f32(2.0) * f32(percent) / f32(100.0) + f32(1.0)
+
+
+def test_filmic_desaturate_v1(o):
+    """test_filmicrgb.c:350-455; as there, the sigmas come from a latitude of 0.2 on both sides"""
+    sigma = f32(np.power(f32(0.2) / f32(3.0), f32(2.0)))
+    saturation = _saturation_gui_to_internal(5.0)
+    log_space = [val_to_log(v) for v in grey_space(21)]
+    width = len(log_space)
+    for x, v in enumerate(log_space):
+        ret = o.oracle_kat_desaturate_v1(float(v), float(sigma), float(sigma), float(saturation))
+        mirrored = o.oracle_kat_desaturate_v1(float(log_space[width - x - 1]), float(sigma), float(sigma), float(saturation))
+        assert abs(ret - mirrored) <= E
+        if x == 0 or x == width - 1:
+            assert abs(ret - float(f32(1.0) - f32(1.0) / saturation)) <= E
+        if 0.2 * width < x < (1.0 - 0.2) * width - 1:
+            assert abs(ret - 1.0) <= 1e-2
+    for v in log_space:
+        assert abs(o.oracle_kat_desaturate_v1(float(v), float(sigma), float(sigma), float(_saturation_gui_to_internal(1e6))) - 1.0) <= 1e-2
+    for v in grey_max_dr() + grey_max_dr_neg():
+        ret = o.oracle_kat_desaturate_v1(float(v), float(sigma), float(sigma), float(saturation))
+        assert 0.0 < ret <= 1.0
+
+
+def test_linear_saturation(o):
+    """test_filmicrgb.c:459-520"""
+    ratios = (f32(0.2126), f32(0.7152), f32(0.0722))
+    for v in grey_space():
+        assert abs(o.oracle_kat_linear_saturation(float(v), float(v), 0.05) - float(v)) <= E
+    for p in rgb_space():
+        lum = p[0] * ratios[0] + p[1] * ratios[1] + p[2] * ratios[2]
+        for c in range(3):
+            assert abs(o.oracle_kat_linear_saturation(float(p[c]), float(lum), 1.0) - float(p[c])) <= E
+            assert abs(o.oracle_kat_linear_saturation(float(p[c]), float(lum), 0.0) - float(lum)) <= E

@@ -51,11 +51,22 @@ def test_filmic_nondefault_geometry():
     _check(filmic.commit(p), _images()["scene"])
 
 
-def test_filmic_rejects_legacy_colour_science():
+@pytest.mark.parametrize("imgname", ["scene", "adversarial"])
+@pytest.mark.parametrize("version", [0, 1, 2])
+@pytest.mark.parametrize("preserve_color", [0, 1, 2, 3, 4, 5])
+def test_filmic_colour_sciences_of_2019_2020(imgname, version, preserve_color):
+    """filmic_split_v1 / _v2_v3, filmic_chroma_v1 / _v2_v3 (filmicrgb.c:1534-1737)"""
+    for saturation, curves in ((10.0, (3, 3)), (-30.0, (0, 1)), (60.0, (2, 2))):
+        p = filmic.UserParams.defaults(version=version, preserve_color=preserve_color, saturation=saturation,
+                                       shadows=curves[0], highlights=curves[1])
+        _check(filmic.commit(p), _images()[imgname])
+
+
+def test_filmic_rejects_an_unknown_colour_science():
     from ansel_amd import lib
     h = hc.hip()
     d = filmic.commit(filmic.UserParams.defaults())
-    d.version = 1
+    d.version = 10
     piece = abi.Piece.make(8, 8)
     buf = lib.DeviceBuffer(0, 8 * 8 * 16)
     assert h.dt_hip_iop_filmicrgb_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG

@@ -94,6 +94,22 @@ def test_fused_pipe_equals_modulewise_and_cpu(w, h):
         assert not diff.any(), "%s: %d pixels differ" % (which, int(diff.sum()))
 
 
+@pytest.mark.parametrize("version,preserve_color", [(0, 0), (1, 1), (2, 3)])
+def test_pipe_with_a_2019_colour_science_runs_filmic_in_its_own_launch(version, preserve_color):
+    """old edits (filmic colour sciences v1..v3): the planner keeps the module out of the fused run"""
+    w, h = 400, 300
+    raw, lut, d_lut, coeffs = _setup(w, h, seed=9)
+    fd = filmic.commit(filmic.UserParams.defaults(version=version, preserve_color=preserve_color, saturation=10.0))
+    dev_nodes = pipe.light_pipe_nodes(w, h, d_lut.ptr, float(lut[0]), coeffs, with_filmic=True, filmic=fd)
+    modulewise = _run_chain_modulewise(dev_nodes, raw, w, h)
+    fused, groups = _run_executor(dev_nodes, raw, w, h, fusion=True)
+    assert groups == 5, groups  # raw chain | demosaic | exposure..calibration | filmic | colorout, u16
+    assert np.array_equal(modulewise, fused)
+    host_nodes = pipe.light_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, with_filmic=True, filmic=fd)
+    cpu = _run_cpu("oracle", host_nodes, raw, w, h)
+    assert np.array_equal(cpu, fused)
+
+
 def test_executor_falls_back_to_single_launches_for_unfusable_geometry():
     """width not a multiple of 4: the CFA group is not fusable; results must still be exact"""
     w, h = 402, 301

@@ -113,12 +113,12 @@ def test_colour_modules(imgname):
     _exact(a, b, "channelmixerrgb grey")
 
 
-@pytest.mark.parametrize("version", [3, 4, 5, 7, 9])
+@pytest.mark.parametrize("version", [0, 1, 2, 3, 4, 5, 7, 9])
 @pytest.mark.parametrize("curves", [(3, 3), (0, 1), (2, 2)])
 def test_filmic(version, curves):
     img = synth.rgba_image(W, H, seed=2, lo=-0.02, hi=6.0)
     piece = abi.Piece.make(W, H)
-    for pc in ((0, 1, 2, 3, 4, 5) if version == 3 else (1,)):
+    for pc in ((0, 1, 2, 3, 4, 5) if version <= 3 else (1,)):
         p = filmic.UserParams.defaults(version=version, shadows=curves[0], highlights=curves[1], preserve_color=pc,
                                        saturation=10.0 if version < 5 else 25.0)
         d = filmic.commit(p)
