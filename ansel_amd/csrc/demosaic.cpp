@@ -10,6 +10,7 @@ int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters
 int ppg_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, const float *in_pass1,
                         float4 *out);
 int green_eq_lavg_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, int x, int y, float thr);
+int green_eq_favg_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, int x, int y);
 int pre_median_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, float threshold);
 int color_smoothing_launch(int devid, float4 *img, int width, int height, int passes);
 int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
@@ -29,10 +30,9 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
     set_last_error("demosaic: only Bayer mosaics are implemented on device");
     return DT_HIP_INVALID_ARG;
   }
-  if(d->green_eq > 1)
+  if(d->green_eq > 3)
   {
-    // green_equilibration_favg(), basic.c:296-329: the ratio of two binary64 OpenMP sums over the frame
-    set_last_error("demosaic: the full-average green equilibration depends on the host's thread count: not reproduced");
+    set_last_error("demosaic: green_eq %u is not a dt_iop_demosaic_greeneq_t", d->green_eq);
     return DT_HIP_INVALID_ARG;
   }
   if(d->color_smoothing > 5 || (d->median_thrs != 0.0f && d->demosaicing_method != DT_HIP_DEMOSAIC_PPG))
@@ -59,11 +59,18 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
   const float *in = (const float *)dev_in;
   float *geq = nullptr, *med = nullptr;
   int err = DT_HIP_SUCCESS;
-  if(d->green_eq == 1)
+  float *aux = nullptr;
+  if(d->green_eq)
   {
+    // demosaic.c:1137-1163: _FULL = favg, _LOCAL = lavg, _BOTH = favg then lavg
     geq = (float *)dt_hip_alloc_device_buffer(devid, (size_t)w * h * sizeof(float));
-    err = geq ? green_eq_lavg_launch(devid, in, geq, w, h, piece->filters, piece->roi_in.x, piece->roi_in.y, d->green_eq_threshold)
-              : DT_HIP_SYSMEM_ALLOCATION;
+    if(d->green_eq == 3) aux = (float *)dt_hip_alloc_device_buffer(devid, (size_t)w * h * sizeof(float));
+    if(!geq || (d->green_eq == 3 && !aux)) err = DT_HIP_SYSMEM_ALLOCATION;
+    if(err == DT_HIP_SUCCESS && d->green_eq >= 2)
+      err = green_eq_favg_launch(devid, in, aux ? aux : geq, w, h, piece->filters, piece->roi_in.x, piece->roi_in.y);
+    if(err == DT_HIP_SUCCESS && (d->green_eq & 1))
+      err = green_eq_lavg_launch(devid, aux ? aux : in, geq, w, h, piece->filters, piece->roi_in.x, piece->roi_in.y,
+                                 d->green_eq_threshold);
     in = geq;
   }
   if(err == DT_HIP_SUCCESS)
@@ -102,6 +109,7 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
   if(err == DT_HIP_SUCCESS && d->color_smoothing)
     err = color_smoothing_launch(devid, (float4 *)dev_out, piece->roi_out.width, piece->roi_out.height, (int)d->color_smoothing);
   if(geq) dt_hip_release_mem_object(geq);
+  if(aux) dt_hip_release_mem_object(aux);
   if(med) dt_hip_release_mem_object(med);
   return err;
 }

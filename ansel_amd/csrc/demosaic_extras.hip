@@ -1,5 +1,6 @@
 // demosaic_extras.hip -- the optional steps process() runs around the interpolation (src/iop/demosaic.c:1137-1250):
 //   green_equilibration_lavg()  src/iop/demosaic/basic.c:248-293   on the mosaic, before
+//   green_equilibration_favg()  src/iop/demosaic/basic.c:296-329   on the mosaic, before (alone or ahead of _lavg)
 //   pre_median()                src/iop/demosaic/basic.c:136-186   on the green sites, inside demosaic_ppg() (ppg.c:58-67)
 //   color_smoothing()           src/iop/demosaic/basic.c:191-243   on the output, after
 // All three are local: one thread per pixel, reads through L1/L2.  Algorithmic bytes: 8 / 8 / 2 x (16 + 16 + 16) per pass.
@@ -47,6 +48,99 @@ __global__ __launch_bounds__(256) void green_eq_lavg(const float *__restrict__ i
       if((v < 0.95f) && (flat_d < thr) && (flat_a < thr)) v = v * m_diag / m_axial;
     }
   }
+  out[p] = v;
+}
+
+// green_equilibration_favg(): the greens of the lattice's rows are scaled by sum(greens of the other rows) / sum(own).
+// The reference forms the two sums in binary64 in an OpenMP reduction, so its low bits follow the host's thread count;
+// here each sum is carried as an unevaluated pair (TwoSum) in a fixed order -- ~2^-100 relative, i.e. the correctly
+// rounded binary64 sum for all practical purposes, which every order of the reference's additions approximates to a few
+// ulp of binary64.  After the product is rounded to binary32 a pixel can differ from a given run of the reference only
+// when in * ratio falls within ~1e-15 of a rounding boundary (expected: about one pixel in 1e8).
+struct dd_t
+{
+  double hi, lo;
+};
+__device__ __forceinline__ dd_t dd_add(const dd_t a, const double b)
+{
+  const double s = a.hi + b;
+  const double bb = s - a.hi;
+  const double e = (a.hi - (s - bb)) + (b - bb);
+  return { s, isfinite(s) ? a.lo + e : 0.0 }; // an infinite or NaN sum stays what binary64 addition makes of it
+}
+__device__ __forceinline__ dd_t dd_merge(const dd_t a, const dd_t b)
+{
+  dd_t r = dd_add(a, b.hi);
+  r.lo += b.lo;
+  const double s = r.hi + r.lo; // renormalise
+  return { s, isfinite(s) ? r.lo - (s - r.hi) : 0.0 };
+}
+
+#define FAVG_BLOCKS 1024
+// partial sums: workgroup b takes the lattice rows b, b + FAVG_BLOCKS, ...; a lane the sites lane, lane + 256, ... of a row
+__global__ __launch_bounds__(256) void green_eq_favg_sums(const float *__restrict__ in, const int width, const int height, const int oi,
+                                                          const int g2_offset, dd_t *__restrict__ partial)
+{
+  __shared__ dd_t red[2][256];
+  const int sites = (width - 1 - g2_offset - oi + 1) / 2; // i = oi, oi + 2, ... < width - 1 - g2_offset
+  const int rows = height / 2;                            // j = 0, 2, ... < height - 1
+  dd_t s1 = { 0.0, 0.0 }, s2 = { 0.0, 0.0 };
+  for(int r = blockIdx.x; r < rows; r += FAVG_BLOCKS)
+  {
+    const float *row = in + (size_t)(2 * r) * width;
+    for(int k = threadIdx.x; k < sites; k += 256)
+    {
+      const int i = oi + 2 * k;
+      s1 = dd_add(s1, (double)row[i]);
+      s2 = dd_add(s2, (double)row[width + i + g2_offset]);
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for(int half = 128; half > 0; half >>= 1)
+  {
+    if((int)threadIdx.x < half)
+    {
+      red[0][threadIdx.x] = dd_merge(red[0][threadIdx.x], red[0][threadIdx.x + half]);
+      red[1][threadIdx.x] = dd_merge(red[1][threadIdx.x], red[1][threadIdx.x + half]);
+    }
+    __syncthreads();
+  }
+  if(threadIdx.x == 0)
+  {
+    partial[blockIdx.x] = red[0][0];
+    partial[FAVG_BLOCKS + blockIdx.x] = red[1][0];
+  }
+}
+
+// the partials in order, then { gr_ratio, 1 } or { 0, 0 } where "sum1 > 0.0 && sum2 > 0.0" fails (the copy is the result)
+__global__ __launch_bounds__(64) void green_eq_favg_ratio(const dd_t *__restrict__ partial, double *__restrict__ ratio)
+{
+  if(threadIdx.x != 0) return;
+  dd_t s1 = { 0.0, 0.0 }, s2 = { 0.0, 0.0 };
+  for(int b = 0; b < FAVG_BLOCKS; b++)
+  {
+    s1 = dd_merge(s1, partial[b]);
+    s2 = dd_merge(s2, partial[FAVG_BLOCKS + b]);
+  }
+  const double sum1 = s1.hi, sum2 = s2.hi;
+  const bool valid = sum1 > 0.0 && sum2 > 0.0;
+  ratio[0] = valid ? sum2 / sum1 : 0.0;
+  ratio[1] = valid ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(256) void green_eq_favg_apply(const float *__restrict__ in, float *__restrict__ out, const int width,
+                                                           const int height, const int oi, const int g2_offset,
+                                                           const double *__restrict__ ratio)
+{
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(i >= width || j >= height) return;
+  const size_t p = (size_t)j * width + i;
+  float v = in[p];
+  const double gr_ratio = ratio[0];
+  if(ratio[1] != 0.0 && (j & 1) == 0 && j < height - 1 && i >= oi && ((i - oi) & 1) == 0 && i < width - 1 - g2_offset)
+    v = (float)((double)v * gr_ratio);
   out[p] = v;
 }
 
@@ -149,6 +243,28 @@ int green_eq_lavg_launch(int devid, const float *in, float *out, int width, int 
   launch_scope ls(devid, "green_eq_lavg");
   green_eq_lavg<<<dim3((width + 63) / 64, (height + 3) / 4), 256, 0, stream_of(devid)>>>(in, out, width, height, oj, oi, thr);
   return check_launch("green_eq_lavg");
+}
+
+int green_eq_favg_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, int x, int y)
+{
+  auto FCh = [&](int row, int col) { return (int)(filters >> (((row << 1 & 14) + (col & 1)) << 1) & 3); };
+  const int oi = (FCh(y, x) & 1) != 1 ? 1 : 0;
+  const int g2_offset = oi ? -1 : 1;
+  hipStream_t s = stream_of(devid);
+  dd_t *partial = (dd_t *)dt_hip_alloc_device_buffer(devid, sizeof(dd_t) * 2 * FAVG_BLOCKS + 2 * sizeof(double));
+  if(!partial) return DT_HIP_SYSMEM_ALLOCATION;
+  double *ratio = (double *)(partial + 2 * FAVG_BLOCKS);
+  {
+    launch_scope ls(devid, "green_eq_favg_sums");
+    green_eq_favg_sums<<<FAVG_BLOCKS, 256, 0, s>>>(in, width, height, oi, g2_offset, partial);
+    green_eq_favg_ratio<<<1, 64, 0, s>>>(partial, ratio);
+  }
+  {
+    launch_scope ls(devid, "green_eq_favg_apply");
+    green_eq_favg_apply<<<dim3((width + 63) / 64, (height + 3) / 4), 256, 0, s>>>(in, out, width, height, oi, g2_offset, ratio);
+  }
+  dt_hip_release_mem_object(partial);
+  return check_launch("green_eq_favg");
 }
 
 int pre_median_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, float threshold)

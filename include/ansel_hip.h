@@ -296,9 +296,11 @@ int dt_hip_iop_highlights_resolve(int devid, dt_hip_mem_t dev_out, dt_hip_mem_t 
 #define DT_HIP_DEMOSAIC_RCD 5   /* DT_IOP_DEMOSAIC_RCD   */
 /* Around the interpolation, process() (demosaic.c:1137-1250) runs the module's optional steps:
  *   green_eq         0 DT_IOP_GREEN_EQ_NO, 1 _LOCAL: green_equilibration_lavg() (demosaic/basic.c:248-293) on the mosaic,
- *                    with green_eq_threshold = 0.0001f * img->exif_iso (demosaic.c:1049).  2 _FULL and 3 _BOTH are
- *                    refused: green_equilibration_favg() (:296-329) scales by the ratio of two binary64 OpenMP sums
- *                    over the frame, whose value depends on the host's thread count.
+ *                    with green_eq_threshold = 0.0001f * img->exif_iso (demosaic.c:1049).  2 _FULL:
+ *                    green_equilibration_favg() (:296-329), 3 _BOTH: _favg then _lavg.  _favg scales by the ratio of two
+ *                    binary64 sums over the frame which the reference adds in an OpenMP reduction (their low bits follow
+ *                    the thread count); the device adds them as double-double pairs in a fixed order: a pixel is within
+ *                    one ulp of binary32 of any run of the reference (in practice equal).  Not available on row bands.
  *   median_thrs      > 0: pre_median() (basic.c:136-186) of the green sites before PPG (ppg.c:58-67); PPG only
  *   color_smoothing  0..5 passes of color_smoothing() (basic.c:191-243) on the output */
 typedef struct dt_hip_demosaic_data_t

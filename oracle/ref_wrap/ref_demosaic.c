@@ -43,15 +43,20 @@ int ref_demosaic(const dt_hip_piece_t *v, const dt_hip_demosaic_data_t *d, const
   const uint32_t filters = ref_shift_dcraw_filters(v->filters, piece.roi_in.x, piece.roi_in.y);
   /* the optional steps of process(), demosaic.c:1137-1250, in its order */
   float *geq = NULL;
-  if(d->green_eq == 1)
+  float *aux = NULL;
+  if(d->green_eq)
   {
-    geq = (float *)malloc(sizeof(float) * (size_t)roi.width * roi.height);
-    if(!geq) return 1;
-    green_equilibration_lavg(geq, (const float *)in, roi.width, roi.height, v->filters, roi.x, roi.y, d->green_eq_threshold);
+    const size_t bytes = sizeof(float) * (size_t)roi.width * roi.height;
+    geq = (float *)malloc(bytes);
+    if(d->green_eq == 3) aux = (float *)malloc(bytes);
+    if(!geq || (d->green_eq == 3 && !aux) || d->green_eq > 3) return 1;
+    if(d->green_eq >= 2)
+      green_equilibration_favg(aux ? aux : geq, (const float *)in, roi.width, roi.height, v->filters, roi.x, roi.y);
+    if(d->green_eq & 1)
+      green_equilibration_lavg(geq, aux ? aux : (const float *)in, roi.width, roi.height, v->filters, roi.x, roi.y,
+                               d->green_eq_threshold);
     in = geq;
   }
-  else if(d->green_eq)
-    return 1;
   int rc = 0;
   if(d->demosaicing_method == DT_HIP_DEMOSAIC_RCD)
     rcd_demosaic(&piece, (float *)out, (const float *)in, &roo, &roi, filters);
@@ -62,6 +67,7 @@ int ref_demosaic(const dt_hip_piece_t *v, const dt_hip_demosaic_data_t *d, const
   else
     rc = 1;
   free(geq);
+  free(aux);
   if(rc == 0 && d->color_smoothing) color_smoothing((float *)out, &roo, (int)d->color_smoothing);
   return rc;
 }

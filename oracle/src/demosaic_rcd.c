@@ -371,6 +371,29 @@ static float mean_abs_pairs(const float g[4])
   return acc / 6.0f;
 }
 
+/* green_equilibration_favg(), src/iop/demosaic/basic.c:296-329: the greens of the even rows are scaled by
+ * sum(greens of the odd rows) / sum(greens of the even rows), both sums in binary64 over the 2x2 cells of the frame.
+ * The reference adds inside an OpenMP reduction: the low bits of its sums follow the thread count.  This is the sum in
+ * index order (the reference on one thread); tests allow 1 ulp of binary32 per pixel against either. */
+static void green_eq_favg(float *out, const float *in, const int width, const int height, const uint32_t filters, const int x,
+                          const int y)
+{
+  const int oi = (oracle_fc(y, x, filters) & 1) != 1 ? 1 : 0;
+  const int g2_offset = oi ? -1 : 1;
+  double sum1 = 0.0, sum2 = 0.0;
+  memcpy(out, in, sizeof(float) * (size_t)width * height);
+  for(int j = 0; j < height - 1; j += 2)
+    for(int i = oi; i < width - 1 - g2_offset; i += 2)
+    {
+      sum1 += in[(size_t)j * width + i];
+      sum2 += in[(size_t)(j + 1) * width + i + g2_offset];
+    }
+  if(!(sum1 > 0.0 && sum2 > 0.0)) return;
+  const double gr_ratio = sum2 / sum1;
+  for(int j = 0; j < height - 1; j += 2)
+    for(int i = oi; i < width - 1 - g2_offset; i += 2) out[(size_t)j * width + i] = in[(size_t)j * width + i] * gr_ratio;
+}
+
 static void green_eq_lavg(float *out, const float *in, const int width, const int height, const uint32_t filters, const int x,
                           const int y, const float thr)
 {
@@ -437,25 +460,32 @@ static void color_smoothing(float *out, const int width, const int height, const
 }
 
 /* process(), src/iop/demosaic.c:1041-1253, Bayer branch: [green equilibration, local average] -> demosaic ->
- * [colour smoothing].  The "full average" equilibration (basic.c:296-329) scales one green by the ratio of two
- * binary64 OpenMP sums over the frame -- not a function of the input alone; neither this nor the device runs it. */
+ * [colour smoothing]. */
 int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d, const void *in_, void *out)
 {
-  if(d->green_eq > 1 || d->color_smoothing > 5) return 1;
+  if(d->green_eq > 3 || d->color_smoothing > 5) return 1;
   if(d->median_thrs != 0.0f && d->demosaicing_method != DT_HIP_DEMOSAIC_PPG) return 1;
   if(!piece->filters || piece->filters == 9u) return 1;
   const float *in = (const float *)in_;
   float *geq = NULL;
-  if(d->green_eq == 1)
+  float *aux = NULL;
+  if(d->green_eq)
   {
-    geq = (float *)malloc(sizeof(float) * (size_t)piece->roi_in.width * piece->roi_in.height);
-    if(!geq) return 1;
-    green_eq_lavg(geq, in, piece->roi_in.width, piece->roi_in.height, piece->filters, piece->roi_in.x, piece->roi_in.y,
-                  d->green_eq_threshold);
+    /* demosaic.c:1137-1163 */
+    const size_t bytes = sizeof(float) * (size_t)piece->roi_in.width * piece->roi_in.height;
+    geq = (float *)malloc(bytes);
+    if(d->green_eq == 3) aux = (float *)malloc(bytes);
+    if(!geq || (d->green_eq == 3 && !aux)) return 1;
+    if(d->green_eq >= 2)
+      green_eq_favg(aux ? aux : geq, in, piece->roi_in.width, piece->roi_in.height, piece->filters, piece->roi_in.x, piece->roi_in.y);
+    if(d->green_eq & 1)
+      green_eq_lavg(geq, aux ? aux : in, piece->roi_in.width, piece->roi_in.height, piece->filters, piece->roi_in.x,
+                    piece->roi_in.y, d->green_eq_threshold);
     in = geq;
   }
   const int rc = demosaic_methods(piece, d, in, out);
   free(geq);
+  free(aux);
   if(rc == 0 && d->color_smoothing) color_smoothing((float *)out, piece->roi_out.width, piece->roi_out.height, (int)d->color_smoothing);
   return rc;
 }

@@ -126,15 +126,58 @@ def test_demosaic_optional_steps(w, h, xy, method, geq, smooth, median, geq_thr)
     assert not np.array_equal(np.nan_to_num(got), np.nan_to_num(plain))  # the steps did something
 
 
-def test_full_average_green_equilibration_is_refused():
+@pytest.mark.parametrize("w,h,xy", [(640, 400, (0, 0)), (207, 131, (1, 1)), (1504, 1000, (1, 0)), (120, 96, (0, 1)), (4001, 3001, (0, 0))])
+@pytest.mark.parametrize("geq,method", [(2, abi.DT_HIP_DEMOSAIC_RCD), (3, abi.DT_HIP_DEMOSAIC_PPG), (3, abi.DT_HIP_DEMOSAIC_RCD)])
+def test_full_average_green_equilibration(w, h, xy, geq, method):
+    """green_equilibration_favg() (demosaic/basic.c:296-329), alone and ahead of the local average.  The two frame-wide
+    binary64 sums are order dependent in the reference (OpenMP reduction); the device carries them as double-double
+    pairs in a fixed order.  Tolerance: one ulp of binary32 per pixel against the index-order sum of the oracle; on
+    these frames no pixel differs."""
+    import numpy as np
+    import checkers as ck
+    import hipcheck as hc
+    from ansel_amd import synth
+    cfa = synth.bayer_mosaic(w, h, seed=11).astype(np.float32)
+    img = ((cfa - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(xy[0], xy[1], w, h), roi_out=abi.Roi.make(xy[0], xy[1], w, h))
+    d = abi.DemosaicData(geq, 0, method, 0.0, 0.08)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4), pre_fill=np.zeros((h, w, 4), np.float32))
+    want = np.zeros((h, w, 4), np.float32)
+    assert ck.call(ck.oracle(), "oracle_demosaic", piece, d, img, want) == 0
+    ulp = np.abs(got[..., :3].view(np.int32).astype(np.int64) - want[..., :3].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, int(ulp.max())
+    assert int((ulp != 0).sum()) == 0, "pixels off by one ulp: %d" % int((ulp != 0).sum())
+    plain = hc.run_hip("dt_hip_iop_demosaic_process", piece, abi.DemosaicData(0, 0, method, 0.0, 0.0), img, (h, w, 4),
+                       pre_fill=np.zeros((h, w, 4), np.float32))
+    assert not np.array_equal(got, plain)
+
+
+@pytest.mark.parametrize("bad,where", [(float("nan"), (10, 11)), (float("inf"), (10, 11)), (float("inf"), (11, 10)), (-1e9, (10, 11))])
+def test_full_average_green_equilibration_with_sums_that_are_not_positive_numbers(bad, where):
+    import numpy as np
+    import checkers as ck
+    import hipcheck as hc
+    from ansel_amd import synth
+    w, h = 64, 48
+    img = np.random.default_rng(0).random((h, w)).astype(np.float32)
+    img[where] = bad
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1)
+    d = abi.DemosaicData(2, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.0)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4), pre_fill=np.zeros((h, w, 4), np.float32))
+    want = np.zeros((h, w, 4), np.float32)
+    assert ck.call(ck.oracle(), "oracle_demosaic", piece, d, img, want) == 0
+    hc.assert_bit_exact(got, want, "favg with %r" % bad)
+
+
+def test_states_that_are_not_states_of_the_module_are_refused():
     import ctypes as C
     import hipcheck as hc
     from ansel_amd import lib, synth
     l = hc.hip()
     buf = lib.DeviceBuffer(0, 64 * 48 * 16)
     piece = abi.Piece.make(64, 48, filters=synth.FILTERS_RGGB, channels=1)
-    for geq in (2, 3):
-        d = abi.DemosaicData(geq, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.1)
-        assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
+    d = abi.DemosaicData(4, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.1)
+    assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
     d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.3, 0.0)   # a median threshold only exists for PPG
     assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG

@@ -688,10 +688,33 @@ def test_demosaic_optional_steps(w, h, xy, method, geq, smooth, median, geq_thr)
     _exact(a, b, "demosaic extras", mask)
 
 
-def test_full_average_green_equilibration_is_refused():
+@pytest.mark.parametrize("w,h,xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (120, 96, (1, 0)), (64, 40, (0, 1))])
+@pytest.mark.parametrize("geq", [2, 3])
+def test_full_average_green_equilibration(w, h, xy, geq):
+    """green_equilibration_favg() (demosaic/basic.c:296-329), alone and ahead of the local average.  The reference adds its
+    two binary64 sums inside an OpenMP reduction, so their low bits follow the thread count: a pixel may differ by one
+    ulp of binary32 from the index-order sum of the restatement (none does on these frames)"""
+    cfa = synth.bayer_mosaic(w, h, seed=11).astype(np.float32)
+    img = ((cfa - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(xy[0], xy[1], w, h), roi_out=abi.Roi.make(xy[0], xy[1], w, h))
+    d = abi.DemosaicData(geq, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.08)
+    a, b = _pair("demosaic", piece, d, img, (h, w, 4))
+    plain, _ = _pair("demosaic", piece, abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.0), img, (h, w, 4))
+    assert not np.array_equal(a, plain)
+    ulp = np.abs(a[..., :3].view(np.int32).astype(np.int64) - b[..., :3].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, int(ulp.max())
+    assert int((ulp != 0).sum()) == 0, "pixels off by one ulp: %d" % int((ulp != 0).sum())
+
+
+@pytest.mark.parametrize("bad,where", [(np.nan, (10, 11)), (np.inf, (10, 11)), (np.inf, (11, 10)), (-1e9, (10, 11))])
+def test_full_average_green_equilibration_with_sums_that_are_not_positive_numbers(bad, where):
+    """sum1 > 0.0 && sum2 > 0.0 fails (NaN, a negative sum): the copy is the result; an infinite sum gives a ratio of
+    0 or inf, applied as it is"""
     w, h = 64, 48
     img = np.random.default_rng(0).random((h, w)).astype(np.float32)
+    img[where] = bad
     piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1)
-    out = np.zeros((h, w, 4), np.float32)
-    for geq in (2, 3):
-        assert ck.call(ck.oracle(), "oracle_demosaic", piece, abi.DemosaicData(geq, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.1), img, out) != 0
+    d = abi.DemosaicData(2, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.0)
+    a, b = _pair("demosaic", piece, d, img, (h, w, 4))
+    _exact(a, b, "favg with %r" % bad)
