@@ -135,13 +135,26 @@ class FinalscaleData(C.Structure):
 
 
 class LabData(C.Structure):
-    """dt_hip_lab_data_t: the 3x3 (rows padded to 4) of the RGB <-> Lab glue"""
-    _fields_ = [("matrix", m34)]
+    """dt_hip_lab_data_t: the 3x3 (rows padded to 4) of the RGB <-> Lab glue, and the tone curves of a work profile
+    that has them"""
+    _fields_ = [("matrix", m34), ("nonlinearlut", C.c_int), ("unbounded_coeffs", (C.c_float * 3) * 3),
+                ("lut", C.c_void_p * 3), ("lut_first", C.c_float * 3)]
 
     @classmethod
-    def make(cls, m):
+    def make(cls, m, luts=None):
+        """luts: three (pointer or None, lut[0], (a, b, c) of the fitted power law) per channel"""
         d = cls()
         set_m34(d.matrix, m)
+        for c in range(3):
+            d.lut_first[c] = -1.0
+        if luts:
+            for c, (ptr, first, coeffs) in enumerate(luts):
+                d.lut[c] = ptr
+                d.lut_first[c] = first if ptr else -1.0
+                for k in range(3):
+                    d.unbounded_coeffs[c][k] = coeffs[k]
+                if ptr and first >= 0.0:
+                    d.nonlinearlut += 1
         return d
 
 

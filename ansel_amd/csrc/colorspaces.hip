@@ -126,22 +126,38 @@ namespace
 struct lab_args
 {
   float m[3][4];
+  // _apply_tonecurves(), iop_profile.c:332-372: the channels that have a curve
+  const float *lut[3];
+  float coeff[3][3];
+  int curve[3];
 };
 
-// _transform_rgb_to_lab_matrix(), src/colorprofiles/iop_profile.c:405-418 + dt_XYZ_to_Lab()
-__global__ __launch_bounds__(256) void rgb_to_lab(const float4 *in, float4 *out, const size_t n,
-                                                  const lab_args a)
+__device__ __forceinline__ float4 lab_curves(float4 p, const lab_args &a)
 {
-  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
-    out[k] = px_rgb_to_lab(in[k], a.m);
+  if(a.curve[0]) p.x = eval_trc(p.x, a.lut[0], a.coeff[0]);
+  if(a.curve[1]) p.y = eval_trc(p.y, a.lut[1], a.coeff[1]);
+  if(a.curve[2]) p.z = eval_trc(p.z, a.lut[2], a.coeff[2]);
+  return p;
 }
 
-// _transform_lab_to_rgb_matrix(), :423-450 + dt_Lab_to_XYZ()
-__global__ __launch_bounds__(256) void lab_to_rgb(const float4 *in, float4 *out, const size_t n,
-                                                  const lab_args a)
+// _transform_rgb_to_lab_matrix(), src/colorprofiles/iop_profile.c:377-418 + dt_XYZ_to_Lab(); TRC: the profile's input
+// curves ahead of the matrix (:389-393)
+template <bool TRC>
+__global__ __launch_bounds__(256) void rgb_to_lab(const float4 *in, float4 *out, const size_t n, const lab_args a)
 {
   for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
-    out[k] = px_lab_to_rgb(in[k], a.m);
+    out[k] = px_rgb_to_lab(TRC ? lab_curves(in[k], a) : in[k], a.m);
+}
+
+// _transform_lab_to_rgb_matrix(), :423-463 + dt_Lab_to_XYZ(); TRC: the profile's output curves behind the matrix (:455-462)
+template <bool TRC>
+__global__ __launch_bounds__(256) void lab_to_rgb(const float4 *in, float4 *out, const size_t n, const lab_args a)
+{
+  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+  {
+    const float4 rgb = px_lab_to_rgb(in[k], a.m);
+    out[k] = TRC ? lab_curves(rgb, a) : rgb;
+  }
 }
 
 int lab_launch(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, dt_hip_mem_t dev_in,
@@ -151,13 +167,30 @@ int lab_launch(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *
   const size_t n = (size_t)piece->roi_out.width * piece->roi_out.height;
   if(n == 0) return DT_HIP_SUCCESS;
   lab_args a;
+  memset(&a, 0, sizeof(a));
   memcpy(a.m, d->matrix, sizeof(a.m));
+  bool trc = false;
+  if(d->nonlinearlut)
+    for(int c = 0; c < 3; c++)
+    {
+      a.lut[c] = (const float *)d->lut[c];
+      a.curve[c] = a.lut[c] && d->lut_first[c] >= 0.0f;
+      for(int k = 0; k < 3; k++) a.coeff[c][k] = d->unbounded_coeffs[c][k];
+      trc |= a.curve[c] != 0;
+    }
   hipStream_t s = stream_of(devid);
+  const unsigned grid = stream_grid(n, 256);
+  const float4 *in = (const float4 *)dev_in;
+  float4 *out = (float4 *)dev_out;
   launch_scope ls(devid, to_lab ? "rgb_to_lab" : "lab_to_rgb");
-  if(to_lab)
-    rgb_to_lab<<<stream_grid(n, 256), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, n, a);
+  if(to_lab && trc)
+    rgb_to_lab<true><<<grid, 256, 0, s>>>(in, out, n, a);
+  else if(to_lab)
+    rgb_to_lab<false><<<grid, 256, 0, s>>>(in, out, n, a);
+  else if(trc)
+    lab_to_rgb<true><<<grid, 256, 0, s>>>(in, out, n, a);
   else
-    lab_to_rgb<<<stream_grid(n, 256), 256, 0, s>>>((const float4 *)dev_in, (float4 *)dev_out, n, a);
+    lab_to_rgb<false><<<grid, 256, 0, s>>>(in, out, n, a);
   return check_launch(to_lab ? "rgb_to_lab" : "lab_to_rgb");
 }
 } // namespace

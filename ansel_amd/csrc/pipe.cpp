@@ -200,7 +200,8 @@ struct dt_hip_pipe_t
       }
       else if(fusion && nodes[i].piece.channels == 4 && !blended(i)
               && ((nodes[i].op >= OP_EXPOSURE && nodes[i].op <= OP_COLOROUT)
-                  || (nodes[i].op == OP_LAB_TO_RGB && i + 1 < n && nodes[i + 1].op >= OP_EXPOSURE && nodes[i + 1].op <= OP_COLOROUT)))
+                  || (nodes[i].op == OP_LAB_TO_RGB && !nodes[i].as<dt_hip_lab_data_t>()->nonlinearlut && i + 1 < n
+                      && nodes[i + 1].op >= OP_EXPOSURE && nodes[i + 1].op <= OP_COLOROUT)))
       {
         rgb_group_t r;
         memset(&r, 0, sizeof(r));
@@ -255,6 +256,7 @@ struct dt_hip_pipe_t
           }
         }
         else if(r.n_ops > 0 && j < n && nodes[j].op == OP_RGB_TO_LAB && !blended(j) && nodes[j].piece.channels == 4
+                && !nodes[j].as<dt_hip_lab_data_t>()->nonlinearlut
                 && nodes[j].piece.roi_out.width == r.width && nodes[j].piece.roi_out.height == r.height)
         {
           // ... and the RGB -> Lab glue in front of a Lab module its last one
@@ -395,7 +397,7 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
     // diffuse or sharpen followed by the RGB -> Lab glue: the conversion is the tail of the module's last kernel
     if(pipe->fusion && g.kind == group_t::SINGLE && pipe->nodes[g.first].op == OP_DIFFUSE && gi + 1 < ng
        && pipe->groups[gi + 1].kind == group_t::SINGLE && pipe->nodes[pipe->groups[gi + 1].first].op == OP_RGB_TO_LAB
-       && !is_blend(gi + 2))
+       && !pipe->nodes[pipe->groups[gi + 1].first].as<dt_hip_lab_data_t>()->nonlinearlut && !is_blend(gi + 2))
     {
       const node_t &df = pipe->nodes[g.first], &lab = pipe->nodes[pipe->groups[gi + 1].first];
       const bool final_pair = gi + 2 == ng;

@@ -514,10 +514,19 @@ void dt_hip_iop_nlmeans_tiling(const dt_hip_piece_t *piece, const dt_hip_nlmeans
  * dt_ioppr_transform_image_colorspace(), src/colorprofiles/iop_profile.c:540-596) for a linear matrix
  * work profile: _transform_rgb_to_lab_matrix() / _transform_lab_to_rgb_matrix() (:377-463).
  * matrix = the profile's RGB -> XYZ(D50) (to Lab) resp. XYZ(D50) -> RGB (from Lab) 3x3, rows padded
- * to 4.  Alpha is carried over (the pipe converts in place).  dev_in == dev_out is allowed. */
+ * to 4.  Alpha is carried over (the pipe converts in place).  dev_in == dev_out is allowed.
+ * A work profile with tone curves (profile_info->nonlinearlut, e.g. sRGB or Adobe RGB chosen as the work profile):
+ * nonlinearlut != 0 and lut / unbounded_coeffs / lut_first = the profile's lut_in / unbounded_coeffs_in (to Lab, curves
+ * ahead of the matrix, :389-393) resp. lut_out / unbounded_coeffs_out (from Lab, curves behind it, :455-462), as
+ * _apply_tonecurves() (:332-372) reads them; device buffers of DT_HIP_LUT_SAMPLES floats, NULL or lut_first[c] < 0 =
+ * the channel is linear.  Such a conversion runs in its own launch (a linear one is fused into its neighbours). */
 typedef struct dt_hip_lab_data_t
 {
   float matrix[3][4];
+  int nonlinearlut;
+  float unbounded_coeffs[3][3];
+  dt_hip_mem_t lut[3];
+  float lut_first[3]; /* lut[c][0], copied host side like dt_hip_conversion_t's */
 } dt_hip_lab_data_t;
 int dt_hip_transform_rgb_to_lab(int devid, const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d,
                                 dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);

@@ -381,6 +381,14 @@ static inline float lab_f_inv_(const float x)
   return (x > epsilon) ? x * x * x : (116.0f * x - 16.0f) / kappa;
 }
 
+/* _apply_tonecurves(), src/colorprofiles/iop_profile.c:332-372, on one pixel: the channels that have a curve */
+static inline void lab_curves(const dt_hip_lab_data_t *d, float v[4])
+{
+  if(!d->nonlinearlut) return;
+  for(int c = 0; c < 3; c++)
+    if(d->lut[c] && d->lut_first[c] >= 0.0f) v[c] = eval_trc(v[c], (const float *)d->lut[c], d->unbounded_coeffs[c]);
+}
+
 int oracle_rgb_to_lab(const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, const void *in_, void *out_)
 {
   const float *in = (const float *)in_;
@@ -392,6 +400,7 @@ int oracle_rgb_to_lab(const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, c
   {
     px_t p;
     for(int c = 0; c < 4; c++) p.v[c] = in[4 * k + c];
+    lab_curves(d, p.v); /* iop_profile.c:389-393 */
     const px_t xyz = mat3(m, p);
     float f[3];
     for(int i = 0; i < 3; i++) f[i] = lab_f_(xyz.v[i] / LAB_D50[i]);
@@ -420,7 +429,8 @@ int oracle_lab_to_rgb(const dt_hip_piece_t *piece, const dt_hip_lab_data_t *d, c
     xyz.v[1] = LAB_D50[1] * lab_f_inv_(fy);
     xyz.v[2] = LAB_D50[2] * lab_f_inv_(fz);
     xyz.v[3] = 0.0f;
-    const px_t rgb = mat3(m, xyz);
+    px_t rgb = mat3(m, xyz);
+    lab_curves(d, rgb.v); /* iop_profile.c:455-462 */
     for(int c = 0; c < 3; c++) out[4 * k + c] = rgb.v[c];
     out[4 * k + 3] = in[4 * k + 3];
   }

@@ -73,3 +73,25 @@ def test_channelmixerrgb_defaults_and_grey():
     for d in (params.channelmixerrgb(), params.channelmixerrgb(grey=(0.3, 0.5, 0.2), clip=False, gamut=2.0),
               params.channelmixerrgb(gamut=0.0, red=(1.1, -0.05, -0.05))):
         _both("channelmixerrgb", "dt_hip_iop_channelmixerrgb_process", piece, d, d, img)
+
+
+@pytest.mark.parametrize("imgname", ["scene", "adversarial"])
+@pytest.mark.parametrize("channels", [(0, 0, 0), (1, 1, 1), (1, 0, 1)])
+def test_lab_glue_linear_and_with_the_tone_curves_of_the_work_profile(imgname, channels):
+    """RGB <-> Lab around Lab modules (iop_profile.c:377-463); a work profile with tone curves runs _apply_tonecurves()
+    (:332-372) ahead of the matrix on the way in and behind it on the way out"""
+    img = _images()[imgname]
+    piece = abi.Piece.make(W, H)
+    enc, dec, ce, cd = _luts()
+    d_enc, d_dec = lib.DeviceBuffer.from_numpy(0, enc), lib.DeviceBuffer.from_numpy(0, dec)
+
+    def make(m, lut, dlut, co, dev):
+        if not any(channels):
+            return abi.LabData.make(m)
+        return abi.LabData.make(m, [((dlut.ptr if dev else lut.ctypes.data) if on else None, float(lut[0]), co) for on in channels])
+    _both("rgb_to_lab", "dt_hip_transform_rgb_to_lab", piece, make(params.WORK_IN, dec, d_dec, cd, False),
+          make(params.WORK_IN, dec, d_dec, cd, True), img)
+    lab = hc.run_cpu("oracle", "rgb_to_lab", piece, abi.LabData.make(params.WORK_IN), img, img.shape)
+    lab = np.where(np.isfinite(lab), lab, 0).astype(np.float32)
+    _both("lab_to_rgb", "dt_hip_transform_lab_to_rgb", piece, make(params.WORK_OUT, enc, d_enc, ce, False),
+          make(params.WORK_OUT, enc, d_enc, ce, True), lab)

@@ -352,3 +352,35 @@ def test_lab_glue_is_fused_into_the_pointwise_runs():
     assert ck.call(o, "oracle_exposure", rgb, nodes[1].data, a, b) == 0
     assert ck.call(o, "oracle_rgb_to_lab", rgb, nodes[2].data, b, c) == 0
     assert np.array_equal(outs[True].view(np.uint32), c.view(np.uint32))
+
+
+def test_lab_glue_with_tone_curves_runs_in_its_own_launch():
+    """a work profile with tone curves: the conversions are not stages of the fused run; same bits as the oracle chain"""
+    w, h = 320, 200
+    enc, dec = params.srgb_encode_lut(), params.srgb_decode_lut()
+    d_enc, d_dec = lib.DeviceBuffer.from_numpy(0, enc), lib.DeviceBuffer.from_numpy(0, dec)
+    ce, cd = params.unbounded_coeffs(enc), params.unbounded_coeffs(dec)
+    rgb = abi.Piece.make(w, h, channels=4, processed_maximum=synth.WB_COEFFS)
+    img = synth.rgba_image(w, h, seed=9, lo=0.0, hi=1.0)
+    lab_in = np.zeros_like(img)
+    assert ck.call(ck.oracle(), "oracle_rgb_to_lab", rgb, abi.LabData.make(params.WORK_IN), img, lab_in) == 0
+
+    def nodes(dev):
+        return [pipe.Node("lab_to_rgb", abi.LabData.make(params.WORK_OUT, [(d_enc.ptr if dev else enc.ctypes.data, float(enc[0]), ce)] * 3), rgb),
+                pipe.Node("exposure", abi.ExposureData(-0.000244140625, 1.6245047), rgb),
+                pipe.Node("rgb_to_lab", abi.LabData.make(params.WORK_IN, [(d_dec.ptr if dev else dec.ctypes.data, float(dec[0]), cd)] * 3), rgb)]
+    din = lib.DeviceBuffer.from_numpy(0, lab_in)
+    dout = lib.DeviceBuffer(0, w * h * 16)
+    p = pipe.DevicePipe(0, nodes(True), fusion=True)
+    assert p.num_groups == 3
+    p.process(din.ptr, dout.ptr)
+    assert lib.load().dt_hip_finish(0) == 1
+    got = dout.to_numpy((h, w, 4), np.float32)
+    p.close()
+    o = ck.oracle()
+    host = nodes(False)
+    a, b, c = np.zeros_like(img), np.zeros_like(img), np.zeros_like(img)
+    assert ck.call(o, "oracle_lab_to_rgb", rgb, host[0].data, lab_in, a) == 0
+    assert ck.call(o, "oracle_exposure", rgb, host[1].data, a, b) == 0
+    assert ck.call(o, "oracle_rgb_to_lab", rgb, host[2].data, b, c) == 0
+    assert np.array_equal(got.view(np.uint32), c.view(np.uint32))

@@ -287,6 +287,33 @@ def test_lab_glue(imgname):
         assert float(np.abs(b2[..., :3] - img[..., :3])[ok].max()) < 2e-3  # a round trip, roughly
 
 
+@pytest.mark.parametrize("channels", [(1, 1, 1), (1, 0, 1), (0, 1, 0)])
+def test_lab_glue_of_a_work_profile_with_tone_curves(channels):
+    """a work profile that has tone curves (sRGB chosen as the work profile): _apply_tonecurves() ahead of the matrix on the
+    way to Lab, behind it on the way back (iop_profile.c:389-393, :455-462); all three channels or only some"""
+    img = synth.rgba_image(W, H, seed=4, lo=-0.05, hi=1.6)
+    img[..., 3] = np.linspace(0, 1, W * H, dtype=np.float32).reshape(H, W)
+    piece = abi.Piece.make(W, H)
+    dec, enc = params.srgb_decode_lut(), params.srgb_encode_lut()
+
+    def luts(lut):
+        co = params.unbounded_coeffs(lut)
+        return [(lut.ctypes.data if on else None, float(lut[0]), co) for on in channels]
+    to_lab, to_rgb = abi.LabData.make(params.WORK_IN, luts(dec)), abi.LabData.make(params.WORK_OUT, luts(enc))
+    assert to_lab.nonlinearlut == sum(channels)
+    a, b = _pair("rgb_to_lab", piece, to_lab, img, img.shape)
+    _exact(a, b, "rgb_to_lab with input curves")
+    assert np.array_equal(b[..., 3], img[..., 3])
+    linear, _ = _pair("rgb_to_lab", piece, abi.LabData.make(params.WORK_IN), img, img.shape)
+    assert not np.array_equal(a, linear)
+    lab = np.where(np.isfinite(b), b, 0).astype(np.float32)
+    a2, b2 = _pair("lab_to_rgb", piece, to_rgb, lab, lab.shape)
+    _exact(a2, b2, "lab_to_rgb with output curves")
+    if channels == (1, 1, 1):
+        ok = (img[..., :3].min(axis=-1) > 0.01) & (img[..., :3].max(axis=-1) < 0.95)
+        assert float(np.abs(b2[..., :3] - img[..., :3])[ok].max()) < 2e-3  # a round trip, roughly
+
+
 @pytest.mark.parametrize("w,h", [(300, 200), (123, 457)])
 @pytest.mark.parametrize("ss,sr,detail", [(50.0, 25.0, 0.33), (8.0, 5.0, -0.5), (0.3, 2.0, 1.5), (20.0, 60.0, 4.0)])
 def test_bilat_bilateral_grid(w, h, ss, sr, detail):
