@@ -18,6 +18,7 @@
 #include "hip_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 using namespace ansel;
 
@@ -37,6 +38,7 @@ namespace
 #define M3 (3 * TS + 3)
 #define PAD 32
 #define NT 512
+#define CHAIN_U 8 // sites of a stage-3 chain fetched ahead
 
 // plane offsets in floats: the reference's buffer layout, amaze.cc:274-327 (128 bytes between planes)
 enum
@@ -98,18 +100,84 @@ struct amaze_args
 #define EPSSQ 1e-10f
 #define ARTHRESH 0.75f
 
-// all threads of the workgroup over a rows x cols rectangle of the tile
-#define FOR_RECT(r0, r1, c0, c1)                                                    \
+// one site of a stage-3 chain (amaze.cc:585-705): `prev` is the already updated neighbour, c0 / c1 the site's and the next
+// neighbour's colour difference, a0..a2 the Hamilton-Adams alternative around the site, before / here / after the mosaic
+__device__ __forceinline__ float chain_site(const float prev, const float c0, const float c1, const float a0, const float a1,
+                                            const float a2, const float before, const float here, const float after,
+                                            const bool gsite, const float clip_pt)
+{
+  const float cdvar = 3.f * (sqr(prev) + sqr(c0) + sqr(c1)) - sqr(prev + c0 + c1);
+  const float altvar = 3.f * (sqr(a0) + sqr(a1) + sqr(a2)) - sqr(a0 + a1 + a2);
+  float h = c0;
+  if(altvar < cdvar) h = a1;
+  if(gsite)
+  {
+    const float Gint = -h + here;
+    if(h > 0)
+    {
+      if(3.f * h > (Gint + here))
+        h = -ulim(Gint, before, after) + here;
+      else
+      {
+        const float wt = 1.f - 3.f * h / (EPS + Gint + here);
+        h = wt * h + (1.f - wt) * (-ulim(Gint, before, after) + here);
+      }
+    }
+    if(Gint > clip_pt) h = -ulim(Gint, before, after) + here;
+  }
+  else
+  {
+    const float Gint = h + here;
+    if(h < 0)
+    {
+      if(3.f * h < -(Gint + here))
+        h = ulim(Gint, before, after) - here;
+      else
+      {
+        const float wt = 1.f + 3.f * h / (EPS + Gint + here);
+        h = wt * h + (1.f - wt) * (ulim(Gint, before, after) - here);
+      }
+    }
+    if(Gint > clip_pt) h = ulim(Gint, before, after) - here;
+  }
+  return h;
+}
+
+
+// all threads of the workgroup over a rows x cols rectangle of the tile: whole tile rows are dealt out (a division by the
+// constant TS instead of one by the rectangle's width), the lanes left and right of the rectangle idle
+#define FOR_RECT(r0, r1, c0, c1)                                            \
+  for(int _k = tid, _n = ((r1) - (r0)) * TS; _k < _n; _k += NT)             \
+    for(int rr = (r0) + _k / TS, cc = _k % TS, _once = 1; _once && cc >= (c0) && cc < (c1); _once = 0)
+// ... a division by the rectangle's width, no idle lanes (the output stage: 128 of 160 columns)
+#define FOR_RECT_TIGHT(r0, r1, c0, c1)                                                            \
   for(int _k = tid, _w = (c1) - (c0), _n = _w > 0 ? ((r1) - (r0)) * _w : 0; _k < _n; _k += NT) \
     for(int rr = (r0) + _k / _w, cc = (c0) + _k % _w, _once = 1; _once; _once = 0)
+// ... over rows x the TSH columns of a half-width plane
+#define FOR_HALF(r0, r1)                                                    \
+  for(int _k = tid, _n = ((r1) - (r0)) * TSH; _k < _n; _k += NT)            \
+    for(int rr = (r0) + _k / TSH, cc = _k % TSH, _once = 1; _once; _once = 0)
 // all threads over the R/B sites (every other column, phase from the CFA) of rows r0..r1, columns from c0
 #define FOR_RB(r0, r1, c0, c1)                                                                       \
   for(int _k = tid, _n = ((r1) - (r0)) * TSH; _k < _n; _k += NT)                                     \
     for(int rr = (r0) + _k / TSH, cc = (c0) + (fct(rr, 2, filters) & 1) + 2 * (_k % TSH), _once = 1; _once && cc < (c1); _once = 0)
 
+// TIMED: the measuring build (ANSEL_HIP_AMAZE_TIMED, tools/amaze_stage_clocks.py) adds the cycles between the STAMPs of
+// every tile into stamps[]
+#define N_STAMPS 20
+template <bool TIMED>
 __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, float *__restrict__ out,
-                                                  float *__restrict__ slabs, const amaze_args a)
+                                                  float *__restrict__ slabs, const amaze_args a,
+                                                  unsigned long long *__restrict__ stamps)
 {
+  long long t_prev = 0;
+#define STAMP(k)                                                           \
+  if(TIMED && threadIdx.x == 0)                                            \
+  {                                                                        \
+    const long long _t = (long long)__builtin_readcyclecounter();          \
+    atomicAdd(&stamps[k], (unsigned long long)(_t - t_prev));              \
+    t_prev = _t;                                                           \
+  }
   __shared__ float vote[TS * TSH];
   __shared__ int nyq[4];
   const int tid = threadIdx.x;
@@ -138,8 +206,10 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     const int rrmin = top < 0 ? 16 : 0, ccmin = left < 0 ? 16 : 0;
     const int rrmax = bottom > height ? height - top : rr1, ccmax = right > width ? width - left : cc1;
 
+    if(TIMED) t_prev = (long long)__builtin_readcyclecounter();
     for(int k = tid; k < O_END; k += NT) B[k] = 0.0f;
     __syncthreads();
+    STAMP(0)
 
     // ---- S0 tile load, amaze.cc:352-460: the nine fills in the reference's order (later ones overwrite
     //      earlier ones; the right strip wraps into the next tile row, the bottom strip may run past the
@@ -151,26 +221,26 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     cfa[_i] = _v;         \
     green[_i] = _v;       \
   }
-    if(rrmin > 0) FOR_RECT(0, 16, ccmin, ccmax) PUT(rr * TS + cc, in[(size_t)(32 - rr + top) * width + (cc + left)]);
-    __syncthreads();
-    FOR_RECT(rrmin, rrmax, ccmin, ccmax) PUT(rr * TS + cc, in[(size_t)(rr + top) * width + (cc + left)]);
-    __syncthreads();
-    if(rrmax < rr1) FOR_RECT(0, 16, ccmin, ccmax) PUT((rrmax + rr) * TS + cc, in[(size_t)(height - rr - 2) * width + (left + cc)]);
-    __syncthreads();
-    if(ccmin > 0) FOR_RECT(rrmin, rrmax, 0, 16) PUT(rr * TS + cc, in[(size_t)(rr + top) * width + (32 - cc + left)]);
-    __syncthreads();
-    if(ccmax < cc1) FOR_RECT(rrmin, rrmax, 0, 16) PUT(rr * TS + ccmax + cc, in[(size_t)(top + rr) * width + (width - cc - 2)]);
-    __syncthreads();
-    if(rrmin > 0 && ccmin > 0) FOR_RECT(0, 16, 0, 16) PUT(rr * TS + cc, in[(size_t)(32 - rr) * width + (32 - cc)]);
-    __syncthreads();
-    if(rrmax < rr1 && ccmax < cc1)
-      FOR_RECT(0, 16, 0, 16) PUT((rrmax + rr) * TS + ccmax + cc, in[(size_t)(height - rr - 2) * width + (width - cc - 2)]);
-    __syncthreads();
-    if(rrmin > 0 && ccmax < cc1) FOR_RECT(0, 16, 0, 16) PUT(rr * TS + ccmax + cc, in[(size_t)(32 - rr) * width + (width - cc - 2)]);
-    __syncthreads();
-    if(rrmax < rr1 && ccmin > 0) FOR_RECT(0, 16, 0, 16) PUT((rrmax + rr) * TS + cc, in[(size_t)(height - rr - 2) * width + (32 - cc)]);
-    __syncthreads();
+    // (the conditions are uniform: a barrier only behind a fill that ran)
+#define FILL(cond, loop, idx, v) \
+  if(cond)                       \
+  {                              \
+    loop PUT(idx, v);            \
+    __syncthreads();             \
+  }
+    FILL(rrmin > 0, FOR_RECT(0, 16, ccmin, ccmax), rr * TS + cc, in[(size_t)(32 - rr + top) * width + (cc + left)])
+    FILL(true, FOR_RECT(rrmin, rrmax, ccmin, ccmax), rr * TS + cc, in[(size_t)(rr + top) * width + (cc + left)])
+    FILL(rrmax < rr1, FOR_RECT(0, 16, ccmin, ccmax), (rrmax + rr) * TS + cc, in[(size_t)(height - rr - 2) * width + (left + cc)])
+    FILL(ccmin > 0, FOR_RECT(rrmin, rrmax, 0, 16), rr * TS + cc, in[(size_t)(rr + top) * width + (32 - cc + left)])
+    FILL(ccmax < cc1, FOR_RECT(rrmin, rrmax, 0, 16), rr * TS + ccmax + cc, in[(size_t)(top + rr) * width + (width - cc - 2)])
+    FILL(rrmin > 0 && ccmin > 0, FOR_RECT(0, 16, 0, 16), rr * TS + cc, in[(size_t)(32 - rr) * width + (32 - cc)])
+    FILL(rrmax < rr1 && ccmax < cc1, FOR_RECT(0, 16, 0, 16), (rrmax + rr) * TS + ccmax + cc,
+         in[(size_t)(height - rr - 2) * width + (width - cc - 2)])
+    FILL(rrmin > 0 && ccmax < cc1, FOR_RECT(0, 16, 0, 16), rr * TS + ccmax + cc, in[(size_t)(32 - rr) * width + (width - cc - 2)])
+    FILL(rrmax < rr1 && ccmin > 0, FOR_RECT(0, 16, 0, 16), (rrmax + rr) * TS + cc, in[(size_t)(height - rr - 2) * width + (32 - cc)])
+#undef FILL
 #undef PUT
+    STAMP(1)
 
     // ---- S1 gradients, :463-473
     FOR_RECT(2, rr1 - 2, 2, cc1 - 2)
@@ -184,6 +254,7 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(2)
     // ---- S2 colour differences by adaptive ratios and by Hamilton-Adams, :478-582
     FOR_RECT(4, rr1 - 4, 4, cc1 - 4)
     {
@@ -238,102 +309,40 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(3)
     // ---- S3 choose the smoother estimate and bound it, in place (:585-705).  hcd only depends on hcd two
-    //      columns to the left in the same row, vcd on vcd two rows up in the same column: chains.
+    //      columns to the left in the same row, vcd on vcd two rows up in the same column: chains, one lane each,
+    //      the updated neighbour carried in a register.  Nothing else a site reads depends on the chain, so a lane
+    //      fetches what CHAIN_U sites read in one go: one memory round trip per CHAIN_U sites.
+    //      (Staging column blocks of the horizontal chains in LDS was measured and is slower: the stage waits for the
+    //      slab traffic of the other workgroups either way.)
     for(int chain = tid; chain < 4 * TS; chain += NT)
     {
       const bool horizontal = chain < 2 * TS;
-      const int line = (horizontal ? chain : chain - 2 * TS) >> 1, par = chain & 1;
-      if(horizontal)
+      const int line = (horizontal ? chain : chain - 2 * TS) >> 1, par = chain & 1; // neighbouring lanes share cache lines
+      const int len = horizontal ? cc1 : rr1, lines = horizontal ? rr1 : cc1; // extent along / across the chain
+      if(line < 4 || line >= lines - 4) continue;
+      const int step = horizontal ? 1 : TS;
+      float *const cd = horizontal ? hcd : vcd;
+      const float *const alt = horizontal ? hcdalt : vcdalt;
+      const int origin = horizontal ? line * TS : line; // index of position 0 of the chain's line
+      const bool gsite = (horizontal ? fct(line, 4 + par, filters) : fct(4 + par, line, filters)) & 1;
+      float carried = cd[origin + (2 + par) * step]; // the neighbour in front of the first site: never written
+      for(int p0 = 4 + par; p0 < len - 4; p0 += 2 * CHAIN_U)
       {
-        const int rr = line;
-        if(rr >= 4 && rr < rr1 - 4)
-          for(int cc = 4 + par; cc < cc1 - 4; cc += 2)
+        float C[CHAIN_U + 1], A[CHAIN_U + 2], F[2 * CHAIN_U + 1];
+#pragma unroll
+        for(int k = 0; k <= CHAIN_U; k++) C[k] = (p0 + 2 * k < TS) ? cd[origin + (p0 + 2 * k) * step] : 0.f;
+#pragma unroll
+        for(int k = 0; k <= CHAIN_U + 1; k++) A[k] = (p0 - 2 + 2 * k < TS) ? alt[origin + (p0 - 2 + 2 * k) * step] : 0.f;
+#pragma unroll
+        for(int k = 0; k <= 2 * CHAIN_U; k++) F[k] = (p0 - 1 + k < TS) ? cfa[origin + (p0 - 1 + k) * step] : 0.f;
+#pragma unroll
+        for(int k = 0; k < CHAIN_U; k++)
+          if(p0 + 2 * k < len - 4)
           {
-            const int i = rr * TS + cc;
-            const bool gsite = fct(rr, cc, filters) & 1;
-            const float hcdvar = 3.f * (sqr(hcd[i - 2]) + sqr(hcd[i]) + sqr(hcd[i + 2])) - sqr(hcd[i - 2] + hcd[i] + hcd[i + 2]);
-            const float hcdaltvar = 3.f * (sqr(hcdalt[i - 2]) + sqr(hcdalt[i]) + sqr(hcdalt[i + 2]))
-                                    - sqr(hcdalt[i - 2] + hcdalt[i] + hcdalt[i + 2]);
-            float h = hcd[i];
-            if(hcdaltvar < hcdvar) h = hcdalt[i];
-            if(gsite)
-            {
-              const float Ginth = -h + cfa[i];
-              if(h > 0)
-              {
-                if(3.f * h > (Ginth + cfa[i]))
-                  h = -ulim(Ginth, cfa[i - 1], cfa[i + 1]) + cfa[i];
-                else
-                {
-                  const float hwt = 1.f - 3.f * h / (EPS + Ginth + cfa[i]);
-                  h = hwt * h + (1.f - hwt) * (-ulim(Ginth, cfa[i - 1], cfa[i + 1]) + cfa[i]);
-                }
-              }
-              if(Ginth > clip_pt) h = -ulim(Ginth, cfa[i - 1], cfa[i + 1]) + cfa[i];
-            }
-            else
-            {
-              const float Ginth = h + cfa[i];
-              if(h < 0)
-              {
-                if(3.f * h < -(Ginth + cfa[i]))
-                  h = ulim(Ginth, cfa[i - 1], cfa[i + 1]) - cfa[i];
-                else
-                {
-                  const float hwt = 1.f + 3.f * h / (EPS + Ginth + cfa[i]);
-                  h = hwt * h + (1.f - hwt) * (ulim(Ginth, cfa[i - 1], cfa[i + 1]) - cfa[i]);
-                }
-              }
-              if(Ginth > clip_pt) h = ulim(Ginth, cfa[i - 1], cfa[i + 1]) - cfa[i];
-            }
-            hcd[i] = h;
-          }
-      }
-      else
-      {
-        const int cc = line;
-        if(cc >= 4 && cc < cc1 - 4)
-          for(int rr = 4 + par; rr < rr1 - 4; rr += 2)
-          {
-            const int i = rr * TS + cc;
-            const bool gsite = fct(rr, cc, filters) & 1;
-            const float vcdvar = 3.f * (sqr(vcd[i - V2]) + sqr(vcd[i]) + sqr(vcd[i + V2])) - sqr(vcd[i - V2] + vcd[i] + vcd[i + V2]);
-            const float vcdaltvar = 3.f * (sqr(vcdalt[i - V2]) + sqr(vcdalt[i]) + sqr(vcdalt[i + V2]))
-                                    - sqr(vcdalt[i - V2] + vcdalt[i] + vcdalt[i + V2]);
-            float v = vcd[i];
-            if(vcdaltvar < vcdvar) v = vcdalt[i];
-            if(gsite)
-            {
-              const float Gintv = -v + cfa[i];
-              if(v > 0)
-              {
-                if(3.f * v > (Gintv + cfa[i]))
-                  v = -ulim(Gintv, cfa[i - V1], cfa[i + V1]) + cfa[i];
-                else
-                {
-                  const float vwt = 1.f - 3.f * v / (EPS + Gintv + cfa[i]);
-                  v = vwt * v + (1.f - vwt) * (-ulim(Gintv, cfa[i - V1], cfa[i + V1]) + cfa[i]);
-                }
-              }
-              if(Gintv > clip_pt) v = -ulim(Gintv, cfa[i - V1], cfa[i + V1]) + cfa[i];
-            }
-            else
-            {
-              const float Gintv = v + cfa[i];
-              if(v < 0)
-              {
-                if(3.f * v < -(Gintv + cfa[i]))
-                  v = ulim(Gintv, cfa[i - V1], cfa[i + V1]) - cfa[i];
-                else
-                {
-                  const float vwt = 1.f + 3.f * v / (EPS + Gintv + cfa[i]);
-                  v = vwt * v + (1.f - vwt) * (ulim(Gintv, cfa[i - V1], cfa[i + V1]) - cfa[i]);
-                }
-              }
-              if(Gintv > clip_pt) v = ulim(Gintv, cfa[i - V1], cfa[i + V1]) - cfa[i];
-            }
-            vcd[i] = v;
+            carried = chain_site(carried, C[k], C[k + 1], A[k], A[k + 1], A[k + 2], F[2 * k], F[2 * k + 1], F[2 * k + 2], gsite, clip_pt);
+            cd[origin + (p0 + 2 * k) * step] = carried;
           }
       }
     }
@@ -345,6 +354,7 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(4)
     // ---- S4 H/V weight at R/B sites from colour-difference variances, :707-760
     FOR_RB(6, rr1 - 6, 6, cc1 - 6)
     {
@@ -384,6 +394,7 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(5)
     // ---- S5 Nyquist texture test, :763-820; bounding box of the flagged sites by LDS atomics
     {
       const float gg0 = 0.5f * 0.07384411893421103f, gg1 = 0.5f * 0.06207511968171489f, gg2 = 0.5f * 0.0521818194747806f;
@@ -472,6 +483,7 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(6)
     // ---- S7 the weight vote, in place, row r sees row r-1 voted (:894-905): staged in LDS, one barrier per row
     for(int k = tid; k < TS * TSH; k += NT) vote[k] = hvwt[k];
     __syncthreads();
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     for(int k = tid; k < TS * TSH; k += NT) hvwt[k] = vote[k];
     __syncthreads();
+    STAMP(7)
     // green at R/B sites and its curvature, :907-917
     FOR_RB(8, rr1 - 8, 8, cc1 - 8)
     {
@@ -537,8 +550,9 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(8)
     // ---- S9 diagonal gradients and squared diagonal differences, :958-983 (delp/delm reuse cddiffsq)
-    FOR_RECT(6, rr1 - 6, 0, TSH)
+    FOR_HALF(6, rr1 - 6)
     {
       const int c2 = 6 + 2 * cc;
       if(c2 < cc1 - 6)
@@ -611,6 +625,7 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(9)
     // ---- S10 vote on the diagonal weight, in place, row by row (:1109-1126), in LDS like S7
     for(int k = tid; k < TS * TSH; k += NT) vote[k] = pmwt[k];
     __syncthreads();
@@ -635,6 +650,7 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(10)
     // ---- S11 where the diagonal estimate discriminates better, redo green from R+B, :1129-1236
     FOR_RB(12, rr1 - 12, 12, cc1 - 12)
     {
@@ -681,8 +697,9 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(11)
     // ---- S12 split G-B from G-R: the B coset moves to the second plane, :1239-1244
-    FOR_RECT(0, TS, 0, TSH)
+    FOR_HALF(0, TS)
     {
       // rr, cc enumerate (tile row, half-plane column)
       if(rr >= 13 - a.ey && rr < rr1 - 12 && ((rr - (13 - a.ey)) & 1) == 0)
@@ -721,8 +738,9 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     }
     __syncthreads();
 
+    STAMP(12)
     // ---- S14 output, :1278-1411 (alpha is left as it is)
-    FOR_RECT(16, rr1 - 16, 16, cc1 - 16)
+    FOR_RECT_TIGHT(16, rr1 - 16, 16, cc1 - 16)
     {
       const int row = rr + top, col = cc + left, i = rr * TS + cc;
       if(col < width && row < height)
@@ -749,7 +767,9 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
       }
     }
     __syncthreads();
+    STAMP(13)
   }
+#undef STAMP
 }
 
 } // namespace
@@ -786,12 +806,35 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   a.ntx = (width + 16 + (TS - 32) - 1) / (TS - 32);
   const int nty = (height + 16 + (TS - 32) - 1) / (TS - 32);
   a.ntiles = a.ntx * nty;
-  const int blocks = a.ntiles < 512 ? a.ntiles : 512;
+  // two 512-thread workgroups per CU (the vote plane is 50 KiB of LDS each)
+  const char *const blocks_env = getenv("ANSEL_HIP_AMAZE_BLOCKS");
+  const int max_blocks = blocks_env ? atoi(blocks_env) : 512;
+  const int blocks = a.ntiles < max_blocks ? a.ntiles : max_blocks;
   float *slabs = (float *)dt_hip_alloc_device_buffer(devid, (size_t)blocks * O_END * sizeof(float));
   if(!slabs) return DT_HIP_SYSMEM_ALLOCATION;
+  if(getenv("ANSEL_HIP_AMAZE_TIMED"))
+  {
+    // the measuring build: cycles per stage summed over the tiles, printed (tools/amaze_stage_clocks.py)
+    unsigned long long *stamps = (unsigned long long *)dt_hip_alloc_device_buffer(devid, sizeof(unsigned long long) * N_STAMPS);
+    if(!stamps)
+    {
+      dt_hip_release_mem_object(slabs);
+      return DT_HIP_SYSMEM_ALLOCATION;
+    }
+    hipStream_t s = stream_of(devid);
+    unsigned long long host[N_STAMPS];
+    if(hipMemsetAsync(stamps, 0, sizeof(host), s) == hipSuccess)
+    {
+      amaze_tiles<true><<<blocks, NT, 0, s>>>(in, (float *)out, slabs, a, stamps);
+      if(hipMemcpyAsync(host, stamps, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
+        for(int k = 0; k < 14; k++) fprintf(stderr, "[amaze_timed] stamp %d cycles_per_tile %llu\n", k, host[k] / (unsigned long long)a.ntiles);
+    }
+    dt_hip_release_mem_object(stamps);
+  }
+  else
   {
     launch_scope ls(devid, "amaze_tiles");
-    amaze_tiles<<<blocks, NT, 0, stream_of(devid)>>>(in, (float *)out, slabs, a);
+    amaze_tiles<false><<<blocks, NT, 0, stream_of(devid)>>>(in, (float *)out, slabs, a, nullptr);
   }
   dt_hip_release_mem_object(slabs);
   return check_launch("amaze_tiles");

@@ -53,3 +53,25 @@ def test_amaze_highlights_and_flat_areas():
     want = pre.copy()
     assert ck.call(ck.oracle(), "oracle_demosaic", piece, d, cfa, want) == 0
     assert int((ck.ulp_diff(got, want) > 0).sum()) == 0
+
+
+@pytest.mark.parametrize("filters", [0x94949494, 0x49494949, 0x61616161, 0x16161616])
+def test_amaze_many_tiles_per_workgroup(filters, monkeypatch):
+    """three workgroups walk a frame of 96 tiles (a 24 MP frame has 1 500 tiles for 512 workgroups): the tile buffer is
+    zeroed between tiles, the frame is the oracle's.  Fine checkerboards and stripes switch the Nyquist branches on."""
+    w, h = 1504, 1000
+    raw = synth.bayer_mosaic(w, h, seed=21).astype(np.float32)
+    cfa = ((raw - 512) / np.float32(synth.WHITE - 512) * np.float32(1.7)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    cfa[100:420, 200:900] *= (0.55 + 0.45 * ((xx[100:420, 200:900] + yy[100:420, 200:900]) & 1)).astype(np.float32)
+    cfa[500:900, 300:1300] *= (0.6 + 0.4 * ((xx[500:900, 300:1300] >> 1) & 1)).astype(np.float32)
+    cfa[300:700, 1000:1450] *= (0.6 + 0.4 * (yy[300:700, 1000:1450] & 1)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=filters, channels=1, processed_maximum=(1.5, 1.0, 1.2, 1.0))
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_AMAZE, 0.0)
+    monkeypatch.setenv("ANSEL_HIP_AMAZE_BLOCKS", "3")
+    pre = np.full((h, w, 4), -7.0, np.float32)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, cfa, (h, w, 4), pre_fill=pre)
+    want = pre.copy()
+    assert ck.call(ck.oracle(), "oracle_demosaic", piece, d, cfa, want) == 0
+    diff = ck.ulp_diff(got, want)
+    assert int((diff > 0).sum()) == 0, "%d values differ, max %d ulp" % (int((diff > 0).sum()), int(diff.max()))
