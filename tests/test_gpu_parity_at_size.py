@@ -6,6 +6,7 @@ stays fast; those cannot see what only a full frame exercises: 64-bit offsets (a
 non-local means, XCD-rotated launches at real widths, tile grids with thousands of workgroups.  Here:
 
   config 2   6000 x 4000   light pipe (rawprepare ... RCD ... filmic ... u16)
+  config 2'  6000 x 4000   the same with AMaZE instead of RCD
   config 3   9504 x 6336   + denoise (profiled) wavelets + diffuse or sharpen + non-local means in Lab
   metric    11648 x 8736   light pipe                            (what bench.py's `value` is quoted on)
   config 4  11648 x 8736   config 3's modules, the frame cut into 8 row bands run in lockstep
@@ -59,6 +60,10 @@ def _nodes(which, w, h, lut_ptr, lut):
     coeffs = params.unbounded_coeffs(lut)
     if which == "light":
         return pipe.light_pipe_nodes(w, h, lut_ptr, float(lut[0]), coeffs, with_filmic=True, filmic=filmic.default_data())
+    if which == "light_amaze":
+        from ansel_amd import abi
+        return pipe.light_pipe_nodes(w, h, lut_ptr, float(lut[0]), coeffs, with_filmic=True, filmic=filmic.default_data(),
+                                     demosaic_method=abi.DT_HIP_DEMOSAIC_AMAZE)
     return pipe.denoise_pipe_nodes(w, h, lut_ptr, float(lut[0]), coeffs, filmic=filmic.default_data(),
                                    diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
 
@@ -149,6 +154,11 @@ def _case(which, size, bands=0, host_gib=8):
 
 def test_config2_light_pipe_24MP_equals_the_oracle():
     _case("light", "24MP", host_gib=6)
+
+
+def test_light_pipe_24MP_with_amaze_equals_the_oracle():
+    """the other demosaic the north star names: 1 500 tiles on 512 workgroups, each walking three of them"""
+    _case("light_amaze", "24MP", host_gib=6)
 
 
 def test_config3_full_pipe_60MP_equals_the_oracle():
