@@ -300,6 +300,21 @@ BLENDIF_L_out, BLENDIF_A_out, BLENDIF_B_out, BLENDIF_C_out, BLENDIF_h_out = 4, 5
 MASK_GUIDE_IN_BEFORE_BLUR, MASK_GUIDE_OUT_BEFORE_BLUR, MASK_GUIDE_IN_AFTER_BLUR, MASK_GUIDE_OUT_AFTER_BLUR = 1, 2, 5, 6
 
 
+class DetailmaskData(C.Structure):
+    """dt_hip_detailmask_data_t: the white-balance coefficients the hidden "detailmask" stage normalises by and the plane
+    (roi_out floats) it leaves the raw detail mask in"""
+    _fields_ = [("wb", C.c_float * 4), ("mask", C.c_void_p)]
+
+    @classmethod
+    def make(cls, wb, mask_ptr):
+        d = cls()
+        for k in range(3):
+            d.wb[k] = wb[k]
+        d.wb[3] = 1.0
+        d.mask = mask_ptr
+        return d
+
+
 class BlendData(C.Structure):
     """dt_hip_blend_data_t: the fields of dt_develop_blend_params_t (src/develop/blend.h:199-244) the
     uniform / parametric RGB (scene) blend reads + the work profile's RGB -> XYZ(D50) matrix"""
@@ -308,7 +323,7 @@ class BlendData(C.Structure):
                 ("blendif", C.c_uint32), ("feathering_radius", C.c_float), ("blur_radius", C.c_float),
                 ("details", C.c_float), ("contrast", C.c_float), ("brightness", C.c_float),
                 ("blendif_parameters", C.c_float * 64), ("blendif_boost_factors", C.c_float * 16), ("matrix_in", m34),
-                ("form_mask", C.c_void_p), ("feathering_guide", C.c_uint32)]
+                ("form_mask", C.c_void_p), ("feathering_guide", C.c_uint32), ("detail_mask", C.c_void_p)]
 
     @classmethod
     def uniform(cls, matrix_in, opacity=100.0, blend_mode=BLEND_NORMAL, blend_parameter=0.0, blend_cst=BLEND_CS_RGB_SCENE):

@@ -888,10 +888,16 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   if(piece->channels != (raw ? 1 : 4)) return DT_HIP_INVALID_ARG;
   // drawn / raster masks and the details threshold: rendered and refined by the host into ONE plane, as the reference's
   // device blend receives them (blend.c:1278-1325)
-  const float *const form = (const float *)d->form_mask;
-  if(((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->details != 0.f) && !form)
+  const float *form = (const float *)d->form_mask;
+  float *refined = nullptr; // the form mask times the detail mask, built here when the raw detail mask is at hand
+  if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) && !form)
   {
-    set_last_error("blend: a drawn / raster mask or a details threshold needs the host-rendered form mask (form_mask)");
+    set_last_error("blend: a drawn / raster mask needs the host-rendered form mask (form_mask)");
+    return DT_HIP_INVALID_ARG;
+  }
+  if(d->details != 0.f && !form && !d->detail_mask)
+  {
+    set_last_error("blend: a details threshold needs the raw detail mask (detail_mask) or a plane refined by the host (form_mask)");
     return DT_HIP_INVALID_ARG;
   }
   if(form && raw)
@@ -941,6 +947,25 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   const bool use_masks = form || parametric;
   const bool raster_only = form && (d->mask_mode & DT_HIP_MASK_RASTER) && !(d->mask_mode & DT_HIP_MASK_SHAPE) && !parametric;
   const bool post = use_masks && !raster_only;
+  if(d->details != 0.f && d->detail_mask && post)
+  {
+    // _refine_with_detail_mask(), blend.c:361-425 (:789): the form mask -- or the neutral fill of a parametric-only blend,
+    // :749-757 -- times the blurred sigmoid of the raw detail mask
+    if(raw)
+    {
+      set_last_error("blend: the details threshold in the raw colourspace is not built");
+      return DT_HIP_INVALID_ARG;
+    }
+    refined = (float *)dt_hip_alloc_device_buffer(devid, (size_t)a.owidth * a.oheight * sizeof(float));
+    if(!refined) return DT_HIP_SYSMEM_ALLOCATION;
+    const int rerr = detail_refine_launch(devid, (const float *)d->detail_mask, form, seed, d->details, a.owidth, a.oheight, refined);
+    if(rerr != DT_HIP_SUCCESS)
+    {
+      dt_hip_release_mem_object(refined);
+      return rerr;
+    }
+    form = refined;
+  }
   int form_kind = 0; // form_mask_kernel: 0 = no form plane involved
   if(raster_only)
     form_kind = 4;
@@ -985,6 +1010,7 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     // its input there
     set_last_error("blend: feathering guided by the module's input needs roi_in == roi_out (the reference reads outside "
                    "its input otherwise)");
+    if(refined) dt_hip_release_mem_object(refined);
     return DT_HIP_INVALID_ARG;
   }
   const bool spatial = blur || feather;
@@ -1000,6 +1026,7 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     {
       if(plane) dt_hip_release_mem_object(plane);
       if(scratch) dt_hip_release_mem_object(scratch);
+      if(refined) dt_hip_release_mem_object(refined);
       return DT_HIP_SYSMEM_ALLOCATION;
     }
   }
@@ -1045,6 +1072,7 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
   auto release_planes = [&]() {
     if(plane) dt_hip_release_mem_object(plane);   // stream-ordered: re-used only by later launches
     if(scratch) dt_hip_release_mem_object(scratch);
+    if(refined) dt_hip_release_mem_object(refined);
   };
   if(raw)
   {

@@ -144,6 +144,9 @@ void denoiseprofile_band_abort(dn_band_job_t *job);
 // guided by width x height float4 pixels
 int guided_filter_launch(int devid, const float4 *guide, float *mask, int width, int height, int w, float sqrt_eps,
                          float guide_weight, float minv, float maxv);
+// detailmask.hip: the refinement a blend's details threshold applies to its form mask (`form` NULL: the constant `fill`)
+int detail_refine_launch(int devid, const float *rawdetail, const float *form, float fill, float level, int width, int height,
+                         float *refined);
 // local contrast (bilateral grid) on row bands: the grid is one accumulation over the frame in pixel order, so the bands
 // take turns (bilat.hip).  begin: the zeroed grid of the frame; splat: the band's rows on top of what the grid holds;
 // finish: blur of the complete grid (this band's copy) and the slice of the band's rows

@@ -50,6 +50,7 @@ enum op_t
   OP_BLEND,
   OP_EXPORT_ROWS,
   OP_EXPORT_U8,
+  OP_DETAILMASK,
   OP_UNKNOWN
 };
 
@@ -82,6 +83,7 @@ const op_info_t k_ops[] = {
   { "blend", sizeof(dt_hip_blend_data_t), 0 },
   { "export_rows", sizeof(dt_hip_export_rows_t), 0 },
   { "export_u8", 0, 4 },
+  { "detailmask", sizeof(dt_hip_detailmask_data_t), 16 },
 };
 
 struct node_t
@@ -138,6 +140,7 @@ int run_single(int devid, const node_t &n, dt_hip_mem_t in, dt_hip_mem_t out)
     case OP_COLOROUT: return dt_hip_iop_colorout_process(devid, &n.piece, n.as<dt_hip_conversion_t>(), in, out);
     case OP_FINALSCALE: return dt_hip_iop_finalscale_process(devid, &n.piece, n.as<dt_hip_finalscale_data_t>(), in, out);
     case OP_INITIALSCALE: return dt_hip_iop_initialscale_process(devid, &n.piece, n.as<dt_hip_finalscale_data_t>(), in, out);
+    case OP_DETAILMASK: return dt_hip_iop_detailmask_process(devid, &n.piece, n.as<dt_hip_detailmask_data_t>(), in, out);
     case OP_EXPORT_U16: return dt_hip_export_convert_u16(devid, n.piece.roi_out.width, n.piece.roi_out.height, in, out);
     case OP_EXPORT_U8: return dt_hip_export_convert_u8(devid, n.piece.roi_out.width, n.piece.roi_out.height, in, out);
     case OP_EXPORT_ROWS:
@@ -716,6 +719,14 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
     {
       // the bilateral grid is relayed from band to band; the local laplacian's pyramid is not
       set_last_error("band mode: local contrast runs on row bands in its bilateral-grid mode only");
+      return DT_HIP_INVALID_ARG;
+    }
+    if(n.op == OP_DETAILMASK
+       || (n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->details != 0.0f && n.as<dt_hip_blend_data_t>()->detail_mask))
+    {
+      // the raw detail mask is one plane of the frame on one device; its 9 x 9 blur reads across band borders
+      set_last_error("band mode: the detail mask (the \"detailmask\" stage, a blend's details threshold) has no row-band "
+                     "implementation");
       return DT_HIP_INVALID_ARG;
     }
     if(n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->feathering_radius > 0.1f)

@@ -841,6 +841,7 @@ size_t dt_hip_abi_sizeof(const char *name)
   S("bilat", dt_hip_bilat_data_t);
   S("finalscale", dt_hip_finalscale_data_t);
   S("blend", dt_hip_blend_data_t);
+  S("detailmask", dt_hip_detailmask_data_t);
   S("export_rows", dt_hip_export_rows_t);
   S("tile_plan", dt_hip_tile_plan_t);
   S("band", dt_hip_band_t);

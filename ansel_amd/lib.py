@@ -113,6 +113,7 @@ def load():
         "dt_hip_iop_diffuse_process": (i, [i, P(abi.Piece), P(abi.DiffuseData), vp, vp]),
         "dt_hip_iop_denoiseprofile_process": (i, [i, P(abi.Piece), P(abi.DenoiseprofileData), vp, vp]),
         "dt_hip_iop_nlmeans_process": (i, [i, P(abi.Piece), P(abi.NlmeansData), vp, vp]),
+        "dt_hip_iop_detailmask_process": (i, [i, P(abi.Piece), P(abi.DetailmaskData), vp, vp]),
         "dt_hip_transform_rgb_to_lab": (i, [i, P(abi.Piece), P(abi.LabData), vp, vp]),
         "dt_hip_transform_lab_to_rgb": (i, [i, P(abi.Piece), P(abi.LabData), vp, vp]),
         "dt_hip_iop_bilat_process": (i, [i, P(abi.Piece), P(abi.BilatData), vp, vp]),

@@ -623,8 +623,9 @@ int dt_hip_raw_unpack(int devid, dt_hip_mem_t dev_packed, int width, int height,
  * Feathering (blend.c:603-623, :825-852): the guided filter of src/pixel/guided_filter.c over the mask, guided by the
  * module's input or output (feathering_guide), before or after the blur as _develop_mask_get_post_operations() orders
  * them (blend.c:427-469) -- its 512-pixel tile grid and Kahan box means reproduced, bit-identical to the CPU path.
- * Refused with DT_HIP_INVALID_ARG (never approximated): GUI mask display, and a drawn / raster mask mode or a details
- * threshold WITHOUT the plane. */
+ * The details threshold (blend.c:361-425) runs on the device when the raw detail mask is at hand (`detail_mask`).
+ * Refused with DT_HIP_INVALID_ARG (never approximated): GUI mask display, a drawn / raster mask mode without the plane,
+ * a details threshold with neither the raw detail mask nor a plane refined by the host. */
 #define DT_HIP_BLEND_CS_RAW 1 /* dt_develop_blend_colorspace_t, blend.h:51-58 */
 #define DT_HIP_BLEND_CS_LAB 2
 #define DT_HIP_BLEND_CS_RGB_DISPLAY 3
@@ -650,8 +651,7 @@ typedef struct dt_hip_blend_data_t
   float opacity;          /* 0 .. 100 */
   uint32_t mask_combine;  /* DT_HIP_COMBINE_* bits */
   uint32_t blendif;       /* bit i: channel i active; bit 16 + i: channel i inverted (blend.h:141-197) */
-  float feathering_radius, blur_radius, details; /* details is applied by the host to form_mask before the upload, as in
-                                                    the reference */
+  float feathering_radius, blur_radius, details; /* details: see detail_mask */
   float contrast, brightness;                    /* mask tone curve */
   float blendif_parameters[4 * DT_HIP_BLENDIF_SIZE];
   float blendif_boost_factors[DT_HIP_BLENDIF_SIZE];
@@ -660,10 +660,31 @@ typedef struct dt_hip_blend_data_t
                              (dt_hip_copy_host_to_device(devid, mask, width, height, 4)); required when mask_mode has
                              DT_HIP_MASK_SHAPE / _RASTER or details != 0 */
   uint32_t feathering_guide; /* DT_HIP_MASK_GUIDE_*; read when feathering_radius > 0.1 */
+  dt_hip_mem_t detail_mask;  /* NULL, or the raw detail mask of the hidden "detailmask" stage (dt_hip_iop_detailmask_process):
+                                roi_out.width x roi_out.height floats on the device.  With details != 0 the blend then
+                                refines the form mask itself, _refine_with_detail_mask() (blend.c:361-425, :789): the
+                                sigmoid of dt_masks_calc_detail_mask() around the threshold, its 9 x 9 blur, times the
+                                form mask (or the neutral fill of a parametric-only blend).  The mask must have the
+                                geometry of roi_out (no distorting module between the two stages: the warp of
+                                dt_dev_distort_detail_mask() is not built).  NULL with details != 0: form_mask is taken as
+                                already refined by the host */
 } dt_hip_blend_data_t;
 /* dev_in: the module's input, roi_in; dev_out: the module's output, roi_out, blended in place */
 int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d,
                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+
+/* The hidden "detailmask" stage behind demosaic (src/iop/detailmask.c:111-170): copies its input and leaves the raw
+ * detail mask of dt_masks_calc_rawdetail_mask() (src/develop/masks/detail.c:283-316) -- the Scharr gradient magnitude of
+ * sqrt(mean of the white-balance-normalised, clipped-at-0 RGB), borders extended by one -- in `mask`
+ * (roi_out.width x roi_out.height floats on the device, the caller's buffer).  wb: piece->dsc_in.temperature.coeffs when
+ * the white balance is enabled, else 1, 1, 1.  Frames below 3 x 3 are refused. */
+typedef struct dt_hip_detailmask_data_t
+{
+  float wb[4];
+  dt_hip_mem_t mask;
+} dt_hip_detailmask_data_t;
+int dt_hip_iop_detailmask_process(int devid, const dt_hip_piece_t *piece, const dt_hip_detailmask_data_t *d,
+                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
 
 /* ---- 3. export-pipe executor ----------------------------------------------------------- */
 /* The device-resident part of dt_dev_pixelpipe_process_rec() (src/develop/pixelpipe_hb.c:881-1282)

@@ -30,7 +30,9 @@ $X $R/develop/blend.h $G/blend_h.inc dt_develop_blend_colorspace_t dt_develop_bl
   DEVELOP_BLENDIF_PARAMETER_ITEMS
 $X $R/develop/blend.c $G/blend_c.inc dt_develop_blendif_process_parameters dt_develop_blendif_init_masking_profile \
   _develop_blend_process_mask_tone_curve _develop_mask_post_processing _develop_mask_get_post_operations \
-  _develop_blend_process_feather
+  _develop_blend_process_feather _detail_mask_threshold
+$X $R/develop/masks/detail.c $G/masks_detail.inc dt_masks_extend_border dt_masks_blur_9x9_coeff FAST_BLUR_9 dt_masks_blur_9x9 \
+  dt_masks_calc_rawdetail_mask calcBlendFactor dt_masks_calc_detail_mask
 $X $R/develop/blends/blendif_rgb_jzczhz.c $G/blendif_rgb_jzczhz.inc DT_BLENDIF_RGB_CH DT_BLENDIF_RGB_BCH \
   _blendif_compute_factor _blendif_gray _blendif_rgb_red _blendif_rgb_green _blendif_rgb_blue _blendif_jzczhz \
   _blendif_combine_channels dt_develop_blendif_rgb_jzczhz_make_mask _blend_normal _blend_multiply _blend_add _blend_subtract \

@@ -88,6 +88,23 @@ static int parametric_used(const dt_develop_blend_params_t *params)
   return active_channels != 0;
 }
 
+#include "gen/masks_detail.inc"
+
+/* the hidden stage behind demosaic, src/iop/detailmask.c:111-150 */
+int ref_detailmask(const dt_hip_piece_t *v, const dt_hip_detailmask_data_t *h, const void *in, void *out)
+{
+  ref_reset_fp_mode();
+  const int width = v->roi_out.width, height = v->roi_out.height;
+  if(!h->mask || width < 3 || height < 3) return 1;
+  memcpy(out, in, sizeof(float) * 4 * (size_t)width * height);
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)width * height);
+  if(!tmp) return 1;
+  dt_aligned_pixel_t wb = { h->wb[0], h->wb[1], h->wb[2], 1.0f };
+  dt_masks_calc_rawdetail_mask((float *)out, (float *)h->mask, tmp, width, height, wb);
+  free(tmp);
+  return 0;
+}
+
 /* `in` = the module's input (roi_in), `out` = the module's output (roi_out), blended in place */
 int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, const void *in, void *out)
 {
@@ -96,7 +113,8 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
   /* drawn / raster masks (and the details refinement of them) come rendered, as one plane: what
    * _develop_blend_init_raster_mask() / _init_drawn_mask() / _refine_with_detail_mask() leave in `mask` (blend.c:740-790) */
   const float *const form = (const float *)h->form_mask;
-  if(((h->mask_mode & (DEVELOP_MASK_SHAPE | DEVELOP_MASK_RASTER)) || h->details != 0.f) && !form) return -1;
+  if((h->mask_mode & (DEVELOP_MASK_SHAPE | DEVELOP_MASK_RASTER)) && !form) return -1;
+  if(h->details != 0.f && !form && !h->detail_mask) return -1;
   if(form && h->blend_cst == DEVELOP_BLEND_CS_RAW) return -1;
   dt_develop_blend_params_t d;
   memset(&d, 0, sizeof(d));
@@ -167,6 +185,20 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
     {
       const float fill = (d.mask_combine & DEVELOP_COMBINE_INCL) ? 0.0f : 1.0f;
       dt_iop_image_fill(mask, fill, owidth, oheight, 1);
+    }
+    if(h->details != 0.f && h->detail_mask)
+    {
+      /* _refine_with_detail_mask(), blend.c:361-425, with the raw detail mask in the geometry of roi_out
+       * (dt_dev_distort_detail_mask() hands `lum` back unchanged then) */
+      const int detail = (h->details > 0.0f);
+      const float threshold = _detail_mask_threshold(h->details, detail);
+      float *tmp = dt_pixelpipe_cache_alloc_align_float(buffsize, &pipe);
+      float *lum = dt_pixelpipe_cache_alloc_align_float(buffsize, &pipe);
+      if(!tmp || !lum) return 1;
+      dt_masks_calc_detail_mask((float *)h->detail_mask, lum, tmp, owidth, oheight, threshold, detail);
+      for(size_t idx = 0; idx < buffsize; idx++) mask[idx] = mask[idx] * lum[idx];
+      dt_pixelpipe_cache_free_align(tmp);
+      dt_pixelpipe_cache_free_align(lum);
     }
     if(d.blend_cst == DEVELOP_BLEND_CS_LAB)
       dt_develop_blendif_lab_make_mask(&piece, (const float *)in, (const float *)out, mask);

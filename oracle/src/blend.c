@@ -815,8 +815,10 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   if((d->blend_cst != DT_HIP_BLEND_CS_RGB_SCENE && !lab && !display) || piece->channels != 4) return 1;
   /* drawn / raster masks and the details threshold: rendered and refined by the host into ONE plane, as the reference's
    * device blend receives them (blend.c:1278-1325) */
-  if(((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) || d->details != 0.f) && !d->form_mask) return 1;
-  const float *const form = (const float *)d->form_mask;
+  if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) && !d->form_mask) return 1;
+  if(d->details != 0.f && !d->form_mask && !d->detail_mask) return 1;
+  const float *form = (const float *)d->form_mask;
+  float *refined = NULL;
   if(lab && !lab_mode_supported(d->blend_mode & 0xFFu)) return 1;
   const unsigned CH_MASK = lab ? LAB_MASK : RGB_MASK;
   if(!(d->mask_mode & DT_HIP_MASK_ENABLED)) return 0;
@@ -853,6 +855,17 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   /* blend.c:732-745: a raster mask alone is form * opacity, no make_mask(), no post operations */
   const int raster_only = form && (d->mask_mode & DT_HIP_MASK_RASTER) && !(d->mask_mode & DT_HIP_MASK_SHAPE) && !parametric;
   const int use_masks = form || parametric;
+  if(d->details != 0.f && d->detail_mask && use_masks && !raster_only)
+  {
+    /* _refine_with_detail_mask(), blend.c:361-425 (:789): the form mask -- or the neutral fill of a parametric-only
+     * blend, :749-757 -- times the blurred sigmoid of the raw detail mask (same geometry: nothing to warp) */
+    const size_t n = (size_t)owidth * oheight;
+    refined = (float *)malloc(sizeof(float) * n);
+    if(!refined) return 1;
+    oracle_detail_mask((const float *)d->detail_mask, refined, owidth, oheight, d->details);
+    for(size_t k = 0; k < n; k++) refined[k] = (form ? form[k] : seed) * refined[k];
+    form = refined;
+  }
   int kind; /* 0 uniform, 1 constant after make_mask, 2 per pixel, 3 unconditional on a form plane, 4 raster only */
   float constant = opacity;
   if(!use_masks) kind = 0;
@@ -931,7 +944,11 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   if(spatial)
   {
     plane = (float *)malloc(sizeof(float) * (size_t)owidth * oheight);
-    if(!plane) return 1;
+    if(!plane)
+    {
+      free(refined);
+      return 1;
+    }
   }
   for(int pass = spatial ? 0 : 1; pass < 2; pass++)
   {
@@ -969,6 +986,7 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
         if(err)
         {
           free(plane);
+          free(refined);
           return 1;
         }
       }
@@ -1025,5 +1043,6 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
     }
   }
   free(plane);
+  free(refined);
   return 0;
 }

@@ -319,3 +319,42 @@ def form_cases(blend_cst=abi.BLEND_CS_RGB_SCENE):
     d.details = -0.3  # a parametric-only mask refined by the detail mask: the host supplies the refined fill
     out.append(("parametric-details", d))
     return out
+
+
+def detail_cases(blend_cst=abi.BLEND_CS_RGB_SCENE):
+    """(name, BlendData, needs a form plane): a details threshold refined on the spot from the raw detail mask
+    (_refine_with_detail_mask(), blend.c:361-425): positive (keep detail) and negative (keep flat areas) levels, on a
+    drawn mask, on a parametric-only mask with either combine mode, with post operations behind it"""
+    lab = blend_cst == abi.BLEND_CS_LAB
+    ch_in = abi.BLENDIF_L_in if lab else abi.BLENDIF_GRAY_in
+    out = []
+
+    def base(opacity=80.0):
+        return abi.BlendData.uniform(M, opacity, abi.BLEND_NORMAL, blend_cst=blend_cst)
+
+    for level in (0.35, -0.5, 1.0, -1.0):
+        d = base()
+        d.mask_mode |= abi.MASK_SHAPE
+        d.details = level
+        out.append(("drawn-details%+.2f" % level, d, True))
+    for combine in (0, abi.COMBINE_INV, abi.COMBINE_INCL):
+        d = base(70.0)
+        d.channel(ch_in, 0.05, 0.3, 0.7, 0.95)
+        d.mask_combine = combine
+        d.details = 0.25
+        out.append(("parametric-details-c%d" % combine, d, False))
+    d = base(90.0)
+    d.mask_mode |= abi.MASK_SHAPE
+    d.channel(ch_in, 0.0, 0.2, 0.8, 1.0)
+    d.details = -0.2
+    d.blur_radius = 3.0
+    d.contrast = 0.3
+    out.append(("drawn+parametric-details-blurred-toned", d, True))
+    d = base(60.0)
+    d.mask_mode |= abi.MASK_RASTER  # a raster mask alone is form * opacity: no refinement (blend.c:740-745)
+    d.details = 0.5
+    out.append(("raster-only-details-ignored", d, True))
+    d = base(60.0)
+    d.details = 0.5  # no mask at all: uniform opacity, no refinement (blend.c:735-739)
+    out.append(("uniform-details-ignored", d, False))
+    return out

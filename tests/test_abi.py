@@ -34,7 +34,7 @@ def test_ctypes_mirror_covers_the_header():
     ("roi", abi.Roi), ("piece", abi.Piece), ("tiling", abi.Tiling), ("rawprepare", abi.RawprepareData),
     ("temperature", abi.TemperatureData), ("highlights", abi.HighlightsData), ("demosaic", abi.DemosaicData),
     ("exposure", abi.ExposureData), ("conversion", abi.Conversion), ("channelmixerrgb", abi.ChannelmixerrgbData),
-    ("filmic_spline", abi.FilmicSpline), ("filmicrgb", abi.FilmicrgbData), ("diffuse", abi.DiffuseData), ("denoiseprofile", abi.DenoiseprofileData), ("nlmeans", abi.NlmeansData), ("lab", abi.LabData), ("bilat", abi.BilatData), ("finalscale", abi.FinalscaleData), ("blend", abi.BlendData), ("export_rows", abi.ExportRowsData), ("tile_plan", abi.TilePlan), ("band", abi.Band),
+    ("filmic_spline", abi.FilmicSpline), ("filmicrgb", abi.FilmicrgbData), ("diffuse", abi.DiffuseData), ("denoiseprofile", abi.DenoiseprofileData), ("nlmeans", abi.NlmeansData), ("lab", abi.LabData), ("bilat", abi.BilatData), ("finalscale", abi.FinalscaleData), ("blend", abi.BlendData), ("detailmask", abi.DetailmaskData), ("export_rows", abi.ExportRowsData), ("tile_plan", abi.TilePlan), ("band", abi.Band),
     ("band_state", abi.BandState)])
 def test_struct_sizes_match_the_compiled_library(name, ctype):
     l = lib.load()

@@ -219,3 +219,85 @@ def test_feathering_guided_by_a_larger_input_is_refused():
     assert b"roi_in == roi_out" in l.dt_hip_last_error()
     d.feathering_guide = abi.MASK_GUIDE_OUT_AFTER_BLUR  # guided by the output: any roi
     _check(piece, d, a, b, "feathering guided by the output under a roi offset")
+
+
+# ---- the details threshold on the device: the hidden "detailmask" stage and _refine_with_detail_mask() ---------------
+@pytest.mark.parametrize("w,h,wb", [(1200, 801, (2.1, 1.0, 1.6)), (37, 23, (1.0, 1.0, 1.0)), (9, 9, (1.7, 1.0, 1.2)), (3, 3, (1.0, 1.0, 1.0))])
+def test_detailmask_stage(w, h, wb):
+    """src/iop/detailmask.c: the input copied, the raw detail mask (dt_masks_calc_rawdetail_mask) in the side-band plane;
+    device == oracle == reference, negative and non-finite samples included"""
+    from ansel_amd import synth
+    img = synth.rgba_image(w, h, seed=8, lo=-0.05, hi=1.4)
+    if w > 10:
+        img[3, 4, 0] = np.nan
+        img[5, 6, 1] = np.inf
+        img[7, 2, 2] = -3.0
+    piece = abi.Piece.make(w, h)
+    dplane = lib.DeviceBuffer.from_numpy(0, np.full((h, w), -9.0, np.float32))
+    got = hc.run_hip("dt_hip_iop_detailmask_process", piece, abi.DetailmaskData.make(wb, dplane.ptr), img, img.shape)
+    assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
+    plane = dplane.to_numpy((h, w), np.float32)
+    for which in hc.checkers_available():
+        want = ck.aligned_empty((h, w), np.float32)
+        l = ck.ref() if which == "ref" else ck.oracle()
+        assert ck.call(l, which + "_detailmask", piece, abi.DetailmaskData.make(wb, want.ctypes.data), img, np.zeros_like(img)) == 0
+        assert int((ck.ulp_diff(plane, want) > 0).sum()) == 0, which
+    dplane.release()
+
+
+DETAIL_CASES = [(cs, n, d, f) for cs in (abi.BLEND_CS_RGB_SCENE, abi.BLEND_CS_RGB_DISPLAY, abi.BLEND_CS_LAB)
+                for n, d, f in blend_cases.detail_cases(cs)]
+
+
+@pytest.mark.parametrize("cs,name,d,with_form", DETAIL_CASES, ids=["cs%d-%s" % (c[0], c[1]) for c in DETAIL_CASES])
+def test_blend_details_threshold_from_the_raw_detail_mask(cs, name, d, with_form):
+    """the stage's plane stays on the device; the blend refines its form mask with it (blend.c:361-425)"""
+    from ansel_amd import synth
+    w, h = 131, 67
+    a, b = blend_cases.lab_images(w, h, 53) if cs == abi.BLEND_CS_LAB else blend_cases.images(w, h, 44)
+    rgb = blend_cases.images(w, h, 44)[0]
+    piece = abi.Piece.make(w, h)
+    drm = lib.DeviceBuffer(0, w * h * 4)
+    hc.run_hip("dt_hip_iop_detailmask_process", piece, abi.DetailmaskData.make((2.0, 1.0, 1.5), drm.ptr), rgb, rgb.shape)
+    rm = ck.aligned_empty((h, w), np.float32)
+    rm[...] = drm.to_numpy((h, w), np.float32)
+    form = host_form = dform = None
+    if with_form:
+        form = blend_cases.form_plane(w, h)
+        dform = lib.DeviceBuffer.from_numpy(0, form)
+        host_form = ck.aligned_empty(form.shape, np.float32)
+        host_form[...] = form
+    d.detail_mask, d.form_mask = drm.ptr, (dform.ptr if with_form else None)
+    got = hc.run_hip("dt_hip_develop_blend_process", piece, d, a, b.shape, pre_fill=b)
+    d.detail_mask, d.form_mask = rm.ctypes.data, (host_form.ctypes.data if with_form else None)
+    for which in hc.checkers_available():
+        want = b.copy()
+        l = ck.ref() if which == "ref" else ck.oracle()
+        assert ck.call(l, which + "_develop_blend", piece, d, a, want) == 0
+        assert int((ck.ulp_diff(got, want) > 0).sum()) == 0, name + " vs " + which
+    drm.release()
+    if dform:
+        dform.release()
+
+
+def test_blend_details_threshold_full_frame():
+    """24 MP: the stage and a drawn + parametric mask refined by it"""
+    from ansel_amd import synth
+    w, h = 6000, 4000
+    img = synth.rgba_image(1024, 1024, seed=3, lo=0.0, hi=1.0)
+    a = np.tile(img, (4, 6, 1))[:h, :w].copy()
+    b = np.ascontiguousarray(a[::-1])
+    piece = abi.Piece.make(w, h)
+    drm = lib.DeviceBuffer(0, w * h * 4)
+    hc.run_hip("dt_hip_iop_detailmask_process", piece, abi.DetailmaskData.make((2.0, 1.0, 1.5), drm.ptr), a, a.shape)
+    rm = ck.aligned_empty((h, w), np.float32)
+    rm[...] = drm.to_numpy((h, w), np.float32)
+    d = abi.BlendData.uniform(blend_cases.M, 85.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.2, 0.6, 0.9, boost=1.0)
+    d.details = 0.3
+    d.detail_mask = drm.ptr
+    got = hc.run_hip("dt_hip_develop_blend_process", piece, d, a, b.shape, pre_fill=b)
+    d.detail_mask = rm.ctypes.data
+    want = b.copy()
+    assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, want) == 0
+    assert int((ck.ulp_diff(got, want) > 0).sum()) == 0
+    drm.release()

@@ -384,3 +384,36 @@ def test_lab_glue_with_tone_curves_runs_in_its_own_launch():
     assert ck.call(o, "oracle_exposure", rgb, host[1].data, a, b) == 0
     assert ck.call(o, "oracle_rgb_to_lab", rgb, host[2].data, b, c) == 0
     assert np.array_equal(got.view(np.uint32), c.view(np.uint32))
+
+
+def test_detailmask_stage_and_a_details_threshold_in_a_pipe():
+    """the hidden stage writes its plane while the frame goes through; a blend further down refines its mask with it"""
+    w, h = 320, 200
+    hc.hip()
+    img = synth.rgba_image(w, h, seed=6, lo=0.0, hi=1.5)
+    rgb = abi.Piece.make(w, h, channels=4)
+    d_plane = lib.DeviceBuffer(0, w * h * 4)
+    h_plane = ck.aligned_empty((h, w), np.float32)
+
+    def nodes(plane_ptr):
+        bd = abi.BlendData.uniform(params.WORK_IN, 75.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.2, 0.6, 0.9, boost=1.0)
+        bd.details = 0.3
+        bd.detail_mask = plane_ptr
+        return [pipe.Node("detailmask", abi.DetailmaskData.make((2.0, 1.0, 1.5), plane_ptr), rgb),
+                pipe.Node("exposure", abi.ExposureData(0.01, 1.7), rgb),
+                pipe.Node("blend", bd, rgb)]
+    din = lib.DeviceBuffer.from_numpy(0, img)
+    dout = lib.DeviceBuffer(0, w * h * 16)
+    p = pipe.DevicePipe(0, nodes(d_plane.ptr), fusion=True)
+    p.process(din.ptr, dout.ptr)
+    assert lib.load().dt_hip_finish(0) == 1
+    got = dout.to_numpy((h, w, 4), np.float32)
+    p.close()
+    o = ck.oracle()
+    host = nodes(h_plane.ctypes.data)
+    a, b = np.zeros_like(img), np.zeros_like(img)
+    assert ck.call(o, "oracle_detailmask", rgb, host[0].data, img, a) == 0
+    assert ck.call(o, "oracle_exposure", rgb, host[1].data, a, b) == 0
+    assert ck.call(o, "oracle_develop_blend", rgb, host[2].data, a, b) == 0
+    assert int((ck.ulp_diff(got, b) > 0).sum()) == 0
+    assert int((ck.ulp_diff(d_plane.to_numpy((h, w), np.float32), h_plane) > 0).sum()) == 0

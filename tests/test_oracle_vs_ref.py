@@ -745,3 +745,62 @@ def test_full_average_green_equilibration_with_sums_that_are_not_positive_number
     d = abi.DemosaicData(2, 0, abi.DT_HIP_DEMOSAIC_PPG, 0.0, 0.0)
     a, b = _pair("demosaic", piece, d, img, (h, w, 4))
     _exact(a, b, "favg with %r" % bad)
+
+
+@pytest.mark.parametrize("w,h,wb", [(300, 200, (2.1, 1.0, 1.6)), (37, 23, (1.0, 1.0, 1.0)), (9, 9, (1.7, 1.0, 1.2)), (3, 3, (1.0, 1.0, 1.0))])
+def test_detailmask_stage(w, h, wb):
+    """the hidden stage behind demosaic (src/iop/detailmask.c): copies its input and leaves the raw detail mask of
+    dt_masks_calc_rawdetail_mask() in the side-band plane; negative and non-finite samples included"""
+    img = synth.rgba_image(w, h, seed=8, lo=-0.05, hi=1.4)
+    if w > 10:
+        img[3, 4, 0] = np.nan
+        img[5, 6, 1] = np.inf
+        img[7, 2, 2] = -3.0
+    piece = abi.Piece.make(w, h)
+    planes = []
+    outs = []
+    for which in ("ref", "oracle"):
+        plane = ck.aligned_empty((h, w), np.float32)
+        plane[...] = -9.0
+        out = np.zeros_like(img)
+        l = ck.ref() if which == "ref" else ck.oracle()
+        assert ck.call(l, which + "_detailmask", piece, abi.DetailmaskData.make(wb, plane.ctypes.data), img, out) == 0
+        planes.append(plane)
+        outs.append(out)
+    assert np.array_equal(outs[0].view(np.uint32), img.view(np.uint32)) and np.array_equal(outs[1].view(np.uint32), img.view(np.uint32))
+    _exact(planes[0], planes[1], "raw detail mask")
+    assert float(np.nanmax(planes[1])) > 0.0
+
+
+DETAIL_CASES = [(cs, n, d, f) for cs in (abi.BLEND_CS_RGB_SCENE, abi.BLEND_CS_RGB_DISPLAY, abi.BLEND_CS_LAB)
+                for n, d, f in blend_cases.detail_cases(cs)]
+
+
+@pytest.mark.parametrize("cs,name,d,with_form", DETAIL_CASES, ids=["cs%d-%s" % (c[0], c[1]) for c in DETAIL_CASES])
+def test_develop_blend_details_threshold_from_the_raw_detail_mask(cs, name, d, with_form):
+    """_refine_with_detail_mask() (blend.c:361-425): sigmoid of the raw detail mask around the threshold, 9 x 9 blur,
+    times the form mask or the neutral fill of a parametric-only blend"""
+    w, h = 131, 67
+    a, b = blend_cases.lab_images(w, h, 53) if cs == abi.BLEND_CS_LAB else blend_cases.images(w, h, 44)
+    rgb = blend_cases.images(w, h, 44)[0]
+    rm = ck.aligned_empty((h, w), np.float32)
+    assert ck.call(ck.oracle(), "oracle_detailmask", abi.Piece.make(w, h), abi.DetailmaskData.make((2.0, 1.0, 1.5), rm.ctypes.data),
+                   rgb, np.zeros_like(rgb)) == 0
+    rm[2, 3] = np.nan
+    rm[4, 5] = np.inf
+    d.detail_mask = rm.ctypes.data
+    if with_form:
+        form = ck.aligned_empty((h, w), np.float32)
+        form[...] = blend_cases.form_plane(w, h)
+        d.form_mask = form.ctypes.data
+    piece = abi.Piece.make(w, h)
+    x, y = b.copy(), b.copy()
+    assert ck.call(ck.ref(), "ref_develop_blend", piece, d, a, x) == 0
+    assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, y) == 0
+    _exact(x, y, "blend with a details threshold, " + name)
+    if "ignored" not in name and name != "parametric-details-c2":  # inclusive combine: the neutral fill is 0, times anything
+        d.detail_mask = None
+        d.details = 0.0
+        z = b.copy()
+        assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, z) == 0
+        assert not np.array_equal(z.view(np.uint32), y.view(np.uint32))  # the refinement did something
