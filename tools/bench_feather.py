@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time the blend stage with mask feathering (the guided filter) and with a mask blur on a 24 MP frame (run on the GPU box).
+"""Time the blend stage with mask feathering (the guided filter), with a mask blur and with a details threshold on a 24 MP
+frame (run on the GPU box).
 
     python tools/bench_feather.py [radius]"""
 import ctypes as C
@@ -24,9 +25,14 @@ def main():
     da, db = lib.DeviceBuffer.from_numpy(0, a), lib.DeviceBuffer.from_numpy(0, b)
     piece = abi.Piece.make(w, h)
     d = abi.BlendData.uniform(params.WORK_IN, 80.0).channel(abi.BLENDIF_GRAY_in, 0.05, 0.2, 0.6, 0.9, boost=1.0)
-    for label, r, blur in (("parametric mask only", 0.0, 0.0), ("+ feathering radius %g" % radius, radius, 0.0),
-                           ("+ mask blur radius %g" % radius, 0.0, radius)):
+    rm = lib.DeviceBuffer(0, w * h * 4)
+    scratch = lib.DeviceBuffer(0, w * h * 16)
+    lib.check(l.dt_hip_iop_detailmask_process(0, C.byref(piece), C.byref(abi.DetailmaskData.make((2.0, 1.0, 1.5), rm.ptr)),
+                                              da.ptr, scratch.ptr), "detailmask")
+    for label, r, blur, details in (("parametric mask only", 0.0, 0.0, 0.0), ("+ feathering radius %g" % radius, radius, 0.0, 0.0),
+                                    ("+ mask blur radius %g" % radius, 0.0, radius, 0.0), ("+ details threshold 0.3", 0.0, 0.0, 0.3)):
         d.feathering_radius, d.feathering_guide, d.blur_radius = r, abi.MASK_GUIDE_OUT_AFTER_BLUR, blur
+        d.details, d.detail_mask = details, (rm.ptr if details else None)
         l.dt_hip_events_reset(0)
         l.dt_hip_events_enable(0, 1)
         ts = []
