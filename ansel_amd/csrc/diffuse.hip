@@ -164,6 +164,20 @@ __device__ __forceinline__ float pde_channel(const float H[9], const float L[9],
   return max_zero(acc + L[4]);
 }
 
+// The fourth channel is a channel like the others to the reference (it loops over four), and in a pipe it is all +0 where
+// this module runs: colorin's matrix leaves 0 x + 0 y + 0 z there.  With +0 in all 18 samples of a support the update is
+// +0 whatever the parameters are -- every squared ratio is +0 / 1e-8, the gradients are +0 (direction (1, 0), magnitude 0),
+// each convolution adds +-0 products onto +0, update / energy is +-0 or NaN and max_zero(that + +0) is +0 either way -- so a
+// wave whose lanes all see that (one ballot) skips the channel: a quarter of the kernel's arithmetic.  Any other bit
+// pattern, -0 included, takes the full path.
+__device__ __forceinline__ bool alpha_is_blank(const float4 H4[9], const float4 L4[9])
+{
+  unsigned bits = 0;
+#pragma unroll
+  for(int k = 0; k < 9; k++) bits |= __float_as_uint(H4[k].w) | __float_as_uint(L4[k].w);
+  return __builtin_amdgcn_ballot_w64(bits != 0) == 0ull;
+}
+
 // SHARED (dilations up to PDE_SHARED_MULT, where the three column sets of a 256-pixel segment overlap): every thread
 // squares the ratios of the CENTRE column of its support -- three samples it has fetched anyway -- into LDS, the first
 // and last `mult` threads also those of their left / right column, and the nine ratios of a support are read back
@@ -273,9 +287,14 @@ __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf
 #pragma unroll
   for(int k = 0; k < 9; k++) { H[k] = H4[k].z; L[k] = L4[k].z; }
   o.z = pde_channel(H, L, energy.z, a);
+  if(alpha_is_blank(H4, L4))
+    o.w = 0.0f;
+  else
+  {
 #pragma unroll
-  for(int k = 0; k < 9; k++) { H[k] = H4[k].w; L[k] = L4[k].w; }
-  o.w = pde_channel(H, L, energy.w, a);
+    for(int k = 0; k < 9; k++) { H[k] = H4[k].w; L[k] = L4[k].w; }
+    o.w = pde_channel(H, L, energy.w, a);
+  }
   const size_t idx = rows[1] + col;
   if(final_pass) nt_store(out + idx, o);
   else out[idx] = o;
@@ -391,9 +410,14 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
 #pragma unroll
       for(int k = 0; k < 9; k++) { H[k] = H4[k].z; L[k] = L4[k].z; }
       o.z = pde_channel(H, L, energy.z, a);
+      if(alpha_is_blank(H4, L4))
+        o.w = 0.0f;
+      else
+      {
 #pragma unroll
-      for(int k = 0; k < 9; k++) { H[k] = H4[k].w; L[k] = L4[k].w; }
-      o.w = pde_channel(H, L, energy.w, a);
+        for(int k = 0; k < 9; k++) { H[k] = H4[k].w; L[k] = L4[k].w; }
+        o.w = pde_channel(H, L, energy.w, a);
+      }
     }
     if(a.post_lab) o = px_rgb_to_lab(o, a.post_m);
     if(final_pass) nt_store(out + idx, o);
