@@ -149,9 +149,12 @@ __device__ __forceinline__ float pde_channel(const float H[9], const float L[9],
 {
   // HF/LF energy over the 3x3 support, diffuse.c:823-845
   energy = max_zero(a.variance_threshold + energy * a.regularization - 1e-8f) + 1e-8f;
-  float cos2g, sin2g, csg, cos2l, sin2l, csl;
-  const float mg = direction((L[7] - L[1]) * 0.5f, (L[5] - L[3]) * 0.5f, cos2g, sin2g, csg);
-  const float ml = direction((H[7] - H[1]) * 0.5f, (H[5] - H[3]) * 0.5f, cos2l, sin2l, csl);
+  // the direction of the low-frequency gradient steers orders 1 and 3, that of the high-frequency one orders 2 and 4; an
+  // isotropic order (anisotropy 0, the module's default for all four) reads neither the angle nor the magnitude, so a
+  // direction nobody reads is not computed (uniform branches: the kinds are parameters)
+  float cos2g = 0.f, sin2g = 0.f, csg = 0.f, cos2l = 0.f, sin2l = 0.f, csl = 0.f, mg = 0.f, ml = 0.f;
+  if(a.kind[0] | a.kind[2]) mg = direction((L[7] - L[1]) * 0.5f, (L[5] - L[3]) * 0.5f, cos2g, sin2g, csg);
+  if(a.kind[1] | a.kind[3]) ml = direction((H[7] - H[1]) * 0.5f, (H[5] - H[3]) * 0.5f, cos2l, sin2l, csl);
   const float d0 = convolve(a.kind[0], fast_expf(-mg * a.anisotropy[0]), csg, cos2g, sin2g, L);
   const float d1 = convolve(a.kind[1], fast_expf(-ml * a.anisotropy[1]), csl, cos2l, sin2l, L);
   const float d2 = convolve(a.kind[2], fast_expf(-mg * a.anisotropy[2]), csg, cos2g, sin2g, H);
