@@ -804,3 +804,18 @@ def test_develop_blend_details_threshold_from_the_raw_detail_mask(cs, name, d, w
         z = b.copy()
         assert ck.call(ck.oracle(), "oracle_develop_blend", piece, d, a, z) == 0
         assert not np.array_equal(z.view(np.uint32), y.view(np.uint32))  # the refinement did something
+
+
+@pytest.mark.parametrize("preset,over", [("default", {}), ("lens_deblur_soft", dict(iterations=2)),
+                                         ("lens_deblur_soft", dict(iterations=1, anisotropy_second=-3.0, anisotropy_fourth=1.5,
+                                                                   variance_threshold=-0.5, regularization=2.5)),
+                                         ("fast_local_contrast", {}), ("inpaint_highlights", dict(iterations=2, threshold=0.6))])
+def test_diffuse_leaves_a_blank_fourth_channel_blank(preset, over):
+    """what the device's shortcut rests on (diffuse.hip, alpha_is_blank): with +0 in the fourth channel of the input the
+    reference's four-channel update leaves +0 there, whatever the parameters -- checked on the reference's own code"""
+    w, h = 160, 120
+    img = synth.rgba_image(w, h, seed=12, lo=-0.02, hi=1.5)
+    assert not img[..., 3].any()
+    a, b = _pair("diffuse", abi.Piece.make(w, h), params.diffuse(preset, **over), img, img.shape)
+    for out in (a, b):
+        assert np.array_equal(out[..., 3].view(np.uint32), np.zeros((h, w), np.uint32))
