@@ -76,33 +76,49 @@ struct blur_args
   float c[13]; // dt_masks_blur_9x9_coeff(): by (|dy|, |dx|) 00 10 11 20 21 22 30 31 32 33 40 41 42
 };
 
-// FAST_BLUR_9 (detail.c:205-218) at the clamped position, clipped to [0, 1], times the form mask (or `fill`): the refined
-// form mask of _refine_with_detail_mask().  The samples of a weight are added in the reference's order, the thirteen
-// products from the widest ring inwards.
+// The 9 x 9 blur of dt_masks_blur_9x9() (detail.c:224-243) at the clamped position, clipped to [0, 1], times the form
+// mask (or `fill`): the refined form mask of _refine_with_detail_mask().  The kernel has thirteen distinct weights, one
+// per ring of samples at the same (|dy|, |dx|); the reference adds the samples of a ring in a fixed order, multiplies the
+// sum by the ring's weight and adds the thirteen products from the widest ring inwards.  RING[] lists the rings in that
+// order, each with its samples' (dy, dx) in the order they are added; the loops unroll into straight-line code.
+struct ring_t
+{
+  int weight, n;       // index into blur_args::c, number of samples
+  signed char at[8][2]; // (dy, dx)
+};
+__device__ constexpr ring_t RING[13] = {
+  { 12, 8, { { -4, -2 }, { -4, 2 }, { -2, -4 }, { -2, 4 }, { 2, -4 }, { 2, 4 }, { 4, -2 }, { 4, 2 } } },
+  { 11, 8, { { -4, -1 }, { -4, 1 }, { -1, -4 }, { -1, 4 }, { 1, -4 }, { 1, 4 }, { 4, -1 }, { 4, 1 } } },
+  { 10, 4, { { -4, 0 }, { 0, -4 }, { 0, 4 }, { 4, 0 } } },
+  { 9, 4, { { -3, -3 }, { -3, 3 }, { 3, -3 }, { 3, 3 } } },
+  { 8, 8, { { -3, -2 }, { -3, 2 }, { -2, -3 }, { -2, 3 }, { 2, -3 }, { 2, 3 }, { 3, -2 }, { 3, 2 } } },
+  { 7, 8, { { -3, -1 }, { -3, 1 }, { -1, -3 }, { -1, 3 }, { 1, -3 }, { 1, 3 }, { 3, -1 }, { 3, 1 } } },
+  { 6, 4, { { -3, 0 }, { 0, -3 }, { 0, 3 }, { 3, 0 } } },
+  { 5, 4, { { -2, -2 }, { -2, 2 }, { 2, -2 }, { 2, 2 } } },
+  { 4, 8, { { -2, -1 }, { -2, 1 }, { -1, -2 }, { -1, 2 }, { 1, -2 }, { 1, 2 }, { 2, -1 }, { 2, 1 } } },
+  { 3, 4, { { -2, 0 }, { 0, -2 }, { 0, 2 }, { 2, 0 } } },
+  { 2, 4, { { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } } },
+  { 1, 4, { { -1, 0 }, { 0, -1 }, { 0, 1 }, { 1, 0 } } },
+  { 0, 1, { { 0, 0 } } },
+};
+
 __global__ __launch_bounds__(256) void detail_refine(const float *__restrict__ src, const float *__restrict__ form,
                                                      float *__restrict__ out, const int width, const int height, const float fill,
                                                      const blur_args a)
 {
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), row = blockIdx.y * 4 + (threadIdx.x >> 6);
   if(col >= width || row >= height) return;
-  const int w1 = width, w2 = 2 * width, w3 = 3 * width, w4 = 4 * width;
   const float *const s = src + (size_t)inner(row, 4, height) * width + inner(col, 4, width);
-#define S(o) s[(o)]
-  const float v
-      = a.c[12] * (S(-w4 - 2) + S(-w4 + 2) + S(-w2 - 4) + S(-w2 + 4) + S(w2 - 4) + S(w2 + 4) + S(w4 - 2) + S(w4 + 2))
-        + a.c[11] * (S(-w4 - 1) + S(-w4 + 1) + S(-w1 - 4) + S(-w1 + 4) + S(w1 - 4) + S(w1 + 4) + S(w4 - 1) + S(w4 + 1))
-        + a.c[10] * (S(-w4) + S(-4) + S(4) + S(w4))
-        + a.c[9] * (S(-w3 - 3) + S(-w3 + 3) + S(w3 - 3) + S(w3 + 3))
-        + a.c[8] * (S(-w3 - 2) + S(-w3 + 2) + S(-w2 - 3) + S(-w2 + 3) + S(w2 - 3) + S(w2 + 3) + S(w3 - 2) + S(w3 + 2))
-        + a.c[7] * (S(-w3 - 1) + S(-w3 + 1) + S(-w1 - 3) + S(-w1 + 3) + S(w1 - 3) + S(w1 + 3) + S(w3 - 1) + S(w3 + 1))
-        + a.c[6] * (S(-w3) + S(-3) + S(3) + S(w3))
-        + a.c[5] * (S(-w2 - 2) + S(-w2 + 2) + S(w2 - 2) + S(w2 + 2))
-        + a.c[4] * (S(-w2 - 1) + S(-w2 + 1) + S(-w1 - 2) + S(-w1 + 2) + S(w1 - 2) + S(w1 + 2) + S(w2 - 1) + S(w2 + 1))
-        + a.c[3] * (S(-w2) + S(-2) + S(2) + S(w2))
-        + a.c[2] * (S(-w1 - 1) + S(-w1 + 1) + S(w1 - 1) + S(w1 + 1))
-        + a.c[1] * (S(-w1) + S(-1) + S(1) + S(w1))
-        + a.c[0] * S(0);
-#undef S
+  float v = 0.0f;
+#pragma unroll
+  for(int k = 0; k < 13; k++)
+  {
+    float ring = s[RING[k].at[0][0] * width + RING[k].at[0][1]];
+#pragma unroll
+    for(int j = 1; j < RING[k].n; j++) ring = ring + s[RING[k].at[j][0] * width + RING[k].at[j][1]];
+    const float term = a.c[RING[k].weight] * ring;
+    v = k ? v + term : term;
+  }
   const float lum = fminf(1.0f, fmaxf(0.0f, v));
   const size_t k = (size_t)row * width + col;
   out[k] = (form ? form[k] : fill) * lum;
