@@ -60,6 +60,7 @@ struct pde_args
   int width, height, mult;
   float anisotropy[4];
   int kind[4]; // 0 isotrope, 1 isophote, 2 gradient (check_isotropy_mode(), diffuse.c:151-161)
+  int same02, same13; // orders 1 and 3 (2 and 4) have the same kind and anisotropy: one kernel for both
   float variance_threshold, regularization;
   float abcd[4], strength;
   int post_lab;        // the pipe's RGB -> Lab glue behind the module, applied where the last pass stores (strip kernel)
@@ -90,15 +91,18 @@ __device__ __forceinline__ float direction(float gx, float gy, float &cos2, floa
   return mag;
 }
 
-// compute_kernel(), diffuse.c:725-757, convolved on the spot with the 9 samples p[] (k = 0..8 order
-// of the reference's accumulation loop, :913-919): d = kern[k] * p[k] + d
-__device__ __forceinline__ float convolve(const int kind, const float c2, const float cs, const float cos2,
-                                          const float sin2, const float p[9])
+// compute_kernel(), diffuse.c:725-757: the five distinct weights of the 3 x 3 kernel of one order (k[0] the corners
+// 0 and 8, k[1] top and bottom, k[2] = -k[0] the other diagonal, k[3] left and right, k[4] the centre)
+struct kernel5
 {
   float k0, k1, k2, k3, k4;
+};
+__device__ __forceinline__ kernel5 order_kernel(const int kind, const float c2, const float cs, const float cos2, const float sin2)
+{
+  kernel5 w;
   if(kind == 0)
   {
-    k0 = 0.25f; k1 = 0.5f; k2 = 0.25f; k3 = 0.5f; k4 = -3.0f; // isotrope_laplacian(), :705-723
+    w.k0 = 0.25f; w.k1 = 0.5f; w.k2 = 0.25f; w.k3 = 0.5f; w.k4 = -3.0f; // isotrope_laplacian(), :705-723
   }
   else
   {
@@ -115,22 +119,29 @@ __device__ __forceinline__ float convolve(const int kind, const float c2, const 
       a11 = cos2 + c2 * sin2;
       a01 = (1.0f - c2) * cs;
     }
-    k0 = a01 * 0.5f; // build_matrix(), :677-703
-    k1 = a11;
-    k2 = -k0;
-    k3 = a00;
-    k4 = -2.0f * (a00 + a11);
+    w.k0 = a01 * 0.5f; // build_matrix(), :677-703
+    w.k1 = a11;
+    w.k2 = -w.k0;
+    w.k3 = a00;
+    w.k4 = -2.0f * (a00 + a11);
   }
+  return w;
+}
+
+// ... convolved on the spot with the 9 samples p[] (k = 0..8 order of the reference's accumulation loop, :913-919):
+// d = kern[k] * p[k] + d
+__device__ __forceinline__ float convolve(const kernel5 w, const float p[9])
+{
   float d = 0.0f;
-  d = k0 * p[0] + d;
-  d = k1 * p[1] + d;
-  d = k2 * p[2] + d;
-  d = k3 * p[3] + d;
-  d = k4 * p[4] + d;
-  d = k3 * p[5] + d;
-  d = k2 * p[6] + d;
-  d = k1 * p[7] + d;
-  d = k0 * p[8] + d;
+  d = w.k0 * p[0] + d;
+  d = w.k1 * p[1] + d;
+  d = w.k2 * p[2] + d;
+  d = w.k3 * p[3] + d;
+  d = w.k4 * p[4] + d;
+  d = w.k3 * p[5] + d;
+  d = w.k2 * p[6] + d;
+  d = w.k1 * p[7] + d;
+  d = w.k0 * p[8] + d;
   return d;
 }
 
@@ -155,10 +166,16 @@ __device__ __forceinline__ float pde_channel(const float H[9], const float L[9],
   float cos2g = 0.f, sin2g = 0.f, csg = 0.f, cos2l = 0.f, sin2l = 0.f, csl = 0.f, mg = 0.f, ml = 0.f;
   if(a.kind[0] | a.kind[2]) mg = direction((L[7] - L[1]) * 0.5f, (L[5] - L[3]) * 0.5f, cos2g, sin2g, csg);
   if(a.kind[1] | a.kind[3]) ml = direction((H[7] - H[1]) * 0.5f, (H[5] - H[3]) * 0.5f, cos2l, sin2l, csl);
-  const float d0 = convolve(a.kind[0], fast_expf(-mg * a.anisotropy[0]), csg, cos2g, sin2g, L);
-  const float d1 = convolve(a.kind[1], fast_expf(-ml * a.anisotropy[1]), csl, cos2l, sin2l, L);
-  const float d2 = convolve(a.kind[2], fast_expf(-mg * a.anisotropy[2]), csg, cos2g, sin2g, H);
-  const float d3 = convolve(a.kind[3], fast_expf(-ml * a.anisotropy[3]), csl, cos2l, sin2l, H);
+  // orders 1 and 3 share the direction of the low-frequency gradient, orders 2 and 4 that of the high-frequency one; with
+  // the same anisotropy (the presets' case) they share the kernel too (uniform: the anisotropies are parameters)
+  const kernel5 w0 = order_kernel(a.kind[0], fast_expf(-mg * a.anisotropy[0]), csg, cos2g, sin2g);
+  const kernel5 w1 = order_kernel(a.kind[1], fast_expf(-ml * a.anisotropy[1]), csl, cos2l, sin2l);
+  const kernel5 w2 = a.same02 ? w0 : order_kernel(a.kind[2], fast_expf(-mg * a.anisotropy[2]), csg, cos2g, sin2g);
+  const kernel5 w3 = a.same13 ? w1 : order_kernel(a.kind[3], fast_expf(-ml * a.anisotropy[3]), csl, cos2l, sin2l);
+  const float d0 = convolve(w0, L);
+  const float d1 = convolve(w1, L);
+  const float d2 = convolve(w2, H);
+  const float d3 = convolve(w3, H);
   float update = d0 * a.abcd[0];
   update = d1 * a.abcd[1] + update;
   update = d2 * a.abcd[2] + update;
@@ -610,6 +627,8 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
     a.anisotropy[k] = sqf(user_aniso[k]); // compute_anisotropy_factor(), diffuse.c:970-976
     a.kind[k] = user_aniso[k] == 0.0f ? 0 : (user_aniso[k] > 0.0f ? 1 : 2);
   }
+  a.same02 = a.kind[0] == a.kind[2] && a.anisotropy[0] == a.anisotropy[2];
+  a.same13 = a.kind[1] == a.kind[3] && a.anisotropy[1] == a.anisotropy[3];
   const float regularization = powf(10.0f, d->regularization) - 1.0f; // diffuse.c:999-1000
   a.variance_threshold = powf(10.0f, d->variance_threshold);
   const float speed[4] = { d->first, d->second, d->third, d->fourth };
