@@ -102,6 +102,7 @@ enum
 typedef struct
 {
   float buf[O_END];
+  float priv[O_END]; /* probe only (oracle_amaze_unshare): private storage of planes taken out of their sharing */
 } tile_t;
 
 /* test hook: start every tile from this value instead of 0, to expose reads of never-written words */
@@ -111,16 +112,24 @@ void oracle_amaze_poison(const float v) { g_amaze_poison = v; }
  * i.e. exactly what the reference does with OMP_NUM_THREADS=1 (only the flag plane is cleared per tile) */
 static int g_amaze_persistent = 0;
 void oracle_amaze_persistent(const int on) { g_amaze_persistent = on; }
+/* probe (tools/amaze_alias_probe.py): which of the reference's plane sharings (amaze.cc:300-327) the RESULT depends on.
+ * Bit set = that plane gets zero-initialised storage of its own instead of its partner's memory:
+ *   1 dgrb0 / dgrb1 (with vcdalt)   2 delp / delm / rbint (with cddiffsq)   4 pmwt (with delhvsqsum)
+ *   8 rbm / rbp (with vcd)         16 the second Nyquist flag plane (with cddiffsq's bytes)   32 dgrb2 (with dgintv)
+ * 0 = the reference's layout.  A frame that changes under a bit shows where a stencil reads what the partner left. */
+static unsigned g_amaze_unshare = 0;
+void oracle_amaze_unshare(const unsigned bits) { g_amaze_unshare = bits; }
 
 static void amaze_tile(tile_t *t, const float *in, float *out, const int width, const int height, const int top,
                        const int left, const uint32_t filters, const int ex, const int ey, const float clip_pt)
 {
   if(!g_amaze_persistent)
   {
-    memset(t, 0, sizeof(*t));
+    memset(t->buf, 0, sizeof(t->buf));
     if(g_amaze_poison != 0.0f)
       for(int k = 0; k < O_END; k++) t->buf[k] = g_amaze_poison;
   }
+  if(g_amaze_unshare) memset(t->priv, 0, sizeof(t->priv));
   else
     memset((unsigned char *)(t->buf + O_NYQUIST) + 3 * TSH, 0, sizeof(unsigned char) * (TS - 6) * TSH); /* amaze.cc:337 */
   const float clip_pt8 = 0.8f * clip_pt;
@@ -134,14 +143,17 @@ static void amaze_tile(tile_t *t, const float *in, float *out, const int width, 
   float *const dirwts0 = B + O_DIRWTS0, *const dirwts1 = B + O_DIRWTS1, *const vcd = B + O_VCD, *const hcd = B + O_HCD;
   float *const vcdalt = B + O_VCDALT, *const hcdalt = B + O_HCDALT, *const cddiffsq = B + O_CDDIFFSQ;
   float *const hvwt = B + O_HVWT, *const dgintv = B + O_DGRB2, *const dginth = B + O_DGINTH;
-  float *const dgrb2 = B + O_DGRB2; /* [2 * k] = h, [2 * k + 1] = v */
+  float *const Q = t->priv;
+  const unsigned un = g_amaze_unshare;
+  float *const dgrb2 = (un & 32 ? Q : B) + O_DGRB2; /* [2 * k] = h, [2 * k + 1] = v */
   float *const dsq1m = B + O_DSQ1M, *const dsq1p = B + O_DSQ1P, *const nyqutest = B + O_NYQUTEST;
   unsigned char *const nyquist = (unsigned char *)(B + O_NYQUIST);
   /* shared storage, amaze.cc:300-327 */
-  float *const dgrb0 = vcdalt, *const dgrb1 = vcdalt + TS * TSH;
-  float *const delp = cddiffsq, *const delm = cddiffsq + TS * TSH + PAD, *const rbint = delm;
-  float *const pmwt = delhvsqsum, *const rbm = vcd, *const rbp = vcd + TS * TSH + PAD;
-  unsigned char *const nyquist2 = (unsigned char *)cddiffsq;
+  float *const dgrb0 = un & 1 ? Q + O_VCDALT : vcdalt, *const dgrb1 = dgrb0 + TS * TSH;
+  float *const delp = un & 2 ? Q + O_CDDIFFSQ : cddiffsq, *const delm = delp + TS * TSH + PAD, *const rbint = delm;
+  float *const pmwt = un & 4 ? Q + O_DELHVSQSUM : delhvsqsum;
+  float *const rbm = un & 8 ? Q + O_VCD : vcd, *const rbp = rbm + TS * TSH + PAD;
+  unsigned char *const nyquist2 = un & 16 ? (unsigned char *)(Q + O_NYQUIST) : (unsigned char *)cddiffsq;
 #define FCT(r, c) oracle_fc((r), (c), filters)
 
   /* S0 tile load with 16 mirrored photosites beyond every frame edge, amaze.cc:352-460.
