@@ -819,3 +819,48 @@ def test_diffuse_leaves_a_blank_fourth_channel_blank(preset, over):
     a, b = _pair("diffuse", abi.Piece.make(w, h), params.diffuse(preset, **over), img, img.shape)
     for out in (a, b):
         assert np.array_equal(out[..., 3].view(np.uint32), np.zeros((h, w), np.uint32))
+
+
+@pytest.mark.parametrize("version", [0, 1, 2])
+@pytest.mark.parametrize("extra", [dict(contrast=1.5, latitude=25.0, balance=12.0, output_power=3.2, white_point_source=5.5,
+                                        black_point_source=-9.2, saturation=-30.0),
+                                   dict(custom_grey=1, grey_point_source=12.0, grey_point_target=20.0, balance=-20.0, saturation=60.0),
+                                   dict(latitude=5.0, saturation=0.0), dict(latitude=95.0, saturation=100.0)])
+def test_filmic_colour_sciences_of_2019_2020_over_the_curve_geometry(version, extra):
+    """sigma_toe / sigma_shoulder follow the spline's latitude (commit_params(), filmicrgb.c:4101): narrow and wide
+    latitudes, custom grey, negative and zero saturation, every norm"""
+    img = synth.rgba_image(W, H, seed=5, lo=-0.02, hi=8.0)
+    piece = abi.Piece.make(W, H)
+    for pc in range(6):
+        p = filmic.UserParams.defaults(version=version, preserve_color=pc, **extra)
+        a, b = _pair("filmicrgb", piece, filmic.commit(p), img, img.shape)
+        _exact(a, b, "filmic v%d norm %d" % (version, pc))
+
+
+@pytest.mark.parametrize("method", [abi.DT_HIP_DEMOSAIC_RCD, abi.DT_HIP_DEMOSAIC_AMAZE, abi.DT_HIP_DEMOSAIC_PPG])
+@pytest.mark.parametrize("geq,smooth", [(2, 2), (3, 1)])
+def test_full_average_green_equilibration_around_every_interpolation(method, geq, smooth):
+    """the full-average equilibration ahead of RCD / AMaZE / PPG, with colour smoothing behind (demosaic.c:1137-1250)"""
+    w, h = 300, 200
+    cfa = synth.bayer_mosaic(w, h, seed=13).astype(np.float32)
+    img = ((cfa - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS)
+    d = abi.DemosaicData(geq, smooth, method, 0.0, 0.08)
+    a, b = _pair("demosaic", piece, d, img, (h, w, 4))
+    mask = None
+    if method == abi.DT_HIP_DEMOSAIC_RCD:
+        m = np.zeros((h, w), np.uint8)
+        ck.oracle().oracle_rcd_stale_mask(ck.ptr(m), w, h, C.c_uint32(synth.FILTERS_RGGB))
+        mask = np.zeros((h, w), np.uint8)
+        mask[:, w - 9:w - 6] = m[:, w - 9:w - 6]
+        from scipy.ndimage import binary_dilation
+        mask = binary_dilation(mask, iterations=smooth, structure=np.ones((3, 3))).astype(np.uint8)[..., None]
+    elif method == abi.DT_HIP_DEMOSAIC_AMAZE:
+        m = np.zeros((h, w), np.uint8)
+        ck.oracle().oracle_amaze_stale_mask(ck.ptr(m), w, h)
+        from scipy.ndimage import binary_dilation
+        mask = binary_dilation(m, iterations=smooth, structure=np.ones((3, 3))).astype(np.uint8)[..., None]
+    d_ulp = ck.ulp_diff(a, b)
+    if mask is not None:
+        d_ulp = d_ulp * (mask == 0)
+    assert int((d_ulp > 1).sum()) == 0 and int((d_ulp > 0).sum()) == 0, "%d differ" % int((d_ulp > 0).sum())
