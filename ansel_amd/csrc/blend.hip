@@ -917,6 +917,35 @@ __global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ i
 
 } // namespace
 
+namespace ansel
+{
+// dt_develop_blend_get_mask_usage(), blend.c:262-320: is any parametric channel of the blend's colourspace away from its
+// full range
+static bool blend_is_parametric(const dt_hip_blend_data_t *d)
+{
+  if(!(d->mask_mode & DT_HIP_MASK_PARAMETRIC)) return false;
+  const unsigned CH_MASK = d->blend_cst == DT_HIP_BLEND_CS_LAB ? LAB_MASK : RGB_MASK;
+  for(unsigned ch = 0; ch < DT_HIP_BLENDIF_SIZE; ch++)
+  {
+    const unsigned bit = 1u << ch;
+    if(!(CH_MASK & bit) || !(d->blendif & bit)) continue;
+    const float *c = &d->blendif_parameters[ch * 4];
+    if(fabsf(c[0]) > 1e-6f || fabsf(c[1]) > 1e-6f || fabsf(c[2] - 1.0f) > 1e-6f || fabsf(c[3] - 1.0f) > 1e-6f) return true;
+  }
+  return false;
+}
+
+// does this blend run _refine_with_detail_mask() (blend.c:789)?  Only an enabled blend with a mask source other than a
+// raster mask alone, a non-zero threshold and the raw detail mask at hand (:379) -- what the row-band walker refuses
+int blend_refines_with_detail_mask(const dt_hip_blend_data_t *d)
+{
+  if(!d || !(d->mask_mode & DT_HIP_MASK_ENABLED) || d->details == 0.f || !d->detail_mask) return 0;
+  const bool form = d->form_mask != nullptr, parametric = blend_is_parametric(d);
+  const bool raster_only = form && (d->mask_mode & DT_HIP_MASK_RASTER) && !(d->mask_mode & DT_HIP_MASK_SHAPE) && !parametric;
+  return (form || parametric) && !raster_only;
+}
+} // namespace ansel
+
 extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *piece, const dt_hip_blend_data_t *d,
                                             dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
 {
@@ -939,11 +968,9 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     set_last_error("blend: a drawn / raster mask needs the host-rendered form mask (form_mask)");
     return DT_HIP_INVALID_ARG;
   }
-  if(d->details != 0.f && !form && !d->detail_mask)
-  {
-    set_last_error("blend: a details threshold needs the raw detail mask (detail_mask) or a plane refined by the host (form_mask)");
-    return DT_HIP_INVALID_ARG;
-  }
+  // a details threshold is read where the reference reads it (blend.c:732-790): behind use_masks && !raster_only, and
+  // _refine_with_detail_mask() returns silently when the pipe holds no raw detail mask (:379) -- so a uniform, disabled
+  // or raster-only blend that carries a stale `details` value, or one without the plane, blends as if it were 0
   if(form && raw)
   {
     set_last_error("blend: form masks in the raw colourspace are not built");
@@ -965,17 +992,7 @@ extern "C" int dt_hip_develop_blend_process(int devid, const dt_hip_piece_t *pie
     return DT_HIP_SUCCESS;
 
   const float opacity = fminf(fmaxf(d->opacity / 100.0f, 0.0f), 1.0f);
-  // dt_develop_blend_get_mask_usage(), blend.c:262-320: is any parametric channel away from its full range
-  bool parametric = false;
-  if(d->mask_mode & DT_HIP_MASK_PARAMETRIC)
-    for(unsigned ch = 0; ch < DT_HIP_BLENDIF_SIZE; ch++)
-    {
-      const unsigned bit = 1u << ch;
-      if(!(CH_MASK & bit) || !(d->blendif & bit)) continue;
-      const float *c = &d->blendif_parameters[ch * 4];
-      if(fabsf(c[0]) > 1e-6f || fabsf(c[1]) > 1e-6f || fabsf(c[2] - 1.0f) > 1e-6f || fabsf(c[3] - 1.0f) > 1e-6f)
-        parametric = true;
-    }
+  const bool parametric = blend_is_parametric(d);
   // make_mask(), blendif_rgb_jzczhz.c:196-324: which of its three cases
   const unsigned any_channel_active = d->blendif & CH_MASK;
   const unsigned mask_inclusive = d->mask_combine & DT_HIP_COMBINE_INCL;

@@ -34,7 +34,7 @@ struct gf_tile
 };
 
 constexpr int GF_PLANES = 13;                        // 0: mask, 1-3: guide, 4-6: covariance, 7-12: variance
-constexpr size_t GF_BATCH_BYTES = (size_t)8 << 30;   // both plane sets of one batch
+constexpr size_t GF_BATCH_MAX = (size_t)8 << 30;     // both plane sets of one batch, at most (and at most half of what is free)
 
 // Kahan_sum(), src/math/math.h:105-111
 __device__ __forceinline__ float kahan(const float m, float &c, const float add)
@@ -268,6 +268,10 @@ int guided_filter_launch(int devid, const float4 *guide, float *mask, int width,
   if(!bak) return DT_HIP_SYSMEM_ALLOCATION;
   int err = DT_HIP_SUCCESS;
   if(hipMemcpyAsync(bak, mask, np * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) err = DT_HIP_DEFAULT_ERROR;
+  // the batch budget follows the device: batching does not change the result, so a device with little free memory (or
+  // a caller inside the host tiler's budget) runs more, smaller batches instead of failing
+  const size_t GF_BATCH_BYTES = std::max<size_t>(std::min<size_t>(GF_BATCH_MAX, (size_t)dt_hip_get_device_available(devid) / 2),
+                                                 (size_t)64 << 20);
   size_t first = 0;
   while(first < tiles.size() && err == DT_HIP_SUCCESS)
   {

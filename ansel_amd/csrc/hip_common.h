@@ -151,6 +151,7 @@ int detail_refine_launch(int devid, const float *rawdetail, const float *form, f
 // take turns (bilat.hip).  begin: the zeroed grid of the frame; splat: the band's rows on top of what the grid holds;
 // finish: blur of the complete grid (this band's copy) and the slice of the band's rows
 int bilat_band_supported(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d);
+int blend_refines_with_detail_mask(const dt_hip_blend_data_t *d); // blend.hip
 int bilat_band_begin(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t *grid, size_t *bytes);
 int bilat_band_splat(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t grid,
                      dt_hip_mem_t in_rows, int row0, int rows);

@@ -721,8 +721,7 @@ int dt_hip_pipe_band_begin(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_hi
       set_last_error("band mode: local contrast runs on row bands in its bilateral-grid mode only");
       return DT_HIP_INVALID_ARG;
     }
-    if(n.op == OP_DETAILMASK
-       || (n.op == OP_BLEND && n.as<dt_hip_blend_data_t>()->details != 0.0f && n.as<dt_hip_blend_data_t>()->detail_mask))
+    if(n.op == OP_DETAILMASK || (n.op == OP_BLEND && blend_refines_with_detail_mask(n.as<dt_hip_blend_data_t>())))
     {
       // the raw detail mask is one plane of the frame on one device; its 9 x 9 blur reads across band borders
       set_last_error("band mode: the detail mask (the \"detailmask\" stage, a blend's details threshold) has no row-band "
@@ -986,7 +985,13 @@ int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_b
     if(gang.rc[k] >= 0 && (rc = dt_hip_pipe_band_resolve(pipe, &b, &st[k])) != DT_HIP_SUCCESS) fail(rc);
     if(!meet()) return give_up();
     // 3. mosaic rows the demosaic reads beyond the band
-    if(st[k].halo_buf)
+    if(st[k].halo_buf && ((k > 0 && b.halo_top > bands[k - 1].rows) || (k + 1 < n && b.halo_bottom > bands[k + 1].rows)))
+    {
+      // caller-supplied bands thinner than the demosaic's halo: the pull below would read outside the neighbour's buffer
+      fail(DT_HIP_INVALID_ARG);
+      errors[k] = "dt_hip_pipe_process_bands: a band owns fewer rows than the mosaic halo its neighbour needs: use fewer bands";
+    }
+    else if(st[k].halo_buf)
     {
       char *const mine = (char *)st[k].halo_buf;
       const size_t rb = st[k].row_bytes;

@@ -654,6 +654,15 @@ int dt_hip_enqueue_copy_image(int devid, dt_hip_mem_t src, dt_hip_mem_t dst, con
   if(!valid_device(devid) || !src || !dst || !orig_src || !orig_dst || !region) return DT_HIP_INVALID_ARG;
   const alloc_t a = alloc_of(src), b = alloc_of(dst);
   if(a.width <= 0 || b.width <= 0 || a.bpp != b.bpp) return DT_HIP_INVALID_ARG;
+  // clEnqueueCopyImage returns CL_INVALID_VALUE for a window that leaves either image
+  const size_t lim = 0x7fffffff;
+  if(region[0] > lim || region[1] > lim || orig_src[0] > lim || orig_src[1] > lim || orig_dst[0] > lim || orig_dst[1] > lim
+     || orig_src[0] + region[0] > (size_t)a.width || orig_dst[0] + region[0] > (size_t)b.width
+     || (a.height > 0 && orig_src[1] + region[1] > (size_t)a.height) || (b.height > 0 && orig_dst[1] + region[1] > (size_t)b.height))
+  {
+    set_last_error("enqueue_copy_image: the window leaves the image");
+    return DT_HIP_INVALID_ARG;
+  }
   return dt_hip_enqueue_copy_region(devid, src, a.width, (int)orig_src[0], (int)orig_src[1], dst, b.width, (int)orig_dst[0],
                                     (int)orig_dst[1], (int)region[0], (int)region[1], a.bpp);
 }

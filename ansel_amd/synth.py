@@ -108,10 +108,42 @@ def adversarial_rgba(width, height, seed=7):
     return img
 
 
-def bayer_mosaic_tiled(width, height, seed=1, tile=2048, iso=400.0):
-    """Large mosaics for the benchmark: one seeded tile x tile mosaic repeated to width x height
-    (tile is even, so the CFA phase is preserved).  Seconds instead of minutes at 100 MP."""
-    t = bayer_mosaic(min(tile, width), min(tile, height), seed=seed, iso=iso)
-    ry = -(-height // t.shape[0])
-    rx = -(-width // t.shape[1])
-    return np.ascontiguousarray(np.tile(t, (ry, rx))[:height, :width])
+def _mosaic_from_scene(rgb, rng, iso, filters):
+    """the sensor model of bayer_mosaic() on a given scene: CFA sampling, white-balance attenuation, noise, quantisation"""
+    height, width = rgb.shape[:2]
+    rows = np.arange(height)[:, None]
+    cols = np.arange(width)[None, :]
+    c = fc(rows, cols, filters)
+    c3 = np.where(c == 3, 1, c)
+    sensor = np.take_along_axis(rgb, c3[..., None], axis=-1)[..., 0]
+    wb = np.asarray(WB_COEFFS, dtype=np.float32)
+    sensor = sensor / wb[c] * np.float32(0.85)
+    a = np.float32(2e-5 * iso / 100.0)
+    b = np.float32(2e-7)
+    sigma = np.sqrt(np.maximum(a * sensor + b, 0)).astype(np.float32)
+    sensor = sensor + sigma * rng.standard_normal(sensor.shape, dtype=np.float32)
+    dn = np.rint(sensor * np.float32(WHITE - BLACK) + np.float32(BLACK))
+    return np.clip(dn, 0, WHITE).astype(np.uint16)
+
+
+def bayer_mosaic_tiled(width, height, seed=1, tile=2048, iso=400.0, filters=FILTERS_RGGB):
+    """Large mosaics for the benchmark and the at-size parity tests, in seconds instead of minutes at 100 MP: the
+    frame is a grid of tile x tile mosaics (tile is even, so the CFA phase is preserved), EVERY TILE WITH ITS OWN
+    SEED -- its own noise realisation over its own variant of the scene (one of the four mirror images of a seeded
+    base scene, its own exposure and colour cast), mosaiced after the mirroring -- so no two tiles of a 100 MP frame
+    hold the same values (a first version repeated one tile 24 times: addressing at scale, value diversity of 4 MP)."""
+    tw, th = min(tile, width), min(tile, height)
+    base = scene_rgb(tw, th, seed)
+    out = np.empty((height, width), np.uint16)
+    k = 0
+    for y0 in range(0, height, th):
+        for x0 in range(0, width, tw):
+            rng = np.random.default_rng((seed + 1000, k))
+            v = base[::-1] if k & 1 else base
+            v = v[:, ::-1] if k & 2 else v
+            gain = (np.float32(rng.uniform(0.5, 1.05)) * (np.float32(1.0) + np.float32(0.12) * rng.standard_normal(3).astype(np.float32)))
+            t = _mosaic_from_scene(v * gain.astype(np.float32), rng, iso, filters)
+            hh, ww = min(th, height - y0), min(tw, width - x0)
+            out[y0:y0 + hh, x0:x0 + ww] = t[:hh, :ww]
+            k += 1
+    return out

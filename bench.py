@@ -8,9 +8,12 @@ the dominant kernel and the reference's CPU path timed beside it.
 
 A "step" is one pass of the export pipe over one synthetic raw frame: every module of the pipe,
 input mosaic already resident in HBM, output RGBA u16 left in HBM.  Workload (config.workload):
-BASELINE.json's metric is quoted on a 100 MP raw (11648 x 8736 RGGB); the pipe is config 2's
-module list (rawprepare, white balance, highlight clip, RCD demosaic, exposure, colorin,
-color calibration, filmic RGB, colorout, float->u16), all at module defaults.
+BASELINE.json's metric is "MPix/s full export pixelpipe (100 MP raw)": the FULL pipe -- config 3's
+module list (rawprepare, white balance, highlight clip, RCD demosaic, denoise (profiled) wavelets,
+exposure, colorin, color calibration, diffuse or sharpen, non-local means and local contrast
+(bilateral grid) in Lab, filmic RGB, colorout, float->u16), every heavy iop the north star names, all at
+module defaults -- on the 100 MP frame (11648 x 8736 RGGB).  `--pipe light` times config 2's module list
+(no denoise / diffuse / local contrast) instead; at N = 1 the default run also carries it as `config.light_pipe`.
 
 N > 1: one process per GPU, one frame per GPU (BASELINE.json config 5: batch export shards
 frames across GPUs, no data-path collective) -> "scaling": "weak"; value = N frames / max time.
@@ -19,11 +22,10 @@ an 8-byte all-reduce and one 9-row halo send/recv per frame -> "scaling": "stron
 Started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) it spawns its own N ranks under
 torch.distributed.run on 127.0.0.1; a launcher whose WORLD_SIZE disagrees with --gpus is an error.
 
-Besides `value` (the light pipe on the 100 MP frame, the workload the metric is quoted on) the line carries,
-at N = 1: `config.full_pipe` -- config 3's module list (+ profiled-wavelet denoise, diffuse or sharpen,
-non-local means in Lab) on the SAME 100 MP frame, timed in the same run; `verified` -- the output buffer the
-timed steps wrote, compared word for word with the oracle's chain after the timed region (the oracle is the
-checker here, never the thing measured); `cpu_baseline` -- the reference's own code on the host cores.
+Besides `value` the line carries, at N = 1: `config.light_pipe` -- config 2's module list on the SAME 100 MP
+frame, timed in the same run; `verified` -- the output buffer the timed steps wrote, compared word for word with
+the oracle's chain after the timed region (the oracle is the checker here, never the thing measured);
+`cpu_baseline` -- the reference's own code on the host cores, same module chain.
 
 PyTorch is used for device memory, the stream and torch.distributed only; all pixel work goes
 through the C-ABI of libansel_hip.so (include/ansel_hip.h).  There is no CPU fallback.
@@ -45,22 +47,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", default="100MP", help="24MP | 45MP | 60MP | 100MP | WxH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the post-timing comparison of the timed output buffer with the oracle chain")
-    ap.add_argument("--no-full-pipe", action="store_true",
-                    help="skip the config.full_pipe leg (config 3's modules on the same frame)")
-    ap.add_argument("--full-steps", type=int, default=3, help="timed steps of the config.full_pipe leg")
+    ap.add_argument("--no-light-pipe", action="store_true",
+                    help="skip the config.light_pipe leg (config 2's modules on the same frame)")
+    ap.add_argument("--light-steps", type=int, default=10, help="timed steps of the config.light_pipe leg")
     ap.add_argument("--no-host-legs", action="store_true",
-                    help="skip the PCIe-inclusive host-to-host measurements (profiling runs: only the timed region's kernels)")
+                    help="skip the PCIe-inclusive host-to-host measurements (--pipe light only; never `value`)")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per module (A/B against the fused executor)")
-    ap.add_argument("--cpu-sample", default="24MP", help="frame size of the bounded CPU sample")
-    ap.add_argument("--pipe", default="light", choices=("light", "denoise"),
-                    help="light = BASELINE.json config 2 (the metric's workload); denoise = config 3 (+ denoise (profiled) "
-                         "wavelets + non-local means in Lab + diffuse or sharpen), quoted on 60MP")
+    ap.add_argument("--cpu-sample", default=None,
+                    help="frame size of the bounded CPU sample (default: 3000x2000 for the full pipe, 24MP for the light one)")
+    ap.add_argument("--pipe", default="full", choices=("full", "light", "denoise"),
+                    help="full = the metric's workload: config 3's modules (denoise (profiled) wavelets, diffuse or sharpen, "
+                         "non-local means) + local contrast (bilateral grid); light = BASELINE.json config 2; "
+                         "denoise = full without local contrast (round 2's config.full_pipe)")
     ap.add_argument("--mode", default="batch", choices=("batch", "tiled"),
                     help="N > 1: batch = one frame per GPU (config 5, weak); tiled = ONE frame cut into row bands, "
                          "one band per GPU, halo rows exchanged over RCCL (config 4, strong)")
@@ -82,10 +86,11 @@ def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light"):
         from ansel_amd import filmic as fm
         filmic = fm.default_data()
     coeffs = params.unbounded_coeffs(lut)
-    if which == "denoise":
-        # BASELINE.json config 3: + denoise (profiled wavelets) + non-local means + diffuse or sharpen
+    if which in ("full", "denoise"):
+        # BASELINE.json config 3: + denoise (profiled wavelets) + non-local means + diffuse or sharpen; "full" also
+        # runs local contrast (bilateral grid) behind non-local means, inside the same Lab section
         return pipe.denoise_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, filmic=filmic, with_nlmeans=True,
-                                       with_bilat=False)
+                                       with_bilat=(which == "full"))
     return pipe.light_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, with_filmic=with_filmic,
                                  filmic=filmic)
 
@@ -255,23 +260,34 @@ def verify_output(out16, raw_host, width, height, with_filmic, which):
             "against": "oracle/liboracle.so chain on the same mosaic, %.1f s on %d host threads" % (t_oracle, os.cpu_count() or 1)}
 
 
-def measured_traffic(tag, args):
-    """HBM bytes per launch of `tag` from the COMMITTED PMC summary of this exact configuration (not collected in
-    this run: counters need rocprofv3 around the process -- tools/profile_round.sh -> tools/pmc_hbm_json.py:
-    separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of MI355X_MICROARCH.md); None when no
+PMC_SUMMARIES = {  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of THIS configuration, newest first
+    "full": ("r03_pmc_hbm_bytes_100MP_full.json",),
+    "light": ("r03_pmc_hbm_bytes_100MP_light_fused.json", "r02_pmc_hbm_bytes_100MP_light_fused.json"),
+}
+
+
+def pmc_table(args):
+    """{kernel tag: HBM bytes per launch} from the COMMITTED PMC summary of this exact configuration (not collected
+    in this run: counters need rocprofv3 around the process -- tools/profile_round.sh -> tools/pmc_hbm_json.py:
+    separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of MI355X_MICROARCH.md); ({}, None) when no
     summary matches the configuration."""
-    if args.size != "100MP" or args.pipe != "light" or args.no_fusion or args.mode != "batch":
-        return None, None
-    for name in ("r02_pmc_hbm_bytes_100MP_light_fused.json", "r01_h_pmc_hbm_bytes_100MP_light_fused.json"):
+    if args.size != "100MP" or args.no_fusion or args.mode != "batch":
+        return {}, None
+    for name in PMC_SUMMARIES.get(args.pipe, ()):
         path = os.path.join(ROOT, "profiles", name)
         try:
             kernels = json.load(open(path))["kernels"]
         except (OSError, ValueError, KeyError):
             continue
-        for key in (tag, tag.replace("_u16", "")):
-            if key in kernels:
-                return kernels[key]["hbm_bytes"], "committed PMC summary profiles/" + name
-    return None, None
+        return {k: v["hbm_bytes"] for k, v in kernels.items() if "hbm_bytes" in v}, "committed PMC summary profiles/" + name
+    return {}, None
+
+
+def traffic_of(table, tag):
+    for key in (tag, tag.replace("_u16", "")):
+        if key in table:
+            return table[key]
+    return None
 
 
 # What binds each kernel, and the peak it is priced against.  HBM: 8 TB/s.  VALU: one wave64 instruction per
@@ -280,7 +296,8 @@ def measured_traffic(tag, args):
 # cycle constants") -> the kernel's issue-cycle total from its instruction mix (profiles/r02_isa_mix.json,
 # tools/valu_model.py) over 1024 SIMDs at 2.4 GHz is its floor.
 KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu", "rcd_tiles": "valu+lds",
-                "nlm_chunks": "valu+lds", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
+                "nlm_chunks": "lds+valu", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
+                "bilat_splat": "latency (one lane per grid node walks its pixels)", "bilat_slice": "hbm", "bilat_blur": "latency",
                 "dn_synthesize": "hbm", "dn_precondition": "hbm", "dn_finish": "hbm", "dn_finish_chain": "hbm", "rgb_to_lab": "hbm",
                 "lab_to_rgb": "hbm"}
 
@@ -300,6 +317,21 @@ def valu_floor_ms(tag, mpix):
     if not k or "issue_floor_ms_per_mpix" not in k:
         return None
     return k["issue_floor_ms_per_mpix"] * mpix
+
+
+def cgroup_cpu_quota():
+    """the container's CPU quota in cores (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unreadable"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / float(per), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / float(per), 2)
+    except (OSError, ValueError):
+        return None
 
 
 def read_kernel_events(l, devid):
@@ -426,44 +458,43 @@ def main():
     if rank == 0 and world == 1 and args.mode == "batch" and not args.no_verify:
         verify = verify_output(out16, raw_host, width, height, with_filmic, args.pipe)
 
-    # ---- config 3's module list on the SAME frame, same run (config.full_pipe)
-    full = None
-    if rank == 0 and world == 1 and args.mode == "batch" and args.pipe == "light" and not args.no_full_pipe:
-        fnodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic, "denoise")
-        fexec = pipe.DevicePipe(devid, fnodes, fusion=not args.no_fusion)
-        fexec.process(raw.data_ptr(), out16.data_ptr())
+    # ---- config 2's module list on the SAME frame, same run (config.light_pipe)
+    light = None
+    if rank == 0 and world == 1 and args.mode == "batch" and args.pipe != "light" and not args.no_light_pipe:
+        lnodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic, "light")
+        lexec = pipe.DevicePipe(devid, lnodes, fusion=not args.no_fusion)
+        lout = torch.empty((height, width, 4), dtype=torch.int16, device=dev)  # `out16` keeps the timed steps' frame
+        lexec.process(raw.data_ptr(), lout.data_ptr())
         torch.cuda.synchronize(dev)
         l.dt_hip_events_reset(devid)
         l.dt_hip_events_enable(devid, 1)
         t1 = time.perf_counter()
-        for _ in range(args.full_steps):
-            fexec.process(raw.data_ptr(), out16.data_ptr())
+        for _ in range(args.light_steps):
+            lexec.process(raw.data_ptr(), lout.data_ptr())
         torch.cuda.synchronize(dev)
-        f_ms = (time.perf_counter() - t1) / args.full_steps * 1e3
+        l_ms = (time.perf_counter() - t1) / args.light_steps * 1e3
         l.dt_hip_events_enable(devid, 0)
-        fk = read_kernel_events(l, devid)
-        f_bpp = pipe.algorithmic_bytes_per_pixel(fnodes)
-        full = {
-            "workload": "%d x %d RGGB u16 raw, export pipe: %s; module defaults" % (width, height, " > ".join(n.op for n in fnodes)),
-            "steps": args.full_steps,
-            "ms_per_step": round(f_ms, 3),
-            "mpix_s": round(npix / 1e6 / (f_ms * 1e-3), 2),
-            "algorithmic_bytes_per_px": f_bpp,
-            "hbm_frac": round(f_bpp * npix / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "launch_groups": fexec.num_groups,
-            "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / args.full_steps, 3) for k, v in sorted(fk.items())},
-            "kernel_launches_per_step": {k: v["launches"] // args.full_steps for k, v in sorted(fk.items())},
+        lk = read_kernel_events(l, devid)
+        l_bpp = pipe.algorithmic_bytes_per_pixel(lnodes)
+        light = {
+            "workload": "%d x %d RGGB u16 raw, export pipe: %s; module defaults" % (width, height, " > ".join(n.op for n in lnodes)),
+            "steps": args.light_steps,
+            "ms_per_step": round(l_ms, 3),
+            "mpix_s": round(npix / 1e6 / (l_ms * 1e-3), 2),
+            "algorithmic_bytes_per_px": l_bpp,
+            "hbm_frac": round(l_bpp * npix / (l_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "launch_groups": lexec.num_groups,
+            "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / args.light_steps, 3) for k, v in sorted(lk.items())},
         }
-        if not args.no_verify and os.environ.get("ANSEL_BENCH_VERIFY_FULL") == "1":
-            full["verify"] = verify_output(out16, raw_host, width, height, with_filmic, "denoise")
-        fexec.close()
+        lexec.close()
+        del lout
 
     # ---- the same step with the boundary's two PCIe legs (never `value`): sensor buffer in pinned host memory ->
     #      basebuffer upload -> pipe -> exported frame back into pinned host memory
     host_ms = None
     host_overlap_ms = None
     host_rows_ms = None
-    if rank == 0 and world == 1 and args.mode == "batch" and not args.no_host_legs:
+    if rank == 0 and world == 1 and args.mode == "batch" and not args.no_host_legs and args.pipe == "light":
         nb_in, nb_out = raw_host.nbytes, npix * 8
         pin_in, pin_out = l.dt_hip_alloc_host_pinned(nb_in), l.dt_hip_alloc_host_pinned(nb_out)
         if pin_in and pin_out:
@@ -514,42 +545,57 @@ def main():
         l.dt_hip_free_host_pinned(pin_out)
 
     if rank == 0:
-        # algorithmic bytes per pixel of each tagged kernel
-        tag_bpp = {"rawprepare_1f": 6, "temperature_1f": 8, "highlights_clip_1f": 8, "rcd_tiles": 20,
-                   "ppg_full": 20, "exposure": 32, "colorin": 32, "channelmixerrgb": 32, "filmicrgb": 32,
+        from ansel_amd import modinfo
+        # algorithmic bytes per pixel and launch of each tagged kernel: a fused
+        # group is credited with the algorithmic bytes of the modules it executes
+        tag_bpp = {"rawprepare_1f": 6, "temperature_1f": 8, "highlights_clip_1f": 8, "rcd_tiles": 20, "rcd_border": 0,
+                   "ppg_full": 20, "amaze_tiles": 20, "exposure": 32, "colorin": 32, "channelmixerrgb": 32, "filmicrgb": 32,
                    "colorout": 32, "export_u16": 24, "dn_precondition": 32, "dn_decompose": 48, "dn_synthesize": 48,
-                   "dn_finish": 48, "diffuse_decompose": 48, "diffuse_pde": 48, "nlm_chunks": 32, "rgb_to_lab": 32,
-                   "lab_to_rgb": 32}
+                   "dn_finish": 48 + 32, "diffuse_decompose": 48, "diffuse_pde": 48, "nlm_chunks": 32, "rgb_to_lab": 32,
+                   "lab_to_rgb": 32, "bilat_splat": 16, "bilat_slice": 32, "bilat_blur": 0, "bilat_lightness": 0}
+        ops = [n.op for n in nodes]
         if not args.no_fusion:
-            # a fused group is credited with the algorithmic bytes of the modules it executes
-            tag_bpp["raw_chain"] = sum(sum(pipe.MODULE_BPP[n.op]) for n in nodes if n.op in ("rawprepare", "temperature", "highlights"))
-            tag_bpp["rgb_chain_u16"] = sum(sum(pipe.MODULE_BPP[n.op]) for n in nodes
-                                           if n.op in ("exposure", "colorin", "channelmixerrgb", "filmicrgb", "colorout", "export_u16"))
-            if args.pipe == "denoise":
-                # two fused RGBA groups: exposure > colorin > calibration | filmic > colorout > u16
-                tag_bpp["rgb_chain"] = 3 * 32
-                tag_bpp["rgb_chain_u16"] = 2 * 32 + 24
-        dominant = max((k for k in kernels if k in tag_bpp), key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])
-        dom = kernels[dominant]
-        dom_bytes = tag_bpp[dominant] * my_rows * width  # rank 0's share of the frame in tiled mode
-        achieved = dom_bytes / (dom["ms_avg"] * 1e-3) / 1e9
-        pipe_bpp = pipe.algorithmic_bytes_per_pixel(nodes)
+            tag_bpp["raw_chain"] = sum(sum(pipe.MODULE_BPP[o]) for o in ops if o in ("rawprepare", "temperature", "highlights"))
+            if args.pipe == "light":
+                tag_bpp["rgb_chain_u16"] = sum(sum(pipe.MODULE_BPP[o]) for o in ops
+                                               if o in ("exposure", "colorin", "channelmixerrgb", "filmicrgb", "colorout", "export_u16"))
+            else:
+                # denoise (profiled)'s last kernel carries exposure > colorin > calibration; the last PDE pass of diffuse
+                # carries rgb_to_lab; the run behind the Lab section carries lab_to_rgb > filmic > colorout > u16
+                tag_bpp["dn_finish_chain"] = 48 + 32 + 3 * 32
+                tag_bpp["rgb_chain_u16"] = 32 + 2 * 32 + 24
+        pmc, pmc_src = pmc_table(args)
+        mpix_mine = my_rows * width / 1e6
         ms_per_step = elapsed / args.steps * 1e3
-        kernel_ms = sum(v["ms_avg"] * v["launches"] for k, v in kernels.items()) / args.steps
-        traffic, traffic_src = measured_traffic(dominant, args)
-        # what binds each kernel of the step: its algorithmic-byte HBM fraction and, where a committed instruction
-        # mix exists, its VALU issue floor (a kernel running at its floor cannot get faster without fewer instructions)
+        pipe_bpp = pipe.algorithmic_bytes_per_pixel(nodes)
+        kernel_ms = sum(v["ms_avg"] * v["launches"] for v in kernels.values()) / args.steps
+        # what binds each kernel of the step.  Per LAUNCH: hbm_frac = algorithmic bytes / time / 8 TB/s (the contract's
+        # figure -- > 1 is possible for a fused group, whose credit is for bytes NOT moved); hbm_frac_moved = the bytes
+        # the PMC counters saw / time / 8 TB/s (physical, always < 1); valu_frac = VALU issue floor / time
         per_kernel = {}
         for k, v in sorted(kernels.items()):
-            if k not in tag_bpp:
-                continue
-            e = {"ms": round(v["ms_avg"], 4), "bound": KERNEL_BOUND.get(k, "hbm"),
-                 "hbm_frac": round(tag_bpp[k] * my_rows * width / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            floor = valu_floor_ms(k, my_rows * width / 1e6)
+            per_launch = v["launches"] / float(args.steps)
+            e = {"ms": round(v["ms_avg"], 4), "launches_per_step": round(per_launch, 2),
+                 "ms_per_step": round(v["ms_avg"] * per_launch, 4), "bound": KERNEL_BOUND.get(k, "hbm")}
+            if tag_bpp.get(k):
+                e["algorithmic_bytes_per_px"] = tag_bpp[k]
+                e["hbm_frac"] = round(tag_bpp[k] * my_rows * width / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            moved = traffic_of(pmc, k)
+            if moved is not None:
+                e["hbm_bytes_moved"] = moved
+                e["hbm_frac_moved"] = round(moved / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                if tag_bpp.get(k):
+                    e["moved_over_algorithmic"] = round(moved / float(tag_bpp[k] * my_rows * width), 3)
+            floor = valu_floor_ms(k, mpix_mine)
             if floor is not None:
                 e["valu_issue_floor_ms"] = round(floor, 4)
                 e["valu_frac"] = round(floor / v["ms_avg"], 4)
             per_kernel[k] = e
+        dominant = max((k for k in kernels if tag_bpp.get(k)), key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])
+        dom = kernels[dominant]
+        dom_bytes = tag_bpp[dominant] * my_rows * width  # rank 0's share of the frame in tiled mode
+        achieved = dom_bytes / (dom["ms_avg"] * 1e-3) / 1e9
+        traffic = traffic_of(pmc, dominant)
         line = {
             "metric": "MPix/s full export pixelpipe (100 MP raw); % MI355X HBM roofline",
             "value": round((1 if args.mode == "tiled" else world) * npix / 1e6 / (elapsed / args.steps), 2),
@@ -564,44 +610,51 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%d x %d RGGB u16 raw (%s), export pipe: %s; module defaults; %s"
-                            % (width, height, args.size, " > ".join(n.op for n in nodes),
-                               "one frame cut into %d row bands, one per GPU" % world if args.mode == "tiled"
-                               else "one frame per GPU"),
+                "workload": "%d x %d RGGB u16 raw (%s), %s export pipe: %s; module defaults; %s"
+                            % (width, height, args.size, args.pipe, " > ".join(ops),
+                               "one frame cut into %d row bands, one per GPU (halo rows and the reductions over RCCL)" % world
+                               if args.mode == "tiled" else "one frame per GPU"),
                 "frame_mpix": round(npix / 1e6, 2),
                 "executor": "dt_hip_pipe_process, %d launch groups (fusion %s)" % (executor.num_groups, "off" if args.no_fusion else "on"),
                 "pipe_algorithmic_bytes_per_px": pipe_bpp,
+                # the metric's second half: the whole step against the HBM roofline of its algorithmic bytes
                 "pipe_hbm_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "pipe_kernel_ms": round(kernel_ms, 4),
-                "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(kernels.items())},
-                "kernel_launches_per_step": {k: v["launches"] // args.steps for k, v in sorted(kernels.items())},
+                "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / args.steps, 3) for k, v in sorted(kernels.items())},
                 "kernel_bounds": per_kernel,
-                "full_pipe": full,
-                # not `value`: one frame from pinned host memory to pinned host memory over PCIe, no overlap
+                "pmc_source": pmc_src,
+                "light_pipe": light,
+                # not `value`: one frame from pinned host memory to pinned host memory over PCIe
                 "host_to_host_ms": None if host_ms is None else round(host_ms, 3),
                 "host_to_host_overlapped_ms": None if host_overlap_ms is None else round(host_overlap_ms, 3),
                 "host_to_host_overlapped_rgb_rows_ms": None if host_rows_ms is None else round(host_rows_ms, 3),
+                "host": {"nproc": os.cpu_count(), "cpu_quota": cgroup_cpu_quota(), "affinity": len(os.sched_getaffinity(0))},
             },
             "roofline": {
-                # the contract's figure: algorithmic bytes of the modules this launch executes / its duration / HBM peak
+                # the contract's figure for the launch with the largest share of the step: algorithmic bytes of the
+                # module(s) it executes / its average duration (HIP events on the launch stream) / HBM peak
                 "bound": "hbm",
                 "kernel": dominant,
+                "share_of_step": round(dom["ms_avg"] * dom["launches"] / args.steps / max(kernel_ms, 1e-9), 3),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic_source": pmc_src if traffic is not None else None,
                 # ... and what actually binds this launch (config.kernel_bounds has every kernel of the step)
                 "binds": per_kernel.get(dominant, {}).get("bound"),
                 "valu_frac": per_kernel.get(dominant, {}).get("valu_frac"),
+                # the whole step: sum of algorithmic bytes / step time / peak (= config.pipe_hbm_frac)
+                "pipe_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
         }
         if verify is not None:
             line["verified"] = verify["verified"]
             line["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline_in_child(args.cpu_sample, with_filmic, args.pipe, (width, height))
+            sample = args.cpu_sample or ("24MP" if args.pipe == "light" else "3000x2000")
+            cb = cpu_baseline_in_child(sample, with_filmic, args.pipe, (width, height))
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)

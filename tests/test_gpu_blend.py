@@ -113,7 +113,7 @@ def test_blend_full_frame():
     _check(abi.Piece.make(w, h), d, a, b, "24 MP")
 
 
-@pytest.mark.parametrize("field,value", [("blend_cst", 5), ("blend_cst", 0), ("details", 0.5),
+@pytest.mark.parametrize("field,value", [("blend_cst", 5), ("blend_cst", 0),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_SHAPE),
                                          ("mask_mode", abi.MASK_ENABLED | abi.MASK_RASTER)])
 def test_blend_refuses_what_is_not_built(field, value):
@@ -128,6 +128,31 @@ def test_blend_refuses_what_is_not_built(field, value):
     assert rc == -997  # DT_HIP_INVALID_ARG
     assert h_.dt_hip_finish(0) == 1
     assert np.array_equal(db.to_numpy(b.shape, np.float32).view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", ["uniform", "disabled", "parametric"])
+def test_a_stale_details_value_without_the_raw_detail_mask_is_ignored(mode):
+    """blend.c:732-790 reads `details` only behind use_masks && !raster_only, and _refine_with_detail_mask() returns
+    silently when the pipe holds no raw detail mask (:379): such a blend equals the same blend with details = 0"""
+    w, h = 48, 20
+    a, b = blend_cases.images(w, h, 5)
+    outs = []
+    for details in (0.0, 0.5):
+        if mode == "parametric":
+            d = dict(CASES)["multi-c0-0.4--0.3"]
+            d = type(d).from_buffer_copy(d)
+        else:
+            d = abi.BlendData.uniform(blend_cases.M, 50.0)
+            if mode == "disabled":
+                d.mask_mode = 0
+        d.details = details
+        h_ = hc.hip()
+        da, db = lib.DeviceBuffer.from_numpy(0, a), lib.DeviceBuffer.from_numpy(0, b)
+        rc = h_.dt_hip_develop_blend_process(0, C.byref(abi.Piece.make(w, h)), C.byref(d), da.ptr, db.ptr)
+        assert rc == 0, h_.dt_hip_last_error()
+        assert h_.dt_hip_finish(0) == 1
+        outs.append(db.to_numpy(b.shape, np.float32).view(np.uint32))
+    assert np.array_equal(outs[0], outs[1])
 
 
 # ---- drawn / raster masks and the details threshold: the host-rendered form mask (blend.c:740-790, :1278-1325) -------

@@ -7,9 +7,11 @@ non-local means, XCD-rotated launches at real widths, tile grids with thousands 
 
   config 2   6000 x 4000   light pipe (rawprepare ... RCD ... filmic ... u16)
   config 2'  6000 x 4000   the same with AMaZE instead of RCD
-  config 3   9504 x 6336   + denoise (profiled) wavelets + diffuse or sharpen + non-local means in Lab
-  metric    11648 x 8736   light pipe                            (what bench.py's `value` is quoted on)
-  config 4  11648 x 8736   config 3's modules, the frame cut into 8 row bands run in lockstep
+  config 3   9504 x 6336   + denoise (profiled) wavelets + diffuse or sharpen + non-local means and local contrast
+                           (bilateral grid) in Lab: the FULL pipe
+  light     11648 x 8736   light pipe                            (bench.py's `config.light_pipe`)
+  metric /  11648 x 8736   the full pipe (what bench.py's `value` is quoted on), unsplit AND cut into 8 row bands run in
+  config 4                 lockstep (the bilateral grid relayed band to band)
 
 each compared word for word (RGBA u16, the exported buffer) with the oracle's module-by-module chain on the
 same synthetic mosaic.  The oracle (oracle/liboracle.so) is OpenMP code whose results do not depend on the
@@ -65,7 +67,7 @@ def _nodes(which, w, h, lut_ptr, lut):
         return pipe.light_pipe_nodes(w, h, lut_ptr, float(lut[0]), coeffs, with_filmic=True, filmic=filmic.default_data(),
                                      demosaic_method=abi.DT_HIP_DEMOSAIC_AMAZE)
     return pipe.denoise_pipe_nodes(w, h, lut_ptr, float(lut[0]), coeffs, filmic=filmic.default_data(),
-                                   diffuse_iterations=2, with_nlmeans=True, with_bilat=False)
+                                   diffuse_iterations=2, with_nlmeans=True, with_bilat=True)
 
 
 def oracle_chain(nodes, raw, w, h):
@@ -165,10 +167,11 @@ def test_config3_full_pipe_60MP_equals_the_oracle():
     _case("denoise", "60MP", host_gib=48)
 
 
-def test_metric_light_pipe_100MP_equals_the_oracle():
+def test_light_pipe_100MP_equals_the_oracle():
     _case("light", "100MP", host_gib=16)
 
 
-def test_config4_full_pipe_100MP_in_8_row_bands_equals_the_oracle():
-    """the unsplit device run, the 8-band lockstep run and the oracle: three times the same 814 MB"""
+def test_metric_full_pipe_100MP_whole_and_in_8_row_bands_equals_the_oracle():
+    """the unsplit device run (bench.py's timed workload), the 8-band lockstep run (config 4) and the oracle: three
+    times the same 814 MB"""
     _case("denoise", "100MP", bands=8, host_gib=80)
