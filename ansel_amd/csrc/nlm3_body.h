@@ -1,0 +1,517 @@
+// nlm3_body.h -- the non-local-means chunk kernel for interior chunks, third version: every wave of the workgroup has ONE
+// role for the whole chunk, and what a role reads again for the next patch offset stays in its registers.
+//
+// Same arithmetic as nlm2_body.h (reference src/pixel/nlmeans_core.c:315-532): per chunk and patch offset the terms of the
+// column-sum recurrence (A1), the recurrence down the rows (A2), the row-sum recurrence across the columns (B), the weight
+// 2^-x and the accumulation (C); offset p lives in table p & 3 from its A1 (stage p) to its C (stage p + 3), one
+// workgroup barrier per stage.  What the second version's counters said (profiles/r02_pmc_sq_100MP.txt):
+// the LDS pipe is the bound -- 2 cycles per 4- or 8-byte read of a wave, 4 per 4-byte write, and a wave on its own issues
+// them at a fifth of that rate -- with 262 KB through it per offset; the two recurrences, on one and two waves, waited for
+// 149 and 112 LDS instructions each.  Here:
+//
+//   * offsets come in rows of equal dy and consecutive dx (the reference's order whenever `scattering` is 0), so the
+//     pixel a lane compares with / accumulates for offset (dy, dx + 1) is the right-hand neighbour of the one for (dy, dx):
+//       - an A1 lane owns TWO adjacent table columns and a chain of <= MSEG + 1 rows one patch height apart.  The chain's
+//         own pixels never change: registers for the whole chunk.  The shifted pixels slide: one new pixel per row and
+//         offset (a ring of two, the loop unrolled by two), instead of four pixel reads per row;
+//       - a C lane owns NPXL adjacent pixels of a row: one new pixel per offset (a ring of NPXL, the loop unrolled by
+//         NPXL) instead of NPXL, and no accumulator slot is ever empty (7 waves x 64 lanes = 56 rows x 8 lanes);
+//     the window is stored de-interleaved by column parity so that lanes two columns apart read adjacent words;
+//   * A2 fetches its whole column (<= 56 terms + the 5 first-row terms the A1 lanes of the chain heads leave in a side
+//     table instead of recomputing them) in ONE round trip, B its whole row as 19 ds_read_b128 and stores it as 18
+//     ds_write_b128 (pitch 84: rows 16-byte aligned, sixteen lanes one row apart hit 64 different banks);
+//   * waves are dealt to roles so that every SIMD (waves w, w + 4, w + 8, w + 12 share one) carries the same load:
+//     A2 A2 B A1 | A1 A1 A1 A1 | C C A1 C | C C C C.
+//
+// Written against the same environment as nlm2_body.h and compiled for the host by tests/native/nlm2_host.cpp.
+#pragma once
+
+#include "nlm2_body.h"
+
+#include <type_traits>
+
+#define NL3_THREADS 1024
+#define NL3_TP 84  // table pitch in floats
+#define NL3_XO 3   // table slot x (frame column left - P - 1 + x) is stored at x + 3: slot 1, the first that is read, is 16-byte aligned
+#define NL3_FP 80  // pitch of the first-row side table (one row per row of the patch)
+#define NL3_WPH 46 // half the window pitch: pixels per column-parity plane of a window row (window <= 92 columns)
+#define NL3_A1_LANES 384
+
+namespace nlm3
+{
+using nlm2::f2;
+using nlm2::imin;
+
+struct alignas(16) f4
+{
+  float x, y, z, w;
+};
+
+// 16- and 8-byte LDS accesses: on the device through a pointer to the aligned struct (what makes the compiler emit
+// ds_read_b128 / ds_read_b64 instead of pairs of dwords), on the host as copies
+#ifdef __HIPCC__
+NLM2_FN f4 ld4(const float *const p) { return *reinterpret_cast<const f4 *>(p); }
+NLM2_FN void st4(float *const p, const f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+NLM2_FN f2 ld2(const float *const p) { return *reinterpret_cast<const f2 *>(p); }
+NLM2_FN void st2(float *const p, const f2 v) { *reinterpret_cast<f2 *>(p) = v; }
+#else
+NLM2_FN f4 ld4(const float *const p)
+{
+  f4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+NLM2_FN void st4(float *const p, const f4 v) { __builtin_memcpy(p, &v, 16); }
+NLM2_FN f2 ld2(const float *const p)
+{
+  f2 v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+NLM2_FN void st2(float *const p, const f2 v) { __builtin_memcpy(p, &v, 8); }
+#endif
+
+// LDS floats of one workgroup: four tables, two first-row side tables, the window (x, y as 8-byte words + z)
+inline size_t lds_floats(const int chk_h, const int reach)
+{
+  return (size_t)4 * chk_h * NL3_TP + 2 * 5 * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
+}
+
+// rows a variant takes: NPXL pixels per C lane on 72 / NPXL... lanes per row, 448 C lanes
+template <int NPXL> constexpr int max_rows() { return NPXL == 9 ? 56 : 74; }
+
+// can this body take the chunk grid?  (the launch and the host harness ask the same question)
+template <int NPXL, int MSEG> inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach)
+{
+  constexpr int S = 5, LPR = (72 + NPXL - 1) / NPXL;
+  if(radius != 2 || chk_w > 72 || (chk_w & 1) || chk_w + 2 * reach > 2 * NL3_WPH || chk_h > max_rows<NPXL>() || chk_h < 2 * S) return false;
+  if(LPR * chk_h > 448) return false;
+  const int ncp = (chk_w + 4) / 2;
+  if(ncp * S > NL3_A1_LANES) return false;
+  const int nseg = NL3_A1_LANES / (ncp * S), m0 = (chk_h - 2) / S + 1;
+  return (m0 + nseg - 1) / nseg <= MSEG;
+}
+
+// the offsets as rows of consecutive column shifts: ndx per row, every row starting at the same column shift
+template <class I2> inline bool regular_grid(const I2 *const patches, const int n, int *const ndx_out)
+{
+  if(n < 1) return false;
+  int ndx = 1;
+  while(ndx < n && patches[ndx].x == patches[0].x) ndx++;
+  if(n % ndx) return false;
+  for(int p = 0; p < n; p++)
+  {
+    const int row = p / ndx, j = p - row * ndx;
+    if(patches[p].x != patches[row * ndx].x || patches[p].y != patches[0].y + j) return false;
+  }
+  *ndx_out = ndx;
+  return true;
+}
+
+// Env: tid(), bid(), lds(), sync(), cvt_i32_sat(), int_as_float().  Args: nlm_args of nlmeans.hip.
+template <int NPXL, int MSEG, class Env, class Args, class F4, class I2>
+NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
+                  const int ndx)
+{
+  constexpr int P = 2, S = 2 * P + 1, TP = NL3_TP, XO = NL3_XO, FP = NL3_FP, WPH = NL3_WPH;
+  constexpr int MAXCH = max_rows<NPXL>();
+  constexpr int LPR = (72 + NPXL - 1) / NPXL; // C lanes per chunk row
+  const int tid = env.tid();
+  const int W = a.W, H = a.H;
+  const int cy_launch = env.bid() / a.nchx, cx = env.bid() - cy_launch * a.nchx;
+  const int cy = cy_launch + a.cy0;
+  const int top = cy * a.chk_h, left = cx * a.chk_w;
+  const int bot = imin(top + a.chk_h, H), right = imin(left + a.chk_w, W);
+  const int ch = bot - top, cw = right - left;
+  const int reach = a.reach;
+  // interior: the chunk is whole and no patch of any offset reaches past the frame (uniform, before any barrier)
+  if(!(top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w)) return;
+
+  float *const lds = env.lds();
+  const int tabsz = ch * TP;
+  const int wh = ch + 2 * reach;
+  const int n = a.npatch, ndy = n / ndx;
+  float *const Fb = lds + 4 * tabsz;            // [2][S][FP]
+  float *const winf = Fb + 2 * S * FP;
+  float *const XY = winf;                       // [wh][2][WPH] 8-byte words
+  float *const Z = winf + 2 * (wh * 2 * WPH);   // [wh][2][WPH]
+  const int r0 = top - reach, c0 = left - reach;
+  const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
+  const int ww = cw + 2 * reach; // window columns that exist
+
+  for(int i = tid; i < wh * 2 * WPH; i += NL3_THREADS)
+  {
+    const int wy = i / (2 * WPH), rem = i - wy * (2 * WPH);
+    const int par = rem / WPH, h = rem - par * WPH;
+    const int wx = 2 * h + par;
+    const int r = r0 + wy, c = c0 + wx; // r is inside the frame for an interior chunk
+    F4 v;
+    v.x = v.y = v.z = v.w = 0.0f;
+    if(wx < ww && c < W) v = in[(long)r * W + c];
+    f2 xy;
+    xy.x = v.x;
+    xy.y = v.y;
+    st2(XY + 2 * i, xy);
+    Z[i] = v.z;
+  }
+  env.sync();
+  // window pixel (wy, wx): index of its words
+  auto widx = [&](const int wy, const int wx) { return (wy * 2 + (wx & 1)) * WPH + (wx >> 1); };
+
+  const int w = tid >> 6, lane = tid & 63;
+  // ---------------------------------------------------------------------------------------------------------------------
+  if(w == 3 || (w >= 4 && w <= 7) || w == 10)
+  {
+    // ---- A1: the terms of the column recurrence (nlmeans_core.c:437-488) for table rows 1.., and the five squared
+    //      differences the first table row sums (init_column_sums(), :208-262)
+    const int ai = w == 3 ? 0 : (w == 10 ? 5 : w - 3);
+    const int u = ai * 64 + lane;
+    const int ncp = (cw + 2 * P) / 2;
+    const int nseg = NL3_A1_LANES / (ncp * S);
+    const int m0 = (ch - 2) / S + 1;
+    const int mseg = (m0 + nseg - 1) / nseg;
+    const bool valid = u < ncp * S * nseg;
+    const int g = u % ncp, q = u / ncp;
+    const int k = q % S, seg = q / S;
+    const int mk = (ch - 2 - k >= 0) ? (ch - 2 - k) / S + 1 : 0;
+    const int j0 = seg * mseg;
+    const int left_over = mk - j0;
+    const int jn = !valid ? -1 : (left_over < 0 ? 0 : (left_over > mseg ? mseg : left_over)); // terms; rows 0 .. jn are read
+    const bool head = valid && seg == 0; // the chain starts at row k of the patch around the chunk's first row
+    const int wr0 = reach - P + k + j0 * S;  // window row of the chain's first row (the one leaving at its first term)
+    const int x0 = 1 + 2 * g;                // table slots x0, x0 + 1
+    const int wc0 = reach - P - 1 + x0;      // window column of slot x0
+    const int toff = (1 + k + j0 * S) * TP + XO + x0; // first term of the chain in a table
+    const int foff = k * FP + XO + x0;
+    // the chain's own pixels
+    float ox[MSEG + 1][2], oy[MSEG + 1][2], oz[MSEG + 1][2];
+#pragma unroll
+    for(int i = 0; i <= MSEG; i++)
+#pragma unroll
+      for(int c = 0; c < 2; c++)
+      {
+        ox[i][c] = oy[i][c] = oz[i][c] = 0.0f;
+        if(i <= jn)
+        {
+          const int wi = widx(wr0 + i * S, wc0 + c);
+          const f2 v = ld2(XY + 2 * wi);
+          ox[i][c] = v.x;
+          oy[i][c] = v.y;
+          oz[i][c] = Z[wi];
+        }
+      }
+    // the shifted pixels: ring slot of column c at step j of a row of offsets is (c + j) & 1
+    float sx[MSEG + 1][2], sy[MSEG + 1][2], sz[MSEG + 1][2];
+#pragma unroll
+    for(int i = 0; i <= MSEG; i++) sx[i][0] = sx[i][1] = sy[i][0] = sy[i][1] = sz[i][0] = sz[i][1] = 0.0f;
+
+    auto step = [&](auto ph_tag, const int p, const bool first, const int dy, const int dx) {
+      constexpr int PH = decltype(ph_tag)::value;
+      float *const T = lds + (p & 3) * tabsz;
+      float *const F = Fb + (p & 1) * S * FP;
+      if(first)
+      {
+        // a new row of offsets: both columns of every row of the chain
+#pragma unroll
+        for(int i = 0; i <= MSEG; i++)
+          if(i <= jn)
+          {
+#pragma unroll
+            for(int c = 0; c < 2; c++)
+            {
+              const int wi = widx(wr0 + i * S + dy, wc0 + c + dx);
+              const f2 v = ld2(XY + 2 * wi);
+              sx[i][c] = v.x;
+              sy[i][c] = v.y;
+              sz[i][c] = Z[wi];
+            }
+          }
+      }
+      else
+      {
+        // the column that slides in: c = 1, ring slot (1 + PH) & 1
+        constexpr int SL = (1 + PH) & 1;
+        const int wx = wc0 + 1 + dx;
+        const int base = (wx & 1) * WPH + (wx >> 1);
+#pragma unroll
+        for(int i = 0; i <= MSEG; i++)
+          if(i <= jn)
+          {
+            const int wi = (wr0 + i * S + dy) * 2 * WPH + base;
+            const f2 v = ld2(XY + 2 * wi);
+            sx[i][SL] = v.x;
+            sy[i][SL] = v.y;
+            sz[i][SL] = Z[wi];
+          }
+      }
+      float px2[2], py2[2], pz2[2];
+#pragma unroll
+      for(int c = 0; c < 2; c++)
+      {
+        const int sl = (c + PH) & 1;
+        const float dx_ = ox[0][c] - sx[0][sl], dy_ = oy[0][c] - sy[0][sl], dz_ = oz[0][c] - sz[0][sl];
+        px2[c] = dx_ * dx_;
+        py2[c] = dy_ * dy_;
+        pz2[c] = dz_ * dz_;
+      }
+      if(head)
+      {
+        f2 d;
+        d.x = px2[0] * n0 + py2[0] * n1 + pz2[0] * n2;
+        d.y = px2[1] * n0 + py2[1] * n1 + pz2[1] * n2;
+        st2(F + foff, d);
+      }
+#pragma unroll
+      for(int i = 1; i <= MSEG; i++)
+        if(i <= jn)
+        {
+          f2 t;
+          float nx2[2], ny2[2], nz2[2];
+#pragma unroll
+          for(int c = 0; c < 2; c++)
+          {
+            const int sl = (c + PH) & 1;
+            const float dx_ = ox[i][c] - sx[i][sl], dy_ = oy[i][c] - sy[i][sl], dz_ = oz[i][c] - sz[i][sl];
+            nx2[c] = dx_ * dx_;
+            ny2[c] = dy_ * dy_;
+            nz2[c] = dz_ * dz_;
+          }
+          t.x = ((nx2[0] - px2[0]) * n0 + (ny2[0] - py2[0]) * n1) + (nz2[0] - pz2[0]) * n2;
+          t.y = ((nx2[1] - px2[1]) * n0 + (ny2[1] - py2[1]) * n1) + (nz2[1] - pz2[1]) * n2;
+          st2(T + toff + (i - 1) * S * TP, t);
+#pragma unroll
+          for(int c = 0; c < 2; c++)
+          {
+            px2[c] = nx2[c];
+            py2[c] = ny2[c];
+            pz2[c] = nz2[c];
+          }
+        }
+    };
+    for(int dyi = 0; dyi < ndy; dyi++)
+    {
+      const int dy = patches[dyi * ndx].x, dx0 = patches[dyi * ndx].y;
+      for(int jb = 0; jb < ndx; jb += 2)
+      {
+        step(std::integral_constant<int, 0>(), dyi * ndx + jb, jb == 0, dy, dx0 + jb);
+        env.sync();
+        if(jb + 1 < ndx)
+        {
+          step(std::integral_constant<int, 1>(), dyi * ndx + jb + 1, false, dy, dx0 + jb + 1);
+          env.sync();
+        }
+      }
+    }
+    env.sync();
+    env.sync();
+    env.sync();
+    return;
+  }
+  // ---------------------------------------------------------------------------------------------------------------------
+  if(w < 2)
+  {
+    // ---- A2: the column recurrence, one lane per table column, the whole column fetched at once
+    const int x = 1 + w * 64 + lane;
+    const bool active = x <= cw + 2 * P;
+    env.sync();
+    for(int p = 0; p < n; p++)
+    {
+      if(active)
+      {
+        float *const col = lds + (p & 3) * tabsz + XO + x;
+        const float *const F = Fb + (p & 1) * S * FP + XO + x;
+        float f[S], term[MAXCH];
+#pragma unroll
+        for(int r = 0; r < S; r++) f[r] = F[r * FP];
+#pragma unroll
+        for(int t = 1; t < MAXCH; t++)
+        {
+          term[t] = 0.0f;
+          if(t < ch) term[t] = col[t * TP];
+        }
+        float v = 0.0f;
+#pragma unroll
+        for(int r = 0; r < S; r++) v += f[r];
+        col[0] = v;
+#pragma unroll
+        for(int t = 1; t < MAXCH; t++)
+          if(t < ch)
+          {
+            v = v + term[t];
+            col[t * TP] = v;
+          }
+      }
+      env.sync();
+    }
+    env.sync();
+    env.sync();
+    return;
+  }
+  // ---------------------------------------------------------------------------------------------------------------------
+  if(w == 2)
+  {
+    // ---- B: the sliding row sum (:405-415), one lane per table row: the row fetched as 19 x 16 bytes, the distortion of
+    //      chunk column c stored at slot c + 1 (18 x 16 bytes)
+    const bool active = lane < ch;
+    env.sync();
+    env.sync();
+    for(int p = 0; p < n; p++)
+    {
+      if(active)
+      {
+        float *const rowp = lds + (p & 3) * tabsz + lane * TP;
+        float cs[80]; // cs[x + XO] = slot x
+#pragma unroll
+        for(int b = 4; b < 80; b += 4)
+        {
+          const f4 v = ld4(rowp + b);
+          cs[b] = v.x;
+          cs[b + 1] = v.y;
+          cs[b + 2] = v.z;
+          cs[b + 3] = v.w;
+        }
+        cs[XO] = 0.0f; // slot 0: the column in front of every patch is never summed (init_column_sums())
+        float distortion = 0.0f;
+#pragma unroll
+        for(int kk = 1; kk < S; kk++) distortion += cs[XO + kk]; // columns left - P .. left + P - 1
+        float d[72];
+#pragma unroll
+        for(int c = 0; c < 72; c++)
+        {
+          distortion = distortion + (cs[XO + c + S] - cs[XO + c]);
+          d[c] = distortion;
+        }
+#pragma unroll
+        for(int b = 0; b < 72; b += 4)
+        {
+          f4 v;
+          v.x = d[b];
+          v.y = d[b + 1];
+          v.z = d[b + 2];
+          v.w = d[b + 3];
+          st4(rowp + 4 + b, v);
+        }
+      }
+      env.sync();
+    }
+    env.sync();
+    return;
+  }
+  // ---------------------------------------------------------------------------------------------------------------------
+  {
+    // ---- C: weights and accumulation (:416-436); center_weight < 0: w = 2^-(distortion * sharpness)
+    const int ci = w == 8 ? 0 : (w == 9 ? 1 : w - 9);
+    const int cl = ci * 64 + lane;
+    const int r = cl / LPR, j8 = cl - r * LPR;
+    const int cb = NPXL * j8; // first chunk column of the lane
+    const bool active = r < ch && cb < cw;
+    float accx[NPXL], accy[NPXL], accz[NPXL], accw[NPXL];
+    float qx[NPXL], qy[NPXL], qz[NPXL];
+#pragma unroll
+    for(int i = 0; i < NPXL; i++) accx[i] = accy[i] = accz[i] = accw[i] = qx[i] = qy[i] = qz[i] = 0.0f;
+    const int doff = r * TP + 4 + cb;
+    const float sharp = a.sharpness;
+
+    auto step = [&](auto m_tag, const int p, const bool first, const int dy, const int dx) {
+      constexpr int M = decltype(m_tag)::value; // step of the row of offsets modulo NPXL: pixel i sits in ring slot (i + M) % NPXL
+      const float *const T = lds + (p & 3) * tabsz + doff;
+      float dist[NPXL];
+#pragma unroll
+      for(int i = 0; i < NPXL; i++) dist[i] = T[i];
+      const int wy = reach + r + dy;
+      if(first)
+      {
+#pragma unroll
+        for(int i = 0; i < NPXL; i++)
+        {
+          const int wi = widx(wy, reach + cb + i + dx);
+          const f2 v = ld2(XY + 2 * wi);
+          qx[i] = v.x;
+          qy[i] = v.y;
+          qz[i] = Z[wi];
+        }
+      }
+      else
+      {
+        constexpr int SL = (NPXL - 1 + M) % NPXL;
+        const int wi = widx(wy, reach + cb + NPXL - 1 + dx);
+        const f2 v = ld2(XY + 2 * wi);
+        qx[SL] = v.x;
+        qy[SL] = v.y;
+        qz[SL] = Z[wi];
+      }
+#pragma unroll
+      for(int i = 0; i < NPXL; i++)
+      {
+        const int sl = (i + M) % NPXL;
+        const float wgt = nlm2::mexp2<Env>(dist[i] * sharp);
+        accx[i] = accx[i] + qx[sl] * wgt;
+        accy[i] = accy[i] + qy[sl] * wgt;
+        accz[i] = accz[i] + qz[sl] * wgt;
+        accw[i] = accw[i] + 1.0f * wgt;
+      }
+    };
+    env.sync();
+    env.sync();
+    env.sync();
+    for(int dyi = 0; dyi < ndy; dyi++)
+    {
+      const int dy = patches[dyi * ndx].x, dx0 = patches[dyi * ndx].y;
+      for(int jb = 0; jb < ndx; jb += NPXL)
+      {
+        auto run = [&](auto m_tag) {
+          constexpr int M = decltype(m_tag)::value;
+          if(jb + M < ndx)
+          {
+            if(active) step(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
+            env.sync();
+          }
+        };
+        run(std::integral_constant<int, 0>());
+        run(std::integral_constant<int, 1>());
+        run(std::integral_constant<int, 2>());
+        run(std::integral_constant<int, 3>());
+        run(std::integral_constant<int, 4>());
+        run(std::integral_constant<int, 5>());
+        run(std::integral_constant<int, 6>());
+        run(std::integral_constant<int, 7>());
+        run(std::integral_constant<int, 8>());
+        if constexpr(NPXL > 9)
+        {
+          run(std::integral_constant<int, 9>());
+          run(std::integral_constant<int, 10>());
+          run(std::integral_constant<int, 11>());
+        }
+      }
+    }
+    // ---- normalise, blend (:490-521)
+    if(!active) return;
+    const int row = top + r;
+    if(row < a.out_row0 || row >= a.out_row1) return;
+#pragma unroll
+    for(int i = 0; i < NPXL; i++)
+    {
+      if(cb + i >= cw) continue;
+      const long o = (long)row * W + left + cb + i;
+      F4 res;
+      if(a.skip_blend)
+      {
+        res.x = accx[i] / accw[i];
+        res.y = accy[i] / accw[i];
+        res.z = accz[i] / accw[i];
+        res.w = accw[i] / accw[i];
+      }
+      else
+      {
+        const F4 ip = in[o];
+        res.x = (ip.x * (1.0f - a.luma)) + (accx[i] / accw[i] * a.luma);
+        res.y = (ip.y * (1.0f - a.chroma)) + (accy[i] / accw[i] * a.chroma);
+        res.z = (ip.z * (1.0f - a.chroma)) + (accz[i] / accw[i] * a.chroma);
+        res.w = (ip.w * 0.0f) + (accw[i] / accw[i] * 1.0f);
+      }
+      out[o] = res;
+    }
+  }
+}
+
+} // namespace nlm3

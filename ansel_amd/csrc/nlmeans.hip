@@ -23,6 +23,7 @@
 #include "hip_common.h"
 #include "nlmeans_core_params.h"
 #include "nlm2_body.h"
+#include "nlm3_body.h"
 
 #include <math.h>
 #include <algorithm>
@@ -842,6 +843,26 @@ __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2_timed(const float4 
   nlm2::body<2, NL2_WP_TIGHT, NL2_TP_TIGHT, true>(env, in, out, a, patches);
 }
 
+// the third version of the interior-chunk kernel (nlm3_body.h): offsets in rows of consecutive column shifts, patch
+// radius 2, chunks of at most 56 rows; same launch shape, border chunks first with the pipelined body
+template <int NPXL, int MSEG>
+__global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                             const nlm_args a, const int2 *__restrict__ patches,
+                                                             const int *__restrict__ order, const int n_border, const int ndx)
+{
+  extern __shared__ float lds[];
+  const int chunk = order[blockIdx.x];
+  if(blockIdx.x < n_border)
+  {
+    pipelined_body(chunk, lds, in, out, a, patches);
+    return;
+  }
+  nlm2_device_env env;
+  env.lds_ = lds;
+  env.chunk_ = chunk;
+  nlm3::body<NPXL, MSEG>(env, in, out, a, patches, ndx);
+}
+
 typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
 template <int P> nlm2_kernel_t nlm2_kernel_of(const bool tight, const bool deep)
 {
@@ -999,7 +1020,13 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     const int nseg = NL2_PAR / (ncol2 * S2), m0 = (a.chk_h - 2) / S2 + 1;
     v2 = (m0 + nseg - 1) / nseg <= NL2_MSEG;
   }
-  static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS, "nlm_chunks_v2 shares the launch shape of nlm_chunks_pipelined");
+  // the third version where it applies (nlm3_body.h): the module's defaults on frames whose chunks have at most 56 rows
+  int ndx3 = 0;
+  const bool v3 = v2 && nlm3::fits<9, 6>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
+                  && getenv("ANSEL_HIP_NLM_V2") == nullptr;
+  const size_t v3_bytes = std::max(nlm3::lds_floats(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
+  static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS && NL3_THREADS == NLM_THREADS,
+                "nlm_chunks_v2 / _v3 share the launch shape of nlm_chunks_pipelined");
   nlm2_kernel_t k2 = nullptr;
   const int nchunks = a.nchx * nchy;
   // the launch order of the chunks: those a patch can leave the frame from (the pipelined body) first
@@ -1045,7 +1072,13 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   {
     launch_scope ls(devid, "nlm_chunks");
     const unsigned grid = (unsigned)nchunks;
-    if(v2)
+    if(v3 && v3_bytes <= 160 * 1024)
+    {
+      const auto k3 = nlm_chunks_v3<9, 6>;
+      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v3_bytes));
+      k3<<<grid, NL3_THREADS, v3_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3);
+    }
+    else if(v2)
       k2<<<grid, NL2_THREADS, v2_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border);
     else if(pipelined)
       nlm_chunks_pipelined<<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);

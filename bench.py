@@ -60,7 +60,7 @@ def parse():
                     help="skip the PCIe-inclusive host-to-host measurements (--pipe light only; never `value`)")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per module (A/B against the fused executor)")
     ap.add_argument("--cpu-sample", default=None,
-                    help="frame size of the bounded CPU sample (default: 3000x2000 for the full pipe, 24MP for the light one)")
+                    help="frame size of the bounded CPU sample (default: 4000x3000 for the full pipe, 24MP for the light one)")
     ap.add_argument("--pipe", default="full", choices=("full", "light", "denoise"),
                     help="full = the metric's workload: config 3's modules (denoise (profiled) wavelets, diffuse or sharpen, "
                          "non-local means) + local contrast (bilateral grid); light = BASELINE.json config 2; "
@@ -158,12 +158,14 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
     w, h = frame_size(size_name)
     nodes = build_pipe(w, h, lut.ctypes.data, lut, with_filmic, which)
     raw, cfa, rgb, out16 = buffers(w, h)
-    counts = sorted({c for c in (16, 32, 64, 128, ncpu) if c <= ncpu} | {ncpu})
+    quota = cgroup_cpu_quota()
+    first = int(round(quota)) if quota and quota >= 1 else 32  # a container with a CPU quota runs best on that many threads
+    counts = sorted({c for c in (16, 32, 64, 128, ncpu, first) if c <= ncpu} | {ncpu})
     sweep = {}
     t_budget = time.time() + 25.0
     # 32 first (the count that has won every sweep on the 256-thread hosts), then outwards: the slow all-threads pass
     # comes last and is skipped when the budget is spent
-    for c in sorted(counts, key=lambda c: (abs(c - 32), c)):
+    for c in sorted(counts, key=lambda c: (abs(c - first), c)):
         set_threads(c)
         _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16)  # warm-up: page in, spin up the team
         times = []
@@ -195,7 +197,7 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
             sample = ("%d x %d RGGB frame (the device's), same module chain, one pass after a warm-up, %.2f s; thread "
                       "count chosen on a %d x %d sample" % (dw, dh, t, w, h))
     return {"value": round(value, 3), "unit": "MPix/s", "cores": best_c, "kind": kind, "sample": sample,
-            "host_threads": ncpu,
+            "host_threads": ncpu, "cpu_quota": quota,
             "binding": "OMP_PROC_BIND=%s OMP_PLACES=%s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
             "thread_sweep_mpix_s": {str(c): round(w * h / 1e6 / t, 3) for c, t in sorted(sweep.items())}}
 
@@ -653,7 +655,7 @@ def main():
             line["verified"] = verify["verified"]
             line["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or ("24MP" if args.pipe == "light" else "3000x2000")
+            sample = args.cpu_sample or ("24MP" if args.pipe == "light" else "4000x3000")
             cb = cpu_baseline_in_child(sample, with_filmic, args.pipe, (width, height))
             if cb is not None:
                 line["cpu_baseline"] = cb

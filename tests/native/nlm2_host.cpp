@@ -9,10 +9,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <thread>
 #include <vector>
 
 #include "nlm2_body.h"
+#include "nlm3_body.h"
 
 namespace
 {
@@ -176,4 +178,80 @@ extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_
   else RUN(3);
 #undef RUN
   return (tight ? 1 : 0) | (deep ? 2 : 0); /* which path ran */
+}
+
+// ---- the third version (ansel_amd/csrc/nlm3_body.h, launched as nlm_chunks_v3): same harness.  Returns 1 when it ran,
+//      0 when the configuration is not one it takes (the launch falls back to the second version then), < 0 on error.
+namespace
+{
+template <int NPXL, int MSEG>
+void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats, const int ndx)
+{
+  std::vector<float> lds(lds_floats + 4096, 0.0f);
+  float *base = lds.data();
+  while((uintptr_t)base & 15) base++; // the kernel's 16-byte LDS accesses
+  std::barrier<> bar(NL3_THREADS);
+  std::vector<std::thread> pool;
+  pool.reserve(NL3_THREADS);
+  for(int t = 0; t < NL3_THREADS; t++)
+    pool.emplace_back([&, t]() {
+      for(int b = 0; b < nchunks; b++)
+      {
+        HostEnv env{ t, b, base, &bar };
+        nlm3::body<NPXL, MSEG>(env, in, out, a, patches, ndx);
+        bar.arrive_and_wait();
+      }
+    });
+  for(auto &th : pool) th.join();
+}
+} // namespace
+
+extern "C" int nlm3_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                             int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                             float luma, float chroma, int *interior_chunks)
+{
+  std::vector<I2> patches;
+  int max_shift = 0;
+  for(int ri = -search_radius; ri <= search_radius; ri++)
+    for(int ci = -search_radius; ci <= search_radius; ci++)
+    {
+      const int r = scatter(scale, scattering, ri, ci), c = scatter(scale, scattering, ci, ri);
+      patches.push_back(I2{ r, c });
+      max_shift = std::max(max_shift, std::max(abs(r), abs(c)));
+    }
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.W = W;
+  a.H = H;
+  a.chk_w = chk_w;
+  a.chk_h = chk_h;
+  a.nchx = (W + chk_w - 1) / chk_w;
+  const int nchy = (H + chk_h - 1) / chk_h;
+  a.radius = patch_radius;
+  a.npatch = (int)patches.size();
+  a.sharpness = sharpness;
+  for(int k = 0; k < 3; k++) a.norm[k] = norm[k];
+  a.luma = luma;
+  a.chroma = chroma;
+  a.skip_blend = (luma == 1.0 && chroma == 1.0);
+  a.reach = patch_radius + 1 + max_shift;
+  a.cy0 = 0;
+  a.out_row0 = 0;
+  a.out_row1 = H;
+  int ndx = 0;
+  if(!nlm3::fits<9, 6>(chk_w, chk_h, patch_radius, a.reach) || !nlm3::regular_grid(patches.data(), a.npatch, &ndx)) return 0;
+  const size_t lds_floats = nlm3::lds_floats(chk_h, a.reach);
+  if(lds_floats * sizeof(float) > 160 * 1024) return 0;
+  int interior = 0;
+  for(int cy = 0; cy < nchy; cy++)
+    for(int cx = 0; cx < a.nchx; cx++)
+    {
+      const int top = cy * chk_h, left = cx * chk_w;
+      const int bot = std::min(top + chk_h, H), right = std::min(left + chk_w, W);
+      if(top >= a.reach && bot + a.reach <= H && left >= a.reach && right + a.reach <= W && bot - top == chk_h && right - left == chk_w)
+        interior++;
+    }
+  if(interior_chunks) *interior_chunks = interior;
+  run3<9, 6>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx);
+  return 1;
 }

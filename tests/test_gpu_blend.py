@@ -187,8 +187,14 @@ def test_blend_with_a_host_rendered_form_mask(cs, name, d):
     d.form_mask = None
     buf = lib.DeviceBuffer.from_numpy(0, b)
     din = lib.DeviceBuffer.from_numpy(0, a)
-    assert l.dt_hip_develop_blend_process(0, C.byref(piece), C.byref(d), din.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
-    assert b"form_mask" in l.dt_hip_last_error()
+    rc = l.dt_hip_develop_blend_process(0, C.byref(piece), C.byref(d), din.ptr, buf.ptr)
+    if d.mask_mode & (abi.MASK_SHAPE | abi.MASK_RASTER):
+        assert rc == abi.DT_HIP_INVALID_ARG
+        assert b"form_mask" in l.dt_hip_last_error()
+    else:
+        # a parametric-only blend whose details threshold has neither plane: the reference's _refine_with_detail_mask()
+        # returns silently without the raw detail mask (blend.c:379) -- the blend runs unrefined
+        assert rc == 0
     for x in (dform, buf, din):
         x.release()
 

@@ -50,6 +50,18 @@ def test_nlmeans(w, h, radius, strength, luma, chroma):
     assert float(np.abs(got[..., :3] - img[..., :3]).max()) > 1e-3
 
 
+@pytest.mark.parametrize("w,h,luma,chroma", [(330, 168, 0.5, 1.0), (260, 168, 1.0, 1.0), (170, 150, 0.3, 0.8), (1200, 560, 0.5, 1.0)])
+def test_nlmeans_third_version_chunk_grids(w, h, luma, chroma, monkeypatch):
+    """frames whose chunk grid the third version of the interior-chunk kernel takes (nlm3_body.h: chunks of at most 56
+    rows, the module's defaults); the same frames through the second version (ANSEL_HIP_NLM_V2) give the same words"""
+    img = _lab_image(w, h, 31)
+    d = abi.NlmeansData(2.0, 50.0, luma, chroma)
+    got3 = _check("nlmeans", abi.Piece.make(w, h), d, img)
+    monkeypatch.setenv("ANSEL_HIP_NLM_V2", "1")
+    got2 = hc.run_hip("dt_hip_iop_nlmeans_process", abi.Piece.make(w, h), d, img, img.shape)
+    assert np.array_equal(got2.view(np.uint32), got3.view(np.uint32))
+
+
 @pytest.mark.parametrize("radius", [5.0, 9.0])
 def test_nlmeans_large_patch_radius_takes_the_fallback_kernels(radius):
     """patch radii whose column-sum table is wider than the pipelined kernel's fixed pitch (P >= 5) run the

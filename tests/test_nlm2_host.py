@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tests", "native", "libnlm2_host.so")
 SRC = os.path.join(ROOT, "tests", "native", "nlm2_host.cpp")
 HDR = os.path.join(ROOT, "ansel_amd", "csrc", "nlm2_body.h")
+HDR3 = os.path.join(ROOT, "ansel_amd", "csrc", "nlm3_body.h")
 
 
 class NlmParams(C.Structure):  # oracle_nlm_params_t, oracle/src/nlmeans_core.h
@@ -27,7 +28,7 @@ class NlmParams(C.Structure):  # oracle_nlm_params_t, oracle/src/nlmeans_core.h
 
 @pytest.fixture(scope="module")
 def host_kernel():
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR3)):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
                                "-I" + os.path.join(ROOT, "ansel_amd", "csrc"), SRC, "-o", SO])
     return C.CDLL(SO)
@@ -83,3 +84,39 @@ def test_configurations_outside_the_kernel_are_refused(host_kernel):
     tail = (C.c_float(1.0), C.c_float(0.0), C.c_float(10.0), norm, C.c_float(1.0), C.c_float(1.0), None)
     assert host_kernel.nlm2_host_run(*args, 4, 2, *tail) == -1   # patch radius 4: the pipelined kernel's
     assert host_kernel.nlm2_host_run(*args, 2, 20, *tail) == -2  # 20 px of shift: the window does not fit the pitch
+
+
+# ---- the third version (nlm3_body.h, launched as nlm_chunks_v3): wave roles, pixels that slide through registers ----
+# (width, height, search radius, scattering, luma, chroma, expected chunk, interior chunks, does the body take it)
+CASES3 = [
+    (170, 150, 7, 0.0, 0.5, 1.0, (64, 51), 1, True),    # the module's defaults: 15 rows of 15 offsets; 64-column chunks
+    (260, 168, 7, 0.0, 1.0, 1.0, (72, 56), 2, True),   # the 100 MP frame's chunk: 72 x 56, no blend
+    (330, 168, 3, 0.0, 0.3, 0.8, (72, 56), 3, True),    # rows of 7 offsets (less than one ring turn of a C lane), 3 chunks
+    (256, 207, 2, 0.0, 0.5, 1.0, (72, 69), 2, False),   # 69-row chunks: the second version's
+    (300, 250, 2, 0.9, 0.5, 1.0, (64, 63), 6, False),   # scattered offsets are no rows of consecutive shifts
+]
+
+
+@pytest.mark.parametrize("w,h,K,scat,luma,chroma,chunk,n_interior,taken", CASES3)
+def test_third_version_on_the_host_equals_the_oracle(host_kernel, oracle_lib, w, h, K, scat, luma, chroma, chunk, n_interior, taken):
+    o = oracle_lib
+    P = 2
+    img = _lab(w, h, 5 + K)
+    p = NlmParams(scat, 1.0, luma, chroma, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    assert (cw, ch) == chunk
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm3_host_run(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(scat),
+                                   C.c_float(p.sharpness), p.norm, C.c_float(luma), C.c_float(chroma), C.byref(seen))
+    assert rc == (1 if taken else 0)
+    if not taken:
+        return
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    assert seen.value == n_interior
+    written = ~np.isnan(got[..., 0])
+    assert int(written.sum()) == n_interior * cw * ch
+    assert np.array_equal(got[written].view(np.uint32), want[written].view(np.uint32))

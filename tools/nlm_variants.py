@@ -31,18 +31,19 @@ def main():
     d = abi.NlmeansData(2.0, 50.0, 0.5, 1.0)
     # (label, environment) -- ANSEL_NLM2_VARIANT bits: 16 no A1, 32 no A2, 64 no B, 128 no C, 256 no first row
     names = {"v1 (nlm_chunks_pipelined)": {"ANSEL_HIP_NLM_V1": "1"},
-             "v2 shipped": {},
-             "v2 two tables": {"ANSEL_NLM2_DEEP": "0"},
-             "v2 loose layout": {"ANSEL_NLM2_LAYOUT": "loose"},
-             "no A1": {"ANSEL_NLM2_VARIANT": "16"}, "no A2": {"ANSEL_NLM2_VARIANT": "32"},
-             "no B": {"ANSEL_NLM2_VARIANT": "64"}, "no C": {"ANSEL_NLM2_VARIANT": "128"},
-             "no A2, no B": {"ANSEL_NLM2_VARIANT": "96"}, "no A1, no C": {"ANSEL_NLM2_VARIANT": "144"},
-             "only barriers": {"ANSEL_NLM2_VARIANT": str(16 + 32 + 64 + 128 + 256)},
-             "two tables, no A2, no B": {"ANSEL_NLM2_DEEP": "0", "ANSEL_NLM2_VARIANT": "96"},
-             "two tables, no A1, no C": {"ANSEL_NLM2_DEEP": "0", "ANSEL_NLM2_VARIANT": "144"}}
+             "v3 shipped (nlm3_body.h)": {},
+             "v2 (nlm2_body.h)": {"ANSEL_HIP_NLM_V2": "1"},
+             "v2 two tables": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_DEEP": "0"},
+             "v2 loose layout": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_LAYOUT": "loose"},
+             "no A1": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_VARIANT": "16"}, "no A2": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_VARIANT": "32"},
+             "no B": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_VARIANT": "64"}, "no C": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_VARIANT": "128"},
+             "no A2, no B": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_VARIANT": "96"}, "no A1, no C": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_VARIANT": "144"},
+             "only barriers": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_VARIANT": str(16 + 32 + 64 + 128 + 256)},
+             "two tables, no A2, no B": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_DEEP": "0", "ANSEL_NLM2_VARIANT": "96"},
+             "two tables, no A1, no C": {"ANSEL_HIP_NLM_V2": "1", "ANSEL_NLM2_DEEP": "0", "ANSEL_NLM2_VARIANT": "144"}}
     out = {"frame": [w, h], "variants": {}}
     for name, env in names.items():
-        for k in ("ANSEL_HIP_NLM_V1", "ANSEL_NLM2_VARIANT", "ANSEL_NLM2_DEEP", "ANSEL_NLM2_LAYOUT"):
+        for k in ("ANSEL_HIP_NLM_V1", "ANSEL_HIP_NLM_V2", "ANSEL_NLM2_VARIANT", "ANSEL_NLM2_DEEP", "ANSEL_NLM2_LAYOUT"):
             os.environ.pop(k, None)
         os.environ.update(env)
         times = []
