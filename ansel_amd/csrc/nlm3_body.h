@@ -71,14 +71,16 @@ NLM2_FN f2 ld2(const float *const p)
 NLM2_FN void st2(float *const p, const f2 v) { __builtin_memcpy(p, &v, 8); }
 #endif
 
-// LDS floats of one workgroup: four tables, two first-row side tables, the window (x, y as 8-byte words + z)
-inline size_t lds_floats(const int chk_h, const int reach)
-{
-  return (size_t)4 * chk_h * NL3_TP + 2 * 5 * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
-}
-
 // rows a variant takes: NPXL pixels per C lane on 72 / NPXL... lanes per row, 448 C lanes
 template <int NPXL> constexpr int max_rows() { return NPXL == 9 ? 56 : 74; }
+
+// LDS floats of one workgroup: four tables -- always of the variant's most rows, so that the column recurrence runs a
+// compile-time number of rows: those beyond the chunk hold garbage nobody reads --, two first-row side tables, the
+// window (x, y as 8-byte words + z)
+template <int NPXL> inline size_t lds_floats(const int chk_h, const int reach)
+{
+  return (size_t)4 * max_rows<NPXL>() * NL3_TP + 2 * 5 * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
+}
 
 // can this body take the chunk grid?  (the launch and the host harness ask the same question)
 template <int NPXL, int MSEG> inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach)
@@ -108,7 +110,19 @@ template <class I2> inline bool regular_grid(const I2 *const patches, const int 
   return true;
 }
 
-// Env: tid(), bid(), lds(), sync(), cvt_i32_sat(), int_as_float().  Args: nlm_args of nlmeans.hip.
+// the column recurrence over table rows T0 .. T1 - 1, every sum stored with ds_write_addtid_b32 (address = M0 + offset +
+// 4 * lane: no address register, 2 LDS cycles per store instead of 4); the row offset must be an immediate
+template <int T0, int T1, int ROWBYTES, class Env> struct column_chain
+{
+  static NLM2_FN void run(const Env &env, float *const wave_base, const int lane, float &v, const float *const term)
+  {
+    v = v + term[T0];
+    env.template st_addtid<T0 * ROWBYTES>(wave_base, lane, v);
+    if constexpr(T0 + 1 < T1) column_chain<T0 + 1, T1, ROWBYTES, Env>::run(env, wave_base, lane, v, term);
+  }
+};
+
+// Env: tid(), bid(), lds(), sync(), prio_high(), st_addtid<>(), cvt_i32_sat(), int_as_float().  Args: nlm_args of nlmeans.hip.
 template <int NPXL, int MSEG, class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
                   const int ndx)
@@ -128,13 +142,15 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   if(!(top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w)) return;
 
   float *const lds = env.lds();
-  const int tabsz = ch * TP;
+  constexpr int tabsz = MAXCH * TP;
   const int wh = ch + 2 * reach;
   const int n = a.npatch, ndy = n / ndx;
-  float *const Fb = lds + 4 * tabsz;            // [2][S][FP]
-  float *const winf = Fb + 2 * S * FP;
-  float *const XY = winf;                       // [wh][2][WPH] 8-byte words
-  float *const Z = winf + 2 * (wh * 2 * WPH);   // [wh][2][WPH]
+  // the window first, the tables behind it: an A1 lane whose chain is shorter than MSEG reads "rows" beyond its chain --
+  // beyond the window for the last chains -- and those words must exist (what they hold does not matter)
+  float *const XY = lds;                        // [wh][2][WPH] 8-byte words
+  float *const Z = XY + 2 * (wh * 2 * WPH);     // [wh][2][WPH]
+  float *const tab = Z + wh * 2 * WPH;          // [4][MAXCH][TP]
+  float *const Fb = tab + 4 * tabsz;            // [2][S][FP]
   const int r0 = top - reach, c0 = left - reach;
   const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
   const int ww = cw + 2 * reach; // window columns that exist
@@ -159,29 +175,38 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   auto widx = [&](const int wy, const int wx) { return (wy * 2 + (wx & 1)) * WPH + (wx >> 1); };
 
   const int w = tid >> 6, lane = tid & 63;
+  const int var = a.variant; // 0; timing experiments (ANSEL_NLM2_VARIANT): 16 / 32 / 64 / 128 switch A1 / A2 / B / C off (wrong results)
   // ---------------------------------------------------------------------------------------------------------------------
   if(w == 3 || (w >= 4 && w <= 7) || w == 10)
   {
     // ---- A1: the terms of the column recurrence (nlmeans_core.c:437-488) for table rows 1.., and the five squared
     //      differences the first table row sums (init_column_sums(), :208-262)
     const int ai = w == 3 ? 0 : (w == 10 ? 5 : w - 3);
-    const int u = ai * 64 + lane;
     const int ncp = (cw + 2 * P) / 2;
     const int nseg = NL3_A1_LANES / (ncp * S);
     const int m0 = (ch - 2) / S + 1;
     const int mseg = (m0 + nseg - 1) / nseg;
-    const bool valid = u < ncp * S * nseg;
+    // lanes beyond the last work item repeat it (same reads, the same values stored to the same words): no lane of the
+    // role is ever masked
+    const int u = imin(ai * 64 + lane, ncp * S * nseg - 1);
     const int g = u % ncp, q = u / ncp;
     const int k = q % S, seg = q / S;
     const int mk = (ch - 2 - k >= 0) ? (ch - 2 - k) / S + 1 : 0;
     const int j0 = seg * mseg;
     const int left_over = mk - j0;
-    const int jn = !valid ? -1 : (left_over < 0 ? 0 : (left_over > mseg ? mseg : left_over)); // terms; rows 0 .. jn are read
-    const bool head = valid && seg == 0; // the chain starts at row k of the patch around the chunk's first row
+    const int jn = left_over < 0 ? 0 : (left_over > mseg ? mseg : left_over); // terms of the chain; its rows are 0 .. jn
+    const bool head = seg == 0; // the chain starts at row k of the patch around the chunk's first row
     const int wr0 = reach - P + k + j0 * S;  // window row of the chain's first row (the one leaving at its first term)
     const int x0 = 1 + 2 * g;                // table slots x0, x0 + 1
     const int wc0 = reach - P - 1 + x0;      // window column of slot x0
-    const int toff = (1 + k + j0 * S) * TP + XO + x0; // first term of the chain in a table
+    // Every lane computes MSEG + 1 rows and MSEG terms whatever its chain's length -- no branch, no lane mask in the loop:
+    // a row beyond the chain reads whatever lies a patch height further down (the tables, behind the window's last rows:
+    // every row of every lane is base + a constant), a term beyond it is not stored; the first-row value of a lane that is
+    // no chain head goes to a word nobody reads (the first two words of the side table, in front of the slots).
+    constexpr int RSTEP = S * 2 * WPH; // words between two rows of a chain
+    const int rowbase = wr0 * 2 * WPH;
+    constexpr int DUMMY = 0;
+    const int toff0 = (1 + k + j0 * S) * TP + XO + x0; // the chain's first term in a table
     const int foff = k * FP + XO + x0;
     // the chain's own pixels
     float ox[MSEG + 1][2], oy[MSEG + 1][2], oz[MSEG + 1][2];
@@ -190,60 +215,44 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
 #pragma unroll
       for(int c = 0; c < 2; c++)
       {
-        ox[i][c] = oy[i][c] = oz[i][c] = 0.0f;
-        if(i <= jn)
-        {
-          const int wi = widx(wr0 + i * S, wc0 + c);
-          const f2 v = ld2(XY + 2 * wi);
-          ox[i][c] = v.x;
-          oy[i][c] = v.y;
-          oz[i][c] = Z[wi];
-        }
+        const int wx = wc0 + c;
+        const int wi = rowbase + i * RSTEP + (wx & 1) * WPH + (wx >> 1);
+        const f2 v = ld2(XY + 2 * wi);
+        ox[i][c] = v.x;
+        oy[i][c] = v.y;
+        oz[i][c] = Z[wi];
       }
     // the shifted pixels: ring slot of column c at step j of a row of offsets is (c + j) & 1
     float sx[MSEG + 1][2], sy[MSEG + 1][2], sz[MSEG + 1][2];
 #pragma unroll
     for(int i = 0; i <= MSEG; i++) sx[i][0] = sx[i][1] = sy[i][0] = sy[i][1] = sz[i][0] = sz[i][1] = 0.0f;
 
-    auto step = [&](auto ph_tag, const int p, const bool first, const int dy, const int dx) {
+    // both columns of every row of the chain at the head of a row of offsets
+    auto load_row_head = [&](const int dy, const int dx) {
+      const int dyo = rowbase + dy * 2 * WPH;
+#pragma unroll
+      for(int c = 0; c < 2; c++)
+      {
+        const int wx = wc0 + c + dx;
+        const int base = dyo + (wx & 1) * WPH + (wx >> 1);
+#pragma unroll
+        for(int i = 0; i <= MSEG; i++)
+        {
+          const int wi = base + i * RSTEP;
+          const f2 v = ld2(XY + 2 * wi);
+          sx[i][c] = v.x;
+          sy[i][c] = v.y;
+          sz[i][c] = Z[wi];
+        }
+      }
+    };
+    // A step computes from the ring; the fetch of what the next step needs follows it (slide()), in flight while the wave
+    // stores its terms and waits at the barrier
+    auto step = [&](auto ph_tag, const int p) {
       constexpr int PH = decltype(ph_tag)::value;
-      float *const T = lds + (p & 3) * tabsz;
+      float *const T = tab + (p & 3) * tabsz;
       float *const F = Fb + (p & 1) * S * FP;
-      if(first)
-      {
-        // a new row of offsets: both columns of every row of the chain
-#pragma unroll
-        for(int i = 0; i <= MSEG; i++)
-          if(i <= jn)
-          {
-#pragma unroll
-            for(int c = 0; c < 2; c++)
-            {
-              const int wi = widx(wr0 + i * S + dy, wc0 + c + dx);
-              const f2 v = ld2(XY + 2 * wi);
-              sx[i][c] = v.x;
-              sy[i][c] = v.y;
-              sz[i][c] = Z[wi];
-            }
-          }
-      }
-      else
-      {
-        // the column that slides in: c = 1, ring slot (1 + PH) & 1
-        constexpr int SL = (1 + PH) & 1;
-        const int wx = wc0 + 1 + dx;
-        const int base = (wx & 1) * WPH + (wx >> 1);
-#pragma unroll
-        for(int i = 0; i <= MSEG; i++)
-          if(i <= jn)
-          {
-            const int wi = (wr0 + i * S + dy) * 2 * WPH + base;
-            const f2 v = ld2(XY + 2 * wi);
-            sx[i][SL] = v.x;
-            sy[i][SL] = v.y;
-            sz[i][SL] = Z[wi];
-          }
-      }
+      const int fo = head ? foff : DUMMY;
       float px2[2], py2[2], pz2[2];
 #pragma unroll
       for(int c = 0; c < 2; c++)
@@ -254,50 +263,77 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         py2[c] = dy_ * dy_;
         pz2[c] = dz_ * dz_;
       }
-      if(head)
       {
         f2 d;
         d.x = px2[0] * n0 + py2[0] * n1 + pz2[0] * n2;
         d.y = px2[1] * n0 + py2[1] * n1 + pz2[1] * n2;
-        st2(F + foff, d);
+        st2(F + fo, d);
       }
 #pragma unroll
       for(int i = 1; i <= MSEG; i++)
-        if(i <= jn)
+      {
+        f2 t;
+        float nx2[2], ny2[2], nz2[2];
+#pragma unroll
+        for(int c = 0; c < 2; c++)
         {
-          f2 t;
-          float nx2[2], ny2[2], nz2[2];
-#pragma unroll
-          for(int c = 0; c < 2; c++)
-          {
-            const int sl = (c + PH) & 1;
-            const float dx_ = ox[i][c] - sx[i][sl], dy_ = oy[i][c] - sy[i][sl], dz_ = oz[i][c] - sz[i][sl];
-            nx2[c] = dx_ * dx_;
-            ny2[c] = dy_ * dy_;
-            nz2[c] = dz_ * dz_;
-          }
-          t.x = ((nx2[0] - px2[0]) * n0 + (ny2[0] - py2[0]) * n1) + (nz2[0] - pz2[0]) * n2;
-          t.y = ((nx2[1] - px2[1]) * n0 + (ny2[1] - py2[1]) * n1) + (nz2[1] - pz2[1]) * n2;
-          st2(T + toff + (i - 1) * S * TP, t);
-#pragma unroll
-          for(int c = 0; c < 2; c++)
-          {
-            px2[c] = nx2[c];
-            py2[c] = ny2[c];
-            pz2[c] = nz2[c];
-          }
+          const int sl = (c + PH) & 1;
+          const float dx_ = ox[i][c] - sx[i][sl], dy_ = oy[i][c] - sy[i][sl], dz_ = oz[i][c] - sz[i][sl];
+          nx2[c] = dx_ * dx_;
+          ny2[c] = dy_ * dy_;
+          nz2[c] = dz_ * dz_;
         }
+        t.x = ((nx2[0] - px2[0]) * n0 + (ny2[0] - py2[0]) * n1) + (nz2[0] - pz2[0]) * n2;
+        t.y = ((nx2[1] - px2[1]) * n0 + (ny2[1] - py2[1]) * n1) + (nz2[1] - pz2[1]) * n2;
+        if(i - 1 < jn) st2(T + toff0 + (i - 1) * S * TP, t); // a lane mask per term (scalar registers), one address register
+        env.sched_fence(); // row by row: the scheduler must not square all seven rows first (42 more registers: spills)
+#pragma unroll
+        for(int c = 0; c < 2; c++)
+        {
+          px2[c] = nx2[c];
+          py2[c] = ny2[c];
+          pz2[c] = nz2[c];
+        }
+      }
+    };
+    // the column that slides in for step j + 1, fetched once step j has taken its squared differences: column c = 1 of
+    // step j + 1 goes to ring slot (1 + j + 1) & 1 = PH, the slot column c = 0 of step j has just left.  Unconditional --
+    // behind the last step of a row it fetches a column nobody uses (it exists: window column <= 2 reach + cw - 1) -- so
+    // that the ring's registers are written on one path only (a conditional fetch made the register allocator keep both
+    // versions of the ring: 19 spills); the head of a row is fetched at the top of the row, 15 exposed fetches per chunk.
+    auto slide = [&](auto ph_tag, const int dy, const int dx) {
+      constexpr int PH = decltype(ph_tag)::value;
+      const int wx = wc0 + 1 + dx + 1;
+      const int base = rowbase + dy * 2 * WPH + (wx & 1) * WPH + (wx >> 1);
+#pragma unroll
+      for(int i = 0; i <= MSEG; i++)
+      {
+        const int wi = base + i * RSTEP;
+        const f2 v = ld2(XY + 2 * wi);
+        sx[i][PH] = v.x;
+        sy[i][PH] = v.y;
+        sz[i][PH] = Z[wi];
+      }
     };
     for(int dyi = 0; dyi < ndy; dyi++)
     {
       const int dy = patches[dyi * ndx].x, dx0 = patches[dyi * ndx].y;
+      if(!(var & 16)) load_row_head(dy, dx0);
       for(int jb = 0; jb < ndx; jb += 2)
       {
-        step(std::integral_constant<int, 0>(), dyi * ndx + jb, jb == 0, dy, dx0 + jb);
+        if(!(var & 16))
+        {
+          step(std::integral_constant<int, 0>(), dyi * ndx + jb);
+          slide(std::integral_constant<int, 0>(), dy, dx0 + jb);
+        }
         env.sync();
         if(jb + 1 < ndx)
         {
-          step(std::integral_constant<int, 1>(), dyi * ndx + jb + 1, false, dy, dx0 + jb + 1);
+          if(!(var & 16))
+          {
+            step(std::integral_constant<int, 1>(), dyi * ndx + jb + 1);
+            slide(std::integral_constant<int, 1>(), dy, dx0 + jb + 1);
+          }
           env.sync();
         }
       }
@@ -312,34 +348,28 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   {
     // ---- A2: the column recurrence, one lane per table column, the whole column fetched at once
     const int x = 1 + w * 64 + lane;
-    const bool active = x <= cw + 2 * P;
+    const bool active = x <= cw + 2 * P && !(var & 32);
+    env.prio_high(); // the two recurrences are the stage's latency chains
     env.sync();
     for(int p = 0; p < n; p++)
     {
       if(active)
       {
-        float *const col = lds + (p & 3) * tabsz + XO + x;
+        float *const col = tab + (p & 3) * tabsz + XO + x;
         const float *const F = Fb + (p & 1) * S * FP + XO + x;
+        // all MAXCH rows, whatever the chunk's height: rows beyond it hold garbage that nobody reads (a guard per row
+        // costs a lane mask per row: 55 pairs of scalar registers, spilled)
         float f[S], term[MAXCH];
 #pragma unroll
         for(int r = 0; r < S; r++) f[r] = F[r * FP];
 #pragma unroll
-        for(int t = 1; t < MAXCH; t++)
-        {
-          term[t] = 0.0f;
-          if(t < ch) term[t] = col[t * TP];
-        }
+        for(int t = 1; t < MAXCH; t++) term[t] = col[t * TP];
         float v = 0.0f;
 #pragma unroll
         for(int r = 0; r < S; r++) v += f[r];
-        col[0] = v;
-#pragma unroll
-        for(int t = 1; t < MAXCH; t++)
-          if(t < ch)
-          {
-            v = v + term[t];
-            col[t * TP] = v;
-          }
+        float *const wave_base = tab + (p & 3) * tabsz + XO + 1 + w * 64; // lane 0's column
+        env.template st_addtid<0>(wave_base, lane, v);
+        column_chain<1, MAXCH, TP * 4, Env>::run(env, wave_base, lane, v, term);
       }
       env.sync();
     }
@@ -352,14 +382,15 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   {
     // ---- B: the sliding row sum (:405-415), one lane per table row: the row fetched as 19 x 16 bytes, the distortion of
     //      chunk column c stored at slot c + 1 (18 x 16 bytes)
-    const bool active = lane < ch;
+    const bool active = lane < ch && !(var & 64);
+    env.prio_high();
     env.sync();
     env.sync();
     for(int p = 0; p < n; p++)
     {
       if(active)
       {
-        float *const rowp = lds + (p & 3) * tabsz + lane * TP;
+        float *const rowp = tab + (p & 3) * tabsz + lane * TP;
         float cs[80]; // cs[x + XO] = slot x
 #pragma unroll
         for(int b = 4; b < 80; b += 4)
@@ -399,25 +430,34 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   }
   // ---------------------------------------------------------------------------------------------------------------------
   {
-    // ---- C: weights and accumulation (:416-436); center_weight < 0: w = 2^-(distortion * sharpness)
+    // ---- C: weights and accumulation (:416-436); center_weight < 0: w = 2^-(distortion * sharpness).
+    // Software-pipelined by one offset: a stage FETCHES the distortions of its offset (ready since the barrier) and the
+    // one pixel that slides into the ring, and ACCUMULATES the offset before it, whose operands arrived a stage ago --
+    // nothing a stage computes with was fetched in that stage (the last offset of a row is the exception: it is
+    // accumulated in its own stage, so that a new row starts with an empty ring).  Ring of NPXL + 1 pixels: pixel i of
+    // step j of a row sits in slot (i + j) % (NPXL + 1); the slot the incoming pixel takes was last read two steps ago.
+    constexpr int NR = NPXL + 1;
+    static_assert(NR % 2 == 0, "the distortions alternate between two register sets with the ring's period");
     const int ci = w == 8 ? 0 : (w == 9 ? 1 : w - 9);
     const int cl = ci * 64 + lane;
     const int r = cl / LPR, j8 = cl - r * LPR;
     const int cb = NPXL * j8; // first chunk column of the lane
-    const bool active = r < ch && cb < cw;
+    const bool active = r < ch && cb < cw && !(var & 128);
     float accx[NPXL], accy[NPXL], accz[NPXL], accw[NPXL];
-    float qx[NPXL], qy[NPXL], qz[NPXL];
+    float qx[NR], qy[NR], qz[NR];
+    float dist[2][NPXL];
 #pragma unroll
-    for(int i = 0; i < NPXL; i++) accx[i] = accy[i] = accz[i] = accw[i] = qx[i] = qy[i] = qz[i] = 0.0f;
+    for(int i = 0; i < NPXL; i++) accx[i] = accy[i] = accz[i] = accw[i] = dist[0][i] = dist[1][i] = 0.0f;
+#pragma unroll
+    for(int i = 0; i < NR; i++) qx[i] = qy[i] = qz[i] = 0.0f;
     const int doff = r * TP + 4 + cb;
     const float sharp = a.sharpness;
 
-    auto step = [&](auto m_tag, const int p, const bool first, const int dy, const int dx) {
-      constexpr int M = decltype(m_tag)::value; // step of the row of offsets modulo NPXL: pixel i sits in ring slot (i + M) % NPXL
-      const float *const T = lds + (p & 3) * tabsz + doff;
-      float dist[NPXL];
+    auto fetch = [&](auto m_tag, const int p, const bool first, const int dy, const int dx) {
+      constexpr int M = decltype(m_tag)::value;
+      const float *const T = tab + (p & 3) * tabsz + doff;
 #pragma unroll
-      for(int i = 0; i < NPXL; i++) dist[i] = T[i];
+      for(int i = 0; i < NPXL; i++) dist[M & 1][i] = T[i];
       const int wy = reach + r + dy;
       if(first)
       {
@@ -433,18 +473,21 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       }
       else
       {
-        constexpr int SL = (NPXL - 1 + M) % NPXL;
+        constexpr int SL = (NPXL - 1 + M) % NR;
         const int wi = widx(wy, reach + cb + NPXL - 1 + dx);
         const f2 v = ld2(XY + 2 * wi);
         qx[SL] = v.x;
         qy[SL] = v.y;
         qz[SL] = Z[wi];
       }
+    };
+    auto accumulate = [&](auto m_tag) {
+      constexpr int M = decltype(m_tag)::value;
 #pragma unroll
       for(int i = 0; i < NPXL; i++)
       {
-        const int sl = (i + M) % NPXL;
-        const float wgt = nlm2::mexp2<Env>(dist[i] * sharp);
+        const int sl = (i + M) % NR;
+        const float wgt = nlm2::mexp2<Env>(dist[M & 1][i] * sharp);
         accx[i] = accx[i] + qx[sl] * wgt;
         accy[i] = accy[i] + qy[sl] * wgt;
         accz[i] = accz[i] + qz[sl] * wgt;
@@ -457,13 +500,18 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     for(int dyi = 0; dyi < ndy; dyi++)
     {
       const int dy = patches[dyi * ndx].x, dx0 = patches[dyi * ndx].y;
-      for(int jb = 0; jb < ndx; jb += NPXL)
+      for(int jb = 0; jb < ndx; jb += NR)
       {
         auto run = [&](auto m_tag) {
           constexpr int M = decltype(m_tag)::value;
           if(jb + M < ndx)
           {
-            if(active) step(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
+            if(active)
+            {
+              fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
+              if(jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
+              if(jb + M + 1 == ndx) accumulate(m_tag);
+            }
             env.sync();
           }
         };
@@ -476,11 +524,13 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         run(std::integral_constant<int, 6>());
         run(std::integral_constant<int, 7>());
         run(std::integral_constant<int, 8>());
-        if constexpr(NPXL > 9)
+        run(std::integral_constant<int, 9>());
+        if constexpr(NR > 10)
         {
-          run(std::integral_constant<int, 9>());
           run(std::integral_constant<int, 10>());
           run(std::integral_constant<int, 11>());
+          run(std::integral_constant<int, 12>());
+          run(std::integral_constant<int, 13>());
         }
       }
     }

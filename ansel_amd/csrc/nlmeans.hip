@@ -791,6 +791,15 @@ struct nlm2_device_env
   __device__ __forceinline__ float *lds() const { return lds_; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ void prio_high() const { __builtin_amdgcn_s_setprio(3); }
+  __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); } // nothing moves across
+  // ds_write_addtid_b32: LDS address = M0 + offset + 4 * lane, data from one register, no address register.  M0 is
+  // written right in front of the store (the compiler does not know the instruction reads it) with the wait state the
+  // hardware wants between an SALU write of M0 and an add-TID instruction
+  template <int OFF> __device__ __forceinline__ void st_addtid(float *const wave_base, const int, const float v) const
+  {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%2" : : "s"(m0v), "v"(v), "n"(OFF) : "memory", "m0");
+  }
   __device__ __forceinline__ bool any(const bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0; }
   static constexpr bool TIMED = false;
   __device__ __forceinline__ long long clock() const { return 0; }
@@ -1024,7 +1033,7 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   int ndx3 = 0;
   const bool v3 = v2 && nlm3::fits<9, 6>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                   && getenv("ANSEL_HIP_NLM_V2") == nullptr;
-  const size_t v3_bytes = std::max(nlm3::lds_floats(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
+  const size_t v3_bytes = std::max(nlm3::lds_floats<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
   static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS && NL3_THREADS == NLM_THREADS,
                 "nlm_chunks_v2 / _v3 share the launch shape of nlm_chunks_pipelined");
   nlm2_kernel_t k2 = nullptr;

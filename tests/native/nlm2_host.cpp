@@ -53,6 +53,9 @@ struct HostEnv
   float *lds() const { return lds_; }
   void sync() const { bar_->arrive_and_wait(); }
   void prio_high() const {}
+  void sched_fence() const {}
+  // ds_write_addtid_b32: base + offset + 4 * lane
+  template <int OFF> void st_addtid(float *const wave_base, const int lane, const float v) const { wave_base[OFF / 4 + lane] = v; }
   bool any(const bool) const { return true; } // a wave-level vote on the device; every slot stays live here
   static constexpr bool TIMED = false;
   long long clock() const { return 0; }
@@ -240,7 +243,7 @@ extern "C" int nlm3_host_run(const float *in, float *out, int W, int H, int chk_
   a.out_row1 = H;
   int ndx = 0;
   if(!nlm3::fits<9, 6>(chk_w, chk_h, patch_radius, a.reach) || !nlm3::regular_grid(patches.data(), a.npatch, &ndx)) return 0;
-  const size_t lds_floats = nlm3::lds_floats(chk_h, a.reach);
+  const size_t lds_floats = nlm3::lds_floats<9>(chk_h, a.reach);
   if(lds_floats * sizeof(float) > 160 * 1024) return 0;
   int interior = 0;
   for(int cy = 0; cy < nchy; cy++)
