@@ -349,7 +349,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // ---- A2: the column recurrence, one lane per table column, the whole column fetched at once
     const int x = 1 + w * 64 + lane;
     const bool active = x <= cw + 2 * P && !(var & 32);
-    env.prio_high(); // the two recurrences are the stage's latency chains
+    if(!(var & 512)) env.prio_high(); // the two recurrences are the stage's latency chains
     env.sync();
     for(int p = 0; p < n; p++)
     {
@@ -383,7 +383,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // ---- B: the sliding row sum (:405-415), one lane per table row: the row fetched as 19 x 16 bytes, the distortion of
     //      chunk column c stored at slot c + 1 (18 x 16 bytes)
     const bool active = lane < ch && !(var & 64);
-    env.prio_high();
+    if(!(var & 512)) env.prio_high();
     env.sync();
     env.sync();
     for(int p = 0; p < n; p++)
@@ -407,20 +407,21 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         for(int kk = 1; kk < S; kk++) distortion += cs[XO + kk]; // columns left - P .. left + P - 1
         float d[72];
 #pragma unroll
-        for(int c = 0; c < 72; c++)
-        {
-          distortion = distortion + (cs[XO + c + S] - cs[XO + c]);
-          d[c] = distortion;
-        }
-#pragma unroll
         for(int b = 0; b < 72; b += 4)
         {
+#pragma unroll
+          for(int c = b; c < b + 4; c++)
+          {
+            distortion = distortion + (cs[XO + c + S] - cs[XO + c]);
+            d[c] = distortion;
+          }
           f4 v;
           v.x = d[b];
           v.y = d[b + 1];
           v.z = d[b + 2];
           v.w = d[b + 3];
           st4(rowp + 4 + b, v);
+          if(!(var & 1024)) env.sched_fence(); // four sums, their store, the next four: the stores' transfer overlaps the chain
         }
       }
       env.sync();

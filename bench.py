@@ -285,11 +285,23 @@ def pmc_table(args):
     return {}, None
 
 
+# which kernels (function names as the PMC summary keeps them, template arguments stripped) a bench tag launches
+TAG_KERNELS = {
+    "nlm_chunks": ("nlm_chunks_v3", "nlm_chunks_v2", "nlm_chunks_pipelined", "nlm_chunks"),
+    "diffuse_pde": ("diffuse_pde_strip", "diffuse_pde"), "diffuse_decompose": ("bspline_decompose_strip", "bspline_decompose"),
+    "dn_decompose": ("dn_decompose_strip", "dn_decompose"), "rgb_chain_u16": ("rgb_chain",), "rgb_chain_rows16": ("rgb_chain",),
+    "bilat_blur": ("bilat_blur_line", "bilat_blur_line_z"), "bilat_splat": ("bilat_splat", "bilat_lightness"),
+    "dn_band_threshold": ("dn_band_sums", "dn_band_threshold"),
+}
+
+
 def traffic_of(table, tag):
-    for key in (tag, tag.replace("_u16", "")):
-        if key in table:
-            return table[key]
-    return None
+    """HBM bytes of ONE launch of `tag` (a tag whose launch runs several kernels: their sum)"""
+    names = TAG_KERNELS.get(tag, (tag, tag.replace("_u16", "")))
+    got = [table[n] for n in dict.fromkeys(names) if n in table]
+    if not got:
+        return None
+    return sum(got) if tag in ("bilat_blur", "bilat_splat", "dn_band_threshold") else got[0]
 
 
 # What binds each kernel, and the peak it is priced against.  HBM: 8 TB/s.  VALU: one wave64 instruction per

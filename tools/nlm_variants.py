@@ -32,6 +32,8 @@ def main():
     # (label, environment) -- ANSEL_NLM2_VARIANT bits: 16 no A1, 32 no A2, 64 no B, 128 no C, 256 no first row
     names = {"v1 (nlm_chunks_pipelined)": {"ANSEL_HIP_NLM_V1": "1"},
              "v3 shipped (nlm3_body.h)": {},
+             "v3 no priority": {"ANSEL_NLM2_VARIANT": "512"}, "v3 B stores at the end": {"ANSEL_NLM2_VARIANT": "1024"},
+             "v3 only A2": {"ANSEL_NLM2_VARIANT": "208"}, "v3 only B": {"ANSEL_NLM2_VARIANT": "176"},
              "v3 no A1": {"ANSEL_NLM2_VARIANT": "16"}, "v3 no A2": {"ANSEL_NLM2_VARIANT": "32"},
              "v3 no B": {"ANSEL_NLM2_VARIANT": "64"}, "v3 no C": {"ANSEL_NLM2_VARIANT": "128"},
              "v3 no A2, no B": {"ANSEL_NLM2_VARIANT": "96"}, "v3 no A1, no C": {"ANSEL_NLM2_VARIANT": "144"},

@@ -9,15 +9,14 @@ OUT="gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-host-legs --no-verify"
+Q="--no-cpu-baseline --no-host-legs --no-verify --no-light-pipe"
 python bench.py "$@" > "$OUT/bench.log" 2>&1
 tail -1 "$OUT/bench.log"
-# the timed region alone (light pipe only): kernel stats and the HBM byte counters bench.py's roofline.traffic cites
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py "$@" $Q --no-full-pipe > "$OUT/stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python bench.py "$@" $Q --no-full-pipe > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python bench.py "$@" $Q --no-full-pipe > "$OUT/write.log" 2>&1
-# light + full pipe in one process (config.full_pipe leg): kernel stats and three SQ passes
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full" -- python bench.py "$@" $Q > "$OUT/stats_full.log" 2>&1
+# the timed region alone (the pipe bench.py's `value` is quoted on, --pipe full unless the arguments say otherwise): kernel
+# stats and the HBM byte counters bench.py's roofline.traffic / kernel_bounds cite
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py "$@" $Q > "$OUT/stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python bench.py "$@" $Q --steps 2 --warmup 1 > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python bench.py "$@" $Q --steps 2 --warmup 1 > "$OUT/write.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU \
   --output-format csv -d "$OUT/sqa" -- python bench.py "$@" $Q --steps 3 --warmup 1 > "$OUT/sqa.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 \
@@ -27,13 +26,11 @@ rocprofv3 --pmc SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/write" -name '*counter_collection.csv' | head -1)
 S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
-SF=$(find "$OUT/stats_full" -name '*kernel_stats.csv' | head -1)
 [ -n "$S" ] && cp "$S" "$OUT/kernel_stats.csv"
-[ -n "$SF" ] && cp "$SF" "$OUT/kernel_stats_light_and_full.csv"
 [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_hbm_json.py "$F" "$W" "$OUT/pmc_hbm_bytes.json" "bench.py $*;"
 A=$(find "$OUT/sqa" -name '*counter_collection.csv' | head -1)
 B=$(find "$OUT/sqb" -name '*counter_collection.csv' | head -1)
 C=$(find "$OUT/sqc" -name '*counter_collection.csv' | head -1)
-[ -n "$A" ] && python tools/pmc_sq_json.py "$OUT/pmc_sq.json" "bench.py $* (light pipe steps, then config.full_pipe steps, one process);" $A $B $C > "$OUT/pmc_sq.txt"
-rm -rf "$OUT/stats" "$OUT/fetch" "$OUT/write" "$OUT/stats_full" "$OUT/sqa" "$OUT/sqb" "$OUT/sqc"
+[ -n "$A" ] && python tools/pmc_sq_json.py "$OUT/pmc_sq.json" "bench.py $* (the timed steps only);" $A $B $C > "$OUT/pmc_sq.txt"
+rm -rf "$OUT/stats" "$OUT/fetch" "$OUT/write" "$OUT/sqa" "$OUT/sqb" "$OUT/sqc"
 ls -la "$OUT"
