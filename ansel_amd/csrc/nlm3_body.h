@@ -89,9 +89,9 @@ template <int NPXL, int MSEG> inline bool fits(const int chk_w, const int chk_h,
   if(radius != 2 || chk_w > 72 || (chk_w & 1) || chk_w + 2 * reach > 2 * NL3_WPH || chk_h > max_rows<NPXL>() || chk_h < 2 * S) return false;
   if(LPR * chk_h > 448) return false;
   const int ncp = (chk_w + 4) / 2;
-  if(ncp * S > NL3_A1_LANES) return false;
+  if(ncp < 32 || ncp > 38) return false; // five waves of 2 x 32 column pairs + one of the rest (body(), A1)
   const int nseg = NL3_A1_LANES / (ncp * S), m0 = (chk_h - 2) / S + 1;
-  return (m0 + nseg - 1) / nseg <= MSEG;
+  return nseg == 2 && (m0 + nseg - 1) / nseg <= MSEG;
 }
 
 // the offsets as rows of consecutive column shifts: ndx per row, every row starting at the same column shift
@@ -186,10 +186,25 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     const int nseg = NL3_A1_LANES / (ncp * S);
     const int m0 = (ch - 2) / S + 1;
     const int mseg = (m0 + nseg - 1) / nseg;
-    // lanes beyond the last work item repeat it (same reads, the same values stored to the same words): no lane of the
-    // role is ever masked
-    const int u = imin(ai * 64 + lane, ncp * S * nseg - 1);
-    const int g = u % ncp, q = u / ncp;
+    // Work items = (column pair g < ncp, chain q < 10).  Lanes 0-31 and 32-63 of a wave are served by the LDS in separate
+    // passes, and a pass is conflict-free when its 32 lanes read 32 consecutive words: waves 0-4 hold column pairs 0-31
+    // of one chain per half (with the items in plain order, 38 to a chain, every half straddled two window rows whose
+    // words share banks: 3-4 LDS cycles per fetch instead of 2, profiles/r03_nlm_bank_model.txt), the last wave the
+    // <= 6 pairs per chain that are left.  Lanes beyond the last item repeat it (same reads, the same values stored to the
+    // same words): no lane of the role is ever masked.
+    const int extra = ncp - 32; // 0 .. 6 (fits())
+    int g, q;
+    if(ai < 5)
+    {
+      q = 2 * ai + (lane >> 5);
+      g = lane & 31;
+    }
+    else
+    {
+      const int l = extra > 0 ? imin(lane, S * nseg * extra - 1) : 0;
+      q = extra > 0 ? l / extra : 0;
+      g = extra > 0 ? 32 + l - q * extra : 0;
+    }
     const int k = q % S, seg = q / S;
     const int mk = (ch - 2 - k >= 0) ? (ch - 2 - k) / S + 1 : 0;
     const int j0 = seg * mseg;
@@ -440,8 +455,11 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     constexpr int NR = NPXL + 1;
     static_assert(NR % 2 == 0, "the distortions alternate between two register sets with the ring's period");
     const int ci = w == 8 ? 0 : (w == 9 ? 1 : w - 9);
-    const int cl = ci * 64 + lane;
-    const int r = cl / LPR, j8 = cl - r * LPR;
+    // a wave holds 8 chunk rows x 8 lanes; its lanes 0-31 take the even rows, 32-63 the odd ones: the nine distortions a
+    // lane reads sit 9 words apart within a row and 84 apart between rows, and four rows TWO apart put the 32 lanes of an
+    // LDS pass on 32 different banks (four consecutive rows: 2-way conflicts on every read)
+    static_assert(LPR == 8, "the lane layout of the C role");
+    const int r = 8 * ci + 2 * ((lane & 31) >> 3) + (lane >> 5), j8 = lane & 7;
     const int cb = NPXL * j8; // first chunk column of the lane
     const bool active = r < ch && cb < cw && !(var & 128);
     float accx[NPXL], accy[NPXL], accz[NPXL], accw[NPXL];
