@@ -245,6 +245,13 @@ class BandState(C.Structure):
                 ("sum_count", C.c_size_t), ("relay_buf", C.c_void_p), ("relay_bytes", C.c_size_t)]
 
 
+class BandStats(C.Structure):
+    """dt_hip_band_stats_t: what the last dt_hip_pipe_process_bands() moved between the devices"""
+    _fields_ = [("bands", C.c_int32), ("devices", C.c_int32), ("exchange_stops", C.c_int32),
+                ("pairs_without_peer_access", C.c_int32), ("peer_copies", C.c_uint64), ("peer_bytes", C.c_uint64),
+                ("host_wait_ns", C.c_uint64)]
+
+
 DT_HIP_BAND_EXCHANGE = 1
 DT_HIP_HIGHLIGHTS_JOURNAL_BYTES = 320
 

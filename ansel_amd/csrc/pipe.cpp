@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -868,16 +870,27 @@ int dt_hip_pipe_band_resolve(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_
 // Bands may share a device (the single-GPU test of this path): a peer copy is then a device copy.
 namespace
 {
+// What the bands of one walk share.  A band publishes POINTS: a hipEvent recorded on its stream behind the work the
+// point stands for, and a counter the other bands' host threads watch.  Somebody who needs that work waits on the HOST
+// only until the event has been recorded (the owner's thread got that far enqueueing), then makes ITS stream wait for
+// the event: no stream is ever drained inside the walk, and a band only waits for the bands it reads from (its two
+// neighbours at a halo stop).  Every band passes the same points in the same order (same node list).
 struct band_gang_t
 {
-  int n;
+  int n = 0;
   std::mutex m;
   std::condition_variable cv;
+  std::vector<int> posted;                    // points band k has published
+  std::vector<std::vector<hipEvent_t>> events; // [band][point]
+  std::vector<int> done;                      // the band's walk has ended (its posted count is final)
+  bool failed = false;
+  // the classic meeting, used once per frame for the 8-byte clipped count that travels through the host
   int waiting = 0;
   unsigned long generation = 0;
-  // all bands meet here; returns the worst (most negative; else largest) code any of them brought
-  std::vector<int> rc;
-  void wait()
+  // statistics of the last walk (dt_hip_pipe_bands_stats())
+  std::atomic<unsigned long long> peer_bytes{ 0 }, peer_copies{ 0 }, host_wait_ns{ 0 };
+
+  void meet()
   {
     std::unique_lock<std::mutex> lk(m);
     const unsigned long g = generation;
@@ -890,17 +903,159 @@ struct band_gang_t
     else
       cv.wait(lk, [&] { return generation != g; });
   }
+  // band k: "everything enqueued on `s` so far is point number posted[k]"
+  bool publish(const int k, hipStream_t s)
+  {
+    hipEvent_t e = nullptr;
+    if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, s) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      if(e) (void)hipEventDestroy(e);
+      fail();
+      return false;
+    }
+    std::lock_guard<std::mutex> lk(m);
+    events[k].push_back(e);
+    posted[k]++;
+    cv.notify_all();
+    return true;
+  }
+  // make stream `s` wait for point `pt` of band j; false when the walk has failed or band j will never get there
+  bool await(const int j, const int pt, hipStream_t s)
+  {
+    hipEvent_t e = nullptr;
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return failed || posted[j] > pt || done[j]; });
+      host_wait_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      if(failed || posted[j] <= pt) return false;
+      e = events[j][pt];
+    }
+    if(hipStreamWaitEvent(s, e, 0) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      fail();
+      return false;
+    }
+    return true;
+  }
+  void fail()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    failed = true;
+    cv.notify_all();
+  }
+  void finished(const int k)
+  {
+    std::lock_guard<std::mutex> lk(m);
+    done[k] = 1;
+    cv.notify_all();
+  }
+  bool has_failed()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    return failed;
+  }
 };
 
-int copy_between(const int dst_devid, void *dst, const int src_devid, const void *src, const size_t bytes, hipStream_t s)
+dt_hip_band_stats_t g_band_stats = { 0, 0, 0, 0, 0, 0, 0 };
+std::mutex g_band_stats_mutex;
+
+int copy_between(band_gang_t &gang, const int dst_devid, void *dst, const int src_devid, const void *src, const size_t bytes,
+                 hipStream_t s)
 {
   if(!bytes) return DT_HIP_SUCCESS;
   const int dd = hip_device_of(dst_devid), sd = hip_device_of(src_devid);
   if(dd == sd) ANSEL_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
-  else ANSEL_HIP_CHECK(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, s));
+  else
+  {
+    ANSEL_HIP_CHECK(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, s));
+    gang.peer_bytes += bytes;
+    gang.peer_copies++;
+  }
   return DT_HIP_SUCCESS;
 }
 } // namespace
+
+void dt_hip_pipe_bands_stats(dt_hip_band_stats_t *out)
+{
+  if(!out) return;
+  std::lock_guard<std::mutex> lk(g_band_stats_mutex);
+  *out = g_band_stats;
+}
+
+// Can the devices of a band walk reach each other?  Checks hipDeviceCanAccessPeer for every ordered pair, enables the
+// access, and moves a small buffer device to device and back with a cross-device event in between -- the three things
+// dt_hip_pipe_process_bands() relies on and a single-GPU box never executes.  0, or an error with the pair in the text.
+int dt_hip_peer_selftest(const int *devids, int n)
+{
+  if(!devids || n < 1) return DT_HIP_INVALID_ARG;
+  for(int i = 0; i < n; i++)
+    if(!valid_device(devids[i])) return DT_HIP_INVALID_ARG;
+  for(int i = 0; i < n; i++)
+    for(int j = 0; j < n; j++)
+    {
+      const int di = hip_device_of(devids[i]), dj = hip_device_of(devids[j]);
+      if(di == dj) continue;
+      int can = 0;
+      if(hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can)
+      {
+        (void)hipGetLastError();
+        set_last_error("peer self-test: device %d cannot access device %d (hipDeviceCanAccessPeer): halo rows would travel "
+                       "through the host", devids[i], devids[j]);
+        return DT_HIP_DEFAULT_ERROR;
+      }
+      (void)stream_of(devids[i]); // makes device i current
+      const hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+      if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+      {
+        (void)hipGetLastError();
+        set_last_error("peer self-test: hipDeviceEnablePeerAccess(%d -> %d): %s", devids[i], devids[j], hipGetErrorString(e));
+        return DT_HIP_DEFAULT_ERROR;
+      }
+      (void)hipGetLastError();
+    }
+  // a ring of copies: device k's pattern travels to device k + 1 behind an event of device k's stream
+  const size_t N = 1 << 16;
+  std::vector<unsigned> pattern(N), back(N);
+  for(int k = 0; k + 1 < n || (n == 1 && k == 0); k++)
+  {
+    const int a = devids[k], b = devids[(k + 1) % n];
+    for(size_t i = 0; i < N; i++) pattern[i] = (unsigned)(i * 2654435761u + (unsigned)k);
+    unsigned *da = (unsigned *)dt_hip_alloc_device_buffer(a, N * 4), *db = (unsigned *)dt_hip_alloc_device_buffer(b, N * 4);
+    int err = (da && db) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
+    hipEvent_t ev = nullptr;
+    if(err == DT_HIP_SUCCESS)
+    {
+      hipStream_t sa = stream_of(a);
+      if(hipMemcpyAsync(da, pattern.data(), N * 4, hipMemcpyHostToDevice, sa) != hipSuccess
+         || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, sa) != hipSuccess)
+        err = DT_HIP_DEFAULT_ERROR;
+      hipStream_t sb = stream_of(b);
+      if(err == DT_HIP_SUCCESS
+         && (hipStreamWaitEvent(sb, ev, 0) != hipSuccess
+             || (hip_device_of(a) == hip_device_of(b) ? hipMemcpyAsync(db, da, N * 4, hipMemcpyDeviceToDevice, sb)
+                                                      : hipMemcpyPeerAsync(db, hip_device_of(b), da, hip_device_of(a), N * 4, sb))
+                    != hipSuccess
+             || hipMemcpyAsync(back.data(), db, N * 4, hipMemcpyDeviceToHost, sb) != hipSuccess
+             || hipStreamSynchronize(sb) != hipSuccess))
+        err = DT_HIP_DEFAULT_ERROR;
+      if(err == DT_HIP_SUCCESS && memcmp(back.data(), pattern.data(), N * 4) != 0) err = DT_HIP_DEFAULT_ERROR;
+      (void)hipStreamSynchronize(sa);
+    }
+    if(ev) (void)hipEventDestroy(ev);
+    if(da) dt_hip_release_mem_object(da);
+    if(db) dt_hip_release_mem_object(db);
+    if(err != DT_HIP_SUCCESS)
+    {
+      (void)hipGetLastError();
+      set_last_error("peer self-test: the copy device %d -> device %d behind a cross-device event did not arrive intact", a, b);
+      return err;
+    }
+  }
+  return DT_HIP_SUCCESS;
+}
 
 int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_band_t *bands, const dt_hip_mem_t *dev_in,
                               const dt_hip_mem_t *dev_out)
@@ -911,8 +1066,10 @@ int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_b
   const int W = pipes[0]->nodes[0].piece.roi_out.width, H = pipes[0]->nodes[0].piece.roi_out.height;
   for(int k = 0; k < n; k++)
   {
-    if(pipes[k]->nodes.size() != pipes[0]->nodes.size() || pipes[k]->nodes[0].piece.roi_out.width != W
-       || pipes[k]->nodes[0].piece.roi_out.height != H)
+    bool same = pipes[k]->nodes.size() == pipes[0]->nodes.size() && pipes[k]->nodes[0].piece.roi_out.width == W
+                && pipes[k]->nodes[0].piece.roi_out.height == H;
+    for(size_t i = 0; same && i < pipes[k]->nodes.size(); i++) same = pipes[k]->nodes[i].op == pipes[0]->nodes[i].op;
+    if(!same)
     {
       set_last_error("dt_hip_pipe_process_bands: pipe %d does not hold the node list of pipe 0", k);
       return DT_HIP_INVALID_ARG;
@@ -923,12 +1080,23 @@ int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_b
       return DT_HIP_INVALID_ARG;
     }
   }
+  // the mosaic halo is pulled out of the neighbour's OWN rows: a band thinner than it cannot serve it
+  for(int k = 0; k < n; k++)
+    if((k > 0 && bands[k].halo_top > bands[k - 1].rows) || (k + 1 < n && bands[k].halo_bottom > bands[k + 1].rows))
+    {
+      set_last_error("dt_hip_pipe_process_bands: band %d owns fewer rows than the mosaic halo its neighbour needs: use fewer bands", k);
+      return DT_HIP_INVALID_ARG;
+    }
   band_gang_t gang;
   gang.n = n;
-  gang.rc.assign(n, DT_HIP_SUCCESS);
+  gang.posted.assign(n, 0);
+  gang.done.assign(n, 0);
+  gang.events.resize(n);
+  std::vector<int> rcs(n, DT_HIP_SUCCESS);
   std::vector<dt_hip_band_state_t> st(n);
   std::vector<unsigned long long> counts(n, 0ull);
   std::vector<std::string> errors(n);
+  std::atomic<int> peer_missing{ 0 }, stops{ 0 };
   for(auto &x : st) memset(&x, 0, sizeof(x));
 
   auto worker = [&](const int k) {
@@ -936,43 +1104,52 @@ int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_b
     const int devid = pipe->devid;
     const dt_hip_band_t &b = bands[k];
     hipStream_t s = stream_of(devid); // also makes the device current for this thread
-    // direct loads / stores between the devices of the gang (an error only means "already enabled" or "same device")
+    // direct loads / stores between the devices of the gang.  A pair without peer access still works (the runtime
+    // stages the copies through the host) but not at xGMI speed: counted, reported by dt_hip_pipe_bands_stats()
     for(int j = 0; j < n; j++)
       if(hip_device_of(pipes[j]->devid) != hip_device_of(devid))
       {
-        (void)hipDeviceEnablePeerAccess(hip_device_of(pipes[j]->devid), 0);
+        int can = 0;
+        if(hipDeviceCanAccessPeer(&can, hip_device_of(devid), hip_device_of(pipes[j]->devid)) != hipSuccess || !can) peer_missing++;
+        else
+        {
+          const hipError_t e = hipDeviceEnablePeerAccess(hip_device_of(pipes[j]->devid), 0);
+          if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peer_missing++;
+        }
         (void)hipGetLastError();
       }
-    auto fail = [&](const int code) {
-      gang.rc[k] = code;
-      errors[k] = dt_hip_last_error();
+    bool walking = false; // the band state holds buffers that give_up() must free
+    auto fail = [&](const int code, const char *what = nullptr) {
+      rcs[k] = code;
+      errors[k] = what ? what : dt_hip_last_error();
+      gang.fail();
     };
-    // every band arrives with its stream drained; all leave with the same verdict
-    bool any_stop = false, all_stop = false; // of the last meet(): bands that stopped for an exchange
-    auto meet = [&]() -> bool {
-      if(gang.rc[k] >= 0 && hipStreamSynchronize(s) != hipSuccess) fail(DT_HIP_DEFAULT_ERROR);
-      gang.wait();
-      bool ok = true;
-      any_stop = false;
-      all_stop = true;
-      for(int j = 0; j < n; j++)
+    auto give_up = [&]() {
+      if(walking) dt_hip_pipe_band_abort(pipe, &st[k]);
+      walking = false;
+      (void)hipStreamSynchronize(s);
+      gang.finished(k);
+    };
+    auto await = [&](const int j, const int pt) -> bool {
+      if(j == k) return true;
+      if(!gang.await(j, pt, s))
       {
-        ok &= gang.rc[j] >= 0;
-        any_stop |= gang.rc[j] == DT_HIP_BAND_EXCHANGE;
-        all_stop &= gang.rc[j] == DT_HIP_BAND_EXCHANGE;
+        if(rcs[k] >= 0) rcs[k] = DT_HIP_DEFAULT_ERROR, errors[k] = "another band failed";
+        return false;
       }
-      gang.wait(); // nobody overwrites its code before everybody has read them
-      return ok;
+      return true;
     };
-    auto give_up = [&]() { dt_hip_pipe_band_abort(pipe, &st[k]); };
 
     // 1. the CFA stages on the own rows
     int rc = dt_hip_pipe_band_begin(pipe, &b, dev_in[k], &st[k]);
     if(rc != DT_HIP_SUCCESS) fail(rc);
-    if(gang.rc[k] >= 0 && st[k].clipped_count
-       && hipMemcpyAsync(&counts[k], st[k].clipped_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess)
+    else walking = true;
+    if(rcs[k] >= 0 && st[k].clipped_count
+       && (hipMemcpyAsync(&counts[k], st[k].clipped_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess
+           || hipStreamSynchronize(s) != hipSuccess))
       fail(DT_HIP_DEFAULT_ERROR);
-    if(!meet()) return give_up();
+    gang.meet(); // the one meeting of the walk: eight bytes per band through the host (the CFA stages are short)
+    if(gang.has_failed()) return give_up();
     // 2. the bypass of the highlight clipping is decided on the frame's count
     if(st[k].clipped_count)
     {
@@ -982,89 +1159,87 @@ int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_b
          || hipStreamSynchronize(s) != hipSuccess) // `total` is a stack variable
         fail(DT_HIP_DEFAULT_ERROR);
     }
-    if(gang.rc[k] >= 0 && (rc = dt_hip_pipe_band_resolve(pipe, &b, &st[k])) != DT_HIP_SUCCESS) fail(rc);
-    if(!meet()) return give_up();
-    // 3. mosaic rows the demosaic reads beyond the band
-    if(st[k].halo_buf && ((k > 0 && b.halo_top > bands[k - 1].rows) || (k + 1 < n && b.halo_bottom > bands[k + 1].rows)))
+    if(rcs[k] >= 0 && (rc = dt_hip_pipe_band_resolve(pipe, &b, &st[k])) != DT_HIP_SUCCESS) fail(rc);
+    if(rcs[k] < 0) return give_up();
+    int pt = 0; // the next point this band publishes; the same number on every band at the same place of the walk
+    // 3. mosaic rows the demosaic reads beyond the band: point 0 = "my CFA rows are final", point 1 = "I have pulled"
+    if(st[k].halo_buf)
     {
-      // caller-supplied bands thinner than the demosaic's halo: the pull below would read outside the neighbour's buffer
-      fail(DT_HIP_INVALID_ARG);
-      errors[k] = "dt_hip_pipe_process_bands: a band owns fewer rows than the mosaic halo its neighbour needs: use fewer bands";
-    }
-    else if(st[k].halo_buf)
-    {
+      if(!gang.publish(k, s)) return fail(DT_HIP_DEFAULT_ERROR, "hipEventRecord"), give_up();
       char *const mine = (char *)st[k].halo_buf;
       const size_t rb = st[k].row_bytes;
       if(k > 0 && b.halo_top && st[k - 1].halo_buf)
       {
+        if(!await(k - 1, pt)) return give_up();
         const dt_hip_band_t &ub = bands[k - 1];
-        rc = copy_between(devid, mine, pipes[k - 1]->devid,
+        rc = copy_between(gang, devid, mine, pipes[k - 1]->devid,
                           (const char *)st[k - 1].halo_buf + (size_t)(ub.halo_top + ub.rows - b.halo_top) * rb,
                           (size_t)b.halo_top * rb, s);
-        if(rc != DT_HIP_SUCCESS) fail(rc);
+        if(rc != DT_HIP_SUCCESS) return fail(rc), give_up();
       }
       if(k + 1 < n && b.halo_bottom && st[k + 1].halo_buf)
       {
+        if(!await(k + 1, pt)) return give_up();
         const dt_hip_band_t &db = bands[k + 1];
-        rc = copy_between(devid, mine + (size_t)(b.halo_top + b.rows) * rb, pipes[k + 1]->devid,
+        rc = copy_between(gang, devid, mine + (size_t)(b.halo_top + b.rows) * rb, pipes[k + 1]->devid,
                           (const char *)st[k + 1].halo_buf + (size_t)db.halo_top * rb, (size_t)b.halo_bottom * rb, s);
-        if(rc != DT_HIP_SUCCESS) fail(rc);
+        if(rc != DT_HIP_SUCCESS) return fail(rc), give_up();
       }
+      if(!gang.publish(k, s)) return fail(DT_HIP_DEFAULT_ERROR, "hipEventRecord"), give_up();
+      // nobody frees or overwrites rows a neighbour is still pulling
+      if((k > 0 && !await(k - 1, pt + 1)) || (k + 1 < n && !await(k + 1, pt + 1))) return give_up();
+      pt += 2;
     }
-    if(!meet()) return give_up();
-    // 4. the walk, stopping where a stencil module needs its neighbours
+    // 4. the walk, stopping where a stencil module needs its neighbours.  A stop is three points: "what the others
+    //    read from me is written", "my turn of a relay is over", "I have pulled everything I need".
     for(;;)
     {
       rc = dt_hip_pipe_band_finish(pipe, &b, &st[k], dev_out[k]);
-      if(rc < 0) fail(rc);
-      else gang.rc[k] = rc; // DT_HIP_SUCCESS or DT_HIP_BAND_EXCHANGE
-      const bool ok = meet();
-      if(!ok)
+      if(rc < 0)
       {
-        if(gang.rc[k] >= 0 && rc == DT_HIP_BAND_EXCHANGE) give_up(); // a finish() that failed has freed its state itself
-        return;
+        walking = false; // a finish() that failed has freed its state itself
+        return fail(rc), give_up();
       }
-      if(!any_stop) return; // every band has written its rows
-      gang.rc[k] = DT_HIP_SUCCESS;
-      if(!all_stop)
-      {
-        // cannot happen for bands of one node list: they stop in front of the same modules
-        if(rc == DT_HIP_BAND_EXCHANGE) give_up();
-        fail(DT_HIP_DEFAULT_ERROR);
-        errors[k] = "dt_hip_pipe_process_bands: the bands did not stop at the same module";
-        return;
-      }
+      if(rc == DT_HIP_SUCCESS) break;
+      stops++;
+      if(!gang.publish(k, s)) return fail(DT_HIP_DEFAULT_ERROR, "hipEventRecord"), give_up();
+      const bool everybody = st[k].relay_buf || (st[k].sum_buf && st[k].sum_planes > 0);
       if(st[k].relay_buf)
       {
         // local contrast: the bands splat their rows into the grid one after the other (the frame's pixel order), each
         // starting from the grid its predecessor left; the last band's grid is the frame's and goes to everybody
-        bool relay_ok = true;
-        for(int turn = 0; turn < n && relay_ok; turn++)
+        if(k > 0)
         {
-          if(turn == k)
-          {
-            if(k > 0 && (rc = copy_between(devid, st[k].relay_buf, pipes[k - 1]->devid, st[k - 1].relay_buf, st[k].relay_bytes, s)) != DT_HIP_SUCCESS)
-              fail(rc);
-            else if((rc = dt_hip_pipe_band_relay(pipe, &b, &st[k])) != DT_HIP_SUCCESS)
-              fail(rc);
-          }
-          relay_ok = meet();
+          if(!await(k - 1, pt + 1)) return give_up();
+          if((rc = copy_between(gang, devid, st[k].relay_buf, pipes[k - 1]->devid, st[k - 1].relay_buf, st[k].relay_bytes, s)) != DT_HIP_SUCCESS)
+            return fail(rc), give_up();
         }
-        if(!relay_ok) return give_up();
-        if(k + 1 < n && (rc = copy_between(devid, st[k].relay_buf, pipes[n - 1]->devid, st[n - 1].relay_buf, st[k].relay_bytes, s)) != DT_HIP_SUCCESS)
-          fail(rc);
+        if((rc = dt_hip_pipe_band_relay(pipe, &b, &st[k])) != DT_HIP_SUCCESS) return fail(rc), give_up();
+      }
+      if(!gang.publish(k, s)) return fail(DT_HIP_DEFAULT_ERROR, "hipEventRecord"), give_up(); // point pt + 1
+      if(st[k].relay_buf && k + 1 < n)
+      {
+        if(!await(n - 1, pt + 1)) return give_up();
+        if((rc = copy_between(gang, devid, st[k].relay_buf, pipes[n - 1]->devid, st[n - 1].relay_buf, st[k].relay_bytes, s)) != DT_HIP_SUCCESS)
+          return fail(rc), give_up();
       }
       if(st[k].sum_buf && st[k].sum_planes > 0)
       {
         const size_t plane = st[k].sum_count / (size_t)st[k].sum_planes, per_row = plane / (size_t)H;
-        for(int j = 0; j < n && gang.rc[k] >= 0; j++)
+        for(int j = 0; j < n; j++)
         {
           if(j == k) continue;
+          if(!await(j, pt)) return give_up();
           const size_t off = (size_t)bands[j].row0 * per_row, len = (size_t)bands[j].rows * per_row;
           // kind Default: the runtime routes the strided copy between the two devices' memories (unified addressing)
           if(hipMemcpy2DAsync(st[k].sum_buf + off, plane * sizeof(double), st[j].sum_buf + off, plane * sizeof(double),
                               len * sizeof(double), (size_t)st[k].sum_planes, hipMemcpyDefault, s) != hipSuccess)
-            fail(DT_HIP_DEFAULT_ERROR);
+            return fail(DT_HIP_DEFAULT_ERROR), give_up();
+          if(hip_device_of(pipes[j]->devid) != hip_device_of(devid))
+          {
+            gang.peer_bytes += len * sizeof(double) * (size_t)st[k].sum_planes;
+            gang.peer_copies++;
+          }
         }
       }
       if(st[k].halo_rows > 0 && st[k].halo_buf)
@@ -1079,43 +1254,98 @@ int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_b
         char *const mine = (char *)st[k].halo_buf;
         const size_t rb = st[k].row_bytes;
         if((k > 0 && bands[k - 1].rows < top) || (k + 1 < n && bands[k + 1].rows < bottom))
+          return fail(DT_HIP_INVALID_ARG, "dt_hip_pipe_process_bands: a band owns fewer rows than the halo its neighbour needs: use fewer bands"),
+                 give_up();
+        if(k > 0 && top)
         {
-          fail(DT_HIP_INVALID_ARG);
-          errors[k] = "dt_hip_pipe_process_bands: a band owns fewer rows than the halo its neighbour needs: use fewer bands";
+          int utop, ubot;
+          parts(k - 1, utop, ubot);
+          if(!await(k - 1, pt)) return give_up();
+          rc = copy_between(gang, devid, mine, pipes[k - 1]->devid,
+                            (const char *)st[k - 1].halo_buf + (size_t)(utop + bands[k - 1].rows - top) * rb, (size_t)top * rb, s);
+          if(rc != DT_HIP_SUCCESS) return fail(rc), give_up();
         }
-        else
+        if(k + 1 < n && bottom)
         {
-          if(k > 0 && top)
-          {
-            int utop, ubot;
-            parts(k - 1, utop, ubot);
-            rc = copy_between(devid, mine, pipes[k - 1]->devid,
-                              (const char *)st[k - 1].halo_buf + (size_t)(utop + bands[k - 1].rows - top) * rb, (size_t)top * rb, s);
-            if(rc != DT_HIP_SUCCESS) fail(rc);
-          }
-          if(k + 1 < n && bottom)
-          {
-            int dtop, dbot;
-            parts(k + 1, dtop, dbot);
-            rc = copy_between(devid, mine + (size_t)(top + b.rows) * rb, pipes[k + 1]->devid,
-                              (const char *)st[k + 1].halo_buf + (size_t)dtop * rb, (size_t)bottom * rb, s);
-            if(rc != DT_HIP_SUCCESS) fail(rc);
-          }
+          int dtop, dbot;
+          parts(k + 1, dtop, dbot);
+          if(!await(k + 1, pt)) return give_up();
+          rc = copy_between(gang, devid, mine + (size_t)(top + b.rows) * rb, pipes[k + 1]->devid,
+                            (const char *)st[k + 1].halo_buf + (size_t)dtop * rb, (size_t)bottom * rb, s);
+          if(rc != DT_HIP_SUCCESS) return fail(rc), give_up();
         }
       }
-      if(!meet()) return give_up();
+      if(!gang.publish(k, s)) return fail(DT_HIP_DEFAULT_ERROR, "hipEventRecord"), give_up(); // point pt + 2
+      // what the others pull from this band stays as it is until they have: the neighbours at a halo stop, everybody
+      // where the table of sums or the grid travelled
+      for(int j = 0; j < n; j++)
+        if(j != k && (everybody || j == k - 1 || j == k + 1) && !await(j, pt + 2)) return give_up();
+      pt += 3;
     }
+    walking = false;
+    if(hipStreamSynchronize(s) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      fail(DT_HIP_DEFAULT_ERROR, "the band's stream reported an error at the end of the walk");
+    }
+    gang.finished(k);
   };
 
   std::vector<std::thread> gangsters;
   gangsters.reserve(n);
-  for(int k = 0; k < n; k++) gangsters.emplace_back(worker, k);
+  int started = 0;
+  try
+  {
+    for(int k = 0; k < n; k++, started++) gangsters.emplace_back(worker, k);
+  }
+  catch(...)
+  {
+    // no thread for band `started`: the others must not wait for it at the meeting
+    gang.fail();
+    {
+      std::lock_guard<std::mutex> lk(gang.m);
+      gang.n = started;
+      if(gang.waiting >= gang.n && gang.n > 0)
+      {
+        gang.waiting = 0;
+        gang.generation++;
+      }
+      for(int k = started; k < n; k++) gang.done[k] = 1;
+      gang.cv.notify_all();
+    }
+    for(int k = started; k < n; k++) rcs[k] = DT_HIP_DEFAULT_ERROR, errors[k] = "no host thread for this band";
+  }
   for(auto &t : gangsters) t.join();
+  for(auto &ev : gang.events)
+    for(hipEvent_t e : ev) (void)hipEventDestroy(e);
+  {
+    std::lock_guard<std::mutex> lk(g_band_stats_mutex);
+    g_band_stats.bands = n;
+    int devs = 0;
+    for(int k = 0; k < n; k++)
+    {
+      bool seen = false;
+      for(int j = 0; j < k; j++) seen |= hip_device_of(pipes[j]->devid) == hip_device_of(pipes[k]->devid);
+      devs += !seen;
+    }
+    g_band_stats.devices = devs;
+    g_band_stats.exchange_stops = n ? stops.load() / n : 0;
+    g_band_stats.peer_copies = gang.peer_copies.load();
+    g_band_stats.peer_bytes = gang.peer_bytes.load();
+    g_band_stats.host_wait_ns = gang.host_wait_ns.load();
+    g_band_stats.pairs_without_peer_access = peer_missing.load();
+  }
   for(int k = 0; k < n; k++)
-    if(gang.rc[k] < 0)
+    if(rcs[k] < 0 && errors[k] != "another band failed")
     {
       set_last_error("band %d of %d: %s", k, n, errors[k].c_str());
-      return gang.rc[k];
+      return rcs[k];
+    }
+  for(int k = 0; k < n; k++)
+    if(rcs[k] < 0)
+    {
+      set_last_error("band %d of %d: %s", k, n, errors[k].c_str());
+      return rcs[k];
     }
   return DT_HIP_SUCCESS;
 }

@@ -855,6 +855,7 @@ size_t dt_hip_abi_sizeof(const char *name)
   S("tile_plan", dt_hip_tile_plan_t);
   S("band", dt_hip_band_t);
   S("band_state", dt_hip_band_state_t);
+  S("band_stats", dt_hip_band_stats_t);
 #undef S
   return 0;
 }

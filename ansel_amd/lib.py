@@ -157,6 +157,8 @@ def load():
         "dt_hip_pipe_band_relay": (i, [vp, P(abi.Band), P(abi.BandState)]),
         "dt_hip_pipe_band_abort": (None, [vp, P(abi.BandState)]),
         "dt_hip_pipe_process_bands": (i, [P(vp), i, P(abi.Band), P(vp), P(vp)]),
+        "dt_hip_pipe_bands_stats": (None, [P(abi.BandStats)]),
+        "dt_hip_peer_selftest": (i, [P(i), i]),
         "dt_hip_iop_highlights_process_deferred": (i, [i, P(abi.Piece), P(abi.HighlightsData), vp, vp, vp]),
         "dt_hip_iop_highlights_resolve": (i, [i, vp, vp]),
     }

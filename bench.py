@@ -65,9 +65,13 @@ def parse():
                     help="full = the metric's workload: config 3's modules (denoise (profiled) wavelets, diffuse or sharpen, "
                          "non-local means) + local contrast (bilateral grid); light = BASELINE.json config 2; "
                          "denoise = full without local contrast (round 2's config.full_pipe)")
-    ap.add_argument("--mode", default="batch", choices=("batch", "tiled"),
+    ap.add_argument("--mode", default="batch", choices=("batch", "tiled", "bands"),
                     help="N > 1: batch = one frame per GPU (config 5, weak); tiled = ONE frame cut into row bands, "
-                         "one band per GPU, halo rows exchanged over RCCL (config 4, strong)")
+                         "one band per GPU and rank, halo rows exchanged over RCCL (config 4, strong); bands = the same walk "
+                         "from ONE process through dt_hip_pipe_process_bands(): one host thread per band, peer copies "
+                         "between the devices ordered by events (no launcher; --gpus = devices, --bands = bands)")
+    ap.add_argument("--bands", type=int, default=0, help="--mode bands: number of row bands (default: one per device); more "
+                                                        "bands than devices puts several on a device (a one-GPU dry run)")
     return ap.parse_args()
 
 
@@ -380,8 +384,113 @@ def self_spawn(args):
     return subprocess.call(cmd, env=env)
 
 
+def bands_mode(args):
+    """BASELINE.json config 4 from ONE process: the frame cut into row bands, band k on device k % --gpus, walked by
+    dt_hip_pipe_process_bands() (a host thread per band; halo rows, the wavelets' partial sums and the bilateral grid as
+    peer copies between the devices, ordered by events).  Peer copies, not RCCL: one process owns every device."""
+    import numpy as np
+    import torch
+    from ansel_amd import abi, lib, params, pipe, synth, tiled
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --mode bands --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    ndev = args.gpus
+    nb = args.bands or ndev
+    l = lib.init()
+    devs = (C.c_int * ndev)(*range(ndev))
+    peer_rc = l.dt_hip_peer_selftest(devs, ndev)
+    peer_msg = None if peer_rc == 0 else l.dt_hip_last_error().decode()
+    if peer_rc != 0:
+        sys.stderr.write("bench.py: peer self-test FAILED: %s\n" % peer_msg)
+    width, height = frame_size(args.size)
+    npix = width * height
+    with_filmic = have_filmic()
+    raw_host = synth.bayer_mosaic_tiled(width, height, seed=1)
+    lut_host = params.srgb_encode_lut()
+    luts, pipes, ins, outs = [], [], [], []
+    nodes0 = None
+    for k in range(nb):
+        d = k % ndev
+        torch.cuda.set_device(d)
+        lut = torch.from_numpy(lut_host).to("cuda:%d" % d)
+        luts.append(lut)
+        nodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic, args.pipe)
+        nodes0 = nodes0 or nodes
+        pipes.append(pipe.DevicePipe(d, nodes, fusion=not args.no_fusion))
+    bands = tiled.plan_bands(width, height, nb, tiled.pipe_demosaic_method(nodes0))
+    for k, b in enumerate(bands):
+        d = "cuda:%d" % (k % ndev)
+        ins.append(torch.from_numpy(np.ascontiguousarray(raw_host[b.row0:b.row0 + b.rows]).view(np.int16)).to(d))
+        outs.append(torch.empty((b.rows, width, 4), dtype=torch.int16, device=d))
+    a_p = (C.c_void_p * nb)(*[p.handle for p in pipes])
+    a_b = (abi.Band * nb)(*bands)
+    a_i = (C.c_void_p * nb)(*[t.data_ptr() for t in ins])
+    a_o = (C.c_void_p * nb)(*[t.data_ptr() for t in outs])
+
+    def step():
+        lib.check(l.dt_hip_pipe_process_bands(a_p, nb, a_b, a_i, a_o), "dt_hip_pipe_process_bands")
+
+    def sync():
+        for d in range(ndev):
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = abi.BandStats()
+    l.dt_hip_pipe_bands_stats(C.byref(st))
+    verify = None
+    if not args.no_verify:
+        whole = np.concatenate([t.cpu().numpy().view(np.uint16) for t in outs], axis=0)
+
+        class _H:  # verify_output() takes a tensor-like with .cpu().numpy()
+            def cpu(self):
+                return self
+
+            def numpy(self):
+                return whole
+        verify = verify_output(_H(), raw_host, width, height, with_filmic, args.pipe)
+    ms = elapsed / args.steps * 1e3
+    bpp = pipe.algorithmic_bytes_per_pixel(nodes0)
+    line = {
+        "metric": "MPix/s full export pixelpipe (100 MP raw); % MI355X HBM roofline",
+        "value": round(npix / 1e6 / (elapsed / args.steps), 2), "unit": "MPix/s", "n_gpus": ndev, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "%d x %d RGGB u16 raw (%s), %s export pipe: %s; module defaults; ONE frame cut into %d row bands on %d "
+                        "device(s) of one process (dt_hip_pipe_process_bands: peer copies ordered by events, not RCCL)"
+                        % (width, height, args.size, args.pipe, " > ".join(n.op for n in nodes0), nb, ndev),
+            "frame_mpix": round(npix / 1e6, 2), "bands": nb, "devices": ndev,
+            "pipe_algorithmic_bytes_per_px": bpp,
+            "pipe_hbm_frac_per_device": round(bpp * npix / ndev / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "exchange_stops_per_frame": st.exchange_stops, "peer_copies_last_frame": st.peer_copies,
+            "peer_bytes_last_frame": st.peer_bytes, "host_wait_ms_all_bands_last_frame": round(st.host_wait_ns / 1e6, 3),
+            "pairs_without_peer_access": st.pairs_without_peer_access,
+            "peer_selftest": "ok" if peer_rc == 0 else peer_msg,
+        },
+        "roofline": None,
+    }
+    if verify is not None:
+        line["verified"] = verify["verified"]
+        line["verify"] = verify
+    print(json.dumps(line), flush=True)
+    for p in pipes:
+        p.close()
+    return 0
+
+
 def main():
     args = parse()
+    if args.mode == "bands":
+        return bands_mode(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(self_spawn(args))

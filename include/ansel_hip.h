@@ -817,11 +817,28 @@ void dt_hip_pipe_band_abort(dt_hip_pipe_t *pipe, dt_hip_band_state_t *state);
  * runs every pipe of the application; default_process_tiling_cl(), tiling.c:1394, is its only way to split a frame):
  * band k of the frame runs on pipes[k] -- n pipes loaded with the same node list, each on its own device (or all on
  * one: the single-GPU test) -- from dev_in[k] (the band's rows of the input, resident on that device) into
- * dev_out[k].  One host thread per band inside the call; halo rows and the wavelets' partial sums travel as peer
- * copies between the devices (xGMI), the 8-byte clipped count through the host.  Returns when every band's rows are
- * written (streams drained).  The assembled rows are bit-identical to dt_hip_pipe_process() on the whole frame. */
+ * dev_out[k].  One host thread per band inside the call; halo rows, the wavelets' partial sums and the bilateral grid
+ * travel as peer copies between the devices (xGMI; peer copies, not RCCL -- one process owns every device), ordered by
+ * hipEvents between the bands' streams: a band waits for the two bands it reads from, no stream is drained inside the
+ * walk; the 8-byte clipped count travels through the host.  Returns when every band's rows are written (streams
+ * drained).  The assembled rows are bit-identical to dt_hip_pipe_process() on the whole frame. */
 int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n_bands, const dt_hip_band_t *bands,
                               const dt_hip_mem_t *dev_in, const dt_hip_mem_t *dev_out);
+
+/* What the last dt_hip_pipe_process_bands() call did between the devices: bands, distinct devices, exchange stops per
+ * band, device-to-device copies and their bytes (zero when every band ran on one device), the host time the band threads
+ * spent waiting for each other to get as far enqueueing (never for a device), and ordered device pairs WITHOUT peer
+ * access (their copies are staged through the host by the runtime: correct, not xGMI speed). */
+typedef struct dt_hip_band_stats_t
+{
+  int32_t bands, devices, exchange_stops, pairs_without_peer_access;
+  uint64_t peer_copies, peer_bytes, host_wait_ns;
+} dt_hip_band_stats_t;
+void dt_hip_pipe_bands_stats(dt_hip_band_stats_t *out);
+/* Before the first multi-device walk: can every device of `devids` reach every other (hipDeviceCanAccessPeer), and does a
+ * device-to-device copy ordered by a cross-device event arrive intact?  0, or an error naming the pair
+ * (dt_hip_last_error()).  With one device in the list it checks the same calls on that device. */
+int dt_hip_peer_selftest(const int *devids, int n);
 
 /* layout self-check for language bindings: sizeof() of the struct named `name` as compiled */
 size_t dt_hip_abi_sizeof(const char *name);

@@ -35,7 +35,7 @@ def test_ctypes_mirror_covers_the_header():
     ("temperature", abi.TemperatureData), ("highlights", abi.HighlightsData), ("demosaic", abi.DemosaicData),
     ("exposure", abi.ExposureData), ("conversion", abi.Conversion), ("channelmixerrgb", abi.ChannelmixerrgbData),
     ("filmic_spline", abi.FilmicSpline), ("filmicrgb", abi.FilmicrgbData), ("diffuse", abi.DiffuseData), ("denoiseprofile", abi.DenoiseprofileData), ("nlmeans", abi.NlmeansData), ("lab", abi.LabData), ("bilat", abi.BilatData), ("finalscale", abi.FinalscaleData), ("blend", abi.BlendData), ("detailmask", abi.DetailmaskData), ("export_rows", abi.ExportRowsData), ("tile_plan", abi.TilePlan), ("band", abi.Band),
-    ("band_state", abi.BandState)])
+    ("band_state", abi.BandState), ("band_stats", abi.BandStats)])
 def test_struct_sizes_match_the_compiled_library(name, ctype):
     l = lib.load()
     assert l.dt_hip_abi_sizeof(name.encode()) == C.sizeof(ctype), name

@@ -392,3 +392,25 @@ def test_c_driver_reports_the_band_that_failed():
         _c_driver(torch, nodes, raw, w, h, 2)
     l.dt_hip_memory_statistics(0, C.byref(cur), C.byref(peak))
     assert cur.value == before
+
+
+def test_c_driver_statistics_and_the_peer_self_test():
+    """what a walk moved between devices (nothing here: one device), and the self-test of the calls a multi-device walk
+    rests on -- peer access, a device-to-device copy ordered by a cross-device event -- on the devices that are there"""
+    import ctypes as C
+    from ansel_amd import abi
+    torch, lut, d_lut = _setup()
+    w, h = 752, 2000
+    nodes = _full_nodes(w, h, d_lut, lut, "everything")
+    raw = synth.bayer_mosaic(w, h, seed=7)
+    _c_driver(torch, nodes, raw, w, h, 4)
+    l = lib.load()
+    st = abi.BandStats()
+    l.dt_hip_pipe_bands_stats(C.byref(st))
+    assert (st.bands, st.devices, st.peer_copies, st.peer_bytes, st.pairs_without_peer_access) == (4, 1, 0, 0, 0)
+    assert st.exchange_stops >= 10  # seven wavelet scales, the sums, diffuse, non-local means, the bilateral relay
+    ndev = torch.cuda.device_count()
+    devs = (C.c_int * ndev)(*range(ndev))
+    rc = l.dt_hip_peer_selftest(devs, ndev)
+    assert rc == 0, l.dt_hip_last_error()
+    assert l.dt_hip_peer_selftest(devs, 0) == abi.DT_HIP_INVALID_ARG
