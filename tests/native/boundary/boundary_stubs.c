@@ -4,11 +4,12 @@
  * unmodified, against include/ansel_opencl_peer.h) and with libansel_hip.so:
  *   * the host-side services those two files call -- cache lines, logging, the CPU fallback's entry -- in the simplest
  *     form that works for one module run (a cache line is a host buffer with at most one device payload);
- *   * one module written the way INTEGRATION.md section 2 tells a maintainer to write it: `exposure`, whose process_cl()
- *     is the four-line stub over dt_hip_iop_exposure_process(), with the module's own tiling_callback();
- *   * two drivers the test calls: the reference's pixelpipe_process_on_GPU() on that module (device path, output synced
- *     to the host cache line) and the reference's default_process_tiling_cl() on it (host-tiled path, the budget
- *     squeezed so that the frame takes many tiles).
+ *   * modules written the way INTEGRATION.md section 2 tells a maintainer to write them (integration_stubs.h, over the
+ *     reference's own dt_iop_<op>_data_t): `exposure` (pointwise) and `diffuse` (a stencil module: tiles overlap), and the
+ *     blend stage dt_develop_blend_process_cl() behind a module that supports blending;
+ *   * the drivers the test calls: the reference's pixelpipe_process_on_GPU() on exposure, plain and blended (device path,
+ *     output synced to the host cache line), and the reference's default_process_tiling_cl() on either module (host-tiled
+ *     path, the budget squeezed so that the frame takes many tiles; every process_cl() call's region is logged).
  */
 #include <math.h>
 #include <stdarg.h>
@@ -20,6 +21,8 @@
 #include "develop/pixelpipe_cpu.h"
 #include "develop/pixelpipe_gpu.h"
 #include "develop/tiling.h"
+
+#include "integration_stubs.h" /* the process_cl() / blend bodies of INTEGRATION.md section 2 over the reference's own data types */
 
 /* ---- logging ------------------------------------------------------------------------------------------------------ */
 static unsigned int g_debug = 0;
@@ -205,12 +208,12 @@ int dt_develop_blend_process(struct dt_iop_module_t *self, struct dt_dev_pixelpi
   g_unexpected++;
   return 1;
 }
+static int g_blend_cl_calls = 0;
 int dt_develop_blend_process_cl(struct dt_iop_module_t *self, struct dt_dev_pixelpipe_t *pipe,
                                 const struct dt_dev_pixelpipe_iop_t *piece, void *dev_in, void *dev_out)
 {
-  (void)self; (void)pipe; (void)piece; (void)dev_in; (void)dev_out;
-  g_unexpected++;
-  return 1;
+  g_blend_cl_calls++;
+  return stub_develop_blend_process_cl(self, pipe, piece, dev_in, dev_out); /* INTEGRATION.md section 2, the blend stage */
 }
 dt_iop_colorspace_type_t dt_develop_blend_colorspace(const struct dt_dev_pixelpipe_iop_t *const piece, dt_iop_colorspace_type_t cst)
 {
@@ -257,60 +260,82 @@ int pixelpipe_process_on_CPU(dt_dev_pixelpipe_t *pipe, const dt_dev_pixelpipe_io
   return 1;
 }
 
-/* ---- the module: exposure, written as INTEGRATION.md section 2 prescribes ------------------------------------------------ */
+/* ---- the modules: exposure and diffuse or sharpen, written as INTEGRATION.md section 2 prescribes (integration_stubs.h) -- */
 static int g_process_cl_calls = 0;
 static size_t g_tile_budget = 0; /* bytes one buffer of a tile may take (0: the device's real budget) */
-
-static dt_hip_piece_t piece_view(const dt_dev_pixelpipe_iop_t *piece)
+static int g_module_flags = IOP_FLAGS_ALLOW_TILING;
+#define TILE_LOG_MAX 4096
+static int g_tile_log[TILE_LOG_MAX][4]; /* roi_in of every process_cl() call: x, y, width, height */
+/* the test rebuilds the reference's tile plan from what the module was actually asked to process */
+int boundary_tile_log(int i, int *xywh)
 {
-  dt_hip_piece_t v;
-  memset(&v, 0, sizeof(v));
-  v.roi_in.x = piece->roi_in.x; v.roi_in.y = piece->roi_in.y; v.roi_in.width = piece->roi_in.width;
-  v.roi_in.height = piece->roi_in.height; v.roi_in.scale = piece->roi_in.scale;
-  v.roi_out.x = piece->roi_out.x; v.roi_out.y = piece->roi_out.y; v.roi_out.width = piece->roi_out.width;
-  v.roi_out.height = piece->roi_out.height; v.roi_out.scale = piece->roi_out.scale;
-  v.filters = piece->dsc_in.filters;
-  v.channels = piece->dsc_in.channels;
-  v.datatype = DT_HIP_TYPE_FLOAT;
-  for(int c = 0; c < 4; c++) v.processed_maximum[c] = piece->dsc_in.processed_maximum[c];
-  return v;
+  if(i < 0 || i >= g_process_cl_calls || i >= TILE_LOG_MAX) return 0;
+  memcpy(xywh, g_tile_log[i], sizeof(g_tile_log[i]));
+  return 1;
 }
+static void log_call(const struct dt_dev_pixelpipe_iop_t *piece)
+{
+  if(g_process_cl_calls < TILE_LOG_MAX)
+  {
+    int *e = g_tile_log[g_process_cl_calls];
+    e[0] = piece->roi_in.x; e[1] = piece->roi_in.y; e[2] = piece->roi_in.width; e[3] = piece->roi_in.height;
+  }
+  g_process_cl_calls++;
+}
+static void squeeze(const struct dt_dev_pixelpipe_t *pipe, struct dt_develop_tiling_t *tiling)
+{
+  if(g_tile_budget) /* the test squeezes the per-buffer budget: factor_cl = free memory / budget */
+    tiling->factor_cl = (float)dt_opencl_get_device_available(pipe->devid) / (float)g_tile_budget;
+}
+static int module_flags(void) { return g_module_flags; }
+
 static const char *exposure_name(void) { return "exposure"; }
-static int exposure_flags(void) { return IOP_FLAGS_ALLOW_TILING; }
 static int exposure_process_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
                                const struct dt_dev_pixelpipe_iop_t *piece, void *dev_in, void *dev_out)
 {
-  (void)self;
-  g_process_cl_calls++;
-  const dt_hip_piece_t v = piece_view(piece);
-  return dt_hip_iop_exposure_process(pipe->devid, &v, (const dt_hip_exposure_data_t *)piece->data, dev_in, dev_out) == DT_HIP_SUCCESS;
+  log_call(piece);
+  return stub_exposure_process_cl(self, pipe, piece, dev_in, dev_out);
 }
 static void exposure_tiling_callback(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
                                      const struct dt_dev_pixelpipe_iop_t *piece, struct dt_develop_tiling_t *tiling)
 {
   default_tiling_callback(self, pipe, piece, tiling); /* the reference's own default, tiling.c:1423-1463 */
-  if(g_tile_budget) /* the test squeezes the per-buffer budget: factor_cl = free memory / budget */
-    tiling->factor_cl = (float)dt_opencl_get_device_available(pipe->devid) / (float)g_tile_budget;
+  squeeze(pipe, tiling);
 }
-static int exposure_process_tiling_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
-                                      const struct dt_dev_pixelpipe_iop_t *piece, const void *const i, void *const o, const int bpp)
+static const char *diffuse_name(void) { return "diffuse"; }
+static int diffuse_process_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                              const struct dt_dev_pixelpipe_iop_t *piece, void *dev_in, void *dev_out)
+{
+  log_call(piece);
+  return stub_diffuse_process_cl(self, pipe, piece, dev_in, dev_out);
+}
+static void diffuse_tiling_callback(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                                    const struct dt_dev_pixelpipe_iop_t *piece, struct dt_develop_tiling_t *tiling)
+{
+  stub_diffuse_tiling_callback(self, pipe, piece, tiling); /* overlap = what the module's stencils reach */
+  squeeze(pipe, tiling);
+}
+static int module_process_tiling_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                                    const struct dt_dev_pixelpipe_iop_t *piece, const void *const i, void *const o, const int bpp)
 {
   return default_process_tiling_cl(self, pipe, piece, i, o, bpp);
 }
 
-static void make_module(dt_iop_module_t *m, dt_develop_t *dev)
+static void make_module(dt_iop_module_t *m, dt_develop_t *dev, const int diffuse)
 {
   memset(m, 0, sizeof(*m));
   memset(dev, 0, sizeof(*dev));
-  strcpy(m->op, "exposure");
+  strcpy(m->op, diffuse ? "diffuse" : "exposure");
   m->dev = dev;
-  m->name = exposure_name;
-  m->flags = exposure_flags;
-  m->tiling_callback = exposure_tiling_callback;
-  m->process_cl = exposure_process_cl;
-  m->process_tiling_cl = exposure_process_tiling_cl;
+  m->name = diffuse ? diffuse_name : exposure_name;
+  m->flags = module_flags;
+  m->tiling_callback = diffuse ? diffuse_tiling_callback : exposure_tiling_callback;
+  m->process_cl = diffuse ? diffuse_process_cl : exposure_process_cl;
+  m->process_tiling_cl = module_process_tiling_cl;
+  g_module_flags = IOP_FLAGS_ALLOW_TILING;
+  (void)integration_stub_table(0);
 }
-static void make_piece(dt_dev_pixelpipe_iop_t *piece, dt_iop_module_t *m, dt_hip_exposure_data_t *d, int w, int h)
+static void make_piece(dt_dev_pixelpipe_iop_t *piece, dt_iop_module_t *m, void *d, int w, int h)
 {
   memset(piece, 0, sizeof(*piece));
   piece->module = m;
@@ -328,18 +353,52 @@ static void make_piece(dt_dev_pixelpipe_iop_t *piece, dt_iop_module_t *m, dt_hip
   piece->dsc_in.cst = piece->dsc_out.cst = IOP_CS_RGB;
   for(int c = 0; c < 4; c++) piece->dsc_in.processed_maximum[c] = piece->dsc_out.processed_maximum[c] = 1.0f;
 }
+static dt_iop_exposure_data_t exposure_data(const float black, const float scale)
+{
+  dt_iop_exposure_data_t d; /* what commit_params() leaves in piece->data (exposure.c:381-420) */
+  memset(&d, 0, sizeof(d));
+  d.black = black;
+  d.scale = scale;
+  return d;
+}
 
 /* the reference's pixelpipe_process_on_GPU() on the module: device path, output synced back into the host line.
- * Returns its return value; *flow = the dt_pixelpipe_flow_t bits it set, *calls = process_cl() invocations */
-int boundary_run_exposure_gpu(const float *in, float *out, int w, int h, float black, float scale, int *flow, int *calls)
+ * Returns its return value; *flow = the dt_pixelpipe_flow_t bits it set, *calls = process_cl() invocations.
+ * blend != NULL: the module supports blending and carries these blend parameters (the fields of dt_hip_blend_data_t,
+ * moved into the reference's dt_develop_blend_params_t by name) -- dt_develop_blend_process_cl() runs behind process_cl() */
+static int run_exposure_gpu(const float *in, float *out, int w, int h, float black, float scale, const dt_hip_blend_data_t *blend,
+                            int *flow, int *calls)
 {
   if(dt_hip_init() != DT_HIP_SUCCESS) return -1;
   dt_iop_module_t m;
   dt_develop_t dev;
   dt_dev_pixelpipe_iop_t piece;
-  dt_hip_exposure_data_t d = { black, scale };
-  make_module(&m, &dev);
+  dt_iop_exposure_data_t d = exposure_data(black, scale);
+  make_module(&m, &dev, 0);
   make_piece(&piece, &m, &d, w, h);
+  dt_develop_blend_params_t bp;
+  memset(&bp, 0, sizeof(bp));
+  if(blend)
+  {
+    g_module_flags |= IOP_FLAGS_SUPPORTS_BLENDING;
+    bp.mask_mode = blend->mask_mode;
+    bp.blend_cst = blend->blend_cst;
+    bp.blend_mode = blend->blend_mode;
+    bp.blend_parameter = blend->blend_parameter;
+    bp.opacity = blend->opacity;
+    bp.mask_combine = blend->mask_combine;
+    bp.blendif = blend->blendif;
+    bp.feathering_radius = blend->feathering_radius;
+    bp.feathering_guide = blend->feathering_guide;
+    bp.blur_radius = blend->blur_radius;
+    bp.contrast = blend->contrast;
+    bp.brightness = blend->brightness;
+    bp.details = blend->details;
+    memcpy(bp.blendif_parameters, blend->blendif_parameters, sizeof(bp.blendif_parameters));
+    memcpy(bp.blendif_boost_factors, blend->blendif_boost_factors, sizeof(bp.blendif_boost_factors));
+    memcpy(g_stub_work_matrix_in, blend->matrix_in, sizeof(g_stub_work_matrix_in));
+    piece.blendop_data = &bp;
+  }
   dev.image_storage.dsc = piece.dsc_in;
   dt_dev_pixelpipe_t pipe;
   memset(&pipe, 0, sizeof(pipe));
@@ -356,6 +415,7 @@ int boundary_run_exposure_gpu(const float *in, float *out, int w, int h, float b
   dt_pixelpipe_flow_t fl = PIXELPIPE_FLOW_NONE;
   gboolean cache_output = TRUE; /* the test reads the result from the host line */
   g_process_cl_calls = 0;
+  g_blend_cl_calls = 0;
   g_tile_budget = 0;
   const int rc = pixelpipe_process_on_GPU(&pipe, &piece, NULL, &tiling, &fl, &cache_output, &ein, &eout);
   dt_opencl_finish(pipe.devid);
@@ -366,17 +426,43 @@ int boundary_run_exposure_gpu(const float *in, float *out, int w, int h, float b
   if(calls) *calls = g_process_cl_calls;
   return rc;
 }
+int boundary_run_exposure_gpu(const float *in, float *out, int w, int h, float black, float scale, int *flow, int *calls)
+{
+  return run_exposure_gpu(in, out, w, h, black, scale, NULL, flow, calls);
+}
+int boundary_run_exposure_blended_gpu(const float *in, float *out, int w, int h, float black, float scale,
+                                      const dt_hip_blend_data_t *blend, int *flow, int *blend_calls)
+{
+  int calls = 0;
+  const int rc = run_exposure_gpu(in, out, w, h, black, scale, blend, flow, &calls);
+  if(blend_calls) *blend_calls = g_blend_cl_calls;
+  return rc;
+}
 
-/* the reference's default_process_tiling_cl() on the module with `budget` bytes per tile buffer: TRUE on success */
-int boundary_run_exposure_tiled(const float *in, float *out, int w, int h, float black, float scale, size_t budget, int *calls)
+/* the reference's default_process_tiling_cl() on a module with `budget` bytes per tile buffer: TRUE on success.
+ * diffuse == NULL: exposure (black, scale); else diffuse or sharpen with these parameters (a stencil module: the
+ * reference's plan cuts overlapping tiles) */
+static int run_tiled(const float *in, float *out, int w, int h, float black, float scale, const dt_hip_diffuse_data_t *diffuse,
+                     size_t budget, int *calls)
 {
   if(dt_hip_init() != DT_HIP_SUCCESS) return -1;
   dt_iop_module_t m;
   dt_develop_t dev;
   dt_dev_pixelpipe_iop_t piece;
-  dt_hip_exposure_data_t d = { black, scale };
-  make_module(&m, &dev);
-  make_piece(&piece, &m, &d, w, h);
+  dt_iop_exposure_data_t d = exposure_data(black, scale);
+  dt_iop_diffuse_data_t dd;
+  memset(&dd, 0, sizeof(dd));
+  if(diffuse)
+  {
+    dd.iterations = diffuse->iterations; dd.sharpness = diffuse->sharpness; dd.radius = diffuse->radius;
+    dd.regularization = diffuse->regularization; dd.variance_threshold = diffuse->variance_threshold;
+    dd.anisotropy_first = diffuse->anisotropy_first; dd.anisotropy_second = diffuse->anisotropy_second;
+    dd.anisotropy_third = diffuse->anisotropy_third; dd.anisotropy_fourth = diffuse->anisotropy_fourth;
+    dd.threshold = diffuse->threshold; dd.first = diffuse->first; dd.second = diffuse->second; dd.third = diffuse->third;
+    dd.fourth = diffuse->fourth; dd.radius_center = diffuse->radius_center;
+  }
+  make_module(&m, &dev, diffuse != NULL);
+  make_piece(&piece, &m, diffuse ? (void *)&dd : (void *)&d, w, h);
   dt_dev_pixelpipe_t pipe;
   memset(&pipe, 0, sizeof(pipe));
   pipe.dev = &dev;
@@ -392,4 +478,13 @@ int boundary_run_exposure_tiled(const float *in, float *out, int w, int h, float
   dt_opencl_release_device(pipe.devid);
   if(calls) *calls = g_process_cl_calls;
   return ok;
+}
+int boundary_run_exposure_tiled(const float *in, float *out, int w, int h, float black, float scale, size_t budget, int *calls)
+{
+  return run_tiled(in, out, w, h, black, scale, NULL, budget, calls);
+}
+int boundary_run_diffuse_tiled(const float *in, float *out, int w, int h, const dt_hip_diffuse_data_t *diffuse, size_t budget,
+                               int *calls)
+{
+  return run_tiled(in, out, w, h, 0.0f, 1.0f, diffuse, budget, calls);
 }
