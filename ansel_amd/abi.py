@@ -17,6 +17,8 @@ DT_HIP_HIGHLIGHTS_CLIP = 0
 DT_HIP_DEMOSAIC_PPG = 0
 DT_HIP_DEMOSAIC_AMAZE = 1
 DT_HIP_DEMOSAIC_RCD = 5
+DT_HIP_DEMOSAIC_VNG4 = 2
+DT_HIP_DEMOSAIC_DUAL = 2048
 
 DT_HIP_ADAPTATION_LINEAR_BRADFORD = 0
 DT_HIP_ADAPTATION_CAT16 = 1
@@ -80,7 +82,8 @@ class HighlightsData(C.Structure):
 
 class DemosaicData(C.Structure):
     _fields_ = [("green_eq", C.c_uint32), ("color_smoothing", C.c_uint32),
-                ("demosaicing_method", C.c_uint32), ("median_thrs", C.c_float), ("green_eq_threshold", C.c_float)]
+                ("demosaicing_method", C.c_uint32), ("median_thrs", C.c_float), ("green_eq_threshold", C.c_float),
+                ("dual_thrs", C.c_float), ("wb_coeffs", C.c_float * 4)]
 
 
 class ExposureData(C.Structure):

@@ -14,6 +14,8 @@ int green_eq_favg_launch(int devid, const float *in, float *out, int width, int 
 int pre_median_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, float threshold);
 int color_smoothing_launch(int devid, float4 *img, int width, int height, int passes);
 int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
+int vng4_demosaic_launch(int devid, const dt_hip_piece_t *piece, const float *in, float4 *out);
+int dual_demosaic_launch(int devid, const dt_hip_piece_t *piece, const float *raw, float4 *rgb, float dual_threshold, const float wb[4]);
 }
 extern "C" uint32_t dt_hip_crop_dcraw_filters(uint32_t filters, uint32_t crop_x, uint32_t crop_y);
 
@@ -33,6 +35,23 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
   if(d->green_eq > 3)
   {
     set_last_error("demosaic: green_eq %u is not a dt_iop_demosaic_greeneq_t", d->green_eq);
+    return DT_HIP_INVALID_ARG;
+  }
+  const bool dual = (d->demosaicing_method & DT_HIP_DEMOSAIC_DUAL) != 0;
+  const uint32_t method = d->demosaicing_method & ~(uint32_t)DT_HIP_DEMOSAIC_DUAL;
+  if(dual && (method != DT_HIP_DEMOSAIC_RCD && method != DT_HIP_DEMOSAIC_AMAZE))
+  {
+    set_last_error("demosaic: the dual methods are RCD + VNG4 and AMaZE + VNG4 (method %u)", d->demosaicing_method);
+    return DT_HIP_INVALID_ARG;
+  }
+  if(dual && !(d->dual_thrs == d->dual_thrs))
+  {
+    set_last_error("demosaic: the dual threshold is not a number");
+    return DT_HIP_INVALID_ARG;
+  }
+  if(band && (dual || method == DT_HIP_DEMOSAIC_VNG4))
+  {
+    set_last_error("demosaic: VNG4 and the dual methods have no row-band mode (the detail mask's blur reads across bands)");
     return DT_HIP_INVALID_ARG;
   }
   if(d->color_smoothing > 5 || (d->median_thrs != 0.0f && d->demosaicing_method != DT_HIP_DEMOSAIC_PPG))
@@ -74,8 +93,11 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
     in = geq;
   }
   if(err == DT_HIP_SUCCESS)
-    switch(d->demosaicing_method)
+    switch(method)
     {
+      case DT_HIP_DEMOSAIC_VNG4:
+        err = vng4_demosaic_launch(devid, piece, in, (float4 *)dev_out);
+        break;
       case DT_HIP_DEMOSAIC_RCD:
         err = rcd_demosaic_launch(devid, piece, filters, in, (float4 *)dev_out, band);
         break;
@@ -106,6 +128,9 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
         set_last_error("demosaic: method %u is not implemented on device", d->demosaicing_method);
         err = DT_HIP_INVALID_ARG;
     }
+  // demosaic.c:1243-1247: the blend with VNG4 of the mosaic as the module received it (not the green-equilibrated copy)
+  if(err == DT_HIP_SUCCESS && dual)
+    err = dual_demosaic_launch(devid, piece, (const float *)dev_in, (float4 *)dev_out, d->dual_thrs, d->wb_coeffs);
   if(err == DT_HIP_SUCCESS && d->color_smoothing)
     err = color_smoothing_launch(devid, (float4 *)dev_out, piece->roi_out.width, piece->roi_out.height, (int)d->color_smoothing);
   if(geq) dt_hip_release_mem_object(geq);
@@ -140,7 +165,24 @@ void dt_hip_iop_demosaic_tiling(const dt_hip_piece_t *piece, const dt_hip_demosa
   tiling->overhead = 0;
   tiling->xalign = 2;
   tiling->yalign = 2;
-  tiling->overlap = (d->demosaicing_method == DT_HIP_DEMOSAIC_RCD) ? 10 : 5; // PPG and AMaZE: 5
+  const uint32_t method = d->demosaicing_method & ~(uint32_t)DT_HIP_DEMOSAIC_DUAL;
+  tiling->overlap = method == DT_HIP_DEMOSAIC_RCD ? 10 : 5; // PPG and AMaZE: 5
+  if(method == DT_HIP_DEMOSAIC_VNG4)
+  {
+    // demosaic.c:1995-2002: VNG4
+    tiling->xalign = tiling->yalign = 6;
+    tiling->overlap = 6;
+    tiling->factor_cl += 1.0f; // the linear interpolation
+  }
+  if(d->demosaicing_method & DT_HIP_DEMOSAIC_DUAL)
+  {
+    // demosaic.c:2004-2011: "make sure VNG4 is also possible"
+    tiling->factor += 1.0f;
+    tiling->xalign = tiling->xalign > 6 ? tiling->xalign : 6;
+    tiling->yalign = tiling->yalign > 6 ? tiling->yalign : 6;
+    tiling->overlap = tiling->overlap > 6 ? tiling->overlap : 6;
+    tiling->factor_cl += 2.0f + 0.75f; // VNG4's linear interpolation and result; luminance, raw mask, blend mask
+  }
 }
 
 } // extern "C"

@@ -181,6 +181,44 @@ int detail_refine_launch(int devid, const float *rawdetail, const float *form, f
   return check_launch("detail_refine");
 }
 
+// The blend mask of the dual demosaic (dual.c:83-85): dt_masks_calc_rawdetail_mask() of the high-frequency image with the
+// white-balance coefficients of the buffer, then dt_masks_calc_detail_mask(..., threshold, detail = TRUE) in place.
+int dual_blend_mask_launch(int devid, float4 *rgb, const float wb[3], float threshold, int width, int height, float *mask)
+{
+  if(width < 9 || height < 9) return DT_HIP_INVALID_ARG;
+  const size_t n = (size_t)width * height;
+  float *lum = (float *)dt_hip_alloc_device_buffer(devid, n * sizeof(float));
+  float *raw = (float *)dt_hip_alloc_device_buffer(devid, n * sizeof(float));
+  if(!lum || !raw)
+  {
+    if(lum) dt_hip_release_mem_object(lum);
+    if(raw) dt_hip_release_mem_object(raw);
+    return DT_HIP_SYSMEM_ALLOCATION;
+  }
+  blur_args a;
+  blur_9x9_coeff(a.c, 2.0f);
+  hipStream_t s = stream_of(devid);
+  {
+    launch_scope ls(devid, "rawdetail_luminance");
+    rawdetail_luminance<<<pixel_grid(n), 256, 0, s>>>(rgb, rgb, lum, n, wb[0], wb[1], wb[2]); // the copy is onto itself
+  }
+  {
+    launch_scope ls(devid, "rawdetail_scharr");
+    rawdetail_scharr<<<dim3((width + 63) / 64, (height + 3) / 4), 256, 0, s>>>(lum, raw, width, height);
+  }
+  {
+    launch_scope ls(devid, "detail_sigmoid");
+    detail_sigmoid<<<pixel_grid(n), 256, 0, s>>>(raw, lum, n, threshold, 1);
+  }
+  {
+    launch_scope ls(devid, "detail_refine");
+    detail_refine<<<dim3((width + 63) / 64, (height + 3) / 4), 256, 0, s>>>(lum, nullptr, mask, width, height, 1.0f, a);
+  }
+  dt_hip_release_mem_object(lum);
+  dt_hip_release_mem_object(raw);
+  return check_launch("dual_blend_mask");
+}
+
 } // namespace ansel
 
 extern "C" int dt_hip_iop_detailmask_process(int devid, const dt_hip_piece_t *piece, const dt_hip_detailmask_data_t *d,

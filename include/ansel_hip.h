@@ -293,7 +293,12 @@ int dt_hip_iop_highlights_resolve(int devid, dt_hip_mem_t dev_out, dt_hip_mem_t 
  * (dt_dev_get_roi_filters, src/develop/imageop.c:139) is applied inside. */
 #define DT_HIP_DEMOSAIC_PPG 0   /* DT_IOP_DEMOSAIC_PPG   (demosaic.c enum) */
 #define DT_HIP_DEMOSAIC_AMAZE 1 /* DT_IOP_DEMOSAIC_AMAZE */
+#define DT_HIP_DEMOSAIC_VNG4 2  /* DT_IOP_DEMOSAIC_VNG4  (vng.c:34-221: the interpolation the dual methods blend with) */
 #define DT_HIP_DEMOSAIC_RCD 5   /* DT_IOP_DEMOSAIC_RCD   */
+#define DT_HIP_DEMOSAIC_DUAL 2048 /* DEMOSAIC_DUAL (demosaic.c:110) or-ed onto RCD / AMaZE: DT_IOP_DEMOSAIC_RCD_VNG, _AMAZE_VNG --
+                                     dual_demosaic(), src/iop/demosaic/dual.c:40-110: VNG4 of the mosaic (as it came in, not
+                                     green-equilibrated) with two passes of colour smoothing, blended with the high-frequency
+                                     interpolation by the blurred sigmoid of ITS raw detail mask around dual_thrs */
 /* Around the interpolation, process() (demosaic.c:1137-1250) runs the module's optional steps:
  *   green_eq         0 DT_IOP_GREEN_EQ_NO, 1 _LOCAL: green_equilibration_lavg() (demosaic/basic.c:248-293) on the mosaic,
  *                    with green_eq_threshold = 0.0001f * img->exif_iso (demosaic.c:1049).  2 _FULL:
@@ -310,6 +315,8 @@ typedef struct dt_hip_demosaic_data_t
   uint32_t demosaicing_method;
   float median_thrs;
   float green_eq_threshold;
+  float dual_thrs;    /* dt_iop_demosaic_data_t.dual_thrs; read with DT_HIP_DEMOSAIC_DUAL only (<= 0: no blend, dual.c:52) */
+  float wb_coeffs[4]; /* piece->dsc_in.temperature.coeffs: the detail mask divides by them (dual.c:84); DUAL only */
 } dt_hip_demosaic_data_t;
 int dt_hip_iop_demosaic_process(int devid, const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d,
                                 dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);

@@ -114,7 +114,6 @@ int ref_develop_blend(const dt_hip_piece_t *v, const dt_hip_blend_data_t *h, con
    * _develop_blend_init_raster_mask() / _init_drawn_mask() / _refine_with_detail_mask() leave in `mask` (blend.c:740-790) */
   const float *const form = (const float *)h->form_mask;
   if((h->mask_mode & (DEVELOP_MASK_SHAPE | DEVELOP_MASK_RASTER)) && !form) return -1;
-  if(h->details != 0.f && !form && !h->detail_mask) return -1;
   if(form && h->blend_cst == DEVELOP_BLEND_CS_RAW) return -1;
   dt_develop_blend_params_t d;
   memset(&d, 0, sizeof(d));

@@ -816,7 +816,7 @@ int oracle_develop_blend(const dt_hip_piece_t *piece, const dt_hip_blend_data_t 
   /* drawn / raster masks and the details threshold: rendered and refined by the host into ONE plane, as the reference's
    * device blend receives them (blend.c:1278-1325) */
   if((d->mask_mode & (DT_HIP_MASK_SHAPE | DT_HIP_MASK_RASTER)) && !d->form_mask) return 1;
-  if(d->details != 0.f && !d->form_mask && !d->detail_mask) return 1;
+  /* a details threshold without the raw detail mask: _refine_with_detail_mask() returns silently (blend.c:379) */
   const float *form = (const float *)d->form_mask;
   float *refined = NULL;
   if(lab && !lab_mode_supported(d->blend_mode & 0xFFu)) return 1;

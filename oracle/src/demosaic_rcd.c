@@ -424,7 +424,12 @@ static const unsigned char k_median9[19][2] = { { 1, 2 }, { 4, 5 }, { 7, 8 }, { 
                                                 { 4, 5 }, { 7, 8 }, { 0, 3 }, { 5, 8 }, { 4, 7 }, { 3, 6 }, { 1, 4 },
                                                 { 2, 5 }, { 4, 7 }, { 4, 2 }, { 6, 4 }, { 4, 2 } };
 
+void oracle_color_smoothing(float *out, int width, int height, int passes);
 static void color_smoothing(float *out, const int width, const int height, const int passes)
+{
+  oracle_color_smoothing(out, width, height, passes);
+}
+void oracle_color_smoothing(float *out, const int width, const int height, const int passes)
 {
   const size_t npix = (size_t)width * height;
   for(int pass = 0; pass < passes; pass++)
@@ -461,6 +466,9 @@ static void color_smoothing(float *out, const int width, const int height, const
 
 /* process(), src/iop/demosaic.c:1041-1253, Bayer branch: [green equilibration, local average] -> demosaic ->
  * [colour smoothing]. */
+int oracle_demosaic_vng4(float *out, const float *in, int width, int height, int rx, int ry, uint32_t filters);
+int oracle_dual_demosaic(float *rgb, const float *raw, int width, int height, int rx, int ry, uint32_t filters, float dual_threshold,
+                         const float wb[4]);
 int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d, const void *in_, void *out)
 {
   if(d->green_eq > 3 || d->color_smoothing > 5) return 1;
@@ -483,7 +491,22 @@ int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d
                     piece->roi_in.y, d->green_eq_threshold);
     in = geq;
   }
-  const int rc = demosaic_methods(piece, d, in, out);
+  int rc;
+  if(d->demosaicing_method == DT_HIP_DEMOSAIC_VNG4)
+    rc = oracle_demosaic_vng4((float *)out, in, piece->roi_in.width, piece->roi_in.height, piece->roi_in.x, piece->roi_in.y,
+                              piece->filters);
+  else if(d->demosaicing_method & DT_HIP_DEMOSAIC_DUAL)
+  {
+    /* demosaic.c:1243-1247: the high-frequency method, then the blend with VNG4 of the mosaic as the module received it */
+    dt_hip_demosaic_data_t base = *d;
+    base.demosaicing_method = d->demosaicing_method & ~DT_HIP_DEMOSAIC_DUAL;
+    rc = demosaic_methods(piece, &base, in, out);
+    if(rc == 0)
+      rc = oracle_dual_demosaic((float *)out, (const float *)in_, piece->roi_in.width, piece->roi_in.height, piece->roi_in.x,
+                                piece->roi_in.y, piece->filters, d->dual_thrs, d->wb_coeffs);
+  }
+  else
+    rc = demosaic_methods(piece, d, in, out);
   free(geq);
   free(aux);
   if(rc == 0 && d->color_smoothing) color_smoothing((float *)out, piece->roi_out.width, piece->roi_out.height, (int)d->color_smoothing);

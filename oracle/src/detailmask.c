@@ -124,11 +124,20 @@ static const ring_t RINGS[13] = {
 
 /* dt_masks_calc_detail_mask(): `out` = the blurred sigmoid of the raw detail mask `rm`; level = the blend's details
  * threshold (!= 0) */
+void oracle_detail_mask_threshold(const float *rm, float *out, int width, int height, float threshold, int detail);
 void oracle_detail_mask(const float *rm, float *out, const int width, const int height, const float level)
 {
   const int detail = level > 0.0f;
   /* _detail_mask_threshold(), blend.c:355-359 */
   const float threshold = 0.005f * (detail ? powf(level, 2.0f) : 1.0f - powf(fabs(level), 0.5f));
+  oracle_detail_mask_threshold(rm, out, width, height, threshold, detail);
+}
+
+/* dt_masks_calc_detail_mask(src, out, tmp, width, height, threshold, detail), src/develop/masks/detail.c:325-335; rm == out
+ * is allowed (the reference's dual demosaic calls it in place) */
+void oracle_detail_mask_threshold(const float *rm, float *out, const int width, const int height, const float threshold,
+                                  const int detail)
+{
   float *tmp = (float *)malloc(sizeof(float) * (size_t)width * height);
   for(size_t idx = 0; idx < (size_t)width * height; idx++)
   {

@@ -181,3 +181,78 @@ def test_states_that_are_not_states_of_the_module_are_refused():
     assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
     d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.3, 0.0)   # a median threshold only exists for PPG
     assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
+
+
+# ---- VNG4 and the dual demosaic (vng.c:34-221, dual.c:35-110) -------------------------------------------------------------
+@pytest.mark.parametrize("w,h,roi_xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (120, 96, (1, 0)), (64, 40, (0, 1)), (19, 17, (0, 0)),
+                                         (1502, 1002, (0, 0))])
+def test_vng4(w, h, roi_xy):
+    rng = np.random.default_rng(w)
+    img = _normalised_cfa(w, h, seed=8)
+    img[rng.integers(4, h - 4, 5), rng.integers(4, w - 4, 5)] = [0.0, -0.01, 2.0, np.inf, 1e-30]
+    img[h // 2:h // 2 + 6, 3:12] = 0.25  # flat: every gradient zero, the pixel keeps its linear interpolation
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(*roi_xy, w, h), roi_out=abi.Roi.make(*roi_xy, w, h))
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_VNG4, 0.0)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4))
+    exp = hc.run_cpu("oracle", "demosaic", piece, d, img, (h, w, 4))
+    hc.assert_bit_exact(got, exp, "vng4 vs oracle")
+    ref = hc.run_cpu("ref", "demosaic", piece, d, img, (h, w, 4))
+    if ref is not None:
+        hc.assert_bit_exact(got, ref, "vng4 vs reference")
+
+
+@pytest.mark.parametrize("w,h,roi_xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (1502, 1002, (0, 1))])
+@pytest.mark.parametrize("base,geq,smooth,thrs", [(abi.DT_HIP_DEMOSAIC_RCD, 0, 0, 0.2), (abi.DT_HIP_DEMOSAIC_RCD, 1, 2, 0.05),
+                                                   (abi.DT_HIP_DEMOSAIC_AMAZE, 0, 1, 0.6), (abi.DT_HIP_DEMOSAIC_RCD, 0, 0, 0.0)])
+def test_dual_demosaic(w, h, roi_xy, base, geq, smooth, thrs):
+    """RCD + VNG4 and AMaZE + VNG4: VNG4 of the un-equilibrated mosaic, two smoothing passes, the blurred sigmoid of the
+    high-frequency image's raw detail mask, the blend -- every word equal to the oracle's (which equals the reference's
+    dual_demosaic() wherever that is a function of its input, tests/test_oracle_vs_ref.py)"""
+    img = _normalised_cfa(w, h, seed=9)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(*roi_xy, w, h), roi_out=abi.Roi.make(*roi_xy, w, h))
+    d = abi.DemosaicData(geq, smooth, base | abi.DT_HIP_DEMOSAIC_DUAL, 0.0, 0.04, thrs, (C.c_float * 4)(*synth.WB_COEFFS))
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4))
+    exp = hc.run_cpu("oracle", "demosaic", piece, d, img, (h, w, 4))
+    hc.assert_bit_exact(got, exp, "dual vs oracle")
+    if thrs > 0:
+        plain = hc.run_hip("dt_hip_iop_demosaic_process", piece, abi.DemosaicData(geq, smooth, base, 0.0, 0.04), img, (h, w, 4))
+        assert not np.array_equal(got, plain)
+
+
+def test_dual_demosaic_in_a_pipe():
+    """the executor takes the dual method as a demosaic node of its own (never fused, never on row bands)"""
+    import torch
+    from ansel_amd import filmic, params, pipe
+    w, h = 640, 480
+    lut = params.srgb_encode_lut()
+    d_lut = torch.from_numpy(lut).to("cuda:0")
+    coeffs = params.unbounded_coeffs(lut)
+    raw = synth.bayer_mosaic(w, h, seed=4)
+
+    def nodes(ptr):
+        ns = pipe.light_pipe_nodes(w, h, ptr, float(lut[0]), coeffs, with_filmic=True, filmic=filmic.default_data())
+        for n in ns:
+            if n.op == "demosaic":
+                n.data = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD | abi.DT_HIP_DEMOSAIC_DUAL, 0.0, 0.0, 0.2,
+                                          (C.c_float * 4)(*synth.WB_COEFFS))
+        return ns
+    p = pipe.DevicePipe(0, nodes(d_lut.data_ptr()), fusion=True)
+    d_in = torch.from_numpy(raw.view(np.int16)).to("cuda:0")
+    d_out = torch.zeros((h, w, 4), dtype=torch.int16, device="cuda:0")
+    p.process(d_in.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize()
+    p.close()
+    got = d_out.cpu().numpy().view(np.uint16)
+    src = raw
+    o = ck.oracle()
+    for n in nodes(lut.ctypes.data):
+        if n.op == "export_u16":
+            exp = np.zeros((h, w, 4), np.uint16)
+            o.oracle_export_convert_u16(w, h, ck.ptr(src), ck.ptr(exp))
+            break
+        dst = np.zeros((h, w) if n.op in ("rawprepare", "temperature", "highlights") else (h, w, 4), np.float32)
+        assert ck.call(o, "oracle_" + n.op, n.piece, n.data, np.ascontiguousarray(src), dst) == 0, n.op
+        src = dst
+    assert np.array_equal(got, exp)

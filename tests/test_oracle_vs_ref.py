@@ -864,3 +864,70 @@ def test_full_average_green_equilibration_around_every_interpolation(method, geq
     if mask is not None:
         d_ulp = d_ulp * (mask == 0)
     assert int((d_ulp > 1).sum()) == 0 and int((d_ulp > 0).sum()) == 0, "%d differ" % int((d_ulp > 0).sum())
+
+
+# ---- VNG4 and the dual demosaic (src/iop/demosaic/vng.c:34-221, dual.c:35-110) ---------------------------------------
+@pytest.mark.parametrize("w,h,xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (120, 96, (1, 0)), (64, 40, (0, 1)), (19, 17, (0, 0))])
+def test_demosaic_vng4(w, h, xy):
+    """the linear interpolation with its border ring and the gradient-thresholded averages, the two greens mixed at the
+    end: oracle == the reference's vng_interpolate(), every CFA phase, non-finite samples included"""
+    rng = np.random.default_rng(w + 5 * h)
+    cfa = synth.bayer_mosaic(w, h, seed=8).astype(np.float32)
+    img = ((cfa - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    img[rng.integers(4, h - 4, 5), rng.integers(4, w - 4, 5)] = [0.0, -0.01, 2.0, np.inf, 1e-30]
+    img[h // 2:h // 2 + 6, 3:12] = 0.25  # a flat patch: every gradient zero, the pixel keeps its linear interpolation
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(xy[0], xy[1], w, h), roi_out=abi.Roi.make(xy[0], xy[1], w, h))
+    a, b = _pair("demosaic", piece, abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_VNG4, 0.0), img, (h, w, 4))
+    _exact(a, b, "vng4")
+
+
+@pytest.mark.parametrize("w,h,xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (160, 140, (0, 1))])
+@pytest.mark.parametrize("base,geq,smooth,thrs", [(abi.DT_HIP_DEMOSAIC_RCD, 0, 0, 0.2), (abi.DT_HIP_DEMOSAIC_RCD, 1, 2, 0.05),
+                                                   (abi.DT_HIP_DEMOSAIC_AMAZE, 0, 0, 0.2), (abi.DT_HIP_DEMOSAIC_AMAZE, 0, 1, 0.6),
+                                                   (abi.DT_HIP_DEMOSAIC_RCD, 0, 0, 0.0)])
+def test_dual_demosaic(w, h, xy, base, geq, smooth, thrs):
+    """RCD + VNG4 / AMaZE + VNG4: the blend by the blurred sigmoid of the high-frequency image's raw detail mask, the VNG4
+    side taken from the un-equilibrated mosaic and smoothed twice; threshold 0 leaves the high-frequency image"""
+    cfa = synth.bayer_mosaic(w, h, seed=9).astype(np.float32)
+    img = ((cfa - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(xy[0], xy[1], w, h), roi_out=abi.Roi.make(xy[0], xy[1], w, h))
+    d = abi.DemosaicData(geq, smooth, base | abi.DT_HIP_DEMOSAIC_DUAL, 0.0, 0.04, thrs, (C.c_float * 4)(*synth.WB_COEFFS))
+    a, b = _pair("demosaic", piece, d, img, (h, w, 4))
+    mask = None
+    if base == abi.DT_HIP_DEMOSAIC_RCD:
+        # the reference's stale scratch columns (DESIGN.md section 3) reach the blend through the detail mask's 3 x 3
+        # gradient and 9 x 9 blur, and through the colour smoothing's medians
+        from scipy.ndimage import binary_dilation
+        m = np.zeros((h, w), np.uint8)
+        filters = ck.oracle().oracle_shift_dcraw_filters(C.c_uint32(synth.FILTERS_RGGB), xy[0], xy[1])
+        ck.oracle().oracle_rcd_stale_mask(ck.ptr(m), w, h, C.c_uint32(filters))
+        mask = np.zeros((h, w), np.uint8)
+        mask[:, w - 9:w - 6] = m[:, w - 9:w - 6]
+        if thrs > 0:
+            mask = binary_dilation(mask, iterations=5 + smooth, structure=np.ones((3, 3))).astype(np.uint8)
+            # ... and the mask's 4-pixel border repeats its nearest interior value: to the frame's edge
+            hit = mask.any(axis=1)
+            mask[np.nonzero(binary_dilation(hit, iterations=1))[0], w - 16:] = 1
+        elif smooth:
+            mask = binary_dilation(mask, iterations=smooth, structure=np.ones((3, 3))).astype(np.uint8)
+        mask = mask[..., None]
+    if base == abi.DT_HIP_DEMOSAIC_AMAZE:
+        m = np.zeros((h, w), np.uint8)
+        ck.oracle().oracle_amaze_stale_mask(ck.ptr(m), w, h)
+        from scipy.ndimage import binary_dilation
+        mask = None
+        if m.any() and thrs > 0:
+            mask = binary_dilation(m, iterations=5 + smooth, structure=np.ones((3, 3))).astype(np.uint8)
+            if mask[h - 6:].any():
+                mask[h - 6:] = 1
+            if mask[:, w - 6:].any():
+                mask[:, w - 6:] = 1
+            mask = mask[..., None]
+        elif m.any():
+            mask = (binary_dilation(m, iterations=smooth, structure=np.ones((3, 3))) if smooth else m).astype(np.uint8)[..., None]
+    _exact(a, b, "dual demosaic", mask)
+    if thrs > 0:
+        plain, _ = _pair("demosaic", piece, abi.DemosaicData(geq, smooth, base, 0.0, 0.04), img, (h, w, 4))
+        assert not np.array_equal(a, plain)  # the blend changed the picture
