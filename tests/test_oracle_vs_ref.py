@@ -465,10 +465,15 @@ def test_develop_blend_with_a_host_rendered_form_mask(cs, name, d):
     assert ck.call(o, "oracle_develop_blend", piece, d, a, y) == 0
     _exact(x, y, "blend with a form mask, " + name)
     assert not np.array_equal(x.view(np.uint32), b.view(np.uint32))
-    # and without the plane the same parameters are refused, never approximated
+    # without the plane a drawn / raster mask is refused, never approximated; a parametric-only blend whose details
+    # threshold has no raw detail mask runs unrefined, as _refine_with_detail_mask() does (blend.c:379)
     d.form_mask = None
-    assert ck.call(o, "oracle_develop_blend", piece, d, a, y) != 0
-    assert ck.call(r, "ref_develop_blend", piece, d, a, x) != 0
+    drawn = bool(d.mask_mode & (abi.MASK_SHAPE | abi.MASK_RASTER))
+    x, y = b.copy(), b.copy()
+    assert (ck.call(o, "oracle_develop_blend", piece, d, a, y) != 0) == drawn
+    assert (ck.call(r, "ref_develop_blend", piece, d, a, x) != 0) == drawn
+    if not drawn:
+        _exact(x, y, "parametric blend, details without a detail mask, " + name)
 
 
 def test_develop_blend_roi_offset():
