@@ -116,8 +116,12 @@ void oracle_amaze_persistent(const int on) { g_amaze_persistent = on; }
  * Bit set = that plane gets zero-initialised storage of its own instead of its partner's memory:
  *   1 dgrb0 / dgrb1 (with vcdalt)   2 delp / delm / rbint (with cddiffsq)   4 pmwt (with delhvsqsum)
  *   8 rbm / rbp (with vcd)         16 the second Nyquist flag plane (with cddiffsq's bytes)   32 dgrb2 (with dgintv)
+ *  64 (not a sharing) the Nyquist refinement runs over the whole tile interior instead of the bounding box of the flagged
+ *     sites, and also where the reference skips it because that box has no extent (amaze.cc:800-828): a frame that does
+ *     NOT change under this bit shows that the box is an optimisation, not a dependency of the whole tile
  * 0 = the reference's layout.  A frame that changes under a bit shows where a stencil reads what the partner left. */
 static unsigned g_amaze_unshare = 0;
+
 void oracle_amaze_unshare(const unsigned bits) { g_amaze_unshare = bits; }
 
 static void amaze_tile(tile_t *t, const float *in, float *out, const int width, const int height, const int top,
@@ -391,7 +395,16 @@ static void amaze_tile(tile_t *t, const float *in, float *out, const int width, 
         nyendcol = nyendcol < cc ? cc : nyendcol;
       }
     }
-  const int do_nyquist = nystartrow != nyendrow && nystartcol != nyendcol;
+  int do_nyquist = nystartrow != nyendrow && nystartcol != nyendcol;
+  if(g_amaze_unshare & 64)
+  {
+    /* probe: every site of the interior is voted on, flagged or not */
+    do_nyquist = 1;
+    nystartrow = 0;
+    nyendrow = rr1;
+    nystartcol = 0;
+    nyendcol = cc1;
+  }
   if(do_nyquist)
   {
     nyendrow++;

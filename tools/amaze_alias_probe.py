@@ -21,7 +21,8 @@ import checkers as ck  # noqa: E402
 from ansel_amd import abi, synth  # noqa: E402
 
 PAIRS = [(1, "dgrb0 / dgrb1 in vcdalt"), (2, "delp / delm / rbint in cddiffsq"), (4, "pmwt in delhvsqsum"),
-         (8, "rbm / rbp in vcd"), (16, "second Nyquist flag plane in cddiffsq's bytes"), (32, "dgrb2 in dgintv")]
+         (8, "rbm / rbp in vcd"), (16, "second Nyquist flag plane in cddiffsq's bytes"), (32, "dgrb2 in dgintv"),
+         (64, "(not a sharing) Nyquist refinement over the whole tile, not the flags' bounding box")]
 
 
 def frame(w, h, seed):
