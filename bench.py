@@ -309,10 +309,9 @@ def traffic_of(table, tag):
 
 
 # What binds each kernel, and the peak it is priced against.  HBM: 8 TB/s.  VALU: one wave64 instruction per
-# SIMD every 2 cycles for full-rate binary32, 4 for binary64 and packed, 8 for the quarter-rate transcendental
-# unit (profiles/r02_valu_issue_cycles.json, measured by tools/valu_microbench; MI355X_MICROARCH.md "Per-instruction
-# cycle constants") -> the kernel's issue-cycle total from its instruction mix (profiles/r02_isa_mix.json,
-# tools/valu_model.py) over 1024 SIMDs at 2.4 GHz is its floor.
+# SIMD every 2 cycles for full-rate binary32, 4 for binary64, 8 for the quarter-rate transcendental unit
+# (MI355X_MICROARCH.md "Per-instruction cycle constants") -> the kernel's issue-cycle total from its instruction mix
+# (profiles/r03_isa_mix.json, tools/valu_model.py arch) over 1024 SIMDs at 2.4 GHz is its floor.
 KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu", "rcd_tiles": "valu+lds",
                 "nlm_chunks": "lds+valu", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
                 "bilat_splat": "latency (one lane per grid node walks its pixels)", "bilat_slice": "hbm", "bilat_blur": "latency",
@@ -322,14 +321,16 @@ KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu"
 
 def valu_floor_ms(tag, mpix):
     """VALU issue floor of `tag` on a frame of `mpix` megapixels from the COMMITTED instruction-mix table
-    (profiles/r02_isa_mix.json: rocprofv3 SQ counters of this bench priced with tools/valu_microbench's cycles per
-    instruction class, tools/valu_model.py); None when the table lacks the kernel"""
+    (profiles/r03_isa_mix.json: rocprofv3 SQ counters of this bench priced at the ARCHITECTURAL issue rate of a SIMD-32 --
+    2 cycles per wave64 binary32 / integer instruction, 4 binary64, 8 transcendental -- at the 2.4 GHz peak clock,
+    tools/valu_model.py ... arch: a lower bound whatever the sustained clock); None when the table lacks the kernel"""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r02_isa_mix.json")))
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_isa_mix.json")))
     except (OSError, ValueError):
         return None
     alias = {"dn_decompose": "dn_decompose_strip", "nlm_chunks": "nlm_chunks_v2", "diffuse_decompose": "bspline_decompose_strip",
-             "diffuse_pde": "diffuse_pde_strip", "dn_finish_chain": "dn_finish_chain"}
+             "diffuse_pde": "diffuse_pde_strip", "dn_finish_chain": "dn_finish_chain", "nlm_chunks_v3": "nlm_chunks_v3"}
+    alias["nlm_chunks"] = "nlm_chunks_v3"
     kernels = mix.get("kernels", {})
     k = kernels.get(tag) or kernels.get(tag.replace("_u16", "")) or kernels.get(alias.get(tag, ""))
     if not k or "issue_floor_ms_per_mpix" not in k:

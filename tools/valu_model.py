@@ -2,7 +2,13 @@
 """The VALU issue floor of each profiled kernel: its dynamic instruction mix (rocprofv3 SQ counters, tools/pmc_sq_json.py)
 priced with the issue cost of each instruction class measured on this chip (tools/valu_microbench).
 
-    python tools/valu_model.py <pmc_sq.json> <valu_microbench.json> <frame pixels of the profiled run> <out.json>
+    python tools/valu_model.py <pmc_sq.json> <valu_microbench.json | arch> <frame pixels of the profiled run> <out.json>
+
+`arch` (round 3, what bench.py's valu_frac uses): the ARCHITECTURAL issue rate of a SIMD-32 instead of the microbenchmark's
+wall cycles -- 2 cycles per wave64 instruction for binary32 / integer / everything unclassified, 4 for binary64 and 64-bit
+integer, 8 for the quarter-rate transcendental unit, 16 for binary64 transcendentals (MI355X_MICROARCH.md, "Per-instruction
+cycle constants") at the 2.4 GHz peak clock: a true lower bound (floor / measured <= 1 whatever the sustained clock),
+where the wall-cycle prices of round 2 folded the clock deficit into the "floor" and overshot (1.01 on rgb_chain).
 
 For every kernel: valu_per_wave (SQ_INSTS_VALU / waves), the share of each counted class, and
 issue_cycles_per_wave = sum over classes of count x cycles, where `cycles` is the wall-clock cost of one wave64
@@ -23,9 +29,13 @@ import sys
 
 def main():
     sq = json.load(open(sys.argv[1]))
-    mb = json.load(open(sys.argv[2]))["classes"]
     mpix = float(sys.argv[3]) / 1e6
-    cyc = {k: v["W8"]["wall"] for k, v in mb.items()}
+    if sys.argv[2] == "arch":
+        cyc = {"v_add_f32": 2.0, "v_mul_f32": 2.0, "v_fma_f32": 2.0, "v_add_f64": 4.0, "v_mul_f64": 4.0, "v_fma_f64": 4.0,
+               "v_rcp_f32": 8.0, "v_rcp_f64": 16.0, "v_cvt_f64_f32": 2.0, "v_add_u32": 2.0, "v_and_b32": 2.0}
+    else:
+        mb = json.load(open(sys.argv[2]))["classes"]
+        cyc = {k: v["W8"]["wall"] for k, v in mb.items()}
     f32 = {"ADD_F32": cyc["v_add_f32"], "MUL_F32": cyc["v_mul_f32"], "FMA_F32": cyc["v_fma_f32"]}
     f64 = {"ADD_F64": cyc["v_add_f64"], "MUL_F64": cyc["v_mul_f64"], "FMA_F64": cyc["v_fma_f64"]}
     int32 = min(cyc["v_add_u32"], cyc["v_and_b32"])  # lower bound: most INT32 work is address adds
