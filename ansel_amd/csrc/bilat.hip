@@ -106,6 +106,116 @@ __global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat(const float *__rest
   }
 }
 
+// The second version of the gather.  What bound the first: 644 waves at 100 MP -- fewer than the chip has SIMDs -- each
+// walking ~10^4 pixels alone on its SIMD at ~80 dependent instructions a pixel, three exact divisions among them (the
+// pixel's column and lightness by the cell sizes, the contribution by sigma_s^2).  None of the three needs to be where
+// the chain is:
+//   * the lightness cell (zi, zf) of a pixel is the same for the four nodes it reaches: bilat_zcells computes it once per
+//     pixel, in parallel, where the first version only copied L out of the pixel;
+//   * the column weight wx depends on (node column, pixel column) only: every lane tabulates it once for the columns
+//     of its footprint (LDS, [column][lane]) -- 0 for the columns at the footprint's rim that belong to the cell beyond,
+//     whose contributions are then +0 and leave the sums (all >= +0) as they are, so the walk needs no branch;
+//   * x / sigma_s^2 has a wave-uniform denominator: its reciprocal and the Newton step on it are computed once, and a
+//     quotient is the remaining five operations of the correctly rounded sequence (div_by, below);
+//   * a wave's lanes are nodes of ONE grid row, so the row loop, the row weight and the row pointer are scalar.
+// ~20 instructions a pixel and the two read-add-write round trips of the cells, in pixel order as before.
+struct inv_t
+{
+  float d, y1; // the denominator and its refined reciprocal
+};
+__device__ __forceinline__ inv_t inv_of(const float d)
+{
+  const float y = __builtin_amdgcn_rcpf(d); // v_rcp_f32: within 1 ulp
+  inv_t r = { d, fmaf(fmaf(-d, y, 1.0f), y, y) };
+  return r;
+}
+// n / d, correctly rounded -- i.e. the quotient `/` gives -- for n = 0 and for operands and quotients well inside the
+// normal range (the caller's business): the sequence the compiler expands a division to, less its range scaling and its
+// special-case fix-up, and with the denominator's part hoisted.  tools/div_by_check.c: no difference from n / d in 2 10^9
+// random cases, with reciprocal seeds up to 2 ulp off.
+__device__ __forceinline__ float div_by(const float n, const inv_t i)
+{
+  const float q = n * i.y1;
+  const float q1 = fmaf(fmaf(-i.d, q, n), i.y1, q);
+  return fmaf(fmaf(-i.d, q1, n), i.y1, q1);
+}
+
+// (zf, zi) per pixel: image_to_grid()'s third axis, bilateral.c:127-155
+__global__ __launch_bounds__(256) void bilat_zcells(const float4 *__restrict__ in, float2 *__restrict__ zc, const size_t n,
+                                                    const float sigma_r, const int size_z)
+{
+  for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+  {
+    float zf;
+    const int zi = axis(in[k].x, sigma_r, size_z, zf);
+    zc[k] = make_float2(zf, __int_as_float(zi));
+  }
+}
+
+// blockIdx.y = the grid row Y, blockIdx.x = a block of 64 grid columns.  TABLE: the column weights fit in LDS
+template <bool TABLE>
+__global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat2(const float2 *__restrict__ zc, float *__restrict__ buf,
+                                                              const grid_t b, const int row_lo, const int row_hi,
+                                                              const int accumulate, const int fast_div)
+{
+  extern __shared__ float acc[]; // [size_z][SPLAT_THREADS], then the column weights [footprint column][SPLAT_THREADS]
+  float *const wxt = acc + b.size_z * SPLAT_THREADS;
+  const int tid = threadIdx.x;
+  const int Y = blockIdx.y, X = blockIdx.x * SPLAT_THREADS + tid;
+  const bool live = X < b.size_x;
+  for(int z = 0; z < b.size_z; z++)
+    acc[z * SPLAT_THREADS + tid] = (accumulate && live) ? buf[(size_t)(X + Y * b.size_x) * b.size_z + z] : 0.0f;
+  const float s2 = b.sigma_s * b.sigma_s;
+  const inv_t is2 = inv_of(s2);
+  // a dead lane walks the last node's columns and adds +0
+  const int Xn = live ? X : b.size_x - 1;
+  const int i0 = max(0, (int)floorf((Xn - 1) * b.sigma_s) - 2), i1 = min(b.width - 1, (int)ceilf((Xn + 1) * b.sigma_s) + 2);
+  const int j0 = max(row_lo, (int)floorf((Y - 1) * b.sigma_s) - 2), j1 = min(row_hi - 1, (int)ceilf((Y + 1) * b.sigma_s) + 2);
+  auto column_weight = [&](const int i) {
+    float xf;
+    const int xi = axis((float)i, b.sigma_s, b.size_x, xf);
+    return !live ? 0.0f : (xi == X ? 1.0f - xf : (xi == X - 1 ? xf : 0.0f));
+  };
+  if(TABLE)
+    for(int i = i0; i <= i1; i++) wxt[(i - i0) * SPLAT_THREADS + tid] = column_weight(i);
+  // the widest footprint of the wave: lanes with a narrower one add +0 beyond theirs
+  int span = i1 - i0 + 1;
+#pragma unroll
+  for(int off = 32; off >= 1; off >>= 1) span = max(span, __shfl_xor(span, off, 64));
+  for(int j = j0; j <= j1; j++)
+  {
+    float yf;
+    const int yi = axis((float)j, b.sigma_s, b.size_y, yf);
+    if(yi != Y && yi != Y - 1) continue; // uniform
+    const float wy = yi == Y ? (1.0f - yf) : yf;
+    const float2 *const rowp = zc + (size_t)(j - row_lo) * b.width;
+    for(int ub = 0; ub < span; ub += 16)
+    {
+      float2 cell[16];
+#pragma unroll
+      for(int u = 0; u < 16; u++) cell[u] = rowp[min(i0 + ub + u, i1)];
+#pragma unroll
+      for(int u = 0; u < 16; u++)
+      {
+        const int i = i0 + ub + u;
+        float wx = TABLE ? wxt[min(ub + u, i1 - i0) * SPLAT_THREADS + tid] : column_weight(min(i, i1));
+        if(i > i1) wx = 0.0f;
+        const float zf = cell[u].x;
+        const int zi = __float_as_int(cell[u].y);
+        const float num = wx * wy * 100.0f;
+        const float contrib = fast_div ? div_by(num, is2) : num / s2; // (1-xf)*(1-yf)*100/s2 and its three siblings
+        acc[zi * SPLAT_THREADS + tid] += (contrib * (1.0f - zf));
+        acc[(zi + 1) * SPLAT_THREADS + tid] += (contrib * zf);
+      }
+    }
+  }
+  if(live)
+  {
+    float *const cell = buf + (size_t)(X + Y * b.size_x) * b.size_z;
+    for(int z = 0; z < b.size_z; z++) cell[z] = acc[z * SPLAT_THREADS + tid];
+  }
+}
+
 // blur_line(), bilateral.c:299-338
 __global__ __launch_bounds__(64) void bilat_blur_line(float *__restrict__ buf, const int offset1, const int offset2,
                                                       const int offset3, const int size1, const int size2, const int size3)
@@ -252,15 +362,38 @@ int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_ro
   hipStream_t s = stream_of(devid);
   const int nodes = b.size_x * b.size_y;
   const size_t n = (size_t)b.width * (row_hi - row_lo);
-  float *L = (float *)dt_hip_alloc_device_buffer(devid, n * sizeof(float));
-  if(!L) return DT_HIP_SYSMEM_ALLOCATION;
+  static const bool v1 = getenv("ANSEL_HIP_BILAT_SPLAT_V1") != nullptr; // the first gather, for A/B timing
+  if(v1)
+  {
+    float *L = (float *)dt_hip_alloc_device_buffer(devid, n * sizeof(float));
+    if(!L) return DT_HIP_SYSMEM_ALLOCATION;
+    {
+      launch_scope ls(devid, "bilat_splat");
+      bilat_lightness<<<stream_grid(n, 256), 256, 0, s>>>(in_rows, L, n);
+      bilat_splat<<<(nodes + SPLAT_THREADS - 1) / SPLAT_THREADS, SPLAT_THREADS, (size_t)b.size_z * SPLAT_THREADS * sizeof(float), s>>>(
+          L, buf, b, row_lo, row_hi, accumulate);
+    }
+    dt_hip_release_mem_object(L); // stream-ordered
+    return DT_HIP_SUCCESS;
+  }
+  float2 *zc = (float2 *)dt_hip_alloc_device_buffer(devid, n * sizeof(float2));
+  if(!zc) return DT_HIP_SYSMEM_ALLOCATION;
   {
     launch_scope ls(devid, "bilat_splat");
-    bilat_lightness<<<stream_grid(n, 256), 256, 0, s>>>(in_rows, L, n);
-    bilat_splat<<<(nodes + SPLAT_THREADS - 1) / SPLAT_THREADS, SPLAT_THREADS, (size_t)b.size_z * SPLAT_THREADS * sizeof(float), s>>>(
-        L, buf, b, row_lo, row_hi, accumulate);
+    bilat_zcells<<<stream_grid(n, 256), 256, 0, s>>>(in_rows, zc, n, b.sigma_r, b.size_z);
+    const size_t cells = (size_t)b.size_z * SPLAT_THREADS * sizeof(float);
+    const size_t table = (size_t)((int)ceilf(2.0f * b.sigma_s) + 8) * SPLAT_THREADS * sizeof(float);
+    // div_by()'s premise: numerators are 0 or >= 2^-46 * 100 (two fractions of at least one ulp of a grid coordinate
+    // below 2^12 each), so with sigma_s^2 inside [2^-3, 2^40] every quotient is a normal number far from either end
+    const float s2 = b.sigma_s * b.sigma_s;
+    const int fast_div = s2 >= 0.125f && s2 <= 1099511627776.0f;
+    const dim3 grid((b.size_x + SPLAT_THREADS - 1) / SPLAT_THREADS, b.size_y);
+    if(cells + table <= 64 * 1024)
+      bilat_splat2<true><<<grid, SPLAT_THREADS, cells + table, s>>>(zc, buf, b, row_lo, row_hi, accumulate, fast_div);
+    else
+      bilat_splat2<false><<<grid, SPLAT_THREADS, cells, s>>>(zc, buf, b, row_lo, row_hi, accumulate, fast_div);
   }
-  dt_hip_release_mem_object(L); // stream-ordered
+  dt_hip_release_mem_object(zc); // stream-ordered
   return DT_HIP_SUCCESS;
 }
 

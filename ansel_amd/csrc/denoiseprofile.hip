@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256) void dn_finish_chain(float4 *__restrict__ out,
 // fast_mexp2f(), src/math/math.h:306-317
 __device__ __forceinline__ float mexp2(const float x)
 {
-  const float k0 = 1065353216.0f + x * (1056964608.0f - 1065353216.0f);
+  // x * -2^23 is exact (a power of two; an overflow is -inf either way), so the fused form rounds once to the same value
+  // as the reference's product-then-sum: one instruction instead of two
+  const float k0 = fmaf(x, 1056964608.0f - 1065353216.0f, 1065353216.0f);
   return __int_as_float(k0 >= 8388608.0f ? (int)k0 : 0);
 }
 
@@ -389,6 +391,7 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
     if(second) n1 = in[y + ecol1];
   }
   int s0 = 0; // ring slot of row k
+  float up1 = 0.f, up2 = 0.f, up2_next = 0.f; // the weights of the taps straight above, left by this lane one and two rows ago
   for(int k = 0; k < nrows; k++)
   {
     {
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
     {
       const int sc = s0 + 2 >= DN_RING ? s0 + 2 - DN_RING : s0 + 2;
       const float4 px = ring[sc * tw + tid + 2 * mult];
-      float sum[4] = { 0.f, 0.f, 0.f, 0.f }, wgt = 0.f;
+      float sum[4] = { 0.f, 0.f, 0.f, 0.f }, wgt = 0.f, down1 = 0.f, down2 = 0.f;
 #pragma unroll
       for(int jj = 0; jj < 5; jj++)
       {
@@ -431,11 +434,21 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
         {
           const float fi = ii == 0 || ii == 4 ? 0.0625f : (ii == 2 ? 0.375f : 0.25f);
           const float4 p2 = tap[ii];
-          // dn_weight(), eaw.c:181-195
-          const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
-          const float dot = (dx * dx + dy * dy + dz * dz) * inv_sigma2;
-          const float arg = dot * 0.02f - 9.0f;
-          const float wp = mexp2(0 > arg ? 0.0f : arg);
+          // dn_weight(), eaw.c:181-195.  It squares the differences of the two pixels, so the weight of this pixel's tap
+          // straight above is bit for bit the weight the pixel up there computed for its tap straight below: this lane,
+          // one or two rows ago (unless that row belongs to the strip in front: a uniform branch)
+          float wp;
+          if(ii == 2 && jj == 0 && k >= 2) wp = up2;
+          else if(ii == 2 && jj == 1 && k >= 1) wp = up1;
+          else
+          {
+            const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
+            const float dot = (dx * dx + dy * dy + dz * dz) * inv_sigma2;
+            const float arg = dot * 0.02f - 9.0f;
+            wp = mexp2(0 > arg ? 0.0f : arg);
+          }
+          if(ii == 2 && jj == 3) down1 = wp;
+          if(ii == 2 && jj == 4) down2 = wp;
           const float w = (fi * fj) * wp;
           wgt += w;
           sum[0] += w * p2.x;
@@ -446,6 +459,9 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
         // five reads in flight, not twenty-five: the next row's reads stay behind the sums of this one
         asm volatile("" : "+v"(wgt), "+v"(sum[0]), "+v"(sum[1]), "+v"(sum[2]), "+v"(sum[3]) : : "memory");
       }
+      up1 = down1;
+      up2 = up2_next;
+      up2_next = down2;
       float c4[4], d4[4];
       const float pin[4] = { px.x, px.y, px.z, px.w };
 #pragma unroll

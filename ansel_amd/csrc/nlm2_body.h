@@ -78,6 +78,18 @@ template <class Env> NLM2_FN float mexp2(const float x)
   return Env::int_as_float(k0 >= 0x800000 ? k0 : 0);
 }
 
+// The same for x = distortion * sharpness, given the distortion and sharpness * -2^23 (exact: a power of two).  Scaling
+// by a power of two commutes with the product's rounding -- (d * s) * -2^23 == d * (s * -2^23) bit for bit -- except where
+// d * s is subnormal or overflows, and there both forms convert to the same integer (0; INT_MIN): one product instead
+// of two.  And the NaN correction as ONE instruction: maxNum(v, -inf) is v for every number and -inf, which converts
+// to INT_MIN, for a NaN (v is the result of a product, so a quiet one).
+template <class Env> NLM2_FN float mexp2_scaled(const float distortion, const float sharp_m23)
+{
+  const float v = Env::max_num(distortion * sharp_m23, -__builtin_inff());
+  const int k0 = (int)(0x3f800000u + (unsigned)Env::cvt_i32_sat(v));
+  return Env::int_as_float(k0 >= 0x800000 ? k0 : 0);
+}
+
 // Env: tid(), bid(), lds(), sync(), prio_high(), cvt_i32_sat(), int_as_float(); TIMED + clock() for the measuring build.
 // Args: nlm_args of nlmeans.hip (W, H, chk_w, chk_h, nchx, npatch, sharpness, norm[3], luma, chroma, skip_blend,
 // reach, cy0, out_row0, out_row1, variant).  F4 / I2: float4 / int2.

@@ -470,7 +470,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
 #pragma unroll
     for(int i = 0; i < NR; i++) qx[i] = qy[i] = qz[i] = 0.0f;
     const int doff = r * TP + 4 + cb;
-    const float sharp = a.sharpness;
+    const float sharp_m23 = a.sharpness * -8388608.0f;
 
     auto fetch = [&](auto m_tag, const int p, const bool first, const int dy, const int dx) {
       constexpr int M = decltype(m_tag)::value;
@@ -506,7 +506,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       for(int i = 0; i < NPXL; i++)
       {
         const int sl = (i + M) % NR;
-        const float wgt = nlm2::mexp2<Env>(dist[M & 1][i] * sharp);
+        const float wgt = nlm2::mexp2_scaled<Env>(dist[M & 1][i], sharp_m23);
         accx[i] = accx[i] + qx[sl] * wgt;
         accy[i] = accy[i] + qy[sl] * wgt;
         accz[i] = accz[i] + qz[sl] * wgt;

@@ -67,6 +67,7 @@ struct HostEnv
     if(v <= -2147483648.0f) return (int)0x80000000;
     return (int)v;
   }
+  static float max_num(const float a, const float b) { return fmaxf(a, b); } // v_max_f32: the number, if one is a NaN
   static float int_as_float(const int v)
   {
     float f;
