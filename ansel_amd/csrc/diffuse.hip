@@ -325,8 +325,14 @@ __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf
 // rolls the three rows of its three columns through registers and fetches ONE new row (6 float4) per output row
 // instead of three (18), and the squared ratios go into a ring of four LDS rows, one NEW row per output row: 4 - 8
 // divisions per pixel where the per-row kernel has 12 - 24.  Same operands, same operations, same order.
+// HSUB: the high-frequency plane is not in memory -- `hf` is the low-pass plane of this scale, `hsub` that of the next
+// coarser one, and a support sample is their difference, the subtraction decompose_2D_Bspline() stores (bspline.h:369-374:
+// same operands, same operation).  The analysis then writes 16 B per pixel and scale instead of 32, and this kernel, which
+// waits for its arithmetic and not for its fetches, reads 48 instead of 32.
 #define PDE_RING 4
-__global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__restrict__ hf, const float4 *__restrict__ lf,
+template <bool HSUB>
+__global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__restrict__ hf, const float4 *__restrict__ hsub,
+                                                         const float4 *__restrict__ lf,
                                                          float4 *__restrict__ out, const pde_args a, const int final_pass,
                                                          const unsigned char *__restrict__ mask, const int strip,
                                                          const int strips_per_class)
@@ -352,7 +358,13 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
 #pragma unroll
     for(int jj = 0; jj < 3; jj++)
     {
-      H4[3 * ii + jj] = hf[y + cols[jj]];
+      if(HSUB)
+      {
+        const float4 c = hf[y + cols[jj]], low = hsub[y + cols[jj]];
+        H4[3 * ii + jj] = make_float4(c.x - low.x, c.y - low.y, c.z - low.z, c.w - low.w);
+      }
+      else
+        H4[3 * ii + jj] = hf[y + cols[jj]];
       L4[3 * ii + jj] = lf[y + cols[jj]];
     }
   };
@@ -607,11 +619,16 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
   const int iterations = it_req > 1 ? it_req : 1;
 
   // planes: HF[scales], two low-pass ping-pong, two iteration ping-pong (diffuse.c:1167-1195)
+  // LF chain (every scale on the strip kernel): hf[s] holds the LOW-pass plane of scale s + 1 instead, nothing stores a
+  // high-frequency plane, and one plane besides them serves the synthesis' ping-pong (a plane fewer than the reference)
+  static const bool per_row_pde = getenv("ANSEL_HIP_PDE_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
+  static const bool hf_planes = getenv("ANSEL_HIP_DIFFUSE_HF_PLANES") != nullptr; // the stored-HF path, for A/B timing
+  const bool lf_chain = !per_row_pde && !hf_planes && (1 << (scales - 1)) <= PDE_SHARED_MULT;
   float4 *hf[DIFFUSE_MAX_SCALES] = { nullptr };
   float4 *lf[2] = { nullptr, nullptr }, *tmp[2] = { nullptr, nullptr };
   bool ok = true;
   for(int s = 0; s < scales; s++) ok &= (hf[s] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
-  for(int k = 0; k < 2; k++) ok &= (lf[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
+  for(int k = 0; k < (lf_chain ? 1 : 2); k++) ok &= (lf[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
   if(iterations > 1)
     for(int k = 0; k < 2 && k < iterations - 1; k++)
       ok &= (tmp[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
@@ -659,10 +676,21 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
     float4 *dst = (it == iterations - 1) ? (float4 *)dev_out : tmp[it % 2];
     const float4 *level = src;
     float4 *residual = lf[0];
+    // the chain reads the iteration's input until its last pass: not when that pass writes the same plane
+    const bool chain = lf_chain && (const float4 *)dst != src;
+    if(!chain && !lf[1])
+    {
+      lf[1] = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
+      if(!lf[1])
+      {
+        err = DT_HIP_SYSMEM_ALLOCATION;
+        break;
+      }
+    }
     for(int s = 0; s < scales && err == DT_HIP_SUCCESS; s++)
     {
-      float4 *low = lf[s % 2];
-      err = bspline_launch_decompose(devid, st, level, hf[s], low, w, h, 1 << s);
+      float4 *low = chain ? hf[s] : lf[s % 2];
+      err = bspline_launch_decompose(devid, st, level, chain ? nullptr : hf[s], low, w, h, 1 << s);
       level = low;
       residual = low;
     }
@@ -684,13 +712,15 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
         a.post_lab = 1;
         memcpy(a.post_m, post_lab->matrix, sizeof(a.post_m));
       }
-      float4 *to = (s == 0) ? dst : pp[count % 2];
+      // chain: scale s reads the low-pass planes of scales s (hf[s - 1], or the iteration's input) and s + 1 (hf[s]) and
+      // the running sum; free to write are lf[0] and, once scale s + 1 is done, hf[s + 1]: they alternate
+      float4 *to = (s == 0) ? dst : (chain ? (count % 2 == 0 ? lf[0] : hf[s + 1]) : pp[count % 2]);
       const int rows = (h <= a.mult) ? h : ((h + a.mult - 1) / a.mult) * a.mult;
       {
         launch_scope ls(devid, "diffuse_pde");
         // gridDim.x padded to a multiple of 8: a column block stays on one XCD, the rows above and below hit its L2
         const dim3 grid(xcd_pad((w + 255) / 256), rows);
-        static const bool per_row = getenv("ANSEL_HIP_PDE_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
+        const bool per_row = per_row_pde;
         if(a.mult <= PDE_SHARED_MULT && !per_row)
         {
           const int classes = h < a.mult ? h : a.mult, per_class = (h + a.mult - 1) / a.mult;
@@ -698,8 +728,13 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           int strip = 32;
           while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
           const int spc = (per_class + strip - 1) / strip;
-          diffuse_pde_strip<<<dim3(gx, classes * spc), 256, (size_t)PDE_RING * (256 + 2 * a.mult) * sizeof(float4), st>>>(
-              hf[s], cur, to, a, s == 0, mask, strip, spc);
+          const size_t ring = (size_t)PDE_RING * (256 + 2 * a.mult) * sizeof(float4);
+          if(chain)
+            diffuse_pde_strip<true><<<dim3(gx, classes * spc), 256, ring, st>>>(s == 0 ? src : hf[s - 1], hf[s], cur, to, a, s == 0,
+                                                                                  mask, strip, spc);
+          else
+            diffuse_pde_strip<false><<<dim3(gx, classes * spc), 256, ring, st>>>(hf[s], nullptr, cur, to, a, s == 0, mask, strip,
+                                                                                   spc);
         }
         else if(a.mult <= PDE_SHARED_MULT)
           diffuse_pde<true><<<grid, 256, (size_t)3 * (256 + 2 * a.mult) * sizeof(float4), st>>>(hf[s], cur, to, a, s == 0, mask);

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void bspline_decompose_strip(const float4 *__r
       const float4 low = tap5(t[0], t[1], t[2], t[3], t[4]);
       const size_t o = (size_t)row * width + col;
       lf[o] = low;
-      nt_store(hf + o, make_float4(c.x - low.x, c.y - low.y, c.z - low.z, c.w - low.w));
+      // hf == nullptr: the caller keeps every low-pass plane and its PDE kernel forms centre - low itself (diffuse.hip)
+      if(hf) nt_store(hf + o, make_float4(c.x - low.x, c.y - low.y, c.z - low.z, c.w - low.w));
     }
     a = b;
     b = c;
