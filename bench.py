@@ -294,7 +294,7 @@ TAG_KERNELS = {
     "nlm_chunks": ("nlm_chunks_v3", "nlm_chunks_v2", "nlm_chunks_pipelined", "nlm_chunks"),
     "diffuse_pde": ("diffuse_pde_strip", "diffuse_pde"), "diffuse_decompose": ("bspline_decompose_strip", "bspline_decompose"),
     "dn_decompose": ("dn_decompose_strip", "dn_decompose"), "rgb_chain_u16": ("rgb_chain",), "rgb_chain_rows16": ("rgb_chain",),
-    "bilat_blur": ("bilat_blur_line", "bilat_blur_line_z"), "bilat_splat": ("bilat_splat", "bilat_lightness"),
+    "bilat_blur": ("bilat_blur_line", "bilat_blur_line_z"), "bilat_splat": ("bilat_splat2", "bilat_zcells", "bilat_splat", "bilat_lightness"),
     "dn_band_threshold": ("dn_band_sums", "dn_band_threshold"),
 }
 
@@ -314,7 +314,7 @@ def traffic_of(table, tag):
 # (profiles/r03_isa_mix.json, tools/valu_model.py arch) over 1024 SIMDs at 2.4 GHz is its floor.
 KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu", "rcd_tiles": "valu+lds",
                 "nlm_chunks": "lds+valu", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
-                "bilat_splat": "latency (one lane per grid node walks its pixels)", "bilat_slice": "hbm", "bilat_blur": "latency",
+                "bilat_splat": "latency (one lane per grid node walks its pixels in order)", "bilat_slice": "hbm", "bilat_blur": "latency",
                 "dn_synthesize": "hbm", "dn_precondition": "hbm", "dn_finish": "hbm", "dn_finish_chain": "hbm", "rgb_to_lab": "hbm",
                 "lab_to_rgb": "hbm"}
 

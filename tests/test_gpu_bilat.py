@@ -25,7 +25,9 @@ def _lab_image(w, h, seed):
 
 
 @pytest.mark.parametrize("w,h", [(300, 200), (123, 457), (1500, 1000)])
-@pytest.mark.parametrize("ss,sr,detail", [(50.0, 25.0, 0.33), (8.0, 5.0, -0.5), (0.3, 2.0, 1.5), (20.0, 60.0, 4.0)])
+# (150, ...) on the large frame: a footprint wider than the LDS table of column weights holds (the gather computes them inline)
+@pytest.mark.parametrize("ss,sr,detail", [(50.0, 25.0, 0.33), (8.0, 5.0, -0.5), (0.3, 2.0, 1.5), (20.0, 60.0, 4.0),
+                                          (150.0, 10.0, 0.7)])
 def test_bilat(w, h, ss, sr, detail):
     if ss < 1.0 and w * h > 500000:
         pytest.skip("sub-pixel sigma on the large frame: the grid has millions of nodes, covered on the small frames")

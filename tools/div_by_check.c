@@ -1,4 +1,10 @@
-// is q = fma(r1, y1, q1) the correctly rounded n / d for every y within a few ulp of 1/d (v_rcp_f32: 1 ulp)?
+// div_by() of ansel_amd/csrc/bilat.hip on the host: is the quotient's sequence with the denominator's part hoisted --
+// y1 = fma(fma(-d, y, 1), y, y) once; q = n * y1, q1 = fma(fma(-d, q, n), y1, q), result = fma(fma(-d, q1, n), y1, q1)
+// per numerator -- the correctly rounded n / d for EVERY reciprocal seed y within 2 ulp of 1 / d (v_rcp_f32: 1 ulp),
+// for n = 0 and n in [2^-40, 2^8), d in [2^-3, 2^24)?  (Every operation scales exactly with the operands' exponents, so
+// the ranges stand for any operands whose quotient and residuals stay normal.)
+//   gcc -O2 -ffp-contract=off -o div_by_check tools/div_by_check.c -lm && ./div_by_check [cases, default 4e8]
+// prints "<bad> bad of <cases x 5>"; tests/test_div_by.py runs 2e7 cases.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,11 +20,12 @@ static float fdiv_inv(float n, float d, float y)
   float r1 = fmaf(-d, q1, n);
   return fmaf(r1, y1, q1);
 }
-int main()
+int main(int argc, char **argv)
 {
+  const long cases = argc > 1 ? atol(argv[1]) : 400000000L;
   uint64_t s = 88172645463325252ull;
   long bad = 0, tot = 0;
-  for(long it = 0; it < 400000000L; it++)
+  for(long it = 0; it < cases; it++)
   {
     s ^= s << 13; s ^= s >> 7; s ^= s << 17;
     uint32_t a = (uint32_t)s, b = (uint32_t)(s >> 32);
@@ -39,5 +46,5 @@ int main()
     }
   }
   printf("%ld bad of %ld\n", bad, tot);
-  return 0;
+  return bad != 0;
 }
