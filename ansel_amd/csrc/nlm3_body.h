@@ -94,6 +94,9 @@ template <int NPXL, int MSEG> inline bool fits(const int chk_w, const int chk_h,
   return nseg == 2 && (m0 + nseg - 1) / nseg <= MSEG;
 }
 
+// a chunk of the border ring the BORDER body takes (the others keep the first version's body): rows for every chain
+inline constexpr bool border_fits(const int cw, const int ch) { return ch >= 10 && cw >= 1; }
+
 // the offsets as rows of consecutive column shifts: ndx per row, every row starting at the same column shift
 template <class I2> inline bool regular_grid(const I2 *const patches, const int n, int *const ndx_out)
 {
@@ -123,7 +126,19 @@ template <int T0, int T1, int ROWBYTES, class Env> struct column_chain
 };
 
 // Env: tid(), bid(), lds(), sync(), prio_high(), st_addtid<>(), cvt_i32_sat(), int_as_float().  Args: nlm_args of nlmeans.hip.
-template <int NPXL, int MSEG, class Env, class Args, class F4, class I2>
+// BORDER: a chunk of the outermost ring, where patches and shifted pixels leave the frame and the reference clips, per
+// offset, the rows and columns a patch sums (init_column_sums(), :208-262; the three branches of :437-488) and the
+// pixels it weighs (:398-404).  All of that clipping is "this squared difference is not there", and the interior's
+// arithmetic reproduces it with the squared difference set to +0 where one of its two pixels lies outside the frame:
+//   * a term (entering - leaving) with one side +0 is the reference's add-only / subtract-only branch bit for bit
+//     ((x - 0) n == x n, (0 - x) n == -(x n), and s + (-t) == s - t), with both sides +0 it is +0, its "no change";
+//   * a column sum that starts below the chunk's first row (rows whose shifted pixel is above the frame) is the sum, in
+//     ascending rows, of what has entered by then -- the from-scratch sum of the reference; the rows above hold
+//     partial sums nobody reads.  Columns outside the patch range stay +0, as the reference's table does;
+//   * the row recurrence needs no clipping at all: in front of the first weighed column it adds zeros;
+//   * C gives weight +0 to the pixels the offset does not reach (their shifted pixel is a zero of the window).
+// The chunk may be narrower / lower than the grid's (the frame's last column and row of chunks).
+template <int NPXL, int MSEG, bool BORDER = false, class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
                   const int ndx)
 {
@@ -139,7 +154,8 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int ch = bot - top, cw = right - left;
   const int reach = a.reach;
   // interior: the chunk is whole and no patch of any offset reaches past the frame (uniform, before any barrier)
-  if(!(top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w)) return;
+  const bool interior = top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w;
+  if(BORDER ? (interior || !border_fits(cw, ch)) : !interior) return;
 
   float *const lds = env.lds();
   constexpr int tabsz = MAXCH * TP;
@@ -163,7 +179,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     const int r = r0 + wy, c = c0 + wx; // r is inside the frame for an interior chunk
     F4 v;
     v.x = v.y = v.z = v.w = 0.0f;
-    if(wx < ww && c < W) v = in[(long)r * W + c];
+    if(wx < ww && c < W && (!BORDER || (r >= 0 && r < H && c >= 0))) v = in[(long)r * W + c];
     f2 xy;
     xy.x = v.x;
     xy.y = v.y;
@@ -182,8 +198,8 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // ---- A1: the terms of the column recurrence (nlmeans_core.c:437-488) for table rows 1.., and the five squared
     //      differences the first table row sums (init_column_sums(), :208-262)
     const int ai = w == 3 ? 0 : (w == 10 ? 5 : w - 3);
-    const int ncp = (cw + 2 * P) / 2;
-    const int nseg = NL3_A1_LANES / (ncp * S);
+    const int ncp = (cw + 2 * P + 1) / 2; // (an odd last slot has a partner nobody reads)
+    const int nseg = 2;                   // fits(); a narrower border chunk keeps the layout and repeats items
     const int m0 = (ch - 2) / S + 1;
     const int mseg = (m0 + nseg - 1) / nseg;
     // Work items = (column pair g < ncp, chain q < 10).  Lanes 0-31 and 32-63 of a wave are served by the LDS in separate
@@ -237,6 +253,17 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         oy[i][c] = v.y;
         oz[i][c] = Z[wi];
       }
+    // BORDER: which of the chain's rows and columns are in the frame, and (per row of offsets / per offset) whose shifted
+    // pixel is
+    bool own_row[MSEG + 1], row_ok[MSEG + 1], own_col[2];
+#pragma unroll
+    for(int i = 0; i <= MSEG; i++)
+    {
+      const int R = r0 + wr0 + i * S;
+      own_row[i] = row_ok[i] = !BORDER || (R >= 0 && R < H);
+    }
+#pragma unroll
+    for(int c = 0; c < 2; c++) own_col[c] = !BORDER || (c0 + wc0 + c >= 0 && c0 + wc0 + c < W);
     // the shifted pixels: ring slot of column c at step j of a row of offsets is (c + j) & 1
     float sx[MSEG + 1][2], sy[MSEG + 1][2], sz[MSEG + 1][2];
 #pragma unroll
@@ -263,11 +290,17 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     };
     // A step computes from the ring; the fetch of what the next step needs follows it (slide()), in flight while the wave
     // stores its terms and waits at the barrier
-    auto step = [&](auto ph_tag, const int p) {
+    auto step = [&](auto ph_tag, const int p, const int dx) {
       constexpr int PH = decltype(ph_tag)::value;
       float *const T = tab + (p & 3) * tabsz;
       float *const F = Fb + (p & 1) * S * FP;
       const int fo = head ? foff : DUMMY;
+      bool col_ok[2] = { true, true };
+      if(BORDER)
+      {
+#pragma unroll
+        for(int c = 0; c < 2; c++) col_ok[c] = own_col[c] && (unsigned)(c0 + wc0 + c + dx) < (unsigned)W;
+      }
       float px2[2], py2[2], pz2[2];
 #pragma unroll
       for(int c = 0; c < 2; c++)
@@ -277,6 +310,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         px2[c] = dx_ * dx_;
         py2[c] = dy_ * dy_;
         pz2[c] = dz_ * dz_;
+        if(BORDER && !(row_ok[0] && col_ok[c])) px2[c] = py2[c] = pz2[c] = 0.0f;
       }
       {
         f2 d;
@@ -297,6 +331,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
           nx2[c] = dx_ * dx_;
           ny2[c] = dy_ * dy_;
           nz2[c] = dz_ * dz_;
+          if(BORDER && !(row_ok[i] && col_ok[c])) nx2[c] = ny2[c] = nz2[c] = 0.0f;
         }
         t.x = ((nx2[0] - px2[0]) * n0 + (ny2[0] - py2[0]) * n1) + (nz2[0] - pz2[0]) * n2;
         t.y = ((nx2[1] - px2[1]) * n0 + (ny2[1] - py2[1]) * n1) + (nz2[1] - pz2[1]) * n2;
@@ -333,12 +368,17 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     for(int dyi = 0; dyi < ndy; dyi++)
     {
       const int dy = patches[dyi * ndx].x, dx0 = patches[dyi * ndx].y;
+      if(BORDER)
+      {
+#pragma unroll
+        for(int i = 0; i <= MSEG; i++) row_ok[i] = own_row[i] && (unsigned)(r0 + wr0 + i * S + dy) < (unsigned)H;
+      }
       if(!(var & 16)) load_row_head(dy, dx0);
       for(int jb = 0; jb < ndx; jb += 2)
       {
         if(!(var & 16))
         {
-          step(std::integral_constant<int, 0>(), dyi * ndx + jb);
+          step(std::integral_constant<int, 0>(), dyi * ndx + jb, dx0 + jb);
           slide(std::integral_constant<int, 0>(), dy, dx0 + jb);
         }
         env.sync();
@@ -346,7 +386,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         {
           if(!(var & 16))
           {
-            step(std::integral_constant<int, 1>(), dyi * ndx + jb + 1);
+            step(std::integral_constant<int, 1>(), dyi * ndx + jb + 1, dx0 + jb + 1);
             slide(std::integral_constant<int, 1>(), dy, dx0 + jb + 1);
           }
           env.sync();
@@ -465,6 +505,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     float accx[NPXL], accy[NPXL], accz[NPXL], accw[NPXL];
     float qx[NR], qy[NR], qz[NR];
     float dist[2][NPXL];
+    unsigned reached[2] = { ~0u, ~0u }; // BORDER: bit i = the offset's shifted pixel of pixel i is in the frame
 #pragma unroll
     for(int i = 0; i < NPXL; i++) accx[i] = accy[i] = accz[i] = accw[i] = dist[0][i] = dist[1][i] = 0.0f;
 #pragma unroll
@@ -477,6 +518,16 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       const float *const T = tab + (p & 3) * tabsz + doff;
 #pragma unroll
       for(int i = 0; i < NPXL; i++) dist[M & 1][i] = T[i];
+      if(BORDER)
+      {
+        unsigned m = 0;
+        if((unsigned)(top + r + dy) < (unsigned)H)
+        {
+#pragma unroll
+          for(int i = 0; i < NPXL; i++) m |= ((unsigned)(left + cb + i + dx) < (unsigned)W ? 1u : 0u) << i;
+        }
+        reached[M & 1] = m;
+      }
       const int wy = reach + r + dy;
       if(first)
       {
@@ -506,7 +557,8 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       for(int i = 0; i < NPXL; i++)
       {
         const int sl = (i + M) % NR;
-        const float wgt = nlm2::mexp2_scaled<Env>(dist[M & 1][i], sharp_m23);
+        float wgt = nlm2::mexp2_scaled<Env>(dist[M & 1][i], sharp_m23);
+        if(BORDER && !(reached[M & 1] >> i & 1u)) wgt = 0.0f;
         accx[i] = accx[i] + qx[sl] * wgt;
         accy[i] = accy[i] + qy[sl] * wgt;
         accz[i] = accz[i] + qz[sl] * wgt;

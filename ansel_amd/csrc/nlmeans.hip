@@ -862,14 +862,19 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__res
 {
   extern __shared__ float lds[];
   const int chunk = order[blockIdx.x];
-  if(blockIdx.x < n_border)
-  {
-    pipelined_body(chunk, lds, in, out, a, patches);
-    return;
-  }
   nlm2_device_env env;
   env.lds_ = lds;
   env.chunk_ = chunk;
+  if(blockIdx.x < n_border)
+  {
+    // the outermost ring: the same body with the squared differences that are not there set to +0 (nlm3_body.h, BORDER);
+    // a last row of chunks lower than ten rows keeps the first version's body
+    const int cy = chunk / a.nchx + a.cy0, cx = chunk % a.nchx;
+    const int cw = min(a.chk_w, a.W - cx * a.chk_w), ch = min(a.chk_h, a.H - cy * a.chk_h);
+    if(a.variant & 2048 || !nlm3::border_fits(cw, ch)) pipelined_body(chunk, lds, in, out, a, patches);
+    else nlm3::body<NPXL, MSEG, true>(env, in, out, a, patches, ndx);
+    return;
+  }
   nlm3::body<NPXL, MSEG>(env, in, out, a, patches, ndx);
 }
 

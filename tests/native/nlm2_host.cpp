@@ -189,7 +189,8 @@ extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_
 namespace
 {
 template <int NPXL, int MSEG>
-void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats, const int ndx)
+void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats, const int ndx,
+          const bool border = false)
 {
   std::vector<float> lds(lds_floats + 4096, 0.0f);
   float *base = lds.data();
@@ -204,15 +205,38 @@ void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nch
         HostEnv env{ t, b, base, &bar };
         nlm3::body<NPXL, MSEG>(env, in, out, a, patches, ndx);
         bar.arrive_and_wait();
+        if(border)
+        {
+          nlm3::body<NPXL, MSEG, true>(env, in, out, a, patches, ndx); // the chunks of the outermost ring it takes
+          bar.arrive_and_wait();
+        }
       }
     });
   for(auto &th : pool) th.join();
 }
 } // namespace
 
+static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                          int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                          float luma, float chroma, int *interior_chunks, const bool border);
 extern "C" int nlm3_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                              int search_radius, float scale, float scattering, float sharpness, const float *norm,
                              float luma, float chroma, int *interior_chunks)
+{
+  return nlm3_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma,
+                        chroma, interior_chunks, false);
+}
+// ... and the border ring with the BORDER body; *chunks = the chunks written (interior + border ring taken)
+extern "C" int nlm3_host_run_all(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                                 int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                                 float luma, float chroma, int *chunks)
+{
+  return nlm3_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma,
+                        chroma, chunks, true);
+}
+static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                          int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                          float luma, float chroma, int *interior_chunks, const bool border)
 {
   std::vector<I2> patches;
   int max_shift = 0;
@@ -254,8 +278,10 @@ extern "C" int nlm3_host_run(const float *in, float *out, int W, int H, int chk_
       const int bot = std::min(top + chk_h, H), right = std::min(left + chk_w, W);
       if(top >= a.reach && bot + a.reach <= H && left >= a.reach && right + a.reach <= W && bot - top == chk_h && right - left == chk_w)
         interior++;
+      else if(border && nlm3::border_fits(right - left, bot - top))
+        interior++;
     }
   if(interior_chunks) *interior_chunks = interior;
-  run3<9, 6>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx);
+  run3<9, 6>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx, border);
   return 1;
 }

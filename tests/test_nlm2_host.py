@@ -120,3 +120,42 @@ def test_third_version_on_the_host_equals_the_oracle(host_kernel, oracle_lib, w,
     written = ~np.isnan(got[..., 0])
     assert int(written.sum()) == n_interior * cw * ch
     assert np.array_equal(got[written].view(np.uint32), want[written].view(np.uint32))
+
+
+# the border ring with the BORDER body: frames whose every chunk is in the ring, partial last chunks (odd width, a last row
+# of chunks lower than 10 rows keeps the first version's body and stays unwritten), offsets longer than a chunk is far
+# from the edge
+CASES3B = [
+    (170, 150, 7, 0.5, 1.0),
+    (260, 168, 7, 1.0, 1.0),
+    (151, 140, 3, 0.3, 0.8),   # 64 x 51 chunks, the last 23 columns (odd) and 38 rows
+    (181, 140, 7, 0.5, 1.0),   # 72 x 51, the last 37 columns
+    (173, 159, 7, 0.5, 0.9),   # 68 x 53, the last 37 columns
+]
+
+
+@pytest.mark.parametrize("w,h,K,luma,chroma", CASES3B)
+def test_third_version_border_ring_on_the_host_equals_the_oracle(host_kernel, oracle_lib, w, h, K, luma, chroma):
+    o = oracle_lib
+    P = 2
+    img = _lab(w, h, 11 + K)
+    p = NlmParams(0.0, 1.0, luma, chroma, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm3_host_run_all(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(0.0),
+                                       C.c_float(p.sharpness), p.norm, C.c_float(luma), C.c_float(chroma), C.byref(seen))
+    if rc == 0:
+        pytest.skip("chunk grid %d x %d is not the third version's" % (cw, ch))
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    written = ~np.isnan(got[..., 0])
+    assert seen.value > 0 and int(written.sum()) > 0
+    bad = written & (got.view(np.uint32) != want.view(np.uint32)).any(axis=-1)
+    assert int(bad.sum()) == 0, "%d of %d written pixels differ; first at %s" % (int(bad.sum()), int(written.sum()), np.argwhere(bad)[:5].tolist())
+    # every chunk with at least 10 rows is written
+    nrows_last = h - (h - 1) // ch * ch
+    expect = w * (h if nrows_last >= 10 else h - nrows_last)
+    assert int(written.sum()) == expect
