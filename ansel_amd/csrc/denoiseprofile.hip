@@ -251,6 +251,19 @@ __device__ __forceinline__ float mexp2(const float x)
   return __int_as_float(k0 >= 8388608.0f ? (int)k0 : 0);
 }
 
+// mexp2(0 > arg ? 0 : arg) -- dn_weight()'s argument, eaw.c:181-195 -- with the clamp at zero moved behind the
+// conversion: a negative argument gives k0 above 0x3f800000 (its value for +-0), where an integer minimum brings it
+// back; a NaN converts to 0 (v_cvt_i32_f32) and fails the test as it does in the reference; -inf saturates to
+// INT_MAX and is cut to 0x3f800000 like every negative argument.  Five instructions instead of six.
+__device__ __forceinline__ float mexp2_of_clamped(const float arg)
+{
+  const float k0 = fmaf(arg, 1056964608.0f - 1065353216.0f, 1065353216.0f);
+  int k;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(k) : "v"(k0)); // truncating, saturating, NaN -> 0: the instruction's semantics, not C's
+  k = min(k, 0x3f800000);
+  return __int_as_float(k >= 0x800000 ? k : 0);
+}
+
 __device__ __forceinline__ int walk_row(const int b, const int height, const int mult)
 {
   if(height <= mult) return b < height ? b : -1;
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
         const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
         const float dot = (dx * dx + dy * dy + dz * dz) * inv_sigma2;
         const float arg = dot * 0.02f - 9.0f;
-        const float wp = mexp2(0 > arg ? 0.0f : arg);
+        const float wp = mexp2_of_clamped(arg);
         const float w = (fi * fj) * wp;
         wgt += w; // the reference keeps one weight sum per channel; they are identical
         sum[0] += w * p2.x;
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
             const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
             const float dot = (dx * dx + dy * dy + dz * dz) * inv_sigma2;
             const float arg = dot * 0.02f - 9.0f;
-            wp = mexp2(0 > arg ? 0.0f : arg);
+            wp = mexp2_of_clamped(arg);
           }
           if(ii == 2 && jj == 3) down1 = wp;
           if(ii == 2 && jj == 4) down2 = wp;

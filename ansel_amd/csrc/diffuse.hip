@@ -18,6 +18,8 @@
 // taps clamp to column 0 / width-1 whatever the dilation (bspline.h:143-149), so those two columns
 // are blurred by every workgroup as well.
 #include "hip_common.h"
+
+#include <type_traits>
 #include "devmath.h"
 #include "px_colorspaces.h"
 
@@ -351,9 +353,12 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
   const int cols[3] = { clampi(col - mult, 0, a.width - 1), clampi(col, 0, a.width - 1), clampi(col + mult, 0, a.width - 1) };
   // support row v of the strip (output row kk reads v = kk, kk + 1, kk + 2) = frame row r_first + (v - 1) mult, clamped
 #define PDE_ROW(v) ((size_t)clampi(r_first + ((v) - 1) * mult, 0, a.height - 1) * a.width)
-  float4 H4[9], L4[9];
-  // fetch support row v into slot `ii` of the window and leave its squared ratios in ring row v % PDE_RING
-  auto fetch_row = [&](const int v, const int ii) {
+  // the three support rows of the window live in three register sets used in rotation -- support row v in set v % 3, the
+  // row loop unrolled by three -- so that moving the window down a row moves no register (it was 48 v_mov per row)
+  float4 Hw[3][3], Lw[3][3];
+  // fetch support row v into set `slot` and leave its squared ratios in ring row v % PDE_RING
+  auto fetch_row = [&](const int v, auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
     const size_t y = PDE_ROW(v);
 #pragma unroll
     for(int jj = 0; jj < 3; jj++)
@@ -361,49 +366,36 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       if(HSUB)
       {
         const float4 c = hf[y + cols[jj]], low = hsub[y + cols[jj]];
-        H4[3 * ii + jj] = make_float4(c.x - low.x, c.y - low.y, c.z - low.z, c.w - low.w);
+        Hw[SL][jj] = make_float4(c.x - low.x, c.y - low.y, c.z - low.z, c.w - low.w);
       }
       else
-        H4[3 * ii + jj] = hf[y + cols[jj]];
-      L4[3 * ii + jj] = lf[y + cols[jj]];
+        Hw[SL][jj] = hf[y + cols[jj]];
+      Lw[SL][jj] = lf[y + cols[jj]];
     }
-  };
-  auto ratios_of = [&](const int v, const int ii) {
     float4 *const ring = r2s + (v % PDE_RING) * tw;
     {
-      const float4 h = H4[3 * ii + 1], l = L4[3 * ii + 1];
+      const float4 h = Hw[SL][1], l = Lw[SL][1];
       ring[tx + mult] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
     }
     if(tx < mult)
     {
-      const float4 h = H4[3 * ii], l = L4[3 * ii];
+      const float4 h = Hw[SL][0], l = Lw[SL][0];
       ring[tx] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
     }
     if(tx >= 256 - mult)
     {
-      const float4 h = H4[3 * ii + 2], l = L4[3 * ii + 2];
+      const float4 h = Hw[SL][2], l = Lw[SL][2];
       ring[tx + 2 * mult] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
     }
   };
-  fetch_row(0, 1);
-  fetch_row(1, 2);
-  ratios_of(0, 1);
-  ratios_of(1, 2);
-  for(int kk = 0; kk < nrows; kk++)
-  {
-    // the window moves down one row of the class; the new bottom row
-#pragma unroll
-    for(int jj = 0; jj < 3; jj++)
-    {
-      H4[jj] = H4[3 + jj];
-      L4[jj] = L4[3 + jj];
-      H4[3 + jj] = H4[6 + jj];
-      L4[3 + jj] = L4[6 + jj];
-    }
-    fetch_row(kk + 2, 2);
-    ratios_of(kk + 2, 2);
+  // output row kk of the strip: its support rows kk, kk + 1 (fetched) and kk + 2 (fetched here), in sets T, T + 1, T + 2 mod 3
+  auto row_step = [&](auto t_tag, const int kk) {
+    constexpr int T = decltype(t_tag)::value, S0 = T, S1 = (T + 1) % 3, S2 = (T + 2) % 3;
+    fetch_row(kk + 2, std::integral_constant<int, S2>());
     __syncthreads();
-    if(!live) continue;
+    if(!live) return;
+    const float4 H4[9] = { Hw[S0][0], Hw[S0][1], Hw[S0][2], Hw[S1][0], Hw[S1][1], Hw[S1][2], Hw[S2][0], Hw[S2][1], Hw[S2][2] };
+    const float4 L4[9] = { Lw[S0][0], Lw[S0][1], Lw[S0][2], Lw[S1][0], Lw[S1][1], Lw[S1][2], Lw[S2][0], Lw[S2][1], Lw[S2][2] };
     const int row = r_first + kk * mult;
     float4 energy = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -454,6 +446,14 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     if(a.post_lab) o = px_rgb_to_lab(o, a.post_m);
     if(final_pass) nt_store(out + idx, o);
     else out[idx] = o;
+  };
+  fetch_row(0, std::integral_constant<int, 0>());
+  fetch_row(1, std::integral_constant<int, 1>());
+  for(int kk = 0; kk < nrows; kk += 3)
+  {
+    row_step(std::integral_constant<int, 0>(), kk);
+    if(kk + 1 < nrows) row_step(std::integral_constant<int, 1>(), kk + 1);
+    if(kk + 2 < nrows) row_step(std::integral_constant<int, 2>(), kk + 2);
   }
 #undef PDE_ROW
 }
