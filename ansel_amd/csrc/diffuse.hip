@@ -65,6 +65,7 @@ struct pde_args
   int same02, same13; // orders 1 and 3 (2 and 4) have the same kind and anisotropy: one kernel for both
   float variance_threshold, regularization;
   float abcd[4], strength;
+  int wskip;
   int post_lab;        // the pipe's RGB -> Lab glue behind the module, applied where the last pass stores (strip kernel)
   float post_m[3][4];
 };
@@ -373,20 +374,15 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       Lw[SL][jj] = lf[y + cols[jj]];
     }
     float4 *const ring = r2s + (v % PDE_RING) * tw;
-    {
-      const float4 h = Hw[SL][1], l = Lw[SL][1];
-      ring[tx + mult] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
-    }
-    if(tx < mult)
-    {
-      const float4 h = Hw[SL][0], l = Lw[SL][0];
-      ring[tx] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
-    }
-    if(tx >= 256 - mult)
-    {
-      const float4 h = Hw[SL][2], l = Lw[SL][2];
-      ring[tx + 2 * mult] = make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), ratio2(h.w, l.w));
-    }
+    // the fourth channel's squared ratio is +0 when both samples are +0 (0 / 1e-8, squared): a wave whose samples all
+    // are -- what a pipe hands this module, see alpha_is_blank() -- skips that division (a uniform branch)
+    auto ratios = [&](const float4 h, const float4 l) {
+      const bool blank = a.wskip && __builtin_amdgcn_ballot_w64((__float_as_uint(h.w) | __float_as_uint(l.w)) != 0) == 0ull;
+      return make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), blank ? 0.0f : ratio2(h.w, l.w));
+    };
+    ring[tx + mult] = ratios(Hw[SL][1], Lw[SL][1]);
+    if(tx < mult) ring[tx] = ratios(Hw[SL][0], Lw[SL][0]);
+    if(tx >= 256 - mult) ring[tx + 2 * mult] = ratios(Hw[SL][2], Lw[SL][2]);
   };
   // output row kk of the strip: its support rows kk, kk + 1 (fetched) and kk + 2 (fetched here), in sets T, T + 1, T + 2 mod 3
   auto row_step = [&](auto t_tag, const int kk) {
@@ -397,6 +393,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     const float4 H4[9] = { Hw[S0][0], Hw[S0][1], Hw[S0][2], Hw[S1][0], Hw[S1][1], Hw[S1][2], Hw[S2][0], Hw[S2][1], Hw[S2][2] };
     const float4 L4[9] = { Lw[S0][0], Lw[S0][1], Lw[S0][2], Lw[S1][0], Lw[S1][1], Lw[S1][2], Lw[S2][0], Lw[S2][1], Lw[S2][2] };
     const int row = r_first + kk * mult;
+    const bool blank = alpha_is_blank(H4, L4);
     float4 energy = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for(int ii = 0; ii < 3; ii++)
@@ -409,7 +406,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
         energy.x += r.x;
         energy.y += r.y;
         energy.z += r.z;
-        energy.w += r.w;
+        if(!(blank && a.wskip)) energy.w += r.w; // (nobody reads it otherwise)
       }
       // three reads in flight, not nine (they sit on top of the 72 registers of the support)
       asm volatile("" : "+v"(energy.x), "+v"(energy.y), "+v"(energy.z), "+v"(energy.w) : : "memory");
@@ -434,7 +431,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
 #pragma unroll
       for(int k = 0; k < 9; k++) { H[k] = H4[k].z; L[k] = L4[k].z; }
       o.z = pde_channel(H, L, energy.z, a);
-      if(alpha_is_blank(H4, L4))
+      if(blank)
         o.w = 0.0f;
       else
       {
@@ -638,6 +635,7 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
   memset(&a, 0, sizeof(a));
   a.width = w;
   a.height = h;
+  a.wskip = getenv("ANSEL_HIP_PDE_NO_WSKIP") ? 0 : 1;
   const float user_aniso[4] = { d->anisotropy_first, d->anisotropy_second, d->anisotropy_third, d->anisotropy_fourth };
   for(int k = 0; k < 4; k++)
   {
