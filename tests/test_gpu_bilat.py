@@ -31,6 +31,8 @@ def _lab_image(w, h, seed):
 def test_bilat(w, h, ss, sr, detail):
     if ss < 1.0 and w * h > 500000:
         pytest.skip("sub-pixel sigma on the large frame: the grid has millions of nodes, covered on the small frames")
+    if ss > 100.0 and min(w, h) < 200:
+        pytest.skip("a grid line shorter than 4 nodes: refused, see test_bilat_refuses_a_grid_the_reference_overruns")
     img = _lab_image(w, h, 29)
     d = abi.BilatData.bilateral(ss, sr, detail)
     piece = abi.Piece.make(w, h)
@@ -45,6 +47,16 @@ def test_bilat(w, h, ss, sr, detail):
         r = np.zeros_like(img)
         assert ck.call(ref, "ref_bilat", piece, d, img, r) == 0
         assert float(np.abs(r[..., 0] - got[..., 0]).max()) < 1e-3
+
+
+def test_bilat_refuses_a_grid_the_reference_overruns():
+    """blur_line() touches four nodes of every grid line unconditionally (bilateral.c:266-340): on a 3-node line the
+    reference writes past its buffer, so there is nothing to be identical to"""
+    from ansel_amd import lib
+    w, h = 123, 457
+    img = _lab_image(w, h, 3)
+    with pytest.raises(lib.AnselHipError, match="below the 4 entries"):
+        hc.run_hip("dt_hip_iop_bilat_process", abi.Piece.make(w, h), abi.BilatData.bilateral(150.0, 10.0, 0.7), img, img.shape)
 
 
 @pytest.mark.parametrize("w,h", [(300, 200), (123, 457), (64, 64), (257, 130), (1500, 1000)])
