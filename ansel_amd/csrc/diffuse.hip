@@ -158,23 +158,54 @@ __device__ __forceinline__ float ratio2(const float h, const float l)
   return ratio * ratio;
 }
 
+// The four orders' kinds and the two "same kernel" flags are parameters, and branching on them (uniformly) cuts a channel's
+// update into a dozen basic blocks that the scheduler cannot interleave with each other or with the next channel.  MODE >= 0
+// spells them at compile time -- kind[0] + 3 kind[1] + 9 kind[2] + 27 kind[3] + 81 same02 + 162 same13 -- for the
+// combinations the presets use (the strip kernel is instantiated for them); MODE < 0 reads the arguments.
+#define PDE_MODE_ISOTROPIC (81 + 162)                 // the module's defaults: four isotropic orders
+#define PDE_MODE_DEBLUR (1 + 9 + 81 + 162)            // lens deblur, sharpen ...: orders 1 and 3 along the isophotes, 2 and 4 isotropic
+template <int MODE> struct pde_mode
+{
+  static __device__ __forceinline__ int kind(const int i, const pde_args &a)
+  {
+    if constexpr(MODE < 0) return a.kind[i];
+    else return (i == 0 ? MODE : (i == 1 ? MODE / 3 : (i == 2 ? MODE / 9 : MODE / 27))) % 3;
+  }
+  static __device__ __forceinline__ bool same02(const pde_args &a)
+  {
+    if constexpr(MODE < 0) return a.same02 != 0;
+    else return (MODE / 81) % 2 != 0;
+  }
+  static __device__ __forceinline__ bool same13(const pde_args &a)
+  {
+    if constexpr(MODE < 0) return a.same13 != 0;
+    else return (MODE / 162) % 2 != 0;
+  }
+};
+inline int pde_mode_of(const pde_args &a)
+{
+  return a.kind[0] + 3 * a.kind[1] + 9 * a.kind[2] + 27 * a.kind[3] + 81 * (a.same02 ? 1 : 0) + 162 * (a.same13 ? 1 : 0);
+}
+
 // energy: the sum of the squared ratios of the nine samples, added in the order of the reference's loop
+template <int MODE = -1>
 __device__ __forceinline__ float pde_channel(const float H[9], const float L[9], float energy, const pde_args &a)
 {
+  typedef pde_mode<MODE> M;
   // HF/LF energy over the 3x3 support, diffuse.c:823-845
   energy = max_zero(a.variance_threshold + energy * a.regularization - 1e-8f) + 1e-8f;
   // the direction of the low-frequency gradient steers orders 1 and 3, that of the high-frequency one orders 2 and 4; an
   // isotropic order (anisotropy 0, the module's default for all four) reads neither the angle nor the magnitude, so a
   // direction nobody reads is not computed (uniform branches: the kinds are parameters)
   float cos2g = 0.f, sin2g = 0.f, csg = 0.f, cos2l = 0.f, sin2l = 0.f, csl = 0.f, mg = 0.f, ml = 0.f;
-  if(a.kind[0] | a.kind[2]) mg = direction((L[7] - L[1]) * 0.5f, (L[5] - L[3]) * 0.5f, cos2g, sin2g, csg);
-  if(a.kind[1] | a.kind[3]) ml = direction((H[7] - H[1]) * 0.5f, (H[5] - H[3]) * 0.5f, cos2l, sin2l, csl);
+  if(M::kind(0, a) | M::kind(2, a)) mg = direction((L[7] - L[1]) * 0.5f, (L[5] - L[3]) * 0.5f, cos2g, sin2g, csg);
+  if(M::kind(1, a) | M::kind(3, a)) ml = direction((H[7] - H[1]) * 0.5f, (H[5] - H[3]) * 0.5f, cos2l, sin2l, csl);
   // orders 1 and 3 share the direction of the low-frequency gradient, orders 2 and 4 that of the high-frequency one; with
   // the same anisotropy (the presets' case) they share the kernel too (uniform: the anisotropies are parameters)
-  const kernel5 w0 = order_kernel(a.kind[0], fast_expf(-mg * a.anisotropy[0]), csg, cos2g, sin2g);
-  const kernel5 w1 = order_kernel(a.kind[1], fast_expf(-ml * a.anisotropy[1]), csl, cos2l, sin2l);
-  const kernel5 w2 = a.same02 ? w0 : order_kernel(a.kind[2], fast_expf(-mg * a.anisotropy[2]), csg, cos2g, sin2g);
-  const kernel5 w3 = a.same13 ? w1 : order_kernel(a.kind[3], fast_expf(-ml * a.anisotropy[3]), csl, cos2l, sin2l);
+  const kernel5 w0 = order_kernel(M::kind(0, a), fast_expf(-mg * a.anisotropy[0]), csg, cos2g, sin2g);
+  const kernel5 w1 = order_kernel(M::kind(1, a), fast_expf(-ml * a.anisotropy[1]), csl, cos2l, sin2l);
+  const kernel5 w2 = M::same02(a) ? w0 : order_kernel(M::kind(2, a), fast_expf(-mg * a.anisotropy[2]), csg, cos2g, sin2g);
+  const kernel5 w3 = M::same13(a) ? w1 : order_kernel(M::kind(3, a), fast_expf(-ml * a.anisotropy[3]), csl, cos2l, sin2l);
   const float d0 = convolve(w0, L);
   const float d1 = convolve(w1, L);
   const float d2 = convolve(w2, H);
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf
 // same operands, same operation).  The analysis then writes 16 B per pixel and scale instead of 32, and this kernel, which
 // waits for its arithmetic and not for its fetches, reads 48 instead of 32.
 #define PDE_RING 4
-template <bool HSUB>
+template <bool HSUB, int MODE>
 __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__restrict__ hf, const float4 *__restrict__ hsub,
                                                          const float4 *__restrict__ lf,
                                                          float4 *__restrict__ out, const pde_args a, const int final_pass,
@@ -424,20 +455,20 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       float H[9], L[9];
 #pragma unroll
       for(int k = 0; k < 9; k++) { H[k] = H4[k].x; L[k] = L4[k].x; }
-      o.x = pde_channel(H, L, energy.x, a);
+      o.x = pde_channel<MODE>(H, L, energy.x, a);
 #pragma unroll
       for(int k = 0; k < 9; k++) { H[k] = H4[k].y; L[k] = L4[k].y; }
-      o.y = pde_channel(H, L, energy.y, a);
+      o.y = pde_channel<MODE>(H, L, energy.y, a);
 #pragma unroll
       for(int k = 0; k < 9; k++) { H[k] = H4[k].z; L[k] = L4[k].z; }
-      o.z = pde_channel(H, L, energy.z, a);
+      o.z = pde_channel<MODE>(H, L, energy.z, a);
       if(blank)
         o.w = 0.0f;
       else
       {
 #pragma unroll
         for(int k = 0; k < 9; k++) { H[k] = H4[k].w; L[k] = L4[k].w; }
-        o.w = pde_channel(H, L, energy.w, a);
+        o.w = pde_channel<MODE>(H, L, energy.w, a);
       }
     }
     if(a.post_lab) o = px_rgb_to_lab(o, a.post_m);
@@ -727,12 +758,24 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
           const int spc = (per_class + strip - 1) / strip;
           const size_t ring = (size_t)PDE_RING * (256 + 2 * a.mult) * sizeof(float4);
+          static const bool generic = getenv("ANSEL_HIP_PDE_GENERIC") != nullptr; // the kinds read at run time, for A/B timing
+          const int mode = generic ? -1 : pde_mode_of(a);
+          const dim3 sgrid(gx, classes * spc);
+          const float4 *const h0 = chain ? (s == 0 ? src : hf[s - 1]) : hf[s], *const h1 = chain ? hf[s] : nullptr;
+#define PDE_LAUNCH(HS, MD) diffuse_pde_strip<HS, MD><<<sgrid, 256, ring, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
           if(chain)
-            diffuse_pde_strip<true><<<dim3(gx, classes * spc), 256, ring, st>>>(s == 0 ? src : hf[s - 1], hf[s], cur, to, a, s == 0,
-                                                                                  mask, strip, spc);
+          {
+            if(mode == PDE_MODE_ISOTROPIC) PDE_LAUNCH(true, PDE_MODE_ISOTROPIC);
+            else if(mode == PDE_MODE_DEBLUR) PDE_LAUNCH(true, PDE_MODE_DEBLUR);
+            else PDE_LAUNCH(true, -1);
+          }
           else
-            diffuse_pde_strip<false><<<dim3(gx, classes * spc), 256, ring, st>>>(hf[s], nullptr, cur, to, a, s == 0, mask, strip,
-                                                                                   spc);
+          {
+            if(mode == PDE_MODE_ISOTROPIC) PDE_LAUNCH(false, PDE_MODE_ISOTROPIC);
+            else if(mode == PDE_MODE_DEBLUR) PDE_LAUNCH(false, PDE_MODE_DEBLUR);
+            else PDE_LAUNCH(false, -1);
+          }
+#undef PDE_LAUNCH
         }
         else if(a.mult <= PDE_SHARED_MULT)
           diffuse_pde<true><<<grid, 256, (size_t)3 * (256 + 2 * a.mult) * sizeof(float4), st>>>(hf[s], cur, to, a, s == 0, mask);
