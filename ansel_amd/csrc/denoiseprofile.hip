@@ -365,6 +365,14 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
 // ring (the finest scale of a whole frame: a row is fetched 1.14 times per strip, which costs less than the pass that
 // wrote and re-read the transformed plane: 0.89 + 1.9 -> 2.4 ms at 100 MP)
 #define DN_RING 6
+// dn_weight(), eaw.c:181-195, without the filter coefficient
+__device__ __forceinline__ float dn_photometric(const float4 px, const float4 p2, const float inv_sigma2)
+{
+  const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
+  const float dot = (dx * dx + dy * dy + dz * dz) * inv_sigma2;
+  const float arg = dot * 0.02f - 9.0f;
+  return mexp2_of_clamped(arg);
+}
 template <bool PRE>
 __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                           float4 *__restrict__ detail, double *__restrict__ partial,
@@ -404,7 +412,17 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
     if(second) n1 = in[y + ecol1];
   }
   int s0 = 0; // ring slot of row k
-  float up1 = 0.f, up2 = 0.f, up2_next = 0.f; // the weights of the taps straight above, left by this lane one and two rows ago
+  // the weights of the taps straight above, left by this lane one and two rows ago; for the strip's first two rows, whose
+  // rows above belong to the strip in front, computed here from the ring rows that are in already
+  float up1 = 0.f, up2 = 0.f, up2_next = 0.f;
+  __syncthreads();
+  {
+    const float4 c0 = ring[2 * tw + tid + 2 * mult], c1 = ring[3 * tw + tid + 2 * mult];
+    const float4 a0 = ring[0 * tw + tid + 2 * mult], a1 = ring[1 * tw + tid + 2 * mult];
+    up2 = dn_photometric(c0, a0, inv_sigma2);      // row 0 <- two rows above
+    up1 = dn_photometric(c0, a1, inv_sigma2);      // row 0 <- the row above
+    up2_next = dn_photometric(c1, a1, inv_sigma2); // row 1 <- two rows above
+  }
   for(int k = 0; k < nrows; k++)
   {
     {
@@ -449,17 +467,11 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
           const float4 p2 = tap[ii];
           // dn_weight(), eaw.c:181-195.  It squares the differences of the two pixels, so the weight of this pixel's tap
           // straight above is bit for bit the weight the pixel up there computed for its tap straight below: this lane,
-          // one or two rows ago (unless that row belongs to the strip in front: a uniform branch)
+          // one or two rows ago (the strip's first two rows: the prologue) -- no branch in the 25 taps
           float wp;
-          if(ii == 2 && jj == 0 && k >= 2) wp = up2;
-          else if(ii == 2 && jj == 1 && k >= 1) wp = up1;
-          else
-          {
-            const float dx = px.x - p2.x, dy = px.y - p2.y, dz = px.z - p2.z;
-            const float dot = (dx * dx + dy * dy + dz * dz) * inv_sigma2;
-            const float arg = dot * 0.02f - 9.0f;
-            wp = mexp2_of_clamped(arg);
-          }
+          if(ii == 2 && jj == 0) wp = up2;
+          else if(ii == 2 && jj == 1) wp = up1;
+          else wp = dn_photometric(px, p2, inv_sigma2);
           if(ii == 2 && jj == 3) down1 = wp;
           if(ii == 2 && jj == 4) down2 = wp;
           const float w = (fi * fj) * wp;
