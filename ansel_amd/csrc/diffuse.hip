@@ -162,8 +162,17 @@ __device__ __forceinline__ float ratio2(const float h, const float l)
 // update into a dozen basic blocks that the scheduler cannot interleave with each other or with the next channel.  MODE >= 0
 // spells them at compile time -- kind[0] + 3 kind[1] + 9 kind[2] + 27 kind[3] + 81 same02 + 162 same13 -- for the
 // combinations the presets use (the strip kernel is instantiated for them); MODE < 0 reads the arguments.
-#define PDE_MODE_ISOTROPIC (81 + 162)                 // the module's defaults: four isotropic orders
-#define PDE_MODE_DEBLUR (1 + 9 + 81 + 162)            // lens deblur, sharpen ...: orders 1 and 3 along the isophotes, 2 and 4 isotropic
+// (the presets of init_presets(), diffuse.c:298-583, by the signs of their four anisotropies)
+#define PDE_MODE_ISOTROPIC (81 + 162)                 // the module's defaults, bloom: four isotropic orders
+#define PDE_MODE_DEBLUR (1 + 9 + 81 + 162)            // lens deblur, dehaze, denoise: orders 1 and 3 along the isophotes, 2 and 4 isotropic
+#define PDE_MODE_ISOPHOTE (1 + 3 + 9 + 27 + 81 + 162) // surface blur, sharpen demosaicing: all four along the isophotes
+#define PDE_MODE_GRADIENT (2 + 6 + 18 + 54 + 81 + 162) // simulate line drawing: all four along the gradients
+#define PDE_MODE_WATERCOLOR (9 + 27)                  // simulate watercolor: orders 3 and 4 along the isophotes
+#define PDE_MODE_CONTRAST (2 + 54)                    // add local contrast: orders 1 and 4 along the gradients
+#define PDE_MODE_INPAINT (27)                         // inpaint highlights: order 4 along the isophotes
+#define PDE_MODE_FAST (9)                             // fast sharpness, fast local contrast: order 3 along the isophotes
+#define PDE_MODES(X) X(PDE_MODE_ISOTROPIC) X(PDE_MODE_DEBLUR) X(PDE_MODE_ISOPHOTE) X(PDE_MODE_GRADIENT) X(PDE_MODE_WATERCOLOR) \
+  X(PDE_MODE_CONTRAST) X(PDE_MODE_INPAINT) X(PDE_MODE_FAST)
 template <int MODE> struct pde_mode
 {
   static __device__ __forceinline__ int kind(const int i, const pde_args &a)
@@ -763,16 +772,19 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           const dim3 sgrid(gx, classes * spc);
           const float4 *const h0 = chain ? (s == 0 ? src : hf[s - 1]) : hf[s], *const h1 = chain ? hf[s] : nullptr;
 #define PDE_LAUNCH(HS, MD) diffuse_pde_strip<HS, MD><<<sgrid, 256, ring, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
-          if(chain)
+          bool launched = false;
+#define PDE_CASE(MD)                     \
+  if(!launched && mode == (MD))          \
+  {                                      \
+    if(chain) PDE_LAUNCH(true, MD);      \
+    else PDE_LAUNCH(false, MD);          \
+    launched = true;                     \
+  }
+          PDE_MODES(PDE_CASE)
+#undef PDE_CASE
+          if(!launched)
           {
-            if(mode == PDE_MODE_ISOTROPIC) PDE_LAUNCH(true, PDE_MODE_ISOTROPIC);
-            else if(mode == PDE_MODE_DEBLUR) PDE_LAUNCH(true, PDE_MODE_DEBLUR);
-            else PDE_LAUNCH(true, -1);
-          }
-          else
-          {
-            if(mode == PDE_MODE_ISOTROPIC) PDE_LAUNCH(false, PDE_MODE_ISOTROPIC);
-            else if(mode == PDE_MODE_DEBLUR) PDE_LAUNCH(false, PDE_MODE_DEBLUR);
+            if(chain) PDE_LAUNCH(true, -1);
             else PDE_LAUNCH(false, -1);
           }
 #undef PDE_LAUNCH

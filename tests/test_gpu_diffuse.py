@@ -68,6 +68,35 @@ def test_diffuse_matches_cpu(preset, over, size, imgname):
         assert int((ck.ulp_diff(got, ref) > 0).sum()) == 0
 
 
+# the sign patterns of the reference's presets (init_presets(), diffuse.c:298-583): each takes a kernel with the orders'
+# kinds spelled at compile time; the last mixes three kinds with unequal anisotropies and takes the run-time kernel
+PATTERNS = [
+    ("isophote x4", dict(anisotropy_first=4.0, anisotropy_second=4.0, anisotropy_third=4.0, anisotropy_fourth=4.0)),
+    ("gradient x4", dict(anisotropy_first=-5.0, anisotropy_second=-5.0, anisotropy_third=-5.0, anisotropy_fourth=-5.0)),
+    ("watercolor", dict(anisotropy_third=4.0, anisotropy_fourth=4.0)),
+    ("local contrast", dict(anisotropy_first=-2.5, anisotropy_fourth=-2.5)),
+    ("inpaint", dict(anisotropy_fourth=2.0)),
+    ("fast", dict(anisotropy_third=5.0)),
+    ("deblur", dict(anisotropy_first=2.0, anisotropy_third=2.0)),
+    ("isotropic", {}),
+    ("same kinds, other anisotropies", dict(anisotropy_first=2.0, anisotropy_third=3.0)),
+    ("mixed", dict(anisotropy_first=-1.0, anisotropy_second=2.0, anisotropy_third=0.5, anisotropy_fourth=-0.25)),
+]
+
+
+@pytest.mark.parametrize("name,aniso", PATTERNS, ids=[p[0] for p in PATTERNS])
+def test_diffuse_kind_patterns(name, aniso):
+    w, h = 389, 251
+    img = _with_alpha(synth.rgba_image(w, h, seed=16, lo=-0.02, hi=1.5), "patches")
+    piece = abi.Piece.make(w, h)
+    d = params.diffuse("default", iterations=2, radius=12, regularization=1.5, variance_threshold=0.3, sharpness=0.1,
+                       first=-0.25, second=0.125, third=-0.125, fourth=0.0625, **aniso)
+    got = hc.run_hip("dt_hip_iop_diffuse_process", piece, d, img, img.shape)
+    want = _cpu("oracle", piece, d, img)
+    diff = ck.ulp_diff(got, want)
+    assert int((diff > 0).sum()) == 0, "%d px differ, max %d ulp" % (int((diff > 0).sum()), int(diff.max()))
+
+
 INPAINT_CASES = [
     ("inpaint_highlights", dict(iterations=4, threshold=1.0), (333, 217)),
     ("inpaint_highlights", dict(iterations=1, threshold=0.25, radius=8, sharpness=0.2), (640, 401)),
