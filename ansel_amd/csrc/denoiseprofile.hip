@@ -134,20 +134,30 @@ __device__ __forceinline__ float4 dn_finish_pixel(const float4 *__restrict__ out
 {
   {
     float4 acc;
+    float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
     if(sy.nbands > 0)
     {
+      // every band's sample and the residue are fetched before the first is used: with a fetch inside each band's
+      // (uniform) branch a wave had ONE 16-byte fetch per lane in flight at a time, and eight waves per SIMD of that do
+      // not cover the latency of 8 TB/s (a band the module does not have fetches the first one again)
+      float4 d[BANDS];
+#pragma unroll
+      for(int b = 0; b < BANDS; b++) d[b] = sy.detail[b < sy.nbands ? b : 0][j];
+      if(residue) res = residue[j];
       // the accumulator of denoiseprofile.c:1398 starts zeroed; bands are added finest first (:1400-1421)
       acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for(int b = 0; b < BANDS; b++)
-        if(b < sy.nbands) synthesize_band(acc, sy.detail[b][j], sy.thrs + 4 * b);
+        if(b < sy.nbands) synthesize_band(acc, d[b], sy.thrs + 4 * b);
     }
     else
+    {
       acc = out[j];
+      if(residue) res = residue[j];
+    }
     float v[4] = { acc.x, acc.y, acc.z, acc.w };
     if(residue)
     {
-      const float4 res = residue[j];
       v[0] = acc.x + res.x;
       v[1] = acc.y + res.y;
       v[2] = acc.z + res.z;
