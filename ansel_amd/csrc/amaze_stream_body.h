@@ -1,0 +1,818 @@
+// amaze_stream_body.h -- AMaZE demosaic with every plane of a tile ON CHIP: the body of the gfx950 kernel
+// amaze_stream (demosaic_amaze.hip), written over an environment so that the same source also runs on the host in
+// the CPU suite (tests/native/amaze_host.cpp: one fiber per thread, every LDS access checked for races and for ring
+// slots read after they were overwritten) against the oracle before a GPU is involved.
+//
+// Reference: amaze_demosaic_RT(), src/iop/demosaic/amaze.cc:181-1419 -- per 160 x 160 tile a fixed sequence of stencil
+// stages over tile-sized planes (1.5 MB per tile; the first device kernel, amaze_tiles, keeps them in a slab of global
+// memory and moves 25 x the algorithmic bytes).  Here a tile is walked top to bottom in steps of R rows.  Every stage
+// runs once per step on ITS rows of the step -- stage X works on tile rows [s R - L_X, s R - L_X + R), L_X being the
+// number of rows X trails the load by: what X reads below a row must have been produced -- and its planes live in LDS
+// as rings of just the rows between their producer and their last consumer (135 KB in all).  A phase = the stages of a
+// step that do not depend on each other, then a workgroup barrier.
+//
+// What makes the result the reference's, bit for bit (oracle/src/demosaic_amaze.c restates it):
+//   * the arithmetic of every stage is the first kernel's, operation for operation;
+//   * the three Gauss-Seidel sweeps keep their order.  The two votes (amaze.cc:894-905, :1109-1126) read row r-1 voted and
+//     row r+1 unvoted: one row per sub-phase.  The choice between the two colour-difference estimates (:585-705) reads the
+//     UPDATED neighbour two sites back, along the row for hcd and down the column for vcd.  Down the column is the
+//     direction of the walk (two sites per lane and step, in order).  Along the row it would be a chain of 76 dependent
+//     steps -- but a site's result is one of only TWO values whatever its neighbour was (the bounded raw estimate or the
+//     bounded alternative), so every site first computes both candidates, then which it would pick for either candidate of
+//     its neighbour (two bits), and then finds its own pick by walking back to the nearest site whose pick does not depend
+//     on its neighbour, counting the sites that invert: no serial sweep;
+//   * the Nyquist refinement (:763-956) runs over the bounding box of the flagged sites, and only if that box has an
+//     extent.  Neither is a dependency of the whole tile: a site of the second flag plane can only be set with four
+//     flagged neighbours out of eight, which lie in two rows and two columns at least -- so where the reference skips the
+//     refinement, or a site lies outside its box, the unconditional vote yields 0 and everything behind it does nothing
+//     (tools/amaze_alias_probe.py bit 64 shows the same on the oracle);
+//   * of the reference's plane sharings (amaze.cc:300-327) ONE reaches the kept 128 x 128 pixels of a full tile: the second
+//     flag plane lives in cddiffsq's bytes and is cleared / written for tile rows 4..155 only, so the area weights of rows
+//     150 and 151 read, as flags of rows 156 and 157, the BYTES of the squared colour differences of tile row 19, columns
+//     80..119 (profiles/r03_amaze_alias_probe.txt, bit 16).  Those 80 floats are kept aside when row 19 passes.
+// Tiles the frame cuts (the last tile row / column: shorter planes, mirrored fills that overrun into the flag bytes, more
+// sharings in reach of the kept pixels) stay with amaze_tiles.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#ifndef AMZ_FN
+#define AMZ_FN static inline
+#endif
+
+namespace amz
+{
+
+constexpr int TS = 160, TSH = 80;
+constexpr int R = 4;    // rows per step
+constexpr int NT = 640; // threads: one per site of a full-width stage
+constexpr float EPS = 1e-5f, EPSSQ = 1e-10f, ARTHRESH = 0.75f;
+
+// rows a stage trails the load by
+constexpr int L_LOAD = 0, L_S1 = 2, L_S2 = 4, L_S3V = 6, L_S4 = 9, L_S5 = 11, L_S6 = 13, L_INT = 19, L_VOTE = 20, L_S8 = 22,
+              L_S13 = 25, L_S14 = 26;
+constexpr int L_S9 = 17, L_RB = 19, L_RBI = 20; // the diagonal branch: gradients, R/B estimates, their vote and R+B
+constexpr int STEPS = (TS - 17 + L_S14) / R + 1; // the last kept row is 143
+
+// ---- the planes: WIDTH words per row (floats, or bytes for the flag planes), DEPTH rows
+//      DEPTH = R + (last consumer's lag + the rows it reads above its own) - (producer's lag)
+template <int OFF_, int W_, int D_> struct plane
+{
+  static constexpr int OFF = OFF_, W = W_, D = D_, END = OFF_ + W_ * D_;
+  AMZ_FN int idx(const int r, const int c) { return OFF + (int)((unsigned)r % (unsigned)D) * W + c; }
+};
+// float planes, full width
+typedef plane<0, TS, R + 26> P_CFA;           // load; the area weights read 7 rows up at lag 19, the output at 26
+typedef plane<P_CFA::END, TS, R + 4> P_D0;    // S1 -> S2 (2 rows up)
+typedef plane<P_D0::END, TS, R + 4> P_D1;
+typedef plane<P_D1::END, TS, R + 4> P_DQ;     // at lag 9 -> S5 (2 up)
+typedef plane<P_DQ::END, TS, R + 8> P_VCD;    // S2 -> S4 (3 up at lag 9)
+typedef plane<P_VCD::END, TS, R + 5> P_HCD;   // S2 -> S4
+typedef plane<P_HCD::END, TS, R + 4> P_VCDALT; // S2 -> S3 down the columns (2 up at lag 6)
+typedef plane<P_VCDALT::END, TS, R> P_HCDALT;
+typedef plane<P_HCDALT::END, TS, R> P_HR0;    // the two candidates of a site of the row chains
+typedef plane<P_HR0::END, TS, R> P_HR1;
+typedef plane<P_HR1::END, TS, R + 7> P_DGV;   // dgintv: S2 -> S4 (2 up)
+typedef plane<P_DGV::END, TS, R + 5> P_DGH;
+// float planes, one word per R/B site (or per pair of columns)
+typedef plane<P_DGH::END, TSH, R + 5> P_HWT;  // S2 -> S4
+typedef plane<P_HWT::END, TSH, R + 5> P_VWT;
+typedef plane<P_VWT::END, TSH, R + 4> P_CDD;  // cddiffsq at lag 9 -> S5 (2 up)
+typedef plane<P_CDD::END, TSH, R + 18> P_HVWT; // S4 -> the output (1 up at lag 26)
+typedef plane<P_HVWT::END, TSH, R + 13> P_VCDH; // vcd / hcd at the R/B sites, lag 9 -> the curvature refinement at 22
+typedef plane<P_VCDH::END, TSH, R + 13> P_HCDH;
+typedef plane<P_HCDH::END, TSH, R + 6> P_GREEN; // green at the R/B sites, lag 20 -> 26
+typedef plane<P_GREEN::END, TSH, R + 8> P_DGO;  // G - R at R sites, G - B at B sites: lag 20 -> S13 (3 up at 25)
+typedef plane<P_DGO::END, TSH, R + 2> P_DGP;    // the other difference at those sites: S13 -> output (1 up)
+typedef plane<P_DGP::END, TSH, R + 4> P_GH;     // dgrb2
+typedef plane<P_GH::END, TSH, R + 4> P_GV;
+typedef plane<P_GV::END, TSH, R + 4> P_DELP;    // S9 -> R/B estimates (2 up)
+typedef plane<P_DELP::END, TSH, R + 4> P_DELM;
+typedef plane<P_DELM::END, TSH, R + 4> P_DSQP;
+typedef plane<P_DSQP::END, TSH, R + 4> P_DSQM;
+typedef plane<P_DSQM::END, TSH, R + 1> P_RBP;
+typedef plane<P_RBP::END, TSH, R + 1> P_RBM;
+typedef plane<P_RBM::END, TSH, R + 3> P_PMWT;   // lag 19 -> vote at 20 (1 up) -> S11 at 22
+typedef plane<P_PMWT::END, TSH, R + 4> P_RBINT; // lag 20 -> S11 (2 up)
+constexpr int CDD19 = P_RBINT::END; // the 80 floats behind the second flag plane's rows 156..159
+constexpr int FLOATS_END = CDD19 + TSH;
+// byte planes (offsets in bytes)
+typedef plane<FLOATS_END * 4, TS, R> P_HB;      // the two picks of a site of the row chains
+typedef plane<P_HB::END, TSH, R + 4> P_NY;      // S5 -> S6 (2 up)
+typedef plane<P_NY::END, TSH, R + 12> P_NY2;    // S6 -> area weights (6 up at lag 19) -> refinement at 22
+constexpr int LDS_BYTES = (P_NY2::END + 15) & ~15;
+
+struct args
+{
+  int width, height;
+  uint32_t filters;
+  int ex, ey;
+  float clip_pt;
+};
+
+AMZ_FN float sqr(const float x) { return x * x; }
+AMZ_FN float fmin2(const float a, const float b) { return b < a ? b : a; } // std::min
+AMZ_FN float fmax2(const float a, const float b) { return a < b ? b : a; } // std::max
+AMZ_FN float lim(const float a, const float b, const float c) { return fmax2(b, fmin2(a, c)); }
+AMZ_FN float ulim(const float a, const float b, const float c) { return (b < c) ? lim(a, b, c) : lim(a, c, b); }
+AMZ_FN float intp(const float a, const float b, const float c) { return a * (b - c) + c; }
+AMZ_FN uint32_t f2u(const float f)
+{
+  union { float f; uint32_t u; } x;
+  x.f = f;
+  return x.u;
+}
+AMZ_FN float u2f(const uint32_t u)
+{
+  union { float f; uint32_t u; } x;
+  x.u = u;
+  return x.f;
+}
+// xmul2f / xdiv2f / xdivf, amaze.cc:77-121: exponent arithmetic unless the value is +-0
+AMZ_FN float expo(const float d, const int n)
+{
+  const uint32_t u = f2u(d);
+  return (u & 0x7FFFFFFFu) ? u2f(u + ((uint32_t)n << 23)) : d;
+}
+AMZ_FN float xmul2f(const float d) { return expo(d, 1); }
+AMZ_FN float xdiv2f(const float d) { return expo(d, -1); }
+AMZ_FN float xdivf(const float d, const int n) { return expo(d, -n); }
+// clampnan(), amaze.cc:61-75: only infinities are clamped (the NaN branch is shadowed)
+AMZ_FN float clampnan(const float x, const float m, const float M)
+{
+  const bool finite = (f2u(x) & 0x7F800000u) != 0x7F800000u;
+  return finite ? x : (x < m ? m : (x > M ? M : x));
+}
+AMZ_FN int fct(const int r, const int c, const uint32_t filters) { return filters >> ((((r << 1) & 14) + (c & 1)) << 1) & 3; }
+
+// the colour-difference variance a site of a chain compares (amaze.cc:590-600)
+AMZ_FN float cdvar3(const float a, const float b, const float c) { return 3.f * (sqr(a) + sqr(b) + sqr(c)) - sqr(a + b + c); }
+// ... and what becomes of the estimate h it picks (amaze.cc:611-705): bounded where green would overshoot or clip
+AMZ_FN float chain_bound(float h, const float before, const float here, const float after, const bool gsite, const float clip_pt)
+{
+  if(gsite)
+  {
+    const float Gint = -h + here;
+    if(h > 0)
+    {
+      if(3.f * h > (Gint + here))
+        h = -ulim(Gint, before, after) + here;
+      else
+      {
+        const float wt = 1.f - 3.f * h / (EPS + Gint + here);
+        h = wt * h + (1.f - wt) * (-ulim(Gint, before, after) + here);
+      }
+    }
+    if(Gint > clip_pt) h = -ulim(Gint, before, after) + here;
+  }
+  else
+  {
+    const float Gint = h + here;
+    if(h < 0)
+    {
+      if(3.f * h < -(Gint + here))
+        h = ulim(Gint, before, after) - here;
+      else
+      {
+        const float wt = 1.f + 3.f * h / (EPS + Gint + here);
+        h = wt * h + (1.f - wt) * (ulim(Gint, before, after) - here);
+      }
+    }
+    if(Gint > clip_pt) h = ulim(Gint, before, after) - here;
+  }
+  return h;
+}
+
+// One full tile (160 x 160, none of it cut by the frame's bottom or right edge; the mirrored top / left border included).
+// All NT threads of the workgroup call this with the same arguments.
+template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, const args &a, const int top, const int left)
+{
+  const int tid = env.tid();
+  const int width = a.width;
+  const uint32_t filters = a.filters;
+  const float clip_pt = a.clip_pt, clip_pt8 = 0.8f * a.clip_pt;
+  const int rrmin = top < 0 ? 16 : 0, ccmin = left < 0 ? 16 : 0;
+
+#define LD(P, r, c) env.ldf(P::idx((r), (c)), (r))
+#define ST(P, r, c, v) env.stf(P::idx((r), (c)), (r), (v))
+#define LDB(P, r, c) env.ldb(P::idx((r), (c)), (r))
+#define STB(P, r, c, v) env.stb(P::idx((r), (c)), (r), (v))
+#define IN_(x, lo, hi) ((x) >= (lo) && (x) < (hi))
+// every thread over the sites of the R rows of a stage with lag L: all columns ...
+#define FOR_FULL(L)                                      \
+  for(int _k = tid; _k < R * TS; _k += NT)               \
+    for(int rr = s * R - (L) + _k / TS, cc = _k % TS, _once = 1; _once && rr >= 0 && rr < TS; _once = 0)
+// ... the R/B sites (q: the column parity of the R/B sites of the row; h: the site's word in a half-width plane)
+#define FOR_RB(L)                                                                                         \
+  for(int _k = tid; _k < R * TSH; _k += NT)                                                               \
+    for(int rr = s * R - (L) + _k / TSH, h = _k % TSH, q = rr >= 0 ? (fct(rr, 2, filters) & 1) : 0, cc = q + 2 * h, _once = 1; \
+        _once && rr >= 0 && rr < TS; _once = 0)
+
+  // the tile starts from zeros, like the reference's buffer in the oracle
+  for(int k = tid; k < LDS_BYTES / 4; k += NT) env.zero(k);
+  env.sync();
+
+  for(int s = 0; s < STEPS; s++)
+  {
+    // ---- phase 1: tile rows from the mosaic, amaze.cc:352-460 (top / left border mirrored; the corner's own rule);
+    //      the squared gradients S5 reads, :463-473, from rows loaded long ago
+    FOR_FULL(L_LOAD)
+    {
+      float v;
+      if(rr < rrmin && cc < ccmin)
+        v = in[(size_t)(32 - rr) * width + (32 - cc)];
+      else
+      {
+        const int row = rr < rrmin ? 32 - rr + top : rr + top, col = cc < ccmin ? 32 - cc + left : cc + left;
+        v = in[(size_t)row * width + col];
+      }
+      ST(P_CFA, rr, cc, v);
+    }
+    FOR_FULL(L_S4)
+    {
+      float v = 0.f;
+      if(IN_(rr, 2, TS - 2) && IN_(cc, 2, TS - 2))
+      {
+        const float delh = fabsf(LD(P_CFA, rr, cc + 1) - LD(P_CFA, rr, cc - 1));
+        const float delv = fabsf(LD(P_CFA, rr + 1, cc) - LD(P_CFA, rr - 1, cc));
+        v = sqr(delh) + sqr(delv);
+      }
+      ST(P_DQ, rr, cc, v);
+    }
+    env.sync();
+
+    // ---- phase 2: S1 directional gradients, :463-473; S9 diagonal gradients and squared differences, :958-983
+    FOR_FULL(L_S1)
+    {
+      float v0 = 0.f, v1 = 0.f;
+      if(IN_(rr, 2, TS - 2) && IN_(cc, 2, TS - 2))
+      {
+        const float c0 = LD(P_CFA, rr, cc);
+        const float delh = fabsf(LD(P_CFA, rr, cc + 1) - LD(P_CFA, rr, cc - 1));
+        const float delv = fabsf(LD(P_CFA, rr + 1, cc) - LD(P_CFA, rr - 1, cc));
+        v0 = EPS + fabsf(LD(P_CFA, rr + 2, cc) - c0) + fabsf(c0 - LD(P_CFA, rr - 2, cc)) + delv;
+        v1 = EPS + fabsf(LD(P_CFA, rr, cc + 2) - c0) + fabsf(c0 - LD(P_CFA, rr, cc - 2)) + delh;
+      }
+      ST(P_D0, rr, cc, v0);
+      ST(P_D1, rr, cc, v1);
+    }
+    for(int _k = tid; _k < R * TSH; _k += NT)
+    {
+      const int rr = s * R - L_S9 + _k / TSH, hh = _k % TSH;
+      if(rr < 0 || rr >= TS) continue;
+      float vp = 0.f, vm = 0.f, sp = 0.f, sm = 0.f;
+      const int c2 = 2 * hh; // the even column of the pair
+      if(IN_(rr, 6, TS - 6) && IN_(c2, 6, TS - 6))
+      {
+        const bool odd = fct(rr, 2, filters) & 1;
+        const int ga = odd ? c2 + 1 : c2, sb = odd ? c2 : c2 + 1; // gradients at the green site of the pair, squares at the other
+        vp = fabsf(LD(P_CFA, rr - 1, ga + 1) - LD(P_CFA, rr + 1, ga - 1));
+        vm = fabsf(LD(P_CFA, rr + 1, ga + 1) - LD(P_CFA, rr - 1, ga - 1));
+        const float b = LD(P_CFA, rr, sb);
+        sp = (sqr(b - LD(P_CFA, rr + 1, sb - 1)) + sqr(b - LD(P_CFA, rr - 1, sb + 1)));
+        sm = (sqr(b - LD(P_CFA, rr - 1, sb - 1)) + sqr(b - LD(P_CFA, rr + 1, sb + 1)));
+      }
+      ST(P_DELP, rr, hh, vp);
+      ST(P_DELM, rr, hh, vm);
+      ST(P_DSQP, rr, hh, sp);
+      ST(P_DSQM, rr, hh, sm);
+    }
+    env.sync();
+
+    // ---- phase 3: S2 colour differences by adaptive ratios and by Hamilton-Adams, :478-582;
+    //      diagonal R/B estimates, :986-1107
+    FOR_FULL(L_S2)
+    {
+      float v = 0.f, hd = 0.f, va = 0.f, ha = 0.f, gv = 0.f, gh = 0.f;
+      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      {
+        const bool gsite = fct(rr, cc, filters) & 1;
+        const float c = LD(P_CFA, rr, cc);
+        const float cu1 = LD(P_CFA, rr - 1, cc), cu2 = LD(P_CFA, rr - 2, cc), cd1 = LD(P_CFA, rr + 1, cc), cd2 = LD(P_CFA, rr + 2, cc);
+        const float cl1 = LD(P_CFA, rr, cc - 1), cl2 = LD(P_CFA, rr, cc - 2), cr1 = LD(P_CFA, rr, cc + 1), cr2 = LD(P_CFA, rr, cc + 2);
+        const float d0c = LD(P_D0, rr, cc), d0u2 = LD(P_D0, rr - 2, cc), d0d2 = LD(P_D0, rr + 2, cc);
+        const float d0u1 = LD(P_D0, rr - 1, cc), d0d1 = LD(P_D0, rr + 1, cc);
+        const float d1c = LD(P_D1, rr, cc), d1l2 = LD(P_D1, rr, cc - 2), d1r2 = LD(P_D1, rr, cc + 2);
+        const float d1l1 = LD(P_D1, rr, cc - 1), d1r1 = LD(P_D1, rr, cc + 1);
+        const float cru = cu1 * (d0u2 + d0c) / (d0u2 * (EPS + c) + d0c * (EPS + cu2));
+        const float crd = cd1 * (d0d2 + d0c) / (d0d2 * (EPS + c) + d0c * (EPS + cd2));
+        const float crl = cl1 * (d1l2 + d1c) / (d1l2 * (EPS + c) + d1c * (EPS + cl2));
+        const float crr = cr1 * (d1r2 + d1c) / (d1r2 * (EPS + c) + d1c * (EPS + cr2));
+        const float guha = cu1 + xdiv2f(c - cu2);
+        const float gdha = cd1 + xdiv2f(c - cd2);
+        const float glha = cl1 + xdiv2f(c - cl2);
+        const float grha = cr1 + xdiv2f(c - cr2);
+        float guar = fabsf(1.f - cru) < ARTHRESH ? c * cru : guha;
+        float gdar = fabsf(1.f - crd) < ARTHRESH ? c * crd : gdha;
+        float glar = fabsf(1.f - crl) < ARTHRESH ? c * crl : glha;
+        float grar = fabsf(1.f - crr) < ARTHRESH ? c * crr : grha;
+        const float hwt = d1l1 / (d1l1 + d1r1);
+        const float vwt = d0u1 / (d0d1 + d0u1);
+        const float Gintvha = vwt * gdha + (1.f - vwt) * guha;
+        const float Ginthha = hwt * grha + (1.f - hwt) * glha;
+        if(gsite)
+        {
+          v = c - (vwt * gdar + (1.f - vwt) * guar);
+          hd = c - (hwt * grar + (1.f - hwt) * glar);
+          va = c - Gintvha;
+          ha = c - Ginthha;
+        }
+        else
+        {
+          v = (vwt * gdar + (1.f - vwt) * guar) - c;
+          hd = (hwt * grar + (1.f - hwt) * glar) - c;
+          va = Gintvha - c;
+          ha = Ginthha - c;
+          // S4 forms the same two quotients at the R/B sites
+          ST(P_HWT, rr, cc >> 1, hwt);
+          ST(P_VWT, rr, cc >> 1, vwt);
+        }
+        if(c > clip_pt8 || Gintvha > clip_pt8 || Ginthha > clip_pt8)
+        {
+          guar = guha;
+          gdar = gdha;
+          glar = glha;
+          grar = grha;
+          v = va;
+          hd = ha;
+        }
+        gv = fmin2(sqr(guha - gdha), sqr(guar - gdar));
+        gh = fmin2(sqr(glha - grha), sqr(glar - grar));
+      }
+      ST(P_VCD, rr, cc, v);
+      ST(P_HCD, rr, cc, hd);
+      ST(P_VCDALT, rr, cc, va);
+      ST(P_HCDALT, rr, cc, ha);
+      ST(P_DGV, rr, cc, gv);
+      ST(P_DGH, rr, cc, gh);
+    }
+    FOR_RB(L_RB)
+    {
+      float pw = 0.f, vp = 0.f, vm = 0.f;
+      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
+      {
+        const float ge0 = 0.13719494435797422f, ge1 = 0.05640252782101291f;
+        const float c = LD(P_CFA, rr, cc);
+        const float cse1 = LD(P_CFA, rr + 1, cc + 1), cse2 = LD(P_CFA, rr + 2, cc + 2);
+        const float cnw1 = LD(P_CFA, rr - 1, cc - 1), cnw2 = LD(P_CFA, rr - 2, cc - 2);
+        const float cne1 = LD(P_CFA, rr - 1, cc + 1), cne2 = LD(P_CFA, rr - 2, cc + 2);
+        const float csw1 = LD(P_CFA, rr + 1, cc - 1), csw2 = LD(P_CFA, rr + 2, cc - 2);
+        const float crse = xmul2f(cse1) / (EPS + c + (cse2));
+        const float crnw = xmul2f(cnw1) / (EPS + c + (cnw2));
+        const float crne = xmul2f(cne1) / (EPS + c + (cne2));
+        const float crsw = xmul2f(csw1) / (EPS + c + (csw2));
+        const float rbse = fabsf(1.f - crse) < ARTHRESH ? c * crse : (cse1) + xdiv2f(c - cse2);
+        const float rbnw = fabsf(1.f - crnw) < ARTHRESH ? c * crnw : (cnw1) + xdiv2f(c - cnw2);
+        const float rbne = fabsf(1.f - crne) < ARTHRESH ? c * crne : (cne1) + xdiv2f(c - cne2);
+        const float rbsw = fabsf(1.f - crsw) < ARTHRESH ? c * crsw : (csw1) + xdiv2f(c - csw2);
+#define HH(P, dr, dc) LD(P, rr + (dr), (cc + (dc)) >> 1)
+        const float wtse = EPS + HH(P_DELM, 0, 0) + HH(P_DELM, 1, 1) + HH(P_DELM, 2, 2);
+        const float wtnw = EPS + HH(P_DELM, 0, 0) + HH(P_DELM, -1, -1) + HH(P_DELM, -2, -2);
+        const float wtne = EPS + HH(P_DELP, 0, 0) + HH(P_DELP, -1, 1) + HH(P_DELP, -2, 2);
+        const float wtsw = EPS + HH(P_DELP, 0, 0) + HH(P_DELP, 1, -1) + HH(P_DELP, 2, -2);
+        vm = (wtse * rbnw + wtnw * rbse) / (wtse + wtnw);
+        vp = (wtne * rbsw + wtsw * rbne) / (wtne + wtsw);
+        const float rbvarm
+            = EPSSQ + (ge0 * (HH(P_DSQM, -1, 0) + HH(P_DSQM, 0, -1) + HH(P_DSQM, 0, 1) + HH(P_DSQM, 1, 0))
+                       + ge1 * (HH(P_DSQM, -2, -1) + HH(P_DSQM, -2, 1) + HH(P_DSQM, -1, -2) + HH(P_DSQM, -1, 2)
+                                + HH(P_DSQM, 1, -2) + HH(P_DSQM, 1, 2) + HH(P_DSQM, 2, -1) + HH(P_DSQM, 2, 1)));
+        pw = rbvarm / ((EPSSQ + (ge0 * (HH(P_DSQP, -1, 0) + HH(P_DSQP, 0, -1) + HH(P_DSQP, 0, 1) + HH(P_DSQP, 1, 0))
+                                 + ge1 * (HH(P_DSQP, -2, -1) + HH(P_DSQP, -2, 1) + HH(P_DSQP, -1, -2) + HH(P_DSQP, -1, 2)
+                                          + HH(P_DSQP, 1, -2) + HH(P_DSQP, 1, 2) + HH(P_DSQP, 2, -1) + HH(P_DSQP, 2, 1))))
+                       + rbvarm);
+#undef HH
+        if(vp < c)
+        {
+          if(xmul2f(vp) < c)
+            vp = ulim(vp, csw1, cne1);
+          else
+          {
+            const float pwt = xmul2f(c - vp) / (EPS + vp + c);
+            vp = pwt * vp + (1.f - pwt) * ulim(vp, csw1, cne1);
+          }
+        }
+        if(vm < c)
+        {
+          if(xmul2f(vm) < c)
+            vm = ulim(vm, cnw1, cse1);
+          else
+          {
+            const float mwt = xmul2f(c - vm) / (EPS + vm + c);
+            vm = mwt * vm + (1.f - mwt) * ulim(vm, cnw1, cse1);
+          }
+        }
+        if(vp > clip_pt) vp = ulim(vp, csw1, cne1);
+        if(vm > clip_pt) vm = ulim(vm, cnw1, cse1);
+      }
+      ST(P_PMWT, rr, h, pw);
+      ST(P_RBP, rr, h, vp);
+      ST(P_RBM, rr, h, vm);
+    }
+    env.sync();
+
+    // ---- phase 4: S3 (:585-705) down the columns -- a lane per column and row parity, its two rows of the step in
+    //      order -- and the two candidates of every site of the row chains
+    for(int _k = tid; _k < 2 * TS; _k += NT)
+    {
+      const int cc = _k % TS, par = _k / TS;
+      if(!IN_(cc, 4, TS - 4)) continue;
+      for(int j = 0; j < R / 2; j++)
+      {
+        const int rr = s * R - L_S3V + par + 2 * j;
+        if(!IN_(rr, 4, TS - 4)) continue;
+        const bool gsite = fct(rr, cc, filters) & 1;
+        const float prev = LD(P_VCD, rr - 2, cc), c0 = LD(P_VCD, rr, cc), c1 = LD(P_VCD, rr + 2, cc);
+        const float a0 = LD(P_VCDALT, rr - 2, cc), a1 = LD(P_VCDALT, rr, cc), a2 = LD(P_VCDALT, rr + 2, cc);
+        const float hpick = cdvar3(a0, a1, a2) < cdvar3(prev, c0, c1) ? a1 : c0;
+        ST(P_VCD, rr, cc, chain_bound(hpick, LD(P_CFA, rr - 1, cc), LD(P_CFA, rr, cc), LD(P_CFA, rr + 1, cc), gsite, clip_pt));
+      }
+    }
+    FOR_FULL(L_S2)
+    {
+      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      {
+        const bool gsite = fct(rr, cc, filters) & 1;
+        const float before = LD(P_CFA, rr, cc - 1), here = LD(P_CFA, rr, cc), after = LD(P_CFA, rr, cc + 1);
+        ST(P_HR0, rr, cc, chain_bound(LD(P_HCD, rr, cc), before, here, after, gsite, clip_pt));
+        ST(P_HR1, rr, cc, chain_bound(LD(P_HCDALT, rr, cc), before, here, after, gsite, clip_pt));
+      }
+    }
+    env.sync();
+
+    // ---- phase 5: which candidate a site picks, for either candidate of its neighbour two columns back
+    FOR_FULL(L_S2)
+    {
+      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      {
+        const float c0 = LD(P_HCD, rr, cc), c1 = LD(P_HCD, rr, cc + 2);
+        const float altvar = cdvar3(LD(P_HCDALT, rr, cc - 2), LD(P_HCDALT, rr, cc), LD(P_HCDALT, rr, cc + 2));
+        float p0, p1;
+        if(cc - 2 >= 4)
+        {
+          p0 = LD(P_HR0, rr, cc - 2);
+          p1 = LD(P_HR1, rr, cc - 2);
+        }
+        else
+          p0 = p1 = LD(P_HCD, rr, cc - 2); // in front of the first site of the chain: never written
+        const unsigned bits = (altvar < cdvar3(p0, c0, c1) ? 1u : 0u) | (altvar < cdvar3(p1, c0, c1) ? 2u : 0u);
+        STB(P_HB, rr, cc, (unsigned char)bits);
+      }
+    }
+    env.sync();
+
+    // ---- phase 6: the pick of a site: back to the nearest site that picks the same whatever came before it (0 or 3),
+    //      inverted once per site on the way whose pick is the opposite of its neighbour's (1; 2 copies it)
+    FOR_FULL(L_S2)
+    {
+      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      {
+        unsigned inv = 0, bits;
+        for(int j = cc;; j -= 2)
+        {
+          bits = LDB(P_HB, rr, j);
+          if(bits == 0u || bits == 3u) break;
+          inv ^= (bits == 1u) ? 1u : 0u;
+        }
+        const unsigned pick = (bits & 1u) ^ inv;
+        ST(P_HCD, rr, cc, pick ? LD(P_HR1, rr, cc) : LD(P_HR0, rr, cc));
+      }
+    }
+    env.sync();
+
+    // ---- phase 7: squared difference of the two estimates at the R/B sites (:703) and the estimates themselves for the
+    //      stages far behind; S4 the H/V weight from colour-difference variances, :707-760
+    FOR_RB(L_S4)
+    {
+      const float v0 = LD(P_VCD, rr, cc), h0 = LD(P_HCD, rr, cc);
+      const float cd = (IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4)) ? sqr(v0 - h0) : 0.f;
+      ST(P_CDD, rr, h, cd);
+      ST(P_VCDH, rr, h, v0);
+      ST(P_HCDH, rr, h, h0);
+      if(rr == 19 && cc >= TSH) env.stf(CDD19 + cc - TSH, -1, cd);
+      float w = 0.f;
+      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
+      {
+        const float v1 = LD(P_VCD, rr - 1, cc), v2 = LD(P_VCD, rr - 2, cc), v3 = LD(P_VCD, rr - 3, cc);
+        const float w1 = LD(P_VCD, rr + 1, cc), w2 = LD(P_VCD, rr + 2, cc), w3 = LD(P_VCD, rr + 3, cc);
+        const float l1 = LD(P_HCD, rr, cc - 1), l2 = LD(P_HCD, rr, cc - 2), l3 = LD(P_HCD, rr, cc - 3);
+        const float r1 = LD(P_HCD, rr, cc + 1), r2 = LD(P_HCD, rr, cc + 2), r3 = LD(P_HCD, rr, cc + 3);
+        const float uave = v0 + v1 + v2 + v3;
+        const float dave = v0 + w1 + w2 + w3;
+        const float lave = h0 + l1 + l2 + l3;
+        const float rave = h0 + r1 + r2 + r3;
+        float vu = sqr(v0 - uave) + sqr(v1 - uave) + sqr(v2 - uave) + sqr(v3 - uave);
+        float vd = sqr(v0 - dave) + sqr(w1 - dave) + sqr(w2 - dave) + sqr(w3 - dave);
+        float hl = sqr(h0 - lave) + sqr(l1 - lave) + sqr(l2 - lave) + sqr(l3 - lave);
+        float hr = sqr(h0 - rave) + sqr(r1 - rave) + sqr(r2 - rave) + sqr(r3 - rave);
+        const float hwt = LD(P_HWT, rr, h);
+        const float vwt = LD(P_VWT, rr, h);
+        const float vcdvar = EPSSQ + vwt * vd + (1.f - vwt) * vu;
+        const float hcdvar = EPSSQ + hwt * hr + (1.f - hwt) * hl;
+        const float g0 = LD(P_DGV, rr, cc), e0 = LD(P_DGH, rr, cc);
+        vu = (g0) + (LD(P_DGV, rr - 1, cc)) + (LD(P_DGV, rr - 2, cc));
+        vd = (g0) + (LD(P_DGV, rr + 1, cc)) + (LD(P_DGV, rr + 2, cc));
+        hl = (e0) + (LD(P_DGH, rr, cc - 1)) + (LD(P_DGH, rr, cc - 2));
+        hr = (e0) + (LD(P_DGH, rr, cc + 1)) + (LD(P_DGH, rr, cc + 2));
+        const float vcdvar1 = EPSSQ + vwt * vd + (1.f - vwt) * vu;
+        const float hcdvar1 = EPSSQ + hwt * hr + (1.f - hwt) * hl;
+        const float varwt = hcdvar / (vcdvar + hcdvar);
+        const float diffwt = hcdvar1 / (vcdvar1 + hcdvar1);
+        // the product is formed in binary64 in the reference (0.5 is a double literal there)
+        if((0.5 - (double)varwt) * (0.5 - (double)diffwt) > 0 && fabsf(0.5f - diffwt) < fabsf(0.5f - varwt))
+          w = varwt;
+        else
+          w = diffwt;
+      }
+      ST(P_HVWT, rr, h, w);
+    }
+    env.sync();
+
+    // ---- phase 8: S5 Nyquist texture test, :763-820
+    FOR_RB(L_S5)
+    {
+      unsigned char flag = 0;
+      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
+      {
+        const float gg0 = 0.5f * 0.07384411893421103f, gg1 = 0.5f * 0.06207511968171489f, gg2 = 0.5f * 0.0521818194747806f;
+        const float gg3 = 0.5f * 0.03687419286733595f, gg4 = 0.5f * 0.03099732204057846f, gg5 = 0.5f * 0.018413194161458882f;
+        const float go0 = 0.14659727707323927f, go1 = 0.103592713382435f, go2 = 0.0732036125103057f, go3 = 0.0365543548389495f;
+#define CD(dr, dc) LD(P_CDD, rr + (dr), (cc + (dc)) >> 1)
+#define DQ(dr, dc) LD(P_DQ, rr + (dr), cc + (dc))
+        const float test
+            = (go0 * CD(0, 0) + go1 * (CD(-1, -1) + CD(-1, 1) + CD(1, -1) + CD(1, 1))
+               + go2 * (CD(-2, 0) + CD(0, -2) + CD(0, 2) + CD(2, 0)) + go3 * (CD(-2, -2) + CD(-2, 2) + CD(2, -2) + CD(2, 2)))
+              - (gg0 * DQ(0, 0) + gg1 * (DQ(-1, 0) + DQ(0, 1) + DQ(0, -1) + DQ(1, 0))
+                 + gg2 * (DQ(-1, -1) + DQ(-1, 1) + DQ(1, -1) + DQ(1, 1))
+                 + gg3 * (DQ(-2, 0) + DQ(0, -2) + DQ(0, 2) + DQ(2, 0))
+                 + gg4 * (DQ(-2, -1) + DQ(-2, 1) + DQ(-1, -2) + DQ(-1, 2) + DQ(1, -2) + DQ(1, 2) + DQ(2, -1) + DQ(2, 1))
+                 + gg5 * (DQ(-2, -2) + DQ(-2, 2) + DQ(2, -2) + DQ(2, 2)));
+#undef CD
+#undef DQ
+        flag = test > 0.f ? 1 : 0;
+      }
+      STB(P_NY, rr, h, flag);
+    }
+    env.sync();
+
+    // ---- phase 9: S6 majority vote on the flags, :832-845.  Rows 156..159 of the second flag plane are bytes of the
+    //      squared colour differences of row 19 (see the header)
+    FOR_RB(L_S6)
+    {
+      unsigned char f2 = 0;
+      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
+      {
+#define NY(dr, dc) LDB(P_NY, rr + (dr), (cc + (dc)) >> 1)
+        const unsigned n = NY(-2, 0) + NY(-1, -1) + NY(-1, 1) + NY(0, -2) + NY(0, 2) + NY(1, -1) + NY(1, 1) + NY(2, 0);
+        f2 = n > 4 ? 1 : (n < 4 ? 0 : NY(0, 0));
+#undef NY
+      }
+      else if(rr >= TS - 4)
+        f2 = (unsigned char)(f2u(env.ldf(CDD19 + (rr - (TS - 4)) * 20 + (h >> 2), -1)) >> (8 * (h & 3)));
+      STB(P_NY2, rr, h, f2);
+    }
+    env.sync();
+
+    // ---- phase 10: area interpolation of the weight in flagged regions, :850-890
+    FOR_RB(L_INT)
+    {
+      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8) && LDB(P_NY2, rr, h))
+      {
+        float sumcfa = 0.f, sumh = 0.f, sumv = 0.f, sumsqh = 0.f, sumsqv = 0.f, areawt = 0.f;
+        for(int p = -6; p < 7; p += 2)
+          for(int qq = -6; qq < 7; qq += 2)
+            if(LDB(P_NY2, rr + p, (cc + qq) >> 1))
+            {
+              const float c = LD(P_CFA, rr + p, cc + qq);
+              const float l = LD(P_CFA, rr + p, cc + qq - 1), r = LD(P_CFA, rr + p, cc + qq + 1);
+              const float u = LD(P_CFA, rr + p - 1, cc + qq), d = LD(P_CFA, rr + p + 1, cc + qq);
+              sumcfa += c;
+              sumh += (l + r);
+              sumv += (u + d);
+              sumsqh += sqr(c - l) + sqr(c - r);
+              sumsqv += sqr(c - u) + sqr(c - d);
+              areawt += 1;
+            }
+        sumh = sumcfa - xdiv2f(sumh);
+        sumv = sumcfa - xdiv2f(sumv);
+        areawt = xdiv2f(areawt);
+        const float hcdvar = EPSSQ + fabsf(areawt * sumsqh - sumh * sumh);
+        const float vcdvar = EPSSQ + fabsf(areawt * sumsqv - sumv * sumv);
+        ST(P_HVWT, rr, h, hcdvar / (vcdvar + hcdvar));
+      }
+    }
+    env.sync();
+
+    // ---- phases 11..14: the two votes, in place, one row per sub-phase: row r sees row r-1 voted (:894-905, :1109-1126);
+    //      behind the second one R + B of the site (:1123)
+    for(int j = 0; j < R; j++)
+    {
+      if(tid < TSH)
+      {
+        const int rr = s * R - L_VOTE + j, h = tid;
+        if(IN_(rr, 8, TS - 8))
+        {
+          const int cc = (fct(rr, 2, filters) & 1) + 2 * h;
+          if(IN_(cc, 8, TS - 8))
+          {
+            const float alt = xdivf(LD(P_HVWT, rr - 1, (cc - 1) >> 1) + LD(P_HVWT, rr - 1, (cc + 1) >> 1)
+                                        + LD(P_HVWT, rr + 1, (cc - 1) >> 1) + LD(P_HVWT, rr + 1, (cc + 1) >> 1),
+                                    2);
+            const float w = LD(P_HVWT, rr, h);
+            ST(P_HVWT, rr, h, fabsf(0.5f - w) < fabsf(0.5f - alt) ? alt : w);
+          }
+        }
+      }
+      else if(tid >= 128 && tid < 128 + TSH)
+      {
+        const int rr = s * R - L_RBI + j, h = tid - 128;
+        if(rr >= 0 && rr < TS)
+        {
+          const int cc = (fct(rr, 2, filters) & 1) + 2 * h;
+          float rb = 0.f;
+          if(IN_(rr, 10, TS - 10) && IN_(cc, 10, TS - 10))
+          {
+            const float alt = xdivf(LD(P_PMWT, rr - 1, (cc - 1) >> 1) + LD(P_PMWT, rr - 1, (cc + 1) >> 1)
+                                        + LD(P_PMWT, rr + 1, (cc - 1) >> 1) + LD(P_PMWT, rr + 1, (cc + 1) >> 1),
+                                    2);
+            float w = LD(P_PMWT, rr, h);
+            if(fabsf(0.5f - w) < fabsf(0.5f - alt))
+            {
+              w = alt;
+              ST(P_PMWT, rr, h, w);
+            }
+            rb = xdiv2f(LD(P_CFA, rr, cc) + LD(P_RBM, rr, h) * (1.f - w) + LD(P_RBP, rr, h) * w);
+          }
+          ST(P_RBINT, rr, h, rb);
+        }
+      }
+      env.sync();
+    }
+
+    // ---- phase 15: green at the R/B sites and its curvature, :907-917
+    FOR_RB(L_VOTE)
+    {
+      const float c = LD(P_CFA, rr, cc);
+      float g = c, dg = 0.f, ch = 0.f, cv = 0.f;
+      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
+      {
+        dg = intp(LD(P_HVWT, rr, h), LD(P_VCDH, rr, h), LD(P_HCDH, rr, h));
+        g = c + dg;
+        if(LDB(P_NY2, rr, h))
+        {
+          ch = sqr(g - xdiv2f(LD(P_CFA, rr, cc - 1) + LD(P_CFA, rr, cc + 1)));
+          cv = sqr(g - xdiv2f(LD(P_CFA, rr - 1, cc) + LD(P_CFA, rr + 1, cc)));
+        }
+      }
+      ST(P_GREEN, rr, h, g);
+      ST(P_DGO, rr, h, dg);
+      ST(P_GH, rr, h, ch);
+      ST(P_GV, rr, h, cv);
+    }
+    env.sync();
+
+    // ---- phase 16: S8 refine flagged regions with the curvature of green, :923-956; then S11 where the diagonal
+    //      estimate discriminates better, green from R + B, :1129-1236 (it overrides S8 at a site that takes both)
+    FOR_RB(L_S8)
+    {
+      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8) && LDB(P_NY2, rr, h))
+      {
+        const float q0 = 0.169917f, q1 = 0.108947f, q2 = 0.069855f, q3 = 0.0287182f;
+#define QUINC(P)                                                                                                         \
+  (EPSSQ + (q0 * LD(P, rr, h) + q1 * (LD(P, rr - 1, (cc - 1) >> 1) + LD(P, rr - 1, (cc + 1) >> 1) + LD(P, rr + 1, (cc - 1) >> 1) + LD(P, rr + 1, (cc + 1) >> 1)) \
+            + q2 * (LD(P, rr - 2, h) + LD(P, rr, h - 1) + LD(P, rr, h + 1) + LD(P, rr + 2, h))                                                                    \
+            + q3 * (LD(P, rr - 2, h - 1) + LD(P, rr - 2, h + 1) + LD(P, rr + 2, h - 1) + LD(P, rr + 2, h + 1))))
+        const float gvarh = QUINC(P_GH);
+        const float gvarv = QUINC(P_GV);
+#undef QUINC
+        const float dg = (LD(P_HCDH, rr, h) * gvarv + LD(P_VCDH, rr, h) * gvarh) / (gvarv + gvarh);
+        ST(P_DGO, rr, h, dg);
+        ST(P_GREEN, rr, h, LD(P_CFA, rr, cc) + dg);
+      }
+      if(IN_(rr, 12, TS - 12) && IN_(cc, 12, TS - 12))
+      {
+        const float pm = LD(P_PMWT, rr, h), hv = LD(P_HVWT, rr, h);
+        if(!(fabsf(0.5f - pm) < fabsf(0.5f - hv)))
+        {
+          const float c = LD(P_CFA, rr, cc);
+          const float cu = LD(P_CFA, rr - 1, cc), cd = LD(P_CFA, rr + 1, cc), cl = LD(P_CFA, rr, cc - 1), cr = LD(P_CFA, rr, cc + 1);
+          const float rb = LD(P_RBINT, rr, h);
+          const float rbu = LD(P_RBINT, rr - 2, h), rbd = LD(P_RBINT, rr + 2, h), rbl = LD(P_RBINT, rr, h - 1), rbr = LD(P_RBINT, rr, h + 1);
+          // binary64 where the reference has double literals
+          const float cru = (float)((double)cu * 2.0 / (double)(EPS + rb + rbu));
+          const float crd = (float)((double)cd * 2.0 / (double)(EPS + rb + rbd));
+          const float crl = (float)((double)cl * 2.0 / (double)(EPS + rb + rbl));
+          const float crr = (float)((double)cr * 2.0 / (double)(EPS + rb + rbr));
+          const float gu = fabsf(1.f - cru) < ARTHRESH ? rb * cru : cu + xdiv2f(rb - rbu);
+          const float gd = fabsf(1.f - crd) < ARTHRESH ? rb * crd : cd + xdiv2f(rb - rbd);
+          const float gl = fabsf(1.f - crl) < ARTHRESH ? rb * crl : cl + xdiv2f(rb - rbl);
+          const float gr = fabsf(1.f - crr) < ARTHRESH ? rb * crr : cr + xdiv2f(rb - rbr);
+          // the directional gradients of S1 at the four green neighbours, formed again from the mosaic
+          const float cu2 = LD(P_CFA, rr - 2, cc), cu3 = LD(P_CFA, rr - 3, cc), cd2 = LD(P_CFA, rr + 2, cc), cd3 = LD(P_CFA, rr + 3, cc);
+          const float cl2 = LD(P_CFA, rr, cc - 2), cl3 = LD(P_CFA, rr, cc - 3), cr2 = LD(P_CFA, rr, cc + 2), cr3 = LD(P_CFA, rr, cc + 3);
+          const float d0u = EPS + fabsf(cd - cu) + fabsf(cu - cu3) + fabsf(c - cu2);
+          const float d0d = EPS + fabsf(cd3 - cd) + fabsf(cd - cu) + fabsf(cd2 - c);
+          const float d1l = EPS + fabsf(cr - cl) + fabsf(cl - cl3) + fabsf(c - cl2);
+          const float d1r = EPS + fabsf(cr3 - cr) + fabsf(cr - cl) + fabsf(cr2 - c);
+          float Gintv = (d0u * gd + d0d * gu) / (d0d + d0u);
+          float Ginth = (d1l * gr + d1r * gl) / (d1l + d1r);
+          if(Gintv < rb)
+          {
+            if(2 * Gintv < rb)
+              Gintv = ulim(Gintv, cu, cd);
+            else
+            {
+              const float vwt = (float)(2.0 * (double)(rb - Gintv) / (double)(EPS + Gintv + rb));
+              Gintv = vwt * Gintv + (1.f - vwt) * ulim(Gintv, cu, cd);
+            }
+          }
+          if(Ginth < rb)
+          {
+            if(2 * Ginth < rb)
+              Ginth = ulim(Ginth, cl, cr);
+            else
+            {
+              const float hwt = (float)(2.0 * (double)(rb - Ginth) / (double)(EPS + Ginth + rb));
+              Ginth = hwt * Ginth + (1.f - hwt) * ulim(Ginth, cl, cr);
+            }
+          }
+          if(Ginth > clip_pt) Ginth = ulim(Ginth, cl, cr);
+          if(Gintv > clip_pt) Gintv = ulim(Gintv, cu, cd);
+          const float g = Ginth * (1.f - hv) + Gintv * hv;
+          ST(P_GREEN, rr, h, g);
+          ST(P_DGO, rr, h, g - c);
+        }
+      }
+    }
+    env.sync();
+
+    // ---- phase 17: S13 chrominance at the opposite R/B sites from the four diagonal neighbours, :1246-1276 (the split
+    //      of :1239-1244 is in the indexing: a site keeps its own difference, this stage gives it the other one)
+    FOR_RB(L_S13)
+    {
+      float v = 0.f;
+      if(IN_(rr, 14, TS - 14) && IN_(cc, 14, TS - 14))
+      {
+#define D(dr, dc) LD(P_DGO, rr + (dr), (cc + (dc)) >> 1)
+        const float nw1 = D(-1, -1), nw3 = D(-3, -3), se1 = D(1, 1), se3 = D(3, 3);
+        const float ne1 = D(-1, 1), ne3 = D(-3, 3), sw1 = D(1, -1), sw3 = D(3, -3);
+        const float wtnw = 1.f / (EPS + fabsf(nw1 - se1) + fabsf(nw1 - nw3) + fabsf(se1 - nw3));
+        const float wtne = 1.f / (EPS + fabsf(ne1 - sw1) + fabsf(ne1 - ne3) + fabsf(sw1 - ne3));
+        const float wtsw = 1.f / (EPS + fabsf(sw1 - ne1) + fabsf(sw1 - se3) + fabsf(ne1 - sw3)); // se3: as the reference has it
+        const float wtse = 1.f / (EPS + fabsf(se1 - nw1) + fabsf(se1 - sw3) + fabsf(nw1 - se3)); // sw3: likewise
+        v = (wtnw * (1.325f * nw1 - 0.175f * nw3 - 0.075f * D(-1, -3) - 0.075f * D(-3, -1))
+             + wtne * (1.325f * ne1 - 0.175f * ne3 - 0.075f * D(-1, 3) - 0.075f * D(1, 1))
+             + wtsw * (1.325f * sw1 - 0.175f * sw3 - 0.075f * D(1, -3) - 0.075f * D(-1, -1))
+             + wtse * (1.325f * se1 - 0.175f * se3 - 0.075f * D(1, 3) - 0.075f * D(3, 1)))
+            / (wtnw + wtne + wtsw + wtse);
+#undef D
+      }
+      ST(P_DGP, rr, h, v);
+    }
+    env.sync();
+
+    // ---- phase 18: S14 output, :1278-1411 (alpha is left as it is)
+    FOR_FULL(L_S14)
+    {
+      if(IN_(rr, 16, TS - 16) && IN_(cc, 16, TS - 16))
+      {
+        float *const o = out + 4 * ((size_t)(rr + top) * width + (cc + left));
+        const int col = fct(rr, cc, filters);
+        if(col & 1)
+        {
+          // a green site: the vertical neighbours are of one R/B colour, the horizontal ones of the other
+          const bool vert_red = fct(rr - 1, cc, filters) == 0;
+          const int hl = (cc - 1) >> 1, hr = (cc + 1) >> 1, hv = cc >> 1;
+          const float wu = LD(P_HVWT, rr - 1, hv), wr = LD(P_HVWT, rr, hr), wl = LD(P_HVWT, rr, hl), wd = LD(P_HVWT, rr + 1, hv);
+          const float temp = 1.f / (wu + 2.f - wr - wl + wd);
+          // dgrb0 (G - R) and dgrb1 (G - B) at the four neighbours
+          const float u0 = vert_red ? LD(P_DGO, rr - 1, hv) : LD(P_DGP, rr - 1, hv), u1 = vert_red ? LD(P_DGP, rr - 1, hv) : LD(P_DGO, rr - 1, hv);
+          const float d0 = vert_red ? LD(P_DGO, rr + 1, hv) : LD(P_DGP, rr + 1, hv), d1 = vert_red ? LD(P_DGP, rr + 1, hv) : LD(P_DGO, rr + 1, hv);
+          const float r0 = vert_red ? LD(P_DGP, rr, hr) : LD(P_DGO, rr, hr), r1 = vert_red ? LD(P_DGO, rr, hr) : LD(P_DGP, rr, hr);
+          const float l0 = vert_red ? LD(P_DGP, rr, hl) : LD(P_DGO, rr, hl), l1 = vert_red ? LD(P_DGO, rr, hl) : LD(P_DGP, rr, hl);
+          const float g = LD(P_CFA, rr, cc);
+          o[0] = clampnan(g - ((wu)*u0 + (1.f - wr) * r0 + (1.f - wl) * l0 + (wd)*d0) * temp, 0.0f, 1.0f);
+          o[2] = clampnan(g - ((wu)*u1 + (1.f - wr) * r1 + (1.f - wl) * l1 + (wd)*d1) * temp, 0.0f, 1.0f);
+          o[1] = clampnan(g, 0.0f, 1.0f);
+        }
+        else
+        {
+          const int hh = cc >> 1;
+          const float g = LD(P_GREEN, rr, hh), own = LD(P_DGO, rr, hh), opp = LD(P_DGP, rr, hh);
+          o[0] = clampnan(g - (col == 0 ? own : opp), 0.0f, 1.0f);
+          o[2] = clampnan(g - (col == 0 ? opp : own), 0.0f, 1.0f);
+          o[1] = clampnan(g, 0.0f, 1.0f);
+        }
+      }
+    }
+    env.sync();
+  }
+#undef LD
+#undef ST
+#undef LDB
+#undef STB
+#undef IN_
+#undef FOR_FULL
+#undef FOR_RB
+}
+
+} // namespace amz
