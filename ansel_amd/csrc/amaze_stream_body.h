@@ -8,7 +8,7 @@
 // memory and moves 25 x the algorithmic bytes).  Here a tile is walked top to bottom in steps of R rows.  Every stage
 // runs once per step on ITS rows of the step -- stage X works on tile rows [s R - L_X, s R - L_X + R), L_X being the
 // number of rows X trails the load by: what X reads below a row must have been produced -- and its planes live in LDS
-// as rings of just the rows between their producer and their last consumer (135 KB in all).  A phase = the stages of a
+// as rings of just the rows between their producer and their last consumer (all but 640 bytes of a CU's 160 KB, ring depths rounded up to powers of two).  A phase = the stages of a
 // step that do not depend on each other, then a workgroup barrier.
 //
 // What makes the result the reference's, bit for bit (oracle/src/demosaic_amaze.c restates it):
@@ -38,6 +38,7 @@
 
 #ifndef AMZ_FN
 #define AMZ_FN static inline
+#define AMZ_MEMBER static inline
 #endif
 
 namespace amz
@@ -46,12 +47,14 @@ namespace amz
 constexpr int TS = 160, TSH = 80;
 constexpr int R = 4;    // rows per step
 constexpr int NT = 640; // threads: one per site of a full-width stage
+constexpr int STREAM_THREADS = NT;
 constexpr float EPS = 1e-5f, EPSSQ = 1e-10f, ARTHRESH = 0.75f;
 
 // rows a stage trails the load by
 constexpr int L_LOAD = 0, L_S1 = 2, L_S2 = 4, L_S3V = 6, L_S4 = 9, L_S5 = 11, L_S6 = 13, L_INT = 19, L_VOTE = 20, L_S8 = 22,
               L_S13 = 25, L_S14 = 26;
 constexpr int L_S9 = 17, L_RB = 19, L_RBI = 20; // the diagonal branch: gradients, R/B estimates, their vote and R+B
+constexpr int L_DQ = 5; // the squared gradients: formed late in a step for S5 of the NEXT step (lag 11 - 2 rows - R)
 constexpr int STEPS = (TS - 17 + L_S14) / R + 1; // the last kept row is 143
 
 // ---- the planes: WIDTH words per row (floats, or bytes for the flag planes), DEPTH rows
@@ -59,48 +62,52 @@ constexpr int STEPS = (TS - 17 + L_S14) / R + 1; // the last kept row is 143
 template <int OFF_, int W_, int D_> struct plane
 {
   static constexpr int OFF = OFF_, W = W_, D = D_, END = OFF_ + W_ * D_;
-  AMZ_FN int idx(const int r, const int c) { return OFF + (int)((unsigned)r % (unsigned)D) * W + c; }
+  AMZ_MEMBER int idx(const int r, const int c) { return OFF + (int)((unsigned)r % (unsigned)D) * W + c; }
 };
+// (a power of two wherever LDS allows: the slot of a row is then one AND; 163 200 of the CU's 163 840 bytes)
 // float planes, full width
-typedef plane<0, TS, R + 26> P_CFA;           // load; the area weights read 7 rows up at lag 19, the output at 26
-typedef plane<P_CFA::END, TS, R + 4> P_D0;    // S1 -> S2 (2 rows up)
-typedef plane<P_D0::END, TS, R + 4> P_D1;
-typedef plane<P_D1::END, TS, R + 4> P_DQ;     // at lag 9 -> S5 (2 up)
-typedef plane<P_DQ::END, TS, R + 8> P_VCD;    // S2 -> S4 (3 up at lag 9)
-typedef plane<P_VCD::END, TS, R + 5> P_HCD;   // S2 -> S4
-typedef plane<P_HCD::END, TS, R + 4> P_VCDALT; // S2 -> S3 down the columns (2 up at lag 6)
+typedef plane<0, TS, 32> P_CFA;               // load; the area weights read 7 rows up at lag 19, the output at 26: R + 26
+typedef plane<P_CFA::END, TS, 8> P_D0;        // S1 -> S2 (2 rows up): R + 4
+typedef plane<P_D0::END, TS, 8> P_D1;
+typedef plane<P_D1::END, TS, 8> P_DQ;         // at lag 5, behind S5 in its step -> S5 of the next step (2 up)
+typedef plane<P_DQ::END, TS, 16> P_VCD;       // S2 -> S4 (3 up at lag 9): R + 8
+typedef plane<P_VCD::END, TS, R> P_HCD;       // S2 -> the horizontal half of S4 in the same step
+typedef plane<P_HCD::END, TS, 8> P_VCDALT;    // S2 -> S3 down the columns (2 up at lag 6)
 typedef plane<P_VCDALT::END, TS, R> P_HCDALT;
 typedef plane<P_HCDALT::END, TS, R> P_HR0;    // the two candidates of a site of the row chains
 typedef plane<P_HR0::END, TS, R> P_HR1;
-typedef plane<P_HR1::END, TS, R + 7> P_DGV;   // dgintv: S2 -> S4 (2 up)
-typedef plane<P_DGV::END, TS, R + 5> P_DGH;
+typedef plane<P_HR1::END, TS, 16> P_DGV;      // dgintv: S2 -> S4 (2 up): R + 7
+typedef plane<P_DGV::END, TS, R> P_DGH;
 // float planes, one word per R/B site (or per pair of columns)
-typedef plane<P_DGH::END, TSH, R + 5> P_HWT;  // S2 -> S4
-typedef plane<P_HWT::END, TSH, R + 5> P_VWT;
-typedef plane<P_VWT::END, TSH, R + 4> P_CDD;  // cddiffsq at lag 9 -> S5 (2 up)
-typedef plane<P_CDD::END, TSH, R + 18> P_HVWT; // S4 -> the output (1 up at lag 26)
-typedef plane<P_HVWT::END, TSH, R + 13> P_VCDH; // vcd / hcd at the R/B sites, lag 9 -> the curvature refinement at 22
-typedef plane<P_VCDH::END, TSH, R + 13> P_HCDH;
-typedef plane<P_HCDH::END, TSH, R + 6> P_GREEN; // green at the R/B sites, lag 20 -> 26
-typedef plane<P_GREEN::END, TSH, R + 8> P_DGO;  // G - R at R sites, G - B at B sites: lag 20 -> S13 (3 up at 25)
-typedef plane<P_DGO::END, TSH, R + 2> P_DGP;    // the other difference at those sites: S13 -> output (1 up)
-typedef plane<P_DGP::END, TSH, R + 4> P_GH;     // dgrb2
-typedef plane<P_GH::END, TSH, R + 4> P_GV;
-typedef plane<P_GV::END, TSH, R + 4> P_DELP;    // S9 -> R/B estimates (2 up)
-typedef plane<P_DELP::END, TSH, R + 4> P_DELM;
-typedef plane<P_DELM::END, TSH, R + 4> P_DSQP;
-typedef plane<P_DSQP::END, TSH, R + 4> P_DSQM;
+typedef plane<P_DGH::END, TSH, R> P_HWT;      // S2 -> the horizontal half of S4
+typedef plane<P_HWT::END, TSH, 16> P_VWT;     // S2 -> S4: R + 5
+typedef plane<P_VWT::END, TSH, 16> P_HVAR;    // the horizontal variances of S4, formed at lag 4 for lag 9
+typedef plane<P_HVAR::END, TSH, 16> P_HVAR1;
+typedef plane<P_HVAR1::END, TSH, 8> P_CDD;    // cddiffsq at lag 9 -> S5 (2 up)
+typedef plane<P_CDD::END, TSH, 32> P_HVWT;    // S4 -> the output (1 up at lag 26): R + 18
+typedef plane<P_HVWT::END, TSH, 32> P_VCDH;   // vcd / hcd at the R/B sites, lag 9 / 4 -> the curvature refinement at 22
+typedef plane<P_VCDH::END, TSH, 32> P_HCDH;
+typedef plane<P_HCDH::END, TSH, 16> P_GREEN;  // green at the R/B sites, lag 20 -> 26
+typedef plane<P_GREEN::END, TSH, 16> P_DGO;   // G - R at R sites, G - B at B sites: lag 20 -> S13 (3 up at 25): R + 8
+typedef plane<P_DGO::END, TSH, 8> P_DGP;      // the other difference at those sites: S13 -> output (1 up)
+typedef plane<P_DGP::END, TSH, 8> P_GH;       // dgrb2
+typedef plane<P_GH::END, TSH, 8> P_GV;
+typedef plane<P_GV::END, TSH, 8> P_DELP;      // S9 -> R/B estimates (2 up)
+typedef plane<P_DELP::END, TSH, 8> P_DELM;
+typedef plane<P_DELM::END, TSH, 8> P_DSQP;
+typedef plane<P_DSQP::END, TSH, 8> P_DSQM;
 typedef plane<P_DSQM::END, TSH, R + 1> P_RBP;
 typedef plane<P_RBP::END, TSH, R + 1> P_RBM;
 typedef plane<P_RBM::END, TSH, R + 3> P_PMWT;   // lag 19 -> vote at 20 (1 up) -> S11 at 22
-typedef plane<P_PMWT::END, TSH, R + 4> P_RBINT; // lag 20 -> S11 (2 up)
+typedef plane<P_PMWT::END, TSH, 8> P_RBINT;     // lag 20 -> S11 (2 up)
 constexpr int CDD19 = P_RBINT::END; // the 80 floats behind the second flag plane's rows 156..159
 constexpr int FLOATS_END = CDD19 + TSH;
 // byte planes (offsets in bytes)
 typedef plane<FLOATS_END * 4, TS, R> P_HB;      // the two picks of a site of the row chains
-typedef plane<P_HB::END, TSH, R + 4> P_NY;      // S5 -> S6 (2 up)
-typedef plane<P_NY::END, TSH, R + 12> P_NY2;    // S6 -> area weights (6 up at lag 19) -> refinement at 22
+typedef plane<P_HB::END, TSH, 8> P_NY;          // S5 -> S6 (2 up)
+typedef plane<P_NY::END, TSH, 16> P_NY2;        // S6 -> area weights (6 up at lag 19) -> refinement at 22
 constexpr int LDS_BYTES = (P_NY2::END + 15) & ~15;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS of a gfx950 CU");
 
 struct args
 {
@@ -144,6 +151,19 @@ AMZ_FN float clampnan(const float x, const float m, const float M)
   return finite ? x : (x < m ? m : (x > M ? M : x));
 }
 AMZ_FN int fct(const int r, const int c, const uint32_t filters) { return filters >> ((((r << 1) & 14) + (c & 1)) << 1) & 3; }
+
+// (float)((double)a * 2.0 / (double)b), amaze.cc:1150-1190.  A binary64 quotient of two binary32 numbers rounded to binary32 IS
+// the correctly rounded binary32 quotient (53 >= 2 * 24 + 2: the second rounding never meets a tie the first one made), and
+// doubling is exact -- so unless 2 a leaves binary32's range, or the quotient its normal range (where the two roundings act
+// on different grids), one binary32 division gives the same bits
+AMZ_FN float div2_via_double(const float a, const float b)
+{
+  const float a2 = a + a, q = a2 / b;
+  const uint32_t e = f2u(q) & 0x7F800000u, ea = f2u(a2) & 0x7F800000u;
+  // (a quotient of +-0 -- not NaN, so b is neither 0 nor NaN -- comes from a = +-0 and is +-0 either way)
+  if((e != 0u || a2 == 0.f) && e != 0x7F800000u && ea != 0x7F800000u) return q;
+  return (float)((double)a * 2.0 / (double)b);
+}
 
 // the colour-difference variance a site of a chain compares (amaze.cc:590-600)
 AMZ_FN float cdvar3(const float a, const float b, const float c) { return 3.f * (sqr(a) + sqr(b) + sqr(c)) - sqr(a + b + c); }
@@ -208,40 +228,41 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     for(int rr = s * R - (L) + _k / TSH, h = _k % TSH, q = rr >= 0 ? (fct(rr, 2, filters) & 1) : 0, cc = q + 2 * h, _once = 1; \
         _once && rr >= 0 && rr < TS; _once = 0)
 
+// ... all columns, two sites each on the upper half of the threads (for a stage that shares its phase with an R/B stage)
+#define FOR_FULL_UPPER(L)                                     \
+  for(int _k = tid - NT / 2; _k >= 0 && _k < R * TS; _k += NT / 2) \
+    for(int rr = s * R - (L) + _k / TS, cc = _k % TS, _once = 1; _once && rr >= 0 && rr < TS; _once = 0)
+// ... the same on the second half of the threads (for a stage that shares its phase with another R/B stage)
+#define FOR_RB2(L)                                                                                        \
+  for(int _k = tid - NT / 2; _k >= 0 && _k < R * TSH; _k += NT)                                           \
+    for(int rr = s * R - (L) + _k / TSH, h = _k % TSH, q = rr >= 0 ? (fct(rr, 2, filters) & 1) : 0, cc = q + 2 * h, _once = 1; \
+        _once && rr >= 0 && rr < TS; _once = 0)
+
+  static_assert(NT == R * TS, "one photosite of the step's rows per thread");
+  // tile rows from the mosaic, amaze.cc:352-460 (top / left border mirrored; the corner's own rule)
+  auto mosaic = [&](const int rr, const int cc) -> float {
+    if(rr < rrmin && cc < ccmin) return in[(size_t)(32 - rr) * width + (32 - cc)];
+    const int row = rr < rrmin ? 32 - rr + top : rr + top, col = cc < ccmin ? 32 - cc + left : cc + left;
+    return in[(size_t)row * width + col];
+  };
+  float pre = mosaic(tid / TS, tid % TS);
   // the tile starts from zeros, like the reference's buffer in the oracle
   for(int k = tid; k < LDS_BYTES / 4; k += NT) env.zero(k);
   env.sync();
 
   for(int s = 0; s < STEPS; s++)
   {
-    // ---- phase 1: tile rows from the mosaic, amaze.cc:352-460 (top / left border mirrored; the corner's own rule);
-    //      the squared gradients S5 reads, :463-473, from rows loaded long ago
-    FOR_FULL(L_LOAD)
+    // ---- phase 1: the step's tile rows
     {
-      float v;
-      if(rr < rrmin && cc < ccmin)
-        v = in[(size_t)(32 - rr) * width + (32 - cc)];
-      else
-      {
-        const int row = rr < rrmin ? 32 - rr + top : rr + top, col = cc < ccmin ? 32 - cc + left : cc + left;
-        v = in[(size_t)row * width + col];
-      }
-      ST(P_CFA, rr, cc, v);
-    }
-    FOR_FULL(L_S4)
-    {
-      float v = 0.f;
-      if(IN_(rr, 2, TS - 2) && IN_(cc, 2, TS - 2))
-      {
-        const float delh = fabsf(LD(P_CFA, rr, cc + 1) - LD(P_CFA, rr, cc - 1));
-        const float delv = fabsf(LD(P_CFA, rr + 1, cc) - LD(P_CFA, rr - 1, cc));
-        v = sqr(delh) + sqr(delv);
-      }
-      ST(P_DQ, rr, cc, v);
+      // (one photosite per thread and step, fetched a step ahead: the round trip to memory runs under the step before)
+      const int rr = s * R + tid / TS, cc = tid % TS;
+      if(rr < TS) ST(P_CFA, rr, cc, pre);
+      if(rr + R < TS) pre = mosaic(rr + R, cc);
     }
     env.sync();
+    env.stamp(1);
 
-    // ---- phase 2: S1 directional gradients, :463-473; S9 diagonal gradients and squared differences, :958-983
+    // ---- phase 2: S1 directional gradients, :463-473
     FOR_FULL(L_S1)
     {
       float v0 = 0.f, v1 = 0.f;
@@ -256,31 +277,10 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       ST(P_D0, rr, cc, v0);
       ST(P_D1, rr, cc, v1);
     }
-    for(int _k = tid; _k < R * TSH; _k += NT)
-    {
-      const int rr = s * R - L_S9 + _k / TSH, hh = _k % TSH;
-      if(rr < 0 || rr >= TS) continue;
-      float vp = 0.f, vm = 0.f, sp = 0.f, sm = 0.f;
-      const int c2 = 2 * hh; // the even column of the pair
-      if(IN_(rr, 6, TS - 6) && IN_(c2, 6, TS - 6))
-      {
-        const bool odd = fct(rr, 2, filters) & 1;
-        const int ga = odd ? c2 + 1 : c2, sb = odd ? c2 : c2 + 1; // gradients at the green site of the pair, squares at the other
-        vp = fabsf(LD(P_CFA, rr - 1, ga + 1) - LD(P_CFA, rr + 1, ga - 1));
-        vm = fabsf(LD(P_CFA, rr + 1, ga + 1) - LD(P_CFA, rr - 1, ga - 1));
-        const float b = LD(P_CFA, rr, sb);
-        sp = (sqr(b - LD(P_CFA, rr + 1, sb - 1)) + sqr(b - LD(P_CFA, rr - 1, sb + 1)));
-        sm = (sqr(b - LD(P_CFA, rr - 1, sb - 1)) + sqr(b - LD(P_CFA, rr + 1, sb + 1)));
-      }
-      ST(P_DELP, rr, hh, vp);
-      ST(P_DELM, rr, hh, vm);
-      ST(P_DSQP, rr, hh, sp);
-      ST(P_DSQM, rr, hh, sm);
-    }
     env.sync();
+    env.stamp(2);
 
-    // ---- phase 3: S2 colour differences by adaptive ratios and by Hamilton-Adams, :478-582;
-    //      diagonal R/B estimates, :986-1107
+    // ---- phase 3: S2 colour differences by adaptive ratios and by Hamilton-Adams, :478-582
     FOR_FULL(L_S2)
     {
       float v = 0.f, hd = 0.f, va = 0.f, ha = 0.f, gv = 0.f, gh = 0.f;
@@ -346,7 +346,236 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       ST(P_DGV, rr, cc, gv);
       ST(P_DGH, rr, cc, gh);
     }
-    FOR_RB(L_RB)
+    env.sync();
+    env.stamp(3);
+
+    // ---- phase 4: S3 (:585-705) down the columns -- a lane of the lower half of the threads per column and row parity, its two rows of
+    //      the step in order -- and, on the upper half, the two candidates of every site of the row chains (two sites each)
+    for(int _k = tid; _k < 2 * TS; _k += NT)
+    {
+      const int cc = _k % TS, par = _k / TS;
+      if(!IN_(cc, 4, TS - 4)) continue;
+      for(int j = 0; j < R / 2; j++)
+      {
+        const int rr = s * R - L_S3V + par + 2 * j;
+        if(!IN_(rr, 4, TS - 4)) continue;
+        const bool gsite = fct(rr, cc, filters) & 1;
+        const float prev = LD(P_VCD, rr - 2, cc), c0 = LD(P_VCD, rr, cc), c1 = LD(P_VCD, rr + 2, cc);
+        const float a0 = LD(P_VCDALT, rr - 2, cc), a1 = LD(P_VCDALT, rr, cc), a2 = LD(P_VCDALT, rr + 2, cc);
+        const float hpick = cdvar3(a0, a1, a2) < cdvar3(prev, c0, c1) ? a1 : c0;
+        ST(P_VCD, rr, cc, chain_bound(hpick, LD(P_CFA, rr - 1, cc), LD(P_CFA, rr, cc), LD(P_CFA, rr + 1, cc), gsite, clip_pt));
+      }
+    }
+    FOR_FULL_UPPER(L_S2)
+    {
+      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      {
+        const bool gsite = fct(rr, cc, filters) & 1;
+        const float before = LD(P_CFA, rr, cc - 1), here = LD(P_CFA, rr, cc), after = LD(P_CFA, rr, cc + 1);
+        ST(P_HR0, rr, cc, chain_bound(LD(P_HCD, rr, cc), before, here, after, gsite, clip_pt));
+        ST(P_HR1, rr, cc, chain_bound(LD(P_HCDALT, rr, cc), before, here, after, gsite, clip_pt));
+      }
+    }
+    env.sync();
+    env.stamp(4);
+
+    // ---- phase 5: S4 the H/V weight from colour-difference variances, :707-760: what a site reads down its column (what it reads along
+    //      its row was formed five rows ago, below), with it the squared difference of the two estimates at the R/B sites, :703.
+    //      Upper half: which candidate a site of the row chains picks, for either candidate of its neighbour two columns back
+    FOR_RB(L_S4)
+    {
+      const float v0 = LD(P_VCD, rr, cc), h0 = LD(P_HCDH, rr, h);
+      const float cd = (IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4)) ? sqr(v0 - h0) : 0.f;
+      ST(P_CDD, rr, h, cd);
+      ST(P_VCDH, rr, h, v0);
+      if(rr == 19 && cc >= TSH) env.stf(CDD19 + cc - TSH, -1, cd);
+      float w = 0.f;
+      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
+      {
+        const float v1 = LD(P_VCD, rr - 1, cc), v2 = LD(P_VCD, rr - 2, cc), v3 = LD(P_VCD, rr - 3, cc);
+        const float w1 = LD(P_VCD, rr + 1, cc), w2 = LD(P_VCD, rr + 2, cc), w3 = LD(P_VCD, rr + 3, cc);
+        const float uave = v0 + v1 + v2 + v3;
+        const float dave = v0 + w1 + w2 + w3;
+        float vu = sqr(v0 - uave) + sqr(v1 - uave) + sqr(v2 - uave) + sqr(v3 - uave);
+        float vd = sqr(v0 - dave) + sqr(w1 - dave) + sqr(w2 - dave) + sqr(w3 - dave);
+        const float vwt = LD(P_VWT, rr, h);
+        const float vcdvar = EPSSQ + vwt * vd + (1.f - vwt) * vu;
+        const float hcdvar = LD(P_HVAR, rr, h);
+        const float g0 = LD(P_DGV, rr, cc);
+        vu = (g0) + (LD(P_DGV, rr - 1, cc)) + (LD(P_DGV, rr - 2, cc));
+        vd = (g0) + (LD(P_DGV, rr + 1, cc)) + (LD(P_DGV, rr + 2, cc));
+        const float vcdvar1 = EPSSQ + vwt * vd + (1.f - vwt) * vu;
+        const float hcdvar1 = LD(P_HVAR1, rr, h);
+        const float varwt = hcdvar / (vcdvar + hcdvar);
+        const float diffwt = hcdvar1 / (vcdvar1 + hcdvar1);
+        // the reference forms (0.5 - varwt) * (0.5 - diffwt) in binary64 (0.5 is a double literal there) and asks for > 0:
+        // either factor is 0 or at least 2^-25 in size, the product cannot underflow -- both below 0.5 or both above
+        if(((varwt < 0.5f && diffwt < 0.5f) || (varwt > 0.5f && diffwt > 0.5f)) && fabsf(0.5f - diffwt) < fabsf(0.5f - varwt))
+          w = varwt;
+        else
+          w = diffwt;
+      }
+      ST(P_HVWT, rr, h, w);
+    }
+    FOR_FULL_UPPER(L_S2)
+    {
+      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      {
+        const float c0 = LD(P_HCD, rr, cc), c1 = LD(P_HCD, rr, cc + 2);
+        const float altvar = cdvar3(LD(P_HCDALT, rr, cc - 2), LD(P_HCDALT, rr, cc), LD(P_HCDALT, rr, cc + 2));
+        float p0, p1;
+        if(cc - 2 >= 4)
+        {
+          p0 = LD(P_HR0, rr, cc - 2);
+          p1 = LD(P_HR1, rr, cc - 2);
+        }
+        else
+          p0 = p1 = LD(P_HCD, rr, cc - 2); // in front of the first site of the chain: never written
+        const unsigned bits = (altvar < cdvar3(p0, c0, c1) ? 1u : 0u) | (altvar < cdvar3(p1, c0, c1) ? 2u : 0u);
+        STB(P_HB, rr, cc, (unsigned char)bits);
+      }
+    }
+    env.sync();
+    env.stamp(5);
+
+    // ---- phase 6: S5 Nyquist texture test, :763-820.  Upper half: the pick of a site of the row chains: back to the nearest site that
+    //      picks the same whatever came before it (0 or 3), inverted once per site on the way whose pick is the opposite of its
+    //      neighbour's (1; 2 copies it)
+    FOR_RB(L_S5)
+    {
+      unsigned char flag = 0;
+      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
+      {
+        const float gg0 = 0.5f * 0.07384411893421103f, gg1 = 0.5f * 0.06207511968171489f, gg2 = 0.5f * 0.0521818194747806f;
+        const float gg3 = 0.5f * 0.03687419286733595f, gg4 = 0.5f * 0.03099732204057846f, gg5 = 0.5f * 0.018413194161458882f;
+        const float go0 = 0.14659727707323927f, go1 = 0.103592713382435f, go2 = 0.0732036125103057f, go3 = 0.0365543548389495f;
+#define CD(dr, dc) LD(P_CDD, rr + (dr), (cc + (dc)) >> 1)
+#define DQ(dr, dc) LD(P_DQ, rr + (dr), cc + (dc))
+        const float test
+            = (go0 * CD(0, 0) + go1 * (CD(-1, -1) + CD(-1, 1) + CD(1, -1) + CD(1, 1))
+               + go2 * (CD(-2, 0) + CD(0, -2) + CD(0, 2) + CD(2, 0)) + go3 * (CD(-2, -2) + CD(-2, 2) + CD(2, -2) + CD(2, 2)))
+              - (gg0 * DQ(0, 0) + gg1 * (DQ(-1, 0) + DQ(0, 1) + DQ(0, -1) + DQ(1, 0))
+                 + gg2 * (DQ(-1, -1) + DQ(-1, 1) + DQ(1, -1) + DQ(1, 1))
+                 + gg3 * (DQ(-2, 0) + DQ(0, -2) + DQ(0, 2) + DQ(2, 0))
+                 + gg4 * (DQ(-2, -1) + DQ(-2, 1) + DQ(-1, -2) + DQ(-1, 2) + DQ(1, -2) + DQ(1, 2) + DQ(2, -1) + DQ(2, 1))
+                 + gg5 * (DQ(-2, -2) + DQ(-2, 2) + DQ(2, -2) + DQ(2, 2)));
+#undef CD
+#undef DQ
+        flag = test > 0.f ? 1 : 0;
+      }
+      STB(P_NY, rr, h, flag);
+    }
+    FOR_FULL_UPPER(L_S2)
+    {
+      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      {
+        unsigned inv = 0, bits;
+        for(int j = cc;; j -= 2)
+        {
+          bits = LDB(P_HB, rr, j);
+          if(bits == 0u || bits == 3u) break;
+          inv ^= (bits == 1u) ? 1u : 0u;
+        }
+        const unsigned pick = (bits & 1u) ^ inv;
+        ST(P_HCD, rr, cc, pick ? LD(P_HR1, rr, cc) : LD(P_HR0, rr, cc));
+      }
+    }
+    env.sync();
+    env.stamp(6);
+
+    // ---- phase 7: S6 majority vote on the flags, :832-845 (rows 156..159 of the second flag plane are bytes of the squared colour
+    //      differences of row 19, see the header); S9 diagonal gradients and squared differences, :958-983.  Upper half: the
+    //      half of S4 that reads along the row, on the rows whose chains phase 6 just resolved
+    FOR_RB(L_S6)
+    {
+      unsigned char f2 = 0;
+      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
+      {
+#define NY(dr, dc) LDB(P_NY, rr + (dr), (cc + (dc)) >> 1)
+        const unsigned n = NY(-2, 0) + NY(-1, -1) + NY(-1, 1) + NY(0, -2) + NY(0, 2) + NY(1, -1) + NY(1, 1) + NY(2, 0);
+        f2 = n > 4 ? 1 : (n < 4 ? 0 : NY(0, 0));
+#undef NY
+      }
+      else if(rr >= TS - 4)
+        f2 = (unsigned char)(f2u(env.ldf(CDD19 + (rr - (TS - 4)) * 20 + (h >> 2), -1)) >> (8 * (h & 3)));
+      STB(P_NY2, rr, h, f2);
+    }
+    for(int _k = tid; _k < R * TSH; _k += NT)
+    {
+      const int rr = s * R - L_S9 + _k / TSH, hh = _k % TSH;
+      if(rr < 0 || rr >= TS) continue;
+      float vp = 0.f, vm = 0.f, sp = 0.f, sm = 0.f;
+      const int c2 = 2 * hh; // the even column of the pair
+      if(IN_(rr, 6, TS - 6) && IN_(c2, 6, TS - 6))
+      {
+        const bool odd = fct(rr, 2, filters) & 1;
+        const int ga = odd ? c2 + 1 : c2, sb = odd ? c2 : c2 + 1; // gradients at the green site of the pair, squares at the other
+        vp = fabsf(LD(P_CFA, rr - 1, ga + 1) - LD(P_CFA, rr + 1, ga - 1));
+        vm = fabsf(LD(P_CFA, rr + 1, ga + 1) - LD(P_CFA, rr - 1, ga - 1));
+        const float b = LD(P_CFA, rr, sb);
+        sp = (sqr(b - LD(P_CFA, rr + 1, sb - 1)) + sqr(b - LD(P_CFA, rr - 1, sb + 1)));
+        sm = (sqr(b - LD(P_CFA, rr - 1, sb - 1)) + sqr(b - LD(P_CFA, rr + 1, sb + 1)));
+      }
+      ST(P_DELP, rr, hh, vp);
+      ST(P_DELM, rr, hh, vm);
+      ST(P_DSQP, rr, hh, sp);
+      ST(P_DSQM, rr, hh, sm);
+    }
+    for(int _k = tid - NT / 2; _k >= 0 && _k < R * TSH; _k += NT)
+    {
+      const int rr = s * R - L_S2 + _k / TSH, h = _k % TSH;
+      if(rr < 0 || rr >= TS) continue;
+      const int cc = (fct(rr, 2, filters) & 1) + 2 * h;
+      const float h0 = LD(P_HCD, rr, cc);
+      ST(P_HCDH, rr, h, h0);
+      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
+      {
+        const float l1 = LD(P_HCD, rr, cc - 1), l2 = LD(P_HCD, rr, cc - 2), l3 = LD(P_HCD, rr, cc - 3);
+        const float r1 = LD(P_HCD, rr, cc + 1), r2 = LD(P_HCD, rr, cc + 2), r3 = LD(P_HCD, rr, cc + 3);
+        const float lave = h0 + l1 + l2 + l3;
+        const float rave = h0 + r1 + r2 + r3;
+        float hl = sqr(h0 - lave) + sqr(l1 - lave) + sqr(l2 - lave) + sqr(l3 - lave);
+        float hr = sqr(h0 - rave) + sqr(r1 - rave) + sqr(r2 - rave) + sqr(r3 - rave);
+        const float hwt = LD(P_HWT, rr, h);
+        ST(P_HVAR, rr, h, EPSSQ + hwt * hr + (1.f - hwt) * hl);
+        const float e0 = LD(P_DGH, rr, cc);
+        hl = (e0) + (LD(P_DGH, rr, cc - 1)) + (LD(P_DGH, rr, cc - 2));
+        hr = (e0) + (LD(P_DGH, rr, cc + 1)) + (LD(P_DGH, rr, cc + 2));
+        ST(P_HVAR1, rr, h, EPSSQ + hwt * hr + (1.f - hwt) * hl);
+      }
+    }
+    env.sync();
+    env.stamp(7);
+
+    // ---- phase 8: area interpolation of the weight in flagged regions, :850-890.  Upper half: diagonal R/B estimates, :986-1107
+    FOR_RB(L_INT)
+    {
+      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8) && LDB(P_NY2, rr, h))
+      {
+        float sumcfa = 0.f, sumh = 0.f, sumv = 0.f, sumsqh = 0.f, sumsqv = 0.f, areawt = 0.f;
+        for(int p = -6; p < 7; p += 2)
+          for(int qq = -6; qq < 7; qq += 2)
+            if(LDB(P_NY2, rr + p, (cc + qq) >> 1))
+            {
+              const float c = LD(P_CFA, rr + p, cc + qq);
+              const float l = LD(P_CFA, rr + p, cc + qq - 1), r = LD(P_CFA, rr + p, cc + qq + 1);
+              const float u = LD(P_CFA, rr + p - 1, cc + qq), d = LD(P_CFA, rr + p + 1, cc + qq);
+              sumcfa += c;
+              sumh += (l + r);
+              sumv += (u + d);
+              sumsqh += sqr(c - l) + sqr(c - r);
+              sumsqv += sqr(c - u) + sqr(c - d);
+              areawt += 1;
+            }
+        sumh = sumcfa - xdiv2f(sumh);
+        sumv = sumcfa - xdiv2f(sumv);
+        areawt = xdiv2f(areawt);
+        const float hcdvar = EPSSQ + fabsf(areawt * sumsqh - sumh * sumh);
+        const float vcdvar = EPSSQ + fabsf(areawt * sumsqv - sumv * sumv);
+        ST(P_HVWT, rr, h, hcdvar / (vcdvar + hcdvar));
+      }
+    }
+    FOR_RB2(L_RB)
     {
       float pw = 0.f, vp = 0.f, vm = 0.f;
       if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
@@ -409,246 +638,91 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       ST(P_RBM, rr, h, vm);
     }
     env.sync();
+    env.stamp(8);
 
-    // ---- phase 4: S3 (:585-705) down the columns -- a lane per column and row parity, its two rows of the step in
-    //      order -- and the two candidates of every site of the row chains
-    for(int _k = tid; _k < 2 * TS; _k += NT)
+    // ---- phase 9: the two votes, in place, row r sees row r-1 voted (:894-905, :1109-1126): ONE wave each walks its R rows in order (a
+    //      wave's LDS accesses execute in order), two sites per lane, no workgroup barrier in between; behind the second vote
+    //      R + B of the site (:1123).  The other waves meanwhile form the squared gradients S5 reads in the next step, :463-473
+    if(tid < 64)
     {
-      const int cc = _k % TS, par = _k / TS;
-      if(!IN_(cc, 4, TS - 4)) continue;
-      for(int j = 0; j < R / 2; j++)
+      for(int j = 0; j < R; j++)
       {
-        const int rr = s * R - L_S3V + par + 2 * j;
-        if(!IN_(rr, 4, TS - 4)) continue;
-        const bool gsite = fct(rr, cc, filters) & 1;
-        const float prev = LD(P_VCD, rr - 2, cc), c0 = LD(P_VCD, rr, cc), c1 = LD(P_VCD, rr + 2, cc);
-        const float a0 = LD(P_VCDALT, rr - 2, cc), a1 = LD(P_VCDALT, rr, cc), a2 = LD(P_VCDALT, rr + 2, cc);
-        const float hpick = cdvar3(a0, a1, a2) < cdvar3(prev, c0, c1) ? a1 : c0;
-        ST(P_VCD, rr, cc, chain_bound(hpick, LD(P_CFA, rr - 1, cc), LD(P_CFA, rr, cc), LD(P_CFA, rr + 1, cc), gsite, clip_pt));
-      }
-    }
-    FOR_FULL(L_S2)
-    {
-      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
-      {
-        const bool gsite = fct(rr, cc, filters) & 1;
-        const float before = LD(P_CFA, rr, cc - 1), here = LD(P_CFA, rr, cc), after = LD(P_CFA, rr, cc + 1);
-        ST(P_HR0, rr, cc, chain_bound(LD(P_HCD, rr, cc), before, here, after, gsite, clip_pt));
-        ST(P_HR1, rr, cc, chain_bound(LD(P_HCDALT, rr, cc), before, here, after, gsite, clip_pt));
-      }
-    }
-    env.sync();
-
-    // ---- phase 5: which candidate a site picks, for either candidate of its neighbour two columns back
-    FOR_FULL(L_S2)
-    {
-      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
-      {
-        const float c0 = LD(P_HCD, rr, cc), c1 = LD(P_HCD, rr, cc + 2);
-        const float altvar = cdvar3(LD(P_HCDALT, rr, cc - 2), LD(P_HCDALT, rr, cc), LD(P_HCDALT, rr, cc + 2));
-        float p0, p1;
-        if(cc - 2 >= 4)
+        const int rr = s * R - L_VOTE + j;
+        if(IN_(rr, 8, TS - 8) && tid < TSH / 2)
         {
-          p0 = LD(P_HR0, rr, cc - 2);
-          p1 = LD(P_HR1, rr, cc - 2);
+          // two sites per lane, everything fetched before anything is stored: one LDS round trip per row
+          const int q = fct(rr, 2, filters) & 1, ha = 2 * tid, hb = ha + 1, ca = q + 2 * ha, cb = ca + 2;
+          const int hl = ca > 0 ? (ca - 1) >> 1 : 0, hr = cb + 1 < TS ? (cb + 1) >> 1 : TSH - 1; // (clamped for the lanes at the rim, which store nothing)
+          const float a0 = LD(P_HVWT, rr - 1, hl), a1 = LD(P_HVWT, rr - 1, (ca + 1) >> 1), a2 = LD(P_HVWT, rr - 1, hr);
+          const float b0 = LD(P_HVWT, rr + 1, hl), b1 = LD(P_HVWT, rr + 1, (ca + 1) >> 1), b2 = LD(P_HVWT, rr + 1, hr);
+          const float wa = LD(P_HVWT, rr, ha), wb = LD(P_HVWT, rr, hb);
+          const float alta = xdivf(a0 + a1 + b0 + b1, 2), altb = xdivf(a1 + a2 + b1 + b2, 2);
+          if(IN_(ca, 8, TS - 8)) ST(P_HVWT, rr, ha, fabsf(0.5f - wa) < fabsf(0.5f - alta) ? alta : wa);
+          if(IN_(cb, 8, TS - 8)) ST(P_HVWT, rr, hb, fabsf(0.5f - wb) < fabsf(0.5f - altb) ? altb : wb);
         }
-        else
-          p0 = p1 = LD(P_HCD, rr, cc - 2); // in front of the first site of the chain: never written
-        const unsigned bits = (altvar < cdvar3(p0, c0, c1) ? 1u : 0u) | (altvar < cdvar3(p1, c0, c1) ? 2u : 0u);
-        STB(P_HB, rr, cc, (unsigned char)bits);
+        env.wave_sync();
       }
     }
-    env.sync();
-
-    // ---- phase 6: the pick of a site: back to the nearest site that picks the same whatever came before it (0 or 3),
-    //      inverted once per site on the way whose pick is the opposite of its neighbour's (1; 2 copies it)
-    FOR_FULL(L_S2)
+    else if(tid >= 128 && tid < 192)
     {
-      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      for(int j = 0; j < R; j++)
       {
-        unsigned inv = 0, bits;
-        for(int j = cc;; j -= 2)
+        const int rr = s * R - L_RBI + j, lane = tid - 128;
+        if(rr >= 0 && rr < TS && lane < TSH / 2)
         {
-          bits = LDB(P_HB, rr, j);
-          if(bits == 0u || bits == 3u) break;
-          inv ^= (bits == 1u) ? 1u : 0u;
-        }
-        const unsigned pick = (bits & 1u) ^ inv;
-        ST(P_HCD, rr, cc, pick ? LD(P_HR1, rr, cc) : LD(P_HR0, rr, cc));
-      }
-    }
-    env.sync();
-
-    // ---- phase 7: squared difference of the two estimates at the R/B sites (:703) and the estimates themselves for the
-    //      stages far behind; S4 the H/V weight from colour-difference variances, :707-760
-    FOR_RB(L_S4)
-    {
-      const float v0 = LD(P_VCD, rr, cc), h0 = LD(P_HCD, rr, cc);
-      const float cd = (IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4)) ? sqr(v0 - h0) : 0.f;
-      ST(P_CDD, rr, h, cd);
-      ST(P_VCDH, rr, h, v0);
-      ST(P_HCDH, rr, h, h0);
-      if(rr == 19 && cc >= TSH) env.stf(CDD19 + cc - TSH, -1, cd);
-      float w = 0.f;
-      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
-      {
-        const float v1 = LD(P_VCD, rr - 1, cc), v2 = LD(P_VCD, rr - 2, cc), v3 = LD(P_VCD, rr - 3, cc);
-        const float w1 = LD(P_VCD, rr + 1, cc), w2 = LD(P_VCD, rr + 2, cc), w3 = LD(P_VCD, rr + 3, cc);
-        const float l1 = LD(P_HCD, rr, cc - 1), l2 = LD(P_HCD, rr, cc - 2), l3 = LD(P_HCD, rr, cc - 3);
-        const float r1 = LD(P_HCD, rr, cc + 1), r2 = LD(P_HCD, rr, cc + 2), r3 = LD(P_HCD, rr, cc + 3);
-        const float uave = v0 + v1 + v2 + v3;
-        const float dave = v0 + w1 + w2 + w3;
-        const float lave = h0 + l1 + l2 + l3;
-        const float rave = h0 + r1 + r2 + r3;
-        float vu = sqr(v0 - uave) + sqr(v1 - uave) + sqr(v2 - uave) + sqr(v3 - uave);
-        float vd = sqr(v0 - dave) + sqr(w1 - dave) + sqr(w2 - dave) + sqr(w3 - dave);
-        float hl = sqr(h0 - lave) + sqr(l1 - lave) + sqr(l2 - lave) + sqr(l3 - lave);
-        float hr = sqr(h0 - rave) + sqr(r1 - rave) + sqr(r2 - rave) + sqr(r3 - rave);
-        const float hwt = LD(P_HWT, rr, h);
-        const float vwt = LD(P_VWT, rr, h);
-        const float vcdvar = EPSSQ + vwt * vd + (1.f - vwt) * vu;
-        const float hcdvar = EPSSQ + hwt * hr + (1.f - hwt) * hl;
-        const float g0 = LD(P_DGV, rr, cc), e0 = LD(P_DGH, rr, cc);
-        vu = (g0) + (LD(P_DGV, rr - 1, cc)) + (LD(P_DGV, rr - 2, cc));
-        vd = (g0) + (LD(P_DGV, rr + 1, cc)) + (LD(P_DGV, rr + 2, cc));
-        hl = (e0) + (LD(P_DGH, rr, cc - 1)) + (LD(P_DGH, rr, cc - 2));
-        hr = (e0) + (LD(P_DGH, rr, cc + 1)) + (LD(P_DGH, rr, cc + 2));
-        const float vcdvar1 = EPSSQ + vwt * vd + (1.f - vwt) * vu;
-        const float hcdvar1 = EPSSQ + hwt * hr + (1.f - hwt) * hl;
-        const float varwt = hcdvar / (vcdvar + hcdvar);
-        const float diffwt = hcdvar1 / (vcdvar1 + hcdvar1);
-        // the product is formed in binary64 in the reference (0.5 is a double literal there)
-        if((0.5 - (double)varwt) * (0.5 - (double)diffwt) > 0 && fabsf(0.5f - diffwt) < fabsf(0.5f - varwt))
-          w = varwt;
-        else
-          w = diffwt;
-      }
-      ST(P_HVWT, rr, h, w);
-    }
-    env.sync();
-
-    // ---- phase 8: S5 Nyquist texture test, :763-820
-    FOR_RB(L_S5)
-    {
-      unsigned char flag = 0;
-      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
-      {
-        const float gg0 = 0.5f * 0.07384411893421103f, gg1 = 0.5f * 0.06207511968171489f, gg2 = 0.5f * 0.0521818194747806f;
-        const float gg3 = 0.5f * 0.03687419286733595f, gg4 = 0.5f * 0.03099732204057846f, gg5 = 0.5f * 0.018413194161458882f;
-        const float go0 = 0.14659727707323927f, go1 = 0.103592713382435f, go2 = 0.0732036125103057f, go3 = 0.0365543548389495f;
-#define CD(dr, dc) LD(P_CDD, rr + (dr), (cc + (dc)) >> 1)
-#define DQ(dr, dc) LD(P_DQ, rr + (dr), cc + (dc))
-        const float test
-            = (go0 * CD(0, 0) + go1 * (CD(-1, -1) + CD(-1, 1) + CD(1, -1) + CD(1, 1))
-               + go2 * (CD(-2, 0) + CD(0, -2) + CD(0, 2) + CD(2, 0)) + go3 * (CD(-2, -2) + CD(-2, 2) + CD(2, -2) + CD(2, 2)))
-              - (gg0 * DQ(0, 0) + gg1 * (DQ(-1, 0) + DQ(0, 1) + DQ(0, -1) + DQ(1, 0))
-                 + gg2 * (DQ(-1, -1) + DQ(-1, 1) + DQ(1, -1) + DQ(1, 1))
-                 + gg3 * (DQ(-2, 0) + DQ(0, -2) + DQ(0, 2) + DQ(2, 0))
-                 + gg4 * (DQ(-2, -1) + DQ(-2, 1) + DQ(-1, -2) + DQ(-1, 2) + DQ(1, -2) + DQ(1, 2) + DQ(2, -1) + DQ(2, 1))
-                 + gg5 * (DQ(-2, -2) + DQ(-2, 2) + DQ(2, -2) + DQ(2, 2)));
-#undef CD
-#undef DQ
-        flag = test > 0.f ? 1 : 0;
-      }
-      STB(P_NY, rr, h, flag);
-    }
-    env.sync();
-
-    // ---- phase 9: S6 majority vote on the flags, :832-845.  Rows 156..159 of the second flag plane are bytes of the
-    //      squared colour differences of row 19 (see the header)
-    FOR_RB(L_S6)
-    {
-      unsigned char f2 = 0;
-      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
-      {
-#define NY(dr, dc) LDB(P_NY, rr + (dr), (cc + (dc)) >> 1)
-        const unsigned n = NY(-2, 0) + NY(-1, -1) + NY(-1, 1) + NY(0, -2) + NY(0, 2) + NY(1, -1) + NY(1, 1) + NY(2, 0);
-        f2 = n > 4 ? 1 : (n < 4 ? 0 : NY(0, 0));
-#undef NY
-      }
-      else if(rr >= TS - 4)
-        f2 = (unsigned char)(f2u(env.ldf(CDD19 + (rr - (TS - 4)) * 20 + (h >> 2), -1)) >> (8 * (h & 3)));
-      STB(P_NY2, rr, h, f2);
-    }
-    env.sync();
-
-    // ---- phase 10: area interpolation of the weight in flagged regions, :850-890
-    FOR_RB(L_INT)
-    {
-      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8) && LDB(P_NY2, rr, h))
-      {
-        float sumcfa = 0.f, sumh = 0.f, sumv = 0.f, sumsqh = 0.f, sumsqv = 0.f, areawt = 0.f;
-        for(int p = -6; p < 7; p += 2)
-          for(int qq = -6; qq < 7; qq += 2)
-            if(LDB(P_NY2, rr + p, (cc + qq) >> 1))
-            {
-              const float c = LD(P_CFA, rr + p, cc + qq);
-              const float l = LD(P_CFA, rr + p, cc + qq - 1), r = LD(P_CFA, rr + p, cc + qq + 1);
-              const float u = LD(P_CFA, rr + p - 1, cc + qq), d = LD(P_CFA, rr + p + 1, cc + qq);
-              sumcfa += c;
-              sumh += (l + r);
-              sumv += (u + d);
-              sumsqh += sqr(c - l) + sqr(c - r);
-              sumsqv += sqr(c - u) + sqr(c - d);
-              areawt += 1;
-            }
-        sumh = sumcfa - xdiv2f(sumh);
-        sumv = sumcfa - xdiv2f(sumv);
-        areawt = xdiv2f(areawt);
-        const float hcdvar = EPSSQ + fabsf(areawt * sumsqh - sumh * sumh);
-        const float vcdvar = EPSSQ + fabsf(areawt * sumsqv - sumv * sumv);
-        ST(P_HVWT, rr, h, hcdvar / (vcdvar + hcdvar));
-      }
-    }
-    env.sync();
-
-    // ---- phases 11..14: the two votes, in place, one row per sub-phase: row r sees row r-1 voted (:894-905, :1109-1126);
-    //      behind the second one R + B of the site (:1123)
-    for(int j = 0; j < R; j++)
-    {
-      if(tid < TSH)
-      {
-        const int rr = s * R - L_VOTE + j, h = tid;
-        if(IN_(rr, 8, TS - 8))
-        {
-          const int cc = (fct(rr, 2, filters) & 1) + 2 * h;
-          if(IN_(cc, 8, TS - 8))
+          const int q = fct(rr, 2, filters) & 1, ha = 2 * lane, hb = ha + 1, ca = q + 2 * ha, cb = ca + 2;
+          const int hl = ca > 0 ? (ca - 1) >> 1 : 0, hr = cb + 1 < TS ? (cb + 1) >> 1 : TSH - 1;
+          float rba = 0.f, rbb = 0.f;
+          if(IN_(rr, 10, TS - 10))
           {
-            const float alt = xdivf(LD(P_HVWT, rr - 1, (cc - 1) >> 1) + LD(P_HVWT, rr - 1, (cc + 1) >> 1)
-                                        + LD(P_HVWT, rr + 1, (cc - 1) >> 1) + LD(P_HVWT, rr + 1, (cc + 1) >> 1),
-                                    2);
-            const float w = LD(P_HVWT, rr, h);
-            ST(P_HVWT, rr, h, fabsf(0.5f - w) < fabsf(0.5f - alt) ? alt : w);
-          }
-        }
-      }
-      else if(tid >= 128 && tid < 128 + TSH)
-      {
-        const int rr = s * R - L_RBI + j, h = tid - 128;
-        if(rr >= 0 && rr < TS)
-        {
-          const int cc = (fct(rr, 2, filters) & 1) + 2 * h;
-          float rb = 0.f;
-          if(IN_(rr, 10, TS - 10) && IN_(cc, 10, TS - 10))
-          {
-            const float alt = xdivf(LD(P_PMWT, rr - 1, (cc - 1) >> 1) + LD(P_PMWT, rr - 1, (cc + 1) >> 1)
-                                        + LD(P_PMWT, rr + 1, (cc - 1) >> 1) + LD(P_PMWT, rr + 1, (cc + 1) >> 1),
-                                    2);
-            float w = LD(P_PMWT, rr, h);
-            if(fabsf(0.5f - w) < fabsf(0.5f - alt))
+            const float a0 = LD(P_PMWT, rr - 1, hl), a1 = LD(P_PMWT, rr - 1, (ca + 1) >> 1), a2 = LD(P_PMWT, rr - 1, hr);
+            const float b0 = LD(P_PMWT, rr + 1, hl), b1 = LD(P_PMWT, rr + 1, (ca + 1) >> 1), b2 = LD(P_PMWT, rr + 1, hr);
+            float wa = LD(P_PMWT, rr, ha), wb = LD(P_PMWT, rr, hb);
+            const float ma = LD(P_RBM, rr, ha), pa = LD(P_RBP, rr, ha), mb = LD(P_RBM, rr, hb), pb = LD(P_RBP, rr, hb);
+            const float fa = LD(P_CFA, rr, ca), fb = LD(P_CFA, rr, cb);
+            const float alta = xdivf(a0 + a1 + b0 + b1, 2), altb = xdivf(a1 + a2 + b1 + b2, 2);
+            if(IN_(ca, 10, TS - 10))
             {
-              w = alt;
-              ST(P_PMWT, rr, h, w);
+              if(fabsf(0.5f - wa) < fabsf(0.5f - alta))
+              {
+                wa = alta;
+                ST(P_PMWT, rr, ha, wa);
+              }
+              rba = xdiv2f(fa + ma * (1.f - wa) + pa * wa);
             }
-            rb = xdiv2f(LD(P_CFA, rr, cc) + LD(P_RBM, rr, h) * (1.f - w) + LD(P_RBP, rr, h) * w);
+            if(IN_(cb, 10, TS - 10))
+            {
+              if(fabsf(0.5f - wb) < fabsf(0.5f - altb))
+              {
+                wb = altb;
+                ST(P_PMWT, rr, hb, wb);
+              }
+              rbb = xdiv2f(fb + mb * (1.f - wb) + pb * wb);
+            }
           }
-          ST(P_RBINT, rr, h, rb);
+          ST(P_RBINT, rr, ha, rba);
+          ST(P_RBINT, rr, hb, rbb);
         }
+        env.wave_sync();
       }
-      env.sync();
     }
+    // (the waves that do not vote share the gradients' 640 sites)
+    for(int w = tid >= 192 ? tid - 128 : (tid >= 64 && tid < 128 ? tid - 64 : -1), _k = w; w >= 0 && _k < R * TS; _k += NT - 128)
+      for(int rr = s * R - L_DQ + _k / TS, cc = _k % TS, _once = 1; _once && rr >= 0 && rr < TS; _once = 0)
+    {
+      float v = 0.f;
+      if(IN_(rr, 2, TS - 2) && IN_(cc, 2, TS - 2))
+      {
+        const float delh = fabsf(LD(P_CFA, rr, cc + 1) - LD(P_CFA, rr, cc - 1));
+        const float delv = fabsf(LD(P_CFA, rr + 1, cc) - LD(P_CFA, rr - 1, cc));
+        v = sqr(delh) + sqr(delv);
+      }
+      ST(P_DQ, rr, cc, v);
+    }
+    env.sync();
+    env.stamp(9);
 
-    // ---- phase 15: green at the R/B sites and its curvature, :907-917
+    // ---- phase 10: green at the R/B sites and its curvature, :907-917
     FOR_RB(L_VOTE)
     {
       const float c = LD(P_CFA, rr, cc);
@@ -669,9 +743,10 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       ST(P_GV, rr, h, cv);
     }
     env.sync();
+    env.stamp(10);
 
-    // ---- phase 16: S8 refine flagged regions with the curvature of green, :923-956; then S11 where the diagonal
-    //      estimate discriminates better, green from R + B, :1129-1236 (it overrides S8 at a site that takes both)
+    // ---- phase 11: S8 refine flagged regions with the curvature of green, :923-956; then S11 where the diagonal estimate discriminates
+    //      better, green from R + B, :1129-1236 (it overrides S8 at a site that takes both)
     FOR_RB(L_S8)
     {
       if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8) && LDB(P_NY2, rr, h))
@@ -697,11 +772,11 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
           const float cu = LD(P_CFA, rr - 1, cc), cd = LD(P_CFA, rr + 1, cc), cl = LD(P_CFA, rr, cc - 1), cr = LD(P_CFA, rr, cc + 1);
           const float rb = LD(P_RBINT, rr, h);
           const float rbu = LD(P_RBINT, rr - 2, h), rbd = LD(P_RBINT, rr + 2, h), rbl = LD(P_RBINT, rr, h - 1), rbr = LD(P_RBINT, rr, h + 1);
-          // binary64 where the reference has double literals
-          const float cru = (float)((double)cu * 2.0 / (double)(EPS + rb + rbu));
-          const float crd = (float)((double)cd * 2.0 / (double)(EPS + rb + rbd));
-          const float crl = (float)((double)cl * 2.0 / (double)(EPS + rb + rbl));
-          const float crr = (float)((double)cr * 2.0 / (double)(EPS + rb + rbr));
+          // the reference divides in binary64 (double literals) and rounds the quotient to binary32
+          const float cru = div2_via_double(cu, EPS + rb + rbu);
+          const float crd = div2_via_double(cd, EPS + rb + rbd);
+          const float crl = div2_via_double(cl, EPS + rb + rbl);
+          const float crr = div2_via_double(cr, EPS + rb + rbr);
           const float gu = fabsf(1.f - cru) < ARTHRESH ? rb * cru : cu + xdiv2f(rb - rbu);
           const float gd = fabsf(1.f - crd) < ARTHRESH ? rb * crd : cd + xdiv2f(rb - rbd);
           const float gl = fabsf(1.f - crl) < ARTHRESH ? rb * crl : cl + xdiv2f(rb - rbl);
@@ -721,7 +796,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
               Gintv = ulim(Gintv, cu, cd);
             else
             {
-              const float vwt = (float)(2.0 * (double)(rb - Gintv) / (double)(EPS + Gintv + rb));
+              const float vwt = div2_via_double(rb - Gintv, EPS + Gintv + rb);
               Gintv = vwt * Gintv + (1.f - vwt) * ulim(Gintv, cu, cd);
             }
           }
@@ -731,7 +806,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
               Ginth = ulim(Ginth, cl, cr);
             else
             {
-              const float hwt = (float)(2.0 * (double)(rb - Ginth) / (double)(EPS + Ginth + rb));
+              const float hwt = div2_via_double(rb - Ginth, EPS + Ginth + rb);
               Ginth = hwt * Ginth + (1.f - hwt) * ulim(Ginth, cl, cr);
             }
           }
@@ -744,9 +819,10 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       }
     }
     env.sync();
+    env.stamp(11);
 
-    // ---- phase 17: S13 chrominance at the opposite R/B sites from the four diagonal neighbours, :1246-1276 (the split
-    //      of :1239-1244 is in the indexing: a site keeps its own difference, this stage gives it the other one)
+    // ---- phase 12: S13 chrominance at the opposite R/B sites from the four diagonal neighbours, :1246-1276 (the split of :1239-1244 is in
+    //      the indexing: a site keeps its own difference, this stage gives it the other one)
     FOR_RB(L_S13)
     {
       float v = 0.f;
@@ -769,8 +845,9 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       ST(P_DGP, rr, h, v);
     }
     env.sync();
+    env.stamp(12);
 
-    // ---- phase 18: S14 output, :1278-1411 (alpha is left as it is)
+    // ---- phase 13: S14 output, :1278-1411 (alpha is left as it is)
     FOR_FULL(L_S14)
     {
       if(IN_(rr, 16, TS - 16) && IN_(cc, 16, TS - 16))
@@ -790,21 +867,20 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
           const float r0 = vert_red ? LD(P_DGP, rr, hr) : LD(P_DGO, rr, hr), r1 = vert_red ? LD(P_DGO, rr, hr) : LD(P_DGP, rr, hr);
           const float l0 = vert_red ? LD(P_DGP, rr, hl) : LD(P_DGO, rr, hl), l1 = vert_red ? LD(P_DGO, rr, hl) : LD(P_DGP, rr, hl);
           const float g = LD(P_CFA, rr, cc);
-          o[0] = clampnan(g - ((wu)*u0 + (1.f - wr) * r0 + (1.f - wl) * l0 + (wd)*d0) * temp, 0.0f, 1.0f);
-          o[2] = clampnan(g - ((wu)*u1 + (1.f - wr) * r1 + (1.f - wl) * l1 + (wd)*d1) * temp, 0.0f, 1.0f);
-          o[1] = clampnan(g, 0.0f, 1.0f);
+          env.store_rgb(o, clampnan(g - ((wu)*u0 + (1.f - wr) * r0 + (1.f - wl) * l0 + (wd)*d0) * temp, 0.0f, 1.0f), clampnan(g, 0.0f, 1.0f),
+                        clampnan(g - ((wu)*u1 + (1.f - wr) * r1 + (1.f - wl) * l1 + (wd)*d1) * temp, 0.0f, 1.0f));
         }
         else
         {
           const int hh = cc >> 1;
           const float g = LD(P_GREEN, rr, hh), own = LD(P_DGO, rr, hh), opp = LD(P_DGP, rr, hh);
-          o[0] = clampnan(g - (col == 0 ? own : opp), 0.0f, 1.0f);
-          o[2] = clampnan(g - (col == 0 ? opp : own), 0.0f, 1.0f);
-          o[1] = clampnan(g, 0.0f, 1.0f);
+          env.store_rgb(o, clampnan(g - (col == 0 ? own : opp), 0.0f, 1.0f), clampnan(g, 0.0f, 1.0f),
+                        clampnan(g - (col == 0 ? opp : own), 0.0f, 1.0f));
         }
       }
     }
     env.sync();
+    env.stamp(13);
   }
 #undef LD
 #undef ST
@@ -812,7 +888,9 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
 #undef STB
 #undef IN_
 #undef FOR_FULL
+#undef FOR_FULL_UPPER
 #undef FOR_RB
+#undef FOR_RB2
 }
 
 } // namespace amz

@@ -15,10 +15,18 @@
 //       along columns (step 2) -- one thread per chain, 2 x 2 x 160 chains;
 //   S7 / S10  diagonal-neighbour votes on the H/V and +/- weights: row r reads row r-1 already
 //       voted -- the plane is staged in LDS and the rows are walked with one barrier per row.
+//
+// Round 3: the full tiles of a frame -- all but its last tile row and column -- run in amaze_stream, which keeps every
+// plane in LDS (amaze_stream_body.h); amaze_tiles keeps the tiles the frame cuts.
 #include "hip_common.h"
 
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
+
+#define AMZ_FN __device__ __forceinline__
+#define AMZ_MEMBER static __device__ __forceinline__
+#include "amaze_stream_body.h"
 
 using namespace ansel;
 
@@ -37,7 +45,8 @@ namespace
 #define M2 (2 * TS + 2)
 #define M3 (3 * TS + 3)
 #define PAD 32
-#define NT 512
+#define NT ((int)blockDim.x) // the slab tiles run in workgroups of 512 (amaze_tiles) or 640 (amaze_frame) threads
+#define SLAB_THREADS 512
 #define CHAIN_U 8 // sites of a stage-3 chain fetched ahead
 
 // plane offsets in floats: the reference's buffer layout, amaze.cc:274-327 (128 bytes between planes)
@@ -94,6 +103,7 @@ struct amaze_args
   uint32_t filters;
   int ex, ey;
   float clip_pt;
+  int nsx, nsy; // tiles [0, nsx) x [0, nsy) of the grid are amaze_stream's; ntiles counts the others
 };
 
 #define EPS 1e-5f
@@ -166,9 +176,8 @@ __device__ __forceinline__ float chain_site(const float prev, const float c0, co
 // every tile into stamps[]
 #define N_STAMPS 20
 template <bool TIMED>
-__global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, float *__restrict__ out,
-                                                  float *__restrict__ slabs, const amaze_args a,
-                                                  unsigned long long *__restrict__ stamps)
+__device__ __forceinline__ void slab_tile(const float *__restrict__ in, float *__restrict__ out, float *const B, const amaze_args &a,
+                                          const int tile, float *const vote, int *const nyq, unsigned long long *__restrict__ stamps)
 {
   long long t_prev = 0;
 #define STAMP(k)                                                           \
@@ -178,13 +187,10 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
     atomicAdd(&stamps[k], (unsigned long long)(_t - t_prev));              \
     t_prev = _t;                                                           \
   }
-  __shared__ float vote[TS * TSH];
-  __shared__ int nyq[4];
   const int tid = threadIdx.x;
   const int width = a.width, height = a.height;
   const uint32_t filters = a.filters;
   const float clip_pt = a.clip_pt, clip_pt8 = 0.8f * a.clip_pt;
-  float *const B = slabs + (size_t)blockIdx.x * O_END;
   float *const cfa = B + O_CFA, *const green = B + O_GREEN, *const delhvsqsum = B + O_DELHVSQSUM;
   float *const dirwts0 = B + O_DIRWTS0, *const dirwts1 = B + O_DIRWTS1, *const vcd = B + O_VCD, *const hcd = B + O_HCD;
   float *const vcdalt = B + O_VCDALT, *const hcdalt = B + O_HCDALT, *const cddiffsq = B + O_CDDIFFSQ;
@@ -198,9 +204,12 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
   unsigned char *const nyquist2 = (unsigned char *)cddiffsq;
   const float *const d0 = dirwts0, *const d1 = dirwts1;
 
-  for(int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x)
   {
-    const int top = -16 + (tile / a.ntx) * (TS - 32), left = -16 + (tile % a.ntx) * (TS - 32);
+    // the tiles right of amaze_stream's, then the tile rows below them
+    const int right_cols = a.ntx - a.nsx, right_tiles = right_cols * a.nsy;
+    const int ty = tile < right_tiles ? tile / right_cols : a.nsy + (tile - right_tiles) / a.ntx;
+    const int tx = tile < right_tiles ? a.nsx + tile % right_cols : (tile - right_tiles) % a.ntx;
+    const int top = -16 + ty * (TS - 32), left = -16 + tx * (TS - 32);
     const int bottom = min(top + TS, height + 16), right = min(left + TS, width + 16);
     const int rr1 = bottom - top, cc1 = right - left;
     const int rrmin = top < 0 ? 16 : 0, ccmin = left < 0 ? 16 : 0;
@@ -772,6 +781,122 @@ __global__ __launch_bounds__(NT) void amaze_tiles(const float *__restrict__ in, 
 #undef STAMP
 }
 
+template <bool TIMED>
+__global__ __launch_bounds__(SLAB_THREADS) void amaze_tiles(const float *__restrict__ in, float *__restrict__ out,
+                                                            float *__restrict__ slabs, const amaze_args a,
+                                                            unsigned long long *__restrict__ stamps)
+{
+  __shared__ float vote[TS * TSH];
+  __shared__ int nyq[4];
+  float *const B = slabs + (size_t)blockIdx.x * O_END;
+  for(int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) slab_tile<TIMED>(in, out, B, a, tile, vote, nyq, stamps);
+}
+
+// ---- the full tiles, on chip
+struct stream_env
+{
+  float *lds;
+  __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
+  __device__ __forceinline__ float ldf(const int idx, const int) const { return lds[idx]; }
+  __device__ __forceinline__ void stf(const int idx, const int, const float v) const { lds[idx] = v; }
+  __device__ __forceinline__ unsigned char ldb(const int bidx, const int) const { return ((const unsigned char *)lds)[bidx]; }
+  __device__ __forceinline__ void stb(const int bidx, const int, const unsigned char v) const { ((unsigned char *)lds)[bidx] = v; }
+  __device__ __forceinline__ void zero(const int word) const { lds[word] = 0.0f; }
+  // a workgroup barrier that orders LDS only: __syncthreads() also waits for the global stores in flight (the output rows),
+  // a round trip to memory per step that nothing in the tile depends on
+  __device__ __forceinline__ void sync() const
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  }
+  // between two stretches of ONE wave's LDS accesses: the hardware executes them in program order, the compiler must too
+  __device__ __forceinline__ void wave_sync() const
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  }
+  __device__ __forceinline__ void stamp(const int) const {}
+  // the three colour values of a pixel as one 12-byte store (alpha is left as it is)
+  __device__ __forceinline__ void store_rgb(float *const o, const float r, const float g, const float b) const
+  {
+    typedef float v3f_t __attribute__((ext_vector_type(3)));
+    const v3f_t v = { r, g, b };
+    __builtin_memcpy(o, &v, 12);
+  }
+};
+// the measuring build (ANSEL_HIP_AMAZE_TIMED): cycles between the barriers of a step, summed per phase over all tiles
+struct stream_env_timed : stream_env
+{
+  long long acc[16]; // (indexed by literals only: registers)
+  long long t_prev;
+  __device__ __forceinline__ void stamp(const int k)
+  {
+    const long long t = (long long)__builtin_readcyclecounter();
+    acc[k] += t - t_prev;
+    t_prev = t;
+  }
+};
+
+template <bool TIMED>
+__global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_stream(const float *__restrict__ in, float *__restrict__ out, const amz::args a,
+                                                        const int nsx, const int ntiles, unsigned long long *__restrict__ stamps)
+{
+  extern __shared__ __attribute__((aligned(16))) float amz_lds[];
+  if(TIMED)
+  {
+    stream_env_timed env;
+    env.lds = amz_lds;
+#pragma unroll
+    for(int k = 0; k < 16; k++) env.acc[k] = 0;
+    for(int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+    {
+      env.t_prev = (long long)__builtin_readcyclecounter();
+      amz::tile(env, in, out, a, -16 + (tile / nsx) * (TS - 32), -16 + (tile % nsx) * (TS - 32));
+    }
+    if(threadIdx.x == 0)
+#pragma unroll
+      for(int k = 0; k < 16; k++) atomicAdd(&stamps[k], (unsigned long long)env.acc[k]);
+  }
+  else
+  {
+    stream_env env{ amz_lds };
+    for(int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+      amz::tile(env, in, out, a, -16 + (tile / nsx) * (TS - 32), -16 + (tile % nsx) * (TS - 32));
+  }
+}
+
+// ---- one launch for the frame: the workgroups draw tiles from a queue, the tiles the frame cuts first (slab_tile: the vote
+//      plane in the first 50 KB of the LDS block the streaming tiles use whole), then the full ones.  A workgroup per CU
+//      either way; drawn, not dealt, because the two kinds of tile do not take the same time
+__global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_frame(const float *__restrict__ in, float *__restrict__ out,
+                                                                   float *__restrict__ slabs, const amaze_args a, const amz::args sa,
+                                                                   unsigned int *__restrict__ queue)
+{
+  extern __shared__ __attribute__((aligned(16))) float amz_lds[];
+  __shared__ int nyq[4];
+  __shared__ unsigned int drawn;
+  stream_env env{ amz_lds };
+  float *const B = slabs + (size_t)blockIdx.x * O_END;
+  const unsigned int items = (unsigned int)(a.ntiles + a.nsx * a.nsy);
+  for(;;)
+  {
+    if(threadIdx.x == 0) drawn = atomicAdd(queue, 1u);
+    __syncthreads();
+    const unsigned int item = drawn;
+    __syncthreads();
+    if(item >= items) break;
+    if(item < (unsigned int)a.ntiles)
+      slab_tile<false>(in, out, B, a, (int)item, amz_lds, nyq, nullptr);
+    else
+    {
+      const int t = (int)item - a.ntiles;
+      amz::tile(env, in, out, sa, -16 + (t / a.nsx) * (TS - 32), -16 + (t % a.nsx) * (TS - 32));
+    }
+  }
+}
+
 } // namespace
 
 namespace ansel
@@ -805,14 +930,93 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   a.clip_pt = fminf(piece->processed_maximum[0], fminf(piece->processed_maximum[1], piece->processed_maximum[2]));
   a.ntx = (width + 16 + (TS - 32) - 1) / (TS - 32);
   const int nty = (height + 16 + (TS - 32) - 1) / (TS - 32);
-  a.ntiles = a.ntx * nty;
+  // the tiles that lie in the frame whole (top + 160 <= height, left + 160 <= width) go to amaze_stream
+  a.nsx = width >= TS - 16 ? (width - (TS - 16)) / (TS - 32) + 1 : 0;
+  a.nsy = height >= TS - 16 ? (height - (TS - 16)) / (TS - 32) + 1 : 0;
+  if(getenv("ANSEL_HIP_AMAZE_SLAB") || a.nsx == 0 || a.nsy == 0) a.nsx = a.nsy = 0; // the first kernel for every tile
+  a.ntiles = a.ntx * nty - a.nsx * a.nsy;
+  hipStream_t s = stream_of(devid);
+  const bool timed = getenv("ANSEL_HIP_AMAZE_TIMED") != nullptr;
+  const bool unfused = timed || getenv("ANSEL_HIP_AMAZE_UNFUSED") != nullptr; // one kernel per kind of tile: for measurements
+  amz::args sa;
+  sa.width = width;
+  sa.height = height;
+  sa.filters = filters;
+  sa.ex = a.ex;
+  sa.ey = a.ey;
+  sa.clip_pt = a.clip_pt;
+  const int stream_tiles = a.nsx * a.nsy;
+  if(stream_tiles > 0)
+  {
+    // the opt-in to more than 64 KB of LDS is per device
+    static std::atomic<unsigned long long> attr_set{ 0ull };
+    const int hd = hip_device_of(devid);
+    if(hd < 0 || hd >= 64) return DT_HIP_INVALID_ARG;
+    if(!(attr_set.load() >> hd & 1ull))
+    {
+      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)amaze_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)amz::LDS_BYTES));
+      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)amaze_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)amz::LDS_BYTES));
+      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)amaze_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)amz::LDS_BYTES));
+      attr_set.fetch_or(1ull << hd);
+    }
+  }
+  // one workgroup per CU: the LDS of a CU each (ANSEL_HIP_AMAZE_BLOCKS: fewer, so that the tests see a workgroup walk many tiles)
+  const char *const sb_env = getenv("ANSEL_HIP_AMAZE_STREAM_BLOCKS") ? getenv("ANSEL_HIP_AMAZE_STREAM_BLOCKS") : getenv("ANSEL_HIP_AMAZE_BLOCKS");
+  const int sb_max = sb_env && atoi(sb_env) > 0 ? atoi(sb_env) : 256;
+  if(stream_tiles > 0 && !unfused)
+  {
+    const int items = stream_tiles + a.ntiles, blocks = items < sb_max ? items : sb_max;
+    // a slab per workgroup that may draw a cut tile: all of them
+    float *slabs = (float *)dt_hip_alloc_device_buffer(devid, (size_t)(a.ntiles > 0 ? blocks : 1) * O_END * sizeof(float));
+    unsigned int *queue = (unsigned int *)dt_hip_alloc_device_buffer(devid, 256);
+    int rc = DT_HIP_SUCCESS;
+    if(!slabs || !queue)
+      rc = DT_HIP_SYSMEM_ALLOCATION;
+    else if(hipMemsetAsync(queue, 0, sizeof(unsigned int), s) != hipSuccess)
+      rc = DT_HIP_DEFAULT_ERROR;
+    else
+    {
+      launch_scope ls(devid, "amaze_frame");
+      amaze_frame<<<blocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, slabs, a, sa, queue);
+    }
+    if(rc == DT_HIP_SUCCESS) rc = check_launch("amaze_frame");
+    if(queue) dt_hip_release_mem_object(queue);
+    if(slabs) dt_hip_release_mem_object(slabs);
+    return rc;
+  }
+  if(stream_tiles > 0)
+  {
+    const int sblocks = stream_tiles < sb_max ? stream_tiles : sb_max;
+    if(timed)
+    {
+      unsigned long long *stamps = (unsigned long long *)dt_hip_alloc_device_buffer(devid, sizeof(unsigned long long) * 32);
+      if(!stamps) return DT_HIP_SYSMEM_ALLOCATION;
+      unsigned long long host[32];
+      if(hipMemsetAsync(stamps, 0, sizeof(host), s) == hipSuccess)
+      {
+        amaze_stream<true><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.nsx, stream_tiles, stamps);
+        if(hipMemcpyAsync(host, stamps, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
+          for(int k = 0; k < 16; k++)
+            fprintf(stderr, "[amaze_stream_timed] phase %d cycles_per_tile %llu\n", k, host[k] / (unsigned long long)stream_tiles);
+      }
+      dt_hip_release_mem_object(stamps);
+    }
+    else
+    {
+      launch_scope ls(devid, "amaze_stream");
+      amaze_stream<false><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.nsx, stream_tiles, nullptr);
+    }
+    const int rc = check_launch("amaze_stream");
+    if(rc != DT_HIP_SUCCESS) return rc;
+    if(a.ntiles == 0) return DT_HIP_SUCCESS;
+  }
   // two 512-thread workgroups per CU (the vote plane is 50 KiB of LDS each)
   const char *const blocks_env = getenv("ANSEL_HIP_AMAZE_BLOCKS");
   const int max_blocks = blocks_env ? atoi(blocks_env) : 512;
   const int blocks = a.ntiles < max_blocks ? a.ntiles : max_blocks;
   float *slabs = (float *)dt_hip_alloc_device_buffer(devid, (size_t)blocks * O_END * sizeof(float));
   if(!slabs) return DT_HIP_SYSMEM_ALLOCATION;
-  if(getenv("ANSEL_HIP_AMAZE_TIMED"))
+  if(timed)
   {
     // the measuring build: cycles per stage summed over the tiles, printed (tools/amaze_stage_clocks.py)
     unsigned long long *stamps = (unsigned long long *)dt_hip_alloc_device_buffer(devid, sizeof(unsigned long long) * N_STAMPS);
@@ -821,11 +1025,10 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
       dt_hip_release_mem_object(slabs);
       return DT_HIP_SYSMEM_ALLOCATION;
     }
-    hipStream_t s = stream_of(devid);
     unsigned long long host[N_STAMPS];
     if(hipMemsetAsync(stamps, 0, sizeof(host), s) == hipSuccess)
     {
-      amaze_tiles<true><<<blocks, NT, 0, s>>>(in, (float *)out, slabs, a, stamps);
+      amaze_tiles<true><<<blocks, SLAB_THREADS, 0, s>>>(in, (float *)out, slabs, a, stamps);
       if(hipMemcpyAsync(host, stamps, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
         for(int k = 0; k < 14; k++) fprintf(stderr, "[amaze_timed] stamp %d cycles_per_tile %llu\n", k, host[k] / (unsigned long long)a.ntiles);
     }
@@ -834,7 +1037,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   else
   {
     launch_scope ls(devid, "amaze_tiles");
-    amaze_tiles<false><<<blocks, NT, 0, stream_of(devid)>>>(in, (float *)out, slabs, a, nullptr);
+    amaze_tiles<false><<<blocks, SLAB_THREADS, 0, s>>>(in, (float *)out, slabs, a, nullptr);
   }
   dt_hip_release_mem_object(slabs);
   return check_launch("amaze_tiles");

@@ -2,7 +2,8 @@
 // (ansel_amd/csrc/amaze_stream_body.h) compiled for the host.  A workgroup is NT fibers (ucontext) that a scheduler
 // runs one after the other from barrier to barrier, its LDS a heap block with a shadow: every access is checked for
 //   * a race -- a word read in the phase another thread writes it in, or written in the phase another thread reads or
-//     writes it in (the sequential schedule would hide those) --, and
+//     writes it in (the sequential schedule would hide those); inside one wave the unit is the stretch between two
+//     wave_sync(), across waves the stretch between two workgroup barriers --, and
 //   * a stale ring slot -- a plane's row read after a later row has overwritten its slot, or before it was produced.
 // So the CPU suite compares the kernel with the oracle bit for bit, and proves its schedule, before a GPU is involved.
 // -ffp-contract=off like the device build.
@@ -25,9 +26,11 @@ struct Shared
 {
   std::vector<uint8_t> lds;
   std::vector<int16_t> tag;            // the row a word holds (-1: the zero the tile starts from)
-  std::vector<int32_t> wphase, rphase; // the phase of the last write / read
-  std::vector<int16_t> wtid, rtid;     // ... and who (-2: several readers)
-  int phase = 1;
+  std::vector<int32_t> wphase, rphase; // the round of the last write / read (a round: every runnable fiber up to its next yield)
+  std::vector<int32_t> wblock, rblock; // ... and the workgroup phase (between two workgroup barriers) it belongs to
+  std::vector<int16_t> wtid, rtid;     // ... and who (-2: readers of several waves, -3: several readers of one wave)
+  int phase = 1, block = 1;
+  std::vector<char> at_block;
   long errors = 0;
   std::string first;
   ucontext_t main;
@@ -58,25 +61,45 @@ struct HostEnv
       sh->first = b;
     }
   }
+  // two accesses conflict when nothing orders them: threads of different waves inside one workgroup phase; threads of one
+  // wave inside one round (a wave's LDS accesses execute in program order, and wave_sync() ends a round)
+  bool unordered(const int other, const int oround, const int oblock) const
+  {
+    if(other == tid_ || oblock != sh->block) return false;
+    if(other < 0) return other == -2 || oround == sh->phase;
+    return (other >> 6) != (tid_ >> 6) || oround == sh->phase;
+  }
   void on_read(const int addr, const int row) const
   {
-    if(sh->wphase[addr] == sh->phase && sh->wtid[addr] != tid_) fail("read of a word another thread writes in this phase", addr, row);
+    if(unordered(sh->wtid[addr], sh->wphase[addr], sh->wblock[addr])) fail("read of a word another thread writes in this phase", addr, row);
     if(row >= 0 && sh->tag[addr] >= 0 && sh->tag[addr] != row) fail("stale ring slot", addr, row);
-    if(sh->rphase[addr] == sh->phase)
+    if(sh->rblock[addr] == sh->block && sh->rtid[addr] != tid_)
     {
-      if(sh->rtid[addr] != tid_) sh->rtid[addr] = -2;
+      // keep the strongest record: readers of another wave conflict with any later write of the phase
+      const int o = sh->rtid[addr];
+      if(o == -2 || (o >= 0 && (o >> 6) != (tid_ >> 6)))
+        sh->rtid[addr] = -2;
+      else if(sh->rphase[addr] == sh->phase)
+        sh->rtid[addr] = -3;
+      else
+      {
+        sh->rphase[addr] = sh->phase;
+        sh->rtid[addr] = (int16_t)tid_;
+      }
     }
     else
     {
       sh->rphase[addr] = sh->phase;
+      sh->rblock[addr] = sh->block;
       sh->rtid[addr] = (int16_t)tid_;
     }
   }
   void on_write(const int addr, const int row) const
   {
-    if(sh->wphase[addr] == sh->phase && sh->wtid[addr] != tid_) fail("word written by two threads in one phase", addr, row);
-    if(sh->rphase[addr] == sh->phase && sh->rtid[addr] != tid_) fail("write of a word another thread reads in this phase", addr, row);
+    if(unordered(sh->wtid[addr], sh->wphase[addr], sh->wblock[addr])) fail("word written by two threads in one phase", addr, row);
+    if(unordered(sh->rtid[addr], sh->rphase[addr], sh->rblock[addr])) fail("write of a word another thread reads in this phase", addr, row);
     sh->wphase[addr] = sh->phase;
+    sh->wblock[addr] = sh->block;
     sh->wtid[addr] = (int16_t)tid_;
     sh->tag[addr] = (int16_t)row;
   }
@@ -110,7 +133,20 @@ struct HostEnv
       sh->lds[(size_t)word * 4 + b] = 0;
     }
   }
-  void sync() const { swapcontext(&sh->ctx[tid_], &sh->main); }
+  void sync() const
+  {
+    sh->at_block[tid_] = 1;
+    swapcontext(&sh->ctx[tid_], &sh->main);
+  }
+  // orders the LDS accesses of ONE wave (on the device they execute in program order; here the fibers of the wave meet)
+  void wave_sync() const { swapcontext(&sh->ctx[tid_], &sh->main); }
+  void stamp(int) const {}
+  void store_rgb(float *const o, const float r, const float g, const float b) const
+  {
+    o[0] = r;
+    o[1] = g;
+    o[2] = b;
+  }
 };
 
 void fiber(const int t)
@@ -137,6 +173,9 @@ extern "C" int amaze_host_run(const float *in, float *out, int width, int height
   sh.tag.assign(amz::LDS_BYTES, -1);
   sh.wphase.assign(amz::LDS_BYTES, 0);
   sh.rphase.assign(amz::LDS_BYTES, 0);
+  sh.wblock.assign(amz::LDS_BYTES, 0);
+  sh.rblock.assign(amz::LDS_BYTES, 0);
+  sh.at_block.assign(amz::NT, 0);
   sh.wtid.assign(amz::LDS_BYTES, -1);
   sh.rtid.assign(amz::LDS_BYTES, -1);
   sh.in = in;
@@ -171,17 +210,26 @@ extern "C" int amaze_host_run(const float *in, float *out, int width, int height
     sh.ctx[t].uc_link = &sh.main;
     makecontext(&sh.ctx[t], (void (*)())fiber, 1, t);
   }
+  // a round: every fiber that is not waiting at a workgroup barrier runs up to its next yield; when all of them wait
+  // there, the barrier opens
   for(;;)
   {
-    int live = 0;
+    int live = 0, ran = 0;
     for(int t = 0; t < NT; t++)
       if(!sh.done[t])
       {
-        swapcontext(&sh.main, &sh.ctx[t]);
         live++;
+        if(sh.at_block[t]) continue;
+        swapcontext(&sh.main, &sh.ctx[t]);
+        ran++;
       }
     if(!live) break;
     sh.phase++;
+    if(!ran)
+    {
+      for(int t = 0; t < NT; t++) sh.at_block[t] = 0;
+      sh.block++;
+    }
   }
   if(err && errlen > 0)
   {

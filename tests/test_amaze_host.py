@@ -1,0 +1,137 @@
+"""The gfx950 kernel that keeps an AMaZE tile on chip (ansel_amd/csrc/amaze_stream_body.h, launched as amaze_frame /
+amaze_stream) compiled for the HOST (tests/native/amaze_host.cpp): a workgroup is 640 fibers run from barrier to barrier,
+its LDS a heap block with a shadow that flags every race and every ring slot read after it was overwritten.  Against the
+oracle, bit for bit, on every full tile of the frame -- the tiles the frame cuts belong to the first kernel.  The same
+source runs on the device; this pins its schedule (lags, ring depths, the thread halves that share a phase, the votes a single
+wave walks) without a GPU.  The -m gpu tests then only have to show that the device executes it the same."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import checkers as ck
+from ansel_amd import abi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "native", "libamaze_host.so")
+SRC = os.path.join(ROOT, "tests", "native", "amaze_host.cpp")
+HDR = os.path.join(ROOT, "ansel_amd", "csrc", "amaze_stream_body.h")
+TS = 160
+
+
+def build(so=SO, defines=()):
+    if defines or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", *defines,
+                               "-I" + os.path.join(ROOT, "ansel_amd", "csrc"), SRC, "-o", so])
+    return so
+
+
+@pytest.fixture(scope="module")
+def host_kernel():
+    lib = C.CDLL(build())
+    lib.amaze_host_run.restype = C.c_int
+    return lib
+
+
+def textured(w, h, seed, gain=1.7):
+    """a scene with fine checkerboards and stripes laid over parts of it: they switch the Nyquist branches on"""
+    raw = synth.bayer_mosaic(w, h, seed=seed).astype(np.float32)
+    cfa = ((raw - 512) / np.float32(synth.WHITE - 512) * np.float32(gain)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = (slice(h // 8, h // 2), slice(w // 6, 2 * w // 3))
+    cfa[a] *= (0.55 + 0.45 * ((xx[a] + yy[a]) & 1)).astype(np.float32)
+    b = (slice(h // 2, 7 * h // 8), slice(w // 4, 7 * w // 8))
+    cfa[b] *= (0.6 + 0.4 * ((xx[b] >> 1) & 1)).astype(np.float32)
+    c = (slice(h // 3, 2 * h // 3), slice(3 * w // 4, w - 8))
+    cfa[c] *= (0.6 + 0.4 * (yy[c] & 1)).astype(np.float32)
+    return cfa
+
+
+def run(lib, cfa, filters, pm):
+    h, w = cfa.shape
+    got = np.full((h, w, 4), -7.0, np.float32)
+    ns, na, err = C.c_int(), C.c_int(), C.create_string_buffer(512)
+    ne = lib.amaze_host_run(ck.ptr(cfa), ck.ptr(got), w, h, C.c_uint32(filters), C.c_float(min(pm[:3])), C.byref(ns), C.byref(na), err, 512)
+    return got, ne, err.value.decode(), ns.value, na.value
+
+
+def oracle(cfa, filters, pm):
+    h, w = cfa.shape
+    piece = abi.Piece.make(w, h, filters=filters, channels=1, processed_maximum=pm)
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_AMAZE, 0.0)
+    want = np.full((h, w, 4), -7.0, np.float32)
+    assert ck.call(ck.oracle(), "oracle_demosaic", piece, d, cfa, want) == 0
+    return want
+
+
+def check(lib, cfa, filters, pm=(1.5, 1.0, 1.2, 1.0)):
+    h, w = cfa.shape
+    got, ne, err, ns, na = run(lib, cfa, filters, pm)
+    assert ne == 0, "%d schedule errors, the first: %s" % (ne, err)
+    nsx, nsy = (w - (TS - 16)) // (TS - 32) + 1, (h - (TS - 16)) // (TS - 32) + 1
+    assert ns == nsx * nsy and na > ns
+    written = got[..., 0] != -7.0
+    # the full tiles keep rows / columns [0, 128 n) of the frame
+    assert written[:128 * nsy, :128 * nsx].all() and not written[128 * nsy:].any() and not written[:, 128 * nsx:].any()
+    assert (got[..., 3] == -7.0).all()  # alpha is not written
+    want = oracle(cfa, filters, pm)
+    diff = (ck.ulp_diff(got, want) > 0) & written[..., None]
+    assert int(diff.sum()) == 0, "%d values differ" % int(diff.sum())
+
+
+@pytest.mark.parametrize("filters", [0x94949494, 0x49494949, 0x61616161, 0x16161616])
+def test_streaming_tiles_equal_the_oracle(host_kernel, filters):
+    """6 full tiles (the mirrored top / left border and its corner among them), every CFA phase"""
+    check(host_kernel, textured(517, 389, seed=906), filters)
+
+
+def test_streaming_tiles_many(host_kernel):
+    """24 full tiles of a frame whose textures flag most of them for the Nyquist refinement -- the frames in which the last
+    kept row of a tile depends on the bytes behind the second flag plane (profiles/r03_amaze_alias_probe.txt)"""
+    check(host_kernel, textured(800, 600, seed=21), 0x49494949)
+
+
+def test_streaming_tiles_highlights_and_flat_areas(host_kernel):
+    """clipped highlights (the > clip_pt branches), constant planes (0 / 0 guarded by eps), zeros (the +-0 quotients of the
+    exact binary32 replacement of the reference's binary64 divisions)"""
+    w, h = 450, 330
+    raw = synth.bayer_mosaic(w, h, seed=9).astype(np.float32)
+    cfa = ((raw - 512) / np.float32(synth.WHITE - 512) * np.float32(3.0)).astype(np.float32)
+    cfa[60:120, 80:200] = 1.0
+    cfa[150:200, 30:90] = 0.0
+    cfa[20:50, 220:260] = -0.05
+    cfa = np.minimum(cfa, 1.0).astype(np.float32)
+    check(host_kernel, cfa, synth.FILTERS_RGGB, pm=(1.0, 1.0, 1.0, 1.0))
+
+
+def test_streaming_tiles_adversarial_values(host_kernel):
+    """tiny values (their squares are denormals), huge values and negatives: every stage's selects and exact divisions on
+    the same bits as the oracle.  (Photosites that are themselves near the smallest normal make the reference's exponent
+    tricks, amaze.cc:77-121, wrap into NaNs; which of two NaN operands an addition hands on -- its sign ends up in the
+    result through those tricks -- is the compiler's choice, on x86 and on the GPU: not a function of the input.)"""
+    w, h = 320, 320
+    rng = np.random.default_rng(5)
+    cfa = textured(w, h, seed=4)
+    cfa[40:80, 40:120] *= np.float32(1e-30)
+    cfa[100:140, 150:260] *= np.float32(1e30)
+    cfa[200:230, 30:200] *= -1.0
+    cfa[rng.integers(0, h, 300), rng.integers(0, w, 300)] = 0.0
+    check(host_kernel, cfa.astype(np.float32), 0x61616161)
+
+
+def test_the_checker_sees_a_broken_schedule(tmp_path):
+    """the harness is only worth something if it fails when the schedule is wrong: one row of lag less behind the
+    Nyquist test (S6 reads flags S5 has not produced) must be reported as a stale ring slot"""
+    src = open(HDR).read()
+    assert "L_S6 = 13" in src
+    hdr_dir = tmp_path / "csrc"
+    hdr_dir.mkdir()
+    (hdr_dir / "amaze_stream_body.h").write_text(src.replace("L_S6 = 13", "L_S6 = 12"))
+    so = str(tmp_path / "libamaze_host_broken.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I" + str(hdr_dir), SRC, "-o", so])
+    lib = C.CDLL(so)
+    lib.amaze_host_run.restype = C.c_int
+    _, ne, err, _, _ = run(lib, textured(300, 200, seed=3), 0x94949494, (1.5, 1.0, 1.2, 1.0))
+    assert ne > 0 and ("stale ring slot" in err or "another thread" in err), err

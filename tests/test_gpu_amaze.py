@@ -38,9 +38,32 @@ def test_amaze(w, h, filters):
         assert int(((ck.ulp_diff(got, r).max(-1) > 0) & (mask == 0)).sum()) == 0
 
 
+@pytest.mark.parametrize("which", ["ANSEL_HIP_AMAZE_UNFUSED", "ANSEL_HIP_AMAZE_SLAB"])
+@pytest.mark.parametrize("filters", [0x94949494, 0x16161616])
+def test_amaze_kernel_variants(which, filters, monkeypatch):
+    """the frame's full tiles run on chip (amaze_frame: one launch, the workgroups draw cut tiles and full tiles from a
+    queue); the same frame with one launch per kind of tile (the measuring configuration) and with the first kernel for
+    every tile must be the same bits"""
+    w, h = 1504, 1000
+    raw = synth.bayer_mosaic(w, h, seed=33).astype(np.float32)
+    cfa = ((raw - 512) / np.float32(synth.WHITE - 512) * np.float32(1.7)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    cfa[100:700, 200:1300] *= (0.55 + 0.45 * ((xx[100:700, 200:1300] + yy[100:700, 200:1300]) & 1)).astype(np.float32)
+    piece = abi.Piece.make(w, h, filters=filters, channels=1, processed_maximum=(1.5, 1.0, 1.2, 1.0))
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_AMAZE, 0.0)
+    pre = np.full((h, w, 4), -7.0, np.float32)
+    base = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, cfa, (h, w, 4), pre_fill=pre)
+    monkeypatch.setenv(which, "1")
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, cfa, (h, w, 4), pre_fill=pre)
+    assert np.array_equal(got.view(np.uint32), base.view(np.uint32))
+    want = pre.copy()
+    assert ck.call(ck.oracle(), "oracle_demosaic", piece, d, cfa, want) == 0
+    assert int((ck.ulp_diff(got, want) > 0).sum()) == 0
+
+
 def test_amaze_highlights_and_flat_areas():
     """clipped highlights (the > clip_pt branches), a constant plane (all weights 0/0-guarded by eps)"""
-    w, h = 320, 256
+    w, h = 450, 330  # (six of its twelve tiles are full ones: on chip)
     raw = synth.bayer_mosaic(w, h, seed=9).astype(np.float32)
     cfa = ((raw - 512) / np.float32(synth.WHITE - 512) * np.float32(3.0)).astype(np.float32)
     cfa[60:120, 80:200] = 1.0
@@ -57,8 +80,8 @@ def test_amaze_highlights_and_flat_areas():
 
 @pytest.mark.parametrize("filters", [0x94949494, 0x49494949, 0x61616161, 0x16161616])
 def test_amaze_many_tiles_per_workgroup(filters, monkeypatch):
-    """three workgroups walk a frame of 96 tiles (a 24 MP frame has 1 500 tiles for 512 workgroups): the tile buffer is
-    zeroed between tiles, the frame is the oracle's.  Fine checkerboards and stripes switch the Nyquist branches on."""
+    """three workgroups walk a frame of 96 tiles (a 24 MP frame has 1 500 tiles for 256 workgroups), cut tiles and full ones
+    as the queue hands them out: the tile buffer and the LDS rings are zeroed between tiles, the frame is the oracle's.  Fine checkerboards and stripes switch the Nyquist branches on."""
     w, h = 1504, 1000
     raw = synth.bayer_mosaic(w, h, seed=21).astype(np.float32)
     cfa = ((raw - 512) / np.float32(synth.WHITE - 512) * np.float32(1.7)).astype(np.float32)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where a workgroup of amaze_tiles spends its cycles (run on the GPU box): the measuring build (ANSEL_HIP_AMAZE_TIMED)
-prints the cycles between the stage stamps, averaged over the tiles; then the plain kernel is timed.
+"""Where the AMaZE workgroups spend their cycles (run on the GPU box): the measuring builds (ANSEL_HIP_AMAZE_TIMED) print the
+cycles between the barriers of a step of amaze_stream (the full tiles, on chip: `[amaze_stream_timed] phase k`) and between
+the stage stamps of amaze_tiles (the tiles the frame cuts: `[amaze_timed] stamp k`), averaged over the tiles; then the plain
+launch is timed.
 
     python tools/amaze_stage_clocks.py [WxH]"""
 import ctypes as C
