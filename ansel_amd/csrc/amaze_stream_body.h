@@ -30,8 +30,8 @@
 //     flag plane lives in cddiffsq's bytes and is cleared / written for tile rows 4..155 only, so the area weights of rows
 //     150 and 151 read, as flags of rows 156 and 157, the BYTES of the squared colour differences of tile row 19, columns
 //     80..119 (profiles/r03_amaze_alias_probe.txt, bit 16).  Those 80 floats are kept aside when row 19 passes.
-// Tiles the frame cuts (the last tile row / column: shorter planes, mirrored fills that overrun into the flag bytes, more
-// sharings in reach of the kept pixels) stay with amaze_tiles.
+// Tiles the frame cuts (the last tile row / column) are shorter / narrower planes with mirrored strips; the two kinds of them
+// that a top-to-bottom walk cannot reproduce (stream_tile_ok()) stay with the first kernel's body.
 #pragma once
 #include <stdint.h>
 #include <math.h>
@@ -39,6 +39,7 @@
 #ifndef AMZ_FN
 #define AMZ_FN static inline
 #define AMZ_MEMBER static inline
+#define AMZ_HD static inline // ... called from the launch code as well
 #endif
 
 namespace amz
@@ -203,15 +204,36 @@ AMZ_FN float chain_bound(float h, const float before, const float here, const fl
   return h;
 }
 
-// One full tile (160 x 160, none of it cut by the frame's bottom or right edge; the mirrored top / left border included).
-// All NT threads of the workgroup call this with the same arguments.
+// The tiles this kernel takes: all but those whose mirrored right strip (16 columns from ccmax) or bottom strip (16 rows from
+// rrmax) runs past the 160 x 160 plane -- the right one wraps into the next row, the bottom one into the flag bytes behind the
+// plane in the reference's buffer, and flags nobody raised break the argument that the Nyquist refinement needs no tile-wide
+// state (see the header).  Those tiles, and the one below, keep the first kernel's body.
+AMZ_HD bool stream_tile_ok(const int width, const int height, const int top, const int left)
+{
+  const int bottom = top + TS < height + 16 ? top + TS : height + 16, right = left + TS < width + 16 ? left + TS : width + 16;
+  const int rrmax = bottom > height ? height - top : bottom - top, ccmax = right > width ? width - left : right - left;
+  if((rrmax < bottom - top && rrmax > TS - 16) || (ccmax < right - left && ccmax > TS - 16)) return false;
+  // a narrower tile of odd width: the split of the two colour differences (amaze.cc:1239-1244) stops one R/B site short of what
+  // the last kept column's chrominance reads, and that word of the G - B plane still holds the alternative colour difference
+  // of a tile row further down (the planes share memory): not something a top-to-bottom walk has at hand
+  return !(right - left < TS && ((right - left) & 1));
+}
+
+// One tile.  All NT threads of the workgroup call this with the same arguments.
 template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, const args &a, const int top, const int left)
 {
   const int tid = env.tid();
   const int width = a.width;
   const uint32_t filters = a.filters;
   const float clip_pt = a.clip_pt, clip_pt8 = 0.8f * a.clip_pt;
+  // the tile in the frame, amaze.cc:339-350: rr1 x cc1 photosites of which rows [rrmin, rrmax) and columns [ccmin, ccmax) lie in
+  // the frame, the rest (16 at a frame edge) is mirrored
+  const int height = a.height;
+  const int bottom = top + TS < height + 16 ? top + TS : height + 16, right = left + TS < width + 16 ? left + TS : width + 16;
+  const int rr1 = bottom - top, cc1 = right - left;
   const int rrmin = top < 0 ? 16 : 0, ccmin = left < 0 ? 16 : 0;
+  const int rrmax = bottom > height ? height - top : rr1, ccmax = right > width ? width - left : cc1;
+  const int steps = rr1 > 32 ? (rr1 - 17 + L_S14) / R + 1 : 0; // the last kept row is rr1 - 17
 
 #define LD(P, r, c) env.ldf(P::idx((r), (c)), (r))
 #define ST(P, r, c, v) env.stf(P::idx((r), (c)), (r), (v))
@@ -239,10 +261,14 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
         _once && rr >= 0 && rr < TS; _once = 0)
 
   static_assert(NT == R * TS, "one photosite of the step's rows per thread");
-  // tile rows from the mosaic, amaze.cc:352-460 (top / left border mirrored; the corner's own rule)
+  // tile rows from the mosaic, amaze.cc:352-460: the nine fills of the reference as one function of the photosite -- they do
+  // not overlap in the tiles this kernel takes (stream_tile_ok()).  A strip mirrors about the frame edge, a corner about
+  // row / column 32 of the FRAME on the side of a top / left edge (the reference's own rule); what no fill reaches stays 0
   auto mosaic = [&](const int rr, const int cc) -> float {
-    if(rr < rrmin && cc < ccmin) return in[(size_t)(32 - rr) * width + (32 - cc)];
-    const int row = rr < rrmin ? 32 - rr + top : rr + top, col = cc < ccmin ? 32 - cc + left : cc + left;
+    const bool r0 = rr < rrmin, r2 = rr >= rrmax, c0 = cc < ccmin, c2 = cc >= ccmax;
+    if((r2 && rr >= rrmax + 16) || (c2 && cc >= ccmax + 16)) return 0.f;
+    const int row = r0 ? ((c0 || c2) ? 32 - rr : 32 - rr + top) : (r2 ? height - (rr - rrmax) - 2 : rr + top);
+    const int col = c0 ? ((r0 || r2) ? 32 - cc : 32 - cc + left) : (c2 ? width - (cc - ccmax) - 2 : cc + left);
     return in[(size_t)row * width + col];
   };
   float pre = mosaic(tid / TS, tid % TS);
@@ -250,7 +276,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
   for(int k = tid; k < LDS_BYTES / 4; k += NT) env.zero(k);
   env.sync();
 
-  for(int s = 0; s < STEPS; s++)
+  for(int s = 0; s < steps; s++)
   {
     // ---- phase 1: the step's tile rows
     {
@@ -266,7 +292,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     FOR_FULL(L_S1)
     {
       float v0 = 0.f, v1 = 0.f;
-      if(IN_(rr, 2, TS - 2) && IN_(cc, 2, TS - 2))
+      if(IN_(rr, 2, rr1 - 2) && IN_(cc, 2, cc1 - 2))
       {
         const float c0 = LD(P_CFA, rr, cc);
         const float delh = fabsf(LD(P_CFA, rr, cc + 1) - LD(P_CFA, rr, cc - 1));
@@ -284,7 +310,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     FOR_FULL(L_S2)
     {
       float v = 0.f, hd = 0.f, va = 0.f, ha = 0.f, gv = 0.f, gh = 0.f;
-      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      if(IN_(rr, 4, rr1 - 4) && IN_(cc, 4, cc1 - 4))
       {
         const bool gsite = fct(rr, cc, filters) & 1;
         const float c = LD(P_CFA, rr, cc);
@@ -354,11 +380,11 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     for(int _k = tid; _k < 2 * TS; _k += NT)
     {
       const int cc = _k % TS, par = _k / TS;
-      if(!IN_(cc, 4, TS - 4)) continue;
+      if(!IN_(cc, 4, cc1 - 4)) continue;
       for(int j = 0; j < R / 2; j++)
       {
         const int rr = s * R - L_S3V + par + 2 * j;
-        if(!IN_(rr, 4, TS - 4)) continue;
+        if(!IN_(rr, 4, rr1 - 4)) continue;
         const bool gsite = fct(rr, cc, filters) & 1;
         const float prev = LD(P_VCD, rr - 2, cc), c0 = LD(P_VCD, rr, cc), c1 = LD(P_VCD, rr + 2, cc);
         const float a0 = LD(P_VCDALT, rr - 2, cc), a1 = LD(P_VCDALT, rr, cc), a2 = LD(P_VCDALT, rr + 2, cc);
@@ -368,7 +394,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     }
     FOR_FULL_UPPER(L_S2)
     {
-      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      if(IN_(rr, 4, rr1 - 4) && IN_(cc, 4, cc1 - 4))
       {
         const bool gsite = fct(rr, cc, filters) & 1;
         const float before = LD(P_CFA, rr, cc - 1), here = LD(P_CFA, rr, cc), after = LD(P_CFA, rr, cc + 1);
@@ -385,12 +411,12 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     FOR_RB(L_S4)
     {
       const float v0 = LD(P_VCD, rr, cc), h0 = LD(P_HCDH, rr, h);
-      const float cd = (IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4)) ? sqr(v0 - h0) : 0.f;
+      const float cd = (IN_(rr, 4, rr1 - 4) && IN_(cc, 4, cc1 - 4)) ? sqr(v0 - h0) : 0.f;
       ST(P_CDD, rr, h, cd);
       ST(P_VCDH, rr, h, v0);
       if(rr == 19 && cc >= TSH) env.stf(CDD19 + cc - TSH, -1, cd);
       float w = 0.f;
-      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
+      if(IN_(rr, 6, rr1 - 6) && IN_(cc, 6, cc1 - 6))
       {
         const float v1 = LD(P_VCD, rr - 1, cc), v2 = LD(P_VCD, rr - 2, cc), v3 = LD(P_VCD, rr - 3, cc);
         const float w1 = LD(P_VCD, rr + 1, cc), w2 = LD(P_VCD, rr + 2, cc), w3 = LD(P_VCD, rr + 3, cc);
@@ -419,7 +445,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     }
     FOR_FULL_UPPER(L_S2)
     {
-      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      if(IN_(rr, 4, rr1 - 4) && IN_(cc, 4, cc1 - 4))
       {
         const float c0 = LD(P_HCD, rr, cc), c1 = LD(P_HCD, rr, cc + 2);
         const float altvar = cdvar3(LD(P_HCDALT, rr, cc - 2), LD(P_HCDALT, rr, cc), LD(P_HCDALT, rr, cc + 2));
@@ -444,7 +470,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     FOR_RB(L_S5)
     {
       unsigned char flag = 0;
-      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
+      if(IN_(rr, 6, rr1 - 6) && IN_(cc, 6, cc1 - 6))
       {
         const float gg0 = 0.5f * 0.07384411893421103f, gg1 = 0.5f * 0.06207511968171489f, gg2 = 0.5f * 0.0521818194747806f;
         const float gg3 = 0.5f * 0.03687419286733595f, gg4 = 0.5f * 0.03099732204057846f, gg5 = 0.5f * 0.018413194161458882f;
@@ -467,7 +493,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     }
     FOR_FULL_UPPER(L_S2)
     {
-      if(IN_(rr, 4, TS - 4) && IN_(cc, 4, TS - 4))
+      if(IN_(rr, 4, rr1 - 4) && IN_(cc, 4, cc1 - 4))
       {
         unsigned inv = 0, bits;
         for(int j = cc;; j -= 2)
@@ -489,7 +515,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     FOR_RB(L_S6)
     {
       unsigned char f2 = 0;
-      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
+      if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8))
       {
 #define NY(dr, dc) LDB(P_NY, rr + (dr), (cc + (dc)) >> 1)
         const unsigned n = NY(-2, 0) + NY(-1, -1) + NY(-1, 1) + NY(0, -2) + NY(0, 2) + NY(1, -1) + NY(1, 1) + NY(2, 0);
@@ -506,7 +532,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       if(rr < 0 || rr >= TS) continue;
       float vp = 0.f, vm = 0.f, sp = 0.f, sm = 0.f;
       const int c2 = 2 * hh; // the even column of the pair
-      if(IN_(rr, 6, TS - 6) && IN_(c2, 6, TS - 6))
+      if(IN_(rr, 6, rr1 - 6) && IN_(c2, 6, cc1 - 6))
       {
         const bool odd = fct(rr, 2, filters) & 1;
         const int ga = odd ? c2 + 1 : c2, sb = odd ? c2 : c2 + 1; // gradients at the green site of the pair, squares at the other
@@ -528,7 +554,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       const int cc = (fct(rr, 2, filters) & 1) + 2 * h;
       const float h0 = LD(P_HCD, rr, cc);
       ST(P_HCDH, rr, h, h0);
-      if(IN_(rr, 6, TS - 6) && IN_(cc, 6, TS - 6))
+      if(IN_(rr, 6, rr1 - 6) && IN_(cc, 6, cc1 - 6))
       {
         const float l1 = LD(P_HCD, rr, cc - 1), l2 = LD(P_HCD, rr, cc - 2), l3 = LD(P_HCD, rr, cc - 3);
         const float r1 = LD(P_HCD, rr, cc + 1), r2 = LD(P_HCD, rr, cc + 2), r3 = LD(P_HCD, rr, cc + 3);
@@ -550,7 +576,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     // ---- phase 8: area interpolation of the weight in flagged regions, :850-890.  Upper half: diagonal R/B estimates, :986-1107
     FOR_RB(L_INT)
     {
-      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8) && LDB(P_NY2, rr, h))
+      if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8) && LDB(P_NY2, rr, h))
       {
         float sumcfa = 0.f, sumh = 0.f, sumv = 0.f, sumsqh = 0.f, sumsqv = 0.f, areawt = 0.f;
         for(int p = -6; p < 7; p += 2)
@@ -578,7 +604,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     FOR_RB2(L_RB)
     {
       float pw = 0.f, vp = 0.f, vm = 0.f;
-      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
+      if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8))
       {
         const float ge0 = 0.13719494435797422f, ge1 = 0.05640252782101291f;
         const float c = LD(P_CFA, rr, cc);
@@ -648,7 +674,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       for(int j = 0; j < R; j++)
       {
         const int rr = s * R - L_VOTE + j;
-        if(IN_(rr, 8, TS - 8) && tid < TSH / 2)
+        if(IN_(rr, 8, rr1 - 8) && tid < TSH / 2)
         {
           // two sites per lane, everything fetched before anything is stored: one LDS round trip per row
           const int q = fct(rr, 2, filters) & 1, ha = 2 * tid, hb = ha + 1, ca = q + 2 * ha, cb = ca + 2;
@@ -657,8 +683,8 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
           const float b0 = LD(P_HVWT, rr + 1, hl), b1 = LD(P_HVWT, rr + 1, (ca + 1) >> 1), b2 = LD(P_HVWT, rr + 1, hr);
           const float wa = LD(P_HVWT, rr, ha), wb = LD(P_HVWT, rr, hb);
           const float alta = xdivf(a0 + a1 + b0 + b1, 2), altb = xdivf(a1 + a2 + b1 + b2, 2);
-          if(IN_(ca, 8, TS - 8)) ST(P_HVWT, rr, ha, fabsf(0.5f - wa) < fabsf(0.5f - alta) ? alta : wa);
-          if(IN_(cb, 8, TS - 8)) ST(P_HVWT, rr, hb, fabsf(0.5f - wb) < fabsf(0.5f - altb) ? altb : wb);
+          if(IN_(ca, 8, cc1 - 8)) ST(P_HVWT, rr, ha, fabsf(0.5f - wa) < fabsf(0.5f - alta) ? alta : wa);
+          if(IN_(cb, 8, cc1 - 8)) ST(P_HVWT, rr, hb, fabsf(0.5f - wb) < fabsf(0.5f - altb) ? altb : wb);
         }
         env.wave_sync();
       }
@@ -673,7 +699,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
           const int q = fct(rr, 2, filters) & 1, ha = 2 * lane, hb = ha + 1, ca = q + 2 * ha, cb = ca + 2;
           const int hl = ca > 0 ? (ca - 1) >> 1 : 0, hr = cb + 1 < TS ? (cb + 1) >> 1 : TSH - 1;
           float rba = 0.f, rbb = 0.f;
-          if(IN_(rr, 10, TS - 10))
+          if(IN_(rr, 10, rr1 - 10))
           {
             const float a0 = LD(P_PMWT, rr - 1, hl), a1 = LD(P_PMWT, rr - 1, (ca + 1) >> 1), a2 = LD(P_PMWT, rr - 1, hr);
             const float b0 = LD(P_PMWT, rr + 1, hl), b1 = LD(P_PMWT, rr + 1, (ca + 1) >> 1), b2 = LD(P_PMWT, rr + 1, hr);
@@ -681,7 +707,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
             const float ma = LD(P_RBM, rr, ha), pa = LD(P_RBP, rr, ha), mb = LD(P_RBM, rr, hb), pb = LD(P_RBP, rr, hb);
             const float fa = LD(P_CFA, rr, ca), fb = LD(P_CFA, rr, cb);
             const float alta = xdivf(a0 + a1 + b0 + b1, 2), altb = xdivf(a1 + a2 + b1 + b2, 2);
-            if(IN_(ca, 10, TS - 10))
+            if(IN_(ca, 10, cc1 - 10))
             {
               if(fabsf(0.5f - wa) < fabsf(0.5f - alta))
               {
@@ -690,7 +716,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
               }
               rba = xdiv2f(fa + ma * (1.f - wa) + pa * wa);
             }
-            if(IN_(cb, 10, TS - 10))
+            if(IN_(cb, 10, cc1 - 10))
             {
               if(fabsf(0.5f - wb) < fabsf(0.5f - altb))
               {
@@ -711,7 +737,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       for(int rr = s * R - L_DQ + _k / TS, cc = _k % TS, _once = 1; _once && rr >= 0 && rr < TS; _once = 0)
     {
       float v = 0.f;
-      if(IN_(rr, 2, TS - 2) && IN_(cc, 2, TS - 2))
+      if(IN_(rr, 2, rr1 - 2) && IN_(cc, 2, cc1 - 2))
       {
         const float delh = fabsf(LD(P_CFA, rr, cc + 1) - LD(P_CFA, rr, cc - 1));
         const float delv = fabsf(LD(P_CFA, rr + 1, cc) - LD(P_CFA, rr - 1, cc));
@@ -727,7 +753,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     {
       const float c = LD(P_CFA, rr, cc);
       float g = c, dg = 0.f, ch = 0.f, cv = 0.f;
-      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8))
+      if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8))
       {
         dg = intp(LD(P_HVWT, rr, h), LD(P_VCDH, rr, h), LD(P_HCDH, rr, h));
         g = c + dg;
@@ -749,7 +775,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     //      better, green from R + B, :1129-1236 (it overrides S8 at a site that takes both)
     FOR_RB(L_S8)
     {
-      if(IN_(rr, 8, TS - 8) && IN_(cc, 8, TS - 8) && LDB(P_NY2, rr, h))
+      if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8) && LDB(P_NY2, rr, h))
       {
         const float q0 = 0.169917f, q1 = 0.108947f, q2 = 0.069855f, q3 = 0.0287182f;
 #define QUINC(P)                                                                                                         \
@@ -763,7 +789,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
         ST(P_DGO, rr, h, dg);
         ST(P_GREEN, rr, h, LD(P_CFA, rr, cc) + dg);
       }
-      if(IN_(rr, 12, TS - 12) && IN_(cc, 12, TS - 12))
+      if(IN_(rr, 12, rr1 - 12) && IN_(cc, 12, cc1 - 12))
       {
         const float pm = LD(P_PMWT, rr, h), hv = LD(P_HVWT, rr, h);
         if(!(fabsf(0.5f - pm) < fabsf(0.5f - hv)))
@@ -826,7 +852,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     FOR_RB(L_S13)
     {
       float v = 0.f;
-      if(IN_(rr, 14, TS - 14) && IN_(cc, 14, TS - 14))
+      if(IN_(rr, 14, rr1 - 14) && IN_(cc, 14, cc1 - 14))
       {
 #define D(dr, dc) LD(P_DGO, rr + (dr), (cc + (dc)) >> 1)
         const float nw1 = D(-1, -1), nw3 = D(-3, -3), se1 = D(1, 1), se3 = D(3, 3);
@@ -850,7 +876,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     // ---- phase 13: S14 output, :1278-1411 (alpha is left as it is)
     FOR_FULL(L_S14)
     {
-      if(IN_(rr, 16, TS - 16) && IN_(cc, 16, TS - 16))
+      if(IN_(rr, 16, rr1 - 16) && IN_(cc, 16, cc1 - 16) && rr + top < height && cc + left < width)
       {
         float *const o = out + 4 * ((size_t)(rr + top) * width + (cc + left));
         const int col = fct(rr, cc, filters);

@@ -16,8 +16,8 @@
 //   S7 / S10  diagonal-neighbour votes on the H/V and +/- weights: row r reads row r-1 already
 //       voted -- the plane is staged in LDS and the rows are walked with one barrier per row.
 //
-// Round 3: the full tiles of a frame -- all but its last tile row and column -- run in amaze_stream, which keeps every
-// plane in LDS (amaze_stream_body.h); amaze_tiles keeps the tiles the frame cuts.
+// Round 3: amaze_stream keeps every plane of a tile in LDS (amaze_stream_body.h); the body below stays for the few kinds of
+// cut tile that kernel refuses (amz::stream_tile_ok()), drawn from the same queue in the same launch (amaze_frame).
 #include "hip_common.h"
 
 #include <math.h>
@@ -26,6 +26,7 @@
 
 #define AMZ_FN __device__ __forceinline__
 #define AMZ_MEMBER static __device__ __forceinline__
+#define AMZ_HD __host__ __device__ __forceinline__
 #include "amaze_stream_body.h"
 
 using namespace ansel;
@@ -103,7 +104,7 @@ struct amaze_args
   uint32_t filters;
   int ex, ey;
   float clip_pt;
-  int nsx, nsy; // tiles [0, nsx) x [0, nsy) of the grid are amaze_stream's; ntiles counts the others
+  int slab_all; // the first kernel's body for every tile (ANSEL_HIP_AMAZE_SLAB); else only for those amz::stream_tile_ok() refuses
 };
 
 #define EPS 1e-5f
@@ -177,7 +178,8 @@ __device__ __forceinline__ float chain_site(const float prev, const float c0, co
 #define N_STAMPS 20
 template <bool TIMED>
 __device__ __forceinline__ void slab_tile(const float *__restrict__ in, float *__restrict__ out, float *const B, const amaze_args &a,
-                                          const int tile, float *const vote, int *const nyq, unsigned long long *__restrict__ stamps)
+                                          const int top, const int left, float *const vote, int *const nyq,
+                                          unsigned long long *__restrict__ stamps)
 {
   long long t_prev = 0;
 #define STAMP(k)                                                           \
@@ -205,11 +207,6 @@ __device__ __forceinline__ void slab_tile(const float *__restrict__ in, float *_
   const float *const d0 = dirwts0, *const d1 = dirwts1;
 
   {
-    // the tiles right of amaze_stream's, then the tile rows below them
-    const int right_cols = a.ntx - a.nsx, right_tiles = right_cols * a.nsy;
-    const int ty = tile < right_tiles ? tile / right_cols : a.nsy + (tile - right_tiles) / a.ntx;
-    const int tx = tile < right_tiles ? a.nsx + tile % right_cols : (tile - right_tiles) % a.ntx;
-    const int top = -16 + ty * (TS - 32), left = -16 + tx * (TS - 32);
     const int bottom = min(top + TS, height + 16), right = min(left + TS, width + 16);
     const int rr1 = bottom - top, cc1 = right - left;
     const int rrmin = top < 0 ? 16 : 0, ccmin = left < 0 ? 16 : 0;
@@ -789,7 +786,11 @@ __global__ __launch_bounds__(SLAB_THREADS) void amaze_tiles(const float *__restr
   __shared__ float vote[TS * TSH];
   __shared__ int nyq[4];
   float *const B = slabs + (size_t)blockIdx.x * O_END;
-  for(int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) slab_tile<TIMED>(in, out, B, a, tile, vote, nyq, stamps);
+  for(int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x)
+  {
+    const int top = -16 + (tile / a.ntx) * (TS - 32), left = -16 + (tile % a.ntx) * (TS - 32);
+    if(a.slab_all || !amz::stream_tile_ok(a.width, a.height, top, left)) slab_tile<TIMED>(in, out, B, a, top, left, vote, nyq, stamps);
+  }
 }
 
 // ---- the full tiles, on chip
@@ -841,7 +842,7 @@ struct stream_env_timed : stream_env
 
 template <bool TIMED>
 __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_stream(const float *__restrict__ in, float *__restrict__ out, const amz::args a,
-                                                        const int nsx, const int ntiles, unsigned long long *__restrict__ stamps)
+                                                        const int ntx, const int ntiles, unsigned long long *__restrict__ stamps)
 {
   extern __shared__ __attribute__((aligned(16))) float amz_lds[];
   if(TIMED)
@@ -852,8 +853,10 @@ __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_stream(const float 
     for(int k = 0; k < 16; k++) env.acc[k] = 0;
     for(int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     {
+      const int top = -16 + (tile / ntx) * (TS - 32), left = -16 + (tile % ntx) * (TS - 32);
+      if(!amz::stream_tile_ok(a.width, a.height, top, left)) continue;
       env.t_prev = (long long)__builtin_readcyclecounter();
-      amz::tile(env, in, out, a, -16 + (tile / nsx) * (TS - 32), -16 + (tile % nsx) * (TS - 32));
+      amz::tile(env, in, out, a, top, left);
     }
     if(threadIdx.x == 0)
 #pragma unroll
@@ -863,13 +866,17 @@ __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_stream(const float 
   {
     stream_env env{ amz_lds };
     for(int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-      amz::tile(env, in, out, a, -16 + (tile / nsx) * (TS - 32), -16 + (tile % nsx) * (TS - 32));
+    {
+      const int top = -16 + (tile / ntx) * (TS - 32), left = -16 + (tile % ntx) * (TS - 32);
+      if(amz::stream_tile_ok(a.width, a.height, top, left)) amz::tile(env, in, out, a, top, left);
+    }
   }
 }
 
-// ---- one launch for the frame: the workgroups draw tiles from a queue, the tiles the frame cuts first (slab_tile: the vote
-//      plane in the first 50 KB of the LDS block the streaming tiles use whole), then the full ones.  A workgroup per CU
-//      either way; drawn, not dealt, because the two kinds of tile do not take the same time
+// ---- one launch for the frame: the workgroups draw tiles from a queue, last tile first -- the tiles amz::stream_tile_ok()
+//      refuses lie in the last tile row / column and take the first kernel's body (slab_tile: the vote plane in the first
+//      50 KB of the LDS block the other tiles use whole).  A workgroup per CU either way; drawn, not dealt, because the two
+//      kinds of tile do not take the same time
 __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_frame(const float *__restrict__ in, float *__restrict__ out,
                                                                    float *__restrict__ slabs, const amaze_args a, const amz::args sa,
                                                                    unsigned int *__restrict__ queue)
@@ -879,21 +886,19 @@ __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_frame(const float *
   __shared__ unsigned int drawn;
   stream_env env{ amz_lds };
   float *const B = slabs + (size_t)blockIdx.x * O_END;
-  const unsigned int items = (unsigned int)(a.ntiles + a.nsx * a.nsy);
   for(;;)
   {
     if(threadIdx.x == 0) drawn = atomicAdd(queue, 1u);
     __syncthreads();
     const unsigned int item = drawn;
     __syncthreads();
-    if(item >= items) break;
-    if(item < (unsigned int)a.ntiles)
-      slab_tile<false>(in, out, B, a, (int)item, amz_lds, nyq, nullptr);
+    if(item >= (unsigned int)a.ntiles) break;
+    const int tile = a.ntiles - 1 - (int)item;
+    const int top = -16 + (tile / a.ntx) * (TS - 32), left = -16 + (tile % a.ntx) * (TS - 32);
+    if(amz::stream_tile_ok(a.width, a.height, top, left))
+      amz::tile(env, in, out, sa, top, left);
     else
-    {
-      const int t = (int)item - a.ntiles;
-      amz::tile(env, in, out, sa, -16 + (t / a.nsx) * (TS - 32), -16 + (t % a.nsx) * (TS - 32));
-    }
+      slab_tile<false>(in, out, B, a, top, left, amz_lds, nyq, nullptr);
   }
 }
 
@@ -930,11 +935,15 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   a.clip_pt = fminf(piece->processed_maximum[0], fminf(piece->processed_maximum[1], piece->processed_maximum[2]));
   a.ntx = (width + 16 + (TS - 32) - 1) / (TS - 32);
   const int nty = (height + 16 + (TS - 32) - 1) / (TS - 32);
-  // the tiles that lie in the frame whole (top + 160 <= height, left + 160 <= width) go to amaze_stream
-  a.nsx = width >= TS - 16 ? (width - (TS - 16)) / (TS - 32) + 1 : 0;
-  a.nsy = height >= TS - 16 ? (height - (TS - 16)) / (TS - 32) + 1 : 0;
-  if(getenv("ANSEL_HIP_AMAZE_SLAB") || a.nsx == 0 || a.nsy == 0) a.nsx = a.nsy = 0; // the first kernel for every tile
-  a.ntiles = a.ntx * nty - a.nsx * a.nsy;
+  a.ntiles = a.ntx * nty;
+  a.slab_all = getenv("ANSEL_HIP_AMAZE_SLAB") != nullptr;
+  // which tiles keep every plane on chip (amaze_stream_body.h): all but some of the last tile row / column
+  int stream_tiles = 0;
+  if(!a.slab_all)
+    for(int ty = 0; ty < nty; ty++)
+      for(int tx = 0; tx < a.ntx; tx++)
+        if(amz::stream_tile_ok(width, height, -16 + ty * (TS - 32), -16 + tx * (TS - 32))) stream_tiles++;
+  const int slab_tiles = a.ntiles - stream_tiles;
   hipStream_t s = stream_of(devid);
   const bool timed = getenv("ANSEL_HIP_AMAZE_TIMED") != nullptr;
   const bool unfused = timed || getenv("ANSEL_HIP_AMAZE_UNFUSED") != nullptr; // one kernel per kind of tile: for measurements
@@ -945,7 +954,6 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   sa.ex = a.ex;
   sa.ey = a.ey;
   sa.clip_pt = a.clip_pt;
-  const int stream_tiles = a.nsx * a.nsy;
   if(stream_tiles > 0)
   {
     // the opt-in to more than 64 KB of LDS is per device
@@ -963,11 +971,11 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   // one workgroup per CU: the LDS of a CU each (ANSEL_HIP_AMAZE_BLOCKS: fewer, so that the tests see a workgroup walk many tiles)
   const char *const sb_env = getenv("ANSEL_HIP_AMAZE_STREAM_BLOCKS") ? getenv("ANSEL_HIP_AMAZE_STREAM_BLOCKS") : getenv("ANSEL_HIP_AMAZE_BLOCKS");
   const int sb_max = sb_env && atoi(sb_env) > 0 ? atoi(sb_env) : 256;
-  if(stream_tiles > 0 && !unfused)
+  if(stream_tiles > 0 && slab_tiles > 0 && !unfused)
   {
-    const int items = stream_tiles + a.ntiles, blocks = items < sb_max ? items : sb_max;
-    // a slab per workgroup that may draw a cut tile: all of them
-    float *slabs = (float *)dt_hip_alloc_device_buffer(devid, (size_t)(a.ntiles > 0 ? blocks : 1) * O_END * sizeof(float));
+    const int blocks = a.ntiles < sb_max ? a.ntiles : sb_max;
+    // a slab per workgroup: any of them may draw a tile of the first kind
+    float *slabs = (float *)dt_hip_alloc_device_buffer(devid, (size_t)blocks * O_END * sizeof(float));
     unsigned int *queue = (unsigned int *)dt_hip_alloc_device_buffer(devid, 256);
     int rc = DT_HIP_SUCCESS;
     if(!slabs || !queue)
@@ -986,7 +994,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   }
   if(stream_tiles > 0)
   {
-    const int sblocks = stream_tiles < sb_max ? stream_tiles : sb_max;
+    const int sblocks = a.ntiles < sb_max ? a.ntiles : sb_max;
     if(timed)
     {
       unsigned long long *stamps = (unsigned long long *)dt_hip_alloc_device_buffer(devid, sizeof(unsigned long long) * 32);
@@ -994,7 +1002,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
       unsigned long long host[32];
       if(hipMemsetAsync(stamps, 0, sizeof(host), s) == hipSuccess)
       {
-        amaze_stream<true><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.nsx, stream_tiles, stamps);
+        amaze_stream<true><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.ntx, a.ntiles, stamps);
         if(hipMemcpyAsync(host, stamps, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
           for(int k = 0; k < 16; k++)
             fprintf(stderr, "[amaze_stream_timed] phase %d cycles_per_tile %llu\n", k, host[k] / (unsigned long long)stream_tiles);
@@ -1004,11 +1012,11 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
     else
     {
       launch_scope ls(devid, "amaze_stream");
-      amaze_stream<false><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.nsx, stream_tiles, nullptr);
+      amaze_stream<false><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.ntx, a.ntiles, nullptr);
     }
     const int rc = check_launch("amaze_stream");
     if(rc != DT_HIP_SUCCESS) return rc;
-    if(a.ntiles == 0) return DT_HIP_SUCCESS;
+    if(slab_tiles == 0) return DT_HIP_SUCCESS;
   }
   // two 512-thread workgroups per CU (the vote plane is 50 KiB of LDS each)
   const char *const blocks_env = getenv("ANSEL_HIP_AMAZE_BLOCKS");
@@ -1030,7 +1038,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
     {
       amaze_tiles<true><<<blocks, SLAB_THREADS, 0, s>>>(in, (float *)out, slabs, a, stamps);
       if(hipMemcpyAsync(host, stamps, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
-        for(int k = 0; k < 14; k++) fprintf(stderr, "[amaze_timed] stamp %d cycles_per_tile %llu\n", k, host[k] / (unsigned long long)a.ntiles);
+        for(int k = 0; k < 14; k++) fprintf(stderr, "[amaze_timed] stamp %d cycles_per_tile %llu\n", k, host[k] / (unsigned long long)(slab_tiles > 0 ? slab_tiles : 1));
     }
     dt_hip_release_mem_object(stamps);
   }

@@ -162,7 +162,7 @@ void fiber(const int t)
 
 extern "C" int amaze_host_lds_bytes(void) { return amz::LDS_BYTES; }
 
-// Runs the kernel body over every full tile of the frame (the tiles amaze_stream takes; the pixels of the other tiles are
+// Runs the kernel body over every tile of the frame that amz::stream_tile_ok() admits (the pixels of the other tiles are
 // left as they are in `out`).  Returns the number of schedule errors (0 = none), the first one as text in err.
 extern "C" int amaze_host_run(const float *in, float *out, int width, int height, uint32_t filters, float clip_pt,
                               int *stream_tiles, int *all_tiles, char *err, int errlen)
@@ -193,7 +193,7 @@ extern "C" int amaze_host_run(const float *in, float *out, int width, int height
       const int top = -16 + ty * (amz::TS - 32), left = -16 + tx * (amz::TS - 32);
       if(!(top < height && left < width)) continue;
       all++;
-      if(top + amz::TS <= height && left + amz::TS <= width) sh.tiles.push_back({ top, left });
+      if(amz::stream_tile_ok(width, height, top, left)) sh.tiles.push_back({ top, left });
     }
   if(stream_tiles) *stream_tiles = (int)sh.tiles.size();
   if(all_tiles) *all_tiles = all;

@@ -1,7 +1,8 @@
 """The gfx950 kernel that keeps an AMaZE tile on chip (ansel_amd/csrc/amaze_stream_body.h, launched as amaze_frame /
 amaze_stream) compiled for the HOST (tests/native/amaze_host.cpp): a workgroup is 640 fibers run from barrier to barrier,
 its LDS a heap block with a shadow that flags every race and every ring slot read after it was overwritten.  Against the
-oracle, bit for bit, on every full tile of the frame -- the tiles the frame cuts belong to the first kernel.  The same
+oracle, bit for bit, on every tile the kernel takes -- all but those of a frame's last tile row / column whose mirrored strips
+overrun their plane or whose width is odd (amz::stream_tile_ok()), which belong to the first kernel.  The same
 source runs on the device; this pins its schedule (lags, ring depths, the thread halves that share a phase, the votes a single
 wave walks) without a GPU.  The -m gpu tests then only have to show that the device executes it the same."""
 import ctypes as C
@@ -66,15 +67,40 @@ def oracle(cfa, filters, pm):
     return want
 
 
-def check(lib, cfa, filters, pm=(1.5, 1.0, 1.2, 1.0)):
+def stream_tile_ok(w, h, top, left):
+    """amz::stream_tile_ok(), restated"""
+    bottom, right = min(top + TS, h + 16), min(left + TS, w + 16)
+    rrmax = h - top if bottom > h else bottom - top
+    ccmax = w - left if right > w else right - left
+    if (rrmax < bottom - top and rrmax > TS - 16) or (ccmax < right - left and ccmax > TS - 16):
+        return False
+    return not (right - left < TS and (right - left) & 1)
+
+
+def kept_pixels(w, h):
+    """the pixels the tiles of the on-chip kernel write, and how many tiles those are / there are"""
+    mask = np.zeros((h, w), bool)
+    ok = n = 0
+    for top in range(-16, h, TS - 32):
+        for left in range(-16, w, TS - 32):
+            n += 1
+            if stream_tile_ok(w, h, top, left):
+                ok += 1
+                bottom, right = min(top + TS, h + 16), min(left + TS, w + 16)
+                mask[max(top + 16, 0):max(min(bottom - 16, h), 0), max(left + 16, 0):max(min(right - 16, w), 0)] = True
+    return mask, ok, n
+
+
+def check(lib, cfa, filters, pm=(1.5, 1.0, 1.2, 1.0), all_tiles=None):
     h, w = cfa.shape
     got, ne, err, ns, na = run(lib, cfa, filters, pm)
     assert ne == 0, "%d schedule errors, the first: %s" % (ne, err)
-    nsx, nsy = (w - (TS - 16)) // (TS - 32) + 1, (h - (TS - 16)) // (TS - 32) + 1
-    assert ns == nsx * nsy and na > ns
+    mask, ok, n = kept_pixels(w, h)
+    assert (ns, na) == (ok, n)
+    if all_tiles is not None:
+        assert (ok == n) == all_tiles
     written = got[..., 0] != -7.0
-    # the full tiles keep rows / columns [0, 128 n) of the frame
-    assert written[:128 * nsy, :128 * nsx].all() and not written[128 * nsy:].any() and not written[:, 128 * nsx:].any()
+    assert np.array_equal(written, mask)
     assert (got[..., 3] == -7.0).all()  # alpha is not written
     want = oracle(cfa, filters, pm)
     diff = (ck.ulp_diff(got, want) > 0) & written[..., None]
@@ -83,8 +109,18 @@ def check(lib, cfa, filters, pm=(1.5, 1.0, 1.2, 1.0)):
 
 @pytest.mark.parametrize("filters", [0x94949494, 0x49494949, 0x61616161, 0x16161616])
 def test_streaming_tiles_equal_the_oracle(host_kernel, filters):
-    """6 full tiles (the mirrored top / left border and its corner among them), every CFA phase"""
-    check(host_kernel, textured(517, 389, seed=906), filters)
+    """a frame of odd size: 9 of its 20 tiles (the mirrored top / left border and its corner, the bottom tile row with its
+    mirrored strip among them); the last tile column is of odd width and stays with the first kernel.  Every CFA phase"""
+    check(host_kernel, textured(517, 389, seed=906), filters, all_tiles=False)
+
+
+@pytest.mark.parametrize("w,h,filters", [(600, 400, 0x94949494), (496, 432, 0x16161616), (288, 330, 0x49494949), (64, 64, 0x61616161),
+                                         (160, 160, 0x94949494), (401, 333, 0x49494949), (305, 304, 0x61616161)])
+def test_streaming_tiles_cut_by_the_frame(host_kernel, w, h, filters):
+    """tiles the frame cuts on the right and at the bottom: shorter / narrower planes, the mirrored right and bottom strips and
+    their corners.  The first four frames (the geometry of the 24 MP and 100 MP frames among them: a last column 144 or 32 wide,
+    a last row 64 high) have EVERY tile on chip"""
+    check(host_kernel, textured(w, h, seed=w + h), filters, all_tiles=(w, h) in ((600, 400), (496, 432), (288, 330), (64, 64), (160, 160)))
 
 
 def test_streaming_tiles_many(host_kernel):
