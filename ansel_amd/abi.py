@@ -18,6 +18,8 @@ DT_HIP_DEMOSAIC_PPG = 0
 DT_HIP_DEMOSAIC_AMAZE = 1
 DT_HIP_DEMOSAIC_RCD = 5
 DT_HIP_DEMOSAIC_VNG4 = 2
+DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME = 3
+DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR = 4
 DT_HIP_DEMOSAIC_DUAL = 2048
 
 DT_HIP_ADAPTATION_LINEAR_BRADFORD = 0

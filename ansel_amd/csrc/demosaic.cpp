@@ -13,6 +13,7 @@ int green_eq_lavg_launch(int devid, const float *in, float *out, int width, int 
 int green_eq_favg_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, int x, int y);
 int pre_median_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, float threshold);
 int color_smoothing_launch(int devid, float4 *img, int width, int height, int passes);
+int passthrough_launch(int devid, const float *in, float4 *out, int width, int height, uint32_t filters, bool color);
 int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
 int vng4_demosaic_launch(int devid, const dt_hip_piece_t *piece, const float *in, float4 *out);
 int dual_demosaic_launch(int devid, const dt_hip_piece_t *piece, const float *raw, float4 *rgb, float dual_threshold, const float wb[4]);
@@ -49,9 +50,11 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
     set_last_error("demosaic: the dual threshold is not a number");
     return DT_HIP_INVALID_ARG;
   }
-  if(band && (dual || method == DT_HIP_DEMOSAIC_VNG4))
+  const bool pass = method == DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME || method == DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR;
+  if(band && (dual || pass || method == DT_HIP_DEMOSAIC_VNG4))
   {
-    set_last_error("demosaic: VNG4 and the dual methods have no row-band mode (the detail mask's blur reads across bands)");
+    set_last_error("demosaic: VNG4, the dual methods and the passthrough modes have no row-band mode (the detail mask's blur reads "
+                   "across bands; the passthrough modes are not export states)");
     return DT_HIP_INVALID_ARG;
   }
   if(d->color_smoothing > 5 || (d->median_thrs != 0.0f && d->demosaicing_method != DT_HIP_DEMOSAIC_PPG))
@@ -79,7 +82,7 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
   float *geq = nullptr, *med = nullptr;
   int err = DT_HIP_SUCCESS;
   float *aux = nullptr;
-  if(d->green_eq)
+  if(d->green_eq && !pass) // (the passthrough modes take the mosaic as it came in, demosaic.c:1111-1118)
   {
     // demosaic.c:1137-1163: _FULL = favg, _LOCAL = lavg, _BOTH = favg then lavg
     geq = (float *)dt_hip_alloc_device_buffer(devid, (size_t)w * h * sizeof(float));
@@ -95,6 +98,11 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
   if(err == DT_HIP_SUCCESS)
     switch(method)
     {
+      case DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME:
+      case DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR:
+        err = passthrough_launch(devid, (const float *)dev_in, (float4 *)dev_out, w, h, piece->filters,
+                                 method == DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR);
+        break;
       case DT_HIP_DEMOSAIC_VNG4:
         err = vng4_demosaic_launch(devid, piece, in, (float4 *)dev_out);
         break;

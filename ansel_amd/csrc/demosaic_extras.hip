@@ -267,6 +267,37 @@ int green_eq_favg_launch(int devid, const float *in, float *out, int width, int 
   return check_launch("green_eq_favg");
 }
 
+// passthrough_monochrome() / passthrough_color(), src/iop/demosaic/passthrough.c:21-67: the photosite in all three channels,
+// or in its own (the colour from the unshifted filters at the output position) with 0 in the other two; alpha is left as it is
+template <bool COLOR>
+__global__ __launch_bounds__(256) void passthrough(const float *__restrict__ in, float *__restrict__ out, const int width,
+                                                   const size_t npixels, const uint32_t filters)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= npixels) return;
+  const float v = in[i];
+  typedef float v3f_t __attribute__((ext_vector_type(3)));
+  v3f_t o = { v, v, v };
+  if(COLOR)
+  {
+    const int row = (int)(i / (size_t)width), col = (int)(i % (size_t)width);
+    const int c = filters >> ((((row << 1) & 14) + (col & 1)) << 1) & 3;
+    o = v3f_t{ c == 0 ? v : 0.0f, c == 1 ? v : 0.0f, c == 2 ? v : 0.0f };
+  }
+  __builtin_memcpy(out + 4 * i, &o, 12);
+}
+
+int passthrough_launch(int devid, const float *in, float4 *out, int width, int height, uint32_t filters, bool color)
+{
+  const size_t np = (size_t)width * height;
+  launch_scope ls(devid, "passthrough");
+  if(color)
+    passthrough<true><<<pixel_grid(np), 256, 0, stream_of(devid)>>>(in, (float *)out, width, np, filters);
+  else
+    passthrough<false><<<pixel_grid(np), 256, 0, stream_of(devid)>>>(in, (float *)out, width, np, filters);
+  return check_launch("passthrough");
+}
+
 int pre_median_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, float threshold)
 {
   launch_scope ls(devid, "pre_median");

@@ -295,6 +295,11 @@ int dt_hip_iop_highlights_resolve(int devid, dt_hip_mem_t dev_out, dt_hip_mem_t 
 #define DT_HIP_DEMOSAIC_AMAZE 1 /* DT_IOP_DEMOSAIC_AMAZE */
 #define DT_HIP_DEMOSAIC_VNG4 2  /* DT_IOP_DEMOSAIC_VNG4  (vng.c:34-221: the interpolation the dual methods blend with) */
 #define DT_HIP_DEMOSAIC_RCD 5   /* DT_IOP_DEMOSAIC_RCD   */
+#define DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME 3 /* DT_IOP_DEMOSAIC_PASSTHROUGH_MONOCHROME: the photosite in R, G and B
+                                                    (passthrough_monochrome(), src/iop/demosaic/passthrough.c:21-41) */
+#define DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR 4      /* DT_IOP_DEMOSAIC_PASSTHROUGH_COLOR: the photosite in its own channel, 0 in the
+                                                    other two (passthrough_color(), passthrough.c:44-67).  Both take the mosaic as
+                                                    it came in -- no green equilibration, demosaic.c:1111-1118 -- and leave alpha */
 #define DT_HIP_DEMOSAIC_DUAL 2048 /* DEMOSAIC_DUAL (demosaic.c:110) or-ed onto RCD / AMaZE: DT_IOP_DEMOSAIC_RCD_VNG, _AMAZE_VNG --
                                      dual_demosaic(), src/iop/demosaic/dual.c:40-110: VNG4 of the mosaic (as it came in, not
                                      green-equilibrated) with two passes of colour smoothing, blended with the high-frequency

@@ -9,6 +9,7 @@
 #define INLINE inline
 #include "iop/demosaic/rcd.c"
 #include "iop/demosaic/ppg.c"
+#include "iop/demosaic/passthrough.c"
 
 /* VNG4 and the dual demosaic (src/iop/demosaic/vng.c:34-221, dual.c:35-110): the two functions lifted as they are; what
  * they call beyond the pixel code is a timer, a log line and the detail-mask functions of src/develop/masks/detail.c, which
@@ -88,7 +89,12 @@ int ref_demosaic(const dt_hip_piece_t *v, const dt_hip_demosaic_data_t *d, const
   }
   int rc = 0;
   const uint32_t method = d->demosaicing_method & ~(uint32_t)DT_HIP_DEMOSAIC_DUAL;
-  if(method == DT_HIP_DEMOSAIC_RCD)
+  /* demosaic.c:1111-1118: in front of the Bayer branch, on `pixels` */
+  if(d->demosaicing_method == DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME)
+    passthrough_monochrome((float *)out, (const float *)in0, &roo, &roi);
+  else if(d->demosaicing_method == DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR)
+    passthrough_color((float *)out, (const float *)in0, &roo, &roi, v->filters, NULL);
+  else if(method == DT_HIP_DEMOSAIC_RCD)
     rcd_demosaic(&piece, (float *)out, (const float *)in, &roo, &roi, filters);
   else if(method == DT_HIP_DEMOSAIC_AMAZE)
     amaze_demosaic_RT(&piece, (const float *)in, (float *)out, &roi, &roo, filters);

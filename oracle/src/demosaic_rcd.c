@@ -492,7 +492,31 @@ int oracle_demosaic(const dt_hip_piece_t *piece, const dt_hip_demosaic_data_t *d
     in = geq;
   }
   int rc;
-  if(d->demosaicing_method == DT_HIP_DEMOSAIC_VNG4)
+  if(d->demosaicing_method == DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME || d->demosaicing_method == DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR)
+  {
+    /* passthrough_monochrome() / passthrough_color(), src/iop/demosaic/passthrough.c:21-67, called in front of the Bayer
+     * branch (demosaic.c:1111-1118): the mosaic as the module received it, whatever green_eq says; the colour of a photosite
+     * from the unshifted filters at the OUTPUT position (process() zeroes roo.x / roo.y: the roi offset plays no part);
+     * channel 3 is not written */
+    const float *const px = (const float *)in_;
+    float *const o = (float *)out;
+    const int w = piece->roi_out.width, h = piece->roi_out.height;
+    for(int row = 0; row < h; row++)
+      for(int col = 0; col < w; col++)
+      {
+        const float v = px[(size_t)row * piece->roi_in.width + col];
+        float *const q = o + 4 * ((size_t)row * w + col);
+        if(d->demosaicing_method == DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME)
+          q[0] = q[1] = q[2] = v;
+        else
+        {
+          q[0] = q[1] = q[2] = 0.0f;
+          q[oracle_fc(row, col, piece->filters)] = v;
+        }
+      }
+    rc = 0;
+  }
+  else if(d->demosaicing_method == DT_HIP_DEMOSAIC_VNG4)
     rc = oracle_demosaic_vng4((float *)out, in, piece->roi_in.width, piece->roi_in.height, piece->roi_in.x, piece->roi_in.y,
                               piece->filters);
   else if(d->demosaicing_method & DT_HIP_DEMOSAIC_DUAL)

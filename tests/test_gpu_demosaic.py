@@ -82,7 +82,7 @@ def test_demosaic_rejects_unsupported():
     d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.0)
     buf = lib.DeviceBuffer(0, 64 * 64 * 16)
     assert h_.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
-    d2 = abi.DemosaicData(0, 0, 3, 0.0)
+    d2 = abi.DemosaicData(0, 0, 6, 0.0)  # LMMSE: not on the device
     piece2 = abi.Piece.make(64, 64, filters=synth.FILTERS_RGGB, channels=1)
     assert h_.dt_hip_iop_demosaic_process(0, C.byref(piece2), C.byref(d2), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
 
@@ -181,6 +181,32 @@ def test_states_that_are_not_states_of_the_module_are_refused():
     assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
     d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD, 0.3, 0.0)   # a median threshold only exists for PPG
     assert l.dt_hip_iop_demosaic_process(0, C.byref(piece), C.byref(d), buf.ptr, buf.ptr) == abi.DT_HIP_INVALID_ARG
+
+
+@pytest.mark.parametrize("w,h,roi_xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (1, 1, (0, 0)), (1502, 1002, (0, 1))])
+@pytest.mark.parametrize("method,geq,smooth", [(abi.DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME, 0, 0), (abi.DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR, 0, 0),
+                                               (abi.DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR, 1, 2)])
+def test_passthrough(w, h, roi_xy, method, geq, smooth):
+    """the passthrough states of the module (passthrough.c:21-67; demosaic.c:1111-1118): device == oracle == reference, alpha
+    left as it was"""
+    if smooth and (w < 3 or h < 3):
+        pytest.skip("colour smoothing on a frame without an interior")
+    img = _normalised_cfa(w, h, seed=8)
+    piece = abi.Piece.make(w, h, filters=0x61616161, channels=1, processed_maximum=synth.WB_COEFFS,
+                           roi_in=abi.Roi.make(*roi_xy, w, h), roi_out=abi.Roi.make(*roi_xy, w, h))
+    d = abi.DemosaicData(geq, smooth, method, 0.0)
+    pre = np.full((h, w, 4), -3.0, np.float32)
+    got = hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4), pre_fill=pre)
+    exp = pre.copy()
+    assert ck.call(ck.oracle(), "oracle_demosaic", piece, d, img, exp) == 0
+    hc.assert_bit_exact(got, exp, "passthrough vs oracle")
+    if not smooth:
+        assert (got[..., 3] == -3.0).all()
+    ref = ck.ref()
+    if ref is not None:
+        r = pre.copy()
+        assert ck.call(ref, "ref_demosaic", piece, d, img, r) == 0
+        hc.assert_bit_exact(got, r, "passthrough vs reference")
 
 
 # ---- VNG4 and the dual demosaic (vng.c:34-221, dual.c:35-110) -------------------------------------------------------------

@@ -887,6 +887,21 @@ def test_demosaic_vng4(w, h, xy):
     _exact(a, b, "vng4")
 
 
+@pytest.mark.parametrize("w,h,xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (33, 21, (1, 0))])
+@pytest.mark.parametrize("method,geq,smooth", [(abi.DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME, 0, 0), (abi.DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR, 0, 0),
+                                               (abi.DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR, 1, 2), (abi.DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME, 3, 1)])
+def test_demosaic_passthrough(w, h, xy, method, geq, smooth):
+    """the two passthrough states of the module (passthrough.c:21-67): the photosite in all channels / in its own; the mosaic as
+    it came in whatever green_eq says, the colour from the unshifted filters at the output position, alpha untouched, colour
+    smoothing behind it as behind every method (demosaic.c:1249): oracle == the reference's functions"""
+    img = ((synth.bayer_mosaic(w, h, seed=3).astype(np.float32) - 512.0) / np.float32(synth.WHITE - 512)).astype(np.float32)
+    for filters in (synth.FILTERS_RGGB, 0x16161616):
+        piece = abi.Piece.make(w, h, filters=filters, channels=1, processed_maximum=synth.WB_COEFFS,
+                               roi_in=abi.Roi.make(xy[0], xy[1], w, h), roi_out=abi.Roi.make(xy[0], xy[1], w, h))
+        a, b = _pair("demosaic", piece, abi.DemosaicData(geq, smooth, method, 0.0), img, (h, w, 4))
+        _exact(a, b, "passthrough")
+
+
 @pytest.mark.parametrize("w,h,xy", [(300, 200, (0, 0)), (207, 131, (1, 1)), (160, 140, (0, 1))])
 @pytest.mark.parametrize("base,geq,smooth,thrs", [(abi.DT_HIP_DEMOSAIC_RCD, 0, 0, 0.2), (abi.DT_HIP_DEMOSAIC_RCD, 1, 2, 0.05),
                                                    (abi.DT_HIP_DEMOSAIC_AMAZE, 0, 0, 0.2), (abi.DT_HIP_DEMOSAIC_AMAZE, 0, 1, 0.6),

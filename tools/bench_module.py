@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--preset", default="lens_deblur_soft")
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--cpu", action="store_true",
+                    help="amaze: also time the reference's own code (oracle/_ref/libansel_ref_fast.so, its release flags, OpenMP) on "
+                         "the host for the same frame, and check the device output against it outside the reference's stale pixels")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -92,6 +95,35 @@ def main():
     res = {"module": args.module, "size": "%dx%d" % (w, h), "ms_per_call": round(ms, 3), "kernels": kernels}
     for k, v in kernels.items():
         v["GBps_at_48B_per_px"] = round(48 * npix / (v["ms_avg"] * 1e-3) / 1e9, 1)
+    if args.module == "amaze":
+        for k, v in kernels.items():
+            v["GBps_at_20B_per_px"] = round(20 * npix / (v["ms_avg"] * 1e-3) / 1e9, 1)
+            v["hbm_frac_algorithmic"] = round(20 * npix / (v["ms_avg"] * 1e-3) / 8e12, 4)
+    if args.cpu and args.module == "amaze":
+        # the reported baseline: the reference's CPU path on this box's host cores (TEST INFRASTRUCTURE, the checker's library)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import checkers as ck
+        ref = ck.ref(fast=True)
+        if ref is not None:
+            host_in = ck.aligned_empty((h, w), np.float32)
+            host_in[...] = img.cpu().numpy()
+            host_out = ck.aligned_empty((h, w, 4), np.float32)
+            host_out[...] = 0
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                assert ck.call(ref, "ref_demosaic", piece, d, host_in, host_out) == 0
+                ts.append(time.perf_counter() - t0)
+            quota = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                quota = None if q == "max" else float(q) / float(per)
+            except Exception:
+                pass
+            res["cpu_baseline"] = {"value": round(npix / min(ts) / 1e6, 2), "unit": "MPix/s", "kind": "reference", "ms": round(min(ts) * 1e3, 1),
+                                   "threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count())), "nproc": os.cpu_count(), "cpu_quota": quota,
+                                   "sample": "the same %d x %d frame, amaze_demosaic_RT() with the reference's release flags" % (w, h)}
+            res["device_over_cpu"] = round(min(ts) * 1e3 / ms, 1)
     print(json.dumps(res, indent=1))
 
 
