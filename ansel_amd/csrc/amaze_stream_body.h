@@ -63,7 +63,18 @@ constexpr int STEPS = (TS - 17 + L_S14) / R + 1; // the last kept row is 143
 template <int OFF_, int W_, int D_> struct plane
 {
   static constexpr int OFF = OFF_, W = W_, D = D_, END = OFF_ + W_ * D_;
-  AMZ_MEMBER int idx(const int r, const int c) { return OFF + (int)((unsigned)r % (unsigned)D) * W + c; }
+  // (rows are below 256: with that known, the remainder by a depth that is no power of two needs no 32-bit multiply-high)
+  AMZ_MEMBER int idx(const int r, const int c) { return OFF + (int)(((unsigned)r & 255u) % (unsigned)D) * W + c; }
+  // the same in steps, for the planes whose depth is no power of two: the slot of a row once, those of the rows around it by
+  // an addition and a wrap (-D < k < D)
+  AMZ_MEMBER int slot(const int r) { return (int)(((unsigned)r & 255u) % (unsigned)D); }
+  AMZ_MEMBER int step(const int sl, const int k)
+  {
+    int t = sl + k;
+    t += t < 0 ? D : 0;
+    return t >= D ? t - D : t;
+  }
+  AMZ_MEMBER int at(const int sl, const int c) { return OFF + sl * W + c; }
 };
 // (a power of two wherever LDS allows: the slot of a row is then one AND; 163 200 of the CU's 163 840 bytes)
 // float planes, full width
@@ -97,6 +108,7 @@ typedef plane<P_GV::END, TSH, 8> P_DELP;      // S9 -> R/B estimates (2 up)
 typedef plane<P_DELP::END, TSH, 8> P_DELM;
 typedef plane<P_DELM::END, TSH, 8> P_DSQP;
 typedef plane<P_DSQP::END, TSH, 8> P_DSQM;
+static_assert(70 % (R + 1) == 0 && 70 % (R + 3) == 0, "the offset that keeps a stepped slot's first row non-negative");
 typedef plane<P_DSQM::END, TSH, R + 1> P_RBP;
 typedef plane<P_RBP::END, TSH, R + 1> P_RBM;
 typedef plane<P_RBM::END, TSH, R + 3> P_PMWT;   // lag 19 -> vote at 20 (1 up) -> S11 at 22
@@ -116,6 +128,7 @@ struct args
   uint32_t filters;
   int ex, ey;
   float clip_pt;
+  int variant; // 0; a measuring run switches the first (1) / the second (2) vote off with it -- the output is then wrong
 };
 
 AMZ_FN float sqr(const float x) { return x * x; }
@@ -235,6 +248,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
   const int rrmax = bottom > height ? height - top : rr1, ccmax = right > width ? width - left : cc1;
   const int steps = rr1 > 32 ? (rr1 - 17 + L_S14) / R + 1 : 0; // the last kept row is rr1 - 17
 
+#define AMZ_UNROLL _Pragma("unroll")
 #define LD(P, r, c) env.ldf(P::idx((r), (c)), (r))
 #define ST(P, r, c, v) env.stf(P::idx((r), (c)), (r), (v))
 #define LDB(P, r, c) env.ldb(P::idx((r), (c)), (r))
@@ -659,77 +673,112 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
         if(vp > clip_pt) vp = ulim(vp, csw1, cne1);
         if(vm > clip_pt) vm = ulim(vm, cnw1, cse1);
       }
-      ST(P_PMWT, rr, h, pw);
-      ST(P_RBP, rr, h, vp);
-      ST(P_RBM, rr, h, vm);
+      {
+        // (three planes whose depth is no power of two: the slot of the step's first row on the scalar unit, this thread's row
+        // from there; + 70, a multiple of both depths, keeps the row of the first steps non-negative)
+        const int jr = rr - (s * R - L_RB);
+        env.stf(P_PMWT::at(P_PMWT::step(P_PMWT::slot(s * R - L_RB + 70), jr), h), rr, pw);
+        const int sr = P_RBP::step(P_RBP::slot(s * R - L_RB + 70), jr);
+        env.stf(P_RBP::at(sr, h), rr, vp);
+        env.stf(P_RBM::at(sr, h), rr, vm);
+      }
     }
     env.sync();
     env.stamp(8);
 
-    // ---- phase 9: the two votes, in place, row r sees row r-1 voted (:894-905, :1109-1126): ONE wave each walks its R rows in order (a
-    //      wave's LDS accesses execute in order), two sites per lane, no workgroup barrier in between; behind the second vote
-    //      R + B of the site (:1123).  The other waves meanwhile form the squared gradients S5 reads in the next step, :463-473
-    if(tid < 64)
+    // ---- phase 9: the two votes, in place, row r sees row r-1 voted (:894-905, :1109-1126): ONE wave each walks its R rows in order, two
+    //      sites per lane, in registers.  The other waves meanwhile form the squared gradients S5 reads in the next step, :463-473
+    if(tid < 64 && !(a.variant & 1))
     {
+      // lane l of the wave owns the sites 2 l and 2 l + 1 of every row.  Everything that does not depend on a vote -- the
+      // unvoted values of the R rows and of the row below them, the row above as the step before left it -- is fetched at once,
+      // by every lane and for every row (from a neighbouring row or site where one is not there: those values are not used),
+      // so that the fetches are one straight stretch of code; then the rows are walked in registers, the one voted value per
+      // row that belongs to the neighbouring lane (lane - 1 or lane + 1, by the row's CFA phase) arriving by a lane shuffle
+      // instead of a round trip through LDS
+      const int lane = tid & 63, ha = lane < TSH / 2 ? 2 * lane : TSH - 2, hb = ha + 1;
+      const bool own = lane < TSH / 2;
+      const int r0 = s * R - L_VOTE;
+      // the rows fetched: r0 - 1 .. r0 + R, moved into the plane where the tile begins / ends (rows that are voted on are not moved)
+      const int rb = r0 < 1 ? 1 : (r0 > TS - R - 2 ? TS - R - 2 : r0), sw = P_HVWT::slot(rb);
+      float raw[R][2], below[R][3];
+      float pa = env.ldf(P_HVWT::at(P_HVWT::step(sw, -1), ha), -1), pb = env.ldf(P_HVWT::at(P_HVWT::step(sw, -1), hb), -1);
+      AMZ_UNROLL
       for(int j = 0; j < R; j++)
       {
-        const int rr = s * R - L_VOTE + j;
-        if(IN_(rr, 8, rr1 - 8) && tid < TSH / 2)
-        {
-          // two sites per lane, everything fetched before anything is stored: one LDS round trip per row
-          const int q = fct(rr, 2, filters) & 1, ha = 2 * tid, hb = ha + 1, ca = q + 2 * ha, cb = ca + 2;
-          const int hl = ca > 0 ? (ca - 1) >> 1 : 0, hr = cb + 1 < TS ? (cb + 1) >> 1 : TSH - 1; // (clamped for the lanes at the rim, which store nothing)
-          const float a0 = LD(P_HVWT, rr - 1, hl), a1 = LD(P_HVWT, rr - 1, (ca + 1) >> 1), a2 = LD(P_HVWT, rr - 1, hr);
-          const float b0 = LD(P_HVWT, rr + 1, hl), b1 = LD(P_HVWT, rr + 1, (ca + 1) >> 1), b2 = LD(P_HVWT, rr + 1, hr);
-          const float wa = LD(P_HVWT, rr, ha), wb = LD(P_HVWT, rr, hb);
-          const float alta = xdivf(a0 + a1 + b0 + b1, 2), altb = xdivf(a1 + a2 + b1 + b2, 2);
-          if(IN_(ca, 8, cc1 - 8)) ST(P_HVWT, rr, ha, fabsf(0.5f - wa) < fabsf(0.5f - alta) ? alta : wa);
-          if(IN_(cb, 8, cc1 - 8)) ST(P_HVWT, rr, hb, fabsf(0.5f - wb) < fabsf(0.5f - altb) ? altb : wb);
-        }
-        env.wave_sync();
+        const int q = fct(rb + j, 2, filters) & 1, sj = P_HVWT::step(sw, j), sd = P_HVWT::step(sw, j + 1);
+        // the three sites of the rows above / below that this lane's two sites see: ha + q - 1, ha + q, ha + q + 1
+        const int n0 = ha + q - 1 < 0 ? 0 : ha + q - 1, n1 = ha + q, n2 = ha + q + 1 > TSH - 1 ? TSH - 1 : ha + q + 1;
+        raw[j][0] = env.ldf(P_HVWT::at(sj, ha), -1);
+        raw[j][1] = env.ldf(P_HVWT::at(sj, hb), -1);
+        below[j][0] = env.ldf(P_HVWT::at(sd, n0), -1);
+        below[j][1] = env.ldf(P_HVWT::at(sd, n1), -1);
+        below[j][2] = env.ldf(P_HVWT::at(sd, n2), -1);
+      }
+      AMZ_UNROLL
+      for(int j = 0; j < R; j++)
+      {
+        const int rr = r0 + j;
+        const int q = (rr >= 0 ? fct(rr, 2, filters) : 0) & 1, ca = q + 2 * ha, cb = ca + 2;
+        // the voted row above at ha + q - 1, ha + q, ha + q + 1: with q = 1 own, own, lane + 1's first; with q = 0 lane - 1's
+        // second, own, own
+        const float from_next = env.shfl_down1(pa), from_prev = env.shfl_up1(pb);
+        const float a0 = q ? pa : from_prev, a1 = q ? pb : pa, a2 = q ? from_next : pb;
+        const float alta = xdivf(a0 + a1 + below[j][0] + below[j][1], 2), altb = xdivf(a1 + a2 + below[j][1] + below[j][2], 2);
+        const bool row_in = own && IN_(rr, 8, rr1 - 8); // (then rb == r0: the fetched row j is row rr)
+        const bool ina = row_in && IN_(ca, 8, cc1 - 8), inb = row_in && IN_(cb, 8, cc1 - 8);
+        float wa = raw[j][0], wb = raw[j][1];
+        const bool ta = ina && fabsf(0.5f - wa) < fabsf(0.5f - alta), tb = inb && fabsf(0.5f - wb) < fabsf(0.5f - altb);
+        wa = ta ? alta : wa;
+        wb = tb ? altb : wb;
+        if(ta) env.stf(P_HVWT::at(P_HVWT::step(sw, j), ha), rr, wa);
+        if(tb) env.stf(P_HVWT::at(P_HVWT::step(sw, j), hb), rr, wb);
+        pa = wa;
+        pb = wb;
       }
     }
-    else if(tid >= 128 && tid < 192)
+    else if(tid >= 128 && tid < 192 && !(a.variant & 2))
     {
+      // (the same walk over the diagonal weight)
+      const int lane = tid & 63, ha = lane < TSH / 2 ? 2 * lane : TSH - 2, hb = ha + 1;
+      const bool own = lane < TSH / 2;
+      const int r0 = s * R - L_RBI;
+      // the rows fetched: r0 - 1 .. r0 + R, moved into the plane where the tile begins / ends (rows that are voted on are not moved)
+      const int rb = r0 < 1 ? 1 : (r0 > TS - R - 2 ? TS - R - 2 : r0), sw = P_PMWT::slot(rb);
+      float raw[R][2], below[R][3];
+      float pa = env.ldf(P_PMWT::at(P_PMWT::step(sw, -1), ha), -1), pb = env.ldf(P_PMWT::at(P_PMWT::step(sw, -1), hb), -1);
+      AMZ_UNROLL
       for(int j = 0; j < R; j++)
       {
-        const int rr = s * R - L_RBI + j, lane = tid - 128;
-        if(rr >= 0 && rr < TS && lane < TSH / 2)
-        {
-          const int q = fct(rr, 2, filters) & 1, ha = 2 * lane, hb = ha + 1, ca = q + 2 * ha, cb = ca + 2;
-          const int hl = ca > 0 ? (ca - 1) >> 1 : 0, hr = cb + 1 < TS ? (cb + 1) >> 1 : TSH - 1;
-          float rba = 0.f, rbb = 0.f;
-          if(IN_(rr, 10, rr1 - 10))
-          {
-            const float a0 = LD(P_PMWT, rr - 1, hl), a1 = LD(P_PMWT, rr - 1, (ca + 1) >> 1), a2 = LD(P_PMWT, rr - 1, hr);
-            const float b0 = LD(P_PMWT, rr + 1, hl), b1 = LD(P_PMWT, rr + 1, (ca + 1) >> 1), b2 = LD(P_PMWT, rr + 1, hr);
-            float wa = LD(P_PMWT, rr, ha), wb = LD(P_PMWT, rr, hb);
-            const float ma = LD(P_RBM, rr, ha), pa = LD(P_RBP, rr, ha), mb = LD(P_RBM, rr, hb), pb = LD(P_RBP, rr, hb);
-            const float fa = LD(P_CFA, rr, ca), fb = LD(P_CFA, rr, cb);
-            const float alta = xdivf(a0 + a1 + b0 + b1, 2), altb = xdivf(a1 + a2 + b1 + b2, 2);
-            if(IN_(ca, 10, cc1 - 10))
-            {
-              if(fabsf(0.5f - wa) < fabsf(0.5f - alta))
-              {
-                wa = alta;
-                ST(P_PMWT, rr, ha, wa);
-              }
-              rba = xdiv2f(fa + ma * (1.f - wa) + pa * wa);
-            }
-            if(IN_(cb, 10, cc1 - 10))
-            {
-              if(fabsf(0.5f - wb) < fabsf(0.5f - altb))
-              {
-                wb = altb;
-                ST(P_PMWT, rr, hb, wb);
-              }
-              rbb = xdiv2f(fb + mb * (1.f - wb) + pb * wb);
-            }
-          }
-          ST(P_RBINT, rr, ha, rba);
-          ST(P_RBINT, rr, hb, rbb);
-        }
-        env.wave_sync();
+        const int q = fct(rb + j, 2, filters) & 1, sj = P_PMWT::step(sw, j), sd = P_PMWT::step(sw, j + 1);
+        // the three sites of the rows above / below that this lane's two sites see: ha + q - 1, ha + q, ha + q + 1
+        const int n0 = ha + q - 1 < 0 ? 0 : ha + q - 1, n1 = ha + q, n2 = ha + q + 1 > TSH - 1 ? TSH - 1 : ha + q + 1;
+        raw[j][0] = env.ldf(P_PMWT::at(sj, ha), -1);
+        raw[j][1] = env.ldf(P_PMWT::at(sj, hb), -1);
+        below[j][0] = env.ldf(P_PMWT::at(sd, n0), -1);
+        below[j][1] = env.ldf(P_PMWT::at(sd, n1), -1);
+        below[j][2] = env.ldf(P_PMWT::at(sd, n2), -1);
+      }
+      AMZ_UNROLL
+      for(int j = 0; j < R; j++)
+      {
+        const int rr = r0 + j;
+        const int q = (rr >= 0 ? fct(rr, 2, filters) : 0) & 1, ca = q + 2 * ha, cb = ca + 2;
+        // the voted row above at ha + q - 1, ha + q, ha + q + 1: with q = 1 own, own, lane + 1's first; with q = 0 lane - 1's
+        // second, own, own
+        const float from_next = env.shfl_down1(pa), from_prev = env.shfl_up1(pb);
+        const float a0 = q ? pa : from_prev, a1 = q ? pb : pa, a2 = q ? from_next : pb;
+        const float alta = xdivf(a0 + a1 + below[j][0] + below[j][1], 2), altb = xdivf(a1 + a2 + below[j][1] + below[j][2], 2);
+        const bool row_in = own && IN_(rr, 10, rr1 - 10); // (then rb == r0: the fetched row j is row rr)
+        const bool ina = row_in && IN_(ca, 10, cc1 - 10), inb = row_in && IN_(cb, 10, cc1 - 10);
+        float wa = raw[j][0], wb = raw[j][1];
+        const bool ta = ina && fabsf(0.5f - wa) < fabsf(0.5f - alta), tb = inb && fabsf(0.5f - wb) < fabsf(0.5f - altb);
+        wa = ta ? alta : wa;
+        wb = tb ? altb : wb;
+        if(ta) env.stf(P_PMWT::at(P_PMWT::step(sw, j), ha), rr, wa);
+        if(tb) env.stf(P_PMWT::at(P_PMWT::step(sw, j), hb), rr, wb);
+        pa = wa;
+        pb = wb;
       }
     }
     // (the waves that do not vote share the gradients' 640 sites)
@@ -767,6 +816,19 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       ST(P_DGO, rr, h, dg);
       ST(P_GH, rr, h, ch);
       ST(P_GV, rr, h, cv);
+    }
+    // ... and on the other half of the threads R + B of the site from the two diagonal estimates and their voted weight, :1123
+    FOR_RB2(L_RBI)
+    {
+      float rb = 0.f;
+      const int jr = rr - (s * R - L_RBI);
+      if(IN_(rr, 10, rr1 - 10) && IN_(cc, 10, cc1 - 10))
+      {
+        const float w = env.ldf(P_PMWT::at(P_PMWT::step(P_PMWT::slot(s * R - L_RBI + 70), jr), h), rr);
+        const int sr = P_RBM::step(P_RBM::slot(s * R - L_RBI + 70), jr);
+        rb = xdiv2f(LD(P_CFA, rr, cc) + env.ldf(P_RBM::at(sr, h), rr) * (1.f - w) + env.ldf(P_RBP::at(sr, h), rr) * w);
+      }
+      ST(P_RBINT, rr, h, rb);
     }
     env.sync();
     env.stamp(10);
@@ -909,6 +971,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     env.stamp(13);
   }
 #undef LD
+#undef AMZ_UNROLL
 #undef ST
 #undef LDB
 #undef STB

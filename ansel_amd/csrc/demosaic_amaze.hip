@@ -818,6 +818,16 @@ struct stream_env
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   }
+  // the value of lane - 1 / lane + 1 of the wave (the first / last lane keeps its own): one DPP move (wave_shr:1 / wave_shl:1)
+  // instead of a ds_bpermute round trip
+  __device__ __forceinline__ float shfl_up1(const float v) const
+  {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, false));
+  }
+  __device__ __forceinline__ float shfl_down1(const float v) const
+  {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xf, 0xf, false));
+  }
   __device__ __forceinline__ void stamp(const int) const {}
   // the three colour values of a pixel as one 12-byte store (alpha is left as it is)
   __device__ __forceinline__ void store_rgb(float *const o, const float r, const float g, const float b) const
@@ -954,6 +964,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   sa.ex = a.ex;
   sa.ey = a.ey;
   sa.clip_pt = a.clip_pt;
+  sa.variant = getenv("ANSEL_HIP_AMAZE_VARIANT") ? atoi(getenv("ANSEL_HIP_AMAZE_VARIANT")) : 0; // measuring builds only
   if(stream_tiles > 0)
   {
     // the opt-in to more than 64 KB of LDS is per device

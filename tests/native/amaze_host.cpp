@@ -31,6 +31,7 @@ struct Shared
   std::vector<int16_t> wtid, rtid;     // ... and who (-2: readers of several waves, -3: several readers of one wave)
   int phase = 1, block = 1;
   std::vector<char> at_block;
+  std::vector<float> xchg; // lane shuffles
   long errors = 0;
   std::string first;
   ucontext_t main;
@@ -140,6 +141,18 @@ struct HostEnv
   }
   // orders the LDS accesses of ONE wave (on the device they execute in program order; here the fibers of the wave meet)
   void wave_sync() const { swapcontext(&sh->ctx[tid_], &sh->main); }
+  // the value of lane - 1 / lane + 1 of the wave (every lane of the wave calls it; the first / last lane gets its own)
+  float shfl_up1(const float v) const { return shuffle(v, -1); }
+  float shfl_down1(const float v) const { return shuffle(v, 1); }
+  float shuffle(const float v, const int d) const
+  {
+    sh->xchg[tid_] = v;
+    swapcontext(&sh->ctx[tid_], &sh->main);
+    const int src = (tid_ & 63) + d;
+    const float r = (src < 0 || src > 63) ? v : sh->xchg[(tid_ & ~63) + src];
+    swapcontext(&sh->ctx[tid_], &sh->main);
+    return r;
+  }
   void stamp(int) const {}
   void store_rgb(float *const o, const float r, const float g, const float b) const
   {
@@ -176,6 +189,7 @@ extern "C" int amaze_host_run(const float *in, float *out, int width, int height
   sh.wblock.assign(amz::LDS_BYTES, 0);
   sh.rblock.assign(amz::LDS_BYTES, 0);
   sh.at_block.assign(amz::NT, 0);
+  sh.xchg.assign(amz::NT, 0.f);
   sh.wtid.assign(amz::LDS_BYTES, -1);
   sh.rtid.assign(amz::LDS_BYTES, -1);
   sh.in = in;
@@ -185,6 +199,7 @@ extern "C" int amaze_host_run(const float *in, float *out, int width, int height
   sh.a.filters = filters;
   sh.a.ex = sh.a.ey = 0;
   sh.a.clip_pt = clip_pt;
+  sh.a.variant = 0;
   const int ntx = (width + 16 + (amz::TS - 32) - 1) / (amz::TS - 32), nty = (height + 16 + (amz::TS - 32) - 1) / (amz::TS - 32);
   int all = 0;
   for(int ty = 0; ty < nty; ty++)
