@@ -724,7 +724,10 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
         // second, own, own
         const float from_next = env.shfl_down1(pa), from_prev = env.shfl_up1(pb);
         const float a0 = q ? pa : from_prev, a1 = q ? pb : pa, a2 = q ? from_next : pb;
-        const float alta = xdivf(a0 + a1 + below[j][0] + below[j][1], 2), altb = xdivf(a1 + a2 + below[j][1] + below[j][2], 2);
+        // (env.add(): x + y with the operands in this order -- where both are NaNs the sum is the first one's, on x86 and on the GPU
+        // alike, and the exponent arithmetic of xdivf() carries its sign into numbers)
+        const float alta = xdivf(env.add(env.add(env.add(a0, a1), below[j][0]), below[j][1]), 2);
+        const float altb = xdivf(env.add(env.add(env.add(a1, a2), below[j][1]), below[j][2]), 2);
         const bool row_in = own && IN_(rr, 8, rr1 - 8); // (then rb == r0: the fetched row j is row rr)
         const bool ina = row_in && IN_(ca, 8, cc1 - 8), inb = row_in && IN_(cb, 8, cc1 - 8);
         float wa = raw[j][0], wb = raw[j][1];
@@ -768,7 +771,10 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
         // second, own, own
         const float from_next = env.shfl_down1(pa), from_prev = env.shfl_up1(pb);
         const float a0 = q ? pa : from_prev, a1 = q ? pb : pa, a2 = q ? from_next : pb;
-        const float alta = xdivf(a0 + a1 + below[j][0] + below[j][1], 2), altb = xdivf(a1 + a2 + below[j][1] + below[j][2], 2);
+        // (env.add(): x + y with the operands in this order -- where both are NaNs the sum is the first one's, on x86 and on the GPU
+        // alike, and the exponent arithmetic of xdivf() carries its sign into numbers)
+        const float alta = xdivf(env.add(env.add(env.add(a0, a1), below[j][0]), below[j][1]), 2);
+        const float altb = xdivf(env.add(env.add(env.add(a1, a2), below[j][1]), below[j][2]), 2);
         const bool row_in = own && IN_(rr, 10, rr1 - 10); // (then rb == r0: the fetched row j is row rr)
         const bool ina = row_in && IN_(ca, 10, cc1 - 10), inb = row_in && IN_(cb, 10, cc1 - 10);
         float wa = raw[j][0], wb = raw[j][1];
@@ -826,7 +832,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
       {
         const float w = env.ldf(P_PMWT::at(P_PMWT::step(P_PMWT::slot(s * R - L_RBI + 70), jr), h), rr);
         const int sr = P_RBM::step(P_RBM::slot(s * R - L_RBI + 70), jr);
-        rb = xdiv2f(LD(P_CFA, rr, cc) + env.ldf(P_RBM::at(sr, h), rr) * (1.f - w) + env.ldf(P_RBP::at(sr, h), rr) * w);
+        rb = xdiv2f(env.add(env.add(LD(P_CFA, rr, cc), env.ldf(P_RBM::at(sr, h), rr) * (1.f - w)), env.ldf(P_RBP::at(sr, h), rr) * w));
       }
       ST(P_RBINT, rr, h, rb);
     }

@@ -828,6 +828,13 @@ struct stream_env
   {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xf, 0xf, false));
   }
+  // x + y with the operands in this order (the compiler is free to swap them, and of two NaNs the sum is the first)
+  __device__ __forceinline__ float add(const float x, const float y) const
+  {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  }
   __device__ __forceinline__ void stamp(const int) const {}
   // the three colour values of a pixel as one 12-byte store (alpha is left as it is)
   __device__ __forceinline__ void store_rgb(float *const o, const float r, const float g, const float b) const

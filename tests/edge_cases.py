@@ -118,6 +118,11 @@ def adversarial(module, w=200, h=150):
         # reference reads those bytes back as Nyquist flags through its aliased planes (amaze.cc:300-327, :830) --
         # a mosaic is finite by construction (u16 -> rawprepare), so that path has no input that reaches it
         specials = specials[3:]
+        # ... and no sample whose square overflows (+-1e30: its inf - inf makes a third of THIS frame NaN): where a NaN's sign
+        # then turns into a number through the exponent tricks of amaze.cc:77-121, what comes out depends on which operand of an
+        # addition the compiler put first and on x - NaN keeping the NaN's sign (x86) or flipping it (v_sub_f32) -- the compiler's
+        # and the machine's choice, not the algorithm's.  +-1e18 has the magnitude without the overflow
+        specials = [1e18 if v == 1e30 else (-1e18 if v == -1e30 else v) for v in specials]
     flat = inp.reshape(-1)
     for k, i in enumerate(rng.choice(flat.size, size=60, replace=False)):
         flat[i] = specials[k % len(specials)]

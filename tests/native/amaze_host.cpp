@@ -153,6 +153,7 @@ struct HostEnv
     swapcontext(&sh->ctx[tid_], &sh->main);
     return r;
   }
+  float add(const float x, const float y) const { return x + y; }
   void stamp(int) const {}
   void store_rgb(float *const o, const float r, const float g, const float b) const
   {
