@@ -23,7 +23,7 @@ Started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) it spa
 torch.distributed.run on 127.0.0.1; a launcher whose WORLD_SIZE disagrees with --gpus is an error.
 
 Besides `value` the line carries, at N = 1: `config.light_pipe` -- config 2's module list on the SAME 100 MP
-frame, timed in the same run; `verified` -- the output buffer the timed steps wrote, compared word for word with
+frame, timed in the same run (and, as `config.light_pipe.with_amaze`, once more with AMaZE in RCD's place); `verified` -- the output buffer the timed steps wrote, compared word for word with
 the oracle's chain after the timed region (the oracle is the checker here, never the thing measured);
 `cpu_baseline` -- the reference's own code on the host cores, same module chain.
 
@@ -83,8 +83,8 @@ def frame_size(name):
     return int(w), int(h)
 
 
-def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light"):
-    from ansel_amd import params, pipe
+def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light", demosaic_method=None):
+    from ansel_amd import abi, params, pipe
     filmic = None
     if with_filmic:
         from ansel_amd import filmic as fm
@@ -96,7 +96,7 @@ def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light"):
         return pipe.denoise_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, filmic=filmic, with_nlmeans=True,
                                        with_bilat=(which == "full"))
     return pipe.light_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, with_filmic=with_filmic,
-                                 filmic=filmic)
+                                 filmic=filmic, demosaic_method=abi.DT_HIP_DEMOSAIC_RCD if demosaic_method is None else demosaic_method)
 
 
 def have_filmic():
@@ -611,6 +611,27 @@ def main():
             "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / args.light_steps, 3) for k, v in sorted(lk.items())},
         }
         lexec.close()
+        # ... and the same ten modules with the other demosaic the north star names, AMaZE, in RCD's place (3 steps)
+        try:
+            anodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic, "light", abi.DT_HIP_DEMOSAIC_AMAZE)
+            aexec = pipe.DevicePipe(devid, anodes, fusion=not args.no_fusion)
+            aexec.process(raw.data_ptr(), lout.data_ptr())
+            torch.cuda.synchronize(dev)
+            l.dt_hip_events_reset(devid)
+            l.dt_hip_events_enable(devid, 1)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                aexec.process(raw.data_ptr(), lout.data_ptr())
+            torch.cuda.synchronize(dev)
+            a_ms = (time.perf_counter() - t1) / 3 * 1e3
+            l.dt_hip_events_enable(devid, 0)
+            ak = read_kernel_events(l, devid)
+            light["with_amaze"] = {"ms_per_step": round(a_ms, 3), "mpix_s": round(npix / 1e6 / (a_ms * 1e-3), 2),
+                                   "hbm_frac": round(l_bpp * npix / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / 3, 3) for k, v in sorted(ak.items())}}
+            aexec.close()
+        except Exception as e:  # the leg is informative: the line does not depend on it
+            light["with_amaze"] = {"error": str(e)[:200]}
         del lout
 
     # ---- the same step with the boundary's two PCIe legs (never `value`): sensor buffer in pinned host memory ->
