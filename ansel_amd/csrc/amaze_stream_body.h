@@ -181,40 +181,28 @@ AMZ_FN float div2_via_double(const float a, const float b)
 
 // the colour-difference variance a site of a chain compares (amaze.cc:590-600)
 AMZ_FN float cdvar3(const float a, const float b, const float c) { return 3.f * (sqr(a) + sqr(b) + sqr(c)) - sqr(a + b + c); }
-// ... and what becomes of the estimate h it picks (amaze.cc:611-705): bounded where green would overshoot or clip
-AMZ_FN float chain_bound(float h, const float before, const float here, const float after, const bool gsite, const float clip_pt)
+// ... and what becomes of the estimate h it picks (amaze.cc:611-705): bounded where green would overshoot or clip.  The
+// reference has one branch for a green site and its mirror image for a red / blue one -- every quantity of the second is the
+// first's with the sign of h flipped, and negation commutes with every rounding (-(a) + -(b) = -(a + b), (-a) x = -(a x),
+// 1 + (-q) = 1 - q) -- so the red / blue case is the green one on -h with the result negated, bit for bit: neighbouring
+// lanes are sites of both kinds, and one body runs where two did
+AMZ_FN float chain_bound(const float h_in, const float before, const float here, const float after, const bool gsite, const float clip_pt)
 {
-  if(gsite)
+  const uint32_t flip = gsite ? 0u : 0x80000000u;
+  float h = u2f(f2u(h_in) ^ flip);
+  const float Gint = -h + here;
+  if(h > 0)
   {
-    const float Gint = -h + here;
-    if(h > 0)
+    if(3.f * h > (Gint + here))
+      h = -ulim(Gint, before, after) + here;
+    else
     {
-      if(3.f * h > (Gint + here))
-        h = -ulim(Gint, before, after) + here;
-      else
-      {
-        const float wt = 1.f - 3.f * h / (EPS + Gint + here);
-        h = wt * h + (1.f - wt) * (-ulim(Gint, before, after) + here);
-      }
+      const float wt = 1.f - 3.f * h / (EPS + Gint + here);
+      h = wt * h + (1.f - wt) * (-ulim(Gint, before, after) + here);
     }
-    if(Gint > clip_pt) h = -ulim(Gint, before, after) + here;
   }
-  else
-  {
-    const float Gint = h + here;
-    if(h < 0)
-    {
-      if(3.f * h < -(Gint + here))
-        h = ulim(Gint, before, after) - here;
-      else
-      {
-        const float wt = 1.f + 3.f * h / (EPS + Gint + here);
-        h = wt * h + (1.f - wt) * (ulim(Gint, before, after) - here);
-      }
-    }
-    if(Gint > clip_pt) h = ulim(Gint, before, after) - here;
-  }
-  return h;
+  if(Gint > clip_pt) h = -ulim(Gint, before, after) + here;
+  return u2f(f2u(h) ^ flip);
 }
 
 // The tiles this kernel takes: all but those whose mirrored right strip (16 columns from ccmax) or bottom strip (16 rows from
@@ -350,19 +338,17 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
         const float vwt = d0u1 / (d0d1 + d0u1);
         const float Gintvha = vwt * gdha + (1.f - vwt) * guha;
         const float Ginthha = hwt * grha + (1.f - hwt) * glha;
-        if(gsite)
+        // (site - estimate at a green site, estimate - site at a red / blue one: x - y = -(y - x) exactly, one body for both)
+        v = c - (vwt * gdar + (1.f - vwt) * guar);
+        hd = c - (hwt * grar + (1.f - hwt) * glar);
+        va = c - Gintvha;
+        ha = c - Ginthha;
+        if(!gsite)
         {
-          v = c - (vwt * gdar + (1.f - vwt) * guar);
-          hd = c - (hwt * grar + (1.f - hwt) * glar);
-          va = c - Gintvha;
-          ha = c - Ginthha;
-        }
-        else
-        {
-          v = (vwt * gdar + (1.f - vwt) * guar) - c;
-          hd = (hwt * grar + (1.f - hwt) * glar) - c;
-          va = Gintvha - c;
-          ha = Ginthha - c;
+          v = -v;
+          hd = -hd;
+          va = -va;
+          ha = -ha;
           // S4 forms the same two quotients at the R/B sites
           ST(P_HWT, rr, cc >> 1, hwt);
           ST(P_VWT, rr, cc >> 1, vwt);
