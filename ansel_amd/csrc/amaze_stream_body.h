@@ -128,6 +128,9 @@ struct args
   uint32_t filters;
   int ex, ey;
   float clip_pt;
+  // a row band of the frame: `in` holds the mosaic from frame row in_row0 on, `out` the frame rows
+  // [out_row0, out_row1) and nothing else is written.  The whole frame: 0, 0, height
+  int in_row0, out_row0, out_row1;
   int variant; // 0; a measuring run switches the first (1) / the second (2) vote off with it -- the output is then wrong
 };
 
@@ -271,7 +274,7 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     if((r2 && rr >= rrmax + 16) || (c2 && cc >= ccmax + 16)) return 0.f;
     const int row = r0 ? ((c0 || c2) ? 32 - rr : 32 - rr + top) : (r2 ? height - (rr - rrmax) - 2 : rr + top);
     const int col = c0 ? ((r0 || r2) ? 32 - cc : 32 - cc + left) : (c2 ? width - (cc - ccmax) - 2 : cc + left);
-    return in[(size_t)row * width + col];
+    return in[(size_t)(row - a.in_row0) * width + col];
   };
   float pre = mosaic(tid / TS, tid % TS);
   // the tile starts from zeros, like the reference's buffer in the oracle
@@ -930,9 +933,9 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     // ---- phase 13: S14 output, :1278-1411 (alpha is left as it is)
     FOR_FULL(L_S14)
     {
-      if(IN_(rr, 16, rr1 - 16) && IN_(cc, 16, cc1 - 16) && rr + top < height && cc + left < width)
+      if(IN_(rr, 16, rr1 - 16) && IN_(cc, 16, cc1 - 16) && rr + top < height && cc + left < width && IN_(rr + top, a.out_row0, a.out_row1))
       {
-        float *const o = out + 4 * ((size_t)(rr + top) * width + (cc + left));
+        float *const o = out + 4 * ((size_t)(rr + top - a.out_row0) * width + (cc + left));
         const int col = fct(rr, cc, filters);
         if(col & 1)
         {

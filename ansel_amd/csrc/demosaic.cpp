@@ -14,7 +14,7 @@ int green_eq_favg_launch(int devid, const float *in, float *out, int width, int 
 int pre_median_launch(int devid, const float *in, float *out, int width, int height, uint32_t filters, float threshold);
 int color_smoothing_launch(int devid, float4 *img, int width, int height, int passes);
 int passthrough_launch(int devid, const float *in, float4 *out, int width, int height, uint32_t filters, bool color);
-int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out);
+int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out, const rcd_band_t *band);
 int vng4_demosaic_launch(int devid, const dt_hip_piece_t *piece, const float *in, float4 *out);
 int dual_demosaic_launch(int devid, const dt_hip_piece_t *piece, const float *raw, float4 *rgb, float dual_threshold, const float wb[4]);
 }
@@ -124,13 +124,7 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
         if(err == DT_HIP_SUCCESS) err = ppg_demosaic_launch(devid, piece, filters, med ? med : in, in, (float4 *)dev_out);
         break;
       case DT_HIP_DEMOSAIC_AMAZE:
-        if(band)
-        {
-          set_last_error("demosaic: AMaZE has no row-band mode");
-          err = DT_HIP_INVALID_ARG;
-          break;
-        }
-        err = amaze_demosaic_launch(devid, piece, filters, in, (float4 *)dev_out);
+        err = amaze_demosaic_launch(devid, piece, filters, in, (float4 *)dev_out, band);
         break;
       default:
         set_last_error("demosaic: method %u is not implemented on device", d->demosaicing_method);

@@ -859,7 +859,8 @@ struct stream_env_timed : stream_env
 
 template <bool TIMED>
 __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_stream(const float *__restrict__ in, float *__restrict__ out, const amz::args a,
-                                                        const int ntx, const int ntiles, unsigned long long *__restrict__ stamps)
+                                                        const int ntx, const int ntiles, const int ty0,
+                                                        unsigned long long *__restrict__ stamps)
 {
   extern __shared__ __attribute__((aligned(16))) float amz_lds[];
   if(TIMED)
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_stream(const float 
     for(int k = 0; k < 16; k++) env.acc[k] = 0;
     for(int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     {
-      const int top = -16 + (tile / ntx) * (TS - 32), left = -16 + (tile % ntx) * (TS - 32);
+      const int top = -16 + (ty0 + tile / ntx) * (TS - 32), left = -16 + (tile % ntx) * (TS - 32);
       if(!amz::stream_tile_ok(a.width, a.height, top, left)) continue;
       env.t_prev = (long long)__builtin_readcyclecounter();
       amz::tile(env, in, out, a, top, left);
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_stream(const float 
     stream_env env{ amz_lds };
     for(int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     {
-      const int top = -16 + (tile / ntx) * (TS - 32), left = -16 + (tile % ntx) * (TS - 32);
+      const int top = -16 + (ty0 + tile / ntx) * (TS - 32), left = -16 + (tile % ntx) * (TS - 32);
       if(amz::stream_tile_ok(a.width, a.height, top, left)) amz::tile(env, in, out, a, top, left);
     }
   }
@@ -924,7 +925,9 @@ __global__ __launch_bounds__(amz::STREAM_THREADS) void amaze_frame(const float *
 namespace ansel
 {
 
-int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out)
+// band: a row band of the frame -- `in` holds the mosaic rows [in_row0, in_row0 + in_rows), `out` the rows
+// [out_row0, out_row0 + out_rows), the tile rows [tv0, tv1) of the frame's own 128-row tile grid are run; nullptr: the frame
+int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out, const rcd_band_t *band)
 {
   const int width = piece->roi_in.width, height = piece->roi_in.height;
   if(width <= 0 || height <= 0) return DT_HIP_SUCCESS;
@@ -953,14 +956,35 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   a.ntx = (width + 16 + (TS - 32) - 1) / (TS - 32);
   const int nty = (height + 16 + (TS - 32) - 1) / (TS - 32);
   a.ntiles = a.ntx * nty;
-  a.slab_all = getenv("ANSEL_HIP_AMAZE_SLAB") != nullptr;
+  a.slab_all = getenv("ANSEL_HIP_AMAZE_SLAB") != nullptr && !band;
+  const int ty_first = band ? band->tv0 : 0, ty_end = band ? (band->tv1 < nty ? band->tv1 : nty) : nty;
+  if(band)
+  {
+    // what the band's tile rows read of the mosaic and write of the output must be in the buffers
+    const int need0 = ty_first * (TS - 32) - 16 > 0 ? ty_first * (TS - 32) - 16 : 0;
+    const int need1 = ty_end * (TS - 32) + 16 < height ? ty_end * (TS - 32) + 16 : height;
+    if(ty_first < 0 || ty_end <= ty_first || band->in_row0 > need0 || band->in_row0 + band->in_rows < need1
+       || band->out_row0 != ty_first * (TS - 32)
+       || band->out_row0 + band->out_rows != (ty_end * (TS - 32) < height ? ty_end * (TS - 32) : height))
+    {
+      set_last_error("amaze band: tile rows [%d,%d) need frame rows outside the band buffers", ty_first, ty_end);
+      return DT_HIP_INVALID_ARG;
+    }
+    a.ntiles = a.ntx * (ty_end - ty_first);
+  }
   // which tiles keep every plane on chip (amaze_stream_body.h): all but some of the last tile row / column
   int stream_tiles = 0;
   if(!a.slab_all)
-    for(int ty = 0; ty < nty; ty++)
+    for(int ty = ty_first; ty < ty_end; ty++)
       for(int tx = 0; tx < a.ntx; tx++)
         if(amz::stream_tile_ok(width, height, -16 + ty * (TS - 32), -16 + tx * (TS - 32))) stream_tiles++;
   const int slab_tiles = a.ntiles - stream_tiles;
+  if(band && slab_tiles > 0)
+  {
+    set_last_error("amaze band: %d tiles of these tile rows take the first kernel's body (a last tile column of odd width, a mirrored "
+                   "strip past its plane), which has no row-band mode", slab_tiles);
+    return DT_HIP_INVALID_ARG;
+  }
   hipStream_t s = stream_of(devid);
   const bool timed = getenv("ANSEL_HIP_AMAZE_TIMED") != nullptr;
   const bool unfused = timed || getenv("ANSEL_HIP_AMAZE_UNFUSED") != nullptr; // one kernel per kind of tile: for measurements
@@ -971,6 +995,9 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   sa.ex = a.ex;
   sa.ey = a.ey;
   sa.clip_pt = a.clip_pt;
+  sa.in_row0 = band ? band->in_row0 : 0;
+  sa.out_row0 = band ? band->out_row0 : 0;
+  sa.out_row1 = band ? band->out_row0 + band->out_rows : height;
   sa.variant = getenv("ANSEL_HIP_AMAZE_VARIANT") ? atoi(getenv("ANSEL_HIP_AMAZE_VARIANT")) : 0; // measuring builds only
   if(stream_tiles > 0)
   {
@@ -1020,7 +1047,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
       unsigned long long host[32];
       if(hipMemsetAsync(stamps, 0, sizeof(host), s) == hipSuccess)
       {
-        amaze_stream<true><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.ntx, a.ntiles, stamps);
+        amaze_stream<true><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.ntx, a.ntiles, ty_first, stamps);
         if(hipMemcpyAsync(host, stamps, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
           for(int k = 0; k < 16; k++)
             fprintf(stderr, "[amaze_stream_timed] phase %d cycles_per_tile %llu\n", k, host[k] / (unsigned long long)stream_tiles);
@@ -1030,7 +1057,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
     else
     {
       launch_scope ls(devid, "amaze_stream");
-      amaze_stream<false><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.ntx, a.ntiles, nullptr);
+      amaze_stream<false><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.ntx, a.ntiles, ty_first, nullptr);
     }
     const int rc = check_launch("amaze_stream");
     if(rc != DT_HIP_SUCCESS) return rc;

@@ -472,6 +472,7 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
 namespace
 {
 const int RCD_TV = 94, RCD_TS = 112, RCD_HALO = 9; // tile pitch, tile size, RCD_BORDER (rcd.c:70-76)
+const int AMZ_TV = 128, AMZ_HALO = 16;              // AMaZE: rows a tile keeps, rows it reads beyond them (amaze.cc:181-350)
 
 struct band_priv_t
 {
@@ -673,6 +674,32 @@ int dt_hip_plan_bands(int width, int height, int demosaic_method, int n_bands, d
       b.halo_top = b.row0 - tv0 * RCD_TV;
       const int need1 = (tv1 - 1) * RCD_TV + RCD_TS < height ? (tv1 - 1) * RCD_TV + RCD_TS : height;
       b.halo_bottom = need1 > row1 ? need1 - row1 : 0;
+    }
+    return DT_HIP_SUCCESS;
+  }
+  if(demosaic_method == DT_HIP_DEMOSAIC_AMAZE)
+  {
+    // AMaZE's own tiles (amaze.cc:181-350): 160 rows of the mosaic 16 above a tile row's 128 kept rows.  A band owns whole
+    // tile rows, so it needs 16 mosaic rows of either neighbour; the rows a tile mirrors at the frame's bottom edge lie in
+    // the last band's own rows and in what the band above it fetches of them (fewer than 16 rows are left there)
+    if(width < 34 || height < 34) return DT_HIP_INVALID_ARG;
+    const int tile_rows = (height + AMZ_TV - 1) / AMZ_TV;
+    if(tile_rows < n_bands)
+    {
+      set_last_error("dt_hip_plan_bands: %d rows give %d AMaZE tile rows, fewer than %d bands", height, tile_rows, n_bands);
+      return DT_HIP_INVALID_ARG;
+    }
+    for(int k = 0; k < n_bands; k++)
+    {
+      const int tv0 = (int)((long)k * tile_rows / n_bands), tv1 = (int)((long)(k + 1) * tile_rows / n_bands);
+      dt_hip_band_t &b = bands[k];
+      b.tile_row0 = tv0;
+      b.tile_row1 = tv1;
+      b.row0 = tv0 * AMZ_TV;
+      const int row1 = tv1 < tile_rows ? tv1 * AMZ_TV : height;
+      b.rows = row1 - b.row0;
+      b.halo_top = tv0 ? AMZ_HALO : 0;
+      b.halo_bottom = height - row1 < AMZ_HALO ? height - row1 : AMZ_HALO;
     }
     return DT_HIP_SUCCESS;
   }
@@ -2156,9 +2183,9 @@ int dt_hip_pipe_band_finish(dt_hip_pipe_t *pipe, const dt_hip_band_t *band, dt_h
     if(first.op == OP_DEMOSAIC)
     {
       const dt_hip_demosaic_data_t *d = first.as<dt_hip_demosaic_data_t>();
-      if(d->demosaicing_method != DT_HIP_DEMOSAIC_RCD)
+      if(d->demosaicing_method != DT_HIP_DEMOSAIC_RCD && d->demosaicing_method != DT_HIP_DEMOSAIC_AMAZE)
       {
-        set_last_error("band mode: only the RCD demosaic runs on row bands");
+        set_last_error("band mode: only the RCD and AMaZE demosaics run on row bands");
         err = DT_HIP_INVALID_ARG;
       }
       else

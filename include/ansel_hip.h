@@ -746,7 +746,8 @@ int dt_hip_batch_drain(dt_hip_batch_t *batch);
  * A band owns frame rows [row0, row0 + rows) of every module output (all modules of the export
  * pipe run at scale 1 with identical geometry; rawprepare's crop is the only offset).  Bands are
  * cut on RCD tile rows: row0 = 94 * tv0 + 9 (0 for the first band).  The demosaic of a band reads
- * `halo` = 9 mosaic rows of each neighbour; those rows are exchanged once, after the CFA stages:
+ * `halo` = 9 mosaic rows of each neighbour; those rows are exchanged once, after the CFA stages.  With the
+ * AMaZE demosaic the cuts are its own tile rows (row0 = 128 * tv0, amaze.cc:181-350) and the halo 16 rows:
  *
  *   dt_hip_pipe_band_begin()   CFA stages on the band's own rows, into a buffer laid out as
  *                              [halo_top rows][rows][halo_bottom rows] of `row_bytes` each
@@ -789,7 +790,7 @@ typedef struct dt_hip_band_t
 {
   int32_t row0, rows;
   int32_t halo_top, halo_bottom; /* mosaic rows needed from the bands above / below */
-  int32_t tile_row0, tile_row1;  /* RCD tile rows [tile_row0, tile_row1) of the frame */
+  int32_t tile_row0, tile_row1;  /* RCD (or AMaZE) tile rows [tile_row0, tile_row1) of the frame */
 } dt_hip_band_t;
 typedef struct dt_hip_band_state_t
 {

@@ -178,8 +178,25 @@ extern "C" int amaze_host_lds_bytes(void) { return amz::LDS_BYTES; }
 
 // Runs the kernel body over every tile of the frame that amz::stream_tile_ok() admits (the pixels of the other tiles are
 // left as they are in `out`).  Returns the number of schedule errors (0 = none), the first one as text in err.
+static int run_band(const float *in, float *out, int width, int height, uint32_t filters, float clip_pt, int in_row0, int out_row0,
+                    int out_row1, int ty0, int ty1, int *stream_tiles, int *all_tiles, char *err, int errlen);
+
 extern "C" int amaze_host_run(const float *in, float *out, int width, int height, uint32_t filters, float clip_pt,
                               int *stream_tiles, int *all_tiles, char *err, int errlen)
+{
+  return run_band(in, out, width, height, filters, clip_pt, 0, 0, height, 0, 1 << 30, stream_tiles, all_tiles, err, errlen);
+}
+
+// The same on a row band: `in` holds the mosaic from frame row in_row0 on, `out` the frame rows [out_row0, out_row1), the
+// tile rows [ty0, ty1) of the frame's grid are walked (amaze_demosaic_launch() with a band does exactly this)
+extern "C" int amaze_host_run_band(const float *in, float *out, int width, int height, uint32_t filters, float clip_pt, int in_row0,
+                                   int out_row0, int out_row1, int ty0, int ty1, int *stream_tiles, int *all_tiles, char *err, int errlen)
+{
+  return run_band(in, out, width, height, filters, clip_pt, in_row0, out_row0, out_row1, ty0, ty1, stream_tiles, all_tiles, err, errlen);
+}
+
+static int run_band(const float *in, float *out, int width, int height, uint32_t filters, float clip_pt, int in_row0, int out_row0,
+                    int out_row1, int ty0, int ty1, int *stream_tiles, int *all_tiles, char *err, int errlen)
 {
   Shared sh;
   G = &sh;
@@ -201,9 +218,12 @@ extern "C" int amaze_host_run(const float *in, float *out, int width, int height
   sh.a.ex = sh.a.ey = 0;
   sh.a.clip_pt = clip_pt;
   sh.a.variant = 0;
+  sh.a.in_row0 = in_row0;
+  sh.a.out_row0 = out_row0;
+  sh.a.out_row1 = out_row1;
   const int ntx = (width + 16 + (amz::TS - 32) - 1) / (amz::TS - 32), nty = (height + 16 + (amz::TS - 32) - 1) / (amz::TS - 32);
   int all = 0;
-  for(int ty = 0; ty < nty; ty++)
+  for(int ty = ty0 > 0 ? ty0 : 0; ty < nty && ty < ty1; ty++)
     for(int tx = 0; tx < ntx; tx++)
     {
       const int top = -16 + ty * (amz::TS - 32), left = -16 + tx * (amz::TS - 32);

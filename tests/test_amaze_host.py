@@ -171,3 +171,32 @@ def test_the_checker_sees_a_broken_schedule(tmp_path):
     lib.amaze_host_run.restype = C.c_int
     _, ne, err, _, _ = run(lib, textured(300, 200, seed=3), 0x94949494, (1.5, 1.0, 1.2, 1.0))
     assert ne > 0 and ("stale ring slot" in err or "another thread" in err), err
+
+
+@pytest.mark.parametrize("w,h,n", [(600, 400, 2), (496, 432, 3), (288, 330, 2)])
+def test_streaming_tiles_on_row_bands(host_kernel, w, h, n):
+    """the kernel on a row band (dt_hip_plan_bands() with the AMaZE demosaic: whole tile rows, 16 mosaic rows of either
+    neighbour): the band's buffers hold its own rows and the halo only -- everything else is NaN here --, the tile rows are the
+    frame's own, and the assembled bands are the oracle's frame"""
+    cfa = textured(w, h, seed=w)
+    filters, pm = 0x61616161, (1.5, 1.0, 1.2, 1.0)
+    want = oracle(cfa, filters, pm)
+    tile_rows = (h + 127) // 128
+    assert tile_rows >= n
+    lib = host_kernel
+    lib.amaze_host_run_band.restype = C.c_int
+    got = np.full((h, w, 4), -7.0, np.float32)
+    for k in range(n):
+        tv0, tv1 = k * tile_rows // n, (k + 1) * tile_rows // n
+        row0, row1 = tv0 * 128, (tv1 * 128 if tv1 < tile_rows else h)
+        top, bottom = (16 if tv0 else 0), min(16, h - row1)
+        band_in = np.ascontiguousarray(cfa[row0 - top:row1 + bottom])
+        band_out = np.full((row1 - row0, w, 4), -7.0, np.float32)
+        ns, na, err = C.c_int(), C.c_int(), C.create_string_buffer(512)
+        ne = lib.amaze_host_run_band(ck.ptr(band_in), ck.ptr(band_out), w, h, C.c_uint32(filters), C.c_float(min(pm[:3])),
+                                     row0 - top, row0, row1, tv0, tv1, C.byref(ns), C.byref(na), err, 512)
+        assert ne == 0, err.value.decode()
+        assert ns.value == na.value  # every tile of these frames is one the kernel takes
+        got[row0:row1] = band_out
+    assert int((ck.ulp_diff(got[..., :3], want[..., :3]) > 0).sum()) == 0
+    assert (got[..., 3] == -7.0).all()

@@ -25,9 +25,11 @@ def _setup():
     return torch, lut, d_lut
 
 
-def _nodes(w, h, d_lut, lut):
+def _nodes(w, h, d_lut, lut, demosaic_method=None):
+    from ansel_amd import abi
     return pipe.light_pipe_nodes(w, h, d_lut.data_ptr(), float(lut[0]), params.unbounded_coeffs(lut),
-                                 with_filmic=True, filmic=filmic.default_data())
+                                 with_filmic=True, filmic=filmic.default_data(),
+                                 demosaic_method=abi.DT_HIP_DEMOSAIC_RCD if demosaic_method is None else demosaic_method)
 
 
 def _whole(torch, nodes, raw, w, h, fusion):
@@ -60,6 +62,30 @@ def test_bands_equal_the_unsplit_frame(w, h, n, fusion):
     nodes = _nodes(w, h, d_lut, lut)
     raw = synth.bayer_mosaic(w, h, seed=5)
     assert np.array_equal(_banded(torch, nodes, raw, w, h, n, fusion), _whole(torch, nodes, raw, w, h, fusion))
+
+
+@pytest.mark.parametrize("w,h,n", [(1504, 1000, 2), (1504, 1000, 5), (600, 400, 3), (752, 2000, 8)])
+def test_bands_with_the_amaze_demosaic_equal_the_unsplit_frame(w, h, n):
+    """AMaZE on row bands: whole tile rows of the frame's own 128-row grid per band, 16 mosaic rows of either neighbour; the
+    on-chip kernel indexes the band's buffers with frame rows"""
+    from ansel_amd import abi
+    torch, lut, d_lut = _setup()
+    nodes = _nodes(w, h, d_lut, lut, abi.DT_HIP_DEMOSAIC_AMAZE)
+    raw = synth.bayer_mosaic(w, h, seed=7)
+    whole = _whole(torch, nodes, raw, w, h, True)
+    assert np.array_equal(_banded(torch, nodes, raw, w, h, n, True), whole)
+    assert np.array_equal(_c_driver(torch, nodes, raw, w, h, n), whole)
+
+
+def test_amaze_bands_of_a_frame_with_tiles_of_the_first_kind_are_refused():
+    """a frame of odd width keeps its last tile column in the first kernel, which has no row-band mode"""
+    from ansel_amd import abi
+    torch, lut, d_lut = _setup()
+    w, h = 517, 389
+    nodes = _nodes(w, h, d_lut, lut, abi.DT_HIP_DEMOSAIC_AMAZE)
+    raw = synth.bayer_mosaic(w, h, seed=7)
+    with pytest.raises(lib.AnselHipError, match="no row-band mode"):
+        _banded(torch, nodes, raw, w, h, 2, True)
 
 
 @pytest.mark.parametrize("fusion", [True, False])

@@ -17,7 +17,7 @@ sys.path.insert(0, HERE)
 
 import band_engine as be  # noqa: E402
 import checkers as ck  # noqa: E402
-from ansel_amd import abi, filmic, params, pipe, tiled  # noqa: E402
+from ansel_amd import abi, filmic, lib, params, pipe, tiled  # noqa: E402
 
 needs_oracle = pytest.mark.skipif(ck.oracle() is None, reason="oracle/liboracle.so not built")
 
@@ -46,6 +46,31 @@ def test_rcd_bands_partition_the_frame_on_tile_rows(w, h, n):
         assert b.rows >= 9  # a neighbour's halo never spans more than one band
 
 
+@pytest.mark.parametrize("w,h,n", [(1504, 1000, 2), (1504, 1000, 5), (600, 400, 3), (11648, 8736, 8), (500, 129, 2)])
+def test_amaze_bands_partition_the_frame_on_tile_rows(w, h, n):
+    """with the AMaZE demosaic a band owns whole 128-row tile rows of the frame's own grid and asks either neighbour for the 16
+    mosaic rows its tiles read beyond them (fewer where the frame ends first)"""
+    bands = tiled.plan_bands(w, h, n, abi.DT_HIP_DEMOSAIC_AMAZE)
+    tile_rows = (h + 127) // 128
+    assert bands[0].row0 == 0 and bands[0].halo_top == 0 and bands[-1].halo_bottom == 0
+    assert bands[-1].row0 + bands[-1].rows == h and bands[0].tile_row0 == 0 and bands[-1].tile_row1 == tile_rows
+    for k, b in enumerate(bands):
+        assert b.rows > 0 and b.row0 == 128 * b.tile_row0 and b.tile_row1 > b.tile_row0
+        if k:
+            assert b.row0 == bands[k - 1].row0 + bands[k - 1].rows and b.tile_row0 == bands[k - 1].tile_row1 and b.halo_top == 16
+        if k + 1 < n:
+            assert b.halo_bottom == min(16, h - b.row0 - b.rows)
+        # what the band's tiles read of the mosaic is in its own rows + halo
+        first = max(128 * b.tile_row0 - 16, 0)
+        last = min(128 * b.tile_row1 + 16, h)
+        assert b.row0 - b.halo_top <= first and b.row0 + b.rows + b.halo_bottom >= last
+
+
+def test_amaze_bands_need_a_tile_row_each():
+    with pytest.raises(lib.AnselHipError):
+        tiled.plan_bands(600, 400, 5, abi.DT_HIP_DEMOSAIC_AMAZE)  # 4 tile rows
+
+
 def test_bands_without_demosaic_are_two_row_aligned():
     bands = tiled.plan_bands(640, 486, 4, demosaic_method=-1)
     assert sum(b.rows for b in bands) == 486
@@ -60,10 +85,10 @@ def _free_port():
     return port
 
 
-def _nodes(w, h, lut):
+def _nodes(w, h, lut, demosaic_method=abi.DT_HIP_DEMOSAIC_RCD):
     coeffs = params.unbounded_coeffs(lut)
     return pipe.light_pipe_nodes(w, h, lut.ctypes.data, float(lut[0]), coeffs, with_filmic=True,
-                                 filmic=filmic.default_data())
+                                 filmic=filmic.default_data(), demosaic_method=demosaic_method)
 
 
 def _rank_main(rank, world, port, w, h, n_top, n_bottom, outdir):
@@ -113,6 +138,22 @@ def test_local_protocol_matches_the_unsplit_frame_for_three_bands(n_top, n_botto
     nodes = _nodes(w, h, lut)
     raw = be.test_frame(w, h, n_top, n_bottom)
     bands = tiled.plan_bands(w, h, n)
+    engine = be.OracleBandEngine(nodes, w, h)
+    outs = [np.zeros((b.rows, w, 4), np.uint16) for b in bands]
+    tiled.process_bands_locally(engine, bands, [raw[b.row0:b.row0 + b.rows] for b in bands], outs, w)
+    assert np.array_equal(np.concatenate(outs, axis=0), be.whole_frame(nodes, raw, w, h))
+
+
+@needs_oracle
+@pytest.mark.parametrize("w,h,n", [(256, 500, 3), (300, 330, 2)])
+def test_local_protocol_with_the_amaze_demosaic(w, h, n):
+    """the same with AMaZE: bands of whole 128-row tile rows, 16 halo rows; each band demosaics a frame that is zero beyond
+    its rows and halo, so the assembled frame equals the unsplit one only if that halo is what its tiles read"""
+    lut = params.srgb_encode_lut()
+    nodes = _nodes(w, h, lut, abi.DT_HIP_DEMOSAIC_AMAZE)
+    raw = be.test_frame(w, h, 12, 8)
+    bands = tiled.plan_bands(w, h, n, tiled.pipe_demosaic_method(nodes))
+    assert bands[1].halo_top == 16
     engine = be.OracleBandEngine(nodes, w, h)
     outs = [np.zeros((b.rows, w, 4), np.uint16) for b in bands]
     tiled.process_bands_locally(engine, bands, [raw[b.row0:b.row0 + b.rows] for b in bands], outs, w)
