@@ -998,7 +998,8 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   sa.in_row0 = band ? band->in_row0 : 0;
   sa.out_row0 = band ? band->out_row0 : 0;
   sa.out_row1 = band ? band->out_row0 + band->out_rows : height;
-  sa.variant = getenv("ANSEL_HIP_AMAZE_VARIANT") ? atoi(getenv("ANSEL_HIP_AMAZE_VARIANT")) : 0; // measuring builds only
+  // (honoured by the measuring launch only: with a part of a phase switched off the output is wrong)
+  sa.variant = timed && getenv("ANSEL_HIP_AMAZE_VARIANT") ? atoi(getenv("ANSEL_HIP_AMAZE_VARIANT")) : 0;
   if(stream_tiles > 0)
   {
     // the opt-in to more than 64 KB of LDS is per device
