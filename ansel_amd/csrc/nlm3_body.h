@@ -82,6 +82,29 @@ template <int NPXL> inline size_t lds_floats(const int chk_h, const int reach)
   return (size_t)4 * max_rows<NPXL>() * NL3_TP + 2 * 5 * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
 }
 
+// ---- the fused variant (round 4; launched as nlm_chunks_v4): THREE tables and no B role.  Chunks of 57 - 64 rows (the 45 MP
+// and 60 MP frames' grids: 64) do not fit four tables beside the window (179 KB), nor 2 + 1 + 6 + 8 = 17 waves a workgroup.
+// The row recurrence moves into the C role: a C lane owns NPXL = 9 adjacent pixels of a row, eight lanes a row; it reads
+// the NPXL + 5 column sums its pixels' patches span, and the recurrence runs along the row in eight phases -- in phase k the
+// lanes k of every row hold their final sums, the carry travels to lane k + 1 by a DPP row shift (lanes k' < k just
+// recompute what they had: no lane mask).  72 dependent additions per wave and offset instead of per workgroup, but no
+// table that lives for a fourth stage, no 37 b128 accesses per row, and sixteen waves: A2 A2 A1 A1 | A1 A1 A1 A1 | C x 8.
+constexpr int FUSED_MAXCH = 64;
+template <int NPXL> inline size_t lds_floats_fused(const int chk_h, const int reach)
+{
+  return (size_t)3 * FUSED_MAXCH * NL3_TP + 2 * 5 * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
+}
+template <int NPXL, int MSEG> inline bool fits_fused(const int chk_w, const int chk_h, const int radius, const int reach)
+{
+  constexpr int S = 5, LPR = (72 + NPXL - 1) / NPXL;
+  if(radius != 2 || chk_w > 72 || (chk_w & 1) || chk_w + 2 * reach > 2 * NL3_WPH || chk_h > FUSED_MAXCH || chk_h < 2 * S) return false;
+  if(LPR != 8) return false; // two pixel rows per 16-lane DPP row
+  const int ncp = (chk_w + 4) / 2;
+  if(ncp < 32 || ncp > 38) return false;
+  const int nseg = NL3_A1_LANES / (ncp * S), m0 = (chk_h - 2) / S + 1;
+  return nseg == 2 && (m0 + nseg - 1) / nseg <= MSEG;
+}
+
 // can this body take the chunk grid?  (the launch and the host harness ask the same question)
 template <int NPXL, int MSEG> inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach)
 {
@@ -125,7 +148,7 @@ template <int T0, int T1, int ROWBYTES, class Env> struct column_chain
   }
 };
 
-// Env: tid(), bid(), lds(), sync(), prio_high(), st_addtid<>(), cvt_i32_sat(), int_as_float().  Args: nlm_args of nlmeans.hip.
+// Env: tid(), bid(), lds(), sync(), prio_high(), st_addtid<>(), lane_shr1(), cvt_i32_sat(), int_as_float().  Args: nlm_args of nlmeans.hip.
 // BORDER: a chunk of the outermost ring, where patches and shifted pixels leave the frame and the reference clips, per
 // offset, the rows and columns a patch sums (init_column_sums(), :208-262; the three branches of :437-488) and the
 // pixels it weighs (:398-404).  All of that clipping is "this squared difference is not there", and the interior's
@@ -138,12 +161,14 @@ template <int T0, int T1, int ROWBYTES, class Env> struct column_chain
 //   * the row recurrence needs no clipping at all: in front of the first weighed column it adds zeros;
 //   * C gives weight +0 to the pixels the offset does not reach (their shifted pixel is a zero of the window).
 // The chunk may be narrower / lower than the grid's (the frame's last column and row of chunks).
-template <int NPXL, int MSEG, bool BORDER = false, class Env, class Args, class F4, class I2>
+template <int NPXL, int MSEG, bool BORDER = false, bool FUSED = false, class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
                   const int ndx)
 {
   constexpr int P = 2, S = 2 * P + 1, TP = NL3_TP, XO = NL3_XO, FP = NL3_FP, WPH = NL3_WPH;
-  constexpr int MAXCH = max_rows<NPXL>();
+  constexpr int MAXCH = FUSED ? FUSED_MAXCH : max_rows<NPXL>();
+  constexpr int NT = FUSED ? 3 : 4; // tables: offset p lives in table tslot(p) from its A1 to its C
+  auto tslot = [](const int p) { return FUSED ? p % 3 : (p & 3); };
   constexpr int LPR = (72 + NPXL - 1) / NPXL; // C lanes per chunk row
   const int tid = env.tid();
   const int W = a.W, H = a.H;
@@ -165,8 +190,8 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   // beyond the window for the last chains -- and those words must exist (what they hold does not matter)
   float *const XY = lds;                        // [wh][2][WPH] 8-byte words
   float *const Z = XY + 2 * (wh * 2 * WPH);     // [wh][2][WPH]
-  float *const tab = Z + wh * 2 * WPH;          // [4][MAXCH][TP]
-  float *const Fb = tab + 4 * tabsz;            // [2][S][FP]
+  float *const tab = Z + wh * 2 * WPH;          // [NT][MAXCH][TP]
+  float *const Fb = tab + NT * tabsz;           // [2][S][FP]
   const int r0 = top - reach, c0 = left - reach;
   const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
   const int ww = cw + 2 * reach; // window columns that exist
@@ -193,11 +218,11 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int w = tid >> 6, lane = tid & 63;
   const int var = a.variant; // 0; timing experiments (ANSEL_NLM2_VARIANT): 16 / 32 / 64 / 128 switch A1 / A2 / B / C off (wrong results)
   // ---------------------------------------------------------------------------------------------------------------------
-  if(w == 3 || (w >= 4 && w <= 7) || w == 10)
+  if(FUSED ? (w >= 2 && w <= 7) : (w == 3 || (w >= 4 && w <= 7) || w == 10))
   {
     // ---- A1: the terms of the column recurrence (nlmeans_core.c:437-488) for table rows 1.., and the five squared
     //      differences the first table row sums (init_column_sums(), :208-262)
-    const int ai = w == 3 ? 0 : (w == 10 ? 5 : w - 3);
+    const int ai = FUSED ? w - 2 : (w == 3 ? 0 : (w == 10 ? 5 : w - 3));
     const int ncp = (cw + 2 * P + 1) / 2; // (an odd last slot has a partner nobody reads)
     const int nseg = 2;                   // fits(); a narrower border chunk keeps the layout and repeats items
     const int m0 = (ch - 2) / S + 1;
@@ -292,7 +317,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // stores its terms and waits at the barrier
     auto step = [&](auto ph_tag, const int p, const int dx) {
       constexpr int PH = decltype(ph_tag)::value;
-      float *const T = tab + (p & 3) * tabsz;
+      float *const T = tab + tslot(p) * tabsz;
       float *const F = Fb + (p & 1) * S * FP;
       const int fo = head ? foff : DUMMY;
       bool col_ok[2] = { true, true };
@@ -395,7 +420,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     }
     env.sync();
     env.sync();
-    env.sync();
+    if(!FUSED) env.sync();
     return;
   }
   // ---------------------------------------------------------------------------------------------------------------------
@@ -410,7 +435,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     {
       if(active)
       {
-        float *const col = tab + (p & 3) * tabsz + XO + x;
+        float *const col = tab + tslot(p) * tabsz + XO + x;
         const float *const F = Fb + (p & 1) * S * FP + XO + x;
         // all MAXCH rows, whatever the chunk's height: rows beyond it hold garbage that nobody reads (a guard per row
         // costs a lane mask per row: 55 pairs of scalar registers, spilled)
@@ -422,18 +447,18 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         float v = 0.0f;
 #pragma unroll
         for(int r = 0; r < S; r++) v += f[r];
-        float *const wave_base = tab + (p & 3) * tabsz + XO + 1 + w * 64; // lane 0's column
+        float *const wave_base = tab + tslot(p) * tabsz + XO + 1 + w * 64; // lane 0's column
         env.template st_addtid<0>(wave_base, lane, v);
         column_chain<1, MAXCH, TP * 4, Env>::run(env, wave_base, lane, v, term);
       }
       env.sync();
     }
     env.sync();
-    env.sync();
+    if(!FUSED) env.sync();
     return;
   }
   // ---------------------------------------------------------------------------------------------------------------------
-  if(w == 2)
+  if(!FUSED && w == 2)
   {
     // ---- B: the sliding row sum (:405-415), one lane per table row: the row fetched as 19 x 16 bytes, the distortion of
     //      chunk column c stored at slot c + 1 (18 x 16 bytes)
@@ -494,7 +519,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // step j of a row sits in slot (i + j) % (NPXL + 1); the slot the incoming pixel takes was last read two steps ago.
     constexpr int NR = NPXL + 1;
     static_assert(NR % 2 == 0, "the distortions alternate between two register sets with the ring's period");
-    const int ci = w == 8 ? 0 : (w == 9 ? 1 : w - 9);
+    const int ci = FUSED ? w - 8 : (w == 8 ? 0 : (w == 9 ? 1 : w - 9));
     // a wave holds 8 chunk rows x 8 lanes; its lanes 0-31 take the even rows, 32-63 the odd ones: the nine distortions a
     // lane reads sit 9 words apart within a row and 84 apart between rows, and four rows TWO apart put the 32 lanes of an
     // LDS pass on 32 different banks (four consecutive rows: 2-way conflicts on every read)
@@ -512,12 +537,56 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     for(int i = 0; i < NR; i++) qx[i] = qy[i] = qz[i] = 0.0f;
     const int doff = r * TP + 4 + cb;
     const float sharp_m23 = a.sharpness * -8388608.0f;
+    // FUSED: the column sums of slots cb .. cb + NPXL + S - 1 (slot x at x + XO), fetched by every lane of the wave -- rows
+    // beyond the chunk are table rows nobody wrote, and nobody uses what comes of them
+    [[maybe_unused]] float cs[NPXL + S];
+    [[maybe_unused]] const bool row_head = j8 == 0;
+    [[maybe_unused]] auto fetch_sums = [&](const int p) {
+      const float *const T = tab + tslot(p) * tabsz + r * TP + XO + cb;
+#pragma unroll
+      for(int i = 0; i < NPXL + S; i++) cs[i] = T[i];
+    };
+    // FUSED: the sliding row sum (:405-415) of the offset whose column sums are in cs[], into dist[M & 1].  The chain of a
+    // row runs through its eight lanes: phase k completes lane k, whose last sum is the carry of lane k + 1 (a DPP shift
+    // by one lane; lane 0 of a row starts from the sum of the first 2 P columns); every lane recomputes its nine sums in
+    // every phase from the carry it sees -- from its own phase on that is the final one.
+    [[maybe_unused]] auto row_chain = [&](auto m_tag) {
+      constexpr int M = decltype(m_tag)::value;
+      float e[NPXL];
+      // slot 0: the column in front of every patch is never summed (init_column_sums())
+      e[0] = cs[S] - (row_head ? 0.0f : cs[0]);
+#pragma unroll
+      for(int i = 1; i < NPXL; i++) e[i] = cs[i + S] - cs[i];
+      float first = 0.0f;
+#pragma unroll
+      for(int kk = 1; kk < S; kk++) first += cs[kk]; // columns left - P .. left + P - 1 (the row's lane 0 only)
+      float carry = first;
+#pragma unroll
+      for(int ph = 0; ph < LPR; ph++)
+      {
+        float d = carry;
+#pragma unroll
+        for(int i = 0; i < NPXL; i++)
+        {
+          d = d + e[i];
+          dist[M & 1][i] = d;
+        }
+        if(ph + 1 < LPR)
+        {
+          const float from_left = env.lane_shr1(d);
+          carry = row_head ? first : from_left;
+        }
+      }
+    };
 
     auto fetch = [&](auto m_tag, const int p, const bool first, const int dy, const int dx) {
       constexpr int M = decltype(m_tag)::value;
-      const float *const T = tab + (p & 3) * tabsz + doff;
+      if constexpr(!FUSED)
+      {
+        const float *const T = tab + (p & 3) * tabsz + doff;
 #pragma unroll
-      for(int i = 0; i < NPXL; i++) dist[M & 1][i] = T[i];
+        for(int i = 0; i < NPXL; i++) dist[M & 1][i] = T[i];
+      }
       if(BORDER)
       {
         unsigned m = 0;
@@ -567,7 +636,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     };
     env.sync();
     env.sync();
-    env.sync();
+    if(!FUSED) env.sync();
     for(int dyi = 0; dyi < ndy; dyi++)
     {
       const int dy = patches[dyi * ndx].x, dx0 = patches[dyi * ndx].y;
@@ -577,7 +646,20 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
           constexpr int M = decltype(m_tag)::value;
           if(jb + M < ndx)
           {
-            if(active)
+            if constexpr(FUSED)
+            {
+              // the sums and the pixel of this offset are fetched, the offset before is accumulated while they travel,
+              // then the row recurrence of this offset
+              fetch_sums(dyi * ndx + jb + M);
+              if(active)
+              {
+                fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
+                if(jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
+              }
+              if(!(var & 64)) row_chain(m_tag);
+              if(active && jb + M + 1 == ndx) accumulate(m_tag);
+            }
+            else if(active)
             {
               fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
               if(jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());

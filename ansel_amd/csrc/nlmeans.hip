@@ -801,6 +801,11 @@ struct nlm2_device_env
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%2" : : "s"(m0v), "v"(v), "n"(OFF) : "memory", "m0");
   }
   __device__ __forceinline__ bool any(const bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0; }
+  // the value of the lane to the left within a row of 16 lanes (DPP row_shr:1); lane 0 of a row gets 0
+  __device__ __forceinline__ float lane_shr1(const float v) const
+  {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+  }
   static constexpr bool TIMED = false;
   __device__ __forceinline__ long long clock() const { return 0; }
   static __device__ __forceinline__ float int_as_float(const int v) { return __int_as_float(v); }
@@ -876,6 +881,29 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__res
     return;
   }
   nlm3::body<NPXL, MSEG>(env, in, out, a, patches, ndx);
+}
+
+// the fused variant of the third version (nlm3_body.h, FUSED): three tables, the row recurrence inside the C role --
+// chunks of up to 64 rows (the 45 MP and 60 MP frames' grids)
+template <int NPXL, int MSEG>
+__global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                             const nlm_args a, const int2 *__restrict__ patches,
+                                                             const int *__restrict__ order, const int n_border, const int ndx)
+{
+  extern __shared__ float lds[];
+  const int chunk = order[blockIdx.x];
+  nlm2_device_env env;
+  env.lds_ = lds;
+  env.chunk_ = chunk;
+  if(blockIdx.x < n_border)
+  {
+    const int cy = chunk / a.nchx + a.cy0, cx = chunk % a.nchx;
+    const int cw = min(a.chk_w, a.W - cx * a.chk_w), ch = min(a.chk_h, a.H - cy * a.chk_h);
+    if(!nlm3::border_fits(cw, ch)) pipelined_body(chunk, lds, in, out, a, patches);
+    else nlm3::body<NPXL, MSEG, true, true>(env, in, out, a, patches, ndx);
+    return;
+  }
+  nlm3::body<NPXL, MSEG, false, true>(env, in, out, a, patches, ndx);
 }
 
 typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
@@ -1040,6 +1068,12 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   const bool v3 = v2 && nlm3::fits<9, 6>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                   && getenv("ANSEL_HIP_NLM_V2") == nullptr;
   const size_t v3_bytes = std::max(nlm3::lds_floats<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
+  // its fused variant for the grids the third version does not take (57 - 64 rows); ANSEL_HIP_NLM_FUSED=1: wherever it fits
+  const size_t v4_bytes = std::max(nlm3::lds_floats_fused<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
+  const char *const fused_env = getenv("ANSEL_HIP_NLM_FUSED");
+  const bool v4 = v2 && nlm3::fits_fused<9, 7>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
+                  && v4_bytes <= 160 * 1024 && getenv("ANSEL_HIP_NLM_V2") == nullptr
+                  && (fused_env ? atoi(fused_env) != 0 : !(v3 && v3_bytes <= 160 * 1024));
   static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS && NL3_THREADS == NLM_THREADS,
                 "nlm_chunks_v2 / _v3 share the launch shape of nlm_chunks_pipelined");
   nlm2_kernel_t k2 = nullptr;
@@ -1087,7 +1121,13 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   {
     launch_scope ls(devid, "nlm_chunks");
     const unsigned grid = (unsigned)nchunks;
-    if(v3 && v3_bytes <= 160 * 1024)
+    if(v4)
+    {
+      const auto k4 = nlm_chunks_v4<9, 7>;
+      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v4_bytes));
+      k4<<<grid, NL3_THREADS, v4_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3);
+    }
+    else if(v3 && v3_bytes <= 160 * 1024)
     {
       const auto k3 = nlm_chunks_v3<9, 6>;
       ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v3_bytes));

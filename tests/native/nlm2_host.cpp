@@ -43,11 +43,38 @@ struct Args
   int variant;
 };
 
+// what the lanes of a wave exchange (DPP on the device): a slot per thread, two sets used in turn, one wave barrier per exchange
+struct WaveExchange
+{
+  float slot[2][1024];
+  std::barrier<> *wave_bar[16];
+  WaveExchange()
+  {
+    for(auto &b : wave_bar) b = new std::barrier<>(64);
+  }
+  ~WaveExchange()
+  {
+    for(auto &b : wave_bar) delete b;
+  }
+};
+
 struct HostEnv
 {
   int tid_, bid_;
   float *lds_;
   std::barrier<> *bar_;
+  WaveExchange *xch_ = nullptr;
+  mutable int xch_turn_ = 0;
+  // DPP row_shr:1: the value of the lane to the left within a row of 16 lanes, 0 for the row's first lane.  Every lane of
+  // the wave calls it (the device executes it with all lanes enabled)
+  float lane_shr1(const float v) const
+  {
+    const int set = xch_turn_ & 1;
+    xch_turn_++;
+    xch_->slot[set][tid_] = v;
+    xch_->wave_bar[tid_ >> 6]->arrive_and_wait();
+    return (tid_ & 15) ? xch_->slot[set][tid_ - 1] : 0.0f;
+  }
   int tid() const { return tid_; }
   int bid() const { return bid_; }
   float *lds() const { return lds_; }
@@ -188,11 +215,12 @@ extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_
 //      0 when the configuration is not one it takes (the launch falls back to the second version then), < 0 on error.
 namespace
 {
-template <int NPXL, int MSEG>
+template <int NPXL, int MSEG, bool FUSED = false>
 void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats, const int ndx,
           const bool border = false)
 {
   std::vector<float> lds(lds_floats + 4096, 0.0f);
+  WaveExchange xch;
   float *base = lds.data();
   while((uintptr_t)base & 15) base++; // the kernel's 16-byte LDS accesses
   std::barrier<> bar(NL3_THREADS);
@@ -202,12 +230,13 @@ void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nch
     pool.emplace_back([&, t]() {
       for(int b = 0; b < nchunks; b++)
       {
-        HostEnv env{ t, b, base, &bar };
-        nlm3::body<NPXL, MSEG>(env, in, out, a, patches, ndx);
+        HostEnv env{ t, b, base, &bar, &xch };
+        nlm3::body<NPXL, MSEG, false, FUSED>(env, in, out, a, patches, ndx);
         bar.arrive_and_wait();
         if(border)
         {
-          nlm3::body<NPXL, MSEG, true>(env, in, out, a, patches, ndx); // the chunks of the outermost ring it takes
+          HostEnv envb{ t, b, base, &bar, &xch };
+          nlm3::body<NPXL, MSEG, true, FUSED>(envb, in, out, a, patches, ndx); // the chunks of the outermost ring it takes
           bar.arrive_and_wait();
         }
       }
@@ -218,7 +247,22 @@ void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nch
 
 static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                           int search_radius, float scale, float scattering, float sharpness, const float *norm,
-                          float luma, float chroma, int *interior_chunks, const bool border);
+                          float luma, float chroma, int *interior_chunks, const bool border, const bool fused = false);
+// ---- the fused variant (nlm3_body.h FUSED, launched as nlm_chunks_v4): three tables, the row recurrence in the C role
+extern "C" int nlm4_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                             int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                             float luma, float chroma, int *interior_chunks)
+{
+  return nlm3_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma,
+                        chroma, interior_chunks, false, true);
+}
+extern "C" int nlm4_host_run_all(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                                 int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                                 float luma, float chroma, int *chunks)
+{
+  return nlm3_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma,
+                        chroma, chunks, true, true);
+}
 extern "C" int nlm3_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                              int search_radius, float scale, float scattering, float sharpness, const float *norm,
                              float luma, float chroma, int *interior_chunks)
@@ -236,7 +280,7 @@ extern "C" int nlm3_host_run_all(const float *in, float *out, int W, int H, int 
 }
 static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                           int search_radius, float scale, float scattering, float sharpness, const float *norm,
-                          float luma, float chroma, int *interior_chunks, const bool border)
+                          float luma, float chroma, int *interior_chunks, const bool border, const bool fused)
 {
   std::vector<I2> patches;
   int max_shift = 0;
@@ -267,8 +311,10 @@ static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, 
   a.out_row0 = 0;
   a.out_row1 = H;
   int ndx = 0;
-  if(!nlm3::fits<9, 6>(chk_w, chk_h, patch_radius, a.reach) || !nlm3::regular_grid(patches.data(), a.npatch, &ndx)) return 0;
-  const size_t lds_floats = nlm3::lds_floats<9>(chk_h, a.reach);
+  if(!(fused ? nlm3::fits_fused<9, 7>(chk_w, chk_h, patch_radius, a.reach) : nlm3::fits<9, 6>(chk_w, chk_h, patch_radius, a.reach))
+     || !nlm3::regular_grid(patches.data(), a.npatch, &ndx))
+    return 0;
+  const size_t lds_floats = fused ? nlm3::lds_floats_fused<9>(chk_h, a.reach) : nlm3::lds_floats<9>(chk_h, a.reach);
   if(lds_floats * sizeof(float) > 160 * 1024) return 0;
   int interior = 0;
   for(int cy = 0; cy < nchy; cy++)
@@ -282,6 +328,7 @@ static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, 
         interior++;
     }
   if(interior_chunks) *interior_chunks = interior;
-  run3<9, 6>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx, border);
+  if(fused) run3<9, 7, true>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx, border);
+  else run3<9, 6>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx, border);
   return 1;
 }

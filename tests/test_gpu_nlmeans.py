@@ -62,6 +62,31 @@ def test_nlmeans_third_version_chunk_grids(w, h, luma, chroma, monkeypatch):
     assert np.array_equal(got2.view(np.uint32), got3.view(np.uint32))
 
 
+# (width, height) -> chunk: (260, 192) 72 x 64 (the 45 MP / 60 MP frames' grid); (330, 171) 72 x 57; (170, 183) 64 x 61;
+# (700, 315) 72 x 63; (1200, 640) 72 x 64, 16 x 10 chunks; (150, 128) 64-row chunks all in the border ring
+@pytest.mark.parametrize("w,h,luma,chroma", [(260, 192, 0.5, 1.0), (330, 171, 1.0, 1.0), (170, 183, 0.3, 0.8), (700, 315, 0.5, 1.0),
+                                             (1200, 640, 0.5, 1.0), (150, 128, 0.5, 1.0), (293, 247, 0.5, 1.0)])
+def test_nlmeans_fused_variant_chunk_grids(w, h, luma, chroma, monkeypatch):
+    """frames whose chunks have 57 - 64 rows: the fused variant of the third version (nlm3_body.h FUSED, nlm_chunks_v4:
+    three tables, the row recurrence inside the weights' waves); the second version (ANSEL_HIP_NLM_V2, measuring builds
+    only) gives the same words"""
+    img = _lab_image(w, h, 37)
+    d = abi.NlmeansData(2.0, 50.0, luma, chroma)
+    got4 = _check("nlmeans", abi.Piece.make(w, h), d, img)
+    monkeypatch.setenv("ANSEL_HIP_NLM_V2", "1")
+    got2 = hc.run_hip("dt_hip_iop_nlmeans_process", abi.Piece.make(w, h), d, img, img.shape)
+    assert np.array_equal(got2.view(np.uint32), got4.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h", [(330, 168), (1200, 560)])
+def test_nlmeans_fused_variant_on_the_third_versions_grids(w, h, monkeypatch):
+    """ANSEL_HIP_NLM_FUSED=1 (measuring builds): the fused variant on chunk grids the third version takes"""
+    img = _lab_image(w, h, 41)
+    d = abi.NlmeansData(2.0, 50.0, 0.5, 1.0)
+    monkeypatch.setenv("ANSEL_HIP_NLM_FUSED", "1")
+    _check("nlmeans", abi.Piece.make(w, h), d, img)
+
+
 @pytest.mark.parametrize("radius", [5.0, 9.0])
 def test_nlmeans_large_patch_radius_takes_the_fallback_kernels(radius):
     """patch radii whose column-sum table is wider than the pipelined kernel's fixed pitch (P >= 5) run the

@@ -159,3 +159,79 @@ def test_third_version_border_ring_on_the_host_equals_the_oracle(host_kernel, or
     nrows_last = h - (h - 1) // ch * ch
     expect = w * (h if nrows_last >= 10 else h - nrows_last)
     assert int(written.sum()) == expect
+
+
+# ---- the fused variant (nlm3_body.h FUSED, launched as nlm_chunks_v4): three tables, the row recurrence inside the C role
+#      (a DPP lane shift on the device, a per-wave exchange here).  The chunk grids of 57 - 64 rows -- the 45 MP and 60 MP
+#      frames': 64 -- and, for the A/B against the third version, the ones that one takes too.
+# (width, height, search radius, luma, chroma, expected chunk, interior chunks)
+CASES4 = [
+    (260, 192, 7, 0.5, 1.0, (72, 64), 2),    # the 45 MP / 60 MP frames' chunk: 72 x 64, the module's defaults
+    (260, 171, 7, 1.0, 1.0, (72, 57), 2),    # 57 rows: one more than the third version's
+    (170, 183, 3, 0.3, 0.8, (64, 61), 1),    # 64 x 61, rows of 7 offsets
+    (260, 168, 7, 0.5, 1.0, (72, 56), 2),    # the 100 MP frame's chunk on the fused schedule
+]
+
+
+@pytest.mark.parametrize("w,h,K,luma,chroma,chunk,n_interior", CASES4)
+def test_fused_variant_on_the_host_equals_the_oracle(host_kernel, oracle_lib, w, h, K, luma, chroma, chunk, n_interior):
+    o = oracle_lib
+    P = 2
+    img = _lab(w, h, 7 + K)
+    p = NlmParams(0.0, 1.0, luma, chroma, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    assert (cw, ch) == chunk
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm4_host_run(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(0.0),
+                                   C.c_float(p.sharpness), p.norm, C.c_float(luma), C.c_float(chroma), C.byref(seen))
+    assert rc == 1
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    assert seen.value == n_interior
+    written = ~np.isnan(got[..., 0])
+    assert int(written.sum()) == n_interior * cw * ch
+    bad = written & (got.view(np.uint32) != want.view(np.uint32)).any(axis=-1)
+    assert int(bad.sum()) == 0, "%d of %d written pixels differ; first at %s" % (int(bad.sum()), int(written.sum()), np.argwhere(bad)[:5].tolist())
+
+
+def test_fused_variant_refuses_what_it_does_not_fit(host_kernel):
+    img = np.zeros((207, 256, 4), np.float32)
+    norm = (C.c_float * 4)(1, 1, 1, 1)
+    tail = (C.c_float(1.0), C.c_float(0.0), C.c_float(10.0), norm, C.c_float(1.0), C.c_float(1.0), None)
+    assert host_kernel.nlm4_host_run(ck.ptr(img), ck.ptr(img), 256, 207, 72, 69, 2, 2, *tail) == 0   # 69 rows
+    assert host_kernel.nlm4_host_run(ck.ptr(img), ck.ptr(img), 256, 207, 72, 64, 3, 2, *tail) == 0   # patch radius 3
+
+
+CASES4B = [
+    (170, 128, 7, 0.5, 1.0),   # 64-row chunks, every chunk in the ring
+    (181, 171, 3, 0.3, 0.8),   # 72 x 57, the last 37 columns
+    (151, 140, 3, 1.0, 1.0),   # 64 x 51 chunks, the last 23 columns (odd) and 38 rows
+]
+
+
+@pytest.mark.parametrize("w,h,K,luma,chroma", CASES4B)
+def test_fused_variant_border_ring_on_the_host_equals_the_oracle(host_kernel, oracle_lib, w, h, K, luma, chroma):
+    o = oracle_lib
+    P = 2
+    img = _lab(w, h, 13 + K)
+    p = NlmParams(0.0, 1.0, luma, chroma, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm4_host_run_all(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(0.0),
+                                       C.c_float(p.sharpness), p.norm, C.c_float(luma), C.c_float(chroma), C.byref(seen))
+    assert rc == 1, "chunk grid %d x %d" % (cw, ch)
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    written = ~np.isnan(got[..., 0])
+    assert seen.value > 0 and int(written.sum()) > 0
+    bad = written & (got.view(np.uint32) != want.view(np.uint32)).any(axis=-1)
+    assert int(bad.sum()) == 0, "%d of %d written pixels differ; first at %s" % (int(bad.sum()), int(written.sum()), np.argwhere(bad)[:5].tolist())
+    nrows_last = h - (h - 1) // ch * ch
+    expect = w * (h if nrows_last >= 10 else h - nrows_last)
+    assert int(written.sum()) == expect
