@@ -1,6 +1,11 @@
 """Build libansel_hip.so (the product) for gfx950 with hipcc, in-tree.
 
-    python -m ansel_amd.build [--force]
+    python -m ansel_amd.build [--force] [--measuring]
+
+--measuring builds ansel_amd/libansel_hip_measuring.so instead: every translation unit with -DANSEL_HIP_MEASURING, which
+compiles the superseded kernel versions and the A/B switches of the kernels' development (read from the environment:
+ANSEL_HIP_* / ANSEL_NLM2_*, hip_common.h measuring_env()) back in.  tools/ load it through ANSEL_HIP_LIB; the product
+library has neither and reads no environment variable on a launch path.
 
 hipcc cross-compiles without a GPU.  Each translation unit becomes an object under
 ansel_amd/csrc/_obj/ (rebuilt only when it or a header is newer), then everything is linked
@@ -51,18 +56,21 @@ def _headers_mtime():
     return max(m, os.path.getmtime(os.path.abspath(__file__)))
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=True, measuring=False):
+    obj_dir = OBJ + "_measuring" if measuring else OBJ
+    lib_path = os.path.join(HERE, "libansel_hip_measuring.so") if measuring else LIB
+    common = COMMON + (["-DANSEL_HIP_MEASURING"] if measuring else [])
+    os.makedirs(obj_dir, exist_ok=True)
     hm = _headers_mtime()
     objs = []
     procs = []
     for f in _sources():
         src = os.path.join(CSRC, f)
-        obj = os.path.join(OBJ, f.rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(obj_dir, f.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hm):
             continue
-        cmd = [HIPCC] + COMMON + EXTRA.get(f, []) + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + common + EXTRA.get(f, []) + ["-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print("[ansel_amd.build] hipcc", f, flush=True)
         procs.append((f, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -77,13 +85,13 @@ def build(force=False, verbose=True):
             sys.stdout.write(out.decode(errors="replace"))
     if failed:
         raise RuntimeError("hipcc failed")
-    if force or procs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    if force or procs or not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path]
         if verbose:
-            print("[ansel_amd.build] link", os.path.relpath(LIB, ROOT), flush=True)
+            print("[ansel_amd.build] link", os.path.relpath(lib_path, ROOT), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, measuring="--measuring" in sys.argv)

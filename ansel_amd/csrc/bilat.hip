@@ -45,6 +45,7 @@ __device__ __forceinline__ int axis(const float v, const float sigma, const int 
   return xi;
 }
 
+#ifdef ANSEL_HIP_MEASURING // the first gather: A/B timing only (ANSEL_HIP_BILAT_SPLAT_V1); bilat_splat2 below is the product's
 // dt_bilateral_splat(), bilateral.c:183-256, gathered per grid node
 // Row bands (a frame over several GPUs, pipe.cpp): a band splats its OWN rows [row_lo, row_hi) of the frame on top of
 // what the bands above it have accumulated (`accumulate`: the node's z column starts from `buf` instead of zero) --
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat(const float *__rest
     for(int z = 0; z < b.size_z; z++) cell[z] = acc[z * SPLAT_THREADS + tid];
   }
 }
+#endif // ANSEL_HIP_MEASURING
 
 // The second version of the gather.  What bound the first: 644 waves at 100 MP -- fewer than the chip has SIMDs -- each
 // walking ~10^4 pixels alone on its SIMD at ~80 dependent instructions a pixel, three exact divisions among them (the
@@ -352,16 +354,19 @@ int bilat_grid_of(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, gri
   return DT_HIP_SUCCESS;
 }
 
+#ifdef ANSEL_HIP_MEASURING
 __global__ __launch_bounds__(256) void bilat_lightness(const float4 *__restrict__ in, float *__restrict__ L, const size_t n)
 {
   for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) L[k] = in[k].x;
 }
+#endif
 
 int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_rows, int row_lo, int row_hi, int accumulate)
 {
   hipStream_t s = stream_of(devid);
   const int nodes = b.size_x * b.size_y;
   const size_t n = (size_t)b.width * (row_hi - row_lo);
+#ifdef ANSEL_HIP_MEASURING
   static const bool v1 = getenv("ANSEL_HIP_BILAT_SPLAT_V1") != nullptr; // the first gather, for A/B timing
   if(v1)
   {
@@ -376,6 +381,7 @@ int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_ro
     dt_hip_release_mem_object(L); // stream-ordered
     return DT_HIP_SUCCESS;
   }
+#endif
   float2 *zc = (float2 *)dt_hip_alloc_device_buffer(devid, n * sizeof(float2));
   if(!zc) return DT_HIP_SYSMEM_ALLOCATION;
   {

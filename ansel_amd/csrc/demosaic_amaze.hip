@@ -956,7 +956,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   a.ntx = (width + 16 + (TS - 32) - 1) / (TS - 32);
   const int nty = (height + 16 + (TS - 32) - 1) / (TS - 32);
   a.ntiles = a.ntx * nty;
-  a.slab_all = getenv("ANSEL_HIP_AMAZE_SLAB") != nullptr && !band;
+  a.slab_all = (dispatch_override(DISPATCH_AMAZE_SLAB) || measuring_env("ANSEL_HIP_AMAZE_SLAB") != nullptr) && !band;
   const int ty_first = band ? band->tv0 : 0, ty_end = band ? (band->tv1 < nty ? band->tv1 : nty) : nty;
   if(band)
   {
@@ -986,8 +986,8 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
     return DT_HIP_INVALID_ARG;
   }
   hipStream_t s = stream_of(devid);
-  const bool timed = getenv("ANSEL_HIP_AMAZE_TIMED") != nullptr;
-  const bool unfused = timed || getenv("ANSEL_HIP_AMAZE_UNFUSED") != nullptr; // one kernel per kind of tile: for measurements
+  const bool timed = measuring_env("ANSEL_HIP_AMAZE_TIMED") != nullptr;
+  const bool unfused = timed || dispatch_override(DISPATCH_AMAZE_UNFUSED) || measuring_env("ANSEL_HIP_AMAZE_UNFUSED") != nullptr; // one kernel per kind of tile
   amz::args sa;
   sa.width = width;
   sa.height = height;
@@ -999,7 +999,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   sa.out_row0 = band ? band->out_row0 : 0;
   sa.out_row1 = band ? band->out_row0 + band->out_rows : height;
   // (honoured by the measuring launch only: with a part of a phase switched off the output is wrong)
-  sa.variant = timed && getenv("ANSEL_HIP_AMAZE_VARIANT") ? atoi(getenv("ANSEL_HIP_AMAZE_VARIANT")) : 0;
+  sa.variant = timed && measuring_env("ANSEL_HIP_AMAZE_VARIANT") ? atoi(measuring_env("ANSEL_HIP_AMAZE_VARIANT")) : 0;
   if(stream_tiles > 0)
   {
     // the opt-in to more than 64 KB of LDS is per device
@@ -1015,8 +1015,8 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
     }
   }
   // one workgroup per CU: the LDS of a CU each (ANSEL_HIP_AMAZE_BLOCKS: fewer, so that the tests see a workgroup walk many tiles)
-  const char *const sb_env = getenv("ANSEL_HIP_AMAZE_STREAM_BLOCKS") ? getenv("ANSEL_HIP_AMAZE_STREAM_BLOCKS") : getenv("ANSEL_HIP_AMAZE_BLOCKS");
-  const int sb_max = sb_env && atoi(sb_env) > 0 ? atoi(sb_env) : 256;
+  const char *const sb_env = measuring_env("ANSEL_HIP_AMAZE_STREAM_BLOCKS") ? measuring_env("ANSEL_HIP_AMAZE_STREAM_BLOCKS") : measuring_env("ANSEL_HIP_AMAZE_BLOCKS");
+  const int sb_max = dispatch_override(DISPATCH_AMAZE_BLOCKS) > 0 ? dispatch_override(DISPATCH_AMAZE_BLOCKS) : (sb_env && atoi(sb_env) > 0 ? atoi(sb_env) : 256);
   if(stream_tiles > 0 && slab_tiles > 0 && !unfused)
   {
     const int blocks = a.ntiles < sb_max ? a.ntiles : sb_max;
@@ -1065,8 +1065,8 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
     if(slab_tiles == 0) return DT_HIP_SUCCESS;
   }
   // two 512-thread workgroups per CU (the vote plane is 50 KiB of LDS each)
-  const char *const blocks_env = getenv("ANSEL_HIP_AMAZE_BLOCKS");
-  const int max_blocks = blocks_env ? atoi(blocks_env) : 512;
+  const char *const blocks_env = measuring_env("ANSEL_HIP_AMAZE_BLOCKS");
+  const int max_blocks = dispatch_override(DISPATCH_AMAZE_BLOCKS) > 0 ? dispatch_override(DISPATCH_AMAZE_BLOCKS) : (blocks_env ? atoi(blocks_env) : 512);
   const int blocks = a.ntiles < max_blocks ? a.ntiles : max_blocks;
   float *slabs = (float *)dt_hip_alloc_device_buffer(devid, (size_t)blocks * O_END * sizeof(float));
   if(!slabs) return DT_HIP_SYSMEM_ALLOCATION;

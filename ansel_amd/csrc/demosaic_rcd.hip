@@ -88,8 +88,9 @@ struct rcd_args
   int tv0, in_row0, out_row0, out_row1;
 };
 
+#ifdef ANSEL_HIP_MEASURING
 // The first version of the tile kernel (row-major planes, one index decode per site and step): kept for A/B timing
-// (ANSEL_HIP_RCD_V1) -- rcd_tiles below computes the same values from de-interleaved planes.
+// (ANSEL_HIP_RCD_V1, measuring builds only) -- rcd_tiles below computes the same values from de-interleaved planes.
 __global__ __launch_bounds__(NT) void rcd_tiles_v1(const float *__restrict__ in, float4 *__restrict__ out,
                                                     const rcd_args a)
 {
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(NT) void rcd_tiles_v1(const float *__restrict__ in,
     if(ok_hi) dst[1] = hi;
   }
 }
+#endif // ANSEL_HIP_MEASURING
 
 // ---- the tile kernel, second version ------------------------------------------------------------------------------
 // Same steps, same arithmetic; what changed is where the samples sit and how a lane finds them.
@@ -753,7 +755,9 @@ int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters
     set_last_error("rcd band: tile rows [%d,%d) need frame rows outside the band buffer", band->tv0, band->tv1);
     return DT_HIP_INVALID_ARG;
   }
+#ifdef ANSEL_HIP_MEASURING
   static const bool v1 = getenv("ANSEL_HIP_RCD_V1") != nullptr; // the first tile kernel, for A/B timing
+#endif
   // the opt-in to more than 64 KB of LDS is per device
   static std::atomic<unsigned long long> attr_set{ 0ull };
   const int hip_dev = hip_device_of(devid);
@@ -761,13 +765,18 @@ int rcd_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters
   if(!(attr_set.load() >> hip_dev & 1ull))
   {
     ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)rcd_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES));
+#ifdef ANSEL_HIP_MEASURING
     ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)rcd_tiles_v1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+#endif
     attr_set.fetch_or(1ull << hip_dev);
   }
   {
     launch_scope ls(devid, "rcd_tiles");
+#ifdef ANSEL_HIP_MEASURING
     if(v1) rcd_tiles_v1<<<(unsigned)(tile_rows * a.num_horizontal), NT, LDS_BYTES, s>>>(in, out, a);
-    else rcd_tiles<<<(unsigned)(tile_rows * a.num_horizontal), NT, LDS2_BYTES, s>>>(in, out, a);
+    else
+#endif
+      rcd_tiles<<<(unsigned)(tile_rows * a.num_horizontal), NT, LDS2_BYTES, s>>>(in, out, a);
   }
   return check_launch("rcd_tiles");
 }

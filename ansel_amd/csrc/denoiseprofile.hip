@@ -289,6 +289,7 @@ __device__ __forceinline__ double wave_sum_halving(double v)
   return v; // lane 0 holds the halving-tree sum of the wave
 }
 
+#ifdef ANSEL_HIP_MEASURING // the per-row kernel: A/B timing only (ANSEL_HIP_DN_PER_ROW); the strips below are the product's
 // eaw_dn_decompose(), eaw.c:242-327: one workgroup = one 256-pixel segment of one row
 __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                     float4 *__restrict__ detail, double *__restrict__ partial,
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
     partial[4 * ((size_t)row * nseg + bx) + c] = seg;
   }
 }
+#endif // ANSEL_HIP_MEASURING
 
 // The same step on STRIPS: one workgroup = one 256-pixel segment x up to `strip` rows of one dilation class (rows c,
 // c + mult, c + 2 mult, ...: consecutive rows of the class share four of their five tap rows).  The tap rows live in a
@@ -383,14 +385,65 @@ __device__ __forceinline__ float dn_photometric(const float4 px, const float4 p2
   const float arg = dot * 0.02f - 9.0f;
   return mexp2_of_clamped(arg);
 }
-template <bool PRE>
+// The halving-tree sums of FOUR quantities over the wave in one tree (round 4; wave_sum_halving() four times was 72 of the
+// kernel's ~830 instructions per pixel): the tree adds lane i + 32 onto lane i, then i + 16, ... -- in the first step only
+// half the lanes do useful work, in the second a quarter.  v_permlane32_swap trades the upper half of one quantity for the
+// lower half of another, so that ONE addition forms the first level of both (lanes 0-31: q0[i] + q0[i + 32], lanes 32-63:
+// q1[i - 32] + q1[i], the same two operands as the tree's); v_permlane16_swap does the same with the 16-lane rows for
+// the second level of all four; the last four levels stay inside a row (DPP row_shl).  Every sum adds the same pairs as
+// wave_sum_halving() -- binary64 addition commutes -- so the same bits.  Returns, in lanes 0 / 16 / 32 / 48, the sums of
+// q0 / q2 / q1 / q3.
+__device__ __forceinline__ double wave_sum4_halving(const double q0, const double q1, const double q2, const double q3)
+{
+  union d2
+  {
+    double d;
+    unsigned u[2];
+  };
+  auto level = [](const double a, const double b, const bool rows16) {
+    d2 x, y, rx, ry;
+    x.d = a;
+    y.d = b;
+#pragma unroll
+    for(int h = 0; h < 2; h++)
+    {
+      const auto r = rows16 ? __builtin_amdgcn_permlane16_swap(x.u[h], y.u[h], false, false)
+                            : __builtin_amdgcn_permlane32_swap(x.u[h], y.u[h], false, false);
+      rx.u[h] = r[0];
+      ry.u[h] = r[1];
+    }
+    return rx.d + ry.d;
+  };
+  const double s01 = level(q0, q1, false), s23 = level(q2, q3, false);
+  d2 t;
+  t.d = level(s01, s23, true);
+#define DN_ROW_SHL(n)                                                                                     \
+  {                                                                                                       \
+    d2 o;                                                                                                 \
+    o.u[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t.u[0], 0x100 + (n), 0xf, 0xf, true);          \
+    o.u[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t.u[1], 0x100 + (n), 0xf, 0xf, true);          \
+    t.d = t.d + o.d;                                                                                      \
+  }
+  DN_ROW_SHL(8)
+  DN_ROW_SHL(4)
+  DN_ROW_SHL(2)
+  DN_ROW_SHL(1)
+#undef DN_ROW_SHL
+  return t.d;
+}
+
+// MULT: the dilation at compile time (1 .. 64: the seven scales of a frame), so that the 25 taps of a lane are one base
+// address per tap row + immediates (the counters had 11 % of this kernel's VALU instructions as integer address
+// arithmetic); 0: read `mult_arg`
+template <bool PRE, int MULT>
 __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                           float4 *__restrict__ detail, double *__restrict__ partial,
-                                                          const int width, const int height, const int mult,
+                                                          const int width, const int height, const int mult_arg,
                                                           const float inv_sigma2, const int nseg, const int in_row0,
                                                           const int in_rows, const int strip, const int strips_per_class,
                                                           const vst_args fa)
 {
+  const int mult = MULT ? MULT : mult_arg;
 #define DN_FETCH(p) (PRE ? dn_precondition_pixel((p), fa) : (p))
   extern __shared__ float4 ring[]; // [DN_RING][256 + 4 * mult]
   __shared__ double runs[2][4][4];
@@ -510,11 +563,9 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
       coarse[o] = make_float4(c4[0], c4[1], c4[2], c4[3]);
       detail[o] = make_float4(d4[0], d4[1], d4[2], d4[3]);
     }
-#pragma unroll
-    for(int c = 0; c < 4; c++)
     {
-      const double s = wave_sum_halving(sq[c]);
-      if(lane == 0) runs[k & 1][wave][c] = s;
+      const double s = wave_sum4_halving(sq[0], sq[1], sq[2], sq[3]);
+      if((lane & 15) == 0) runs[k & 1][wave][((lane >> 5) & 1) | ((lane >> 3) & 2)] = s; // lanes 0 / 16 / 32 / 48: channels 0 / 2 / 1 / 3
     }
     s0 = s0 + 1 == DN_RING ? 0 : s0 + 1;
   }
@@ -534,6 +585,7 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
                              const int height, const int mult, const float inv_sigma2, const int nseg, const int in_row0,
                              const int in_rows, const vst_args *pre = nullptr)
 {
+#ifdef ANSEL_HIP_MEASURING
   static const bool per_row = getenv("ANSEL_HIP_DN_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
   if(per_row && !pre)
   {
@@ -542,6 +594,7 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
                                                             in_row0, in_rows);
     return;
   }
+#endif
   const int classes = height < mult ? height : mult, per_class = (height + mult - 1) / mult;
   int strip = 32;
   while(strip > 4 && (size_t)nseg * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
@@ -550,12 +603,27 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
   const size_t lds = (size_t)DN_RING * (256 + 4 * mult) * sizeof(float4);
   vst_args none;
   memset(&none, 0, sizeof(none));
+#define DN_LAUNCH(PRE_, M_, FA_)                                                                                                  \
+  dn_decompose_strip<PRE_, M_><<<grid, 256, lds, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0, \
+                                                       in_rows, strip, strips_per_class, FA_)
   if(pre)
-    dn_decompose_strip<true><<<grid, 256, lds, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0,
-                                                     in_rows, strip, strips_per_class, *pre);
+  {
+    if(mult == 1) DN_LAUNCH(true, 1, *pre);
+    else DN_LAUNCH(true, 0, *pre);
+  }
   else
-    dn_decompose_strip<false><<<grid, 256, lds, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0,
-                                                      in_rows, strip, strips_per_class, none);
+    switch(mult)
+    {
+      case 1: DN_LAUNCH(false, 1, none); break;
+      case 2: DN_LAUNCH(false, 2, none); break;
+      case 4: DN_LAUNCH(false, 4, none); break;
+      case 8: DN_LAUNCH(false, 8, none); break;
+      case 16: DN_LAUNCH(false, 16, none); break;
+      case 32: DN_LAUNCH(false, 32, none); break;
+      case 64: DN_LAUNCH(false, 64, none); break;
+      default: DN_LAUNCH(false, 0, none); break;
+    }
+#undef DN_LAUNCH
 }
 
 struct thr_args

@@ -750,7 +750,7 @@ int diffuse_process_rows(int devid, const dt_hip_piece_t *piece, const dt_hip_di
 int diffuse_process_post_lab(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, dt_hip_mem_t dev_in,
                              dt_hip_mem_t dev_out, const dt_hip_lab_data_t *lab)
 {
-  if(!lab || getenv("ANSEL_HIP_PDE_PER_ROW")) return DT_HIP_INVALID_ARG; // only the strip kernel has the tail
+  if(!lab || measuring_env("ANSEL_HIP_PDE_PER_ROW")) return DT_HIP_INVALID_ARG; // only the strip kernel has the tail
   return diffuse_run(devid, piece, d, 0, dev_in, dev_out, lab);
 }
 static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diffuse_data_t *d, int first_row, dt_hip_mem_t dev_in,
@@ -774,8 +774,8 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
   // planes: HF[scales], two low-pass ping-pong, two iteration ping-pong (diffuse.c:1167-1195)
   // LF chain (every scale on the strip kernel): hf[s] holds the LOW-pass plane of scale s + 1 instead, nothing stores a
   // high-frequency plane, and one plane besides them serves the synthesis' ping-pong (a plane fewer than the reference)
-  static const bool per_row_pde = getenv("ANSEL_HIP_PDE_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
-  static const bool hf_planes = getenv("ANSEL_HIP_DIFFUSE_HF_PLANES") != nullptr; // the stored-HF path, for A/B timing
+  static const bool per_row_pde = measuring_env("ANSEL_HIP_PDE_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
+  static const bool hf_planes = measuring_env("ANSEL_HIP_DIFFUSE_HF_PLANES") != nullptr; // the stored-HF path, for A/B timing
   const bool lf_chain = !per_row_pde && !hf_planes && (1 << (scales - 1)) <= PDE_SHARED_MULT;
   float4 *hf[DIFFUSE_MAX_SCALES] = { nullptr };
   float4 *lf[2] = { nullptr, nullptr }, *tmp[2] = { nullptr, nullptr };
@@ -787,9 +787,9 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
       ok &= (tmp[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
   int err = ok ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
   // one channel per lane (diffuse_pde_lanes) while every alpha sample is +0: the analysis launches keep the flag
-  static const bool no_lanes = getenv("ANSEL_HIP_PDE_NO_LANES") != nullptr; // the four-channel strips alone, for A/B timing
+  static const bool no_lanes = measuring_env("ANSEL_HIP_PDE_NO_LANES") != nullptr; // the four-channel strips alone, for A/B timing
   unsigned *alpha_flag = nullptr;
-  if(err == DT_HIP_SUCCESS && !per_row_pde && !no_lanes && getenv("ANSEL_HIP_BSPLINE_PER_ROW") == nullptr)
+  if(err == DT_HIP_SUCCESS && !per_row_pde && !no_lanes && measuring_env("ANSEL_HIP_BSPLINE_PER_ROW") == nullptr)
   {
     alpha_flag = (unsigned *)dt_hip_alloc_device_buffer(devid, sizeof(unsigned));
     if(!alpha_flag) err = DT_HIP_SYSMEM_ALLOCATION;
@@ -800,7 +800,7 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
   memset(&a, 0, sizeof(a));
   a.width = w;
   a.height = h;
-  a.wskip = getenv("ANSEL_HIP_PDE_NO_WSKIP") ? 0 : 1;
+  a.wskip = measuring_env("ANSEL_HIP_PDE_NO_WSKIP") ? 0 : 1;
   const float user_aniso[4] = { d->anisotropy_first, d->anisotropy_second, d->anisotropy_third, d->anisotropy_fourth };
   for(int k = 0; k < 4; k++)
   {
@@ -892,7 +892,7 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
           const int spc = (per_class + strip - 1) / strip;
           const size_t ring = (size_t)PDE_RING * (256 + 2 * a.mult) * sizeof(float4);
-          static const bool generic = getenv("ANSEL_HIP_PDE_GENERIC") != nullptr; // the kinds read at run time, for A/B timing
+          static const bool generic = measuring_env("ANSEL_HIP_PDE_GENERIC") != nullptr; // the kinds read at run time, for A/B timing
           const int mode = generic ? -1 : pde_mode_of(a);
           const dim3 sgrid(gx, classes * spc);
           const float4 *const h0 = chain ? (s == 0 ? src : hf[s - 1]) : hf[s], *const h1 = chain ? hf[s] : nullptr;

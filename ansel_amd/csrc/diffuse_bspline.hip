@@ -38,6 +38,7 @@ __device__ __forceinline__ int walk_row(const int b, const int height, const int
   return row < height ? row : -1;
 }
 
+#ifdef ANSEL_HIP_MEASURING // the per-row kernel: A/B timing only (ANSEL_HIP_BSPLINE_PER_ROW); the strips below are the product's
 __device__ __forceinline__ float4 vertical5(const float4 *__restrict__ in, const int width, const int height,
                                             const int row, const int col, const int mult, float4 *centre)
 {
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void bspline_decompose(const float4 *__restric
   lf[o] = low;
   nt_store(hf + o, make_float4(centre.x - low.x, centre.y - low.y, centre.z - low.z, centre.w - low.w));
 }
+#endif // ANSEL_HIP_MEASURING
 
 // The same analysis on STRIPS: a workgroup keeps its R x T columns for up to `strip` rows of one dilation class (rows c,
 // c + m, c + 2 m, ...), whose five vertical taps overlap in four rows: every lane rolls the five samples of its column
@@ -218,6 +220,7 @@ int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 
 {
   const int steps = (w + mult - 1) / mult; // steps of the dilation across a row
   launch_scope ls(devid, "diffuse_decompose");
+#ifdef ANSEL_HIP_MEASURING
   static const bool per_row = getenv("ANSEL_HIP_BSPLINE_PER_ROW") != nullptr; // the per-row kernels, for A/B timing
   if(per_row)
   {
@@ -236,6 +239,7 @@ int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 
     }
     return check_launch("diffuse_decompose");
   }
+#endif
   const int classes = h < mult ? h : mult, per_class = (h + mult - 1) / mult;
   const int gx = mult == 1 ? (steps + 255) / 256 : (mult == 2 ? (steps + 127) / 128 : (mult == 4 ? (steps + 63) / 64 : ((steps + 31) / 32) * (mult / 8)));
   int strip = 32;

@@ -7,8 +7,35 @@
 #include <string.h>
 #include "ansel_hip.h"
 
+// The A/B switches of the kernels' development (superseded kernel versions, roles switched off, clock reads) exist in the
+// MEASURING build only: `python -m ansel_amd.build --measuring` compiles every translation unit with
+// -DANSEL_HIP_MEASURING into ansel_amd/libansel_hip_measuring.so, which tools/ load through ANSEL_HIP_LIB.  The product
+// library carries one kernel per job and reads no environment variable on a launch path: measuring_env() is a constant
+// there, and the superseded kernels are not compiled.
+#ifdef ANSEL_HIP_MEASURING
+#include <stdlib.h>
+static inline const char *measuring_env(const char *name) { return getenv(name); }
+#else
+static inline constexpr const char *measuring_env(const char *) { return nullptr; }
+#endif
+
 namespace ansel
 {
+
+// Test hooks (testhooks.hip, dt_hip_test_dispatch(); not part of include/ansel_hip.h): send a launch to one of the FALLBACK
+// kernels the product carries anyway -- the second non-local-means kernel that takes the chunk grids the third does not,
+// AMaZE's first kernel that takes the tiles the on-chip one does not -- on a frame where the primary kernel applies, so that
+// the tests can compare the two and the oracle on the same frame.  A word in memory set through the C entry, no environment.
+enum dispatch_key_t
+{
+  DISPATCH_NLM_V2 = 0,      // non-local means: the second version wherever the third / fused one would run
+  DISPATCH_NLM_FUSED,       // ... the fused variant wherever it fits (also on the third version's grids)
+  DISPATCH_AMAZE_UNFUSED,   // AMaZE: one launch per kind of tile instead of the mixed queue
+  DISPATCH_AMAZE_SLAB,      // AMaZE: every tile on the first kernel
+  DISPATCH_AMAZE_BLOCKS,    // AMaZE: at most this many workgroups (a workgroup then walks many tiles)
+  DISPATCH_KEYS
+};
+int dispatch_override(dispatch_key_t key); // 0: not set
 
 void set_last_error(const char *fmt, ...);
 

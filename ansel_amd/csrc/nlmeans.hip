@@ -841,6 +841,7 @@ __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2(const float4 *__res
 }
 
 // the measuring build (ANSEL_NLM2_TIMED, tools/nlm_phase_clocks.py): the same body with a clock read around every step
+#ifdef ANSEL_HIP_MEASURING // clock reads around every step (ANSEL_NLM2_TIMED, tools/nlm_phase_clocks.py)
 struct nlm2_timed_env : nlm2_device_env
 {
   static constexpr bool TIMED = true;
@@ -857,6 +858,7 @@ __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2_timed(const float4 
   env.chunk_ = order[blockIdx.x];
   nlm2::body<2, NL2_WP_TIGHT, NL2_TP_TIGHT, true>(env, in, out, a, patches);
 }
+#endif // ANSEL_HIP_MEASURING
 
 // the third version of the interior-chunk kernel (nlm3_body.h): offsets in rows of consecutive column shifts, patch
 // radius 2, chunks of at most 56 rows; same launch shape, border chunks first with the pipelined body
@@ -1049,15 +1051,15 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   const int S2 = 2 * a.radius + 1, ncol2 = a.chk_w + 2 * a.radius;
   // layout: the tight pitches when the chunk fits them; schedule: four tables (one barrier per offset) when they fit
   // LDS beside the window, else two (nlm2_body.h)
-  const bool tight = a.chk_w + 2 * a.reach <= NL2_WP_TIGHT && ncol2 + 1 <= NL2_TP_TIGHT && getenv("ANSEL_NLM2_LAYOUT") == nullptr;
+  const bool tight = a.chk_w + 2 * a.reach <= NL2_WP_TIGHT && ncol2 + 1 <= NL2_TP_TIGHT && measuring_env("ANSEL_NLM2_LAYOUT") == nullptr;
   const int WP2 = tight ? NL2_WP_TIGHT : NL2_WP_LOOSE, TP2 = tight ? NL2_TP_TIGHT : NL2_TP_LOOSE;
   const bool deep = nlm2::lds_floats(4, a.chk_h, a.reach, a.npatch, WP2, TP2) * sizeof(float) <= 160 * 1024 && a.chk_h <= 64
-                    && getenv("ANSEL_NLM2_DEEP") == nullptr;
+                    && measuring_env("ANSEL_NLM2_DEEP") == nullptr;
   // the border workgroups of the same launch run the pipelined body: the launch's LDS is the larger of the two
   const size_t v2_bytes = std::max(nlm2::lds_floats(deep ? 4 : 2, a.chk_h, a.reach, a.npatch, WP2, TP2) * sizeof(float), pipe_bytes);
   bool v2 = pipelined && p.center_weight < 0 && a.radius >= 1 && a.radius <= 3 && ncol2 * S2 <= NL2_PAR
             && a.chk_w * a.chk_h <= NL2_PAR * NL2_PX && a.chk_w + 2 * a.reach <= WP2 && ncol2 + 1 <= TP2 && a.npatch <= 4096
-            && a.chk_h <= NL2_SERIAL / 2 && v2_bytes <= 160 * 1024 && getenv("ANSEL_HIP_NLM_V1") == nullptr;
+            && a.chk_h <= NL2_SERIAL / 2 && v2_bytes <= 160 * 1024 && measuring_env("ANSEL_HIP_NLM_V1") == nullptr;
   if(v2)
   {
     const int nseg = NL2_PAR / (ncol2 * S2), m0 = (a.chk_h - 2) / S2 + 1;
@@ -1065,15 +1067,16 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   }
   // the third version where it applies (nlm3_body.h): the module's defaults on frames whose chunks have at most 56 rows
   int ndx3 = 0;
+  const bool force_v2 = dispatch_override(DISPATCH_NLM_V2) || measuring_env("ANSEL_HIP_NLM_V2") != nullptr;
   const bool v3 = v2 && nlm3::fits<9, 6>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
-                  && getenv("ANSEL_HIP_NLM_V2") == nullptr;
+                  && !force_v2;
   const size_t v3_bytes = std::max(nlm3::lds_floats<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
   // its fused variant for the grids the third version does not take (57 - 64 rows); ANSEL_HIP_NLM_FUSED=1: wherever it fits
   const size_t v4_bytes = std::max(nlm3::lds_floats_fused<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
-  const char *const fused_env = getenv("ANSEL_HIP_NLM_FUSED");
+  const char *const fused_env = measuring_env("ANSEL_HIP_NLM_FUSED");
+  const bool force_fused = dispatch_override(DISPATCH_NLM_FUSED) || (fused_env && atoi(fused_env) != 0);
   const bool v4 = v2 && nlm3::fits_fused<9, 7>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
-                  && v4_bytes <= 160 * 1024 && getenv("ANSEL_HIP_NLM_V2") == nullptr
-                  && (fused_env ? atoi(fused_env) != 0 : !(v3 && v3_bytes <= 160 * 1024));
+                  && v4_bytes <= 160 * 1024 && !force_v2 && (force_fused || !(v3 && v3_bytes <= 160 * 1024));
   static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS && NL3_THREADS == NLM_THREADS,
                 "nlm_chunks_v2 / _v3 share the launch shape of nlm_chunks_pipelined");
   nlm2_kernel_t k2 = nullptr;
@@ -1084,10 +1087,12 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   if(v2)
   {
     k2 = a.radius == 1 ? nlm2_kernel_of<1>(tight, deep) : (a.radius == 2 ? nlm2_kernel_of<2>(tight, deep) : nlm2_kernel_of<3>(tight, deep));
-    if(a.radius == 2 && tight && deep && getenv("ANSEL_NLM2_TIMED")) k2 = nlm_chunks_v2_timed;
+#ifdef ANSEL_HIP_MEASURING
+    if(a.radius == 2 && tight && deep && measuring_env("ANSEL_NLM2_TIMED")) k2 = nlm_chunks_v2_timed;
+#endif
     if(v2_bytes > 64 * 1024)
       ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_bytes));
-    const char *const var_env = getenv("ANSEL_NLM2_VARIANT");
+    const char *const var_env = measuring_env("ANSEL_NLM2_VARIANT");
     a.variant = var_env ? atoi(var_env) : 0;
     order.resize(nchunks);
     std::vector<int> inner;

@@ -8,6 +8,7 @@
 // of pointwise modules are planned into fused launches (pipe_fused.hip).
 #include "hip_common.h"
 #include "pipe_fused.h"
+#include "amaze_stream_body.h" // amz::stream_tile_ok(): which AMaZE tiles the on-chip kernel takes (band planning)
 
 #include <algorithm>
 #include <condition_variable>
@@ -689,6 +690,19 @@ int dt_hip_plan_bands(int width, int height, int demosaic_method, int n_bands, d
       set_last_error("dt_hip_plan_bands: %d rows give %d AMaZE tile rows, fewer than %d bands", height, tile_rows, n_bands);
       return DT_HIP_INVALID_ARG;
     }
+    // only the on-chip kernel walks a band (demosaic_amaze.hip): a frame that keeps tiles in the first kernel's body -- a
+    // last tile column of odd width, a mirrored strip past its plane -- would be refused by the band's demosaic launch,
+    // after the CFA stages and the halo copies of every band have run.  Say so here, where the caller can still take
+    // the unsplit path
+    for(int ty = 0; ty < tile_rows; ty++)
+      for(int tx = 0; tx < (width + AMZ_HALO + AMZ_TV - 1) / AMZ_TV; tx++) // the launch's tile columns (demosaic_amaze.hip)
+        if(!amz::stream_tile_ok(width, height, -AMZ_HALO + ty * AMZ_TV, -AMZ_HALO + tx * AMZ_TV))
+        {
+          set_last_error("dt_hip_plan_bands: the AMaZE tile at row %d, column %d of a %d x %d frame is not one the on-chip kernel takes "
+                         "(odd width of the last tile column, or a mirrored strip past its plane): no band mode for this frame",
+                         ty * AMZ_TV, tx * AMZ_TV, width, height);
+          return DT_HIP_INVALID_ARG;
+        }
     for(int k = 0; k < n_bands; k++)
     {
       const int tv0 = (int)((long)k * tile_rows / n_bands), tv1 = (int)((long)(k + 1) * tile_rows / n_bands);

@@ -2,7 +2,32 @@
 #include "hip_common.h"
 #include "devmath.h"
 
+#include <atomic>
+#include <string.h>
+
 using namespace ansel;
+
+// ---- dispatch overrides (hip_common.h dispatch_key_t) ----
+namespace
+{
+std::atomic<int> g_dispatch[DISPATCH_KEYS];
+const char *const g_dispatch_names[DISPATCH_KEYS] = { "nlm_v2", "nlm_fused", "amaze_unfused", "amaze_slab", "amaze_blocks" };
+} // namespace
+namespace ansel
+{
+int dispatch_override(const dispatch_key_t key) { return g_dispatch[key].load(std::memory_order_relaxed); }
+} // namespace ansel
+extern "C" int dt_hip_test_dispatch(const char *key, int value)
+{
+  if(!key) return DT_HIP_INVALID_ARG;
+  for(int k = 0; k < DISPATCH_KEYS; k++)
+    if(!strcmp(key, g_dispatch_names[k]))
+    {
+      g_dispatch[k].store(value);
+      return DT_HIP_SUCCESS;
+    }
+  return DT_HIP_INVALID_ARG;
+}
 
 // ---- test hooks: the device build of devmath.h on plain arrays (tests/test_gpu_devmath.py) ----
 namespace

@@ -7,7 +7,9 @@ import os
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libansel_hip.so")
+# ANSEL_HIP_LIB: another build of the same library -- tools/ load the measuring build (ansel_amd/build.py --measuring), whose
+# A/B switches the product library does not have
+LIB_PATH = os.environ.get("ANSEL_HIP_LIB") or os.path.join(HERE, "libansel_hip.so")
 
 _lib = None
 
@@ -161,6 +163,7 @@ def load():
         "dt_hip_peer_selftest": (i, [P(i), i]),
         "dt_hip_iop_highlights_process_deferred": (i, [i, P(abi.Piece), P(abi.HighlightsData), vp, vp, vp]),
         "dt_hip_iop_highlights_resolve": (i, [i, vp, vp]),
+        "dt_hip_test_dispatch": (i, [C.c_char_p, i]),
     }
     missing = []
     for name, (res, args) in protos.items():
@@ -175,6 +178,12 @@ def load():
     lib._ansel_protos = protos
     _lib = lib
     return lib
+
+
+def test_dispatch(key, value):
+    """dt_hip_test_dispatch() (csrc/testhooks.hip): send launches to a fallback kernel the library carries anyway -- "nlm_v2",
+    "nlm_fused", "amaze_unfused", "amaze_slab", "amaze_blocks" -- on frames where the primary kernel applies; 0 clears"""
+    check(load().dt_hip_test_dispatch(key.encode(), int(value)), "dt_hip_test_dispatch(%s)" % key)
 
 
 def check(rc, what=""):

@@ -70,3 +70,33 @@ def test_product_does_not_touch_the_oracle():
                 if re.search(r"liboracle|libansel_ref|import\s+checkers|oracle_\w+\s*\(|ref_\w+process", text):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_product_library_reads_no_environment_on_a_launch_path():
+    """the A/B switches of the kernels' development (superseded kernel versions, roles switched off, clock reads) exist in
+    the MEASURING build only (ansel_amd/build.py --measuring, -DANSEL_HIP_MEASURING): the product library does not import
+    getenv, names no ANSEL_* variable, and does not carry the superseded kernels"""
+    import subprocess
+    so = os.path.join(ROOT, "ansel_amd", "libansel_hip.so")
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", so]).decode()
+    assert "getenv" not in undefined
+    blob = open(so, "rb").read()
+    assert b"ANSEL_HIP_" not in blob and b"ANSEL_NLM" not in blob
+    for gone in (b"rcd_tiles_v1", b"nlm_chunks_v2_timed", b"bilat_lightness", b"18bspline_decomposeILi", b"12dn_decomposeEPK"):
+        assert gone not in blob, gone
+    # every getenv() in the sources sits behind the measuring build's macro
+    for f in sorted(os.listdir(os.path.join(ROOT, "ansel_amd", "csrc"))):
+        if not f.endswith((".hip", ".cpp", ".h")):
+            continue
+        lines = open(os.path.join(ROOT, "ansel_amd", "csrc", f)).read().split("\n")
+        depth = []
+        for ln in lines:
+            s = ln.strip()
+            if s.startswith("#ifdef ANSEL_HIP_MEASURING"):
+                depth.append(True)
+            elif s.startswith(("#if", "#ifdef", "#ifndef")):
+                depth.append(False)
+            elif s.startswith("#endif") and depth:
+                depth.pop()
+            elif re.search(r"(?<![_\w])getenv\s*\(", s.split("//")[0]) and not any(depth):
+                raise AssertionError("%s: getenv() outside #ifdef ANSEL_HIP_MEASURING: %s" % (f, s))

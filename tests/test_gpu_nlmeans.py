@@ -28,6 +28,20 @@ def _noisy(w, h, seed):
     return np.ascontiguousarray(img.astype(np.float32))
 
 
+@pytest.fixture
+def dispatch():
+    """dt_hip_test_dispatch(): a fallback kernel on a frame the primary kernel takes; cleared behind the test"""
+    from ansel_amd import lib
+    keys = []
+
+    def force(key, value=1):
+        lib.test_dispatch(key, value)
+        keys.append(key)
+    yield force
+    for k in keys:
+        lib.test_dispatch(k, 0)
+
+
 def _check(op, piece, d, img):
     got = hc.run_hip("dt_hip_iop_%s_process" % op, piece, d, img, img.shape)
     want = np.zeros_like(img)
@@ -51,13 +65,13 @@ def test_nlmeans(w, h, radius, strength, luma, chroma):
 
 
 @pytest.mark.parametrize("w,h,luma,chroma", [(330, 168, 0.5, 1.0), (260, 168, 1.0, 1.0), (170, 150, 0.3, 0.8), (1200, 560, 0.5, 1.0)])
-def test_nlmeans_third_version_chunk_grids(w, h, luma, chroma, monkeypatch):
+def test_nlmeans_third_version_chunk_grids(w, h, luma, chroma, dispatch):
     """frames whose chunk grid the third version of the interior-chunk kernel takes (nlm3_body.h: chunks of at most 56
-    rows, the module's defaults); the same frames through the second version (ANSEL_HIP_NLM_V2) give the same words"""
+    rows, the module's defaults); the same frames through the second version (the "nlm_v2" test hook) give the same words"""
     img = _lab_image(w, h, 31)
     d = abi.NlmeansData(2.0, 50.0, luma, chroma)
     got3 = _check("nlmeans", abi.Piece.make(w, h), d, img)
-    monkeypatch.setenv("ANSEL_HIP_NLM_V2", "1")
+    dispatch("nlm_v2")
     got2 = hc.run_hip("dt_hip_iop_nlmeans_process", abi.Piece.make(w, h), d, img, img.shape)
     assert np.array_equal(got2.view(np.uint32), got3.view(np.uint32))
 
@@ -66,24 +80,24 @@ def test_nlmeans_third_version_chunk_grids(w, h, luma, chroma, monkeypatch):
 # (700, 315) 72 x 63; (1200, 640) 72 x 64, 16 x 10 chunks; (150, 128) 64-row chunks all in the border ring
 @pytest.mark.parametrize("w,h,luma,chroma", [(260, 192, 0.5, 1.0), (330, 171, 1.0, 1.0), (170, 183, 0.3, 0.8), (700, 315, 0.5, 1.0),
                                              (1200, 640, 0.5, 1.0), (150, 128, 0.5, 1.0), (293, 247, 0.5, 1.0)])
-def test_nlmeans_fused_variant_chunk_grids(w, h, luma, chroma, monkeypatch):
+def test_nlmeans_fused_variant_chunk_grids(w, h, luma, chroma, dispatch):
     """frames whose chunks have 57 - 64 rows: the fused variant of the third version (nlm3_body.h FUSED, nlm_chunks_v4:
-    three tables, the row recurrence inside the weights' waves); the second version (ANSEL_HIP_NLM_V2, measuring builds
-    only) gives the same words"""
+    three tables, the row recurrence inside the weights' waves); the second version (the "nlm_v2" test hook) gives the same
+    words"""
     img = _lab_image(w, h, 37)
     d = abi.NlmeansData(2.0, 50.0, luma, chroma)
     got4 = _check("nlmeans", abi.Piece.make(w, h), d, img)
-    monkeypatch.setenv("ANSEL_HIP_NLM_V2", "1")
+    dispatch("nlm_v2")
     got2 = hc.run_hip("dt_hip_iop_nlmeans_process", abi.Piece.make(w, h), d, img, img.shape)
     assert np.array_equal(got2.view(np.uint32), got4.view(np.uint32))
 
 
 @pytest.mark.parametrize("w,h", [(330, 168), (1200, 560)])
-def test_nlmeans_fused_variant_on_the_third_versions_grids(w, h, monkeypatch):
-    """ANSEL_HIP_NLM_FUSED=1 (measuring builds): the fused variant on chunk grids the third version takes"""
+def test_nlmeans_fused_variant_on_the_third_versions_grids(w, h, dispatch):
+    """the "nlm_fused" test hook: the fused variant on chunk grids the third version takes"""
     img = _lab_image(w, h, 41)
     d = abi.NlmeansData(2.0, 50.0, 0.5, 1.0)
-    monkeypatch.setenv("ANSEL_HIP_NLM_FUSED", "1")
+    dispatch("nlm_fused")
     _check("nlmeans", abi.Piece.make(w, h), d, img)
 
 

@@ -84,7 +84,7 @@ def test_amaze_bands_of_a_frame_with_tiles_of_the_first_kind_are_refused():
     w, h = 517, 389
     nodes = _nodes(w, h, d_lut, lut, abi.DT_HIP_DEMOSAIC_AMAZE)
     raw = synth.bayer_mosaic(w, h, seed=7)
-    with pytest.raises(lib.AnselHipError, match="no row-band mode"):
+    with pytest.raises(lib.AnselHipError, match="no band mode"):  # dt_hip_plan_bands() says so, before any band runs a stage
         _banded(torch, nodes, raw, w, h, 2, True)
 
 

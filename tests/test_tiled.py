@@ -46,7 +46,7 @@ def test_rcd_bands_partition_the_frame_on_tile_rows(w, h, n):
         assert b.rows >= 9  # a neighbour's halo never spans more than one band
 
 
-@pytest.mark.parametrize("w,h,n", [(1504, 1000, 2), (1504, 1000, 5), (600, 400, 3), (11648, 8736, 8), (500, 129, 2)])
+@pytest.mark.parametrize("w,h,n", [(1504, 1000, 2), (1504, 1000, 5), (600, 400, 3), (11648, 8736, 8), (500, 144, 2)])
 def test_amaze_bands_partition_the_frame_on_tile_rows(w, h, n):
     """with the AMaZE demosaic a band owns whole 128-row tile rows of the frame's own grid and asks either neighbour for the 16
     mosaic rows its tiles read beyond them (fewer where the frame ends first)"""
@@ -69,6 +69,15 @@ def test_amaze_bands_partition_the_frame_on_tile_rows(w, h, n):
 def test_amaze_bands_need_a_tile_row_each():
     with pytest.raises(lib.AnselHipError):
         tiled.plan_bands(600, 400, 5, abi.DT_HIP_DEMOSAIC_AMAZE)  # 4 tile rows
+
+
+@pytest.mark.parametrize("w,h", [(517, 389), (6024, 4000), (600, 392)])
+def test_amaze_frames_with_tiles_of_the_first_kernel_have_no_band_plan(w, h):
+    """only the on-chip AMaZE kernel walks a band; a frame that keeps tiles in the first kernel's body -- a last tile column of
+    odd width, width or height 1..15 past a multiple of 128 (a mirrored strip running past its plane) -- is refused by the PLAN,
+    before any band has run a stage (it used to surface inside dt_hip_pipe_band_finish())"""
+    with pytest.raises(lib.AnselHipError, match="no band mode"):
+        tiled.plan_bands(w, h, 2, abi.DT_HIP_DEMOSAIC_AMAZE)
 
 
 def test_bands_without_demosaic_are_two_row_aligned():

@@ -12,6 +12,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the A/B switches exist in the measuring build only (python -m ansel_amd.build --measuring, before gpurun)
+os.environ.setdefault("ANSEL_HIP_LIB", os.path.join(ROOT, "ansel_amd", "libansel_hip_measuring.so"))
 import numpy as np  # noqa: E402
 
 from ansel_amd import abi, lib, synth  # noqa: E402
