@@ -29,9 +29,7 @@
 namespace ansel
 {
 // diffuse_bspline.hip: one a-trous B-spline analysis in -> (hf, lf) at dilation mult
-// alpha_flag (may be NULL): a device word the kernel sets to 1 when a fourth-channel sample it reads or writes is not +0
-int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, float4 *lf, int w, int h, int mult,
-                             unsigned *alpha_flag);
+int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, float4 *lf, int w, int h, int mult);
 }
 using namespace ansel;
 
@@ -380,10 +378,8 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
                                                          const float4 *__restrict__ lf,
                                                          float4 *__restrict__ out, const pde_args a, const int final_pass,
                                                          const unsigned char *__restrict__ mask, const int strip,
-                                                         const int strips_per_class, const unsigned *__restrict__ alpha_flag)
+                                                         const int strips_per_class)
 {
-  // behind a launch of diffuse_pde_lanes: this one works only if that one did not (some alpha sample is not +0)
-  if(alpha_flag && !*alpha_flag) return;
   extern __shared__ float4 r2s[]; // [PDE_RING][256 + 2 * mult]; slot x of a row = column clamp(seg - mult + x)
   const int mult = a.mult;
   const int cls = blockIdx.y / strips_per_class, k0s = (blockIdx.y - cls * strips_per_class) * strip;
@@ -497,118 +493,6 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     if(kk + 2 < nrows) row_step(std::integral_constant<int, 2>(), kk + 2);
   }
 #undef PDE_ROW
-}
-
-// The same strips with ONE COLOUR CHANNEL PER LANE (round 4).  The update of a channel reads nothing of the other channels
-// (energy, gradient direction, the four kernels: all per channel, diffuse.c:823-925), and a lane that carries a pixel's
-// four channels holds 2 x 9 float4 of support: 113 registers, four waves per SIMD, and the waves wait for their own
-// division -> square root -> division chains in 45 % of their cycles (profiles/r03_pmc_sq_100MP_full.json).  Here a pixel is
-// three lanes -- x, y, z -- with 2 x 9 floats of support each: the same instructions per channel, a third of the registers,
-// twice the waves in flight.  A workgroup is 64 columns x 3 lanes; the loads are dwords, three of every four consecutive
-// ones (the lines are the ones the float4 loads fetched); the squared ratios go through the same ring of four LDS rows,
-// three floats per pixel.  The FOURTH channel is not computed at all: this kernel runs only while `alpha_flag` says that
-// every alpha sample the module has seen is +0 (the B-spline analysis, which reads every plane the PDE reads, raises it
-// otherwise) -- then the update is +0 whatever the parameters are (alpha_is_blank() above) -- and leaves at once when the
-// flag is up; the launch behind it (diffuse_pde_strip with the flag's other sense) then does the work.  Results leave
-// through two LDS rows of float4 (w = +0) so that the store is 16 bytes per lane and the pipe's RGB -> Lab tail sees whole
-// pixels: the first wave stores row kk - 1 after the barrier of row kk.
-#define PDEL_NPX 64
-#define PDEL_THREADS (3 * PDEL_NPX)
-template <bool HSUB, int MODE>
-__global__ __launch_bounds__(PDEL_THREADS) void diffuse_pde_lanes(const float *__restrict__ hf, const float *__restrict__ hsub,
-                                                                const float *__restrict__ lf, float4 *__restrict__ out,
-                                                                const pde_args a, const int final_pass,
-                                                                const unsigned char *__restrict__ mask, const int strip,
-                                                                const int strips_per_class, const int gx,
-                                                                const unsigned *__restrict__ alpha_flag)
-{
-  if(*alpha_flag) return;
-  extern __shared__ float pl[]; // ring [PDE_RING][NPX + 2 mult][3]; stage [2][NPX] float4
-  const int mult = a.mult;
-  // gridDim.x is a multiple of 8 and workgroups go to the 8 XCDs round-robin: XCD k takes a contiguous eighth of the
-  // column blocks, so that the halo columns of a block are in the L2 its neighbour filled
-  const int colblk = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-  if(colblk >= gx) return;
-  const int cls = blockIdx.y / strips_per_class, k0s = (blockIdx.y - cls * strips_per_class) * strip;
-  const int n_cls = (a.height - cls + mult - 1) / mult; // rows of this class
-  if(k0s >= n_cls) return;
-  const int nrows = (strip < n_cls - k0s) ? strip : n_cls - k0s;
-  const int r_first = cls + k0s * mult;
-  const int tx = threadIdx.x, px = tx / 3, ch = tx - 3 * px;
-  const int tw = PDEL_NPX + 2 * mult;
-  float *const ring = pl;
-  float4 *const stage = (float4 *)(pl + ((PDE_RING * tw * 3 + 3) & ~3));
-  const int col = colblk * PDEL_NPX + px;
-  const bool live = col < a.width;
-  // lanes past the end of the row keep fetching (clamped): their samples are the clamped columns of their neighbours
-  // (a uniform row pointer + a 32-bit lane offset: the load takes its base from scalar registers)
-  const unsigned c4[3] = { (unsigned)(clampi(col - mult, 0, a.width - 1) * 4 + ch) * 4u, (unsigned)(clampi(col, 0, a.width - 1) * 4 + ch) * 4u,
-                           (unsigned)(clampi(col + mult, 0, a.width - 1) * 4 + ch) * 4u }; // byte offsets in a row
-  auto at = [](const float *const row, const unsigned byte_off) { return *(const float *)((const char *)row + byte_off); };
-#define PDE_ROW4(v) ((size_t)clampi(r_first + ((v) - 1) * mult, 0, a.height - 1) * a.width * 4)
-  if(tx < 2 * PDEL_NPX) stage[tx] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float Hw[3][3], Lw[3][3];
-  auto fetch_row = [&](const int v, auto slot_tag) {
-    constexpr int SL = decltype(slot_tag)::value;
-    const size_t y = PDE_ROW4(v);
-    const float *const hrow = hf + y, *const srow = HSUB ? hsub + y : nullptr, *const lrow = lf + y;
-#pragma unroll
-    for(int jj = 0; jj < 3; jj++)
-    {
-      if(HSUB) Hw[SL][jj] = at(hrow, c4[jj]) - at(srow, c4[jj]);
-      else Hw[SL][jj] = at(hrow, c4[jj]);
-      Lw[SL][jj] = at(lrow, c4[jj]);
-    }
-    float *const row = ring + (v % PDE_RING) * tw * 3 + ch;
-    row[(px + mult) * 3] = ratio2(Hw[SL][1], Lw[SL][1]);
-    if(px < mult) row[px * 3] = ratio2(Hw[SL][0], Lw[SL][0]);
-    if(px >= PDEL_NPX - mult) row[(px + 2 * mult) * 3] = ratio2(Hw[SL][2], Lw[SL][2]);
-  };
-  // the first wave: row kprev of the strip from its LDS row to memory
-  auto flush = [&](const int kprev) {
-    if(tx >= PDEL_NPX) return;
-    const int colp = colblk * PDEL_NPX + tx;
-    if(colp >= a.width) return;
-    float4 o = stage[(kprev & 1) * PDEL_NPX + tx];
-    if(a.post_lab) o = px_rgb_to_lab(o, a.post_m);
-    const size_t idx = (size_t)(r_first + kprev * mult) * a.width + colp;
-    if(final_pass) nt_store(out + idx, o);
-    else out[idx] = o;
-  };
-  auto row_step = [&](auto t_tag, const int kk) {
-    constexpr int T = decltype(t_tag)::value, S0 = T, S1 = (T + 1) % 3, S2 = (T + 2) % 3;
-    fetch_row(kk + 2, std::integral_constant<int, S2>());
-    __syncthreads();
-    if(kk > 0) flush(kk - 1);
-    if(!live) return;
-    const float H[9] = { Hw[S0][0], Hw[S0][1], Hw[S0][2], Hw[S1][0], Hw[S1][1], Hw[S1][2], Hw[S2][0], Hw[S2][1], Hw[S2][2] };
-    const float L[9] = { Lw[S0][0], Lw[S0][1], Lw[S0][2], Lw[S1][0], Lw[S1][1], Lw[S1][2], Lw[S2][0], Lw[S2][1], Lw[S2][2] };
-    float energy = 0.0f; // energy += ratio * ratio over k = 0..8, diffuse.c:829-841
-#pragma unroll
-    for(int ii = 0; ii < 3; ii++)
-    {
-      const float *const row = ring + ((kk + ii) % PDE_RING) * tw * 3 + px * 3 + ch;
-#pragma unroll
-      for(int jj = 0; jj < 3; jj++) energy += row[jj * mult * 3];
-    }
-    float o;
-    if(mask && !mask[(size_t)(r_first + kk * mult) * a.width + col])
-      o = max_zero(H[4] + L[4]); // outside the luminance mask: "only copy input to output", diffuse.c:927-937
-    else
-      o = pde_channel<MODE>(H, L, energy, a);
-    ((float *)&stage[(kk & 1) * PDEL_NPX + px])[ch] = o;
-  };
-  fetch_row(0, std::integral_constant<int, 0>());
-  fetch_row(1, std::integral_constant<int, 1>());
-  for(int kk = 0; kk < nrows; kk += 3)
-  {
-    row_step(std::integral_constant<int, 0>(), kk);
-    if(kk + 1 < nrows) row_step(std::integral_constant<int, 1>(), kk + 1);
-    if(kk + 2 < nrows) row_step(std::integral_constant<int, 2>(), kk + 2);
-  }
-  __syncthreads();
-  flush(nrows - 1);
-#undef PDE_ROW4
 }
 
 // ---- build_mask() + inpaint_mask(), diffuse.c:1106-1152, with the generators of src/iop/noise_generator.h:36-93 ----
@@ -786,15 +670,6 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
     for(int k = 0; k < 2 && k < iterations - 1; k++)
       ok &= (tmp[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane)) != nullptr;
   int err = ok ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
-  // one channel per lane (diffuse_pde_lanes) while every alpha sample is +0: the analysis launches keep the flag
-  static const bool no_lanes = measuring_env("ANSEL_HIP_PDE_NO_LANES") != nullptr; // the four-channel strips alone, for A/B timing
-  unsigned *alpha_flag = nullptr;
-  if(err == DT_HIP_SUCCESS && !per_row_pde && !no_lanes && measuring_env("ANSEL_HIP_BSPLINE_PER_ROW") == nullptr)
-  {
-    alpha_flag = (unsigned *)dt_hip_alloc_device_buffer(devid, sizeof(unsigned));
-    if(!alpha_flag) err = DT_HIP_SYSMEM_ALLOCATION;
-    else if(hipMemsetAsync(alpha_flag, 0, sizeof(unsigned), stream_of(devid)) != hipSuccess) err = DT_HIP_DEFAULT_ERROR;
-  }
 
   pde_args a;
   memset(&a, 0, sizeof(a));
@@ -853,7 +728,7 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
     for(int s = 0; s < scales && err == DT_HIP_SUCCESS; s++)
     {
       float4 *low = chain ? hf[s] : lf[s % 2];
-      err = bspline_launch_decompose(devid, st, level, chain ? nullptr : hf[s], low, w, h, 1 << s, alpha_flag);
+      err = bspline_launch_decompose(devid, st, level, chain ? nullptr : hf[s], low, w, h, 1 << s);
       level = low;
       residual = low;
     }
@@ -896,21 +771,7 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           const int mode = generic ? -1 : pde_mode_of(a);
           const dim3 sgrid(gx, classes * spc);
           const float4 *const h0 = chain ? (s == 0 ? src : hf[s - 1]) : hf[s], *const h1 = chain ? hf[s] : nullptr;
-          // three lanes a pixel first (it leaves at once when the alpha flag is up), the four-channel strips behind it
-          // (they leave at once when it is not)
-          const bool lanes = alpha_flag && a.mult <= PDEL_NPX;
-          const int lgx = (w + PDEL_NPX - 1) / PDEL_NPX;
-          const dim3 lgrid(xcd_pad(lgx), classes * spc);
-          const size_t lring = (((size_t)PDE_RING * (PDEL_NPX + 2 * a.mult) * 3 + 3) & ~(size_t)3) * sizeof(float) + 2 * PDEL_NPX * sizeof(float4);
-          const unsigned *const strip_flag = lanes ? alpha_flag : nullptr;
-#define PDE_LAUNCH(HS, MD)                                                                                                        \
-  do                                                                                                                              \
-  {                                                                                                                               \
-    if(lanes)                                                                                                                     \
-      diffuse_pde_lanes<HS, MD><<<lgrid, PDEL_THREADS, lring, st>>>((const float *)h0, (const float *)h1, (const float *)cur, to, a, \
-                                                                     s == 0, mask, strip, spc, lgx, alpha_flag);                   \
-    diffuse_pde_strip<HS, MD><<<sgrid, 256, ring, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc, strip_flag);                 \
-  } while(0)
+#define PDE_LAUNCH(HS, MD) diffuse_pde_strip<HS, MD><<<sgrid, 256, ring, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
           bool launched = false;
 #define PDE_CASE(MD)                     \
   if(!launched && mode == (MD))          \
@@ -946,7 +807,6 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
     if(tmp[k]) dt_hip_release_mem_object(tmp[k]);
   }
   if(mask) dt_hip_release_mem_object(mask);
-  if(alpha_flag) dt_hip_release_mem_object(alpha_flag);
   return err;
 }
 

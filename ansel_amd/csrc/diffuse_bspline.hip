@@ -108,10 +108,9 @@ template <int R, int T>
 __global__ __launch_bounds__(256) void bspline_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ hf,
                                                                float4 *__restrict__ lf, const int width, const int height,
                                                                const int mult, const int groups, const int strip,
-                                                               const int strips_per_class, unsigned *__restrict__ alpha_flag)
+                                                               const int strips_per_class)
 {
   __shared__ float4 vert[2][(T + 4) * R + 2];
-  unsigned alpha_bits = 0; // the fourth channel of every sample this lane is the centre of, and of what it stores
   const int bx = blockIdx.x;
   const int cls = blockIdx.y / strips_per_class, k0s = (blockIdx.y - cls * strips_per_class) * strip;
   const int n_cls = (height - cls + mult - 1) / mult; // rows of this class
@@ -191,7 +190,6 @@ __global__ __launch_bounds__(256) void bspline_decompose_strip(const float4 *__r
       const float4 low = tap5(t[0], t[1], t[2], t[3], t[4]);
       const size_t o = (size_t)row * width + col;
       lf[o] = low;
-      alpha_bits |= __float_as_uint(c.w) | __float_as_uint(low.w);
       // hf == nullptr: the caller keeps every low-pass plane and its PDE kernel forms centre - low itself (diffuse.hip)
       if(hf) nt_store(hf + o, make_float4(c.x - low.x, c.y - low.y, c.z - low.z, c.w - low.w));
     }
@@ -207,16 +205,13 @@ __global__ __launch_bounds__(256) void bspline_decompose_strip(const float4 *__r
     e2 = n2;
   }
 #undef BS_ROW
-  // diffuse_pde_lanes (diffuse.hip) leaves the fourth channel out while no launch has seen anything but +0 in it
-  if(alpha_flag && __builtin_amdgcn_ballot_w64(alpha_bits != 0) != 0ull && (threadIdx.x & 63) == 0) atomicOr(alpha_flag, 1u);
 }
 
 } // namespace
 
 namespace ansel
 {
-int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, float4 *lf, int w, int h, int mult,
-                             unsigned *alpha_flag)
+int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, float4 *lf, int w, int h, int mult)
 {
   const int steps = (w + mult - 1) / mult; // steps of the dilation across a row
   launch_scope ls(devid, "diffuse_decompose");
@@ -246,10 +241,10 @@ int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 
   while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
   const int spc = (per_class + strip - 1) / strip;
   const dim3 grid(gx, classes * spc);
-  if(mult == 1) bspline_decompose_strip<1, 256><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc, alpha_flag);
-  else if(mult == 2) bspline_decompose_strip<2, 128><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc, alpha_flag);
-  else if(mult == 4) bspline_decompose_strip<4, 64><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc, alpha_flag);
-  else bspline_decompose_strip<8, 32><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, mult / 8, strip, spc, alpha_flag);
+  if(mult == 1) bspline_decompose_strip<1, 256><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc);
+  else if(mult == 2) bspline_decompose_strip<2, 128><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc);
+  else if(mult == 4) bspline_decompose_strip<4, 64><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, 1, strip, spc);
+  else bspline_decompose_strip<8, 32><<<grid, 256, 0, s>>>(in, hf, lf, w, h, mult, mult / 8, strip, spc);
   return check_launch("diffuse_decompose");
 }
 } // namespace ansel

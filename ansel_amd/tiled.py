@@ -60,13 +60,16 @@ class BandWork:
 class BandRequest:
     """what a resumable engine.finish() asks of the other bands: `halo` = the [top][rows][bottom] rows of the
     module input whose first / last part the neighbours fill (`h` rows each, clipped at the frame), `sums` =
-    a float64 vector to all-reduce, `relay` = a buffer the bands fill in turn (engine.relay()); each may be None"""
+    a float64 vector every band must hold the frame-wide version of -- `sum_planes` tables of [frame rows][...] doubles in
+    which a band has filled its own rows and left the rest zero: the bands all-gather their row segments (sum_planes == 0:
+    no such layout, all-reduce) --, `relay` = a buffer the bands fill in turn (engine.relay()); each may be None"""
 
-    def __init__(self, halo, h, sums, relay=None):
+    def __init__(self, halo, h, sums, relay=None, sum_planes=0):
         self.halo = halo
         self.h = h
         self.sums = sums
         self.relay = relay
+        self.sum_planes = sum_planes
 
 
 class _DevicePtr:
@@ -129,7 +132,7 @@ class HipBandEngine:
             halo = device_view(st.halo_buf, (top + band.rows + bottom, st.row_bytes // 4), "<f4", self.device)
         if st.sum_buf:
             sums = device_view(st.sum_buf, (st.sum_count,), "<f8", self.device)
-        return BandRequest(halo, st.halo_rows, sums, relay)
+        return BandRequest(halo, st.halo_rows, sums, relay, sum_planes=int(st.sum_planes))
 
     def relay(self, band, work):
         """this band's turn in a relay stop: its rows on top of what the relay buffer holds"""
@@ -145,6 +148,7 @@ def sum_clipped(work, bands, dist=None, group=None):
     """collective 1: the frame-wide clipped count (no-op for one band)"""
     if len(bands) > 1 and dist is not None and work.count is not None:
         dist.all_reduce(work.count, op=dist.ReduceOp.SUM, group=group)
+        _log("clipped_count_all_reduce", 8)
 
 
 def exchange_halo(work, bands, rank, dist=None, group=None):
@@ -169,8 +173,41 @@ def exchange_halo(work, bands, rank, dist=None, group=None):
             ops.append(dist.P2POp(dist.irecv, work.halo[own0 + b.rows:own0 + b.rows + b.halo_bottom], rank + 1,
                                   group=group))
     if ops:
+        _log("mosaic_halo_send_recv", sum(op.tensor.numel() * op.tensor.element_size() for op in ops if op.op is dist.isend))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+
+
+# what the collectives of the last frame moved (bench.py --mode tiled reports it): name -> [calls, bytes sent by this rank]
+EXCHANGE_LOG = {}
+
+
+def _log(name, nbytes):
+    e = EXCHANGE_LOG.setdefault(name, [0, 0])
+    e[0] += 1
+    e[1] += int(nbytes)
+
+
+def gather_sums(req, bands, rank, dist, group=None):
+    """the frame-wide table of partial sums from the bands' own row segments: every entry is non-zero in exactly one
+    band's table, so nothing is added -- an all-gather of the segments (padded to the longest), the peer of the strided
+    peer copies of dt_hip_pipe_process_bands().  (Round 3 all-reduced the whole table: twice the bytes on a ring, and a
+    sum where a copy does.)"""
+    n = len(bands)
+    height = bands[-1].row0 + bands[-1].rows
+    t = req.sums.view(req.sum_planes, -1)
+    per_row = t.shape[1] // height
+    offs = [b.row0 * per_row for b in bands]
+    lens = [b.rows * per_row for b in bands]
+    longest = max(lens)
+    stage = t.new_zeros((req.sum_planes, longest))
+    stage[:, :lens[rank]] = t[:, offs[rank]:offs[rank] + lens[rank]]
+    parts = [t.new_empty((req.sum_planes, longest)) for _ in range(n)]
+    dist.all_gather(parts, stage, group=group)
+    for j in range(n):
+        if j != rank:
+            t[:, offs[j]:offs[j] + lens[j]] = parts[j][:, :lens[j]]
+    _log("sums_all_gather", stage.numel() * stage.element_size())
 
 
 def _halo_parts(bands, k, h, height):
@@ -188,12 +225,18 @@ def serve_request(req, bands, rank, dist=None, group=None, engine=None, work=Non
         engine.relay(bands[rank], work)
         if many and rank + 1 < n:
             dist.send(req.relay, dst=rank + 1, group=group)
+            _log("grid_relay_send", req.relay.numel() * req.relay.element_size())
         if many:
             dist.broadcast(req.relay, src=n - 1, group=group)
+            _log("grid_broadcast", req.relay.numel() * req.relay.element_size() if rank == n - 1 else 0)
     if n == 1 or dist is None:
         return
     if req.sums is not None:
-        dist.all_reduce(req.sums, op=dist.ReduceOp.SUM, group=group)
+        if req.sum_planes > 0:
+            gather_sums(req, bands, rank, dist, group)
+        else:
+            dist.all_reduce(req.sums, op=dist.ReduceOp.SUM, group=group)
+            _log("sums_all_reduce", req.sums.numel() * req.sums.element_size())
     if req.halo is None:
         return
     height = bands[-1].row0 + bands[-1].rows
@@ -212,6 +255,7 @@ def serve_request(req, bands, rank, dist=None, group=None, engine=None, work=Non
         need = _halo_parts(bands, rank + 1, h, height)[0]
         ops.append(dist.P2POp(dist.isend, req.halo[top + b.rows - need:top + b.rows], rank + 1, group=group))
         ops.append(dist.P2POp(dist.irecv, req.halo[top + b.rows:top + b.rows + bottom], rank + 1, group=group))
+    _log("rgba_halo_send_recv", sum(op.tensor.numel() * op.tensor.element_size() for op in ops if op.op is dist.isend))
     for r in dist.batch_isend_irecv(ops):
         r.wait()
 
@@ -219,6 +263,7 @@ def serve_request(req, bands, rank, dist=None, group=None, engine=None, work=Non
 def process_band(engine, bands, rank, dev_in_band, dev_out_band, width, dist=None, group=None):
     """one frame, this rank's band"""
     band = bands[rank]
+    EXCHANGE_LOG.clear()
     work = engine.begin(band, dev_in_band, width)
     try:
         sum_clipped(work, bands, dist, group)

@@ -60,7 +60,7 @@ def parse():
                     help="skip the PCIe-inclusive host-to-host measurements (--pipe light only; never `value`)")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per module (A/B against the fused executor)")
     ap.add_argument("--cpu-sample", default=None,
-                    help="frame size of the bounded CPU sample (default: 4000x3000 for the full pipe, 24MP for the light one)")
+                    help="frame size of the bounded CPU sample (default: 24MP)")
     ap.add_argument("--pipe", default="full", choices=("full", "light", "denoise"),
                     help="full = the metric's workload: config 3's modules (denoise (profiled) wavelets, diffuse or sharpen, "
                          "non-local means) + local contrast (bilateral grid); light = BASELINE.json config 2; "
@@ -83,7 +83,15 @@ def frame_size(name):
     return int(w), int(h)
 
 
-def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light", demosaic_method=None):
+# diffuse or sharpen in the full pipe: the reference's "lens deblur: soft" preset (src/iop/diffuse.c:304-325: four speeds, orders 1
+# and 3 along the isophotes, radius 8 -> 5 scales) cut from its 8 iterations to 2 -- 10 B-spline analyses + 10 PDE passes, 960 of the
+# pipe's 2 114 algorithmic B/px.  The module's $DEFAULT (diffuse.c:79-98) is 1 iteration with all four speeds 0: the line carries
+# that pipe too, as config.default_diffuse.
+DIFFUSE_TIMED = ("lens_deblur_soft", 2)
+DIFFUSE_DEFAULT = ("default", 1)
+
+
+def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light", demosaic_method=None, diffuse=DIFFUSE_TIMED):
     from ansel_amd import abi, params, pipe
     filmic = None
     if with_filmic:
@@ -94,7 +102,7 @@ def build_pipe(width, height, lut_ptr, lut, with_filmic, which="light", demosaic
         # BASELINE.json config 3: + denoise (profiled wavelets) + non-local means + diffuse or sharpen; "full" also
         # runs local contrast (bilateral grid) behind non-local means, inside the same Lab section
         return pipe.denoise_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, filmic=filmic, with_nlmeans=True,
-                                       with_bilat=(which == "full"))
+                                       with_bilat=(which == "full"), diffuse_preset=diffuse[0], diffuse_iterations=diffuse[1])
     return pipe.light_pipe_nodes(width, height, lut_ptr, float(lut[0]), coeffs, with_filmic=with_filmic,
                                  filmic=filmic, demosaic_method=abi.DT_HIP_DEMOSAIC_RCD if demosaic_method is None else demosaic_method)
 
@@ -159,30 +167,41 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
         return (raw, [ck.aligned_empty((h, w), np.float32) for _ in range(2)],
                 [ck.aligned_empty((h, w, 4), np.float32) for _ in range(2)], ck.aligned_empty((h, w, 4), np.uint16))
 
-    w, h = frame_size(size_name)
-    nodes = build_pipe(w, h, lut.ctypes.data, lut, with_filmic, which)
-    raw, cfa, rgb, out16 = buffers(w, h)
     quota = cgroup_cpu_quota()
     first = int(round(quota)) if quota and quota >= 1 else 32  # a container with a CPU quota runs best on that many threads
     counts = sorted({c for c in (16, 32, 64, 128, ncpu, first) if c <= ncpu} | {ncpu})
+    # the thread count: a sweep on a 6 MP frame of the same chain (a pass there takes 0.1 - 1.5 s) ...
+    sw, sh = 3000, 2000
+    snodes = build_pipe(sw, sh, lut.ctypes.data, lut, with_filmic, which)
+    raw, cfa, rgb, out16 = buffers(sw, sh)
     sweep = {}
-    t_budget = time.time() + 25.0
-    # 32 first (the count that has won every sweep on the 256-thread hosts), then outwards: the slow all-threads pass
-    # comes last and is skipped when the budget is spent
+    t_budget = time.time() + 12.0
     for c in sorted(counts, key=lambda c: (abs(c - first), c)):
         set_threads(c)
-        _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16)  # warm-up: page in, spin up the team
+        _chain_pass(l, prefix, snodes, sw, sh, raw, cfa, rgb, out16)  # warm-up: page in, spin up the team
         times = []
-        while len(times) < 2 or (len(times) < 3 and time.time() < t_budget):
+        for _ in range(2):
             t0 = time.perf_counter()
-            _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16)
+            _chain_pass(l, prefix, snodes, sw, sh, raw, cfa, rgb, out16)
             times.append(time.perf_counter() - t0)
         sweep[c] = min(times)
         if time.time() > t_budget and len(sweep) >= 2:
             break
     best_c = min(sweep, key=sweep.get)
-    best = sweep[best_c]
-    sample = "%d x %d RGGB frame (%s), same module chain, best of %d passes, %.2f s per pass" % (w, h, size_name, 3, best)
+    del raw, cfa, rgb, out16
+    # ... the figure: the sample frame (24 MP unless --cpu-sample says otherwise) at that count, best of two passes after a warm-up
+    w, h = frame_size(size_name)
+    nodes = build_pipe(w, h, lut.ctypes.data, lut, with_filmic, which)
+    raw, cfa, rgb, out16 = buffers(w, h)
+    set_threads(best_c)
+    _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        _chain_pass(l, prefix, nodes, w, h, raw, cfa, rgb, out16)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    sample = "%d x %d RGGB frame (%s), same module chain, best of 2 passes after a warm-up, %.2f s per pass" % (w, h, size_name, best)
     value = w * h / 1e6 / best
     # the device's own frame size, when one pass of it is affordable (<= ~8 s predicted)
     if device_size is not None and device_size != (w, h):
@@ -190,7 +209,6 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
         predicted = best * (dw * dh) / float(w * h)
         if predicted <= 8.0:
             del raw, cfa, rgb, out16
-            set_threads(best_c)
             dn = build_pipe(dw, dh, lut.ctypes.data, lut, with_filmic, which)
             raw, cfa, rgb, out16 = buffers(dw, dh)
             _chain_pass(l, prefix, dn, dw, dh, raw, cfa, rgb, out16)
@@ -199,11 +217,13 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
             t = time.perf_counter() - t0
             value = dw * dh / 1e6 / t
             sample = ("%d x %d RGGB frame (the device's), same module chain, one pass after a warm-up, %.2f s; thread "
-                      "count chosen on a %d x %d sample" % (dw, dh, t, w, h))
-    return {"value": round(value, 3), "unit": "MPix/s", "cores": best_c, "kind": kind, "sample": sample,
+                      "count chosen on a %d x %d frame" % (dw, dh, t, sw, sh))
+    # `cores`: what the container may use -- its cgroup quota where it has one (threads beyond it share those cores)
+    cores = int(round(quota)) if quota and quota >= 1 else best_c
+    return {"value": round(value, 3), "unit": "MPix/s", "cores": min(cores, best_c), "threads": best_c, "kind": kind, "sample": sample,
             "host_threads": ncpu, "cpu_quota": quota,
             "binding": "OMP_PROC_BIND=%s OMP_PLACES=%s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
-            "thread_sweep_mpix_s": {str(c): round(w * h / 1e6 / t, 3) for c, t in sorted(sweep.items())}}
+            "thread_sweep_mpix_s_on_6MP": {str(c): round(sw * sh / 1e6 / t, 3) for c, t in sorted(sweep.items())}}
 
 
 def cpu_baseline_in_child(size_name, with_filmic, which, device_size):
@@ -217,7 +237,7 @@ def cpu_baseline_in_child(size_name, with_filmic, which, device_size):
             "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline(%r, %r, %r, device_size=%r)))"
             % (ROOT, size_name, bool(with_filmic), which, tuple(device_size)))
     try:
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     except subprocess.TimeoutExpired:
         return None
     for ln in out.stdout.splitlines():
@@ -336,6 +356,37 @@ def valu_floor_ms(tag, mpix):
     if not k or "issue_floor_ms_per_mpix" not in k:
         return None
     return k["issue_floor_ms_per_mpix"] * mpix
+
+
+def measured_ceiling(torch, dev, gib=1.0, reps=8):
+    """what a streaming kernel reaches on THIS device in THIS run (beside the 8 TB/s of the data sheet): a
+    device-to-device copy (read + write) and a triad a = b + s c (two reads + a write) over `gib` GiB planes, HIP events
+    on the current stream, best of `reps`"""
+    n = int(gib * (1 << 30)) // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.ones(n, dtype=torch.float32, device=dev)
+    c = torch.ones(n, dtype=torch.float32, device=dev)
+    out = {}
+    for name, fn, streams in (("copy", lambda: a.copy_(b), 2), ("triad", lambda: torch.add(b, c, alpha=2.0, out=a), 3)):
+        fn()
+        best = None
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None or ms < best else best
+        out[name + "_GBs"] = round(streams * n * 4 / (best * 1e-3) / 1e9, 1)
+    del a, b, c
+    return out
+
+
+def band_digest(t):
+    """64-bit digest of a band's exported words (host side, after the timed region)"""
+    import xxhash
+    return xxhash.xxh64(t.cpu().numpy().tobytes()).hexdigest()
 
 
 def cgroup_cpu_quota():
@@ -577,10 +628,60 @@ def main():
     # ---- per-kernel HIP-event timings of the timed region (recorded on the launch stream)
     kernels = read_kernel_events(l, devid)
 
+    # ---- --mode tiled validates itself (after the timed region): every rank digests the band its timed steps wrote, rank 0
+    #      runs the SAME frame unsplit through the same executor and compares band by band -- the assembled bands are the
+    #      unsplit frame or the line says so.  What the collectives moved and how many ranks RCCL saw go on the line too.
+    tiled_check = None
+    if args.mode == "tiled":
+        mine = band_digest(out16)
+        if world > 1:
+            digests = [None] * world
+            dist.all_gather_object(digests, mine)
+            logs = [None] * world
+            dist.all_gather_object(logs, {k: list(v) for k, v in tiled.EXCHANGE_LOG.items()})
+        else:
+            digests, logs = [mine], [{k: list(v) for k, v in tiled.EXCHANGE_LOG.items()}]
+        if rank == 0:
+            whole_in = torch.from_numpy(raw_host.view(np.int16)).to(dev)
+            whole_out = torch.empty((height, width, 4), dtype=torch.int16, device=dev)
+            # the unsplit frame on this rank's executor (the same node list: a DevicePipe runs either way)
+            executor.process(whole_in.data_ptr(), whole_out.data_ptr())
+            torch.cuda.synchronize(dev)
+            want = [band_digest(whole_out[b.row0:b.row0 + b.rows]) for b in bands]
+            del whole_in, whole_out
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
+            tiled_check = {"verified": digests == want, "bands_equal_unsplit": [a == b for a, b in zip(digests, want)],
+                           "against": "the same frame unsplit through dt_hip_pipe_process on rank 0, xxh64 of every band's exported words",
+                           "ranks_seen": dist.get_world_size() if world > 1 else 1, "rccl_version": rccl,
+                           "exchanges_last_frame": [{k: {"calls": v[0], "bytes_sent": v[1]} for k, v in sorted(lg.items())} for lg in logs],
+                           "band_rows": [int(b.rows) for b in bands]}
+
     # ---- after the timed region: the buffer those steps wrote, against the oracle
     verify = None
-    if rank == 0 and world == 1 and args.mode == "batch" and not args.no_verify:
+    ranks_check = None
+    if args.mode == "batch" and world > 1 and not args.no_verify:
+        # N > 1, one frame per GPU: every rank also runs RANK 0's frame once and the digests must agree -- together with rank
+        # 0's comparison against the oracle below that pins every device's output, not only the first one's
+        same_in = torch.from_numpy(synth.bayer_mosaic_tiled(width, height, seed=1).view(np.int16)).to(dev)
+        same_out = torch.empty((height, width, 4), dtype=torch.int16, device=dev)
+        executor.process(same_in.data_ptr(), same_out.data_ptr())
+        torch.cuda.synchronize(dev)
+        digests = [None] * world
+        dist.all_gather_object(digests, band_digest(same_out))
+        del same_in, same_out
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        ranks_check = {"ranks_seen": dist.get_world_size(), "rccl_version": rccl, "all_ranks_equal_on_rank0_frame": len(set(digests)) == 1}
+    if rank == 0 and args.mode == "batch" and not args.no_verify:
         verify = verify_output(out16, raw_host, width, height, with_filmic, args.pipe)
+        if ranks_check is not None:
+            verify.update(ranks_check)
+            verify["verified"] = bool(verify["verified"]) and ranks_check["all_ranks_equal_on_rank0_frame"]
 
     # ---- config 2's module list on the SAME frame, same run (config.light_pipe)
     light = None
@@ -633,6 +734,28 @@ def main():
         except Exception as e:  # the leg is informative: the line does not depend on it
             light["with_amaze"] = {"error": str(e)[:200]}
         del lout
+
+    # ---- the metric's pipe with diffuse or sharpen at the module's $DEFAULT (1 iteration, all speeds 0) instead of the timed preset
+    default_diffuse = None
+    if rank == 0 and world == 1 and args.mode == "batch" and args.pipe == "full" and not args.no_light_pipe:
+        dnodes = build_pipe(width, height, lut.data_ptr(), lut_host, with_filmic, "full", diffuse=DIFFUSE_DEFAULT)
+        dexec = pipe.DevicePipe(devid, dnodes, fusion=not args.no_fusion)
+        dout = torch.empty((height, width, 4), dtype=torch.int16, device=dev)
+        dexec.process(raw.data_ptr(), dout.data_ptr())
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dexec.process(raw.data_ptr(), dout.data_ptr())
+        torch.cuda.synchronize(dev)
+        d_ms = (time.perf_counter() - t1) / 3 * 1e3
+        d_bpp = pipe.algorithmic_bytes_per_pixel(dnodes)
+        default_diffuse = {"diffuse": "module $DEFAULT: 1 iteration, all four speeds 0 (src/iop/diffuse.c:79-98)", "steps": 3,
+                           "ms_per_step": round(d_ms, 3), "mpix_s": round(npix / 1e6 / (d_ms * 1e-3), 2),
+                           "algorithmic_bytes_per_px": d_bpp,
+                           "pipe_hbm_frac": round(d_bpp * npix / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        dexec.close()
+        del dout
+    ceiling = measured_ceiling(torch, dev) if rank == 0 else None
 
     # ---- the same step with the boundary's two PCIe legs (never `value`): sensor buffer in pinned host memory ->
     #      basebuffer upload -> pipe -> exported frame back into pinned host memory
@@ -755,8 +878,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%d x %d RGGB u16 raw (%s), %s export pipe: %s; module defaults; %s"
+                "workload": "%d x %d RGGB u16 raw (%s), %s export pipe: %s; module defaults%s; %s"
                             % (width, height, args.size, args.pipe, " > ".join(ops),
+                               "" if args.pipe == "light" else " except diffuse or sharpen = the reference's 'lens deblur: soft' preset at %d "
+                               "of its 8 iterations (%d B-spline analyses + %d PDE passes per frame; config.default_diffuse has the "
+                               "module's $DEFAULT)" % (DIFFUSE_TIMED[1], 5 * DIFFUSE_TIMED[1], 5 * DIFFUSE_TIMED[1]),
                                "one frame cut into %d row bands, one per GPU (halo rows and the reductions over RCCL)" % world
                                if args.mode == "tiled" else "one frame per GPU"),
                 "frame_mpix": round(npix / 1e6, 2),
@@ -769,6 +895,7 @@ def main():
                 "kernel_bounds": per_kernel,
                 "pmc_source": pmc_src,
                 "light_pipe": light,
+                "default_diffuse": default_diffuse,
                 # not `value`: one frame from pinned host memory to pinned host memory over PCIe
                 "host_to_host_ms": None if host_ms is None else round(host_ms, 3),
                 "host_to_host_overlapped_ms": None if host_overlap_ms is None else round(host_overlap_ms, 3),
@@ -778,13 +905,17 @@ def main():
             "roofline": {
                 # the contract's figure for the launch with the largest share of the step: algorithmic bytes of the
                 # module(s) it executes / its average duration (HIP events on the launch stream) / HBM peak
-                "bound": "hbm",
+                # what binds the dominant launch (the contract's "hbm" | "mfma" does not cover a kernel bound by VALU issue and
+                # the LDS pipe; achieved / peak / frac below stay the HBM figures the contract asks for)
+                "bound": per_kernel.get(dominant, {}).get("bound", "hbm"),
                 "kernel": dominant,
                 "share_of_step": round(dom["ms_avg"] * dom["launches"] / args.steps / max(kernel_ms, 1e-9), 3),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # the ceiling measured in this run on this device: device-to-device copy and triad (GB/s of bytes moved)
+                "peak_measured": ceiling,
                 "traffic": traffic,
                 "traffic_source": pmc_src if traffic is not None else None,
                 # ... and what actually binds this launch (config.kernel_bounds has every kernel of the step)
@@ -792,13 +923,17 @@ def main():
                 "valu_frac": per_kernel.get(dominant, {}).get("valu_frac"),
                 # the whole step: sum of algorithmic bytes / step time / peak (= config.pipe_hbm_frac)
                 "pipe_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pipe_frac_of_measured_copy": None if not ceiling else round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / ceiling["copy_GBs"], 4),
             },
         }
+        if tiled_check is not None:
+            line["verified"] = tiled_check["verified"]
+            line["verify"] = tiled_check
         if verify is not None:
             line["verified"] = verify["verified"]
             line["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample or ("24MP" if args.pipe == "light" else "4000x3000")
+            sample = args.cpu_sample or "24MP"
             cb = cpu_baseline_in_child(sample, with_filmic, args.pipe, (width, height))
             if cb is not None:
                 line["cpu_baseline"] = cb

@@ -114,7 +114,7 @@ class OracleBandEngine:
             f64 = torch.zeros((h, w, 4), dtype=torch.float64)
             f64[band.row0:band.row0 + rows] = torch.from_numpy(src.astype(np.float64))
             f64 = f64.reshape(-1)
-            yield BandRequest(None, 0, f64)
+            yield BandRequest(None, 0, f64, sum_planes=1)  # one table of [frame rows][4 w] doubles: the all-gather path
             frame = f64.numpy().reshape(h, w, 4).astype(np.float32)
         full = np.zeros((h, w, 4), np.float32)
         assert ck.call(self.l, "oracle_" + n.op, n.piece, n.data, frame, full) == 0, n.op

@@ -9,6 +9,8 @@ non-local means, XCD-rotated launches at real widths, tile grids with thousands 
   config 2'  6000 x 4000   the same with AMaZE instead of RCD
   config 3   9504 x 6336   + denoise (profiled) wavelets + diffuse or sharpen + non-local means and local contrast
                            (bilateral grid) in Lab: the FULL pipe
+  config 5   8256 x 5504   the frame of the batch export (45 MP): light pipe and full pipe -- a chunk / tile grid of its own
+                           (non-local-means chunks of 72 x 64: the fused variant of the chunk kernel, as at 60 MP)
   light     11648 x 8736   light pipe                            (bench.py's `config.light_pipe`)
   metric /  11648 x 8736   the full pipe (what bench.py's `value` is quoted on), unsplit AND cut into 8 row bands run in
   config 4                 lockstep (the bilateral grid relayed band to band)
@@ -165,6 +167,14 @@ def test_light_pipe_24MP_with_amaze_equals_the_oracle():
 
 def test_config3_full_pipe_60MP_equals_the_oracle():
     _case("denoise", "60MP", host_gib=48)
+
+
+def test_config5_frame_45MP_light_pipe_equals_the_oracle():
+    _case("light", "45MP", host_gib=10)
+
+
+def test_config5_frame_45MP_full_pipe_equals_the_oracle():
+    _case("denoise", "45MP", host_gib=40)
 
 
 def test_light_pipe_100MP_equals_the_oracle():

@@ -275,6 +275,49 @@ def test_two_ranks_full_pipe_over_gloo_equal_the_unsplit_frame(tmp_path, which):
 
 
 @needs_oracle
+def test_three_ranks_full_pipe_over_gloo_equal_the_unsplit_frame(tmp_path):
+    """world size 3: a middle band with two neighbours -- halo rows from both sides, its segment of the wavelets' table of
+    partial sums gathered from and to two peers, a relay turn that neither starts nor ends the chain"""
+    import torch.multiprocessing as mp
+    w, h, world = 128, 640, 3
+    port = _free_port()
+    mp.spawn(_full_rank_main, args=(world, port, w, h, "everything", str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("band%d.npy" % r)) for r in range(world)], axis=0)
+    lut = params.srgb_encode_lut()
+    want = be.whole_frame(_full_nodes(w, h, lut, "everything"), be.test_frame(w, h, 10, 10), w, h)
+    assert np.array_equal(got, want)
+
+
+def test_the_sums_table_is_gathered_not_reduced():
+    """gather_sums(): every band's own row segment of every plane reaches every band; what lies outside a band's rows
+    in ITS table is never read (poisoned here), which an all-reduce would have added in"""
+    import torch
+
+    class _Dist:  # a one-process stand-in: rank r's call sees all three stages
+        def __init__(self, stages):
+            self.stages = stages
+
+        def all_gather(self, parts, stage, group=None):
+            for p, s in zip(parts, self.stages):
+                p.copy_(s)
+    bands = tiled.plan_bands(128, 640, 3)
+    height, planes, per_row = 640, 2, 8
+    truth = torch.arange(planes * height * per_row, dtype=torch.float64).view(planes, -1)
+    longest = max(b.rows for b in bands) * per_row
+    stages = []
+    for b in bands:
+        st = torch.zeros((planes, longest), dtype=torch.float64)
+        st[:, :b.rows * per_row] = truth[:, b.row0 * per_row:(b.row0 + b.rows) * per_row]
+        stages.append(st)
+    for r, b in enumerate(bands):
+        mine = torch.full((planes, height * per_row), float("nan"), dtype=torch.float64)
+        mine[:, b.row0 * per_row:(b.row0 + b.rows) * per_row] = truth[:, b.row0 * per_row:(b.row0 + b.rows) * per_row]
+        req = tiled.BandRequest(None, 0, mine.view(-1), sum_planes=planes)
+        tiled.gather_sums(req, bands, r, _Dist(stages))
+        assert torch.equal(mine, truth)
+
+
+@needs_oracle
 @pytest.mark.parametrize("which", ["all", "everything"])
 def test_local_protocol_full_pipe_three_bands(which):
     w, h, n = 128, 480, 3
