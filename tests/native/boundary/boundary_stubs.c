@@ -220,11 +220,47 @@ dt_iop_colorspace_type_t dt_develop_blend_colorspace(const struct dt_dev_pixelpi
   (void)piece;
   return cst;
 }
+/* the pipe's work profile: none for the modules that do not ask, the one the test installed for those that do */
+static dt_iop_order_iccprofile_info_t g_work_profile;
+static int g_have_work_profile = 0;
 dt_iop_order_iccprofile_info_t *dt_ioppr_get_pipe_work_profile_info(const struct dt_dev_pixelpipe_t *pipe)
 {
   (void)pipe;
-  return NULL;
+  return g_have_work_profile ? &g_work_profile : NULL;
 }
+
+/* ---- the prepared conversion behind the reference's accessor API (colorprofiles/conversion.h:225-345): a test double that
+ *      holds what dt_colorspaces_prepare_conversion() would have derived from two profiles */
+struct dt_colorspaces_conversion_t
+{
+  dt_colormatrix_t matrix, clip_matrix;
+  int has_clipping;
+  const float *source_curve[3], *target_curve[3];
+  float source_coeffs[9], target_coeffs[9];
+};
+uint64_t dt_colorspaces_conversion_identity(const dt_colorspaces_conversion_t *const c) { return (uint64_t)(uintptr_t)c; }
+gboolean dt_colorspaces_conversion_is_matrix(const dt_colorspaces_conversion_t *const c) { return c != NULL; }
+gboolean dt_colorspaces_conversion_has_clipping(const dt_colorspaces_conversion_t *const c) { return c && c->has_clipping; }
+gboolean dt_colorspaces_conversion_matrix(const dt_colorspaces_conversion_t *const c, dt_colormatrix_t m)
+{
+  if(!c) return FALSE;
+  memcpy(m, c->matrix, sizeof(dt_colormatrix_t));
+  return TRUE;
+}
+gboolean dt_colorspaces_conversion_source_matrix(const dt_colorspaces_conversion_t *const c, dt_colormatrix_t m)
+{
+  return dt_colorspaces_conversion_matrix(c, m);
+}
+gboolean dt_colorspaces_conversion_clip_matrix(const dt_colorspaces_conversion_t *const c, dt_colormatrix_t m)
+{
+  if(!c || !c->has_clipping) return FALSE;
+  memcpy(m, c->clip_matrix, sizeof(dt_colormatrix_t));
+  return TRUE;
+}
+const float *dt_colorspaces_conversion_source_curve(const dt_colorspaces_conversion_t *const c, const int ch) { return c->source_curve[ch]; }
+const float *dt_colorspaces_conversion_target_curve(const dt_colorspaces_conversion_t *const c, const int ch) { return c->target_curve[ch]; }
+const float *dt_colorspaces_conversion_source_coeffs(const dt_colorspaces_conversion_t *const c) { return c->source_coeffs; }
+const float *dt_colorspaces_conversion_target_coeffs(const dt_colorspaces_conversion_t *const c) { return c->target_coeffs; }
 int dt_ioppr_get_iop_order(GList *iop_order_list, const char *op_name, const int multi_priority)
 {
   (void)iop_order_list; (void)op_name; (void)multi_priority;
@@ -315,25 +351,70 @@ static void diffuse_tiling_callback(struct dt_iop_module_t *self, const struct d
   stub_diffuse_tiling_callback(self, pipe, piece, tiling); /* overlap = what the module's stencils reach */
   squeeze(pipe, tiling);
 }
+/* round 4: a mosaic-stage module, a stencil module with overlap 128, a colour module -- each the stub of INTEGRATION.md section 2 */
+static const char *demosaic_name(void) { return "demosaic"; }
+static int demosaic_process_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                               const struct dt_dev_pixelpipe_iop_t *piece, void *dev_in, void *dev_out)
+{
+  log_call(piece);
+  return stub_demosaic_process_cl(self, pipe, piece, dev_in, dev_out);
+}
+static void demosaic_tiling_callback(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                                     const struct dt_dev_pixelpipe_iop_t *piece, struct dt_develop_tiling_t *tiling)
+{
+  stub_demosaic_tiling_callback(self, pipe, piece, tiling); /* overlap 10, xalign = yalign = 2 (demosaic.c:1532-1600) */
+  squeeze(pipe, tiling);
+}
+static const char *denoiseprofile_name(void) { return "denoiseprofile"; }
+static int denoiseprofile_process_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                                     const struct dt_dev_pixelpipe_iop_t *piece, void *dev_in, void *dev_out)
+{
+  log_call(piece);
+  return stub_denoiseprofile_process_cl(self, pipe, piece, dev_in, dev_out);
+}
+static void denoiseprofile_tiling_callback(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                                           const struct dt_dev_pixelpipe_iop_t *piece, struct dt_develop_tiling_t *tiling)
+{
+  stub_denoiseprofile_tiling_callback(self, pipe, piece, tiling); /* overlap 2^(max scale): 128 (denoiseprofile.c:796-848) */
+  squeeze(pipe, tiling);
+}
+static const char *colorin_name(void) { return "colorin"; }
+static int colorin_process_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
+                              const struct dt_dev_pixelpipe_iop_t *piece, void *dev_in, void *dev_out)
+{
+  log_call(piece);
+  return stub_colorin_process_cl(self, pipe, piece, dev_in, dev_out);
+}
+
 static int module_process_tiling_cl(struct dt_iop_module_t *self, const struct dt_dev_pixelpipe_t *pipe,
                                     const struct dt_dev_pixelpipe_iop_t *piece, const void *const i, void *const o, const int bpp)
 {
   return default_process_tiling_cl(self, pipe, piece, i, o, bpp);
 }
 
-static void make_module(dt_iop_module_t *m, dt_develop_t *dev, const int diffuse)
+enum { M_EXPOSURE = 0, M_DIFFUSE = 1, M_DEMOSAIC = 2, M_DENOISEPROFILE = 3, M_COLORIN = 4 };
+static void make_module(dt_iop_module_t *m, dt_develop_t *dev, const int kind)
 {
+  static const char *const ops[] = { "exposure", "diffuse", "demosaic", "denoiseprofile", "colorin" };
+  typedef const char *(*name_fn)(void);
+  static const name_fn names[] = { exposure_name, diffuse_name, demosaic_name, denoiseprofile_name, colorin_name };
   memset(m, 0, sizeof(*m));
   memset(dev, 0, sizeof(*dev));
-  strcpy(m->op, diffuse ? "diffuse" : "exposure");
+  strcpy(m->op, ops[kind]);
   m->dev = dev;
-  m->name = diffuse ? diffuse_name : exposure_name;
+  m->name = names[kind];
   m->flags = module_flags;
-  m->tiling_callback = diffuse ? diffuse_tiling_callback : exposure_tiling_callback;
-  m->process_cl = diffuse ? diffuse_process_cl : exposure_process_cl;
+  m->tiling_callback = kind == M_DIFFUSE ? diffuse_tiling_callback
+                       : (kind == M_DEMOSAIC ? demosaic_tiling_callback
+                                             : (kind == M_DENOISEPROFILE ? denoiseprofile_tiling_callback : exposure_tiling_callback));
+  m->process_cl = kind == M_DIFFUSE ? diffuse_process_cl
+                  : (kind == M_DEMOSAIC ? demosaic_process_cl
+                                        : (kind == M_DENOISEPROFILE ? denoiseprofile_process_cl
+                                                                    : (kind == M_COLORIN ? colorin_process_cl : exposure_process_cl)));
   m->process_tiling_cl = module_process_tiling_cl;
   g_module_flags = IOP_FLAGS_ALLOW_TILING;
-  (void)integration_stub_table(0);
+  static volatile int keep = 0; /* every stub of integration_stubs.h stays referenced: compiled, type-checked, linked */
+  (void)integration_stub_table(keep);
 }
 static void make_piece(dt_dev_pixelpipe_iop_t *piece, dt_iop_module_t *m, void *d, int w, int h)
 {
@@ -461,7 +542,7 @@ static int run_tiled(const float *in, float *out, int w, int h, float black, flo
     dd.threshold = diffuse->threshold; dd.first = diffuse->first; dd.second = diffuse->second; dd.third = diffuse->third;
     dd.fourth = diffuse->fourth; dd.radius_center = diffuse->radius_center;
   }
-  make_module(&m, &dev, diffuse != NULL);
+  make_module(&m, &dev, diffuse != NULL ? M_DIFFUSE : M_EXPOSURE);
   make_piece(&piece, &m, diffuse ? (void *)&dd : (void *)&d, w, h);
   dt_dev_pixelpipe_t pipe;
   memset(&pipe, 0, sizeof(pipe));
@@ -487,4 +568,124 @@ int boundary_run_diffuse_tiled(const float *in, float *out, int w, int h, const 
                                int *calls)
 {
   return run_tiled(in, out, w, h, 0.0f, 1.0f, diffuse, budget, calls);
+}
+
+
+/* ---- round 4: the reference's default_process_tiling_cl() on a MOSAIC-stage module (one channel in, four out, tiles aligned to the
+ *      2 x 2 cell, overlap 10) and on denoise (profiled) wavelets (overlap 128); its pixelpipe_process_on_GPU() on colorin ---- */
+static int run_module_tiled(const int kind, void *data, const float *in, float *out, int w, int h, int in_channels, uint32_t filters,
+                            const float *wb, size_t budget, int *calls)
+{
+  if(dt_hip_init() != DT_HIP_SUCCESS) return -1;
+  dt_iop_module_t m;
+  dt_develop_t dev;
+  dt_dev_pixelpipe_iop_t piece;
+  make_module(&m, &dev, kind);
+  make_piece(&piece, &m, data, w, h);
+  if(in_channels == 1)
+  {
+    piece.dsc_in.channels = 1;
+    piece.dsc_in.bpp = 4;
+    piece.dsc_in.cst = IOP_CS_RAW;
+    piece.dsc_in.filters = filters;
+  }
+  for(int c = 0; c < 4; c++)
+  {
+    piece.dsc_in.temperature.coeffs[c] = piece.dsc_out.temperature.coeffs[c] = wb ? wb[c] : 1.0f;
+    if(wb) piece.dsc_in.processed_maximum[c] = piece.dsc_out.processed_maximum[c] = wb[c];
+  }
+  piece.dsc_in.temperature.enabled = wb != NULL;
+  dt_dev_pixelpipe_t pipe;
+  memset(&pipe, 0, sizeof(pipe));
+  pipe.dev = &dev;
+  pipe.type = DT_DEV_PIXELPIPE_EXPORT;
+  pipe.devid = dt_opencl_reserve_device_for_pipe(pipe.type);
+  pipe.opencl_enabled = TRUE;
+  if(pipe.devid < 0) return -2;
+  g_process_cl_calls = 0;
+  g_tile_budget = budget;
+  const int ok = m.process_tiling_cl(&m, &pipe, &piece, in, out, (int)piece.dsc_in.bpp);
+  dt_opencl_finish(pipe.devid);
+  g_tile_budget = 0;
+  dt_opencl_release_device(pipe.devid);
+  if(calls) *calls = g_process_cl_calls;
+  return ok;
+}
+int boundary_run_demosaic_tiled(const float *mosaic, float *out, int w, int h, unsigned filters, int method, size_t budget, int *calls)
+{
+  dt_iop_demosaic_data_t d; /* what commit_params() leaves in piece->data (demosaic.c:1630-1720) */
+  memset(&d, 0, sizeof(d));
+  d.demosaicing_method = (uint32_t)method;
+  return run_module_tiled(M_DEMOSAIC, &d, mosaic, out, w, h, 1, filters, NULL, budget, calls);
+}
+int boundary_run_denoiseprofile_tiled(const float *in, float *out, int w, int h, const dt_hip_denoiseprofile_data_t *hd, size_t budget,
+                                      int *calls)
+{
+  dt_iop_denoiseprofile_data_t d; /* the reference's struct, filled field by field from the test's parameters */
+  memset(&d, 0, sizeof(d));
+  d.radius = hd->radius; d.nbhood = hd->nbhood; d.strength = hd->strength; d.shadows = hd->shadows; d.bias = hd->bias;
+  d.scattering = hd->scattering; d.central_pixel_weight = hd->central_pixel_weight; d.overshooting = hd->overshooting;
+  memcpy(d.a, hd->a, sizeof(d.a));
+  memcpy(d.b, hd->b, sizeof(d.b));
+  d.mode = (dt_iop_denoiseprofile_mode_t)hd->mode;
+  memcpy(d.force, hd->force, sizeof(d.force));
+  d.wb_adaptive_anscombe = hd->wb_adaptive_anscombe;
+  d.fix_anscombe_and_nlmeans_norm = hd->fix_anscombe_and_nlmeans_norm;
+  d.use_new_vst = hd->use_new_vst;
+  d.wavelet_color_mode = (dt_iop_denoiseprofile_wavelet_mode_t)hd->wavelet_color_mode;
+  return run_module_tiled(M_DENOISEPROFILE, &d, in, out, w, h, 4, 0, hd->wb_coeffs, budget, calls);
+}
+/* colorin through pixelpipe_process_on_GPU(): `conv` carries HOST curves (lut_source[c] = 65536 floats or NULL) -- the stub
+ * uploads them through the accessor API as a port would */
+int boundary_run_colorin_gpu(const float *in, float *out, int w, int h, const dt_hip_conversion_t *conv, int *flow, int *calls)
+{
+  if(dt_hip_init() != DT_HIP_SUCCESS) return -1;
+  dt_iop_module_t m;
+  dt_develop_t dev;
+  dt_dev_pixelpipe_iop_t piece;
+  struct dt_colorspaces_conversion_t c;
+  memset(&c, 0, sizeof(c));
+  for(int r = 0; r < 3; r++)
+    for(int k = 0; k < 4; k++)
+    {
+      c.matrix[r][k] = conv->matrix[r][k];
+      c.clip_matrix[r][k] = conv->clip_matrix[r][k];
+    }
+  c.has_clipping = conv->has_clipping;
+  for(int ch = 0; ch < 3; ch++)
+  {
+    c.source_curve[ch] = (const float *)conv->lut_source[ch];
+    for(int k = 0; k < 3; k++) c.source_coeffs[3 * ch + k] = conv->coeffs_source[ch][k];
+  }
+  dt_iop_colorin_data_t d;
+  memset(&d, 0, sizeof(d));
+  d.conversion = &c;
+  d.blue_mapping = conv->blue_mapping;
+  make_module(&m, &dev, M_COLORIN);
+  make_piece(&piece, &m, &d, w, h);
+  dev.image_storage.dsc = piece.dsc_in;
+  dt_dev_pixelpipe_t pipe;
+  memset(&pipe, 0, sizeof(pipe));
+  pipe.dev = &dev;
+  pipe.type = DT_DEV_PIXELPIPE_EXPORT;
+  pipe.devid = dt_opencl_reserve_device_for_pipe(pipe.type);
+  pipe.opencl_enabled = TRUE;
+  if(pipe.devid < 0) return -2;
+  const size_t bytes = (size_t)w * h * 16;
+  dt_pixel_cache_entry_t ein = { 1, (void *)in, bytes, NULL, 0, 0, 0 }, eout = { 2, out, bytes, NULL, 0, 0, 0 };
+  dt_develop_tiling_t tiling;
+  memset(&tiling, 0, sizeof(tiling));
+  m.tiling_callback(&m, &pipe, &piece, &tiling);
+  dt_pixelpipe_flow_t fl = PIXELPIPE_FLOW_NONE;
+  gboolean cache_output = TRUE;
+  g_process_cl_calls = 0;
+  g_tile_budget = 0;
+  const int rc = pixelpipe_process_on_GPU(&pipe, &piece, NULL, &tiling, &fl, &cache_output, &ein, &eout);
+  dt_opencl_finish(pipe.devid);
+  if(eout.cl_mem) dt_opencl_release_mem_object(eout.cl_mem);
+  if(ein.cl_mem) dt_opencl_release_mem_object(ein.cl_mem);
+  dt_opencl_release_device(pipe.devid);
+  if(flow) *flow = (int)fl;
+  if(calls) *calls = g_process_cl_calls;
+  return rc;
 }

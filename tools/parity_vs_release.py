@@ -6,10 +6,12 @@ equals that build bit for bit (tests/).  The reference SHIPS -O3 -ffast-math -ff
 oracle/_ref/libansel_ref_fast.so is that build of the same sources.  This tool measures the distance between the two worlds,
 per module and for the light / full export pipe on a 24 MP frame:
 
-  * per module: the module's input is the STRICT chain's intermediate at that stage (so the figures are per module, not
-    accumulated); device output against the release build's output on the same input -- ULP histogram over the three colour
-    channels (alpha apart), the largest absolute difference, and the same for the strict reference build against the
-    release build (which must be the same histogram: the device IS the strict build);
+  * per module: the module's input is the ORACLE chain's intermediate at that stage (so the figures are per module, not
+    accumulated; the oracle is the strict build's arithmetic with the canonical orders of DESIGN.md section 3 where the
+    reference's own result depends on its thread count -- the RCD scratch columns, the wavelets' sum of detail^2, the
+    bilateral grid's slices); device output against the release build's output on the same input -- ULP histogram over the
+    three colour channels (alpha apart), the largest absolute difference -- , whether the device equals the oracle (it must),
+    and the same histogram for the strict reference build (multi-threaded, as it comes) against the release build;
   * per pipe: the device's exported RGBA u16 against the release build's module-by-module chain -- histogram of |difference|
     in LSB of the 16-bit output.
 
@@ -110,8 +112,8 @@ def main():
     args = ap.parse_args()
     import checkers as ck
     from ansel_amd import filmic, params, pipe, synth
-    strict, fast = ck.ref(), ck.ref(fast=True)
-    if strict is None or fast is None:
+    strict, fast, canon = ck.ref(), ck.ref(fast=True), ck.oracle()
+    if strict is None or fast is None or canon is None:
         raise SystemExit("oracle/_ref/libansel_ref.so / libansel_ref_fast.so missing: make -f oracle/Makefile ref (needs /root/reference)")
     dev = not args.no_device
     lib_mod = None
@@ -130,7 +132,8 @@ def main():
                                        with_nlmeans=True, with_bilat=True)
     raw = synth.bayer_mosaic_tiled(w, h, seed=2)
     res = {"frame": [w, h], "device_in_the_loop": dev,
-           "strict_build": "oracle/_ref/libansel_ref.so: -O2 -fno-fast-math -ffp-contract=off (the parity bar; the device equals it bit for bit)",
+           "oracle": "oracle/liboracle.so: the strict build's arithmetic, canonical orders where the reference depends on its thread count (the parity bar)",
+           "strict_build": "oracle/_ref/libansel_ref.so: -O2 -fno-fast-math -ffp-contract=off, OpenMP as it comes",
            "release_build": "oracle/_ref/libansel_ref_fast.so: -O3 -ffast-math -ffp-contract=fast, OpenMP on %d threads (what the reference ships, "
                             "CMakeLists.txt:239-272)" % (os.cpu_count() or 1),
            "modules": {}, "pipes": {}}
@@ -140,19 +143,22 @@ def main():
     src = raw
     t0 = time.time()
     for hn, dn in zip(host_nodes, dev_nodes):
+        want = cpu_module(canon, "oracle_", hn, src, w, h)
         want_strict = cpu_module(strict, "ref_", hn, src, w, h)
         got_fast = cpu_module(fast, "ref_", hn, src, w, h)
-        got_dev = device_module(pipe, lib_mod, dn, src, w, h) if dev else want_strict
+        got_dev = device_module(pipe, lib_mod, dn, src, w, h) if dev else want
         if hn.op == "export_u16":
             e = {"device_vs_release_lsb": lsb_hist(got_dev, got_fast), "strict_vs_release_lsb": lsb_hist(want_strict, got_fast),
-                 "device_equals_strict": bool(np.array_equal(got_dev, want_strict))}
+                 "device_equals_oracle": bool(np.array_equal(got_dev, want)), "strict_build_equals_oracle": bool(np.array_equal(want_strict, want))}
         else:
             e = {"device_vs_release": stats(got_dev, got_fast), "strict_vs_release": stats(want_strict, got_fast),
-                 "device_equals_strict": bool(np.array_equal(got_dev.view(np.uint32), want_strict.view(np.uint32)))}
+                 "device_equals_oracle": bool(np.array_equal(got_dev.view(np.uint32), want.view(np.uint32))),
+                 # False where the reference is not a function of its input (its threads): RCD, the wavelets, the bilateral grid
+                 "strict_build_equals_oracle": bool(np.array_equal(want_strict.view(np.uint32), want.view(np.uint32)))}
         res["modules"][hn.op] = e
-        print("%-16s device==strict %s  %s" % (hn.op, e["device_equals_strict"], json.dumps(e.get("device_vs_release", e.get("device_vs_release_lsb")))[:200]),
+        print("%-16s device==oracle %s  %s" % (hn.op, e["device_equals_oracle"], json.dumps(e.get("device_vs_release", e.get("device_vs_release_lsb")))[:200]),
               file=sys.stderr, flush=True)
-        src = want_strict
+        src = want
     # ---- per pipe: exported words, device pipe against the release build's chain
     for which in ("light", "full"):
         hn = nodes_of(which, lut.ctypes.data)
@@ -164,6 +170,10 @@ def main():
         for n in hn:
             src = cpu_module(strict, "ref_", n, src, w, h)
         strict_out = src
+        src = raw
+        for n in hn:
+            src = cpu_module(canon, "oracle_", n, src, w, h)
+        canon_out = src
         if dev:
             import torch
             dn = nodes_of(which, d_lut.ptr)
@@ -175,10 +185,11 @@ def main():
             dev_out = d_out.to_numpy((h, w, 4), np.uint16)
             p.close()
         else:
-            dev_out = strict_out
+            dev_out = canon_out
         res["pipes"][which] = {"modules": [n.op for n in hn], "device_vs_release_lsb": lsb_hist(dev_out, fast_out),
                                "strict_vs_release_lsb": lsb_hist(strict_out, fast_out),
-                               "device_equals_strict_chain": bool(np.array_equal(dev_out, strict_out))}
+                               "device_vs_strict_build_lsb": lsb_hist(dev_out, strict_out),
+                               "device_equals_oracle_chain": bool(np.array_equal(dev_out, canon_out))}
         print("pipe %-6s %s" % (which, json.dumps(res["pipes"][which])), file=sys.stderr, flush=True)
     res["seconds"] = round(time.time() - t0, 1)
     print(json.dumps(res, indent=1))
