@@ -50,6 +50,17 @@ int dt_hip_iop_demosaic_process_band(int devid, const dt_hip_piece_t *piece, con
     set_last_error("demosaic: the dual threshold is not a number");
     return DT_HIP_INVALID_ARG;
   }
+  // the detail mask of the dual methods divides by the white-balance coefficients (dual.c:84): zeros -- what a caller that
+  // never filled the field passes -- would make every luminance inf, the mask 1 everywhere and the blend silently the plain
+  // RCD / AMaZE result.  The reference's coefficients are the image's, finite and positive
+  if(dual && d->dual_thrs > 0.0f)
+    for(int c = 0; c < 3; c++)
+      if(!(d->wb_coeffs[c] > 0.0f) || !(d->wb_coeffs[c] <= 3.402823466e38f))
+      {
+        set_last_error("demosaic: the dual methods need the white-balance coefficients of the buffer descriptor (wb_coeffs[%d] = %g)",
+                       c, (double)d->wb_coeffs[c]);
+        return DT_HIP_INVALID_ARG;
+      }
   const bool pass = method == DT_HIP_DEMOSAIC_PASSTHROUGH_MONOCHROME || method == DT_HIP_DEMOSAIC_PASSTHROUGH_COLOR;
   if(band && (dual || pass || method == DT_HIP_DEMOSAIC_VNG4))
   {

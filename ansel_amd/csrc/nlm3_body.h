@@ -216,7 +216,14 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   auto widx = [&](const int wy, const int wx) { return (wy * 2 + (wx & 1)) * WPH + (wx >> 1); };
 
   const int w = tid >> 6, lane = tid & 63;
-  const int var = a.variant; // 0; timing experiments (ANSEL_NLM2_VARIANT): 16 / 32 / 64 / 128 switch A1 / A2 / B / C off (wrong results)
+  // 0; timing experiments (ANSEL_NLM2_VARIANT, measuring builds): 16 / 32 / 64 / 128 switch A1 / A2 / B / C off (wrong results).
+  // A constant in the product's device build: the switches' uniform branches would cut a stage into basic blocks that the
+  // scheduler cannot interleave
+#if defined(__HIPCC__) && !defined(ANSEL_HIP_MEASURING)
+  constexpr int var = 0;
+#else
+  const int var = a.variant;
+#endif
   // ---------------------------------------------------------------------------------------------------------------------
   if(FUSED ? (w >= 2 && w <= 7) : (w == 3 || (w >= 4 && w <= 7) || w == 10))
   {

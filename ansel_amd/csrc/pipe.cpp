@@ -1057,12 +1057,17 @@ int dt_hip_peer_selftest(const int *devids, int n)
       }
       (void)hipGetLastError();
     }
-  // a ring of copies: device k's pattern travels to device k + 1 behind an event of device k's stream
+  // every ORDERED pair (a, b): a's pattern travels to b behind an event of a's stream -- dt_hip_pipe_process_bands() pulls halo
+  // rows from both neighbours, the bilateral grid from the last band to every band, the wavelets' sums from every band to every
+  // band -- once as a linear peer copy and once as the strided hipMemcpy2DAsync(hipMemcpyDefault) the sums' all-gather uses
   const size_t N = 1 << 16;
   std::vector<unsigned> pattern(N), back(N);
-  for(int k = 0; k + 1 < n || (n == 1 && k == 0); k++)
+  for(int pair = 0; pair < (n == 1 ? 1 : n * n); pair++)
   {
-    const int a = devids[k], b = devids[(k + 1) % n];
+    const int ka = n == 1 ? 0 : pair / n, kb = n == 1 ? 0 : pair % n;
+    if(n > 1 && ka == kb) continue;
+    const int k = pair;
+    const int a = devids[ka], b = devids[kb];
     for(size_t i = 0; i < N; i++) pattern[i] = (unsigned)(i * 2654435761u + (unsigned)k);
     unsigned *da = (unsigned *)dt_hip_alloc_device_buffer(a, N * 4), *db = (unsigned *)dt_hip_alloc_device_buffer(b, N * 4);
     int err = (da && db) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
@@ -1083,6 +1088,18 @@ int dt_hip_peer_selftest(const int *devids, int n)
              || hipStreamSynchronize(sb) != hipSuccess))
         err = DT_HIP_DEFAULT_ERROR;
       if(err == DT_HIP_SUCCESS && memcmp(back.data(), pattern.data(), N * 4) != 0) err = DT_HIP_DEFAULT_ERROR;
+      // the strided form: 64 rows of 256 words out of rows of 1024, kind Default (the runtime routes between the two memories)
+      if(err == DT_HIP_SUCCESS
+         && (hipMemsetAsync(db, 0, N * 4, sb) != hipSuccess
+             || hipMemcpy2DAsync(db + 128, 1024 * 4, da + 128, 1024 * 4, 256 * 4, 64, hipMemcpyDefault, sb) != hipSuccess
+             || hipMemcpyAsync(back.data(), db, N * 4, hipMemcpyDeviceToHost, sb) != hipSuccess
+             || hipStreamSynchronize(sb) != hipSuccess))
+        err = DT_HIP_DEFAULT_ERROR;
+      for(size_t i = 0; err == DT_HIP_SUCCESS && i < N; i++)
+      {
+        const size_t col = i % 1024;
+        if(back[i] != ((col >= 128 && col < 384) ? pattern[i] : 0u)) err = DT_HIP_DEFAULT_ERROR;
+      }
       (void)hipStreamSynchronize(sa);
     }
     if(ev) (void)hipEventDestroy(ev);
@@ -1166,9 +1183,12 @@ int dt_hip_pipe_process_bands(dt_hip_pipe_t *const *pipes, int n, const dt_hip_b
       gang.fail();
     };
     auto give_up = [&]() {
+      // the failure is published (fail() before every give_up() that follows an error of this band) and the own stream drained
+      // BEFORE the band's buffers go back to the pool: a healthy neighbour may have peer copies in flight that read them --
+      // what they copy is discarded, but it must still be this band's memory -- and a fault stays attributed to this band
+      (void)hipStreamSynchronize(s);
       if(walking) dt_hip_pipe_band_abort(pipe, &st[k]);
       walking = false;
-      (void)hipStreamSynchronize(s);
       gang.finished(k);
     };
     auto await = [&](const int j, const int pt) -> bool {

@@ -247,6 +247,17 @@ def test_dual_demosaic(w, h, roi_xy, base, geq, smooth, thrs):
         assert not np.array_equal(got, plain)
 
 
+def test_dual_demosaic_needs_the_white_balance_coefficients():
+    """a caller that never filled wb_coeffs (zeros) would get the plain RCD result under the dual method's name: refused"""
+    from ansel_amd import lib
+    w, h = 300, 200
+    img = _normalised_cfa(w, h, seed=9)
+    piece = abi.Piece.make(w, h, filters=synth.FILTERS_RGGB, channels=1, processed_maximum=synth.WB_COEFFS)
+    d = abi.DemosaicData(0, 0, abi.DT_HIP_DEMOSAIC_RCD | abi.DT_HIP_DEMOSAIC_DUAL, 0.0, 0.04, 0.2)
+    with pytest.raises(lib.AnselHipError, match="white-balance"):
+        hc.run_hip("dt_hip_iop_demosaic_process", piece, d, img, (h, w, 4))
+
+
 def test_dual_demosaic_in_a_pipe():
     """the executor takes the dual method as a demosaic node of its own (never fused, never on row bands)"""
     import torch
