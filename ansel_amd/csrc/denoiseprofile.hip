@@ -435,14 +435,24 @@ __device__ __forceinline__ double wave_sum4_halving(const double q0, const doubl
 // MULT: the dilation at compile time (1 .. 64: the seven scales of a frame), so that the 25 taps of a lane are one base
 // address per tap row + immediates (the counters had 11 % of this kernel's VALU instructions as integer address
 // arithmetic); 0: read `mult_arg`
-template <bool PRE, int MULT>
+// ALPHA0: the fourth channel of every sample this launch reads is +0 -- what the Y0U0V0 transform leaves there (it sets the
+// channel to 0.0f), and what a decomposition leaves in its coarse plane when its input's was: the 25 weighted taps of the
+// channel are then +0 (a weight is finite and >= 0), the coarse value is +0 / wgt -- +0 unless the weights sum to 0 or NaN, which a
+// pixel that is not finite makes them do -- and the detail +0 - that.  The launch leaves the channel's 50 multiply-adds and its
+// division out (the division is made where a wave holds such a pixel) and RAISES `alpha_flag` when a coarse alpha it writes is
+// not +0: the next scale's ALPHA0 launch (flag_sense 1) then leaves at once and the four-channel launch behind it (flag_sense
+// 2) runs instead.  flag_sense 0: run whatever the flag says (the first scale: its input is +0 by construction).
+template <bool PRE, int MULT, bool ALPHA0>
 __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                           float4 *__restrict__ detail, double *__restrict__ partial,
                                                           const int width, const int height, const int mult_arg,
                                                           const float inv_sigma2, const int nseg, const int in_row0,
                                                           const int in_rows, const int strip, const int strips_per_class,
-                                                          const vst_args fa)
+                                                          const vst_args fa, unsigned *__restrict__ alpha_flag, const int flag_sense)
 {
+  if(flag_sense == 1 && *alpha_flag) return;
+  if(flag_sense == 2 && !*alpha_flag) return;
+  unsigned alpha_bits = 0; // ALPHA0: the coarse alphas this lane wrote
   const int mult = MULT ? MULT : mult_arg;
 #define DN_FETCH(p) (PRE ? dn_precondition_pixel((p), fa) : (p))
   extern __shared__ float4 ring[]; // [DN_RING][256 + 4 * mult]
@@ -542,7 +552,7 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
           sum[0] += w * p2.x;
           sum[1] += w * p2.y;
           sum[2] += w * p2.z;
-          sum[3] += w * p2.w;
+          if(!ALPHA0) sum[3] += w * p2.w;
         }
         // five reads in flight, not twenty-five: the next row's reads stay behind the sums of this one
         asm volatile("" : "+v"(wgt), "+v"(sum[0]), "+v"(sum[1]), "+v"(sum[2]), "+v"(sum[3]) : : "memory");
@@ -555,7 +565,15 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
 #pragma unroll
       for(int c = 0; c < 4; c++)
       {
-        c4[c] = sum[c] / wgt;
+        if(ALPHA0 && c == 3)
+        {
+          // +0 / wgt: +0 for a positive sum of weights (at most 1: no infinity), the division's own result where a lane of
+          // the wave holds another (a uniform branch)
+          c4[3] = __builtin_amdgcn_ballot_w64(!(wgt > 0.0f)) == 0ull ? 0.0f : 0.0f / wgt;
+          alpha_bits |= __float_as_uint(c4[3]);
+        }
+        else
+          c4[c] = sum[c] / wgt;
         d4[c] = pin[c] - c4[c];
         sq[c] = (double)(d4[c] * d4[c]);
       }
@@ -578,13 +596,16 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
     const double seg = ((runs[pr][0][c] + runs[pr][1][c]) + runs[pr][2][c]) + runs[pr][3][c];
     partial[4 * ((size_t)(r_first + (nrows - 1) * mult) * nseg + bx) + c] = seg;
   }
+  if(ALPHA0 && alpha_flag && __builtin_amdgcn_ballot_w64(alpha_bits != 0) != 0ull && lane == 0) atomicOr(alpha_flag, 1u);
 }
 
 // one a-trous step of `height` rows (see dn_decompose for in_row0 / in_rows)
 static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, float4 *detail, double *partial, const int width,
                              const int height, const int mult, const float inv_sigma2, const int nseg, const int in_row0,
-                             const int in_rows, const vst_args *pre = nullptr)
+                             const int in_rows, const vst_args *pre = nullptr, unsigned *alpha_flag = nullptr)
 {
+  // alpha_flag != nullptr: the caller's input alpha is +0 by construction at its first scale (the Y0U0V0 transform, vst 2) and
+  // the flag carries "still +0" from scale to scale: the three-channel launch first, the four-channel one behind it
 #ifdef ANSEL_HIP_MEASURING
   static const bool per_row = getenv("ANSEL_HIP_DN_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
   if(per_row && !pre)
@@ -603,9 +624,22 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
   const size_t lds = (size_t)DN_RING * (256 + 4 * mult) * sizeof(float4);
   vst_args none;
   memset(&none, 0, sizeof(none));
-#define DN_LAUNCH(PRE_, M_, FA_)                                                                                                  \
-  dn_decompose_strip<PRE_, M_><<<grid, 256, lds, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0, \
-                                                       in_rows, strip, strips_per_class, FA_)
+#define DN_LAUNCH_(PRE_, M_, A0_, FA_, SENSE_)                                                                                          \
+  dn_decompose_strip<PRE_, M_, A0_><<<grid, 256, lds, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0, \
+                                                            in_rows, strip, strips_per_class, FA_, alpha_flag, SENSE_)
+#define DN_LAUNCH(PRE_, M_, FA_)                  \
+  do                                              \
+  {                                               \
+    if(alpha_flag && (PRE_))                      \
+      DN_LAUNCH_(PRE_, M_, true, FA_, 0);         \
+    else if(alpha_flag)                           \
+    {                                             \
+      DN_LAUNCH_(PRE_, M_, true, FA_, 1);         \
+      DN_LAUNCH_(PRE_, M_, false, FA_, 2);        \
+    }                                             \
+    else                                          \
+      DN_LAUNCH_(PRE_, M_, false, FA_, 0);        \
+  } while(0)
   if(pre)
   {
     if(mult == 1) DN_LAUNCH(true, 1, *pre);
@@ -624,6 +658,7 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
       default: DN_LAUNCH(false, 0, none); break;
     }
 #undef DN_LAUNCH
+#undef DN_LAUNCH_
 }
 
 struct thr_args
@@ -1290,6 +1325,14 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
   forward_args(s, fa);
   const float4 *b1 = (const float4 *)dev_in;
   float4 *b2 = tmp, *b3 = precond;
+  // the Y0U0V0 transform sets the fourth channel to 0.0f: the decompositions leave it out for as long as it stays +0
+  unsigned *alpha_flag = nullptr;
+  if(err == DT_HIP_SUCCESS && s.vst == 2)
+  {
+    alpha_flag = (unsigned *)dt_hip_alloc_device_buffer(devid, sizeof(unsigned));
+    if(!alpha_flag) err = DT_HIP_SYSMEM_ALLOCATION;
+    else if(hipMemsetAsync(alpha_flag, 0, sizeof(unsigned), st) != hipSuccess) err = DT_HIP_DEFAULT_ERROR;
+  }
   for(int scale = 0; scale < s.max_scale && err == DT_HIP_SUCCESS; scale++)
   {
     const int mult = 1 << scale;
@@ -1298,7 +1341,7 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
     {
       launch_scope ls(devid, "dn_decompose");
       launch_decompose(st, b1, b2, det[scale], partial + (size_t)scale * n_partial * 4, w, h, mult,
-                       1.0f / (sigma_band * sigma_band), nseg, 0, h, scale == 0 ? &fa : nullptr);
+                       1.0f / (sigma_band * sigma_band), nseg, 0, h, scale == 0 ? &fa : nullptr, alpha_flag);
     }
     err = check_launch("denoiseprofile band");
     b1 = b2; // the coarse plane just written is the next scale's input; the other plane takes the next coarse
@@ -1345,6 +1388,7 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
   if(partial) dt_hip_release_mem_object(partial);
   if(thrs) dt_hip_release_mem_object(thrs);
   if(accs) dt_hip_release_mem_object(accs);
+  if(alpha_flag) dt_hip_release_mem_object(alpha_flag);
   return err;
 }
 

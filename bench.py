@@ -287,7 +287,7 @@ def verify_output(out16, raw_host, width, height, with_filmic, which):
 
 
 PMC_SUMMARIES = {  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of THIS configuration, newest first
-    "full": ("r03_pmc_hbm_bytes_100MP_full.json",),
+    "full": ("r04_pmc_hbm_bytes_100MP_full.json", "r03_pmc_hbm_bytes_100MP_full.json"),
     "light": ("r03_pmc_hbm_bytes_100MP_light_fused.json", "r02_pmc_hbm_bytes_100MP_light_fused.json"),
 }
 
@@ -331,7 +331,7 @@ def traffic_of(table, tag):
 # What binds each kernel, and the peak it is priced against.  HBM: 8 TB/s.  VALU: one wave64 instruction per
 # SIMD every 2 cycles for full-rate binary32, 4 for binary64, 8 for the quarter-rate transcendental unit
 # (MI355X_MICROARCH.md "Per-instruction cycle constants") -> the kernel's issue-cycle total from its instruction mix
-# (profiles/r03_isa_mix.json, tools/valu_model.py arch) over 1024 SIMDs at 2.4 GHz is its floor.
+# (profiles/r04_isa_mix.json, tools/valu_model.py arch) over 1024 SIMDs at 2.4 GHz is its floor.
 KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu", "rcd_tiles": "valu+lds",
                 "nlm_chunks": "lds+valu", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
                 "bilat_splat": "latency (one lane per grid node walks its pixels in order)", "bilat_slice": "hbm", "bilat_blur": "latency",
@@ -339,20 +339,27 @@ KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu"
                 "lab_to_rgb": "hbm"}
 
 
-def valu_floor_ms(tag, mpix):
-    """VALU issue floor of `tag` on a frame of `mpix` megapixels from the COMMITTED instruction-mix table
-    (profiles/r03_isa_mix.json: rocprofv3 SQ counters of this bench priced at the ARCHITECTURAL issue rate of a SIMD-32 --
-    2 cycles per wave64 binary32 / integer instruction, 4 binary64, 8 transcendental -- at the 2.4 GHz peak clock,
-    tools/valu_model.py ... arch: a lower bound whatever the sustained clock); None when the table lacks the kernel"""
+def valu_floor_ms(tag, mpix, table="r04_isa_mix.json"):
+    """VALU issue floor of `tag` on a frame of `mpix` megapixels from a COMMITTED instruction-mix table: the rocprofv3 SQ
+    counters of this bench (profiles/r04_pmc_sq_100MP_full.json) priced per instruction class -- r04_isa_mix.json at the
+    ARCHITECTURAL issue rate of a SIMD-32 (2 cycles per wave64 binary32 / integer instruction, 4 binary64, 8 transcendental;
+    tools/valu_model.py ... arch: a lower bound whatever the sustained clock), r04_isa_mix_measured_rates.json at the rates
+    tools/valu_microbench.hip measures on this chip at full occupancy (add / mul 2.5 - 2.7, fma 3.0, conversions 4.2,
+    transcendentals 8.2; what the counters do not classify at the cheapest full-rate cost) -- at the 2.4 GHz peak clock.  A tag
+    that launches several instantiations of a kernel (the wavelets: one per dilation) takes their mean.  None when the table
+    lacks the kernel"""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_isa_mix.json")))
+        mix = json.load(open(os.path.join(ROOT, "profiles", table)))
     except (OSError, ValueError):
         return None
-    alias = {"dn_decompose": "dn_decompose_strip", "nlm_chunks": "nlm_chunks_v2", "diffuse_decompose": "bspline_decompose_strip",
-             "diffuse_pde": "diffuse_pde_strip", "dn_finish_chain": "dn_finish_chain", "nlm_chunks_v3": "nlm_chunks_v3"}
-    alias["nlm_chunks"] = "nlm_chunks_v3"
+    alias = {"dn_decompose": "dn_decompose_strip", "nlm_chunks": "nlm_chunks_v3", "diffuse_decompose": "bspline_decompose_strip",
+             "diffuse_pde": "diffuse_pde_strip", "dn_finish_chain": "dn_finish_chain"}
     kernels = mix.get("kernels", {})
-    k = kernels.get(tag) or kernels.get(tag.replace("_u16", "")) or kernels.get(alias.get(tag, ""))
+    base = alias.get(tag, tag.replace("_u16", ""))
+    inst = [v for k, v in kernels.items() if k.startswith(base + "<") and "issue_floor_ms_per_mpix" in v]
+    if inst:
+        return sum(v["issue_floor_ms_per_mpix"] for v in inst) / len(inst) * mpix
+    k = kernels.get(tag) or kernels.get(base)
     if not k or "issue_floor_ms_per_mpix" not in k:
         return None
     return k["issue_floor_ms_per_mpix"] * mpix
@@ -858,6 +865,9 @@ def main():
             if floor is not None:
                 e["valu_issue_floor_ms"] = round(floor, 4)
                 e["valu_frac"] = round(floor / v["ms_avg"], 4)
+            floor_m = valu_floor_ms(k, mpix_mine, "r04_isa_mix_measured_rates.json")
+            if floor_m is not None:  # the same instruction mix priced at the issue rates measured on this chip
+                e["valu_frac_at_measured_rates"] = round(floor_m / v["ms_avg"], 4)
             per_kernel[k] = e
         dominant = max((k for k in kernels if tag_bpp.get(k)), key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])
         dom = kernels[dominant]
@@ -921,6 +931,7 @@ def main():
                 # ... and what actually binds this launch (config.kernel_bounds has every kernel of the step)
                 "binds": per_kernel.get(dominant, {}).get("bound"),
                 "valu_frac": per_kernel.get(dominant, {}).get("valu_frac"),
+                "valu_frac_at_measured_rates": per_kernel.get(dominant, {}).get("valu_frac_at_measured_rates"),
                 # the whole step: sum of algorithmic bytes / step time / peak (= config.pipe_hbm_frac)
                 "pipe_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "pipe_frac_of_measured_copy": None if not ceiling else round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / ceiling["copy_GBs"], 4),
