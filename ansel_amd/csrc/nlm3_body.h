@@ -225,11 +225,19 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int var = a.variant;
 #endif
   // ---------------------------------------------------------------------------------------------------------------------
-  if(FUSED ? (w >= 2 && w <= 7) : (w == 3 || (w >= 4 && w <= 7) || w == 10))
+  // which wave plays what (waves w, w + 4, w + 8, w + 12 share a SIMD).  Four roles: layout 0 is round 3's -- A2 A2 B A1 | A1 A1 A1 A1 |
+  // C C A1 C | C C C C --, layout 1 (measuring builds, ANSEL_NLM2_VARIANT bit 4096) deals the VALU instructions evenly over the SIMDs
+  // instead of the VALU + LDS instructions: A2 A2 B A1 | A1 A1 A1 C | A1 A1 C C | C C C C
+  const bool lay1 = !FUSED && (var & 4096);
+  const int a1_index = FUSED ? ((w >= 2 && w <= 7) ? w - 2 : -1)
+                             : (lay1 ? ((w >= 3 && w <= 6) ? w - 3 : ((w == 8 || w == 9) ? w - 4 : -1))
+                                     : (w == 3 ? 0 : ((w >= 4 && w <= 7) ? w - 3 : (w == 10 ? 5 : -1))));
+  const int c_index = FUSED ? w - 8 : (lay1 ? (w == 7 ? 0 : w - 9) : (w == 8 ? 0 : (w == 9 ? 1 : w - 9)));
+  if(a1_index >= 0)
   {
     // ---- A1: the terms of the column recurrence (nlmeans_core.c:437-488) for table rows 1.., and the five squared
     //      differences the first table row sums (init_column_sums(), :208-262)
-    const int ai = FUSED ? w - 2 : (w == 3 ? 0 : (w == 10 ? 5 : w - 3));
+    const int ai = a1_index;
     const int ncp = (cw + 2 * P + 1) / 2; // (an odd last slot has a partner nobody reads)
     const int nseg = 2;                   // fits(); a narrower border chunk keeps the layout and repeats items
     const int m0 = (ch - 2) / S + 1;
@@ -526,7 +534,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // step j of a row sits in slot (i + j) % (NPXL + 1); the slot the incoming pixel takes was last read two steps ago.
     constexpr int NR = NPXL + 1;
     static_assert(NR % 2 == 0, "the distortions alternate between two register sets with the ring's period");
-    const int ci = FUSED ? w - 8 : (w == 8 ? 0 : (w == 9 ? 1 : w - 9));
+    const int ci = c_index;
     // a wave holds 8 chunk rows x 8 lanes; its lanes 0-31 take the even rows, 32-63 the odd ones: the nine distortions a
     // lane reads sit 9 words apart within a row and 84 apart between rows, and four rows TWO apart put the 32 lanes of an
     // LDS pass on 32 different banks (four consecutive rows: 2-way conflicts on every read)

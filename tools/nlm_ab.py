@@ -52,7 +52,7 @@ def main():
     fused = {"ANSEL_HIP_NLM_FUSED": "1"}
     res = {}
     res["11648x2184 (72 x 56 chunks)"] = run(l, 11648, 2184, {
-        "v3": {}, "v4 fused": fused,
+        "v3": {}, "v3 roles dealt by VALU load (layout 1)": {"ANSEL_NLM2_VARIANT": "4096"}, "v3 again": {}, "v4 fused": fused,
         "v4 no A1": dict(fused, ANSEL_NLM2_VARIANT="16"), "v4 no A2": dict(fused, ANSEL_NLM2_VARIANT="32"),
         "v4 no row chain": dict(fused, ANSEL_NLM2_VARIANT="64"), "v4 no C": dict(fused, ANSEL_NLM2_VARIANT="128"),
         "v4 only barriers": dict(fused, ANSEL_NLM2_VARIANT=str(16 + 32 + 64 + 128)),
