@@ -67,7 +67,15 @@ struct vst_args
 __device__ __forceinline__ float chan(const float4 &v, const int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 // precondition(), precondition_v2(), precondition_Y0U0V0(): denoiseprofile.c:852-870, :916-933, :1021-1051
-__device__ __forceinline__ float4 dn_precondition_pixel(const float4 px, const vst_args &a)
+// t3_of_zero (Y0U0V0 only; pass have_t3 = false otherwise): the transformed fourth channel of a pixel whose alpha is +0 -- the same
+// expression on the same operands, formed once per thread: a wave whose pixels all carry +0 there (what a pipe hands this module)
+// takes it instead of a fourth powf per pixel (a uniform branch)
+__device__ __forceinline__ float dn_vst_y0u0v0_alpha(const float alpha, const vst_args &a)
+{
+  return ansel_math::powf_exact(max_first(alpha + a.b, 0.0f), a.expon[3]) * a.scale[3];
+}
+__device__ __forceinline__ float4 dn_precondition_pixel(const float4 px, const vst_args &a, const float t3_of_zero = 0.0f,
+                                                        const bool have_t3 = false)
 {
   float o[4];
   if(a.vst == 0)
@@ -89,7 +97,9 @@ __device__ __forceinline__ float4 dn_precondition_pixel(const float4 px, const v
   {
     float t[4];
 #pragma unroll
-    for(int c = 0; c < 4; c++) t[c] = ansel_math::powf_exact(max_first(chan(px, c) + a.b, 0.0f), a.expon[c]) * a.scale[c];
+    for(int c = 0; c < 3; c++) t[c] = ansel_math::powf_exact(max_first(chan(px, c) + a.b, 0.0f), a.expon[c]) * a.scale[c];
+    if(have_t3 && __builtin_amdgcn_ballot_w64(__float_as_uint(px.w) != 0u) == 0ull) t[3] = t3_of_zero;
+    else t[3] = dn_vst_y0u0v0_alpha(px.w, a);
 #pragma unroll
     for(int c = 0; c < 3; c++)
     {
@@ -442,19 +452,38 @@ __device__ __forceinline__ double wave_sum4_halving(const double q0, const doubl
 // division out (the division is made where a wave holds such a pixel) and RAISES `alpha_flag` when a coarse alpha it writes is
 // not +0: the next scale's ALPHA0 launch (flag_sense 1) then leaves at once and the four-channel launch behind it (flag_sense
 // 2) runs instead.  flag_sense 0: run whatever the flag says (the first scale: its input is +0 by construction).
+// (the kernel's arguments as the kernarg segment lays them out: where `fa` sits, for kernarg_at())
+struct dn_strip_kernargs
+{
+  const float4 *in;
+  float4 *coarse, *detail;
+  double *partial;
+  int width, height, mult_arg;
+  float inv_sigma2;
+  int nseg, in_row0, in_rows, strip, strips_per_class;
+  vst_args fa;
+  unsigned *alpha_flag;
+  int flag_sense;
+};
 template <bool PRE, int MULT, bool ALPHA0>
 __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                           float4 *__restrict__ detail, double *__restrict__ partial,
                                                           const int width, const int height, const int mult_arg,
                                                           const float inv_sigma2, const int nseg, const int in_row0,
                                                           const int in_rows, const int strip, const int strips_per_class,
-                                                          const vst_args fa, unsigned *__restrict__ alpha_flag, const int flag_sense)
+                                                          const vst_args fa_by_value, unsigned *__restrict__ alpha_flag, const int flag_sense)
 {
+  // the transform's ~40 parameters are read from the kernarg segment where a fetch uses them: as a by-value argument they
+  // sat in scalar registers for the whole row loop and 53 of them were spilled to vector lanes (hip_common.h kernarg_at())
+  const vst_args &fa = kernarg_at<vst_args>((int)offsetof(dn_strip_kernargs, fa));
+  (void)fa_by_value;
   if(flag_sense == 1 && *alpha_flag) return;
   if(flag_sense == 2 && !*alpha_flag) return;
   unsigned alpha_bits = 0; // ALPHA0: the coarse alphas this lane wrote
   const int mult = MULT ? MULT : mult_arg;
-#define DN_FETCH(p) (PRE ? dn_precondition_pixel((p), fa) : (p))
+  const bool have_t3 = PRE && fa.vst == 2;
+  const float t3_of_zero = have_t3 ? dn_vst_y0u0v0_alpha(0.0f, fa) : 0.0f;
+#define DN_FETCH(p) (PRE ? dn_precondition_pixel((p), fa, t3_of_zero, have_t3) : (p))
   extern __shared__ float4 ring[]; // [DN_RING][256 + 4 * mult]
   __shared__ double runs[2][4][4];
   const int bx = blockIdx.x;

@@ -864,9 +864,13 @@ __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2_timed(const float4 
 // radius 2, chunks of at most 56 rows; same launch shape, border chunks first with the pipelined body
 template <int NPXL, int MSEG>
 __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                             const nlm_args a, const int2 *__restrict__ patches,
+                                                             const nlm_args a_by_value, const int2 *__restrict__ patches,
                                                              const int *__restrict__ order, const int n_border, const int ndx)
 {
+  // the launch's ~30 parameters are read from the kernarg segment where they are used (hip_common.h kernarg_at(): behind the two
+  // pointers), not held in scalar registers through the offsets' loop
+  const nlm_args &a = kernarg_at<nlm_args>(16);
+  (void)a_by_value;
   extern __shared__ float lds[];
   const int chunk = order[blockIdx.x];
   nlm2_device_env env;
@@ -889,9 +893,11 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__res
 // chunks of up to 64 rows (the 45 MP and 60 MP frames' grids)
 template <int NPXL, int MSEG>
 __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                             const nlm_args a, const int2 *__restrict__ patches,
+                                                             const nlm_args a_by_value, const int2 *__restrict__ patches,
                                                              const int *__restrict__ order, const int n_border, const int ndx)
 {
+  const nlm_args &a = kernarg_at<nlm_args>(16); // (see nlm_chunks_v3)
+  (void)a_by_value;
   extern __shared__ float lds[];
   const int chunk = order[blockIdx.x];
   nlm2_device_env env;
