@@ -30,6 +30,10 @@ namespace ansel
 {
 // diffuse_bspline.hip: one a-trous B-spline analysis in -> (hf, lf) at dilation mult
 int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, float4 *lf, int w, int h, int mult);
+#ifdef ANSEL_HIP_MEASURING
+// ... two scales (dilations mult and 2 mult, mult 1 or 4) in one pass: in -> low1, low2 (diffuse_bspline.hip; no faster)
+int bspline_launch_decompose2(int devid, hipStream_t s, const float4 *in, float4 *low1, float4 *low2, int w, int h, int mult);
+#endif
 }
 using namespace ansel;
 
@@ -727,6 +731,17 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
     }
     for(int s = 0; s < scales && err == DT_HIP_SUCCESS; s++)
     {
+#ifdef ANSEL_HIP_MEASURING
+      // the chain keeps every low-pass plane: two scales in one pass where the pair kernel has the dilation (1 + 2, 4 + 8)
+      static const bool pairs = measuring_env("ANSEL_HIP_BSPLINE_PAIRS") != nullptr;
+      if(chain && pairs && s + 1 < scales && (s == 0 || s == 2))
+      {
+        err = bspline_launch_decompose2(devid, st, level, hf[s], hf[s + 1], w, h, 1 << s);
+        s++;
+        level = residual = hf[s];
+        continue;
+      }
+#endif
       float4 *low = chain ? hf[s] : lf[s % 2];
       err = bspline_launch_decompose(devid, st, level, chain ? nullptr : hf[s], low, w, h, 1 << s);
       level = low;

@@ -207,10 +207,188 @@ __global__ __launch_bounds__(256) void bspline_decompose_strip(const float4 *__r
 #undef BS_ROW
 }
 
+
+#ifdef ANSEL_HIP_MEASURING
+// MEASURING BUILD ONLY -- equal in time to the two single-scale launches it replaces (profiles/r04_negative_results.txt,
+// item 6): either form WRITES at 2.5 - 2.6 TB/s, and the pair saves reads only.
+// TWO consecutive scales in one pass (round 4): low1 = blur_m(in), low2 = blur_2m(low1).  The analysis is bound by its bytes
+// (4.8 TB/s moved: the device's copy rate), and run scale by scale it reads every low-pass plane back that it has just written:
+// 16 + 16 bytes per pixel and scale.  Here a workgroup owns 256 adjacent columns for up to `strip` rows of one dilation class
+// of the COARSER scale (rows c, c + 2m, c + 4m, ...), one lane per column of the 256 + 12m the first scale's vertical pass
+// needs.  Per output row of low2:
+//   X  the lane's five samples of `in` (rows 2m apart from the last step's: three stay, two new ones were fetched a step
+//      ahead) -> vertical taps of low1's next row into LDS (VA); the lane's five samples of low1 (the five rows low2's row
+//      taps: 2m apart, the same class -- produced by this very lane, in registers) -> vertical taps of low2's row (VC)
+//   -- one barrier (VA and VC alternate between two buffers) --
+//   Y  horizontal taps of VA: low1's next row at the lane's column (256 + 8m of them), kept and, where the strip owns the
+//      row, written; horizontal taps of VC: low2's row, written.
+// in -> (low1, low2): 16 bytes read and 32 written per pixel instead of 32 + 32.  Same taps, same order, same clamping
+// (bspline.h:118-149: rows and columns clamp to the frame's, whatever the dilation), same binary32 values.  A row of low1
+// whose (virtual) index lies outside the frame is the row at the clamped index: formed from scratch (five direct fetches) and
+// not written -- the strip that owns row 0 / height - 1 writes it.
+__device__ __forceinline__ float4 bs_row_taps(const float4 *__restrict__ V, const int col, const int step, const int origin,
+                                              const int width)
+{
+  float4 t[5];
+#pragma unroll
+  for(int j = 0; j < 5; j++) t[j] = V[clampi(col + (j - 2) * step, 0, width - 1) - origin];
+  return tap5(t[0], t[1], t[2], t[3], t[4]);
+}
+
+template <int M, int AHEAD>
+__global__ __launch_bounds__(320) void bspline_decompose2_strip(const float4 *__restrict__ in, float4 *__restrict__ low1,
+                                                                float4 *__restrict__ low2, const int width, const int height,
+                                                                const int strip, const int strips_per_class)
+{
+  constexpr int M2 = 2 * M, WA = 256 + 12 * M, WB = 256 + 8 * M;
+  static_assert(WA <= 320, "a lane a column");
+  __shared__ float4 VA[2][WA], VC[2][WB];
+  const int c0 = (int)blockIdx.x * 256;
+  const int cls = blockIdx.y / strips_per_class, k0s = (blockIdx.y - cls * strips_per_class) * strip;
+  const int n_cls = (height - cls + M2 - 1) / M2; // rows of this class of the coarser scale
+  if(k0s >= n_cls) return;
+  const int nrows = (strip < n_cls - k0s) ? strip : n_cls - k0s;
+  const int r_first = cls + k0s * M2;
+  const int tid = threadIdx.x;
+  const int ca = c0 - 6 * M + tid, cb = c0 - 4 * M + tid;
+  const bool on_a = tid < WA && ca >= 0 && ca < width;                 // a column of the first vertical pass
+  const bool on_b = tid < WB && cb >= 0 && cb < width;                 // ... of low1's row / the second vertical pass
+  const bool on_c = on_b && tid >= 4 * M && tid < 4 * M + 256;          // ... of the 256 this workgroup writes
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 a = z, b = z, c = z, d = z, e = z; // `in` at rows sigma - 2m .. sigma + 2m (clamped)
+  // ... and the two new rows (sigma + m, sigma + 2m) of the next AHEAD steps, in flight: a step is a few hundred cycles, a
+  // fetch from memory several thousand -- one step ahead and four workgroups a CU left the analysis waiting (3.9 TB/s)
+  float4 nd[AHEAD], ne[AHEAD];
+  float4 r0 = z, r1 = z, r2 = z, r3 = z, r4 = z;            // low1 at the five rows low2's current row taps
+  bool rolling = false;
+#define BS_AT(r) in[(size_t)clampi((r), 0, height - 1) * width + ca]
+  const int ca_safe = clampi(ca, 0, width - 1);
+#define BS_SAFE(r) in[(size_t)clampi((r), 0, height - 1) * width + ca_safe]
+#pragma unroll
+  for(int j = 0; j < AHEAD; j++)
+  {
+    const int sj = r_first + (j - 2) * M2;
+    nd[j] = BS_SAFE(sj + M);
+    ne[j] = BS_SAFE(sj + 2 * M);
+  }
+  // entry q = low1's row at the clamped index of sigma_q = r_first + (q - 2) 2m; output row k taps entries k .. k + 4.
+  // One step; J is the queue slot of its pair of rows, refilled at once for the step AHEAD later (the loop below is unrolled
+  // AHEAD times so that the slots are fixed registers: shifting a queue would be a use of every fetch in flight)
+#define BS_STEP(kk, J) \
+  { \
+    const int k = (kk); \
+    const int q = k + 5, sig = r_first + (q - 2) * M2, buf = q & 1; \
+    const bool produce = q <= nrows + 3; \
+    if(produce) \
+    { \
+      if(sig >= 0 && sig < height) \
+      { \
+        if(rolling) \
+        { \
+          a = c; \
+          b = d; \
+          c = e; \
+        } \
+        else \
+        { \
+          if(on_a) \
+          { \
+            a = BS_AT(sig - 2 * M); \
+            b = BS_AT(sig - M); \
+            c = BS_AT(sig); \
+          } \
+          rolling = true; \
+        } \
+        d = nd[J]; \
+        e = ne[J]; \
+        if(on_a) VA[buf][tid] = tap5(a, b, c, d, e); \
+      } \
+      else \
+      { \
+        /* outside the frame: the row at the clamped index, from scratch (the window of the rows inside starts afresh) */ \
+        rolling = false; \
+        const int tau = clampi(sig, 0, height - 1); \
+        if(on_a) VA[buf][tid] = tap5(BS_AT(tau - 2 * M), BS_AT(tau - M), BS_AT(tau), BS_AT(tau + M), BS_AT(tau + 2 * M)); \
+      } \
+    } \
+    /* every lane, every step (rows and columns clamp): a condition around a fetch makes the compiler wait for it at once */ \
+    nd[J] = BS_SAFE(sig + AHEAD * M2 + M); \
+    ne[J] = BS_SAFE(sig + AHEAD * M2 + 2 * M); \
+    if(k >= 0 && on_b) VC[buf][tid] = tap5(r0, r1, r2, r3, r4); \
+    __syncthreads(); \
+    if(k >= 0 && on_c) low2[(size_t)(r_first + k * M2) * width + cb] = bs_row_taps(VC[buf], cb, M2, c0 - 4 * M, width); \
+    if(produce) \
+    { \
+      r0 = r1; \
+      r1 = r2; \
+      r2 = r3; \
+      r3 = r4; \
+      if(on_b) \
+      { \
+        r4 = bs_row_taps(VA[buf], cb, M, c0 - 6 * M, width); \
+        if(on_c && q >= 2 && q - 2 < nrows) low1[(size_t)sig * width + cb] = r4; \
+      } \
+    } \
+  }
+  for(int k0 = -5; k0 < nrows; k0 += AHEAD)
+  {
+    BS_STEP(k0, 0)
+    if constexpr(AHEAD > 1)
+      if(k0 + 1 < nrows) BS_STEP(k0 + 1, 1)
+    if constexpr(AHEAD > 2)
+      if(k0 + 2 < nrows) BS_STEP(k0 + 2, 2)
+    if constexpr(AHEAD > 3)
+      if(k0 + 3 < nrows) BS_STEP(k0 + 3, 3)
+  }
+#undef BS_STEP
+#undef BS_AT
+#undef BS_SAFE
+}
+#endif // ANSEL_HIP_MEASURING
+
 } // namespace
 
 namespace ansel
 {
+#ifdef ANSEL_HIP_MEASURING
+// two scales at once (dilations mult and 2 mult; mult 1 or 4): in -> low1, low2.  DT_HIP_INVALID_ARG for another dilation
+int bspline_launch_decompose2(int devid, hipStream_t s, const float4 *in, float4 *low1, float4 *low2, int w, int h, int mult)
+{
+  (void)devid;
+  if(mult != 1 && mult != 4) return DT_HIP_INVALID_ARG;
+  const int m2 = 2 * mult;
+  const int classes = h < m2 ? h : m2, per_class = (h + m2 - 1) / m2;
+  const int gx = (w + 255) / 256;
+  // four rows of low1 a strip are formed twice (its neighbours' too): long strips
+  int strip = 64;
+  while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
+  const int spc = (per_class + strip - 1) / strip;
+  const dim3 grid(gx, classes * spc);
+  launch_scope ls(devid, "diffuse_decompose");
+  // how far ahead the fetches run
+  static const char *const ahead_env = measuring_env("ANSEL_HIP_BSPLINE_AHEAD");
+  const int ahead = ahead_env ? atoi(ahead_env) : 1;
+#define BS_PAIR(MM) \
+  switch(ahead) \
+  { \
+    case 2: bspline_decompose2_strip<MM, 2><<<grid, 320, 0, s>>>(in, low1, low2, w, h, strip, spc); break; \
+    case 4: bspline_decompose2_strip<MM, 4><<<grid, 320, 0, s>>>(in, low1, low2, w, h, strip, spc); break; \
+    case 3: bspline_decompose2_strip<MM, 3><<<grid, 320, 0, s>>>(in, low1, low2, w, h, strip, spc); break; \
+    default: bspline_decompose2_strip<MM, 1><<<grid, 320, 0, s>>>(in, low1, low2, w, h, strip, spc); break; \
+  }
+  if(mult == 1)
+  {
+    BS_PAIR(1);
+  }
+  else
+  {
+    BS_PAIR(4);
+  }
+#undef BS_PAIR
+  return check_launch("diffuse_decompose");
+}
+#endif // ANSEL_HIP_MEASURING
+
 int bspline_launch_decompose(int devid, hipStream_t s, const float4 *in, float4 *hf, float4 *lf, int w, int h, int mult)
 {
   const int steps = (w + mult - 1) / mult; // steps of the dilation across a row
