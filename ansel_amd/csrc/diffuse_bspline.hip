@@ -210,9 +210,9 @@ __global__ __launch_bounds__(256) void bspline_decompose_strip(const float4 *__r
 
 #ifdef ANSEL_HIP_MEASURING
 // MEASURING BUILD ONLY -- equal in time to the two single-scale launches it replaces (profiles/r04_negative_results.txt,
-// item 6): either form WRITES at 2.5 - 2.6 TB/s, and the pair saves reads only.
-// TWO consecutive scales in one pass (round 4): low1 = blur_m(in), low2 = blur_2m(low1).  The analysis is bound by its bytes
-// (4.8 TB/s moved: the device's copy rate), and run scale by scale it reads every low-pass plane back that it has just written:
+// item 6): either form writes 2.5 - 2.6 TB/s, as a copy does, and the pair saves reads only.
+// TWO consecutive scales in one pass (round 4): low1 = blur_m(in), low2 = blur_2m(low1).  The analysis moves its bytes at
+// the device's copy rate (4.8 - 5.1 TB/s), and run scale by scale it reads every low-pass plane back that it has just written:
 // 16 + 16 bytes per pixel and scale.  Here a workgroup owns 256 adjacent columns for up to `strip` rows of one dilation class
 // of the COARSER scale (rows c, c + 2m, c + 4m, ...), one lane per column of the 256 + 12m the first scale's vertical pass
 // needs.  Per output row of low2:

@@ -538,6 +538,11 @@ struct batch_slot_t
   dt_hip_mem_t d_in, d_out;
   hipEvent_t up, done, down;
   bool in_flight;
+  // with a writer: the frame's place in the stream, its host buffer, and what became of it (guarded by the batch's mutex)
+  long seq;
+  void *host_out;
+  bool written;
+  int write_err;
 };
 
 struct dt_hip_batch_t
@@ -547,7 +552,45 @@ struct dt_hip_batch_t
   hipStream_t s_up, s_down;
   std::vector<batch_slot_t> slots;
   int next;
+  // the fourth leg: the format's write_image() of frame n on a host thread of its own while frames n + 1 ... are on the
+  // device (imageio_core.c:965 runs it after the pipe, serially).  The thread takes the slots in submission order
+  dt_hip_batch_writer_t writer;
+  void *writer_user;
+  long submitted;
+  std::thread writer_thread;
+  std::mutex mtx;
+  std::condition_variable cv_job, cv_done;
+  std::vector<int> jobs; // slots whose download is enqueued, oldest first
+  bool quit;
 };
+
+namespace
+{
+void batch_writer_loop(dt_hip_batch_t *b)
+{
+  (void)make_current(b->pipe->devid);
+  for(;;)
+  {
+    int k;
+    {
+      std::unique_lock<std::mutex> lk(b->mtx);
+      b->cv_job.wait(lk, [&] { return b->quit || !b->jobs.empty(); });
+      if(b->jobs.empty()) return; // quit, and nothing left to write
+      k = b->jobs.front();
+      b->jobs.erase(b->jobs.begin());
+    }
+    batch_slot_t &sl = b->slots[k];
+    int err = hipEventSynchronize(sl.down) == hipSuccess ? DT_HIP_SUCCESS : DT_HIP_DEFAULT_ERROR;
+    if(err == DT_HIP_SUCCESS && b->writer(b->writer_user, sl.seq, sl.host_out, b->out_bytes) != 0) err = DT_HIP_WRITER_FAILED;
+    {
+      std::lock_guard<std::mutex> lk(b->mtx);
+      sl.write_err = err;
+      sl.written = true;
+    }
+    b->cv_done.notify_all();
+  }
+}
+} // namespace
 
 dt_hip_batch_t *dt_hip_batch_new(dt_hip_pipe_t *pipe, int depth, size_t in_bytes, size_t out_bytes)
 {
@@ -557,6 +600,10 @@ dt_hip_batch_t *dt_hip_batch_new(dt_hip_pipe_t *pipe, int depth, size_t in_bytes
   b->in_bytes = in_bytes;
   b->out_bytes = out_bytes;
   b->next = 0;
+  b->writer = nullptr;
+  b->writer_user = nullptr;
+  b->submitted = 0;
+  b->quit = false;
   b->s_up = b->s_down = nullptr;
   // streams and events belong to the device that is current when they are made: the pipe's, not whatever the
   // calling thread used last (hipEventRecord rejects an event of another device than its stream's)
@@ -587,6 +634,15 @@ void dt_hip_batch_free(dt_hip_batch_t *b)
   if(!b) return;
   make_current(b->pipe->devid);
   dt_hip_batch_drain(b);
+  if(b->writer_thread.joinable())
+  {
+    {
+      std::lock_guard<std::mutex> lk(b->mtx);
+      b->quit = true;
+    }
+    b->cv_job.notify_all();
+    b->writer_thread.join();
+  }
   // a submit that failed half way leaves its upload (or download) enqueued without marking the slot in flight:
   // the copy streams must be idle before the slot buffers go back to the pool
   if(b->s_up) (void)hipStreamSynchronize(b->s_up);
@@ -609,8 +665,29 @@ int dt_hip_batch_wait(dt_hip_batch_t *b, int slot)
   if(!b || slot < 0 || slot >= (int)b->slots.size()) return DT_HIP_INVALID_ARG;
   batch_slot_t &sl = b->slots[slot];
   if(!sl.in_flight) return DT_HIP_SUCCESS;
+  if(b->writer)
+  {
+    // the frame is done when its writer has returned: only then may the caller reuse host_out
+    std::unique_lock<std::mutex> lk(b->mtx);
+    b->cv_done.wait(lk, [&] { return sl.written; });
+    sl.in_flight = false;
+    if(sl.write_err == DT_HIP_WRITER_FAILED) set_last_error("dt_hip_batch_wait: the writer refused frame %ld", sl.seq);
+    return sl.write_err;
+  }
   ANSEL_HIP_CHECK(hipEventSynchronize(sl.down));
   sl.in_flight = false;
+  return DT_HIP_SUCCESS;
+}
+
+int dt_hip_batch_set_writer(dt_hip_batch_t *b, dt_hip_batch_writer_t writer, void *user)
+{
+  if(!b) return DT_HIP_INVALID_ARG;
+  // between frames only: no slot may be in flight
+  const int e = dt_hip_batch_drain(b);
+  if(e != DT_HIP_SUCCESS) return e;
+  b->writer = writer;
+  b->writer_user = user;
+  if(writer && !b->writer_thread.joinable()) b->writer_thread = std::thread(batch_writer_loop, b);
   return DT_HIP_SUCCESS;
 }
 
@@ -645,6 +722,19 @@ int dt_hip_batch_submit(dt_hip_batch_t *b, const void *host_in, void *host_out)
   ANSEL_HIP_CHECK(hipMemcpyAsync(host_out, sl.d_out, b->out_bytes, hipMemcpyDeviceToHost, b->s_down));
   ANSEL_HIP_CHECK(hipEventRecord(sl.down, b->s_down));
   sl.in_flight = true;
+  if(b->writer)
+  {
+    {
+      std::lock_guard<std::mutex> lk(b->mtx);
+      sl.seq = b->submitted;
+      sl.host_out = host_out;
+      sl.written = false;
+      sl.write_err = DT_HIP_SUCCESS;
+      b->jobs.push_back(k);
+    }
+    b->cv_job.notify_one();
+  }
+  b->submitted++;
   b->next = (k + 1) % (int)b->slots.size();
   return k;
 }

@@ -151,6 +151,7 @@ def load():
         "dt_hip_batch_submit": (i, [vp, vp, vp]),
         "dt_hip_batch_wait": (i, [vp, i]),
         "dt_hip_batch_drain": (i, [vp]),
+        "dt_hip_batch_set_writer": (i, [vp, vp, vp]),
         "dt_hip_plan_bands": (i, [i, i, i, i, P(abi.Band)]),
         "dt_hip_band_halo_rows": (i, [C.c_char_p, P(abi.Piece), vp, sz]),
         "dt_hip_pipe_band_begin": (i, [vp, P(abi.Band), vp, P(abi.BandState)]),

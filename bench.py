@@ -367,14 +367,17 @@ def valu_floor_ms(tag, mpix, table="r04_isa_mix.json"):
 
 def measured_ceiling(torch, dev, gib=1.0, reps=8):
     """what a streaming kernel reaches on THIS device in THIS run (beside the 8 TB/s of the data sheet): a
-    device-to-device copy (read + write) and a triad a = b + s c (two reads + a write) over `gib` GiB planes, HIP events
-    on the current stream, best of `reps`"""
+    device-to-device copy (read + write), a triad a = b + s c (two reads + a write), a fill (write) and a sum (read) over
+    `gib` GiB planes, HIP events on the current stream, best of `reps`"""
     n = int(gib * (1 << 30)) // 4
     a = torch.empty(n, dtype=torch.float32, device=dev)
     b = torch.ones(n, dtype=torch.float32, device=dev)
     c = torch.ones(n, dtype=torch.float32, device=dev)
     out = {}
-    for name, fn, streams in (("copy", lambda: a.copy_(b), 2), ("triad", lambda: torch.add(b, c, alpha=2.0, out=a), 3)):
+    # fill (writes only) and sum (reads only) tell which direction a kernel is short of: the B-spline analysis and the wavelet
+    # levels write as many bytes as they read
+    for name, fn, streams in (("copy", lambda: a.copy_(b), 2), ("triad", lambda: torch.add(b, c, alpha=2.0, out=a), 3),
+                              ("fill", lambda: a.fill_(1.5), 1), ("sum", lambda: b.sum(), 1)):
         fn()
         best = None
         for _ in range(reps):
@@ -769,6 +772,7 @@ def main():
     host_ms = None
     host_overlap_ms = None
     host_rows_ms = None
+    host_rows_writer_ms = None
     if rank == 0 and world == 1 and args.mode == "batch" and not args.no_host_legs and args.pipe == "light":
         nb_in, nb_out = raw_host.nbytes, npix * 8
         pin_in, pin_out = l.dt_hip_alloc_host_pinned(nb_in), l.dt_hip_alloc_host_pinned(nb_out)
@@ -814,6 +818,26 @@ def main():
                     assert rc >= 0, l.dt_hip_last_error()
                 l.dt_hip_batch_drain(batch)
                 host_rows_ms = (time.perf_counter() - t1) / nfr * 1e3
+                # ... and with the fourth leg: a writer (dt_hip_batch_set_writer -- the format's write_image(), imageio_core.c:965)
+                # that copies the frame's scanlines out of the pinned buffer, as an uncompressed TIFF's write() does, on the
+                # batch's writer thread while the next frames are on the device
+                sink = np.empty(npix * 6, np.uint8)
+                WRITER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_size_t)
+
+                def write_image(user, seq, host_out, nbytes):
+                    C.memmove(sink.ctypes.data, host_out, nbytes)
+                    return 0
+
+                cb = WRITER(write_image)
+                if l.dt_hip_batch_set_writer(batch, cb, None) == 0:
+                    for k in range(nfr + 3):
+                        if k == 3:
+                            l.dt_hip_batch_drain(batch)
+                            t1 = time.perf_counter()
+                        rc = l.dt_hip_batch_submit(batch, pin_in, pin_out)
+                        assert rc >= 0, l.dt_hip_last_error()
+                    assert l.dt_hip_batch_drain(batch) == 0
+                    host_rows_writer_ms = (time.perf_counter() - t1) / nfr * 1e3
                 l.dt_hip_batch_free(batch)
             rows_exec.close()
         l.dt_hip_free_host_pinned(pin_in)
@@ -910,6 +934,7 @@ def main():
                 "host_to_host_ms": None if host_ms is None else round(host_ms, 3),
                 "host_to_host_overlapped_ms": None if host_overlap_ms is None else round(host_overlap_ms, 3),
                 "host_to_host_overlapped_rgb_rows_ms": None if host_rows_ms is None else round(host_rows_ms, 3),
+                "host_to_host_overlapped_rgb_rows_and_writer_ms": None if host_rows_writer_ms is None else round(host_rows_writer_ms, 3),
                 "host": {"nproc": os.cpu_count(), "cpu_quota": cgroup_cpu_quota(), "affinity": len(os.sched_getaffinity(0))},
             },
             "roofline": {

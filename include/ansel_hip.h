@@ -36,6 +36,7 @@ extern "C" {
 #define DT_HIP_DEFAULT_ERROR (-999)
 #define DT_HIP_SYSMEM_ALLOCATION (-998)
 #define DT_HIP_INVALID_ARG (-997)
+#define DT_HIP_WRITER_FAILED (-996) /* a batch's writer callback returned non-zero (dt_hip_batch_set_writer) */
 #define DT_HIP_MAX_ERRORS 5 /* src/common/opencl.h:50 */
 
 /* opaque device allocation, stands for cl_mem */
@@ -735,6 +736,16 @@ void dt_hip_batch_free(dt_hip_batch_t *batch);
 int dt_hip_batch_submit(dt_hip_batch_t *batch, const void *host_in, void *host_out);
 int dt_hip_batch_wait(dt_hip_batch_t *batch, int slot);
 int dt_hip_batch_drain(dt_hip_batch_t *batch);
+/* The fourth leg -- the file encoder.  dt_imageio_export_with_flags() calls format->write_image() on the exported buffer
+ * after the pipe has run (src/imageio/imageio_core.c:965), frame after frame on the exporting thread; with a writer set
+ * the batch calls it for frame n on a host thread of its own as soon as the frame's download has landed, while frames
+ * n + 1 ... are uploaded, processed and downloaded.  One writer thread: frames are written in submission order, `seq`
+ * counts them from 0 since dt_hip_batch_new().  A frame's slot is done (dt_hip_batch_wait) when its writer has returned --
+ * host_out is the writer's until then -- and a writer that returns non-zero makes that wait (and a drain, and the submit
+ * that needs the slot) return DT_HIP_WRITER_FAILED; the frames behind it are still written.  Set or cleared (NULL)
+ * between frames: the call drains the batch first. */
+typedef int (*dt_hip_batch_writer_t)(void *user, long seq, void *host_out, size_t bytes);
+int dt_hip_batch_set_writer(dt_hip_batch_t *batch, dt_hip_batch_writer_t writer, void *user);
 
 /* ---- 3b. one frame over several devices: row bands ---------------------------------------- */
 /* Replaces default_process_tiling_cl() / _default_process_tiling_cl_ptp() (src/develop/tiling.c:842,
