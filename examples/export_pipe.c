@@ -10,6 +10,9 @@
  *
  * bands > 1: the same frame cut into row bands and walked by dt_hip_pipe_process_bands() -- one pipe per band, band k on
  * device k % (number of devices) -- which must print the same hash as the unsplit run.
+ * bands < 0: a batch export of -bands frames (the same frame every time) through dt_hip_batch_*: upload, kernels, download
+ * and the "encoder" -- a writer callback that hashes the frame, where format->write_image() would compress and write it
+ * (src/imageio/imageio_core.c:965) -- of consecutive frames overlapped.  Prints written=N and the hash every frame had.
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdint.h>
@@ -45,11 +48,33 @@ static dt_hip_piece_t piece_of(int w, int h, uint32_t filters, uint32_t channels
   return p;
 }
 
+/* the batch's writer: called on the batch's writer thread, frame after frame in submission order */
+typedef struct
+{
+  long frames;
+  uint64_t first_hash;
+  int all_equal;
+} encoder_t;
+
+static int write_image(void *user, long seq, void *host_out, size_t bytes)
+{
+  encoder_t *e = (encoder_t *)user;
+  uint64_t fnv = 0xcbf29ce484222325ull;
+  const unsigned char *b = (const unsigned char *)host_out;
+  for(size_t k = 0; k < bytes; k++) fnv = (fnv ^ b[k]) * 0x100000001b3ull;
+  if(seq != e->frames) return 1; /* out of order */
+  if(seq == 0) e->first_hash = fnv;
+  else if(fnv != e->first_hash) e->all_equal = 0;
+  e->frames++;
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   const int w = argc > 2 ? atoi(argv[1]) : 1504, h = argc > 2 ? atoi(argv[2]) : 1000;
-  const int nbands = argc > 3 ? atoi(argv[3]) : 1;
-  if(nbands < 1 || nbands > 16) return 1;
+  const int arg3 = argc > 3 ? atoi(argv[3]) : 1;
+  const int nframes = arg3 < 0 ? -arg3 : 0, nbands = arg3 < 0 ? 1 : arg3;
+  if(nbands < 1 || nbands > 16 || nframes > 64) return 1;
   const uint32_t RGGB = 0x94949494u;
   const float wb[4] = { 2.1f, 1.0f, 1.6f, 1.0f }, ones[4] = { 1.f, 1.f, 1.f, 1.f };
 
@@ -97,7 +122,43 @@ int main(int argc, char **argv)
 
   struct timespec t0, t1;
   double best = 1e30;
-  if(nbands == 1)
+  if(nframes)
+  {
+    /* three slots; the pinned buffers go round with them: submit() hands a slot out again only when its frame's writer
+     * has returned, so slot k's buffers are free to refill as soon as the wait for it comes back */
+    enum { DEPTH = 3 };
+    encoder_t enc = { 0, 0, 1 };
+    uint16_t *pin_in[DEPTH], *pin_out[DEPTH];
+    for(int k = 0; k < DEPTH; k++)
+    {
+      pin_in[k] = (uint16_t *)dt_hip_alloc_host_pinned(npix * sizeof(uint16_t));
+      pin_out[k] = (uint16_t *)dt_hip_alloc_host_pinned(npix * 4 * sizeof(uint16_t));
+      if(!pin_in[k] || !pin_out[k]) return 1;
+    }
+    dt_hip_batch_t *batch = dt_hip_batch_new(pipe, DEPTH, npix * sizeof(uint16_t), npix * 4 * sizeof(uint16_t));
+    if(!batch) return 1;
+    CHECK(dt_hip_batch_set_writer(batch, write_image, &enc));
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for(int f = 0; f < nframes; f++)
+    {
+      const int k = f % DEPTH;
+      CHECK(dt_hip_batch_wait(batch, k));                   /* frame f - DEPTH has been written */
+      memcpy(pin_in[k], raw, npix * sizeof(uint16_t));      /* "decode" frame f */
+      if(dt_hip_batch_submit(batch, pin_in[k], pin_out[k]) != k) return 1;
+    }
+    CHECK(dt_hip_batch_drain(batch));
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    best = ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / nframes;
+    memcpy(out, pin_out[(nframes - 1) % DEPTH], npix * 4 * sizeof(uint16_t));
+    dt_hip_batch_free(batch);
+    for(int k = 0; k < DEPTH; k++)
+    {
+      dt_hip_free_host_pinned(pin_in[k]);
+      dt_hip_free_host_pinned(pin_out[k]);
+    }
+    printf("written=%ld all_equal=%d ", enc.frames, enc.all_equal);
+  }
+  else if(nbands == 1)
   {
     for(int pass = 0; pass < 3; pass++)
     {

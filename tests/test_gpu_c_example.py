@@ -71,3 +71,15 @@ def test_c_example_in_row_bands_exports_the_same_bytes(bands):
     f0 = dict(f.split("=") for f in whole.stdout.split() if "=" in f)
     f1 = dict(f.split("=") for f in split.stdout.split() if "=" in f)
     assert f1["bands"] == str(bands) and f0["fnv1a"] == f1["fnv1a"]
+
+
+def test_c_example_batch_with_a_writer_exports_the_same_bytes_every_frame():
+    """examples/export_pipe W H -N: N frames through dt_hip_batch_* with the encoder as a writer callback, from plain C"""
+    exe = os.path.join(ROOT, "examples", "export_pipe")
+    w, h = 400, 300
+    whole = subprocess.run([exe, str(w), str(h)], capture_output=True, text=True, timeout=120)
+    batch = subprocess.run([exe, str(w), str(h), "-7"], capture_output=True, text=True, timeout=120)
+    assert whole.returncode == 0 and batch.returncode == 0, whole.stderr + batch.stderr
+    f0 = dict(f.split("=") for f in whole.stdout.split() if "=" in f)
+    f1 = dict(f.split("=") for f in batch.stdout.split() if "=" in f)
+    assert f1["written"] == "7" and f1["all_equal"] == "1" and f0["fnv1a"] == f1["fnv1a"]
