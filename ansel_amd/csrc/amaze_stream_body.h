@@ -576,7 +576,8 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
     env.sync();
     env.stamp(7);
 
-    // ---- phase 8: area interpolation of the weight in flagged regions, :850-890.  Upper half: diagonal R/B estimates, :986-1107
+    // ---- phase 8: area interpolation of the weight in flagged regions, :850-890 (the lower half of the threads, a site each: few sites
+    //      are flagged); then, on all of them, the diagonal R/B estimates, :986-1107
     FOR_RB(L_INT)
     {
       if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8) && LDB(P_NY2, rr, h))
@@ -604,72 +605,65 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
         ST(P_HVWT, rr, h, hcdvar / (vcdvar + hcdvar));
       }
     }
-    FOR_RB2(L_RB)
+    // the diagonal estimates, two lanes a site: lane 2 k takes site k's nw - se diagonal ("m"), lane 2 k + 1 its ne - sw one ("p") --
+    // the reference's two halves (:986-1107) are one expression on different neighbours and planes -- and they trade the
+    // two variances for the weight by a lane swap.  a: the neighbour towards se / ne, b: towards nw / sw
     {
-      float pw = 0.f, vp = 0.f, vm = 0.f;
-      if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8))
+      const int _k = tid >> 1, half = tid & 1;
+      const int rr = s * R - L_RB + _k / TSH, h = _k % TSH;
+      const int q = rr >= 0 ? (fct(rr, 2, filters) & 1) : 0, cc = q + 2 * h;
+      if(rr >= 0 && rr < TS)
       {
-        const float ge0 = 0.13719494435797422f, ge1 = 0.05640252782101291f;
-        const float c = LD(P_CFA, rr, cc);
-        const float cse1 = LD(P_CFA, rr + 1, cc + 1), cse2 = LD(P_CFA, rr + 2, cc + 2);
-        const float cnw1 = LD(P_CFA, rr - 1, cc - 1), cnw2 = LD(P_CFA, rr - 2, cc - 2);
-        const float cne1 = LD(P_CFA, rr - 1, cc + 1), cne2 = LD(P_CFA, rr - 2, cc + 2);
-        const float csw1 = LD(P_CFA, rr + 1, cc - 1), csw2 = LD(P_CFA, rr + 2, cc - 2);
-        const float crse = xmul2f(cse1) / (EPS + c + (cse2));
-        const float crnw = xmul2f(cnw1) / (EPS + c + (cnw2));
-        const float crne = xmul2f(cne1) / (EPS + c + (cne2));
-        const float crsw = xmul2f(csw1) / (EPS + c + (csw2));
-        const float rbse = fabsf(1.f - crse) < ARTHRESH ? c * crse : (cse1) + xdiv2f(c - cse2);
-        const float rbnw = fabsf(1.f - crnw) < ARTHRESH ? c * crnw : (cnw1) + xdiv2f(c - cnw2);
-        const float rbne = fabsf(1.f - crne) < ARTHRESH ? c * crne : (cne1) + xdiv2f(c - cne2);
-        const float rbsw = fabsf(1.f - crsw) < ARTHRESH ? c * crsw : (csw1) + xdiv2f(c - csw2);
-#define HH(P, dr, dc) LD(P, rr + (dr), (cc + (dc)) >> 1)
-        const float wtse = EPS + HH(P_DELM, 0, 0) + HH(P_DELM, 1, 1) + HH(P_DELM, 2, 2);
-        const float wtnw = EPS + HH(P_DELM, 0, 0) + HH(P_DELM, -1, -1) + HH(P_DELM, -2, -2);
-        const float wtne = EPS + HH(P_DELP, 0, 0) + HH(P_DELP, -1, 1) + HH(P_DELP, -2, 2);
-        const float wtsw = EPS + HH(P_DELP, 0, 0) + HH(P_DELP, 1, -1) + HH(P_DELP, 2, -2);
-        vm = (wtse * rbnw + wtnw * rbse) / (wtse + wtnw);
-        vp = (wtne * rbsw + wtsw * rbne) / (wtne + wtsw);
-        const float rbvarm
-            = EPSSQ + (ge0 * (HH(P_DSQM, -1, 0) + HH(P_DSQM, 0, -1) + HH(P_DSQM, 0, 1) + HH(P_DSQM, 1, 0))
-                       + ge1 * (HH(P_DSQM, -2, -1) + HH(P_DSQM, -2, 1) + HH(P_DSQM, -1, -2) + HH(P_DSQM, -1, 2)
-                                + HH(P_DSQM, 1, -2) + HH(P_DSQM, 1, 2) + HH(P_DSQM, 2, -1) + HH(P_DSQM, 2, 1)));
-        pw = rbvarm / ((EPSSQ + (ge0 * (HH(P_DSQP, -1, 0) + HH(P_DSQP, 0, -1) + HH(P_DSQP, 0, 1) + HH(P_DSQP, 1, 0))
-                                 + ge1 * (HH(P_DSQP, -2, -1) + HH(P_DSQP, -2, 1) + HH(P_DSQP, -1, -2) + HH(P_DSQP, -1, 2)
-                                          + HH(P_DSQP, 1, -2) + HH(P_DSQP, 1, 2) + HH(P_DSQP, 2, -1) + HH(P_DSQP, 2, 1))))
-                       + rbvarm);
-#undef HH
-        if(vp < c)
+        float pw = 0.f, v = 0.f;
+        if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8))
         {
-          if(xmul2f(vp) < c)
-            vp = ulim(vp, csw1, cne1);
-          else
+          const float ge0 = 0.13719494435797422f, ge1 = 0.05640252782101291f;
+          const int dra = half ? -1 : 1; // a: one row down (se) or up (ne), one column right; b: the opposite site
+          static_assert(P_DELP::W == P_DELM::W && P_DELP::D == P_DELM::D && P_DSQP::W == P_DSQM::W && P_DSQP::D == P_DSQM::D,
+                        "one index for the planes of both diagonals");
+          const int pdel = half ? P_DELP::OFF - P_DELM::OFF : 0, pdsq = half ? P_DSQP::OFF - P_DSQM::OFF : 0;
+          const float c = LD(P_CFA, rr, cc);
+          const float ca1 = LD(P_CFA, rr + dra, cc + 1), ca2 = LD(P_CFA, rr + 2 * dra, cc + 2);
+          const float cb1 = LD(P_CFA, rr - dra, cc - 1), cb2 = LD(P_CFA, rr - 2 * dra, cc - 2);
+          const float cra = xmul2f(ca1) / (EPS + c + (ca2));
+          const float crb = xmul2f(cb1) / (EPS + c + (cb2));
+          const float rba = fabsf(1.f - cra) < ARTHRESH ? c * cra : (ca1) + xdiv2f(c - ca2);
+          const float rbb = fabsf(1.f - crb) < ARTHRESH ? c * crb : (cb1) + xdiv2f(c - cb2);
+#define HD(dr, dc) env.ldf(P_DELM::idx(rr + (dr), (cc + (dc)) >> 1) + pdel, rr + (dr))
+#define HS(dr, dc) env.ldf(P_DSQM::idx(rr + (dr), (cc + (dc)) >> 1) + pdsq, rr + (dr))
+          const float d0 = HD(0, 0);
+          const float wta = EPS + d0 + HD(dra, 1) + HD(2 * dra, 2);
+          const float wtb = EPS + d0 + HD(-dra, -1) + HD(-2 * dra, -2);
+          v = (wta * rbb + wtb * rba) / (wta + wtb);
+          const float rbvar
+              = EPSSQ + (ge0 * (HS(-1, 0) + HS(0, -1) + HS(0, 1) + HS(1, 0))
+                         + ge1 * (HS(-2, -1) + HS(-2, 1) + HS(-1, -2) + HS(-1, 2) + HS(1, -2) + HS(1, 2) + HS(2, -1) + HS(2, 1)));
+#undef HD
+#undef HS
+          const float rbvar_other = env.swap1(rbvar);
+          // (the m lane's: rbvarm / (rbvarp + rbvarm); the p lane's quotient is not used)
+          pw = rbvar / (rbvar_other + rbvar);
+          if(v < c)
           {
-            const float pwt = xmul2f(c - vp) / (EPS + vp + c);
-            vp = pwt * vp + (1.f - pwt) * ulim(vp, csw1, cne1);
+            if(xmul2f(v) < c)
+              v = ulim(v, cb1, ca1);
+            else
+            {
+              const float wt = xmul2f(c - v) / (EPS + v + c);
+              v = wt * v + (1.f - wt) * ulim(v, cb1, ca1);
+            }
           }
+          if(v > clip_pt) v = ulim(v, cb1, ca1);
         }
-        if(vm < c)
         {
-          if(xmul2f(vm) < c)
-            vm = ulim(vm, cnw1, cse1);
-          else
-          {
-            const float mwt = xmul2f(c - vm) / (EPS + vm + c);
-            vm = mwt * vm + (1.f - mwt) * ulim(vm, cnw1, cse1);
-          }
+          // (three planes whose depth is no power of two: the slot of the step's first row on the scalar unit, this thread's row
+          // from there; + 70, a multiple of both depths, keeps the row of the first steps non-negative)
+          const int jr = rr - (s * R - L_RB);
+          if(!half) env.stf(P_PMWT::at(P_PMWT::step(P_PMWT::slot(s * R - L_RB + 70), jr), h), rr, pw);
+          const int sr = P_RBP::step(P_RBP::slot(s * R - L_RB + 70), jr);
+          static_assert(P_RBP::W == P_RBM::W && P_RBP::D == P_RBM::D, "one index for both estimates");
+          env.stf(P_RBM::at(sr, h) + (half ? P_RBP::OFF - P_RBM::OFF : 0), rr, v);
         }
-        if(vp > clip_pt) vp = ulim(vp, csw1, cne1);
-        if(vm > clip_pt) vm = ulim(vm, cnw1, cse1);
-      }
-      {
-        // (three planes whose depth is no power of two: the slot of the step's first row on the scalar unit, this thread's row
-        // from there; + 70, a multiple of both depths, keeps the row of the first steps non-negative)
-        const int jr = rr - (s * R - L_RB);
-        env.stf(P_PMWT::at(P_PMWT::step(P_PMWT::slot(s * R - L_RB + 70), jr), h), rr, pw);
-        const int sr = P_RBP::step(P_RBP::slot(s * R - L_RB + 70), jr);
-        env.stf(P_RBP::at(sr, h), rr, vp);
-        env.stf(P_RBM::at(sr, h), rr, vm);
       }
     }
     env.sync();
@@ -830,74 +824,79 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
 
     // ---- phase 11: S8 refine flagged regions with the curvature of green, :923-956; then S11 where the diagonal estimate discriminates
     //      better, green from R + B, :1129-1236 (it overrides S8 at a site that takes both)
-    FOR_RB(L_S8)
+    //      Two lanes a site: the heavy part of S11 is the same expression along the column and along the row (:1150-1222), so
+    //      lane 2 k walks site k's column, lane 2 k + 1 its row -- one instruction stream on different operands -- and the two
+    //      trade their estimates by a lane swap; S8's two curvature sums likewise.  All ten waves work, none idles
     {
-      if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8) && LDB(P_NY2, rr, h))
+      const int _k = tid >> 1, half = tid & 1;
+      const int rr = s * R - L_S8 + _k / TSH, h = _k % TSH;
+      const int q = rr >= 0 ? (fct(rr, 2, filters) & 1) : 0, cc = q + 2 * h;
+      if(rr >= 0 && rr < TS)
       {
-        const float q0 = 0.169917f, q1 = 0.108947f, q2 = 0.069855f, q3 = 0.0287182f;
-#define QUINC(P)                                                                                                         \
-  (EPSSQ + (q0 * LD(P, rr, h) + q1 * (LD(P, rr - 1, (cc - 1) >> 1) + LD(P, rr - 1, (cc + 1) >> 1) + LD(P, rr + 1, (cc - 1) >> 1) + LD(P, rr + 1, (cc + 1) >> 1)) \
-            + q2 * (LD(P, rr - 2, h) + LD(P, rr, h - 1) + LD(P, rr, h + 1) + LD(P, rr + 2, h))                                                                    \
-            + q3 * (LD(P, rr - 2, h - 1) + LD(P, rr - 2, h + 1) + LD(P, rr + 2, h - 1) + LD(P, rr + 2, h + 1))))
-        const float gvarh = QUINC(P_GH);
-        const float gvarv = QUINC(P_GV);
-#undef QUINC
-        const float dg = (LD(P_HCDH, rr, h) * gvarv + LD(P_VCDH, rr, h) * gvarh) / (gvarv + gvarh);
-        ST(P_DGO, rr, h, dg);
-        ST(P_GREEN, rr, h, LD(P_CFA, rr, cc) + dg);
-      }
-      if(IN_(rr, 12, rr1 - 12) && IN_(cc, 12, cc1 - 12))
-      {
-        const float pm = LD(P_PMWT, rr, h), hv = LD(P_HVWT, rr, h);
-        if(!(fabsf(0.5f - pm) < fabsf(0.5f - hv)))
+        if(IN_(rr, 8, rr1 - 8) && IN_(cc, 8, cc1 - 8) && LDB(P_NY2, rr, h))
         {
-          const float c = LD(P_CFA, rr, cc);
-          const float cu = LD(P_CFA, rr - 1, cc), cd = LD(P_CFA, rr + 1, cc), cl = LD(P_CFA, rr, cc - 1), cr = LD(P_CFA, rr, cc + 1);
-          const float rb = LD(P_RBINT, rr, h);
-          const float rbu = LD(P_RBINT, rr - 2, h), rbd = LD(P_RBINT, rr + 2, h), rbl = LD(P_RBINT, rr, h - 1), rbr = LD(P_RBINT, rr, h + 1);
-          // the reference divides in binary64 (double literals) and rounds the quotient to binary32
-          const float cru = div2_via_double(cu, EPS + rb + rbu);
-          const float crd = div2_via_double(cd, EPS + rb + rbd);
-          const float crl = div2_via_double(cl, EPS + rb + rbl);
-          const float crr = div2_via_double(cr, EPS + rb + rbr);
-          const float gu = fabsf(1.f - cru) < ARTHRESH ? rb * cru : cu + xdiv2f(rb - rbu);
-          const float gd = fabsf(1.f - crd) < ARTHRESH ? rb * crd : cd + xdiv2f(rb - rbd);
-          const float gl = fabsf(1.f - crl) < ARTHRESH ? rb * crl : cl + xdiv2f(rb - rbl);
-          const float gr = fabsf(1.f - crr) < ARTHRESH ? rb * crr : cr + xdiv2f(rb - rbr);
-          // the directional gradients of S1 at the four green neighbours, formed again from the mosaic
-          const float cu2 = LD(P_CFA, rr - 2, cc), cu3 = LD(P_CFA, rr - 3, cc), cd2 = LD(P_CFA, rr + 2, cc), cd3 = LD(P_CFA, rr + 3, cc);
-          const float cl2 = LD(P_CFA, rr, cc - 2), cl3 = LD(P_CFA, rr, cc - 3), cr2 = LD(P_CFA, rr, cc + 2), cr3 = LD(P_CFA, rr, cc + 3);
-          const float d0u = EPS + fabsf(cd - cu) + fabsf(cu - cu3) + fabsf(c - cu2);
-          const float d0d = EPS + fabsf(cd3 - cd) + fabsf(cd - cu) + fabsf(cd2 - c);
-          const float d1l = EPS + fabsf(cr - cl) + fabsf(cl - cl3) + fabsf(c - cl2);
-          const float d1r = EPS + fabsf(cr3 - cr) + fabsf(cr - cl) + fabsf(cr2 - c);
-          float Gintv = (d0u * gd + d0d * gu) / (d0d + d0u);
-          float Ginth = (d1l * gr + d1r * gl) / (d1l + d1r);
-          if(Gintv < rb)
+          const float q0 = 0.169917f, q1 = 0.108947f, q2 = 0.069855f, q3 = 0.0287182f;
+          // (the two planes have one shape: the lane's is a constant number of words behind the other)
+          static_assert(P_GV::W == P_GH::W && P_GV::D == P_GH::D, "one index for both curvature planes");
+          const int pl = half ? P_GV::OFF - P_GH::OFF : 0;
+#define LDQ(r, c) env.ldf(P_GH::idx((r), (c)) + pl, (r))
+          const float mine
+              = (EPSSQ + (q0 * LDQ(rr, h) + q1 * (LDQ(rr - 1, (cc - 1) >> 1) + LDQ(rr - 1, (cc + 1) >> 1) + LDQ(rr + 1, (cc - 1) >> 1) + LDQ(rr + 1, (cc + 1) >> 1))
+                          + q2 * (LDQ(rr - 2, h) + LDQ(rr, h - 1) + LDQ(rr, h + 1) + LDQ(rr + 2, h))
+                          + q3 * (LDQ(rr - 2, h - 1) + LDQ(rr - 2, h + 1) + LDQ(rr + 2, h - 1) + LDQ(rr + 2, h + 1))));
+#undef LDQ
+          const float other = env.swap1(mine);
+          const float gvarh = half ? other : mine, gvarv = half ? mine : other;
+          const float dg = (LD(P_HCDH, rr, h) * gvarv + LD(P_VCDH, rr, h) * gvarh) / (gvarv + gvarh);
+          if(!half)
           {
-            if(2 * Gintv < rb)
-              Gintv = ulim(Gintv, cu, cd);
-            else
+            ST(P_DGO, rr, h, dg);
+            ST(P_GREEN, rr, h, LD(P_CFA, rr, cc) + dg);
+          }
+        }
+        if(IN_(rr, 12, rr1 - 12) && IN_(cc, 12, cc1 - 12))
+        {
+          const float pm = LD(P_PMWT, rr, h), hv = LD(P_HVWT, rr, h);
+          if(!(fabsf(0.5f - pm) < fabsf(0.5f - hv)))
+          {
+            // a: the neighbour above / to the left, b: below / to the right
+            const int dr = half ? 0 : 1, dc = half ? 1 : 0;
+            const float c = LD(P_CFA, rr, cc);
+            const float ca = LD(P_CFA, rr - dr, cc - dc), cb = LD(P_CFA, rr + dr, cc + dc);
+            const float rb = LD(P_RBINT, rr, h);
+            const float rba = LD(P_RBINT, rr - 2 * dr, h - dc), rbb = LD(P_RBINT, rr + 2 * dr, h + dc);
+            // the reference divides in binary64 (double literals) and rounds the quotient to binary32
+            const float cra = div2_via_double(ca, EPS + rb + rba);
+            const float crb = div2_via_double(cb, EPS + rb + rbb);
+            const float ga = fabsf(1.f - cra) < ARTHRESH ? rb * cra : ca + xdiv2f(rb - rba);
+            const float gb = fabsf(1.f - crb) < ARTHRESH ? rb * crb : cb + xdiv2f(rb - rbb);
+            // the directional gradients of S1 at the two green neighbours, formed again from the mosaic
+            const float ca2 = LD(P_CFA, rr - 2 * dr, cc - 2 * dc), ca3 = LD(P_CFA, rr - 3 * dr, cc - 3 * dc);
+            const float cb2 = LD(P_CFA, rr + 2 * dr, cc + 2 * dc), cb3 = LD(P_CFA, rr + 3 * dr, cc + 3 * dc);
+            const float da = EPS + fabsf(cb - ca) + fabsf(ca - ca3) + fabsf(c - ca2);
+            const float db = EPS + fabsf(cb3 - cb) + fabsf(cb - ca) + fabsf(cb2 - c);
+            // (the reference's two denominators are d0d + d0u and d1l + d1r: b + a and a + b -- binary32 addition commutes)
+            float Gint = (da * gb + db * ga) / (db + da);
+            if(Gint < rb)
             {
-              const float vwt = div2_via_double(rb - Gintv, EPS + Gintv + rb);
-              Gintv = vwt * Gintv + (1.f - vwt) * ulim(Gintv, cu, cd);
+              if(2 * Gint < rb)
+                Gint = ulim(Gint, ca, cb);
+              else
+              {
+                const float wt = div2_via_double(rb - Gint, EPS + Gint + rb);
+                Gint = wt * Gint + (1.f - wt) * ulim(Gint, ca, cb);
+              }
+            }
+            if(Gint > clip_pt) Gint = ulim(Gint, ca, cb);
+            const float other = env.swap1(Gint);
+            const float Gintv = half ? other : Gint, Ginth = half ? Gint : other;
+            const float g = Ginth * (1.f - hv) + Gintv * hv;
+            if(!half)
+            {
+              ST(P_GREEN, rr, h, g);
+              ST(P_DGO, rr, h, g - c);
             }
           }
-          if(Ginth < rb)
-          {
-            if(2 * Ginth < rb)
-              Ginth = ulim(Ginth, cl, cr);
-            else
-            {
-              const float hwt = div2_via_double(rb - Ginth, EPS + Ginth + rb);
-              Ginth = hwt * Ginth + (1.f - hwt) * ulim(Ginth, cl, cr);
-            }
-          }
-          if(Ginth > clip_pt) Ginth = ulim(Ginth, cl, cr);
-          if(Gintv > clip_pt) Gintv = ulim(Gintv, cu, cd);
-          const float g = Ginth * (1.f - hv) + Gintv * hv;
-          ST(P_GREEN, rr, h, g);
-          ST(P_DGO, rr, h, g - c);
         }
       }
     }

@@ -828,6 +828,11 @@ struct stream_env
   {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xf, 0xf, false));
   }
+  // the value of lane ^ 1 (both lanes of the pair call it): one DPP move (quad_perm [1, 0, 3, 2])
+  __device__ __forceinline__ float swap1(const float v) const
+  {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, false));
+  }
   // x + y with the operands in this order (the compiler is free to swap them, and of two NaNs the sum is the first)
   __device__ __forceinline__ float add(const float x, const float y) const
   {

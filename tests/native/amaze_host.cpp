@@ -144,6 +144,15 @@ struct HostEnv
   // the value of lane - 1 / lane + 1 of the wave (every lane of the wave calls it; the first / last lane gets its own)
   float shfl_up1(const float v) const { return shuffle(v, -1); }
   float shfl_down1(const float v) const { return shuffle(v, 1); }
+  // the value of lane ^ 1 (both lanes of the pair call it)
+  float swap1(const float v) const
+  {
+    sh->xchg[tid_] = v;
+    swapcontext(&sh->ctx[tid_], &sh->main);
+    const float r = sh->xchg[tid_ ^ 1];
+    swapcontext(&sh->ctx[tid_], &sh->main);
+    return r;
+  }
   float shuffle(const float v, const int d) const
   {
     sh->xchg[tid_] = v;
