@@ -246,9 +246,15 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
 #define STB(P, r, c, v) env.stb(P::idx((r), (c)), (r), (v))
 #define IN_(x, lo, hi) ((x) >= (lo) && (x) < (hi))
 // every thread over the sites of the R rows of a stage with lag L: all columns ...
-#define FOR_FULL(L)                                      \
-  for(int _k = tid; _k < R * TS; _k += NT)               \
-    for(int rr = s * R - (L) + _k / TS, cc = _k % TS, _once = 1; _once && rr >= 0 && rr < TS; _once = 0)
+// (eight of the ten waves lie in ONE tile row -- 160 columns are two and a half waves -- and with the row known to be the same
+// in every lane the ring slots of the rows a site touches, times the pitch, are scalar arithmetic instead of 30 % of the
+// kernel's vector instructions: the body is compiled twice, for a row in a scalar register and for a row per lane)
+#define FOR_FULL(L)                                                                                                  \
+  AMZ_UNROLL                                                                                                         \
+  for(int _u = 0; _u < 2; _u++)                                                                                      \
+    if((_u == 0) == full_one_row)                                                                                    \
+      for(int rr = s * R - (L) + (_u == 0 ? env.uniform(full_row) : full_row), cc = full_col, _once = 1;             \
+          _once && rr >= 0 && rr < TS; _once = 0)
 // ... the R/B sites (q: the column parity of the R/B sites of the row; h: the site's word in a half-width plane)
 #define FOR_RB(L)                                                                                         \
   for(int _k = tid; _k < R * TSH; _k += NT)                                                               \
@@ -266,6 +272,8 @@ template <typename Env> AMZ_FN void tile(Env &env, const float *in, float *out, 
         _once && rr >= 0 && rr < TS; _once = 0)
 
   static_assert(NT == R * TS, "one photosite of the step's rows per thread");
+  const int full_row = tid / TS, full_col = tid % TS;
+  const bool full_one_row = env.uniform((int)(((tid & ~63) / TS) == ((tid | 63) / TS))) != 0;
   // tile rows from the mosaic, amaze.cc:352-460: the nine fills of the reference as one function of the photosite -- they do
   // not overlap in the tiles this kernel takes (stream_tile_ok()).  A strip mirrors about the frame edge, a corner about
   // row / column 32 of the FRAME on the side of a top / left edge (the reference's own rule); what no fill reaches stays 0

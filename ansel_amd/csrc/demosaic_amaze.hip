@@ -828,6 +828,8 @@ struct stream_env
   {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xf, 0xf, false));
   }
+  // a value that is the same in every lane of the wave, as the compiler cannot know: in a scalar register
+  __device__ __forceinline__ int uniform(const int v) const { return __builtin_amdgcn_readfirstlane(v); }
   // the value of lane ^ 1 (both lanes of the pair call it): one DPP move (quad_perm [1, 0, 3, 2])
   __device__ __forceinline__ float swap1(const float v) const
   {

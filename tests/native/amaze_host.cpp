@@ -144,6 +144,7 @@ struct HostEnv
   // the value of lane - 1 / lane + 1 of the wave (every lane of the wave calls it; the first / last lane gets its own)
   float shfl_up1(const float v) const { return shuffle(v, -1); }
   float shfl_down1(const float v) const { return shuffle(v, 1); }
+  int uniform(const int v) const { return v; }
   // the value of lane ^ 1 (both lanes of the pair call it)
   float swap1(const float v) const
   {
