@@ -466,7 +466,7 @@ struct dn_strip_kernargs
   int flag_sense;
 };
 template <bool PRE, int MULT, bool ALPHA0>
-__global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                           float4 *__restrict__ detail, double *__restrict__ partial,
                                                           const int width, const int height, const int mult_arg,
                                                           const float inv_sigma2, const int nseg, const int in_row0,
@@ -484,7 +484,6 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
   const bool have_t3 = PRE && fa.vst == 2;
   const float t3_of_zero = have_t3 ? dn_vst_y0u0v0_alpha(0.0f, fa) : 0.0f;
 #define DN_FETCH(p) (PRE ? dn_precondition_pixel((p), fa, t3_of_zero, have_t3) : (p))
-  extern __shared__ float4 ring[]; // [DN_RING][256 + 4 * mult]
   __shared__ double runs[2][4][4];
   const int bx = blockIdx.x;
   const int cls = blockIdx.y / strips_per_class, k0 = (blockIdx.y - cls * strips_per_class) * strip;
@@ -493,6 +492,26 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
   const int nrows = min(strip, n_cls - k0);
   const int r_first = cls + k0 * mult;
   const int tw = 256 + 4 * mult;
+  // the rows' samples: [DN_RING][256 + 4 * mult] float4 -- or, for an ALPHA0 launch, three planes of floats a row (the fourth
+  // channel is +0 and is not kept): 12 bytes a sample instead of 16 are two more workgroups a CU (the kernel loses 11 % with
+  // 8 KB of LDS more a workgroup, measured: profiles/r04_negative_results.txt item 8), and a tap's three ds_read_b32 move through
+  // the LDS in 6 cycles where its ds_read_b128 took 8
+  extern __shared__ float4 ring[];
+  float *const ringf = reinterpret_cast<float *>(ring);
+  auto ring_put = [&](const int slot, const int c, const float4 v) {
+    if(ALPHA0)
+    {
+      ringf[(slot * 3 + 0) * tw + c] = v.x;
+      ringf[(slot * 3 + 1) * tw + c] = v.y;
+      ringf[(slot * 3 + 2) * tw + c] = v.z;
+    }
+    else
+      ring[slot * tw + c] = v;
+  };
+  auto ring_get = [&](const int slot, const int c) -> float4 {
+    if(ALPHA0) return make_float4(ringf[(slot * 3 + 0) * tw + c], ringf[(slot * 3 + 1) * tw + c], ringf[(slot * 3 + 2) * tw + c], 0.0f);
+    return ring[slot * tw + c];
+  };
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = bx * 256 + tid;
   // the one or two ring entries this thread fetches per row
@@ -504,8 +523,8 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
   for(int q = 0; q < 4; q++)
   {
     const size_t y = DN_IN_ROW(q);
-    ring[q * tw + tid] = DN_FETCH(in[y + ecol0]);
-    if(second) ring[q * tw + tid + 256] = DN_FETCH(in[y + ecol1]);
+    ring_put(q, tid, DN_FETCH(in[y + ecol0]));
+    if(second) ring_put(q, tid + 256, DN_FETCH(in[y + ecol1]));
   }
   float4 n0, n1 = make_float4(0.f, 0.f, 0.f, 0.f);
   {
@@ -519,8 +538,8 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
   float up1 = 0.f, up2 = 0.f, up2_next = 0.f;
   __syncthreads();
   {
-    const float4 c0 = ring[2 * tw + tid + 2 * mult], c1 = ring[3 * tw + tid + 2 * mult];
-    const float4 a0 = ring[0 * tw + tid + 2 * mult], a1 = ring[1 * tw + tid + 2 * mult];
+    const float4 c0 = ring_get(2, tid + 2 * mult), c1 = ring_get(3, tid + 2 * mult);
+    const float4 a0 = ring_get(0, tid + 2 * mult), a1 = ring_get(1, tid + 2 * mult);
     up2 = dn_photometric(c0, a0, inv_sigma2);      // row 0 <- two rows above
     up1 = dn_photometric(c0, a1, inv_sigma2);      // row 0 <- the row above
     up2_next = dn_photometric(c1, a1, inv_sigma2); // row 1 <- two rows above
@@ -529,8 +548,8 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
   {
     {
       const int sl = s0 + 4 >= DN_RING ? s0 + 4 - DN_RING : s0 + 4;
-      ring[sl * tw + tid] = DN_FETCH(n0);
-      if(second) ring[sl * tw + tid + 256] = DN_FETCH(n1);
+      ring_put(sl, tid, DN_FETCH(n0));
+      if(second) ring_put(sl, tid + 256, DN_FETCH(n1));
     }
     __syncthreads();
     if(k > 0 && tid < 4)
@@ -551,17 +570,16 @@ __global__ __launch_bounds__(256) void dn_decompose_strip(const float4 *__restri
     if(col < width)
     {
       const int sc = s0 + 2 >= DN_RING ? s0 + 2 - DN_RING : s0 + 2;
-      const float4 px = ring[sc * tw + tid + 2 * mult];
+      const float4 px = ring_get(sc, tid + 2 * mult);
       float sum[4] = { 0.f, 0.f, 0.f, 0.f }, wgt = 0.f, down1 = 0.f, down2 = 0.f;
 #pragma unroll
       for(int jj = 0; jj < 5; jj++)
       {
         const int sl = s0 + jj >= DN_RING ? s0 + jj - DN_RING : s0 + jj;
-        const float4 *const line = ring + sl * tw + tid;
         const float fj = jj == 0 || jj == 4 ? 0.0625f : (jj == 2 ? 0.375f : 0.25f);
         float4 tap[5];
 #pragma unroll
-        for(int ii = 0; ii < 5; ii++) tap[ii] = line[ii * mult];
+        for(int ii = 0; ii < 5; ii++) tap[ii] = ring_get(sl, tid + ii * mult);
 #pragma unroll
         for(int ii = 0; ii < 5; ii++)
         {
@@ -650,11 +668,20 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
   while(strip > 4 && (size_t)nseg * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
   const int strips_per_class = (per_class + strip - 1) / strip;
   const dim3 grid(nseg, classes * strips_per_class);
-  const size_t lds = (size_t)DN_RING * (256 + 4 * mult) * sizeof(float4);
+  // (an ALPHA0 launch keeps three floats a sample: DN_LDS())
+  size_t lds = (size_t)DN_RING * (256 + 4 * mult) * sizeof(float);
+#ifdef ANSEL_HIP_MEASURING
+  // how much the kernel needs its occupancy: LDS asked for and not used (bytes), for A/B timing
+  static const char *const pad_env = measuring_env("ANSEL_HIP_DN_LDS_PAD");
+  const size_t lds_pad = pad_env ? (size_t)atoi(pad_env) : 0;
+#else
+  const size_t lds_pad = 0;
+#endif
+#define DN_LDS(A0_) (lds * ((A0_) ? 3 : 4) + lds_pad)
   vst_args none;
   memset(&none, 0, sizeof(none));
 #define DN_LAUNCH_(PRE_, M_, A0_, FA_, SENSE_)                                                                                          \
-  dn_decompose_strip<PRE_, M_, A0_><<<grid, 256, lds, st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0, \
+  dn_decompose_strip<PRE_, M_, A0_><<<grid, 256, DN_LDS(A0_), st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0, \
                                                             in_rows, strip, strips_per_class, FA_, alpha_flag, SENSE_)
 #define DN_LAUNCH(PRE_, M_, FA_)                  \
   do                                              \
@@ -688,6 +715,7 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
     }
 #undef DN_LAUNCH
 #undef DN_LAUNCH_
+#undef DN_LDS
 }
 
 struct thr_args
