@@ -781,7 +781,12 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           int strip = 32;
           while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
           const int spc = (per_class + strip - 1) / strip;
-          const size_t ring = (size_t)PDE_RING * (256 + 2 * a.mult) * sizeof(float4);
+          size_t ring = (size_t)PDE_RING * (256 + 2 * a.mult) * sizeof(float4);
+#ifdef ANSEL_HIP_MEASURING
+          // how much the kernel needs its occupancy: LDS asked for and not used (bytes), for A/B timing
+          static const char *const pad_env = measuring_env("ANSEL_HIP_PDE_LDS_PAD");
+          if(pad_env) ring += (size_t)atoi(pad_env);
+#endif
           static const bool generic = measuring_env("ANSEL_HIP_PDE_GENERIC") != nullptr; // the kinds read at run time, for A/B timing
           const int mode = generic ? -1 : pde_mode_of(a);
           const dim3 sgrid(gx, classes * spc);
