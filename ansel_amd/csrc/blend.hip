@@ -877,7 +877,9 @@ template <int CS>
 __global__ __launch_bounds__(256) void blend_mask_kernel(const float4 *__restrict__ in, const float4 *__restrict__ out,
                                                          float *__restrict__ plane, const blend_args a_by_value)
 {
-  const blend_args &a = kernarg_at<blend_args>(24); // after the three pointers
+  constexpr int at = kernarg_offset_after<blend_args, const float4 *, const float4 *, float *>(); // after the three pointers
+  static_assert(at == 24, "the blend kernels' by-value parameter block follows three pointers");
+  const blend_args &a = kernarg_at<blend_args>(at);
   (void)a_by_value;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= (size_t)a.owidth * a.oheight) return;
@@ -890,7 +892,9 @@ template <int CS, int MASK>
 __global__ __launch_bounds__(256) void blend_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                     const float *__restrict__ plane, const blend_args a_by_value)
 {
-  const blend_args &a = kernarg_at<blend_args>(24); // after the three pointers
+  constexpr int at = kernarg_offset_after<blend_args, const float4 *, const float4 *, float *>(); // after the three pointers
+  static_assert(at == 24, "the blend kernels' by-value parameter block follows three pointers");
+  const blend_args &a = kernarg_at<blend_args>(at);
   (void)a_by_value;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= (size_t)a.owidth * a.oheight) return;

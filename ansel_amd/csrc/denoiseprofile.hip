@@ -465,8 +465,19 @@ struct dn_strip_kernargs
   unsigned *alpha_flag;
   int flag_sense;
 };
+// Waves per SIMD the register allocation aims at: eight (64 VGPRs) where the ring lets eight workgroups share a CU -- the
+// kernel answers to its occupancy, profiles/r04_negative_results.txt item 8 --, as many as the ring allows at the large
+// dilations (MULT 32 / 64: 12 - 16 bytes x 6 x (256 + 4 MULT) of LDS a workgroup, five to three of them a CU), and six for
+// the transform-applying launch at a dilation only known at run time (it would need 66 registers: no scratch instead)
+template <bool PRE, int MULT, bool ALPHA0> constexpr int dn_strip_waves()
+{
+  if(PRE && MULT == 0) return 6;
+  const int lds = DN_RING * (256 + 4 * (MULT ? MULT : 1)) * (ALPHA0 ? 12 : 16);
+  const int wgs = (160 * 1024) / lds;
+  return wgs >= 8 ? 8 : (wgs < 1 ? 1 : wgs);
+}
 template <bool PRE, int MULT, bool ALPHA0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_waves<PRE, MULT, ALPHA0>(), 8))) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                           float4 *__restrict__ detail, double *__restrict__ partial,
                                                           const int width, const int height, const int mult_arg,
                                                           const float inv_sigma2, const int nseg, const int in_row0,
@@ -481,6 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if(flag_sense == 2 && !*alpha_flag) return;
   unsigned alpha_bits = 0; // ALPHA0: the coarse alphas this lane wrote
   const int mult = MULT ? MULT : mult_arg;
+  constexpr bool LATE2 = PRE && MULT == 1;
   const bool have_t3 = PRE && fa.vst == 2;
   const float t3_of_zero = have_t3 ? dn_vst_y0u0v0_alpha(0.0f, fa) : 0.0f;
 #define DN_FETCH(p) (PRE ? dn_precondition_pixel((p), fa, t3_of_zero, have_t3) : (p))
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   {
     const size_t y = DN_IN_ROW(4);
     n0 = in[y + ecol0];
-    if(second) n1 = in[y + ecol1];
+    if(!LATE2 && second) n1 = in[y + ecol1];
   }
   int s0 = 0; // ring slot of row k
   // the weights of the taps straight above, left by this lane one and two rows ago; for the strip's first two rows, whose
@@ -549,7 +561,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     {
       const int sl = s0 + 4 >= DN_RING ? s0 + 4 - DN_RING : s0 + 4;
       ring_put(sl, tid, DN_FETCH(n0));
-      if(second) ring_put(sl, tid + 256, DN_FETCH(n1));
+      // LATE2: the (few) lanes with a second ring entry fetch it here, where it is transformed, instead of holding it in
+      // four more registers across the 25 taps -- what pushed the launch that applies the transform over its 64 registers
+      // (12 - 24 bytes of scratch, folded reloads in the tap loop: round 4's review).  At dilation 1 they are four lanes of
+      // the workgroup's first wave; the seven other workgroups of the CU cover the fetch
+      if(LATE2) { if(second) ring_put(sl, tid + 256, DN_FETCH(in[DN_IN_ROW(k + 4) + ecol1])); }
+      else if(second) ring_put(sl, tid + 256, DN_FETCH(n1));
     }
     __syncthreads();
     if(k > 0 && tid < 4)
@@ -563,7 +580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     {
       const size_t y = DN_IN_ROW(k + 5);
       n0 = in[y + ecol0];
-      if(second) n1 = in[y + ecol1];
+      if(!LATE2 && second) n1 = in[y + ecol1];
     }
     const int row = r_first + k * mult;
     double sq[4] = { 0.0, 0.0, 0.0, 0.0 };

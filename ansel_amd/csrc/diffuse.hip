@@ -21,6 +21,7 @@
 
 #include <type_traits>
 #include "devmath.h"
+#include "ieee_inrange.h"
 #include "px_colorspaces.h"
 
 #include <math.h>
@@ -72,7 +73,24 @@ struct pde_args
   int wskip;
   int post_lab;        // the pipe's RGB -> Lab glue behind the module, applied where the last pass stores (strip kernel)
   float post_m[3][4];
+  int approx_div;      // measuring builds only (ANSEL_HIP_PDE_APPROX_DIV): PDE_APPROX below
 };
+
+// What would the north star's 1 ULP buy?  Measuring builds can run the strip kernel with every division as v_rcp, one
+// product and ONE residual correction (4 instructions instead of 11; <= 1 ulp) and the square root as the bare v_sqrt_f32
+// (1 ulp): tools/pde_div_ab.py times both arms and commits the ULP histogram of the module's output beside the
+// milliseconds (profiles/r05_pde_div_ab.json).  Never in the product: PDE_APPROX() is the constant 0 there.
+#ifdef ANSEL_HIP_MEASURING
+#define PDE_APPROX(a) ((a).approx_div != 0)
+#else
+#define PDE_APPROX(a) false
+#endif
+__device__ __forceinline__ float div_1ulp(const float x, const float y)
+{
+  const float r = __builtin_amdgcn_rcpf(y);
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
+}
 
 // dt_fast_expf(), src/math/math.h:254-267.  The float -> int conversion of an out-of-range or NaN
 // value is INT_MIN on the reference's target (cvttss2si), which its k0 > 0 test turns into 0.
@@ -85,11 +103,33 @@ __device__ __forceinline__ float fast_expf(const float x)
 }
 
 // diffuse.c:851-866: magnitude of a 2-vector and {cos^2, sin^2, cos*sin} of its argument
-__device__ __forceinline__ float direction(float gx, float gy, float &cos2, float &sin2, float &cs)
+// Round 5: the square root and the division without their range scaffolding (ieee_inrange.h) where every lane of the
+// wave has gx gx + gy gy == +0 or in [2^-96, +inf) -- one multiplication, one class test and one ballot per call: the
+// magnitude is then +0 or in [2^-48, 2^64), the divisor 1 or that magnitude -- inside the range in which the division's
+// scale / fix-up instructions do nothing -- and the numerator is 1.  Same operations otherwise, so the same bits; a wave
+// with a gradient outside (below 2^-48: dark pixels one ulp apart; not finite) takes the long forms.  The two forms
+// rejoin at once: a channel's update stays one block for the scheduler, and only the magnitude and the reciprocal leave
+// the branch (the non-zero flag is formed behind it: with it inside, the modes with two directions needed 130 registers).
+__device__ __forceinline__ float direction(float gx, float gy, float &cos2, float &sin2, float &cs, const bool approx = false)
 {
-  const float mag = sqrtf(gx * gx + gy * gy);
+  const float s2 = gx * gx + gy * gy;
+  float mag, inv;
+  if(approx)
+  {
+    mag = __builtin_amdgcn_sqrtf(s2);
+    inv = div_1ulp(1.0f, mag + (1.0f - ((mag != 0.0f) ? 1.0f : 0.0f)));
+  }
+  else if(__builtin_amdgcn_ballot_w64(!ansel_ieee::zero_or_above_2m96(s2)) == 0ull)
+  {
+    mag = ansel_ieee::sqrt_core(s2);
+    inv = ansel_ieee::rcp_core(mag + (1.0f - ((mag != 0.0f) ? 1.0f : 0.0f)));
+  }
+  else
+  {
+    mag = sqrtf(s2);
+    inv = 1.0f / (mag + (1.0f - ((mag != 0.0f) ? 1.0f : 0.0f)));
+  }
   const float nonzero = (mag != 0.0f) ? 1.0f : 0.0f;
-  const float inv = 1.0f / (mag + (1.0f - nonzero));
   gx = gx * inv + (1.0f - nonzero);
   gy = gy * inv;
   cos2 = gx * gx;
@@ -161,6 +201,41 @@ __device__ __forceinline__ float ratio2(const float h, const float l)
   const float ratio = h / safe;
   return ratio * ratio;
 }
+// The three colour channels' squared ratios of one sample, the division's range scaffolding left out where a wave's
+// operands allow it (round 5; ieee_inrange.h).  The divisor is max_zero(l - 1e-8) + 1e-8: finite, never NaN, >= 1e-8 > 2^-27.
+// One test per sample -- the largest of |h| and of the divisors over the three channels <= 2^64 -- and one ballot per
+// wave: then every divisor is a normal number below 2^126 and exponent(h) - exponent(divisor) <= 64 + 27 < 96, which is
+// all of div_core()'s domain except the small numerators -- |h| < 2^-103, or a subnormal quotient -- and the zeros and
+// NaNs.  Those do not reach the result: a quotient below 2^-76 in magnitude, however its last bits fall, squares to +0
+// (2^-152 is below half the smallest subnormal), as +-0 does; and a NaN numerator gives a NaN either way, whose only
+// reader is the energy sum that max_zero() (not finite -> 0) closes.  (v_max3 skips a NaN numerator; an infinite one fails
+// the test.)  A wave that fails -- magnitudes no image carries -- divides the long way.
+__device__ __forceinline__ float4 ratio2_rgb(const float4 h, const float4 l, const float w_ratio, const bool approx = false)
+{
+  if(approx)
+  {
+    const float ax = div_1ulp(h.x, max_zero(l.x - 1e-8f) + 1e-8f), ay = div_1ulp(h.y, max_zero(l.y - 1e-8f) + 1e-8f),
+                az = div_1ulp(h.z, max_zero(l.z - 1e-8f) + 1e-8f);
+    return make_float4(ax * ax, ay * ay, az * az, w_ratio);
+  }
+  const float sx = max_zero(l.x - 1e-8f) + 1e-8f, sy = max_zero(l.y - 1e-8f) + 1e-8f, sz = max_zero(l.z - 1e-8f) + 1e-8f;
+  const float top = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(h.x), __builtin_fabsf(h.y)), __builtin_fabsf(h.z)),
+                                    __builtin_fmaxf(__builtin_fmaxf(sx, sy), sz));
+  float rx, ry, rz;
+  if(__builtin_amdgcn_ballot_w64(!(top <= 0x1p64f)) == 0ull)
+  {
+    rx = ansel_ieee::div_core(h.x, sx);
+    ry = ansel_ieee::div_core(h.y, sy);
+    rz = ansel_ieee::div_core(h.z, sz);
+  }
+  else
+  {
+    rx = h.x / sx;
+    ry = h.y / sy;
+    rz = h.z / sz;
+  }
+  return make_float4(rx * rx, ry * ry, rz * rz, w_ratio);
+}
 
 // The four orders' kinds and the two "same kernel" flags are parameters, and branching on them (uniformly) cuts a channel's
 // update into a dozen basic blocks that the scheduler cannot interleave with each other or with the next channel.  MODE >= 0
@@ -211,8 +286,8 @@ __device__ __forceinline__ float pde_channel(const float H[9], const float L[9],
   // isotropic order (anisotropy 0, the module's default for all four) reads neither the angle nor the magnitude, so a
   // direction nobody reads is not computed (uniform branches: the kinds are parameters)
   float cos2g = 0.f, sin2g = 0.f, csg = 0.f, cos2l = 0.f, sin2l = 0.f, csl = 0.f, mg = 0.f, ml = 0.f;
-  if(M::kind(0, a) | M::kind(2, a)) mg = direction((L[7] - L[1]) * 0.5f, (L[5] - L[3]) * 0.5f, cos2g, sin2g, csg);
-  if(M::kind(1, a) | M::kind(3, a)) ml = direction((H[7] - H[1]) * 0.5f, (H[5] - H[3]) * 0.5f, cos2l, sin2l, csl);
+  if(M::kind(0, a) | M::kind(2, a)) mg = direction((L[7] - L[1]) * 0.5f, (L[5] - L[3]) * 0.5f, cos2g, sin2g, csg, PDE_APPROX(a));
+  if(M::kind(1, a) | M::kind(3, a)) ml = direction((H[7] - H[1]) * 0.5f, (H[5] - H[3]) * 0.5f, cos2l, sin2l, csl, PDE_APPROX(a));
   // orders 1 and 3 share the direction of the low-frequency gradient, orders 2 and 4 that of the high-frequency one; with
   // the same anisotropy (the presets' case) they share the kernel too (uniform: the anisotropies are parameters)
   const kernel5 w0 = order_kernel(M::kind(0, a), fast_expf(-mg * a.anisotropy[0]), csg, cos2g, sin2g);
@@ -227,7 +302,7 @@ __device__ __forceinline__ float pde_channel(const float H[9], const float L[9],
   update = d1 * a.abcd[1] + update;
   update = d2 * a.abcd[2] + update;
   update = d3 * a.abcd[3] + update;
-  const float acc = H[4] * a.strength + update / energy;
+  const float acc = H[4] * a.strength + (PDE_APPROX(a) ? div_1ulp(update, energy) : update / energy);
   return max_zero(acc + L[4]);
 }
 
@@ -422,7 +497,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     // are -- what a pipe hands this module, see alpha_is_blank() -- skips that division (a uniform branch)
     auto ratios = [&](const float4 h, const float4 l) {
       const bool blank = a.wskip && __builtin_amdgcn_ballot_w64((__float_as_uint(h.w) | __float_as_uint(l.w)) != 0) == 0ull;
-      return make_float4(ratio2(h.x, l.x), ratio2(h.y, l.y), ratio2(h.z, l.z), blank ? 0.0f : ratio2(h.w, l.w));
+      return ratio2_rgb(h, l, blank ? 0.0f : ratio2(h.w, l.w), PDE_APPROX(a));
     };
     ring[tx + mult] = ratios(Hw[SL][1], Lw[SL][1]);
     if(tx < mult) ring[tx] = ratios(Hw[SL][0], Lw[SL][0]);
@@ -680,6 +755,10 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
   a.width = w;
   a.height = h;
   a.wskip = measuring_env("ANSEL_HIP_PDE_NO_WSKIP") ? 0 : 1;
+  {
+    const char *const approx_env = measuring_env("ANSEL_HIP_PDE_APPROX_DIV"); // read per call: tools/pde_div_ab.py flips it
+    a.approx_div = approx_env && atoi(approx_env) != 0;
+  }
   const float user_aniso[4] = { d->anisotropy_first, d->anisotropy_second, d->anisotropy_third, d->anisotropy_fourth };
   for(int k = 0; k < 4; k++)
   {

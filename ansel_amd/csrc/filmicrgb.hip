@@ -27,7 +27,9 @@ template <int MODE, bool EXPORT>
 __global__ __launch_bounds__(256) void filmic_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                       const size_t npixels, const fargs a_by_value)
 {
-  const fargs &a = kernarg_at<fargs>(24); // after two pointers and a size_t (hip_common.h)
+  constexpr int at = kernarg_offset_after<fargs, const float4 *, float4 *, size_t>(); // after two pointers and a size_t (hip_common.h)
+  static_assert(at == 24, "filmic_kernel: the by-value parameter block follows two pointers and a size_t");
+  const fargs &a = kernarg_at<fargs>(at);
   (void)a_by_value;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
   if(k < npixels)

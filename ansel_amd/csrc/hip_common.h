@@ -101,6 +101,16 @@ template <typename T> __device__ __forceinline__ const T &kernarg_at(const int o
   typedef const T __attribute__((address_space(4))) *p4;
   return *(const T *)(p4)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offset);
 }
+// where a by-value argument of type T sits in the kernarg segment when the arguments in front of it have the types
+// Before...: every argument at its natural alignment, in declaration order (the code-object metadata's .offset; the
+// tests read it back: tests/test_kernel_resources.py).  The kernels that call kernarg_at() spell their offset with
+// this, and static_assert the number their comment quotes.
+template <typename T, typename... Before> constexpr int kernarg_offset_after()
+{
+  size_t off = 0;
+  ((off = (off + alignof(Before) - 1) / alignof(Before) * alignof(Before) + sizeof(Before)), ...);
+  return (int)((off + alignof(T) - 1) / alignof(T) * alignof(T));
+}
 
 // XCD-aware 2-D launch for stencil kernels that walk the frame row by row.  The eight XCDs of an MI355X have
 // private L2s and workgroups are handed to them round-robin by linear workgroup id (x fastest); with gridDim.x not

@@ -869,7 +869,9 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__res
 {
   // the launch's ~30 parameters are read from the kernarg segment where they are used (hip_common.h kernarg_at(): behind the two
   // pointers), not held in scalar registers through the offsets' loop
-  const nlm_args &a = kernarg_at<nlm_args>(16);
+  constexpr int at = kernarg_offset_after<nlm_args, const float4 *, float4 *>();
+  static_assert(at == 16, "nlm_chunks_v3: the by-value nlm_args follows the two plane pointers");
+  const nlm_args &a = kernarg_at<nlm_args>(at);
   (void)a_by_value;
   extern __shared__ float lds[];
   const int chunk = order[blockIdx.x];
@@ -896,7 +898,9 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__res
                                                              const nlm_args a_by_value, const int2 *__restrict__ patches,
                                                              const int *__restrict__ order, const int n_border, const int ndx)
 {
-  const nlm_args &a = kernarg_at<nlm_args>(16); // (see nlm_chunks_v3)
+  constexpr int at = kernarg_offset_after<nlm_args, const float4 *, float4 *>(); // (see nlm_chunks_v3)
+  static_assert(at == 16, "nlm_chunks_v4: the by-value nlm_args follows the two plane pointers");
+  const nlm_args &a = kernarg_at<nlm_args>(at);
   (void)a_by_value;
   extern __shared__ float lds[];
   const int chunk = order[blockIdx.x];

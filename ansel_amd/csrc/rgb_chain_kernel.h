@@ -24,7 +24,8 @@ struct chain_args
 };
 
 // offset of the by-value chain_args in the kernarg segment of rgb_chain(): after two pointers and a size_t
-constexpr int CHAIN_ARGS_KERNARG_OFFSET = 24;
+constexpr int CHAIN_ARGS_KERNARG_OFFSET = ansel::kernarg_offset_after<chain_args, const float4 *, void *, size_t>();
+static_assert(CHAIN_ARGS_KERNARG_OFFSET == 24, "rgb_chain: the by-value chain_args follows two pointers and a size_t");
 constexpr int CM_NONE = -1;
 constexpr int FM_NONE = -1;
 

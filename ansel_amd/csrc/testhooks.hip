@@ -1,6 +1,7 @@
 // testhooks.hip -- device-side self-test entry points (not part of include/ansel_hip.h).
 #include "hip_common.h"
 #include "devmath.h"
+#include "ieee_inrange.h"
 
 #include <atomic>
 #include <string.h>
@@ -47,6 +48,10 @@ __global__ void devmath_test(const float *__restrict__ x, const float *__restric
     else if(FN == 6) r = ansel_math::sinf_exact(x[k]);
     else if(FN == 7) r = ansel_math::cosf_exact(x[k]);
     else if(FN == 9) r = ansel_math::logf_exact(x[k]);
+    else if(FN == 10) r = ansel_ieee::div_core(x[k], y[k]);
+    else if(FN == 11) r = ansel_ieee::rcp_core(x[k]);
+    else if(FN == 12) r = ansel_ieee::sqrt_core(x[k]);
+    else if(FN == 13) r = ansel_ieee::zero_or_above_2m96(x[k]) ? 1.0f : 0.0f;
     else r = fmodf(x[k], y[k]); // the device library's: fmod is exact, any correct implementation agrees
     o[k] = r;
   }
@@ -69,4 +74,9 @@ int dt_hip_test_sinf(int devid, const void *x, const void *y, void *o, size_t n)
 int dt_hip_test_cosf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<7>(devid, x, y, o, n); }
 int dt_hip_test_fmodf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<8>(devid, x, y, o, n); }
 int dt_hip_test_logf(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<9>(devid, x, y, o, n); }
+// ieee_inrange.h: the division / reciprocal / square root without range scaffolding, on operands INSIDE their stated domains
+int dt_hip_test_div_core(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<10>(devid, x, y, o, n); }
+int dt_hip_test_rcp_core(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<11>(devid, x, y, o, n); }
+int dt_hip_test_sqrt_core(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<12>(devid, x, y, o, n); }
+int dt_hip_test_zero_or_above_2m96(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<13>(devid, x, y, o, n); }
 }

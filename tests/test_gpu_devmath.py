@@ -72,3 +72,90 @@ def test_device_libm_matches_host_libm(fn):
         getattr(hl, "libm_" + fn)(x.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
     same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
     assert same.all(), "%s: %d of %d results differ from libm" % (fn, int((~same).sum()), x.size)
+
+
+# ---- ieee_inrange.h: division / reciprocal / square root without the range scaffolding (round 5) -------------------------
+def _hook(name):
+    f = getattr(hc.hip(), "dt_hip_test_" + name)
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    return f
+
+
+def _run_hook(name, x, y=None):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(x if y is None else y, np.float32)
+    dx, dy = lib.DeviceBuffer.from_numpy(0, x), lib.DeviceBuffer.from_numpy(0, y)
+    do = lib.DeviceBuffer(0, x.nbytes)
+    lib.check(_hook(name)(0, dx.ptr, dy.ptr, do.ptr, x.size), name)
+    return do.to_numpy(x.shape, np.float32)
+
+
+def _floats(rng, n, e_lo, e_hi, signed=True):
+    """n floats with uniformly drawn exponents in [e_lo, e_hi] (unbiased), random 23-bit mantissas (the all-zero and all-one
+    mantissas over-represented: the rounding boundaries)"""
+    e = rng.integers(e_lo, e_hi + 1, n, dtype=np.int64)
+    m = rng.integers(0, 1 << 23, n, dtype=np.int64)
+    pick = rng.integers(0, 8, n)
+    m = np.where(pick == 0, 0, np.where(pick == 1, (1 << 23) - 1, np.where(pick == 2, 1, m)))
+    s = rng.integers(0, 2, n, dtype=np.int64) if signed else np.zeros(n, np.int64)
+    return (((s << 31) | ((e + 127) << 23) | m).astype(np.uint32)).view(np.float32)
+
+
+def test_inrange_division_is_the_ieee_division_on_its_domain():
+    """div_core(a, b), ansel_amd/csrc/ieee_inrange.h: b normal below 2^126, |a| >= 2^-103, -125 <= e(a) - e(b) < 96 -- the
+    domain in which v_div_scale / v_div_fmas / v_div_fixup do nothing.  Against the host's (correctly rounded) division."""
+    rng = np.random.default_rng(51)
+    n = 4_000_000
+    b = _floats(rng, n, -126, 125)
+    eb = ((b.view(np.uint32) >> 23) & 0xff).astype(np.int64) - 127
+    lo = np.maximum(-103, eb - 125)
+    hi = np.minimum(127, eb + 95)
+    ea = lo + (rng.random(n) * (hi - lo + 1)).astype(np.int64)
+    ea = np.clip(ea, lo, hi)
+    a = _floats(rng, n, 0, 0)
+    a = ((a.view(np.uint32) & 0x807fffff) | ((ea + 127).astype(np.uint32) << 23)).view(np.float32)
+    # what the diffusion kernel feeds it: |h| <= 2^64 over divisors in [1e-8, 2^64]
+    b2 = np.abs(_floats(rng, n, -27, 64)) + np.float32(1e-8)
+    a2 = _floats(rng, n, -103, 64)
+    a = np.concatenate([a, a2, (rng.random(n, dtype=np.float32) * 2 - 1)])
+    b = np.concatenate([b, b2, rng.random(n, dtype=np.float32) + np.float32(1e-8)])
+    got = _run_hook("div_core", a, b)
+    with np.errstate(all="ignore"):
+        exp = (a / b).astype(np.float32)
+    bad = got.view(np.uint32) != exp.view(np.uint32)
+    assert not bad.any(), "%d of %d quotients differ, first a=%r b=%r got=%r exp=%r" % (
+        int(bad.sum()), a.size, a[bad][0], b[bad][0], got[bad][0], exp[bad][0])
+    # zero numerators: +0 whatever the signs (the callers square it / add it to a non-negative)
+    z = _run_hook("div_core", np.array([0.0, -0.0, 0.0, -0.0], np.float32), np.array([1e-8, 1e-8, -3.5, 2.0 ** 100], np.float32))
+    assert (z.view(np.uint32) == 0).all()
+
+
+def test_inrange_reciprocal_and_square_root():
+    rng = np.random.default_rng(52)
+    n = 4_000_000
+    b = np.concatenate([_floats(rng, n, -126, 125), _floats(rng, n, -48, 64, signed=False), np.ones(8, np.float32)])
+    got = _run_hook("rcp_core", b)
+    exp = (np.float32(1.0) / b).astype(np.float32)
+    bad = got.view(np.uint32) != exp.view(np.uint32)
+    assert not bad.any(), "%d reciprocals differ, first b=%r got=%r exp=%r" % (int(bad.sum()), b[bad][0], got[bad][0], exp[bad][0])
+    x = np.concatenate([_floats(rng, n, -96, 127, signed=False), np.zeros(8, np.float32),
+                        (rng.random(n, dtype=np.float32) ** 4).astype(np.float32) * np.float32(1e-3) + np.float32(2.0 ** -96),
+                        np.array([2.0 ** -96, np.finfo(np.float32).max, 1.0, 4.0, 2.0], np.float32)])
+    got = _run_hook("sqrt_core", x)
+    exp = np.sqrt(x).astype(np.float32)
+    bad = got.view(np.uint32) != exp.view(np.uint32)
+    assert not bad.any(), "%d square roots differ, first x=%r got=%r exp=%r" % (int(bad.sum()), x[bad][0], got[bad][0], exp[bad][0])
+
+
+def test_inrange_guard_is_the_stated_interval():
+    """zero_or_above_2m96(): +-0 or 2^-96 <= |x| < inf, nothing else (NaN, infinities, everything below 2^-96 fail)"""
+    rng = np.random.default_rng(53)
+    x = np.concatenate([rng.integers(0, 2**32, 3_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                        _floats(rng, 1_000_000, -100, -92), np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 2.0 ** -96,
+                        np.nextafter(np.float32(2.0 ** -96), np.float32(0)), np.finfo(np.float32).max, 1e-45], np.float32)])
+    got = _run_hook("zero_or_above_2m96", x) != 0
+    with np.errstate(all="ignore"):
+        ax = np.abs(x)
+        exp = (x == 0) | ((ax >= np.float32(2.0 ** -96)) & np.isfinite(x))
+    assert (got == exp).all()

@@ -1,0 +1,66 @@
+"""What the compiler made of the shipped kernels, read from the code objects' metadata (tools/kernel_resources.py):
+no scratch memory in the hot kernels of the export pipe (round 4's review found 12 - 24 bytes with folded spills in the
+first wavelet scale while DESIGN.md said "no spills"), register counts that keep the occupancy DESIGN.md quotes, and the
+kernarg offsets the kernels read their by-value parameter blocks at (hip_common.h kernarg_at())."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources as kr  # noqa: E402
+
+OBJ = os.path.join(ROOT, "ansel_amd", "csrc", "_obj")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.isdir(OBJ) or not any(f.endswith(".o") for f in os.listdir(OBJ)):
+        pytest.skip("no objects under ansel_amd/csrc/_obj (run __graft_entry__.build())")
+    rows = kr.table(OBJ)
+    assert len(rows) > 100
+    return rows
+
+
+# the kernels of the metric's workload (bench.py's full pipe, every launch group) and of the other BASELINE configurations
+HOT = [r"^void dn_decompose_strip<", r"^void diffuse_pde_strip<(true|false), \d+>", r"bspline_decompose_strip", r"^void nlm_chunks_v3<9, 6>",
+       r"^void nlm_chunks_v4<9, 7>", r"^void nlm_tail<", r"^void ansel::rgb_chain<", r"^void dn_finish_chain<", r"rcd_tiles", r"raw_chain",
+       r"bilat_(zcells|splat2|blur_line|blur_line_z|slice)", r"dn_band_(sums|threshold)", r"^void filmic_kernel<", r"conv_kernel|colorspace"]
+
+
+def test_hot_kernels_use_no_scratch(kernels):
+    hot = [k for k in kernels if any(re.search(p, k["demangled"]) for p in HOT)]
+    assert len(hot) >= 60, "the patterns must find the pipe's kernels: %d" % len(hot)
+    bad = ["%s: %d B scratch, %d VGPR + %d SGPR spills" % (k["demangled"][:80], k["scratch"], k["vgpr_spills"], k["sgpr_spills"])
+           for k in hot if k["scratch"] != 0 or k["vgpr_spills"] != 0]
+    assert not bad, "\n".join(bad)
+
+
+def test_occupancy_bounds_design_quotes(kernels):
+    by = {}
+    for k in kernels:
+        by.setdefault(re.sub(r"\(.*", "", k["demangled"]), k)
+    # eight workgroups of four waves a CU: <= 64 VGPRs for every wavelet launch a frame's seven scales take
+    for name, k in by.items():
+        if name.startswith("void dn_decompose_strip<") and not name.startswith("void dn_decompose_strip<true, 0"):
+            assert k["vgpr"] <= 64, (name, k["vgpr"])
+        # four waves a SIMD: <= 128 for the preset modes of the diffusion PDE and for the sixteen-wave non-local-means workgroups
+        if re.match(r"void diffuse_pde_strip<(true|false), \d+>", name) or name.startswith("void nlm_chunks_v"):
+            assert k["vgpr"] <= 128, (name, k["vgpr"])
+
+
+def test_kernarg_offsets_match_what_the_kernels_read(kernels):
+    """kernarg_at<T>(offset) reads a by-value argument in place; the offset each kernel computes (and static_asserts) must be
+    where the code object says the argument is"""
+    want = {r"^void filmic_kernel<": (3, 24), r"^void blend_kernel<": (3, 24), r"^void blend_mask_kernel<": (3, 24),
+            r"^void nlm_chunks_v3<": (2, 16), r"^void nlm_chunks_v4<": (2, 16), r"^void ansel::rgb_chain<": (3, 24)}
+    seen = set()
+    for k in kernels:
+        for pat, (index, offset) in want.items():
+            if re.search(pat, k["demangled"]):
+                seen.add(pat)
+                off, size, kind = k["args"][index]
+                assert kind == "by_value" and off == offset and size > 16, (k["demangled"][:60], k["args"][:5])
+    assert seen == set(want)

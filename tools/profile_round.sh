@@ -23,6 +23,10 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INS
   --output-format csv -d "$OUT/sqb" -- python bench.py "$@" $Q --steps 3 --warmup 1 > "$OUT/sqb.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
   --output-format csv -d "$OUT/sqc" -- python bench.py "$@" $Q --steps 3 --warmup 1 > "$OUT/sqc.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/grbm" -- python bench.py "$@" $Q --steps 3 --warmup 1 > "$OUT/grbm.log" 2>&1
+G=$(find "$OUT/grbm" -name '*counter_collection.csv' | head -1)
+[ -n "$G" ] && python tools/pmc_sclk_json.py "$G" "$OUT/sclk_per_kernel.json" "bench.py $* (the timed steps only);" > "$OUT/sclk_per_kernel.txt"
+rm -rf "$OUT/grbm"
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/write" -name '*counter_collection.csv' | head -1)
 S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
