@@ -161,10 +161,17 @@ template <int T0, int T1, int ROWBYTES, class Env> struct column_chain
 //   * the row recurrence needs no clipping at all: in front of the first weighed column it adds zeros;
 //   * C gives weight +0 to the pixels the offset does not reach (their shifted pixel is a zero of the window).
 // The chunk may be narrower / lower than the grid's (the frame's last column and row of chunks).
-template <int NPXL, int MSEG, bool BORDER = false, bool FUSED = false, class Env, class Args, class F4, class I2>
+// TALL (round 5; FUSED, interior chunks): the chunk grid's rows are higher than the body holds (65 - 69: the 24 / 42 / 150 MP
+// frames).  The body runs the chunk's first TALL_HEAD rows exactly as it runs a chunk of that height -- window, tables,
+// chains: nothing below row TALL_HEAD - 1 enters them -- and its A2 lanes store, per offset, the column sum they hold behind
+// the last row to seeds_out[offset][slot]: nlm_tail_body.h continues the recurrence from there through the rows that are left.
+constexpr int TALL_HEAD = 64;
+constexpr int TALL_SEED_PITCH = 80; // floats per offset (NLT_SEED_PITCH)
+template <int NPXL, int MSEG, bool BORDER = false, bool FUSED = false, bool TALL = false, class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
-                  const int ndx)
+                  const int ndx, float *__restrict__ seeds_out = nullptr)
 {
+  static_assert(!TALL || (FUSED && !BORDER), "the head of a tall chunk runs on the fused interior body");
   constexpr int P = 2, S = 2 * P + 1, TP = NL3_TP, XO = NL3_XO, FP = NL3_FP, WPH = NL3_WPH;
   constexpr int MAXCH = FUSED ? FUSED_MAXCH : max_rows<NPXL>();
   constexpr int NT = FUSED ? 3 : 4; // tables: offset p lives in table tslot(p) from its A1 to its C
@@ -176,11 +183,12 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int cy = cy_launch + a.cy0;
   const int top = cy * a.chk_h, left = cx * a.chk_w;
   const int bot = imin(top + a.chk_h, H), right = imin(left + a.chk_w, W);
-  const int ch = bot - top, cw = right - left;
+  const int ch_grid = bot - top, cw = right - left;
   const int reach = a.reach;
   // interior: the chunk is whole and no patch of any offset reaches past the frame (uniform, before any barrier)
-  const bool interior = top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w;
-  if(BORDER ? (interior || !border_fits(cw, ch)) : !interior) return;
+  const bool interior = top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch_grid == a.chk_h && cw == a.chk_w;
+  if(BORDER ? (interior || !border_fits(cw, ch_grid)) : !interior) return;
+  const int ch = TALL ? TALL_HEAD : ch_grid; // the rows this body computes
 
   float *const lds = env.lds();
   constexpr int tabsz = MAXCH * TP;
@@ -465,6 +473,11 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         float *const wave_base = tab + tslot(p) * tabsz + XO + 1 + w * 64; // lane 0's column
         env.template st_addtid<0>(wave_base, lane, v);
         column_chain<1, MAXCH, TP * 4, Env>::run(env, wave_base, lane, v, term);
+        if constexpr(TALL)
+        {
+          static_assert(!TALL || MAXCH == TALL_HEAD, "the exported sum is the one behind the head's last row");
+          seeds_out[(size_t)p * TALL_SEED_PITCH + x] = v;
+        }
       }
       env.sync();
     }

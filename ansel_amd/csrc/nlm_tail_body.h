@@ -1,0 +1,270 @@
+// nlm_tail_body.h -- the rows of a TALL non-local-means chunk behind its 64th (round 5).
+//
+// The reference's chunk height is a function of the frame (compute_slice_height(), src/pixel/nlmeans_core.c:264-295): 69
+// rows at 24 MP (6000 x 4000), 68 at 42 MP, 67 at 150 MP.  The fused chunk kernel (nlm3_body.h FUSED, nlm_chunks_v4) holds
+// at most 64 rows in one workgroup -- 69 rows x 8 lanes of its weights' role are nine waves (2 + 6 + 9 = 17 > 16) and three
+// tables + the window 169 KB -- so until round 5 those frames took the second version at half the rate per pixel.  Now a
+// tall chunk is cut where the running sums allow it: the recurrence down the rows (nlmeans_core.c:437-488) is one sum per
+// table column and offset, so the fused kernel runs the chunk's first 64 rows unchanged ("head": same window, same tables,
+// same chains) and its column-recurrence waves EXPORT, per offset, the 72 + 4 column sums they hold behind row 63
+// (304 bytes); this body continues them through the 1 - 5 rows that are left ("tail"), every term, sum and weight formed
+// by the same operations on the same operands in the same order as the bodies of nlm2_body.h / nlm3_body.h form them.
+//
+// One workgroup of 512 threads per interior chunk, four stages in flight, one barrier per offset:
+//   (a) offset s      waves 2-7   a lane = (table column x, tail row j): the term D(row + P) - D(row - P - 1) of the column
+//                                 recurrence (the lane's own two pixels stay in registers for the chunk)      -> T[s % 3]
+//   (b) offset s - 1  wave 1 + twelve lanes of wave 0   a lane = a table column: the exported sum + its <= 5 terms, in place
+//   (c) offset s - 2  lanes 0-4 of wave 0   a lane = a tail row: the sliding row sum (:405-415), 72 dependent additions
+//                                                                                                              -> D[s % 2]
+//   (d) offset s - 3  waves 2-7   a lane = a pixel: weight 2^-(distortion x sharpness), four accumulations (:416-436)
+// then the normalisation and the blend (:490-521).  A workgroup needs ~35 KB of LDS (the window is 19 + <= 5 rows): four of
+// them share a CU and hide each other's row chain.  Compiled for the host by tests/native/nlm2_host.cpp like the others.
+#pragma once
+
+#include "nlm2_body.h"
+#include "nlm3_body.h" // f4, ld4(), st4()
+
+#define NLT_THREADS 512
+#define NLT_WP 92         // window pitch in pixels (chunk width + 2 x reach <= 92, as nlm2_body.h's tight layout)
+#define NLT_TP 80         // table pitch in floats: slots 0 .. chunk width + 4
+#define NLT_ROWS 5        // most tail rows: chunks are at most 69 rows high, the head takes 64
+#define NLT_SEED_PITCH 80 // floats per offset in the export: slot x of the table at word x
+#define NLT_HEAD_ROWS 64
+
+namespace nlmt
+{
+using nlm2::f2;
+using nlm2::imin;
+
+// LDS floats of one workgroup
+inline size_t lds_floats(const int tail_rows, const int reach, const int npatch)
+{
+  const int wh = tail_rows + 2 * reach;
+  return (size_t)wh * NLT_WP * 3 + 3 * NLT_ROWS * NLT_TP + 2 * NLT_ROWS * NLT_TP + ((npatch + 3) & ~3);
+}
+
+inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach, const int npatch)
+{
+  return radius == 2 && chk_h > NLT_HEAD_ROWS && chk_h - NLT_HEAD_ROWS <= NLT_ROWS && chk_w + 2 * reach <= NLT_WP && chk_w + 5 <= NLT_TP
+         && reach >= 3 && (chk_w + 4) * NLT_ROWS <= NLT_THREADS - 128 && npatch <= 4096;
+}
+
+// Env: tid(), bid(), lds(), sync(), cvt_i32_sat(), int_as_float(), max_num().  Args: nlm_args of nlmeans.hip.
+// seeds: this chunk's exported column sums, [npatch][NLT_SEED_PITCH].
+template <class Env, class Args, class F4, class I2>
+NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
+                  const float *__restrict__ seeds)
+{
+  constexpr int P = 2, S = 2 * P + 1, WP = NLT_WP, TP = NLT_TP;
+  const int tid = env.tid();
+  const int W = a.W, H = a.H;
+  const int cy_launch = env.bid() / a.nchx, cx = env.bid() - cy_launch * a.nchx;
+  const int cy = cy_launch + a.cy0;
+  const int top = cy * a.chk_h, left = cx * a.chk_w;
+  const int bot = imin(top + a.chk_h, H), right = imin(left + a.chk_w, W);
+  const int ch = bot - top, cw = right - left;
+  const int reach = a.reach;
+  // the launch lists interior chunks only (the test of nlm3::body()): whole, no patch of any offset past the frame
+  if(!(top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w)) return;
+  const int R0 = NLT_HEAD_ROWS, TR = ch - R0; // the tail: chunk rows R0 .. ch - 1
+  const int n = a.npatch;
+  const int ncol = cw + 2 * P; // table slots 1 .. ncol (slot x = frame column left - P - 1 + x); slot 0 is never summed
+
+  float *const lds = env.lds();
+  const int wh = TR + 2 * reach; // window row wy = frame row top + R0 - reach + wy, window column wx = frame column left - reach + wx
+  f2 *const XY = (f2 *)lds;                  // [wh][WP]
+  float *const Z = lds + 2 * wh * WP;        // [wh][WP]
+  float *const Tb = Z + wh * WP;             // [3][NLT_ROWS][TP]: terms, then column sums
+  float *const Db = Tb + 3 * NLT_ROWS * TP;  // [2][NLT_ROWS][TP]: distortions
+  int *const dsv = (int *)(Db + 2 * NLT_ROWS * TP); // window shift of every offset
+  const int r0 = top + R0 - reach, c0 = left - reach;
+  const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
+
+  for(int i = tid; i < wh * WP; i += NLT_THREADS)
+  {
+    const int wy = i / WP, wx = i - wy * WP;
+    const int c = c0 + wx;
+    F4 v;
+    v.x = v.y = v.z = v.w = 0.0f;
+    if(c < W) v = in[(long)(r0 + wy) * W + c]; // the pitch may run past the frame's right edge; the rows are inside it
+    f2 xy;
+    xy.x = v.x;
+    xy.y = v.y;
+    XY[i] = xy;
+    Z[i] = v.z;
+  }
+  for(int i = tid; i < n; i += NLT_THREADS) dsv[i] = patches[i].x * WP + patches[i].y;
+  env.sync();
+
+  const int w = tid >> 6, lane = tid & 63;
+  const int u = tid - 128;
+  // ---- (a): the lane's term, and its two own pixels
+  const bool a_on = w >= 2 && u < ncol * TR;
+  const int aj = a_on ? u / ncol : 0, ax = a_on ? 1 + u - aj * ncol : 1;
+  const int awc = reach - P - 1 + ax;
+  const int a_enter = (aj + P + reach) * WP + awc, a_leave = (aj - P - 1 + reach) * WP + awc; // rows R0 + aj + P and R0 + aj - P - 1
+  const f2 oe_xy = XY[a_enter], ol_xy = XY[a_leave];
+  const float oe_z = Z[a_enter], ol_z = Z[a_leave];
+  // ---- (b): the lane's table column
+  const bool b_on = (w == 1 && 1 + lane <= ncol) || (w == 0 && lane >= 16 && 49 + lane <= ncol);
+  const int bx = w == 1 ? 1 + lane : 49 + lane; // wave 1: slots 1 .. 64; lanes 16 .. 27 of wave 0: slots 65 .. 76
+  // ---- (c): the lane's tail row
+  const bool c_on = w == 0 && lane < TR;
+  // ---- (d): the lane's pixel
+  const bool d_on = w >= 2 && u < cw * TR;
+  const int dj = d_on ? u / cw : 0, dc = d_on ? u - dj * cw : 0;
+  const int d_win = (dj + reach) * WP + reach + dc;
+  float accx = 0.0f, accy = 0.0f, accz = 0.0f, accw = 0.0f;
+  const float sharp_m23 = a.sharpness * -8388608.0f;
+  float seed = b_on ? seeds[bx] : 0.0f; // offset 0's, for stage 1
+
+  for(int s = 0; s < n + 3; s++)
+  {
+    if(a_on && s < n)
+    {
+      // nlmeans_core.c:437-488 as nlm3_body.h's A1 forms it: (own - shifted)^2 per channel of the entering and of the leaving
+      // row, term = ((nx2 - px2) n0 + (ny2 - py2) n1) + (nz2 - pz2) n2
+      const int dS = dsv[s];
+      const f2 se = XY[a_enter + dS], sl = XY[a_leave + dS];
+      const float sez = Z[a_enter + dS], slz = Z[a_leave + dS];
+      const float ex = oe_xy.x - se.x, ey = oe_xy.y - se.y, ez = oe_z - sez;
+      const float lx = ol_xy.x - sl.x, ly = ol_xy.y - sl.y, lz = ol_z - slz;
+      const float nx2 = ex * ex, ny2 = ey * ey, nz2 = ez * ez;
+      const float px2 = lx * lx, py2 = ly * ly, pz2 = lz * lz;
+      Tb[((s % 3) * NLT_ROWS + aj) * TP + ax] = ((nx2 - px2) * n0 + (ny2 - py2) * n1) + (nz2 - pz2) * n2;
+    }
+    if(b_on && s >= 1 && s <= n)
+    {
+      // the column recurrence continued from the exported sum (nlm3_body.h column_chain: v = v + term)
+      float *const col = Tb + (((s - 1) % 3) * NLT_ROWS) * TP + bx;
+      float v = seed;
+      if(s < n) seed = seeds[(size_t)s * NLT_SEED_PITCH + bx]; // the next offset's, a stage ahead
+#pragma unroll
+      for(int j = 0; j < NLT_ROWS; j++)
+      {
+        if(j < TR)
+        {
+          v = v + col[j * TP];
+          col[j * TP] = v;
+        }
+      }
+    }
+    if(c_on && s >= 2 && s <= n + 1)
+    {
+      // the sliding row sum (:405-415) as nlm3_body.h's B role forms it: slot 0 is never summed, the first four slots
+      // added onto +0 in order, then one (entering - leaving) per column
+      const float *const cs = Tb + (((s - 2) % 3) * NLT_ROWS + lane) * TP;
+      float *const d = Db + (((s - 2) & 1) * NLT_ROWS + lane) * TP;
+      // the row in batches of sixteen columns (sixteen-byte accesses: the rows are 16-byte aligned), the five slots that
+      // leave the window next carried in registers; columns beyond the chunk's (a 64- or 68-column grid) compute on
+      // whatever the table holds there and are never read
+      float head[8];
+      {
+        const nlm3::f4 h0 = nlm3::ld4(cs), h1 = nlm3::ld4(cs + 4);
+        head[0] = 0.0f; // slot 0
+        head[1] = h0.y;
+        head[2] = h0.z;
+        head[3] = h0.w;
+        head[4] = h1.x;
+        head[5] = h1.y;
+        head[6] = h1.z;
+        head[7] = h1.w;
+      }
+      float distortion = 0.0f;
+#pragma unroll
+      for(int kk = 1; kk < S; kk++) distortion += head[kk];
+      // lo[k] = slot jb + k (leaving at column jb + k), hi = slots jb + 5 .. (entering)
+      float lo[S];
+#pragma unroll
+      for(int k = 0; k < S; k++) lo[k] = head[k];
+      float pend[3] = { head[5], head[6], head[7] }; // slots jb + 5 .. jb + 7, fetched with the batch before
+#pragma unroll
+      for(int jb = 0; jb < 80; jb += 16)
+      {
+        if(jb < cw)
+        {
+          // slots jb + 8 .. jb + 23
+          float in16[16];
+#pragma unroll
+          for(int q = 0; q < 16; q += 4)
+          {
+            nlm3::f4 v;
+            v.x = v.y = v.z = v.w = 0.0f;
+            if(jb + 8 + q < TP) v = nlm3::ld4(cs + jb + 8 + q);
+            in16[q] = v.x;
+            in16[q + 1] = v.y;
+            in16[q + 2] = v.z;
+            in16[q + 3] = v.w;
+          }
+          float slot[S + 16 + 3]; // slots jb .. jb + 23
+#pragma unroll
+          for(int k = 0; k < S; k++) slot[k] = lo[k];
+#pragma unroll
+          for(int k = 0; k < 3; k++) slot[S + k] = pend[k];
+#pragma unroll
+          for(int k = 0; k < 16; k++) slot[S + 3 + k] = in16[k];
+          float dd[16];
+#pragma unroll
+          for(int k = 0; k < 16; k++)
+          {
+            distortion = distortion + (slot[k + S] - slot[k]);
+            dd[k] = distortion;
+          }
+#pragma unroll
+          for(int q = 0; q < 16; q += 4)
+          {
+            nlm3::f4 v;
+            v.x = dd[q];
+            v.y = dd[q + 1];
+            v.z = dd[q + 2];
+            v.w = dd[q + 3];
+            if(jb + q < TP) nlm3::st4(d + jb + q, v);
+          }
+#pragma unroll
+          for(int k = 0; k < S; k++) lo[k] = slot[16 + k];
+#pragma unroll
+          for(int k = 0; k < 3; k++) pend[k] = slot[16 + S + k];
+        }
+      }
+    }
+    if(d_on && s >= 3)
+    {
+      const int p = s - 3;
+      const int wo = d_win + dsv[p];
+      const float dist = Db[((p & 1) * NLT_ROWS + dj) * TP + dc];
+      const f2 q = XY[wo];
+      const float qz = Z[wo];
+      const float wgt = nlm2::mexp2_scaled<Env>(dist, sharp_m23);
+      accx = accx + q.x * wgt;
+      accy = accy + q.y * wgt;
+      accz = accz + qz * wgt;
+      accw = accw + 1.0f * wgt;
+    }
+    env.sync();
+  }
+
+  // ---- normalise, blend (:490-521)
+  if(!d_on) return;
+  const int row = top + R0 + dj;
+  if(row < a.out_row0 || row >= a.out_row1) return;
+  const long o = (long)row * W + left + dc;
+  F4 res;
+  if(a.skip_blend)
+  {
+    res.x = accx / accw;
+    res.y = accy / accw;
+    res.z = accz / accw;
+    res.w = accw / accw;
+  }
+  else
+  {
+    const F4 ip = in[o];
+    res.x = (ip.x * (1.0f - a.luma)) + (accx / accw * a.luma);
+    res.y = (ip.y * (1.0f - a.chroma)) + (accy / accw * a.chroma);
+    res.z = (ip.z * (1.0f - a.chroma)) + (accz / accw * a.chroma);
+    res.w = (ip.w * 0.0f) + (accw / accw * 1.0f);
+  }
+  out[o] = res;
+}
+
+} // namespace nlmt

@@ -24,6 +24,7 @@
 #include "nlmeans_core_params.h"
 #include "nlm2_body.h"
 #include "nlm3_body.h"
+#include "nlm_tail_body.h"
 
 #include <math.h>
 #include <algorithm>
@@ -893,10 +894,14 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__res
 
 // the fused variant of the third version (nlm3_body.h, FUSED): three tables, the row recurrence inside the C role --
 // chunks of up to 64 rows (the 45 MP and 60 MP frames' grids)
-template <int NPXL, int MSEG>
+// TALL (round 5): a chunk grid of 65 - 69 rows (the 24 / 42 / 150 MP frames).  Interior chunks: the body runs the first 64 rows
+// and exports the column sums behind them, per offset, to seeds[interior ordinal][offset][slot] (nlm3_body.h TALL); nlm_tail
+// below continues them through the rows that are left.  The outermost ring keeps the first version's body, whole chunks.
+template <int NPXL, int MSEG, bool TALL>
 __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                              const nlm_args a_by_value, const int2 *__restrict__ patches,
-                                                             const int *__restrict__ order, const int n_border, const int ndx)
+                                                             const int *__restrict__ order, const int n_border, const int ndx,
+                                                             float *__restrict__ seeds)
 {
   constexpr int at = kernarg_offset_after<nlm_args, const float4 *, float4 *>(); // (see nlm_chunks_v3)
   static_assert(at == 16, "nlm_chunks_v4: the by-value nlm_args follows the two plane pointers");
@@ -911,11 +916,29 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__res
   {
     const int cy = chunk / a.nchx + a.cy0, cx = chunk % a.nchx;
     const int cw = min(a.chk_w, a.W - cx * a.chk_w), ch = min(a.chk_h, a.H - cy * a.chk_h);
-    if(!nlm3::border_fits(cw, ch)) pipelined_body(chunk, lds, in, out, a, patches);
+    if(TALL || !nlm3::border_fits(cw, ch)) pipelined_body(chunk, lds, in, out, a, patches);
     else nlm3::body<NPXL, MSEG, true, true>(env, in, out, a, patches, ndx);
     return;
   }
-  nlm3::body<NPXL, MSEG, false, true>(env, in, out, a, patches, ndx);
+  if constexpr(TALL)
+    nlm3::body<NPXL, MSEG, false, true, true>(env, in, out, a, patches, ndx,
+                                              seeds + (size_t)(blockIdx.x - n_border) * a.npatch * nlm3::TALL_SEED_PITCH);
+  else
+    nlm3::body<NPXL, MSEG, false, true>(env, in, out, a, patches, ndx);
+}
+
+// the rows of the interior chunks of a tall grid behind the 64th (nlm_tail_body.h): one workgroup of 512 threads per
+// interior chunk, in the order (and with the export slots) of the head launch
+__global__ __launch_bounds__(NLT_THREADS, 2) void nlm_tail(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                           const nlm_args a, const int2 *__restrict__ patches,
+                                                           const int *__restrict__ order, const int n_border,
+                                                           const float *__restrict__ seeds)
+{
+  extern __shared__ float lds[];
+  nlm2_device_env env;
+  env.lds_ = lds;
+  env.chunk_ = order[n_border + blockIdx.x];
+  nlmt::body(env, in, out, a, patches, seeds + (size_t)blockIdx.x * a.npatch * NLT_SEED_PITCH);
 }
 
 typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
@@ -1087,6 +1110,13 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   const bool force_fused = dispatch_override(DISPATCH_NLM_FUSED) || (fused_env && atoi(fused_env) != 0);
   const bool v4 = v2 && nlm3::fits_fused<9, 7>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                   && v4_bytes <= 160 * 1024 && !force_v2 && (force_fused || !(v3 && v3_bytes <= 160 * 1024));
+  // chunk grids of 65 - 69 rows (24 / 42 / 150 MP): the fused body on the first 64 rows of every interior chunk + nlm_tail
+  static_assert(NLT_HEAD_ROWS == nlm3::TALL_HEAD && NLT_SEED_PITCH == nlm3::TALL_SEED_PITCH, "head and tail share the export's layout");
+  const size_t tall_bytes = std::max(nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach) * sizeof(float), pipe_bytes);
+  const size_t tail_bytes = nlmt::lds_floats(a.chk_h - NLT_HEAD_ROWS, a.reach, a.npatch) * sizeof(float);
+  const bool tall = v2 && !v3 && !v4 && !force_v2 && nlmt::fits(a.chk_w, a.chk_h, a.radius, a.reach, a.npatch)
+                    && nlm3::fits_fused<9, 7>(a.chk_w, NLT_HEAD_ROWS, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
+                    && tall_bytes <= 160 * 1024 && tail_bytes <= 64 * 1024;
   static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS && NL3_THREADS == NLM_THREADS,
                 "nlm_chunks_v2 / _v3 share the launch shape of nlm_chunks_pipelined");
   nlm2_kernel_t k2 = nullptr;
@@ -1133,14 +1163,30 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     return DT_HIP_DEFAULT_ERROR;
   }
   const int *const dev_order = (const int *)((const unsigned char *)dev_patches + patch_bytes);
+  float *seeds = nullptr;
+  if(tall && nchunks > n_border)
+  {
+    seeds = (float *)dt_hip_alloc_device_buffer(devid, (size_t)(nchunks - n_border) * a.npatch * NLT_SEED_PITCH * sizeof(float));
+    if(!seeds)
+    {
+      dt_hip_release_mem_object(dev_patches);
+      return DT_HIP_SYSMEM_ALLOCATION;
+    }
+  }
   {
     launch_scope ls(devid, "nlm_chunks");
     const unsigned grid = (unsigned)nchunks;
-    if(v4)
+    if(tall)
     {
-      const auto k4 = nlm_chunks_v4<9, 7>;
+      const auto kt = nlm_chunks_v4<9, 7, true>;
+      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_bytes));
+      kt<<<grid, NL3_THREADS, tall_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, seeds);
+    }
+    else if(v4)
+    {
+      const auto k4 = nlm_chunks_v4<9, 7, false>;
       ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v4_bytes));
-      k4<<<grid, NL3_THREADS, v4_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3);
+      k4<<<grid, NL3_THREADS, v4_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, nullptr);
     }
     else if(v3 && v3_bytes <= 160 * 1024)
     {
@@ -1157,8 +1203,16 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     else
       nlm_chunks<false><<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
   }
+  int err = check_launch("nlm_chunks");
+  if(err == DT_HIP_SUCCESS && tall && nchunks > n_border)
+  {
+    launch_scope ls(devid, "nlm_tail");
+    nlm_tail<<<(unsigned)(nchunks - n_border), NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, seeds);
+    err = check_launch("nlm_tail");
+  }
+  if(seeds) dt_hip_release_mem_object(seeds);
   dt_hip_release_mem_object(dev_patches);
-  return check_launch("nlm_chunks");
+  return err;
 }
 
 } // namespace ansel

@@ -15,6 +15,7 @@
 
 #include "nlm2_body.h"
 #include "nlm3_body.h"
+#include "nlm_tail_body.h"
 
 namespace
 {
@@ -330,5 +331,101 @@ static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, 
   if(interior_chunks) *interior_chunks = interior;
   if(fused) run3<9, 7, true>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx, border);
   else run3<9, 6>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx, border);
+  return 1;
+}
+
+// ---- a tall chunk grid (65 - 69 rows; round 5): the fused body on the first 64 rows of every interior chunk, exporting the
+//      column sums behind them (nlm3_body.h TALL), then nlm_tail_body.h on the rows that are left.  Interior chunks only
+//      (the device's launch hands the outermost ring to the first version's body).  Returns 1 when it ran, 0 when the
+//      configuration is not one the pair takes.
+extern "C" int nlm_tall_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                                 int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                                 float luma, float chroma, int *interior_chunks)
+{
+  std::vector<I2> patches;
+  int max_shift = 0;
+  for(int ri = -search_radius; ri <= search_radius; ri++)
+    for(int ci = -search_radius; ci <= search_radius; ci++)
+    {
+      const int r = scatter(scale, scattering, ri, ci), c = scatter(scale, scattering, ci, ri);
+      patches.push_back(I2{ r, c });
+      max_shift = std::max(max_shift, std::max(abs(r), abs(c)));
+    }
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.W = W;
+  a.H = H;
+  a.chk_w = chk_w;
+  a.chk_h = chk_h;
+  a.nchx = (W + chk_w - 1) / chk_w;
+  const int nchy = (H + chk_h - 1) / chk_h;
+  a.radius = patch_radius;
+  a.npatch = (int)patches.size();
+  a.sharpness = sharpness;
+  for(int k = 0; k < 3; k++) a.norm[k] = norm[k];
+  a.luma = luma;
+  a.chroma = chroma;
+  a.skip_blend = (luma == 1.0 && chroma == 1.0);
+  a.reach = patch_radius + 1 + max_shift;
+  a.cy0 = 0;
+  a.out_row0 = 0;
+  a.out_row1 = H;
+  int ndx = 0;
+  if(!nlmt::fits(chk_w, chk_h, patch_radius, a.reach, a.npatch) || !nlm3::fits_fused<9, 7>(chk_w, NLT_HEAD_ROWS, patch_radius, a.reach)
+     || !nlm3::regular_grid(patches.data(), a.npatch, &ndx))
+    return 0;
+  const size_t head_floats = nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach);
+  const size_t tail_floats = nlmt::lds_floats(chk_h - NLT_HEAD_ROWS, a.reach, a.npatch);
+  if(head_floats * sizeof(float) > 160 * 1024 || tail_floats * sizeof(float) > 64 * 1024) return 0;
+  int interior = 0;
+  for(int cy = 0; cy < nchy; cy++)
+    for(int cx = 0; cx < a.nchx; cx++)
+    {
+      const int top = cy * chk_h, left = cx * chk_w;
+      const int bot = std::min(top + chk_h, H), right = std::min(left + chk_w, W);
+      if(top >= a.reach && bot + a.reach <= H && left >= a.reach && right + a.reach <= W && bot - top == chk_h && right - left == chk_w)
+        interior++;
+    }
+  if(interior_chunks) *interior_chunks = interior;
+  const int nchunks = a.nchx * nchy;
+  const size_t per_chunk = (size_t)a.npatch * NLT_SEED_PITCH;
+  std::vector<float> seeds(per_chunk * nchunks, __builtin_nanf(""));
+  const F4 *const fin = (const F4 *)in;
+  F4 *const fout = (F4 *)out;
+  {
+    std::vector<float> lds(head_floats + 4096, 0.0f);
+    WaveExchange xch;
+    float *base = lds.data();
+    while((uintptr_t)base & 15) base++;
+    std::barrier<> bar(NL3_THREADS);
+    std::vector<std::thread> pool;
+    for(int t = 0; t < NL3_THREADS; t++)
+      pool.emplace_back([&, t]() {
+        for(int b = 0; b < nchunks; b++)
+        {
+          HostEnv env{ t, b, base, &bar, &xch };
+          nlm3::body<9, 7, false, true, true>(env, fin, fout, a, patches.data(), ndx, seeds.data() + per_chunk * b);
+          bar.arrive_and_wait();
+        }
+      });
+    for(auto &th : pool) th.join();
+  }
+  {
+    std::vector<float> lds(tail_floats + 4096, 0.0f);
+    float *base = lds.data();
+    while((uintptr_t)base & 15) base++;
+    std::barrier<> bar(NLT_THREADS);
+    std::vector<std::thread> pool;
+    for(int t = 0; t < NLT_THREADS; t++)
+      pool.emplace_back([&, t]() {
+        for(int b = 0; b < nchunks; b++)
+        {
+          HostEnv env{ t, b, base, &bar };
+          nlmt::body(env, fin, fout, a, patches.data(), seeds.data() + per_chunk * b);
+          bar.arrive_and_wait();
+        }
+      });
+    for(auto &th : pool) th.join();
+  }
   return 1;
 }

@@ -115,17 +115,27 @@ def test_inrange_division_is_the_ieee_division_on_its_domain():
     ea = np.clip(ea, lo, hi)
     a = _floats(rng, n, 0, 0)
     a = ((a.view(np.uint32) & 0x807fffff) | ((ea + 127).astype(np.uint32) << 23)).view(np.float32)
-    # what the diffusion kernel feeds it: |h| <= 2^64 over divisors in [1e-8, 2^64]
-    b2 = np.abs(_floats(rng, n, -27, 64)) + np.float32(1e-8)
-    a2 = _floats(rng, n, -103, 64)
-    a = np.concatenate([a, a2, (rng.random(n, dtype=np.float32) * 2 - 1)])
-    b = np.concatenate([b, b2, rng.random(n, dtype=np.float32) + np.float32(1e-8)])
+    a = np.concatenate([a, (rng.random(n, dtype=np.float32) * 2 - 1)])
+    b = np.concatenate([b, rng.random(n, dtype=np.float32) + np.float32(1e-8)])
     got = _run_hook("div_core", a, b)
     with np.errstate(all="ignore"):
         exp = (a / b).astype(np.float32)
     bad = got.view(np.uint32) != exp.view(np.uint32)
     assert not bad.any(), "%d of %d quotients differ, first a=%r b=%r got=%r exp=%r" % (
         int(bad.sum()), a.size, a[bad][0], b[bad][0], got[bad][0], exp[bad][0])
+    # what the diffusion kernel feeds it (diffuse.hip ratio2_rgb()): |h| <= 2^64 -- any magnitude below, subnormals and zeros
+    # included -- over divisors in [1e-8, 2^64].  Outside div_core()'s own domain (small numerators, subnormal quotients) the
+    # quotient may differ in its last bits, and the kernel only ever SQUARES it: the squares must be the same bits
+    b2 = np.abs(_floats(rng, n, -27, 63)) + np.float32(1e-8)
+    a2 = np.concatenate([_floats(rng, n // 2, -126, 64), (1e-39 * rng.random(n // 4)).astype(np.float32),
+                         _floats(rng, n // 4, -110, -95)])
+    got = _run_hook("div_core", a2, b2)
+    with np.errstate(all="ignore"):
+        exp = (a2 / b2).astype(np.float32)
+        sq_got, sq_exp = (got * got).astype(np.float32), (exp * exp).astype(np.float32)
+    bad = sq_got.view(np.uint32) != sq_exp.view(np.uint32)
+    assert not bad.any(), "%d squared ratios differ, first h=%r safe=%r got=%r exp=%r" % (
+        int(bad.sum()), a2[bad][0], b2[bad][0], got[bad][0], exp[bad][0])
     # zero numerators: +0 whatever the signs (the callers square it / add it to a non-negative)
     z = _run_hook("div_core", np.array([0.0, -0.0, 0.0, -0.0], np.float32), np.array([1e-8, 1e-8, -3.5, 2.0 ** 100], np.float32))
     assert (z.view(np.uint32) == 0).all()

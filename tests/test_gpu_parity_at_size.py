@@ -165,6 +165,13 @@ def test_light_pipe_24MP_with_amaze_equals_the_oracle():
     _case("light_amaze", "24MP", host_gib=6)
 
 
+def test_full_pipe_24MP_equals_the_oracle():
+    """the full pipe on the frame of BASELINE configs 1 and 2 -- 6000 x 4000, the commonest sensor: its non-local-means chunks
+    are 69 rows high, the grid the fused chunk kernel + nlm_tail take since round 5 (round 4's review, "weak" item 4: no record
+    ran the full pipe at 24 MP); whole and in 3 row bands (a band's chunk rows start inside the frame's grid)"""
+    _case("denoise", "24MP", bands=3, host_gib=24)
+
+
 def test_config3_full_pipe_60MP_equals_the_oracle():
     _case("denoise", "60MP", host_gib=48)
 

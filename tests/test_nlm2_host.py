@@ -18,6 +18,7 @@ SO = os.path.join(ROOT, "tests", "native", "libnlm2_host.so")
 SRC = os.path.join(ROOT, "tests", "native", "nlm2_host.cpp")
 HDR = os.path.join(ROOT, "ansel_amd", "csrc", "nlm2_body.h")
 HDR3 = os.path.join(ROOT, "ansel_amd", "csrc", "nlm3_body.h")
+HDRT = os.path.join(ROOT, "ansel_amd", "csrc", "nlm_tail_body.h")
 
 
 class NlmParams(C.Structure):  # oracle_nlm_params_t, oracle/src/nlmeans_core.h
@@ -28,7 +29,7 @@ class NlmParams(C.Structure):  # oracle_nlm_params_t, oracle/src/nlmeans_core.h
 
 @pytest.fixture(scope="module")
 def host_kernel():
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR3)):
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR3), os.path.getmtime(HDRT)):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
                                "-I" + os.path.join(ROOT, "ansel_amd", "csrc"), SRC, "-o", SO])
     return C.CDLL(SO)
@@ -235,3 +236,49 @@ def test_fused_variant_border_ring_on_the_host_equals_the_oracle(host_kernel, or
     nrows_last = h - (h - 1) // ch * ch
     expect = w * (h if nrows_last >= 10 else h - nrows_last)
     assert int(written.sum()) == expect
+
+
+# ---- tall chunk grids (65 - 69 rows: the 24 MP frame's 69, 42 MP's 68, 150 MP's 67; round 5): the fused body on a chunk's first
+#      64 rows, exporting the column sums behind them, and nlm_tail_body.h on the rows that are left
+# (width, height, search radius, luma, chroma, expected chunk, interior chunks)
+CASES_TALL = [
+    (256, 207, 2, 0.5, 1.0, (72, 69), 2),    # 69 rows: five tail rows, rows of 5 offsets
+    (260, 207, 7, 1.0, 1.0, (72, 69), 2),    # ... with the module's 225 offsets, no blend
+    (260, 204, 7, 0.5, 1.0, (72, 68), 2),    # 68 rows
+    (170, 201, 3, 0.3, 0.8, (64, 67), 1),    # 67 rows, 64-column chunks (slots beyond the chunk in the tail's row batches)
+    (260, 198, 3, 0.5, 1.0, (72, 66), 2),    # 66 rows
+    (250, 195, 3, 0.5, 0.9, (68, 65), 2),    # 65 rows: ONE tail row; 68-column chunks
+]
+
+
+@pytest.mark.parametrize("w,h,K,luma,chroma,chunk,n_interior", CASES_TALL)
+def test_tall_chunks_head_and_tail_on_the_host_equal_the_oracle(host_kernel, oracle_lib, w, h, K, luma, chroma, chunk, n_interior):
+    o = oracle_lib
+    P = 2
+    img = _lab(w, h, 17 + K)
+    p = NlmParams(0.0, 1.0, luma, chroma, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    assert (cw, ch) == chunk
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm_tall_host_run(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(0.0),
+                                       C.c_float(p.sharpness), p.norm, C.c_float(luma), C.c_float(chroma), C.byref(seen))
+    assert rc == 1
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    assert seen.value == n_interior
+    written = ~np.isnan(got[..., 0])
+    assert int(written.sum()) == n_interior * cw * ch, "head and tail together write every pixel of the interior chunks"
+    bad = written & (got.view(np.uint32) != want.view(np.uint32)).any(axis=-1)
+    assert int(bad.sum()) == 0, "%d of %d written pixels differ; first at %s" % (int(bad.sum()), int(written.sum()), np.argwhere(bad)[:5].tolist())
+
+
+def test_tall_pair_refuses_what_it_does_not_fit(host_kernel):
+    img = np.zeros((207, 256, 4), np.float32)
+    norm = (C.c_float * 4)(1, 1, 1, 1)
+    tail = (C.c_float(1.0), C.c_float(0.0), C.c_float(10.0), norm, C.c_float(1.0), C.c_float(1.0), None)
+    assert host_kernel.nlm_tall_host_run(ck.ptr(img), ck.ptr(img), 256, 192, 72, 64, 2, 2, *tail) == 0   # 64 rows: the fused variant's own
+    assert host_kernel.nlm_tall_host_run(ck.ptr(img), ck.ptr(img), 256, 207, 72, 69, 3, 2, *tail) == 0   # patch radius 3
+    assert host_kernel.nlm_tall_host_run(ck.ptr(img), ck.ptr(img), 256, 207, 72, 69, 2, 2, C.c_float(1.0), C.c_float(0.9), *tail[2:]) == 0  # scattered

@@ -10,8 +10,9 @@
 //   s_memrealtime  the constant 100 MHz reference
 // so that   sclk = 100 MHz x d(memtime) / d(memrealtime)   and   cycles per instruction per SIMD = d(memtime) / (W x N)
 // are both measured in the same loop, on every SIMD of the chip at once (the chip clocks to its power budget: one CU alone
-// runs faster).  A workgroup is 1024 threads = 16 waves = 4 per SIMD and owns its CU through its LDS request; W = 4: one
-// workgroup a CU, W = 8: two.  Streams: ILP independent chains per wave (1 = a dependent chain, 4, 8), 64 instructions of
+// runs faster).  ONE workgroup per CU (it owns the CU through its LDS request), 256 x W threads = W waves per SIMD, W = 2 and
+// 4, every wave released by the same barrier (a first version ran W = 8 as two workgroups per CU: their waves did not
+// overlap for the whole loop and the per-wave tick count read low).  Streams: ILP independent chains per wave (1 = a dependent chain, 4, 8), 64 instructions of
 // ONE class per loop trip, plus two mixes shaped like the kernels (the PDE's multiply / add / fma / compare / select mix
 // and the non-local-means weight: v_mul, v_max, v_cvt, v_add_u32, v_cmp, v_cndmask, 4 x v_fma-less multiply-adds).
 #include <hip/hip_runtime.h>
@@ -171,26 +172,26 @@ int main(int argc, char **argv)
          "(s_memtime) per wave64 instruction per SIMD = d(memtime) / (W x instructions per wave), median over the waves; sclk_mhz = 100 x "
          "d(memtime) / d(memrealtime), median; ns = wall time (HIP events) per instruction per SIMD; cycles_at_2400 = what round 2 - 4 "
          "called 'measured cycles' (wall x 2.4 GHz)\",\n \"classes\": {\n",
-         prop.name, cus, prop.clockRate / 1000, trips, trips * 64);
+         prop.gcnArchName, cus, prop.clockRate / 1000, trips, trips * 64);
   for(int op = 0; op < OP_COUNT; op++)
   {
     printf("  \"%s\": {", k_names[op]);
     bool first = true;
     const int ilps[3] = { 1, 4, 8 };
     for(int ii = 0; ii < 3; ii++)
-      for(int W = 4; W <= 8; W += 4)
+      for(int W = 2; W <= 4; W += 2)
       {
         const int ILP = ilps[ii];
         if((op == OP_MIX_PDE || op == OP_MIX_NLM) && ILP == 8) continue;
         const kern_t k = ILP == 1 ? kernel_of<1>(op) : (ILP == 4 ? kernel_of<4>(op) : kernel_of<8>(op));
-        // one workgroup a CU (W = 4) or two (W = 8): the LDS request keeps the dispatcher from stacking them unevenly
-        const size_t lds = W == 4 ? 96 * 1024 : 64 * 1024;
+        // one workgroup a CU: the LDS request keeps the dispatcher from stacking two
+        const size_t lds = 96 * 1024;
         CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int blocks = cus * (W / 4);
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), lds, 0, out, recs, 20); // warm-up
+        const int blocks = cus;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256 * W), lds, 0, out, recs, 20); // warm-up
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(a, 0));
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), lds, 0, out, recs, trips);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256 * W), lds, 0, out, recs, trips);
         CHECK(hipEventRecord(b, 0));
         CHECK(hipEventSynchronize(b));
         float ms = 0.f;
@@ -200,6 +201,7 @@ int main(int argc, char **argv)
         const double ninstr = (double)trips * 64.0 * k_per_slot[op]; // per wave
         for(int i = 0; i < blocks * 16; i++)
         {
+          if((i & 15) >= 4 * W) continue; // waves the workgroup does not have
           cyc.push_back((double)h[i].ticks / (ninstr * W));
           clk.push_back(h[i].real > 0 ? 100.0 * (double)h[i].ticks / (double)h[i].real : 0.0);
         }
