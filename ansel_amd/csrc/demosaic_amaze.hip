@@ -936,6 +936,10 @@ namespace ansel
 // [out_row0, out_row0 + out_rows), the tile rows [tv0, tv1) of the frame's own 128-row tile grid are run; nullptr: the frame
 int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filters, const float *in, float4 *out, const rcd_band_t *band)
 {
+  // the test hooks' overrides (testhooks.hip dt_hip_test_dispatch(): tests only, not in include/ansel_hip.h) are read ONCE per
+  // launch: a concurrent toggle cannot be seen as two values by one launch (grid size against allocation)
+  const int ov_slab = dispatch_override(DISPATCH_AMAZE_SLAB), ov_unfused = dispatch_override(DISPATCH_AMAZE_UNFUSED),
+            ov_blocks = dispatch_override(DISPATCH_AMAZE_BLOCKS);
   const int width = piece->roi_in.width, height = piece->roi_in.height;
   if(width <= 0 || height <= 0) return DT_HIP_SUCCESS;
   if(width < 34 || height < 34)
@@ -963,7 +967,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   a.ntx = (width + 16 + (TS - 32) - 1) / (TS - 32);
   const int nty = (height + 16 + (TS - 32) - 1) / (TS - 32);
   a.ntiles = a.ntx * nty;
-  a.slab_all = (dispatch_override(DISPATCH_AMAZE_SLAB) || measuring_env("ANSEL_HIP_AMAZE_SLAB") != nullptr) && !band;
+  a.slab_all = (ov_slab || measuring_env("ANSEL_HIP_AMAZE_SLAB") != nullptr) && !band;
   const int ty_first = band ? band->tv0 : 0, ty_end = band ? (band->tv1 < nty ? band->tv1 : nty) : nty;
   if(band)
   {
@@ -994,7 +998,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   }
   hipStream_t s = stream_of(devid);
   const bool timed = measuring_env("ANSEL_HIP_AMAZE_TIMED") != nullptr;
-  const bool unfused = timed || dispatch_override(DISPATCH_AMAZE_UNFUSED) || measuring_env("ANSEL_HIP_AMAZE_UNFUSED") != nullptr; // one kernel per kind of tile
+  const bool unfused = timed || ov_unfused || measuring_env("ANSEL_HIP_AMAZE_UNFUSED") != nullptr; // one kernel per kind of tile
   amz::args sa;
   sa.width = width;
   sa.height = height;
@@ -1023,7 +1027,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   }
   // one workgroup per CU: the LDS of a CU each (ANSEL_HIP_AMAZE_BLOCKS: fewer, so that the tests see a workgroup walk many tiles)
   const char *const sb_env = measuring_env("ANSEL_HIP_AMAZE_STREAM_BLOCKS") ? measuring_env("ANSEL_HIP_AMAZE_STREAM_BLOCKS") : measuring_env("ANSEL_HIP_AMAZE_BLOCKS");
-  const int sb_max = dispatch_override(DISPATCH_AMAZE_BLOCKS) > 0 ? dispatch_override(DISPATCH_AMAZE_BLOCKS) : (sb_env && atoi(sb_env) > 0 ? atoi(sb_env) : 256);
+  const int sb_max = ov_blocks > 0 ? ov_blocks : (sb_env && atoi(sb_env) > 0 ? atoi(sb_env) : 256);
   if(stream_tiles > 0 && slab_tiles > 0 && !unfused)
   {
     const int blocks = a.ntiles < sb_max ? a.ntiles : sb_max;
@@ -1073,7 +1077,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   }
   // two 512-thread workgroups per CU (the vote plane is 50 KiB of LDS each)
   const char *const blocks_env = measuring_env("ANSEL_HIP_AMAZE_BLOCKS");
-  const int max_blocks = dispatch_override(DISPATCH_AMAZE_BLOCKS) > 0 ? dispatch_override(DISPATCH_AMAZE_BLOCKS) : (blocks_env ? atoi(blocks_env) : 512);
+  const int max_blocks = ov_blocks > 0 ? ov_blocks : (blocks_env ? atoi(blocks_env) : 512);
   const int blocks = a.ntiles < max_blocks ? a.ntiles : max_blocks;
   float *slabs = (float *)dt_hip_alloc_device_buffer(devid, (size_t)blocks * O_END * sizeof(float));
   if(!slabs) return DT_HIP_SYSMEM_ALLOCATION;

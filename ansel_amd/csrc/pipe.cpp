@@ -566,7 +566,7 @@ struct dt_hip_batch_t
 
 namespace
 {
-void batch_writer_loop(dt_hip_batch_t *b)
+static void batch_writer_loop(dt_hip_batch_t *b)
 {
   (void)make_current(b->pipe->devid);
   for(;;)
@@ -672,6 +672,8 @@ int dt_hip_batch_wait(dt_hip_batch_t *b, int slot)
     b->cv_done.wait(lk, [&] { return sl.written; });
     sl.in_flight = false;
     if(sl.write_err == DT_HIP_WRITER_FAILED) set_last_error("dt_hip_batch_wait: the writer refused frame %ld", sl.seq);
+    else if(sl.write_err != DT_HIP_SUCCESS)
+      set_last_error("dt_hip_batch_wait: the download of frame %ld did not complete (hipEventSynchronize on the writer thread)", sl.seq);
     return sl.write_err;
   }
   ANSEL_HIP_CHECK(hipEventSynchronize(sl.down));
@@ -687,7 +689,21 @@ int dt_hip_batch_set_writer(dt_hip_batch_t *b, dt_hip_batch_writer_t writer, voi
   if(e != DT_HIP_SUCCESS) return e;
   b->writer = writer;
   b->writer_user = user;
-  if(writer && !b->writer_thread.joinable()) b->writer_thread = std::thread(batch_writer_loop, b);
+  if(writer && !b->writer_thread.joinable())
+  {
+    // std::thread's constructor throws std::system_error when the system has no thread to give: not through a C boundary
+    try
+    {
+      b->writer_thread = std::thread(batch_writer_loop, b);
+    }
+    catch(const std::exception &e)
+    {
+      b->writer = nullptr;
+      b->writer_user = nullptr;
+      set_last_error("dt_hip_batch_set_writer: cannot start the writer thread (%s)", e.what());
+      return DT_HIP_DEFAULT_ERROR;
+    }
+  }
   return DT_HIP_SUCCESS;
 }
 
@@ -710,7 +726,14 @@ int dt_hip_batch_submit(dt_hip_batch_t *b, const void *host_in, void *host_out)
   batch_slot_t &sl = b->slots[k];
   // the slot's previous frame must have left the device before its buffers are reused
   const int w = dt_hip_batch_wait(b, k);
-  if(w != DT_HIP_SUCCESS) return w;
+  if(w != DT_HIP_SUCCESS)
+  {
+    // the failure belongs to the frame that held this slot, NOT to the one being submitted (which is not submitted):
+    // the message says so, the slot is free again, and the caller may submit the same frame once more
+    const std::string prev = dt_hip_last_error();
+    set_last_error("dt_hip_batch_submit: the previous frame of slot %d failed (%s); the new frame was not submitted", k, prev.c_str());
+    return w;
+  }
   hipStream_t compute = stream_of(b->pipe->devid);
   ANSEL_HIP_CHECK(hipMemcpyAsync(sl.d_in, host_in, b->in_bytes, hipMemcpyHostToDevice, b->s_up));
   ANSEL_HIP_CHECK(hipEventRecord(sl.up, b->s_up));
@@ -1093,7 +1116,7 @@ struct band_gang_t
 dt_hip_band_stats_t g_band_stats = { 0, 0, 0, 0, 0, 0, 0 };
 std::mutex g_band_stats_mutex;
 
-int copy_between(band_gang_t &gang, const int dst_devid, void *dst, const int src_devid, const void *src, const size_t bytes,
+static int copy_between(band_gang_t &gang, const int dst_devid, void *dst, const int src_devid, const void *src, const size_t bytes,
                  hipStream_t s)
 {
   if(!bytes) return DT_HIP_SUCCESS;
@@ -1674,9 +1697,9 @@ int dt_hip_default_process_tiling_ptp(int devid, const char *op, const dt_hip_pi
 // modify_roi_in() (src/iop/finalscale.c:76-107, the full-resolution pipeline of an export) is the one restated here.
 namespace
 {
-int ra_align_up(const int n, const int a) { return n + a - (n % a); } // tiling.c:92-95: one more step even when aligned
-int ra_align_down(const int n, const int a) { return n - (n % a); }
-int ra_align_close(const int n, const int a)
+static int ra_align_up(const int n, const int a) { return n + a - (n % a); } // tiling.c:92-95: one more step even when aligned
+static int ra_align_down(const int n, const int a) { return n - (n % a); }
+static int ra_align_close(const int n, const int a)
 {
   const int off = n % a;
   const int shift = (off > a / 2) ? a - off : -off;
@@ -1684,7 +1707,7 @@ int ra_align_close(const int n, const int a)
 }
 
 // finalscale modify_roi_in(), finalscale.c:76-107
-void finalscale_modify_roi_in(const dt_hip_roi_t *roi_out, dt_hip_roi_t *roi_in)
+static void finalscale_modify_roi_in(const dt_hip_roi_t *roi_out, dt_hip_roi_t *roi_in)
 {
   *roi_in = *roi_out;
   if(roi_in->scale > 1.f)
@@ -1708,7 +1731,7 @@ void finalscale_modify_roi_in(const dt_hip_roi_t *roi_out, dt_hip_roi_t *roi_in)
 
 // _fit_output_to_input_roi(), tiling.c:197-237, its iterative search.  The Nelder-Mead fallback (:170-190) is for
 // modules that distort; finalscale's search converges in one or two steps, so its failure is reported, not papered over
-bool fit_output_to_input_roi(const dt_hip_roi_t *iroi, dt_hip_roi_t *oroi, const int delta, int iter)
+static bool fit_output_to_input_roi(const dt_hip_roi_t *iroi, dt_hip_roi_t *oroi, const int delta, int iter)
 {
   dt_hip_roi_t probe = *iroi;
   finalscale_modify_roi_in(oroi, &probe);

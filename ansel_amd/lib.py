@@ -24,6 +24,10 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
+        if os.environ.get("ANSEL_HIP_LIB"):
+            raise AnselHipError(
+                "ANSEL_HIP_LIB=%s does not exist: the measuring build is made by `python -m ansel_amd.build --measuring` "
+                "(tools/ default to it; unset the variable for the product library)" % LIB_PATH)
         raise AnselHipError(
             "%s not found: build it with `python -m ansel_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)

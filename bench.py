@@ -287,7 +287,7 @@ def verify_output(out16, raw_host, width, height, with_filmic, which):
 
 
 PMC_SUMMARIES = {  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of THIS configuration, newest first
-    "full": ("r04_pmc_hbm_bytes_100MP_full.json", "r03_pmc_hbm_bytes_100MP_full.json"),
+    "full": ("r05_pmc_hbm_bytes_100MP_full.json", "r04_pmc_hbm_bytes_100MP_full.json", "r03_pmc_hbm_bytes_100MP_full.json"),
     "light": ("r03_pmc_hbm_bytes_100MP_light_fused.json", "r02_pmc_hbm_bytes_100MP_light_fused.json"),
 }
 
@@ -309,9 +309,32 @@ def pmc_table(args):
     return {}, None
 
 
+def sclk_table(args):
+    """{kernel name: effective shader clock in MHz during its launches} from the COMMITTED summary of a rocprofv3 --pmc
+    GRBM_GUI_ACTIVE pass over this configuration (tools/profile_round.sh -> tools/pmc_sclk_json.py; MI355X_MICROARCH.md
+    "DVFS give-back": the chip clocks to its power budget, effective clock = busy cycles / wall time).  Round 4's review,
+    item 4: a kernel's VALU floor is instructions x architectural cycles / CLOCK, and the clock is not the 2.4 GHz of the
+    data sheet under an FMA-dense stream (profiles/r05_valu_issue_cycles.json: 1.87 - 1.96 GHz for v_fma_f32, 2.2 - 2.3 for
+    v_add_f32, 2.4 for the half- and quarter-rate classes, at 2.0 cycles per full-rate wave64 instruction throughout)"""
+    if args.size != "100MP" or args.no_fusion or args.mode != "batch" or args.pipe != "full":
+        return {}, None
+    path = os.path.join(ROOT, "profiles", "r05_sclk_per_kernel_100MP_full.json")
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return {}, None
+    return {k: v["sclk_mhz"] for k, v in kernels.items() if "sclk_mhz" in v}, "committed profiles/r05_sclk_per_kernel_100MP_full.json"
+
+
+def sclk_of(table, tag):
+    names = TAG_KERNELS.get(tag, (tag, tag.replace("_u16", "")))
+    got = [v for k, v in table.items() for n in dict.fromkeys(names) if k == n or k.startswith(n + "<")]
+    return round(sum(got) / len(got), 1) if got else None
+
+
 # which kernels (function names as the PMC summary keeps them, template arguments stripped) a bench tag launches
 TAG_KERNELS = {
-    "nlm_chunks": ("nlm_chunks_v3", "nlm_chunks_v2", "nlm_chunks_pipelined", "nlm_chunks"),
+    "nlm_chunks": ("nlm_chunks_v3", "nlm_chunks_v4", "nlm_chunks_v2", "nlm_chunks_pipelined", "nlm_chunks"),
     "diffuse_pde": ("diffuse_pde_strip", "diffuse_pde"), "diffuse_decompose": ("bspline_decompose_strip", "bspline_decompose"),
     "dn_decompose": ("dn_decompose_strip", "dn_decompose"), "rgb_chain_u16": ("rgb_chain",), "rgb_chain_rows16": ("rgb_chain",),
     "bilat_blur": ("bilat_blur_line", "bilat_blur_line_z"), "bilat_splat": ("bilat_splat2", "bilat_zcells", "bilat_splat", "bilat_lightness"),
@@ -333,21 +356,27 @@ def traffic_of(table, tag):
 # (MI355X_MICROARCH.md "Per-instruction cycle constants") -> the kernel's issue-cycle total from its instruction mix
 # (profiles/r04_isa_mix.json, tools/valu_model.py arch) over 1024 SIMDs at 2.4 GHz is its floor.
 KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu", "rcd_tiles": "valu+lds",
-                "nlm_chunks": "lds+valu", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
+                "nlm_chunks": "lds+valu", "nlm_tail": "latency (a 72-addition row chain per offset; four workgroups a CU)", "diffuse_pde": "valu", "dn_decompose": "valu", "diffuse_decompose": "hbm",
                 "bilat_splat": "latency (one lane per grid node walks its pixels in order)", "bilat_slice": "hbm", "bilat_blur": "latency",
                 "dn_synthesize": "hbm", "dn_precondition": "hbm", "dn_finish": "hbm", "dn_finish_chain": "hbm", "rgb_to_lab": "hbm",
                 "lab_to_rgb": "hbm"}
 
 
-def valu_floor_ms(tag, mpix, table="r04_isa_mix.json"):
-    """VALU issue floor of `tag` on a frame of `mpix` megapixels from a COMMITTED instruction-mix table: the rocprofv3 SQ
-    counters of this bench (profiles/r04_pmc_sq_100MP_full.json) priced per instruction class -- r04_isa_mix.json at the
-    ARCHITECTURAL issue rate of a SIMD-32 (2 cycles per wave64 binary32 / integer instruction, 4 binary64, 8 transcendental;
-    tools/valu_model.py ... arch: a lower bound whatever the sustained clock), r04_isa_mix_measured_rates.json at the rates
-    tools/valu_microbench.hip measures on this chip at full occupancy (add / mul 2.5 - 2.7, fma 3.0, conversions 4.2,
-    transcendentals 8.2; what the counters do not classify at the cheapest full-rate cost) -- at the 2.4 GHz peak clock.  A tag
-    that launches several instantiations of a kernel (the wavelets: one per dilation) takes their mean.  None when the table
-    lacks the kernel"""
+def valu_floor_ms(tag, mpix, table=None):
+    if table is None:
+        table = "r05_isa_mix.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_isa_mix.json")) else "r04_isa_mix.json"
+    return _valu_floor_ms(tag, mpix, table)
+
+
+def _valu_floor_ms(tag, mpix, table):
+    """VALU issue floor of `tag` on a frame of `mpix` megapixels from a COMMITTED instruction-mix table (tools/valu_model.py ... arch
+    over the rocprofv3 SQ counters of this bench): the dynamic instruction mix priced per class at the ARCHITECTURAL issue rate of a
+    SIMD-32 -- 2 cycles per full-rate wave64 instruction, 4 for binary64 and conversions, 8 for the transcendental unit -- at the 2.4 GHz
+    peak clock.  profiles/r05_valu_issue_cycles.json (tools/valu_clock_microbench.hip: the shader clock read beside the cycle count)
+    confirms those rates on this chip -- v_fma / v_mul / v_add 1.9 - 2.1 cycles, v_cmp / v_cvt / v_div_scale / v_div_fixup / v_max3 3.3 -
+    4.0, v_rcp / v_sqrt 6.3 - 8.0 -- and shows what rounds 2 - 4 called "measured rates" (2.5 - 3.0 cycles: wall time x an assumed 2.4
+    GHz) to be the CLOCK: 1.87 - 1.96 GHz under an FMA stream, 2.0 - 2.1 under multiplies, 2.2 - 2.3 under additions.  A tag that launches
+    several instantiations of a kernel (the wavelets: one per dilation) takes their mean.  None when the table lacks the kernel"""
     try:
         mix = json.load(open(os.path.join(ROOT, "profiles", table)))
     except (OSError, ValueError):
@@ -391,6 +420,44 @@ def measured_ceiling(torch, dev, gib=1.0, reps=8):
         out[name + "_GBs"] = round(streams * n * 4 / (best * 1e-3) / 1e9, 1)
     del a, b, c
     return out
+
+
+def full_pipe_leg(torch, np, pipe, synth, l, devid, dev, size, lut, lut_host, with_filmic, fusion, verify=True, steps=3):
+    """the metric's pipe on another frame size, after the timed region: ms per step, per-kernel ms, non-local means per megapixel,
+    and the exported words against the oracle"""
+    w, h = frame_size(size)
+    raw_host = synth.bayer_mosaic_tiled(w, h, seed=1)
+    raw = torch.from_numpy(raw_host.view(np.int16)).to(dev)
+    nodes = build_pipe(w, h, lut.data_ptr(), lut_host, with_filmic, "full")
+    ex = pipe.DevicePipe(devid, nodes, fusion=fusion)
+    out = torch.empty((h, w, 4), dtype=torch.int16, device=dev)
+    ex.process(raw.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize(dev)
+    l.dt_hip_events_reset(devid)
+    l.dt_hip_events_enable(devid, 1)
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        ex.process(raw.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t1) / steps * 1e3
+    l.dt_hip_events_enable(devid, 0)
+    k = read_kernel_events(l, devid)
+    bpp = pipe.algorithmic_bytes_per_pixel(nodes)
+    mpix = w * h / 1e6
+    kms = {n: round(v["ms_avg"] * v["launches"] / steps, 3) for n, v in sorted(k.items())}
+    nlm_ms = kms.get("nlm_chunks", 0.0) + kms.get("nlm_tail", 0.0)
+    leg = {"workload": "%d x %d RGGB u16 raw (%s), the same full export pipe" % (w, h, size), "steps": steps, "ms_per_step": round(ms, 3),
+           "mpix_s": round(mpix / (ms * 1e-3), 2), "algorithmic_bytes_per_px": bpp,
+           "pipe_hbm_frac": round(bpp * w * h / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": kms,
+           "nlmeans_ms_per_mpix": round(nlm_ms / mpix, 4),
+           "nlmeans_chunk_rows": "69 (compute_slice_height(4000), nlmeans_core.c:264-295): nlm_chunks_v4 on the first 64 rows of every "
+                                 "interior chunk + nlm_tail on the other five" if size == "24MP" else None}
+    ex.close()
+    if verify:
+        leg["verify"] = verify_output(out, raw_host, w, h, with_filmic, "full")
+        leg["verified"] = leg["verify"]["verified"]
+    del out, raw
+    return leg
 
 
 def band_digest(t):
@@ -765,6 +832,13 @@ def main():
                            "pipe_hbm_frac": round(d_bpp * npix / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         dexec.close()
         del dout
+    # ---- the same full pipe on the 24 MP frame of BASELINE configs 1 / 2 (6000 x 4000, the commonest sensor): its non-local-means
+    #      chunks are 69 rows high -- until round 5 the grid of the half-rate second version (round 4's review, "weak" item 4: no
+    #      record ran the full pipe at 24 MP); verified against the oracle like the timed frame
+    full24 = None
+    if rank == 0 and world == 1 and args.mode == "batch" and args.pipe == "full" and args.size == "100MP" and not args.no_light_pipe:
+        full24 = full_pipe_leg(torch, np, pipe, synth, l, devid, dev, "24MP", lut, lut_host, with_filmic, not args.no_fusion,
+                               verify=not args.no_verify)
     ceiling = measured_ceiling(torch, dev) if rank == 0 else None
 
     # ---- the same step with the boundary's two PCIe legs (never `value`): sensor buffer in pinned host memory ->
@@ -829,15 +903,22 @@ def main():
                     return 0
 
                 cb = WRITER(write_image)
-                if l.dt_hip_batch_set_writer(batch, cb, None) == 0:
+                # host_out is the WRITER's until the slot's wait returns (include/ansel_hip.h): one pinned buffer per slot, rotated
+                # as tests/test_gpu_batch.py and examples/export_pipe.c do (the first version of this leg handed all three slots
+                # the same buffer: the writer copied it while the next frame's download overwrote it)
+                pin_outs = [pin_out] + [l.dt_hip_alloc_host_pinned(npix * 6) for _ in range(2)]
+                if all(pin_outs) and l.dt_hip_batch_set_writer(batch, cb, None) == 0:
                     for k in range(nfr + 3):
                         if k == 3:
                             l.dt_hip_batch_drain(batch)
                             t1 = time.perf_counter()
-                        rc = l.dt_hip_batch_submit(batch, pin_in, pin_out)
+                        rc = l.dt_hip_batch_submit(batch, pin_in, pin_outs[k % 3])
                         assert rc >= 0, l.dt_hip_last_error()
                     assert l.dt_hip_batch_drain(batch) == 0
                     host_rows_writer_ms = (time.perf_counter() - t1) / nfr * 1e3
+                for pb in pin_outs[1:]:
+                    if pb:
+                        l.dt_hip_free_host_pinned(pb)
                 l.dt_hip_batch_free(batch)
             rows_exec.close()
         l.dt_hip_free_host_pinned(pin_in)
@@ -864,6 +945,7 @@ def main():
                 tag_bpp["dn_finish_chain"] = 48 + 32 + 3 * 32
                 tag_bpp["rgb_chain_u16"] = 32 + 2 * 32 + 24
         pmc, pmc_src = pmc_table(args)
+        sclk, sclk_src = sclk_table(args)
         mpix_mine = my_rows * width / 1e6
         ms_per_step = elapsed / args.steps * 1e3
         pipe_bpp = pipe.algorithmic_bytes_per_pixel(nodes)
@@ -876,23 +958,39 @@ def main():
             per_launch = v["launches"] / float(args.steps)
             e = {"ms": round(v["ms_avg"], 4), "launches_per_step": round(per_launch, 2),
                  "ms_per_step": round(v["ms_avg"] * per_launch, 4), "bound": KERNEL_BOUND.get(k, "hbm")}
+            # hbm_frac: the bytes the launch MOVED (PMC counters, committed summary) / its time / 8 TB/s -- physical, never above 1.
+            # hbm_frac_algorithmic: SURVEY 8d's credit for the modules the launch executes / its time / 8 TB/s -- above 1 for a
+            # fused group, whose credit is for bytes fusion does NOT move (round 4's review, item 8: a figure above 1 under the name
+            # hbm_frac read as a defect)
             if tag_bpp.get(k):
                 e["algorithmic_bytes_per_px"] = tag_bpp[k]
-                e["hbm_frac"] = round(tag_bpp[k] * my_rows * width / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                e["hbm_frac_algorithmic"] = round(tag_bpp[k] * my_rows * width / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             moved = traffic_of(pmc, k)
             if moved is not None:
                 e["hbm_bytes_moved"] = moved
-                e["hbm_frac_moved"] = round(moved / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                e["hbm_frac"] = round(moved / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 if tag_bpp.get(k):
                     e["moved_over_algorithmic"] = round(moved / float(tag_bpp[k] * my_rows * width), 3)
             floor = valu_floor_ms(k, mpix_mine)
             if floor is not None:
+                # the instruction mix at the ARCHITECTURAL issue rates (2 / 4 / 8 cycles per full- / half- / quarter-rate wave64
+                # instruction: what profiles/r05_valu_issue_cycles.json measures with the clock read beside it) at 2.4 GHz ...
                 e["valu_issue_floor_ms"] = round(floor, 4)
                 e["valu_frac"] = round(floor / v["ms_avg"], 4)
-            floor_m = valu_floor_ms(k, mpix_mine, "r04_isa_mix_measured_rates.json")
-            if floor_m is not None:  # the same instruction mix priced at the issue rates measured on this chip
-                e["valu_frac_at_measured_rates"] = round(floor_m / v["ms_avg"], 4)
+                clk = sclk_of(sclk, k)
+                if clk:  # ... and at the clock the chip sustained during this kernel's launches (GRBM_GUI_ACTIVE / duration)
+                    e["sclk_mhz"] = clk
+                    e["valu_frac_at_sustained_clock"] = round(floor * 2400.0 / clk / v["ms_avg"], 4)
             per_kernel[k] = e
+        # diffuse or sharpen as a pair: the analysis stores ONE plane per scale (the PDE forms the detail from two low-pass
+        # planes where it reads them), so its launches move 16 B/px less and the PDE's 16 more than SURVEY 8d's per-stage credit
+        if "diffuse_pde" in per_kernel and "diffuse_decompose" in per_kernel \
+           and "hbm_bytes_moved" in per_kernel["diffuse_pde"] and "hbm_bytes_moved" in per_kernel["diffuse_decompose"]:
+            pd, dd = per_kernel["diffuse_pde"], per_kernel["diffuse_decompose"]
+            per_kernel["diffuse_pair_moved_over_algorithmic"] = round(
+                (pd["hbm_bytes_moved"] + dd["hbm_bytes_moved"]) / float((tag_bpp["diffuse_pde"] + tag_bpp["diffuse_decompose"]) * my_rows * width), 3)
+        moved_per_step = sum(e["hbm_bytes_moved"] * e["launches_per_step"] for e in per_kernel.values()
+                             if isinstance(e, dict) and "hbm_bytes_moved" in e)
         dominant = max((k for k in kernels if tag_bpp.get(k)), key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"])
         dom = kernels[dominant]
         dom_bytes = tag_bpp[dominant] * my_rows * width  # rank 0's share of the frame in tiled mode
@@ -930,6 +1028,7 @@ def main():
                 "pmc_source": pmc_src,
                 "light_pipe": light,
                 "default_diffuse": default_diffuse,
+                "full_pipe_24MP": full24,
                 # not `value`: one frame from pinned host memory to pinned host memory over PCIe
                 "host_to_host_ms": None if host_ms is None else round(host_ms, 3),
                 "host_to_host_overlapped_ms": None if host_overlap_ms is None else round(host_overlap_ms, 3),
@@ -956,9 +1055,14 @@ def main():
                 # ... and what actually binds this launch (config.kernel_bounds has every kernel of the step)
                 "binds": per_kernel.get(dominant, {}).get("bound"),
                 "valu_frac": per_kernel.get(dominant, {}).get("valu_frac"),
-                "valu_frac_at_measured_rates": per_kernel.get(dominant, {}).get("valu_frac_at_measured_rates"),
-                # the whole step: sum of algorithmic bytes / step time / peak (= config.pipe_hbm_frac)
+                "valu_frac_at_sustained_clock": per_kernel.get(dominant, {}).get("valu_frac_at_sustained_clock"),
+                "sclk_mhz": per_kernel.get(dominant, {}).get("sclk_mhz"),
+                "sclk_source": sclk_src,
+                # the whole step, both ways: sum of ALGORITHMIC bytes / step time / peak (= config.pipe_hbm_frac: the metric's figure;
+                # it credits the pipe with bytes that fusion never moves) and the bytes the PMC counters saw the step MOVE / step time / peak
                 "pipe_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pipe_frac_counter_bytes": None if not moved_per_step else round(moved_per_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pipe_counter_bytes_per_step": None if not moved_per_step else int(moved_per_step),
                 "pipe_frac_of_measured_copy": None if not ceiling else round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / ceiling["copy_GBs"], 4),
             },
         }

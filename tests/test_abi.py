@@ -24,6 +24,34 @@ def test_library_exports_every_declared_symbol():
     assert not l._ansel_missing, l._ansel_missing
 
 
+def test_exports_beyond_the_header_are_the_test_hooks_and_nothing_else():
+    """what the product library exports and include/ansel_hip.h does not declare: the device-side self-test entry points of
+    testhooks.hip (dt_hip_test_*: devmath / in-range arithmetic on plain arrays, and dt_hip_test_dispatch(), which sends a
+    launch to a fallback kernel so that a test can compare two kernels on one frame).  INTEGRATION.md says they are for the
+    tests only; nothing else may leak out of the library"""
+    import subprocess
+    so = os.path.join(ROOT, "ansel_amd", "libansel_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    extra = sorted(e for e in exported - set(_declared_symbols()) if not e.startswith("_"))
+    not_hooks = [e for e in extra if not e.startswith("dt_hip_test_")]
+    assert not not_hooks, not_hooks
+    assert "dt_hip_test_dispatch" in extra
+
+
+def test_measuring_build_compiles():
+    """every translation unit with -DANSEL_HIP_MEASURING (the A/B switches and superseded kernels tools/ load through
+    ANSEL_HIP_LIB): no test runs it, so at least it must build -- objects that are up to date are not rebuilt"""
+    from ansel_amd import build
+    path = build.build(verbose=False, measuring=True)
+    assert os.path.exists(path)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", path], capture_output=True, text=True, check=True).stdout
+    assert " U getenv" in syms  # the measuring build reads its switches from the environment; the product must not:
+    prod = subprocess.run(["nm", "-D", os.path.join(ROOT, "ansel_amd", "libansel_hip.so")], capture_output=True, text=True, check=True).stdout
+    assert " U getenv" not in prod
+
+
 def test_ctypes_mirror_covers_the_header():
     declared = set(_declared_symbols())
     mirrored = set(lib.load()._ansel_protos)
