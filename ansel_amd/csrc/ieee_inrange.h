@@ -25,7 +25,7 @@
 namespace ansel_ieee
 {
 
-// a / b for: b normal, 2^-126 <= |b| < 2^126; a == +-0 (returns +0: the SIGN of a zero quotient is lost) or
+// a / b for: b normal, 2^-126 <= |b| < 2^126; a == +-0 (returns a zero whose SIGN is not the quotient's) or
 // 2^-103 <= |a| and -125 <= exponent(a) - exponent(b) < 96; a NaN gives a NaN (any payload)
 __device__ __forceinline__ float div_core(const float a, const float b)
 {
@@ -63,10 +63,13 @@ __device__ __forceinline__ float sqrt_core(const float x)
   return t;
 }
 
-// x == +-0 or 2^-96 <= |x| < +inf, as one multiplication and one class test (x * 2^-30 is normal exactly then)
+// x == +0 or 2^-96 <= x < +inf -- sqrt_core()'s domain -- on the bit pattern: everything else (negative numbers and -0, NaNs,
+// +inf, the subnormals and the normals below 2^-96) fails.  (A first version tested the class of x * 2^-30: one instruction
+// fewer, and wrong -- a nonzero x below 2^-120 scales to zero and passed; tests/test_gpu_devmath.py caught it.)
 __device__ __forceinline__ bool zero_or_above_2m96(const float x)
 {
-  return __builtin_amdgcn_classf(x * 0x1p-30f, 0x008 | 0x100 | 0x020 | 0x040); // -normal, +normal, -0, +0
+  const unsigned u = __float_as_uint(x);
+  return u == 0u || (u - 0x0f800000u) <= (0x7f7fffffu - 0x0f800000u);
 }
 
 } // namespace ansel_ieee

@@ -14,15 +14,14 @@
 //   (a) offset s      waves 2-7   a lane = (table column x, tail row j): the term D(row + P) - D(row - P - 1) of the column
 //                                 recurrence (the lane's own two pixels stay in registers for the chunk)      -> T[s % 3]
 //   (b) offset s - 1  wave 1 + twelve lanes of wave 0   a lane = a table column: the exported sum + its <= 5 terms, in place
-//   (c) offset s - 2  lanes 0-4 of wave 0   a lane = a tail row: the sliding row sum (:405-415), 72 dependent additions
-//                                                                                                              -> D[s % 2]
+//   (c) offset s - 2  wave 0   eight lanes = a tail row: the sliding row sum (:405-415), the chain passed from lane to lane
+//                                 by a DPP shift as in the fused chunk kernel                                  -> D[s % 2]
 //   (d) offset s - 3  waves 2-7   a lane = a pixel: weight 2^-(distortion x sharpness), four accumulations (:416-436)
 // then the normalisation and the blend (:490-521).  A workgroup needs ~35 KB of LDS (the window is 19 + <= 5 rows): four of
 // them share a CU and hide each other's row chain.  Compiled for the host by tests/native/nlm2_host.cpp like the others.
 #pragma once
 
 #include "nlm2_body.h"
-#include "nlm3_body.h" // f4, ld4(), st4()
 
 #define NLT_THREADS 512
 #define NLT_WP 92         // window pitch in pixels (chunk width + 2 x reach <= 92, as nlm2_body.h's tight layout)
@@ -49,7 +48,7 @@ inline bool fits(const int chk_w, const int chk_h, const int radius, const int r
          && reach >= 3 && (chk_w + 4) * NLT_ROWS <= NLT_THREADS - 128 && npatch <= 4096;
 }
 
-// Env: tid(), bid(), lds(), sync(), cvt_i32_sat(), int_as_float(), max_num().  Args: nlm_args of nlmeans.hip.
+// Env: tid(), bid(), lds(), sync(), lane_shr1(), cvt_i32_sat(), int_as_float(), max_num().  Args: nlm_args of nlmeans.hip.
 // seeds: this chunk's exported column sums, [npatch][NLT_SEED_PITCH].
 template <class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
@@ -108,8 +107,6 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   // ---- (b): the lane's table column
   const bool b_on = (w == 1 && 1 + lane <= ncol) || (w == 0 && lane >= 16 && 49 + lane <= ncol);
   const int bx = w == 1 ? 1 + lane : 49 + lane; // wave 1: slots 1 .. 64; lanes 16 .. 27 of wave 0: slots 65 .. 76
-  // ---- (c): the lane's tail row
-  const bool c_on = w == 0 && lane < TR;
   // ---- (d): the lane's pixel
   const bool d_on = w >= 2 && u < cw * TR;
   const int dj = d_on ? u / cw : 0, dc = d_on ? u - dj * cw : 0;
@@ -149,82 +146,52 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         }
       }
     }
-    if(c_on && s >= 2 && s <= n + 1)
+    if(w == 0 && s >= 2 && s <= n + 1)
     {
-      // the sliding row sum (:405-415) as nlm3_body.h's B role forms it: slot 0 is never summed, the first four slots
-      // added onto +0 in order, then one (entering - leaving) per column
-      const float *const cs = Tb + (((s - 2) % 3) * NLT_ROWS + lane) * TP;
-      float *const d = Db + (((s - 2) & 1) * NLT_ROWS + lane) * TP;
-      // the row in batches of sixteen columns (sixteen-byte accesses: the rows are 16-byte aligned), the five slots that
-      // leave the window next carried in registers; columns beyond the chunk's (a 64- or 68-column grid) compute on
-      // whatever the table holds there and are never read
-      float head[8];
+      // the sliding row sum (:405-415) as nlm3_body.h's fused variant forms it (row_chain()): a tail row is eight lanes, a lane
+      // nine adjacent columns; it reads the 9 + 5 column sums its columns' patches span, forms its nine (entering - leaving)
+      // terms, and the chain of the row runs through the eight lanes in eight phases -- the carry moves to the next lane by
+      // a DPP row shift, the row's first lane starts from the sum of the first four slots (slot 0 is never summed); lanes
+      // that are done recompute.  One wave, ~110 instructions per offset (a first version walked a row in ONE lane: ~400
+      // instructions of a wave that issues one every ~4.7 cycles: 1.64 ms of a 24 MP frame's 7.97).  All 64 lanes run it
+      // (the shift is a wave operation); lanes 40 - 63 read table rows that do not exist (the words do) and store nothing
+      constexpr int NPX = 9;
+      const int cj = lane >> 3, j8 = lane & 7, cb = NPX * j8;
+      const float *const T = Tb + (((s - 2) % 3) * NLT_ROWS + cj) * TP + cb;
+      float cs[NPX + S];
+#pragma unroll
+      for(int i = 0; i < NPX + S; i++) cs[i] = T[i];
+      const bool row_head = j8 == 0;
+      float e[NPX];
+      e[0] = cs[S] - (row_head ? 0.0f : cs[0]);
+#pragma unroll
+      for(int i = 1; i < NPX; i++) e[i] = cs[i + S] - cs[i];
+      float first = 0.0f;
+#pragma unroll
+      for(int kk = 1; kk < S; kk++) first += cs[kk];
+      float carry = first;
+      float dist[NPX];
+#pragma unroll
+      for(int ph = 0; ph < 8; ph++)
       {
-        const nlm3::f4 h0 = nlm3::ld4(cs), h1 = nlm3::ld4(cs + 4);
-        head[0] = 0.0f; // slot 0
-        head[1] = h0.y;
-        head[2] = h0.z;
-        head[3] = h0.w;
-        head[4] = h1.x;
-        head[5] = h1.y;
-        head[6] = h1.z;
-        head[7] = h1.w;
-      }
-      float distortion = 0.0f;
+        float d = carry;
 #pragma unroll
-      for(int kk = 1; kk < S; kk++) distortion += head[kk];
-      // lo[k] = slot jb + k (leaving at column jb + k), hi = slots jb + 5 .. (entering)
-      float lo[S];
-#pragma unroll
-      for(int k = 0; k < S; k++) lo[k] = head[k];
-      float pend[3] = { head[5], head[6], head[7] }; // slots jb + 5 .. jb + 7, fetched with the batch before
-#pragma unroll
-      for(int jb = 0; jb < 80; jb += 16)
-      {
-        if(jb < cw)
+        for(int i = 0; i < NPX; i++)
         {
-          // slots jb + 8 .. jb + 23
-          float in16[16];
-#pragma unroll
-          for(int q = 0; q < 16; q += 4)
-          {
-            nlm3::f4 v;
-            v.x = v.y = v.z = v.w = 0.0f;
-            if(jb + 8 + q < TP) v = nlm3::ld4(cs + jb + 8 + q);
-            in16[q] = v.x;
-            in16[q + 1] = v.y;
-            in16[q + 2] = v.z;
-            in16[q + 3] = v.w;
-          }
-          float slot[S + 16 + 3]; // slots jb .. jb + 23
-#pragma unroll
-          for(int k = 0; k < S; k++) slot[k] = lo[k];
-#pragma unroll
-          for(int k = 0; k < 3; k++) slot[S + k] = pend[k];
-#pragma unroll
-          for(int k = 0; k < 16; k++) slot[S + 3 + k] = in16[k];
-          float dd[16];
-#pragma unroll
-          for(int k = 0; k < 16; k++)
-          {
-            distortion = distortion + (slot[k + S] - slot[k]);
-            dd[k] = distortion;
-          }
-#pragma unroll
-          for(int q = 0; q < 16; q += 4)
-          {
-            nlm3::f4 v;
-            v.x = dd[q];
-            v.y = dd[q + 1];
-            v.z = dd[q + 2];
-            v.w = dd[q + 3];
-            if(jb + q < TP) nlm3::st4(d + jb + q, v);
-          }
-#pragma unroll
-          for(int k = 0; k < S; k++) lo[k] = slot[16 + k];
-#pragma unroll
-          for(int k = 0; k < 3; k++) pend[k] = slot[16 + S + k];
+          d = d + e[i];
+          dist[i] = d;
         }
+        if(ph + 1 < 8)
+        {
+          const float from_left = env.lane_shr1(d);
+          carry = row_head ? first : from_left;
+        }
+      }
+      if(cj < TR)
+      {
+        float *const d = Db + (((s - 2) & 1) * NLT_ROWS + cj) * TP + cb;
+#pragma unroll
+        for(int i = 0; i < NPX; i++) d[i] = dist[i];
       }
     }
     if(d_on && s >= 3)

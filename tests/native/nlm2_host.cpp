@@ -415,12 +415,13 @@ extern "C" int nlm_tall_host_run(const float *in, float *out, int W, int H, int 
     float *base = lds.data();
     while((uintptr_t)base & 15) base++;
     std::barrier<> bar(NLT_THREADS);
+    WaveExchange xch;
     std::vector<std::thread> pool;
     for(int t = 0; t < NLT_THREADS; t++)
       pool.emplace_back([&, t]() {
         for(int b = 0; b < nchunks; b++)
         {
-          HostEnv env{ t, b, base, &bar };
+          HostEnv env{ t, b, base, &bar, &xch };
           nlmt::body(env, fin, fout, a, patches.data(), seeds.data() + per_chunk * b);
           bar.arrive_and_wait();
         }

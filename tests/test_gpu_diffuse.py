@@ -115,6 +115,8 @@ def _extreme_rgba(w, h, seed=23):
     img[4 * h8:5 * h8, :, :3] *= np.float32(1e-30)
     img[5 * h8:6 * h8, ::5, :3] = np.float32(3.0e38)
     img[5 * h8:6 * h8, 1::5, :3] = np.float32(0.0)
+    # gradients whose squares are subnormal or tiny normals (values around 2^-63 .. 2^-55: squared gradient 2^-130 .. 2^-112)
+    img[6 * h8:7 * h8, :, :3] = (rng.random((min(h8, h - 6 * h8), w, 3)) * 2.0 ** rng.integers(-63, -54, (min(h8, h - 6 * h8), w, 1))).astype(np.float32)
     return img
 
 
