@@ -171,7 +171,7 @@ template <int NPXL, int MSEG, bool BORDER = false, bool FUSED = false, bool TALL
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
                   const int ndx, float *__restrict__ seeds_out = nullptr)
 {
-  static_assert(!TALL || (FUSED && !BORDER), "the head of a tall chunk runs on the fused interior body");
+  static_assert(!TALL || FUSED, "the head of a tall chunk runs on the fused body");
   constexpr int P = 2, S = 2 * P + 1, TP = NL3_TP, XO = NL3_XO, FP = NL3_FP, WPH = NL3_WPH;
   constexpr int MAXCH = FUSED ? FUSED_MAXCH : max_rows<NPXL>();
   constexpr int NT = FUSED ? 3 : 4; // tables: offset p lives in table tslot(p) from its A1 to its C
@@ -187,8 +187,8 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int reach = a.reach;
   // interior: the chunk is whole and no patch of any offset reaches past the frame (uniform, before any barrier)
   const bool interior = top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch_grid == a.chk_h && cw == a.chk_w;
-  if(BORDER ? (interior || !border_fits(cw, ch_grid)) : !interior) return;
-  const int ch = TALL ? TALL_HEAD : ch_grid; // the rows this body computes
+  const int ch = TALL ? imin(TALL_HEAD, ch_grid) : ch_grid; // the rows this body computes
+  if(BORDER ? (interior || !border_fits(cw, ch)) : !interior) return;
 
   float *const lds = env.lds();
   constexpr int tabsz = MAXCH * TP;

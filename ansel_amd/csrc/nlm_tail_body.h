@@ -39,7 +39,7 @@ using nlm2::imin;
 inline size_t lds_floats(const int tail_rows, const int reach, const int npatch)
 {
   const int wh = tail_rows + 2 * reach;
-  return (size_t)wh * NLT_WP * 3 + 3 * NLT_ROWS * NLT_TP + 2 * NLT_ROWS * NLT_TP + ((npatch + 3) & ~3);
+  return (size_t)wh * NLT_WP * 3 + 3 * NLT_ROWS * NLT_TP + 2 * NLT_ROWS * NLT_TP + 3 * ((npatch + 3) & ~3);
 }
 
 inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach, const int npatch)
@@ -50,7 +50,12 @@ inline bool fits(const int chk_w, const int chk_h, const int radius, const int r
 
 // Env: tid(), bid(), lds(), sync(), lane_shr1(), cvt_i32_sat(), int_as_float(), max_num().  Args: nlm_args of nlmeans.hip.
 // seeds: this chunk's exported column sums, [npatch][NLT_SEED_PITCH].
-template <class Env, class Args, class F4, class I2>
+// BORDER: a chunk of the outermost ring (the head ran nlm3::body<..., BORDER, FUSED, TALL> on it).  As there, all clipping is
+// "this squared difference is not there": it is +0 where the row or column of one of its two pixels lies outside the frame
+// (nlm3_body.h, BORDER: why that reproduces init_column_sums() and the three branches of nlmeans_core.c:437-488), a pixel whose
+// shifted pixel lies outside gets weight +0 for that offset (:398-404), and the window holds zeros there.  The chunk may be
+// narrower / lower than the grid's.
+template <bool BORDER = false, class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
                   const float *__restrict__ seeds)
 {
@@ -63,8 +68,9 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int bot = imin(top + a.chk_h, H), right = imin(left + a.chk_w, W);
   const int ch = bot - top, cw = right - left;
   const int reach = a.reach;
-  // the launch lists interior chunks only (the test of nlm3::body()): whole, no patch of any offset past the frame
-  if(!(top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w)) return;
+  // interior (the test of nlm3::body()): the chunk is whole and no patch of any offset reaches past the frame
+  const bool interior = top >= reach && bot + reach <= H && left >= reach && right + reach <= W && ch == a.chk_h && cw == a.chk_w;
+  if(BORDER ? (interior || ch <= NLT_HEAD_ROWS || cw < 1) : !interior) return;
   const int R0 = NLT_HEAD_ROWS, TR = ch - R0; // the tail: chunk rows R0 .. ch - 1
   const int n = a.npatch;
   const int ncol = cw + 2 * P; // table slots 1 .. ncol (slot x = frame column left - P - 1 + x); slot 0 is never summed
@@ -76,6 +82,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   float *const Tb = Z + wh * WP;             // [3][NLT_ROWS][TP]: terms, then column sums
   float *const Db = Tb + 3 * NLT_ROWS * TP;  // [2][NLT_ROWS][TP]: distortions
   int *const dsv = (int *)(Db + 2 * NLT_ROWS * TP); // window shift of every offset
+  int *const pdy = dsv + ((n + 3) & ~3), *const pdx = pdy + ((n + 3) & ~3); // BORDER: its row and column shift
   const int r0 = top + R0 - reach, c0 = left - reach;
   const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
 
@@ -85,14 +92,23 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     const int c = c0 + wx;
     F4 v;
     v.x = v.y = v.z = v.w = 0.0f;
-    if(c < W) v = in[(long)(r0 + wy) * W + c]; // the pitch may run past the frame's right edge; the rows are inside it
+    // the pitch may run past the frame's right edge; the rows of an interior chunk's window are inside the frame
+    if(c < W && (!BORDER || (c >= 0 && r0 + wy >= 0 && r0 + wy < H))) v = in[(long)(r0 + wy) * W + c];
     f2 xy;
     xy.x = v.x;
     xy.y = v.y;
     XY[i] = xy;
     Z[i] = v.z;
   }
-  for(int i = tid; i < n; i += NLT_THREADS) dsv[i] = patches[i].x * WP + patches[i].y;
+  for(int i = tid; i < n; i += NLT_THREADS)
+  {
+    dsv[i] = patches[i].x * WP + patches[i].y;
+    if(BORDER)
+    {
+      pdy[i] = patches[i].x;
+      pdx[i] = patches[i].y;
+    }
+  }
   env.sync();
 
   const int w = tid >> 6, lane = tid & 63;
@@ -104,6 +120,10 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int a_enter = (aj + P + reach) * WP + awc, a_leave = (aj - P - 1 + reach) * WP + awc; // rows R0 + aj + P and R0 + aj - P - 1
   const f2 oe_xy = XY[a_enter], ol_xy = XY[a_leave];
   const float oe_z = Z[a_enter], ol_z = Z[a_leave];
+  // BORDER: the frame rows / column of the lane's own pixels
+  const int a_re = top + R0 + aj + P, a_rl = top + R0 + aj - P - 1, a_c = left - P - 1 + ax;
+  const bool own_e = !BORDER || ((unsigned)a_re < (unsigned)H), own_l = !BORDER || ((unsigned)a_rl < (unsigned)H),
+             own_c = !BORDER || ((unsigned)a_c < (unsigned)W);
   // ---- (b): the lane's table column
   const bool b_on = (w == 1 && 1 + lane <= ncol) || (w == 0 && lane >= 16 && 49 + lane <= ncol);
   const int bx = w == 1 ? 1 + lane : 49 + lane; // wave 1: slots 1 .. 64; lanes 16 .. 27 of wave 0: slots 65 .. 76
@@ -126,8 +146,15 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       const float sez = Z[a_enter + dS], slz = Z[a_leave + dS];
       const float ex = oe_xy.x - se.x, ey = oe_xy.y - se.y, ez = oe_z - sez;
       const float lx = ol_xy.x - sl.x, ly = ol_xy.y - sl.y, lz = ol_z - slz;
-      const float nx2 = ex * ex, ny2 = ey * ey, nz2 = ez * ez;
-      const float px2 = lx * lx, py2 = ly * ly, pz2 = lz * lz;
+      float nx2 = ex * ex, ny2 = ey * ey, nz2 = ez * ez;
+      float px2 = lx * lx, py2 = ly * ly, pz2 = lz * lz;
+      if(BORDER)
+      {
+        const int dy = pdy[s], dx = pdx[s];
+        const bool col_ok = own_c && (unsigned)(a_c + dx) < (unsigned)W;
+        if(!(col_ok && own_e && (unsigned)(a_re + dy) < (unsigned)H)) nx2 = ny2 = nz2 = 0.0f;
+        if(!(col_ok && own_l && (unsigned)(a_rl + dy) < (unsigned)H)) px2 = py2 = pz2 = 0.0f;
+      }
       Tb[((s % 3) * NLT_ROWS + aj) * TP + ax] = ((nx2 - px2) * n0 + (ny2 - py2) * n1) + (nz2 - pz2) * n2;
     }
     if(b_on && s >= 1 && s <= n)
@@ -201,7 +228,8 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       const float dist = Db[((p & 1) * NLT_ROWS + dj) * TP + dc];
       const f2 q = XY[wo];
       const float qz = Z[wo];
-      const float wgt = nlm2::mexp2_scaled<Env>(dist, sharp_m23);
+      float wgt = nlm2::mexp2_scaled<Env>(dist, sharp_m23);
+      if(BORDER && !((unsigned)(top + R0 + dj + pdy[p]) < (unsigned)H && (unsigned)(left + dc + pdx[p]) < (unsigned)W)) wgt = 0.0f;
       accx = accx + q.x * wgt;
       accy = accy + q.y * wgt;
       accz = accz + qz * wgt;

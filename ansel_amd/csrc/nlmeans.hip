@@ -894,9 +894,9 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__res
 
 // the fused variant of the third version (nlm3_body.h, FUSED): three tables, the row recurrence inside the C role --
 // chunks of up to 64 rows (the 45 MP and 60 MP frames' grids)
-// TALL (round 5): a chunk grid of 65 - 69 rows (the 24 / 42 / 150 MP frames).  Interior chunks: the body runs the first 64 rows
-// and exports the column sums behind them, per offset, to seeds[interior ordinal][offset][slot] (nlm3_body.h TALL); nlm_tail
-// below continues them through the rows that are left.  The outermost ring keeps the first version's body, whole chunks.
+// TALL (round 5): a chunk grid of 65 - 69 rows (the 24 / 42 / 150 MP frames).  The body runs a chunk's first 64 rows and exports
+// the column sums behind them, per offset, to seeds[position in the launch][offset][slot] (nlm3_body.h TALL); nlm_tail below
+// continues them through the rows that are left -- interior chunks and the outermost ring alike (BORDER bodies).
 template <int NPXL, int MSEG, bool TALL>
 __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                              const nlm_args a_by_value, const int2 *__restrict__ patches,
@@ -916,19 +916,18 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__res
   {
     const int cy = chunk / a.nchx + a.cy0, cx = chunk % a.nchx;
     const int cw = min(a.chk_w, a.W - cx * a.chk_w), ch = min(a.chk_h, a.H - cy * a.chk_h);
-    if(TALL || !nlm3::border_fits(cw, ch)) pipelined_body(chunk, lds, in, out, a, patches);
-    else nlm3::body<NPXL, MSEG, true, true>(env, in, out, a, patches, ndx);
+    // (a tall chunk: the head's rows decide; a chunk the BORDER body refuses is lower than ten rows and has no tail)
+    if(!nlm3::border_fits(cw, TALL ? min(ch, nlm3::TALL_HEAD) : ch)) pipelined_body(chunk, lds, in, out, a, patches);
+    else nlm3::body<NPXL, MSEG, true, true, TALL>(env, in, out, a, patches, ndx,
+                                                  TALL ? seeds + (size_t)blockIdx.x * a.npatch * nlm3::TALL_SEED_PITCH : nullptr);
     return;
   }
-  if constexpr(TALL)
-    nlm3::body<NPXL, MSEG, false, true, true>(env, in, out, a, patches, ndx,
-                                              seeds + (size_t)(blockIdx.x - n_border) * a.npatch * nlm3::TALL_SEED_PITCH);
-  else
-    nlm3::body<NPXL, MSEG, false, true>(env, in, out, a, patches, ndx);
+  nlm3::body<NPXL, MSEG, false, true, TALL>(env, in, out, a, patches, ndx,
+                                            TALL ? seeds + (size_t)blockIdx.x * a.npatch * nlm3::TALL_SEED_PITCH : nullptr);
 }
 
-// the rows of the interior chunks of a tall grid behind the 64th (nlm_tail_body.h): one workgroup of 512 threads per
-// interior chunk, in the order (and with the export slots) of the head launch
+// the rows of the chunks of a tall grid behind the 64th (nlm_tail_body.h): one workgroup of 512 threads per chunk, in the
+// order (and with the export slots) of the head launch
 __global__ __launch_bounds__(NLT_THREADS, 2) void nlm_tail(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                            const nlm_args a, const int2 *__restrict__ patches,
                                                            const int *__restrict__ order, const int n_border,
@@ -937,8 +936,10 @@ __global__ __launch_bounds__(NLT_THREADS, 2) void nlm_tail(const float4 *__restr
   extern __shared__ float lds[];
   nlm2_device_env env;
   env.lds_ = lds;
-  env.chunk_ = order[n_border + blockIdx.x];
-  nlmt::body(env, in, out, a, patches, seeds + (size_t)blockIdx.x * a.npatch * NLT_SEED_PITCH);
+  env.chunk_ = order[blockIdx.x];
+  const float *const mine = seeds + (size_t)blockIdx.x * a.npatch * NLT_SEED_PITCH;
+  if(blockIdx.x < n_border) nlmt::body<true>(env, in, out, a, patches, mine);
+  else nlmt::body<false>(env, in, out, a, patches, mine);
 }
 
 typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
@@ -1164,9 +1165,9 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   }
   const int *const dev_order = (const int *)((const unsigned char *)dev_patches + patch_bytes);
   float *seeds = nullptr;
-  if(tall && nchunks > n_border)
+  if(tall)
   {
-    seeds = (float *)dt_hip_alloc_device_buffer(devid, (size_t)(nchunks - n_border) * a.npatch * NLT_SEED_PITCH * sizeof(float));
+    seeds = (float *)dt_hip_alloc_device_buffer(devid, (size_t)nchunks * a.npatch * NLT_SEED_PITCH * sizeof(float));
     if(!seeds)
     {
       dt_hip_release_mem_object(dev_patches);
@@ -1204,10 +1205,10 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
       nlm_chunks<false><<<grid, NLM_THREADS, lds_bytes, s>>>(in, out, a, dev_patches);
   }
   int err = check_launch("nlm_chunks");
-  if(err == DT_HIP_SUCCESS && tall && nchunks > n_border)
+  if(err == DT_HIP_SUCCESS && tall)
   {
     launch_scope ls(devid, "nlm_tail");
-    nlm_tail<<<(unsigned)(nchunks - n_border), NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, seeds);
+    nlm_tail<<<(unsigned)nchunks, NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, seeds);
     err = check_launch("nlm_tail");
   }
   if(seeds) dt_hip_release_mem_object(seeds);

@@ -338,9 +338,27 @@ static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, 
 //      column sums behind them (nlm3_body.h TALL), then nlm_tail_body.h on the rows that are left.  Interior chunks only
 //      (the device's launch hands the outermost ring to the first version's body).  Returns 1 when it ran, 0 when the
 //      configuration is not one the pair takes.
+static int nlm_tall_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                              int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                              float luma, float chroma, int *interior_chunks, const bool border);
 extern "C" int nlm_tall_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                                  int search_radius, float scale, float scattering, float sharpness, const float *norm,
                                  float luma, float chroma, int *interior_chunks)
+{
+  return nlm_tall_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma, chroma,
+                            interior_chunks, false);
+}
+// ... and the outermost ring with the BORDER bodies; *chunks = the chunks written
+extern "C" int nlm_tall_host_run_all(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                                     int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                                     float luma, float chroma, int *chunks)
+{
+  return nlm_tall_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma, chroma,
+                            chunks, true);
+}
+static int nlm_tall_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                              int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                              float luma, float chroma, int *interior_chunks, const bool border)
 {
   std::vector<I2> patches;
   int max_shift = 0;
@@ -385,6 +403,8 @@ extern "C" int nlm_tall_host_run(const float *in, float *out, int W, int H, int 
       const int bot = std::min(top + chk_h, H), right = std::min(left + chk_w, W);
       if(top >= a.reach && bot + a.reach <= H && left >= a.reach && right + a.reach <= W && bot - top == chk_h && right - left == chk_w)
         interior++;
+      else if(border && nlm3::border_fits(right - left, std::min(bot - top, NLT_HEAD_ROWS)))
+        interior++;
     }
   if(interior_chunks) *interior_chunks = interior;
   const int nchunks = a.nchx * nchy;
@@ -406,6 +426,12 @@ extern "C" int nlm_tall_host_run(const float *in, float *out, int W, int H, int 
           HostEnv env{ t, b, base, &bar, &xch };
           nlm3::body<9, 7, false, true, true>(env, fin, fout, a, patches.data(), ndx, seeds.data() + per_chunk * b);
           bar.arrive_and_wait();
+          if(border)
+          {
+            HostEnv envb{ t, b, base, &bar, &xch };
+            nlm3::body<9, 7, true, true, true>(envb, fin, fout, a, patches.data(), ndx, seeds.data() + per_chunk * b);
+            bar.arrive_and_wait();
+          }
         }
       });
     for(auto &th : pool) th.join();
@@ -422,8 +448,14 @@ extern "C" int nlm_tall_host_run(const float *in, float *out, int W, int H, int 
         for(int b = 0; b < nchunks; b++)
         {
           HostEnv env{ t, b, base, &bar, &xch };
-          nlmt::body(env, fin, fout, a, patches.data(), seeds.data() + per_chunk * b);
+          nlmt::body<false>(env, fin, fout, a, patches.data(), seeds.data() + per_chunk * b);
           bar.arrive_and_wait();
+          if(border)
+          {
+            HostEnv envb{ t, b, base, &bar, &xch };
+            nlmt::body<true>(envb, fin, fout, a, patches.data(), seeds.data() + per_chunk * b);
+            bar.arrive_and_wait();
+          }
         }
       });
     for(auto &th : pool) th.join();

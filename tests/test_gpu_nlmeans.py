@@ -94,9 +94,12 @@ def test_nlmeans_fused_variant_chunk_grids(w, h, luma, chroma, dispatch):
 
 # (width, height) -> chunk: (260, 207) 72 x 69 (the 24 MP frame's grid); (260, 204) 72 x 68 (42 MP); (170, 201) 64 x 67 (150 MP's
 # height); (260, 198) 72 x 66; (250, 195) 68 x 65: one tail row; (1200, 690) 72 x 69, 17 x 10 chunks, 8 x 15 of them interior;
-# (150, 138) 69-row chunks all in the border ring; (400, 483) 69 rows, SEVEN chunk rows, the last of them the frame's last
+# (150, 138) 69-row chunks all in the border ring; (400, 483) 69 rows, SEVEN chunk rows, the last of them the frame's last;
+# (151, 274) 64 x 69, the last row of chunks 67 rows (a tail of three) and the last 23 columns; (200, 196) 68 x 66, the last row of
+# chunks 64 rows: a head without a tail.  The outermost ring runs the BORDER bodies of head and tail
 @pytest.mark.parametrize("w,h,luma,chroma", [(260, 207, 0.5, 1.0), (260, 204, 1.0, 1.0), (170, 201, 0.3, 0.8), (260, 198, 0.5, 1.0),
-                                             (250, 195, 0.5, 0.9), (1200, 690, 0.5, 1.0), (150, 138, 0.5, 1.0), (400, 483, 0.5, 1.0)])
+                                             (250, 195, 0.5, 0.9), (1200, 690, 0.5, 1.0), (150, 138, 0.5, 1.0), (400, 483, 0.5, 1.0),
+                                             (151, 274, 0.5, 0.9), (200, 196, 0.5, 1.0)])
 def test_nlmeans_tall_chunk_grids(w, h, luma, chroma, dispatch):
     """frames whose chunks have 65 - 69 rows (24 MP: 69, 42 MP: 68, 150 MP: 67): the fused variant on the first 64 rows of
     every interior chunk + nlm_tail on the rows that are left (nlm_tail_body.h, round 5); the second version (the "nlm_v2"

@@ -282,3 +282,41 @@ def test_tall_pair_refuses_what_it_does_not_fit(host_kernel):
     assert host_kernel.nlm_tall_host_run(ck.ptr(img), ck.ptr(img), 256, 192, 72, 64, 2, 2, *tail) == 0   # 64 rows: the fused variant's own
     assert host_kernel.nlm_tall_host_run(ck.ptr(img), ck.ptr(img), 256, 207, 72, 69, 3, 2, *tail) == 0   # patch radius 3
     assert host_kernel.nlm_tall_host_run(ck.ptr(img), ck.ptr(img), 256, 207, 72, 69, 2, 2, C.c_float(1.0), C.c_float(0.9), *tail[2:]) == 0  # scattered
+
+
+# ... and the outermost ring of a tall grid: the BORDER bodies of head and tail (frames whose every chunk is in the ring, partial
+# last chunks: a last row of chunks of 65 - 68 rows has a tail of its own height, one of 10 - 64 rows has none, one lower than ten
+# rows keeps the first version's body and stays unwritten)
+CASES_TALL_B = [
+    (170, 138, 7, 0.5, 1.0),   # 64 x 69, every chunk in the ring
+    (260, 207, 7, 1.0, 1.0),   # 72 x 69: three rows of chunks, the middle ones interior
+    (181, 204, 3, 0.3, 0.8),   # 72 x 68, the last 37 columns
+    (151, 274, 3, 0.5, 0.9),   # 64 x 69 (274 = 3 x 69 + 67): the last row of chunks 67 rows, the last 23 columns (odd)
+    (200, 196, 2, 0.5, 1.0),   # 68 x 66 (196 = 2 x 66 + 64): the last row of chunks 64 rows -- a head without a tail
+]
+
+
+@pytest.mark.parametrize("w,h,K,luma,chroma", CASES_TALL_B)
+def test_tall_chunks_border_ring_on_the_host_equals_the_oracle(host_kernel, oracle_lib, w, h, K, luma, chroma):
+    o = oracle_lib
+    P = 2
+    img = _lab(w, h, 19 + K)
+    p = NlmParams(0.0, 1.0, luma, chroma, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    assert 65 <= ch <= 69, (cw, ch)
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm_tall_host_run_all(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(0.0),
+                                           C.c_float(p.sharpness), p.norm, C.c_float(luma), C.c_float(chroma), C.byref(seen))
+    assert rc == 1, "chunk grid %d x %d" % (cw, ch)
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    written = ~np.isnan(got[..., 0])
+    assert seen.value > 0 and int(written.sum()) > 0
+    bad = written & (got.view(np.uint32) != want.view(np.uint32)).any(axis=-1)
+    assert int(bad.sum()) == 0, "%d of %d written pixels differ; first at %s" % (int(bad.sum()), int(written.sum()), np.argwhere(bad)[:5].tolist())
+    nrows_last = h - (h - 1) // ch * ch
+    expect = w * (h if nrows_last >= 10 else h - nrows_last)
+    assert int(written.sum()) == expect
