@@ -13,7 +13,7 @@
 // One workgroup of 512 threads per interior chunk, four stages in flight, one barrier per offset:
 //   (a) offset s      waves 2-7   a lane = (table column x, tail row j): the term D(row + P) - D(row - P - 1) of the column
 //                                 recurrence (the lane's own two pixels stay in registers for the chunk)      -> T[s % 3]
-//   (b) offset s - 1  wave 1 + twelve lanes of wave 0   a lane = a table column: the exported sum + its <= 5 terms, in place
+//   (b) offset s - 1  wave 1   a lane = a table column (its first twelve lanes: two): the exported sum + its <= 5 terms, in place
 //   (c) offset s - 2  wave 0   eight lanes = a tail row: the sliding row sum (:405-415), the chain passed from lane to lane
 //                                 by a DPP shift as in the fused chunk kernel                                  -> D[s % 2]
 //   (d) offset s - 3  waves 2-7   a lane = a pixel: weight 2^-(distortion x sharpness), four accumulations (:416-436)
@@ -125,15 +125,16 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const bool own_e = !BORDER || ((unsigned)a_re < (unsigned)H), own_l = !BORDER || ((unsigned)a_rl < (unsigned)H),
              own_c = !BORDER || ((unsigned)a_c < (unsigned)W);
   // ---- (b): the lane's table column
-  const bool b_on = (w == 1 && 1 + lane <= ncol) || (w == 0 && lane >= 16 && 49 + lane <= ncol);
-  const int bx = w == 1 ? 1 + lane : 49 + lane; // wave 1: slots 1 .. 64; lanes 16 .. 27 of wave 0: slots 65 .. 76
+  // wave 1: slot 1 + lane, and its first twelve lanes slot 65 + lane as well (wave 0 carries the row chain: nothing else)
+  const bool b_on = w == 1 && 1 + lane <= ncol, b2_on = w == 1 && 65 + lane <= ncol;
+  const int bx = 1 + lane, bx2 = 65 + lane;
   // ---- (d): the lane's pixel
   const bool d_on = w >= 2 && u < cw * TR;
   const int dj = d_on ? u / cw : 0, dc = d_on ? u - dj * cw : 0;
   const int d_win = (dj + reach) * WP + reach + dc;
   float accx = 0.0f, accy = 0.0f, accz = 0.0f, accw = 0.0f;
   const float sharp_m23 = a.sharpness * -8388608.0f;
-  float seed = b_on ? seeds[bx] : 0.0f; // offset 0's, for stage 1
+  float seed = b_on ? seeds[bx] : 0.0f, seed2 = b2_on ? seeds[bx2] : 0.0f; // offset 0's, for stage 1
 
   for(int s = 0; s < n + 3; s++)
   {
@@ -170,6 +171,21 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         {
           v = v + col[j * TP];
           col[j * TP] = v;
+        }
+      }
+      if(b2_on)
+      {
+        float *const col2 = Tb + (((s - 1) % 3) * NLT_ROWS) * TP + bx2;
+        float v2 = seed2;
+        if(s < n) seed2 = seeds[(size_t)s * NLT_SEED_PITCH + bx2];
+#pragma unroll
+        for(int j = 0; j < NLT_ROWS; j++)
+        {
+          if(j < TR)
+          {
+            v2 = v2 + col2[j * TP];
+            col2[j * TP] = v2;
+          }
         }
       }
     }

@@ -928,18 +928,20 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__res
 
 // the rows of the chunks of a tall grid behind the 64th (nlm_tail_body.h): one workgroup of 512 threads per chunk, in the
 // order (and with the export slots) of the head launch
-__global__ __launch_bounds__(NLT_THREADS, 2) void nlm_tail(const float4 *__restrict__ in, float4 *__restrict__ out,
+// (two instantiations, two launches: with both bodies in one kernel the interior chunks' launch carried the ring's scalar
+// registers -- 86 where 80 let four workgroups share a CU)
+template <bool BORDER>
+__global__ __launch_bounds__(NLT_THREADS, 8) void nlm_tail(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                            const nlm_args a, const int2 *__restrict__ patches,
-                                                           const int *__restrict__ order, const int n_border,
+                                                           const int *__restrict__ order, const int first,
                                                            const float *__restrict__ seeds)
 {
   extern __shared__ float lds[];
   nlm2_device_env env;
   env.lds_ = lds;
-  env.chunk_ = order[blockIdx.x];
-  const float *const mine = seeds + (size_t)blockIdx.x * a.npatch * NLT_SEED_PITCH;
-  if(blockIdx.x < n_border) nlmt::body<true>(env, in, out, a, patches, mine);
-  else nlmt::body<false>(env, in, out, a, patches, mine);
+  const int pos = first + (int)blockIdx.x; // position in the head launch: its chunk and its export slot
+  env.chunk_ = order[pos];
+  nlmt::body<BORDER>(env, in, out, a, patches, seeds + (size_t)pos * a.npatch * NLT_SEED_PITCH);
 }
 
 typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
@@ -1208,7 +1210,9 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   if(err == DT_HIP_SUCCESS && tall)
   {
     launch_scope ls(devid, "nlm_tail");
-    nlm_tail<<<(unsigned)nchunks, NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, seeds);
+    if(n_border > 0) nlm_tail<true><<<(unsigned)n_border, NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, 0, seeds);
+    if(nchunks > n_border)
+      nlm_tail<false><<<(unsigned)(nchunks - n_border), NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, seeds);
     err = check_launch("nlm_tail");
   }
   if(seeds) dt_hip_release_mem_object(seeds);

@@ -323,7 +323,9 @@ def sclk_table(args):
         kernels = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):
         return {}, None
-    return {k: v["sclk_mhz"] for k, v in kernels.items() if "sclk_mhz" in v}, "committed profiles/r05_sclk_per_kernel_100MP_full.json"
+    # (launches of a few microseconds -- the wavelets' four-channel launches that leave at once -- have no meaningful ratio)
+    return ({k: v["sclk_mhz"] for k, v in kernels.items() if "sclk_mhz" in v and v.get("ms_avg", 0.0) >= 0.05},
+            "committed profiles/r05_sclk_per_kernel_100MP_full.json")
 
 
 def sclk_of(table, tag):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--preset", default="lens_deblur_soft")
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--radius", type=float, default=2.0, help="nlmeans: the module's patch radius (2 = its default)")
     ap.add_argument("--cpu", action="store_true",
                     help="amaze: also time the reference's own code (oracle/_ref/libansel_ref_fast.so, its release flags, OpenMP) on "
                          "the host for the same frame, and check the device output against it outside the reference's stale pixels")
@@ -62,7 +63,7 @@ def main():
         d = abi.BilatData.bilateral()
         fn = l.dt_hip_iop_bilat_process
     elif args.module == "nlmeans":
-        d = abi.NlmeansData(2.0, 50.0, 0.5, 1.0)
+        d = abi.NlmeansData(args.radius, 50.0, 0.5, 1.0)
         fn = l.dt_hip_iop_nlmeans_process
     elif args.module == "denoiseprofile_nlm":
         d = params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS)

@@ -36,5 +36,19 @@ A=$(find "$OUT/sqa" -name '*counter_collection.csv' | head -1)
 B=$(find "$OUT/sqb" -name '*counter_collection.csv' | head -1)
 C=$(find "$OUT/sqc" -name '*counter_collection.csv' | head -1)
 [ -n "$A" ] && python tools/pmc_sq_json.py "$OUT/pmc_sq.json" "bench.py $* (the timed steps only);" $A $B $C > "$OUT/pmc_sq.txt"
+# the kernels' VALU issue floors: the instruction mix of the SQ passes at the architectural issue rates (tools/valu_model.py ... arch)
+PIX=$(python - "$@" <<'PYEOF'
+import sys
+sys.path.insert(0, ".")
+from ansel_amd import synth
+size = "100MP"
+a = sys.argv[1:]
+if "--size" in a:
+    size = a[a.index("--size") + 1]
+w, h = synth.SIZES[size] if size in synth.SIZES else map(int, size.lower().split("x"))
+print(w * h)
+PYEOF
+)
+[ -f "$OUT/pmc_sq.json" ] && python tools/valu_model.py "$OUT/pmc_sq.json" arch "$PIX" "$OUT/isa_mix.json" > "$OUT/isa_mix.txt" 2>&1
 rm -rf "$OUT/stats" "$OUT/fetch" "$OUT/write" "$OUT/sqa" "$OUT/sqb" "$OUT/sqc"
 ls -la "$OUT"
