@@ -127,11 +127,11 @@ def test_third_version_on_the_host_equals_the_oracle(host_kernel, oracle_lib, w,
 # of chunks lower than 10 rows keeps the first version's body and stays unwritten), offsets longer than a chunk is far
 # from the edge
 CASES3B = [
-    (170, 150, 7, 0.5, 1.0),
-    (260, 168, 7, 1.0, 1.0),
+    (170, 150, 5, 0.5, 1.0),   # (search radius 5: rows of 11 offsets, more than one turn of a C lane's ring of ten, at half the
+    (260, 168, 7, 1.0, 1.0),   #  module's 225 offsets -- the host harness is 1 024 OS threads on a barrier; one case keeps the 225)
     (151, 140, 3, 0.3, 0.8),   # 64 x 51 chunks, the last 23 columns (odd) and 38 rows
-    (181, 140, 7, 0.5, 1.0),   # 72 x 51, the last 37 columns
-    (173, 159, 7, 0.5, 0.9),   # 68 x 53, the last 37 columns
+    (181, 140, 5, 0.5, 1.0),   # 72 x 51, the last 37 columns
+    (173, 159, 5, 0.5, 0.9),   # 68 x 53, the last 37 columns
 ]
 
 
@@ -168,9 +168,9 @@ def test_third_version_border_ring_on_the_host_equals_the_oracle(host_kernel, or
 # (width, height, search radius, luma, chroma, expected chunk, interior chunks)
 CASES4 = [
     (260, 192, 7, 0.5, 1.0, (72, 64), 2),    # the 45 MP / 60 MP frames' chunk: 72 x 64, the module's defaults
-    (260, 171, 7, 1.0, 1.0, (72, 57), 2),    # 57 rows: one more than the third version's
+    (260, 171, 5, 1.0, 1.0, (72, 57), 2),    # 57 rows: one more than the third version's
     (170, 183, 3, 0.3, 0.8, (64, 61), 1),    # 64 x 61, rows of 7 offsets
-    (260, 168, 7, 0.5, 1.0, (72, 56), 2),    # the 100 MP frame's chunk on the fused schedule
+    (260, 168, 5, 0.5, 1.0, (72, 56), 2),    # the 100 MP frame's chunk on the fused schedule
 ]
 
 
@@ -207,7 +207,7 @@ def test_fused_variant_refuses_what_it_does_not_fit(host_kernel):
 
 
 CASES4B = [
-    (170, 128, 7, 0.5, 1.0),   # 64-row chunks, every chunk in the ring
+    (170, 128, 5, 0.5, 1.0),   # 64-row chunks, every chunk in the ring
     (181, 171, 3, 0.3, 0.8),   # 72 x 57, the last 37 columns
     (151, 140, 3, 1.0, 1.0),   # 64 x 51 chunks, the last 23 columns (odd) and 38 rows
 ]
@@ -244,7 +244,7 @@ def test_fused_variant_border_ring_on_the_host_equals_the_oracle(host_kernel, or
 CASES_TALL = [
     (256, 207, 2, 0.5, 1.0, (72, 69), 2),    # 69 rows: five tail rows, rows of 5 offsets
     (260, 207, 7, 1.0, 1.0, (72, 69), 2),    # ... with the module's 225 offsets, no blend
-    (260, 204, 7, 0.5, 1.0, (72, 68), 2),    # 68 rows
+    (260, 204, 3, 0.5, 1.0, (72, 68), 2),    # 68 rows
     (170, 201, 3, 0.3, 0.8, (64, 67), 1),    # 67 rows, 64-column chunks (slots beyond the chunk in the tail's row batches)
     (260, 198, 3, 0.5, 1.0, (72, 66), 2),    # 66 rows
     (250, 195, 3, 0.5, 0.9, (68, 65), 2),    # 65 rows: ONE tail row; 68-column chunks
@@ -288,8 +288,9 @@ def test_tall_pair_refuses_what_it_does_not_fit(host_kernel):
 # last chunks: a last row of chunks of 65 - 68 rows has a tail of its own height, one of 10 - 64 rows has none, one lower than ten
 # rows keeps the first version's body and stays unwritten)
 CASES_TALL_B = [
-    (170, 138, 7, 0.5, 1.0),   # 64 x 69, every chunk in the ring
-    (260, 207, 7, 1.0, 1.0),   # 72 x 69: three rows of chunks, the middle ones interior
+    (170, 138, 3, 0.5, 1.0),   # 64 x 69, every chunk in the ring (49 offsets: the 225 of the module's defaults run on the interior
+                               # case above and, on the device, in tests/test_gpu_nlmeans.py)
+    (260, 207, 3, 1.0, 1.0),   # 72 x 69: three rows of chunks, the middle ones interior
     (181, 204, 3, 0.3, 0.8),   # 72 x 68, the last 37 columns
     (151, 274, 3, 0.5, 0.9),   # 64 x 69 (274 = 3 x 69 + 67): the last row of chunks 67 rows, the last 23 columns (odd)
     (200, 196, 2, 0.5, 1.0),   # 68 x 66 (196 = 2 x 66 + 64): the last row of chunks 64 rows -- a head without a tail
