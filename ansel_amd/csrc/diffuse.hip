@@ -476,22 +476,35 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
   // the three support rows of the window live in three register sets used in rotation -- support row v in set v % 3, the
   // row loop unrolled by three -- so that moving the window down a row moves no register (it was 48 v_mov per row)
   float4 Hw[3][3], Lw[3][3];
+  // the output of the row step before, stored behind the NEXT row step's fetches and barrier (row_step())
+  struct
+  {
+    float4 o;
+    size_t idx;
+    bool have;
+  } pending;
+  pending.have = false;
   // fetch support row v into set `slot` and leave its squared ratios in ring row v % PDE_RING
   auto fetch_row = [&](const int v, auto slot_tag) {
     constexpr int SL = decltype(slot_tag)::value;
     const size_t y = PDE_ROW(v);
+    // ALL nine fetches of the row are issued before the first is used (round 5).  The compiler had scheduled the first
+    // subtraction c - low between the fifth and the sixth fetch: `s_waitcnt vmcnt(0)` there -- two memory round trips per row
+    // step instead of one, and, the vector-memory counter being in order, the first of them also waited for the store the row
+    // step before had just issued.  That store now goes out in the middle of THIS row step (row_step(): `pending`), a whole
+    // update's arithmetic ahead of the next wait for fetches.
+    float4 c[3], low[3];
 #pragma unroll
     for(int jj = 0; jj < 3; jj++)
     {
-      if(HSUB)
-      {
-        const float4 c = hf[y + cols[jj]], low = hsub[y + cols[jj]];
-        Hw[SL][jj] = make_float4(c.x - low.x, c.y - low.y, c.z - low.z, c.w - low.w);
-      }
-      else
-        Hw[SL][jj] = hf[y + cols[jj]];
+      c[jj] = hf[y + cols[jj]];
+      if(HSUB) low[jj] = hsub[y + cols[jj]];
       Lw[SL][jj] = lf[y + cols[jj]];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for(int jj = 0; jj < 3; jj++)
+      Hw[SL][jj] = HSUB ? make_float4(c[jj].x - low[jj].x, c[jj].y - low[jj].y, c[jj].z - low[jj].z, c[jj].w - low[jj].w) : c[jj];
     float4 *const ring = r2s + (v % PDE_RING) * tw;
     // the fourth channel's squared ratio is +0 when both samples are +0 (0 / 1e-8, squared): a wave whose samples all
     // are -- what a pipe hands this module, see alpha_is_blank() -- skips that division (a uniform branch)
@@ -506,6 +519,8 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
   // output row kk of the strip: its support rows kk, kk + 1 (fetched) and kk + 2 (fetched here), in sets T, T + 1, T + 2 mod 3
   auto row_step = [&](auto t_tag, const int kk) {
     constexpr int T = decltype(t_tag)::value, S0 = T, S1 = (T + 1) % 3, S2 = (T + 2) % 3;
+    // (a mode spelled at compile time whose orders read at most ONE of the two gradient directions)
+    constexpr bool WIDE_READS = MODE >= 0 && !(((MODE % 3) | ((MODE / 9) % 3)) && (((MODE / 3) % 3) | ((MODE / 27) % 3)));
     fetch_row(kk + 2, std::integral_constant<int, S2>());
     __syncthreads();
     if(!live) return;
@@ -513,6 +528,18 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     const float4 L4[9] = { Lw[S0][0], Lw[S0][1], Lw[S0][2], Lw[S1][0], Lw[S1][1], Lw[S1][2], Lw[S2][0], Lw[S2][1], Lw[S2][2] };
     const int row = r_first + kk * mult;
     const bool blank = alpha_is_blank(H4, L4);
+    // the output of the row step before goes out HERE: every register of the fetched row has been read by now (the blank test
+    // reads the last of them), so no wait for a fetch comes behind this store -- the compiler merges the counters of the two
+    // paths of a branch conservatively, and a store in front of the first use of a fetched register made that use wait for
+    // the store as well (`s_waitcnt vmcnt(0)`)
+    __builtin_amdgcn_sched_barrier(0);
+    if(pending.have)
+    {
+      if(final_pass) nt_store(out + pending.idx, pending.o);
+      else out[pending.idx] = pending.o;
+      pending.have = false;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float4 energy = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for(int ii = 0; ii < 3; ii++)
@@ -527,8 +554,10 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
         energy.z += r.z;
         if(!(blank && a.wskip)) energy.w += r.w; // (nobody reads it otherwise)
       }
-      // three reads in flight, not nine (they sit on top of the 72 registers of the support)
-      asm volatile("" : "+v"(energy.x), "+v"(energy.y), "+v"(energy.z), "+v"(energy.w) : : "memory");
+      // three reads in flight, not nine (they sit on top of the 72 registers of the support) -- six + three where the mode
+      // leaves the registers (one direction or none: 122 of 128; two directions would need 134): a round trip through the
+      // LDS fewer per row step
+      if(!WIDE_READS || ii >= 1) asm volatile("" : "+v"(energy.x), "+v"(energy.y), "+v"(energy.z), "+v"(energy.w) : : "memory");
     }
     const size_t idx = (size_t)row * a.width + col;
     float4 o;
@@ -560,8 +589,9 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       }
     }
     if(a.post_lab) o = px_rgb_to_lab(o, a.post_m);
-    if(final_pass) nt_store(out + idx, o);
-    else out[idx] = o;
+    pending.o = o;
+    pending.idx = idx;
+    pending.have = true;
   };
   fetch_row(0, std::integral_constant<int, 0>());
   fetch_row(1, std::integral_constant<int, 1>());
@@ -570,6 +600,11 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     row_step(std::integral_constant<int, 0>(), kk);
     if(kk + 1 < nrows) row_step(std::integral_constant<int, 1>(), kk + 1);
     if(kk + 2 < nrows) row_step(std::integral_constant<int, 2>(), kk + 2);
+  }
+  if(pending.have)
+  {
+    if(final_pass) nt_store(out + pending.idx, pending.o);
+    else out[pending.idx] = pending.o;
   }
 #undef PDE_ROW
 }
