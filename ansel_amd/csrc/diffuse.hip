@@ -74,6 +74,7 @@ struct pde_args
   int post_lab;        // the pipe's RGB -> Lab glue behind the module, applied where the last pass stores (strip kernel)
   float post_m[3][4];
   int approx_div;      // measuring builds only (ANSEL_HIP_PDE_APPROX_DIV): PDE_APPROX below
+  int off;             // measuring builds only (ANSEL_HIP_PDE_OFF): parts of the strip kernel switched off, PDE_OFF below
 };
 
 // What would the north star's 1 ULP buy?  Measuring builds can run the strip kernel with every division as v_rcp, one
@@ -82,8 +83,13 @@ struct pde_args
 // milliseconds (profiles/r05_pde_div_ab.json).  Never in the product: PDE_APPROX() is the constant 0 there.
 #ifdef ANSEL_HIP_MEASURING
 #define PDE_APPROX(a) ((a).approx_div != 0)
+// timing experiments (wrong results): 1 no barrier, 2 no fetches behind the strip's first rows (the registers keep what they
+// hold), 4 no squared-ratio ring (no LDS stores / reads; the energy is a constant), 8 no store, 16 no update arithmetic (the
+// output is a sample) -- tools/pde_off_ab.py times the strip kernel with each switched off in turn
+#define PDE_OFF(a, bit) (((a).off & (bit)) != 0)
 #else
 #define PDE_APPROX(a) false
+#define PDE_OFF(a, bit) false
 #endif
 __device__ __forceinline__ float div_1ulp(const float x, const float y)
 {
@@ -494,12 +500,24 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     // step before had just issued.  That store now goes out in the middle of THIS row step (row_step(): `pending`), a whole
     // update's arithmetic ahead of the next wait for fetches.
     float4 c[3], low[3];
-#pragma unroll
-    for(int jj = 0; jj < 3; jj++)
+    if(PDE_OFF(a, 2) && v >= 2)
     {
-      c[jj] = hf[y + cols[jj]];
-      if(HSUB) low[jj] = hsub[y + cols[jj]];
-      Lw[SL][jj] = lf[y + cols[jj]];
+#pragma unroll
+      for(int jj = 0; jj < 3; jj++)
+      {
+        c[jj] = Hw[SL][jj];
+        low[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    else
+    {
+#pragma unroll
+      for(int jj = 0; jj < 3; jj++)
+      {
+        c[jj] = hf[y + cols[jj]];
+        if(HSUB) low[jj] = hsub[y + cols[jj]];
+        Lw[SL][jj] = lf[y + cols[jj]];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -512,6 +530,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       const bool blank = a.wskip && __builtin_amdgcn_ballot_w64((__float_as_uint(h.w) | __float_as_uint(l.w)) != 0) == 0ull;
       return ratio2_rgb(h, l, blank ? 0.0f : ratio2(h.w, l.w), PDE_APPROX(a));
     };
+    if(PDE_OFF(a, 4)) return;
     ring[tx + mult] = ratios(Hw[SL][1], Lw[SL][1]);
     if(tx < mult) ring[tx] = ratios(Hw[SL][0], Lw[SL][0]);
     if(tx >= 256 - mult) ring[tx + 2 * mult] = ratios(Hw[SL][2], Lw[SL][2]);
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     // (a mode spelled at compile time whose orders read at most ONE of the two gradient directions)
     constexpr bool WIDE_READS = MODE >= 0 && !(((MODE % 3) | ((MODE / 9) % 3)) && (((MODE / 3) % 3) | ((MODE / 27) % 3)));
     fetch_row(kk + 2, std::integral_constant<int, S2>());
-    __syncthreads();
+    if(!PDE_OFF(a, 1)) __syncthreads();
     if(!live) return;
     const float4 H4[9] = { Hw[S0][0], Hw[S0][1], Hw[S0][2], Hw[S1][0], Hw[S1][1], Hw[S1][2], Hw[S2][0], Hw[S2][1], Hw[S2][2] };
     const float4 L4[9] = { Lw[S0][0], Lw[S0][1], Lw[S0][2], Lw[S1][0], Lw[S1][1], Lw[S1][2], Lw[S2][0], Lw[S2][1], Lw[S2][2] };
@@ -533,7 +552,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     // paths of a branch conservatively, and a store in front of the first use of a fetched register made that use wait for
     // the store as well (`s_waitcnt vmcnt(0)`)
     __builtin_amdgcn_sched_barrier(0);
-    if(pending.have)
+    if(pending.have && !PDE_OFF(a, 8))
     {
       if(final_pass) nt_store(out + pending.idx, pending.o);
       else out[pending.idx] = pending.o;
@@ -541,6 +560,8 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     }
     __builtin_amdgcn_sched_barrier(0);
     float4 energy = make_float4(0.f, 0.f, 0.f, 0.f);
+    if(PDE_OFF(a, 4)) energy = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+    else
 #pragma unroll
     for(int ii = 0; ii < 3; ii++)
     {
@@ -567,6 +588,8 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       const float4 h = H4[4], l = L4[4];
       o = make_float4(max_zero(h.x + l.x), max_zero(h.y + l.y), max_zero(h.z + l.z), max_zero(h.w + l.w));
     }
+    else if(PDE_OFF(a, 16))
+      o = make_float4(H4[4].x + energy.x, L4[4].y + energy.y, H4[0].z + energy.z, L4[8].w);
     else
     {
       float H[9], L[9];
@@ -793,6 +816,8 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
   {
     const char *const approx_env = measuring_env("ANSEL_HIP_PDE_APPROX_DIV"); // read per call: tools/pde_div_ab.py flips it
     a.approx_div = approx_env && atoi(approx_env) != 0;
+    const char *const off_env = measuring_env("ANSEL_HIP_PDE_OFF"); // read per call: tools/pde_off_ab.py
+    a.off = off_env ? atoi(off_env) : 0;
   }
   const float user_aniso[4] = { d->anisotropy_first, d->anisotropy_second, d->anisotropy_third, d->anisotropy_fourth };
   for(int k = 0; k < 4; k++)

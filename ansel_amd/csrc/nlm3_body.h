@@ -648,18 +648,57 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         qz[SL] = Z[wi];
       }
     };
+    // The weights and accumulations of an offset, THREE pixels abreast (round 5).  The compiler had emitted the nine pixels one
+    // after the other through two scratch registers: 13 instructions a pixel, each waiting for the one before -- and a wave
+    // issues a dependent instruction every ~8 cycles, an independent one every ~5 (profiles/r05_valu_issue_cycles.json): ~950
+    // cycles of a ~2 300-cycle stage in every one of the role's waves.  Here each step of the weight (dt_fast_mexp2f(): product,
+    // NaN guard, conversion, exponent add, range select) and each of the four accumulations is written for three pixels at a time
+    // and fenced, so that three independent instructions follow each other; same operations on the same operands per pixel.
     auto accumulate = [&](auto m_tag) {
       constexpr int M = decltype(m_tag)::value;
+      static_assert(NPXL % 3 == 0, "accumulate() takes the pixels of a lane in threes");
 #pragma unroll
-      for(int i = 0; i < NPXL; i++)
+      for(int g = 0; g < NPXL; g += 3)
       {
-        const int sl = (i + M) % NR;
-        float wgt = nlm2::mexp2_scaled<Env>(dist[M & 1][i], sharp_m23);
-        if(BORDER && !(reached[M & 1] >> i & 1u)) wgt = 0.0f;
-        accx[i] = accx[i] + qx[sl] * wgt;
-        accy[i] = accy[i] + qy[sl] * wgt;
-        accz[i] = accz[i] + qz[sl] * wgt;
-        accw[i] = accw[i] + 1.0f * wgt;
+        float v[3], wgt[3], t[3];
+        int k0[3];
+#pragma unroll
+        for(int j = 0; j < 3; j++) v[j] = dist[M & 1][g + j] * sharp_m23;
+        env.sched_fence();
+#pragma unroll
+        for(int j = 0; j < 3; j++) v[j] = Env::max_num(v[j], -__builtin_inff());
+        env.sched_fence();
+#pragma unroll
+        for(int j = 0; j < 3; j++) k0[j] = Env::cvt_i32_sat(v[j]);
+        env.sched_fence();
+#pragma unroll
+        for(int j = 0; j < 3; j++) k0[j] = (int)(0x3f800000u + (unsigned)k0[j]);
+        env.sched_fence();
+#pragma unroll
+        for(int j = 0; j < 3; j++)
+        {
+          wgt[j] = Env::int_as_float(k0[j] >= 0x800000 ? k0[j] : 0);
+          if(BORDER && !(reached[M & 1] >> (g + j) & 1u)) wgt[j] = 0.0f;
+        }
+        env.sched_fence();
+#pragma unroll
+        for(int j = 0; j < 3; j++) t[j] = qx[(g + j + M) % NR] * wgt[j];
+        env.sched_fence();
+#pragma unroll
+        for(int j = 0; j < 3; j++) accx[g + j] = accx[g + j] + t[j];
+#pragma unroll
+        for(int j = 0; j < 3; j++) t[j] = qy[(g + j + M) % NR] * wgt[j];
+        env.sched_fence();
+#pragma unroll
+        for(int j = 0; j < 3; j++) accy[g + j] = accy[g + j] + t[j];
+#pragma unroll
+        for(int j = 0; j < 3; j++) t[j] = qz[(g + j + M) % NR] * wgt[j];
+        env.sched_fence();
+#pragma unroll
+        for(int j = 0; j < 3; j++) accz[g + j] = accz[g + j] + t[j];
+#pragma unroll
+        for(int j = 0; j < 3; j++) accw[g + j] = accw[g + j] + 1.0f * wgt[j];
+        env.sched_fence();
       }
     };
     env.sync();
