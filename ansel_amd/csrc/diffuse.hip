@@ -457,8 +457,45 @@ __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf
 // coarser one, and a support sample is their difference, the subtraction decompose_2D_Bspline() stores (bspline.h:369-374:
 // same operands, same operation).  The analysis then writes 16 B per pixel and scale instead of 32, and this kernel, which
 // waits for its arithmetic and not for its fetches, reads 48 instead of 32.
+// DMA (round 5, HSUB only): the kernel has two bounds of the same size -- its bytes and its update's arithmetic (11.7 and
+// 12.0 ms of 16.9) -- that overlapped by half: a wave fetched its row, waited, then computed with nothing in flight.  Here the rows
+// arrive by LDS-DMA (global_load_lds_dwordx4: no destination registers, so the fetch of support row kk + 3 is in flight during ALL of
+// output row kk's arithmetic, and nothing the register allocator does can touch data that has not landed).  Each WAVE owns a landing zone
+// of [3 planes][64 + 2 mult] samples -- its own 64 columns and the mult either side: what its lanes' three support columns span -- fills
+// it itself (each lane one sample per plane, the first 2 mult lanes one more) and reads it back after ITS OWN `s_waitcnt vmcnt(0)`: no
+// barrier beyond the ratio ring's.  A sample is fetched once per wave (1.03 - 1.5 times per workgroup) instead of by three lanes.  The
+// fetches are inline assembly (hipcc waits vmcnt(0) at every barrier for an LDS-DMA it knows of); the only vector-memory operation
+// the compiler sees in the loop is the store.
 #define PDE_RING 4
-template <bool HSUB, int MODE>
+#define PDE_DMA_MAX_MULT 16
+// three planes' pieces of one landing-zone row segment: lane l's 16 bytes at base + voff go to LDS byte dst + 16 l.  M0 carries the
+// destination and is the compiler's: saved and restored inside the statement.  lgkmcnt(0) first: the zone's previous contents have been
+// READ (the ds_reads have returned) before anything is sent to overwrite them.  s_nop 4: an SGPR operand a VALU wrote (readfirstlane)
+// is five wait states from a vector-memory instruction reading it, and nothing pads an inline statement.
+template <int NPL>
+__device__ __forceinline__ void pde_dma_planes(const float4 *const p0, const float4 *const p1, const float4 *const p2, const unsigned voff,
+                                               const unsigned d0, const unsigned d1, const unsigned d2)
+{
+  unsigned keep;
+  if constexpr(NPL == 3)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 4\n\ts_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(p0), "s"(p1), "s"(p2), "s"(d0), "s"(d1), "s"(d2)
+                 : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 4\n\ts_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(p0), "s"(p2), "s"(d0), "s"(d2)
+                 : "memory");
+}
+template <bool HSUB, int MODE, bool DMA = false>
 __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__restrict__ hf, const float4 *__restrict__ hsub,
                                                          const float4 *__restrict__ lf,
                                                          float4 *__restrict__ out, const pde_args a, const int final_pass,
@@ -482,6 +519,21 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
   // the three support rows of the window live in three register sets used in rotation -- support row v in set v % 3, the
   // row loop unrolled by three -- so that moving the window down a row moves no register (it was 48 v_mov per row)
   float4 Hw[3][3], Lw[3][3];
+  // DMA: this wave's landing zone behind the ring, [NPL][zw] samples; slot x of a plane's row = column clamp(col0 - mult + x) where
+  // col0 is the wave's first column: lane l reads slots l, l + mult, l + 2 mult = its three support columns cols[]
+  constexpr int NPL = HSUB ? 3 : 2;
+  const int lane = tx & 63, zw = 64 + 2 * mult;
+  float4 *const zone = r2s + PDE_RING * tw + (tx >> 6) * NPL * zw;
+  const unsigned zone_lds = DMA ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)zone) : 0u;
+  const unsigned off_main = (unsigned)cols[0] * 16u, off_halo = (unsigned)clampi(col - mult + 64, 0, a.width - 1) * 16u;
+  // send for support row v: every lane one sample per plane, the first 2 mult lanes the zone's last 2 mult slots as well
+  auto dma_row = [&](const int v) {
+    const size_t y = PDE_ROW(v);
+    const unsigned pl = (unsigned)zw * 16u;
+    pde_dma_planes<NPL>(hf + y, hsub + y, lf + y, off_main, zone_lds, zone_lds + pl, zone_lds + (NPL - 1) * pl);
+    if(lane < 2 * mult)
+      pde_dma_planes<NPL>(hf + y, hsub + y, lf + y, off_halo, zone_lds + 1024u, zone_lds + pl + 1024u, zone_lds + (NPL - 1) * pl + 1024u);
+  };
   // the output of the row step before, stored behind the NEXT row step's fetches and barrier (row_step())
   struct
   {
@@ -500,7 +552,19 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     // step before had just issued.  That store now goes out in the middle of THIS row step (row_step(): `pending`), a whole
     // update's arithmetic ahead of the next wait for fetches.
     float4 c[3], low[3];
-    if(PDE_OFF(a, 2) && v >= 2)
+    if constexpr(DMA)
+    {
+      // everything this wave sent for has landed (and the row step before's store has left)
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+      for(int jj = 0; jj < 3; jj++)
+      {
+        c[jj] = zone[lane + jj * mult];
+        if(HSUB) low[jj] = zone[zw + lane + jj * mult];
+        Lw[SL][jj] = zone[(NPL - 1) * zw + lane + jj * mult];
+      }
+    }
+    else if(PDE_OFF(a, 2) && v >= 2)
     {
 #pragma unroll
       for(int jj = 0; jj < 3; jj++)
@@ -541,6 +605,17 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     // (a mode spelled at compile time whose orders read at most ONE of the two gradient directions)
     constexpr bool WIDE_READS = MODE >= 0 && !(((MODE % 3) | ((MODE / 9) % 3)) && (((MODE / 3) % 3) | ((MODE / 27) % 3)));
     fetch_row(kk + 2, std::integral_constant<int, S2>());
+    if constexpr(DMA)
+    {
+      // the row step before's pixel leaves, then the fetch of the NEXT step's row: both in flight through all of this step's arithmetic
+      if(pending.have)
+      {
+        if(final_pass) nt_store(out + pending.idx, pending.o);
+        else out[pending.idx] = pending.o;
+        pending.have = false;
+      }
+      if(kk + 1 < nrows) dma_row(kk + 3);
+    }
     if(!PDE_OFF(a, 1)) __syncthreads();
     if(!live) return;
     const float4 H4[9] = { Hw[S0][0], Hw[S0][1], Hw[S0][2], Hw[S1][0], Hw[S1][1], Hw[S1][2], Hw[S2][0], Hw[S2][1], Hw[S2][2] };
@@ -616,14 +691,18 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
     pending.idx = idx;
     pending.have = true;
   };
+  if constexpr(DMA) dma_row(0);
   fetch_row(0, std::integral_constant<int, 0>());
+  if constexpr(DMA) dma_row(1);
   fetch_row(1, std::integral_constant<int, 1>());
+  if constexpr(DMA) dma_row(2);
   for(int kk = 0; kk < nrows; kk += 3)
   {
     row_step(std::integral_constant<int, 0>(), kk);
     if(kk + 1 < nrows) row_step(std::integral_constant<int, 1>(), kk + 1);
     if(kk + 2 < nrows) row_step(std::integral_constant<int, 2>(), kk + 2);
   }
+  if constexpr(DMA) asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); // nothing of this wave's is on its way to an LDS it has left
   if(pending.have)
   {
     if(final_pass) nt_store(out + pending.idx, pending.o);
@@ -797,6 +876,7 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
   // high-frequency plane, and one plane besides them serves the synthesis' ping-pong (a plane fewer than the reference)
   static const bool per_row_pde = measuring_env("ANSEL_HIP_PDE_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
   static const bool hf_planes = measuring_env("ANSEL_HIP_DIFFUSE_HF_PLANES") != nullptr; // the stored-HF path, for A/B timing
+  static const bool no_dma = measuring_env("ANSEL_HIP_PDE_NO_DMA") != nullptr; // the rows through registers (round 4's fetch), for A/B timing
   const bool lf_chain = !per_row_pde && !hf_planes && (1 << (scales - 1)) <= PDE_SHARED_MULT;
   float4 *hf[DIFFUSE_MAX_SCALES] = { nullptr };
   float4 *lf[2] = { nullptr, nullptr }, *tmp[2] = { nullptr, nullptr };
@@ -931,11 +1011,16 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           const dim3 sgrid(gx, classes * spc);
           const float4 *const h0 = chain ? (s == 0 ? src : hf[s - 1]) : hf[s], *const h1 = chain ? hf[s] : nullptr;
 #define PDE_LAUNCH(HS, MD) diffuse_pde_strip<HS, MD><<<sgrid, 256, ring, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
+          // the rows by LDS-DMA into per-wave landing zones behind the ring (the kernel's comment): the two-plane path of the chain
+          const bool dma = chain && a.mult <= PDE_DMA_MAX_MULT && !no_dma;
+          const size_t ring_dma = ring + (size_t)4 * 3 * (64 + 2 * a.mult) * sizeof(float4);
+#define PDE_LAUNCH_DMA(MD) diffuse_pde_strip<true, MD, true><<<sgrid, 256, ring_dma, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
           bool launched = false;
 #define PDE_CASE(MD)                     \
   if(!launched && mode == (MD))          \
   {                                      \
-    if(chain) PDE_LAUNCH(true, MD);      \
+    if(dma) PDE_LAUNCH_DMA(MD);          \
+    else if(chain) PDE_LAUNCH(true, MD); \
     else PDE_LAUNCH(false, MD);          \
     launched = true;                     \
   }
@@ -943,9 +1028,11 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
 #undef PDE_CASE
           if(!launched)
           {
-            if(chain) PDE_LAUNCH(true, -1);
+            if(dma) PDE_LAUNCH_DMA(-1);
+            else if(chain) PDE_LAUNCH(true, -1);
             else PDE_LAUNCH(false, -1);
           }
+#undef PDE_LAUNCH_DMA
 #undef PDE_LAUNCH
         }
         else if(a.mult <= PDE_SHARED_MULT)

@@ -25,7 +25,7 @@ def kernels():
 
 
 # the kernels of the metric's workload (bench.py's full pipe, every launch group) and of the other BASELINE configurations
-HOT = [r"^void dn_decompose_strip<", r"^void diffuse_pde_strip<(true|false), \d+>", r"bspline_decompose_strip", r"^void nlm_chunks_v3<9, 6>",
+HOT = [r"^void dn_decompose_strip<", r"^void diffuse_pde_strip<(true|false), \d+, (true|false)>", r"bspline_decompose_strip", r"^void nlm_chunks_v3<9, 6>",
        r"^void nlm_chunks_v4<9, 7>", r"^void nlm_tail<", r"^void ansel::rgb_chain<", r"^void dn_finish_chain<", r"rcd_tiles", r"raw_chain",
        r"bilat_(zcells|splat2|blur_line|blur_line_z|slice)", r"dn_band_(sums|threshold)", r"^void filmic_kernel<", r"conv_kernel|colorspace"]
 
@@ -47,8 +47,19 @@ def test_occupancy_bounds_design_quotes(kernels):
         if name.startswith("void dn_decompose_strip<") and not name.startswith("void dn_decompose_strip<true, 0"):
             assert k["vgpr"] <= 64, (name, k["vgpr"])
         # four waves a SIMD: <= 128 for the preset modes of the diffusion PDE and for the sixteen-wave non-local-means workgroups
-        if re.match(r"void diffuse_pde_strip<(true|false), \d+>", name) or name.startswith("void nlm_chunks_v"):
+        if re.match(r"void diffuse_pde_strip<(true|false), \d+, (true|false)>", name) or name.startswith("void nlm_chunks_v"):
             assert k["vgpr"] <= 128, (name, k["vgpr"])
+
+
+def test_the_pde_has_its_dma_instantiations(kernels):
+    """every preset mode of the diffusion PDE exists with its rows fetched by LDS-DMA (the chain's path at dilations <= 16) and
+    without (the larger dilations, the stored-detail path)"""
+    names = {re.sub(r"\(.*", "", k["demangled"]) for k in kernels}
+    modes = {re.match(r"void diffuse_pde_strip<true, (-?\d+), true>", n).group(1) for n in names
+             if re.match(r"void diffuse_pde_strip<true, -?\d+, true>", n)}
+    assert len(modes) == 9, modes  # eight preset combinations + the run-time kinds
+    for m in modes:
+        assert "void diffuse_pde_strip<true, %s, false>" % m in names and "void diffuse_pde_strip<false, %s, false>" % m in names
 
 
 def test_kernarg_offsets_match_what_the_kernels_read(kernels):
