@@ -20,6 +20,12 @@ CASES = [
                               variance_threshold=-0.5, regularization=2.5), (417, 283)),
     ("fast_local_contrast", {}, (700, 500)),            # 10 scales, dilation up to 512 > frame height
     ("fast_local_contrast", dict(radius=100, radius_center=40), (1211, 160)),
+    # frames narrower than a wave's 64 columns, than a landing zone's halo (the PDE's rows arrive by LDS-DMA: every slot of a
+    # zone is a clamped column), one column short of / past a 256-column workgroup, and lower than a strip
+    ("lens_deblur_soft", dict(iterations=2), (37, 29)),
+    ("default", dict(radius=16), (9, 70)),
+    ("lens_deblur_soft", dict(iterations=1), (255, 33)),
+    ("default", dict(radius=16), (257, 19)),
 ]
 
 
