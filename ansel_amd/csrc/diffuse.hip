@@ -998,6 +998,10 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           const int classes = h < a.mult ? h : a.mult, per_class = (h + a.mult - 1) / a.mult;
           const int gx = (w + 255) / 256;
           int strip = 32;
+#ifdef ANSEL_HIP_MEASURING
+          static const char *const strip_env = measuring_env("ANSEL_HIP_PDE_STRIP"); // rows a workgroup keeps its columns for, for A/B timing
+          if(strip_env) strip = atoi(strip_env);
+#endif
           while(strip > 4 && (size_t)gx * classes * ((per_class + strip - 1) / strip) < 2048) strip /= 2;
           const int spc = (per_class + strip - 1) / strip;
           size_t ring = (size_t)PDE_RING * (256 + 2 * a.mult) * sizeof(float4);
