@@ -287,7 +287,7 @@ def verify_output(out16, raw_host, width, height, with_filmic, which):
 
 
 PMC_SUMMARIES = {  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of THIS configuration, newest first
-    "full": ("r05_pmc_hbm_bytes_100MP_full.json", "r04_pmc_hbm_bytes_100MP_full.json", "r03_pmc_hbm_bytes_100MP_full.json"),
+    "full": ("r05_dma_pmc_hbm_bytes_100MP_full.json", "r05_pmc_hbm_bytes_100MP_full.json", "r04_pmc_hbm_bytes_100MP_full.json", "r03_pmc_hbm_bytes_100MP_full.json"),
     "light": ("r03_pmc_hbm_bytes_100MP_light_fused.json", "r02_pmc_hbm_bytes_100MP_light_fused.json"),
 }
 
@@ -318,14 +318,18 @@ def sclk_table(args):
     v_add_f32, 2.4 for the half- and quarter-rate classes, at 2.0 cycles per full-rate wave64 instruction throughout)"""
     if args.size != "100MP" or args.no_fusion or args.mode != "batch" or args.pipe != "full":
         return {}, None
-    path = os.path.join(ROOT, "profiles", "r05_sclk_per_kernel_100MP_full.json")
-    try:
-        kernels = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
+    kernels = None
+    for name in ("r05_dma_sclk_per_kernel_100MP_full.json", "r05_sclk_per_kernel_100MP_full.json"):  # newest first
+        try:
+            kernels = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+    if kernels is None:
         return {}, None
     # (launches of a few microseconds -- the wavelets' four-channel launches that leave at once -- have no meaningful ratio)
     return ({k: v["sclk_mhz"] for k, v in kernels.items() if "sclk_mhz" in v and v.get("ms_avg", 0.0) >= 0.05},
-            "committed profiles/r05_sclk_per_kernel_100MP_full.json")
+            "committed profiles/" + name)
 
 
 def sclk_of(table, tag):
@@ -366,7 +370,7 @@ KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu"
 
 def valu_floor_ms(tag, mpix, table=None):
     if table is None:
-        table = "r05_isa_mix.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_isa_mix.json")) else "r04_isa_mix.json"
+        table = next((t for t in ("r05_dma_isa_mix.json", "r05_isa_mix.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r04_isa_mix.json")
     return _valu_floor_ms(tag, mpix, table)
 
 
