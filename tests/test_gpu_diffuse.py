@@ -185,3 +185,19 @@ def test_diffuse_tiling_follows_the_reference():
     l.dt_hip_iop_diffuse_tiling(C.byref(abi.Piece.make(100, 100)), C.byref(d), C.byref(t))
     scales = ck.oracle().oracle_diffuse_scales(C.byref(abi.Piece.make(100, 100)), C.byref(d))
     assert t.overlap == 1 << scales and abs(t.factor - (6.0625 + scales)) < 1e-6
+
+
+def test_diffuse_is_the_same_bits_every_run():
+    """the PDE's support rows arrive by LDS-DMA behind hand-written waits (diffuse.hip, diffuse_pde_strip<.., true>): a missing
+    wait would not fail every time.  Eight runs of the bench's preset on a frame of several workgroups and strips per dilation
+    class, a NaN-filled output buffer in front of each: one result, and it is the oracle's"""
+    w, h = 1211, 777
+    img = synth.rgba_image(w, h, seed=11, lo=0.0, hi=1.3)
+    piece = abi.Piece.make(w, h)
+    d = params.diffuse("lens_deblur_soft", iterations=2)
+    want = _cpu("oracle", piece, d, img)
+    assert want is not None
+    fill = np.full(img.shape, np.float32(np.nan), np.float32)
+    for _ in range(8):
+        got = hc.run_hip("dt_hip_iop_diffuse_process", piece, d, img, img.shape, pre_fill=fill)
+        assert int((ck.ulp_diff(got, want) > 0).sum()) == 0
