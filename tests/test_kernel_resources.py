@@ -62,6 +62,31 @@ def test_the_pde_has_its_dma_instantiations(kernels):
         assert "void diffuse_pde_strip<true, %s, false>" % m in names and "void diffuse_pde_strip<false, %s, false>" % m in names
 
 
+def test_the_pde_dma_kernel_fetches_its_rows_without_destination_registers():
+    """diffuse_pde_strip<true, MODE, true> takes its support rows by LDS-DMA (global_load_lds_dwordx4, inline assembly with M0 saved
+    and restored in the statement): six per row step (three planes, main + halo piece) in each of the three unrolled row steps and
+    in the prologue's three rows, and NO register-destination global load in the kernel but the luminance mask's byte"""
+    import subprocess
+    import tempfile
+    obj = os.path.join(OBJ, "diffuse.o")
+    if not os.path.exists(obj):
+        pytest.skip("no diffuse.o")
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat"), os.path.join(td, "co")
+        subprocess.run([kr.LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
+        subprocess.run([kr.LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+        text = subprocess.run([kr.LLVM + "/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+    # the bench's preset: orders 1 and 3 along the isophotes (PDE_MODE_DEBLUR = 253)
+    m = re.search(r"<_ZN\S*diffuse_pde_stripILb1ELi253ELb1E\S*>:\n(.*?)\n\n", text, re.S)
+    assert m, "diffuse_pde_strip<true, 253, true> not found in diffuse.o"
+    body = m.group(1)
+    assert body.count("global_load_lds_dwordx4") == 36, body.count("global_load_lds_dwordx4")
+    assert len(re.findall(r"s_mov_b32 m0, s\d+", body)) >= 36 + 12  # a destination per piece + M0 restored per statement
+    assert "global_load_dwordx4" not in body and "global_load_dwordx2" not in body
+    assert body.count("global_store_dwordx4") >= 2
+
+
 def test_kernarg_offsets_match_what_the_kernels_read(kernels):
     """kernarg_at<T>(offset) reads a by-value argument in place; the offset each kernel computes (and static_asserts) must be
     where the code object says the argument is"""
