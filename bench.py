@@ -368,6 +368,21 @@ KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu"
                 "lab_to_rgb": "hbm"}
 
 
+def fp32_valu_figure(tag, dom, pixels):
+    """the dominant launch against the binary32 vector peak, for the kernel SURVEY 8(d) says is not an HBM kernel: non-local means'
+    algorithmic flops -- (2 K + 1)^2 offsets x ~25 flop per pixel and offset at K = 7, the module's default on a full-resolution
+    export: 5.6 kflop per pixel -- over its average duration, against the 157.3 TFLOP/s of MI355X_MICROARCH.md (256 CUs x 4 SIMDs
+    x 32 lanes x 2 flop per FMA x 2.4 GHz).  The kernel's instructions are additions, multiplications and integer operations, not
+    FMAs (0.3 %): one flop per lane and issue slot, so 0.5 is the most this figure can reach; roofline.valu_frac is the same launch
+    in issue slots."""
+    if tag != "nlm_chunks" or not dom.get("ms_avg"):
+        return None
+    flops = 225 * 25.0 * pixels
+    ach = flops / (dom["ms_avg"] * 1e-3) / 1e12
+    return {"achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
+            "flops_per_px": 5625, "ceiling_for_a_stream_without_fma": 0.5}
+
+
 def valu_floor_ms(tag, mpix, table=None):
     if table is None:
         table = next((t for t in ("r05_dma_isa_mix.json", "r05_isa_mix.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r04_isa_mix.json")
@@ -1064,6 +1079,8 @@ def main():
                 "valu_frac_at_sustained_clock": per_kernel.get(dominant, {}).get("valu_frac_at_sustained_clock"),
                 "sclk_mhz": per_kernel.get(dominant, {}).get("sclk_mhz"),
                 "sclk_source": sclk_src,
+                # "for NLM report achieved fraction of fp32 VALU peak and of HBM, and say which binds"
+                "fp32_valu": fp32_valu_figure(dominant, dom, my_rows * width),
                 # the whole step, both ways: sum of ALGORITHMIC bytes / step time / peak (= config.pipe_hbm_frac: the metric's figure;
                 # it credits the pipe with bytes that fusion never moves) and the bytes the PMC counters saw the step MOVE / step time / peak
                 "pipe_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
