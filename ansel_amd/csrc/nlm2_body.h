@@ -93,7 +93,11 @@ template <class Env> NLM2_FN float mexp2_scaled(const float distortion, const fl
 // Env: tid(), bid(), lds(), sync(), prio_high(), cvt_i32_sat(), int_as_float(); TIMED + clock() for the measuring build.
 // Args: nlm_args of nlmeans.hip (W, H, chk_w, chk_h, nchx, npatch, sharpness, norm[3], luma, chroma, skip_blend,
 // reach, cy0, out_row0, out_row1, variant).  F4 / I2: float4 / int2.
-template <int P, int WP, int TP, bool DEEP, class Env, class Args, class F4, class I2>
+// CENTER (round 5): the weight of denoise (profiled)'s non-local-means mode (center_weight >= 0, nlmeans_core.c:416-424): the
+// squared difference of the two CENTRE pixels, scaled by center_weight x the patch's area (a.cpn: compute_center_pixel_norm(),
+// :147-153), joins the patch's distortion, the sum is divided by 1 + center_weight, and the weight is 2^-max(0, that x sharpness
+// - 2).  Only the C role changes; the module's default patch radius there is 1, which the third version's bodies do not take.
+template <int P, int WP, int TP, bool DEEP, bool CENTER = false, class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches)
 {
   constexpr int S = 2 * P + 1;
@@ -335,7 +339,18 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
 #pragma unroll
     for(int k = 0; k < NL2_PX; k++)
     {
-      const float w = mexp2<Env>(dist[k] * a.sharpness);
+      float w;
+      if constexpr(CENTER)
+      {
+        // pixel_difference(own, shifted, center_norm), :156-165: (diff * diff) * norm per channel, summed (x + y) + z
+        const int own = pix[k] & 0xffff;
+        const f2 o = XY[own];
+        const float dx = o.x - qx[k], dy = o.y - qy[k], dz = Z[own] - qz[k];
+        const float dis = (dist[k] + (dx * dx * a.cpn + dy * dy * a.cpn + dz * dz * a.cpn)) / (1.0f + a.center_weight);
+        w = mexp2<Env>(Env::max_num(0.0f, dis * a.sharpness - 2.0f));
+      }
+      else
+        w = mexp2<Env>(dist[k] * a.sharpness);
       accx[k] = accx[k] + qx[k] * w;
       accy[k] = accy[k] + qy[k] * w;
       accz[k] = accz[k] + qz[k] * w;

@@ -819,7 +819,7 @@ struct nlm2_device_env
   }
 };
 
-template <int P, int WP, int TP, bool DEEP>
+template <int P, int WP, int TP, bool DEEP, bool CENTER>
 __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                              const nlm_args a, const int2 *__restrict__ patches,
                                                              const int *__restrict__ order, const int n_border)
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2(const float4 *__res
   nlm2_device_env env;
   env.lds_ = lds;
   env.chunk_ = chunk;
-  nlm2::body<P, WP, TP, DEEP>(env, in, out, a, patches);
+  nlm2::body<P, WP, TP, DEEP, CENTER>(env, in, out, a, patches);
 }
 
 // the measuring build (ANSEL_NLM2_TIMED, tools/nlm_phase_clocks.py): the same body with a clock read around every step
@@ -945,10 +945,15 @@ __global__ __launch_bounds__(NLT_THREADS, 8) void nlm_tail(const float4 *__restr
 }
 
 typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
-template <int P> nlm2_kernel_t nlm2_kernel_of(const bool tight, const bool deep)
+template <int P, bool CENTER> nlm2_kernel_t nlm2_kernel_of_(const bool tight, const bool deep)
 {
-  if(tight) return deep ? nlm_chunks_v2<P, NL2_WP_TIGHT, NL2_TP_TIGHT, true> : nlm_chunks_v2<P, NL2_WP_TIGHT, NL2_TP_TIGHT, false>;
-  return deep ? nlm_chunks_v2<P, NL2_WP_LOOSE, NL2_TP_LOOSE, true> : nlm_chunks_v2<P, NL2_WP_LOOSE, NL2_TP_LOOSE, false>;
+  if(tight) return deep ? nlm_chunks_v2<P, NL2_WP_TIGHT, NL2_TP_TIGHT, true, CENTER> : nlm_chunks_v2<P, NL2_WP_TIGHT, NL2_TP_TIGHT, false, CENTER>;
+  return deep ? nlm_chunks_v2<P, NL2_WP_LOOSE, NL2_TP_LOOSE, true, CENTER> : nlm_chunks_v2<P, NL2_WP_LOOSE, NL2_TP_LOOSE, false, CENTER>;
+}
+// center: the weight of denoise (profiled)'s non-local-means mode (nlm2_body.h, CENTER)
+template <int P> nlm2_kernel_t nlm2_kernel_of(const bool tight, const bool deep, const bool center)
+{
+  return center ? nlm2_kernel_of_<P, true>(tight, deep) : nlm2_kernel_of_<P, false>(tight, deep);
 }
 
 int sgn(const int v) { return (v > 0) - (v < 0); }
@@ -1082,8 +1087,8 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   if(lds_bytes > 64 * 1024)
     ANSEL_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   // interior chunks (all but the outermost ring: 97.5 % of a 100 MP frame) take nlm_chunks_v2's body when the
-  // configuration is one it is built for: the weight without the centre-pixel term (denoise (non-local means)),
-  // patch radius 1..3
+  // configuration is one it is built for: patch radius 1..3, either weight (denoise (non-local means)'s, and -- round 5 --
+  // the one with the centre-pixel term of denoise (profiled)'s non-local-means mode, whose default patch radius is 1)
   const int S2 = 2 * a.radius + 1, ncol2 = a.chk_w + 2 * a.radius;
   // layout: the tight pitches when the chunk fits them; schedule: four tables (one barrier per offset) when they fit
   // LDS beside the window, else two (nlm2_body.h)
@@ -1093,7 +1098,8 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
                     && measuring_env("ANSEL_NLM2_DEEP") == nullptr;
   // the border workgroups of the same launch run the pipelined body: the launch's LDS is the larger of the two
   const size_t v2_bytes = std::max(nlm2::lds_floats(deep ? 4 : 2, a.chk_h, a.reach, a.npatch, WP2, TP2) * sizeof(float), pipe_bytes);
-  bool v2 = pipelined && p.center_weight < 0 && a.radius >= 1 && a.radius <= 3 && ncol2 * S2 <= NL2_PAR
+  const bool center = !(p.center_weight < 0); // denoise (profiled)'s weight: the second version's body takes it, the later ones do not
+  bool v2 = pipelined && a.radius >= 1 && a.radius <= 3 && ncol2 * S2 <= NL2_PAR
             && a.chk_w * a.chk_h <= NL2_PAR * NL2_PX && a.chk_w + 2 * a.reach <= WP2 && ncol2 + 1 <= TP2 && a.npatch <= 4096
             && a.chk_h <= NL2_SERIAL / 2 && v2_bytes <= 160 * 1024 && measuring_env("ANSEL_HIP_NLM_V1") == nullptr;
   if(v2)
@@ -1104,20 +1110,20 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   // the third version where it applies (nlm3_body.h): the module's defaults on frames whose chunks have at most 56 rows
   int ndx3 = 0;
   const bool force_v2 = dispatch_override(DISPATCH_NLM_V2) || measuring_env("ANSEL_HIP_NLM_V2") != nullptr;
-  const bool v3 = v2 && nlm3::fits<9, 6>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
+  const bool v3 = v2 && !center && nlm3::fits<9, 6>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                   && !force_v2;
   const size_t v3_bytes = std::max(nlm3::lds_floats<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
   // its fused variant for the grids the third version does not take (57 - 64 rows); ANSEL_HIP_NLM_FUSED=1: wherever it fits
   const size_t v4_bytes = std::max(nlm3::lds_floats_fused<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
   const char *const fused_env = measuring_env("ANSEL_HIP_NLM_FUSED");
   const bool force_fused = dispatch_override(DISPATCH_NLM_FUSED) || (fused_env && atoi(fused_env) != 0);
-  const bool v4 = v2 && nlm3::fits_fused<9, 7>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
+  const bool v4 = v2 && !center && nlm3::fits_fused<9, 7>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                   && v4_bytes <= 160 * 1024 && !force_v2 && (force_fused || !(v3 && v3_bytes <= 160 * 1024));
   // chunk grids of 65 - 69 rows (24 / 42 / 150 MP): the fused body on the first 64 rows of every interior chunk + nlm_tail
   static_assert(NLT_HEAD_ROWS == nlm3::TALL_HEAD && NLT_SEED_PITCH == nlm3::TALL_SEED_PITCH, "head and tail share the export's layout");
   const size_t tall_bytes = std::max(nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach) * sizeof(float), pipe_bytes);
   const size_t tail_bytes = nlmt::lds_floats(a.chk_h - NLT_HEAD_ROWS, a.reach, a.npatch) * sizeof(float);
-  const bool tall = v2 && !v3 && !v4 && !force_v2 && nlmt::fits(a.chk_w, a.chk_h, a.radius, a.reach, a.npatch)
+  const bool tall = v2 && !center && !v3 && !v4 && !force_v2 && nlmt::fits(a.chk_w, a.chk_h, a.radius, a.reach, a.npatch)
                     && nlm3::fits_fused<9, 7>(a.chk_w, NLT_HEAD_ROWS, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                     && tall_bytes <= 160 * 1024 && tail_bytes <= 64 * 1024;
   static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS && NL3_THREADS == NLM_THREADS,
@@ -1129,7 +1135,8 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   int n_border = 0;
   if(v2)
   {
-    k2 = a.radius == 1 ? nlm2_kernel_of<1>(tight, deep) : (a.radius == 2 ? nlm2_kernel_of<2>(tight, deep) : nlm2_kernel_of<3>(tight, deep));
+    k2 = a.radius == 1 ? nlm2_kernel_of<1>(tight, deep, center)
+                       : (a.radius == 2 ? nlm2_kernel_of<2>(tight, deep, center) : nlm2_kernel_of<3>(tight, deep, center));
 #ifdef ANSEL_HIP_MEASURING
     if(a.radius == 2 && tight && deep && measuring_env("ANSEL_NLM2_TIMED")) k2 = nlm_chunks_v2_timed;
 #endif

@@ -42,6 +42,7 @@ struct Args
   int reach;
   int cy0, out_row0, out_row1;
   int variant;
+  float center_weight, cpn; // CENTER bodies (denoise (profiled)'s weight): nlm_args of nlmeans.hip
 };
 
 // what the lanes of a wave exchange (DPP on the device): a slot per thread, two sets used in turn, one wave barrier per exchange
@@ -111,7 +112,7 @@ int scatter(const float scale, const float scattering, const int i1, const int i
   return (int)(scale * ((a1 * a1 * a1 + 7.0 * a1 * sqrt((double)a2)) * sgn(i1) * scattering / 6.0 + i1));
 }
 
-template <int P, int WP, int TP, bool DEEP>
+template <int P, int WP, int TP, bool DEEP, bool CENTER = false>
 void run(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats)
 {
   std::vector<float> lds(lds_floats + 4096, 0.0f);
@@ -123,7 +124,7 @@ void run(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchu
       for(int b = 0; b < nchunks; b++)
       {
         HostEnv env{ t, b, lds.data(), &bar };
-        nlm2::body<P, WP, TP, DEEP>(env, in, out, a, patches);
+        nlm2::body<P, WP, TP, DEEP, CENTER>(env, in, out, a, patches);
         bar.arrive_and_wait(); // the next chunk reuses the LDS block
       }
     });
@@ -135,9 +136,27 @@ void run(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchu
 // Runs the kernel body over every chunk of the frame (only interior chunks write; the rest of `out` is left as it
 // is).  Returns 0, or a negative number when the configuration is outside what nlm_chunks_v2 takes (the same tests as
 // nlmeans_core_launch()).  chk_w / chk_h: the frame's chunk grid (oracle_nlmeans_slice_width / _height).
+static int nlm2_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                          int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                          float luma, float chroma, int *interior_chunks, const float center_weight);
 extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                              int search_radius, float scale, float scattering, float sharpness, const float *norm,
                              float luma, float chroma, int *interior_chunks)
+{
+  return nlm2_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma, chroma,
+                        interior_chunks, -1.0f);
+}
+// ... with the weight of denoise (profiled)'s non-local-means mode (center_weight >= 0: nlm2_body.h, CENTER)
+extern "C" int nlm2_host_run_center(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                                    int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                                    float luma, float chroma, int *interior_chunks, float center_weight)
+{
+  return nlm2_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma, chroma,
+                        interior_chunks, center_weight);
+}
+static int nlm2_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                          int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                          float luma, float chroma, int *interior_chunks, const float center_weight)
 {
   const char *const var_env = getenv("ANSEL_NLM2_VARIANT");
   std::vector<I2> patches;
@@ -169,6 +188,9 @@ extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_
   a.out_row0 = 0;
   a.out_row1 = H;
   a.variant = var_env ? atoi(var_env) : 0;
+  a.center_weight = center_weight;
+  a.cpn = center_weight * (2 * patch_radius + 1) * (2 * patch_radius + 1); // compute_center_pixel_norm(), nlmeans_core.c:147-153
+  const bool center = !(center_weight < 0);
   const int S = 2 * patch_radius + 1, ncol = chk_w + 2 * patch_radius;
   if(patch_radius < 1 || patch_radius > 3) return -1;
   // the same choices as nlmeans_core_launch(): the tight layout when the chunk fits it, four tables when they fit LDS
@@ -197,18 +219,25 @@ extern "C" int nlm2_host_run(const float *in, float *out, int W, int H, int chk_
   const int nchunks = a.nchx * nchy;
   const F4 *const fin = (const F4 *)in;
   F4 *const fout = (F4 *)out;
-#define RUN(P_)                                                                                                      \
-  do                                                                                                                 \
-  {                                                                                                                  \
-    if(tight && deep) run<P_, NL2_WP_TIGHT, NL2_TP_TIGHT, true>(fin, fout, a, patches.data(), nchunks, lds_floats);   \
-    else if(tight) run<P_, NL2_WP_TIGHT, NL2_TP_TIGHT, false>(fin, fout, a, patches.data(), nchunks, lds_floats);     \
-    else if(deep) run<P_, NL2_WP_LOOSE, NL2_TP_LOOSE, true>(fin, fout, a, patches.data(), nchunks, lds_floats);       \
-    else run<P_, NL2_WP_LOOSE, NL2_TP_LOOSE, false>(fin, fout, a, patches.data(), nchunks, lds_floats);               \
+#define RUN_(P_, C_)                                                                                                      \
+  do                                                                                                                      \
+  {                                                                                                                       \
+    if(tight && deep) run<P_, NL2_WP_TIGHT, NL2_TP_TIGHT, true, C_>(fin, fout, a, patches.data(), nchunks, lds_floats);    \
+    else if(tight) run<P_, NL2_WP_TIGHT, NL2_TP_TIGHT, false, C_>(fin, fout, a, patches.data(), nchunks, lds_floats);      \
+    else if(deep) run<P_, NL2_WP_LOOSE, NL2_TP_LOOSE, true, C_>(fin, fout, a, patches.data(), nchunks, lds_floats);        \
+    else run<P_, NL2_WP_LOOSE, NL2_TP_LOOSE, false, C_>(fin, fout, a, patches.data(), nchunks, lds_floats);                \
+  } while(0)
+#define RUN(P_)                  \
+  do                             \
+  {                              \
+    if(center) RUN_(P_, true);   \
+    else RUN_(P_, false);        \
   } while(0)
   if(patch_radius == 1) RUN(1);
   else if(patch_radius == 2) RUN(2);
   else RUN(3);
 #undef RUN
+#undef RUN_
   return (tight ? 1 : 0) | (deep ? 2 : 0); /* which path ran */
 }
 

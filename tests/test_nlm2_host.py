@@ -78,6 +78,42 @@ def test_interior_chunk_kernel_on_the_host_equals_the_oracle(host_kernel, oracle
     assert np.array_equal(got[written].view(np.uint32), want[written].view(np.uint32))
 
 
+# denoise (profiled) in non-local-means mode: the weight with the centre pixel's term (center_weight >= 0, nlmeans_core.c:416-424);
+# the module's defaults there are patch radius 1, search radius 7, central pixel weight 0.1
+# (width, height, patch radius, search radius, scattering, center_weight, expected chunk, interior chunks)
+CASES_CENTER = [
+    (170, 150, 1, 7, 0.0, 0.1, (64, 51), 1),     # the module's defaults: 225 offsets
+    (300, 250, 1, 3, 0.0, 0.0, (64, 63), 6),     # central pixel weight 0: the division by 1, the floor at -2
+    (300, 250, 2, 2, 0.0, 1.0, (64, 63), 6),     # patch radius 2, the centre as heavy as the patch
+    (256, 207, 3, 2, 0.9, 0.4, (72, 69), 2),     # patch radius 3, scattered offsets, the largest chunk (two tables)
+]
+
+
+@pytest.mark.parametrize("w,h,P,K,scat,cw_,chunk,n_interior", CASES_CENTER)
+def test_interior_chunk_kernel_with_the_centre_pixel_term_equals_the_oracle(host_kernel, oracle_lib, w, h, P, K, scat, cw_, chunk, n_interior):
+    o = oracle_lib
+    rng = np.random.default_rng(77 + P + K)
+    # what the module hands the core: a variance-stabilised frame, values around 0 .. a few units (denoiseprofile.c:1599-1680)
+    img = np.ascontiguousarray((_lab(w, h, 21 + P + K) * np.float32(0.05) + rng.normal(0, 0.3, (h, w, 4))).astype(np.float32))
+    p = NlmParams(scat, 1.0, 1.0, 1.0, cw_, 1.3, P, K, (C.c_float * 4)(1.0, 1.0, 1.0, 1.0))
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    assert (cw, ch) == chunk
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm2_host_run_center(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(scat),
+                                          C.c_float(p.sharpness), p.norm, C.c_float(1.0), C.c_float(1.0), C.byref(seen), C.c_float(cw_))
+    assert rc >= 0 and seen.value == n_interior
+    written = ~np.isnan(got[..., 0])
+    assert int(written.sum()) == n_interior * cw * ch
+    assert np.array_equal(got[written].view(np.uint32), want[written].view(np.uint32))
+    # the weights are not all the floor's: the centre term is exercised
+    assert np.unique(want[written][..., 0]).size > 100
+
+
 def test_configurations_outside_the_kernel_are_refused(host_kernel):
     img = np.zeros((100, 100, 4), np.float32)
     norm = (C.c_float * 4)(1, 1, 1, 1)
