@@ -1015,7 +1015,7 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           const dim3 sgrid(gx, classes * spc);
           const float4 *const h0 = chain ? (s == 0 ? src : hf[s - 1]) : hf[s], *const h1 = chain ? hf[s] : nullptr;
 #define PDE_LAUNCH(HS, MD) diffuse_pde_strip<HS, MD><<<sgrid, 256, ring, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
-          // the rows by LDS-DMA into per-wave landing zones behind the ring (the kernel's comment): the two-plane path of the chain
+          // the rows by LDS-DMA into per-wave landing zones behind the ring (the kernel's comment): the low-pass chain (three planes a row) at the dilations whose halo is at most a quarter of a wave
           const bool dma = chain && a.mult <= PDE_DMA_MAX_MULT && !no_dma;
           const size_t ring_dma = ring + (size_t)4 * 3 * (64 + 2 * a.mult) * sizeof(float4);
 #define PDE_LAUNCH_DMA(MD) diffuse_pde_strip<true, MD, true><<<sgrid, 256, ring_dma, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
