@@ -1020,7 +1020,9 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
     if(!(attr_set.load() >> hd & 1ull))
     {
       ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)amaze_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)amz::LDS_BYTES));
+#ifdef ANSEL_HIP_MEASURING
       ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)amaze_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)amz::LDS_BYTES));
+#endif
       ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)amaze_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)amz::LDS_BYTES));
       attr_set.fetch_or(1ull << hd);
     }
@@ -1052,6 +1054,8 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
   if(stream_tiles > 0)
   {
     const int sblocks = a.ntiles < sb_max ? a.ntiles : sb_max;
+#ifdef ANSEL_HIP_MEASURING
+    // the phase-clock instantiation exists in the measuring library only (tools/amaze_stage_clocks.py)
     if(timed)
     {
       unsigned long long *stamps = (unsigned long long *)dt_hip_alloc_device_buffer(devid, sizeof(unsigned long long) * 32);
@@ -1067,6 +1071,7 @@ int amaze_demosaic_launch(int devid, const dt_hip_piece_t *piece, uint32_t filte
       dt_hip_release_mem_object(stamps);
     }
     else
+#endif
     {
       launch_scope ls(devid, "amaze_stream");
       amaze_stream<false><<<sblocks, amz::STREAM_THREADS, amz::LDS_BYTES, s>>>(in, (float *)out, sa, a.ntx, a.ntiles, ty_first, nullptr);

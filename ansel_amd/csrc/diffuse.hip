@@ -472,6 +472,10 @@ __global__ __launch_bounds__(256) void diffuse_pde(const float4 *__restrict__ hf
 // destination and is the compiler's: saved and restored inside the statement.  lgkmcnt(0) first: the zone's previous contents have been
 // READ (the ds_reads have returned) before anything is sent to overwrite them.  s_nop 4: an SGPR operand a VALU wrote (readfirstlane)
 // is five wait states from a vector-memory instruction reading it, and nothing pads an inline statement.
+// The statement is gfx950's: global_load_lds_dwordx4 exists there and not before, and the s_nop padding is that target's hazard table.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "pde_dma_planes(): LDS-DMA of 16 bytes per lane and its hazard padding are written for gfx950 only"
+#endif
 template <int NPL>
 __device__ __forceinline__ void pde_dma_planes(const float4 *const p0, const float4 *const p1, const float4 *const p2, const unsigned voff,
                                                const unsigned d0, const unsigned d1, const unsigned d2)
@@ -524,7 +528,9 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
   constexpr int NPL = HSUB ? 3 : 2;
   const int lane = tx & 63, zw = 64 + 2 * mult;
   float4 *const zone = r2s + PDE_RING * tw + (tx >> 6) * NPL * zw;
-  const unsigned zone_lds = DMA ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)zone) : 0u;
+  // the zone's LDS byte address (what M0 takes): the pointer in the LDS address space, not the low half of a generic one
+  using lds_f4_ptr = __attribute__((address_space(3))) float4 *;
+  const unsigned zone_lds = DMA ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(__UINTPTR_TYPE__)(lds_f4_ptr)zone) : 0u;
   const unsigned off_main = (unsigned)cols[0] * 16u, off_halo = (unsigned)clampi(col - mult + 64, 0, a.width - 1) * 16u;
   // send for support row v: every lane one sample per plane, the first 2 mult lanes the zone's last 2 mult slots as well
   auto dma_row = [&](const int v) {
@@ -1016,6 +1022,8 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           const float4 *const h0 = chain ? (s == 0 ? src : hf[s - 1]) : hf[s], *const h1 = chain ? hf[s] : nullptr;
 #define PDE_LAUNCH(HS, MD) diffuse_pde_strip<HS, MD><<<sgrid, 256, ring, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
           // the rows by LDS-DMA into per-wave landing zones behind the ring (the kernel's comment): the low-pass chain (three planes a row) at the dilations whose halo is at most a quarter of a wave
+          // (with a luminance mask the byte the row step loads makes the compiler wait for every vector-memory operation in flight,
+          // the row fetch included, in the middle of a step: masked runs keep the form -- same result -- but not its overlap)
           const bool dma = chain && a.mult <= PDE_DMA_MAX_MULT && !no_dma;
           const size_t ring_dma = ring + (size_t)4 * 3 * (64 + 2 * a.mult) * sizeof(float4);
 #define PDE_LAUNCH_DMA(MD) diffuse_pde_strip<true, MD, true><<<sgrid, 256, ring_dma, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)

@@ -1123,7 +1123,7 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   static_assert(NLT_HEAD_ROWS == nlm3::TALL_HEAD && NLT_SEED_PITCH == nlm3::TALL_SEED_PITCH, "head and tail share the export's layout");
   const size_t tall_bytes = std::max(nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach) * sizeof(float), pipe_bytes);
   const size_t tail_bytes = nlmt::lds_floats(a.chk_h - NLT_HEAD_ROWS, a.reach, a.npatch) * sizeof(float);
-  const bool tall = v2 && !center && !v3 && !v4 && !force_v2 && nlmt::fits(a.chk_w, a.chk_h, a.radius, a.reach, a.npatch)
+  bool tall = v2 && !center && !v3 && !v4 && !force_v2 && nlmt::fits(a.chk_w, a.chk_h, a.radius, a.reach, a.npatch)
                     && nlm3::fits_fused<9, 7>(a.chk_w, NLT_HEAD_ROWS, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                     && tall_bytes <= 160 * 1024 && tail_bytes <= 64 * 1024;
   static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS && NL3_THREADS == NLM_THREADS,
@@ -1173,37 +1173,39 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     return DT_HIP_DEFAULT_ERROR;
   }
   const int *const dev_order = (const int *)((const unsigned char *)dev_patches + patch_bytes);
+  // the head's export: one column-sum row per chunk and offset (NLT_SEED_PITCH floats: ~14.5 B per pixel of the frame, written
+  // once, read once -- the module's one per-call device allocation beyond in + out, dt_hip_iop_nlmeans_tiling()).  A frame
+  // it does not fit beside keeps the second version's body, which needs nothing of the kind
   float *seeds = nullptr;
   if(tall)
   {
     seeds = (float *)dt_hip_alloc_device_buffer(devid, (size_t)nchunks * a.npatch * NLT_SEED_PITCH * sizeof(float));
-    if(!seeds)
-    {
-      dt_hip_release_mem_object(dev_patches);
-      return DT_HIP_SYSMEM_ALLOCATION;
-    }
+    if(!seeds) tall = false;
+  }
+  // the opt-in to more than 64 KB of LDS, before anything is launched: a failure leaves nothing behind
+  hipError_t attr_err = hipSuccess;
+  if(tall)
+    attr_err = hipFuncSetAttribute((const void *)nlm_chunks_v4<9, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_bytes);
+  else if(v4)
+    attr_err = hipFuncSetAttribute((const void *)nlm_chunks_v4<9, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v4_bytes);
+  else if(v3 && v3_bytes <= 160 * 1024)
+    attr_err = hipFuncSetAttribute((const void *)nlm_chunks_v3<9, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v3_bytes);
+  if(attr_err != hipSuccess)
+  {
+    set_last_error("%s:%d hipFuncSetAttribute(nlm_chunks): %s", __FILE__, __LINE__, hipGetErrorString(attr_err));
+    if(seeds) dt_hip_release_mem_object(seeds);
+    dt_hip_release_mem_object(dev_patches);
+    return DT_HIP_DEFAULT_ERROR;
   }
   {
     launch_scope ls(devid, "nlm_chunks");
     const unsigned grid = (unsigned)nchunks;
     if(tall)
-    {
-      const auto kt = nlm_chunks_v4<9, 7, true>;
-      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_bytes));
-      kt<<<grid, NL3_THREADS, tall_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, seeds);
-    }
+      nlm_chunks_v4<9, 7, true><<<grid, NL3_THREADS, tall_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, seeds);
     else if(v4)
-    {
-      const auto k4 = nlm_chunks_v4<9, 7, false>;
-      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v4_bytes));
-      k4<<<grid, NL3_THREADS, v4_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, nullptr);
-    }
+      nlm_chunks_v4<9, 7, false><<<grid, NL3_THREADS, v4_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, nullptr);
     else if(v3 && v3_bytes <= 160 * 1024)
-    {
-      const auto k3 = nlm_chunks_v3<9, 6>;
-      ANSEL_HIP_CHECK(hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v3_bytes));
-      k3<<<grid, NL3_THREADS, v3_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3);
-    }
+      nlm_chunks_v3<9, 6><<<grid, NL3_THREADS, v3_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3);
     else if(v2)
       k2<<<grid, NL2_THREADS, v2_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border);
     else if(pipelined)

@@ -3,8 +3,8 @@ commit step that turns them into the per-piece data the kernel reads (commit_par
 filmicrgb.c:4005-4110, with the spline solver dt_iop_filmic_rgb_compute_spline(), :3686-4003).
 
 commit() below is the product's host-side implementation (binary32 arithmetic in the reference's
-order, via numpy scalars and the platform libm).  tests/test_filmic_commit.py checks it field by
-field against the reference's own solver (oracle/_ref)."""
+order, via numpy scalars and the platform libm).  tests/test_oracle_vs_ref.py
+(test_filmic_commit_matches_reference_solver) checks it field by field against the reference's own solver (oracle/_ref)."""
 import ctypes as C
 import math
 
