@@ -218,63 +218,80 @@ __global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat2(const float2 *__re
   }
 }
 
-// blur_line(), bilateral.c:299-338
-__global__ __launch_bounds__(64) void bilat_blur_line(float *__restrict__ buf, const int offset1, const int offset2,
-                                                      const int offset3, const int size1, const int size2, const int size3)
+// ---- dt_bilateral_blur(), src/pixel/bilateral.c:266-352, as out-of-place stencils -------------------------------------------------
+// The reference walks every grid line in place, carrying the two samples it has just overwritten in scalars: each result is a
+// function of the line's ORIGINAL samples i - 2 .. i + 2 only, and the walk's first two and last two steps are that stencil with
+// the taps beyond the line's ends left out.  So a pass is a 5-tap stencil that any lane can evaluate for any cell -- what has to be
+// kept is each result's operands and the order they meet in, (centre + w1 (next + previous)) + w2 (second next + second previous):
+//   along x and y:  6/16, 4/16, 1/16           (bilateral.c:299-338)
+//   along z:        the -2 derivative 4/16 (next - previous) + 2/16 (second next - second previous)   (:258-297)
+// `at(k)` is sample k of the line, n >= 4 its length (bilat_grid_of() refuses shorter lines: the reference writes past them).
+template <class At> __device__ __forceinline__ float bilat_smooth_tap(const int i, const int n, const At at)
 {
-  const int line = blockIdx.x * blockDim.x + threadIdx.x;
-  if(line >= size1 * size2) return;
-  const int j = line / size1, k = line - j * size1;
-  const float w0 = 6.f / 16.f, w1 = 4.f / 16.f, w2 = 1.f / 16.f;
-  size_t index = (size_t)k * offset1 + (size_t)j * offset2;
-  float tmp1 = buf[index];
-  buf[index] = buf[index] * w0 + w1 * buf[index + offset3] + w2 * buf[index + 2 * offset3];
-  index += offset3;
-  float tmp2 = buf[index];
-  buf[index] = buf[index] * w0 + w1 * (buf[index + offset3] + tmp1) + w2 * buf[index + 2 * offset3];
-  index += offset3;
-  for(int i = 2; i < size3 - 2; i++)
-  {
-    const float tmp3 = buf[index];
-    buf[index] = buf[index] * w0 + w1 * (buf[index + offset3] + tmp2) + w2 * (buf[index + 2 * offset3] + tmp1);
-    index += offset3;
-    tmp1 = tmp2;
-    tmp2 = tmp3;
-  }
-  const float tmp3 = buf[index];
-  buf[index] = buf[index] * w0 + w1 * (buf[index + offset3] + tmp2) + w2 * tmp1;
-  index += offset3;
-  buf[index] = buf[index] * w0 + w1 * tmp3 + w2 * tmp2;
+  constexpr float centre = 6.f / 16.f, near = 4.f / 16.f, far = 1.f / 16.f;
+  const float c = at(i) * centre;
+  if(i == 0) return (c + near * at(1)) + far * at(2);
+  if(i == 1) return (c + near * (at(2) + at(0))) + far * at(3);
+  if(i == n - 1) return (c + near * at(n - 2)) + far * at(n - 3);
+  if(i == n - 2) return (c + near * (at(n - 1) + at(n - 3))) + far * at(n - 4);
+  return (c + near * (at(i + 1) + at(i - 1))) + far * (at(i + 2) + at(i - 2));
+}
+template <class At> __device__ __forceinline__ float bilat_derivative_tap(const int i, const int n, const At at)
+{
+  constexpr float near = 4.f / 16.f, far = 2.f / 16.f;
+  if(i == 0) return near * at(1) + far * at(2);
+  if(i == 1) return near * (at(2) - at(0)) + far * at(3);
+  if(i == n - 1) return -near * at(n - 2) - far * at(n - 3);
+  if(i == n - 2) return near * (at(n - 1) - at(n - 3)) - far * at(n - 4);
+  return near * (at(i + 1) - at(i - 1)) + far * (at(i + 2) - at(i - 2));
 }
 
-// blur_line_z(), bilateral.c:258-297
-__global__ __launch_bounds__(64) void bilat_blur_line_z(float *__restrict__ buf, const int offset1, const int offset2,
-                                                        const int offset3, const int size1, const int size2,
-                                                        const int size3)
+// The three passes in ONE launch, src -> dst (two buffers: every cell reads its neighbours' unblurred values).  Layout [y][x][z], z
+// contiguous.  A workgroup owns `npw` whole z-lines of one grid row y -- a contiguous run of the row, so lanes walk memory in order:
+//   1. per cell, the y-pass over the x-pass: the x-smoothed value of the five rows y - 2 .. y + 2 at the cell's (x, z), each from
+//      its five x-taps (25 reads of a grid that lives in L2; the x-pass of a row is recomputed by the five rows that use it -- a
+//      grid is 10^-3 of the frame), smoothed along y, into LDS;
+//   2. barrier; the z-derivative along each z-line from LDS -> dst.
+// XPASS false: src holds the x-pass already (bilat_blur_x below; grids too large to recompute it five times).
+template <bool XPASS>
+__global__ __launch_bounds__(256) void bilat_blur_yz(const float *__restrict__ src, float *__restrict__ dst, const int size_x,
+                                                     const int size_y, const int size_z, const int npw)
 {
-  const int line = blockIdx.x * blockDim.x + threadIdx.x;
-  if(line >= size1 * size2) return;
-  const int j = line / size1, k = line - j * size1;
-  const float w1 = 4.f / 16.f, w2 = 2.f / 16.f;
-  size_t index = (size_t)k * offset1 + (size_t)j * offset2;
-  float tmp1 = buf[index];
-  buf[index] = w1 * buf[index + offset3] + w2 * buf[index + 2 * offset3];
-  index += offset3;
-  float tmp2 = buf[index];
-  buf[index] = w1 * (buf[index + offset3] - tmp1) + w2 * buf[index + 2 * offset3];
-  index += offset3;
-  for(int i = 2; i < size3 - 2; i++)
+  extern __shared__ float lines[]; // [nodes of this workgroup][size_z]
+  const int y = blockIdx.y, node0 = blockIdx.x * npw;
+  const int nn = min(npw, size_x - node0), ncell = nn * size_z;
+  const size_t pitch_x = (size_t)size_z, pitch_y = (size_t)size_x * size_z;
+  for(int c = threadIdx.x; c < ncell; c += 256)
   {
-    const float tmp3 = buf[index];
-    buf[index] = +w1 * (buf[index + offset3] - tmp2) + w2 * (buf[index + 2 * offset3] - tmp1);
-    index += offset3;
-    tmp1 = tmp2;
-    tmp2 = tmp3;
+    const int x = node0 + c / size_z, z = c - (c / size_z) * size_z;
+    const auto row_value = [&](const int yy) {
+      const float *const p = src + yy * pitch_y + z;
+      if(!XPASS) return p[x * pitch_x];
+      return bilat_smooth_tap(x, size_x, [&](const int k) { return p[k * pitch_x]; });
+    };
+    lines[c] = bilat_smooth_tap(y, size_y, row_value);
   }
-  const float tmp3 = buf[index];
-  buf[index] = w1 * (buf[index + offset3] - tmp2) - w2 * tmp1;
-  index += offset3;
-  buf[index] = -w1 * tmp3 - w2 * tmp2;
+  __syncthreads();
+  float *const out_row = dst + y * pitch_y + node0 * pitch_x;
+  for(int c = threadIdx.x; c < ncell; c += 256)
+  {
+    const int node = c / size_z, z = c - node * size_z;
+    const float *const line = lines + node * size_z;
+    out_row[c] = bilat_derivative_tap(z, size_z, [&](const int k) { return line[k]; });
+  }
+}
+// the x-pass alone, src -> dst, one lane per cell
+__global__ __launch_bounds__(256) void bilat_blur_x(const float *__restrict__ src, float *__restrict__ dst, const int size_x,
+                                                    const int size_z, const size_t cells)
+{
+  const size_t row_cells = (size_t)size_x * size_z;
+  for(size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x)
+  {
+    const size_t in_row = c % row_cells;
+    const int x = (int)(in_row / size_z);
+    const float *const p = src + (c - (size_t)x * size_z); // the line's sample 0 at this cell's (y, z)
+    dst[c] = bilat_smooth_tap(x, size_x, [&](const int k) { return p[(size_t)k * size_z]; });
+  }
 }
 
 // dt_bilateral_slice(), bilateral.c:356-393
@@ -403,24 +420,42 @@ int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_ro
   return DT_HIP_SUCCESS;
 }
 
-// dt_bilateral_blur() in place on the complete grid, then the slice of `rows` rows from frame row `row0`
+// dt_bilateral_blur() of the complete grid, then the slice of `rows` rows from frame row `row0`.  The blur is out of place: the
+// fused launch leaves it in a second grid the slice reads (buf keeps the splat); a grid of more than BLUR_FUSED_CELLS cells takes
+// its x-pass in a launch of its own (second grid), and the y- and z-passes bring it back into buf
+constexpr size_t BLUR_FUSED_CELLS = (size_t)1 << 22;
 int bilat_blur_and_slice(int devid, const grid_t &b, float *buf, const dt_hip_bilat_data_t *d, const float4 *in_rows,
                          float4 *out_rows, int row0, int rows)
 {
   hipStream_t s = stream_of(devid);
-  const int ox = b.size_z, oy = b.size_x * b.size_z, oz = 1;
+  const size_t cells = (size_t)b.size_x * b.size_y * b.size_z;
+  float *const second = (float *)dt_hip_alloc_device_buffer(devid, cells * sizeof(float));
+  if(!second) return DT_HIP_SYSMEM_ALLOCATION;
+  const float *blurred;
   {
     launch_scope ls(devid, "bilat_blur");
-    // dt_bilateral_blur(), bilateral.c:341-352
-    bilat_blur_line<<<(b.size_z * b.size_y + 63) / 64, 64, 0, s>>>(buf, oz, oy, ox, b.size_z, b.size_y, b.size_x);
-    bilat_blur_line<<<(b.size_z * b.size_x + 63) / 64, 64, 0, s>>>(buf, oz, ox, oy, b.size_z, b.size_x, b.size_y);
-    bilat_blur_line_z<<<(b.size_x * b.size_y + 63) / 64, 64, 0, s>>>(buf, ox, oy, oz, b.size_x, b.size_y, b.size_z);
+    // z-lines per workgroup: ~2048 cells (eight per lane), whole lines
+    const int npw = b.size_z >= 2048 ? 1 : 2048 / b.size_z;
+    const dim3 grid((b.size_x + npw - 1) / npw, b.size_y);
+    const size_t lds = (size_t)npw * b.size_z * sizeof(float);
+    if(cells <= BLUR_FUSED_CELLS && !dispatch_override(DISPATCH_BILAT_BLUR_SPLIT))
+    {
+      bilat_blur_yz<true><<<grid, 256, lds, s>>>(buf, second, b.size_x, b.size_y, b.size_z, npw);
+      blurred = second;
+    }
+    else
+    {
+      bilat_blur_x<<<stream_grid(cells, 256), 256, 0, s>>>(buf, second, b.size_x, b.size_z, cells);
+      bilat_blur_yz<false><<<grid, 256, lds, s>>>(second, buf, b.size_x, b.size_y, b.size_z, npw);
+      blurred = buf;
+    }
   }
   {
     const float norm = -d->detail * b.sigma_r * 0.04f;
     launch_scope ls(devid, "bilat_slice");
-    bilat_slice<<<stream_grid((size_t)b.width * rows, 256), 256, 0, s>>>(in_rows, out_rows, buf, b, norm, row0, rows);
+    bilat_slice<<<stream_grid((size_t)b.width * rows, 256), 256, 0, s>>>(in_rows, out_rows, blurred, b, norm, row0, rows);
   }
+  dt_hip_release_mem_object(second); // stream-ordered
   return check_launch("bilat");
 }
 } // namespace
@@ -507,8 +542,8 @@ int dt_hip_iop_bilat_process(int devid, const dt_hip_piece_t *piece, const dt_hi
 }
 
 // tiling_callback(), src/iop/bilat.c:252-297.  factor / maxbuf / overlap are the reference's, for the host's own
-// tiling; factor_cl / maxbuf_cl are what THIS implementation holds on the device: in + out + one grid (the blur is
-// in place), or in + out + the (2 + 6)-plane padded pyramid of local_laplacian_memory_use(), locallaplacian.c:566-591
+// tiling; factor_cl / maxbuf_cl are what THIS implementation holds on the device: in + out + two grids (the blur is
+// out of place: the splat and its blurred copy), or in + out + the (2 + 6)-plane padded pyramid of local_laplacian_memory_use(), locallaplacian.c:566-591
 void dt_hip_iop_bilat_tiling(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_tiling_t *tiling)
 {
   const int width = piece->roi_in.width, height = piece->roi_in.height;
@@ -524,7 +559,7 @@ void dt_hip_iop_bilat_tiling(const dt_hip_piece_t *piece, const dt_hip_bilat_dat
     const float grid = (float)((size_t)b.size_x * b.size_y * b.size_z * sizeof(float));
     tiling->factor = 2.0f + 2.0f * grid / basebuffer; // dt_bilateral_memory_use(), bilateral.c:80-94 (OpenCL build)
     tiling->maxbuf = fmaxf(1.0f, grid / basebuffer);
-    tiling->factor_cl = 2.0f + grid / basebuffer;
+    tiling->factor_cl = 2.0f + 2.0f * grid / basebuffer;
     tiling->maxbuf_cl = tiling->maxbuf;
     tiling->overlap = (unsigned)ceilf(4 * sigma_s);
   }

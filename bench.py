@@ -203,11 +203,14 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
     best = min(times)
     sample = "%d x %d RGGB frame (%s), same module chain, best of 2 passes after a warm-up, %.2f s per pass" % (w, h, size_name, best)
     value = w * h / 1e6 / best
-    # the device's own frame size, when one pass of it is affordable (<= ~8 s predicted)
+    on_sample = {"value": round(value, 3), "unit": "MPix/s", "sample": sample}
+    # the device's own frame size -- the frame the metric is quoted on -- when one pass of it is affordable: <= ~40 s predicted
+    # (round 6; it was 8 s, which left the full pipe's figure on the 24 MP sample: the 100 MP full chain is ~22 s a pass at the
+    # ~4.6 MPix/s of the boxes seen, warm-up + one timed pass ~45 s of the run)
     if device_size is not None and device_size != (w, h):
         dw, dh = device_size
         predicted = best * (dw * dh) / float(w * h)
-        if predicted <= 8.0:
+        if predicted <= 40.0:
             del raw, cfa, rgb, out16
             dn = build_pipe(dw, dh, lut.ctypes.data, lut, with_filmic, which)
             raw, cfa, rgb, out16 = buffers(dw, dh)
@@ -221,7 +224,7 @@ def cpu_baseline(size_name, with_filmic, which="light", device_size=None):
     # `cores`: what the container may use -- its cgroup quota where it has one (threads beyond it share those cores)
     cores = int(round(quota)) if quota and quota >= 1 else best_c
     return {"value": round(value, 3), "unit": "MPix/s", "cores": min(cores, best_c), "threads": best_c, "kind": kind, "sample": sample,
-            "host_threads": ncpu, "cpu_quota": quota,
+            "on_sample_frame": on_sample, "host_threads": ncpu, "cpu_quota": quota,
             "binding": "OMP_PROC_BIND=%s OMP_PLACES=%s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
             "thread_sweep_mpix_s_on_6MP": {str(c): round(sw * sh / 1e6 / t, 3) for c, t in sorted(sweep.items())}}
 
@@ -237,7 +240,7 @@ def cpu_baseline_in_child(size_name, with_filmic, which, device_size):
             "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline(%r, %r, %r, device_size=%r)))"
             % (ROOT, size_name, bool(with_filmic), which, tuple(device_size)))
     try:
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=420)
     except subprocess.TimeoutExpired:
         return None
     for ln in out.stdout.splitlines():
@@ -868,7 +871,9 @@ def main():
     host_overlap_ms = None
     host_rows_ms = None
     host_rows_writer_ms = None
-    if rank == 0 and world == 1 and args.mode == "batch" and not args.no_host_legs and args.pipe == "light":
+    # (round 6: also for the metric's own workload, --pipe full -- the sequential and the overlapped leg; the two writer-side legs
+    #  stay with the light pipe, where the bus and not the kernels is the bound)
+    if rank == 0 and world == 1 and args.mode == "batch" and not args.no_host_legs and args.pipe in ("light", "full"):
         nb_in, nb_out = raw_host.nbytes, npix * 8
         pin_in, pin_out = l.dt_hip_alloc_host_pinned(nb_in), l.dt_hip_alloc_host_pinned(nb_out)
         if pin_in and pin_out:
@@ -899,9 +904,9 @@ def main():
                 l.dt_hip_batch_free(batch)
             # ... and with the scanline packing of the format writer done by the chain ("export_rows": RGB u16
             # rows, 6 B/px instead of 8 over the bus)
-            rows_exec = pipe.DevicePipe(devid, nodes + [pipe.Node("export_rows", abi.ExportRowsData(16, 3), nodes[-1].piece)],
+            rows_exec = None if args.pipe != "light" else pipe.DevicePipe(devid, nodes + [pipe.Node("export_rows", abi.ExportRowsData(16, 3), nodes[-1].piece)],
                                         fusion=not args.no_fusion)
-            batch = l.dt_hip_batch_new(rows_exec.handle, 3, nb_in, npix * 6)
+            batch = l.dt_hip_batch_new(rows_exec.handle, 3, nb_in, npix * 6) if rows_exec is not None else None
             if batch:
                 nfr = 8
                 for k in range(nfr + 3):
@@ -941,7 +946,8 @@ def main():
                     if pb:
                         l.dt_hip_free_host_pinned(pb)
                 l.dt_hip_batch_free(batch)
-            rows_exec.close()
+            if rows_exec is not None:
+                rows_exec.close()
         l.dt_hip_free_host_pinned(pin_in)
         l.dt_hip_free_host_pinned(pin_out)
 
@@ -1055,6 +1061,9 @@ def main():
                 "host_to_host_overlapped_ms": None if host_overlap_ms is None else round(host_overlap_ms, 3),
                 "host_to_host_overlapped_rgb_rows_ms": None if host_rows_ms is None else round(host_rows_ms, 3),
                 "host_to_host_overlapped_rgb_rows_and_writer_ms": None if host_rows_writer_ms is None else round(host_rows_writer_ms, 3),
+                # which leg binds a stream of exports of this frame: the overlapped host-to-host time over the kernels' own (~1: the
+                # kernels; well above 1: the bus)
+                "host_to_host_overlapped_over_step": None if host_overlap_ms is None else round(host_overlap_ms / ms_per_step, 3),
                 "host": {"nproc": os.cpu_count(), "cpu_quota": cgroup_cpu_quota(), "affinity": len(os.sched_getaffinity(0))},
             },
             "roofline": {

@@ -49,6 +49,26 @@ def test_bilat(w, h, ss, sr, detail):
         assert float(np.abs(r[..., 0] - got[..., 0]).max()) < 1e-3
 
 
+@pytest.mark.parametrize("w,h,ss,sr", [(300, 200, 8.0, 5.0), (123, 457, 0.3, 2.0), (1500, 1000, 50.0, 25.0), (640, 480, 160.0, 25.0)])
+def test_bilat_blur_with_the_x_pass_in_its_own_launch(w, h, ss, sr):
+    """grids beyond 2^22 cells take the blur's x-pass in a launch of its own (bilat_blur_x + bilat_blur_yz<false>); the test hook
+    sends an ordinary grid that way: same words as the fused launch and as the oracle; the last case is a 4-node grid line"""
+    from ansel_amd import lib
+    img = _lab_image(w, h, 31)
+    d = abi.BilatData.bilateral(ss, sr, 0.6)
+    piece = abi.Piece.make(w, h)
+    fused = hc.run_hip("dt_hip_iop_bilat_process", piece, d, img, img.shape)
+    lib.test_dispatch("bilat_blur_split", 1)
+    try:
+        split = hc.run_hip("dt_hip_iop_bilat_process", piece, d, img, img.shape)
+    finally:
+        lib.test_dispatch("bilat_blur_split", 0)
+    want = np.zeros_like(img)
+    assert ck.call(ck.oracle(), "oracle_bilat", piece, d, img, want) == 0
+    assert np.array_equal(split.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(fused.view(np.uint32), want.view(np.uint32))
+
+
 def test_bilat_refuses_a_grid_the_reference_overruns():
     """blur_line() touches four nodes of every grid line unconditionally (bilateral.c:266-340): on a 3-node line the
     reference writes past its buffer, so there is nothing to be identical to"""
