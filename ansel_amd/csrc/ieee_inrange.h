@@ -51,6 +51,24 @@ __device__ __forceinline__ float rcp_core(const float b)
   return __builtin_fmaf(e3, r, q);
 }
 
+// n / d for a divisor that many numerators share (wave-uniform): y1 = rcp_refined(d) once -- v_rcp_f32 and the expansion's Newton
+// step --, then the expansion's five operations per numerator and v_div_fixup_f32 for the numerators they do not take (infinite: the
+// quotient is an infinity, not the NaN of inf - inf; NaN; zero, with the quotient's sign).  Correctly rounded for d normal in
+// [2^-126, 2^126) and |n| in [2^-103, 2^96 |d|) (div_core()'s domain); outside it a quotient may come out an ulp off -- the caller's
+// business (nlm3_body.h CENTER: the weight behind such a quotient is 0 or 1 either way).
+__device__ __forceinline__ float rcp_refined(const float d)
+{
+  const float y = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
+}
+__device__ __forceinline__ float div_uniform(const float n, const float d, const float y1)
+{
+  const float q = n * y1;
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q, n), y1, q);
+  const float q2 = __builtin_fmaf(__builtin_fmaf(-d, q1, n), y1, q1);
+  return __builtin_amdgcn_div_fixupf(q2, d, n);
+}
+
 // sqrtf(x) for x == +0 or 2^-96 <= x < +inf
 __device__ __forceinline__ float sqrt_core(const float x)
 {

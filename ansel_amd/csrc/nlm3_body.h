@@ -74,12 +74,18 @@ NLM2_FN void st2(float *const p, const f2 v) { __builtin_memcpy(p, &v, 8); }
 // rows a variant takes: NPXL pixels per C lane on 72 / NPXL... lanes per row, 448 C lanes
 template <int NPXL> constexpr int max_rows() { return NPXL == 9 ? 56 : 74; }
 
+// Patch radius P (round 6: 1 beside the module's default 2 -- denoise (profiled)'s non-local-means mode defaults to 1): the chains of
+// the A1 role are S = 2 P + 1 rows apart, cut into a1_segments<P>() segments so that S x segments chains of 32 column pairs fill
+// the ten half-waves of the role's five main waves (P = 2: 5 x 2 = 10; P = 1: 3 x 3 = 9, the tenth half-wave repeats the ninth).
+// Radius 3 would need 7 x 2 = 14 half-waves or chains of 9 rows in registers: it keeps the second version's body.
+template <int P> constexpr int a1_segments() { return P == 1 ? 3 : 2; }
+
 // LDS floats of one workgroup: four tables -- always of the variant's most rows, so that the column recurrence runs a
 // compile-time number of rows: those beyond the chunk hold garbage nobody reads --, two first-row side tables, the
 // window (x, y as 8-byte words + z)
-template <int NPXL> inline size_t lds_floats(const int chk_h, const int reach)
+template <int NPXL, int P = 2> inline size_t lds_floats(const int chk_h, const int reach)
 {
-  return (size_t)4 * max_rows<NPXL>() * NL3_TP + 2 * 5 * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
+  return (size_t)4 * max_rows<NPXL>() * NL3_TP + 2 * (2 * P + 1) * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
 }
 
 // ---- the fused variant (round 4; launched as nlm_chunks_v4): THREE tables and no B role.  Chunks of 57 - 64 rows (the 45 MP
@@ -90,31 +96,35 @@ template <int NPXL> inline size_t lds_floats(const int chk_h, const int reach)
 // recompute what they had: no lane mask).  72 dependent additions per wave and offset instead of per workgroup, but no
 // table that lives for a fourth stage, no 37 b128 accesses per row, and sixteen waves: A2 A2 A1 A1 | A1 A1 A1 A1 | C x 8.
 constexpr int FUSED_MAXCH = 64;
-template <int NPXL> inline size_t lds_floats_fused(const int chk_h, const int reach)
+template <int NPXL, int P = 2> inline size_t lds_floats_fused(const int chk_h, const int reach)
 {
-  return (size_t)3 * FUSED_MAXCH * NL3_TP + 2 * 5 * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
+  return (size_t)3 * FUSED_MAXCH * NL3_TP + 2 * (2 * P + 1) * NL3_FP + (size_t)(chk_h + 2 * reach) * 2 * NL3_WPH * 3;
 }
-template <int NPXL, int MSEG> inline bool fits_fused(const int chk_w, const int chk_h, const int radius, const int reach)
+// the A1 role's dealing (body(), A1): five waves of 2 x 32 column pairs, one chain per half-wave, + one wave of the pairs that are left
+template <int MSEG, int P> inline bool a1_fits(const int chk_w, const int chk_h)
 {
-  constexpr int S = 5, LPR = (72 + NPXL - 1) / NPXL;
-  if(radius != 2 || chk_w > 72 || (chk_w & 1) || chk_w + 2 * reach > 2 * NL3_WPH || chk_h > FUSED_MAXCH || chk_h < 2 * S) return false;
+  constexpr int S = 2 * P + 1, NSEG = a1_segments<P>(), NCH = S * NSEG;
+  static_assert(NCH <= 10, "one chain per half-wave of the five main A1 waves");
+  const int ncp = (chk_w + 2 * P + 1) / 2;
+  if(ncp < 32 || NCH * (ncp - 32) > 64) return false;
+  const int m0 = (chk_h - 2) / S + 1;
+  return (m0 + NSEG - 1) / NSEG <= MSEG;
+}
+template <int NPXL, int MSEG, int P = 2> inline bool fits_fused(const int chk_w, const int chk_h, const int radius, const int reach)
+{
+  constexpr int S = 2 * P + 1, LPR = (72 + NPXL - 1) / NPXL;
+  if(radius != P || chk_w > 72 || (chk_w & 1) || chk_w + 2 * reach > 2 * NL3_WPH || chk_h > FUSED_MAXCH || chk_h < 2 * S) return false;
   if(LPR != 8) return false; // two pixel rows per 16-lane DPP row
-  const int ncp = (chk_w + 4) / 2;
-  if(ncp < 32 || ncp > 38) return false;
-  const int nseg = NL3_A1_LANES / (ncp * S), m0 = (chk_h - 2) / S + 1;
-  return nseg == 2 && (m0 + nseg - 1) / nseg <= MSEG;
+  return a1_fits<MSEG, P>(chk_w, chk_h);
 }
 
 // can this body take the chunk grid?  (the launch and the host harness ask the same question)
-template <int NPXL, int MSEG> inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach)
+template <int NPXL, int MSEG, int P = 2> inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach)
 {
-  constexpr int S = 5, LPR = (72 + NPXL - 1) / NPXL;
-  if(radius != 2 || chk_w > 72 || (chk_w & 1) || chk_w + 2 * reach > 2 * NL3_WPH || chk_h > max_rows<NPXL>() || chk_h < 2 * S) return false;
+  constexpr int S = 2 * P + 1, LPR = (72 + NPXL - 1) / NPXL;
+  if(radius != P || chk_w > 72 || (chk_w & 1) || chk_w + 2 * reach > 2 * NL3_WPH || chk_h > max_rows<NPXL>() || chk_h < 2 * S) return false;
   if(LPR * chk_h > 448) return false;
-  const int ncp = (chk_w + 4) / 2;
-  if(ncp < 32 || ncp > 38) return false; // five waves of 2 x 32 column pairs + one of the rest (body(), A1)
-  const int nseg = NL3_A1_LANES / (ncp * S), m0 = (chk_h - 2) / S + 1;
-  return nseg == 2 && (m0 + nseg - 1) / nseg <= MSEG;
+  return a1_fits<MSEG, P>(chk_w, chk_h);
 }
 
 // a chunk of the border ring the BORDER body takes (the others keep the first version's body): rows for every chain
@@ -167,12 +177,19 @@ template <int T0, int T1, int ROWBYTES, class Env> struct column_chain
 // the last row to seeds_out[offset][slot]: nlm_tail_body.h continues the recurrence from there through the rows that are left.
 constexpr int TALL_HEAD = 64;
 constexpr int TALL_SEED_PITCH = 80; // floats per offset (NLT_SEED_PITCH)
-template <int NPXL, int MSEG, bool BORDER = false, bool FUSED = false, bool TALL = false, class Env, class Args, class F4, class I2>
+// P, CENTER (round 6): patch radius 1 or 2; the weight of denoise (profiled)'s non-local-means mode (center_weight >= 0,
+// nlmeans_core.c:416-424) in the C role -- the squared difference of the two CENTRE pixels x a.cpn joins the patch's distortion, the
+// sum is divided by 1 + center_weight (Env::div_uniform(): the correctly rounded quotient by a wave-uniform divisor), and the weight
+// is 2^-max(0, that x sharpness - 2).  A C lane keeps its NPXL own pixels in registers beside the ring of shifted ones.
+template <int NPXL, int MSEG, bool BORDER = false, bool FUSED = false, bool TALL = false, int P = 2, bool CENTER = false, class Env,
+          class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
                   const int ndx, float *__restrict__ seeds_out = nullptr)
 {
   static_assert(!TALL || FUSED, "the head of a tall chunk runs on the fused body");
-  constexpr int P = 2, S = 2 * P + 1, TP = NL3_TP, XO = NL3_XO, FP = NL3_FP, WPH = NL3_WPH;
+  static_assert(!TALL || (P == 2 && !CENTER), "nlm_tail_body.h continues patch radius 2 without the centre term");
+  constexpr int S = 2 * P + 1, TP = NL3_TP, XO = NL3_XO, FP = NL3_FP, WPH = NL3_WPH;
+  constexpr int NSEG = a1_segments<P>(), NCH = S * NSEG;
   constexpr int MAXCH = FUSED ? FUSED_MAXCH : max_rows<NPXL>();
   constexpr int NT = FUSED ? 3 : 4; // tables: offset p lives in table tslot(p) from its A1 to its C
   auto tslot = [](const int p) { return FUSED ? p % 3 : (p & 3); };
@@ -236,18 +253,23 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   // which wave plays what (waves w, w + 4, w + 8, w + 12 share a SIMD).  Four roles: layout 0 is round 3's -- A2 A2 B A1 | A1 A1 A1 A1 |
   // C C A1 C | C C C C --, layout 1 (measuring builds, ANSEL_NLM2_VARIANT bit 4096) deals the VALU instructions evenly over the SIMDs
   // instead of the VALU + LDS instructions: A2 A2 B A1 | A1 A1 A1 C | A1 A1 C C | C C C C
-  const bool lay1 = !FUSED && (var & 4096);
+  // CENTER (four roles): a C wave carries ~2.4 times the instructions of the plain weight -- A2 C C A1 | A2 C C A1 | B C C A1 | C A1 A1 A1
+  // puts two of them on three SIMDs and one beside three A1 waves on the fourth
+  const bool lay1 = !FUSED && !CENTER && (var & 4096);
   const int a1_index = FUSED ? ((w >= 2 && w <= 7) ? w - 2 : -1)
-                             : (lay1 ? ((w >= 3 && w <= 6) ? w - 3 : ((w == 8 || w == 9) ? w - 4 : -1))
-                                     : (w == 3 ? 0 : ((w >= 4 && w <= 7) ? w - 3 : (w == 10 ? 5 : -1))));
-  const int c_index = FUSED ? w - 8 : (lay1 ? (w == 7 ? 0 : w - 9) : (w == 8 ? 0 : (w == 9 ? 1 : w - 9)));
+                       : CENTER ? (w == 7 ? 0 : (w == 11 ? 1 : (w >= 12 ? w - 10 : -1)))
+                                : (lay1 ? ((w >= 3 && w <= 6) ? w - 3 : ((w == 8 || w == 9) ? w - 4 : -1))
+                                        : (w == 3 ? 0 : ((w >= 4 && w <= 7) ? w - 3 : (w == 10 ? 5 : -1))));
+  const int c_index = FUSED ? w - 8
+                      : CENTER ? (w <= 6 ? w - 3 : w - 4) // waves 3 - 6 and 8 - 10
+                               : (lay1 ? (w == 7 ? 0 : w - 9) : (w == 8 ? 0 : (w == 9 ? 1 : w - 9)));
   if(a1_index >= 0)
   {
     // ---- A1: the terms of the column recurrence (nlmeans_core.c:437-488) for table rows 1.., and the five squared
     //      differences the first table row sums (init_column_sums(), :208-262)
     const int ai = a1_index;
     const int ncp = (cw + 2 * P + 1) / 2; // (an odd last slot has a partner nobody reads)
-    const int nseg = 2;                   // fits(); a narrower border chunk keeps the layout and repeats items
+    constexpr int nseg = NSEG;            // fits(); a narrower border chunk keeps the layout and repeats items
     const int m0 = (ch - 2) / S + 1;
     const int mseg = (m0 + nseg - 1) / nseg;
     // Work items = (column pair g < ncp, chain q < 10).  Lanes 0-31 and 32-63 of a wave are served by the LDS in separate
@@ -260,7 +282,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     int g, q;
     if(ai < 5)
     {
-      q = 2 * ai + (lane >> 5);
+      q = imin(2 * ai + (lane >> 5), NCH - 1); // (patch radius 1: nine chains, the tenth half-wave repeats the ninth)
       g = lane & 31;
     }
     else
@@ -545,8 +567,13 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // nothing a stage computes with was fetched in that stage (the last offset of a row is the exception: it is
     // accumulated in its own stage, so that a new row starts with an empty ring).  Ring of NPXL + 1 pixels: pixel i of
     // step j of a row sits in slot (i + j) % (NPXL + 1); the slot the incoming pixel takes was last read two steps ago.
-    constexpr int NR = NPXL + 1;
-    static_assert(NR % 2 == 0, "the distortions alternate between two register sets with the ring's period");
+    // CENTER: the lane's own pixels take 3 NPXL more registers (128 is all a sixteen-wave workgroup has), so a stage ACCUMULATES the
+    // offset before FIRST and fetches behind it: one set of distortions, a ring of NPXL pixels (the incoming pixel takes the slot the
+    // accumulation has just left), the weights one pixel at a time; the fetches are still in flight across the barrier.
+    constexpr int NR = CENTER ? NPXL : NPXL + 1;
+    constexpr int DB = CENTER ? 1 : 2; // sets of distortions
+    constexpr int AB = CENTER ? 1 : 3; // pixels abreast in accumulate()
+    static_assert(CENTER || NR % 2 == 0, "the distortions alternate between two register sets with the ring's period");
     const int ci = c_index;
     // a wave holds 8 chunk rows x 8 lanes; its lanes 0-31 take the even rows, 32-63 the odd ones: the nine distortions a
     // lane reads sit 9 words apart within a row and 84 apart between rows, and four rows TWO apart put the 32 lanes of an
@@ -557,14 +584,31 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     const bool active = r < ch && cb < cw && !(var & 128);
     float accx[NPXL], accy[NPXL], accz[NPXL], accw[NPXL];
     float qx[NR], qy[NR], qz[NR];
-    float dist[2][NPXL];
+    float dist[DB][NPXL];
     unsigned reached[2] = { ~0u, ~0u }; // BORDER: bit i = the offset's shifted pixel of pixel i is in the frame
 #pragma unroll
-    for(int i = 0; i < NPXL; i++) accx[i] = accy[i] = accz[i] = accw[i] = dist[0][i] = dist[1][i] = 0.0f;
+    for(int i = 0; i < NPXL; i++) accx[i] = accy[i] = accz[i] = accw[i] = dist[0][i] = dist[DB - 1][i] = 0.0f;
 #pragma unroll
     for(int i = 0; i < NR; i++) qx[i] = qy[i] = qz[i] = 0.0f;
     const int doff = r * TP + 4 + cb;
     const float sharp_m23 = a.sharpness * -8388608.0f;
+    // CENTER: the lane's own pixels (they never change) and the divisor 1 + center_weight with its refined reciprocal
+    [[maybe_unused]] float ox[CENTER ? NPXL : 1], oy[CENTER ? NPXL : 1], oz[CENTER ? NPXL : 1];
+    [[maybe_unused]] const float cden = 1.0f + a.center_weight;
+    [[maybe_unused]] const float crcp = Env::rcp_refined(cden);
+    if constexpr(CENTER)
+    {
+#pragma unroll
+      for(int i = 0; i < NPXL; i++)
+      {
+        // (a lane without pixels -- beyond the chunk's rows or columns -- reads words of the window or the tables behind it)
+        const int wi = widx(reach + r, reach + cb + i);
+        const f2 v = ld2(XY + 2 * wi);
+        ox[i] = v.x;
+        oy[i] = v.y;
+        oz[i] = Z[wi];
+      }
+    }
     // FUSED: the column sums of slots cb .. cb + NPXL + S - 1 (slot x at x + XO), fetched by every lane of the wave -- rows
     // beyond the chunk are table rows nobody wrote, and nobody uses what comes of them
     [[maybe_unused]] float cs[NPXL + S];
@@ -574,7 +618,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
 #pragma unroll
       for(int i = 0; i < NPXL + S; i++) cs[i] = T[i];
     };
-    // FUSED: the sliding row sum (:405-415) of the offset whose column sums are in cs[], into dist[M & 1].  The chain of a
+    // FUSED: the sliding row sum (:405-415) of the offset whose column sums are in cs[], into dist[M & (DB - 1)].  The chain of a
     // row runs through its eight lanes: phase k completes lane k, whose last sum is the carry of lane k + 1 (a DPP shift
     // by one lane; lane 0 of a row starts from the sum of the first 2 P columns); every lane recomputes its nine sums in
     // every phase from the carry it sees -- from its own phase on that is the final one.
@@ -597,7 +641,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         for(int i = 0; i < NPXL; i++)
         {
           d = d + e[i];
-          dist[M & 1][i] = d;
+          dist[M & (DB - 1)][i] = d;
         }
         if(ph + 1 < LPR)
         {
@@ -613,7 +657,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       {
         const float *const T = tab + (p & 3) * tabsz + doff;
 #pragma unroll
-        for(int i = 0; i < NPXL; i++) dist[M & 1][i] = T[i];
+        for(int i = 0; i < NPXL; i++) dist[M & (DB - 1)][i] = T[i];
       }
       if(BORDER)
       {
@@ -623,7 +667,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
 #pragma unroll
           for(int i = 0; i < NPXL; i++) m |= ((unsigned)(left + cb + i + dx) < (unsigned)W ? 1u : 0u) << i;
         }
-        reached[M & 1] = m;
+        reached[M & (DB - 1)] = m;
       }
       const int wy = reach + r + dy;
       if(first)
@@ -656,48 +700,76 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
     // and fenced, so that three independent instructions follow each other; same operations on the same operands per pixel.
     auto accumulate = [&](auto m_tag) {
       constexpr int M = decltype(m_tag)::value;
-      static_assert(NPXL % 3 == 0, "accumulate() takes the pixels of a lane in threes");
+      static_assert(NPXL % AB == 0, "accumulate() takes the pixels of a lane AB at a time");
 #pragma unroll
-      for(int g = 0; g < NPXL; g += 3)
+      for(int g = 0; g < NPXL; g += AB)
       {
-        float v[3], wgt[3], t[3];
-        int k0[3];
+        float v[AB], wgt[AB], t[AB];
+        int k0[AB];
+        if constexpr(CENTER)
+        {
+          // pixel_difference(own, shifted, center_norm), :156-165: (diff * diff) * norm per channel, summed (x + y) + z; then
+          // (distortion + that) / (1 + center_weight), x sharpness - 2, floored at 0 (:421-423), and dt_fast_mexp2f()'s product.
+          // No NaN guard behind it: fmaxf() has turned a NaN into 0, and -inf converts to INT_MIN on either target
+          float cx2[AB], cy2[AB], cz2[AB];
 #pragma unroll
-        for(int j = 0; j < 3; j++) v[j] = dist[M & 1][g + j] * sharp_m23;
+          for(int j = 0; j < AB; j++)
+          {
+            const float dx_ = ox[g + j] - qx[(g + j + M) % NR], dy_ = oy[g + j] - qy[(g + j + M) % NR], dz_ = oz[g + j] - qz[(g + j + M) % NR];
+            cx2[j] = dx_ * dx_ * a.cpn;
+            cy2[j] = dy_ * dy_ * a.cpn;
+            cz2[j] = dz_ * dz_ * a.cpn;
+          }
+          env.sched_fence();
+#pragma unroll
+          for(int j = 0; j < AB; j++) v[j] = dist[M & (DB - 1)][g + j] + (cx2[j] + cy2[j] + cz2[j]);
+          env.sched_fence();
+#pragma unroll
+          for(int j = 0; j < AB; j++) v[j] = Env::div_uniform(v[j], cden, crcp);
+          env.sched_fence();
+#pragma unroll
+          for(int j = 0; j < AB; j++) v[j] = Env::max_num(0.0f, v[j] * a.sharpness - 2.0f) * -8388608.0f;
+          env.sched_fence();
+        }
+        else
+        {
+#pragma unroll
+          for(int j = 0; j < AB; j++) v[j] = dist[M & (DB - 1)][g + j] * sharp_m23;
+          env.sched_fence();
+#pragma unroll
+          for(int j = 0; j < AB; j++) v[j] = Env::max_num(v[j], -__builtin_inff());
+          env.sched_fence();
+        }
+#pragma unroll
+        for(int j = 0; j < AB; j++) k0[j] = Env::cvt_i32_sat(v[j]);
         env.sched_fence();
 #pragma unroll
-        for(int j = 0; j < 3; j++) v[j] = Env::max_num(v[j], -__builtin_inff());
+        for(int j = 0; j < AB; j++) k0[j] = (int)(0x3f800000u + (unsigned)k0[j]);
         env.sched_fence();
 #pragma unroll
-        for(int j = 0; j < 3; j++) k0[j] = Env::cvt_i32_sat(v[j]);
-        env.sched_fence();
-#pragma unroll
-        for(int j = 0; j < 3; j++) k0[j] = (int)(0x3f800000u + (unsigned)k0[j]);
-        env.sched_fence();
-#pragma unroll
-        for(int j = 0; j < 3; j++)
+        for(int j = 0; j < AB; j++)
         {
           wgt[j] = Env::int_as_float(k0[j] >= 0x800000 ? k0[j] : 0);
-          if(BORDER && !(reached[M & 1] >> (g + j) & 1u)) wgt[j] = 0.0f;
+          if(BORDER && !(reached[M & (DB - 1)] >> (g + j) & 1u)) wgt[j] = 0.0f;
         }
         env.sched_fence();
 #pragma unroll
-        for(int j = 0; j < 3; j++) t[j] = qx[(g + j + M) % NR] * wgt[j];
+        for(int j = 0; j < AB; j++) t[j] = qx[(g + j + M) % NR] * wgt[j];
         env.sched_fence();
 #pragma unroll
-        for(int j = 0; j < 3; j++) accx[g + j] = accx[g + j] + t[j];
+        for(int j = 0; j < AB; j++) accx[g + j] = accx[g + j] + t[j];
 #pragma unroll
-        for(int j = 0; j < 3; j++) t[j] = qy[(g + j + M) % NR] * wgt[j];
+        for(int j = 0; j < AB; j++) t[j] = qy[(g + j + M) % NR] * wgt[j];
         env.sched_fence();
 #pragma unroll
-        for(int j = 0; j < 3; j++) accy[g + j] = accy[g + j] + t[j];
+        for(int j = 0; j < AB; j++) accy[g + j] = accy[g + j] + t[j];
 #pragma unroll
-        for(int j = 0; j < 3; j++) t[j] = qz[(g + j + M) % NR] * wgt[j];
+        for(int j = 0; j < AB; j++) t[j] = qz[(g + j + M) % NR] * wgt[j];
         env.sched_fence();
 #pragma unroll
-        for(int j = 0; j < 3; j++) accz[g + j] = accz[g + j] + t[j];
+        for(int j = 0; j < AB; j++) accz[g + j] = accz[g + j] + t[j];
 #pragma unroll
-        for(int j = 0; j < 3; j++) accw[g + j] = accw[g + j] + 1.0f * wgt[j];
+        for(int j = 0; j < AB; j++) accw[g + j] = accw[g + j] + 1.0f * wgt[j];
         env.sched_fence();
       }
     };
@@ -711,28 +783,43 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       {
         auto run = [&](auto m_tag) {
           constexpr int M = decltype(m_tag)::value;
-          if(jb + M < ndx)
+          if constexpr(M < NR)
           {
-            if constexpr(FUSED)
+            if(jb + M < ndx)
             {
-              // the sums and the pixel of this offset are fetched, the offset before is accumulated while they travel,
-              // then the row recurrence of this offset
-              fetch_sums(dyi * ndx + jb + M);
-              if(active)
+              if constexpr(CENTER)
+              {
+                // the offset before first, then this offset's fetches behind it (one set of distortions, a ring of NPXL)
+                if(active && jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
+                if constexpr(FUSED) fetch_sums(dyi * ndx + jb + M);
+                if(active) fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
+                if constexpr(FUSED)
+                {
+                  if(!(var & 64)) row_chain(m_tag);
+                }
+                if(active && jb + M + 1 == ndx) accumulate(m_tag);
+              }
+              else if constexpr(FUSED)
+              {
+                // the sums and the pixel of this offset are fetched, the offset before is accumulated while they travel,
+                // then the row recurrence of this offset
+                fetch_sums(dyi * ndx + jb + M);
+                if(active)
+                {
+                  fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
+                  if(jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
+                }
+                if(!(var & 64)) row_chain(m_tag);
+                if(active && jb + M + 1 == ndx) accumulate(m_tag);
+              }
+              else if(active)
               {
                 fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
                 if(jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
+                if(jb + M + 1 == ndx) accumulate(m_tag);
               }
-              if(!(var & 64)) row_chain(m_tag);
-              if(active && jb + M + 1 == ndx) accumulate(m_tag);
+              env.sync();
             }
-            else if(active)
-            {
-              fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
-              if(jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
-              if(jb + M + 1 == ndx) accumulate(m_tag);
-            }
-            env.sync();
           }
         };
         run(std::integral_constant<int, 0>());

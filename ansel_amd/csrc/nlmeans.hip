@@ -23,6 +23,7 @@
 #include "hip_common.h"
 #include "nlmeans_core_params.h"
 #include "nlm2_body.h"
+#include "ieee_inrange.h"
 #include "nlm3_body.h"
 #include "nlm_tail_body.h"
 
@@ -817,6 +818,12 @@ struct nlm2_device_env
     asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v)); // the instruction's own semantics, not C's (undefined out of range)
     return r;
   }
+  // n / d, correctly rounded, for a wave-uniform divisor d in [1, 2^20] (nlm3_body.h CENTER: 1 + center_weight; the launch checks it):
+  // ieee_inrange.h div_uniform().  Numerators below 2^-103 or from 2^96 on may come out an ulp off (their residuals are subnormal /
+  // the expansion would have scaled): the weight behind them is 1 or 0 either way for a sharpness in [2^-60, 2^60], which is what
+  // the launch admits.  tests/test_gpu_devmath.py compares it with the host's division.
+  static __device__ __forceinline__ float rcp_refined(const float d) { return ansel_ieee::rcp_refined(d); }
+  static __device__ __forceinline__ float div_uniform(const float n, const float d, const float y1) { return ansel_ieee::div_uniform(n, d, y1); }
 };
 
 template <int P, int WP, int TP, bool DEEP, bool CENTER>
@@ -863,7 +870,8 @@ __global__ __launch_bounds__(NL2_THREADS) void nlm_chunks_v2_timed(const float4 
 
 // the third version of the interior-chunk kernel (nlm3_body.h): offsets in rows of consecutive column shifts, patch
 // radius 2, chunks of at most 56 rows; same launch shape, border chunks first with the pipelined body
-template <int NPXL, int MSEG>
+// P, CENTER (round 6): patch radius 1 beside 2; the weight with the centre pixel's term (denoise (profiled)'s non-local-means mode)
+template <int NPXL, int MSEG, int P = 2, bool CENTER = false>
 __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                              const nlm_args a_by_value, const int2 *__restrict__ patches,
                                                              const int *__restrict__ order, const int n_border, const int ndx)
@@ -886,10 +894,10 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__res
     const int cy = chunk / a.nchx + a.cy0, cx = chunk % a.nchx;
     const int cw = min(a.chk_w, a.W - cx * a.chk_w), ch = min(a.chk_h, a.H - cy * a.chk_h);
     if(a.variant & 2048 || !nlm3::border_fits(cw, ch)) pipelined_body(chunk, lds, in, out, a, patches);
-    else nlm3::body<NPXL, MSEG, true>(env, in, out, a, patches, ndx);
+    else nlm3::body<NPXL, MSEG, true, false, false, P, CENTER>(env, in, out, a, patches, ndx);
     return;
   }
-  nlm3::body<NPXL, MSEG>(env, in, out, a, patches, ndx);
+  nlm3::body<NPXL, MSEG, false, false, false, P, CENTER>(env, in, out, a, patches, ndx);
 }
 
 // the fused variant of the third version (nlm3_body.h, FUSED): three tables, the row recurrence inside the C role --
@@ -897,7 +905,7 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v3(const float4 *__res
 // TALL (round 5): a chunk grid of 65 - 69 rows (the 24 / 42 / 150 MP frames).  The body runs a chunk's first 64 rows and exports
 // the column sums behind them, per offset, to seeds[position in the launch][offset][slot] (nlm3_body.h TALL); nlm_tail below
 // continues them through the rows that are left -- interior chunks and the outermost ring alike (BORDER bodies).
-template <int NPXL, int MSEG, bool TALL>
+template <int NPXL, int MSEG, bool TALL, int P = 2, bool CENTER = false>
 __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                              const nlm_args a_by_value, const int2 *__restrict__ patches,
                                                              const int *__restrict__ order, const int n_border, const int ndx,
@@ -918,12 +926,12 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__res
     const int cw = min(a.chk_w, a.W - cx * a.chk_w), ch = min(a.chk_h, a.H - cy * a.chk_h);
     // (a tall chunk: the head's rows decide; a chunk the BORDER body refuses is lower than ten rows and has no tail)
     if(!nlm3::border_fits(cw, TALL ? min(ch, nlm3::TALL_HEAD) : ch)) pipelined_body(chunk, lds, in, out, a, patches);
-    else nlm3::body<NPXL, MSEG, true, true, TALL>(env, in, out, a, patches, ndx,
-                                                  TALL ? seeds + (size_t)blockIdx.x * a.npatch * nlm3::TALL_SEED_PITCH : nullptr);
+    else nlm3::body<NPXL, MSEG, true, true, TALL, P, CENTER>(env, in, out, a, patches, ndx,
+                                                             TALL ? seeds + (size_t)blockIdx.x * a.npatch * nlm3::TALL_SEED_PITCH : nullptr);
     return;
   }
-  nlm3::body<NPXL, MSEG, false, true, TALL>(env, in, out, a, patches, ndx,
-                                            TALL ? seeds + (size_t)blockIdx.x * a.npatch * nlm3::TALL_SEED_PITCH : nullptr);
+  nlm3::body<NPXL, MSEG, false, true, TALL, P, CENTER>(env, in, out, a, patches, ndx,
+                                                       TALL ? seeds + (size_t)blockIdx.x * a.npatch * nlm3::TALL_SEED_PITCH : nullptr);
 }
 
 // the rows of the chunks of a tall grid behind the 64th (nlm_tail_body.h): one workgroup of 512 threads per chunk, in the
@@ -1110,15 +1118,30 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   // the third version where it applies (nlm3_body.h): the module's defaults on frames whose chunks have at most 56 rows
   int ndx3 = 0;
   const bool force_v2 = dispatch_override(DISPATCH_NLM_V2) || measuring_env("ANSEL_HIP_NLM_V2") != nullptr;
-  const bool v3 = v2 && !center && nlm3::fits<9, 6>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
-                  && !force_v2;
-  const size_t v3_bytes = std::max(nlm3::lds_floats<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
+  // round 6: patch radius 1 (the <9, 7, 1> instantiations) beside 2, and the weight with the centre pixel's term where its division
+  // has a divisor and a sharpness inside what nlm2_device_env::div_uniform() is exact / harmless for (anything else -- no preset
+  // comes near -- keeps the second version's IEEE division)
+  const bool p1 = a.radius == 1;
+  const float cden = 1.0f + p.center_weight;
+  const bool center_ok = !center || (cden >= 1.0f && cden <= 1048576.0f && p.sharpness >= 0x1p-60f && p.sharpness <= 0x1p60f);
+  const bool v3 = v2 && center_ok && (p1 ? nlm3::fits<9, 7, 1>(a.chk_w, a.chk_h, a.radius, a.reach) : nlm3::fits<9, 6>(a.chk_w, a.chk_h, a.radius, a.reach))
+                  && nlm3::regular_grid(patches.data(), a.npatch, &ndx3) && !force_v2;
+  const size_t v3_bytes = std::max((p1 ? nlm3::lds_floats<9, 1>(a.chk_h, a.reach) : nlm3::lds_floats<9>(a.chk_h, a.reach)) * sizeof(float), pipe_bytes);
   // its fused variant for the grids the third version does not take (57 - 64 rows); ANSEL_HIP_NLM_FUSED=1: wherever it fits
-  const size_t v4_bytes = std::max(nlm3::lds_floats_fused<9>(a.chk_h, a.reach) * sizeof(float), pipe_bytes);
+  const size_t v4_bytes = std::max((p1 ? nlm3::lds_floats_fused<9, 1>(a.chk_h, a.reach) : nlm3::lds_floats_fused<9>(a.chk_h, a.reach)) * sizeof(float), pipe_bytes);
   const char *const fused_env = measuring_env("ANSEL_HIP_NLM_FUSED");
   const bool force_fused = dispatch_override(DISPATCH_NLM_FUSED) || (fused_env && atoi(fused_env) != 0);
-  const bool v4 = v2 && !center && nlm3::fits_fused<9, 7>(a.chk_w, a.chk_h, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
+  const bool v4 = v2 && center_ok
+                  && (p1 ? nlm3::fits_fused<9, 7, 1>(a.chk_w, a.chk_h, a.radius, a.reach) : nlm3::fits_fused<9, 7>(a.chk_w, a.chk_h, a.radius, a.reach))
+                  && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                   && v4_bytes <= 160 * 1024 && !force_v2 && (force_fused || !(v3 && v3_bytes <= 160 * 1024));
+  // the instantiation a launch takes: (patch radius, weight) -> kernel
+  typedef void (*nlm3_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int, int);
+  typedef void (*nlm4_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int, int, float *);
+  const nlm3_kernel_t k3 = p1 ? (center ? nlm_chunks_v3<9, 7, 1, true> : nlm_chunks_v3<9, 7, 1, false>)
+                              : (center ? nlm_chunks_v3<9, 6, 2, true> : nlm_chunks_v3<9, 6, 2, false>);
+  const nlm4_kernel_t k4 = p1 ? (center ? nlm_chunks_v4<9, 7, false, 1, true> : nlm_chunks_v4<9, 7, false, 1, false>)
+                              : (center ? nlm_chunks_v4<9, 7, false, 2, true> : nlm_chunks_v4<9, 7, false, 2, false>);
   // chunk grids of 65 - 69 rows (24 / 42 / 150 MP): the fused body on the first 64 rows of every interior chunk + nlm_tail
   static_assert(NLT_HEAD_ROWS == nlm3::TALL_HEAD && NLT_SEED_PITCH == nlm3::TALL_SEED_PITCH, "head and tail share the export's layout");
   const size_t tall_bytes = std::max(nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach) * sizeof(float), pipe_bytes);
@@ -1187,9 +1210,9 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   if(tall)
     attr_err = hipFuncSetAttribute((const void *)nlm_chunks_v4<9, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_bytes);
   else if(v4)
-    attr_err = hipFuncSetAttribute((const void *)nlm_chunks_v4<9, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v4_bytes);
+    attr_err = hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v4_bytes);
   else if(v3 && v3_bytes <= 160 * 1024)
-    attr_err = hipFuncSetAttribute((const void *)nlm_chunks_v3<9, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v3_bytes);
+    attr_err = hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v3_bytes);
   if(attr_err != hipSuccess)
   {
     set_last_error("%s:%d hipFuncSetAttribute(nlm_chunks): %s", __FILE__, __LINE__, hipGetErrorString(attr_err));
@@ -1203,9 +1226,9 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     if(tall)
       nlm_chunks_v4<9, 7, true><<<grid, NL3_THREADS, tall_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, seeds);
     else if(v4)
-      nlm_chunks_v4<9, 7, false><<<grid, NL3_THREADS, v4_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, nullptr);
+      k4<<<grid, NL3_THREADS, v4_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, nullptr);
     else if(v3 && v3_bytes <= 160 * 1024)
-      nlm_chunks_v3<9, 6><<<grid, NL3_THREADS, v3_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3);
+      k3<<<grid, NL3_THREADS, v3_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3);
     else if(v2)
       k2<<<grid, NL2_THREADS, v2_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border);
     else if(pipelined)

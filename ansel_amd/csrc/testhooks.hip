@@ -53,6 +53,7 @@ __global__ void devmath_test(const float *__restrict__ x, const float *__restric
     else if(FN == 11) r = ansel_ieee::rcp_core(x[k]);
     else if(FN == 12) r = ansel_ieee::sqrt_core(x[k]);
     else if(FN == 13) r = ansel_ieee::zero_or_above_2m96(x[k]) ? 1.0f : 0.0f;
+    else if(FN == 14) r = ansel_ieee::div_uniform(x[k], y[k], ansel_ieee::rcp_refined(y[k]));
     else r = fmodf(x[k], y[k]); // the device library's: fmod is exact, any correct implementation agrees
     o[k] = r;
   }
@@ -80,4 +81,5 @@ int dt_hip_test_div_core(int devid, const void *x, const void *y, void *o, size_
 int dt_hip_test_rcp_core(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<11>(devid, x, y, o, n); }
 int dt_hip_test_sqrt_core(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<12>(devid, x, y, o, n); }
 int dt_hip_test_zero_or_above_2m96(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<13>(devid, x, y, o, n); }
+int dt_hip_test_div_uniform(int devid, const void *x, const void *y, void *o, size_t n) { return devmath_launch<14>(devid, x, y, o, n); }
 }

@@ -97,6 +97,9 @@ struct HostEnv
     return (int)v;
   }
   static float max_num(const float a, const float b) { return fmaxf(a, b); } // v_max_f32: the number, if one is a NaN
+  // the device's quotient by a wave-uniform divisor (nlmeans.hip div_uniform(): correctly rounded, checked on the GPU)
+  static float rcp_refined(const float d) { return 1.0f / d; }
+  static float div_uniform(const float n, const float d, const float) { return n / d; }
   static float int_as_float(const int v)
   {
     float f;
@@ -245,7 +248,7 @@ static int nlm2_host_run_(const float *in, float *out, int W, int H, int chk_w, 
 //      0 when the configuration is not one it takes (the launch falls back to the second version then), < 0 on error.
 namespace
 {
-template <int NPXL, int MSEG, bool FUSED = false>
+template <int NPXL, int MSEG, bool FUSED = false, int P = 2, bool CENTER = false>
 void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nchunks, const size_t lds_floats, const int ndx,
           const bool border = false)
 {
@@ -261,12 +264,12 @@ void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nch
       for(int b = 0; b < nchunks; b++)
       {
         HostEnv env{ t, b, base, &bar, &xch };
-        nlm3::body<NPXL, MSEG, false, FUSED>(env, in, out, a, patches, ndx);
+        nlm3::body<NPXL, MSEG, false, FUSED, false, P, CENTER>(env, in, out, a, patches, ndx);
         bar.arrive_and_wait();
         if(border)
         {
           HostEnv envb{ t, b, base, &bar, &xch };
-          nlm3::body<NPXL, MSEG, true, FUSED>(envb, in, out, a, patches, ndx); // the chunks of the outermost ring it takes
+          nlm3::body<NPXL, MSEG, true, FUSED, false, P, CENTER>(envb, in, out, a, patches, ndx); // the chunks of the outermost ring it takes
           bar.arrive_and_wait();
         }
       }
@@ -277,7 +280,17 @@ void run3(const F4 *in, F4 *out, const Args &a, const I2 *patches, const int nch
 
 static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                           int search_radius, float scale, float scattering, float sharpness, const float *norm,
-                          float luma, float chroma, int *interior_chunks, const bool border, const bool fused = false);
+                          float luma, float chroma, int *interior_chunks, const bool border, const bool fused = false,
+                          const float center_weight = -1.0f);
+// round 6: patch radius 1 or 2, either weight (center_weight < 0: denoise (non-local means)'s), third version or fused, with or
+// without the outermost ring
+extern "C" int nlm3_host_run_ex(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                                int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                                float luma, float chroma, int *chunks, float center_weight, int border, int fused)
+{
+  return nlm3_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma,
+                        chroma, chunks, border != 0, fused != 0, center_weight);
+}
 // ---- the fused variant (nlm3_body.h FUSED, launched as nlm_chunks_v4): three tables, the row recurrence in the C role
 extern "C" int nlm4_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                              int search_radius, float scale, float scattering, float sharpness, const float *norm,
@@ -310,7 +323,8 @@ extern "C" int nlm3_host_run_all(const float *in, float *out, int W, int H, int 
 }
 static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                           int search_radius, float scale, float scattering, float sharpness, const float *norm,
-                          float luma, float chroma, int *interior_chunks, const bool border, const bool fused)
+                          float luma, float chroma, int *interior_chunks, const bool border, const bool fused,
+                          const float center_weight)
 {
   std::vector<I2> patches;
   int max_shift = 0;
@@ -340,11 +354,17 @@ static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, 
   a.cy0 = 0;
   a.out_row0 = 0;
   a.out_row1 = H;
+  a.center_weight = center_weight;
+  a.cpn = center_weight * (2 * patch_radius + 1) * (2 * patch_radius + 1); // compute_center_pixel_norm(), nlmeans_core.c:147-153
+  const bool center = !(center_weight < 0);
   int ndx = 0;
-  if(!(fused ? nlm3::fits_fused<9, 7>(chk_w, chk_h, patch_radius, a.reach) : nlm3::fits<9, 6>(chk_w, chk_h, patch_radius, a.reach))
-     || !nlm3::regular_grid(patches.data(), a.npatch, &ndx))
-    return 0;
-  const size_t lds_floats = fused ? nlm3::lds_floats_fused<9>(chk_h, a.reach) : nlm3::lds_floats<9>(chk_h, a.reach);
+  // the instantiations the launch has (nlmeans.hip): patch radius 2 on <9, 6> / fused <9, 7>, patch radius 1 on <9, 7> either way
+  const bool p1 = patch_radius == 1;
+  const bool takes = p1 ? (fused ? nlm3::fits_fused<9, 7, 1>(chk_w, chk_h, patch_radius, a.reach) : nlm3::fits<9, 7, 1>(chk_w, chk_h, patch_radius, a.reach))
+                        : (fused ? nlm3::fits_fused<9, 7>(chk_w, chk_h, patch_radius, a.reach) : nlm3::fits<9, 6>(chk_w, chk_h, patch_radius, a.reach));
+  if(!takes || !nlm3::regular_grid(patches.data(), a.npatch, &ndx)) return 0;
+  const size_t lds_floats = p1 ? (fused ? nlm3::lds_floats_fused<9, 1>(chk_h, a.reach) : nlm3::lds_floats<9, 1>(chk_h, a.reach))
+                               : (fused ? nlm3::lds_floats_fused<9>(chk_h, a.reach) : nlm3::lds_floats<9>(chk_h, a.reach));
   if(lds_floats * sizeof(float) > 160 * 1024) return 0;
   int interior = 0;
   for(int cy = 0; cy < nchy; cy++)
@@ -358,8 +378,23 @@ static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, 
         interior++;
     }
   if(interior_chunks) *interior_chunks = interior;
-  if(fused) run3<9, 7, true>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx, border);
-  else run3<9, 6>((const F4 *)in, (F4 *)out, a, patches.data(), a.nchx * nchy, lds_floats, ndx, border);
+  const F4 *const fin = (const F4 *)in;
+  F4 *const fout = (F4 *)out;
+  const int nch = a.nchx * nchy;
+  if(p1)
+  {
+    if(fused && center) run3<9, 7, true, 1, true>(fin, fout, a, patches.data(), nch, lds_floats, ndx, border);
+    else if(fused) run3<9, 7, true, 1, false>(fin, fout, a, patches.data(), nch, lds_floats, ndx, border);
+    else if(center) run3<9, 7, false, 1, true>(fin, fout, a, patches.data(), nch, lds_floats, ndx, border);
+    else run3<9, 7, false, 1, false>(fin, fout, a, patches.data(), nch, lds_floats, ndx, border);
+  }
+  else if(center)
+  {
+    if(fused) run3<9, 7, true, 2, true>(fin, fout, a, patches.data(), nch, lds_floats, ndx, border);
+    else run3<9, 6, false, 2, true>(fin, fout, a, patches.data(), nch, lds_floats, ndx, border);
+  }
+  else if(fused) run3<9, 7, true>(fin, fout, a, patches.data(), nch, lds_floats, ndx, border);
+  else run3<9, 6>(fin, fout, a, patches.data(), nch, lds_floats, ndx, border);
   return 1;
 }
 

@@ -141,6 +141,49 @@ def test_inrange_division_is_the_ieee_division_on_its_domain():
     assert ((z.view(np.uint32) & 0x7fffffff) == 0).all()
 
 
+def test_division_by_a_shared_divisor():
+    """div_uniform(n, d, rcp_refined(d)), ieee_inrange.h: the quotient of nlm3_body.h's CENTER weight, d = 1 + center_weight in
+    [1, 2^20].  Against the host's division: every bit for |n| in [2^-103, 2^96 d) and for zero, infinite and NaN numerators;
+    outside that interval the kernel only needs what the weight makes of the quotient -- w = 2^-max(0, q s - 2) for a sharpness
+    s in [2^-60, 2^60]: the same bits (1 for the small quotients, 0 for the large ones)."""
+    rng = np.random.default_rng(61)
+    n = 4_000_000
+    d = np.concatenate([(1.0 + rng.random(n // 2) * 3.0).astype(np.float32), np.abs(_floats(rng, n // 2, 0, 19)),
+                        np.array([1.0, 1.1, 2.0, 1048576.0], np.float32)])
+    m = d.size
+    a = np.concatenate([_floats(rng, m // 2, -103, 95), np.abs(_floats(rng, m - m // 2, -40, 40))])
+    got = _run_hook("div_uniform", a, d)
+    with np.errstate(all="ignore"):
+        exp = (a / d).astype(np.float32)
+    bad = got.view(np.uint32) != exp.view(np.uint32)
+    assert not bad.any(), "%d of %d quotients differ, first n=%r d=%r got=%r exp=%r" % (
+        int(bad.sum()), a.size, a[bad][0], d[bad][0], got[bad][0], exp[bad][0])
+    # the numerators the five operations do not take
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 3.0e38, -3.0e38], np.float32)
+    for dv in (1.0, 1.1, 7.5, 1048576.0):
+        g = _run_hook("div_uniform", sp, np.full(sp.shape, dv, np.float32))
+        with np.errstate(all="ignore"):
+            e = (sp / np.float32(dv)).astype(np.float32)
+        same = (g.view(np.uint32) == e.view(np.uint32)) | (np.isnan(g) & np.isnan(e))
+        assert same.all(), (dv, g, e)
+    # beyond the interval: the weight's bits
+    a2 = np.concatenate([np.abs(_floats(rng, n // 2, -149 + 23, -100)), (1e-39 * rng.random(n // 4)).astype(np.float32),
+                         np.abs(_floats(rng, n // 4, 96, 127)), -np.abs(_floats(rng, n // 8, -140 + 23, -90))])
+    d2 = (1.0 + rng.random(a2.size) * 9.0).astype(np.float32)
+    got = _run_hook("div_uniform", a2, d2)
+    with np.errstate(all="ignore"):
+        exp = (a2 / d2).astype(np.float32)
+
+        def weight(q, s):
+            t = np.maximum(np.float32(0.0), (q * np.float32(s) - np.float32(2.0)).astype(np.float32))
+            v = (t * np.float32(-8388608.0)).astype(np.float32)
+            cv = np.where(np.isfinite(v) & (np.abs(v) < 2147483648.0), np.nan_to_num(v, posinf=0, neginf=0).astype(np.int64), -(1 << 31))
+            k0 = ((0x3f800000 + cv) & 0xffffffff).astype(np.uint32).view(np.int32)
+            return np.where(k0 >= 0x800000, k0, 0)
+        for s_ in (2.0 ** -60, 1.3, 2.0 ** 60):
+            assert np.array_equal(weight(got, s_), weight(exp, s_)), s_
+
+
 def test_inrange_reciprocal_and_square_root():
     rng = np.random.default_rng(52)
     n = 4_000_000

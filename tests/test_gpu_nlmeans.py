@@ -145,3 +145,60 @@ def test_denoiseprofile_nlmeans(over):
     img = _noisy(w, h, 23)
     d = params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS, **over)
     _check("denoiseprofile", abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS), d, img)
+
+
+# ---- round 6: patch radius 1 and the weight with the centre pixel's term on the third version's schedule and its fused variant
+#      (nlm3_body.h P / CENTER).  Chunk grids: (330, 168) / (1200, 560) 72 x 56 -- the 100 MP frame's --, (170, 150) 64 x 51: the third
+#      version; (260, 192) / (1200, 640) 72 x 64 -- the 45 / 60 MP frames' --, (330, 171) 72 x 57, (170, 183) 64 x 61: fused;
+#      (150, 128): every chunk in the outermost ring; (293, 247): odd width, the second version (63-row chunks, 69 columns ...).
+R6_GRIDS = [(330, 168), (170, 150), (1200, 560), (260, 192), (330, 171), (170, 183), (1200, 640), (150, 128), (293, 247)]
+
+
+@pytest.mark.parametrize("w,h", R6_GRIDS)
+def test_nlmeans_patch_radius_one_on_the_third_version(w, h, dispatch):
+    """denoise (non-local means) with patch radius 1 (nine A1 chains of <= 7 terms): oracle, reference, and the second version"""
+    img = _lab_image(w, h, 47)
+    d = abi.NlmeansData(1.0, 35.0, 0.5, 1.0)
+    got = _check("nlmeans", abi.Piece.make(w, h), d, img)
+    dispatch("nlm_v2")
+    got2 = hc.run_hip("dt_hip_iop_nlmeans_process", abi.Piece.make(w, h), d, img, img.shape)
+    assert np.array_equal(got2.view(np.uint32), got.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h", R6_GRIDS)
+@pytest.mark.parametrize("over", [dict(),  # the module's defaults in this mode: patch radius 1, search radius 7, central pixel weight 0.1
+                                  dict(radius=2.0, nbhood=5.0, central_pixel_weight=0.5, strength=1.3),
+                                  dict(radius=1.0, nbhood=4.0, central_pixel_weight=0.0, use_new_vst=False)])
+def test_denoiseprofile_nlmeans_on_the_third_version(w, h, over, dispatch):
+    """denoise (profiled), non-local-means mode (the weight with the centre pixel's term, nlmeans_core.c:416-424) on the chunk grids
+    of the third version and of its fused variant: oracle, reference, and the second version's body (IEEE division)"""
+    img = _noisy(w, h, 53)
+    d = params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS, **over)
+    piece = abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS)
+    got = _check("denoiseprofile", piece, d, img)
+    dispatch("nlm_v2")
+    got2 = hc.run_hip("dt_hip_iop_denoiseprofile_process", piece, d, img, img.shape)
+    assert np.array_equal(got2.view(np.uint32), got.view(np.uint32))
+
+
+def test_denoiseprofile_nlmeans_with_adversarial_samples(dispatch):
+    """non-finite and extreme samples through the centre term's division (div_uniform(): v_div_fixup_f32 takes the infinite and NaN
+    numerators): the same words as the oracle and as the second version's IEEE division"""
+    w, h = 330, 168
+    img = _noisy(w, h, 59)
+    img[40:44, 100:104, 0] = np.float32(3.0e38)
+    img[90, 200, 1] = np.float32(np.inf)
+    img[91, 201, 2] = np.float32(np.nan)
+    img[120:123, 50:60, :3] = np.float32(1e-30)
+    img[10, 300:310, :3] = np.float32(-0.5)
+    d = params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS)
+    piece = abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS)
+    got = hc.run_hip("dt_hip_iop_denoiseprofile_process", piece, d, img, img.shape)
+    want = np.zeros_like(img)
+    assert ck.call(ck.oracle(), "oracle_denoiseprofile", piece, d, img, want) == 0
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), "%d words differ" % int((~same).sum())
+    dispatch("nlm_v2")
+    got2 = hc.run_hip("dt_hip_iop_denoiseprofile_process", piece, d, img, img.shape)
+    same = (got.view(np.uint32) == got2.view(np.uint32)) | (np.isnan(got) & np.isnan(got2))
+    assert same.all()

@@ -357,3 +357,55 @@ def test_tall_chunks_border_ring_on_the_host_equals_the_oracle(host_kernel, orac
     nrows_last = h - (h - 1) // ch * ch
     expect = w * (h if nrows_last >= 10 else h - nrows_last)
     assert int(written.sum()) == expect
+
+
+# ---- round 6: patch radius 1 and the weight with the centre pixel's term (denoise (profiled)'s non-local-means mode, whose
+#      defaults are patch radius 1, search radius 7, central pixel weight 0.1) on the third version's schedule and on the fused one:
+#      nlm3_body.h P / CENTER.  Interior chunks and the outermost ring (BORDER bodies).
+# (width, height, patch radius, search radius, center_weight (< 0: the plain weight), fused, ring too, expected chunk)
+CASES_R6 = [
+    (260, 168, 1, 7, -1.0, False, False, (72, 56)),   # patch radius 1, the 100 MP frame's chunk, 225 offsets: nine chains of <= 7 terms
+    (260, 168, 1, 5, 0.1, False, False, (72, 56)),    # ... with the centre term: denoise (profiled)'s defaults but for the search radius
+    (170, 150, 1, 3, 0.1, False, True, (64, 51)),     # 64 x 51 chunks, the ring with the centre term
+    (260, 192, 1, 5, -1.0, True, False, (72, 64)),    # the fused schedule (the 45 / 60 MP frames' 64-row chunks), patch radius 1
+    (260, 192, 1, 3, 0.4, True, True, (72, 64)),      # ... with the centre term and the ring
+    (260, 168, 2, 5, 1.0, False, False, (72, 56)),    # patch radius 2 with the centre as heavy as the patch
+    (181, 171, 2, 3, 0.0, True, True, (72, 57)),      # fused, radius 2, central weight 0 (the division by 1, the floor at -2), ring
+    (151, 140, 1, 3, -1.0, False, True, (64, 51)),    # plain weight, radius 1, ring with an odd last chunk width and a low last row
+]
+
+
+@pytest.mark.parametrize("w,h,P,K,cw_,fused,ring,chunk", CASES_R6)
+def test_patch_radius_one_and_the_centre_term_on_the_third_version(host_kernel, oracle_lib, w, h, P, K, cw_, fused, ring, chunk):
+    o = oracle_lib
+    center = cw_ >= 0
+    if center:
+        rng = np.random.default_rng(91 + P + K)
+        img = np.ascontiguousarray((_lab(w, h, 23 + P + K) * np.float32(0.05) + rng.normal(0, 0.3, (h, w, 4))).astype(np.float32))
+        p = NlmParams(0.0, 1.0, 1.0, 1.0, cw_, 1.3, P, K, (C.c_float * 4)(1.0, 1.0, 1.0, 1.0))
+    else:
+        img = _lab(w, h, 19 + P + K)
+        p = NlmParams(0.0, 1.0, 0.5, 1.0, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    assert (cw, ch) == chunk
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm3_host_run_ex(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(0.0),
+                                      C.c_float(p.sharpness), p.norm, C.c_float(p.luma), C.c_float(p.chroma), C.byref(seen),
+                                      C.c_float(cw_), int(ring), int(fused))
+    assert rc == 1
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    written = ~np.isnan(got[..., 0])
+    assert seen.value > 0 and int(written.sum()) > 0
+    bad = written & (got.view(np.uint32) != want.view(np.uint32)).any(axis=-1)
+    assert int(bad.sum()) == 0, "%d of %d written pixels differ; first at %s" % (int(bad.sum()), int(written.sum()), np.argwhere(bad)[:5].tolist())
+    if ring:
+        nrows_last = h - (h - 1) // ch * ch
+        assert int(written.sum()) == w * (h if nrows_last >= 10 else h - nrows_last)
+    else:
+        assert int(written.sum()) == seen.value * cw * ch
+    if center:
+        assert np.unique(want[written][..., 0]).size > 100  # the weights are not all the floor's
