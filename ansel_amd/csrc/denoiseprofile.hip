@@ -21,6 +21,9 @@
 //      (v[m] += v[m + off], off = 32..1), then the four wave sums left to right;
 //   2. segment sums, numbered row-major, dealt round-robin to 1024 accumulators (increasing segment
 //      number), which are then reduced by halving (off = 512..1); rounded once to binary32.
+// powf (the variance-stabilising transforms, three per sample each way; the fused run's colour stages) looks its tables up in the
+// workgroup's LDS copy: every kernel of this file that calls it stages them first (devmath.h stage_default_tables())
+#define ANSEL_MATH_DEFAULT_TABS tabs_lds
 #include "hip_common.h"
 #include "pipe_fused.h"
 #include "rgb_chain_kernel.h"
@@ -116,6 +119,7 @@ __device__ __forceinline__ float4 dn_precondition_pixel(const float4 px, const v
 __global__ __launch_bounds__(256) void dn_precondition(const float4 *__restrict__ in, float4 *__restrict__ buf,
                                                        const size_t npix, const vst_args a)
 {
+  ansel_math::stage_default_tables(threadIdx.x);
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
   if(j < npix) buf[j] = dn_precondition_pixel(in[j], a);
 }
@@ -219,6 +223,7 @@ __device__ __forceinline__ float4 dn_finish_pixel(const float4 *__restrict__ out
 __global__ __launch_bounds__(256) void dn_finish(float4 *__restrict__ out, const float4 *__restrict__ residue,
                                                  const size_t npix, const vst_args a, const synth_args sy)
 {
+  ansel_math::stage_default_tables(threadIdx.x);
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
   if(j < npix) nt_store(out + j, dn_finish_pixel(out, residue, j, a, sy));
 }
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(256) void dn_finish_chain(float4 *__restrict__ out,
 {
   const chain_args &c = kernarg_at<chain_args>((int)offsetof(dn_chain_kernargs, c));
   (void)c_by_value;
+  ansel_math::stage_default_tables(threadIdx.x);
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(j < npix)
   {
@@ -488,6 +494,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_wa
   // sat in scalar registers for the whole row loop and 53 of them were spilled to vector lanes (hip_common.h kernarg_at())
   const vst_args &fa = kernarg_at<vst_args>((int)offsetof(dn_strip_kernargs, fa));
   (void)fa_by_value;
+  // PRE: three powf a fetched sample, two dependent table lookups each -- as vector-memory round trips they were what the
+  // transform-applying launch waited for (round 5's counters: 68 % of its cycles); from the workgroup's LDS copy now
+  if(PRE) ansel_math::stage_default_tables(threadIdx.x);
   if(flag_sense == 1 && *alpha_flag) return;
   if(flag_sense == 2 && !*alpha_flag) return;
   unsigned alpha_bits = 0; // ALPHA0: the coarse alphas this lane wrote

@@ -26,8 +26,10 @@
 
 #if defined(__HIPCC__)
 #define ANSEL_HD __host__ __device__ __forceinline__
+#define ANSEL_HDM __host__ __device__ __forceinline__ // member functions
 #else
 #define ANSEL_HD static inline
+#define ANSEL_HDM inline
 #endif
 
 namespace ansel_math
@@ -64,16 +66,63 @@ ANSEL_HD double asdouble(const uint64_t u)
   return f;
 }
 
+// ---- where the lookup tables are read from ------------------------------------------------------------------------------------
+// tabs_global: the constant arrays above (on the device: global memory behind the scalar / vector caches -- a per-lane index makes
+// every lookup a vector-memory round trip, two dependent ones per powf).  tabs_lds (device kernels that call powf / log2f / exp2f per
+// pixel; round 6): the same 1 KB of tables copied once per workgroup into LDS (stage()), a lookup an LDS read.  Same words either way.
+struct tabs_global
+{
+  ANSEL_HDM double powlog(const int j) const { return k_powf_log2_tab[j]; }
+  ANSEL_HDM uint64_t exp2(const int j) const { return k_exp2f_tab[j]; }
+  ANSEL_HDM double log2(const int j) const { return k_log2f_tab[j]; }
+};
+#if defined(__HIPCC__)
+// the workgroup's copy (one per kernel that stages it; a kernel that never names it gets no LDS for it)
+static __shared__ uint64_t libm_lds_words[32 + 32 + 32];
+struct tabs_lds
+{
+  __device__ __forceinline__ double powlog(const int j) const { return reinterpret_cast<const double *>(libm_lds_words)[j]; }
+  __device__ __forceinline__ uint64_t exp2(const int j) const { return libm_lds_words[32 + j]; }
+  __device__ __forceinline__ double log2(const int j) const { return reinterpret_cast<const double *>(libm_lds_words + 64)[j]; }
+};
+// EVERY thread of the workgroup calls it at the top of the kernel, before any exit (threads beyond the tables' 96 words idle), then the
+// workgroup meets at a barrier -- stage_tables_and_sync() -- before the first lookup
+__device__ __forceinline__ void stage_tables(const int tid)
+{
+  static_assert(sizeof(k_powf_log2_tab) == 32 * 8 && sizeof(k_exp2f_tab) == 32 * 8 && sizeof(k_log2f_tab) == 32 * 8, "three tables of 32 words");
+  if(tid < 32) libm_lds_words[tid] = asuint64(k_powf_log2_tab[tid]);
+  else if(tid < 64) libm_lds_words[tid] = k_exp2f_tab[tid - 32];
+  else if(tid < 96) libm_lds_words[tid] = asuint64(k_log2f_tab[tid - 64]);
+}
+__device__ __forceinline__ void stage_tables_and_sync(const int tid)
+{
+  stage_tables(tid);
+  __syncthreads();
+}
+#endif
+// A translation unit whose kernels ALL stage the tables defines ANSEL_MATH_DEFAULT_TABS as tabs_lds in front of this header: every
+// lookup of its code then reads the workgroup's copy (the per-pixel device functions of px_*.h take no table argument)
+#ifndef ANSEL_MATH_DEFAULT_TABS
+#define ANSEL_MATH_DEFAULT_TABS tabs_global
+#endif
+#if defined(__HIPCC__)
+// the first statement of every kernel of such a translation unit (a no-op elsewhere)
+__device__ __forceinline__ void stage_default_tables(const int tid)
+{
+  if constexpr(__is_same(ANSEL_MATH_DEFAULT_TABS, tabs_lds)) stage_tables_and_sync(tid);
+}
+#endif
+
 // ---- log2f: sysdeps/ieee754/flt-32/e_log2f.c ------------------------------------------
 // The table-driven core, valid for a positive normal (or pre-normalised) bit pattern ix.
-ANSEL_HD float log2f_core(const uint32_t ix)
+template <class Tabs = ANSEL_MATH_DEFAULT_TABS> ANSEL_HD float log2f_core(const uint32_t ix, const Tabs tabs = Tabs())
 {
   const uint32_t tmp = ix - 0x3f330000u;
   const int i = (tmp >> (23 - 4)) % 16;
   const uint32_t top = tmp & 0xff800000u;
   const uint32_t iz = ix - top;
   const int k = (int32_t)tmp >> 23;
-  const double invc = k_log2f_tab[2 * i], logc = k_log2f_tab[2 * i + 1];
+  const double invc = tabs.log2(2 * i), logc = tabs.log2(2 * i + 1);
   const double z = (double)asfloat(iz);
   const double r = fma(z, invc, -1.0);
   const double y0 = logc + (double)k;
@@ -88,7 +137,7 @@ ANSEL_HD float log2f_core(const uint32_t ix)
 // glibc's control flow folded for a SIMT machine: one predicate separates the positive normal
 // arguments (straight-line code, the only path a wave of image data ever takes) from everything
 // glibc special-cases (zero, negative, inf, NaN, subnormal), which share one cold block.
-ANSEL_HD float log2f_exact(const float x)
+template <class Tabs = ANSEL_MATH_DEFAULT_TABS> ANSEL_HD float log2f_exact(const float x, const Tabs tabs = Tabs())
 {
   uint32_t ix = asuint(x);
   if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u)
@@ -99,7 +148,7 @@ ANSEL_HD float log2f_exact(const float x)
     ix = asuint(x * 0x1p23f);                                      // subnormal: normalise
     ix -= 23u << 23;
   }
-  const float r = log2f_core(ix);
+  const float r = log2f_core(ix, tabs);
   return ix == 0x3f800000u ? 0.0f : r;                             // log2(1) is exactly +0
 }
 
@@ -133,13 +182,13 @@ ANSEL_HD float logf_exact(const float x)
 }
 
 // ---- exp2 of a double argument, rounded to float: exp2_inline() of e_powf.c -------------
-ANSEL_HD float exp2_from_double(const double xd, const uint32_t sign_bias)
+template <class Tabs = ANSEL_MATH_DEFAULT_TABS> ANSEL_HD float exp2_from_double(const double xd, const uint32_t sign_bias, const Tabs tabs = Tabs())
 {
   double kd = xd + k_exp2f_shift_scaled;
   const uint64_t ki = asuint64(kd);
   kd -= k_exp2f_shift_scaled;
   const double r = xd - kd;
-  uint64_t t = k_exp2f_tab[ki % 32];
+  uint64_t t = tabs.exp2((int)(ki % 32));
   const uint64_t ski = ki + sign_bias;
   t += ski << (52 - 5);
   const double s = asdouble(t);
@@ -167,14 +216,14 @@ ANSEL_HD bool powf_zeroinfnan(const uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7
 // ---- powf: sysdeps/ieee754/flt-32/e_powf.c ------------------------------------------------
 // log2_inline() + the range checks + exp2_inline() for |x| given as a positive normal (or
 // pre-normalised) bit pattern ix: straight-line code, overflow / underflow handled by selects.
-ANSEL_HD float powf_core(const uint32_t ix, const float y, const uint32_t sign_bias)
+template <class Tabs = ANSEL_MATH_DEFAULT_TABS> ANSEL_HD float powf_core(const uint32_t ix, const float y, const uint32_t sign_bias, const Tabs tabs = Tabs())
 {
   const uint32_t tmp = ix - 0x3f330000u;
   const int i = (tmp >> (23 - 4)) % 16;
   const uint32_t top = tmp & 0xff800000u;
   const uint32_t iz = ix - top;
   const int k = (int32_t)top >> 23;
-  const double invc = k_powf_log2_tab[2 * i], logc = k_powf_log2_tab[2 * i + 1];
+  const double invc = tabs.powlog(2 * i), logc = tabs.powlog(2 * i + 1);
   const double z = (double)asfloat(iz);
   const double r = fma(z, invc, -1.0);
   const double y0 = logc + (double)k;
@@ -186,7 +235,7 @@ ANSEL_HD float powf_core(const uint32_t ix, const float y, const uint32_t sign_b
   q = fma(p, r2, q);
   yy = fma(yy, r4, q);
   const double ylogx = (double)y * yy;
-  const float res = exp2_from_double(ylogx, sign_bias);
+  const float res = exp2_from_double(ylogx, sign_bias, tabs);
   // |y * log2(x)| >= 126: overflow above 0x1.fffffffd1d571p+6, underflow at or below -150
   const bool big = (asuint64(ylogx) >> 47 & 0xffff) >= asuint64(126.0) >> 47;
   const bool of = big && ylogx > 0x1.fffffffd1d571p+6;
@@ -197,7 +246,7 @@ ANSEL_HD float powf_core(const uint32_t ix, const float y, const uint32_t sign_b
 }
 
 // everything glibc special-cases: x zero / negative / inf / NaN / subnormal, y zero / inf / NaN
-ANSEL_HD float powf_special(const float x, const float y)
+template <class Tabs = ANSEL_MATH_DEFAULT_TABS> ANSEL_HD float powf_special(const float x, const float y, const Tabs tabs = Tabs())
 {
   uint32_t sign_bias = 0;
   uint32_t ix = asuint(x);
@@ -235,10 +284,10 @@ ANSEL_HD float powf_special(const float x, const float y)
     ix &= 0x7fffffffu;
     ix -= 23u << 23;
   }
-  return powf_core(ix, y, sign_bias);
+  return powf_core(ix, y, sign_bias, tabs);
 }
 
-ANSEL_HD float powf_exact(const float x, const float y)
+template <class Tabs = ANSEL_MATH_DEFAULT_TABS> ANSEL_HD float powf_exact(const float x, const float y, const Tabs tabs = Tabs())
 {
   const uint32_t ix = asuint(x);
   const uint32_t iy = asuint(y);
@@ -246,12 +295,12 @@ ANSEL_HD float powf_exact(const float x, const float y)
   // exhaustively against this image's libm; NaNs stay NaN): a uniform-exponent shortcut for the
   // modules whose default exponent is 1 (color calibration gamut compression)
   if(iy == 0x3f800000u && x == x) return x;
-  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) return powf_special(x, y);
-  return powf_core(ix, y, 0);
+  if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) return powf_special(x, y, tabs);
+  return powf_core(ix, y, 0, tabs);
 }
 
 // ---- exp2f: sysdeps/ieee754/flt-32/e_exp2f.c ----------------------------------------------
-ANSEL_HD float exp2f_exact(const float x)
+template <class Tabs = ANSEL_MATH_DEFAULT_TABS> ANSEL_HD float exp2f_exact(const float x, const Tabs tabs = Tabs())
 {
   const double xd = (double)x;
   const uint32_t abstop = (asuint(x) >> 20) & 0x7ff;
@@ -266,7 +315,7 @@ ANSEL_HD float exp2f_exact(const float x)
   const uint64_t ki = asuint64(kd);
   kd -= k_exp2f_shift_scaled;
   const double r = xd - kd;
-  uint64_t t = k_exp2f_tab[ki % 32];
+  uint64_t t = tabs.exp2((int)(ki % 32));
   t += ki << (52 - 5);
   const double s = asdouble(t);
   const double z = fma(k_exp2f_poly[0], r, k_exp2f_poly[1]);
@@ -278,7 +327,7 @@ ANSEL_HD float exp2f_exact(const float x)
 }
 
 // ---- expf: sysdeps/ieee754/flt-32/e_expf.c --------------------------------------------------
-ANSEL_HD float expf_exact(const float x)
+template <class Tabs = ANSEL_MATH_DEFAULT_TABS> ANSEL_HD float expf_exact(const float x, const Tabs tabs = Tabs())
 {
   const double xd = (double)x;
   const uint32_t abstop = (asuint(x) >> 20) & 0x7ff;
@@ -294,7 +343,7 @@ ANSEL_HD float expf_exact(const float x)
   const uint64_t ki = asuint64(kd);
   kd -= k_exp2f_shift;
   const double r = z - kd;
-  uint64_t t = k_exp2f_tab[ki % 32];
+  uint64_t t = tabs.exp2((int)(ki % 32));
   t += ki << (52 - 5);
   const double s = asdouble(t);
   const double zz = fma(k_exp2f_poly_scaled[0], r, k_exp2f_poly_scaled[1]);

@@ -42,6 +42,8 @@ void set_last_error(const char *fmt, ...);
 
 // per-device state owned by runtime.cpp
 hipStream_t stream_of(int devid); // also makes the device current for the calling thread
+// a small host table -> device memory on the device's stream, through a pinned staging ring: no wait for the stream (runtime.cpp)
+int upload_small(int devid, void *dst_dev, const void *src_host, size_t bytes);
 bool make_current(int devid);
 int hip_device_of(int devid); // the HIP ordinal behind a runtime device id (-1: no such device)
 bool valid_device(int devid);

@@ -1189,11 +1189,12 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   if(order_bytes) memcpy(host_blob.data() + patch_bytes, order.data(), order_bytes);
   int2 *dev_patches = (int2 *)dt_hip_alloc_device_buffer(devid, host_blob.size());
   if(!dev_patches) return DT_HIP_SYSMEM_ALLOCATION;
-  if(hipMemcpyAsync(dev_patches, host_blob.data(), host_blob.size(), hipMemcpyHostToDevice, s) != hipSuccess
-     || hipStreamSynchronize(s) != hipSuccess) // `host_blob` is a stack-lifetime host buffer
+  // (through the runtime's pinned staging ring: `host_blob` is a stack-lifetime buffer, and waiting for the stream here was a host
+  // meeting in the middle of every frame)
+  if(const int uerr = upload_small(devid, dev_patches, host_blob.data(), host_blob.size()); uerr != DT_HIP_SUCCESS)
   {
     dt_hip_release_mem_object(dev_patches);
-    return DT_HIP_DEFAULT_ERROR;
+    return uerr;
   }
   const int *const dev_order = (const int *)((const unsigned char *)dev_patches + patch_bytes);
   // the head's export: one column-sum row per chunk and offset (NLT_SEED_PITCH floats: ~14.5 B per pixel of the frame, written

@@ -1,5 +1,7 @@
 // pipe_fused_rgb_none.hip -- instantiations of the fused RGBA chain (rgb_chain_kernel.h) for filmic
 // mode FM_NONE, one per color-calibration adaptation.
+// powf / log2f / expf look their tables up in the workgroup's LDS copy (devmath.h): rgb_chain() stages it
+#define ANSEL_MATH_DEFAULT_TABS tabs_lds
 #include "rgb_chain_kernel.h"
 namespace ansel
 {

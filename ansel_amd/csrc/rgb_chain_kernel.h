@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, 
   // the ~340 dwords of parameters are read where they are used (hip_common.h kernarg_at())
   const chain_args &a = kernarg_at<chain_args>(CHAIN_ARGS_KERNARG_OFFSET);
   (void)a_by_value;
+  ansel_math::stage_default_tables(threadIdx.x); // (pipe_fused_rgb_*.hip: the lookup tables of the ~12 powf / log2f a pixel, in LDS)
   // one pixel per thread: the ~250 uniform parameters of the five stages are then used once per wave
   // instead of staying live across a grid-stride loop (which spilled 770 SGPRs to VGPR lanes)
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

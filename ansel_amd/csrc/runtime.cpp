@@ -44,6 +44,17 @@ struct device_t
   std::vector<hipEvent_t> event_pool;
   size_t cur_bytes = 0, peak_bytes = 0;
   std::multimap<size_t, void *> free_pool;
+  // upload_small(): a ring of pinned staging buffers, each with the event behind its last copy
+  struct staging_t
+  {
+    void *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool used = false;
+  };
+  std::mutex staging_lock;
+  staging_t staging[8];
+  int staging_next = 0;
 };
 
 struct alloc_t
@@ -90,6 +101,46 @@ bool make_current(int devid)
 }
 
 int hip_device_of(int devid) { return valid_device(devid) ? g_devs[devid]->hip_id : -1; }
+
+// A module's small per-launch table (patch offsets, tile lists: what lived in a std::vector on the launcher's stack) -> device memory on
+// the device's stream WITHOUT waiting for the stream: the bytes go through a pinned staging buffer of the device's ring, which is reused
+// only behind the event recorded after its copy.  (The modules used to hipMemcpyAsync from the stack and then drain the stream -- a host
+// meeting in the middle of a frame, which kept the host from enqueueing ahead and a batch's transfers from overlapping its kernels.)
+int upload_small(int devid, void *dst_dev, const void *src_host, size_t bytes)
+{
+  if(!valid_device(devid) || !dst_dev || (!src_host && bytes)) return DT_HIP_INVALID_ARG;
+  if(bytes == 0) return DT_HIP_SUCCESS;
+  device_t *d = g_devs[devid];
+  if(!make_current(devid)) return DT_HIP_DEFAULT_ERROR;
+  std::lock_guard<std::mutex> g(d->staging_lock);
+  device_t::staging_t &st = d->staging[d->staging_next];
+  d->staging_next = (d->staging_next + 1) % 8;
+  if(st.used && hipEventSynchronize(st.ev) != hipSuccess) return DT_HIP_DEFAULT_ERROR; // eight uploads ago: long done
+  if(st.cap < bytes)
+  {
+    if(st.host) (void)hipHostFree(st.host);
+    st.host = nullptr;
+    st.cap = 0;
+    size_t cap = 4096;
+    while(cap < bytes) cap *= 2;
+    if(hipHostMalloc(&st.host, cap, hipHostMallocDefault) != hipSuccess)
+    {
+      set_last_error("upload_small: no pinned staging buffer of %zu bytes", cap);
+      st.host = nullptr;
+      return DT_HIP_SYSMEM_ALLOCATION;
+    }
+    st.cap = cap;
+  }
+  if(!st.ev && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess) return DT_HIP_DEFAULT_ERROR;
+  memcpy(st.host, src_host, bytes);
+  if(hipMemcpyAsync(dst_dev, st.host, bytes, hipMemcpyHostToDevice, d->stream) != hipSuccess || hipEventRecord(st.ev, d->stream) != hipSuccess)
+  {
+    set_last_error("upload_small: the copy of %zu bytes could not be enqueued", bytes);
+    return DT_HIP_DEFAULT_ERROR;
+  }
+  st.used = true;
+  return DT_HIP_SUCCESS;
+}
 
 hipStream_t stream_of(int devid)
 {
@@ -201,6 +252,11 @@ void dt_hip_cleanup(void)
       (void)hipEventDestroy(e.stop);
     }
     for(auto e : d->event_pool) (void)hipEventDestroy(e);
+    for(auto &st : d->staging)
+    {
+      if(st.ev) (void)hipEventDestroy(st.ev);
+      if(st.host) (void)hipHostFree(st.host);
+    }
     if(d->own_stream) (void)hipStreamDestroy(d->stream);
     delete d;
   }
