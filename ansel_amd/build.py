@@ -36,6 +36,8 @@ EXTRA = {
     # gfx950 (no gain over two scalar operations) and need their operands in adjacent registers (560 v_mov in this
     # kernel)
     "demosaic_rcd.hip": ["-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize"],
+    # (nlmeans.hip with -fslp-vectorize, round 6: 1 885 v_pk_add / v_pk_mul_f32 in nlm_chunks_v3 -- one issue slot for two of the A1 role's
+    # column pairs -- and 22.1 against 21.5 - 22.0 ms at 100 MP: nothing, with spills in every other instantiation)
 }
 
 

@@ -187,7 +187,6 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
                   const int ndx, float *__restrict__ seeds_out = nullptr)
 {
   static_assert(!TALL || FUSED, "the head of a tall chunk runs on the fused body");
-  static_assert(!TALL || (P == 2 && !CENTER), "nlm_tail_body.h continues patch radius 2 without the centre term");
   constexpr int S = 2 * P + 1, TP = NL3_TP, XO = NL3_XO, FP = NL3_FP, WPH = NL3_WPH;
   constexpr int NSEG = a1_segments<P>(), NCH = S * NSEG;
   constexpr int MAXCH = FUSED ? FUSED_MAXCH : max_rows<NPXL>();

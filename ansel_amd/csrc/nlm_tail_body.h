@@ -42,10 +42,10 @@ inline size_t lds_floats(const int tail_rows, const int reach, const int npatch)
   return (size_t)wh * NLT_WP * 3 + 3 * NLT_ROWS * NLT_TP + 2 * NLT_ROWS * NLT_TP + 3 * ((npatch + 3) & ~3);
 }
 
-inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach, const int npatch)
+template <int P = 2> inline bool fits(const int chk_w, const int chk_h, const int radius, const int reach, const int npatch)
 {
-  return radius == 2 && chk_h > NLT_HEAD_ROWS && chk_h - NLT_HEAD_ROWS <= NLT_ROWS && chk_w + 2 * reach <= NLT_WP && chk_w + 5 <= NLT_TP
-         && reach >= 3 && (chk_w + 4) * NLT_ROWS <= NLT_THREADS - 128 && npatch <= 4096;
+  return radius == P && chk_h > NLT_HEAD_ROWS && chk_h - NLT_HEAD_ROWS <= NLT_ROWS && chk_w + 2 * reach <= NLT_WP && chk_w + 2 * P + 1 <= NLT_TP
+         && reach >= P + 1 && (chk_w + 2 * P) * NLT_ROWS <= NLT_THREADS - 128 && npatch <= 4096;
 }
 
 // Env: tid(), bid(), lds(), sync(), lane_shr1(), cvt_i32_sat(), int_as_float(), max_num().  Args: nlm_args of nlmeans.hip.
@@ -55,11 +55,12 @@ inline bool fits(const int chk_w, const int chk_h, const int radius, const int r
 // (nlm3_body.h, BORDER: why that reproduces init_column_sums() and the three branches of nlmeans_core.c:437-488), a pixel whose
 // shifted pixel lies outside gets weight +0 for that offset (:398-404), and the window holds zeros there.  The chunk may be
 // narrower / lower than the grid's.
-template <bool BORDER = false, class Env, class Args, class F4, class I2>
+// P, CENTER (round 6): patch radius 1 beside 2; the weight with the centre pixel's term (nlm3_body.h CENTER) in stage (d).
+template <bool BORDER = false, int P = 2, bool CENTER = false, class Env, class Args, class F4, class I2>
 NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ out, const Args &a, const I2 *__restrict__ patches,
                   const float *__restrict__ seeds)
 {
-  constexpr int P = 2, S = 2 * P + 1, WP = NLT_WP, TP = NLT_TP;
+  constexpr int S = 2 * P + 1, WP = NLT_WP, TP = NLT_TP;
   const int tid = env.tid();
   const int W = a.W, H = a.H;
   const int cy_launch = env.bid() / a.nchx, cx = env.bid() - cy_launch * a.nchx;
@@ -134,6 +135,11 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int d_win = (dj + reach) * WP + reach + dc;
   float accx = 0.0f, accy = 0.0f, accz = 0.0f, accw = 0.0f;
   const float sharp_m23 = a.sharpness * -8388608.0f;
+  // CENTER: the lane's own pixel, the divisor 1 + center_weight and its refined reciprocal (nlm3_body.h)
+  [[maybe_unused]] const f2 own_xy = CENTER ? XY[d_win] : f2{ 0.0f, 0.0f };
+  [[maybe_unused]] const float own_z = CENTER ? Z[d_win] : 0.0f;
+  [[maybe_unused]] const float cden = 1.0f + a.center_weight;
+  [[maybe_unused]] const float crcp = Env::rcp_refined(cden);
   float seed = b_on ? seeds[bx] : 0.0f, seed2 = b2_on ? seeds[bx2] : 0.0f; // offset 0's, for stage 1
 
   for(int s = 0; s < n + 3; s++)
@@ -244,7 +250,18 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       const float dist = Db[((p & 1) * NLT_ROWS + dj) * TP + dc];
       const f2 q = XY[wo];
       const float qz = Z[wo];
-      float wgt = nlm2::mexp2_scaled<Env>(dist, sharp_m23);
+      float wgt;
+      if constexpr(CENTER)
+      {
+        // nlmeans_core.c:416-424, as nlm3_body.h's accumulate() forms it
+        const float dx_ = own_xy.x - q.x, dy_ = own_xy.y - q.y, dz_ = own_z - qz;
+        const float num = dist + (dx_ * dx_ * a.cpn + dy_ * dy_ * a.cpn + dz_ * dz_ * a.cpn);
+        const float v = Env::max_num(0.0f, Env::div_uniform(num, cden, crcp) * a.sharpness - 2.0f) * -8388608.0f;
+        const int k0 = (int)(0x3f800000u + (unsigned)Env::cvt_i32_sat(v));
+        wgt = Env::int_as_float(k0 >= 0x800000 ? k0 : 0);
+      }
+      else
+        wgt = nlm2::mexp2_scaled<Env>(dist, sharp_m23);
       if(BORDER && !((unsigned)(top + R0 + dj + pdy[p]) < (unsigned)H && (unsigned)(left + dc + pdx[p]) < (unsigned)W)) wgt = 0.0f;
       accx = accx + q.x * wgt;
       accy = accy + q.y * wgt;

@@ -938,7 +938,7 @@ __global__ __launch_bounds__(NL3_THREADS) void nlm_chunks_v4(const float4 *__res
 // order (and with the export slots) of the head launch
 // (two instantiations, two launches: with both bodies in one kernel the interior chunks' launch carried the ring's scalar
 // registers -- 86 where 80 let four workgroups share a CU)
-template <bool BORDER>
+template <bool BORDER, int P = 2, bool CENTER = false>
 __global__ __launch_bounds__(NLT_THREADS, 8) void nlm_tail(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                            const nlm_args a, const int2 *__restrict__ patches,
                                                            const int *__restrict__ order, const int first,
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(NLT_THREADS, 8) void nlm_tail(const float4 *__restr
   env.lds_ = lds;
   const int pos = first + (int)blockIdx.x; // position in the head launch: its chunk and its export slot
   env.chunk_ = order[pos];
-  nlmt::body<BORDER>(env, in, out, a, patches, seeds + (size_t)pos * a.npatch * NLT_SEED_PITCH);
+  nlmt::body<BORDER, P, CENTER>(env, in, out, a, patches, seeds + (size_t)pos * a.npatch * NLT_SEED_PITCH);
 }
 
 typedef void (*nlm2_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int);
@@ -1144,11 +1144,18 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
                               : (center ? nlm_chunks_v4<9, 7, false, 2, true> : nlm_chunks_v4<9, 7, false, 2, false>);
   // chunk grids of 65 - 69 rows (24 / 42 / 150 MP): the fused body on the first 64 rows of every interior chunk + nlm_tail
   static_assert(NLT_HEAD_ROWS == nlm3::TALL_HEAD && NLT_SEED_PITCH == nlm3::TALL_SEED_PITCH, "head and tail share the export's layout");
-  const size_t tall_bytes = std::max(nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach) * sizeof(float), pipe_bytes);
+  const size_t tall_bytes = std::max((p1 ? nlm3::lds_floats_fused<9, 1>(NLT_HEAD_ROWS, a.reach) : nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach)) * sizeof(float), pipe_bytes);
   const size_t tail_bytes = nlmt::lds_floats(a.chk_h - NLT_HEAD_ROWS, a.reach, a.npatch) * sizeof(float);
-  bool tall = v2 && !center && !v3 && !v4 && !force_v2 && nlmt::fits(a.chk_w, a.chk_h, a.radius, a.reach, a.npatch)
-                    && nlm3::fits_fused<9, 7>(a.chk_w, NLT_HEAD_ROWS, a.radius, a.reach) && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
+  bool tall = v2 && center_ok && !v3 && !v4 && !force_v2
+                    && (p1 ? nlmt::fits<1>(a.chk_w, a.chk_h, a.radius, a.reach, a.npatch) && nlm3::fits_fused<9, 7, 1>(a.chk_w, NLT_HEAD_ROWS, a.radius, a.reach)
+                           : nlmt::fits<2>(a.chk_w, a.chk_h, a.radius, a.reach, a.npatch) && nlm3::fits_fused<9, 7>(a.chk_w, NLT_HEAD_ROWS, a.radius, a.reach))
+                    && nlm3::regular_grid(patches.data(), a.npatch, &ndx3)
                     && tall_bytes <= 160 * 1024 && tail_bytes <= 64 * 1024;
+  const nlm4_kernel_t k4t = p1 ? (center ? nlm_chunks_v4<9, 7, true, 1, true> : nlm_chunks_v4<9, 7, true, 1, false>)
+                               : (center ? nlm_chunks_v4<9, 7, true, 2, true> : nlm_chunks_v4<9, 7, true, 2, false>);
+  typedef void (*nlmt_kernel_t)(const float4 *, float4 *, nlm_args, const int2 *, const int *, int, const float *);
+  const nlmt_kernel_t kt_ring = p1 ? (center ? nlm_tail<true, 1, true> : nlm_tail<true, 1, false>) : (center ? nlm_tail<true, 2, true> : nlm_tail<true, 2, false>);
+  const nlmt_kernel_t kt_in = p1 ? (center ? nlm_tail<false, 1, true> : nlm_tail<false, 1, false>) : (center ? nlm_tail<false, 2, true> : nlm_tail<false, 2, false>);
   static_assert(NL2_SERIAL == NLP_SERIAL && NL2_THREADS == NLM_THREADS && NL3_THREADS == NLM_THREADS,
                 "nlm_chunks_v2 / _v3 share the launch shape of nlm_chunks_pipelined");
   nlm2_kernel_t k2 = nullptr;
@@ -1209,7 +1216,7 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   // the opt-in to more than 64 KB of LDS, before anything is launched: a failure leaves nothing behind
   hipError_t attr_err = hipSuccess;
   if(tall)
-    attr_err = hipFuncSetAttribute((const void *)nlm_chunks_v4<9, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_bytes);
+    attr_err = hipFuncSetAttribute((const void *)k4t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tall_bytes);
   else if(v4)
     attr_err = hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v4_bytes);
   else if(v3 && v3_bytes <= 160 * 1024)
@@ -1225,7 +1232,7 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
     launch_scope ls(devid, "nlm_chunks");
     const unsigned grid = (unsigned)nchunks;
     if(tall)
-      nlm_chunks_v4<9, 7, true><<<grid, NL3_THREADS, tall_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, seeds);
+      k4t<<<grid, NL3_THREADS, tall_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, seeds);
     else if(v4)
       k4<<<grid, NL3_THREADS, v4_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, ndx3, nullptr);
     else if(v3 && v3_bytes <= 160 * 1024)
@@ -1243,9 +1250,9 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   if(err == DT_HIP_SUCCESS && tall)
   {
     launch_scope ls(devid, "nlm_tail");
-    if(n_border > 0) nlm_tail<true><<<(unsigned)n_border, NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, 0, seeds);
+    if(n_border > 0) kt_ring<<<(unsigned)n_border, NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, 0, seeds);
     if(nchunks > n_border)
-      nlm_tail<false><<<(unsigned)(nchunks - n_border), NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, seeds);
+      kt_in<<<(unsigned)(nchunks - n_border), NLT_THREADS, tail_bytes, s>>>(in, out, a, dev_patches, dev_order, n_border, seeds);
     err = check_launch("nlm_tail");
   }
   if(seeds) dt_hip_release_mem_object(seeds);

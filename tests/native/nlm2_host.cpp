@@ -404,7 +404,15 @@ static int nlm3_host_run_(const float *in, float *out, int W, int H, int chk_w, 
 //      configuration is not one the pair takes.
 static int nlm_tall_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                               int search_radius, float scale, float scattering, float sharpness, const float *norm,
-                              float luma, float chroma, int *interior_chunks, const bool border);
+                              float luma, float chroma, int *interior_chunks, const bool border, const float center_weight = -1.0f);
+// round 6: patch radius 1 or 2, either weight
+extern "C" int nlm_tall_host_run_ex(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
+                                    int search_radius, float scale, float scattering, float sharpness, const float *norm,
+                                    float luma, float chroma, int *chunks, float center_weight, int border)
+{
+  return nlm_tall_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma, chroma,
+                            chunks, border != 0, center_weight);
+}
 extern "C" int nlm_tall_host_run(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                                  int search_radius, float scale, float scattering, float sharpness, const float *norm,
                                  float luma, float chroma, int *interior_chunks)
@@ -420,9 +428,67 @@ extern "C" int nlm_tall_host_run_all(const float *in, float *out, int W, int H, 
   return nlm_tall_host_run_(in, out, W, H, chk_w, chk_h, patch_radius, search_radius, scale, scattering, sharpness, norm, luma, chroma,
                             chunks, true);
 }
+namespace
+{
+template <int P, bool CENTER>
+void run_tall(const F4 *fin, F4 *fout, const Args &a, const I2 *patches, const int nchunks, const int ndx, const size_t head_floats,
+              const size_t tail_floats, const bool border)
+{
+  const size_t per_chunk = (size_t)a.npatch * NLT_SEED_PITCH;
+  std::vector<float> seeds(per_chunk * nchunks, __builtin_nanf(""));
+  {
+    std::vector<float> lds(head_floats + 4096, 0.0f);
+    WaveExchange xch;
+    float *base = lds.data();
+    while((uintptr_t)base & 15) base++;
+    std::barrier<> bar(NL3_THREADS);
+    std::vector<std::thread> pool;
+    for(int t = 0; t < NL3_THREADS; t++)
+      pool.emplace_back([&, t]() {
+        for(int b = 0; b < nchunks; b++)
+        {
+          HostEnv env{ t, b, base, &bar, &xch };
+          nlm3::body<9, 7, false, true, true, P, CENTER>(env, fin, fout, a, patches, ndx, seeds.data() + per_chunk * b);
+          bar.arrive_and_wait();
+          if(border)
+          {
+            HostEnv envb{ t, b, base, &bar, &xch };
+            nlm3::body<9, 7, true, true, true, P, CENTER>(envb, fin, fout, a, patches, ndx, seeds.data() + per_chunk * b);
+            bar.arrive_and_wait();
+          }
+        }
+      });
+    for(auto &th : pool) th.join();
+  }
+  {
+    std::vector<float> lds(tail_floats + 4096, 0.0f);
+    float *base = lds.data();
+    while((uintptr_t)base & 15) base++;
+    std::barrier<> bar(NLT_THREADS);
+    WaveExchange xch;
+    std::vector<std::thread> pool;
+    for(int t = 0; t < NLT_THREADS; t++)
+      pool.emplace_back([&, t]() {
+        for(int b = 0; b < nchunks; b++)
+        {
+          HostEnv env{ t, b, base, &bar, &xch };
+          nlmt::body<false, P, CENTER>(env, fin, fout, a, patches, seeds.data() + per_chunk * b);
+          bar.arrive_and_wait();
+          if(border)
+          {
+            HostEnv envb{ t, b, base, &bar, &xch };
+            nlmt::body<true, P, CENTER>(envb, fin, fout, a, patches, seeds.data() + per_chunk * b);
+            bar.arrive_and_wait();
+          }
+        }
+      });
+    for(auto &th : pool) th.join();
+  }
+}
+} // namespace
 static int nlm_tall_host_run_(const float *in, float *out, int W, int H, int chk_w, int chk_h, int patch_radius,
                               int search_radius, float scale, float scattering, float sharpness, const float *norm,
-                              float luma, float chroma, int *interior_chunks, const bool border)
+                              float luma, float chroma, int *interior_chunks, const bool border, const float center_weight)
 {
   std::vector<I2> patches;
   int max_shift = 0;
@@ -452,11 +518,14 @@ static int nlm_tall_host_run_(const float *in, float *out, int W, int H, int chk
   a.cy0 = 0;
   a.out_row0 = 0;
   a.out_row1 = H;
+  a.center_weight = center_weight;
+  a.cpn = center_weight * (2 * patch_radius + 1) * (2 * patch_radius + 1);
+  const bool center = !(center_weight < 0), p1 = patch_radius == 1;
   int ndx = 0;
-  if(!nlmt::fits(chk_w, chk_h, patch_radius, a.reach, a.npatch) || !nlm3::fits_fused<9, 7>(chk_w, NLT_HEAD_ROWS, patch_radius, a.reach)
-     || !nlm3::regular_grid(patches.data(), a.npatch, &ndx))
-    return 0;
-  const size_t head_floats = nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach);
+  const bool takes = p1 ? nlmt::fits<1>(chk_w, chk_h, patch_radius, a.reach, a.npatch) && nlm3::fits_fused<9, 7, 1>(chk_w, NLT_HEAD_ROWS, patch_radius, a.reach)
+                        : nlmt::fits<2>(chk_w, chk_h, patch_radius, a.reach, a.npatch) && nlm3::fits_fused<9, 7>(chk_w, NLT_HEAD_ROWS, patch_radius, a.reach);
+  if(!takes || !nlm3::regular_grid(patches.data(), a.npatch, &ndx)) return 0;
+  const size_t head_floats = p1 ? nlm3::lds_floats_fused<9, 1>(NLT_HEAD_ROWS, a.reach) : nlm3::lds_floats_fused<9>(NLT_HEAD_ROWS, a.reach);
   const size_t tail_floats = nlmt::lds_floats(chk_h - NLT_HEAD_ROWS, a.reach, a.npatch);
   if(head_floats * sizeof(float) > 160 * 1024 || tail_floats * sizeof(float) > 64 * 1024) return 0;
   int interior = 0;
@@ -472,57 +541,11 @@ static int nlm_tall_host_run_(const float *in, float *out, int W, int H, int chk
     }
   if(interior_chunks) *interior_chunks = interior;
   const int nchunks = a.nchx * nchy;
-  const size_t per_chunk = (size_t)a.npatch * NLT_SEED_PITCH;
-  std::vector<float> seeds(per_chunk * nchunks, __builtin_nanf(""));
   const F4 *const fin = (const F4 *)in;
   F4 *const fout = (F4 *)out;
-  {
-    std::vector<float> lds(head_floats + 4096, 0.0f);
-    WaveExchange xch;
-    float *base = lds.data();
-    while((uintptr_t)base & 15) base++;
-    std::barrier<> bar(NL3_THREADS);
-    std::vector<std::thread> pool;
-    for(int t = 0; t < NL3_THREADS; t++)
-      pool.emplace_back([&, t]() {
-        for(int b = 0; b < nchunks; b++)
-        {
-          HostEnv env{ t, b, base, &bar, &xch };
-          nlm3::body<9, 7, false, true, true>(env, fin, fout, a, patches.data(), ndx, seeds.data() + per_chunk * b);
-          bar.arrive_and_wait();
-          if(border)
-          {
-            HostEnv envb{ t, b, base, &bar, &xch };
-            nlm3::body<9, 7, true, true, true>(envb, fin, fout, a, patches.data(), ndx, seeds.data() + per_chunk * b);
-            bar.arrive_and_wait();
-          }
-        }
-      });
-    for(auto &th : pool) th.join();
-  }
-  {
-    std::vector<float> lds(tail_floats + 4096, 0.0f);
-    float *base = lds.data();
-    while((uintptr_t)base & 15) base++;
-    std::barrier<> bar(NLT_THREADS);
-    WaveExchange xch;
-    std::vector<std::thread> pool;
-    for(int t = 0; t < NLT_THREADS; t++)
-      pool.emplace_back([&, t]() {
-        for(int b = 0; b < nchunks; b++)
-        {
-          HostEnv env{ t, b, base, &bar, &xch };
-          nlmt::body<false>(env, fin, fout, a, patches.data(), seeds.data() + per_chunk * b);
-          bar.arrive_and_wait();
-          if(border)
-          {
-            HostEnv envb{ t, b, base, &bar, &xch };
-            nlmt::body<true>(envb, fin, fout, a, patches.data(), seeds.data() + per_chunk * b);
-            bar.arrive_and_wait();
-          }
-        }
-      });
-    for(auto &th : pool) th.join();
-  }
+  if(p1 && center) run_tall<1, true>(fin, fout, a, patches.data(), nchunks, ndx, head_floats, tail_floats, border);
+  else if(p1) run_tall<1, false>(fin, fout, a, patches.data(), nchunks, ndx, head_floats, tail_floats, border);
+  else if(center) run_tall<2, true>(fin, fout, a, patches.data(), nchunks, ndx, head_floats, tail_floats, border);
+  else run_tall<2, false>(fin, fout, a, patches.data(), nchunks, ndx, head_floats, tail_floats, border);
   return 1;
 }

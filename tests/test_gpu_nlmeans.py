@@ -151,7 +151,10 @@ def test_denoiseprofile_nlmeans(over):
 #      (nlm3_body.h P / CENTER).  Chunk grids: (330, 168) / (1200, 560) 72 x 56 -- the 100 MP frame's --, (170, 150) 64 x 51: the third
 #      version; (260, 192) / (1200, 640) 72 x 64 -- the 45 / 60 MP frames' --, (330, 171) 72 x 57, (170, 183) 64 x 61: fused;
 #      (150, 128): every chunk in the outermost ring; (293, 247): odd width, the second version (63-row chunks, 69 columns ...).
-R6_GRIDS = [(330, 168), (170, 150), (1200, 560), (260, 192), (330, 171), (170, 183), (1200, 640), (150, 128), (293, 247)]
+#      tall grids (the fused head + nlm_tail): (260, 207) 72 x 69 -- the 24 MP frame's --, (170, 201) 64 x 67, (250, 195) 68 x 65: one tail
+#      row, (1200, 690) 17 x 10 chunks, (150, 138): 69-row chunks all in the ring, (151, 274): a last row of chunks of 67 rows
+R6_GRIDS = [(330, 168), (170, 150), (1200, 560), (260, 192), (330, 171), (170, 183), (1200, 640), (150, 128), (293, 247),
+            (260, 207), (170, 201), (250, 195), (1200, 690), (150, 138), (151, 274)]
 
 
 @pytest.mark.parametrize("w,h", R6_GRIDS)

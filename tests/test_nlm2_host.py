@@ -409,3 +409,44 @@ def test_patch_radius_one_and_the_centre_term_on_the_third_version(host_kernel, 
         assert int(written.sum()) == seen.value * cw * ch
     if center:
         assert np.unique(want[written][..., 0]).size > 100  # the weights are not all the floor's
+
+
+# ... and on the tall chunk grids (65 - 69 rows: the 24 MP frame's 69): the fused head + nlm_tail_body.h with P / CENTER
+# (width, height, patch radius, search radius, center_weight, ring too, expected chunk)
+CASES_R6_TALL = [
+    (260, 207, 1, 5, 0.1, False, (72, 69)),    # denoise (profiled)'s defaults (but for the search radius) on the 24 MP frame's chunk
+    (260, 207, 1, 3, -1.0, True, (72, 69)),    # patch radius 1, plain weight, ring
+    (170, 201, 2, 3, 0.5, True, (64, 67)),     # patch radius 2 with the centre term, 67-row chunks, ring
+    (250, 195, 1, 3, 0.0, False, (68, 65)),    # ONE tail row, central weight 0
+]
+
+
+@pytest.mark.parametrize("w,h,P,K,cw_,ring,chunk", CASES_R6_TALL)
+def test_patch_radius_one_and_the_centre_term_on_tall_chunks(host_kernel, oracle_lib, w, h, P, K, cw_, ring, chunk):
+    o = oracle_lib
+    center = cw_ >= 0
+    if center:
+        rng = np.random.default_rng(93 + P + K)
+        img = np.ascontiguousarray((_lab(w, h, 27 + P + K) * np.float32(0.05) + rng.normal(0, 0.3, (h, w, 4))).astype(np.float32))
+        p = NlmParams(0.0, 1.0, 1.0, 1.0, cw_, 1.3, P, K, (C.c_float * 4)(1.0, 1.0, 1.0, 1.0))
+    else:
+        img = _lab(w, h, 29 + P + K)
+        p = NlmParams(0.0, 1.0, 0.5, 1.0, -1.0, 3000.0 / 51.0, P, K, (C.c_float * 4)(1 / 120.0 ** 2, 1 / 512.0 ** 2, 1 / 512.0 ** 2, 1.0))
+    o.oracle_nlmeans_slice_height.restype = C.c_int
+    o.oracle_nlmeans_slice_width.restype = C.c_int
+    ch, cw = o.oracle_nlmeans_slice_height(h), o.oracle_nlmeans_slice_width(w)
+    assert (cw, ch) == chunk
+    got = np.full_like(img, np.nan)
+    seen = C.c_int(0)
+    rc = host_kernel.nlm_tall_host_run_ex(ck.ptr(img), ck.ptr(got), w, h, cw, ch, P, K, C.c_float(1.0), C.c_float(0.0),
+                                          C.c_float(p.sharpness), p.norm, C.c_float(p.luma), C.c_float(p.chroma), C.byref(seen),
+                                          C.c_float(cw_), int(ring))
+    assert rc == 1
+    want = np.zeros_like(img)
+    o.oracle_nlmeans_core(ck.ptr(img), ck.ptr(want), w, h, C.byref(p))
+    written = ~np.isnan(got[..., 0])
+    assert seen.value > 0 and int(written.sum()) > 0
+    bad = written & (got.view(np.uint32) != want.view(np.uint32)).any(axis=-1)
+    assert int(bad.sum()) == 0, "%d of %d written pixels differ; first at %s" % (int(bad.sum()), int(written.sum()), np.argwhere(bad)[:5].tolist())
+    if not ring:
+        assert int(written.sum()) == seen.value * cw * ch
