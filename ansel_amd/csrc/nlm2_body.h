@@ -127,18 +127,32 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int r0 = top - reach, c0 = left - reach;
   const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
 
-  for(int i = tid; i < wh * WP; i += NL2_THREADS)
+  // (four fetches of a thread in flight, then their stores: nlm3_body.h)
+  for(int i0 = tid; i0 < wh * WP; i0 += 4 * NL2_THREADS)
   {
-    const int wy = i / WP, wx = i - wy * WP;
-    const int r = r0 + wy, c = c0 + wx; // r is inside the frame for an interior chunk; the pitch may run past its right edge
-    F4 v;
-    v.x = v.y = v.z = v.w = 0.0f;
-    if(c < W) v = in[(long)r * W + c];
-    f2 xy;
-    xy.x = v.x;
-    xy.y = v.y;
-    XY[i] = xy;
-    Z[i] = v.z;
+    F4 v[4];
+#pragma unroll
+    for(int u = 0; u < 4; u++)
+    {
+      const int i = i0 + u * NL2_THREADS;
+      const int wy = i / WP, wx = i - wy * WP;
+      const int r = r0 + wy, c = c0 + wx; // r is inside the frame for an interior chunk; the pitch may run past its right edge
+      v[u].x = v[u].y = v[u].z = v[u].w = 0.0f;
+      if(i < wh * WP && c < W) v[u] = in[(long)r * W + c];
+    }
+#pragma unroll
+    for(int u = 0; u < 4; u++)
+    {
+      const int i = i0 + u * NL2_THREADS;
+      if(i < wh * WP)
+      {
+        f2 xy;
+        xy.x = v[u].x;
+        xy.y = v[u].y;
+        XY[i] = xy;
+        Z[i] = v[u].z;
+      }
+    }
   }
   for(int i = tid; i < n; i += NL2_THREADS) dsv[i] = patches[i].x * WP + patches[i].y;
 

@@ -220,20 +220,35 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
   const int ww = cw + 2 * reach; // window columns that exist
 
-  for(int i = tid; i < wh * 2 * WPH; i += NL3_THREADS)
+  // four fetches of a thread in flight, then their stores (round 6: the loop had ONE -- `s_waitcnt vmcnt(0)` in front of every store,
+  // seven memory round trips one after the other at the head of every chunk with nothing else running on the CU)
+  for(int i0 = tid; i0 < wh * 2 * WPH; i0 += 4 * NL3_THREADS)
   {
-    const int wy = i / (2 * WPH), rem = i - wy * (2 * WPH);
-    const int par = rem / WPH, h = rem - par * WPH;
-    const int wx = 2 * h + par;
-    const int r = r0 + wy, c = c0 + wx; // r is inside the frame for an interior chunk
-    F4 v;
-    v.x = v.y = v.z = v.w = 0.0f;
-    if(wx < ww && c < W && (!BORDER || (r >= 0 && r < H && c >= 0))) v = in[(long)r * W + c];
-    f2 xy;
-    xy.x = v.x;
-    xy.y = v.y;
-    st2(XY + 2 * i, xy);
-    Z[i] = v.z;
+    F4 v[4];
+#pragma unroll
+    for(int u = 0; u < 4; u++)
+    {
+      const int i = i0 + u * NL3_THREADS;
+      const int wy = i / (2 * WPH), rem = i - wy * (2 * WPH);
+      const int par = rem / WPH, h = rem - par * WPH;
+      const int wx = 2 * h + par;
+      const int r = r0 + wy, c = c0 + wx; // r is inside the frame for an interior chunk
+      v[u].x = v[u].y = v[u].z = v[u].w = 0.0f;
+      if(i < wh * 2 * WPH && wx < ww && c < W && (!BORDER || (r >= 0 && r < H && c >= 0))) v[u] = in[(long)r * W + c];
+    }
+#pragma unroll
+    for(int u = 0; u < 4; u++)
+    {
+      const int i = i0 + u * NL3_THREADS;
+      if(i < wh * 2 * WPH)
+      {
+        f2 xy;
+        xy.x = v[u].x;
+        xy.y = v[u].y;
+        st2(XY + 2 * i, xy);
+        Z[i] = v[u].z;
+      }
+    }
   }
   env.sync();
   // window pixel (wy, wx): index of its words

@@ -87,19 +87,33 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
   const int r0 = top + R0 - reach, c0 = left - reach;
   const float n0 = a.norm[0], n1 = a.norm[1], n2 = a.norm[2];
 
-  for(int i = tid; i < wh * WP; i += NLT_THREADS)
+  // (four fetches of a thread in flight, then their stores: nlm3_body.h)
+  for(int i0 = tid; i0 < wh * WP; i0 += 4 * NLT_THREADS)
   {
-    const int wy = i / WP, wx = i - wy * WP;
-    const int c = c0 + wx;
-    F4 v;
-    v.x = v.y = v.z = v.w = 0.0f;
-    // the pitch may run past the frame's right edge; the rows of an interior chunk's window are inside the frame
-    if(c < W && (!BORDER || (c >= 0 && r0 + wy >= 0 && r0 + wy < H))) v = in[(long)(r0 + wy) * W + c];
-    f2 xy;
-    xy.x = v.x;
-    xy.y = v.y;
-    XY[i] = xy;
-    Z[i] = v.z;
+    F4 v[4];
+#pragma unroll
+    for(int u = 0; u < 4; u++)
+    {
+      const int i = i0 + u * NLT_THREADS;
+      const int wy = i / WP, wx = i - wy * WP;
+      const int c = c0 + wx;
+      v[u].x = v[u].y = v[u].z = v[u].w = 0.0f;
+      // the pitch may run past the frame's right edge; the rows of an interior chunk's window are inside the frame
+      if(i < wh * WP && c < W && (!BORDER || (c >= 0 && r0 + wy >= 0 && r0 + wy < H))) v[u] = in[(long)(r0 + wy) * W + c];
+    }
+#pragma unroll
+    for(int u = 0; u < 4; u++)
+    {
+      const int i = i0 + u * NLT_THREADS;
+      if(i < wh * WP)
+      {
+        f2 xy;
+        xy.x = v[u].x;
+        xy.y = v[u].y;
+        XY[i] = xy;
+        Z[i] = v[u].z;
+      }
+    }
   }
   for(int i = tid; i < n; i += NLT_THREADS)
   {
