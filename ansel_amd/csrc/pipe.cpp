@@ -537,6 +537,7 @@ struct batch_slot_t
 {
   dt_hip_mem_t d_in, d_out;
   hipEvent_t up, done, down;
+  hipEvent_t kstart; // in front of the frame's first kernel (timed with `done` and `down`: the upload policy below)
   bool in_flight;
   // with a writer: the frame's place in the stream, its host buffer, and what became of it (guarded by the batch's mutex)
   long seq;
@@ -552,6 +553,9 @@ struct dt_hip_batch_t
   hipStream_t s_up, s_down;
   std::vector<batch_slot_t> slots;
   int next;
+  // who awaits a frame's upload -- the host (true) or the compute stream: decided from the frames that have completed
+  // (dt_hip_batch_submit())
+  bool host_awaits_upload;
   // the fourth leg: the format's write_image() of frame n on a host thread of its own while frames n + 1 ... are on the
   // device (imageio_core.c:965 runs it after the pipe, serially).  The thread takes the slots in submission order
   dt_hip_batch_writer_t writer;
@@ -600,6 +604,7 @@ dt_hip_batch_t *dt_hip_batch_new(dt_hip_pipe_t *pipe, int depth, size_t in_bytes
   b->in_bytes = in_bytes;
   b->out_bytes = out_bytes;
   b->next = 0;
+  b->host_awaits_upload = false;
   b->writer = nullptr;
   b->writer_user = nullptr;
   b->submitted = 0;
@@ -616,8 +621,7 @@ dt_hip_batch_t *dt_hip_batch_new(dt_hip_pipe_t *pipe, int depth, size_t in_bytes
     sl.d_in = dt_hip_alloc_device_buffer(pipe->devid, in_bytes);
     sl.d_out = dt_hip_alloc_device_buffer(pipe->devid, out_bytes);
     ok = sl.d_in && sl.d_out && hipEventCreateWithFlags(&sl.up, hipEventDisableTiming) == hipSuccess
-         && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess
-         && hipEventCreateWithFlags(&sl.down, hipEventDisableTiming) == hipSuccess;
+         && hipEventCreate(&sl.kstart) == hipSuccess && hipEventCreate(&sl.done) == hipSuccess && hipEventCreate(&sl.down) == hipSuccess;
     b->slots.push_back(sl);
   }
   if(!ok)
@@ -652,6 +656,7 @@ void dt_hip_batch_free(dt_hip_batch_t *b)
     if(sl.d_in) dt_hip_release_mem_object(sl.d_in);
     if(sl.d_out) dt_hip_release_mem_object(sl.d_out);
     if(sl.up) (void)hipEventDestroy(sl.up);
+    if(sl.kstart) (void)hipEventDestroy(sl.kstart);
     if(sl.done) (void)hipEventDestroy(sl.done);
     if(sl.down) (void)hipEventDestroy(sl.down);
   }
@@ -659,6 +664,27 @@ void dt_hip_batch_free(dt_hip_batch_t *b)
   if(b->s_down) (void)hipStreamDestroy(b->s_down);
   delete b;
 }
+
+namespace
+{
+// Who awaits the NEXT frames' uploads.  A frame whose kernels take longer than its two transfers (the full pipe: 67 ms against 3.6 +
+// 15 at 100 MP) wants the HOST to await the upload: with a stream-wait in front of the kernels AND the download's stream-wait behind
+// them, the runtime ran the downloads beside the next frame's kernels at the sum of their times (79 - 83 ms a frame; 71 with the
+// host awaiting -- tools/batch_sdma_probe.py, profiles/r06_batch_probe.txt).  A frame whose transfers are the longer leg (the light
+// pipe: 5.7 ms of kernels) wants everything asynchronous: the host blocked on an upload cannot enqueue the next download (24.8
+// against 16.3 ms a frame).  Measured per completed frame from the slot's events.
+void batch_update_policy(dt_hip_batch_t *b, batch_slot_t &sl)
+{
+  float kernels_ms = 0.0f, down_ms = 0.0f;
+  if(hipEventElapsedTime(&kernels_ms, sl.kstart, sl.done) != hipSuccess || hipEventElapsedTime(&down_ms, sl.done, sl.down) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  const float up_ms = down_ms * (float)((double)b->in_bytes / (double)b->out_bytes);
+  b->host_awaits_upload = kernels_ms > up_ms + down_ms;
+}
+} // namespace
 
 int dt_hip_batch_wait(dt_hip_batch_t *b, int slot)
 {
@@ -671,6 +697,7 @@ int dt_hip_batch_wait(dt_hip_batch_t *b, int slot)
     std::unique_lock<std::mutex> lk(b->mtx);
     b->cv_done.wait(lk, [&] { return sl.written; });
     sl.in_flight = false;
+    if(sl.write_err == DT_HIP_SUCCESS) batch_update_policy(b, sl);
     if(sl.write_err == DT_HIP_WRITER_FAILED) set_last_error("dt_hip_batch_wait: the writer refused frame %ld", sl.seq);
     else if(sl.write_err != DT_HIP_SUCCESS)
       set_last_error("dt_hip_batch_wait: the download of frame %ld did not complete (hipEventSynchronize on the writer thread)", sl.seq);
@@ -678,6 +705,7 @@ int dt_hip_batch_wait(dt_hip_batch_t *b, int slot)
   }
   ANSEL_HIP_CHECK(hipEventSynchronize(sl.down));
   sl.in_flight = false;
+  batch_update_policy(b, sl);
   return DT_HIP_SUCCESS;
 }
 
@@ -737,7 +765,9 @@ int dt_hip_batch_submit(dt_hip_batch_t *b, const void *host_in, void *host_out)
   hipStream_t compute = stream_of(b->pipe->devid);
   ANSEL_HIP_CHECK(hipMemcpyAsync(sl.d_in, host_in, b->in_bytes, hipMemcpyHostToDevice, b->s_up));
   ANSEL_HIP_CHECK(hipEventRecord(sl.up, b->s_up));
-  ANSEL_HIP_CHECK(hipStreamWaitEvent(compute, sl.up, 0));
+  if(b->host_awaits_upload) ANSEL_HIP_CHECK(hipEventSynchronize(sl.up)); // (batch_update_policy(): which, and why)
+  else ANSEL_HIP_CHECK(hipStreamWaitEvent(compute, sl.up, 0));
+  ANSEL_HIP_CHECK(hipEventRecord(sl.kstart, compute));
   const int err = dt_hip_pipe_process(b->pipe, sl.d_in, sl.d_out);
   if(err != DT_HIP_SUCCESS) return err;
   ANSEL_HIP_CHECK(hipEventRecord(sl.done, compute));
