@@ -363,14 +363,16 @@ def test_tall_chunks_border_ring_on_the_host_equals_the_oracle(host_kernel, orac
 #      defaults are patch radius 1, search radius 7, central pixel weight 0.1) on the third version's schedule and on the fused one:
 #      nlm3_body.h P / CENTER.  Interior chunks and the outermost ring (BORDER bodies).
 # (width, height, patch radius, search radius, center_weight (< 0: the plain weight), fused, ring too, expected chunk)
+# (the host harness is 1 024 OS threads on a barrier: search radii kept small; the 225 offsets of the defaults run on the device,
+#  tests/test_gpu_nlmeans.py)
 CASES_R6 = [
-    (260, 168, 1, 7, -1.0, False, False, (72, 56)),   # patch radius 1, the 100 MP frame's chunk, 225 offsets: nine chains of <= 7 terms
+    (260, 168, 1, 5, -1.0, False, False, (72, 56)),   # patch radius 1, the 100 MP frame's chunk: nine chains of <= 7 terms, rows of 11 offsets
     (260, 168, 1, 5, 0.1, False, False, (72, 56)),    # ... with the centre term: denoise (profiled)'s defaults but for the search radius
     (170, 150, 1, 3, 0.1, False, True, (64, 51)),     # 64 x 51 chunks, the ring with the centre term
-    (260, 192, 1, 5, -1.0, True, False, (72, 64)),    # the fused schedule (the 45 / 60 MP frames' 64-row chunks), patch radius 1
-    (260, 192, 1, 3, 0.4, True, True, (72, 64)),      # ... with the centre term and the ring
-    (260, 168, 2, 5, 1.0, False, False, (72, 56)),    # patch radius 2 with the centre as heavy as the patch
-    (181, 171, 2, 3, 0.0, True, True, (72, 57)),      # fused, radius 2, central weight 0 (the division by 1, the floor at -2), ring
+    (260, 192, 1, 4, -1.0, True, False, (72, 64)),    # the fused schedule (the 45 / 60 MP frames' 64-row chunks), patch radius 1
+    (170, 128, 1, 2, 0.4, True, True, (64, 64)),      # ... with the centre term, every chunk in the ring
+    (260, 168, 2, 4, 1.0, False, False, (72, 56)),    # patch radius 2 with the centre as heavy as the patch
+    (181, 171, 2, 2, 0.0, True, True, (72, 57)),      # fused, radius 2, central weight 0 (the division by 1, the floor at -2), ring
     (151, 140, 1, 3, -1.0, False, True, (64, 51)),    # plain weight, radius 1, ring with an odd last chunk width and a low last row
 ]
 
@@ -414,9 +416,9 @@ def test_patch_radius_one_and_the_centre_term_on_the_third_version(host_kernel, 
 # ... and on the tall chunk grids (65 - 69 rows: the 24 MP frame's 69): the fused head + nlm_tail_body.h with P / CENTER
 # (width, height, patch radius, search radius, center_weight, ring too, expected chunk)
 CASES_R6_TALL = [
-    (260, 207, 1, 5, 0.1, False, (72, 69)),    # denoise (profiled)'s defaults (but for the search radius) on the 24 MP frame's chunk
-    (260, 207, 1, 3, -1.0, True, (72, 69)),    # patch radius 1, plain weight, ring
-    (170, 201, 2, 3, 0.5, True, (64, 67)),     # patch radius 2 with the centre term, 67-row chunks, ring
+    (260, 207, 1, 4, 0.1, False, (72, 69)),    # denoise (profiled)'s defaults (but for the search radius) on the 24 MP frame's chunk
+    (170, 138, 1, 2, -1.0, True, (64, 69)),    # patch radius 1, plain weight, every chunk in the ring
+    (170, 201, 2, 2, 0.5, True, (64, 67)),     # patch radius 2 with the centre term, 67-row chunks, ring
     (250, 195, 1, 3, 0.0, False, (68, 65)),    # ONE tail row, central weight 0
 ]
 
