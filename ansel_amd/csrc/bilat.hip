@@ -9,9 +9,11 @@
 //         The device GATHERS in that order: one thread per grid node (x, y) walks the ~(2 sigma_s)^2
 //         pixels that can reach the node, row by row, and adds into the node's z column kept in LDS.
 //         No atomics, no dependence on launch geometry, bit-identical to the one-thread reference.
-// blur    three in-place line recurrences (x, y: 1-4-6-4-1; z: derivative), one thread per line.
-// slice   trilinear lookup per pixel, L += -detail * sigma_r * 0.04 * grid.
+// blur    x, y: 1-4-6-4-1; z: derivative -- as out-of-place 5-tap stencils, one launch (bilat_blur_yz).
+// slice   trilinear lookup per pixel, L += -detail * sigma_r * 0.04 * grid (px_bilat.h: also the first stage of a fused run behind the module).
 #include "hip_common.h"
+#include "pipe_fused.h"
+#include "px_bilat.h"
 
 #include <math.h>
 
@@ -24,26 +26,13 @@ namespace
 #define MAX_RES_R 50   // DT_COMMON_BILATERAL_MAX_RES_R
 #define SPLAT_THREADS 64
 
-struct grid_t
-{
-  int size_x, size_y, size_z, width, height;
-  float sigma_s, sigma_r;
-};
+typedef ansel::bilat_grid_t grid_t;
 
-__host__ __device__ __forceinline__ float clampf(const float v, const float lo, const float hi)
-{
-  return v > lo ? (v < hi ? v : hi) : lo; // CLAMPS(), src/math/math.h
-}
+__host__ __device__ __forceinline__ float clampf(const float v, const float lo, const float hi) { return bilat_clampf(v, lo, hi); }
 inline int clampi_h(const int v, const int lo, const int hi) { return v > lo ? (v < hi ? v : hi) : lo; }
 
-// image_to_grid() / image_to_relgrid(), bilateral.c:127-155: cell index and fraction on one axis
-__device__ __forceinline__ int axis(const float v, const float sigma, const int size, float &frac)
-{
-  const float x = clampf(v / sigma, 0.0f, (float)(size - 1));
-  const int xi = (int)x < size - 2 ? (int)x : size - 2;
-  frac = x - xi;
-  return xi;
-}
+// image_to_grid() / image_to_relgrid(), bilateral.c:127-155: cell index and fraction on one axis (px_bilat.h)
+__device__ __forceinline__ int axis(const float v, const float sigma, const int size, float &frac) { return bilat_axis(v, sigma, size, frac); }
 
 #ifdef ANSEL_HIP_MEASURING // the first gather: A/B timing only (ANSEL_HIP_BILAT_SPLAT_V1); bilat_splat2 below is the product's
 // dt_bilateral_splat(), bilateral.c:183-256, gathered per grid node
@@ -300,28 +289,13 @@ __global__ __launch_bounds__(256) void bilat_slice(const float4 *__restrict__ in
                                                    const float *__restrict__ buf, const grid_t b, const float norm,
                                                    const int row0, const int rows)
 {
-  const int ox = b.size_z, oy = b.size_x * b.size_z, oz = 1;
   const size_t n = (size_t)b.width * rows;
   for(size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x)
   {
     const int jl = (int)(p / b.width), i = (int)(p - (size_t)jl * b.width);
     const int j = row0 + jl;
     const float4 px = in[p];
-    float xf, yf, zf;
-    const float L = px.x;
-    const int xi = axis((float)i, b.sigma_s, b.size_x, xf);
-    const int yi = axis((float)j, b.sigma_s, b.size_y, yf);
-    const int zi = axis(L, b.sigma_r, b.size_z, zf);
-    const size_t gi = ((size_t)xi + (size_t)yi * b.size_x) * b.size_z + zi;
-    const float Lout = fmaxf(0.0f, L
-                       + norm * (buf[gi] * (1.0f - xf) * (1.0f - yf) * (1.0f - zf)
-                                 + buf[gi + ox] * (xf) * (1.0f - yf) * (1.0f - zf)
-                                 + buf[gi + oy] * (1.0f - xf) * (yf) * (1.0f - zf)
-                                 + buf[gi + ox + oy] * (xf) * (yf) * (1.0f - zf)
-                                 + buf[gi + oz] * (1.0f - xf) * (1.0f - yf) * (zf)
-                                 + buf[gi + ox + oz] * (xf) * (1.0f - yf) * (zf)
-                                 + buf[gi + oy + oz] * (1.0f - xf) * (yf) * (zf)
-                                 + buf[gi + ox + oy + oz] * (xf) * (yf) * (zf)));
+    const float Lout = bilat_slice_lightness(px.x, i, j, buf, b, norm);
     nt_store(out + p, make_float4(Lout, px.y, px.z, px.w));
   }
 }
@@ -424,32 +398,40 @@ int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_ro
 // fused launch leaves it in a second grid the slice reads (buf keeps the splat); a grid of more than BLUR_FUSED_CELLS cells takes
 // its x-pass in a launch of its own (second grid), and the y- and z-passes bring it back into buf
 constexpr size_t BLUR_FUSED_CELLS = (size_t)1 << 22;
-int bilat_blur_and_slice(int devid, const grid_t &b, float *buf, const dt_hip_bilat_data_t *d, const float4 *in_rows,
-                         float4 *out_rows, int row0, int rows)
+// the blur: *blurred = the grid that holds it (buf or *second), *second = the grid to release once nothing reads `blurred` any more
+int bilat_blur(int devid, const grid_t &b, float *buf, const float **blurred, float **second_out)
 {
   hipStream_t s = stream_of(devid);
   const size_t cells = (size_t)b.size_x * b.size_y * b.size_z;
   float *const second = (float *)dt_hip_alloc_device_buffer(devid, cells * sizeof(float));
   if(!second) return DT_HIP_SYSMEM_ALLOCATION;
-  const float *blurred;
+  *second_out = second;
+  launch_scope ls(devid, "bilat_blur");
+  // z-lines per workgroup: ~2048 cells (eight per lane), whole lines
+  const int npw = b.size_z >= 2048 ? 1 : 2048 / b.size_z;
+  const dim3 grid((b.size_x + npw - 1) / npw, b.size_y);
+  const size_t lds = (size_t)npw * b.size_z * sizeof(float);
+  if(cells <= BLUR_FUSED_CELLS && !dispatch_override(DISPATCH_BILAT_BLUR_SPLIT))
   {
-    launch_scope ls(devid, "bilat_blur");
-    // z-lines per workgroup: ~2048 cells (eight per lane), whole lines
-    const int npw = b.size_z >= 2048 ? 1 : 2048 / b.size_z;
-    const dim3 grid((b.size_x + npw - 1) / npw, b.size_y);
-    const size_t lds = (size_t)npw * b.size_z * sizeof(float);
-    if(cells <= BLUR_FUSED_CELLS && !dispatch_override(DISPATCH_BILAT_BLUR_SPLIT))
-    {
-      bilat_blur_yz<true><<<grid, 256, lds, s>>>(buf, second, b.size_x, b.size_y, b.size_z, npw);
-      blurred = second;
-    }
-    else
-    {
-      bilat_blur_x<<<stream_grid(cells, 256), 256, 0, s>>>(buf, second, b.size_x, b.size_z, cells);
-      bilat_blur_yz<false><<<grid, 256, lds, s>>>(second, buf, b.size_x, b.size_y, b.size_z, npw);
-      blurred = buf;
-    }
+    bilat_blur_yz<true><<<grid, 256, lds, s>>>(buf, second, b.size_x, b.size_y, b.size_z, npw);
+    *blurred = second;
   }
+  else
+  {
+    bilat_blur_x<<<stream_grid(cells, 256), 256, 0, s>>>(buf, second, b.size_x, b.size_z, cells);
+    bilat_blur_yz<false><<<grid, 256, lds, s>>>(second, buf, b.size_x, b.size_y, b.size_z, npw);
+    *blurred = buf;
+  }
+  return DT_HIP_SUCCESS;
+}
+int bilat_blur_and_slice(int devid, const grid_t &b, float *buf, const dt_hip_bilat_data_t *d, const float4 *in_rows,
+                         float4 *out_rows, int row0, int rows)
+{
+  hipStream_t s = stream_of(devid);
+  const float *blurred = nullptr;
+  float *second = nullptr;
+  const int berr = bilat_blur(devid, b, buf, &blurred, &second);
+  if(berr != DT_HIP_SUCCESS) return berr;
   {
     const float norm = -d->detail * b.sigma_r * 0.04f;
     launch_scope ls(devid, "bilat_slice");
@@ -501,6 +483,41 @@ int bilat_band_finish(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat
   const int gerr = bilat_grid_of(piece, d, b);
   if(gerr != DT_HIP_SUCCESS) return gerr;
   return bilat_blur_and_slice(devid, b, (float *)grid, d, (const float4 *)in_rows, (float4 *)out_rows, row0, rows);
+}
+} // namespace ansel
+
+namespace ansel
+{
+// The module in bilateral-grid mode with the fused RGBA run `chain` behind it (pipe.cpp): splat and blur as the module runs them, the slice
+// as the first stage of the run's kernel -- the module's output plane is neither written nor read.  DT_HIP_INVALID_ARG: not this
+// mode (the caller runs the two one after the other).
+int bilat_process_chain(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                        const rgb_group_t *chain)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || !chain || piece->channels != 4) return DT_HIP_INVALID_ARG;
+  if(d->mode != DT_HIP_BILAT_BILATERAL) return DT_HIP_INVALID_ARG;
+  const int width = piece->roi_in.width, height = piece->roi_in.height;
+  if(width <= 0 || height <= 0 || chain->width != width || chain->height != height) return DT_HIP_INVALID_ARG;
+  grid_t b;
+  if(bilat_grid_of(piece, d, b) != DT_HIP_SUCCESS) return DT_HIP_INVALID_ARG;
+  const size_t cells = (size_t)b.size_x * b.size_y * b.size_z;
+  float *buf = (float *)dt_hip_alloc_device_buffer(devid, cells * sizeof(float));
+  if(!buf) return DT_HIP_SYSMEM_ALLOCATION;
+  int err = bilat_splat_rows(devid, b, buf, (const float4 *)dev_in, 0, height, 0);
+  const float *blurred = nullptr;
+  float *second = nullptr;
+  if(err == DT_HIP_SUCCESS) err = bilat_blur(devid, b, buf, &blurred, &second);
+  if(err == DT_HIP_SUCCESS)
+  {
+    bilat_slice_args sl;
+    sl.b = b;
+    sl.grid = blurred;
+    sl.norm = -d->detail * b.sigma_r * 0.04f;
+    err = rgb_group_launch(devid, *chain, dev_in, dev_out, &sl);
+  }
+  if(second) dt_hip_release_mem_object(second); // stream-ordered
+  dt_hip_release_mem_object(buf);
+  return err;
 }
 } // namespace ansel
 

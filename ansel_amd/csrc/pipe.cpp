@@ -400,6 +400,36 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
         }
       }
     }
+    // local contrast (bilateral grid) followed by a pointwise run: the module's slice -- pointwise, given the blurred grid -- becomes
+    // the run's first stage (bilat.hip bilat_process_chain()): the module's output plane is never written
+    if(pipe->fusion && g.kind == group_t::SINGLE && pipe->nodes[g.first].op == OP_BILAT && gi + 1 < ng
+       && pipe->groups[gi + 1].kind == group_t::RGB && !is_blend(gi + 1))
+    {
+      const group_t &gn = pipe->groups[gi + 1];
+      const node_t &tail = pipe->nodes[gn.first + gn.count - 1];
+      const bool final_pair = gi + 2 == ng || (is_blend(gi + 2) && gi + 3 == ng);
+      // (a blend behind the run wants the run's input -- the module's output -- as a buffer: such runs are not fused)
+      dt_hip_mem_t fout = is_blend(gi + 2) ? NULL : (final_pair ? dev_out : dt_hip_alloc_device_buffer(devid, out_bytes(tail)));
+      if(fout)
+      {
+        const node_t &bl = pipe->nodes[g.first];
+        const int ferr = bilat_process_chain(devid, &bl.piece, bl.as<dt_hip_bilat_data_t>(), cur, fout, &gn.rgb);
+        if(ferr == DT_HIP_SUCCESS)
+        {
+          if(cur_owned) dt_hip_release_mem_object(cur);
+          cur = fout;
+          cur_owned = !final_pair;
+          gi++;
+          continue;
+        }
+        if(!final_pair) dt_hip_release_mem_object(fout);
+        if(ferr != DT_HIP_INVALID_ARG)
+        {
+          if(cur_owned) dt_hip_release_mem_object(cur);
+          return ferr;
+        }
+      }
+    }
     // diffuse or sharpen followed by the RGB -> Lab glue: the conversion is the tail of the module's last kernel
     if(pipe->fusion && g.kind == group_t::SINGLE && pipe->nodes[g.first].op == OP_DIFFUSE && gi + 1 < ng
        && pipe->groups[gi + 1].kind == group_t::SINGLE && pipe->nodes[pipe->groups[gi + 1].first].op == OP_RGB_TO_LAB

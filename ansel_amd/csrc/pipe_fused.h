@@ -38,7 +38,9 @@ struct rgb_group_t
   int pre_lab, post_lab;
   dt_hip_lab_data_t lab_pre, lab_post;
 };
-int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out);
+struct bilat_slice_args;
+// pre_slice (px_bilat.h): local contrast's bilateral-grid slice as the run's first stage (bilat.hip bilat_process_chain())
+int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out, const bilat_slice_args *pre_slice = nullptr);
 // the kernel arguments of a run (rgb_chain_kernel.h): cm_kind = the chromatic adaptation its kernel is instantiated for
 // (CM_NONE without color calibration), fm = the filmic mode (FM_NONE without filmic)
 struct chain_args;
@@ -47,5 +49,10 @@ int rgb_group_fill_args(const rgb_group_t &g, chain_args &a, int &cm_kind, int &
 // kernel; DT_HIP_INVALID_ARG when the combination has no fused kernel (the caller then runs the two one after the other)
 int denoiseprofile_process_chain(int devid, const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
                                  dt_hip_mem_t dev_in, dt_hip_mem_t dev_out, const rgb_group_t *chain);
+
+// bilat.hip: local contrast in bilateral-grid mode with the run `chain` behind it -- the slice is the run's first stage;
+// DT_HIP_INVALID_ARG when the module is in another mode
+int bilat_process_chain(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                        const rgb_group_t *chain);
 
 } // namespace ansel

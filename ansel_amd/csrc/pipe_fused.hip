@@ -270,7 +270,7 @@ int rgb_group_fill_args(const rgb_group_t &g, chain_args &a, int &cm_kind, int &
   return DT_HIP_SUCCESS;
 }
 
-int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out)
+int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out, const bilat_slice_args *pre_slice)
 {
   if(!valid_device(devid) || !dev_in || !dev_out) return DT_HIP_INVALID_ARG;
   const size_t np = (size_t)g.width * g.height;
@@ -279,6 +279,11 @@ int rgb_group_launch(int devid, const rgb_group_t &g, dt_hip_mem_t dev_in, dt_hi
   int cm_kind, fm;
   const int ferr = rgb_group_fill_args(g, a, cm_kind, fm);
   if(ferr != DT_HIP_SUCCESS) return ferr;
+  if(pre_slice)
+  {
+    a.pre_bilat = 1;
+    a.bilat = *pre_slice;
+  }
   hipStream_t s = stream_of(devid);
   const unsigned grid = pixel_grid(np); // one pixel per thread, see rgb_chain_kernel.h
   const float4 *in = (const float4 *)dev_in;

@@ -7,6 +7,7 @@
 #include "px_colorspaces.h"
 #include "px_channelmixerrgb.h"
 #include "px_filmicrgb.h"
+#include "px_bilat.h"
 
 namespace ansel
 {
@@ -21,6 +22,9 @@ struct chain_args
   conv_args colorin, colorout;
   cm_args cm;
   fargs filmic;
+  // local contrast's slice (bilateral-grid mode) in front of everything: the run then reads the MODULE's input (px_bilat.h)
+  int pre_bilat;
+  bilat_slice_args bilat;
 };
 
 // offset of the by-value chain_args in the kernarg segment of rgb_chain(): after two pointers and a size_t
@@ -43,6 +47,11 @@ __global__ __launch_bounds__(256) void rgb_chain(const float4 *__restrict__ in, 
   if(k < npixels)
   {
     float4 v = in[k];
+    if(a.pre_bilat)
+    {
+      const int j = (int)(k / (size_t)a.bilat.b.width), i = (int)(k - (size_t)j * a.bilat.b.width);
+      v.x = bilat_slice_lightness(v.x, i, j, a.bilat.grid, a.bilat.b, a.bilat.norm);
+    }
     if(a.pre_lab) v = px_lab_to_rgb(v, a.lab_pre);
     if(a.has_exposure)
     {

@@ -346,7 +346,7 @@ TAG_KERNELS = {
     "nlm_chunks": ("nlm_chunks_v3", "nlm_chunks_v4", "nlm_chunks_v2", "nlm_chunks_pipelined", "nlm_chunks"),
     "diffuse_pde": ("diffuse_pde_strip", "diffuse_pde"), "diffuse_decompose": ("bspline_decompose_strip", "bspline_decompose"),
     "dn_decompose": ("dn_decompose_strip", "dn_decompose"), "rgb_chain_u16": ("rgb_chain",), "rgb_chain_rows16": ("rgb_chain",),
-    "bilat_blur": ("bilat_blur_line", "bilat_blur_line_z"), "bilat_splat": ("bilat_splat2", "bilat_zcells", "bilat_splat", "bilat_lightness"),
+    "bilat_blur": ("bilat_blur_yz", "bilat_blur_x", "bilat_blur_line", "bilat_blur_line_z"), "bilat_splat": ("bilat_splat2", "bilat_zcells", "bilat_splat", "bilat_lightness"),
     "dn_band_threshold": ("dn_band_sums", "dn_band_threshold"),
 }
 
@@ -971,6 +971,9 @@ def main():
                 # carries rgb_to_lab; the run behind the Lab section carries lab_to_rgb > filmic > colorout > u16
                 tag_bpp["dn_finish_chain"] = 48 + 32 + 3 * 32
                 tag_bpp["rgb_chain_u16"] = 32 + 2 * 32 + 24
+                # round 6: local contrast's slice (32 B/px as a pass of its own) is the first stage of that run when the module sits in front of it
+                if "bilat" in ops and ops.index("bilat") + 1 < len(ops) and ops[ops.index("bilat") + 1] == "lab_to_rgb":
+                    tag_bpp["rgb_chain_u16"] += 32
         pmc, pmc_src = pmc_table(args)
         sclk, sclk_src = sclk_table(args)
         mpix_mine = my_rows * width / 1e6
