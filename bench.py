@@ -290,9 +290,27 @@ def verify_output(out16, raw_host, width, height, with_filmic, which):
 
 
 PMC_SUMMARIES = {  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of THIS configuration, newest first
-    "full": ("r05_dma_pmc_hbm_bytes_100MP_full.json", "r05_pmc_hbm_bytes_100MP_full.json", "r04_pmc_hbm_bytes_100MP_full.json", "r03_pmc_hbm_bytes_100MP_full.json"),
+    "full": ("r06_pmc_hbm_bytes_100MP_full.json", "r05_dma_pmc_hbm_bytes_100MP_full.json", "r05_pmc_hbm_bytes_100MP_full.json", "r04_pmc_hbm_bytes_100MP_full.json", "r03_pmc_hbm_bytes_100MP_full.json"),
     "light": ("r03_pmc_hbm_bytes_100MP_light_fused.json", "r02_pmc_hbm_bytes_100MP_light_fused.json"),
 }
+
+
+def _sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def _table_sha16(src):
+    """the `lib_sha16` a committed counter summary records (tools/profile_round.sh's run), None for the older ones"""
+    if not src:
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", src.split("profiles/")[-1]))).get("lib_sha16")
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_table(args):
@@ -322,7 +340,7 @@ def sclk_table(args):
     if args.size != "100MP" or args.no_fusion or args.mode != "batch" or args.pipe != "full":
         return {}, None
     kernels = None
-    for name in ("r05_dma_sclk_per_kernel_100MP_full.json", "r05_sclk_per_kernel_100MP_full.json"):  # newest first
+    for name in ("r06_sclk_per_kernel_100MP_full.json", "r05_dma_sclk_per_kernel_100MP_full.json", "r05_sclk_per_kernel_100MP_full.json"):  # newest first
         try:
             kernels = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
             break
@@ -371,7 +389,7 @@ KERNEL_BOUND = {"raw_chain": "hbm", "rgb_chain": "valu", "rgb_chain_u16": "valu"
                 "lab_to_rgb": "hbm"}
 
 
-def fp32_valu_figure(tag, dom, pixels):
+def fp32_valu_figure(tag, dom, pixels, nodes=None):
     """the dominant launch against the binary32 vector peak, for the kernel SURVEY 8(d) says is not an HBM kernel: non-local means'
     algorithmic flops -- (2 K + 1)^2 offsets x ~25 flop per pixel and offset at K = 7, the module's default on a full-resolution
     export: 5.6 kflop per pixel -- over its average duration, against the 157.3 TFLOP/s of MI355X_MICROARCH.md (256 CUs x 4 SIMDs
@@ -380,15 +398,22 @@ def fp32_valu_figure(tag, dom, pixels):
     in issue slots."""
     if tag != "nlm_chunks" or not dom.get("ms_avg"):
         return None
-    flops = 225 * 25.0 * pixels
+    # nlmeans' search radius: K = ceil(7 x scale) (src/iop/nlmeans.c:425), the scale of the pipe's node
+    import math
+    k = 7
+    for n in nodes or ():
+        if n.op == "nlmeans":
+            k = int(math.ceil(7.0 * min(float(n.piece.roi_in.scale), 2.0)))
+    offsets = (2 * k + 1) ** 2
+    flops = offsets * 25.0 * pixels
     ach = flops / (dom["ms_avg"] * 1e-3) / 1e12
-    return {"achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
-            "flops_per_px": 5625, "ceiling_for_a_stream_without_fma": 0.5}
+    return {"achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "offsets": offsets,
+            "flops_per_px": int(offsets * 25), "ceiling_for_a_stream_without_fma": 0.5}
 
 
 def valu_floor_ms(tag, mpix, table=None):
     if table is None:
-        table = next((t for t in ("r05_dma_isa_mix.json", "r05_isa_mix.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r04_isa_mix.json")
+        table = next((t for t in ("r06_isa_mix.json", "r05_dma_isa_mix.json", "r05_isa_mix.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r04_isa_mix.json")
     return _valu_floor_ms(tag, mpix, table)
 
 
@@ -976,6 +1001,10 @@ def main():
                     tag_bpp["rgb_chain_u16"] += 32
         pmc, pmc_src = pmc_table(args)
         sclk, sclk_src = sclk_table(args)
+        # the committed counter tables were taken on ONE build of the library: say whether it is the one running (round 5's advisor:
+        # a kernel whose traffic changes without a re-profile made the figures derived from them stale without warning)
+        lib_sha16 = _sha16(os.path.join(ROOT, "ansel_amd", "libansel_hip.so"))
+        tables_sha16 = _table_sha16(pmc_src)
         mpix_mine = my_rows * width / 1e6
         ms_per_step = elapsed / args.steps * 1e3
         pipe_bpp = pipe.algorithmic_bytes_per_pixel(nodes)
@@ -1056,6 +1085,10 @@ def main():
                 "kernels_ms_per_step": {k: round(v["ms_avg"] * v["launches"] / args.steps, 3) for k, v in sorted(kernels.items())},
                 "kernel_bounds": per_kernel,
                 "pmc_source": pmc_src,
+                "lib_sha16": lib_sha16,
+                # True: traffic / hbm_frac / sclk_mhz / valu_frac_at_sustained_clock / pipe_frac_counter_bytes describe THIS build;
+                # False: a build since the tables were taken (re-run tools/profile_round.sh); None: tables without a recorded build
+                "counter_tables_match_this_build": None if tables_sha16 is None else tables_sha16 == lib_sha16,
                 "light_pipe": light,
                 "default_diffuse": default_diffuse,
                 "full_pipe_24MP": full24,
@@ -1092,7 +1125,7 @@ def main():
                 "sclk_mhz": per_kernel.get(dominant, {}).get("sclk_mhz"),
                 "sclk_source": sclk_src,
                 # "for NLM report achieved fraction of fp32 VALU peak and of HBM, and say which binds"
-                "fp32_valu": fp32_valu_figure(dominant, dom, my_rows * width),
+                "fp32_valu": fp32_valu_figure(dominant, dom, my_rows * width, nodes),
                 # the whole step, both ways: sum of ALGORITHMIC bytes / step time / peak (= config.pipe_hbm_frac: the metric's figure;
                 # it credits the pipe with bytes that fusion never moves) and the bytes the PMC counters saw the step MOVE / step time / peak
                 "pipe_frac": round(pipe_bpp * my_rows * width / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
