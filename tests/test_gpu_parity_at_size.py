@@ -192,3 +192,58 @@ def test_metric_full_pipe_100MP_whole_and_in_8_row_bands_equals_the_oracle():
     """the unsplit device run (bench.py's timed workload), the 8-band lockstep run (config 4) and the oracle: three
     times the same 814 MB"""
     _case("denoise", "100MP", bands=8, host_gib=80)
+
+
+# ---- round 6: denoise (profiled) in its non-local-means mode at the module's defaults (patch radius 1, 225 offsets, the weight with the
+#      centre pixel's term) at frame sizes -- the kernels of nlm3_body.h P / CENTER: 6000 x 4000 has 72 x 69 chunks (the fused head +
+#      nlm_tail), 11648 x 8736 has 72 x 56 (the third version: 25 k workgroups), 8256 x 5504 has 72 x 64 (the fused variant)
+@pytest.mark.parametrize("w,h", [(6000, 4000), (8256, 5504), (11648, 8736)])
+def test_denoiseprofile_nlmeans_mode_at_frame_size(w, h):
+    from ansel_amd import abi
+    _need_host_memory(int(3 * w * h * 16 / 2.0 ** 30) + 8)
+    _all_cores()
+    try:
+        rng = np.random.default_rng(5)
+        tile = synth.rgba_image(1024, 1024, seed=9, lo=0.0, hi=0.9)
+        tile[..., :3] += rng.normal(0.0, 0.01, size=(1024, 1024, 3)).astype(np.float32) * np.sqrt(np.maximum(tile[..., :3], 0.01))
+        img = np.ascontiguousarray(np.tile(tile, (-(-h // 1024), -(-w // 1024), 1))[:h, :w].astype(np.float32))
+        # break the tile's period: a gain per 2048-block, so that no two chunks see the same neighbourhood
+        gy, gx = np.arange(h)[:, None] // 2048, np.arange(w)[None, :] // 2048
+        img[..., :3] *= (0.7 + 0.05 * ((gy * 7 + gx * 3) % 7)).astype(np.float32)[..., None]
+        d = params.denoiseprofile(mode=abi.DT_HIP_DENOISEPROFILE_NLMEANS)
+        piece = abi.Piece.make(w, h, processed_maximum=synth.WB_COEFFS)
+        got = hc.run_hip("dt_hip_iop_denoiseprofile_process", piece, d, img, img.shape)
+        want = np.zeros_like(img)
+        t0 = time.time()
+        assert ck.call(ck.oracle(), "oracle_denoiseprofile", piece, d, img, want) == 0
+        bad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        assert bad == 0, "%d of %d words differ (oracle: %.0f s)" % (bad, got.size, time.time() - t0)
+    finally:
+        _restore_cores()
+
+
+@pytest.mark.parametrize("w,h", [(6000, 4000), (11648, 8736)])
+def test_nlmeans_patch_radius_one_at_frame_size(w, h):
+    """denoise (non-local means) with patch radius 1 (nine A1 chains) on the 24 MP frame's 69-row chunks and the 100 MP frame's 56-row ones"""
+    from ansel_amd import abi
+    _need_host_memory(int(3 * w * h * 16 / 2.0 ** 30) + 8)
+    _all_cores()
+    try:
+        rng = np.random.default_rng(7)
+        rgb = synth.rgba_image(1024, 1024, seed=11, lo=0.0, hi=1.0)
+        lab = np.zeros((1024, 1024, 4), np.float32)
+        lab[..., 0] = 100.0 * rgb[..., 1] + rng.normal(0, 1.5, (1024, 1024))
+        lab[..., 1] = 80.0 * (rgb[..., 0] - rgb[..., 1]) + rng.normal(0, 2.0, (1024, 1024))
+        lab[..., 2] = 80.0 * (rgb[..., 1] - rgb[..., 2]) + rng.normal(0, 2.0, (1024, 1024))
+        img = np.ascontiguousarray(np.tile(lab, (-(-h // 1024), -(-w // 1024), 1))[:h, :w].astype(np.float32))
+        gy, gx = np.arange(h)[:, None] // 2048, np.arange(w)[None, :] // 2048
+        img[..., 0] *= (0.8 + 0.04 * ((gy * 5 + gx * 3) % 6)).astype(np.float32)
+        d = abi.NlmeansData(1.0, 35.0, 0.5, 1.0)
+        piece = abi.Piece.make(w, h)
+        got = hc.run_hip("dt_hip_iop_nlmeans_process", piece, d, img, img.shape)
+        want = np.zeros_like(img)
+        assert ck.call(ck.oracle(), "oracle_nlmeans", piece, d, img, want) == 0
+        bad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        assert bad == 0, "%d of %d words differ" % (bad, got.size)
+    finally:
+        _restore_cores()
