@@ -1271,13 +1271,15 @@ int dt_hip_iop_nlmeans_process(int devid, const dt_hip_piece_t *piece, const dt_
 }
 
 // tiling_callback(), src/iop/nlmeans.c:400-414 (factor: in + out + tmp + the per-thread column sums, NUM_BUCKETS 4);
-// on the device the sums live in LDS: in + out
+// on the device the sums live in LDS: in + out -- and, on a chunk grid of 65 - 69 rows (the 24 / 42 / 150 MP frames), the head's
+// export for the tail kernel: one 80-float row of column sums per chunk and offset, at most 225 x 320 B per 72 x 65 pixels = 0.96 of
+// a float4 plane (nlmeans_core_launch(): `seeds`; the module falls back to a body without it when the allocation fails)
 void dt_hip_iop_nlmeans_tiling(const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d, dt_hip_tiling_t *tiling)
 {
   const float scale = (float)fmin(piece->roi_in.scale, 2.0f);
   memset(tiling, 0, sizeof(*tiling));
   tiling->factor = 2.0f + 1.0f + 0.25f * 4;
-  tiling->factor_cl = 2.0f;
+  tiling->factor_cl = 2.0f + (slice_height(piece->roi_in.height) > NLT_HEAD_ROWS ? 0.96f : 0.0f);
   tiling->maxbuf = tiling->maxbuf_cl = 1.0f;
   tiling->overlap = (unsigned)((int)ceilf(d->radius * scale) + (int)ceilf(7 * scale));
   tiling->xalign = tiling->yalign = 1;

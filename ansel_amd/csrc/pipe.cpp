@@ -703,7 +703,7 @@ namespace
 // host awaiting -- tools/batch_sdma_probe.py, profiles/r06_batch_probe.txt).  A frame whose transfers are the longer leg (the light
 // pipe: 5.7 ms of kernels) wants everything asynchronous: the host blocked on an upload cannot enqueue the next download (24.8
 // against 16.3 ms a frame).  Measured per completed frame from the slot's events.
-void batch_update_policy(dt_hip_batch_t *b, batch_slot_t &sl)
+static void batch_update_policy(dt_hip_batch_t *b, batch_slot_t &sl)
 {
   float kernels_ms = 0.0f, down_ms = 0.0f;
   if(hipEventElapsedTime(&kernels_ms, sl.kstart, sl.done) != hipSuccess || hipEventElapsedTime(&down_ms, sl.done, sl.down) != hipSuccess)

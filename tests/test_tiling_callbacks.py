@@ -30,6 +30,9 @@ def test_nlmeans_tiling(scale, radius):
     assert t.factor == pytest.approx(2.0 + 1.0 + 0.25 * 4) and t.maxbuf == 1.0
     assert (t.xalign, t.yalign, t.overhead) == (1, 1, 0)
     assert t.factor_cl == 2.0  # in + out: the column sums live in LDS
+    # a frame whose chunks are 65 - 69 rows high (6000 x 4000: 69): + the head kernel's export for the tail kernel
+    t = _t("dt_hip_iop_nlmeans_tiling", abi.Piece.make(6000, 4000, roi_in=abi.Roi.make(0, 0, 6000, 4000, scale), roi_out=abi.Roi.make(0, 0, 6000, 4000, scale)), abi.NlmeansData(radius, 50.0, 0.5, 1.0))
+    assert t.factor_cl == pytest.approx(2.96)
 
 
 @pytest.mark.parametrize("w,h", [(6000, 4000), (640, 480), (400, 300), (100, 60)])
