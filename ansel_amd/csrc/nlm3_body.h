@@ -741,8 +741,11 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
 #pragma unroll
           for(int j = 0; j < AB; j++) v[j] = Env::div_uniform(v[j], cden, crcp);
           env.sched_fence();
+          // max(0, q s - 2) x -2^23 as min(0, q s' + 2^24) with s' = s x -2^23: scaling by a power of two is exact and commutes
+          // with both roundings (the product's and the difference's: q s - 2 is never subnormal, a subnormal q s leaves -2 either
+          // way, an overflow is -inf either way), max x negative = min, and a NaN gives 0 through either -- one product fewer
 #pragma unroll
-          for(int j = 0; j < AB; j++) v[j] = Env::max_num(0.0f, v[j] * a.sharpness - 2.0f) * -8388608.0f;
+          for(int j = 0; j < AB; j++) v[j] = Env::min_num(0.0f, v[j] * sharp_m23 + 16777216.0f);
           env.sched_fence();
         }
         else

@@ -270,7 +270,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         // nlmeans_core.c:416-424, as nlm3_body.h's accumulate() forms it
         const float dx_ = own_xy.x - q.x, dy_ = own_xy.y - q.y, dz_ = own_z - qz;
         const float num = dist + (dx_ * dx_ * a.cpn + dy_ * dy_ * a.cpn + dz_ * dz_ * a.cpn);
-        const float v = Env::max_num(0.0f, Env::div_uniform(num, cden, crcp) * a.sharpness - 2.0f) * -8388608.0f;
+        const float v = Env::min_num(0.0f, Env::div_uniform(num, cden, crcp) * sharp_m23 + 16777216.0f); // (nlm3_body.h: why this is max(0, q s - 2) x -2^23)
         const int k0 = (int)(0x3f800000u + (unsigned)Env::cvt_i32_sat(v));
         wgt = Env::int_as_float(k0 >= 0x800000 ? k0 : 0);
       }

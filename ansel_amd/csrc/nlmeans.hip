@@ -812,6 +812,7 @@ struct nlm2_device_env
   __device__ __forceinline__ long long clock() const { return 0; }
   static __device__ __forceinline__ float int_as_float(const int v) { return __int_as_float(v); }
   static __device__ __forceinline__ float max_num(const float a, const float b) { return __builtin_fmaxf(a, b); } // v_max_f32
+  static __device__ __forceinline__ float min_num(const float a, const float b) { return __builtin_fminf(a, b); } // v_min_f32
   static __device__ __forceinline__ int cvt_i32_sat(const float v)
   {
     int r;

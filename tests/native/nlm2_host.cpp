@@ -97,6 +97,7 @@ struct HostEnv
     return (int)v;
   }
   static float max_num(const float a, const float b) { return fmaxf(a, b); } // v_max_f32: the number, if one is a NaN
+  static float min_num(const float a, const float b) { return fminf(a, b); }
   // the device's quotient by a wave-uniform divisor (nlmeans.hip div_uniform(): correctly rounded, checked on the GPU)
   static float rcp_refined(const float d) { return 1.0f / d; }
   static float div_uniform(const float n, const float d, const float) { return n / d; }
