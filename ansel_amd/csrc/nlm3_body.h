@@ -148,13 +148,26 @@ template <class I2> inline bool regular_grid(const I2 *const patches, const int 
 
 // the column recurrence over table rows T0 .. T1 - 1, every sum stored with ds_write_addtid_b32 (address = M0 + offset +
 // 4 * lane: no address register, 2 LDS cycles per store instead of 4); the row offset must be an immediate
-template <int T0, int T1, int ROWBYTES, class Env> struct column_chain
+// BLOCKS (round 6; the third version): eight rows per Env::chain8() -- on the device ONE statement that writes M0 once for its eight
+// stores.  A store of its own (st_addtid()) is three issue slots, s_mov_b32 m0 / s_nop / ds_write_addtid_b32, beside the row's one
+// addition: 224 of the ~260 instructions an A2 wave issued per offset.  Measured same box, three runs each, with the C role's fetches
+// behind its accumulation: 21.07 -> 20.86 ms at 100 MP; on the fused variant (64 rows) 14.01 -> 14.11 at 60 MP and at patch radius 1
+// 21.28 -> 21.61: not used there.
+template <int T0, int T1, int ROWBYTES, class Env, bool BLOCKS = false> struct column_chain
 {
   static NLM2_FN void run(const Env &env, float *const wave_base, const int lane, float &v, const float *const term)
   {
-    v = v + term[T0];
-    env.template st_addtid<T0 * ROWBYTES>(wave_base, lane, v);
-    if constexpr(T0 + 1 < T1) column_chain<T0 + 1, T1, ROWBYTES, Env>::run(env, wave_base, lane, v, term);
+    if constexpr(BLOCKS && T0 + 8 <= T1)
+    {
+      env.template chain8<T0, ROWBYTES>(wave_base, lane, v, term);
+      if constexpr(T0 + 8 < T1) column_chain<T0 + 8, T1, ROWBYTES, Env, BLOCKS>::run(env, wave_base, lane, v, term);
+    }
+    else
+    {
+      v = v + term[T0];
+      env.template st_addtid<T0 * ROWBYTES>(wave_base, lane, v);
+      if constexpr(T0 + 1 < T1) column_chain<T0 + 1, T1, ROWBYTES, Env, BLOCKS>::run(env, wave_base, lane, v, term);
+    }
   }
 };
 
@@ -508,7 +521,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         for(int r = 0; r < S; r++) v += f[r];
         float *const wave_base = tab + tslot(p) * tabsz + XO + 1 + w * 64; // lane 0's column
         env.template st_addtid<0>(wave_base, lane, v);
-        column_chain<1, MAXCH, TP * 4, Env>::run(env, wave_base, lane, v, term);
+        column_chain<1, MAXCH, TP * 4, Env, !FUSED && P == 2 && !CENTER>::run(env, wave_base, lane, v, term); // (where it measured a gain)
         if constexpr(TALL)
         {
           static_assert(!TALL || MAXCH == TALL_HEAD, "the exported sum is the one behind the head's last row");
@@ -818,21 +831,23 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
               }
               else if constexpr(FUSED)
               {
-                // the sums and the pixel of this offset are fetched, the offset before is accumulated while they travel,
-                // then the row recurrence of this offset
+                // the offset before is accumulated FIRST, the sums and the pixel of this offset fetched behind it, then the row recurrence of
+                // this offset (round 6: with the fetches in front, every C wave's reads queued at the LDS at the top of a stage ahead of the
+                // column recurrence's, whose chain is the stage's length: 14.2 -> 14.0 ms at 60 MP, same box)
+                if(active && jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
+                env.sched_fence();
                 fetch_sums(dyi * ndx + jb + M);
-                if(active)
-                {
-                  fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
-                  if(jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
-                }
+                if(active) fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
                 if(!(var & 64)) row_chain(m_tag);
                 if(active && jb + M + 1 == ndx) accumulate(m_tag);
               }
               else if(active)
               {
-                fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
+                // accumulate first, fetch behind it: the first LDS reads of a stage then belong to the two recurrences -- the stage's latency
+                // chains -- and not to the seven C waves (round 6: 21.47 -> 21.23 ms at 100 MP, same box, three runs each)
                 if(jb + M > 0) accumulate(std::integral_constant<int, (M + NR - 1) % NR>());
+                env.sched_fence();
+                fetch(m_tag, dyi * ndx + jb + M, jb + M == 0, dy, dx0 + jb + M);
                 if(jb + M + 1 == ndx) accumulate(m_tag);
               }
               env.sync();

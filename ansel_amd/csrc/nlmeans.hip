@@ -802,6 +802,28 @@ struct nlm2_device_env
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%2" : : "s"(m0v), "v"(v), "n"(OFF) : "memory", "m0");
   }
+  // eight rows of the column recurrence in ONE statement: M0 written once, then add / store eight times.  The additions are the
+  // v_add_f32 the compiler emits for `v + term` (no contraction to worry about: there is no product); a VGPR written by a VALU
+  // instruction and read by the LDS instruction behind it is interlocked by the hardware
+  template <int T0, int ROWBYTES> __device__ __forceinline__ void chain8(float *const wave_base, const int, float &v, const float *const term) const
+  {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)wave_base);
+    asm volatile("s_mov_b32 m0, %[b]\n\ts_nop 0\n\t"
+                 "v_add_f32 %[v], %[v], %[t0]\n\tds_write_addtid_b32 %[v] offset:%[o0]\n\t"
+                 "v_add_f32 %[v], %[v], %[t1]\n\tds_write_addtid_b32 %[v] offset:%[o1]\n\t"
+                 "v_add_f32 %[v], %[v], %[t2]\n\tds_write_addtid_b32 %[v] offset:%[o2]\n\t"
+                 "v_add_f32 %[v], %[v], %[t3]\n\tds_write_addtid_b32 %[v] offset:%[o3]\n\t"
+                 "v_add_f32 %[v], %[v], %[t4]\n\tds_write_addtid_b32 %[v] offset:%[o4]\n\t"
+                 "v_add_f32 %[v], %[v], %[t5]\n\tds_write_addtid_b32 %[v] offset:%[o5]\n\t"
+                 "v_add_f32 %[v], %[v], %[t6]\n\tds_write_addtid_b32 %[v] offset:%[o6]\n\t"
+                 "v_add_f32 %[v], %[v], %[t7]\n\tds_write_addtid_b32 %[v] offset:%[o7]"
+                 : [v] "+v"(v)
+                 : [b] "s"(m0v), [t0] "v"(term[T0]), [t1] "v"(term[T0 + 1]), [t2] "v"(term[T0 + 2]), [t3] "v"(term[T0 + 3]),
+                   [t4] "v"(term[T0 + 4]), [t5] "v"(term[T0 + 5]), [t6] "v"(term[T0 + 6]), [t7] "v"(term[T0 + 7]),
+                   [o0] "n"(T0 * ROWBYTES), [o1] "n"((T0 + 1) * ROWBYTES), [o2] "n"((T0 + 2) * ROWBYTES), [o3] "n"((T0 + 3) * ROWBYTES),
+                   [o4] "n"((T0 + 4) * ROWBYTES), [o5] "n"((T0 + 5) * ROWBYTES), [o6] "n"((T0 + 6) * ROWBYTES), [o7] "n"((T0 + 7) * ROWBYTES)
+                 : "memory", "m0");
+  }
   __device__ __forceinline__ bool any(const bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0; }
   // the value of the lane to the left within a row of 16 lanes (DPP row_shr:1); lane 0 of a row gets 0
   __device__ __forceinline__ float lane_shr1(const float v) const

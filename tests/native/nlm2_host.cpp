@@ -85,6 +85,15 @@ struct HostEnv
   void sched_fence() const {}
   // ds_write_addtid_b32: base + offset + 4 * lane
   template <int OFF> void st_addtid(float *const wave_base, const int lane, const float v) const { wave_base[OFF / 4 + lane] = v; }
+  // eight rows of the column recurrence (nlm3_body.h column_chain): v = v + term[t], stored at row t, for t = T0 .. T0 + 7
+  template <int T0, int ROWBYTES> void chain8(float *const wave_base, const int lane, float &v, const float *const term) const
+  {
+    for(int t = T0; t < T0 + 8; t++)
+    {
+      v = v + term[t];
+      wave_base[(size_t)t * (ROWBYTES / 4) + lane] = v;
+    }
+  }
   bool any(const bool) const { return true; } // a wave-level vote on the device; every slot stays live here
   static constexpr bool TIMED = false;
   long long clock() const { return 0; }
