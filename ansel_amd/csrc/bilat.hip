@@ -352,7 +352,9 @@ __global__ __launch_bounds__(256) void bilat_lightness(const float4 *__restrict_
 }
 #endif
 
-int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_rows, int row_lo, int row_hi, int accumulate)
+// zc_pre: the rows' lightness cells, already computed (pipe.cpp: by the non-local-means kernels in front of the module), or nullptr
+int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_rows, int row_lo, int row_hi, int accumulate,
+                     const float2 *zc_pre = nullptr)
 {
   hipStream_t s = stream_of(devid);
   const int nodes = b.size_x * b.size_y;
@@ -373,11 +375,11 @@ int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_ro
     return DT_HIP_SUCCESS;
   }
 #endif
-  float2 *zc = (float2 *)dt_hip_alloc_device_buffer(devid, n * sizeof(float2));
+  float2 *zc = zc_pre ? const_cast<float2 *>(zc_pre) : (float2 *)dt_hip_alloc_device_buffer(devid, n * sizeof(float2));
   if(!zc) return DT_HIP_SYSMEM_ALLOCATION;
   {
     launch_scope ls(devid, "bilat_splat");
-    bilat_zcells<<<stream_grid(n, 256), 256, 0, s>>>(in_rows, zc, n, b.sigma_r, b.size_z);
+    if(!zc_pre) bilat_zcells<<<stream_grid(n, 256), 256, 0, s>>>(in_rows, zc, n, b.sigma_r, b.size_z);
     const size_t cells = (size_t)b.size_z * SPLAT_THREADS * sizeof(float);
     const size_t table = (size_t)((int)ceilf(2.0f * b.sigma_s) + 8) * SPLAT_THREADS * sizeof(float);
     // div_by()'s premise: numerators are 0 or >= 2^-46 * 100 (two fractions of at least one ulp of a grid coordinate
@@ -390,7 +392,7 @@ int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_ro
     else
       bilat_splat2<false><<<grid, SPLAT_THREADS, cells, s>>>(zc, buf, b, row_lo, row_hi, accumulate, fast_div);
   }
-  dt_hip_release_mem_object(zc); // stream-ordered
+  if(!zc_pre) dt_hip_release_mem_object(zc); // stream-ordered
   return DT_HIP_SUCCESS;
 }
 
@@ -491,8 +493,35 @@ namespace ansel
 // The module in bilateral-grid mode with the fused RGBA run `chain` behind it (pipe.cpp): splat and blur as the module runs them, the slice
 // as the first stage of the run's kernel -- the module's output plane is neither written nor read.  DT_HIP_INVALID_ARG: not this
 // mode (the caller runs the two one after the other).
+// the grid's third axis for the frame `piece` describes: what a kernel that writes lightness cells for the module needs
+int bilat_cell_params(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, float *sigma_r, int *size_z)
+{
+  if(!piece || !d || d->mode != DT_HIP_BILAT_BILATERAL || piece->channels != 4) return DT_HIP_INVALID_ARG;
+  grid_t b;
+  if(bilat_grid_of(piece, d, b) != DT_HIP_SUCCESS) return DT_HIP_INVALID_ARG;
+  *sigma_r = b.sigma_r;
+  *size_z = b.size_z;
+  return DT_HIP_SUCCESS;
+}
+// the module (bilateral-grid mode) on a frame whose lightness cells `cells` exist already
+int bilat_process_cells(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                        dt_hip_mem_t cells)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || !cells || piece->channels != 4) return DT_HIP_INVALID_ARG;
+  if(d->mode != DT_HIP_BILAT_BILATERAL) return DT_HIP_INVALID_ARG;
+  const int height = piece->roi_in.height;
+  grid_t b;
+  if(bilat_grid_of(piece, d, b) != DT_HIP_SUCCESS) return DT_HIP_INVALID_ARG;
+  const size_t ncells = (size_t)b.size_x * b.size_y * b.size_z;
+  float *buf = (float *)dt_hip_alloc_device_buffer(devid, ncells * sizeof(float));
+  if(!buf) return DT_HIP_SYSMEM_ALLOCATION;
+  int err = bilat_splat_rows(devid, b, buf, (const float4 *)dev_in, 0, height, 0, (const float2 *)cells);
+  if(err == DT_HIP_SUCCESS) err = bilat_blur_and_slice(devid, b, buf, d, (const float4 *)dev_in, (float4 *)dev_out, 0, height);
+  dt_hip_release_mem_object(buf);
+  return err;
+}
 int bilat_process_chain(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
-                        const rgb_group_t *chain)
+                        const rgb_group_t *chain, dt_hip_mem_t pixel_cells)
 {
   if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || !chain || piece->channels != 4) return DT_HIP_INVALID_ARG;
   if(d->mode != DT_HIP_BILAT_BILATERAL) return DT_HIP_INVALID_ARG;
@@ -503,7 +532,7 @@ int bilat_process_chain(int devid, const dt_hip_piece_t *piece, const dt_hip_bil
   const size_t cells = (size_t)b.size_x * b.size_y * b.size_z;
   float *buf = (float *)dt_hip_alloc_device_buffer(devid, cells * sizeof(float));
   if(!buf) return DT_HIP_SYSMEM_ALLOCATION;
-  int err = bilat_splat_rows(devid, b, buf, (const float4 *)dev_in, 0, height, 0);
+  int err = bilat_splat_rows(devid, b, buf, (const float4 *)dev_in, 0, height, 0, (const float2 *)pixel_cells);
   const float *blurred = nullptr;
   float *second = nullptr;
   if(err == DT_HIP_SUCCESS) err = bilat_blur(devid, b, buf, &blurred, &second);

@@ -499,6 +499,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
       r.w = (ip.w * 0.0f) + (accw[k] / accw[k] * 1.0f);
     }
     out[o] = r;
+    env.store_cell(a, o, r.x);
   }
   if constexpr(Env::TIMED)
   {

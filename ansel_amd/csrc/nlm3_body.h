@@ -899,6 +899,7 @@ NLM2_FN void body(const Env &env, const F4 *__restrict__ in, F4 *__restrict__ ou
         res.w = (ip.w * 0.0f) + (accw[i] / accw[i] * 1.0f);
       }
       out[o] = res;
+      env.store_cell(a, o, res.x);
     }
   }
 }

@@ -24,6 +24,7 @@
 #include "nlmeans_core_params.h"
 #include "nlm2_body.h"
 #include "ieee_inrange.h"
+#include "px_bilat.h"
 #include "nlm3_body.h"
 #include "nlm_tail_body.h"
 
@@ -60,7 +61,22 @@ struct nlm_args
   // stores frame rows [out_row0, out_row1) only; `in` / `out` are addressed with frame row indices
   int cy0, out_row0, out_row1;
   int variant;       // nlm_chunks_v2: 0, or the A/B switches of nlm2_body.h (ANSEL_NLM2_VARIANT; timing experiments)
+  // the lightness cell of every output pixel for the bilateral grid behind the module (nlm_core_params_t::cell_out), or nullptr
+  float2 *zc;
+  float zc_sigma_r;
+  int zc_size_z;
 };
+
+// the epilogue's extra store: bilat_zcells() of the pixel just written (same operands, same function: px_bilat.h)
+__device__ __forceinline__ void nlm_store_cell(const nlm_args &a, const long o, const float L)
+{
+  if(a.zc)
+  {
+    float zf;
+    const int zi = bilat_axis(L, a.zc_sigma_r, a.zc_size_z, zf);
+    a.zc[o] = make_float2(zf, __int_as_float(zi));
+  }
+}
 
 __device__ __forceinline__ int imin(const int a, const int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(const int a, const int b) { return a > b ? a : b; }
@@ -325,6 +341,7 @@ __global__ __launch_bounds__(NLM_THREADS) void nlm_chunks(const float4 *__restri
       r.w = (ip.w * 0.0f) + (s.w / s.w * 1.0f);
     }
     out[o] = r;
+    nlm_store_cell(a, o, r.x);
   }
 }
 
@@ -773,6 +790,7 @@ __device__ __forceinline__ void pipelined_body(const int chunk, float *const lds
       r.w = (ip.w * 0.0f) + (s.w / s.w * 1.0f);
     }
     out[o] = r;
+    nlm_store_cell(a, o, r.x);
   }
 }
 
@@ -793,6 +811,7 @@ struct nlm2_device_env
   __device__ __forceinline__ float *lds() const { return lds_; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ void prio_high() const { __builtin_amdgcn_s_setprio(3); }
+  __device__ __forceinline__ void store_cell(const nlm_args &a, const long o, const float L) const { nlm_store_cell(a, o, L); }
   __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); } // nothing moves across
   // ds_write_addtid_b32: LDS address = M0 + offset + 4 * lane, data from one register, no address register.  M0 is
   // written right in front of the store (the compiler does not know the instruction reads it) with the wait state the
@@ -1086,6 +1105,9 @@ int nlmeans_core_launch(int devid, const float4 *in, float4 *out, int width, int
   a.npatch = (int)patches.size();
   a.cs_pitch = (a.chk_w + 2 * a.radius + 1) | 1; // odd pitches: the row-parallel step strides whole rows
   a.wt_pitch = (a.chk_w + 16) | 1; // 16 spare columns: the batched row recurrence stores whole batches
+  a.zc = p.band ? nullptr : p.cell_out; // (a band's rows are indexed with frame rows: the grid's relay has its own pass)
+  a.zc_sigma_r = p.cell_sigma_r;
+  a.zc_size_z = p.cell_size_z;
   a.sharpness = p.sharpness;
   a.center_weight = p.center_weight;
   a.cpn = p.center_weight * (2 * p.patch_radius + 1) * (2 * p.patch_radius + 1); // compute_center_pixel_norm()
@@ -1341,6 +1363,19 @@ int nlmeans_process_band(int devid, const dt_hip_piece_t *piece, const dt_hip_nl
   p.band = band;
   return nlmeans_core_launch(devid, (const float4 *)dev_in, (float4 *)dev_out, piece->roi_out.width,
                              piece->roi_out.height, p);
+}
+
+// the module with the lightness cells of its output pixels written beside them (pipe.cpp: local contrast's bilateral grid follows)
+int nlmeans_process_cells(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                          dt_hip_mem_t cells, float sigma_r, int size_z)
+{
+  if(!valid_device(devid) || !piece || !d || !dev_in || !dev_out || !cells) return DT_HIP_INVALID_ARG;
+  if(piece->channels != 4) return DT_HIP_INVALID_ARG;
+  nlm_core_params_t p = nlmeans_params(piece, d);
+  p.cell_out = (float2 *)cells;
+  p.cell_sigma_r = sigma_r;
+  p.cell_size_z = size_z;
+  return nlmeans_core_launch(devid, (const float4 *)dev_in, (float4 *)dev_out, piece->roi_out.width, piece->roi_out.height, p);
 }
 
 // process_cpu(), src/iop/nlmeans.c:416-457

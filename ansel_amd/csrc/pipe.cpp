@@ -348,6 +348,17 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
   bool cur_owned = false;
   dt_hip_mem_t held = NULL; // the input of a module whose output is about to be blended
   bool held_owned = false;
+  // the lightness cells of the current buffer's pixels, written by the non-local-means kernels for the bilateral grid of the local
+  // contrast module right behind them (round 6: bilat_zcells' pass over the frame -- 24 B/px -- folded into their epilogue)
+  dt_hip_mem_t cells = NULL;
+  struct cells_guard // whatever path leaves the walk: the cells go back to the pool
+  {
+    dt_hip_mem_t &c;
+    ~cells_guard()
+    {
+      if(c) dt_hip_release_mem_object(c);
+    }
+  } cells_owner{ cells };
   const size_t ng = pipe->groups.size();
   auto is_blend = [&](const size_t k) { return k < ng && pipe->nodes[pipe->groups[k].first].op == OP_BLEND; };
   for(size_t gi = 0; gi < ng; gi++)
@@ -413,9 +424,11 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
       if(fout)
       {
         const node_t &bl = pipe->nodes[g.first];
-        const int ferr = bilat_process_chain(devid, &bl.piece, bl.as<dt_hip_bilat_data_t>(), cur, fout, &gn.rgb);
+        const int ferr = bilat_process_chain(devid, &bl.piece, bl.as<dt_hip_bilat_data_t>(), cur, fout, &gn.rgb, cells);
         if(ferr == DT_HIP_SUCCESS)
         {
+          if(cells) dt_hip_release_mem_object(cells); // stream-ordered
+          cells = NULL;
           if(cur_owned) dt_hip_release_mem_object(cur);
           cur = fout;
           cur_owned = !final_pair;
@@ -476,7 +489,40 @@ int dt_hip_pipe_process(dt_hip_pipe_t *pipe, dt_hip_mem_t dev_in, dt_hip_mem_t d
     else if(g.kind == group_t::RGB)
       err = rgb_group_launch(devid, g.rgb, cur, out);
     else
-      err = run_single(devid, pipe->nodes[g.first], cur, out);
+    {
+      const node_t &nd = pipe->nodes[g.first];
+      err = DT_HIP_INVALID_ARG;
+      // denoise (non-local means) with local contrast's bilateral grid right behind it: the cells of the grid's third axis leave the
+      // non-local-means kernels with the pixels (no blend in between: the grid is splatted from the module's own output)
+      if(pipe->fusion && nd.op == OP_NLMEANS && !is_blend(gi + 1) && gi + 1 < ng && pipe->groups[gi + 1].kind == group_t::SINGLE
+         && pipe->nodes[pipe->groups[gi + 1].first].op == OP_BILAT)
+      {
+        const node_t &bl = pipe->nodes[pipe->groups[gi + 1].first];
+        float sigma_r = 0.0f;
+        int size_z = 0;
+        if(bilat_cell_params(&bl.piece, bl.as<dt_hip_bilat_data_t>(), &sigma_r, &size_z) == DT_HIP_SUCCESS
+           && bl.piece.roi_in.width == nd.piece.roi_out.width && bl.piece.roi_in.height == nd.piece.roi_out.height)
+        {
+          cells = dt_hip_alloc_device_buffer(devid, (size_t)nd.piece.roi_out.width * nd.piece.roi_out.height * 2 * sizeof(float));
+          if(cells)
+          {
+            err = nlmeans_process_cells(devid, &nd.piece, nd.as<dt_hip_nlmeans_data_t>(), cur, out, cells, sigma_r, size_z);
+            if(err != DT_HIP_SUCCESS)
+            {
+              dt_hip_release_mem_object(cells);
+              cells = NULL;
+            }
+          }
+        }
+      }
+      else if(nd.op == OP_BILAT && cells)
+      {
+        err = bilat_process_cells(devid, &nd.piece, nd.as<dt_hip_bilat_data_t>(), cur, out, cells);
+        dt_hip_release_mem_object(cells);
+        cells = NULL;
+      }
+      if(err == DT_HIP_INVALID_ARG && !cells) err = run_single(devid, nd, cur, out);
+    }
     if(err == DT_HIP_SUCCESS && is_blend(gi + 1))
     {
       held = cur;

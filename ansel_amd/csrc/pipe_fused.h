@@ -52,7 +52,13 @@ int denoiseprofile_process_chain(int devid, const dt_hip_piece_t *piece, const d
 
 // bilat.hip: local contrast in bilateral-grid mode with the run `chain` behind it -- the slice is the run's first stage;
 // DT_HIP_INVALID_ARG when the module is in another mode
+// cells: the frame's lightness cells, written by the module in front (nlmeans.hip nlmeans_process_cells()), or NULL
 int bilat_process_chain(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
-                        const rgb_group_t *chain);
+                        const rgb_group_t *chain, dt_hip_mem_t cells = nullptr);
+int bilat_process_cells(int devid, const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                        dt_hip_mem_t cells);
+int bilat_cell_params(const dt_hip_piece_t *piece, const dt_hip_bilat_data_t *d, float *sigma_r, int *size_z);
+int nlmeans_process_cells(int devid, const dt_hip_piece_t *piece, const dt_hip_nlmeans_data_t *d, dt_hip_mem_t dev_in, dt_hip_mem_t dev_out,
+                          dt_hip_mem_t cells, float sigma_r, int size_z);
 
 } // namespace ansel

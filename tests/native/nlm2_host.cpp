@@ -82,6 +82,7 @@ struct HostEnv
   float *lds() const { return lds_; }
   void sync() const { bar_->arrive_and_wait(); }
   void prio_high() const {}
+  template <class A> void store_cell(const A &, long, float) const {} // (the device's extra store for the bilateral grid behind the module)
   void sched_fence() const {}
   // ds_write_addtid_b32: base + offset + 4 * lane
   template <int OFF> void st_addtid(float *const wave_base, const int lane, const float v) const { wave_base[OFF / 4 + lane] = v; }
