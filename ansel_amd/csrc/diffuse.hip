@@ -499,11 +499,7 @@ __device__ __forceinline__ void pde_dma_planes(const float4 *const p0, const flo
                  : "v"(voff), "s"(p0), "s"(p2), "s"(d0), "s"(d2)
                  : "memory");
 }
-// PERWAVE (round 6, DMA only; an A/B behind the "pde_perwave" test hook): the squared-ratio ring per WAVE over its landing zone's
-// columns instead of one per workgroup -- a wave then needs nothing of the other three and the row step's workgroup barrier goes; the
-// price is the ratios of the 2 x dilation columns beside a wave's own 64, formed by every wave (one more pass per wave: lanes below
-// the dilation take the left ones, lanes from 64 - dilation on the right ones) where the shared ring had them from the neighbour wave.
-template <bool HSUB, int MODE, bool DMA = false, bool PERWAVE = false>
+template <bool HSUB, int MODE, bool DMA = false>
 __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__restrict__ hf, const float4 *__restrict__ hsub,
                                                          const float4 *__restrict__ lf,
                                                          float4 *__restrict__ out, const pde_args a, const int final_pass,
@@ -530,11 +526,8 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
   // DMA: this wave's landing zone behind the ring, [NPL][zw] samples; slot x of a plane's row = column clamp(col0 - mult + x) where
   // col0 is the wave's first column: lane l reads slots l, l + mult, l + 2 mult = its three support columns cols[]
   constexpr int NPL = HSUB ? 3 : 2;
-  static_assert(!PERWAVE || DMA, "the per-wave ring lives beside the per-wave landing zones");
   const int lane = tx & 63, zw = 64 + 2 * mult;
-  // PERWAVE: [4 waves][PDE_RING][zw] rings, then the zones
-  float4 *const ring_w = r2s + (tx >> 6) * PDE_RING * zw;
-  float4 *const zone = r2s + (PERWAVE ? 4 * PDE_RING * zw : PDE_RING * tw) + (tx >> 6) * NPL * zw;
+  float4 *const zone = r2s + PDE_RING * tw + (tx >> 6) * NPL * zw;
   // the zone's LDS byte address (what M0 takes): the pointer in the LDS address space, not the low half of a generic one
   using lds_f4_ptr = __attribute__((address_space(3))) float4 *;
   const unsigned zone_lds = DMA ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(__UINTPTR_TYPE__)(lds_f4_ptr)zone) : 0u;
@@ -600,7 +593,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
 #pragma unroll
     for(int jj = 0; jj < 3; jj++)
       Hw[SL][jj] = HSUB ? make_float4(c[jj].x - low[jj].x, c[jj].y - low[jj].y, c[jj].z - low[jj].z, c[jj].w - low[jj].w) : c[jj];
-    float4 *const ring = PERWAVE ? ring_w + (v % PDE_RING) * zw : r2s + (v % PDE_RING) * tw;
+    float4 *const ring = r2s + (v % PDE_RING) * tw;
     // the fourth channel's squared ratio is +0 when both samples are +0 (0 / 1e-8, squared): a wave whose samples all
     // are -- what a pipe hands this module, see alpha_is_blank() -- skips that division (a uniform branch)
     auto ratios = [&](const float4 h, const float4 l) {
@@ -608,17 +601,6 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       return ratio2_rgb(h, l, blank ? 0.0f : ratio2(h.w, l.w), PDE_APPROX(a));
     };
     if(PDE_OFF(a, 4)) return;
-    if constexpr(PERWAVE)
-    {
-      ring[lane + mult] = ratios(Hw[SL][1], Lw[SL][1]);
-      if(lane < mult || lane >= 64 - mult)
-      {
-        const bool left = lane < mult;
-        const float4 h = left ? Hw[SL][0] : Hw[SL][2], l = left ? Lw[SL][0] : Lw[SL][2];
-        ring[left ? lane : lane + 2 * mult] = ratios(h, l);
-      }
-      return;
-    }
     ring[tx + mult] = ratios(Hw[SL][1], Lw[SL][1]);
     if(tx < mult) ring[tx] = ratios(Hw[SL][0], Lw[SL][0]);
     if(tx >= 256 - mult) ring[tx + 2 * mult] = ratios(Hw[SL][2], Lw[SL][2]);
@@ -640,14 +622,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
       }
       if(kk + 1 < nrows) dma_row(kk + 3);
     }
-    if constexpr(PERWAVE)
-    {
-      // the wave's own stores are visible to its own loads in LDS order; nothing may be moved across by the compiler
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    else if(!PDE_OFF(a, 1)) __syncthreads();
+    if(!PDE_OFF(a, 1)) __syncthreads();
     if(!live) return;
     const float4 H4[9] = { Hw[S0][0], Hw[S0][1], Hw[S0][2], Hw[S1][0], Hw[S1][1], Hw[S1][2], Hw[S2][0], Hw[S2][1], Hw[S2][2] };
     const float4 L4[9] = { Lw[S0][0], Lw[S0][1], Lw[S0][2], Lw[S1][0], Lw[S1][1], Lw[S1][2], Lw[S2][0], Lw[S2][1], Lw[S2][2] };
@@ -671,7 +646,7 @@ __global__ __launch_bounds__(256, 3) void diffuse_pde_strip(const float4 *__rest
 #pragma unroll
     for(int ii = 0; ii < 3; ii++)
     {
-      const float4 *const ring = PERWAVE ? ring_w + ((kk + ii) % PDE_RING) * zw + lane : r2s + ((kk + ii) % PDE_RING) * tw + tx;
+      const float4 *const ring = r2s + ((kk + ii) % PDE_RING) * tw + tx;
 #pragma unroll
       for(int jj = 0; jj < 3; jj++)
       {
@@ -1052,15 +1027,7 @@ static int diffuse_run(int devid, const dt_hip_piece_t *piece, const dt_hip_diff
           const bool dma = chain && a.mult <= PDE_DMA_MAX_MULT && !no_dma;
           const size_t ring_dma = ring + (size_t)4 * 3 * (64 + 2 * a.mult) * sizeof(float4);
 #define PDE_LAUNCH_DMA(MD) diffuse_pde_strip<true, MD, true><<<sgrid, 256, ring_dma, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc)
-          // the per-wave ring (A/B: the "pde_perwave" test hook; instantiated for the deblur presets' mode only)
-          const bool perwave = dma && mode == PDE_MODE_DEBLUR && dispatch_override(DISPATCH_PDE_PERWAVE);
-          const size_t ring_pw = (size_t)4 * (PDE_RING + 3) * (64 + 2 * a.mult) * sizeof(float4);
           bool launched = false;
-          if(perwave)
-          {
-            diffuse_pde_strip<true, PDE_MODE_DEBLUR, true, true><<<sgrid, 256, ring_pw, st>>>(h0, h1, cur, to, a, s == 0, mask, strip, spc);
-            launched = true;
-          }
 #define PDE_CASE(MD)                     \
   if(!launched && mode == (MD))          \
   {                                      \

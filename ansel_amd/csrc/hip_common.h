@@ -34,7 +34,6 @@ enum dispatch_key_t
   DISPATCH_AMAZE_SLAB,      // AMaZE: every tile on the first kernel
   DISPATCH_AMAZE_BLOCKS,    // AMaZE: at most this many workgroups (a workgroup then walks many tiles)
   DISPATCH_BILAT_BLUR_SPLIT, // bilateral grid: the blur's x-pass in a launch of its own (what grids beyond 2^22 cells take)
-  DISPATCH_PDE_PERWAVE,      // diffuse or sharpen: the squared-ratio ring per wave (an A/B; not a fallback)
   DISPATCH_KEYS
 };
 int dispatch_override(dispatch_key_t key); // 0: not set

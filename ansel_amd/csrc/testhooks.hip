@@ -13,7 +13,7 @@ namespace
 {
 std::atomic<int> g_dispatch[DISPATCH_KEYS];
 const char *const g_dispatch_names[DISPATCH_KEYS] = { "nlm_v2", "nlm_fused", "amaze_unfused", "amaze_slab", "amaze_blocks",
-                                                       "bilat_blur_split", "pde_perwave" };
+                                                       "bilat_blur_split" };
 } // namespace
 namespace ansel
 {

@@ -201,28 +201,3 @@ def test_diffuse_is_the_same_bits_every_run():
     for _ in range(8):
         got = hc.run_hip("dt_hip_iop_diffuse_process", piece, d, img, img.shape, pre_fill=fill)
         assert int((ck.ulp_diff(got, want) > 0).sum()) == 0
-
-
-# round 6: the squared-ratio ring per WAVE over its landing zone (diffuse_pde_strip<..., PERWAVE>, the "pde_perwave" test hook; an
-# A/B of the deblur presets' kernel, not a fallback): the same words as the workgroup's ring and as the oracle
-@pytest.mark.parametrize("size", [(300, 200), (1030, 517), (70, 33)])
-@pytest.mark.parametrize("imgname", ["scene", "adversarial", "scene-patches"])
-def test_diffuse_per_wave_ratio_ring(size, imgname):
-    from ansel_amd import lib
-    w, h = size
-    img = synth.adversarial_rgba(w, h) if imgname == "adversarial" else synth.rgba_image(w, h, seed=8, lo=-0.02, hi=1.5)
-    if "-" in imgname:
-        img = _with_alpha(img, imgname.split("-")[1])
-    piece = abi.Piece.make(w, h)
-    d = params.diffuse("lens_deblur_soft", iterations=2)
-    shared = hc.run_hip("dt_hip_iop_diffuse_process", piece, d, img, img.shape)
-    lib.test_dispatch("pde_perwave", 1)
-    try:
-        got = hc.run_hip("dt_hip_iop_diffuse_process", piece, d, img, img.shape)
-    finally:
-        lib.test_dispatch("pde_perwave", 0)
-    want = _cpu("oracle", piece, d, img)
-    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
-    assert same.all(), "%d words differ from the oracle" % int((~same).sum())
-    same = (got.view(np.uint32) == shared.view(np.uint32)) | (np.isnan(got) & np.isnan(shared))
-    assert same.all()
