@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=None)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--radius", type=float, default=2.0, help="nlmeans: the module's patch radius (2 = its default)")
+    ap.add_argument("--dispatch", default=None, help="a dt_hip_test_dispatch() key to set for the run (an A/B kernel: e.g. pde_perwave)")
     ap.add_argument("--cpu", action="store_true",
                     help="amaze: also time the reference's own code (oracle/_ref/libansel_ref_fast.so, its release flags, OpenMP) on "
                          "the host for the same frame, and check the device output against it outside the reference's stale pixels")
@@ -31,6 +32,8 @@ def main():
     import torch
     from ansel_amd import abi, lib, params, synth
     l = lib.init()
+    if args.dispatch:
+        lib.test_dispatch(args.dispatch, 1)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream(dev)
     lib.check(l.dt_hip_set_stream(0, C.c_void_p(stream.cuda_stream)), "set_stream")
