@@ -27,7 +27,7 @@ def kernels():
 # the kernels of the metric's workload (bench.py's full pipe, every launch group) and of the other BASELINE configurations
 HOT = [r"^void dn_decompose_strip<", r"^void diffuse_pde_strip<(true|false), \d+, (true|false)>", r"bspline_decompose_strip", r"^void nlm_chunks_v3<9, [67], [12], (true|false)>",
        r"^void nlm_chunks_v4<9, 7, (true|false), [12], (true|false)>", r"^void nlm_tail<", r"^void ansel::rgb_chain<", r"^void dn_finish_chain<", r"rcd_tiles", r"raw_chain",
-       r"bilat_(zcells|splat2|blur_line|blur_line_z|slice)", r"dn_band_(sums|threshold)", r"^void filmic_kernel<", r"^void apply_matrix<", r"^void (rgb_to_lab|lab_to_rgb)<", r"^void channelmixerrgb<"]
+       r"bilat_(zcells|splat2|blur_yz|blur_x|slice)", r"dn_band_(sums|threshold)", r"^void filmic_kernel<", r"^void apply_matrix<", r"^void (rgb_to_lab|lab_to_rgb)<", r"^void channelmixerrgb<"]
 
 
 def test_hot_kernels_use_no_scratch(kernels):
