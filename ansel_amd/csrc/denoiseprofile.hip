@@ -7,7 +7,8 @@
 // accumulate eaw_synthesize() (eaw.c:157-175) -> + residue -> inverse transform.
 //
 // Launches per frame: 1 precondition, per band {decompose, threshold}, 1 finish.  Every band keeps its
-// detail plane (7 x 1.6 GB at 100 MP, of 288 GB), so the soft-threshold accumulation of ALL bands
+// detail plane (7 x 1.6 GB at 100 MP, of 288 GB; on the unsplit frame since round 6: band 0's detail and every band's COARSE
+// plane, the details of bands 1 .. being differences of those, formed where they are read), so the soft-threshold accumulation of ALL bands
 // (eaw_synthesize(), in band order, from a zero accumulator: the same additions in the same order), the
 // residue add and the inverse transform are one pass over the frame -- 144 B/px instead of the 384 B/px
 // of one read-modify-write pass per band.  Nothing returns to the host between launches: the band
@@ -131,6 +132,12 @@ struct synth_args
   int nbands;                 // 0: `out` already holds the accumulator (the non-local-means path)
   const float4 *detail[BANDS]; // the bands' detail planes, finest first
   const float *thrs;          // [nbands][4]
+  // round 6 (the unsplit frame): non-null = only band 0's detail is a plane; detail[b], b >= 1, is band b's COARSE plane, coarse0 is band
+  // 0's, and the detail of band b is formed here, coarse b - 1 minus coarse b -- the subtraction eaw_dn_decompose() stores
+  // (eaw.c:232-238: det = px - sum; px IS the coarse value of the band before), same operands, same operation -- so that the
+  // decompositions of bands 1 .. write one plane instead of two (16 B/px less each) and two planes fewer are held.  The residue is the
+  // last band's coarse plane: read once.  (Band 0's input is the transformed frame, which is never stored: its detail stays a plane.)
+  const float4 *coarse0;
 };
 
 // eaw_synthesize() with boost 1, eaw.c:157-175, for one band on the accumulator in registers
@@ -157,7 +164,20 @@ __device__ __forceinline__ float4 dn_finish_pixel(const float4 *__restrict__ out
       float4 d[BANDS];
 #pragma unroll
       for(int b = 0; b < BANDS; b++) d[b] = sy.detail[b < sy.nbands ? b : 0][j];
-      if(residue) res = residue[j];
+      if(sy.coarse0)
+      {
+        const float4 c0 = sy.coarse0[j];
+        res = c0; // (the residue of a single band; else the last band's coarse plane, which d[] holds)
+#pragma unroll
+        for(int b = 1; b < BANDS; b++)
+          if(b < sy.nbands) res = d[b];
+        // from the coarsest band down, so that d[b - 1] is still the coarse plane when d[b] becomes the detail
+#pragma unroll
+        for(int b = BANDS - 1; b >= 2; b--)
+          if(b < sy.nbands) d[b] = make_float4(d[b - 1].x - d[b].x, d[b - 1].y - d[b].y, d[b - 1].z - d[b].z, d[b - 1].w - d[b].w);
+        if(1 < sy.nbands) d[1] = make_float4(c0.x - d[1].x, c0.y - d[1].y, c0.z - d[1].z, c0.w - d[1].w);
+      }
+      else if(residue) res = residue[j];
       // the accumulator of denoiseprofile.c:1398 starts zeroed; bands are added finest first (:1400-1421)
       acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(256) void dn_decompose(const float4 *__restrict__ i
     }
     const size_t o = (size_t)row * width + col;
     coarse[o] = make_float4(c4[0], c4[1], c4[2], c4[3]);
-    detail[o] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+    if(detail) detail[o] = make_float4(d4[0], d4[1], d4[2], d4[3]); // (nullptr: the synthesis forms it from two coarse planes)
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_wa
       }
       const size_t o = (size_t)row * width + col;
       coarse[o] = make_float4(c4[0], c4[1], c4[2], c4[3]);
-      detail[o] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+      if(detail) detail[o] = make_float4(d4[0], d4[1], d4[2], d4[3]); // (nullptr: the synthesis forms it from two coarse planes)
     }
     {
       const double s = wave_sum4_halving(sq[0], sq[1], sq[2], sq[3]);
@@ -1381,33 +1401,34 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
   if(!runnable) return chain ? DT_HIP_INVALID_ARG : dt_hip_enqueue_copy_buffer_to_buffer(devid, dev_in, dev_out, 0, 0, plane);
   const int nseg = (w + 255) / 256;
   const size_t n_partial = (size_t)h * nseg;
-  float4 *precond = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
-  float4 *tmp = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
   // the tables of partial sums of ALL bands: the thresholds are needed by dn_finish only, so they are reduced together
   // behind the last decomposition (seven pairs of latency-bound launches in a row cost 0.39 ms per frame)
   double *partial = (double *)dt_hip_alloc_device_buffer(devid, (size_t)BANDS * n_partial * 4 * sizeof(double));
   float *thrs = (float *)dt_hip_alloc_device_buffer(devid, BANDS * 4 * sizeof(float));
   double *accs = (double *)dt_hip_alloc_device_buffer(devid, (size_t)BANDS * 4 * 1024 * sizeof(double));
-  int err = (precond && tmp && partial && thrs && accs) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
-  // one detail plane per band, all alive until the single synthesis pass at the end
+  int err = (partial && thrs && accs) ? DT_HIP_SUCCESS : DT_HIP_SYSMEM_ALLOCATION;
+  // Round 6: one COARSE plane per band, all alive until the single synthesis pass at the end, and ONE detail plane -- band 0's, whose
+  // input (the transformed frame) is never stored.  The detail of every other band is the difference of two coarse planes and is formed
+  // where it is read (synth_args::coarse0): bands 1 .. write 16 B/px instead of 32, and the frame holds 1 + bands planes instead of 2 + bands
   synth_args sy;
   memset(&sy, 0, sizeof(sy));
   sy.nbands = s.max_scale;
   sy.thrs = thrs;
-  float4 *det[BANDS] = { nullptr };
+  float4 *coarse[BANDS] = { nullptr };
+  float4 *det0 = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
+  if(!det0) err = DT_HIP_SYSMEM_ALLOCATION;
   for(int k = 0; k < s.max_scale && err == DT_HIP_SUCCESS; k++)
   {
-    det[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
-    sy.detail[k] = det[k];
-    if(!det[k]) err = DT_HIP_SYSMEM_ALLOCATION;
+    coarse[k] = (float4 *)dt_hip_alloc_device_buffer(devid, plane);
+    if(!coarse[k]) err = DT_HIP_SYSMEM_ALLOCATION;
+    sy.detail[k] = k == 0 ? det0 : coarse[k];
   }
+  sy.coarse0 = coarse[0];
   float4 *out = (float4 *)dev_out;
-  // the variance-stabilising transform is applied by the first decomposition as it fetches the module's input
-  // (dn_decompose_strip<true>): `precond` is only the second of the two coarse planes the scales alternate between
+  // the variance-stabilising transform is applied by the first decomposition as it fetches the module's input (dn_decompose_strip<true>)
   vst_args fa;
   forward_args(s, fa);
   const float4 *b1 = (const float4 *)dev_in;
-  float4 *b2 = tmp, *b3 = precond;
   // the Y0U0V0 transform sets the fourth channel to 0.0f: the decompositions leave it out for as long as it stays +0
   unsigned *alpha_flag = nullptr;
   if(err == DT_HIP_SUCCESS && s.vst == 2)
@@ -1423,13 +1444,11 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
     const float sigma_band = powf(varf, scale) * 1.0f;
     {
       launch_scope ls(devid, "dn_decompose");
-      launch_decompose(st, b1, b2, det[scale], partial + (size_t)scale * n_partial * 4, w, h, mult,
+      launch_decompose(st, b1, coarse[scale], scale == 0 ? det0 : nullptr, partial + (size_t)scale * n_partial * 4, w, h, mult,
                        1.0f / (sigma_band * sigma_band), nseg, 0, h, scale == 0 ? &fa : nullptr, alpha_flag);
     }
     err = check_launch("denoiseprofile band");
-    b1 = b2; // the coarse plane just written is the next scale's input; the other plane takes the next coarse
-    b2 = b3;
-    b3 = (float4 *)b1;
+    b1 = coarse[scale]; // the coarse plane just written is the next scale's input, and after the last one the residue
   }
   if(err == DT_HIP_SUCCESS)
   {
@@ -1464,10 +1483,9 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
       }
     err = check_launch("dn_finish");
   }
-  if(precond) dt_hip_release_mem_object(precond);
-  if(tmp) dt_hip_release_mem_object(tmp);
+  if(det0) dt_hip_release_mem_object(det0);
   for(int k = 0; k < BANDS; k++)
-    if(det[k]) dt_hip_release_mem_object(det[k]);
+    if(coarse[k]) dt_hip_release_mem_object(coarse[k]);
   if(partial) dt_hip_release_mem_object(partial);
   if(thrs) dt_hip_release_mem_object(thrs);
   if(accs) dt_hip_release_mem_object(accs);
@@ -1496,7 +1514,7 @@ extern "C" {
 
 
 // tiling_callback(), src/iop/denoiseprofile.c:796-848.  factor / overlap as the reference states them for the host;
-// factor_cl = the planes this implementation holds on the device: wavelets in + out + precond + tmp + one detail
+// factor_cl = the planes this implementation holds on the device: wavelets in + out + band 0's detail + one coarse
 // plane per band (the partial sums are W / 64 of a plane), non-local means in + out + the preconditioned copy (the tables live in LDS)
 void dt_hip_iop_denoiseprofile_tiling(const dt_hip_piece_t *piece, const dt_hip_denoiseprofile_data_t *d,
                                       dt_hip_tiling_t *tiling)
@@ -1518,7 +1536,7 @@ void dt_hip_iop_denoiseprofile_tiling(const dt_hip_piece_t *piece, const dt_hip_
     dn_setup s;
     setup(piece, d, s, false);
     tiling->factor = 5.0f;
-    tiling->factor_cl = 4.0f + (float)s.max_scale + 1.0f / 64.0f; // in, out, precond, tmp, one detail plane per band
+    tiling->factor_cl = 3.0f + (float)s.max_scale + 1.0f / 64.0f; // in, out, band 0's detail, one coarse plane per band
     tiling->overlap = 1u << s.max_scale;
   }
 }
