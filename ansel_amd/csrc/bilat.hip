@@ -357,9 +357,9 @@ int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_ro
                      const float2 *zc_pre = nullptr)
 {
   hipStream_t s = stream_of(devid);
-  const int nodes = b.size_x * b.size_y;
   const size_t n = (size_t)b.width * (row_hi - row_lo);
 #ifdef ANSEL_HIP_MEASURING
+  const int nodes = b.size_x * b.size_y;
   static const bool v1 = getenv("ANSEL_HIP_BILAT_SPLAT_V1") != nullptr; // the first gather, for A/B timing
   if(v1)
   {
