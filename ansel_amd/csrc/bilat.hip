@@ -144,10 +144,10 @@ __global__ __launch_bounds__(256) void bilat_zcells(const float4 *__restrict__ i
 }
 
 // blockIdx.y = the grid row Y, blockIdx.x = a block of 64 grid columns.  TABLE: the column weights fit in LDS
-template <bool TABLE>
+template <bool TABLE, bool FAST_DIV>
 __global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat2(const float2 *__restrict__ zc, float *__restrict__ buf,
                                                               const grid_t b, const int row_lo, const int row_hi,
-                                                              const int accumulate, const int fast_div)
+                                                              const int accumulate)
 {
   extern __shared__ float acc[]; // [size_z][SPLAT_THREADS], then the column weights [footprint column][SPLAT_THREADS]
   float *const wxt = acc + b.size_z * SPLAT_THREADS;
@@ -173,32 +173,87 @@ __global__ __launch_bounds__(SPLAT_THREADS) void bilat_splat2(const float2 *__re
   int span = i1 - i0 + 1;
 #pragma unroll
   for(int off = 32; off >= 1; off >>= 1) span = max(span, __shfl_xor(span, off, 64));
-  for(int j = j0; j <= j1; j++)
-  {
+  span = __builtin_amdgcn_readfirstlane(span); // (the same in every lane: the walk's control flow is scalar)
+  // the rows of the footprint that reach this grid row (uniform), each with its weight
+  auto row_weight = [&](const int j, float &wy) {
     float yf;
     const int yi = axis((float)j, b.sigma_s, b.size_y, yf);
-    if(yi != Y && yi != Y - 1) continue; // uniform
-    const float wy = yi == Y ? (1.0f - yf) : yf;
-    const float2 *const rowp = zc + (size_t)(j - row_lo) * b.width;
-    for(int ub = 0; ub < span; ub += 16)
+    wy = yi == Y ? (1.0f - yf) : yf;
+    return yi == Y || yi == Y - 1;
+  };
+  auto next_row = [&](int j, float &wy) {
+    while(j <= j1 && !row_weight(j, wy)) j++;
+    return j;
+  };
+  // The sixteen contributions of a block FIRST, their column weights fetched in one round trip: the weights live in the same LDS
+  // allocation as the cells, so a weight read between two cells' read-add-write sequences has to stay between them (the compiler
+  // cannot know that no cell is written there) -- which made every pixel TWO dependent LDS round trips (the weight, then the cells:
+  // ~290 cycles a pixel), with the quotient's five dependent operations between them.
+  auto contributions = [&](float(&contrib)[16], const float wy, const int ub) {
+#pragma unroll
+    for(int u = 0; u < 16; u++)
     {
-      float2 cell[16];
-#pragma unroll
-      for(int u = 0; u < 16; u++) cell[u] = rowp[min(i0 + ub + u, i1)];
-#pragma unroll
-      for(int u = 0; u < 16; u++)
-      {
-        const int i = i0 + ub + u;
-        float wx = TABLE ? wxt[min(ub + u, i1 - i0) * SPLAT_THREADS + tid] : column_weight(min(i, i1));
-        if(i > i1) wx = 0.0f;
-        const float zf = cell[u].x;
-        const int zi = __float_as_int(cell[u].y);
-        const float num = wx * wy * 100.0f;
-        const float contrib = fast_div ? div_by(num, is2) : num / s2; // (1-xf)*(1-yf)*100/s2 and its three siblings
-        acc[zi * SPLAT_THREADS + tid] += (contrib * (1.0f - zf));
-        acc[(zi + 1) * SPLAT_THREADS + tid] += (contrib * zf);
-      }
+      const int i = i0 + ub + u;
+      float wx = TABLE ? wxt[min(ub + u, i1 - i0) * SPLAT_THREADS + tid] : column_weight(min(i, i1));
+      if(i > i1) wx = 0.0f;
+      const float num = wx * wy * 100.0f;
+      contrib[u] = FAST_DIV ? div_by(num, is2) : num / s2; // (1-xf)*(1-yf)*100/s2 and its three siblings
     }
+  };
+  auto fetch = [&](float2(&cell)[16], const int j, const int ub) {
+    const float2 *const rowp = zc + (size_t)(j - row_lo) * b.width;
+#pragma unroll
+    for(int u = 0; u < 16; u++)
+    {
+      // a relaxed atomic load of wavefront scope IS the plain global_load_dwordx2 -- and stays where it is written: the compiler
+      // sinks an ordinary load of read-only memory towards its first use (the NEXT round's additions), across any barrier it is given
+      const unsigned long long bits = __hip_atomic_load((const unsigned long long *)(rowp + min(i0 + ub + u, i1)), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
+      cell[u] = make_float2(__uint_as_float((unsigned)bits), __uint_as_float((unsigned)(bits >> 32)));
+    }
+  };
+  auto add = [&](const float2(&cell)[16], const float(&contrib)[16]) {
+#pragma unroll
+    for(int u = 0; u < 16; u++)
+    {
+      const float zf = cell[u].x;
+      const int zi = __float_as_int(cell[u].y);
+      acc[zi * SPLAT_THREADS + tid] += (contrib[u] * (1.0f - zf));
+      acc[(zi + 1) * SPLAT_THREADS + tid] += (contrib[u] * zf);
+    }
+  };
+  // the block behind (j, ub) in the walk; j > j1: none
+  auto advance = [&](int &j, int &ub, float &wy) {
+    ub += 16;
+    if(ub >= span)
+    {
+      ub = 0;
+      j = next_row(j + 1, wy);
+    }
+  };
+  // One walk over blocks of 16 columns, row after row.  A block's (zf, zi) pairs are fetched while the block before it is added (two
+  // sets of registers, the loop unrolled by two so that no set is copied): the walk is one chain of LDS round trips (a cell's
+  // contributions meet in pixel order), and a fetch at the head of every block put a round trip to memory into it every sixteen pixels.
+  float wy = 0.0f;
+  int j = next_row(j0, wy), ub = 0;
+  float2 cell_a[16], cell_b[16];
+  float contrib[16];
+  if(j <= j1) fetch(cell_a, j, 0);
+  while(j <= j1)
+  {
+    contributions(contrib, wy, ub);
+    advance(j, ub, wy);
+    // (behind the last block: any row of the footprint, unconditionally -- with the fetch under a branch the compiler's wait-count
+    // pass takes the path without it and drains every fetch in flight before the additions use the block fetched a round before)
+    fetch(cell_b, min(j, j1), ub);
+    __builtin_amdgcn_sched_barrier(0); // the fetches are ISSUED here (left to itself the compiler sinks them behind the additions)
+    add(cell_a, contrib);
+    if(j > j1) break;
+    contributions(contrib, wy, ub);
+    advance(j, ub, wy);
+    fetch(cell_a, min(j, j1), ub);
+    __builtin_amdgcn_sched_barrier(0);
+    add(cell_b, contrib);
   }
   if(live)
   {
@@ -385,12 +440,18 @@ int bilat_splat_rows(int devid, const grid_t &b, float *buf, const float4 *in_ro
     // div_by()'s premise: numerators are 0 or >= 2^-46 * 100 (two fractions of at least one ulp of a grid coordinate
     // below 2^12 each), so with sigma_s^2 inside [2^-3, 2^40] every quotient is a normal number far from either end
     const float s2 = b.sigma_s * b.sigma_s;
-    const int fast_div = s2 >= 0.125f && s2 <= 1099511627776.0f;
+    const bool fast_div = s2 >= 0.125f && s2 <= 1099511627776.0f;
     const dim3 grid((b.size_x + SPLAT_THREADS - 1) / SPLAT_THREADS, b.size_y);
     if(cells + table <= 64 * 1024)
-      bilat_splat2<true><<<grid, SPLAT_THREADS, cells + table, s>>>(zc, buf, b, row_lo, row_hi, accumulate, fast_div);
+    {
+      if(fast_div) bilat_splat2<true, true><<<grid, SPLAT_THREADS, cells + table, s>>>(zc, buf, b, row_lo, row_hi, accumulate);
+      else bilat_splat2<true, false><<<grid, SPLAT_THREADS, cells + table, s>>>(zc, buf, b, row_lo, row_hi, accumulate);
+    }
     else
-      bilat_splat2<false><<<grid, SPLAT_THREADS, cells, s>>>(zc, buf, b, row_lo, row_hi, accumulate, fast_div);
+    {
+      if(fast_div) bilat_splat2<false, true><<<grid, SPLAT_THREADS, cells, s>>>(zc, buf, b, row_lo, row_hi, accumulate);
+      else bilat_splat2<false, false><<<grid, SPLAT_THREADS, cells, s>>>(zc, buf, b, row_lo, row_hi, accumulate);
+    }
   }
   if(!zc_pre) dt_hip_release_mem_object(zc); // stream-ordered
   return DT_HIP_SUCCESS;
