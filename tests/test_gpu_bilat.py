@@ -1,6 +1,8 @@
 """-m gpu: local contrast, bilateral-grid mode, bit for bit against the oracle (= the reference on
 one thread: its splat sums per OpenMP slice, see oracle/src/bilat.c) and within rounding of the
 reference at its default thread count."""
+import math
+
 import numpy as np
 import pytest
 
@@ -47,6 +49,21 @@ def test_bilat(w, h, ss, sr, detail):
         r = np.zeros_like(img)
         assert ck.call(ref, "ref_bilat", piece, d, img, r) == 0
         assert float(np.abs(r[..., 0] - got[..., 0]).max()) < 1e-3
+
+
+@pytest.mark.parametrize("sr,cells", [(60.0, 5), (25.0, 5), (20.0, 6), (16.0, 7), (14.0, 8), (12.5, 9), (11.0, 10)])
+@pytest.mark.parametrize("w,h,ss", [(700, 500, 12.0), (1500, 1000, 50.0)])
+def test_bilat_lightness_axes(w, h, ss, sr, cells):
+    """grids of 5 .. 10 lightness cells (dt_bilateral_grid_size() allows no fewer than 4 intervals), the image with lightness below
+    0 and above 100 -- the clamped ends of the axis: the same words as the oracle"""
+    img = _lab_image(w, h, 37)
+    d = abi.BilatData.bilateral(ss, sr, 0.45)
+    piece = abi.Piece.make(w, h)
+    assert int(math.ceil(100.0 / (100.0 / max(4, round(100.0 / sr))))) + 1 in (cells, cells + 1)
+    got = hc.run_hip("dt_hip_iop_bilat_process", piece, d, img, img.shape)
+    want = np.zeros_like(img)
+    assert ck.call(ck.oracle(), "oracle_bilat", piece, d, img, want) == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 @pytest.mark.parametrize("w,h,ss,sr", [(300, 200, 8.0, 5.0), (123, 457, 0.3, 2.0), (1500, 1000, 50.0, 25.0), (640, 480, 160.0, 25.0)])
