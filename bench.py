@@ -1041,6 +1041,8 @@ def main():
                     e["sclk_mhz"] = clk
                     e["valu_frac_at_sustained_clock"] = round(floor * 2400.0 / clk / v["ms_avg"], 4)
             per_kernel[k] = e
+        # (denoise (profiled)'s wavelets likewise since round 6: the decompositions of bands 1 .. store their coarse plane only -- 16 B/px
+        # less than SURVEY 8d's 48 each -- and dn_finish forms the details from consecutive coarse planes, reading the same nine planes)
         # diffuse or sharpen as a pair: the analysis stores ONE plane per scale (the PDE forms the detail from two low-pass
         # planes where it reads them), so its launches move 16 B/px less and the PDE's 16 more than SURVEY 8d's per-stage credit
         if "diffuse_pde" in per_kernel and "diffuse_decompose" in per_kernel \
