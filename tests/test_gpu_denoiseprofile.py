@@ -20,6 +20,11 @@ CASES = [
     (dict(color_mode=abi.DT_HIP_DENOISEPROFILE_RGB, wb_adaptive=False, strength=1.7, shadows=0.6, bias=-3.0), (1000, 700)),
     (dict(wb=(0.0, 0.0, 0.0, 0.0), strength=0.4), (257, 259)),
     (dict(force=[[0.5, 0.6, 0.7, 0.4, 0.3, 0.8, 0.2]] * 6), (1536, 1100)),   # 7 bands, uneven force curves
+    # one, two and three bands: the synthesis forms the details of bands 1 .. from consecutive coarse planes (round 6), and with a
+    # single band its residue is that band's coarse plane
+    (dict(), (24, 20)),
+    (dict(color_mode=abi.DT_HIP_DENOISEPROFILE_RGB), (40, 30)),
+    (dict(use_new_vst=False), (64, 48)),
 ]
 
 
