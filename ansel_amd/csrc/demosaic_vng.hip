@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void vng_main(const float4 *__restrict__ lin, 
   if(row >= 2 && col >= 2 && row < height - 2 && col < width - 2)
   {
     const vng_code &code = codes[((row + ry) & 7) * 2 + ((col + rx) & 1)];
-    float gval[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    float grad[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     for(int t = 0; t < code.nterms; t++)
     {
       const vng_term tm = code.terms[t];
@@ -135,25 +135,25 @@ __global__ __launch_bounds__(256) void vng_main(const float4 *__restrict__ lin, 
       const float diff = fabsf(a - b) * (float)tm.weight;
 #pragma unroll
       for(int g = 0; g < 8; g++)
-        if(tm.grads & (1 << g)) gval[g] += diff;
+        if(tm.grads & (1 << g)) grad[g] += diff;
     }
-    float gmin = gval[0], gmax = gval[0];
+    float grad_lo = grad[0], grad_hi = grad[0];
 #pragma unroll
     for(int g = 1; g < 8; g++)
     {
-      if(gmin > gval[g]) gmin = gval[g];
-      if(gmax < gval[g]) gmax = gval[g];
+      if(grad_lo > grad[g]) grad_lo = grad[g];
+      if(grad_hi < grad[g]) grad_hi = grad[g];
     }
-    if(!(gmax == 0)) // `if(gmax == 0) keep the linear interpolation`, :151-155 (a NaN maximum goes on)
+    if(!(grad_hi == 0)) // `if(grad_hi == 0) keep the linear interpolation`, :151-155 (a NaN maximum goes on)
     {
-      const float thold = gmin + (gmax * 0.5f);
+      const float cut = grad_lo + (grad_hi * 0.5f);
       const int color = fc(row + ry, col + rx, filters4);
       const float own = chan(px, color);
       float sum[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
       int num = 0;
 #pragma unroll
       for(int g = 0; g < 8; g++)
-        if(gval[g] <= thold)
+        if(grad[g] <= cut)
         {
           const vng_hood hd = code.hood[g];
           const float4 q = lin[idx + (ptrdiff_t)hd.y * width + hd.x];

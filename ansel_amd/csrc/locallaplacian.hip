@@ -4,7 +4,7 @@
 // has no preview boundary), called from process(), src/iop/bilat.c:352-357.  (OpenCL twin:
 // locallaplaciancl.c; same stages.)
 //
-// L / 100 is padded by 2^last_level on every side; six copies go through the tone curve centred on six
+// L / 100 is padded by 2^top_level on every side; six copies go through the tone curve centred on six
 // grey levels and become Gaussian pyramids; the output pyramid is assembled coarse to fine from the
 // Laplacian coefficients of the two curves bracketing the local grey level.  Every stage is a pure
 // per-pixel function of the planes written by earlier stages -- the reference's "compute the interior,
@@ -34,34 +34,34 @@ __device__ __forceinline__ int clampi(const int v, const int lo, const int hi) {
 // ll_expand_gaussian(), locallaplacian.c:80-118; binary64 where the reference has double literals
 __device__ __forceinline__ float expand_at(const float *__restrict__ c, const int i, const int j, const int wd)
 {
-  const int cw = (wd - 1) / 2 + 1;
-  const int ind = (j / 2) * cw + i / 2;
+  const int half_w = (wd - 1) / 2 + 1;
+  const int at = (j / 2) * half_w + i / 2;
   switch((i & 1) + 2 * (j & 1))
   {
     case 0:
       return (float)(4. / 256.
-                     * (double)(6.0f * (c[ind - cw] + c[ind - 1] + 6.0f * c[ind] + c[ind + 1] + c[ind + cw]) + c[ind - cw - 1]
-                                + c[ind - cw + 1] + c[ind + cw - 1] + c[ind + cw + 1]));
+                     * (double)(6.0f * (c[at - half_w] + c[at - 1] + 6.0f * c[at] + c[at + 1] + c[at + half_w]) + c[at - half_w - 1]
+                                + c[at - half_w + 1] + c[at + half_w - 1] + c[at + half_w + 1]));
     case 1:
       return (float)(4. / 256.
-                     * (24.0 * (double)(c[ind] + c[ind + 1])
-                        + 4.0 * (double)(c[ind - cw] + c[ind - cw + 1] + c[ind + cw] + c[ind + cw + 1])));
+                     * (24.0 * (double)(c[at] + c[at + 1])
+                        + 4.0 * (double)(c[at - half_w] + c[at - half_w + 1] + c[at + half_w] + c[at + half_w + 1])));
     case 2:
       return (float)(4. / 256.
-                     * (24.0 * (double)(c[ind] + c[ind + cw])
-                        + 4.0 * (double)(c[ind - 1] + c[ind + 1] + c[ind + cw - 1] + c[ind + cw + 1])));
-    default: return .25f * (c[ind] + c[ind + 1] + c[ind + cw] + c[ind + cw + 1]);
+                     * (24.0 * (double)(c[at] + c[at + half_w])
+                        + 4.0 * (double)(c[at - 1] + c[at + 1] + c[at + half_w - 1] + c[at + half_w + 1])));
+    default: return .25f * (c[at] + c[at + 1] + c[at + half_w] + c[at + half_w + 1]);
   }
 }
 
 // ll_pad_input(), replication branch, :262-273
 __global__ __launch_bounds__(256) void ll_pad(const float4 *__restrict__ in, float *__restrict__ padded, const int wd,
-                                              const int ht, const int w, const int h, const int max_supp)
+                                              const int ht, const int w, const int h, const int support)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= (size_t)w * h) return;
   const int j = (int)(k / w), i = (int)(k - (size_t)j * w);
-  const int sj = clampi(j - max_supp, 0, ht - 1), si = clampi(i - max_supp, 0, wd - 1);
+  const int sj = clampi(j - support, 0, ht - 1), si = clampi(i - support, 0, wd - 1);
   padded[k] = in[(size_t)sj * wd + si].x * 0.01f;
 }
 
@@ -98,13 +98,13 @@ struct planes6
 
 // apply_curve(), :328-351, for the six grey levels (blockIdx.z)
 __global__ __launch_bounds__(256) void ll_curve(const float *__restrict__ padded, const planes6 out, const int w, const int h,
-                                                const int max_supp, const float sigma, const float shadows,
+                                                const int support, const float sigma, const float shadows,
                                                 const float highlights, const float clarity)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= (size_t)w * h) return;
   const int j = (int)(k / w), i = (int)(k - (size_t)j * w);
-  const int sj = clampi(j, max_supp, h - max_supp - 1), si = clampi(i, max_supp, w - max_supp - 1);
+  const int sj = clampi(j, support, h - support - 1), si = clampi(i, support, w - support - 1);
   const float g = ((float)blockIdx.z + .5f) / (float)LL_NUM_GAMMA;
   out.p[blockIdx.z][k] = curve(padded[(size_t)sj * w + si], g, sigma, shadows, highlights, clarity);
 }
@@ -112,11 +112,11 @@ __global__ __launch_bounds__(256) void ll_curve(const float *__restrict__ padded
 // gauss_reduce() + ll_fill_boundary1(), :173-200, :121-131; blockIdx.z selects one of up to six planes
 __global__ __launch_bounds__(256) void ll_reduce(const planes6 in, const planes6 coarse, const int wd, const int ht)
 {
-  const int cw = (wd - 1) / 2 + 1, ch = (ht - 1) / 2 + 1;
+  const int half_w = (wd - 1) / 2 + 1, half_h = (ht - 1) / 2 + 1;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if(k >= (size_t)cw * ch) return;
-  const int jj0 = (int)(k / cw), ii0 = (int)(k - (size_t)jj0 * cw);
-  const int j = clampi(jj0, 1, ch - 2), i = clampi(ii0, 1, cw - 2);
+  if(k >= (size_t)half_w * half_h) return;
+  const int jj0 = (int)(k / half_w), ii0 = (int)(k - (size_t)jj0 * half_w);
+  const int j = clampi(jj0, 1, half_h - 2), i = clampi(ii0, 1, half_w - 2);
   const float *__restrict__ src = in.p[blockIdx.z];
   float acc = 0.0f;
 #pragma unroll
@@ -170,13 +170,13 @@ __global__ __launch_bounds__(256) void ll_assemble(const assemble_args a)
 // :524-530 (alpha is not written)
 __global__ __launch_bounds__(256) void ll_finish(const float4 *__restrict__ in, float *__restrict__ out,
                                                  const float *__restrict__ level0, const int wd, const int ht, const int w,
-                                                 const int max_supp)
+                                                 const int support)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= (size_t)wd * ht) return;
   const int j = (int)(k / wd), i = (int)(k - (size_t)j * wd);
   const float4 px = in[k];
-  out[4 * k + 0] = 100.0f * level0[(size_t)(j + max_supp) * w + max_supp + i];
+  out[4 * k + 0] = 100.0f * level0[(size_t)(j + support) * w + support + i];
   out[4 * k + 1] = px.y;
   out[4 * k + 2] = px.z;
 }
@@ -193,20 +193,20 @@ int local_laplacian_launch(int devid, const float4 *in, float4 *out, int wd, int
   const int m = wd < ht ? wd : ht;
   const int nl = 31 - __builtin_clz((unsigned)m);
   const int num_levels = nl < LL_MAX_LEVELS ? nl : LL_MAX_LEVELS;
-  const int last_level = num_levels - 1;
-  if(last_level < 1)
+  const int top_level = num_levels - 1;
+  if(top_level < 1)
   {
     set_last_error("local laplacian: frame too small for a pyramid");
     return DT_HIP_INVALID_ARG;
   }
-  const int max_supp = 1 << last_level;
-  const int w = 2 * max_supp + wd, h = 2 * max_supp + ht;
+  const int support = 1 << top_level;
+  const int w = 2 * support + wd, h = 2 * support + ht;
   float *padded[LL_MAX_LEVELS] = { nullptr }, *output[LL_MAX_LEVELS] = { nullptr }, *buf[LL_NUM_GAMMA][LL_MAX_LEVELS] = { { nullptr } };
   bool ok = true;
-  for(int l = 0; l <= last_level; l++)
+  for(int l = 0; l <= top_level; l++)
   {
     const size_t bytes = (size_t)dl(w, l) * dl(h, l) * sizeof(float);
-    if(l < last_level) ok &= (padded[l] = (float *)dt_hip_alloc_device_buffer(devid, bytes)) != nullptr;
+    if(l < top_level) ok &= (padded[l] = (float *)dt_hip_alloc_device_buffer(devid, bytes)) != nullptr;
     ok &= (output[l] = (float *)dt_hip_alloc_device_buffer(devid, bytes)) != nullptr;
     for(int k = 0; k < LL_NUM_GAMMA; k++) ok &= (buf[k][l] = (float *)dt_hip_alloc_device_buffer(devid, bytes)) != nullptr;
   }
@@ -216,14 +216,14 @@ int local_laplacian_launch(int devid, const float4 *in, float4 *out, int wd, int
   {
     {
       launch_scope ls(devid, "ll_pad");
-      ll_pad<<<pixel_grid((size_t)w * h), 256, 0, s>>>(in, padded[0], wd, ht, w, h, max_supp);
+      ll_pad<<<pixel_grid((size_t)w * h), 256, 0, s>>>(in, padded[0], wd, ht, w, h, support);
     }
     {
       // Gaussian pyramid of the padded input; its coarsest level seeds the output pyramid, :405-407
       launch_scope ls(devid, "ll_reduce");
-      for(int l = 1; l <= last_level; l++)
+      for(int l = 1; l <= top_level; l++)
       {
-        planes6 src = { { padded[l - 1] } }, dst = { { l < last_level ? padded[l] : output[last_level] } };
+        planes6 src = { { padded[l - 1] } }, dst = { { l < top_level ? padded[l] : output[top_level] } };
         const size_t n = (size_t)dl(w, l) * dl(h, l);
         ll_reduce<<<dim3(pixel_grid(n), 1, 1), 256, 0, s>>>(src, dst, dl(w, l - 1), dl(h, l - 1));
       }
@@ -232,12 +232,12 @@ int local_laplacian_launch(int devid, const float4 *in, float4 *out, int wd, int
       launch_scope ls(devid, "ll_curve");
       planes6 dst;
       for(int k = 0; k < LL_NUM_GAMMA; k++) dst.p[k] = buf[k][0];
-      ll_curve<<<dim3(pixel_grid((size_t)w * h), 1, LL_NUM_GAMMA), 256, 0, s>>>(padded[0], dst, w, h, max_supp, sigma, shadows,
+      ll_curve<<<dim3(pixel_grid((size_t)w * h), 1, LL_NUM_GAMMA), 256, 0, s>>>(padded[0], dst, w, h, support, sigma, shadows,
                                                                               highlights, clarity);
     }
     {
       launch_scope ls(devid, "ll_reduce");
-      for(int l = 1; l <= last_level; l++)
+      for(int l = 1; l <= top_level; l++)
       {
         planes6 src, dst;
         for(int k = 0; k < LL_NUM_GAMMA; k++)
@@ -251,7 +251,7 @@ int local_laplacian_launch(int devid, const float4 *in, float4 *out, int wd, int
     }
     {
       launch_scope ls(devid, "ll_assemble");
-      for(int l = last_level - 1; l >= 0; l--)
+      for(int l = top_level - 1; l >= 0; l--)
       {
         assemble_args a;
         a.padded = padded[l];
@@ -269,11 +269,11 @@ int local_laplacian_launch(int devid, const float4 *in, float4 *out, int wd, int
     }
     {
       launch_scope ls(devid, "ll_finish");
-      ll_finish<<<pixel_grid((size_t)wd * ht), 256, 0, s>>>(in, (float *)out, output[0], wd, ht, w, max_supp);
+      ll_finish<<<pixel_grid((size_t)wd * ht), 256, 0, s>>>(in, (float *)out, output[0], wd, ht, w, support);
     }
     err = check_launch("local laplacian");
   }
-  for(int l = 0; l <= last_level; l++)
+  for(int l = 0; l <= top_level; l++)
   {
     if(padded[l]) dt_hip_release_mem_object(padded[l]);
     if(output[l]) dt_hip_release_mem_object(output[l]);

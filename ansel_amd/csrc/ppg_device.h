@@ -48,9 +48,10 @@ __device__ __forceinline__ bool ring_lt(const ppg_ctx &k, const int j, const int
 template <bool CLAMP> __device__ void ppg_pass1(const ppg_ctx &k, const int j, const int i, float rgb[3])
 {
   float sum[4] = { 0.f, 0.f, 0.f, 0.f }, cnt[4] = { 0.f, 0.f, 0.f, 0.f };
-  for(int y = j - 1; y != j + 2; y++)
-    for(int x = i - 1; x != i + 2; x++)
+  for(int dy = -1; dy <= 1; dy++)
+    for(int dx = -1; dx <= 1; dx++)
     {
+      const int y = j + dy, x = i + dx;
       const int yy = y + k.oy, xx = x + k.ox;
       if(yy >= 0 && xx >= 0 && yy < k.ih && xx < k.iw)
       {
@@ -74,19 +75,26 @@ template <bool CLAMP> __device__ void ppg_pass1(const ppg_ctx &k, const int j, c
 // pass 2 green at a red/blue site: ppg.c:83-115 / rcd.c:146-187
 template <bool CLAMP> __device__ float ppg_pass2_green(const ppg_ctx &k, const int j, const int i)
 {
-  const float pc = bs<CLAMP>(k, j, i);
-  const float pym = bs<CLAMP>(k, j - 1, i), pym2 = bs<CLAMP>(k, j - 2, i), pym3 = bs<CLAMP>(k, j - 3, i);
-  const float pyM = bs<CLAMP>(k, j + 1, i), pyM2 = bs<CLAMP>(k, j + 2, i), pyM3 = bs<CLAMP>(k, j + 3, i);
-  const float pxm = bs<CLAMP>(k, j, i - 1), pxm2 = bs<CLAMP>(k, j, i - 2), pxm3 = bs<CLAMP>(k, j, i - 3);
-  const float pxM = bs<CLAMP>(k, j, i + 1), pxM2 = bs<CLAMP>(k, j, i + 2), pxM3 = bs<CLAMP>(k, j, i + 3);
-  const float guessx = (pxm + pc + pxM) * 2.0f - pxM2 - pxm2;
-  const float diffx = (fabsf(pxm2 - pc) + fabsf(pxM2 - pc) + fabsf(pxm - pxM)) * 3.0f
-                      + (fabsf(pxM3 - pxM) + fabsf(pxm3 - pxm)) * 2.0f;
-  const float guessy = (pym + pc + pyM) * 2.0f - pyM2 - pym2;
-  const float diffy = (fabsf(pym2 - pc) + fabsf(pyM2 - pc) + fabsf(pym - pyM)) * 3.0f
-                      + (fabsf(pyM3 - pyM) + fabsf(pym3 - pym)) * 2.0f;
-  if(diffx > diffy) return fmaxf(fminf(guessy * .25f, fmaxf(pym, pyM)), fminf(pym, pyM));
-  return fmaxf(fminf(guessx * .25f, fmaxf(pxm, pxM)), fminf(pxm, pxM));
+  // per axis: the second-difference estimate of green from the three samples either side of the site, and how busy the axis is;
+  // the quieter axis' estimate (a quarter of it), held between its two nearest greens
+  const float centre = bs<CLAMP>(k, j, i);
+  struct axis_t
+  {
+    float estimate, activity, lo, hi;
+  };
+  auto along = [&](const int dj, const int di) {
+    const float b1 = bs<CLAMP>(k, j - dj, i - di), b2 = bs<CLAMP>(k, j - 2 * dj, i - 2 * di), b3 = bs<CLAMP>(k, j - 3 * dj, i - 3 * di);
+    const float a1 = bs<CLAMP>(k, j + dj, i + di), a2 = bs<CLAMP>(k, j + 2 * dj, i + 2 * di), a3 = bs<CLAMP>(k, j + 3 * dj, i + 3 * di);
+    axis_t r;
+    r.estimate = (b1 + centre + a1) * 2.0f - a2 - b2;
+    r.activity = (fabsf(b2 - centre) + fabsf(a2 - centre) + fabsf(b1 - a1)) * 3.0f + (fabsf(a3 - a1) + fabsf(b3 - b1)) * 2.0f;
+    r.lo = fminf(b1, a1);
+    r.hi = fmaxf(b1, a1);
+    return r;
+  };
+  const axis_t rows = along(1, 0), cols = along(0, 1);
+  const axis_t &quiet = cols.activity > rows.activity ? rows : cols;
+  return fmaxf(fminf(quiet.estimate * .25f, quiet.hi), quiet.lo);
 }
 
 // channel c (native colour or green) of pixel (j,i) after passes 1-2

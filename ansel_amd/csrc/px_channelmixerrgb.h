@@ -75,9 +75,8 @@ __device__ __forceinline__ f3 gamut_mapping(const f3 input, const float compress
   if(!(sum > 0.f && Y > 0.f)) return { 0.f, 0.f, 0.f };
   float x = input.x / sum;
   float y = input.y / sum;
-  const float uv_denominator = -2.f * x + 12.f * y + 3.f;
-  float u = 4.f * x / uv_denominator;
-  float v = 9.f * y / uv_denominator;
+  const float to_uv = -2.f * x + 12.f * y + 3.f;
+  float u = 4.f * x / to_uv, v = 9.f * y / to_uv; // CIE 1976 u'v' of the chromaticity
   const float D50u = 0.20915914598542354f, D50v = 0.488075320769787f;
   const float du = D50u - u, dv = D50v - v;
   const float Delta = Y * (du * du + dv * dv);
@@ -86,20 +85,18 @@ __device__ __forceinline__ f3 gamut_mapping(const f3 input, const float compress
   const float tmp_v = __builtin_fmaf(correction, dv, v);
   u = (u > D50u) ? fmaxf(tmp_u, D50u) : fminf(tmp_u, D50u);
   v = (v > D50v) ? fmaxf(tmp_v, D50v) : fminf(tmp_v, D50v);
-  const float xy_denominator = 6.f * u - 16.f * v + 12.f;
-  x = 9.f * u / xy_denominator;
-  y = 4.f * v / xy_denominator;
+  const float to_xy = 6.f * u - 16.f * v + 12.f;
+  x = 9.f * u / to_xy, y = 4.f * v / to_xy; // and back
   if(CLIP)
   {
-    x = fmaxf(x, 0.0f);
-    y = fmaxf(y, 0.0f);
+    x = fmaxf(x, 0.0f), y = fmaxf(y, 0.0f);
   }
   y = fmaxf(y, NORM_MIN);
-  const float scale = x + y;
-  if(scale >= 1.f)
+  const float xy_sum = x + y;
+  if(xy_sum >= 1.f)
   {
-    x /= scale;
-    y /= scale;
+    x /= xy_sum;
+    y /= xy_sum;
   }
   return { Y * x / y, Y, Y * (1.f - x - y) / y };
 }
@@ -117,28 +114,28 @@ __device__ __forceinline__ f3 luma_chroma(const f3 in, const float sat[3], const
   mix += in.z * light[2];
   if(version == 2) norm *= INVERSE_SQRT_3;
   float o[3] = { in.x / norm, in.y / norm, in.z / norm };
-  float coeff_ratio = 0.f;
+  float desat = 0.f;
   if(version == 0)
   {
 #pragma unroll
-    for(int c = 0; c < 3; c++) coeff_ratio += (1.0f - o[c]) * (1.0f - o[c]) * sat[c];
+    for(int c = 0; c < 3; c++) desat += (1.0f - o[c]) * (1.0f - o[c]) * sat[c];
   }
   else
   {
     float sp = 0.f;
 #pragma unroll
     for(int c = 0; c < 3; c++) sp += o[c] * sat[c];
-    coeff_ratio = sp / 3.f;
+    desat = sp / 3.f;
   }
 #pragma unroll
   for(int c = 0; c < 3; c++)
   {
-    const float min_ratio = (o[c] < 0.0f) ? o[c] : 0.0f;
-    const float output_inverse = 1.0f - o[c];
-    o[c] = fmaxf(__builtin_fmaf(output_inverse, coeff_ratio, o[c]), min_ratio);
+    const float floor_c = (o[c] < 0.0f) ? o[c] : 0.0f;
+    const float headroom = 1.0f - o[c];
+    o[c] = fmaxf(__builtin_fmaf(headroom, desat, o[c]), floor_c);
   }
   if(version == 2) norm /= enorm({ o[0], o[1], o[2] }) * INVERSE_SQRT_3;
-  norm *= fmaxf(1.f + mix / avg, 0.f);
+  norm *= fmaxf(mix / avg + 1.f, 0.f);
   return { o[0] * norm, o[1] * norm, o[2] * norm };
 }
 

@@ -106,9 +106,9 @@ __device__ __forceinline__ v4 pipe_RGB_to_Ych(const v4 in, const m3 &M)
   const float r = Yrg.y - 0.21902143f;
   const float g = Yrg.z - 0.54371398f;
   const float c = sqrtf(g * g + r * r); // dt_fast_hypotf(g, r)
-  const float cos_h = c != 0.f ? r / c : 1.f;
-  const float sin_h = c != 0.f ? g / c : 0.f;
-  return { Yrg.x, c, cos_h, sin_h };
+  const float hc = c != 0.f ? r / c : 1.f;
+  const float hs = c != 0.f ? g / c : 0.f;
+  return { Yrg.x, c, hc, hs };
 }
 
 __device__ __forceinline__ v4 Ych_to_pipe_RGB(const v4 in, const m3 &M)
@@ -243,32 +243,32 @@ __device__ __forceinline__ v4 norm_tone_mapping_v4(const v4 p, const int type, c
 // ---- gamut mapping ----------------------------------------------------------------------------
 __device__ __forceinline__ v4 filmic_desaturate_v4(const v4 Yo, v4 Yf, const float saturation)
 {
-  const float chroma_original = Yo.y * Yo.x;
-  float chroma_final = Yf.y * Yf.x;
-  const float delta_chroma = saturation * (chroma_original - chroma_final);
-  const bool filmic_brightens = (Yf.x > Yo.x);
-  const bool filmic_resat = (chroma_original < chroma_final);
-  const bool filmic_desat = (chroma_original > chroma_final);
-  const bool user_resat = (saturation > 0.f);
-  const bool user_desat = (saturation < 0.f);
-  chroma_final = (filmic_brightens && filmic_resat) ? (chroma_original + chroma_final) / 2.f
-                 : ((user_resat && filmic_desat) || user_desat) ? chroma_final + delta_chroma
-                                                                : chroma_final;
-  Yf.y = fmaxf(chroma_final / Yf.x, 0.f);
+  const float chroma_in = Yo.y * Yo.x;
+  float chroma_out = Yf.y * Yf.x;
+  const float chroma_shift = saturation * (chroma_in - chroma_out);
+  const bool curve_brightens = (Yf.x > Yo.x);
+  const bool curve_resat = (chroma_in < chroma_out);
+  const bool curve_desat = (chroma_in > chroma_out);
+  const bool asked_resat = (saturation > 0.f);
+  const bool asked_desat = (saturation < 0.f);
+  chroma_out = (curve_brightens && curve_resat) ? (chroma_in + chroma_out) / 2.f
+                 : ((asked_resat && curve_desat) || asked_desat) ? chroma_out + chroma_shift
+                                                                : chroma_out;
+  Yf.y = fmaxf(chroma_out / Yf.x, 0.f);
   return Yf;
 }
 
 __device__ __forceinline__ float clip_chroma_white_raw(const float c[3], const float target_white, const float Y,
-                                                       const float cos_h, const float sin_h)
+                                                       const float hc, const float hs)
 {
-  const float denominator_Y_coeff = c[0] * (0.979381443298969f * cos_h + 0.391752577319588f * sin_h)
-                                    + c[1] * (0.0206185567010309f * cos_h + 0.608247422680412f * sin_h)
-                                    - c[2] * (cos_h + sin_h);
-  const float denominator_target_term = target_white * (0.68285981628866f * cos_h + 0.482137060515464f * sin_h);
-  if(denominator_Y_coeff == 0.f) return FLT_MAX;
-  const float Y_asymptote = denominator_target_term / denominator_Y_coeff;
-  if(Y <= Y_asymptote) return FLT_MAX;
-  const float denominator = Y * denominator_Y_coeff - denominator_target_term;
+  const float y_slope = c[0] * (0.979381443298969f * hc + 0.391752577319588f * hs)
+                                    + c[1] * (0.0206185567010309f * hc + 0.608247422680412f * hs)
+                                    - c[2] * (hc + hs);
+  const float white_term = target_white * (0.68285981628866f * hc + 0.482137060515464f * hs);
+  if(y_slope == 0.f) return FLT_MAX;
+  const float y_pole = white_term / y_slope;
+  if(Y <= y_pole) return FLT_MAX;
+  const float denominator = Y * y_slope - white_term;
   const float numerator = -0.427506877216495f
                           * (Y * (c[0] + 0.856492345150334f * c[1] + 0.554995960637719f * c[2])
                              - 0.988237752433297f * target_white);
@@ -276,42 +276,42 @@ __device__ __forceinline__ float clip_chroma_white_raw(const float c[3], const f
 }
 
 __device__ __forceinline__ float clip_chroma_white(const float c[3], const float target_white, const float Y,
-                                                   const float cos_h, const float sin_h)
+                                                   const float hc, const float hs)
 {
   const float eps = 1e-3f;
   const float max_Y = CIE_Y_1931_to_CIE_Y_2006(target_white);
   const float delta_Y = max_(max_Y - Y, 0.f);
-  float max_chroma;
+  float limit_c;
   if(delta_Y < eps)
-    max_chroma = delta_Y / (eps * max_Y) * clip_chroma_white_raw(c, target_white, (1.f - eps) * max_Y, cos_h, sin_h);
+    limit_c = delta_Y / (eps * max_Y) * clip_chroma_white_raw(c, target_white, (1.f - eps) * max_Y, hc, hs);
   else
-    max_chroma = clip_chroma_white_raw(c, target_white, Y, cos_h, sin_h);
-  return max_chroma >= 0.f ? max_chroma : FLT_MAX;
+    limit_c = clip_chroma_white_raw(c, target_white, Y, hc, hs);
+  return limit_c >= 0.f ? limit_c : FLT_MAX;
 }
 
-__device__ __forceinline__ float clip_chroma_black(const float c[3], const float cos_h, const float sin_h)
+__device__ __forceinline__ float clip_chroma_black(const float c[3], const float hc, const float hs)
 {
-  const float denominator = c[0] * (0.979381443298969f * cos_h + 0.391752577319588f * sin_h)
-                            + c[1] * (0.0206185567010309f * cos_h + 0.608247422680412f * sin_h)
-                            - c[2] * (cos_h + sin_h);
+  const float denominator = c[0] * (0.979381443298969f * hc + 0.391752577319588f * hs)
+                            + c[1] * (0.0206185567010309f * hc + 0.608247422680412f * hs)
+                            - c[2] * (hc + hs);
   if(denominator == 0.f) return FLT_MAX;
   const float numerator = -0.427506877216495f * (c[0] + 0.856492345150334f * c[1] + 0.554995960637719f * c[2]);
-  const float max_chroma = numerator / denominator;
-  return max_chroma >= 0.f ? max_chroma : FLT_MAX;
+  const float limit_c = numerator / denominator;
+  return limit_c >= 0.f ? limit_c : FLT_MAX;
 }
 
-__device__ __forceinline__ float clip_chroma(const m3 &mo, const float target_white, const float Y, const float cos_h,
-                                             const float sin_h, const float chroma)
+__device__ __forceinline__ float clip_chroma(const m3 &mo, const float target_white, const float Y, const float hc,
+                                             const float hs, const float chroma)
 {
-  const float wr = clip_chroma_white(mo.r[0], target_white, Y, cos_h, sin_h);
-  const float wg = clip_chroma_white(mo.r[1], target_white, Y, cos_h, sin_h);
-  const float wb = clip_chroma_white(mo.r[2], target_white, Y, cos_h, sin_h);
-  const float max_chroma_white = min_(min_(wr, wg), wb);
-  const float br = clip_chroma_black(mo.r[0], cos_h, sin_h);
-  const float bg = clip_chroma_black(mo.r[1], cos_h, sin_h);
-  const float bb = clip_chroma_black(mo.r[2], cos_h, sin_h);
-  const float max_chroma_black = min_(min_(br, bg), bb);
-  return min_(min_(chroma, max_chroma_black), max_chroma_white);
+  const float wr = clip_chroma_white(mo.r[0], target_white, Y, hc, hs);
+  const float wg = clip_chroma_white(mo.r[1], target_white, Y, hc, hs);
+  const float wb = clip_chroma_white(mo.r[2], target_white, Y, hc, hs);
+  const float limit_white = min_(min_(wr, wg), wb);
+  const float br = clip_chroma_black(mo.r[0], hc, hs);
+  const float bg = clip_chroma_black(mo.r[1], hc, hs);
+  const float bb = clip_chroma_black(mo.r[2], hc, hs);
+  const float limit_black = min_(min_(br, bg), bb);
+  return min_(min_(chroma, limit_black), limit_white);
 }
 
 __device__ __forceinline__ v4 gamut_check_Yrg(const v4 Ych)
@@ -363,17 +363,17 @@ __device__ __forceinline__ v4 agx_compress_negatives(const v4 p, const float lum
   const float min_rgb = fminf(fminf(p.x, p.y), p.z);
   const float o0 = max_rgb - p.x, o1 = max_rgb - p.y, o2 = max_rgb - p.z;
   const float opponent_y = o0 * luma[0] + o1 * luma[1] + o2 * luma[2];
-  const float max_opponent = fmaxf(fmaxf(o0, o1), o2);
-  const float y_compensated = max_opponent - opponent_y + input_y;
+  const float o_max = fmaxf(fmaxf(o0, o1), o2);
+  const float y_target = o_max - opponent_y + input_y;
   const float offset = fmaxf(-min_rgb, 0.f);
   const v4 s = { p.x + offset, p.y + offset, p.z + offset, p.w + offset };
   const float max_shifted = fmaxf(fmaxf(s.x, s.y), s.z);
   const float q0 = max_shifted - s.x, q1 = max_shifted - s.y, q2 = max_shifted - s.z;
-  const float max_opponent_shifted = fmaxf(fmaxf(q0, q1), q2);
+  const float q_max = fmaxf(fmaxf(q0, q1), q2);
   const float y_opponent_shifted = q0 * luma[0] + q1 * luma[1] + q2 * luma[2];
   float y_new = s.x * luma[0] + s.y * luma[1] + s.z * luma[2];
-  y_new += max_opponent_shifted - y_opponent_shifted;
-  const float ratio = (y_new > y_compensated && y_new > 1e-6f) ? y_compensated / y_new : 1.f;
+  y_new += q_max - y_opponent_shifted;
+  const float ratio = (y_new > y_target && y_new > 1e-6f) ? y_target / y_new : 1.f;
   return { s.x * ratio, s.y * ratio, s.z * ratio, s.w * ratio };
 }
 
@@ -385,21 +385,21 @@ enum { MODE_AGX = 0, MODE_V5 = 1, MODE_SPLIT_V4 = 2, MODE_CHROMA_V4 = 3, MODE_SP
 // filmic_desaturate_v1(), filmicrgb.c:1163-1174
 __device__ __forceinline__ float filmic_desaturate_v1(const float x, const fargs &a)
 {
-  const float radius_toe = x;
-  const float radius_shoulder = 1.0f - x;
-  const float key_toe = ansel_math::expf_exact(-0.5f * radius_toe * radius_toe / a.sigma_toe);
-  const float key_shoulder = ansel_math::expf_exact(-0.5f * radius_shoulder * radius_shoulder / a.sigma_shoulder);
+  const float to_toe = x;
+  const float to_shoulder = 1.0f - x;
+  const float key_toe = ansel_math::expf_exact(-0.5f * to_toe * to_toe / a.sigma_toe);
+  const float key_shoulder = ansel_math::expf_exact(-0.5f * to_shoulder * to_shoulder / a.sigma_shoulder);
   return 1.0f - clamp_simd((key_toe + key_shoulder) / a.saturation);
 }
 
 // filmic_desaturate_v2(), filmicrgb.c:1178-1189
 __device__ __forceinline__ float filmic_desaturate_v2(const float x, const fargs &a)
 {
-  const float radius_toe = x;
-  const float radius_shoulder = 1.0f - x;
+  const float to_toe = x;
+  const float to_shoulder = 1.0f - x;
   const float sat2 = 0.5f / sqrtf(a.saturation);
-  const float key_toe = ansel_math::expf_exact(-radius_toe * radius_toe / a.sigma_toe * sat2);
-  const float key_shoulder = ansel_math::expf_exact(-radius_shoulder * radius_shoulder / a.sigma_shoulder * sat2);
+  const float key_toe = ansel_math::expf_exact(-to_toe * to_toe / a.sigma_toe * sat2);
+  const float key_shoulder = ansel_math::expf_exact(-to_shoulder * to_shoulder / a.sigma_shoulder * sat2);
   return (a.saturation - (key_toe + key_shoulder) * (a.saturation));
 }
 
@@ -486,14 +486,14 @@ template <int MODE> __device__ __forceinline__ float4 px_filmicrgb(const float4 
     rendering = RGB_tone_mapping_v4(rendering, a);
     const v4 pix_out = mat3(a.outset, rendering);
     v4 Yf = pipe_RGB_to_Ych(pix_out, a.input);
-    const float chroma_final = fminf(Yo.y, Yf.y);
-    const float r_mix = a.beta_hue * Yo.y * Yo.z + (1.f - a.beta_hue) * chroma_final * Yf.z;
-    const float g_mix = a.beta_hue * Yo.y * Yo.w + (1.f - a.beta_hue) * chroma_final * Yf.w;
+    const float chroma_out = fminf(Yo.y, Yf.y);
+    const float r_mix = a.beta_hue * Yo.y * Yo.z + (1.f - a.beta_hue) * chroma_out * Yf.z;
+    const float g_mix = a.beta_hue * Yo.y * Yo.w + (1.f - a.beta_hue) * chroma_out * Yf.w;
     const float norm_mix = sqrtf(g_mix * g_mix + r_mix * r_mix);
     v4 Yref = Yo;
     Yref.z = (norm_mix > 1e-9f) ? r_mix / norm_mix : Yo.z;
     Yref.w = (norm_mix > 1e-9f) ? g_mix / norm_mix : Yo.w;
-    Yf.y = chroma_final;
+    Yf.y = chroma_out;
     res = gamut_mapping(Yf, Yref, a, 0.f, EXPORT);
   }
   else if(MODE == MODE_V5)
