@@ -43,11 +43,10 @@ constexpr int HS = TS / 2;     // row length of a half-resolution plane
 constexpr int RCD_BORDER = 9;
 constexpr int RCD_MARGIN = 6;
 constexpr int TV = TS - 2 * RCD_BORDER;
-constexpr int W1 = TS, W2 = 2 * TS, W3 = 3 * TS, W4 = 4 * TS;
+[[maybe_unused]] constexpr int W1 = TS, W2 = 2 * TS, W3 = 3 * TS, W4 = 4 * TS; // (device code only)
 constexpr int NT = 896;        // 14 waves: 112*112 / 896 = 14 and 112*56 / 896 = 7 exactly
 constexpr int FULL_ITERS = TS * TS / NT;
 constexpr int HALF_ITERS = TS * HS / NT;
-constexpr size_t LDS_BYTES = sizeof(float) * (2 * TS * TS + 2 * TS * HS);
 
 #define EPS 1e-5f
 #define EPSSQ 1e-10f
