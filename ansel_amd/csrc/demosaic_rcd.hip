@@ -43,7 +43,7 @@ constexpr int HS = TS / 2;     // row length of a half-resolution plane
 constexpr int RCD_BORDER = 9;
 constexpr int RCD_MARGIN = 6;
 constexpr int TV = TS - 2 * RCD_BORDER;
-[[maybe_unused]] constexpr int W1 = TS, W2 = 2 * TS, W3 = 3 * TS, W4 = 4 * TS; // (device code only)
+[[maybe_unused]] constexpr int W1 = TS, W2 = 2 * TS, W3 = 3 * TS, W4 = 4 * TS; [[maybe_unused]] constexpr size_t LDS_BYTES = sizeof(float) * (2 * TS * TS + 2 * TS * HS); // (W*: device code only; LDS_BYTES: the measuring build's first kernel)
 constexpr int NT = 896;        // 14 waves: 112*112 / 896 = 14 and 112*56 / 896 = 7 exactly
 constexpr int FULL_ITERS = TS * TS / NT;
 constexpr int HALF_ITERS = TS * HS / NT;
