@@ -138,7 +138,19 @@ struct synth_args
   // decompositions of bands 1 .. write one plane instead of two (16 B/px less each) and two planes fewer are held.  The residue is the
   // last band's coarse plane: read once.  (Band 0's input is the transformed frame, which is never stored: its detail stays a plane.)
   const float4 *coarse0;
+  // the planes hold three floats a pixel, their fourth channel being +0 (the launches that wrote them were ALPHA0 ones: dn_decompose_strip P3)
+  int planes3;
+  // non-null: the launch runs only if the word is 0 (gate_sense 1) / is not 0 (gate_sense 2) -- the decompositions' alpha flag: the
+  // synthesis over the three-float planes, or the one over the four-channel sequence's planes (denoiseprofile_run())
+  const unsigned *gate;
+  int gate_sense;
 };
+__device__ __forceinline__ bool dn_gate_closed(const synth_args &sy)
+{
+  if(!sy.gate) return false;
+  const unsigned raised = *sy.gate;
+  return sy.gate_sense == 1 ? raised != 0u : raised == 0u;
+}
 
 // eaw_synthesize() with boost 1, eaw.c:157-175, for one band on the accumulator in registers
 __device__ __forceinline__ void synthesize_band(float4 &acc, const float4 d, const float *__restrict__ t)
@@ -162,11 +174,29 @@ __device__ __forceinline__ float4 dn_finish_pixel(const float4 *__restrict__ out
       // (uniform) branch a wave had ONE 16-byte fetch per lane in flight at a time, and eight waves per SIMD of that do
       // not cover the latency of 8 TB/s (a band the module does not have fetches the first one again)
       float4 d[BANDS];
+      float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if(sy.planes3) // uniform
+      {
 #pragma unroll
-      for(int b = 0; b < BANDS; b++) d[b] = sy.detail[b < sy.nbands ? b : 0][j];
+        for(int b = 0; b < BANDS; b++)
+        {
+          const float *const p3 = reinterpret_cast<const float *>(sy.detail[b < sy.nbands ? b : 0]) + 3 * j;
+          d[b] = make_float4(p3[0], p3[1], p3[2], 0.0f);
+        }
+        if(sy.coarse0)
+        {
+          const float *const p3 = reinterpret_cast<const float *>(sy.coarse0) + 3 * j;
+          c0 = make_float4(p3[0], p3[1], p3[2], 0.0f);
+        }
+      }
+      else
+      {
+#pragma unroll
+        for(int b = 0; b < BANDS; b++) d[b] = sy.detail[b < sy.nbands ? b : 0][j];
+        if(sy.coarse0) c0 = sy.coarse0[j];
+      }
       if(sy.coarse0)
       {
-        const float4 c0 = sy.coarse0[j];
         res = c0; // (the residue of a single band; else the last band's coarse plane, which d[] holds)
 #pragma unroll
         for(int b = 1; b < BANDS; b++)
@@ -243,6 +273,7 @@ __device__ __forceinline__ float4 dn_finish_pixel(const float4 *__restrict__ out
 __global__ __launch_bounds__(256) void dn_finish(float4 *__restrict__ out, const float4 *__restrict__ residue,
                                                  const size_t npix, const vst_args a, const synth_args sy)
 {
+  if(dn_gate_closed(sy)) return;
   ansel_math::stage_default_tables(threadIdx.x);
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one pixel per thread (pixel_grid)
   if(j < npix) nt_store(out + j, dn_finish_pixel(out, residue, j, a, sy));
@@ -268,6 +299,7 @@ __global__ __launch_bounds__(256) void dn_finish_chain(float4 *__restrict__ out,
 {
   const chain_args &c = kernarg_at<chain_args>((int)offsetof(dn_chain_kernargs, c));
   (void)c_by_value;
+  if(dn_gate_closed(sy)) return;
   ansel_math::stage_default_tables(threadIdx.x);
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(j < npix)
@@ -502,7 +534,11 @@ template <bool PRE, int MULT, bool ALPHA0> constexpr int dn_strip_waves()
   const int wgs = (160 * 1024) / lds;
   return wgs >= 8 ? 8 : (wgs < 1 ? 1 : wgs);
 }
-template <bool PRE, int MULT, bool ALPHA0>
+// P3 (ALPHA0 launches of the unsplit frame, round 6): the planes this launch reads and writes hold THREE floats a pixel -- the fourth
+// channel of every one of them is +0 by the launch's premise, so it is not stored (12 instead of 16 B/px either way; the module's
+// own input, which the transform-applying launch reads, stays float4).  A launch that finds the premise broken raises the flag and
+// the caller's four-channel sequence behind it redoes the module (denoiseprofile_run()).
+template <bool PRE, int MULT, bool ALPHA0, bool P3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_waves<PRE, MULT, ALPHA0>(), 8))) void dn_decompose_strip(const float4 *__restrict__ in, float4 *__restrict__ coarse,
                                                           float4 *__restrict__ detail, double *__restrict__ partial,
                                                           const int width, const int height, const int mult_arg,
@@ -525,6 +561,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_wa
   const bool have_t3 = PRE && fa.vst == 2;
   const float t3_of_zero = have_t3 ? dn_vst_y0u0v0_alpha(0.0f, fa) : 0.0f;
 #define DN_FETCH(p) (PRE ? dn_precondition_pixel((p), fa, t3_of_zero, have_t3) : (p))
+  static_assert(!P3 || ALPHA0, "three-float planes are the ALPHA0 launches'");
+  // sample `i` of the input: a float4, or (P3, not the module's own input) three floats and +0
+  auto in_at = [&](const size_t i) -> float4 {
+    if(P3 && !PRE)
+    {
+      const float *const p3 = reinterpret_cast<const float *>(in) + 3 * i;
+      return make_float4(p3[0], p3[1], p3[2], 0.0f);
+    }
+    return in[i];
+  };
+  auto plane_put = [&](float4 *const plane, const size_t i, const float v0, const float v1, const float v2, const float v3) {
+    if(P3)
+    {
+      float *const p3 = reinterpret_cast<float *>(plane) + 3 * i;
+      p3[0] = v0;
+      p3[1] = v1;
+      p3[2] = v2;
+    }
+    else
+      plane[i] = make_float4(v0, v1, v2, v3);
+  };
   __shared__ double runs[2][4][4];
   const int bx = blockIdx.x;
   const int cls = blockIdx.y / strips_per_class, k0 = (blockIdx.y - cls * strips_per_class) * strip;
@@ -564,14 +621,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_wa
   for(int q = 0; q < 4; q++)
   {
     const size_t y = DN_IN_ROW(q);
-    ring_put(q, tid, DN_FETCH(in[y + ecol0]));
-    if(second) ring_put(q, tid + 256, DN_FETCH(in[y + ecol1]));
+    ring_put(q, tid, DN_FETCH(in_at(y + ecol0)));
+    if(second) ring_put(q, tid + 256, DN_FETCH(in_at(y + ecol1)));
   }
   float4 n0, n1 = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     const size_t y = DN_IN_ROW(4);
-    n0 = in[y + ecol0];
-    if(!LATE2 && second) n1 = in[y + ecol1];
+    n0 = in_at(y + ecol0);
+    if(!LATE2 && second) n1 = in_at(y + ecol1);
   }
   int s0 = 0; // ring slot of row k
   // the weights of the taps straight above, left by this lane one and two rows ago; for the strip's first two rows, whose
@@ -594,7 +651,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_wa
       // four more registers across the 25 taps -- what pushed the launch that applies the transform over its 64 registers
       // (12 - 24 bytes of scratch, folded reloads in the tap loop: round 4's review).  At dilation 1 they are four lanes of
       // the workgroup's first wave; the seven other workgroups of the CU cover the fetch
-      if(LATE2) { if(second) ring_put(sl, tid + 256, DN_FETCH(in[DN_IN_ROW(k + 4) + ecol1])); }
+      if(LATE2) { if(second) ring_put(sl, tid + 256, DN_FETCH(in_at(DN_IN_ROW(k + 4) + ecol1))); }
       else if(second) ring_put(sl, tid + 256, DN_FETCH(n1));
     }
     __syncthreads();
@@ -608,8 +665,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_wa
     if(k + 1 < nrows)
     {
       const size_t y = DN_IN_ROW(k + 5);
-      n0 = in[y + ecol0];
-      if(!LATE2 && second) n1 = in[y + ecol1];
+      n0 = in_at(y + ecol0);
+      if(!LATE2 && second) n1 = in_at(y + ecol1);
     }
     const int row = r_first + k * mult;
     double sq[4] = { 0.0, 0.0, 0.0, 0.0 };
@@ -671,8 +728,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_wa
         sq[c] = (double)(d4[c] * d4[c]);
       }
       const size_t o = (size_t)row * width + col;
-      coarse[o] = make_float4(c4[0], c4[1], c4[2], c4[3]);
-      if(detail) detail[o] = make_float4(d4[0], d4[1], d4[2], d4[3]); // (nullptr: the synthesis forms it from two coarse planes)
+      plane_put(coarse, o, c4[0], c4[1], c4[2], c4[3]);
+      if(detail) plane_put(detail, o, d4[0], d4[1], d4[2], d4[3]); // (nullptr: the synthesis forms it from two coarse planes)
     }
     {
       const double s = wave_sum4_halving(sq[0], sq[1], sq[2], sq[3]);
@@ -695,10 +752,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dn_strip_wa
 // one a-trous step of `height` rows (see dn_decompose for in_row0 / in_rows)
 static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, float4 *detail, double *partial, const int width,
                              const int height, const int mult, const float inv_sigma2, const int nseg, const int in_row0,
-                             const int in_rows, const vst_args *pre = nullptr, unsigned *alpha_flag = nullptr)
+                             const int in_rows, const vst_args *pre = nullptr, unsigned *alpha_flag = nullptr, const int mode = 0)
 {
   // alpha_flag != nullptr: the caller's input alpha is +0 by construction at its first scale (the Y0U0V0 transform, vst 2) and
-  // the flag carries "still +0" from scale to scale: the three-channel launch first, the four-channel one behind it
+  // the flag carries "still +0" from scale to scale: the three-channel launch first, the four-channel one behind it.
+  // mode 1 (the unsplit frame's first sequence): the ALPHA0 launch on three-float planes, whatever the flag says; mode 2 (its
+  // second sequence): the four-channel launch on float4 planes, which leaves at once unless the flag is up
 #ifdef ANSEL_HIP_MEASURING
   static const bool per_row = getenv("ANSEL_HIP_DN_PER_ROW") != nullptr; // the per-row kernel, for A/B timing
   if(per_row && !pre)
@@ -732,7 +791,12 @@ static void launch_decompose(hipStream_t st, const float4 *in, float4 *coarse, f
 #define DN_LAUNCH(PRE_, M_, FA_)                  \
   do                                              \
   {                                               \
-    if(alpha_flag && (PRE_))                      \
+    if(mode == 1)                                 \
+      dn_decompose_strip<PRE_, M_, true, true><<<grid, 256, DN_LDS(true), st>>>(in, coarse, detail, partial, width, height, mult, inv_sigma2, nseg, in_row0, \
+                                                            in_rows, strip, strips_per_class, FA_, alpha_flag, 0); \
+    else if(mode == 2)                            \
+      DN_LAUNCH_(PRE_, M_, false, FA_, 2);        \
+    else if(alpha_flag && (PRE_))                 \
       DN_LAUNCH_(PRE_, M_, true, FA_, 0);         \
     else if(alpha_flag)                           \
     {                                             \
@@ -1437,18 +1501,29 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
     if(!alpha_flag) err = DT_HIP_SYSMEM_ALLOCATION;
     else if(hipMemsetAsync(alpha_flag, 0, sizeof(unsigned), st) != hipSuccess) err = DT_HIP_DEFAULT_ERROR;
   }
-  for(int scale = 0; scale < s.max_scale && err == DT_HIP_SUCCESS; scale++)
+  // Y0U0V0 (round 6): TWO sequences over the same planes.  First every scale as an ALPHA0 launch on three-float planes (12 B/px read
+  // and written instead of 16, and 108 instead of 144 read by the synthesis), whatever the flag says; a launch that writes a coarse
+  // alpha other than +0 -- a pixel that is not finite made its weights sum to NaN -- raises the flag.  Then every scale again as the
+  // four-channel launch on float4 planes in the same memory: each leaves at once unless the flag is up (8 launches of ~5 us on a
+  // frame of finite pixels, where the per-scale fallback launches of the rounds before were 6), and redoes the module if it is.
+  // The synthesis is launched for either kind of plane, gated the same way.  Other transforms: one sequence, four channels.
+  const int sequences = alpha_flag ? 2 : 1;
+  for(int seq = 0; seq < sequences && err == DT_HIP_SUCCESS; seq++)
   {
-    const int mult = 1 << scale;
-    const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
-    const float sigma_band = powf(varf, scale) * 1.0f;
+    b1 = (const float4 *)dev_in;
+    for(int scale = 0; scale < s.max_scale && err == DT_HIP_SUCCESS; scale++)
     {
-      launch_scope ls(devid, "dn_decompose");
-      launch_decompose(st, b1, coarse[scale], scale == 0 ? det0 : nullptr, partial + (size_t)scale * n_partial * 4, w, h, mult,
-                       1.0f / (sigma_band * sigma_band), nseg, 0, h, scale == 0 ? &fa : nullptr, alpha_flag);
+      const int mult = 1 << scale;
+      const float varf = sqrtf(2.0f + 2.0f * 4.0f * 4.0f + 6.0f * 6.0f) / 16.0f;
+      const float sigma_band = powf(varf, scale) * 1.0f;
+      {
+        launch_scope ls(devid, "dn_decompose");
+        launch_decompose(st, b1, coarse[scale], scale == 0 ? det0 : nullptr, partial + (size_t)scale * n_partial * 4, w, h, mult,
+                         1.0f / (sigma_band * sigma_band), nseg, 0, h, scale == 0 ? &fa : nullptr, alpha_flag, alpha_flag ? seq + 1 : 0);
+      }
+      err = check_launch("denoiseprofile band");
+      b1 = coarse[scale]; // the coarse plane just written is the next scale's input, and after the last one the residue
     }
-    err = check_launch("denoiseprofile band");
-    b1 = coarse[scale]; // the coarse plane just written is the next scale's input, and after the last one the residue
   }
   if(err == DT_HIP_SUCCESS)
   {
@@ -1470,17 +1545,27 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
     inverse_args(s, ia);
     launch_scope ls(devid, chain ? "dn_finish_chain" : "dn_finish");
     const unsigned grid = pixel_grid(npix);
-    if(!chain) dn_finish<<<grid, 256, 0, st>>>(out, b1, npix, ia, sy);
-    else
-      switch(cm_kind)
+    for(int seq = 0; seq < sequences; seq++)
+    {
+      if(alpha_flag)
       {
-        case CM_NONE: dn_finish_chain<CM_NONE><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
-        case 0: dn_finish_chain<0><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
-        case 1: dn_finish_chain<1><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
-        case 2: dn_finish_chain<2><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
-        case 3: dn_finish_chain<3><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
-        default: dn_finish_chain<4><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
+        // the synthesis over the first sequence's three-float planes if the flag stayed down, over the second's float4 planes if not
+        sy.planes3 = seq == 0;
+        sy.gate = alpha_flag;
+        sy.gate_sense = seq + 1;
       }
+      if(!chain) dn_finish<<<grid, 256, 0, st>>>(out, b1, npix, ia, sy);
+      else
+        switch(cm_kind)
+        {
+          case CM_NONE: dn_finish_chain<CM_NONE><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
+          case 0: dn_finish_chain<0><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
+          case 1: dn_finish_chain<1><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
+          case 2: dn_finish_chain<2><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
+          case 3: dn_finish_chain<3><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
+          default: dn_finish_chain<4><<<grid, 256, 0, st>>>(out, b1, npix, ia, sy, ca); break;
+        }
+    }
     err = check_launch("dn_finish");
   }
   if(det0) dt_hip_release_mem_object(det0);
