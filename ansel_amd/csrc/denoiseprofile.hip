@@ -8,7 +8,8 @@
 //
 // Launches per frame: 1 precondition, per band {decompose, threshold}, 1 finish.  Every band keeps its
 // detail plane (7 x 1.6 GB at 100 MP, of 288 GB; on the unsplit frame since round 6: band 0's detail and every band's COARSE
-// plane, the details of bands 1 .. being differences of those, formed where they are read), so the soft-threshold accumulation of ALL bands
+// plane, the details of bands 1 .. being differences of those, formed where they are read -- three floats a pixel under the Y0U0V0
+// transform, whose fourth channel is +0: denoiseprofile_run()), so the soft-threshold accumulation of ALL bands
 // (eaw_synthesize(), in band order, from a zero accumulator: the same additions in the same order), the
 // residue add and the inverse transform are one pass over the frame -- 144 B/px instead of the 384 B/px
 // of one read-modify-write pass per band.  Nothing returns to the host between launches: the band
