@@ -1544,10 +1544,10 @@ static int denoiseprofile_run(int devid, const dt_hip_piece_t *piece, const dt_h
   {
     vst_args ia;
     inverse_args(s, ia);
-    launch_scope ls(devid, chain ? "dn_finish_chain" : "dn_finish");
     const unsigned grid = pixel_grid(npix);
     for(int seq = 0; seq < sequences; seq++)
     {
+      launch_scope ls(devid, chain ? "dn_finish_chain" : "dn_finish"); // (one per launch: the profiling tables average per launch)
       if(alpha_flag)
       {
         // the synthesis over the first sequence's three-float planes if the flag stayed down, over the second's float4 planes if not

@@ -417,6 +417,17 @@ def valu_floor_ms(tag, mpix, table=None):
     return _valu_floor_ms(tag, mpix, table)
 
 
+def valu_floor_step_ms(tag, mpix):
+    """the issue floors of ALL instantiations the table lists for `tag`, summed: a frame launches each once (the wavelets' scales)"""
+    table = next((t for t in ("r06_isa_mix.json", "r05_dma_isa_mix.json", "r05_isa_mix.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r04_isa_mix.json")
+    try:
+        kernels = json.load(open(os.path.join(ROOT, "profiles", table))).get("kernels", {})
+    except (OSError, ValueError):
+        return None
+    base = {"dn_decompose": "dn_decompose_strip"}.get(tag, tag)
+    return sum(v["issue_floor_ms_per_mpix"] for k, v in kernels.items() if k.startswith(base + "<") and "issue_floor_ms_per_mpix" in v) * mpix
+
+
 def _valu_floor_ms(tag, mpix, table):
     """VALU issue floor of `tag` on a frame of `mpix` megapixels from a COMMITTED instruction-mix table (tools/valu_model.py ... arch
     over the rocprofv3 SQ counters of this bench): the dynamic instruction mix priced per class at the ARCHITECTURAL issue rate of a
@@ -1031,6 +1042,10 @@ def main():
                 if tag_bpp.get(k):
                     e["moved_over_algorithmic"] = round(moved / float(tag_bpp[k] * my_rows * width), 3)
             floor = valu_floor_ms(k, mpix_mine)
+            if floor is not None and k == "dn_decompose":
+                # the tag's launches are of two kinds since round 6 -- seven decompositions and seven that leave at once (the
+                # four-channel sequence behind the alpha flag) --: the floor of a STEP over the step's time, as a per-launch mean
+                floor = valu_floor_step_ms(k, mpix_mine) / max(per_launch, 1.0)
             if floor is not None:
                 # the instruction mix at the ARCHITECTURAL issue rates (2 / 4 / 8 cycles per full- / half- / quarter-rate wave64
                 # instruction: what profiles/r05_valu_issue_cycles.json measures with the clock read beside it) at 2.4 GHz ...
